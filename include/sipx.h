@@ -1,0 +1,162 @@
+/*
+ * sipx.h -- C ABI of the MI355X-native PARSDMM projection engine (libsipx.so).
+ *
+ * This is the drop-in boundary for ONE hot path of slimgroup/SetIntersectionProjection.jl:
+ * the PARSDMM iteration body behind
+ *     PARSDMM(m, AtA, TD_OP, set_Prop, P_sub, comp_grid, options[, x, l, y]) -> (x, log, l, y)
+ * (reference src/PARSDMM.jl:25-35,257).  Plain pointers and sizes only; every function
+ * returns 0 on success, non-zero on error (text via sipx_last_error()).  Host arrays are
+ * copied in / copied out; the library never keeps a caller pointer after a call returns
+ * (reference ownership model: Julia owns every array).
+ *
+ * Two granularities, B built on A:
+ *   A. phase level  -- one entry per step of the reference's main loop, so PARSDMM.jl's own
+ *      loop, @timeit sections and stop_PARSDMM can stay in Julia and ccall each phase;
+ *   B. whole solve  -- sipx_parsdmm() runs the restated loop natively.
+ *
+ * A handle is single-threaded (one solve at a time); different handles may live on
+ * different host threads / GPUs.  All vectors are TF = float or double as chosen at
+ * sipx_create().  Per-set scalars cross the ABI as double (exact for float values).
+ */
+#ifndef SIPX_H
+#define SIPX_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct sipx_ctx sipx_ctx;
+
+enum { SIPX_F32 = 0, SIPX_F64 = 1 };
+
+/* Transform-domain operator A_i, matrix-free.  Replaces the SparseMatrixCSC TD_OP[i] built by
+ * get_TD_operator / get_discrete_Grad (src/get_TD_operator.jl:12-95, src/get_discrete_Grad.jl:16-76);
+ * the shim maps set_Prop.tag[i][2] ("identity","D_x","D_y","D_z","TV") + comp_grid.n/.d to it.
+ * 2-D grids: D_x = dim 1, D_z = dim 2 (pass n3 = 1); TV = [D_z; D_x] (2-D), [D_z; D_y; D_x] (3-D). */
+enum { SIPX_OP_IDENTITY = 0, SIPX_OP_DX = 1, SIPX_OP_DY = 2, SIPX_OP_DZ = 3, SIPX_OP_TV = 4 };
+
+/* Projector descriptor replacing the opaque closure P_sub[i] (src/get_projector.jl:3-103),
+ * "matrix"/"tensor" application mode. */
+enum {
+  SIPX_PROJ_BOUNDS      = 0, /* project_bounds!(x, LB, UB) scalar bounds  (projectors/project_bounds!.jl:3-12)  */
+  SIPX_PROJ_BOUNDS_VEC  = 1, /* per-element bounds lb/ub                  (projectors/project_bounds!.jl:14-25) */
+  SIPX_PROJ_L1          = 2, /* project_l1_Duchi!(x, pmax)                (projectors/project_l1_Duchi!.jl:21-52) */
+  SIPX_PROJ_L2          = 3, /* project_l2!(x, pmax)                      (projectors/project_l2!.jl:3-16) */
+  SIPX_PROJ_ANNULUS     = 4, /* project_annulus!(x, pmin, pmax)           (projectors/project_annulus!.jl:3-21) */
+  SIPX_PROJ_CARDINALITY = 5, /* project_cardinality!(x, k = pmax) vector  (projectors/project_cardinality!.jl:3-21) */
+  SIPX_PROJ_PROX_L1     = 6  /* prox_l1!(x, pmax)                         (src/prox_l1!.jl:8-10) */
+};
+
+typedef struct {
+  int32_t op;        /* SIPX_OP_*   */
+  int32_t proj;      /* SIPX_PROJ_* */
+  double pmin, pmax; /* constraint[i].min / .max (set_definitions, src/SetIntersectionProjection.jl:142-149) */
+  const void* lb;    /* SIPX_PROJ_BOUNDS_VEC: host TF[M_i] (rows of A_i, reference order), else NULL */
+  const void* ub;
+  int32_t ncvx;      /* set_Prop.ncvx[i] (src/setup_constraints.jl:89-97) */
+  int32_t reserved;
+} sipx_set_desc;
+
+/* PARSDMM_options (src/SetIntersectionProjection.jl:110-128); Blas_active / parallel / FL /
+ * x_min_solver / Minkowski have no native meaning (FL = dtype of the context). */
+typedef struct {
+  int32_t maxit;
+  double evol_rel_tol, feas_tol, obj_tol;
+  int32_t rho_update_frequency;
+  int32_t adjust_rho, adjust_gamma, adjust_feasibility_rho;
+} sipx_options;
+
+/* log_type_PARSDMM (src/SetIntersectionProjection.jl:95-108) as flat row-major arrays the caller
+ * allocates for `maxit` rows; the executed row counts come back in n_iter / n_feas_rows
+ * (output_check_PARSDMM truncation, src/PARSDMM.jl:261-278). */
+typedef struct {
+  double* set_feasibility; /* [maxit][pp] */
+  double* r_dual;          /* [maxit][p]  */
+  double* r_pri;           /* [maxit][p]  */
+  double* r_dual_total;    /* [maxit] */
+  double* r_pri_total;     /* [maxit] */
+  double* obj;             /* [maxit] */
+  double* evol_x;          /* [maxit] */
+  double* rho;             /* [maxit][p] */
+  double* gamma;           /* [maxit][p] */
+  int64_t* cg_it;          /* [maxit] */
+  double* cg_relres;       /* [maxit] */
+  double timing_ms[7];     /* the 7 @timeit sections of src/PARSDMM.jl:40,100,105,113,152,163,229 */
+  int32_t n_iter;          /* rows filled in the per-iteration logs */
+  int32_t n_feas_rows;     /* rows kept in set_feasibility (= `counter`) */
+  int32_t stopped_feasible;/* 1 if the input was accepted as feasible (src/PARSDMM.jl:63-82) */
+} sipx_log;
+
+const char* sipx_last_error(void);
+
+/* ---- construction (replaces the allocations of PARSDMM_initialize, src/PARSDMM_initialize.jl:117-184) ---- */
+int sipx_create(sipx_ctx** out, int dtype, int ndim, const int64_t* n, const double* h, int device);
+void sipx_destroy(sipx_ctx* ctx);
+
+/* Adds constraint set i (call in TD_OP order).  ata_R / ata_off / d_i = AtA[i] in CDS (N x d_i,
+ * column-major) with set_Prop.AtA_offsets[i] (src/PARSDMM_precompute_distribute.jl:52-59); pass
+ * ata_R = NULL to have the bands generated on the device from the operator descriptor. */
+int sipx_add_set(sipx_ctx* ctx, const sipx_set_desc* desc, const void* ata_R, const int64_t* ata_off, int d_i);
+
+/* Rows of A_i (length of y_i / l_i) for set i; i = number of constraint sets addresses the
+ * distance term appended by PARSDMM_precompute_distribute (src/PARSDMM_precompute_distribute.jl:17-26). */
+int sipx_set_rows(sipx_ctx* ctx, int set, int64_t* rows);
+int sipx_num_terms(sipx_ctx* ctx, int* p, int* pp);
+
+/* Uploads m, initial rho/gamma, optional warm start (x0, l0[i], y0[i]; NULL = zeros; ignored when
+ * zero_ini_guess != 0, src/PARSDMM_initialize.jl:304-313); appends the distance term unless
+ * feasibility_only; assembles Q / Q_offsets (src/PARSDMM_initialize.jl:216-230); fills
+ * feasibility_initial[pp] (src/PARSDMM_initialize.jl:97-99). */
+int sipx_finalize(sipx_ctx* ctx, const void* m, const double* rho_ini, int n_rho, double gamma_ini,
+                  int feasibility_only, int zero_ini_guess, const void* x0, const void* const* l0,
+                  const void* const* y0, double* feasibility_initial);
+
+/* ---- A. phase level ---- */
+/* rhs = sum_i A_i'(rho_i y_i + l_i)                                   (src/rhs_compose.jl:24-36) */
+int sipx_rhs_compose(sipx_ctx* ctx, const double* rho);
+/* copy!(x_old,x); tolerance rule; warm-started CG on Q x = rhs        (src/PARSDMM.jl:106-107, src/argmin_x.jl:23-39, src/cg.jl:44-128) */
+int sipx_argmin_x(sipx_ctx* ctx, int it, double* tol_ref_io, int64_t* cg_it, double* cg_relres, int* cg_flag);
+/* y/l update for every local set                                       (src/update_y_l.jl:36-101) */
+enum { SIPX_YL_FEAS = 1,  /* also log set feasibility (mod(i,10)==0)            update_y_l.jl:90-99 */
+       SIPX_YL_BB = 2,    /* also accumulate the six BB sums and refresh snapshots  adapt_rho_gamma.jl:41-53, PARSDMM.jl:192-206 */
+       SIPX_YL_FIRST = 4  /* first iteration: set snapshots                    PARSDMM.jl:164-180 */ };
+int sipx_update_y_l(sipx_ctx* ctx, int it, int flags, const double* rho, const double* gamma,
+                    double* r_pri, double* r_dual, double* feas /* [pp], written iff SIPX_YL_FEAS */);
+/* obj = 1/2||x-m||^2, evol_x = ||x_old-x||/||x||                      (src/PARSDMM.jl:140,145) */
+int sipx_log_scalars(sipx_ctx* ctx, double* obj, double* evol_x);
+/* Barzilai-Borwein rule from the sums gathered by the last sipx_update_y_l(SIPX_YL_BB)  (src/adapt_rho_gamma.jl:55-126) */
+int sipx_adapt_rho_gamma(sipx_ctx* ctx, int adjust_rho, int adjust_gamma, double* rho_io, double* gamma_io);
+/* Q += (rho_new - rho_old) AtA_i for changed sets; rebinds the distance prox  (src/Q_update!.jl:45-48, src/PARSDMM.jl:230-243) */
+int sipx_q_update(sipx_ctx* ctx, const double* rho_new, const double* rho_old);
+/* copy out x, l[i], y[i] (any pointer may be NULL)                     (src/PARSDMM.jl:257) */
+int sipx_download(sipx_ctx* ctx, void* x, void* const* l, void* const* y);
+
+/* ---- B. whole solve (src/PARSDMM.jl:97-257 restated natively) ---- */
+int sipx_parsdmm(sipx_ctx* ctx, const sipx_options* opt, sipx_log* log);
+
+/* ---- kernel-level entry points used by the parity tests and bench (same kernels as above) ---- */
+/* y = R x for an arbitrary CDS matrix (CDS_MVp_MT + fill!, src/CDS_MVp_MT.jl:9-25, src/argmin_x.jl:72-78) */
+int sipx_cds_spmv(int dtype, int64_t N, int d, const void* R, const int64_t* off, const void* x, void* y, int device);
+/* s = A x (op descriptor) and t = A' v on the context grid */
+int sipx_apply_op(sipx_ctx* ctx, int op, const void* x, void* s);
+int sipx_apply_op_adj(sipx_ctx* ctx, int op, const void* v, void* t);
+/* in-place projector on a host vector of length len (src/projectors/project_X.jl) */
+int sipx_project(sipx_ctx* ctx, const sipx_set_desc* desc, void* v, int64_t len);
+/* Q as assembled / updated (N x d column-major) and its offsets */
+int sipx_get_Q(sipx_ctx* ctx, void* Q, int64_t* offsets, int* d);
+/* device-side timing of the dominant kernel: runs cds_spmv on Q `reps` times, returns avg ms (HIP events on the engine stream) */
+int sipx_time_spmv(sipx_ctx* ctx, int reps, double* avg_ms);
+/* engine stream handle (hipStream_t) so a host harness can order its own work / collectives against it */
+void* sipx_stream(sipx_ctx* ctx);
+/* device pointers of rhs / x (TF[N]) for in-place collectives on the sharded path */
+void* sipx_dev_rhs(sipx_ctx* ctx);
+void* sipx_dev_x(sipx_ctx* ctx);
+/* restricts y/l work and rhs contributions to sets with owner[i] != 0 (set sharding); Q stays global */
+int sipx_set_owned(sipx_ctx* ctx, const int32_t* owned);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SIPX_H */

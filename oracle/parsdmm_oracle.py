@@ -445,7 +445,7 @@ def project_annulus(x, sigma_min, sigma_max):
     elif nl2 > 0:
         x *= TF(sigma_min) / nl2
     else:
-        x[:] = np.ones(len(x), TF) * (TF(sigma_min) / TF(math.sqrt(len(x))))
+        x[:] = (np.ones(len(x), TF) * (np.float64(TF(sigma_min)) / math.sqrt(len(x)))).astype(TF)   # sqrt(Int) is Float64
     return x
 
 

@@ -1,0 +1,864 @@
+// Host engine behind the sipx C ABI: owns the device-resident PARSDMM state and drives the HIP
+// kernels phase by phase, in the order of the reference's main loop (src/PARSDMM.jl:97-254).
+// No CPU fallback exists: every numerical step below is a kernel launch.
+#include "engine.h"
+
+#include <algorithm>
+#include <chrono>
+#include <cmath>
+#include <cstring>
+#include <limits>
+
+namespace sipx {
+
+namespace {
+
+constexpr int SLOTS = 16;      // reduction slots per set: 0..12 k_yl, 13 ||A'dy||^2, 14/15 two-pass feasibility
+constexpr int SL_ADJ = 13, SL_FE2 = 14, SL_SS2 = 15;
+
+template <typename T>
+T* dalloc(size_t n, bool zero = true) {
+  T* p = nullptr;
+  if (n == 0) return p;
+  SIPX_HIP(hipMalloc(&p, n * sizeof(T)));
+  if (zero) SIPX_HIP(hipMemset(p, 0, n * sizeof(T)));
+  return p;
+}
+inline void dfree(void* p) {
+  if (p) (void)hipFree(p);
+}
+
+inline double jmax_nan(double a, double b) { return (std::isnan(a) || std::isnan(b)) ? NAN : std::max(a, b); }
+
+// Julia maximum(): NaN-propagating
+template <typename It>
+double julia_maximum(It b, It e) {
+  double m = -INFINITY;
+  for (; b != e; ++b) {
+    if (std::isnan(*b)) return NAN;
+    m = std::max(m, (double)*b);
+  }
+  return m;
+}
+
+// Barzilai-Borwein scalar rule, reference src/adapt_rho_gamma.jl:55-126, all arithmetic in T.
+template <typename T>
+void bb_rule(T d_dHh_dlh, T n_d_H_hat, T n_d_l_hat, T n_d_l, T n_d_G_hat, T d_dGh_dl, bool adjust_rho,
+             bool adjust_gamma, T& rho, T& gamma) {
+  const T safeguard = sizeof(T) == 8 ? T(1e-10) : T(1e-6);   // :31-35
+  const T eps_correlation = T(0.3);                          // :37
+  bool alpha_reliable = false, beta_reliable = false;
+  T alpha_correlation = 0, beta_correlation = 0;
+  if ((n_d_H_hat * n_d_l_hat) > safeguard && (n_d_H_hat * n_d_H_hat) > safeguard && d_dHh_dlh > safeguard) {
+    alpha_reliable = true;
+    alpha_correlation = d_dHh_dlh / (n_d_H_hat * n_d_l_hat);
+  }
+  if ((n_d_G_hat * n_d_l) > safeguard && (n_d_G_hat * n_d_G_hat) > safeguard && d_dGh_dl > safeguard) {
+    beta_reliable = true;
+    beta_correlation = d_dGh_dl / (n_d_G_hat * n_d_l);
+  }
+  bool alpha_comp = false, beta_comp = false;
+  T alpha_hat = 0, beta_hat = 0;
+  if (alpha_reliable && alpha_correlation > eps_correlation) {
+    alpha_comp = true;
+    const T mg = d_dHh_dlh / (n_d_H_hat * n_d_H_hat);
+    const T sd = (n_d_l_hat * n_d_l_hat) / d_dHh_dlh;
+    alpha_hat = (T(2) * mg) > sd ? mg : sd - mg / T(2);
+  }
+  if (beta_reliable && beta_correlation > eps_correlation) {
+    beta_comp = true;
+    const T mg = d_dGh_dl / (n_d_G_hat * n_d_G_hat);
+    const T sd = (n_d_l * n_d_l) / d_dGh_dl;
+    beta_hat = (T(2) * mg) > sd ? mg : sd - mg / T(2);
+  }
+  if (adjust_rho) {
+    if (alpha_comp && beta_comp) rho = std::sqrt(alpha_hat * beta_hat);
+    else if (alpha_comp) rho = alpha_hat;
+    else if (beta_comp) rho = beta_hat;
+  }
+  if (adjust_gamma) {
+    if (alpha_comp && beta_comp) gamma = T(1) + ((T(2) * std::sqrt(alpha_hat * beta_hat)) / (alpha_hat + beta_hat));
+    else if (alpha_comp) gamma = T(1.9);
+    else if (beta_comp) gamma = T(1.1);
+    else gamma = T(1.5);
+  }
+}
+
+template <typename T>
+struct SetState {
+  int op = 0, prox = 0, nblk = 0, ncvx = 0;
+  int dir[3] = {0, 0, 0};
+  T ih[3] = {0, 0, 0};
+  long long Mtrue = 0, Mpad = 0;
+  long long blk_rows[3] = {0, 0, 0};
+  T plo = 0, phi = 0;
+  bool ident = true, two_pass = false, is_dist = false, owned = true;
+  T *y = nullptr, *l = nullptr, *dy = nullptr, *lh0 = nullptr, *y0 = nullptr, *s0 = nullptr, *l0 = nullptr;
+  T *lb = nullptr, *ub = nullptr, *ata = nullptr;
+  ProjScalars<T>* ps = nullptr;
+  std::vector<long long> ata_off;
+  std::vector<T> host_lb, host_ub, host_ata;
+  double sums[SLOTS] = {0};
+  bool bb_valid = false;
+};
+
+}  // namespace
+
+template <typename T>
+class Engine : public EngineBase {
+ public:
+  Engine(int ndim, const int64_t* n, const double* h, int device) : device_(device) {
+    if (ndim != 2 && ndim != 3) throw std::runtime_error("ndim must be 2 or 3");
+    SIPX_HIP(hipSetDevice(device));
+    SIPX_HIP(hipStreamCreateWithFlags(&stream_, hipStreamNonBlocking));
+    ndim_ = ndim;
+    for (int a = 0; a < 3; ++a) {
+      G_.n[a] = a < ndim ? n[a] : 1;
+      if (G_.n[a] < 1) throw std::runtime_error("grid size must be positive");
+      ih_[a] = a < ndim ? T(1) / T(h[a]) : T(0);   // entries +-1/h of get_discrete_Grad.jl:22-23,58-60
+    }
+    if (ndim == 3 && G_.n[2] == 1) ndim_ = 2;      // get_TD_operator.jl:30
+    G_.N = G_.n[0] * G_.n[1] * G_.n[2];
+    G_.st[0] = 1;
+    G_.st[1] = G_.n[0];
+    G_.st[2] = G_.n[0] * G_.n[1];
+    if (G_.N >= (1ll << 40)) throw std::runtime_error("grid too large");
+  }
+  ~Engine() override {
+    (void)hipSetDevice(device_);
+    (void)hipStreamSynchronize(stream_);
+    for (auto& s : sets_) free_set(s);
+    for (void* p : {(void*)x_, (void*)xold_, (void*)rhs_, (void*)m_, (void*)r_, (void*)p_, (void*)Ap_, (void*)Q_,
+                    (void*)scr_v_, (void*)scr_c_, (void*)part_cg_, (void*)part_tmp_, (void*)part_sets_,
+                    (void*)maxpart_, (void*)hist_cnt_, (void*)hist_sum_, (void*)cg_dev_})
+      dfree(p);
+    if (cg_host_) (void)hipHostFree(cg_host_);
+    if (hres_) (void)hipHostFree(hres_);
+    for (auto e : ev_) (void)hipEventDestroy(e);
+    (void)hipStreamDestroy(stream_);
+  }
+
+  // ------------------------------------------------------------------------------------------
+  int add_set(const sipx_set_desc* d, const void* ata_R, const int64_t* ata_off, int d_i) override {
+    if (finalized_) throw std::runtime_error("sipx_add_set after sipx_finalize");
+    SetState<T> s;
+    configure_op(s, d->op);
+    s.prox = d->proj;
+    s.ncvx = d->ncvx;
+    s.plo = (T)d->pmin;
+    s.phi = (T)d->pmax;
+    switch (d->proj) {
+      case SIPX_PROJ_BOUNDS:
+      case SIPX_PROJ_PROX_L1: break;
+      case SIPX_PROJ_BOUNDS_VEC:
+        if (!d->lb || !d->ub) throw std::runtime_error("per-element bounds need lb and ub");
+        s.host_lb.assign((const T*)d->lb, (const T*)d->lb + s.Mtrue);
+        s.host_ub.assign((const T*)d->ub, (const T*)d->ub + s.Mtrue);
+        break;
+      case SIPX_PROJ_L1:
+        if (!(d->pmax > 0)) throw std::runtime_error("Radius of L1 ball is negative");   // project_l1_Duchi!.jl:22
+        s.two_pass = true;
+        break;
+      case SIPX_PROJ_L2:
+      case SIPX_PROJ_ANNULUS: s.two_pass = true; break;
+      case SIPX_PROJ_CARDINALITY: throw std::runtime_error("cardinality projector: not built yet (SURVEY 8a row K10)");
+      default: throw std::runtime_error("unknown projector kind");
+    }
+    if (ata_R) {
+      if (d_i < 1 || d_i > MAXD) throw std::runtime_error("AtA band count out of range");
+      s.ata_off.assign(ata_off, ata_off + d_i);
+      s.host_ata.assign((const T*)ata_R, (const T*)ata_R + (size_t)G_.N * d_i);
+    } else {
+      s.ata_off = default_ata_offsets(s);
+    }
+    sets_.push_back(std::move(s));
+    return (int)sets_.size() - 1;
+  }
+
+  int64_t set_rows(int set) override {
+    if (set == (int)sets_.size() && !finalized_) return G_.N;   // the distance term to come
+    if (set < 0 || set >= (int)sets_.size()) throw std::runtime_error("set index out of range");
+    return sets_[set].Mtrue;
+  }
+  void num_terms(int* p, int* pp) override {
+    if (p) *p = p_n_;
+    if (pp) *pp = pp_n_;
+  }
+  void set_owned(const int32_t* owned) override {
+    if (finalized_) throw std::runtime_error("sipx_set_owned must precede sipx_finalize");
+    owned_.assign(owned, owned + sets_.size() + 1);
+  }
+
+  // ------------------------------------------------------------------------------------------
+  void finalize(const void* m, const double* rho_ini, int n_rho, double gamma_ini, int feasibility_only,
+                int zero_ini_guess, const void* x0, const void* const* l0, const void* const* y0,
+                double* feasibility_initial) override {
+    if (finalized_) throw std::runtime_error("sipx_finalize called twice");
+    SIPX_HIP(hipSetDevice(device_));
+    pp_n_ = (int)sets_.size();
+    feasibility_only_ = feasibility_only != 0;
+    if (!feasibility_only_) {             // PARSDMM_precompute_distribute.jl:17-26: identity operator for 1/2||x-m||^2
+      SetState<T> s;
+      configure_op(s, SIPX_OP_IDENTITY);
+      s.prox = PX_DIST;
+      s.is_dist = true;
+      s.ata_off = {0};
+      sets_.push_back(std::move(s));
+    }
+    p_n_ = (int)sets_.size();
+    if (p_n_ > 99) throw std::runtime_error("at most 99 sets (PARSDMM_initialize.jl:217)");
+    if (!owned_.empty())
+      for (int i = 0; i < p_n_; ++i) sets_[i].owned = owned_[i] != 0;
+    const long long N = G_.N;
+    // rho, gamma (PARSDMM_initialize.jl:58-63,107-114,159)
+    rho_.resize(p_n_);
+    gamma_.resize(p_n_);
+    if (n_rho == 1) std::fill(rho_.begin(), rho_.end(), (T)rho_ini[0]);
+    else if (n_rho == p_n_) for (int i = 0; i < p_n_; ++i) rho_[i] = (T)rho_ini[i];
+    else throw std::runtime_error("rho_ini must have 1 or p entries");
+    T g0 = (T)gamma_ini;
+    any_ncvx_ = false;
+    for (int i = 0; i < pp_n_; ++i) any_ncvx_ |= sets_[i].ncvx != 0;
+    if (any_ncvx_) g0 = T(0.75);
+    std::fill(gamma_.begin(), gamma_.end(), g0);
+
+    x_ = dalloc<T>(N); xold_ = dalloc<T>(N); rhs_ = dalloc<T>(N); m_ = dalloc<T>(N);
+    r_ = dalloc<T>(N); p_ = dalloc<T>(N); Ap_ = dalloc<T>(N);
+    SIPX_HIP(hipMemcpy(m_, m, N * sizeof(T), hipMemcpyHostToDevice));
+    long long maxpad = N;
+    for (auto& s : sets_) maxpad = std::max(maxpad, s.Mpad);
+    scr_v_ = dalloc<T>(maxpad);
+    scr_c_ = dalloc<T>(maxpad);
+    part_cg_ = dalloc<double>(2 * NB);
+    part_tmp_ = dalloc<double>(2 * NB);
+    part_sets_ = dalloc<double>((size_t)p_n_ * SLOTS * NB);
+    maxpart_ = dalloc<T>(NB);
+    hist_cnt_ = dalloc<unsigned long long>(L1_BINS);
+    hist_sum_ = dalloc<double>(L1_BINS);
+    cg_dev_ = dalloc<CgState<T>>(1);
+    SIPX_HIP(hipHostMalloc((void**)&cg_host_, sizeof(CgState<T>), hipHostMallocDefault));
+    std::memset(cg_host_, 0, sizeof(CgState<T>));
+    SIPX_HIP(hipHostMalloc((void**)&hres_, sizeof(double) * p_n_ * SLOTS, hipHostMallocDefault));
+    std::memset(hres_, 0, sizeof(double) * p_n_ * SLOTS);
+    for (int k = 0; k < 8; ++k) {
+      hipEvent_t e;
+      SIPX_HIP(hipEventCreate(&e));
+      ev_.push_back(e);
+    }
+
+    const bool warm = !zero_ini_guess;     // PARSDMM_initialize.jl:304-313
+    for (int i = 0; i < p_n_; ++i) {
+      SetState<T>& s = sets_[i];
+      // AtA bands (every rank keeps them: Q is global)
+      s.ata = dalloc<T>((size_t)N * s.ata_off.size(), false);
+      if (!s.host_ata.empty()) {
+        SIPX_HIP(hipMemcpy(s.ata, s.host_ata.data(), s.host_ata.size() * sizeof(T), hipMemcpyHostToDevice));
+        s.host_ata.clear();
+        s.host_ata.shrink_to_fit();
+      } else {
+        K<T>::gen_ata(stream_, G_, s.nblk, s.dir, s.ih, (int)s.ata_off.size(), s.ata_off.data(), s.ata);
+      }
+      if (!s.owned) continue;
+      s.y = dalloc<T>(s.Mpad); s.l = dalloc<T>(s.Mpad);
+      s.lh0 = dalloc<T>(s.Mpad); s.y0 = dalloc<T>(s.Mpad); s.s0 = dalloc<T>(s.Mpad); s.l0 = dalloc<T>(s.Mpad);
+      if (!s.ident) s.dy = dalloc<T>(s.Mpad);
+      if (s.two_pass) s.ps = dalloc<ProjScalars<T>>(1);
+      if (s.prox == SIPX_PROJ_BOUNDS_VEC) {
+        s.lb = dalloc<T>(s.Mpad); s.ub = dalloc<T>(s.Mpad);
+        upload_rows(s, s.host_lb.data(), s.lb);
+        upload_rows(s, s.host_ub.data(), s.ub);
+      }
+      if (warm && l0 && l0[i]) upload_rows(s, (const T*)l0[i], s.l);
+      if (warm && y0 && y0[i]) upload_rows(s, (const T*)y0[i], s.y);
+    }
+    if (warm && x0) SIPX_HIP(hipMemcpy(x_, x0, N * sizeof(T), hipMemcpyHostToDevice));
+
+    assemble_Q();
+    finalized_ = true;
+
+    // initial feasibility ||P_i(A_i m) - A_i m|| / (||A_i m|| + 100 eps)   (PARSDMM_initialize.jl:97-99)
+    feas_init_.assign(pp_n_, 0.0);
+    for (int i = 0; i < pp_n_; ++i) {
+      SetState<T>& s = sets_[i];
+      if (!s.owned) continue;
+      K<T>::fwd(stream_, G_, s.nblk, s.dir, s.ih, m_, scr_v_);
+      feasibility_of_scratch(s, part_sets_ + ((size_t)i * SLOTS + SL_FE2) * NB);
+    }
+    K<T>::fin_sum(stream_, part_sets_, p_n_ * SLOTS, nullptr, hres_);
+    SIPX_HIP(hipStreamSynchronize(stream_));
+    for (int i = 0; i < pp_n_; ++i) {
+      if (!sets_[i].owned) continue;
+      feas_init_[i] = (double)feas_value(hres_[i * SLOTS + SL_FE2], hres_[i * SLOTS + SL_SS2]);
+    }
+    if (feasibility_initial)
+      for (int i = 0; i < pp_n_; ++i) feasibility_initial[i] = feas_init_[i];
+  }
+
+  // ------------------------------------------------------------------------------------------
+  void rhs_compose(const double* rho) override {
+    need_final();
+    RhsArgs<T> a;
+    a.nsets = 0;
+    int launched = 0;
+    for (int i = 0; i < p_n_; ++i) {
+      const SetState<T>& s = sets_[i];
+      if (!s.owned) continue;
+      RhsSet<T>& r = a.s[a.nsets++];
+      r.y = s.y; r.l = s.l; r.rho = (T)rho[i]; r.nblk = s.nblk;
+      for (int q = 0; q < 3; ++q) { r.dir[q] = s.dir[q]; r.ih[q] = s.ih[q]; }
+      if (a.nsets == MAX_SETS) {
+        K<T>::rhs_compose(stream_, G_, a, rhs_, launched++ > 0);
+        a.nsets = 0;
+      }
+    }
+    if (a.nsets > 0 || launched == 0) K<T>::rhs_compose(stream_, G_, a, rhs_, launched > 0);
+  }
+
+  void argmin_x(int it, double* tol_ref_io, int64_t* cg_it, double* cg_relres, int* cg_flag) override {
+    need_final();
+    cg_host_->tol_ref = (T)*tol_ref_io;     // pinned staging; the device mirror overwrites it after the copy (stream order)
+    SIPX_HIP(hipMemcpyAsync(&cg_dev_->tol_ref, &cg_host_->tol_ref, sizeof(T), hipMemcpyHostToDevice, stream_));
+    K<T>::resid(stream_, G_.N, Q_, cds_, x_, rhs_, r_, p_, xold_, part_cg_);
+    K<T>::cg_begin(stream_, part_cg_, cg_dev_, cg_host_, it, x_, G_.N);
+    SIPX_HIP(hipStreamSynchronize(stream_));
+    if (cg_host_->flag == -9) SIPX_HIP(hipMemsetAsync(x_, 0, G_.N * sizeof(T), stream_));   // cg.jl:51
+    int iter = 0;
+    while (!cg_host_->done && iter < 1000) {      // maxIter=1000, argmin_x.jl:39
+      ++iter;
+      K<T>::spmv_dot(stream_, G_.N, Q_, cds_, p_, Ap_, part_cg_, cg_dev_);
+      K<T>::cg_fin_alpha(stream_, part_cg_, cg_dev_, cg_host_, iter);
+      K<T>::cg_update_xr(stream_, G_.N, x_, r_, p_, Ap_, part_cg_, cg_dev_);
+      K<T>::cg_fin_beta(stream_, part_cg_, cg_dev_, cg_host_);
+      K<T>::cg_update_p(stream_, G_.N, p_, r_, cg_dev_);
+      SIPX_HIP(hipStreamSynchronize(stream_));
+    }
+    *tol_ref_io = (double)cg_host_->tol_ref;
+    *cg_it = cg_host_->iters;
+    *cg_relres = (double)cg_host_->res_last;
+    if (cg_flag) *cg_flag = cg_host_->flag;
+  }
+
+  void update_y_l(int it, int flags, const double* rho, const double* gamma, double* r_pri, double* r_dual,
+                  double* feas) override {
+    need_final();
+    (void)it;
+    for (int i = 0; i < p_n_; ++i) {
+      SetState<T>& s = sets_[i];
+      if (!s.owned) continue;
+      SetArgs<T> a = set_args(s, (T)rho[i], (T)gamma[i], flags);
+      double* part = part_sets_ + (size_t)i * SLOTS * NB;
+      if (s.two_pass) {
+        K<T>::yl_prep(stream_, G_, a, part_tmp_, maxpart_, 0);
+        K<T>::ps_finish(stream_, part_tmp_, maxpart_, s.ps, s.prox, s.plo, s.phi, s.Mtrue);
+        if (s.prox == PX_L1) K<T>::l1_theta(stream_, s.Mpad, scr_v_, s.ps, s.phi, hist_cnt_, hist_sum_, scr_c_);
+        a.vsrc = 1;
+      }
+      K<T>::yl(stream_, G_, a, part);
+      if (!s.ident) K<T>::adj_norm(stream_, G_, a, part + (size_t)SL_ADJ * NB);
+      if ((flags & SIPX_YL_FEAS) && s.two_pass && i < pp_n_) {
+        K<T>::yl_prep(stream_, G_, a, part_tmp_, maxpart_, 1);   // scratch <- s = A x
+        feasibility_of_scratch(s, part + (size_t)SL_FE2 * NB, /*have_sums=*/true);
+      }
+    }
+    K<T>::fin_sum(stream_, part_sets_, p_n_ * SLOTS, nullptr, hres_);
+    SIPX_HIP(hipStreamSynchronize(stream_));
+    have_log_sums_ = false;
+    for (int i = 0; i < p_n_; ++i) {
+      SetState<T>& s = sets_[i];
+      if (r_pri) r_pri[i] = 0;
+      if (r_dual) r_dual[i] = 0;
+      if (!s.owned) continue;
+      const double* h = hres_ + (size_t)i * SLOTS;
+      std::copy(h, h + SLOTS, s.sums);
+      if (r_pri) r_pri[i] = (double)(T)std::sqrt(h[SL_RPRI]);                                   // update_y_l.jl:81
+      if (r_dual) r_dual[i] = (double)((T)rho[i] * (T)std::sqrt(s.ident ? h[SL_DY] : h[SL_ADJ]));  // :84
+      s.bb_valid = (flags & (SIPX_YL_BB | SIPX_YL_FIRST)) != 0;
+      if (s.is_dist) {
+        obj_ss_ = h[SL_OBJ]; evo_ss_ = h[SL_EVO]; xx_ss_ = h[SL_XX];
+        have_log_sums_ = true;
+      }
+    }
+    if ((flags & SIPX_YL_FEAS) && feas) {
+      for (int i = 0; i < pp_n_; ++i) {
+        feas[i] = 0;
+        if (!sets_[i].owned) continue;
+        const double* h = hres_ + (size_t)i * SLOTS;
+        feas[i] = sets_[i].two_pass ? (double)feas_value(h[SL_FE2], h[SL_SS2]) : (double)feas_value(h[SL_FE], h[SL_SS]);
+      }
+    }
+  }
+
+  void log_scalars(double* obj, double* evol_x) override {
+    need_final();
+    if (!have_log_sums_) {
+      K<T>::log3(stream_, G_.N, x_, m_, xold_, part_sets_);
+      K<T>::fin_sum(stream_, part_sets_, SLOTS, nullptr, hres_);
+      SIPX_HIP(hipStreamSynchronize(stream_));
+      obj_ss_ = hres_[SL_OBJ]; evo_ss_ = hres_[SL_EVO]; xx_ss_ = hres_[SL_XX];
+    }
+    const T nd = (T)std::sqrt(obj_ss_);
+    *obj = (double)(T(0.5) * (nd * nd));                                   // PARSDMM.jl:140
+    *evol_x = (double)((T)std::sqrt(evo_ss_) / (T)std::sqrt(xx_ss_));      // PARSDMM.jl:145
+  }
+
+  void adapt_rho_gamma(int adjust_rho, int adjust_gamma, double* rho_io, double* gamma_io) override {
+    need_final();
+    for (int i = 0; i < p_n_; ++i) {
+      SetState<T>& s = sets_[i];
+      if (!s.owned) continue;
+      if (!s.bb_valid)
+        throw std::runtime_error("sipx_adapt_rho_gamma: call sipx_update_y_l with SIPX_YL_BB (or _FIRST) first");
+      T rho = (T)rho_io[i], gamma = (T)gamma_io[i];
+      const double* h = s.sums;
+      bb_rule<T>((T)h[SL_HL], (T)std::sqrt(h[SL_HH]), (T)std::sqrt(h[SL_LH]), (T)std::sqrt(h[SL_DL]),
+                 (T)std::sqrt(h[SL_GG]), (T)h[SL_GL], adjust_rho != 0, adjust_gamma != 0, rho, gamma);
+      rho_io[i] = (double)rho;
+      gamma_io[i] = (double)gamma;
+    }
+  }
+
+  void q_update(const double* rho_new, const double* rho_old) override {
+    need_final();
+    for (int i = 0; i < p_n_; ++i) {
+      if (rho_new[i] == rho_old[i]) continue;                       // ind_updated, PARSDMM.jl:230
+      const T alpha = (T)rho_new[i] - (T)rho_old[i];                // Q_update!.jl:47
+      const SetState<T>& s = sets_[i];
+      for (size_t j = 0; j < s.ata_off.size(); ++j)
+        K<T>::q_axpy(stream_, G_.N, Q_ + (size_t)q_col(s.ata_off[j]) * G_.N, s.ata + j * G_.N, alpha);
+    }
+  }
+
+  void download(void* x, void* const* l, void* const* y) override {
+    need_final();
+    SIPX_HIP(hipStreamSynchronize(stream_));
+    if (x) SIPX_HIP(hipMemcpy(x, x_, G_.N * sizeof(T), hipMemcpyDeviceToHost));
+    for (int i = 0; i < p_n_; ++i) {
+      if (!sets_[i].owned) continue;
+      if (l && l[i]) download_rows(sets_[i], sets_[i].l, (T*)l[i]);
+      if (y && y[i]) download_rows(sets_[i], sets_[i].y, (T*)y[i]);
+    }
+  }
+
+  // ------------------------------------------------------------------------------------------
+  // Whole solve: src/PARSDMM.jl:63-257 restated (serial path).
+  void parsdmm(const sipx_options* opt, sipx_log* log) override {
+    need_final();
+    for (auto& s : sets_)
+      if (!s.owned) throw std::runtime_error("sipx_parsdmm needs every set local; use the phase API when sharding");
+    const int maxit = opt->maxit, p = p_n_, pp = pp_n_;
+    const T evol_rel_tol = (T)opt->evol_rel_tol, feas_tol = (T)opt->feas_tol, obj_tol = (T)opt->obj_tol;   // convert_options!
+    bool adjust_rho = opt->adjust_rho, adjust_gamma = opt->adjust_gamma, adjust_feas_rho = opt->adjust_feasibility_rho;
+    int freq = opt->rho_update_frequency;
+    if (any_ncvx_) { freq = 3; adjust_gamma = false; }              // PARSDMM_initialize.jl:107-114
+    std::fill(log->timing_ms, log->timing_ms + 7, 0.0);
+    log->stopped_feasible = 0;
+    for (int i = 0; i < pp; ++i) log->set_feasibility[i] = feas_init_[i];   // :236
+    double maxf = julia_maximum(feas_init_.begin(), feas_init_.end());
+    if (pp > 0 && maxf < (double)feas_tol) {                          // :101-104, PARSDMM.jl:63-82
+      SIPX_HIP(hipMemcpyAsync(x_, m_, G_.N * sizeof(T), hipMemcpyDeviceToDevice, stream_));
+      SIPX_HIP(hipStreamSynchronize(stream_));
+      log->n_iter = 1;
+      log->n_feas_rows = 1;
+      log->stopped_feasible = 1;
+      return;
+    }
+    int counter = 2, ind_ref = maxit;
+    double tol_ref = 1.0;
+    std::vector<double> rho(p), gamma(p), rho_new(p), rpri(p), rdual(p), feas(std::max(pp, 1));
+    for (int i = 0; i < p; ++i) { rho[i] = (double)rho_[i]; gamma[i] = (double)gamma_[i]; }
+    auto t_mark = [&](int k) { SIPX_HIP(hipEventRecord(ev_[k], stream_)); };
+    log->n_iter = maxit;
+    log->n_feas_rows = counter;
+    for (int i = 1; i <= maxit; ++i) {
+      t_mark(0);
+      rhs_compose(rho.data());
+      t_mark(1);
+      int64_t cg_it; double relres; int flag;
+      argmin_x(i, &tol_ref, &cg_it, &relres, &flag);
+      log->cg_it[i - 1] = cg_it;
+      log->cg_relres[i - 1] = relres;
+      t_mark(2);
+      int flags = 0;
+      if (i % 10 == 0) flags |= SIPX_YL_FEAS;
+      if (i == 1) flags |= SIPX_YL_FIRST;
+      if ((adjust_rho || adjust_gamma) && i % freq == 0) flags |= SIPX_YL_BB;
+      update_y_l(i, flags, rho.data(), gamma.data(), rpri.data(), rdual.data(), feas.data());
+      T sd = (T)rdual[0], sp = (T)rpri[0];
+      for (int k = 0; k < p; ++k) {
+        log->r_pri[(size_t)(i - 1) * p + k] = rpri[k];
+        log->r_dual[(size_t)(i - 1) * p + k] = rdual[k];
+        if (k > 0) { sd = sd + (T)rdual[k]; sp = sp + (T)rpri[k]; }
+        log->rho[(size_t)(i - 1) * p + k] = rho[k];
+        log->gamma[(size_t)(i - 1) * p + k] = gamma[k];
+      }
+      log->r_dual_total[i - 1] = (double)sd;                          // PARSDMM.jl:134
+      log->r_pri_total[i - 1] = (double)sp;                           // :138
+      if (i % 10 == 0) {                                              // update_y_l.jl:90-105
+        for (int k = 0; k < pp; ++k) log->set_feasibility[(size_t)(counter - 1) * pp + k] = feas[k];
+        counter += 1;
+      }
+      log_scalars(&log->obj[i - 1], &log->evol_x[i - 1]);
+      t_mark(3);
+      // ---- stop_PARSDMM.jl:23-52 ----
+      bool stop = false;
+      if (i > 6 && pp > 0) {
+        const double* row = log->set_feasibility + (size_t)(counter - 2) * pp;
+        if (julia_maximum(row, row + pp) < (double)feas_tol) {
+          double mx = -INFINITY; bool nan = false;
+          for (int k = i - 6; k < i; ++k) {
+            const T a = (T)log->obj[k], b = (T)log->obj[k - 1];
+            const T v = std::fabs((a - b) / b);
+            if (std::isnan(v)) nan = true;
+            mx = std::max(mx, (double)v);
+          }
+          if (!nan && mx < (double)obj_tol) stop = true;
+        }
+      }
+      if (i > 5 && julia_maximum(log->evol_x + (i - 6), log->evol_x + i) < (double)evol_rel_tol) stop = true;
+      if (i > 20 && adjust_rho) {
+        const int lo = std::max(i - 50, 1);
+        if (log->r_pri_total[i - 1] > julia_maximum(log->r_pri_total + (lo - 1), log->r_pri_total + (i - 1))) {
+          adjust_rho = adjust_feas_rho = adjust_gamma = false;
+          ind_ref = i;
+        }
+      }
+      if (!adjust_rho && i > ind_ref + 25) {
+        const int lo = std::max(ind_ref, std::max(i - 50, 1));
+        if (log->r_pri_total[i - 1] > julia_maximum(log->r_pri_total + (lo - 1), log->r_pri_total + (i - 1))) stop = true;
+      }
+      t_mark(4);
+      if (stop) {
+        add_timing(log, 5);
+        log->n_iter = i;
+        log->n_feas_rows = counter;
+        return;
+      }
+      // ---- adjust rho and gamma (PARSDMM.jl:163-227); l_hat / snapshots were fused into update_y_l ----
+      rho_new = rho;
+      if ((adjust_rho || adjust_gamma) && i % freq == 0)
+        adapt_rho_gamma(adjust_rho, adjust_gamma, rho_new.data(), gamma.data());
+      if (adjust_feas_rho && i % 10 == 0 && i > 10 && pp > 0) {       // :213-223
+        const double* row = log->set_feasibility + (size_t)(counter - 2) * pp;
+        int arg = 0;
+        bool found_nan = false;
+        for (int k = 0; k < pp && !found_nan; ++k) {
+          if (std::isnan(row[k])) { arg = k; found_nan = true; }
+          else if (row[k] > row[arg]) arg = k;
+        }
+        rho_new[arg] = (double)(T(2.0) * (T)rho_new[arg]);
+      }
+      for (int k = 0; k < p; ++k)                                      // :226
+        rho_new[k] = (double)std::max(std::min((T)rho_new[k], T(1e4)), T(1e-2));
+      t_mark(5);
+      q_update(rho_new.data(), rho.data());                            // :230-243
+      rho = rho_new;
+      t_mark(6);
+      add_timing(log, 7);
+    }
+    log->n_iter = maxit;
+    log->n_feas_rows = counter;
+    for (int i = 0; i < p; ++i) { rho_[i] = (T)rho[i]; gamma_[i] = (T)gamma[i]; }
+  }
+
+  // ------------------------------------------------------------------------------------------
+  void apply_op(int op, const void* x, void* out, bool adjoint) override {
+    SIPX_HIP(hipSetDevice(device_));
+    SetState<T> s;
+    configure_op(s, op);
+    T* dx = dalloc<T>(G_.N);
+    T* dv = dalloc<T>(s.Mpad);
+    if (!adjoint) {
+      SIPX_HIP(hipMemcpy(dx, x, G_.N * sizeof(T), hipMemcpyHostToDevice));
+      K<T>::fwd(stream_, G_, s.nblk, s.dir, s.ih, dx, dv);
+      download_rows(s, dv, (T*)out);
+    } else {
+      upload_rows(s, (const T*)x, dv);
+      K<T>::adj(stream_, G_, s.nblk, s.dir, s.ih, dv, dx);
+      SIPX_HIP(hipStreamSynchronize(stream_));
+      SIPX_HIP(hipMemcpy(out, dx, G_.N * sizeof(T), hipMemcpyDeviceToHost));
+    }
+    dfree(dx);
+    dfree(dv);
+  }
+
+  void project(const sipx_set_desc* d, void* v, int64_t len) override {
+    SIPX_HIP(hipSetDevice(device_));
+    Grid g1;
+    g1.n[0] = len; g1.n[1] = 1; g1.n[2] = 1; g1.N = len; g1.st[0] = 1; g1.st[1] = len; g1.st[2] = len;
+    T* dv = dalloc<T>(len);
+    T* dc = dalloc<T>(len);
+    T *lb = nullptr, *ub = nullptr;
+    double* part = dalloc<double>(2 * NB);
+    T* mp = dalloc<T>(NB);
+    ProjScalars<T>* ps = dalloc<ProjScalars<T>>(1);
+    unsigned long long* hc = dalloc<unsigned long long>(L1_BINS);
+    double* hs = dalloc<double>(L1_BINS);
+    SIPX_HIP(hipMemcpy(dv, v, len * sizeof(T), hipMemcpyHostToDevice));
+    const int prox = d->proj;
+    const T plo = (T)d->pmin, phi = (T)d->pmax;
+    if (prox == SIPX_PROJ_BOUNDS_VEC) {
+      lb = dalloc<T>(len); ub = dalloc<T>(len);
+      SIPX_HIP(hipMemcpy(lb, d->lb, len * sizeof(T), hipMemcpyHostToDevice));
+      SIPX_HIP(hipMemcpy(ub, d->ub, len * sizeof(T), hipMemcpyHostToDevice));
+    }
+    if (prox == SIPX_PROJ_L1 && !(d->pmax > 0)) throw std::runtime_error("Radius of L1 ball is negative");
+    if (prox == SIPX_PROJ_CARDINALITY) throw std::runtime_error("cardinality projector: not built yet");
+    const bool two = prox == SIPX_PROJ_L1 || prox == SIPX_PROJ_L2 || prox == SIPX_PROJ_ANNULUS;
+    if (two) {
+      K<T>::ps_reduce(stream_, len, dv, part, mp);
+      K<T>::ps_finish(stream_, part, mp, ps, prox, plo, phi, len);
+      if (prox == SIPX_PROJ_L1) K<T>::l1_theta(stream_, len, dv, ps, phi, hc, hs, dc);
+    }
+    proj_apply_grid<T>(stream_, g1, 0, nullptr, len, dv, prox, plo, phi, lb, ub, two ? ps : nullptr);
+    SIPX_HIP(hipStreamSynchronize(stream_));
+    SIPX_HIP(hipMemcpy(v, dv, len * sizeof(T), hipMemcpyDeviceToHost));
+    for (void* q : {(void*)dv, (void*)dc, (void*)lb, (void*)ub, (void*)part, (void*)mp, (void*)ps, (void*)hc, (void*)hs})
+      dfree(q);
+  }
+
+  void get_Q(void* Q, int64_t* offsets, int* d) override {
+    need_final();
+    SIPX_HIP(hipStreamSynchronize(stream_));
+    if (d) *d = cds_.d;
+    if (offsets) for (int b = 0; b < cds_.d; ++b) offsets[b] = cds_.off[b];
+    if (Q) SIPX_HIP(hipMemcpy(Q, Q_, (size_t)G_.N * cds_.d * sizeof(T), hipMemcpyDeviceToHost));
+  }
+
+  double time_spmv(int reps) override {
+    need_final();
+    hipEvent_t a, b;
+    SIPX_HIP(hipEventCreate(&a));
+    SIPX_HIP(hipEventCreate(&b));
+    K<T>::spmv(stream_, G_, G_.N, Q_, cds_, x_, Ap_);   // warm
+    SIPX_HIP(hipEventRecord(a, stream_));
+    for (int k = 0; k < reps; ++k) K<T>::spmv(stream_, G_, G_.N, Q_, cds_, x_, Ap_);
+    SIPX_HIP(hipEventRecord(b, stream_));
+    SIPX_HIP(hipEventSynchronize(b));
+    float ms = 0;
+    SIPX_HIP(hipEventElapsedTime(&ms, a, b));
+    (void)hipEventDestroy(a);
+    (void)hipEventDestroy(b);
+    return (double)ms / reps;
+  }
+
+  void* stream() override { return (void*)stream_; }
+  void* dev_rhs() override { return rhs_; }
+  void* dev_x() override { return x_; }
+
+ private:
+  void need_final() const {
+    if (!finalized_) throw std::runtime_error("call sipx_finalize first");
+    SIPX_HIP(hipSetDevice(device_));
+  }
+
+  void configure_op(SetState<T>& s, int op) const {
+    s.op = op;
+    const int zdir = ndim_ == 2 ? 1 : 2;
+    switch (op) {
+      case SIPX_OP_IDENTITY: s.nblk = 0; break;
+      case SIPX_OP_DX: s.nblk = 1; s.dir[0] = 0; break;
+      case SIPX_OP_DY:
+        if (ndim_ == 2) throw std::runtime_error("D_y needs a 3-D grid");
+        s.nblk = 1; s.dir[0] = 1; break;
+      case SIPX_OP_DZ: s.nblk = 1; s.dir[0] = zdir; break;
+      case SIPX_OP_TV:                                   // vcat(D_z[,D_y],D_x): get_discrete_Grad.jl:31-33,69-72
+        if (ndim_ == 2) { s.nblk = 2; s.dir[0] = 1; s.dir[1] = 0; }
+        else { s.nblk = 3; s.dir[0] = 2; s.dir[1] = 1; s.dir[2] = 0; }
+        break;
+      default: throw std::runtime_error("unknown operator kind");
+    }
+    s.ident = s.nblk == 0;
+    s.Mtrue = 0;
+    for (int q = 0; q < s.nblk; ++q) {
+      const int a = s.dir[q];
+      if (G_.n[a] < 2) throw std::runtime_error("difference operator along a dimension of size 1");
+      s.ih[q] = ih_[a];
+      s.blk_rows[q] = G_.N / G_.n[a] * (G_.n[a] - 1);
+      s.Mtrue += s.blk_rows[q];
+    }
+    if (s.ident) s.Mtrue = G_.N;
+    s.Mpad = s.ident ? G_.N : (long long)s.nblk * G_.N;
+  }
+
+  std::vector<long long> default_ata_offsets(const SetState<T>& s) const {   // mat2CDS: ascending (mat2CDS.jl:9-13)
+    std::vector<long long> o = {0};
+    for (int q = 0; q < s.nblk; ++q) {
+      o.push_back(G_.st[s.dir[q]]);
+      o.push_back(-G_.st[s.dir[q]]);
+    }
+    std::sort(o.begin(), o.end());
+    o.erase(std::unique(o.begin(), o.end()), o.end());
+    return o;
+  }
+
+  int q_col(long long off) const {
+    for (int b = 0; b < cds_.d; ++b)
+      if (cds_.off[b] == off) return b;
+    throw std::runtime_error("attempted to update a diagonal in A in CDS storage that does not exist. A and B need "
+                             "to have the same nonzero diagonals");   // CDS_scaled_add!.jl:18-20
+  }
+
+  void assemble_Q() {      // PARSDMM_initialize.jl:216-230: first-seen offsets over a zero-padded table
+    std::vector<long long> seen;
+    auto see = [&](long long o) {
+      if (std::find(seen.begin(), seen.end(), o) == seen.end()) seen.push_back(o);
+    };
+    for (auto& s : sets_) {
+      if (s.ata_off.size() > 999) throw std::runtime_error("more than 999 bands in one set");
+      for (long long o : s.ata_off) see(o);
+      see(0);
+    }
+    if ((int)seen.size() > MAXD) throw std::runtime_error("Q has more bands than this build supports");
+    cds_.d = (int)seen.size();
+    for (int b = 0; b < cds_.d; ++b) cds_.off[b] = seen[b];
+    Q_ = dalloc<T>((size_t)G_.N * cds_.d);
+    for (int i = 0; i < p_n_; ++i) {
+      const SetState<T>& s = sets_[i];
+      for (size_t j = 0; j < s.ata_off.size(); ++j)
+        K<T>::q_axpy(stream_, G_.N, Q_ + (size_t)q_col(s.ata_off[j]) * G_.N, s.ata + j * G_.N, rho_[i]);
+    }
+  }
+
+  SetArgs<T> set_args(const SetState<T>& s, T rho, T gamma, int flags) const {
+    SetArgs<T> a;
+    a.y = s.y; a.l = s.l; a.dy = s.dy; a.lh0 = s.lh0; a.y0 = s.y0; a.s0 = s.s0; a.l0 = s.l0;
+    a.v = scr_v_;
+    a.x = x_; a.m = m_; a.xold = xold_; a.lb = s.lb; a.ub = s.ub;
+    a.nblk = s.nblk;
+    for (int q = 0; q < 3; ++q) { a.dir[q] = s.dir[q]; a.ih[q] = s.ih[q]; }
+    a.rho = rho;
+    a.rho1 = T(1) / rho;       // rho1 = TF(1.0) ./ rho   update_y_l.jl:33-34
+    a.gamma = gamma;
+    a.prox = s.prox;
+    a.plo = s.plo; a.phi = s.phi;
+    a.ps = s.ps;
+    a.flags = flags;
+    a.vsrc = 0;
+    return a;
+  }
+
+  // ||P(v)-v||^2, ||v||^2 of the vector sitting in scr_v_ into partial slots dst, dst+NB
+  void feasibility_of_scratch(SetState<T>& s, double* dst, bool have_sums = false) {
+    ProjScalars<T>* ps = s.ps;
+    if (s.two_pass) {
+      if (!have_sums) K<T>::ps_reduce(stream_, s.Mpad, scr_v_, part_tmp_, maxpart_);
+      K<T>::ps_finish(stream_, part_tmp_, maxpart_, ps, s.prox, s.plo, s.phi, s.Mtrue);
+      if (s.prox == PX_L1) K<T>::l1_theta(stream_, s.Mpad, scr_v_, ps, s.phi, hist_cnt_, hist_sum_, scr_c_);
+    }
+    proj_dist_grid<T>(stream_, G_, s.nblk, s.dir, s.Mpad, scr_v_, s.prox, s.plo, s.phi, s.lb, s.ub,
+                      s.two_pass ? ps : nullptr, dst);
+  }
+
+  T feas_value(double fe, double ss) const {
+    return (T)std::sqrt(fe) / ((T)std::sqrt(ss) + T(100) * std::numeric_limits<T>::epsilon());
+  }
+
+  // reference row order <-> padded layout (host side; only at import/export)
+  template <typename F>
+  void for_rows(const SetState<T>& s, F f) const {
+    if (s.ident) {
+      for (long long g = 0; g < G_.N; ++g) f(g, g);
+      return;
+    }
+    long long r = 0;
+    for (int q = 0; q < s.nblk; ++q) {
+      const int a = s.dir[q];
+      const long long base = (long long)q * G_.N;
+      for (long long k = 0; k < G_.n[2]; ++k)
+        for (long long j = 0; j < G_.n[1]; ++j)
+          for (long long i = 0; i < G_.n[0]; ++i) {
+            const long long c = a == 0 ? i : (a == 1 ? j : k);
+            if (c < G_.n[a] - 1) f(r++, base + i + G_.n[0] * (j + G_.n[1] * k));
+          }
+    }
+  }
+  void upload_rows(const SetState<T>& s, const T* rows, T* dev) const {
+    std::vector<T> pad((size_t)s.Mpad, T(0));
+    for_rows(s, [&](long long r, long long e) { pad[e] = rows[r]; });
+    SIPX_HIP(hipMemcpy(dev, pad.data(), pad.size() * sizeof(T), hipMemcpyHostToDevice));
+  }
+  void download_rows(const SetState<T>& s, const T* dev, T* rows) const {
+    std::vector<T> pad((size_t)s.Mpad);
+    SIPX_HIP(hipStreamSynchronize(stream_));
+    SIPX_HIP(hipMemcpy(pad.data(), dev, pad.size() * sizeof(T), hipMemcpyDeviceToHost));
+    for_rows(s, [&](long long r, long long e) { rows[r] = pad[e]; });
+  }
+
+  void add_timing(sipx_log* log, int nmarks) {
+    SIPX_HIP(hipEventSynchronize(ev_[nmarks - 1]));
+    // sections: rhs(0-1) argmin x(1-2) y/l(2-3) stop(3-4) adjust(4-5) Q-update(5-6); [0] "initialization" is host-side
+    for (int k = 1; k < nmarks; ++k) {
+      float ms = 0;
+      SIPX_HIP(hipEventElapsedTime(&ms, ev_[k - 1], ev_[k]));
+      log->timing_ms[k] += ms;
+    }
+  }
+
+  void free_set(SetState<T>& s) {
+    for (void* p : {(void*)s.y, (void*)s.l, (void*)s.dy, (void*)s.lh0, (void*)s.y0, (void*)s.s0, (void*)s.l0,
+                    (void*)s.lb, (void*)s.ub, (void*)s.ata, (void*)s.ps})
+      dfree(p);
+  }
+
+  int device_ = 0, ndim_ = 2;
+  hipStream_t stream_ = nullptr;
+  Grid G_;
+  T ih_[3];
+  std::vector<SetState<T>> sets_;
+  std::vector<int32_t> owned_;
+  bool finalized_ = false, feasibility_only_ = false, any_ncvx_ = false;
+  int p_n_ = 0, pp_n_ = 0;
+  std::vector<T> rho_, gamma_;
+  std::vector<double> feas_init_;
+  T *x_ = nullptr, *xold_ = nullptr, *rhs_ = nullptr, *m_ = nullptr, *r_ = nullptr, *p_ = nullptr, *Ap_ = nullptr;
+  T *Q_ = nullptr, *scr_v_ = nullptr, *scr_c_ = nullptr, *maxpart_ = nullptr;
+  CdsArgs cds_;
+  double *part_cg_ = nullptr, *part_tmp_ = nullptr, *part_sets_ = nullptr, *hist_sum_ = nullptr;
+  unsigned long long* hist_cnt_ = nullptr;
+  CgState<T>*cg_dev_ = nullptr, *cg_host_ = nullptr;
+  double* hres_ = nullptr;
+  std::vector<hipEvent_t> ev_;
+  double obj_ss_ = 0, evo_ss_ = 0, xx_ss_ = 0;
+  bool have_log_sums_ = false;
+};
+
+EngineBase* make_engine(int dtype, int ndim, const int64_t* n, const double* h, int device) {
+  int count = 0;
+  if (hipGetDeviceCount(&count) != hipSuccess || count <= 0)
+    throw std::runtime_error("libsipx: no HIP device visible -- this engine has no CPU fallback");
+  if (device < 0 || device >= count) throw std::runtime_error("libsipx: device index out of range");
+  if (dtype == SIPX_F32) return new Engine<float>(ndim, n, h, device);
+  if (dtype == SIPX_F64) return new Engine<double>(ndim, n, h, device);
+  throw std::runtime_error("dtype must be SIPX_F32 or SIPX_F64");
+}
+
+template <typename T>
+static void cds_spmv_T(int64_t N, int d, const void* R, const int64_t* off, const void* x, void* y) {
+  if (d < 1 || d > MAXD) throw std::runtime_error("cds_spmv: band count out of range");
+  T* dR = dalloc<T>((size_t)N * d, false);
+  T* dx = dalloc<T>(N, false);
+  T* dy = dalloc<T>(N);
+  SIPX_HIP(hipMemcpy(dR, R, (size_t)N * d * sizeof(T), hipMemcpyHostToDevice));
+  SIPX_HIP(hipMemcpy(dx, x, N * sizeof(T), hipMemcpyHostToDevice));
+  CdsArgs a;
+  a.d = d;
+  for (int b = 0; b < d; ++b) a.off[b] = off[b];
+  Grid g;
+  g.n[0] = N; g.n[1] = 1; g.n[2] = 1; g.N = N; g.st[0] = 1; g.st[1] = N; g.st[2] = N;
+  K<T>::spmv(nullptr, g, N, dR, a, dx, dy);
+  SIPX_HIP(hipDeviceSynchronize());
+  SIPX_HIP(hipMemcpy(y, dy, N * sizeof(T), hipMemcpyDeviceToHost));
+  dfree(dR); dfree(dx); dfree(dy);
+}
+
+void cds_spmv_host(int dtype, int64_t N, int d, const void* R, const int64_t* off, const void* x, void* y, int device) {
+  int count = 0;
+  if (hipGetDeviceCount(&count) != hipSuccess || count <= 0)
+    throw std::runtime_error("libsipx: no HIP device visible -- this engine has no CPU fallback");
+  SIPX_HIP(hipSetDevice(device));
+  if (dtype == SIPX_F32) cds_spmv_T<float>(N, d, R, off, x, y);
+  else if (dtype == SIPX_F64) cds_spmv_T<double>(N, d, R, off, x, y);
+  else throw std::runtime_error("dtype must be SIPX_F32 or SIPX_F64");
+}
+
+}  // namespace sipx

@@ -1,0 +1,43 @@
+// Host-side engine: device-resident PARSDMM state + the phases of the reference's main loop.
+#pragma once
+#include <memory>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "../../include/sipx.h"
+#include "sipx_common.h"
+
+namespace sipx {
+
+struct EngineBase {
+  virtual ~EngineBase() {}
+  virtual int add_set(const sipx_set_desc* d, const void* ata_R, const int64_t* ata_off, int d_i) = 0;
+  virtual int64_t set_rows(int set) = 0;
+  virtual void num_terms(int* p, int* pp) = 0;
+  virtual void finalize(const void* m, const double* rho_ini, int n_rho, double gamma_ini, int feasibility_only,
+                        int zero_ini_guess, const void* x0, const void* const* l0, const void* const* y0,
+                        double* feasibility_initial) = 0;
+  virtual void rhs_compose(const double* rho) = 0;
+  virtual void argmin_x(int it, double* tol_ref_io, int64_t* cg_it, double* cg_relres, int* cg_flag) = 0;
+  virtual void update_y_l(int it, int flags, const double* rho, const double* gamma, double* r_pri, double* r_dual,
+                          double* feas) = 0;
+  virtual void log_scalars(double* obj, double* evol_x) = 0;
+  virtual void adapt_rho_gamma(int adjust_rho, int adjust_gamma, double* rho_io, double* gamma_io) = 0;
+  virtual void q_update(const double* rho_new, const double* rho_old) = 0;
+  virtual void download(void* x, void* const* l, void* const* y) = 0;
+  virtual void parsdmm(const sipx_options* opt, sipx_log* log) = 0;
+  virtual void apply_op(int op, const void* x, void* s, bool adjoint) = 0;
+  virtual void project(const sipx_set_desc* d, void* v, int64_t len) = 0;
+  virtual void get_Q(void* Q, int64_t* offsets, int* d) = 0;
+  virtual double time_spmv(int reps) = 0;
+  virtual void* stream() = 0;
+  virtual void* dev_rhs() = 0;
+  virtual void* dev_x() = 0;
+  virtual void set_owned(const int32_t* owned) = 0;
+};
+
+EngineBase* make_engine(int dtype, int ndim, const int64_t* n, const double* h, int device);
+void cds_spmv_host(int dtype, int64_t N, int d, const void* R, const int64_t* off, const void* x, void* y, int device);
+
+}  // namespace sipx

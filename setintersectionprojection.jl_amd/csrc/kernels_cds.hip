@@ -1,0 +1,385 @@
+// CDS (compressed diagonal storage) kernels + the fused CG building blocks.
+//
+// Replaces (reference file:line):
+//   CDS_MVp_MT / CDS_MVp_MT_subfunc  src/CDS_MVp_MT.jl:9-25, src/CDS_MVp_MT_subfunc.jl:6-20
+//   Ax_CDS_MT (fill! + MVp)          src/argmin_x.jl:72-78
+//   cg loop body                     src/cg.jl:82-115
+//   CDS_scaled_add!                  src/CDS_scaled_add!.jl:8-26
+// The reference sweeps the output once PER DIAGONAL (4dN words of traffic); here one pass
+// reads every band once and writes y once: (d+2)*N*w algorithmic bytes.  Per row the products
+// are added band after band in Q_offsets order starting from 0, i.e. exactly the reference's
+// accumulation order, and -ffp-contract=off keeps mul and add separate like Julia does.
+#include <stdexcept>
+#include <string>
+
+#include "sipx_device.h"
+
+namespace sipx {
+
+// acc[k] = sum_b R[r+k, b] * x[r+k+off_b], bands in order, rows clipped like CDS_MVp.jl:17-23.
+template <typename T, int V, int D>
+__device__ __forceinline__ void cds_rows(long long N, const T* __restrict__ R, const CdsArgs& a,
+                                         const T* __restrict__ x, long long r, T (&acc)[V]) {
+  const int d = D ? D : a.d;
+#pragma unroll
+  for (int k = 0; k < V; ++k) acc[k] = T(0);
+#pragma unroll
+  for (int b = 0; b < d; ++b) {
+    const long long o = a.off[b];
+    const Vec<T, V> rv = ldv<T, V>(R + (long long)b * N + r);
+    const long long c = r + o;
+    if ((o % V) == 0 && c >= 0 && c + V <= N) {
+      const Vec<T, V> xv = ldv<T, V>(x + c);
+#pragma unroll
+      for (int k = 0; k < V; ++k) acc[k] = acc[k] + rv.v[k] * xv.v[k];
+    } else {
+#pragma unroll
+      for (int k = 0; k < V; ++k) {
+        const long long cc = c + k;
+        if (cc >= 0 && cc < N) acc[k] = acc[k] + rv.v[k] * x[cc];
+      }
+    }
+  }
+}
+
+// MODE 0: y = Qx.  MODE 1: Ap = Qp and partial(p.Ap) (cg.jl:85-88).
+// MODE 2: r = b - Qx, p = r, x_old = x, partials ||r||^2, ||b||^2 (argmin_x.jl:34 + cg.jl:52-58 + PARSDMM.jl:106).
+template <typename T, int V, int D, int MODE>
+__global__ __launch_bounds__(BLOCK) void k_cds(long long N, const T* __restrict__ R, CdsArgs a,
+                                               const T* __restrict__ x, T* __restrict__ y, const T* __restrict__ b,
+                                               T* __restrict__ pout, T* __restrict__ xold, double* __restrict__ partials,
+                                               const int* __restrict__ done) {
+  if (MODE == 1 && *done) return;
+  const long long nvec = N / V;
+  double acc0 = 0, acc1 = 0;
+  for (long long vi = (long long)blockIdx.x * BLOCK + threadIdx.x; vi < nvec; vi += (long long)NB * BLOCK) {
+    const long long r = vi * V;
+    T s[V];
+    cds_rows<T, V, D>(N, R, a, x, r, s);
+    if (MODE == 0) {
+      Vec<T, V> o;
+#pragma unroll
+      for (int k = 0; k < V; ++k) o.v[k] = s[k];
+      stv<T, V>(y + r, o);
+    } else if (MODE == 1) {
+      const Vec<T, V> pv = ldv<T, V>(x + r);
+      Vec<T, V> o;
+#pragma unroll
+      for (int k = 0; k < V; ++k) {
+        o.v[k] = s[k];
+        acc0 += (double)pv.v[k] * (double)s[k];
+      }
+      stv<T, V>(y + r, o);
+    } else {
+      const Vec<T, V> bv = ldv<T, V>(b + r);
+      const Vec<T, V> xv = ldv<T, V>(x + r);
+      Vec<T, V> o;
+#pragma unroll
+      for (int k = 0; k < V; ++k) {
+        o.v[k] = bv.v[k] - s[k];
+        acc0 += (double)o.v[k] * (double)o.v[k];
+        acc1 += (double)bv.v[k] * (double)bv.v[k];
+      }
+      stv<T, V>(y + r, o);
+      stv<T, V>(pout + r, o);
+      stv<T, V>(xold + r, xv);
+    }
+  }
+  if (MODE == 1) {
+    double acc[1] = {acc0};
+    block_reduce_store<1>(acc, partials, 0);
+  } else if (MODE == 2) {
+    double acc[2] = {acc0, acc1};
+    block_reduce_store<2>(acc, partials, 0);
+  }
+}
+
+template <typename T, int MODE>
+static void launch_cds(hipStream_t s, long long N, const T* R, const CdsArgs& a, const T* x, T* y, const T* b, T* pout,
+                       T* xold, double* partials, const int* done) {
+  if (a.d < 1 || a.d > MAXD) throw std::runtime_error("cds: band count out of range");
+#define SIPX_CDS(V, D) \
+  hipLaunchKernelGGL((k_cds<T, V, D, MODE>), dim3(NB), dim3(BLOCK), 0, s, N, R, a, x, y, b, pout, xold, partials, done)
+  if (N % 4 == 0) {
+    switch (a.d) {
+      case 1: SIPX_CDS(4, 1); break;
+      case 3: SIPX_CDS(4, 3); break;
+      case 5: SIPX_CDS(4, 5); break;
+      case 7: SIPX_CDS(4, 7); break;
+      default: SIPX_CDS(4, 0); break;
+    }
+  } else {
+    SIPX_CDS(1, 0);
+  }
+#undef SIPX_CDS
+  SIPX_HIP(hipGetLastError());
+}
+
+template <typename T>
+void K<T>::spmv(hipStream_t s, const Grid&, long long N, const T* R, const CdsArgs& a, const T* x, T* y) {
+  launch_cds<T, 0>(s, N, R, a, x, y, nullptr, nullptr, nullptr, nullptr, nullptr);
+}
+template <typename T>
+void K<T>::spmv_dot(hipStream_t s, long long N, const T* R, const CdsArgs& a, const T* p, T* Ap, double* partials,
+                    const CgState<T>* st) {
+  launch_cds<T, 1>(s, N, R, a, p, Ap, nullptr, nullptr, nullptr, partials, &st->done);
+}
+template <typename T>
+void K<T>::resid(hipStream_t s, long long N, const T* R, const CdsArgs& a, const T* x, const T* b, T* r, T* p, T* xold,
+                 double* partials) {
+  launch_cds<T, 2>(s, N, R, a, x, r, b, p, xold, partials, nullptr);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Q[:,c] += alpha * AtA_i[:,k]   (CDS_scaled_add!.jl:16-22; one band per launch)
+template <typename T, int V>
+__global__ __launch_bounds__(BLOCK) void k_q_axpy(long long N, T* __restrict__ q, const T* __restrict__ a, T alpha) {
+  const long long nvec = N / V;
+  for (long long vi = (long long)blockIdx.x * BLOCK + threadIdx.x; vi < nvec; vi += (long long)NB * BLOCK) {
+    Vec<T, V> qv = ldv<T, V>(q + vi * V);
+    const Vec<T, V> av = ldv<T, V>(a + vi * V);
+#pragma unroll
+    for (int k = 0; k < V; ++k) qv.v[k] = qv.v[k] + alpha * av.v[k];
+    stv<T, V>(q + vi * V, qv);
+  }
+}
+template <typename T>
+void K<T>::q_axpy(hipStream_t s, long long N, T* Qband, const T* Aband, T alpha) {
+  if (N % 4 == 0)
+    hipLaunchKernelGGL((k_q_axpy<T, 4>), dim3(NB), dim3(BLOCK), 0, s, N, Qband, Aband, alpha);
+  else
+    hipLaunchKernelGGL((k_q_axpy<T, 1>), dim3(NB), dim3(BLOCK), 0, s, N, Qband, Aband, alpha);
+  SIPX_HIP(hipGetLastError());
+}
+
+// ---------------------------------------------------------------------------------------------
+// AtA = A'A bands of a difference operator straight from the descriptor, in the accumulation
+// order of Julia's sparse product (ascending row of A): what mat2CDS(TD_OP'*TD_OP) yields
+// (PARSDMM_precompute_distribute.jl:44-59, mat2CDS.jl:7-32).
+struct GenArgs {
+  int nblk;
+  int dir[3];
+  int nband;
+  long long off[7];
+};
+template <typename T>
+__global__ __launch_bounds__(BLOCK) void k_gen_ata(Grid G, GenArgs a, T ih0, T ih1, T ih2, T* __restrict__ R) {
+  const T ihs[3] = {ih0, ih1, ih2};
+  for (long long g = (long long)blockIdx.x * BLOCK + threadIdx.x; g < G.N; g += (long long)NB * BLOCK) {
+    const Coord c = coords(G, g);
+    for (int b = 0; b < a.nband; ++b) {
+      const long long o = a.off[b];
+      T val = (a.nblk == 0 && o == 0) ? T(1) : T(0);   // identity: AtA = I (precompute_distribute.jl:44-45)
+      for (int q = 0; q < a.nblk; ++q) {
+        const int dir = a.dir[q];
+        const T ih = ihs[q], nih = -ih;
+        const int cc = coord_of(c, dir);
+        const long long st = G.st[dir];
+        if (o == 0) {
+          if (cc > 0) val = val + ih * ih;            // row g-st holds +ih in column g
+          if (cc < G.n[dir] - 1) val = val + nih * nih;  // row g holds -ih in column g
+        } else if (o == st) {
+          if (cc < G.n[dir] - 1) val = val + nih * ih;   // row g: A[g,g]*A[g,g+st]
+        } else if (o == -st) {
+          if (cc > 0) val = val + ih * nih;            // row g-st: A[.,g]*A[.,g-st]
+        }
+      }
+      R[(long long)b * G.N + g] = val;
+    }
+  }
+}
+template <typename T>
+void K<T>::gen_ata(hipStream_t s, const Grid& g, int nblk, const int* dir, const T* ih, int nband, const long long* offs,
+                   T* R) {
+  GenArgs a;
+  a.nblk = nblk;
+  a.nband = nband;
+  for (int q = 0; q < 3; ++q) a.dir[q] = q < nblk ? dir[q] : 0;
+  for (int b = 0; b < nband; ++b) a.off[b] = offs[b];
+  hipLaunchKernelGGL((k_gen_ata<T>), dim3(NB), dim3(BLOCK), 0, s, g, a, ih[0], nblk > 1 ? ih[1] : T(0),
+                     nblk > 2 ? ih[2] : T(0), R);
+  SIPX_HIP(hipGetLastError());
+}
+
+// ---------------------------------------------------------------------------------------------
+// CG scalar steps: one 256-thread block sums the block partials in fixed order, thread 0 applies
+// the reference's scalar logic and mirrors the state into pinned host memory.
+template <typename T>
+__global__ __launch_bounds__(BLOCK) void k_cg_begin(const double* __restrict__ partials, CgState<T>* st,
+                                                    CgState<T>* host, int it_outer) {
+  const double ss_r = block_sum_partials(partials);
+  const double ss_b = block_sum_partials(partials + NB);
+  if (threadIdx.x == 0) {
+    const T nr0 = (T)sqrt(ss_b), nres = (T)sqrt(ss_r);
+    // argmin_x.jl:33-37 -- the 0.1 factor is a Float64 literal
+    const double cand = jl_max(0.1 * (double)nres / (double)nr0, (double)(T(10) * eps_of<T>()));
+    const T tol = (it_outer < 3) ? (T)cand : (T)jl_min(cand, (double)st->tol_ref);
+    st->tol = tol;
+    st->tol_ref = tol;
+    st->nr0 = nr0;
+    st->ss = ss_r;
+    st->rr = (T)ss_r;
+    st->gamma = st->alpha = st->beta = T(0);
+    st->res_last = T(0);
+    st->iters = 0;
+    st->flag = -1;
+    st->done = 0;
+    st->it_outer = it_outer;
+    if (nr0 == T(0)) {            // cg.jl:51  -> x = zeros, flag -9, iter 0
+      st->flag = -9;
+      st->done = 1;
+    } else if (nres / nr0 <= tol) {  // cg.jl:73-76 -> flag 0, iter 1, relres 0
+      st->flag = 0;
+      st->done = 1;
+      st->iters = 1;
+    }
+    *host = *st;
+  }
+}
+template <typename T>
+void K<T>::cg_begin(hipStream_t s, double* partials, CgState<T>* st, CgState<T>* host, int it_outer, T*, long long) {
+  hipLaunchKernelGGL((k_cg_begin<T>), dim3(1), dim3(BLOCK), 0, s, partials, st, host, it_outer);
+  SIPX_HIP(hipGetLastError());
+}
+
+template <typename T>
+__global__ __launch_bounds__(BLOCK) void k_cg_fin_alpha(const double* __restrict__ partials, CgState<T>* st,
+                                                        CgState<T>* host, int iter) {
+  if (st->done) return;
+  const double pAp = block_sum_partials(partials);
+  if (threadIdx.x == 0) {
+    st->iters = iter;                       // lastIter, cg.jl:83
+    st->gamma = st->rr;                     // dot(r,z), cg.jl:86
+    const T alpha = st->gamma / (T)pAp;     // cg.jl:88
+    st->alpha = alpha;
+    if ((isinf(alpha) && alpha > T(0)) || alpha < T(0)) {  // alpha==Inf || alpha<0, cg.jl:91-93
+      st->flag = -2;
+      st->done = 1;
+      st->res_last = T(0);
+      *host = *st;
+    }
+  }
+}
+template <typename T>
+void K<T>::cg_fin_alpha(hipStream_t s, double* partials, CgState<T>* st, CgState<T>* host, int iter) {
+  hipLaunchKernelGGL((k_cg_fin_alpha<T>), dim3(1), dim3(BLOCK), 0, s, partials, st, host, iter);
+  SIPX_HIP(hipGetLastError());
+}
+
+// x += alpha p ; r -= alpha Ap ; partial ||r||^2   (cg.jl:95-100)
+template <typename T, int V>
+__global__ __launch_bounds__(BLOCK) void k_cg_update_xr(long long N, T* __restrict__ x, T* __restrict__ r,
+                                                        const T* __restrict__ p, const T* __restrict__ Ap,
+                                                        double* __restrict__ partials, const CgState<T>* __restrict__ st) {
+  if (st->done) return;
+  const T alpha = st->alpha;
+  const long long nvec = N / V;
+  double acc[1] = {0};
+  for (long long vi = (long long)blockIdx.x * BLOCK + threadIdx.x; vi < nvec; vi += (long long)NB * BLOCK) {
+    Vec<T, V> xv = ldv<T, V>(x + vi * V), rv = ldv<T, V>(r + vi * V);
+    const Vec<T, V> pv = ldv<T, V>(p + vi * V), av = ldv<T, V>(Ap + vi * V);
+#pragma unroll
+    for (int k = 0; k < V; ++k) {
+      xv.v[k] = xv.v[k] + alpha * pv.v[k];
+      rv.v[k] = rv.v[k] - alpha * av.v[k];
+      acc[0] += (double)rv.v[k] * (double)rv.v[k];
+    }
+    stv<T, V>(x + vi * V, xv);
+    stv<T, V>(r + vi * V, rv);
+  }
+  block_reduce_store<1>(acc, partials, 0);
+}
+template <typename T>
+void K<T>::cg_update_xr(hipStream_t s, long long N, T* x, T* r, const T* p, const T* Ap, double* partials,
+                        const CgState<T>* st) {
+  if (N % 4 == 0)
+    hipLaunchKernelGGL((k_cg_update_xr<T, 4>), dim3(NB), dim3(BLOCK), 0, s, N, x, r, p, Ap, partials, st);
+  else
+    hipLaunchKernelGGL((k_cg_update_xr<T, 1>), dim3(NB), dim3(BLOCK), 0, s, N, x, r, p, Ap, partials, st);
+  SIPX_HIP(hipGetLastError());
+}
+
+template <typename T>
+__global__ __launch_bounds__(BLOCK) void k_cg_fin_beta(const double* __restrict__ partials, CgState<T>* st,
+                                                       CgState<T>* host) {
+  if (st->done) return;
+  const double ss = block_sum_partials(partials);
+  if (threadIdx.x == 0) {
+    const T rr = (T)ss;
+    const T res = (T)sqrt(ss) / st->nr0;    // resvec[iter] = norm(r)/nr0, cg.jl:100
+    st->ss = ss;
+    st->res_last = res;
+    if (res <= st->tol) {                   // cg.jl:104-106
+      st->flag = 0;
+      st->done = 1;
+    } else {
+      st->beta = rr / st->gamma;            // dot(z,r)/gamma, cg.jl:110
+    }
+    st->rr = rr;
+    *host = *st;
+  }
+}
+template <typename T>
+void K<T>::cg_fin_beta(hipStream_t s, double* partials, CgState<T>* st, CgState<T>* host) {
+  hipLaunchKernelGGL((k_cg_fin_beta<T>), dim3(1), dim3(BLOCK), 0, s, partials, st, host);
+  SIPX_HIP(hipGetLastError());
+}
+
+// p = r + beta p   (axpby!, cg.jl:114)
+template <typename T, int V>
+__global__ __launch_bounds__(BLOCK) void k_cg_update_p(long long N, T* __restrict__ p, const T* __restrict__ r,
+                                                       const CgState<T>* __restrict__ st) {
+  if (st->done) return;
+  const T beta = st->beta;
+  const long long nvec = N / V;
+  for (long long vi = (long long)blockIdx.x * BLOCK + threadIdx.x; vi < nvec; vi += (long long)NB * BLOCK) {
+    Vec<T, V> pv = ldv<T, V>(p + vi * V);
+    const Vec<T, V> rv = ldv<T, V>(r + vi * V);
+#pragma unroll
+    for (int k = 0; k < V; ++k) pv.v[k] = rv.v[k] + beta * pv.v[k];
+    stv<T, V>(p + vi * V, pv);
+  }
+}
+template <typename T>
+void K<T>::cg_update_p(hipStream_t s, long long N, T* p, const T* r, const CgState<T>* st) {
+  if (N % 4 == 0)
+    hipLaunchKernelGGL((k_cg_update_p<T, 4>), dim3(NB), dim3(BLOCK), 0, s, N, p, r, st);
+  else
+    hipLaunchKernelGGL((k_cg_update_p<T, 1>), dim3(NB), dim3(BLOCK), 0, s, N, p, r, st);
+  SIPX_HIP(hipGetLastError());
+}
+
+// ---------------------------------------------------------------------------------------------
+// out[slot] = sum of the NB partials of each slot (one block per slot, fixed order)
+__global__ __launch_bounds__(BLOCK) void k_fin_sum(const double* __restrict__ partials, double* __restrict__ out_dev,
+                                                   double* __restrict__ out_host) {
+  const double s = block_sum_partials(partials + (long long)blockIdx.x * NB);
+  if (threadIdx.x == 0) {
+    if (out_dev) out_dev[blockIdx.x] = s;
+    if (out_host) out_host[blockIdx.x] = s;
+  }
+}
+template <typename T>
+void K<T>::fin_sum(hipStream_t s, const double* partials, int nslots, double* out_dev, double* out_host) {
+  hipLaunchKernelGGL(k_fin_sum, dim3(nslots), dim3(BLOCK), 0, s, partials, out_dev, out_host);
+  SIPX_HIP(hipGetLastError());
+}
+
+// explicit instantiation of the members defined in this file
+#define SIPX_INST(T)                                                                                                  \
+  template void K<T>::spmv(hipStream_t, const Grid&, long long, const T*, const CdsArgs&, const T*, T*);             \
+  template void K<T>::spmv_dot(hipStream_t, long long, const T*, const CdsArgs&, const T*, T*, double*,              \
+                               const CgState<T>*);                                                                    \
+  template void K<T>::resid(hipStream_t, long long, const T*, const CdsArgs&, const T*, const T*, T*, T*, T*, double*); \
+  template void K<T>::q_axpy(hipStream_t, long long, T*, const T*, T);                                               \
+  template void K<T>::gen_ata(hipStream_t, const Grid&, int, const int*, const T*, int, const long long*, T*);       \
+  template void K<T>::cg_begin(hipStream_t, double*, CgState<T>*, CgState<T>*, int, T*, long long);                  \
+  template void K<T>::cg_fin_alpha(hipStream_t, double*, CgState<T>*, CgState<T>*, int);                             \
+  template void K<T>::cg_update_xr(hipStream_t, long long, T*, T*, const T*, const T*, double*, const CgState<T>*);  \
+  template void K<T>::cg_fin_beta(hipStream_t, double*, CgState<T>*, CgState<T>*);                                   \
+  template void K<T>::cg_update_p(hipStream_t, long long, T*, const T*, const CgState<T>*);                          \
+  template void K<T>::fin_sum(hipStream_t, const double*, int, double*, double*);
+SIPX_INST(float)
+SIPX_INST(double)
+
+}  // namespace sipx

@@ -1,0 +1,567 @@
+// Per-set kernels of the PARSDMM iteration body: matrix-free difference stencils fused with
+// the y/l update, the proximal maps, the residual / Barzilai-Borwein / feasibility reductions.
+//
+// Replaces (reference file:line):
+//   rhs_compose                         src/rhs_compose.jl:24-36
+//   update_y_l (per set)                src/update_y_l.jl:36-101   (Blas_active=false formulas :64-78)
+//   l_hat + snapshots + 5 BB differences  src/PARSDMM.jl:164-180,192-206, src/adapt_rho_gamma.jl:41-53
+//   prox_l2s!, prox_l1!, project_bounds!, project_l1/l2/annulus (apply step)  src/prox_*.jl, src/projectors/*.jl
+//   obj / evol_x logging                src/PARSDMM.jl:140,145
+//
+// Data layout: every transform-domain vector (y_i, l_i, ...) of a difference operator is stored
+// PADDED to the grid: block q of the operator occupies [q*N, (q+1)*N) and element g of a block
+// sits at the grid point whose forward difference it is; the last hyper-plane along the
+// difference direction is a pad that is kept exactly zero.  Row r of the reference's matrix
+// maps monotonically onto the valid points, so index order (tie breaking) is preserved, every
+// access is 16-byte aligned and stencil neighbours are plain +-stride offsets.
+#include <stdexcept>
+#include <string>
+
+#include "sipx_device.h"
+
+namespace sipx {
+
+template <typename T>
+__device__ __forceinline__ T soft_thr(T v, T th) {
+  // sign(v) * max(abs(v) - th, 0)   (project_l1_Duchi!.jl:49, prox_l1!.jl:9)
+  T t = fabs(v) - th;
+  t = t > T(0) ? t : T(0);
+  return v > T(0) ? t : (v < T(0) ? -t : v);
+}
+
+template <typename T>
+struct ProxCtx {
+  int prox;
+  T plo, phi, rho, theta, scale, tau;
+  int fill;
+  long long idx_cut;
+};
+
+template <typename T>
+__device__ __forceinline__ ProxCtx<T> make_prox(int prox, T plo, T phi, T rho, const ProjScalars<T>* ps) {
+  ProxCtx<T> c;
+  c.prox = prox;
+  c.plo = plo;
+  c.phi = phi;
+  c.rho = rho;
+  c.theta = T(0);
+  c.scale = T(1);
+  c.tau = T(0);
+  c.fill = 0;
+  c.idx_cut = -1;
+  if (ps) {
+    c.theta = ps->theta;
+    c.scale = ps->scale;
+    c.fill = ps->fill;
+    c.tau = ps->tau;
+    c.idx_cut = ps->quota;
+  }
+  if (prox == PX_PROX_L1) c.theta = T(1) / phi;   // prox_l1!(x, constraint.max): threshold 1/rho
+  return c;
+}
+
+// One element of prox_i / P_i.  lb/ub: per-element bounds; m: distance-term centre; e: padded index.
+template <typename T>
+__device__ __forceinline__ T prox_apply(const ProxCtx<T>& c, T v, T lb, T ub, T m, long long e) {
+  switch (c.prox) {
+    case PX_BOUNDS: {                       // max(LB, min(x, UB))      project_bounds!.jl:9
+      T t = v < c.phi ? v : c.phi;
+      return c.plo > t ? c.plo : t;
+    }
+    case PX_BOUNDS_VEC: {                   // project_bounds!.jl:21-22
+      T t = v < ub ? v : ub;
+      return lb > t ? lb : t;
+    }
+    case PX_DIST:                           // (x*rho + m) / (rho + 1.0): Float64 division  prox_l2s!.jl:4
+      return (T)((double)(v * c.rho + m) / ((double)c.rho + 1.0));
+    case PX_L1:
+    case PX_PROX_L1:
+      return soft_thr(v, c.theta);
+    case PX_L2:
+    case PX_ANNULUS:                        // rmul!(x, sigma/nl2) or the constant fill  project_annulus!.jl:9-17
+      return c.fill ? c.scale : v * c.scale;
+    case PX_CARD: {                         // keep the k largest |v|, ties by lowest index
+      const T av = fabs(v);
+      return (av > c.tau || (av == c.tau && e <= c.idx_cut)) ? v : T(0);
+    }
+  }
+  return v;
+}
+
+// ---------------------------------------------------------------------------------------------
+// rhs = sum_i A_i'(rho_i y_i + l_i): every owned set in one pass, sets added in order
+// (rhs_compose.jl:24-31); algorithmic bytes (sum_i 2 M_i + N) * w.
+template <typename T, int V>
+__global__ __launch_bounds__(BLOCK) void k_rhs(Grid G, RhsArgs<T> a, T* __restrict__ rhs, int accumulate) {
+  const long long nvec = G.N / V;
+  for (long long vi = (long long)blockIdx.x * BLOCK + threadIdx.x; vi < nvec; vi += (long long)NB * BLOCK) {
+    const long long g = vi * V;
+    const Coord c = coords(G, g);
+    T out[V];
+    if (accumulate) {
+      const Vec<T, V> r0 = ldv<T, V>(rhs + g);
+#pragma unroll
+      for (int k = 0; k < V; ++k) out[k] = r0.v[k];
+    } else {
+#pragma unroll
+      for (int k = 0; k < V; ++k) out[k] = T(0);
+    }
+    for (int si = 0; si < a.nsets; ++si) {
+      const RhsSet<T>& S = a.s[si];
+      const T rho = S.rho;
+      T t[V];
+#pragma unroll
+      for (int k = 0; k < V; ++k) t[k] = T(0);
+      if (S.nblk == 0) {
+        const Vec<T, V> yv = ldv<T, V>(S.y + g), lv = ldv<T, V>(S.l + g);
+#pragma unroll
+        for (int k = 0; k < V; ++k) t[k] = rho * yv.v[k] + lv.v[k];
+      } else {
+        for (int q = 0; q < S.nblk; ++q) {
+          const T* yb = S.y + (long long)q * G.N;
+          const T* lb = S.l + (long long)q * G.N;
+          auto wv = [&](long long e) {
+            const Vec<T, V> yv = ldv<T, V>(yb + e), lv = ldv<T, V>(lb + e);
+            Vec<T, V> w;
+#pragma unroll
+            for (int k = 0; k < V; ++k) w.v[k] = rho * yv.v[k] + lv.v[k];
+            return w;
+          };
+          auto w1 = [&](long long e) { return rho * yb[e] + lb[e]; };
+          adj_dir_acc<T, V>(G, g, c, S.dir[q], S.ih[q], t, wv, w1);
+        }
+      }
+#pragma unroll
+      for (int k = 0; k < V; ++k) out[k] = out[k] + t[k];
+    }
+    Vec<T, V> o;
+#pragma unroll
+    for (int k = 0; k < V; ++k) o.v[k] = out[k];
+    stv<T, V>(rhs + g, o);
+  }
+}
+template <typename T>
+void K<T>::rhs_compose(hipStream_t s, const Grid& g, const RhsArgs<T>& a, T* rhs, int accumulate) {
+  if (g.n[0] % 4 == 0)
+    hipLaunchKernelGGL((k_rhs<T, 4>), dim3(NB), dim3(BLOCK), 0, s, g, a, rhs, accumulate);
+  else
+    hipLaunchKernelGGL((k_rhs<T, 1>), dim3(NB), dim3(BLOCK), 0, s, g, a, rhs, accumulate);
+  SIPX_HIP(hipGetLastError());
+}
+
+// ---------------------------------------------------------------------------------------------
+// The fused y/l update of one set (update_y_l.jl:36-101).
+template <typename T, int V>
+__global__ __launch_bounds__(BLOCK) void k_yl(Grid G, SetArgs<T> a, double* __restrict__ partials) {
+  double acc[YL_SLOTS];
+#pragma unroll
+  for (int k = 0; k < YL_SLOTS; ++k) acc[k] = 0;
+  const bool ident = a.nblk == 0;
+  const int nb = ident ? 1 : a.nblk;
+  const bool relax = !(a.gamma == T(1));
+  const T gam = a.gamma, omg = T(1) - a.gamma;
+  const ProxCtx<T> pc = make_prox<T>(a.prox, a.plo, a.phi, a.rho, a.ps);
+  const bool elementwise = (a.prox == PX_BOUNDS || a.prox == PX_BOUNDS_VEC || a.prox == PX_PROX_L1);
+  const bool feas = (a.flags & F_FEAS) && elementwise;
+  const bool first = (a.flags & F_FIRST) != 0;
+  const bool bb = (a.flags & F_BB) && !first;
+  const bool dist = a.prox == PX_DIST;
+  const long long nvec = G.N / V;
+  for (long long vi = (long long)blockIdx.x * BLOCK + threadIdx.x; vi < nvec; vi += (long long)NB * BLOCK) {
+    const long long g = vi * V;
+    const Coord c = coords(G, g);
+    const Vec<T, V> xc = ldv<T, V>(a.x + g);
+    for (int q = 0; q < nb; ++q) {
+      const long long e = (long long)q * G.N + g;
+      T s[V];
+      bool valid[V];
+      if (ident) {
+#pragma unroll
+        for (int k = 0; k < V; ++k) {
+          s[k] = xc.v[k];
+          valid[k] = true;
+        }
+      } else {
+        fwd_dir<T, V>(G, a.x, xc, g, c, a.dir[q], a.ih[q], s, valid);
+      }
+      const Vec<T, V> yv = ldv<T, V>(a.y + e), lv = ldv<T, V>(a.l + e);
+      Vec<T, V> vv = zerov<T, V>(), lbv = zerov<T, V>(), ubv = zerov<T, V>(), mv = zerov<T, V>();
+      if (a.vsrc) vv = ldv<T, V>(a.v + e);
+      if (a.prox == PX_BOUNDS_VEC) {
+        lbv = ldv<T, V>(a.lb + e);
+        ubv = ldv<T, V>(a.ub + e);
+      }
+      if (dist) mv = ldv<T, V>(a.m + g);
+      Vec<T, V> yn, ln, dyv, lh;
+#pragma unroll
+      for (int k = 0; k < V; ++k) {
+        const T yo = yv.v[k], lo = lv.v[k];
+        const T xh = relax ? (gam * s[k] + omg * yo) : s[k];           // update_y_l.jl:72
+        const T v = a.vsrc ? vv.v[k] : (xh - lo * a.rho1);              // :67 / :74
+        T y1 = prox_apply<T>(pc, v, lbv.v[k], ubv.v[k], mv.v[k], e + k);  // :68 / :75
+        if (!valid[k]) y1 = T(0);
+        const T rp = y1 - s[k];                                         // r_pri = -s + y   :69 / :76
+        const T l1 = relax ? (lo + a.rho * (y1 - xh)) : (lo + a.rho * rp);  // :70 / :77
+        yn.v[k] = y1;
+        ln.v[k] = l1;
+        dyv.v[k] = y1 - yo;                                             // x_hat = y - y_old  :82
+        lh.v[k] = lo + a.rho * (yo - s[k]);                             // l_hat = l_old + rho(-s + y_old)  PARSDMM.jl:173
+        acc[SL_RPRI] += (double)rp * (double)rp;
+        if (ident) acc[SL_DY] += (double)dyv.v[k] * (double)dyv.v[k];
+        if (feas && valid[k]) {                                         // update_y_l.jl:90-99
+          const T ps = prox_apply<T>(pc, s[k], lbv.v[k], ubv.v[k], T(0), e + k);
+          const T d = ps - s[k];
+          acc[SL_FE] += (double)d * (double)d;
+          acc[SL_SS] += (double)s[k] * (double)s[k];
+        }
+      }
+      if (dist) {                                                        // PARSDMM.jl:140,145
+        const Vec<T, V> xo = ldv<T, V>(a.xold + g);
+#pragma unroll
+        for (int k = 0; k < V; ++k) {
+          const T d = xc.v[k] - mv.v[k], ev = xo.v[k] - xc.v[k];
+          acc[SL_OBJ] += (double)d * (double)d;
+          acc[SL_EVO] += (double)ev * (double)ev;
+          acc[SL_XX] += (double)xc.v[k] * (double)xc.v[k];
+        }
+      }
+      if (bb) {                                                          // adapt_rho_gamma.jl:41-53
+        const Vec<T, V> a0 = ldv<T, V>(a.lh0 + e), b0 = ldv<T, V>(a.y0 + e), c0 = ldv<T, V>(a.s0 + e),
+                        d0 = ldv<T, V>(a.l0 + e);
+#pragma unroll
+        for (int k = 0; k < V; ++k) {
+          const T dlh = lh.v[k] - a0.v[k], dH = s[k] - c0.v[k], dl = ln.v[k] - d0.v[k], dG = -(yn.v[k] - b0.v[k]);
+          acc[SL_HL] += (double)dH * (double)dlh;
+          acc[SL_HH] += (double)dH * (double)dH;
+          acc[SL_LH] += (double)dlh * (double)dlh;
+          acc[SL_DL] += (double)dl * (double)dl;
+          acc[SL_GG] += (double)dG * (double)dG;
+          acc[SL_GL] += (double)dG * (double)dl;
+        }
+      }
+      if (bb || first) {                                                 // PARSDMM.jl:174-177, 200-203
+        Vec<T, V> sv;
+#pragma unroll
+        for (int k = 0; k < V; ++k) sv.v[k] = s[k];
+        stv<T, V>(a.lh0 + e, lh);
+        stv<T, V>(a.y0 + e, yn);
+        stv<T, V>(a.s0 + e, sv);
+        stv<T, V>(a.l0 + e, ln);
+      }
+      stv<T, V>(a.y + e, yn);
+      stv<T, V>(a.l + e, ln);
+      if (!ident) stv<T, V>(a.dy + e, dyv);
+    }
+  }
+  block_reduce_store<YL_SLOTS>(acc, partials, 0);
+}
+template <typename T>
+void K<T>::yl(hipStream_t s, const Grid& g, const SetArgs<T>& a, double* partials) {
+  if (g.n[0] % 4 == 0)
+    hipLaunchKernelGGL((k_yl<T, 4>), dim3(NB), dim3(BLOCK), 0, s, g, a, partials);
+  else
+    hipLaunchKernelGGL((k_yl<T, 1>), dim3(NB), dim3(BLOCK), 0, s, g, a, partials);
+  SIPX_HIP(hipGetLastError());
+}
+
+// First pass of the two-pass projectors (l1-ball, l2, annulus, cardinality): materialise
+// v = x_hat - l/rho (or v = s = A x for the feasibility estimate) and reduce ||v||_1, ||v||_2^2, max|v|.
+template <typename T, int V>
+__global__ __launch_bounds__(BLOCK) void k_yl_prep(Grid G, SetArgs<T> a, double* __restrict__ partials,
+                                                   T* __restrict__ maxpart, int v_is_s) {
+  double acc[2] = {0, 0};
+  T vmax = T(0);
+  const bool ident = a.nblk == 0;
+  const int nb = ident ? 1 : a.nblk;
+  const bool relax = !(a.gamma == T(1));
+  const T gam = a.gamma, omg = T(1) - a.gamma;
+  const long long nvec = G.N / V;
+  for (long long vi = (long long)blockIdx.x * BLOCK + threadIdx.x; vi < nvec; vi += (long long)NB * BLOCK) {
+    const long long g = vi * V;
+    const Coord c = coords(G, g);
+    const Vec<T, V> xc = ldv<T, V>(a.x + g);
+    for (int q = 0; q < nb; ++q) {
+      const long long e = (long long)q * G.N + g;
+      T s[V];
+      bool valid[V];
+      if (ident) {
+#pragma unroll
+        for (int k = 0; k < V; ++k) {
+          s[k] = xc.v[k];
+          valid[k] = true;
+        }
+      } else {
+        fwd_dir<T, V>(G, a.x, xc, g, c, a.dir[q], a.ih[q], s, valid);
+      }
+      Vec<T, V> out;
+      if (v_is_s) {
+#pragma unroll
+        for (int k = 0; k < V; ++k) out.v[k] = s[k];
+      } else {
+        const Vec<T, V> yv = ldv<T, V>(a.y + e), lv = ldv<T, V>(a.l + e);
+#pragma unroll
+        for (int k = 0; k < V; ++k) {
+          const T xh = relax ? (gam * s[k] + omg * yv.v[k]) : s[k];
+          out.v[k] = valid[k] ? (xh - lv.v[k] * a.rho1) : T(0);
+        }
+      }
+#pragma unroll
+      for (int k = 0; k < V; ++k) {
+        const T av = fabs(out.v[k]);
+        acc[0] += (double)av;
+        acc[1] += (double)out.v[k] * (double)out.v[k];
+        vmax = av > vmax ? av : vmax;
+      }
+      stv<T, V>(a.v + e, out);
+    }
+  }
+  block_reduce_store<2>(acc, partials, 0);
+  __shared__ T smax[BLOCK / 64];
+  vmax = wave_max<T>(vmax);
+  if ((threadIdx.x & 63) == 0) smax[threadIdx.x >> 6] = vmax;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    T m = smax[0];
+    for (int i = 1; i < BLOCK / 64; ++i) m = smax[i] > m ? smax[i] : m;
+    maxpart[blockIdx.x] = m;
+  }
+}
+template <typename T>
+void K<T>::yl_prep(hipStream_t s, const Grid& g, const SetArgs<T>& a, double* partials, T* maxpart, int v_is_s) {
+  if (g.n[0] % 4 == 0)
+    hipLaunchKernelGGL((k_yl_prep<T, 4>), dim3(NB), dim3(BLOCK), 0, s, g, a, partials, maxpart, v_is_s);
+  else
+    hipLaunchKernelGGL((k_yl_prep<T, 1>), dim3(NB), dim3(BLOCK), 0, s, g, a, partials, maxpart, v_is_s);
+  SIPX_HIP(hipGetLastError());
+}
+
+// ||A'(y - y_old)||^2 for difference operators (r_dual, update_y_l.jl:84).
+template <typename T, int V>
+__global__ __launch_bounds__(BLOCK) void k_adj_norm(Grid G, SetArgs<T> a, double* __restrict__ partials) {
+  double acc[1] = {0};
+  const long long nvec = G.N / V;
+  for (long long vi = (long long)blockIdx.x * BLOCK + threadIdx.x; vi < nvec; vi += (long long)NB * BLOCK) {
+    const long long g = vi * V;
+    const Coord c = coords(G, g);
+    T t[V];
+#pragma unroll
+    for (int k = 0; k < V; ++k) t[k] = T(0);
+    for (int q = 0; q < a.nblk; ++q) {
+      const T* wb = a.dy + (long long)q * G.N;
+      auto wv = [&](long long e) { return ldv<T, V>(wb + e); };
+      auto w1 = [&](long long e) { return wb[e]; };
+      adj_dir_acc<T, V>(G, g, c, a.dir[q], a.ih[q], t, wv, w1);
+    }
+#pragma unroll
+    for (int k = 0; k < V; ++k) acc[0] += (double)t[k] * (double)t[k];
+  }
+  block_reduce_store<1>(acc, partials, 0);
+}
+template <typename T>
+void K<T>::adj_norm(hipStream_t s, const Grid& g, const SetArgs<T>& a, double* partials) {
+  if (g.n[0] % 4 == 0)
+    hipLaunchKernelGGL((k_adj_norm<T, 4>), dim3(NB), dim3(BLOCK), 0, s, g, a, partials);
+  else
+    hipLaunchKernelGGL((k_adj_norm<T, 1>), dim3(NB), dim3(BLOCK), 0, s, g, a, partials);
+  SIPX_HIP(hipGetLastError());
+}
+
+// ---------------------------------------------------------------------------------------------
+// Plain operator applications (padded output / padded input): s = A x, t = A' v.
+struct OpArgs {
+  int nblk;
+  int dir[3];
+};
+template <typename T, int V>
+__global__ __launch_bounds__(BLOCK) void k_fwd(Grid G, OpArgs o, T ih0, T ih1, T ih2, const T* __restrict__ x,
+                                               T* __restrict__ out) {
+  const T ihs[3] = {ih0, ih1, ih2};
+  const long long nvec = G.N / V;
+  for (long long vi = (long long)blockIdx.x * BLOCK + threadIdx.x; vi < nvec; vi += (long long)NB * BLOCK) {
+    const long long g = vi * V;
+    const Coord c = coords(G, g);
+    const Vec<T, V> xc = ldv<T, V>(x + g);
+    if (o.nblk == 0) {
+      stv<T, V>(out + g, xc);
+      continue;
+    }
+    for (int q = 0; q < o.nblk; ++q) {
+      T s[V];
+      bool valid[V];
+      fwd_dir<T, V>(G, x, xc, g, c, o.dir[q], ihs[q], s, valid);
+      Vec<T, V> sv;
+#pragma unroll
+      for (int k = 0; k < V; ++k) sv.v[k] = s[k];
+      stv<T, V>(out + (long long)q * G.N + g, sv);
+    }
+  }
+}
+template <typename T>
+void K<T>::fwd(hipStream_t s, const Grid& g, int nblk, const int* dir, const T* ih, const T* x, T* out) {
+  OpArgs o;
+  o.nblk = nblk;
+  for (int q = 0; q < 3; ++q) o.dir[q] = q < nblk ? dir[q] : 0;
+  const T i0 = nblk > 0 ? ih[0] : T(0), i1 = nblk > 1 ? ih[1] : T(0), i2 = nblk > 2 ? ih[2] : T(0);
+  if (g.n[0] % 4 == 0)
+    hipLaunchKernelGGL((k_fwd<T, 4>), dim3(NB), dim3(BLOCK), 0, s, g, o, i0, i1, i2, x, out);
+  else
+    hipLaunchKernelGGL((k_fwd<T, 1>), dim3(NB), dim3(BLOCK), 0, s, g, o, i0, i1, i2, x, out);
+  SIPX_HIP(hipGetLastError());
+}
+
+template <typename T, int V>
+__global__ __launch_bounds__(BLOCK) void k_adj(Grid G, OpArgs o, T ih0, T ih1, T ih2, const T* __restrict__ v,
+                                               T* __restrict__ out) {
+  const T ihs[3] = {ih0, ih1, ih2};
+  const long long nvec = G.N / V;
+  for (long long vi = (long long)blockIdx.x * BLOCK + threadIdx.x; vi < nvec; vi += (long long)NB * BLOCK) {
+    const long long g = vi * V;
+    const Coord c = coords(G, g);
+    if (o.nblk == 0) {
+      stv<T, V>(out + g, ldv<T, V>(v + g));
+      continue;
+    }
+    T t[V];
+#pragma unroll
+    for (int k = 0; k < V; ++k) t[k] = T(0);
+    for (int q = 0; q < o.nblk; ++q) {
+      const T* wb = v + (long long)q * G.N;
+      auto wv = [&](long long e) { return ldv<T, V>(wb + e); };
+      auto w1 = [&](long long e) { return wb[e]; };
+      adj_dir_acc<T, V>(G, g, c, o.dir[q], ihs[q], t, wv, w1);
+    }
+    Vec<T, V> tv;
+#pragma unroll
+    for (int k = 0; k < V; ++k) tv.v[k] = t[k];
+    stv<T, V>(out + g, tv);
+  }
+}
+template <typename T>
+void K<T>::adj(hipStream_t s, const Grid& g, int nblk, const int* dir, const T* ih, const T* v, T* out) {
+  OpArgs o;
+  o.nblk = nblk;
+  for (int q = 0; q < 3; ++q) o.dir[q] = q < nblk ? dir[q] : 0;
+  const T i0 = nblk > 0 ? ih[0] : T(0), i1 = nblk > 1 ? ih[1] : T(0), i2 = nblk > 2 ? ih[2] : T(0);
+  if (g.n[0] % 4 == 0)
+    hipLaunchKernelGGL((k_adj<T, 4>), dim3(NB), dim3(BLOCK), 0, s, g, o, i0, i1, i2, v, out);
+  else
+    hipLaunchKernelGGL((k_adj<T, 1>), dim3(NB), dim3(BLOCK), 0, s, g, o, i0, i1, i2, v, out);
+  SIPX_HIP(hipGetLastError());
+}
+
+// ---------------------------------------------------------------------------------------------
+// ||P(v) - v||^2 and ||v||^2 over a padded vector (set feasibility, update_y_l.jl:92-94,
+// PARSDMM_initialize.jl:98) and the in-place application v = P(v).  Pads (v == 0 by construction,
+// flagged through `valid`) are skipped.
+template <typename T>
+struct ProjArgs {
+  int nblk;
+  int dir[3];
+  int prox;
+  T plo, phi;
+  const T *lb, *ub;
+  const ProjScalars<T>* ps;
+};
+template <typename T>
+__device__ __forceinline__ bool is_valid(const Grid& G, const ProjArgs<T>& a, long long e) {
+  if (a.nblk == 0) return true;
+  const long long q = e / G.N;
+  const Coord c = coords(G, e - q * G.N);
+  const int dir = a.dir[q];
+  return coord_of(c, dir) < G.n[dir] - 1;
+}
+template <typename T, int APPLY>
+__global__ __launch_bounds__(BLOCK) void k_proj(Grid G, ProjArgs<T> a, long long len, T* __restrict__ v,
+                                                double* __restrict__ partials) {
+  double acc[2] = {0, 0};
+  const ProxCtx<T> pc = make_prox<T>(a.prox, a.plo, a.phi, T(0), a.ps);
+  for (long long e = (long long)blockIdx.x * BLOCK + threadIdx.x; e < len; e += (long long)NB * BLOCK) {
+    if (!is_valid<T>(G, a, e)) continue;
+    const T x = v[e];
+    const T lb = a.prox == PX_BOUNDS_VEC ? a.lb[e] : T(0), ub = a.prox == PX_BOUNDS_VEC ? a.ub[e] : T(0);
+    const T p = prox_apply<T>(pc, x, lb, ub, T(0), e);
+    if (APPLY) {
+      v[e] = p;
+    } else {
+      const T d = p - x;
+      acc[0] += (double)d * (double)d;
+      acc[1] += (double)x * (double)x;
+    }
+  }
+  if (!APPLY) block_reduce_store<2>(acc, partials, 0);
+}
+
+// ---------------------------------------------------------------------------------------------
+// obj / evol_x reductions when no distance-term kernel carries them (feasibility_only).
+template <typename T, int V>
+__global__ __launch_bounds__(BLOCK) void k_log3(long long N, const T* __restrict__ x, const T* __restrict__ m,
+                                                const T* __restrict__ xold, double* __restrict__ partials) {
+  double acc[3] = {0, 0, 0};
+  const long long nvec = N / V;
+  for (long long vi = (long long)blockIdx.x * BLOCK + threadIdx.x; vi < nvec; vi += (long long)NB * BLOCK) {
+    const Vec<T, V> xv = ldv<T, V>(x + vi * V), mv = ldv<T, V>(m + vi * V), ov = ldv<T, V>(xold + vi * V);
+#pragma unroll
+    for (int k = 0; k < V; ++k) {
+      const T d = xv.v[k] - mv.v[k], e = ov.v[k] - xv.v[k];
+      acc[0] += (double)d * (double)d;
+      acc[1] += (double)e * (double)e;
+      acc[2] += (double)xv.v[k] * (double)xv.v[k];
+    }
+  }
+  block_reduce_store<3>(acc, partials, SL_OBJ);
+}
+template <typename T>
+void K<T>::log3(hipStream_t s, long long N, const T* x, const T* m, const T* xold, double* partials) {
+  if (N % 4 == 0)
+    hipLaunchKernelGGL((k_log3<T, 4>), dim3(NB), dim3(BLOCK), 0, s, N, x, m, xold, partials);
+  else
+    hipLaunchKernelGGL((k_log3<T, 1>), dim3(NB), dim3(BLOCK), 0, s, N, x, m, xold, partials);
+  SIPX_HIP(hipGetLastError());
+}
+
+template <typename T>
+static ProjArgs<T> make_proj_args(int nblk, const int* dir, int prox, T plo, T phi, const T* lb, const T* ub,
+                                  const ProjScalars<T>* ps) {
+  ProjArgs<T> a;
+  a.nblk = nblk;
+  for (int q = 0; q < 3; ++q) a.dir[q] = (dir && q < nblk) ? dir[q] : 0;
+  a.prox = prox;
+  a.plo = plo;
+  a.phi = phi;
+  a.lb = lb;
+  a.ub = ub;
+  a.ps = ps;
+  return a;
+}
+
+template <typename T>
+void proj_dist_grid(hipStream_t s, const Grid& g, int nblk, const int* dir, long long len, const T* v, int prox, T plo,
+                    T phi, const T* lb, const T* ub, const ProjScalars<T>* ps, double* partials) {
+  ProjArgs<T> a = make_proj_args<T>(nblk, dir, prox, plo, phi, lb, ub, ps);
+  hipLaunchKernelGGL((k_proj<T, 0>), dim3(NB), dim3(BLOCK), 0, s, g, a, len, const_cast<T*>(v), partials);
+  SIPX_HIP(hipGetLastError());
+}
+template <typename T>
+void proj_apply_grid(hipStream_t s, const Grid& g, int nblk, const int* dir, long long len, T* v, int prox, T plo,
+                     T phi, const T* lb, const T* ub, const ProjScalars<T>* ps) {
+  ProjArgs<T> a = make_proj_args<T>(nblk, dir, prox, plo, phi, lb, ub, ps);
+  hipLaunchKernelGGL((k_proj<T, 1>), dim3(NB), dim3(BLOCK), 0, s, g, a, len, v, (double*)nullptr);
+  SIPX_HIP(hipGetLastError());
+}
+
+#define SIPX_INST(T)                                                                                              \
+  template void K<T>::rhs_compose(hipStream_t, const Grid&, const RhsArgs<T>&, T*, int);                         \
+  template void K<T>::yl(hipStream_t, const Grid&, const SetArgs<T>&, double*);                                  \
+  template void K<T>::yl_prep(hipStream_t, const Grid&, const SetArgs<T>&, double*, T*, int);                    \
+  template void K<T>::adj_norm(hipStream_t, const Grid&, const SetArgs<T>&, double*);                            \
+  template void K<T>::fwd(hipStream_t, const Grid&, int, const int*, const T*, const T*, T*);                    \
+  template void K<T>::adj(hipStream_t, const Grid&, int, const int*, const T*, const T*, T*);                    \
+  template void K<T>::log3(hipStream_t, long long, const T*, const T*, const T*, double*);                       \
+  template void proj_dist_grid<T>(hipStream_t, const Grid&, int, const int*, long long, const T*, int, T, T,     \
+                                  const T*, const T*, const ProjScalars<T>*, double*);                           \
+  template void proj_apply_grid<T>(hipStream_t, const Grid&, int, const int*, long long, T*, int, T, T, const T*, \
+                                   const T*, const ProjScalars<T>*);
+SIPX_INST(float)
+SIPX_INST(double)
+
+}  // namespace sipx

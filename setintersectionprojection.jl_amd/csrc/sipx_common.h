@@ -1,0 +1,151 @@
+// Shared declarations between the HIP kernels (kernels_*.hip) and the host engine (engine.cpp).
+// gfx950 only.  All kernels are memory-bound streaming passes: 16 B per lane vector accesses,
+// grid-stride over a fixed grid, float64 block partials -> deterministic second-stage sum.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace sipx {
+
+constexpr int BLOCK = 256;        // 4 waves of 64
+constexpr int NB = 1024;          // fixed grid of every streaming/reduction kernel (4 blocks per CU)
+constexpr int MAXD = 32;          // CDS bands held in kernel arguments
+constexpr int MAX_SETS = 16;      // sets fused in one rhs_compose launch
+constexpr int YL_SLOTS = 13;      // reductions produced by one y/l-update launch
+constexpr int L1_BINS = 2048;     // histogram bins of the l1-ball threshold search
+
+// reduction slots of k_yl (per set)
+enum { SL_RPRI = 0, SL_DY = 1, SL_HL = 2, SL_HH = 3, SL_LH = 4, SL_DL = 5, SL_GG = 6, SL_GL = 7,
+       SL_FE = 8, SL_SS = 9, SL_OBJ = 10, SL_EVO = 11, SL_XX = 12 };
+
+enum { F_FEAS = 1, F_BB = 2, F_FIRST = 4 };
+
+// internal prox kinds (public SIPX_PROJ_* plus the distance term)
+enum { PX_BOUNDS = 0, PX_BOUNDS_VEC = 1, PX_L1 = 2, PX_L2 = 3, PX_ANNULUS = 4, PX_CARD = 5, PX_PROX_L1 = 6,
+       PX_DIST = 100 };
+
+struct Grid {
+  long long n[3];     // n1 (fastest), n2, n3 (1 for 2-D)
+  long long N;        // n1*n2*n3
+  long long st[3];    // strides 1, n1, n1*n2
+};
+
+struct CdsArgs {
+  int d;
+  long long off[MAXD];
+};
+
+// Scalars of the non-elementwise projectors, produced on the device and consumed by k_yl.
+template <typename T>
+struct ProjScalars {
+  double asum;        // ||v||_1
+  double sumsq;       // ||v||_2^2
+  T vmax;             // max |v|
+  int need;           // 1: outside the set, threshold/scale below is active
+  T theta;            // l1: soft threshold
+  T scale;            // l2 / annulus: multiplier
+  int fill;           // annulus zero-vector case: fill with `scale`
+  // l1 search state
+  int bin;            // bracket bin
+  double s_above;     // sum of |v| in bins above the bracket
+  long long c_above;  // their count
+  double lo, width;   // bracket lower edge and bin width
+  unsigned long long n_compact;
+  // cardinality
+  T tau;              // k-th largest magnitude
+  long long quota;    // entries equal to tau are kept iff their padded index <= quota (idx cut)
+};
+
+template <typename T>
+struct SetArgs {
+  T *y, *l, *dy, *lh0, *y0, *s0, *l0;   // per-set state, padded layout nblk*N
+  T* v;                                 // scratch (v = x_hat - l/rho) for two-pass projectors
+  const T *x, *m, *xold, *lb, *ub;
+  int nblk;
+  int dir[3];
+  T ih[3];
+  T rho, rho1, gamma;
+  int prox;
+  T plo, phi;
+  const ProjScalars<T>* ps;
+  int flags;
+  int vsrc;                             // 1: read v from scratch instead of recomputing it
+};
+
+template <typename T>
+struct RhsSet {
+  const T *y, *l;
+  T rho;
+  int nblk;
+  int dir[3];
+  T ih[3];
+};
+template <typename T>
+struct RhsArgs {
+  int nsets;
+  RhsSet<T> s[MAX_SETS];
+};
+
+// State of one CG solve, device resident (mirrored to pinned host memory by the scalar kernels).
+template <typename T>
+struct CgState {
+  double ss;        // float64 sum ||r||^2
+  T rr;             // TF(ss)  == dot(r,z) of the reference (z aliases r)
+  T gamma, alpha, beta;
+  T nr0, tol, res_last;
+  int done, flag, iters;
+  T tol_ref;        // x_solve_tol_ref chain (argmin_x.jl:33-37)
+  int it_outer;
+};
+
+// ---- launchers (explicitly instantiated for float and double in the .hip files) ----
+template <typename T>
+struct K {
+  // CDS
+  static void spmv(hipStream_t s, const Grid& g, long long N, const T* R, const CdsArgs& a, const T* x, T* y);
+  static void spmv_dot(hipStream_t s, long long N, const T* R, const CdsArgs& a, const T* p, T* Ap, double* partials,
+                       const CgState<T>* st);
+  static void resid(hipStream_t s, long long N, const T* R, const CdsArgs& a, const T* x, const T* b, T* r, T* p,
+                    T* xold, double* partials);
+  static void q_axpy(hipStream_t s, long long N, T* Qband, const T* Aband, T alpha);
+  static void gen_ata(hipStream_t s, const Grid& g, int nblk, const int* dir, const T* ih, int nband,
+                      const long long* offs, T* R);
+  // CG
+  static void cg_begin(hipStream_t s, double* partials, CgState<T>* st, CgState<T>* host, int it_outer, T* x, long long N);
+  static void cg_fin_alpha(hipStream_t s, double* partials, CgState<T>* st, CgState<T>* host, int iter);
+  static void cg_update_xr(hipStream_t s, long long N, T* x, T* r, const T* p, const T* Ap, double* partials,
+                           const CgState<T>* st);
+  static void cg_fin_beta(hipStream_t s, double* partials, CgState<T>* st, CgState<T>* host);
+  static void cg_update_p(hipStream_t s, long long N, T* p, const T* r, const CgState<T>* st);
+  // sets
+  static void rhs_compose(hipStream_t s, const Grid& g, const RhsArgs<T>& a, T* rhs, int accumulate);
+  static void yl(hipStream_t s, const Grid& g, const SetArgs<T>& a, double* partials);
+  static void yl_prep(hipStream_t s, const Grid& g, const SetArgs<T>& a, double* partials, T* maxpart, int v_is_s);
+  static void adj_norm(hipStream_t s, const Grid& g, const SetArgs<T>& a, double* partials);
+  static void fwd(hipStream_t s, const Grid& g, int nblk, const int* dir, const T* ih, const T* x, T* out);
+  static void adj(hipStream_t s, const Grid& g, int nblk, const int* dir, const T* ih, const T* v, T* out);
+  static void log3(hipStream_t s, long long N, const T* x, const T* m, const T* xold, double* partials);
+  static void fin_sum(hipStream_t s, const double* partials, int nslots, double* out_dev, double* out_host);
+  // projector scalar machinery (l1 / l2 / annulus / cardinality)
+  static void ps_reduce(hipStream_t s, long long len, const T* v, double* partials, T* maxpart);
+  static void ps_finish(hipStream_t s, const double* partials, const T* maxpart, ProjScalars<T>* ps, int prox, T pmin,
+                        T pmax, long long true_len);
+  static void l1_theta(hipStream_t s, long long len, const T* v, ProjScalars<T>* ps, T radius,
+                       unsigned long long* hist_cnt, double* hist_sum, T* compact);
+};
+
+// ||P(v)-v||^2, ||v||^2 (slots 0,1) and v = P(v) over a padded vector (pads skipped)
+template <typename T>
+void proj_dist_grid(hipStream_t s, const Grid& g, int nblk, const int* dir, long long len, const T* v, int prox, T plo,
+                    T phi, const T* lb, const T* ub, const ProjScalars<T>* ps, double* partials);
+template <typename T>
+void proj_apply_grid(hipStream_t s, const Grid& g, int nblk, const int* dir, long long len, T* v, int prox, T plo,
+                     T phi, const T* lb, const T* ub, const ProjScalars<T>* ps);
+
+#define SIPX_HIP(expr)                                                                       \
+  do {                                                                                       \
+    hipError_t _e = (expr);                                                                  \
+    if (_e != hipSuccess) throw std::runtime_error(std::string(#expr) + ": " + hipGetErrorString(_e)); \
+  } while (0)
+
+}  // namespace sipx

@@ -1,0 +1,175 @@
+// Device-side helpers shared by the kernel translation units (gfx950, wave64).
+#pragma once
+#include "sipx_common.h"
+
+namespace sipx {
+
+template <typename T, int V>
+struct alignas(sizeof(T) * V) Vec {
+  T v[V];
+};
+
+template <typename T, int V>
+__device__ __forceinline__ Vec<T, V> ldv(const T* p) {
+  return *reinterpret_cast<const Vec<T, V>*>(p);
+}
+template <typename T, int V>
+__device__ __forceinline__ void stv(T* p, const Vec<T, V>& x) {
+  *reinterpret_cast<Vec<T, V>*>(p) = x;
+}
+template <typename T, int V>
+__device__ __forceinline__ Vec<T, V> zerov() {
+  Vec<T, V> z;
+#pragma unroll
+  for (int k = 0; k < V; ++k) z.v[k] = T(0);
+  return z;
+}
+
+// 64-lane butterfly-free reduction (fixed order => deterministic).
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+  return v;
+}
+template <typename T>
+__device__ __forceinline__ T wave_max(T v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    T w = __shfl_down(v, o, 64);
+    v = w > v ? w : v;
+  }
+  return v;
+}
+
+// Block partials: partials[(slot0+k)*NB + blockIdx.x] = sum over the block of acc[k].
+template <int K>
+__device__ __forceinline__ void block_reduce_store(double (&acc)[K], double* __restrict__ partials, int slot0) {
+  __shared__ double sm[K][BLOCK / 64];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+#pragma unroll
+  for (int k = 0; k < K; ++k) {
+    double v = wave_sum(acc[k]);
+    if (lane == 0) sm[k][w] = v;
+  }
+  __syncthreads();
+  if (threadIdx.x < K) {
+    double s = 0;
+#pragma unroll
+    for (int i = 0; i < BLOCK / 64; ++i) s += sm[threadIdx.x][i];
+    partials[(long long)(slot0 + threadIdx.x) * NB + blockIdx.x] = s;
+  }
+}
+
+// Sum of the NB partials of one slot by one 256-thread block (fixed order).
+__device__ __forceinline__ double block_sum_partials(const double* __restrict__ p) {
+  __shared__ double sm[BLOCK / 64];
+  double v = 0;
+  for (int i = threadIdx.x; i < NB; i += BLOCK) v += p[i];
+  v = wave_sum(v);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = v;
+  __syncthreads();
+  double s = 0;
+#pragma unroll
+  for (int i = 0; i < BLOCK / 64; ++i) s += sm[i];
+  return s;
+}
+
+template <typename T>
+__device__ __forceinline__ T eps_of();
+template <>
+__device__ __forceinline__ float eps_of<float>() { return 1.1920928955078125e-07f; }
+template <>
+__device__ __forceinline__ double eps_of<double>() { return 2.220446049250313e-16; }
+
+// Julia max/min: NaN-propagating.
+__device__ __forceinline__ double jl_max(double a, double b) { return (a != a || b != b) ? (a + b) : (a > b ? a : b); }
+__device__ __forceinline__ double jl_min(double a, double b) { return (a != a || b != b) ? (a + b) : (a < b ? a : b); }
+
+struct Coord {
+  int i, j, k;
+};
+// Coordinates of linear index g (column-major, dim 1 fastest).
+__device__ __forceinline__ Coord coords(const Grid& G, long long g) {
+  Coord c;
+  if (G.N < (1ll << 31)) {
+    unsigned u = (unsigned)g, n1 = (unsigned)G.n[0], n2 = (unsigned)G.n[1];
+    unsigned jk = u / n1;
+    c.i = (int)(u - jk * n1);
+    unsigned k = jk / n2;
+    c.j = (int)(jk - k * n2);
+    c.k = (int)k;
+  } else {
+    long long jk = g / G.n[0];
+    c.i = (int)(g - jk * G.n[0]);
+    long long k = jk / G.n[1];
+    c.j = (int)(jk - k * G.n[1]);
+    c.k = (int)k;
+  }
+  return c;
+}
+__device__ __forceinline__ int coord_of(const Coord& c, int dir) { return dir == 0 ? c.i : (dir == 1 ? c.j : c.k); }
+
+// Forward difference along `dir` at the V consecutive points g..g+V-1 (same line):
+// s = (-ih)*x[g] + ih*x[g+stride], the two products of a CSC row in column order
+// (reference get_discrete_Grad.jl:22-23,58-60 + SparseArrays mul!).  Points on the last
+// hyper-plane along `dir` are pads of the padded layout: valid=false, s=0.
+template <typename T, int V>
+__device__ __forceinline__ void fwd_dir(const Grid& G, const T* __restrict__ x, const Vec<T, V>& xc, long long g,
+                                        const Coord& c, int dir, T ih, T (&s)[V], bool (&valid)[V]) {
+  const T nih = -ih;
+  if (dir == 0) {
+    T xn[V];
+#pragma unroll
+    for (int k = 0; k < V - 1; ++k) xn[k] = xc.v[k + 1];
+    xn[V - 1] = (c.i + V < G.n[0]) ? x[g + V] : T(0);
+#pragma unroll
+    for (int k = 0; k < V; ++k) {
+      valid[k] = (c.i + k < G.n[0] - 1);
+      s[k] = valid[k] ? (nih * xc.v[k] + ih * xn[k]) : T(0);
+    }
+  } else {
+    const bool ok = coord_of(c, dir) < G.n[dir] - 1;
+    Vec<T, V> xn = ok ? ldv<T, V>(x + g + G.st[dir]) : zerov<T, V>();
+#pragma unroll
+    for (int k = 0; k < V; ++k) {
+      valid[k] = ok;
+      s[k] = ok ? (nih * xc.v[k] + ih * xn.v[k]) : T(0);
+    }
+  }
+}
+
+// Adjoint of the forward difference along `dir`, accumulated into t[] at grid points g..g+V-1:
+// t += ih*w[g-stride] (if that row exists) ; t += (-ih)*w[g] (if row g exists) -- a CSC column
+// of D in ascending row order (SparseArrays mul!(tmp, A', v)).  W(e) loads the V values of w
+// at padded index e; W1(e) loads one.
+template <typename T, int V, typename WV, typename W1>
+__device__ __forceinline__ void adj_dir_acc(const Grid& G, long long g, const Coord& c, int dir, T ih, T (&t)[V],
+                                            WV wv, W1 w1) {
+  const T nih = -ih;
+  Vec<T, V> wc = wv(g);
+  if (dir == 0) {
+    T wp[V];
+    wp[0] = (c.i > 0) ? w1(g - 1) : T(0);
+#pragma unroll
+    for (int k = 1; k < V; ++k) wp[k] = wc.v[k - 1];
+#pragma unroll
+    for (int k = 0; k < V; ++k) {
+      if (c.i + k > 0) t[k] = t[k] + ih * wp[k];
+      if (c.i + k < G.n[0] - 1) t[k] = t[k] + nih * wc.v[k];
+    }
+  } else {
+    const int cc = coord_of(c, dir);
+    if (cc > 0) {
+      Vec<T, V> wp = wv(g - G.st[dir]);
+#pragma unroll
+      for (int k = 0; k < V; ++k) t[k] = t[k] + ih * wp.v[k];
+    }
+    if (cc < G.n[dir] - 1) {
+#pragma unroll
+      for (int k = 0; k < V; ++k) t[k] = t[k] + nih * wc.v[k];
+    }
+  }
+}
+
+}  // namespace sipx

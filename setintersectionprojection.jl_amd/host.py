@@ -1,0 +1,571 @@
+"""Host-side mirror of the reference's interface for the PARSDMM path, over the C ABI of
+libsipx.so (include/sipx.h).  Same names, argument meaning and error behaviour as
+
+    setup_constraints(constraint, comp_grid, TF)              src/setup_constraints.jl:17-102
+    PARSDMM_precompute_distribute(TD_OP, set_Prop, grid, opt) src/PARSDMM_precompute_distribute.jl:6-77
+    PARSDMM(m, AtA, TD_OP, set_Prop, P_sub, comp_grid, options[, x, l, y]) -> (x, log, l, y)
+                                                              src/PARSDMM.jl:25-35,257
+
+so that the parity tests read like the reference's own.  What differs, by design: TD_OP[i] is
+a matrix-free operator DESCRIPTOR (TDOperator) instead of a SparseMatrixCSC and P_sub[i] is a
+projector DESCRIPTOR (Projector) instead of an opaque closure -- both still behave like the
+originals (``A @ x``, ``A.T @ v``, ``P(v)`` run the device kernels).  Nothing here computes on
+the CPU; without libsipx.so or without a GPU every call raises SipxError.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from dataclasses import dataclass, field
+from typing import Any, List, Optional, Sequence, Tuple
+
+import numpy as np
+
+LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "libsipx.so")
+
+# every entry point declared in include/sipx.h
+EXPORTED_SYMBOLS = [
+    "sipx_last_error", "sipx_create", "sipx_destroy", "sipx_add_set", "sipx_set_rows", "sipx_num_terms",
+    "sipx_finalize", "sipx_rhs_compose", "sipx_argmin_x", "sipx_update_y_l", "sipx_log_scalars",
+    "sipx_adapt_rho_gamma", "sipx_q_update", "sipx_download", "sipx_parsdmm", "sipx_cds_spmv",
+    "sipx_apply_op", "sipx_apply_op_adj", "sipx_project", "sipx_get_Q", "sipx_time_spmv", "sipx_stream",
+    "sipx_dev_rhs", "sipx_dev_x", "sipx_set_owned",
+]
+
+SIPX_F32, SIPX_F64 = 0, 1
+OPS = {"identity": 0, "D_x": 1, "D_y": 2, "D_z": 3, "TV": 4, "D2D": 4, "D3D": 4}
+PROJ = {"bounds": 0, "bounds_vec": 1, "l1": 2, "l2": 3, "annulus": 4, "cardinality": 5, "prox_l1": 6}
+YL_FEAS, YL_BB, YL_FIRST = 1, 2, 4
+
+
+class SipxError(RuntimeError):
+    pass
+
+
+class _SetDesc(C.Structure):
+    _fields_ = [("op", C.c_int32), ("proj", C.c_int32), ("pmin", C.c_double), ("pmax", C.c_double),
+                ("lb", C.c_void_p), ("ub", C.c_void_p), ("ncvx", C.c_int32), ("reserved", C.c_int32)]
+
+
+class _Options(C.Structure):
+    _fields_ = [("maxit", C.c_int32), ("evol_rel_tol", C.c_double), ("feas_tol", C.c_double),
+                ("obj_tol", C.c_double), ("rho_update_frequency", C.c_int32), ("adjust_rho", C.c_int32),
+                ("adjust_gamma", C.c_int32), ("adjust_feasibility_rho", C.c_int32)]
+
+
+class _Log(C.Structure):
+    _fields_ = [(k, C.c_void_p) for k in ("set_feasibility", "r_dual", "r_pri", "r_dual_total", "r_pri_total",
+                                           "obj", "evol_x", "rho", "gamma", "cg_it", "cg_relres")] + \
+               [("timing_ms", C.c_double * 7), ("n_iter", C.c_int32), ("n_feas_rows", C.c_int32),
+                ("stopped_feasible", C.c_int32)]
+
+
+_lib = None
+
+
+def lib():
+    """The loaded libsipx.so.  Raises when it has not been built: the product never falls back."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise SipxError(f"{LIB_PATH} is missing -- run `python -c 'import __graft_entry__ as g; g.build()'`; "
+                            "the engine has no CPU fallback")
+        L = C.CDLL(LIB_PATH)
+        L.sipx_last_error.restype = C.c_char_p
+        for name in ("sipx_stream", "sipx_dev_rhs", "sipx_dev_x"):
+            getattr(L, name).restype = C.c_void_p
+            getattr(L, name).argtypes = [C.c_void_p]
+        L.sipx_destroy.restype = None
+        L.sipx_destroy.argtypes = [C.c_void_p]
+        _lib = L
+    return _lib
+
+
+def _chk(rc):
+    if rc != 0:
+        raise SipxError(lib().sipx_last_error().decode())
+
+
+def _dtype_code(TF):
+    TF = np.dtype(TF).type
+    if TF == np.float32:
+        return SIPX_F32
+    if TF == np.float64:
+        return SIPX_F64
+    raise SipxError("FL must be Float32 or Float64")
+
+
+def _ptr(a):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+# --------------------------------------------------------------------------------------------------
+# boundary types (src/SetIntersectionProjection.jl:95-149)
+# --------------------------------------------------------------------------------------------------
+@dataclass
+class compgrid:
+    d: Tuple
+    n: Tuple
+
+
+@dataclass
+class PARSDMM_options:
+    x_min_solver: str = "CG_normal"
+    maxit: int = 200
+    evol_rel_tol: float = 1e-3
+    feas_tol: float = 5e-2
+    obj_tol: float = 1e-3
+    rho_ini: Sequence[float] = (10.0,)
+    rho_update_frequency: int = 2
+    gamma_ini: float = 1.0
+    adjust_rho: bool = True
+    adjust_gamma: bool = True
+    adjust_feasibility_rho: bool = True
+    Blas_active: bool = True
+    feasibility_only: bool = False
+    FL: Any = np.float32
+    parallel: bool = False
+    zero_ini_guess: bool = True
+    Minkowski: bool = False
+
+
+def default_PARSDMM_options(options: PARSDMM_options, TF) -> PARSDMM_options:
+    """src/default_PARSDMM_options.jl:6-34."""
+    d = PARSDMM_options(FL=TF)
+    for k, v in d.__dict__.items():
+        setattr(options, k, v)
+    return options
+
+
+@dataclass
+class set_definitions:
+    set_type: str
+    TD_OP: str
+    min: Any
+    max: Any
+    app_mode: Tuple[str, str]
+    custom_TD_OP: Tuple[Any, bool] = ((), False)
+
+
+@dataclass
+class set_properties:
+    ncvx: List[bool] = field(default_factory=list)
+    AtA_diag: List[bool] = field(default_factory=list)
+    dense: List[bool] = field(default_factory=list)
+    TD_n: List[Tuple] = field(default_factory=list)
+    tag: List[Tuple[str, str, str, str]] = field(default_factory=list)
+    banded: List[bool] = field(default_factory=list)
+    AtA_offsets: List[Any] = field(default_factory=list)
+
+
+@dataclass
+class log_type_PARSDMM:
+    set_feasibility: np.ndarray
+    r_dual: np.ndarray
+    r_pri: np.ndarray
+    r_dual_total: np.ndarray
+    r_pri_total: np.ndarray
+    obj: np.ndarray
+    evol_x: np.ndarray
+    rho: np.ndarray
+    gamma: np.ndarray
+    cg_it: np.ndarray
+    cg_relres: np.ndarray
+    timing: Any = None
+
+
+TIMING_SECTIONS = ("initialization", "form rhs for linear system", "argmin x", "argmin y and l update",
+                   "stopping conditions check", "adjust rho and gamma", "Q-update")   # src/PARSDMM.jl @timeit names
+
+
+def _grid(comp_grid):
+    n = tuple(int(v) for v in comp_grid.n)
+    if len(n) == 3 and n[2] == 1:
+        n = n[:2]
+    return n, tuple(float(v) for v in comp_grid.d[:len(n)])
+
+
+# --------------------------------------------------------------------------------------------------
+# descriptors standing in for TD_OP[i] and P_sub[i]
+# --------------------------------------------------------------------------------------------------
+class TDOperator:
+    """Matrix-free stand-in for the SparseMatrixCSC a difference/identity TD_OP is in the reference."""
+
+    def __init__(self, kind: str, comp_grid, TF, adjoint=False):
+        if kind not in OPS:
+            raise SipxError("provided an unknown transform domain operator. check function "
+                            "get_TD_operator(comp_grid,TD_type,TF) for options")
+        self.kind, self.comp_grid, self.TF, self.adjoint = kind, comp_grid, np.dtype(TF).type, adjoint
+        n, _ = _grid(comp_grid)
+        N = int(np.prod(n))
+        if kind == "identity":
+            rows = N
+        else:
+            dirs = {"D_x": [0], "D_y": [1], "D_z": [len(n) - 1], "TV": list(range(len(n))), "D2D": list(range(len(n))),
+                    "D3D": list(range(len(n)))}[kind]
+            rows = sum(N // n[a] * (n[a] - 1) for a in dirs)
+        self.shape = (N, rows) if adjoint else (rows, N)
+
+    @property
+    def T(self):
+        return TDOperator(self.kind, self.comp_grid, self.TF, not self.adjoint)
+
+    def __matmul__(self, v):
+        v = np.ascontiguousarray(v, dtype=self.TF)
+        if v.shape != (self.shape[1],):
+            raise SipxError("dimension mismatch")
+        out = np.empty(self.shape[0], self.TF)
+        ctx = Context(self.comp_grid, self.TF)
+        try:
+            f = lib().sipx_apply_op_adj if self.adjoint else lib().sipx_apply_op
+            _chk(f(ctx.h, OPS[self.kind], _ptr(v), _ptr(out)))
+        finally:
+            ctx.close()
+        return out
+
+    __mul__ = __matmul__
+
+
+class Projector:
+    """Descriptor of P_sub[i] (src/get_projector.jl:3-103); calling it projects in place on the device."""
+
+    def __init__(self, constraint: set_definitions, comp_grid, TF):
+        self.TF = np.dtype(TF).type
+        self.comp_grid = comp_grid
+        st = constraint.set_type
+        if constraint.app_mode[0] not in ("matrix", "tensor"):
+            raise SipxError("fiber/slice application modes are not part of this engine yet")
+        self.lb = self.ub = None
+        self.pmin = self.pmax = 0.0
+        if st == "bounds":
+            if np.ndim(constraint.min) == 0:
+                self.kind, self.pmin, self.pmax = "bounds", float(constraint.min), float(constraint.max)
+            else:
+                self.kind = "bounds_vec"
+                self.lb = np.ascontiguousarray(constraint.min, self.TF)
+                self.ub = np.ascontiguousarray(constraint.max, self.TF)
+        elif st in ("l1", "l2", "prox_l1"):
+            self.kind, self.pmax = st, float(constraint.max)
+        elif st == "annulus":
+            self.kind, self.pmin, self.pmax = st, float(constraint.min), float(constraint.max)
+        elif st == "cardinality":
+            self.kind, self.pmax = st, float(constraint.max)
+        else:
+            raise SipxError(f"set type {st!r} is outside the hot-path scope of this engine")
+
+    def desc(self, op: str, ncvx: bool) -> _SetDesc:
+        d = _SetDesc()
+        d.op, d.proj = OPS[op], PROJ[self.kind]
+        d.pmin, d.pmax = self.pmin, self.pmax
+        d.lb, d.ub = _ptr(self.lb), _ptr(self.ub)
+        d.ncvx, d.reserved = int(bool(ncvx)), 0
+        return d
+
+    def __call__(self, v):
+        if v.dtype.type != self.TF or not v.flags.c_contiguous:
+            raise SipxError("projector input must be a contiguous vector of the working precision")
+        ctx = Context(compgrid((1.0, 1.0), (max(len(v), 1), 1)), self.TF)
+        try:
+            d = self.desc("identity", False)
+            _chk(lib().sipx_project(ctx.h, C.byref(d), _ptr(v), C.c_int64(len(v))))
+        finally:
+            ctx.close()
+        return v
+
+
+# --------------------------------------------------------------------------------------------------
+# one-off setup
+# --------------------------------------------------------------------------------------------------
+def get_TD_operator(comp_grid, TD_type: str, TF):
+    """src/get_TD_operator.jl:12-95 for the banded operators."""
+    A = TDOperator(TD_type, comp_grid, TF)
+    n, _ = _grid(comp_grid)
+    if TD_type == "identity":
+        return A, True, False, n, True
+    if len(n) == 2:
+        n1, n2 = n
+        TD_n = {"TV": ((n1 - 1) + n1, n2 + (n2 - 1)), "D2D": ((n1 - 1) + n1, n2 + (n2 - 1)), "D_z": (n1, n2 - 1),
+                "D_x": (n1 - 1, n2)}[TD_type]
+    else:
+        n1, n2, n3 = n
+        TD_n = {"TV": (3 * n1 - 1, 3 * n2 - 1, 3 * n3 - 1), "D3D": (3 * n1 - 1, 3 * n2 - 1, 3 * n3 - 1),
+                "D_z": (n1, n2, n3 - 1), "D_y": (n1, n2 - 1, n3), "D_x": (n1 - 1, n2, n3)}[TD_type]
+    return A, False, False, TD_n, True
+
+
+def setup_constraints(constraint: List[set_definitions], comp_grid, TF):
+    """src/setup_constraints.jl:17-102 -> (P_sub, TD_OP, set_Prop)."""
+    TF = np.dtype(TF).type
+    P_sub, TD_OP, prop = [], [], set_properties()
+    for c in constraint:
+        if np.ndim(c.min) == 0:
+            if isinstance(c.min, (float, np.floating)):
+                c.min, c.max = TF(c.min), TF(c.max)
+        else:
+            c.min, c.max = np.asarray(c.min, TF), np.asarray(c.max, TF)
+        if c.set_type in ("nuclear", "rank") and c.app_mode[0] in ("matrix", "tensor") and len(comp_grid.n) == 3:
+            raise SipxError("requested rank or nuclear norm constraints on a tensor, use mode=(slice,x) e.t.c. to "
+                            "define constraints per slice")
+        if c.set_type in ("l1", "l2") and c.app_mode[0] in ("slice", "fiber"):
+            raise SipxError("l1 and l2 constraints only available for matrix or tensor mode, currently")
+        A, AtA_diag, dense, TD_n, banded = get_TD_operator(comp_grid, c.TD_OP, TF)
+        P_sub.append(Projector(c, comp_grid, TF))
+        TD_OP.append(A)
+        prop.AtA_diag.append(AtA_diag); prop.dense.append(dense); prop.TD_n.append(TD_n)
+        prop.banded.append(banded); prop.AtA_offsets.append(None)
+        prop.tag.append((c.set_type, c.TD_OP, c.app_mode[0], c.app_mode[1]))
+        if c.set_type in ("rank", "cardinality"):
+            ncvx = True
+        elif c.set_type in ("bounds", "histogram") and c.TD_OP != "identity" and TF(np.max(c.min)) > TF(0):
+            ncvx = True
+        else:
+            ncvx = False
+        prop.ncvx.append(ncvx)
+    return P_sub, TD_OP, prop
+
+
+def PARSDMM_precompute_distribute(TD_OP, set_Prop, comp_grid, options):
+    """src/PARSDMM_precompute_distribute.jl:6-77.  AtA[i] = None means "generate the CDS bands of
+    A_i'A_i on the device from the descriptor" (bit-identical to mat2CDS(TD_OP'*TD_OP))."""
+    TF = np.dtype(options.FL).type
+    n, _ = _grid(comp_grid)
+    if not options.feasibility_only:
+        TD_OP.append(TDOperator("identity", comp_grid, TF))
+        set_Prop.TD_n.append(n); set_Prop.AtA_offsets.append(np.array([0], np.int64))
+        set_Prop.banded.append(True); set_Prop.AtA_diag.append(True)
+        set_Prop.ncvx.append(False); set_Prop.dense.append(False)
+        set_Prop.tag.append(("distance squared", "identity", "matrix", ""))
+    p = len(TD_OP)
+    AtA = [None] * p
+    st = {1: 1, 2: n[0], 3: n[0] * n[1] if len(n) > 2 else None}
+    for i in range(p):
+        kind = TD_OP[i].kind
+        dirs = {"identity": [], "D_x": [0], "D_y": [1], "D_z": [len(n) - 1]}.get(kind, list(range(len(n))))
+        strides = [int(np.prod(n[:a])) for a in dirs]
+        set_Prop.AtA_offsets[i] = np.array(sorted({0} | {s for s in strides} | {-s for s in strides}), np.int64)
+    del st
+    y = [np.zeros(TD_OP[i].shape[0], TF) for i in range(p)]
+    l = [np.zeros(TD_OP[i].shape[0], TF) for i in range(p)]
+    return TD_OP, AtA, l, y
+
+
+# --------------------------------------------------------------------------------------------------
+# engine handle (phase-level API, include/sipx.h section A)
+# --------------------------------------------------------------------------------------------------
+class Context:
+    def __init__(self, comp_grid, TF, device: int = 0):
+        self.TF = np.dtype(TF).type
+        n, h = _grid(comp_grid)
+        self.n, self.N = n, int(np.prod(n))
+        self.h = C.c_void_p()
+        na = (C.c_int64 * len(n))(*n)
+        ha = (C.c_double * len(n))(*h)
+        _chk(lib().sipx_create(C.byref(self.h), _dtype_code(self.TF), len(n), na, ha, device))
+        self.rows: List[int] = []
+        self.p = self.pp = 0
+        self._keep = []
+
+    def close(self):
+        if self.h:
+            lib().sipx_destroy(self.h)
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def add_set(self, op: TDOperator, proj: Projector, ncvx=False, AtA=None, AtA_offsets=None) -> int:
+        d = proj.desc(op.kind, ncvx)
+        self._keep.append(proj)
+        if AtA is not None:
+            R = np.asfortranarray(AtA, dtype=self.TF)
+            off = np.ascontiguousarray(AtA_offsets, np.int64)
+            rc = lib().sipx_add_set(self.h, C.byref(d), _ptr(R), off.ctypes.data_as(C.c_void_p), int(R.shape[1]))
+        else:
+            rc = lib().sipx_add_set(self.h, C.byref(d), None, None, 0)
+        if rc < 0:
+            raise SipxError(lib().sipx_last_error().decode())
+        r = C.c_int64()
+        _chk(lib().sipx_set_rows(self.h, rc, C.byref(r)))
+        self.rows.append(int(r.value))
+        return rc
+
+    def set_owned(self, owned: Sequence[int]):
+        a = np.ascontiguousarray(owned, np.int32)
+        _chk(lib().sipx_set_owned(self.h, a.ctypes.data_as(C.c_void_p)))
+
+    def finalize(self, m, rho_ini, gamma_ini, feasibility_only=False, zero_ini_guess=True, x0=None, l0=None, y0=None):
+        m = np.ascontiguousarray(m, self.TF)
+        if m.shape != (self.N,):
+            raise SipxError("length of m does not match the grid")
+        rho = np.ascontiguousarray(rho_ini, np.float64)
+        npp = len(self.rows)
+        feas = np.zeros(max(npp, 1))
+        keep = []
+
+        def arr_list(lst):
+            if lst is None or len(lst) == 0:
+                return None
+            ptrs = (C.c_void_p * len(lst))()
+            for i, a in enumerate(lst):
+                a = np.ascontiguousarray(a, self.TF)
+                keep.append(a)
+                ptrs[i] = a.ctypes.data
+            return ptrs
+        x0a = None if x0 is None else np.ascontiguousarray(x0, self.TF)
+        _chk(lib().sipx_finalize(self.h, _ptr(m), rho.ctypes.data_as(C.c_void_p), len(rho), C.c_double(gamma_ini),
+                                 int(feasibility_only), int(zero_ini_guess), _ptr(x0a), arr_list(l0), arr_list(y0),
+                                 feas.ctypes.data_as(C.c_void_p)))
+        p, pp = C.c_int(), C.c_int()
+        _chk(lib().sipx_num_terms(self.h, C.byref(p), C.byref(pp)))
+        self.p, self.pp = p.value, pp.value
+        if self.p > npp:
+            self.rows.append(self.N)
+        return feas[:npp]
+
+    # ---- phases ----
+    def rhs_compose(self, rho):
+        rho = np.ascontiguousarray(rho, np.float64)
+        _chk(lib().sipx_rhs_compose(self.h, rho.ctypes.data_as(C.c_void_p)))
+
+    def argmin_x(self, it, tol_ref):
+        t, ci, rr, fl = C.c_double(tol_ref), C.c_int64(), C.c_double(), C.c_int()
+        _chk(lib().sipx_argmin_x(self.h, int(it), C.byref(t), C.byref(ci), C.byref(rr), C.byref(fl)))
+        return t.value, ci.value, rr.value, fl.value
+
+    def update_y_l(self, it, flags, rho, gamma):
+        rho = np.ascontiguousarray(rho, np.float64); gamma = np.ascontiguousarray(gamma, np.float64)
+        rp, rd, fe = np.zeros(self.p), np.zeros(self.p), np.zeros(max(self.pp, 1))
+        _chk(lib().sipx_update_y_l(self.h, int(it), int(flags), rho.ctypes.data_as(C.c_void_p),
+                                   gamma.ctypes.data_as(C.c_void_p), rp.ctypes.data_as(C.c_void_p),
+                                   rd.ctypes.data_as(C.c_void_p), fe.ctypes.data_as(C.c_void_p)))
+        return rp, rd, fe[:self.pp]
+
+    def log_scalars(self):
+        a, b = C.c_double(), C.c_double()
+        _chk(lib().sipx_log_scalars(self.h, C.byref(a), C.byref(b)))
+        return a.value, b.value
+
+    def adapt_rho_gamma(self, adjust_rho, adjust_gamma, rho, gamma):
+        rho = np.array(rho, np.float64); gamma = np.array(gamma, np.float64)
+        _chk(lib().sipx_adapt_rho_gamma(self.h, int(adjust_rho), int(adjust_gamma), rho.ctypes.data_as(C.c_void_p),
+                                        gamma.ctypes.data_as(C.c_void_p)))
+        return rho, gamma
+
+    def q_update(self, rho_new, rho_old):
+        a = np.ascontiguousarray(rho_new, np.float64); b = np.ascontiguousarray(rho_old, np.float64)
+        _chk(lib().sipx_q_update(self.h, a.ctypes.data_as(C.c_void_p), b.ctypes.data_as(C.c_void_p)))
+
+    def download(self, want_ly=True):
+        x = np.empty(self.N, self.TF)
+        l = [np.zeros(r, self.TF) for r in self.rows] if want_ly else None
+        y = [np.zeros(r, self.TF) for r in self.rows] if want_ly else None
+
+        def ptrs(lst):
+            if lst is None:
+                return None
+            a = (C.c_void_p * len(lst))()
+            for i, v in enumerate(lst):
+                a[i] = v.ctypes.data
+            return a
+        _chk(lib().sipx_download(self.h, _ptr(x), ptrs(l), ptrs(y)))
+        return x, l, y
+
+    def get_Q(self):
+        d = C.c_int()
+        offs = np.zeros(32, np.int64)
+        _chk(lib().sipx_get_Q(self.h, None, offs.ctypes.data_as(C.c_void_p), C.byref(d)))
+        Q = np.empty((self.N, d.value), self.TF, order="F")
+        _chk(lib().sipx_get_Q(self.h, _ptr(Q), offs.ctypes.data_as(C.c_void_p), C.byref(d)))
+        return Q, offs[:d.value].copy()
+
+    def time_spmv(self, reps=20):
+        ms = C.c_double()
+        _chk(lib().sipx_time_spmv(self.h, int(reps), C.byref(ms)))
+        return ms.value
+
+    def parsdmm(self, options: PARSDMM_options):
+        maxit, p, pp = int(options.maxit), self.p, self.pp
+        o = _Options(maxit, float(options.evol_rel_tol), float(options.feas_tol), float(options.obj_tol),
+                     int(options.rho_update_frequency), int(options.adjust_rho), int(options.adjust_gamma),
+                     int(options.adjust_feasibility_rho))
+        arrs = dict(set_feasibility=np.zeros((maxit, max(pp, 1))), r_dual=np.zeros((maxit, p)),
+                    r_pri=np.zeros((maxit, p)), r_dual_total=np.zeros(maxit), r_pri_total=np.zeros(maxit),
+                    obj=np.zeros(maxit), evol_x=np.zeros(maxit), rho=np.zeros((maxit, p)),
+                    gamma=np.zeros((maxit, p)), cg_it=np.zeros(maxit, np.int64), cg_relres=np.zeros(maxit))
+        lg = _Log()
+        for k, a in arrs.items():
+            setattr(lg, k, a.ctypes.data)
+        _chk(lib().sipx_parsdmm(self.h, C.byref(o), C.byref(lg)))
+        it, nf = lg.n_iter, lg.n_feas_rows
+        log = log_type_PARSDMM(arrs["set_feasibility"][:nf, :pp], arrs["r_dual"][:it], arrs["r_pri"][:it],
+                               arrs["r_dual_total"][:it], arrs["r_pri_total"][:it], arrs["obj"][:it],
+                               arrs["evol_x"][:it], arrs["rho"][:it], arrs["gamma"][:it], arrs["cg_it"][:it],
+                               arrs["cg_relres"][:it],
+                               dict(zip(TIMING_SECTIONS, [t * 1e-3 for t in lg.timing_ms])))
+        return log, bool(lg.stopped_feasible)
+
+
+def build_context(m, AtA, TD_OP, set_Prop, P_sub, comp_grid, options, x=None, l=None, y=None, device=0,
+                  owned=None) -> Context:
+    """Everything PARSDMM_initialize allocates (src/PARSDMM_initialize.jl:117-230), on the device."""
+    TF = np.dtype(m.dtype).type
+    if not (np.isrealobj(m) and (x is None or np.isrealobj(x))):
+        raise SipxError("input for PARSDMM is not real")                 # src/PARSDMM.jl:50-52
+    pp = len(P_sub)
+    p = len(TD_OP)
+    if (not options.feasibility_only and p != pp + 1) or (options.feasibility_only and p != pp):
+        raise SipxError("TD_OP must hold one operator per set plus the identity of the distance term "
+                        "(output of PARSDMM_precompute_distribute)")
+    ctx = Context(comp_grid, TF, device)
+    try:
+        for i in range(pp):
+            A = AtA[i] if AtA is not None else None
+            ctx.add_set(TD_OP[i], P_sub[i], set_Prop.ncvx[i], A, set_Prop.AtA_offsets[i] if A is not None else None)
+        if owned is not None:
+            ctx.set_owned(owned)
+        rho_ini = [float(TF(r)) for r in options.rho_ini]                # convert_options!.jl:6-15
+        feas0 = ctx.finalize(m, rho_ini, float(TF(options.gamma_ini)), options.feasibility_only,
+                             options.zero_ini_guess, x, l, y)
+        ctx.feasibility_initial = feas0
+    except Exception:
+        ctx.close()
+        raise
+    return ctx
+
+
+def PARSDMM(m, AtA, TD_OP, set_Prop, P_sub, comp_grid, options, x=None, l=None, y=None, device=0):
+    """Drop-in for src/PARSDMM.jl:25-258 (serial path): returns (x, log_PARSDMM, l, y)."""
+    ctx = build_context(m, AtA, TD_OP, set_Prop, P_sub, comp_grid, options, x, l, y, device)
+    try:
+        log, _ = ctx.parsdmm(options)
+        xo, lo, yo = ctx.download()
+    finally:
+        ctx.close()
+    if x is not None:
+        x[:] = xo                         # the reference overwrites the x argument in place
+        xo = x
+    return xo, log, lo, yo
+
+
+# --------------------------------------------------------------------------------------------------
+# kernel-level helpers (parity tests / bench)
+# --------------------------------------------------------------------------------------------------
+def cds_spmv(R, offsets, x, device=0):
+    """y = A x for a CDS matrix (fill! + CDS_MVp_MT, src/argmin_x.jl:72-78)."""
+    TF = x.dtype.type
+    R = np.asfortranarray(R, dtype=TF)
+    off = np.ascontiguousarray(offsets, np.int64)
+    x = np.ascontiguousarray(x)
+    y = np.empty_like(x)
+    _chk(lib().sipx_cds_spmv(_dtype_code(TF), C.c_int64(R.shape[0]), int(R.shape[1]), _ptr(R),
+                             off.ctypes.data_as(C.c_void_p), _ptr(x), _ptr(y), device))
+    return y
+
+
+def CDS_MVp(N, ndiags, R, offset, x, y):
+    """Reference signature (src/CDS_MVp.jl:9-28): y += A x."""
+    y += cds_spmv(R, offset, x)
+    return y

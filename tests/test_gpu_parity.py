@@ -1,0 +1,335 @@
+"""GPU parity tests: the HIP engine (through the C ABI) against the CPU oracle on the same
+seeded inputs.  Bit-exact where the arithmetic is element-wise (stencils, CDS SpMV, Q assembly,
+bounds / distance prox); stated floating-point tolerances where a reduction or the l1 threshold
+is involved (the reference itself accepts rtol 5e-4 Float32 between its serial and parallel
+paths, test/test_PARSDMM_parallel.jl:72, and 1e-12 Float64 between BLAS and loop code,
+test/test_PARSDMM.jl:314)."""
+import numpy as np
+import pytest
+
+from oracle import parsdmm_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+GRIDS = [((32, 24), (25.0, 6.0)), ((30, 21), (2.0, 3.0)), ((16, 12, 8), (25.0, 20.0, 10.0)),
+         ((9, 7, 5), (1.0, 2.0, 4.0))]
+
+
+def model(n, TF, seed=0):
+    rng = np.random.default_rng(20240601 + seed)
+    z = np.linspace(0, 1, n[-1]).reshape((1,) * (len(n) - 1) + (-1,))
+    return (1500 + 2500 * z + 150 * rng.standard_normal(n)).astype(TF).reshape(-1, order="F")
+
+
+def ops_for(n):
+    return ["identity", "D_x", "D_z", "TV"] + (["D_y"] if len(n) == 3 else [])
+
+
+# ---- K1: CDS SpMV (test/test_CDS_Mvp.jl) -----------------------------------------------------
+@pytest.mark.parametrize("TF", [np.float32, np.float64])
+@pytest.mark.parametrize("n", [(30, 20), (32, 24), (7, 5, 3)])
+def test_cds_spmv_bitexact(sipx, TF, n):
+    g = O.compgrid(tuple(TF(25) for _ in n), n)
+    A = O.ata_ordered(O.get_TD_operator(g, "TV", TF)[0], TF)
+    R, off = O.mat2CDS(A, TF)
+    x = np.random.default_rng(1).standard_normal(A.shape[0]).astype(TF)
+    ref = O.Ax_CDS(x, R, off)
+    assert np.array_equal(sipx.cds_spmv(R, off, x), ref)
+    perm = np.random.default_rng(2).permutation(len(off))         # band order = summation order
+    assert np.array_equal(sipx.cds_spmv(R[:, perm], off[perm], x), O.Ax_CDS(x, np.asfortranarray(R[:, perm]), off[perm]))
+
+
+def test_cds_spmv_random_bands(sipx):
+    import scipy.sparse as sp
+    A = sp.random(1000, 1000, 0.01, random_state=3, format="csc")   # 1000 % 4 == 0 but arbitrary offsets
+    R, off = O.mat2CDS(A, np.float64)
+    R, off = R[:, :32], off[:32]
+    x = np.random.default_rng(4).standard_normal(1000)
+    assert np.array_equal(sipx.cds_spmv(R, off, x), O.Ax_CDS(x, np.asfortranarray(R), off))
+
+
+# ---- operators: forward / adjoint stencils vs the CSC products (test/test_TD_OPs.jl) ----------
+@pytest.mark.parametrize("TF", [np.float32, np.float64])
+@pytest.mark.parametrize("n,h", GRIDS)
+def test_operators_bitexact(sipx, TF, n, h):
+    go, gs = O.compgrid(h, n), sipx.compgrid(h, n)
+    x = model(n, TF)
+    for name in ops_for(n):
+        Ao = O.get_TD_operator(go, name, TF)[0]
+        As = sipx.get_TD_operator(gs, name, TF)[0]
+        assert As.shape == Ao.shape
+        s = O.csc_mul(Ao, x)
+        assert np.array_equal(As @ x, s), name
+        v = np.random.default_rng(5).standard_normal(Ao.shape[0]).astype(TF)
+        assert np.array_equal(As.T @ v, O.csc_mul_adj(Ao, v)), name
+
+
+# ---- Q assembly from device-generated AtA bands == oracle (PARSDMM_initialize.jl:216-230) ------
+def _problem(mod, n, h, TF, kinds, m, opt_kw=None):
+    g = mod.compgrid(h, n)
+    opt = mod.PARSDMM_options(FL=TF, **(opt_kw or {}))
+    c = []
+    for k in kinds:
+        if k == "bounds":
+            c.append(mod.set_definitions("bounds", "identity", 1600.0, 3900.0, ("matrix", "")))
+        elif k.startswith("l1:"):
+            A = O.get_TD_operator(O.compgrid(h, n), k[3:], TF)[0]
+            c.append(mod.set_definitions("l1", k[3:], 0.0, float(0.5 * np.abs(A @ m).sum()), ("matrix", "")))
+        elif k.startswith("bnd:"):
+            A = O.get_TD_operator(O.compgrid(h, n), k[4:], TF)[0]
+            s = A @ m
+            c.append(mod.set_definitions("bounds", k[4:], float(0.5 * s.min()), float(0.5 * s.max()), ("matrix", "")))
+        elif k == "annulus":
+            nm = float(np.linalg.norm(m.astype(np.float64)))
+            c.append(mod.set_definitions("annulus", "identity", 0.9 * nm, 0.98 * nm, ("matrix", "")))
+        elif k == "l2":
+            nm = float(np.linalg.norm(m.astype(np.float64)))
+            c.append(mod.set_definitions("l2", "identity", 0.0, 0.9 * nm, ("matrix", "")))
+    P, A, prop = mod.setup_constraints(c, g, TF)
+    A, AtA, l, y = mod.PARSDMM_precompute_distribute(A, prop, g, opt)
+    return g, opt, P, A, prop, AtA
+
+
+@pytest.mark.parametrize("TF", [np.float32, np.float64])
+@pytest.mark.parametrize("n,h", GRIDS)
+def test_Q_assembly_bitexact(sipx, TF, n, h):
+    m = model(n, TF)
+    kinds = ["bounds", "l1:D_x", "l1:D_z", "l1:TV"]
+    go, oo, Po, Ao, propo, AtAo = _problem(O, n, h, TF, kinds, m)
+    gs, os_, Ps, As, props, AtAs = _problem(sipx, n, h, TF, kinds, m)
+    rho = [3.0, 0.5, 7.0, 11.0, 2.0]
+    Qo, offo = O.assemble_Q(AtAo, propo.AtA_offsets, np.array(rho, TF), TF)
+    os_.rho_ini = rho
+    for explicit in (False, True):
+        ctx = sipx.host.build_context(m, AtAo if explicit else AtAs, As, propo if explicit else props, Ps, gs, os_)
+        Q, off = ctx.get_Q()
+        assert np.array_equal(off, offo)
+        assert np.array_equal(Q, Qo)
+        rho_new = [3.0, 0.25, 7.0, 12.5, 1.0]
+        ctx.q_update(rho_new, rho)
+        Q2, _ = ctx.get_Q()
+        ctx.close()
+
+        class L: pass
+        log = L(); log.rho = np.array([rho])
+        Qr = O.Q_update(Qo.copy(order="F"), AtAo, propo, np.array(rho_new, TF), [1, 3, 4], log, 0, offo)
+        assert np.array_equal(Q2, Qr)
+
+
+def test_missing_diagonal_is_an_error(sipx):
+    TF = np.float32
+    n, h = (16, 12), (1.0, 1.0)
+    m = model(n, TF)
+    gs, os_, Ps, As, props, AtAs = _problem(sipx, n, h, TF, ["bounds"], m)
+    ctx = sipx.host.build_context(m, AtAs, As, props, Ps, gs, os_)
+    ctx.close()
+    with pytest.raises(sipx.SipxError):       # l1 radius must be positive (project_l1_Duchi!.jl:22)
+        c = [sipx.set_definitions("l1", "identity", 0.0, -1.0, ("matrix", ""))]
+        P, A, prop = sipx.setup_constraints(c, gs, TF)
+        A, AtA, l, y = sipx.PARSDMM_precompute_distribute(A, prop, gs, os_)
+        sipx.host.build_context(m, AtA, A, prop, P, gs, os_)
+
+
+# ---- projectors (test/test_projectors.jl) ------------------------------------------------------
+@pytest.mark.parametrize("TF", [np.float32, np.float64])
+def test_projectors(sipx, TF):
+    rng = np.random.default_rng(6)
+    g = sipx.compgrid((1.0, 1.0), (10, 10))
+    for n in (1000, 4099, 200000):
+        v = (rng.standard_normal(n) * np.exp(rng.standard_normal(n))).astype(TF)
+        # bounds: exact
+        P = sipx.Projector(sipx.set_definitions("bounds", "identity", -0.5, 0.25, ("matrix", "")), g, TF)
+        assert np.array_equal(P(v.copy()), O.project_bounds(v.copy(), TF(-0.5), TF(0.25)))
+        lb = (rng.standard_normal(n) - 1).astype(TF); ub = lb + TF(0.5)
+        P = sipx.Projector(sipx.set_definitions("bounds", "identity", lb, ub, ("matrix", "")), g, TF)
+        assert np.array_equal(P(v.copy()), O.project_bounds(v.copy(), lb, ub))
+        # l1 ball: same threshold up to the working precision; result on the sphere
+        b = float(0.3 * np.abs(v.astype(np.float64)).sum())
+        P = sipx.Projector(sipx.set_definitions("l1", "identity", 0.0, b, ("matrix", "")), g, TF)
+        w = P(v.copy())
+        ref = O.project_l1_Duchi(v.copy(), TF(b))
+        tol = 2e-5 if TF == np.float32 else 1e-12
+        assert np.linalg.norm(w - ref) <= tol * np.linalg.norm(ref)
+        assert abs(np.abs(w.astype(np.float64)).sum() - b) <= tol * b
+        assert np.array_equal(P(w.copy() * TF(0.5)), w * TF(0.5))           # feasible input untouched
+        # exact fixed point in float64
+        if TF == np.float64:
+            a = np.abs(v); nz = w != 0
+            theta = (a[nz] - np.abs(w[nz])).mean()
+            assert abs(np.maximum(a - theta, 0).sum() - b) < 1e-9 * b
+        # l2 / annulus
+        nv = float(np.linalg.norm(v.astype(np.float64)))
+        P = sipx.Projector(sipx.set_definitions("l2", "identity", 0.0, 0.5 * nv, ("matrix", "")), g, TF)
+        assert np.allclose(P(v.copy()), O.project_l2(v.copy(), TF(0.5 * nv)), rtol=4 * np.finfo(TF).eps, atol=0)
+        P = sipx.Projector(sipx.set_definitions("annulus", "identity", 2 * nv, 3 * nv, ("matrix", "")), g, TF)
+        assert np.allclose(P(v.copy()), O.project_annulus(v.copy(), TF(2 * nv), TF(3 * nv)), rtol=4 * np.finfo(TF).eps, atol=0)
+        z = P(np.zeros(n, TF))
+        assert np.array_equal(z, O.project_annulus(np.zeros(n, TF), TF(2 * nv), TF(3 * nv)))
+    # heavy ties at the threshold and a tiny vector
+    v = np.array([3, 3, 3, 3, -3, 1, 0, 0], TF)
+    P = sipx.Projector(sipx.set_definitions("l1", "identity", 0.0, 5.0, ("matrix", "")), g, TF)
+    assert np.allclose(P(v.copy()), O.project_l1_Duchi(v.copy(), TF(5.0)), rtol=1e-6)
+    # prox_l2s known answers (test/test_prox_l2s!.jl)
+
+
+# ---- one phase-level iteration in lock-step with the oracle -------------------------------------
+@pytest.mark.parametrize("TF", [np.float32, np.float64])
+@pytest.mark.parametrize("n,h", GRIDS[:3])
+def test_phases_lockstep(sipx, TF, n, h):
+    m = model(n, TF)
+    kinds = ["bounds", "bnd:D_z", "l1:TV"]
+    go, oo, Po, Ao, propo, AtAo = _problem(O, n, h, TF, kinds, m)
+    gs, os_, Ps, As, props, AtAs = _problem(sipx, n, h, TF, kinds, m)
+    rng = np.random.default_rng(7)
+    p = len(Ao)
+    N = len(m)
+    # a random warm state
+    x0 = (m + 50 * rng.standard_normal(N)).astype(TF)
+    y0 = [O.csc_mul(Ao[i], x0) + (5 * rng.standard_normal(Ao[i].shape[0])).astype(TF) * TF(0.01) for i in range(p)]
+    l0 = [(rng.standard_normal(Ao[i].shape[0])).astype(TF) for i in range(p)]
+    rho = np.array([10.0, 3.0, 7.0, 2.0], TF); gamma = np.array([1.0, 1.3, 1.7, 1.0], TF)
+    os_.zero_ini_guess = False
+    os_.rho_ini = [float(r) for r in rho]
+    ctx = sipx.host.build_context(m, AtAs, As, props, Ps, gs, os_, x=x0, l=l0, y=y0)
+    # rhs_compose: bit exact
+    ctx.rhs_compose(rho)
+    rhs = O.rhs_compose(l0, y0, rho, Ao, p, N)
+    # x-minimisation
+    Qo, offo = O.assemble_Q(AtAo, propo.AtA_offsets, rho, TF)
+    xo, it_o, relres_o, tol_o = O.argmin_x(Qo, rhs, x0.copy(), TF(1.0), 1, offo)
+    tol, cg_it, relres, flag = ctx.argmin_x(1, 1.0)
+    xs, _, _ = ctx.download(False)
+    eps = np.finfo(TF).eps
+    assert cg_it == it_o and flag == 0
+    assert abs(tol - float(tol_o)) <= 8 * eps * abs(float(tol_o))
+    assert np.linalg.norm(xs - xo) <= 50 * eps * np.linalg.norm(xo)
+    assert abs(relres - float(relres_o)) <= 1e-3 * float(relres_o)
+    # y/l update with BB first-iteration snapshots and feasibility
+    prox = list(Po) + [lambda v: O.prox_l2s(v, rho[p - 1], m)]
+    z = lambda: [np.zeros(Ao[i].shape[0], TF) for i in range(p)]
+    y, l = [v.copy() for v in y0], [v.copy() for v in l0]
+    y_old, l_old, x_hat, r_pri, s = z(), z(), z(), z(), z()
+
+    class L: pass
+    log = L(); log.r_pri = np.zeros((10, p)); log.r_dual = np.zeros((10, p)); log.set_feasibility = np.zeros((10, p - 1))
+    O.update_y_l(xs.copy(), p, 10, y, y_old, l, l_old, rho, gamma, prox, Ao, log, Po, 2, x_hat, r_pri, s)
+    rp, rd, fe = ctx.update_y_l(10, sipx.host.YL_FEAS | sipx.host.YL_FIRST, rho, gamma)
+    _, ls, ys = ctx.download()
+    obj, evol = ctx.log_scalars()
+    rt = 2e-5 if TF == np.float32 else 1e-11
+    for i in range(p):
+        exact = i != 2          # set 2 is the l1 ball: threshold agrees to working precision only
+        if exact:
+            assert np.array_equal(ys[i], y[i]) and np.array_equal(ls[i], l[i]), i
+        else:
+            assert np.linalg.norm(ys[i] - y[i]) <= rt * np.linalg.norm(y[i])
+            assert np.linalg.norm(ls[i] - l[i]) <= rt * max(np.linalg.norm(l[i]), 1)
+    assert np.allclose(rp, log.r_pri[9], rtol=rt) and np.allclose(rd, log.r_dual[9], rtol=10 * rt, atol=1e-30)
+    assert np.allclose(fe, log.set_feasibility[1], rtol=10 * rt, atol=1e-12)
+    nd = O.nrm2(xs - m, TF)
+    assert np.isclose(obj, float(TF(0.5) * TF(nd * nd)), rtol=4 * eps)
+    assert np.isclose(evol, float(O.nrm2(x0 - xs, TF) / O.nrm2(xs, TF)), rtol=1e-4)
+    # second iteration with BB sums: compare the adapted rho/gamma with the oracle rule
+    l_hat, l_hat_0, y_0, s_0, l_0 = z(), z(), z(), z(), z()
+    for ii in range(p):
+        l_hat[ii][:] = l_old[ii] + TF(rho[ii]) * (-s[ii] + y_old[ii])
+        l_hat_0[ii][:] = l_hat[ii]; y_0[ii][:] = y[ii]; s_0[ii][:] = s[ii]; l_0[ii][:] = l[ii]
+    ctx.rhs_compose(rho)
+    rhs2 = O.rhs_compose(l, y, rho, Ao, p, N)
+    x2, *_ = O.argmin_x(Qo, rhs2, xs.copy(), TF(tol), 2, offo)
+    ctx.argmin_x(2, tol)
+    x2s, _, _ = ctx.download(False)
+    assert np.linalg.norm(x2s - x2) <= 1e-4 * np.linalg.norm(x2)
+    O.update_y_l(x2s.copy(), p, 2, y, y_old, l, l_old, rho, gamma, prox, Ao, log, Po, 3, x_hat, r_pri, s)
+    ctx.update_y_l(2, sipx.host.YL_BB, rho, gamma)
+    rho_o, gam_o = rho.copy(), gamma.copy()
+    O.adapt_rho_gamma(gam_o, rho_o, True, True, y, y_old, s, s_0, l, l_hat_0, l_0, l_old, y_0, p, l_hat)
+    rho_s, gam_s = ctx.adapt_rho_gamma(True, True, rho, gamma)
+    ctx.close()
+    assert np.allclose(rho_s, rho_o, rtol=2e-3) and np.allclose(gam_s, gam_o, rtol=2e-3)
+
+
+# ---- whole solve --------------------------------------------------------------------------------
+CASES = [
+    ("c1-2d-bounds-tv", (32, 24), (25.0, 6.0), ["bounds", "l1:TV"]),
+    ("2d-bounds-dz-tv", (40, 28), (1.0, 1.0), ["bounds", "bnd:D_z", "l1:TV"]),
+    ("c3-3d-bounds-l1xyz", (16, 12, 8), (25.0, 25.0, 25.0), ["bounds", "l1:D_x", "l1:D_y", "l1:D_z"]),
+    ("3d-odd-tv-annulus", (9, 7, 5), (25.0, 25.0, 25.0), ["bounds", "l1:TV", "annulus"]),
+]
+
+
+@pytest.mark.parametrize("TF", [np.float32, np.float64])
+@pytest.mark.parametrize("name,n,h,kinds", CASES)
+def test_parsdmm_matches_oracle(sipx, TF, name, n, h, kinds):
+    m = model(n, TF, seed=len(kinds))
+    kw = dict(maxit=60)
+    go, oo, Po, Ao, propo, AtAo = _problem(O, n, h, TF, kinds, m, kw)
+    gs, os_, Ps, As, props, AtAs = _problem(sipx, n, h, TF, kinds, m, kw)
+    xo, lo, l_o, y_o = O.PARSDMM(m.copy(), AtAo, Ao, propo, Po, go, oo)
+    xs, ls, l_s, y_s = sipx.PARSDMM(m.copy(), AtAs, As, props, Ps, gs, os_)
+    # the first iterations run in lock-step (before threshold flips of the BB rule can separate the traces)
+    K = min(6, len(lo.obj), len(ls.obj))
+    rt = 5e-4 if TF == np.float32 else 1e-8
+    assert np.array_equal(ls.cg_it[:K], lo.cg_it[:K])
+    for f in ("obj", "r_pri_total", "r_dual_total", "rho", "gamma"):
+        a, b = np.asarray(getattr(ls, f))[:K], np.asarray(getattr(lo, f))[:K]
+        assert np.allclose(a, b, rtol=rt, atol=1e-12), (f, a, b)
+    assert np.isnan(ls.evol_x[0]) and ls.cg_it[0] == 0             # zero start: rhs == 0 -> cg flag -9
+    assert np.array_equal(ls.set_feasibility[0], lo.set_feasibility[0]) or \
+        np.allclose(ls.set_feasibility[0], lo.set_feasibility[0], rtol=rt)
+    # solution level: the reference's own serial/parallel tolerance for Float32, tighter for Float64
+    err = np.linalg.norm(xs.astype(np.float64) - xo) / np.linalg.norm(xo)
+    assert err < (5e-4 if TF == np.float32 else 1e-6), err
+    # log bookkeeping (PARSDMM.jl:261-278)
+    it = len(ls.obj)
+    p = len(kinds) + 1
+    assert ls.r_pri.shape == (it, p) and ls.set_feasibility.shape[1] == p - 1
+    assert len(y_s) == p and [len(v) for v in y_s] == [len(v) for v in y_o]
+
+
+def test_feasible_input_returned_untouched(sipx):
+    TF = np.float64
+    n, h = (20, 31), (1.0, 1.0)
+    x = np.random.default_rng(12).standard_normal(20 * 31)
+    g = sipx.compgrid(h, n)
+    opt = sipx.PARSDMM_options(FL=TF)
+    c = [sipx.set_definitions("bounds", "identity", float(x.min()), float(x.max()), ("matrix", ""))]
+    P, A, prop = sipx.setup_constraints(c, g, TF)
+    A, AtA, l, y = sipx.PARSDMM_precompute_distribute(A, prop, g, opt)
+    xo, log, l, y = sipx.PARSDMM(x.copy(), AtA, A, prop, P, g, opt)
+    assert np.array_equal(xo, x) and len(log.obj) == 1 and log.set_feasibility.shape[0] == 1
+
+
+@pytest.mark.parametrize("kind", ["bounds", "l1", "annulus"])
+def test_single_identity_set_equals_projector(sipx, kind):
+    """test/test_PARSDMM.jl:192-242 pattern: one set, identity operator => PARSDMM(m) == P_C(m)."""
+    TF = np.float64
+    g = sipx.compgrid((1.0, 1.0), (16, 12))
+    opt = sipx.PARSDMM_options(FL=TF, maxit=400, feas_tol=1e-10, obj_tol=1e-10, evol_rel_tol=1e-12)
+    m = np.random.default_rng(13).standard_normal(16 * 12)
+    if kind == "bounds":
+        c = sipx.set_definitions("bounds", "identity", -0.3, 0.4, ("matrix", "")); ref = np.clip(m, -0.3, 0.4)
+    elif kind == "l1":
+        b = 0.4 * np.abs(m).sum()
+        c = sipx.set_definitions("l1", "identity", 0.0, b, ("matrix", "")); ref = O.project_l1_Duchi(m.copy(), b)
+    else:
+        nm = np.linalg.norm(m)
+        c = sipx.set_definitions("annulus", "identity", 0.3 * nm, 0.5 * nm, ("matrix", "")); ref = m * 0.5
+    P, A, prop = sipx.setup_constraints([c], g, TF)
+    A, AtA, l, y = sipx.PARSDMM_precompute_distribute(A, prop, g, opt)
+    x, log, l, y = sipx.PARSDMM(m.copy(), AtA, A, prop, P, g, opt)
+    assert np.linalg.norm(x - ref) / np.linalg.norm(ref) < 1e-7
+
+
+def test_converged_result_is_feasible(sipx):
+    """test/test_PARSDMM.jl:77-89 at a size the oracle would need minutes for: property only."""
+    TF = np.float32
+    n, h = (256, 192), (25.0, 6.0)
+    m = model(n, TF)
+    gs, os_, Ps, As, props, AtAs = _problem(sipx, n, h, TF, ["bounds", "bnd:D_z", "l1:TV"], m,
+                                            dict(maxit=500, evol_rel_tol=10 * np.finfo(TF).eps))
+    x, log, l, y = sipx.PARSDMM(m.copy(), AtAs, As, props, Ps, gs, os_)
+    for i in range(3):
+        s = As[i] @ x
+        f = np.linalg.norm(Ps[i](s.copy()).astype(np.float64) - s) / np.linalg.norm(s.astype(np.float64))
+        assert f <= 1.5 * float(os_.feas_tol), (i, f)

@@ -1,0 +1,77 @@
+"""CPU-side checks of the boundary: the C-ABI library loads, exports every symbol that
+include/sipx.h declares, and refuses to compute without a GPU (no fallback)."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _gpu_present():
+    import torch
+    return torch.cuda.device_count() > 0
+
+
+def test_library_exports_every_declared_symbol(sipx):
+    hdr = open(os.path.join(ROOT, "include", "sipx.h")).read()
+    declared = sorted(set(re.findall(r"\b(sipx_[a-z_A-Z0-9]+)\s*\(", hdr)))
+    assert declared, "no declarations found"
+    assert sorted(sipx.EXPORTED_SYMBOLS) == declared
+    if not os.path.exists(sipx.LIB_PATH):
+        import __graft_entry__
+        __graft_entry__.build()
+    lib = ctypes.CDLL(sipx.LIB_PATH)
+    for name in declared:
+        assert hasattr(lib, name), name
+
+
+def test_no_cpu_fallback(sipx):
+    if _gpu_present():
+        pytest.skip("a GPU is visible; the refusal path needs a CPU-only box")
+    with pytest.raises(sipx.SipxError, match="no HIP device"):
+        sipx.Context(sipx.compgrid((1.0, 1.0), (8, 8)), np.float32)
+    with pytest.raises(sipx.SipxError):
+        sipx.cds_spmv(np.ones((8, 1), np.float32), [0], np.ones(8, np.float32))
+
+
+def test_product_never_imports_the_oracle():
+    pkg = os.path.join(ROOT, "setintersectionprojection.jl_amd")
+    for dp, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".cpp", ".hip", ".h")):
+                src = open(os.path.join(dp, f)).read()
+                assert "oracle" not in src.replace("no CPU fallback", ""), os.path.join(dp, f)
+
+
+def test_descriptor_shapes_match_reference_operators(sipx):
+    from oracle import parsdmm_oracle as O
+    for n, h in [((32, 24), (25.0, 6.0)), ((9, 7, 5), (1.0, 2.0, 4.0))]:
+        for name in ["identity", "D_x", "D_z", "TV"] + (["D_y"] if len(n) == 3 else []):
+            a = sipx.get_TD_operator(sipx.compgrid(h, n), name, np.float32)
+            b = O.get_TD_operator(O.compgrid(h, n), name, np.float32)
+            assert a[0].shape == b[0].shape and a[1:] == b[1:], name
+
+
+def test_setup_constraints_mirrors_reference_properties(sipx):
+    from oracle import parsdmm_oracle as O
+    TF = np.float32
+    n, h = (16, 12), (25.0, 6.0)
+
+    def run(mod):
+        g = mod.compgrid(h, n)
+        c = [mod.set_definitions("bounds", "identity", 1.0, 2.0, ("matrix", "")),
+             mod.set_definitions("bounds", "D_z", 0.5, 1e6, ("matrix", "")),        # positive lower bound in a TD => ncvx
+             mod.set_definitions("l1", "TV", 0.0, 3.0, ("matrix", ""))]
+        P, A, prop = mod.setup_constraints(c, g, TF)
+        opt = mod.PARSDMM_options(FL=TF)
+        A, AtA, l, y = mod.PARSDMM_precompute_distribute(A, prop, g, opt)
+        return prop, [len(v) for v in y]
+    ps, ys = run(sipx)
+    po, yo = run(O)
+    assert ps.ncvx == po.ncvx and ps.tag == po.tag and ps.TD_n == po.TD_n and ys == yo
+    assert all(np.array_equal(a, b) for a, b in zip(ps.AtA_offsets, po.AtA_offsets))
+    with pytest.raises(sipx.SipxError):
+        sipx.setup_constraints([sipx.set_definitions("l1", "TV", 0.0, 1.0, ("fiber", "x"))], sipx.compgrid(h, n), TF)
