@@ -1,0 +1,171 @@
+#!/usr/bin/env python3
+"""bench.py -- PARSDMM iterations/sec on synthetic grids (BASELINE.json metric).
+
+One "step" = one PARSDMM iteration (rhs_compose -> CG x-minimisation -> y/l update of every
+set -> logs -> stop rule -> rho/gamma adaptation -> Q update) on the configuration the metric
+is quoted on: 3-D 256^3 Float32, sets {bounds on I, l1-ball on D_x, D_y, D_z} + the distance
+term (BASELINE.json configs[2]; SURVEY 8d "C3").  Inputs are resident in HBM before the timed
+region.  With --gpus N>1 the constraint sets are sharded over the ranks (one process per GPU,
+RCCL all-reduce of the right-hand side): the same projection problem, so scaling is "strong".
+
+Prints ONE JSON line (rank 0).  roofline = the dominant kernel (cds_spmv fused with the CG dot
+product), timed with HIP events on the engine stream over the timed steps; cpu_baseline = the
+oracle's C/OpenMP port of the reference algorithm on the host cores (rank 0, N=1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec (MI355X_MICROARCH.md); 6290 GB/s measured copy ceiling
+
+CONFIGS = {
+    # name: (n, h, set kinds)
+    "c3": ((256, 256, 256), (25.0, 25.0, 25.0), ["bounds", "l1:D_x", "l1:D_y", "l1:D_z"]),
+    "c2": ((2048, 2048), (25.0, 6.0), ["bounds", "l1:TV"]),
+    "c3-512": ((512, 512, 512), (25.0, 25.0, 25.0), ["bounds", "l1:D_x", "l1:D_y", "l1:D_z"]),
+    "c3-small": ((64, 64, 64), (25.0, 25.0, 25.0), ["bounds", "l1:D_x", "l1:D_y", "l1:D_z"]),
+}
+
+
+def synthetic_model(n, TF, seed):
+    """m = 1500 + 2500*z/(n_last-1) + 150*N(0,1), PCG64 seed 20240601+config# (SURVEY 8d)."""
+    rng = np.random.default_rng(seed)
+    z = np.linspace(0.0, 1.0, n[-1]).reshape((1,) * (len(n) - 1) + (-1,))
+    return (1500.0 + 2500.0 * z + 150.0 * rng.standard_normal(n)).astype(TF).reshape(-1, order="F")
+
+
+def build_problem(mod, n, h, kinds, m, TF, radius_of):
+    g = mod.compgrid(h, n)
+    c = []
+    for k in kinds:
+        if k == "bounds":
+            c.append(mod.set_definitions("bounds", "identity", 1600.0, 3900.0, ("matrix", "")))
+        elif k.startswith("l1:"):
+            c.append(mod.set_definitions("l1", k[3:], 0.0, radius_of(k[3:]), ("matrix", "")))
+    return g, c
+
+
+def bench_options(mod, TF, maxit):
+    # tolerances at zero: the stop rules never fire, so exactly `steps` iterations are timed
+    return mod.PARSDMM_options(FL=TF, maxit=maxit, evol_rel_tol=0.0, feas_tol=0.0, obj_tol=0.0)
+
+
+def cpu_baseline(name, n, h, kinds, steps_budget_s=20.0):
+    """Times the oracle's C/OpenMP port (structure of the reference CPU path) on this host."""
+    try:
+        from oracle import port
+    except Exception as e:                                              # pragma: no cover
+        return {"value": None, "unit": "it/s", "cores": 0, "kind": "port", "sample": f"unavailable: {e}"}
+    return port.time_baseline(name, n, h, kinds, steps_budget_s)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--config", default="c3", choices=sorted(CONFIGS))
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    from __graft_entry__ import load_package
+    sipx = load_package()
+    from sipx import sharded  # noqa: E402  (registered by load_package)
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if args.gpus > 1:
+            raise SystemExit("launch with: python -m torch.distributed.run --nnodes=1 --nproc-per-node N bench.py --gpus N")
+    dist = None
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    TF = np.float32
+    n, h, kinds = CONFIGS[args.config]
+    N = int(np.prod(n))
+    m = synthetic_model(n, TF, 20240601 + 3)
+    gs = sipx.compgrid(h, n)
+
+    def radius_of(opname):                      # sigma = 0.5 ||A m||_1 (the reference tests' own rule)
+        s = sipx.get_TD_operator(gs, opname, TF)[0] @ m
+        return float(0.5 * np.abs(s.astype(np.float64)).sum())
+
+    g, c = build_problem(sipx, n, h, kinds, m, TF, radius_of)
+    P, A, prop = sipx.setup_constraints(c, g, TF)
+    maxit = args.warmup + args.steps + 1
+    opt = bench_options(sipx, TF, maxit)
+    A, AtA, l, y = sipx.PARSDMM_precompute_distribute(A, prop, g, opt)
+    p = len(A)
+    owned = sharded.shard_sets(p, world, rank)
+    ctx = sipx.host.build_context(m, AtA, A, prop, P, g, opt, device=local_rank, owned=owned)
+    comm = sharded.TorchComm(dist, torch.device("cuda", local_rank)) if world > 1 else sharded.LocalComm()
+    drv = sharded.PhaseDriver(ctx, opt, comm, owned, any(prop.ncvx[:len(P)]))
+
+    for _ in range(args.warmup):
+        drv.step()
+    ctx.kernel_stats(True)
+    cg0 = drv.cg_total
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        drv.step()
+        if os.environ.get("SIPX_BENCH_DEBUG"):
+            i = drv.i - 1
+            print(i + 1, "cg", drv.log.cg_it[i], "obj %.4e" % drv.log.obj[i], "rpri", drv.log.r_pri[i], "rho", drv.log.rho[i],
+                  file=sys.stderr, flush=True)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    launches, kms = ctx.kernel_stats(False)
+    if world > 1:
+        tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+    cg_its = drv.cg_total - cg0
+    Q, offs = (None, None)
+    d = len(np.unique(np.concatenate([np.asarray(o) for o in prop.AtA_offsets])))
+    w = np.dtype(TF).itemsize
+    spmv_bytes = (d + 2) * N * w                 # B_spmv = (d+2) N w per launch
+    achieved = (spmv_bytes / (kms / launches * 1e-3) / 1e9) if launches else 0.0
+    log = drv.result_log()
+    finite = bool(np.isfinite(log.obj).all() and np.isfinite(log.r_pri_total).all())
+
+    out = {
+        "metric": "PARSDMM iterations/sec", "value": args.steps / dt, "unit": "it/s", "n_gpus": world,
+        "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
+        "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": f"{args.config}: {'x'.join(map(str, n))} Float32, sets {{{', '.join(kinds)}}} + distance term",
+                   "grid": list(n), "sets": kinds, "parallelism": f"set-sharded x{world}" if world > 1 else "single GPU",
+                   "cg_iterations_in_timed_steps": int(cg_its), "all_logs_finite": finite,
+                   "driver": "phase-level C ABI (sipx_rhs_compose/argmin_x/update_y_l/...)"},
+        "roofline": {"bound": "hbm", "kernel": "k_cds<MODE=1> (cds_spmv + p.Ap partials)", "achieved": achieved,
+                     "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                     "traffic": None, "launches": int(launches), "avg_launch_ms": (kms / launches) if launches else None,
+                     "algorithmic_bytes_per_launch": spmv_bytes},
+    }
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(args.config, n, h, kinds)
+    ctx.close()
+    if rank == 0:
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

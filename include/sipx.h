@@ -148,6 +148,9 @@ int sipx_project(sipx_ctx* ctx, const sipx_set_desc* desc, void* v, int64_t len)
 int sipx_get_Q(sipx_ctx* ctx, void* Q, int64_t* offsets, int* d);
 /* device-side timing of the dominant kernel: runs cds_spmv on Q `reps` times, returns avg ms (HIP events on the engine stream) */
 int sipx_time_spmv(sipx_ctx* ctx, int reps, double* avg_ms);
+/* HIP-event timing of every launch of the dominant kernel (cds_spmv fused with the CG dot product) on the engine
+ * stream: enable=1 starts/clears the collection, enable=0 stops it; launches / total_ms report what was gathered. */
+int sipx_kernel_stats(sipx_ctx* ctx, int enable, int64_t* launches, double* total_ms);
 /* engine stream handle (hipStream_t) so a host harness can order its own work / collectives against it */
 void* sipx_stream(sipx_ctx* ctx);
 /* device pointers of rhs / x (TF[N]) for in-place collectives on the sharded path */

@@ -82,6 +82,9 @@ int sipx_apply_op_adj(sipx_ctx* c, int op, const void* v, void* t) { SIPX_TRY(c-
 int sipx_project(sipx_ctx* c, const sipx_set_desc* d, void* v, int64_t len) { SIPX_TRY(c->e->project(d, v, len)) }
 int sipx_get_Q(sipx_ctx* c, void* Q, int64_t* offsets, int* d) { SIPX_TRY(c->e->get_Q(Q, offsets, d)) }
 int sipx_time_spmv(sipx_ctx* c, int reps, double* avg_ms) { SIPX_TRY(*avg_ms = c->e->time_spmv(reps)) }
+int sipx_kernel_stats(sipx_ctx* c, int enable, int64_t* launches, double* total_ms) {
+  SIPX_TRY(c->e->kernel_stats(enable, launches, total_ms))
+}
 void* sipx_stream(sipx_ctx* c) { return c->e->stream(); }
 void* sipx_dev_rhs(sipx_ctx* c) { return c->e->dev_rhs(); }
 void* sipx_dev_x(sipx_ctx* c) { return c->e->dev_x(); }

@@ -21,7 +21,12 @@ T* dalloc(size_t n, bool zero = true) {
   T* p = nullptr;
   if (n == 0) return p;
   SIPX_HIP(hipMalloc(&p, n * sizeof(T)));
-  if (zero) SIPX_HIP(hipMemset(p, 0, n * sizeof(T)));
+  if (zero) {
+    // hipMemset is queued on the NULL stream; the engine stream is non-blocking, so wait here or the
+    // zero-fill may land after kernels of the engine stream have already written the buffer.
+    SIPX_HIP(hipMemset(p, 0, n * sizeof(T)));
+    SIPX_HIP(hipStreamSynchronize(nullptr));
+  }
   return p;
 }
 inline void dfree(void* p) {
@@ -95,7 +100,8 @@ struct SetState {
   bool ident = true, two_pass = false, is_dist = false, owned = true;
   T *y = nullptr, *l = nullptr, *dy = nullptr, *lh0 = nullptr, *y0 = nullptr, *s0 = nullptr, *l0 = nullptr;
   T *lb = nullptr, *ub = nullptr, *ata = nullptr;
-  ProjScalars<T>* ps = nullptr;
+  ProjScalars<T>* ps = nullptr;    // scalars of prox_i (warm-started across iterations)
+  ProjScalars<T>* psf = nullptr;   // scalars of the feasibility estimate P_i(A_i x)
   std::vector<long long> ata_off;
   std::vector<T> host_lb, host_ub, host_ata;
   double sums[SLOTS] = {0};
@@ -130,11 +136,12 @@ class Engine : public EngineBase {
     for (auto& s : sets_) free_set(s);
     for (void* p : {(void*)x_, (void*)xold_, (void*)rhs_, (void*)m_, (void*)r_, (void*)p_, (void*)Ap_, (void*)Q_,
                     (void*)scr_v_, (void*)scr_c_, (void*)part_cg_, (void*)part_tmp_, (void*)part_sets_,
-                    (void*)maxpart_, (void*)hist_cnt_, (void*)hist_sum_, (void*)cg_dev_})
+                    (void*)maxpart_, (void*)cg_dev_})
       dfree(p);
     if (cg_host_) (void)hipHostFree(cg_host_);
     if (hres_) (void)hipHostFree(hres_);
     for (auto e : ev_) (void)hipEventDestroy(e);
+    for (auto e : stat_ev_) (void)hipEventDestroy(e);
     (void)hipStreamDestroy(stream_);
   }
 
@@ -230,11 +237,9 @@ class Engine : public EngineBase {
     scr_v_ = dalloc<T>(maxpad);
     scr_c_ = dalloc<T>(maxpad);
     part_cg_ = dalloc<double>(2 * NB);
-    part_tmp_ = dalloc<double>(2 * NB);
+    part_tmp_ = dalloc<double>((size_t)(PREP_SLOTS + 2) * NB);
     part_sets_ = dalloc<double>((size_t)p_n_ * SLOTS * NB);
     maxpart_ = dalloc<T>(NB);
-    hist_cnt_ = dalloc<unsigned long long>(L1_BINS);
-    hist_sum_ = dalloc<double>(L1_BINS);
     cg_dev_ = dalloc<CgState<T>>(1);
     SIPX_HIP(hipHostMalloc((void**)&cg_host_, sizeof(CgState<T>), hipHostMallocDefault));
     std::memset(cg_host_, 0, sizeof(CgState<T>));
@@ -262,7 +267,12 @@ class Engine : public EngineBase {
       s.y = dalloc<T>(s.Mpad); s.l = dalloc<T>(s.Mpad);
       s.lh0 = dalloc<T>(s.Mpad); s.y0 = dalloc<T>(s.Mpad); s.s0 = dalloc<T>(s.Mpad); s.l0 = dalloc<T>(s.Mpad);
       if (!s.ident) s.dy = dalloc<T>(s.Mpad);
-      if (s.two_pass) s.ps = dalloc<ProjScalars<T>>(1);
+      if (s.two_pass) {
+        s.ps = dalloc<ProjScalars<T>>(1);
+        s.psf = dalloc<ProjScalars<T>>(1);
+        K<T>::ps_init(stream_, s.ps);
+        K<T>::ps_init(stream_, s.psf);
+      }
       if (s.prox == SIPX_PROJ_BOUNDS_VEC) {
         s.lb = dalloc<T>(s.Mpad); s.ub = dalloc<T>(s.Mpad);
         upload_rows(s, s.host_lb.data(), s.lb);
@@ -325,7 +335,9 @@ class Engine : public EngineBase {
     int iter = 0;
     while (!cg_host_->done && iter < 1000) {      // maxIter=1000, argmin_x.jl:39
       ++iter;
+      if (stats_on_) stat_mark();
       K<T>::spmv_dot(stream_, G_.N, Q_, cds_, p_, Ap_, part_cg_, cg_dev_);
+      if (stats_on_) stat_mark();
       K<T>::cg_fin_alpha(stream_, part_cg_, cg_dev_, cg_host_, iter);
       K<T>::cg_update_xr(stream_, G_.N, x_, r_, p_, Ap_, part_cg_, cg_dev_);
       K<T>::cg_fin_beta(stream_, part_cg_, cg_dev_, cg_host_);
@@ -349,14 +361,16 @@ class Engine : public EngineBase {
       double* part = part_sets_ + (size_t)i * SLOTS * NB;
       if (s.two_pass) {
         K<T>::yl_prep(stream_, G_, a, part_tmp_, maxpart_, 0);
-        K<T>::ps_finish(stream_, part_tmp_, maxpart_, s.ps, s.prox, s.plo, s.phi, s.Mtrue);
-        if (s.prox == PX_L1) K<T>::l1_theta(stream_, s.Mpad, scr_v_, s.ps, s.phi, hist_cnt_, hist_sum_, scr_c_);
+        if (s.prox == PX_L1) K<T>::l1_theta(stream_, s.Mpad, scr_v_, s.ps, s.phi, part_tmp_, maxpart_, scr_c_);
+        else K<T>::ps_finish(stream_, part_tmp_, maxpart_, s.ps, s.prox, s.plo, s.phi, s.Mtrue);
         a.vsrc = 1;
       }
       K<T>::yl(stream_, G_, a, part);
       if (!s.ident) K<T>::adj_norm(stream_, G_, a, part + (size_t)SL_ADJ * NB);
       if ((flags & SIPX_YL_FEAS) && s.two_pass && i < pp_n_) {
-        K<T>::yl_prep(stream_, G_, a, part_tmp_, maxpart_, 1);   // scratch <- s = A x
+        SetArgs<T> af = a;
+        af.ps = s.psf;                                            // its own warm-started probe
+        K<T>::yl_prep(stream_, G_, af, part_tmp_, maxpart_, 1);   // scratch <- s = A x
         feasibility_of_scratch(s, part + (size_t)SL_FE2 * NB, /*have_sums=*/true);
       }
     }
@@ -588,11 +602,10 @@ class Engine : public EngineBase {
     T* dv = dalloc<T>(len);
     T* dc = dalloc<T>(len);
     T *lb = nullptr, *ub = nullptr;
-    double* part = dalloc<double>(2 * NB);
+    double* part = dalloc<double>((size_t)(PREP_SLOTS + 2) * NB);
     T* mp = dalloc<T>(NB);
     ProjScalars<T>* ps = dalloc<ProjScalars<T>>(1);
-    unsigned long long* hc = dalloc<unsigned long long>(L1_BINS);
-    double* hs = dalloc<double>(L1_BINS);
+    K<T>::ps_init(stream_, ps);
     SIPX_HIP(hipMemcpy(dv, v, len * sizeof(T), hipMemcpyHostToDevice));
     const int prox = d->proj;
     const T plo = (T)d->pmin, phi = (T)d->pmax;
@@ -605,14 +618,14 @@ class Engine : public EngineBase {
     if (prox == SIPX_PROJ_CARDINALITY) throw std::runtime_error("cardinality projector: not built yet");
     const bool two = prox == SIPX_PROJ_L1 || prox == SIPX_PROJ_L2 || prox == SIPX_PROJ_ANNULUS;
     if (two) {
-      K<T>::ps_reduce(stream_, len, dv, part, mp);
-      K<T>::ps_finish(stream_, part, mp, ps, prox, plo, phi, len);
-      if (prox == SIPX_PROJ_L1) K<T>::l1_theta(stream_, len, dv, ps, phi, hc, hs, dc);
+      K<T>::ps_reduce(stream_, len, dv, ps, part, mp);
+      if (prox == SIPX_PROJ_L1) K<T>::l1_theta(stream_, len, dv, ps, phi, part, mp, dc);
+      else K<T>::ps_finish(stream_, part, mp, ps, prox, plo, phi, len);
     }
     proj_apply_grid<T>(stream_, g1, 0, nullptr, len, dv, prox, plo, phi, lb, ub, two ? ps : nullptr);
     SIPX_HIP(hipStreamSynchronize(stream_));
     SIPX_HIP(hipMemcpy(v, dv, len * sizeof(T), hipMemcpyDeviceToHost));
-    for (void* q : {(void*)dv, (void*)dc, (void*)lb, (void*)ub, (void*)part, (void*)mp, (void*)ps, (void*)hc, (void*)hs})
+    for (void* q : {(void*)dv, (void*)dc, (void*)lb, (void*)ub, (void*)part, (void*)mp, (void*)ps})
       dfree(q);
   }
 
@@ -641,11 +654,35 @@ class Engine : public EngineBase {
     return (double)ms / reps;
   }
 
+  void kernel_stats(int enable, int64_t* launches, double* total_ms) override {
+    need_final();
+    SIPX_HIP(hipStreamSynchronize(stream_));
+    double tot = 0;
+    for (size_t k = 0; k + 1 < stat_used_; k += 2) {
+      float ms = 0;
+      SIPX_HIP(hipEventElapsedTime(&ms, stat_ev_[k], stat_ev_[k + 1]));
+      tot += ms;
+    }
+    if (launches) *launches = (int64_t)(stat_used_ / 2);
+    if (total_ms) *total_ms = tot;
+    if (enable) stat_used_ = 0;
+    stats_on_ = enable != 0;
+  }
+
   void* stream() override { return (void*)stream_; }
   void* dev_rhs() override { return rhs_; }
   void* dev_x() override { return x_; }
 
  private:
+  void stat_mark() {
+    if (stat_used_ == stat_ev_.size()) {
+      hipEvent_t e;
+      SIPX_HIP(hipEventCreate(&e));
+      stat_ev_.push_back(e);
+    }
+    SIPX_HIP(hipEventRecord(stat_ev_[stat_used_++], stream_));
+  }
+
   void need_final() const {
     if (!finalized_) throw std::runtime_error("call sipx_finalize first");
     SIPX_HIP(hipSetDevice(device_));
@@ -739,11 +776,11 @@ class Engine : public EngineBase {
 
   // ||P(v)-v||^2, ||v||^2 of the vector sitting in scr_v_ into partial slots dst, dst+NB
   void feasibility_of_scratch(SetState<T>& s, double* dst, bool have_sums = false) {
-    ProjScalars<T>* ps = s.ps;
+    ProjScalars<T>* ps = s.psf;
     if (s.two_pass) {
-      if (!have_sums) K<T>::ps_reduce(stream_, s.Mpad, scr_v_, part_tmp_, maxpart_);
-      K<T>::ps_finish(stream_, part_tmp_, maxpart_, ps, s.prox, s.plo, s.phi, s.Mtrue);
-      if (s.prox == PX_L1) K<T>::l1_theta(stream_, s.Mpad, scr_v_, ps, s.phi, hist_cnt_, hist_sum_, scr_c_);
+      if (!have_sums) K<T>::ps_reduce(stream_, s.Mpad, scr_v_, ps, part_tmp_, maxpart_);
+      if (s.prox == PX_L1) K<T>::l1_theta(stream_, s.Mpad, scr_v_, ps, s.phi, part_tmp_, maxpart_, scr_c_);
+      else K<T>::ps_finish(stream_, part_tmp_, maxpart_, ps, s.prox, s.plo, s.phi, s.Mtrue);
     }
     proj_dist_grid<T>(stream_, G_, s.nblk, s.dir, s.Mpad, scr_v_, s.prox, s.plo, s.phi, s.lb, s.ub,
                       s.two_pass ? ps : nullptr, dst);
@@ -796,7 +833,7 @@ class Engine : public EngineBase {
 
   void free_set(SetState<T>& s) {
     for (void* p : {(void*)s.y, (void*)s.l, (void*)s.dy, (void*)s.lh0, (void*)s.y0, (void*)s.s0, (void*)s.l0,
-                    (void*)s.lb, (void*)s.ub, (void*)s.ata, (void*)s.ps})
+                    (void*)s.lb, (void*)s.ub, (void*)s.ata, (void*)s.ps, (void*)s.psf})
       dfree(p);
   }
 
@@ -813,13 +850,15 @@ class Engine : public EngineBase {
   T *x_ = nullptr, *xold_ = nullptr, *rhs_ = nullptr, *m_ = nullptr, *r_ = nullptr, *p_ = nullptr, *Ap_ = nullptr;
   T *Q_ = nullptr, *scr_v_ = nullptr, *scr_c_ = nullptr, *maxpart_ = nullptr;
   CdsArgs cds_;
-  double *part_cg_ = nullptr, *part_tmp_ = nullptr, *part_sets_ = nullptr, *hist_sum_ = nullptr;
-  unsigned long long* hist_cnt_ = nullptr;
+  double *part_cg_ = nullptr, *part_tmp_ = nullptr, *part_sets_ = nullptr;
   CgState<T>*cg_dev_ = nullptr, *cg_host_ = nullptr;
   double* hres_ = nullptr;
   std::vector<hipEvent_t> ev_;
   double obj_ss_ = 0, evo_ss_ = 0, xx_ss_ = 0;
   bool have_log_sums_ = false;
+  std::vector<hipEvent_t> stat_ev_;
+  size_t stat_used_ = 0;
+  bool stats_on_ = false;
 };
 
 EngineBase* make_engine(int dtype, int ndim, const int64_t* n, const double* h, int device) {

@@ -265,11 +265,17 @@ void K<T>::yl(hipStream_t s, const Grid& g, const SetArgs<T>& a, double* partial
 }
 
 // First pass of the two-pass projectors (l1-ball, l2, annulus, cardinality): materialise
-// v = x_hat - l/rho (or v = s = A x for the feasibility estimate) and reduce ||v||_1, ||v||_2^2, max|v|.
+// v = x_hat - l/rho (or v = s = A x for the feasibility estimate) and reduce ||v||_1, ||v||_2^2, nnz,
+// max|v| and -- for the l1 ball -- the probe sums of the threshold search (kernels_proj.hip).
 template <typename T, int V>
 __global__ __launch_bounds__(BLOCK) void k_yl_prep(Grid G, SetArgs<T> a, double* __restrict__ partials,
                                                    T* __restrict__ maxpart, int v_is_s) {
-  double acc[2] = {0, 0};
+  double acc[PREP_SLOTS];
+#pragma unroll
+  for (int k = 0; k < PREP_SLOTS; ++k) acc[k] = 0;
+  double t[L1_K];
+#pragma unroll
+  for (int k = 0; k < L1_K; ++k) t[k] = (a.prox == PX_L1) ? a.ps->t[k] : INFINITY;
   T vmax = T(0);
   const bool ident = a.nblk == 0;
   const int nb = ident ? 1 : a.nblk;
@@ -308,23 +314,14 @@ __global__ __launch_bounds__(BLOCK) void k_yl_prep(Grid G, SetArgs<T> a, double*
 #pragma unroll
       for (int k = 0; k < V; ++k) {
         const T av = fabs(out.v[k]);
-        acc[0] += (double)av;
-        acc[1] += (double)out.v[k] * (double)out.v[k];
+        probe_acc<T>(av, out.v[k], t, acc);
         vmax = av > vmax ? av : vmax;
       }
       stv<T, V>(a.v + e, out);
     }
   }
-  block_reduce_store<2>(acc, partials, 0);
-  __shared__ T smax[BLOCK / 64];
-  vmax = wave_max<T>(vmax);
-  if ((threadIdx.x & 63) == 0) smax[threadIdx.x >> 6] = vmax;
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    T m = smax[0];
-    for (int i = 1; i < BLOCK / 64; ++i) m = smax[i] > m ? smax[i] : m;
-    maxpart[blockIdx.x] = m;
-  }
+  block_reduce_store<PREP_SLOTS>(acc, partials, 0);
+  block_max_store<T>(vmax, maxpart);
 }
 template <typename T>
 void K<T>::yl_prep(hipStream_t s, const Grid& g, const SetArgs<T>& a, double* partials, T* maxpart, int v_is_s) {

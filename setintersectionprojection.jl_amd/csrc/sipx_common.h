@@ -12,7 +12,8 @@ constexpr int NB = 1024;          // fixed grid of every streaming/reduction ker
 constexpr int MAXD = 32;          // CDS bands held in kernel arguments
 constexpr int MAX_SETS = 16;      // sets fused in one rhs_compose launch
 constexpr int YL_SLOTS = 13;      // reductions produced by one y/l-update launch
-constexpr int L1_BINS = 2048;     // histogram bins of the l1-ball threshold search
+constexpr int L1_K = 8;          // probe thresholds of the l1-ball threshold search
+constexpr int PREP_SLOTS = 3 + 2 * L1_K;   // ||v||_1, ||v||_2^2, nnz, S_k, C_k
 
 // reduction slots of k_yl (per set)
 enum { SL_RPRI = 0, SL_DY = 1, SL_HL = 2, SL_HH = 3, SL_LH = 4, SL_DL = 5, SL_GG = 6, SL_GL = 7,
@@ -36,6 +37,8 @@ struct CdsArgs {
 };
 
 // Scalars of the non-elementwise projectors, produced on the device and consumed by k_yl.
+// The l1 part persists across PARSDMM iterations: the thresholds probed during the first pass
+// are centred on the previous iteration's theta (warm start).
 template <typename T>
 struct ProjScalars {
   double asum;        // ||v||_1
@@ -46,10 +49,10 @@ struct ProjScalars {
   T scale;            // l2 / annulus: multiplier
   int fill;           // annulus zero-vector case: fill with `scale`
   // l1 search state
-  int bin;            // bracket bin
-  double s_above;     // sum of |v| in bins above the bracket
-  long long c_above;  // their count
-  double lo, width;   // bracket lower edge and bin width
+  double t[L1_K];     // probe thresholds (ascending; +inf = unused)
+  double lo, hi;      // bracket: lo <= theta* < hi;  elements in (lo, hi] are compacted
+  int refine;         // 1: bracket still holds too many elements -> one more probe pass
+  double theta_prev;  // last non-zero theta (centre of the next probe)
   unsigned long long n_compact;
   // cardinality
   T tau;              // k-th largest magnitude
@@ -127,11 +130,13 @@ struct K {
   static void log3(hipStream_t s, long long N, const T* x, const T* m, const T* xold, double* partials);
   static void fin_sum(hipStream_t s, const double* partials, int nslots, double* out_dev, double* out_host);
   // projector scalar machinery (l1 / l2 / annulus / cardinality)
-  static void ps_reduce(hipStream_t s, long long len, const T* v, double* partials, T* maxpart);
+  static void ps_reduce(hipStream_t s, long long len, const T* v, const ProjScalars<T>* ps, double* partials, T* maxpart);
   static void ps_finish(hipStream_t s, const double* partials, const T* maxpart, ProjScalars<T>* ps, int prox, T pmin,
                         T pmax, long long true_len);
-  static void l1_theta(hipStream_t s, long long len, const T* v, ProjScalars<T>* ps, T radius,
-                       unsigned long long* hist_cnt, double* hist_sum, T* compact);
+  // after yl_prep / ps_reduce filled the PREP_SLOTS partials: bracket, (gated) refine, compaction, exact solve
+  static void l1_theta(hipStream_t s, long long len, const T* v, ProjScalars<T>* ps, T radius, double* partials,
+                       const T* maxpart, T* compact);
+  static void ps_init(hipStream_t s, ProjScalars<T>* ps);
 };
 
 // ||P(v)-v||^2, ||v||^2 (slots 0,1) and v = P(v) over a padded vector (pads skipped)

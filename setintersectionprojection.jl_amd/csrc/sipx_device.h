@@ -75,6 +75,36 @@ __device__ __forceinline__ double block_sum_partials(const double* __restrict__ 
   return s;
 }
 
+// Per-block max of a non-negative value -> maxpart[blockIdx.x].
+template <typename T>
+__device__ __forceinline__ void block_max_store(T vmax, T* __restrict__ maxpart) {
+  __shared__ T smax[BLOCK / 64];
+  vmax = wave_max<T>(vmax);
+  if ((threadIdx.x & 63) == 0) smax[threadIdx.x >> 6] = vmax;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    T m = smax[0];
+    for (int i = 1; i < BLOCK / 64; ++i) m = smax[i] > m ? smax[i] : m;
+    maxpart[blockIdx.x] = m;
+  }
+}
+
+// One magnitude into the first-pass reductions of the two-pass projectors:
+// slot 0 ||v||_1, 1 ||v||_2^2, 2 nnz, 3.. S_k = sum(|v| > t_k), 3+L1_K.. C_k = count(|v| > t_k).
+template <typename T>
+__device__ __forceinline__ void probe_acc(T av, T x, const double (&t)[L1_K], double (&acc)[PREP_SLOTS]) {
+  const double a = (double)av;
+  acc[0] += a;
+  acc[1] += (double)x * (double)x;
+  acc[2] += av > T(0) ? 1.0 : 0.0;
+#pragma unroll
+  for (int k = 0; k < L1_K; ++k) {
+    const bool on = a > t[k];
+    acc[3 + k] += on ? a : 0.0;
+    acc[3 + L1_K + k] += on ? 1.0 : 0.0;
+  }
+}
+
 template <typename T>
 __device__ __forceinline__ T eps_of();
 template <>

@@ -28,7 +28,8 @@ EXPORTED_SYMBOLS = [
     "sipx_last_error", "sipx_create", "sipx_destroy", "sipx_add_set", "sipx_set_rows", "sipx_num_terms",
     "sipx_finalize", "sipx_rhs_compose", "sipx_argmin_x", "sipx_update_y_l", "sipx_log_scalars",
     "sipx_adapt_rho_gamma", "sipx_q_update", "sipx_download", "sipx_parsdmm", "sipx_cds_spmv",
-    "sipx_apply_op", "sipx_apply_op_adj", "sipx_project", "sipx_get_Q", "sipx_time_spmv", "sipx_stream",
+    "sipx_apply_op", "sipx_apply_op_adj", "sipx_project", "sipx_get_Q", "sipx_time_spmv", "sipx_kernel_stats",
+    "sipx_stream",
     "sipx_dev_rhs", "sipx_dev_x", "sipx_set_owned",
 ]
 
@@ -393,7 +394,8 @@ class Context:
         return rc
 
     def set_owned(self, owned: Sequence[int]):
-        a = np.ascontiguousarray(owned, np.int32)
+        a = np.zeros(len(self.rows) + 1, np.int32)       # constraint sets + the distance term
+        a[:len(owned)] = np.asarray(owned, np.int32)[:len(a)]
         _chk(lib().sipx_set_owned(self.h, a.ctypes.data_as(C.c_void_p)))
 
     def finalize(self, m, rho_ini, gamma_ini, feasibility_only=False, zero_ini_guess=True, x0=None, l0=None, y0=None):
@@ -485,6 +487,11 @@ class Context:
         ms = C.c_double()
         _chk(lib().sipx_time_spmv(self.h, int(reps), C.byref(ms)))
         return ms.value
+
+    def kernel_stats(self, enable: bool):
+        n, ms = C.c_int64(), C.c_double()
+        _chk(lib().sipx_kernel_stats(self.h, int(enable), C.byref(n), C.byref(ms)))
+        return n.value, ms.value
 
     def parsdmm(self, options: PARSDMM_options):
         maxit, p, pp = int(options.maxit), self.p, self.pp
