@@ -26,7 +26,7 @@ __device__ __forceinline__ void cds_rows(long long N, const T* __restrict__ R, c
 #pragma unroll
   for (int b = 0; b < d; ++b) {
     const long long o = a.off[b];
-    const Vec<T, V> rv = ldv<T, V>(R + (long long)b * N + r);
+    const Vec<T, V> rv = ldv_nt<T, V>(R + (long long)b * N + r);
     const long long c = r + o;
     if ((o % V) == 0 && c >= 0 && c + V <= N) {
       const Vec<T, V> xv = ldv<T, V>(x + c);

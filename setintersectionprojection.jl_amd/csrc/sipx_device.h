@@ -17,6 +17,30 @@ template <typename T, int V>
 __device__ __forceinline__ void stv(T* p, const Vec<T, V>& x) {
   *reinterpret_cast<Vec<T, V>*>(p) = x;
 }
+// Non-temporal (streaming) vector load: for data read exactly once per pass, e.g. the CDS bands --
+// keeps them from evicting the re-used vectors out of L2 / Infinity Cache (measured +8-10% on cds_spmv).
+template <typename T, int V>
+__device__ __forceinline__ Vec<T, V> ldv_nt(const T* p) {
+  typedef T vt __attribute__((ext_vector_type(V)));
+  Vec<T, V> r;
+  if constexpr (V == 1) {
+    r.v[0] = __builtin_nontemporal_load(p);
+  } else if constexpr (sizeof(T) * V == 16) {
+    const vt t = __builtin_nontemporal_load(reinterpret_cast<const vt*>(p));
+#pragma unroll
+    for (int k = 0; k < V; ++k) r.v[k] = t[k];
+  } else {   // 32-byte vectors: two 16-byte halves
+    typedef T vh __attribute__((ext_vector_type(V / 2)));
+    const vh a = __builtin_nontemporal_load(reinterpret_cast<const vh*>(p));
+    const vh b = __builtin_nontemporal_load(reinterpret_cast<const vh*>(p) + 1);
+#pragma unroll
+    for (int k = 0; k < V / 2; ++k) {
+      r.v[k] = a[k];
+      r.v[V / 2 + k] = b[k];
+    }
+  }
+  return r;
+}
 template <typename T, int V>
 __device__ __forceinline__ Vec<T, V> zerov() {
   Vec<T, V> z;
