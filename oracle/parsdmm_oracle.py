@@ -542,12 +542,13 @@ def PARSDMM_precompute_distribute(TD_OP, set_Prop, comp_grid, options):
 # --------------------------------------------------------------------------------------
 
 
-def rhs_compose(l, y, rho, TD_OP, p, N):
+def rhs_compose(l, y, rho, TD_OP, p, N, only=None):
     """rhs = sum_i A_i'(rho_i y_i + l_i), sets added in order into a zero-filled rhs
-    (src/rhs_compose.jl:24-36)."""
+    (src/rhs_compose.jl:24-36).  `only`: restrict to a subset of sets (the partial sum one
+    worker contributes in the reference's parallel mode, rhs_compose.jl:17-20)."""
     TF = y[0].dtype.type
     rhs = np.zeros(N, TF)
-    for ii in range(p):
+    for ii in (range(p) if only is None else only):
         rhs = rhs + csc_mul_adj(TD_OP[ii], TF(rho[ii]) * y[ii] + l[ii])
     return rhs
 
@@ -615,12 +616,12 @@ def _julia_min(a: float, b: float) -> float:
 
 
 def update_y_l(x, p, i, y, y_old, l, l_old, rho, gamma, prox, TD_OP, log, P_sub, counter,
-               x_hat, r_pri, s, feasibility_only=False):
+               x_hat, r_pri, s, feasibility_only=False, only=None):
     """src/update_y_l.jl:6-109, ``Blas_active=false`` formulas (:64-78).  i is the 1-based
     iteration; counter the 1-based feasibility row."""
     TF = x.dtype.type
     eps = np.finfo(TF).eps
-    for ii in range(p):
+    for ii in (range(p) if only is None else only):
         rho1 = TF(1) / TF(rho[ii])                                       # :33-34
         g = TF(gamma[ii]); r_ = TF(rho[ii])
         y_old[ii][:] = y[ii]; l_old[ii][:] = l[ii]                       # :39-40
@@ -696,10 +697,10 @@ def bb_scalars(TF, d_dHh_dlh, n_d_H_hat, n_d_l_hat, n_d_l, n_d_G_hat, d_dGh_dl,
 
 
 def adapt_rho_gamma(gamma, rho, adjust_gamma, adjust_rho, y, y_old, s, s_0, l, l_hat_0, l_0,
-                    l_old, y_0, p, l_hat):
+                    l_old, y_0, p, l_hat, only=None):
     """src/adapt_rho_gamma.jl:8-132.  Mutates rho, gamma, l_hat in place."""
     TF = y[0].dtype.type
-    for ii in range(p):
+    for ii in (range(p) if only is None else only):
         r_ = TF(rho[ii])
         l_hat[ii][:] = l_old[ii] + r_ * (-s[ii] + y_old[ii])             # :41
         d_l_hat = l_hat[ii] - l_hat_0[ii]                                # :42

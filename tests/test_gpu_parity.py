@@ -333,3 +333,47 @@ def test_converged_result_is_feasible(sipx):
         s = As[i] @ x
         f = np.linalg.norm(Ps[i](s.copy()).astype(np.float64) - s) / np.linalg.norm(s.astype(np.float64))
         assert f <= 1.5 * float(os_.feas_tol), (i, f)
+
+
+# ---- set-sharded path on the real engine: 2 ranks sharing the one GPU, gloo collectives ----------
+def _sharded_worker(rank, world, port, out):
+    import os
+    import sys
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+        sys.path.insert(0, root)
+        from __graft_entry__ import load_package
+        sipx = load_package()
+        from sipx import sharded
+        TF = np.float32
+        n, h = (32, 24, 16), (25.0, 25.0, 25.0)
+        m = model(n, TF, seed=5)
+        gs, os_, Ps, As, props, AtAs = _problem(sipx, n, h, TF, ["bounds", "l1:D_x", "l1:D_y", "l1:D_z"], m, dict(maxit=40))
+        x, log, l, y = sharded.PARSDMM_sharded(m.copy(), AtAs, As, props, Ps, gs, os_, dist=dist, device=0)
+        np.savez(os.path.join(out, f"r{rank}.npz"), x=x, obj=log.obj, cg_it=log.cg_it, rho=log.rho, r_pri=log.r_pri)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_sharded_two_ranks_on_one_gpu(sipx, tmp_path):
+    import os
+    import torch.multiprocessing as mp
+    port = 29600 + (os.getpid() % 2000)
+    mp.spawn(_sharded_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    r0, r1 = np.load(tmp_path / "r0.npz"), np.load(tmp_path / "r1.npz")
+    for k in r0.files:
+        assert np.array_equal(r0[k], r1[k], equal_nan=True), k
+    TF = np.float32
+    n, h = (32, 24, 16), (25.0, 25.0, 25.0)
+    m = model(n, TF, seed=5)
+    gs, os_, Ps, As, props, AtAs = _problem(sipx, n, h, TF, ["bounds", "l1:D_x", "l1:D_y", "l1:D_z"], m, dict(maxit=40))
+    xs, ls, _, _ = sipx.PARSDMM(m.copy(), AtAs, As, props, Ps, gs, os_)
+    K = min(8, len(ls.obj), len(r0["obj"]))
+    assert np.array_equal(r0["cg_it"][:K], ls.cg_it[:K])
+    assert np.allclose(r0["obj"][:K], ls.obj[:K], rtol=5e-4) and np.allclose(r0["r_pri"][:K], ls.r_pri[:K], rtol=5e-4, atol=1e-12)
+    assert np.linalg.norm(r0["x"] - xs) / np.linalg.norm(xs) < 5e-4        # test/test_PARSDMM_parallel.jl:72
