@@ -151,6 +151,9 @@ int sipx_time_spmv(sipx_ctx* ctx, int reps, double* avg_ms);
 /* HIP-event timing of every launch of the dominant kernel (cds_spmv fused with the CG dot product) on the engine
  * stream: enable=1 starts/clears the collection, enable=0 stops it; launches / total_ms report what was gathered. */
 int sipx_kernel_stats(sipx_ctx* ctx, int enable, int64_t* launches, double* total_ms);
+/* diagnostics: state of the projector-scalar search of set `set` (which = 0: prox, 1: feasibility) as 16 doubles:
+ * need, theta, theta_prev, hw, spec_lo, spec_hi, lo, hi, asum, vmax, gathered, overflow, spec_ok, michelot_its, refine, 0 */
+int sipx_debug_proj(sipx_ctx* ctx, int set, int which, double* out16);
 /* engine stream handle (hipStream_t) so a host harness can order its own work / collectives against it */
 void* sipx_stream(sipx_ctx* ctx);
 /* device pointers of rhs / x (TF[N]) for in-place collectives on the sharded path */

@@ -54,13 +54,28 @@ def run(n, h, sets, m, maxit, evol_rel_tol=1e-3, feas_tol=5e-2, obj_tol=1e-3, rh
                 set_feasibility=feas[:nf.value, :pp], evol_x=evol[:it], loop_seconds=secs.value, n_iter=it)
 
 
+def host_threads():
+    """Threads for the CPU baseline: the affinity mask, capped by the cgroup CPU quota and by 16 (the
+    CPU share of a one-GPU box); SIPX_CPU_THREADS overrides."""
+    if os.environ.get("SIPX_CPU_THREADS"):
+        return int(os.environ["SIPX_CPU_THREADS"])
+    n = len(os.sched_getaffinity(0))
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()
+        if q != "max":
+            n = min(n, max(1, int(int(q) / int(per))))
+    except Exception:
+        pass
+    return max(1, min(n, 16))
+
+
 def time_baseline(name, n, h, kinds, budget_s=20.0):
     """cpu_baseline leg of bench.py: the same workload (grid, sets, synthetic model, zero tolerances)
     for as many iterations as fit the budget; reports iterations/sec of the iteration loop."""
     import bench
     TF = np.float32
     m = bench.synthetic_model(n, TF, 20240601 + 3)
-    nthreads = len(os.sched_getaffinity(0))
+    nthreads = host_threads()
     lib = _lib(TF)
     # radii sigma = 0.5 ||A m||_1 from plain numpy differences (setup, not timed)
     M3 = m.reshape(n, order="F").astype(np.float64)

@@ -85,6 +85,7 @@ int sipx_time_spmv(sipx_ctx* c, int reps, double* avg_ms) { SIPX_TRY(*avg_ms = c
 int sipx_kernel_stats(sipx_ctx* c, int enable, int64_t* launches, double* total_ms) {
   SIPX_TRY(c->e->kernel_stats(enable, launches, total_ms))
 }
+int sipx_debug_proj(sipx_ctx* c, int set, int which, double* out16) { SIPX_TRY(c->e->debug_proj(set, which, out16)) }
 void* sipx_stream(sipx_ctx* c) { return c->e->stream(); }
 void* sipx_dev_rhs(sipx_ctx* c) { return c->e->dev_rhs(); }
 void* sipx_dev_x(sipx_ctx* c) { return c->e->dev_x(); }

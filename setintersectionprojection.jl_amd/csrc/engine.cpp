@@ -106,6 +106,7 @@ struct SetState {
   std::vector<T> host_lb, host_ub, host_ata;
   double sums[SLOTS] = {0};
   bool bb_valid = false;
+  T last_rho = T(-1), last_gamma = T(-1);   // parameters of the previous y/l update (speculation of the l1 search)
 };
 
 }  // namespace
@@ -291,8 +292,16 @@ class Engine : public EngineBase {
     for (int i = 0; i < pp_n_; ++i) {
       SetState<T>& s = sets_[i];
       if (!s.owned) continue;
-      K<T>::fwd(stream_, G_, s.nblk, s.dir, s.ih, m_, scr_v_);
-      feasibility_of_scratch(s, part_sets_ + ((size_t)i * SLOTS + SL_FE2) * NB);
+      double* dst = part_sets_ + ((size_t)i * SLOTS + SL_FE2) * NB;
+      if (s.two_pass) {
+        SetArgs<T> a = set_args(s, rho_[i], gamma_[i], 0);
+        a.x = m_;                                              // s = A m produced on the fly
+        K<T>::proj_scalars_set(stream_, G_, a, 1, s.psf, part_tmp_, maxpart_, scr_c_, s.Mtrue);
+        K<T>::proj_dist_set(stream_, G_, a, 1, s.psf, dst);
+      } else {
+        K<T>::fwd(stream_, G_, s.nblk, s.dir, s.ih, m_, scr_v_);
+        proj_dist_grid<T>(stream_, G_, s.nblk, s.dir, s.Mpad, scr_v_, s.prox, s.plo, s.phi, s.lb, s.ub, nullptr, dst);
+      }
     }
     K<T>::fin_sum(stream_, part_sets_, p_n_ * SLOTS, nullptr, hres_);
     SIPX_HIP(hipStreamSynchronize(stream_));
@@ -359,19 +368,19 @@ class Engine : public EngineBase {
       if (!s.owned) continue;
       SetArgs<T> a = set_args(s, (T)rho[i], (T)gamma[i], flags);
       double* part = part_sets_ + (size_t)i * SLOTS * NB;
-      if (s.two_pass) {
-        K<T>::yl_prep(stream_, G_, a, part_tmp_, maxpart_, 0);
-        if (s.prox == PX_L1) K<T>::l1_theta(stream_, s.Mpad, scr_v_, s.ps, s.phi, part_tmp_, maxpart_, scr_c_);
-        else K<T>::ps_finish(stream_, part_tmp_, maxpart_, s.ps, s.prox, s.plo, s.phi, s.Mtrue);
-        a.vsrc = 1;
+      if (s.two_pass) {   // threshold / scale of prox_i from one pass that produces v on the fly (nothing stored)
+        SetArgs<T> ap = a;
+        if (s.last_rho != a.rho || s.last_gamma != a.gamma) ap.flags |= F_NOSPEC;   // v rescaled: theta will jump
+        K<T>::proj_scalars_set(stream_, G_, ap, 0, s.ps, part_tmp_, maxpart_, scr_c_, s.Mtrue);
+        s.last_rho = a.rho;
+        s.last_gamma = a.gamma;
       }
       K<T>::yl(stream_, G_, a, part);
       if (!s.ident) K<T>::adj_norm(stream_, G_, a, part + (size_t)SL_ADJ * NB);
       if ((flags & SIPX_YL_FEAS) && s.two_pass && i < pp_n_) {
-        SetArgs<T> af = a;
-        af.ps = s.psf;                                            // its own warm-started probe
-        K<T>::yl_prep(stream_, G_, af, part_tmp_, maxpart_, 1);   // scratch <- s = A x
-        feasibility_of_scratch(s, part + (size_t)SL_FE2 * NB, /*have_sums=*/true);
+        // ||P_i(s) - s|| with s = A_i x produced on the fly; its own warm-started scalars (psf)
+        K<T>::proj_scalars_set(stream_, G_, a, 1, s.psf, part_tmp_, maxpart_, scr_c_, s.Mtrue);
+        K<T>::proj_dist_set(stream_, G_, a, 1, s.psf, part + (size_t)SL_FE2 * NB);
       }
     }
     K<T>::fin_sum(stream_, part_sets_, p_n_ * SLOTS, nullptr, hres_);
@@ -618,9 +627,7 @@ class Engine : public EngineBase {
     if (prox == SIPX_PROJ_CARDINALITY) throw std::runtime_error("cardinality projector: not built yet");
     const bool two = prox == SIPX_PROJ_L1 || prox == SIPX_PROJ_L2 || prox == SIPX_PROJ_ANNULUS;
     if (two) {
-      K<T>::ps_reduce(stream_, len, dv, ps, part, mp);
-      if (prox == SIPX_PROJ_L1) K<T>::l1_theta(stream_, len, dv, ps, phi, part, mp, dc);
-      else K<T>::ps_finish(stream_, part, mp, ps, prox, plo, phi, len);
+      K<T>::proj_scalars_arr(stream_, len, dv, prox, plo, phi, ps, part, mp, dc, len);
     }
     proj_apply_grid<T>(stream_, g1, 0, nullptr, len, dv, prox, plo, phi, lb, ub, two ? ps : nullptr);
     SIPX_HIP(hipStreamSynchronize(stream_));
@@ -667,6 +674,20 @@ class Engine : public EngineBase {
     if (total_ms) *total_ms = tot;
     if (enable) stat_used_ = 0;
     stats_on_ = enable != 0;
+  }
+
+  void debug_proj(int set, int which, double* o) override {
+    need_final();
+    for (int k = 0; k < 16; ++k) o[k] = 0;
+    if (set < 0 || set >= p_n_) throw std::runtime_error("set index out of range");
+    const ProjScalars<T>* d = which ? sets_[set].psf : sets_[set].ps;
+    if (!d) return;
+    ProjScalars<T> h;
+    SIPX_HIP(hipStreamSynchronize(stream_));
+    SIPX_HIP(hipMemcpy(&h, d, sizeof(h), hipMemcpyDeviceToHost));
+    o[0] = h.need; o[1] = h.theta; o[2] = h.theta_prev; o[3] = h.hw; o[4] = h.spec_lo; o[5] = h.spec_hi; o[6] = h.lo;
+    o[7] = h.hi; o[8] = h.asum; o[9] = h.vmax; o[10] = h.dbg[0]; o[11] = h.dbg[1]; o[12] = h.dbg[2]; o[13] = h.dbg[3];
+    o[14] = h.refine;
   }
 
   void* stream() override { return (void*)stream_; }
@@ -772,18 +793,6 @@ class Engine : public EngineBase {
     a.flags = flags;
     a.vsrc = 0;
     return a;
-  }
-
-  // ||P(v)-v||^2, ||v||^2 of the vector sitting in scr_v_ into partial slots dst, dst+NB
-  void feasibility_of_scratch(SetState<T>& s, double* dst, bool have_sums = false) {
-    ProjScalars<T>* ps = s.psf;
-    if (s.two_pass) {
-      if (!have_sums) K<T>::ps_reduce(stream_, s.Mpad, scr_v_, ps, part_tmp_, maxpart_);
-      if (s.prox == PX_L1) K<T>::l1_theta(stream_, s.Mpad, scr_v_, ps, s.phi, part_tmp_, maxpart_, scr_c_);
-      else K<T>::ps_finish(stream_, part_tmp_, maxpart_, ps, s.prox, s.plo, s.phi, s.Mtrue);
-    }
-    proj_dist_grid<T>(stream_, G_, s.nblk, s.dir, s.Mpad, scr_v_, s.prox, s.plo, s.phi, s.lb, s.ub,
-                      s.two_pass ? ps : nullptr, dst);
   }
 
   T feas_value(double fe, double ss) const {

@@ -32,6 +32,7 @@ struct EngineBase {
   virtual void get_Q(void* Q, int64_t* offsets, int* d) = 0;
   virtual double time_spmv(int reps) = 0;
   virtual void kernel_stats(int enable, int64_t* launches, double* total_ms) = 0;
+  virtual void debug_proj(int set, int which, double* out16) = 0;
   virtual void* stream() = 0;
   virtual void* dev_rhs() = 0;
   virtual void* dev_x() = 0;

@@ -4,14 +4,18 @@
 //   project_l1_Duchi!  src/projectors/project_l1_Duchi!.jl:21-52  -- the reference sorts all M
 //       magnitudes (RadixSort/QuickSort), takes a cumsum and scans serially for the threshold.
 //       Here theta solves  f(theta) = sum(max(|v|-theta,0)) - b = 0  (f convex, piecewise linear):
-//         1. the pass that materialises v also evaluates (S,C)(t) = (sum, count of |v| > t) at
-//            L1_K probe thresholds centred on the previous PARSDMM iteration's theta (registers only),
+//         1. ONE pass produces v on the fly (stencil of x, y, l -- nothing is stored), evaluates
+//            (S,C)(t) = (sum, count of |v| > t) at L1_K probe thresholds centred on the previous
+//            PARSDMM iteration's theta (registers only) and speculatively gathers the magnitudes in a
+//            narrow range around that theta through a per-workgroup LDS buffer (one global atomic
+//            per workgroup),
 //         2. a scalar kernel brackets the root between two probes and tightens the bracket with a
-//            Newton step from the left (Michelot) and the secant from the right,
-//         3. one sparse compaction pass gathers the few magnitudes inside the bracket and the
-//            exact (S,C) above it,
-//         4. a single workgroup runs Michelot's fixed-point iteration on them: exact theta in float64.
-//       A gated extra probe pass handles cold starts.
+//            Newton step from the left (Michelot) and the secant from the right; if the bracket lies
+//            inside the speculative range the gathered values are all that is needed,
+//         3. otherwise (cold start / theta moved a lot) gated fallback passes refine the bracket and
+//            gather it explicitly,
+//         4. a single workgroup runs Michelot's fixed-point iteration on the gathered values:
+//            exact theta in float64.
 //   project_l2!        src/projectors/project_l2!.jl:3-16
 //   project_annulus!   src/projectors/project_annulus!.jl:3-21
 #include <stdexcept>
@@ -21,93 +25,150 @@
 
 namespace sipx {
 
-constexpr long long L1_CAP = 1 << 17;    // bracket population above which one more probe pass is run
-constexpr int SL_ABOVE_S = PREP_SLOTS, SL_ABOVE_C = PREP_SLOTS + 1;   // partial slots of the compaction pass
+constexpr double L1_CAP = 131072.0;     // bracket population above which one more probe pass is run
+constexpr int SPEC_CAP = 1024;           // per-workgroup LDS buffer of the speculative compaction
+constexpr int SL_ABOVE_S = PREP_SLOTS, SL_ABOVE_C = PREP_SLOTS + 1;   // partial slots of the fallback compaction
+enum { M_FIRST = 0, M_PROBE = 1, M_COMPACT = 2, M_DIST = 3 };
 
-// ||v||_1, ||v||_2^2, nnz, probe sums (slots 0..PREP_SLOTS-1) and per-block max|v| of a stored vector.
-template <typename T>
-__global__ __launch_bounds__(BLOCK) void k_ps_reduce(long long len, const T* __restrict__ v,
-                                                     const ProjScalars<T>* __restrict__ ps, int gated,
-                                                     double* __restrict__ partials, T* __restrict__ maxpart) {
-  if (gated && !(ps->need && ps->refine)) return;
+// One pass over the vector.  SRC 0: stored array (V == 1); SRC 1: produced on the fly by a set.
+template <typename T, int V, int MODE, int SRC>
+__global__ __launch_bounds__(BLOCK) void k_pass(Grid G, SetArgs<T> a, int v_is_s, const T* __restrict__ varr,
+                                                long long len, ProjScalars<T>* ps, T* __restrict__ compact,
+                                                double* __restrict__ partials, T* __restrict__ maxpart) {
+  if (MODE == M_PROBE && !(ps->need && !ps->spec_ok && ps->refine)) return;
+  if (MODE == M_COMPACT && !(ps->need && !ps->spec_ok)) return;
+  __shared__ T sbuf[(MODE == M_FIRST || MODE == M_COMPACT) ? SPEC_CAP : 1];
+  __shared__ unsigned int scnt, sused;     // reserved / actually filled prefix of sbuf
+  __shared__ int sovf;
+  __shared__ unsigned long long sbase;
   double acc[PREP_SLOTS];
 #pragma unroll
   for (int k = 0; k < PREP_SLOTS; ++k) acc[k] = 0;
   double t[L1_K];
 #pragma unroll
-  for (int k = 0; k < L1_K; ++k) t[k] = ps ? ps->t[k] : INFINITY;
+  for (int k = 0; k < L1_K; ++k) t[k] = (a.prox == PX_L1 && MODE <= M_PROBE) ? ps->t[k] : INFINITY;
+  double r_lo = 0, r_hi = -1;      // gather range (lo, hi]
+  if (MODE == M_FIRST && a.prox == PX_L1 && !(a.flags & F_NOSPEC)) { r_lo = ps->spec_lo; r_hi = ps->spec_hi; }
+  if (MODE == M_COMPACT) { r_lo = ps->lo; r_hi = ps->hi; }
+  const bool gather = r_hi > r_lo;
   T vmax = T(0);
-  for (long long e = (long long)blockIdx.x * BLOCK + threadIdx.x; e < len; e += (long long)NB * BLOCK) {
-    const T x = v[e], av = fabs(x);
-    probe_acc<T>(av, x, t, acc);
-    vmax = av > vmax ? av : vmax;
+  if (MODE == M_FIRST || MODE == M_COMPACT) {
+    if (threadIdx.x == 0) { scnt = 0; sused = 0; sovf = 0; }
+    __syncthreads();
   }
-  block_reduce_store<PREP_SLOTS>(acc, partials, 0);
-  if (!gated) block_max_store<T>(vmax, maxpart);
-}
-template <typename T>
-void K<T>::ps_reduce(hipStream_t s, long long len, const T* v, const ProjScalars<T>* ps, double* partials, T* maxpart) {
-  hipLaunchKernelGGL((k_ps_reduce<T>), dim3(NB), dim3(BLOCK), 0, s, len, v, ps, 0, partials, maxpart);
-  SIPX_HIP(hipGetLastError());
-}
+  ProxCtx<T> pc;
+  if (MODE == M_DIST) pc = make_prox<T>(a.prox, a.plo, a.phi, T(0), ps);
+  const int lane = threadIdx.x & 63;
 
-template <typename T>
-__device__ __forceinline__ T block_max_partials(const T* __restrict__ maxpart) {
-  __shared__ T smax[BLOCK / 64];
-  T vmax = T(0);
-  for (int i = threadIdx.x; i < NB; i += BLOCK) vmax = maxpart[i] > vmax ? maxpart[i] : vmax;
-  vmax = wave_max<T>(vmax);
-  __syncthreads();
-  if ((threadIdx.x & 63) == 0) smax[threadIdx.x >> 6] = vmax;
-  __syncthreads();
-  for (int i = 0; i < BLOCK / 64; ++i) vmax = smax[i] > vmax ? smax[i] : vmax;
-  return vmax;
-}
-
-template <typename T>
-__global__ __launch_bounds__(BLOCK) void k_ps_finish(const double* __restrict__ partials, const T* __restrict__ maxpart,
-                                                     ProjScalars<T>* ps, int prox, T pmin, T pmax, long long true_len) {
-  const double asum = block_sum_partials(partials);
-  const double sumsq = block_sum_partials(partials + NB);
-  const T vmax = block_max_partials<T>(maxpart);
-  if (threadIdx.x == 0) {
-    ps->asum = asum;
-    ps->sumsq = sumsq;
-    ps->vmax = vmax;
-    ps->need = 0;
-    ps->theta = T(0);
-    ps->scale = T(1);
-    ps->fill = 0;
-    ps->tau = T(0);
-    ps->quota = 0x7fffffffffffffffll;
-    if (prox == PX_L2) {
-      const T nl2 = (T)sqrt(sumsq);                      // project_l2!.jl:8-13
-      if (!(nl2 <= pmax)) {
-        ps->need = 1;
-        ps->scale = pmax / nl2;
+  auto body = [&](T x) {
+    const T av = fabs(x);
+    const double ad = (double)av;
+    if (MODE == M_FIRST || MODE == M_PROBE) {
+      probe_acc<T>(av, x, t, acc);
+      vmax = av > vmax ? av : vmax;
+    }
+    if (MODE == M_COMPACT && ad > r_hi) {
+      acc[0] += ad;
+      acc[1] += 1.0;
+    }
+    if (MODE == M_DIST) {
+      const T pv = prox_apply<T>(pc, x, T(0), T(0), T(0), 0);
+      const T dlt = pv - x;
+      acc[0] += (double)dlt * (double)dlt;
+      acc[1] += (double)x * (double)x;
+    }
+    if ((MODE == M_FIRST || MODE == M_COMPACT) && gather) {
+      const bool in = ad > r_lo && ad <= r_hi;
+      const unsigned long long mask = __ballot(in);
+      if (mask) {
+        const int leader = __ffsll((long long)mask) - 1;
+        const int cnt = __popcll(mask);
+        const int my = __popcll(mask & ((1ull << lane) - 1ull));
+        unsigned int base = 0;
+        if (lane == leader) base = atomicAdd(&scnt, (unsigned int)cnt);
+        base = __shfl(base, leader, 64);
+        if (base + cnt <= SPEC_CAP) {                       // room in the workgroup's LDS buffer
+          if (in) sbuf[base + my] = av;
+          if (lane == leader) atomicMax(&sused, base + (unsigned int)cnt);
+        } else if (MODE == M_FIRST) {
+          sovf = 1;                                         // speculation gathered too much: give it up
+        } else {                                            // fallback compaction never drops: go to global memory
+          unsigned long long gb = 0;
+          if (lane == leader) gb = atomicAdd(&ps->n_compact, (unsigned long long)cnt);
+          gb = __shfl(gb, leader, 64);
+          if (in) compact[gb + my] = av;
+        }
       }
-    } else if (prox == PX_ANNULUS) {
-      const T nl2 = (T)sqrt(sumsq);                      // project_annulus!.jl:9-18
-      if (pmin <= nl2 && nl2 <= pmax) {
-      } else if (nl2 > pmax) {
-        ps->need = 1;
-        ps->scale = pmax / nl2;
-      } else if (nl2 < pmin && nl2 > T(0)) {
-        ps->need = 1;
-        ps->scale = pmin / nl2;
-      } else if (nl2 < pmin && nl2 == T(0)) {
-        ps->need = 1;
-        ps->fill = 1;                                    // sigma_min ./ sqrt(length(x)): Float64 sqrt of an Int
-        ps->scale = (T)((double)pmin / sqrt((double)true_len));
+    }
+  };
+
+  if (SRC == 0) {
+    for (long long e0 = (long long)blockIdx.x * BLOCK; e0 < len; e0 += (long long)NB * BLOCK) {
+      const long long e = e0 + threadIdx.x;
+      body(e < len ? varr[e] : T(0));        // uniform trip count: every lane takes part in the ballots
+    }
+  } else {
+    const bool ident = a.nblk == 0;
+    const int nb = ident ? 1 : a.nblk;
+    const bool relax = !(a.gamma == T(1));
+    const T gam = a.gamma, omg = T(1) - a.gamma;
+    const long long nvec = G.N / V;
+    const long long nit = (nvec + (long long)NB * BLOCK - 1) / ((long long)NB * BLOCK);
+    for (long long it = 0; it < nit; ++it) {
+      const long long vi = it * NB * BLOCK + (long long)blockIdx.x * BLOCK + threadIdx.x;
+      const bool live = vi < nvec;
+      const long long g = live ? vi * V : 0;
+      const Coord c = coords(G, g);
+      const Vec<T, V> xc = ldv<T, V>(a.x + g);
+      for (int q = 0; q < nb; ++q) {
+        const long long e = (long long)q * G.N + g;
+        T s[V];
+        bool valid[V];
+        if (ident) {
+#pragma unroll
+          for (int k = 0; k < V; ++k) { s[k] = xc.v[k]; valid[k] = true; }
+        } else {
+          fwd_dir<T, V>(G, a.x, xc, g, c, a.dir[q], a.ih[q], s, valid);
+        }
+        T out[V];
+        if (v_is_s) {
+#pragma unroll
+          for (int k = 0; k < V; ++k) out[k] = s[k];
+        } else {
+          const Vec<T, V> yv = ldv<T, V>(a.y + e), lv = ldv<T, V>(a.l + e);
+#pragma unroll
+          for (int k = 0; k < V; ++k) {
+            const T xh = relax ? (gam * s[k] + omg * yv.v[k]) : s[k];       // update_y_l.jl:72
+            out[k] = valid[k] ? (xh - lv.v[k] * a.rho1) : T(0);            // :67 / :74
+          }
+        }
+#pragma unroll
+        for (int k = 0; k < V; ++k) body(live ? out[k] : T(0));
       }
     }
   }
-}
-template <typename T>
-void K<T>::ps_finish(hipStream_t s, const double* partials, const T* maxpart, ProjScalars<T>* ps, int prox, T pmin,
-                     T pmax, long long true_len) {
-  hipLaunchKernelGGL((k_ps_finish<T>), dim3(1), dim3(BLOCK), 0, s, partials, maxpart, ps, prox, pmin, pmax, true_len);
-  SIPX_HIP(hipGetLastError());
+
+  if (MODE == M_FIRST || MODE == M_PROBE) {
+    block_reduce_store<PREP_SLOTS>(acc, partials, 0);
+    if (MODE == M_FIRST) block_max_store<T>(vmax, maxpart);
+  } else if (MODE == M_COMPACT) {
+    double a2[2] = {acc[0], acc[1]};
+    block_reduce_store<2>(a2, partials, SL_ABOVE_S);
+  } else {
+    double a2[2] = {acc[0], acc[1]};
+    block_reduce_store<2>(a2, partials, 0);
+  }
+  if ((MODE == M_FIRST || MODE == M_COMPACT) && gather) {   // flush the workgroup's buffer: one global atomic
+    __syncthreads();
+    // reservations grow monotonically, so the stored entries form the prefix [0, sused)
+    const unsigned int cnt = sused;
+    if (threadIdx.x == 0) {
+      sbase = cnt ? atomicAdd(&ps->n_compact, (unsigned long long)cnt) : 0ull;
+      if (MODE == M_FIRST && sovf) atomicOr(&ps->spec_overflow, 1);
+    }
+    __syncthreads();
+    for (unsigned int i = threadIdx.x; i < cnt; i += BLOCK) compact[sbase + i] = sbuf[i];
+  }
 }
 
 template <typename T>
@@ -123,6 +184,11 @@ __global__ void k_ps_init(ProjScalars<T>* ps) {
   ps->refine = 0;
   ps->theta_prev = 0;
   ps->n_compact = 0;
+  ps->spec_lo = 0;
+  ps->spec_hi = -1;
+  ps->s_above = ps->c_above = 0;
+  ps->hw = 1e-2;
+  ps->spec_ok = ps->spec_overflow = 0;
   ps->tau = T(0);
   ps->quota = 0x7fffffffffffffffll;
 }
@@ -132,68 +198,106 @@ void K<T>::ps_init(hipStream_t s, ProjScalars<T>* ps) {
   SIPX_HIP(hipGetLastError());
 }
 
-// ---------------------------------------------------------------------------------------------
-// Bracket of the l1 threshold from the probe sums.  STAGE 0: first decision after the fused
-// probe (thresholds around theta_prev); STAGE 1: after the gated refinement pass.
-template <typename T, int STAGE>
-__global__ __launch_bounds__(BLOCK) void k_l1_decide(const double* __restrict__ partials, const T* __restrict__ maxpart,
-                                                     ProjScalars<T>* ps, T radius) {
-  if (STAGE == 1 && !(ps->need && ps->refine)) return;
-  __shared__ double red[PREP_SLOTS];
+// Sums of all PREP_SLOTS partial slots by one 1024-thread workgroup: every thread issues its
+// PREP_SLOTS*NB/1024 independent loads up front (two per slot), then the slots are reduced wave -> LDS.
+__device__ __forceinline__ void reduce_slots(const double* __restrict__ partials, double* red /*LDS, PREP_SLOTS*/) {
+  static_assert(NB % 1024 == 0, "NB must be a multiple of the reducing workgroup");
+  constexpr int PER = NB / 1024;
+  __shared__ double sm[PREP_SLOTS][16];
+  double v[PREP_SLOTS];
+#pragma unroll
   for (int k = 0; k < PREP_SLOTS; ++k) {
-    const double s = block_sum_partials(partials + (long long)k * NB);
-    if (threadIdx.x == 0) red[k] = s;
+    double a = 0;
+#pragma unroll
+    for (int j = 0; j < PER; ++j) a += partials[(long long)k * NB + j * 1024 + threadIdx.x];
+    v[k] = a;
   }
+  const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+#pragma unroll
+  for (int k = 0; k < PREP_SLOTS; ++k) {
+    const double r = wave_sum(v[k]);
+    if (lane == 0) sm[k][w] = r;
+  }
+  __syncthreads();
+  if (threadIdx.x < PREP_SLOTS) {
+    double r = 0;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) r += sm[threadIdx.x][i];
+    red[threadIdx.x] = r;
+  }
+}
+
+// Scalar decisions after a probe pass.  STAGE 0: after the first pass; STAGE 1: after the gated refinement.
+template <typename T, int STAGE>
+__global__ __launch_bounds__(1024) void k_decide(const double* __restrict__ partials, const T* __restrict__ maxpart,
+                                                 ProjScalars<T>* ps, int prox, T pmin, T pmax, long long true_len,
+                                                 int nospec) {
+  if (STAGE == 1 && !(ps->need && !ps->spec_ok && ps->refine)) return;
+  __shared__ double red[PREP_SLOTS];
+  __shared__ T smax[16];
+  reduce_slots(partials, red);
   T vmax = T(0);
-  if (STAGE == 0) vmax = block_max_partials<T>(maxpart);
+  if (STAGE == 0) {
+    for (int i = threadIdx.x; i < NB; i += 1024) vmax = maxpart[i] > vmax ? maxpart[i] : vmax;
+    vmax = wave_max<T>(vmax);
+    if ((threadIdx.x & 63) == 0) smax[threadIdx.x >> 6] = vmax;
+  }
   __syncthreads();
   if (threadIdx.x != 0) return;
-  const double b = (double)radius;
   if (STAGE == 0) {
+    for (int i = 0; i < 16; ++i) vmax = smax[i] > vmax ? smax[i] : vmax;
     ps->asum = red[0];
     ps->sumsq = red[1];
     ps->vmax = vmax;
+    ps->need = 0;
+    ps->theta = T(0);
     ps->scale = T(1);
     ps->fill = 0;
-    ps->n_compact = 0;
     ps->refine = 0;
-    ps->need = ((T)red[0] <= radius) ? 0 : 1;          // norm(v,1) <= b && return v   project_l1_Duchi!.jl:23
+    ps->spec_ok = 0;
+    if (prox == PX_L2) {
+      const T nl2 = (T)sqrt(red[1]);                     // project_l2!.jl:8-13
+      if (!(nl2 <= pmax)) { ps->need = 1; ps->scale = pmax / nl2; }
+      return;
+    }
+    if (prox == PX_ANNULUS) {
+      const T nl2 = (T)sqrt(red[1]);                     // project_annulus!.jl:9-18
+      if (pmin <= nl2 && nl2 <= pmax) {
+      } else if (nl2 > pmax) { ps->need = 1; ps->scale = pmax / nl2; }
+      else if (nl2 < pmin && nl2 > T(0)) { ps->need = 1; ps->scale = pmin / nl2; }
+      else if (nl2 < pmin && nl2 == T(0)) {              // sigma_min ./ sqrt(length(x)): Float64 sqrt of an Int
+        ps->need = 1; ps->fill = 1;
+        ps->scale = (T)((double)pmin / sqrt((double)true_len));
+      }
+      return;
+    }
+    ps->need = ((T)red[0] <= pmax) ? 0 : 1;              // norm(v,1) <= b && return v   project_l1_Duchi!.jl:23
     if (!ps->need) {
-      ps->theta = T(0);
+      ps->n_compact = 0;
+      ps->spec_overflow = 0;
       return;
     }
   } else {
     vmax = ps->vmax;
   }
-  // candidates: virtual t=0 (S=||v||_1, C=nnz) then the probes, ascending
+  const double b = (double)pmax;
+  // candidates: virtual t=0 (S=||v||_1, C=nnz), the probes, virtual t=vmax (S=C=0)
   double tl = 0, Sl = ps->asum, Cl = red[2], fl = ps->asum - b;
-  double th = (double)vmax, Sh = 0, Ch = 0, fh = -b;
-  (void)Sh;
-  if (STAGE == 1) {                                    // known outer bracket from stage 0
-    tl = ps->lo;
-    th = ps->hi;
-    fl = INFINITY;                                     // replaced by the first probe (== lo) below
-  }
-  bool have_l = STAGE == 0, have_h = STAGE == 0;     // stage 0: f(vmax) = -b is exact
+  double th = (double)vmax, Ch = 0, fh = -b;
+  bool have_l = STAGE == 0, have_h = STAGE == 0;
+  if (STAGE == 1) { tl = ps->lo; th = ps->hi; fl = INFINITY; }
   for (int k = 0; k < L1_K; ++k) {
     const double t = ps->t[k];
     if (!(t < INFINITY)) continue;
     const double S = red[3 + k], C = red[3 + L1_K + k];
     const double f = S - t * C - b;
     if (f >= 0) {
-      if (!have_l || t >= tl) {
-        tl = t; Sl = S; Cl = C; fl = f;
-        have_l = true;
-      }
+      if (!have_l || t >= tl) { tl = t; Sl = S; Cl = C; fl = f; have_l = true; }
     } else if (t < th || (!have_h && t <= th)) {
-      th = t; Sh = S; Ch = C; fh = f;
-      have_h = true;
+      th = t; Ch = C; fh = f; have_h = true;
     }
   }
-  if (!have_l) {                                       // rounding pushed f(lo) below zero: fall back to t = 0
-    tl = 0; Sl = ps->asum; Cl = red[2]; fl = ps->asum - b;
-    ps->t[0] = INFINITY;
-  }
+  if (!have_l) { tl = 0; Sl = ps->asum; Cl = red[2]; fl = ps->asum - b; }
   // Newton from the left (Michelot step) and secant from the right: theta* in [thN, thS]
   double thN = Cl > 0 ? (Sl - b) / Cl : tl;
   if (!(thN >= tl)) thN = tl;
@@ -201,147 +305,194 @@ __global__ __launch_bounds__(BLOCK) void k_l1_decide(const double* __restrict__ 
   if (have_h && fl < INFINITY && fl - fh > 0) thS = tl + fl * (th - tl) / (fl - fh);
   if (!(thS <= th)) thS = th;
   if (!(thS >= thN)) thS = th;
-  const double lo = thN * (1.0 - 1e-9);
-  const double hi = thS * (1.0 + 1e-9) + 1e-300;
-  ps->lo = lo > tl ? lo : tl;
-  ps->hi = hi < th ? hi : th;
-  const double n_est = Cl - Ch;
-  if (STAGE == 0 && n_est > (double)L1_CAP) {          // cold start: subdivide [lo, hi] once more
-    ps->refine = 1;
-    for (int k = 0; k < L1_K; ++k) ps->t[k] = ps->lo + (ps->hi - ps->lo) * (double)k / (double)(L1_K - 1);
+  double lo = thN * (1.0 - 1e-9), hi = thS * (1.0 + 1e-9) + 1e-300;
+  lo = lo > tl ? lo : tl;
+  hi = hi < th ? hi : th;
+  ps->lo = lo;
+  ps->hi = hi;
+  if (STAGE == 0) {
+    // speculative gather usable?  range edges are probes 0 and L1_K-1, so (S,C) above it are known
+    const bool spec = !nospec && ps->spec_hi > ps->spec_lo && !ps->spec_overflow && lo >= ps->spec_lo && hi <= ps->spec_hi;
+    if (spec) {
+      ps->spec_ok = 1;
+      ps->s_above = red[3 + L1_K - 1];
+      ps->c_above = red[3 + 2 * L1_K - 1];
+      return;
+    }
+    ps->n_compact = 0;                                   // discard what the speculation gathered
+    if (Cl - Ch > L1_CAP) {                              // cold start: subdivide [lo, hi] once more
+      ps->refine = 1;
+      for (int k = 0; k < L1_K; ++k) ps->t[k] = lo + (hi - lo) * (double)k / (double)(L1_K - 1);
+    }
   } else {
     ps->refine = 0;
   }
 }
 
-// Gathers the magnitudes in (lo, hi] and reduces (S,C) of those above hi.
-template <typename T>
-__global__ __launch_bounds__(BLOCK) void k_l1_compact(long long len, const T* __restrict__ v, ProjScalars<T>* ps,
-                                                      T* __restrict__ compact, double* __restrict__ partials) {
-  if (!ps->need) return;
-  const double lo = ps->lo, hi = ps->hi;
-  double acc[2] = {0, 0};
-  for (long long e0 = (long long)blockIdx.x * BLOCK; e0 < len; e0 += (long long)NB * BLOCK) {
-    const long long e = e0 + threadIdx.x;
-    const T av = e < len ? fabs(v[e]) : T(0);
-    const double a = (double)av;
-    if (a > hi) {
-      acc[0] += a;
-      acc[1] += 1.0;
-    }
-    const bool in = a > lo && a <= hi;
-    const unsigned long long mask = __ballot(in);
-    if (mask) {
-      const int lane = threadIdx.x & 63;
-      unsigned long long base = 0;
-      if (lane == 0) base = atomicAdd(&ps->n_compact, (unsigned long long)__popcll(mask));
-      base = __shfl(base, 0, 64);
-      if (in) compact[base + __popcll(mask & ((1ull << lane) - 1ull))] = av;
-    }
-  }
-  block_reduce_store<2>(acc, partials, SL_ABOVE_S);
-}
-
-// Michelot's iteration on the compacted magnitudes: theta <- (S_above + S_in(>theta) - b) / (C_above + C_in(>theta)),
+// Michelot's iteration on the gathered magnitudes: theta <- (S_above + S_in(>theta) - b) / (C_above + C_in(>theta)),
 // monotone from the bracket's lower end, exact after finitely many steps (stops when the active count repeats).
+// Then prepares the next call: probes and speculative range centred on the new theta.
 template <typename T>
 __global__ __launch_bounds__(1024) void k_l1_solve(ProjScalars<T>* ps, T radius, const T* __restrict__ compact,
                                                    const double* __restrict__ partials) {
-  if (!ps->need) return;
   __shared__ double ssum[16];
   __shared__ double scnt[16];
   __shared__ double sh_theta, sh_sa, sh_ca;
   __shared__ int sh_done;
-  {   // (S,C) above the bracket: sum the compaction pass's block partials
-    double s = 0, c = 0;
-    for (int i = threadIdx.x; i < NB; i += 1024) {
-      s += partials[(long long)SL_ABOVE_S * NB + i];
-      c += partials[(long long)SL_ABOVE_C * NB + i];
-    }
-    s = wave_sum(s);
-    c = wave_sum(c);
-    if ((threadIdx.x & 63) == 0) {
-      ssum[threadIdx.x >> 6] = s;
-      scnt[threadIdx.x >> 6] = c;
-    }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-      double S = 0, Cc = 0;
-      for (int i = 0; i < 16; ++i) {
-        S += ssum[i];
-        Cc += scnt[i];
+  const int need = ps->need;
+  double theta = 0;
+  int iters_done = 0;
+  if (need) {
+    if (ps->spec_ok) {
+      if (threadIdx.x == 0) { sh_sa = ps->s_above; sh_ca = ps->c_above; }
+    } else {   // (S,C) above the bracket: block partials of the fallback compaction pass
+      double s = 0, c = 0;
+      for (int i = threadIdx.x; i < NB; i += 1024) {
+        s += partials[(long long)SL_ABOVE_S * NB + i];
+        c += partials[(long long)SL_ABOVE_C * NB + i];
       }
-      sh_sa = S;
-      sh_ca = Cc;
-    }
-    __syncthreads();
-  }
-  const long long n = (long long)ps->n_compact;
-  const double sa = sh_sa, ca = sh_ca, b = (double)radius;
-  double theta = ps->lo;
-  double cprev = -1;
-  for (int it = 0; it < 200; ++it) {
-    double s = 0, c = 0;
-    for (long long e = threadIdx.x; e < n; e += 1024) {
-      const double av = (double)compact[e];
-      if (av > theta) {
-        s += av;
-        c += 1.0;
+      s = wave_sum(s);
+      c = wave_sum(c);
+      if ((threadIdx.x & 63) == 0) { ssum[threadIdx.x >> 6] = s; scnt[threadIdx.x >> 6] = c; }
+      __syncthreads();
+      if (threadIdx.x == 0) {
+        double S = 0, Cc = 0;
+        for (int i = 0; i < 16; ++i) { S += ssum[i]; Cc += scnt[i]; }
+        sh_sa = S; sh_ca = Cc;
       }
     }
-    s = wave_sum(s);
-    c = wave_sum(c);
     __syncthreads();
-    if ((threadIdx.x & 63) == 0) {
-      ssum[threadIdx.x >> 6] = s;
-      scnt[threadIdx.x >> 6] = c;
-    }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-      double S = 0, Cc = 0;
-      for (int i = 0; i < 16; ++i) {
-        S += ssum[i];
-        Cc += scnt[i];
+    const long long n = (long long)ps->n_compact;
+    const double sa = sh_sa, ca = sh_ca, b = (double)radius;
+    theta = ps->lo;
+    double cprev = -1;
+    for (int it = 0; it < 200; ++it) {
+      double s = 0, c = 0;
+      for (long long e = threadIdx.x; e < n; e += 1024) {
+        const double av = (double)compact[e];
+        if (av > theta) { s += av; c += 1.0; }
       }
-      const double tot = ca + Cc;
-      double tn = theta;
-      if (tot > 0) tn = (sa + S - b) / tot;
-      sh_done = (Cc == cprev || !(tot > 0)) ? 1 : 0;
-      sh_theta = tn > theta ? tn : theta;
-      scnt[0] = Cc;
+      s = wave_sum(s);
+      c = wave_sum(c);
+      __syncthreads();
+      if ((threadIdx.x & 63) == 0) { ssum[threadIdx.x >> 6] = s; scnt[threadIdx.x >> 6] = c; }
+      __syncthreads();
+      if (threadIdx.x == 0) {
+        double S = 0, Cc = 0;
+        for (int i = 0; i < 16; ++i) { S += ssum[i]; Cc += scnt[i]; }
+        const double tot = ca + Cc;
+        double tn = theta;
+        if (tot > 0) tn = (sa + S - b) / tot;
+        sh_done = (Cc == cprev || !(tot > 0)) ? 1 : 0;
+        sh_theta = tn > theta ? tn : theta;
+        scnt[0] = Cc;
+      }
+      __syncthreads();
+      theta = sh_theta;
+      cprev = scnt[0];
+      iters_done = it + 1;
+      if (sh_done) break;
     }
-    __syncthreads();
-    theta = sh_theta;
-    cprev = scnt[0];
-    if (sh_done) break;
   }
   if (threadIdx.x == 0) {
-    const T th = (T)theta;
-    ps->theta = th > T(0) ? th : T(0);       // theta = max(0, .)   project_l1_Duchi!.jl:46
-    if (theta > 0) {
-      ps->theta_prev = theta;                // warm start of the next probe: thresholds around theta
-      const double mult[L1_K] = {0.5, 0.9, 0.99, 0.999, 1.001, 1.01, 1.1, 2.0};
-      for (int k = 0; k < L1_K; ++k) ps->t[k] = theta * mult[k];
+    if (need) {
+      const T th = (T)theta;
+      ps->theta = th > T(0) ? th : T(0);       // theta = max(0, .)   project_l1_Duchi!.jl:46
     }
+    ps->dbg[0] = (double)ps->n_compact; ps->dbg[1] = ps->spec_overflow; ps->dbg[2] = ps->spec_ok; ps->dbg[3] = iters_done;
+    // ---- state for the next call ----
+    if (need && theta > 0) {
+      double hw = ps->hw;
+      if (ps->theta_prev > 0) {
+        const double d = fabs(theta / ps->theta_prev - 1.0);
+        hw = 3.0 * d;                                  // theta moves slowly while rho, gamma stay put
+        hw = hw < 1e-3 ? 1e-3 : (hw > 1e-2 ? 1e-2 : hw);
+        if (ps->spec_overflow) hw = ps->hw * 0.5;      // the last range gathered too much
+      }
+      ps->hw = hw;
+      ps->theta_prev = theta;
+      const double m[L1_K] = {-1.0, -0.25, -1.0 / 16, -1.0 / 64, 1.0 / 64, 1.0 / 16, 0.25, 1.0};
+      for (int k = 0; k < L1_K; ++k) ps->t[k] = theta * (1.0 + hw * m[k]);
+      ps->spec_lo = ps->t[0];
+      ps->spec_hi = ps->t[L1_K - 1];
+    } else if (ps->theta_prev > 0) {            // inside the ball now: keep probing around the last theta
+      const double m[L1_K] = {-1.0, -0.25, -1.0 / 16, -1.0 / 64, 1.0 / 64, 1.0 / 16, 0.25, 1.0};
+      for (int k = 0; k < L1_K; ++k) ps->t[k] = ps->theta_prev * (1.0 + ps->hw * m[k]);
+      ps->spec_lo = ps->t[0];
+      ps->spec_hi = ps->t[L1_K - 1];
+    }
+    ps->n_compact = 0;
+    ps->spec_overflow = 0;
   }
 }
 
+template <typename T, int SRC>
+static void launch_chain(hipStream_t s, const Grid& g, const SetArgs<T>& a, int v_is_s, const T* varr, long long len,
+                         ProjScalars<T>* ps, double* partials, T* maxpart, T* compact, long long true_len) {
+  const bool vec = SRC == 1 && g.n[0] % 4 == 0;
+#define SIPX_PASS(MODE)                                                                                            \
+  do {                                                                                                             \
+    if (vec)                                                                                                       \
+      hipLaunchKernelGGL((k_pass<T, 4, MODE, SRC>), dim3(NB), dim3(BLOCK), 0, s, g, a, v_is_s, varr, len, ps, compact, \
+                         partials, maxpart);                                                                       \
+    else                                                                                                           \
+      hipLaunchKernelGGL((k_pass<T, 1, MODE, SRC>), dim3(NB), dim3(BLOCK), 0, s, g, a, v_is_s, varr, len, ps, compact, \
+                         partials, maxpart);                                                                       \
+  } while (0)
+  SIPX_PASS(M_FIRST);
+  hipLaunchKernelGGL((k_decide<T, 0>), dim3(1), dim3(1024), 0, s, partials, maxpart, ps, a.prox, a.plo, a.phi, true_len,
+                     (a.flags & F_NOSPEC) ? 1 : 0);
+  if (a.prox == PX_L1) {
+    SIPX_PASS(M_PROBE);
+    hipLaunchKernelGGL((k_decide<T, 1>), dim3(1), dim3(1024), 0, s, partials, maxpart, ps, a.prox, a.plo, a.phi, true_len, 0);
+    SIPX_PASS(M_COMPACT);
+    hipLaunchKernelGGL((k_l1_solve<T>), dim3(1), dim3(1024), 0, s, ps, a.phi, compact, partials);
+  }
+#undef SIPX_PASS
+  SIPX_HIP(hipGetLastError());
+}
+
 template <typename T>
-void K<T>::l1_theta(hipStream_t s, long long len, const T* v, ProjScalars<T>* ps, T radius, double* partials,
-                    const T* maxpart, T* compact) {
-  hipLaunchKernelGGL((k_l1_decide<T, 0>), dim3(1), dim3(BLOCK), 0, s, partials, maxpart, ps, radius);
-  hipLaunchKernelGGL((k_ps_reduce<T>), dim3(NB), dim3(BLOCK), 0, s, len, v, ps, 1, partials, (T*)nullptr);
-  hipLaunchKernelGGL((k_l1_decide<T, 1>), dim3(1), dim3(BLOCK), 0, s, partials, maxpart, ps, radius);
-  hipLaunchKernelGGL((k_l1_compact<T>), dim3(NB), dim3(BLOCK), 0, s, len, v, ps, compact, partials);
-  hipLaunchKernelGGL((k_l1_solve<T>), dim3(1), dim3(1024), 0, s, ps, radius, compact, partials);
+void K<T>::proj_scalars_set(hipStream_t s, const Grid& g, const SetArgs<T>& a, int v_is_s, ProjScalars<T>* ps,
+                            double* partials, T* maxpart, T* compact, long long true_len) {
+  SetArgs<T> b = a;
+  b.ps = ps;
+  launch_chain<T, 1>(s, g, b, v_is_s, nullptr, 0, ps, partials, maxpart, compact, true_len);
+}
+template <typename T>
+void K<T>::proj_scalars_arr(hipStream_t s, long long len, const T* v, int prox, T pmin, T pmax, ProjScalars<T>* ps,
+                            double* partials, T* maxpart, T* compact, long long true_len) {
+  SetArgs<T> a = {};
+  a.prox = prox;
+  a.plo = pmin;
+  a.phi = pmax;
+  a.ps = ps;
+  Grid g = {};
+  g.n[0] = len; g.n[1] = 1; g.n[2] = 1; g.N = len; g.st[0] = 1; g.st[1] = len; g.st[2] = len;
+  launch_chain<T, 0>(s, g, a, 0, v, len, ps, partials, maxpart, compact, true_len);
+}
+template <typename T>
+void K<T>::proj_dist_set(hipStream_t s, const Grid& g, const SetArgs<T>& a, int v_is_s, const ProjScalars<T>* ps,
+                         double* dst) {
+  SetArgs<T> b = a;
+  b.ps = ps;
+  ProjScalars<T>* psm = const_cast<ProjScalars<T>*>(ps);
+  if (g.n[0] % 4 == 0)
+    hipLaunchKernelGGL((k_pass<T, 4, M_DIST, 1>), dim3(NB), dim3(BLOCK), 0, s, g, b, v_is_s, (const T*)nullptr, 0ll, psm,
+                       (T*)nullptr, dst, (T*)nullptr);
+  else
+    hipLaunchKernelGGL((k_pass<T, 1, M_DIST, 1>), dim3(NB), dim3(BLOCK), 0, s, g, b, v_is_s, (const T*)nullptr, 0ll, psm,
+                       (T*)nullptr, dst, (T*)nullptr);
   SIPX_HIP(hipGetLastError());
 }
 
 #define SIPX_INST(T)                                                                                              \
-  template void K<T>::ps_reduce(hipStream_t, long long, const T*, const ProjScalars<T>*, double*, T*);           \
-  template void K<T>::ps_finish(hipStream_t, const double*, const T*, ProjScalars<T>*, int, T, T, long long);    \
   template void K<T>::ps_init(hipStream_t, ProjScalars<T>*);                                                     \
-  template void K<T>::l1_theta(hipStream_t, long long, const T*, ProjScalars<T>*, T, double*, const T*, T*);
+  template void K<T>::proj_scalars_set(hipStream_t, const Grid&, const SetArgs<T>&, int, ProjScalars<T>*, double*, \
+                                       T*, T*, long long);                                                       \
+  template void K<T>::proj_scalars_arr(hipStream_t, long long, const T*, int, T, T, ProjScalars<T>*, double*, T*, \
+                                       T*, long long);                                                           \
+  template void K<T>::proj_dist_set(hipStream_t, const Grid&, const SetArgs<T>&, int, const ProjScalars<T>*, double*);
 SIPX_INST(float)
 SIPX_INST(double)
 

@@ -21,73 +21,6 @@
 
 namespace sipx {
 
-template <typename T>
-__device__ __forceinline__ T soft_thr(T v, T th) {
-  // sign(v) * max(abs(v) - th, 0)   (project_l1_Duchi!.jl:49, prox_l1!.jl:9)
-  T t = fabs(v) - th;
-  t = t > T(0) ? t : T(0);
-  return v > T(0) ? t : (v < T(0) ? -t : v);
-}
-
-template <typename T>
-struct ProxCtx {
-  int prox;
-  T plo, phi, rho, theta, scale, tau;
-  int fill;
-  long long idx_cut;
-};
-
-template <typename T>
-__device__ __forceinline__ ProxCtx<T> make_prox(int prox, T plo, T phi, T rho, const ProjScalars<T>* ps) {
-  ProxCtx<T> c;
-  c.prox = prox;
-  c.plo = plo;
-  c.phi = phi;
-  c.rho = rho;
-  c.theta = T(0);
-  c.scale = T(1);
-  c.tau = T(0);
-  c.fill = 0;
-  c.idx_cut = -1;
-  if (ps) {
-    c.theta = ps->theta;
-    c.scale = ps->scale;
-    c.fill = ps->fill;
-    c.tau = ps->tau;
-    c.idx_cut = ps->quota;
-  }
-  if (prox == PX_PROX_L1) c.theta = T(1) / phi;   // prox_l1!(x, constraint.max): threshold 1/rho
-  return c;
-}
-
-// One element of prox_i / P_i.  lb/ub: per-element bounds; m: distance-term centre; e: padded index.
-template <typename T>
-__device__ __forceinline__ T prox_apply(const ProxCtx<T>& c, T v, T lb, T ub, T m, long long e) {
-  switch (c.prox) {
-    case PX_BOUNDS: {                       // max(LB, min(x, UB))      project_bounds!.jl:9
-      T t = v < c.phi ? v : c.phi;
-      return c.plo > t ? c.plo : t;
-    }
-    case PX_BOUNDS_VEC: {                   // project_bounds!.jl:21-22
-      T t = v < ub ? v : ub;
-      return lb > t ? lb : t;
-    }
-    case PX_DIST:                           // (x*rho + m) / (rho + 1.0): Float64 division  prox_l2s!.jl:4
-      return (T)((double)(v * c.rho + m) / ((double)c.rho + 1.0));
-    case PX_L1:
-    case PX_PROX_L1:
-      return soft_thr(v, c.theta);
-    case PX_L2:
-    case PX_ANNULUS:                        // rmul!(x, sigma/nl2) or the constant fill  project_annulus!.jl:9-17
-      return c.fill ? c.scale : v * c.scale;
-    case PX_CARD: {                         // keep the k largest |v|, ties by lowest index
-      const T av = fabs(v);
-      return (av > c.tau || (av == c.tau && e <= c.idx_cut)) ? v : T(0);
-    }
-  }
-  return v;
-}
-
 // ---------------------------------------------------------------------------------------------
 // rhs = sum_i A_i'(rho_i y_i + l_i): every owned set in one pass, sets added in order
 // (rhs_compose.jl:24-31); algorithmic bytes (sum_i 2 M_i + N) * w.
@@ -261,74 +194,6 @@ void K<T>::yl(hipStream_t s, const Grid& g, const SetArgs<T>& a, double* partial
     hipLaunchKernelGGL((k_yl<T, 4>), dim3(NB), dim3(BLOCK), 0, s, g, a, partials);
   else
     hipLaunchKernelGGL((k_yl<T, 1>), dim3(NB), dim3(BLOCK), 0, s, g, a, partials);
-  SIPX_HIP(hipGetLastError());
-}
-
-// First pass of the two-pass projectors (l1-ball, l2, annulus, cardinality): materialise
-// v = x_hat - l/rho (or v = s = A x for the feasibility estimate) and reduce ||v||_1, ||v||_2^2, nnz,
-// max|v| and -- for the l1 ball -- the probe sums of the threshold search (kernels_proj.hip).
-template <typename T, int V>
-__global__ __launch_bounds__(BLOCK) void k_yl_prep(Grid G, SetArgs<T> a, double* __restrict__ partials,
-                                                   T* __restrict__ maxpart, int v_is_s) {
-  double acc[PREP_SLOTS];
-#pragma unroll
-  for (int k = 0; k < PREP_SLOTS; ++k) acc[k] = 0;
-  double t[L1_K];
-#pragma unroll
-  for (int k = 0; k < L1_K; ++k) t[k] = (a.prox == PX_L1) ? a.ps->t[k] : INFINITY;
-  T vmax = T(0);
-  const bool ident = a.nblk == 0;
-  const int nb = ident ? 1 : a.nblk;
-  const bool relax = !(a.gamma == T(1));
-  const T gam = a.gamma, omg = T(1) - a.gamma;
-  const long long nvec = G.N / V;
-  for (long long vi = (long long)blockIdx.x * BLOCK + threadIdx.x; vi < nvec; vi += (long long)NB * BLOCK) {
-    const long long g = vi * V;
-    const Coord c = coords(G, g);
-    const Vec<T, V> xc = ldv<T, V>(a.x + g);
-    for (int q = 0; q < nb; ++q) {
-      const long long e = (long long)q * G.N + g;
-      T s[V];
-      bool valid[V];
-      if (ident) {
-#pragma unroll
-        for (int k = 0; k < V; ++k) {
-          s[k] = xc.v[k];
-          valid[k] = true;
-        }
-      } else {
-        fwd_dir<T, V>(G, a.x, xc, g, c, a.dir[q], a.ih[q], s, valid);
-      }
-      Vec<T, V> out;
-      if (v_is_s) {
-#pragma unroll
-        for (int k = 0; k < V; ++k) out.v[k] = s[k];
-      } else {
-        const Vec<T, V> yv = ldv<T, V>(a.y + e), lv = ldv<T, V>(a.l + e);
-#pragma unroll
-        for (int k = 0; k < V; ++k) {
-          const T xh = relax ? (gam * s[k] + omg * yv.v[k]) : s[k];
-          out.v[k] = valid[k] ? (xh - lv.v[k] * a.rho1) : T(0);
-        }
-      }
-#pragma unroll
-      for (int k = 0; k < V; ++k) {
-        const T av = fabs(out.v[k]);
-        probe_acc<T>(av, out.v[k], t, acc);
-        vmax = av > vmax ? av : vmax;
-      }
-      stv<T, V>(a.v + e, out);
-    }
-  }
-  block_reduce_store<PREP_SLOTS>(acc, partials, 0);
-  block_max_store<T>(vmax, maxpart);
-}
-template <typename T>
-void K<T>::yl_prep(hipStream_t s, const Grid& g, const SetArgs<T>& a, double* partials, T* maxpart, int v_is_s) {
-  if (g.n[0] % 4 == 0)
-    hipLaunchKernelGGL((k_yl_prep<T, 4>), dim3(NB), dim3(BLOCK), 0, s, g, a, partials, maxpart, v_is_s);
-  else
-    hipLaunchKernelGGL((k_yl_prep<T, 1>), dim3(NB), dim3(BLOCK), 0, s, g, a, partials, maxpart, v_is_s);
   SIPX_HIP(hipGetLastError());
 }
 
@@ -549,7 +414,6 @@ void proj_apply_grid(hipStream_t s, const Grid& g, int nblk, const int* dir, lon
 #define SIPX_INST(T)                                                                                              \
   template void K<T>::rhs_compose(hipStream_t, const Grid&, const RhsArgs<T>&, T*, int);                         \
   template void K<T>::yl(hipStream_t, const Grid&, const SetArgs<T>&, double*);                                  \
-  template void K<T>::yl_prep(hipStream_t, const Grid&, const SetArgs<T>&, double*, T*, int);                    \
   template void K<T>::adj_norm(hipStream_t, const Grid&, const SetArgs<T>&, double*);                            \
   template void K<T>::fwd(hipStream_t, const Grid&, int, const int*, const T*, const T*, T*);                    \
   template void K<T>::adj(hipStream_t, const Grid&, int, const int*, const T*, const T*, T*);                    \

@@ -19,7 +19,7 @@ constexpr int PREP_SLOTS = 3 + 2 * L1_K;   // ||v||_1, ||v||_2^2, nnz, S_k, C_k
 enum { SL_RPRI = 0, SL_DY = 1, SL_HL = 2, SL_HH = 3, SL_LH = 4, SL_DL = 5, SL_GG = 6, SL_GL = 7,
        SL_FE = 8, SL_SS = 9, SL_OBJ = 10, SL_EVO = 11, SL_XX = 12 };
 
-enum { F_FEAS = 1, F_BB = 2, F_FIRST = 4 };
+enum { F_FEAS = 1, F_BB = 2, F_FIRST = 4, F_NOSPEC = 8 /* rho/gamma just changed: skip the speculative gather */ };
 
 // internal prox kinds (public SIPX_PROJ_* plus the distance term)
 enum { PX_BOUNDS = 0, PX_BOUNDS_VEC = 1, PX_L1 = 2, PX_L2 = 3, PX_ANNULUS = 4, PX_CARD = 5, PX_PROX_L1 = 6,
@@ -54,6 +54,13 @@ struct ProjScalars {
   int refine;         // 1: bracket still holds too many elements -> one more probe pass
   double theta_prev;  // last non-zero theta (centre of the next probe)
   unsigned long long n_compact;
+  // speculative compaction fused into the first pass: magnitudes in (spec_lo, spec_hi] are gathered
+  // while v is produced; valid when the final bracket lies inside that range
+  double spec_lo, spec_hi;
+  double s_above, c_above;   // (sum, count) of |v| > spec_hi from the probe
+  double hw;                 // relative half-width of the next speculative range
+  int spec_ok, spec_overflow;
+  double dbg[4];             // diagnostics of the last search: gathered count, overflow, spec_ok, Michelot iterations
   // cardinality
   T tau;              // k-th largest magnitude
   long long quota;    // entries equal to tau are kept iff their padded index <= quota (idx cut)
@@ -123,19 +130,21 @@ struct K {
   // sets
   static void rhs_compose(hipStream_t s, const Grid& g, const RhsArgs<T>& a, T* rhs, int accumulate);
   static void yl(hipStream_t s, const Grid& g, const SetArgs<T>& a, double* partials);
-  static void yl_prep(hipStream_t s, const Grid& g, const SetArgs<T>& a, double* partials, T* maxpart, int v_is_s);
   static void adj_norm(hipStream_t s, const Grid& g, const SetArgs<T>& a, double* partials);
   static void fwd(hipStream_t s, const Grid& g, int nblk, const int* dir, const T* ih, const T* x, T* out);
   static void adj(hipStream_t s, const Grid& g, int nblk, const int* dir, const T* ih, const T* v, T* out);
   static void log3(hipStream_t s, long long N, const T* x, const T* m, const T* xold, double* partials);
   static void fin_sum(hipStream_t s, const double* partials, int nslots, double* out_dev, double* out_host);
-  // projector scalar machinery (l1 / l2 / annulus / cardinality)
-  static void ps_reduce(hipStream_t s, long long len, const T* v, const ProjScalars<T>* ps, double* partials, T* maxpart);
-  static void ps_finish(hipStream_t s, const double* partials, const T* maxpart, ProjScalars<T>* ps, int prox, T pmin,
-                        T pmax, long long true_len);
-  // after yl_prep / ps_reduce filled the PREP_SLOTS partials: bracket, (gated) refine, compaction, exact solve
-  static void l1_theta(hipStream_t s, long long len, const T* v, ProjScalars<T>* ps, T radius, double* partials,
-                       const T* maxpart, T* compact);
+  // Scalars of the two-pass projectors (l1 threshold, l2 / annulus scale) of a vector that is either
+  // produced on the fly by a set (v = x_hat - l/rho, or s = A x when v_is_s) or stored in an array.
+  // Enqueues: first pass (sums + probe + speculative compaction), bracket, gated refinement / compaction, solve.
+  static void proj_scalars_set(hipStream_t s, const Grid& g, const SetArgs<T>& a, int v_is_s, ProjScalars<T>* ps,
+                               double* partials, T* maxpart, T* compact, long long true_len);
+  static void proj_scalars_arr(hipStream_t s, long long len, const T* v, int prox, T pmin, T pmax, ProjScalars<T>* ps,
+                               double* partials, T* maxpart, T* compact, long long true_len);
+  // ||P(v)-v||^2 and ||v||^2 of the set-produced vector into partial slots dst[0..NB), dst[NB..2NB)
+  static void proj_dist_set(hipStream_t s, const Grid& g, const SetArgs<T>& a, int v_is_s, const ProjScalars<T>* ps,
+                            double* dst);
   static void ps_init(hipStream_t s, ProjScalars<T>* ps);
 };
 

@@ -226,4 +226,72 @@ __device__ __forceinline__ void adj_dir_acc(const Grid& G, long long g, const Co
   }
 }
 
+template <typename T>
+__device__ __forceinline__ T soft_thr(T v, T th) {
+  // sign(v) * max(abs(v) - th, 0)   (project_l1_Duchi!.jl:49, prox_l1!.jl:9)
+  T t = fabs(v) - th;
+  t = t > T(0) ? t : T(0);
+  return v > T(0) ? t : (v < T(0) ? -t : v);
+}
+
+template <typename T>
+struct ProxCtx {
+  int prox;
+  T plo, phi, rho, theta, scale, tau;
+  int fill;
+  long long idx_cut;
+};
+
+template <typename T>
+__device__ __forceinline__ ProxCtx<T> make_prox(int prox, T plo, T phi, T rho, const ProjScalars<T>* ps) {
+  ProxCtx<T> c;
+  c.prox = prox;
+  c.plo = plo;
+  c.phi = phi;
+  c.rho = rho;
+  c.theta = T(0);
+  c.scale = T(1);
+  c.tau = T(0);
+  c.fill = 0;
+  c.idx_cut = -1;
+  if (ps) {
+    c.theta = ps->theta;
+    c.scale = ps->scale;
+    c.fill = ps->fill;
+    c.tau = ps->tau;
+    c.idx_cut = ps->quota;
+  }
+  if (prox == PX_PROX_L1) c.theta = T(1) / phi;   // prox_l1!(x, constraint.max): threshold 1/rho
+  return c;
+}
+
+// One element of prox_i / P_i.  lb/ub: per-element bounds; m: distance-term centre; e: padded index.
+template <typename T>
+__device__ __forceinline__ T prox_apply(const ProxCtx<T>& c, T v, T lb, T ub, T m, long long e) {
+  switch (c.prox) {
+    case PX_BOUNDS: {                       // max(LB, min(x, UB))      project_bounds!.jl:9
+      T t = v < c.phi ? v : c.phi;
+      return c.plo > t ? c.plo : t;
+    }
+    case PX_BOUNDS_VEC: {                   // project_bounds!.jl:21-22
+      T t = v < ub ? v : ub;
+      return lb > t ? lb : t;
+    }
+    case PX_DIST:                           // (x*rho + m) / (rho + 1.0): Float64 division  prox_l2s!.jl:4
+      return (T)((double)(v * c.rho + m) / ((double)c.rho + 1.0));
+    case PX_L1:
+    case PX_PROX_L1:
+      return soft_thr(v, c.theta);
+    case PX_L2:
+    case PX_ANNULUS:                        // rmul!(x, sigma/nl2) or the constant fill  project_annulus!.jl:9-17
+      return c.fill ? c.scale : v * c.scale;
+    case PX_CARD: {                         // keep the k largest |v|, ties by lowest index
+      const T av = fabs(v);
+      return (av > c.tau || (av == c.tau && e <= c.idx_cut)) ? v : T(0);
+    }
+  }
+  return v;
+}
+
+
 }  // namespace sipx

@@ -29,6 +29,7 @@ EXPORTED_SYMBOLS = [
     "sipx_finalize", "sipx_rhs_compose", "sipx_argmin_x", "sipx_update_y_l", "sipx_log_scalars",
     "sipx_adapt_rho_gamma", "sipx_q_update", "sipx_download", "sipx_parsdmm", "sipx_cds_spmv",
     "sipx_apply_op", "sipx_apply_op_adj", "sipx_project", "sipx_get_Q", "sipx_time_spmv", "sipx_kernel_stats",
+    "sipx_debug_proj",
     "sipx_stream",
     "sipx_dev_rhs", "sipx_dev_x", "sipx_set_owned",
 ]
@@ -487,6 +488,13 @@ class Context:
         ms = C.c_double()
         _chk(lib().sipx_time_spmv(self.h, int(reps), C.byref(ms)))
         return ms.value
+
+    def debug_proj(self, set_index: int, which: int = 0):
+        out = np.zeros(16)
+        _chk(lib().sipx_debug_proj(self.h, int(set_index), int(which), out.ctypes.data_as(C.c_void_p)))
+        keys = ("need", "theta", "theta_prev", "hw", "spec_lo", "spec_hi", "lo", "hi", "asum", "vmax", "gathered",
+                "overflow", "spec_ok", "michelot_its", "refine")
+        return dict(zip(keys, out))
 
     def kernel_stats(self, enable: bool):
         n, ms = C.c_int64(), C.c_double()
