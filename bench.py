@@ -142,6 +142,12 @@ def main():
     w = np.dtype(TF).itemsize
     spmv_bytes = (d + 2) * N * w                 # B_spmv = (d+2) N w per launch
     achieved = (spmv_bytes / (kms / launches * 1e-3) / 1e9) if launches else 0.0
+    # HBM traffic of the dominant kernel from the PMC counters: separate rocprofv3 --pmc passes, summarised in profiles/
+    traffic, traffic_src = None, None
+    pmc = os.path.join(ROOT, "profiles", "r01_c3_256_pmc.json")
+    if args.config == "c3" and os.path.exists(pmc):
+        traffic = json.load(open(pmc))["dominant_kernel"]["hbm_bytes_per_launch_corrected"]
+        traffic_src = "profiles/r01_c3_256_pmc.json (2*FETCH_SIZE + WRITE_SIZE, gfx950 correction)"
     log = drv.result_log()
     finite = bool(np.isfinite(log.obj).all() and np.isfinite(log.r_pri_total).all())
 
@@ -155,7 +161,7 @@ def main():
                    "driver": "phase-level C ABI (sipx_rhs_compose/argmin_x/update_y_l/...)"},
         "roofline": {"bound": "hbm", "kernel": "k_cds<MODE=1> (cds_spmv + p.Ap partials)", "achieved": achieved,
                      "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                     "traffic": None, "launches": int(launches), "avg_launch_ms": (kms / launches) if launches else None,
+                     "traffic": traffic, "traffic_source": traffic_src, "launches": int(launches), "avg_launch_ms": (kms / launches) if launches else None,
                      "algorithmic_bytes_per_launch": spmv_bytes},
     }
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
