@@ -136,7 +136,7 @@ class Engine : public EngineBase {
     (void)hipStreamSynchronize(stream_);
     for (auto& s : sets_) free_set(s);
     for (void* p : {(void*)x_, (void*)xold_, (void*)rhs_, (void*)m_, (void*)r_, (void*)p_, (void*)Ap_, (void*)Q_,
-                    (void*)scr_v_, (void*)scr_c_, (void*)part_cg_, (void*)part_tmp_, (void*)part_sets_,
+                    (void*)scr_v_, (void*)scr_c_, (void*)scr_i_, (void*)part_cg_, (void*)part_tmp_, (void*)part_sets_,
                     (void*)maxpart_, (void*)cg_dev_})
       dfree(p);
     if (cg_host_) (void)hipHostFree(cg_host_);
@@ -169,7 +169,7 @@ class Engine : public EngineBase {
         break;
       case SIPX_PROJ_L2:
       case SIPX_PROJ_ANNULUS: s.two_pass = true; break;
-      case SIPX_PROJ_CARDINALITY: throw std::runtime_error("cardinality projector: not built yet (SURVEY 8a row K10)");
+      case SIPX_PROJ_CARDINALITY: s.two_pass = true; need_idx_ = true; break;
       default: throw std::runtime_error("unknown projector kind");
     }
     if (ata_R) {
@@ -237,6 +237,7 @@ class Engine : public EngineBase {
     for (auto& s : sets_) maxpad = std::max(maxpad, s.Mpad);
     scr_v_ = dalloc<T>(maxpad);
     scr_c_ = dalloc<T>(maxpad);
+    if (need_idx_) scr_i_ = dalloc<long long>(maxpad);
     part_cg_ = dalloc<double>(2 * NB);
     part_tmp_ = dalloc<double>((size_t)(PREP_SLOTS + 2) * NB);
     part_sets_ = dalloc<double>((size_t)p_n_ * SLOTS * NB);
@@ -271,8 +272,8 @@ class Engine : public EngineBase {
       if (s.two_pass) {
         s.ps = dalloc<ProjScalars<T>>(1);
         s.psf = dalloc<ProjScalars<T>>(1);
-        K<T>::ps_init(stream_, s.ps);
-        K<T>::ps_init(stream_, s.psf);
+        K<T>::ps_init(stream_, s.ps, scr_i_);
+        K<T>::ps_init(stream_, s.psf, scr_i_);
       }
       if (s.prox == SIPX_PROJ_BOUNDS_VEC) {
         s.lb = dalloc<T>(s.Mpad); s.ub = dalloc<T>(s.Mpad);
@@ -614,7 +615,6 @@ class Engine : public EngineBase {
     double* part = dalloc<double>((size_t)(PREP_SLOTS + 2) * NB);
     T* mp = dalloc<T>(NB);
     ProjScalars<T>* ps = dalloc<ProjScalars<T>>(1);
-    K<T>::ps_init(stream_, ps);
     SIPX_HIP(hipMemcpy(dv, v, len * sizeof(T), hipMemcpyHostToDevice));
     const int prox = d->proj;
     const T plo = (T)d->pmin, phi = (T)d->pmax;
@@ -624,15 +624,16 @@ class Engine : public EngineBase {
       SIPX_HIP(hipMemcpy(ub, d->ub, len * sizeof(T), hipMemcpyHostToDevice));
     }
     if (prox == SIPX_PROJ_L1 && !(d->pmax > 0)) throw std::runtime_error("Radius of L1 ball is negative");
-    if (prox == SIPX_PROJ_CARDINALITY) throw std::runtime_error("cardinality projector: not built yet");
-    const bool two = prox == SIPX_PROJ_L1 || prox == SIPX_PROJ_L2 || prox == SIPX_PROJ_ANNULUS;
+    const bool two = prox == SIPX_PROJ_L1 || prox == SIPX_PROJ_L2 || prox == SIPX_PROJ_ANNULUS || prox == SIPX_PROJ_CARDINALITY;
+    long long* di = prox == SIPX_PROJ_CARDINALITY ? dalloc<long long>(len) : nullptr;
     if (two) {
+      K<T>::ps_init(stream_, ps, di);
       K<T>::proj_scalars_arr(stream_, len, dv, prox, plo, phi, ps, part, mp, dc, len);
     }
     proj_apply_grid<T>(stream_, g1, 0, nullptr, len, dv, prox, plo, phi, lb, ub, two ? ps : nullptr);
     SIPX_HIP(hipStreamSynchronize(stream_));
     SIPX_HIP(hipMemcpy(v, dv, len * sizeof(T), hipMemcpyDeviceToHost));
-    for (void* q : {(void*)dv, (void*)dc, (void*)lb, (void*)ub, (void*)part, (void*)mp, (void*)ps})
+    for (void* q : {(void*)dv, (void*)dc, (void*)lb, (void*)ub, (void*)part, (void*)mp, (void*)ps, (void*)di})
       dfree(q);
   }
 
@@ -858,6 +859,8 @@ class Engine : public EngineBase {
   std::vector<double> feas_init_;
   T *x_ = nullptr, *xold_ = nullptr, *rhs_ = nullptr, *m_ = nullptr, *r_ = nullptr, *p_ = nullptr, *Ap_ = nullptr;
   T *Q_ = nullptr, *scr_v_ = nullptr, *scr_c_ = nullptr, *maxpart_ = nullptr;
+  long long* scr_i_ = nullptr;
+  bool need_idx_ = false;
   CdsArgs cds_;
   double *part_cg_ = nullptr, *part_tmp_ = nullptr, *part_sets_ = nullptr;
   CgState<T>*cg_dev_ = nullptr, *cg_host_ = nullptr;

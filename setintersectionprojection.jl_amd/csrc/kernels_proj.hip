@@ -18,8 +18,10 @@
 //            exact theta in float64.
 //   project_l2!        src/projectors/project_l2!.jl:3-16
 //   project_annulus!   src/projectors/project_annulus!.jl:3-21
+#include <cstring>
 #include <stdexcept>
 #include <string>
+#include <type_traits>
 
 #include "sipx_device.h"
 
@@ -36,6 +38,7 @@ __global__ __launch_bounds__(BLOCK) void k_pass(Grid G, SetArgs<T> a, int v_is_s
                                                 long long len, ProjScalars<T>* ps, T* __restrict__ compact,
                                                 double* __restrict__ partials, T* __restrict__ maxpart) {
   if (MODE == M_PROBE && !(ps->need && !ps->spec_ok && ps->refine)) return;
+  long long* const cidx = (MODE == M_COMPACT && a.prox == PX_CARD) ? ps->cidx : nullptr;
   if (MODE == M_COMPACT && !(ps->need && !ps->spec_ok)) return;
   __shared__ T sbuf[(MODE == M_FIRST || MODE == M_COMPACT) ? SPEC_CAP : 1];
   __shared__ unsigned int scnt, sused;     // reserved / actually filled prefix of sbuf
@@ -46,7 +49,7 @@ __global__ __launch_bounds__(BLOCK) void k_pass(Grid G, SetArgs<T> a, int v_is_s
   for (int k = 0; k < PREP_SLOTS; ++k) acc[k] = 0;
   double t[L1_K];
 #pragma unroll
-  for (int k = 0; k < L1_K; ++k) t[k] = (a.prox == PX_L1 && MODE <= M_PROBE) ? ps->t[k] : INFINITY;
+  for (int k = 0; k < L1_K; ++k) t[k] = ((a.prox == PX_L1 || a.prox == PX_CARD) && MODE <= M_PROBE) ? ps->t[k] : INFINITY;
   double r_lo = 0, r_hi = -1;      // gather range (lo, hi]
   if (MODE == M_FIRST && a.prox == PX_L1 && !(a.flags & F_NOSPEC)) { r_lo = ps->spec_lo; r_hi = ps->spec_hi; }
   if (MODE == M_COMPACT) { r_lo = ps->lo; r_hi = ps->hi; }
@@ -60,7 +63,7 @@ __global__ __launch_bounds__(BLOCK) void k_pass(Grid G, SetArgs<T> a, int v_is_s
   if (MODE == M_DIST) pc = make_prox<T>(a.prox, a.plo, a.phi, T(0), ps);
   const int lane = threadIdx.x & 63;
 
-  auto body = [&](T x) {
+  auto body = [&](T x, long long e) {
     const T av = fabs(x);
     const double ad = (double)av;
     if (MODE == M_FIRST || MODE == M_PROBE) {
@@ -72,7 +75,7 @@ __global__ __launch_bounds__(BLOCK) void k_pass(Grid G, SetArgs<T> a, int v_is_s
       acc[1] += 1.0;
     }
     if (MODE == M_DIST) {
-      const T pv = prox_apply<T>(pc, x, T(0), T(0), T(0), 0);
+      const T pv = prox_apply<T>(pc, x, T(0), T(0), T(0), e);
       const T dlt = pv - x;
       acc[0] += (double)dlt * (double)dlt;
       acc[1] += (double)x * (double)x;
@@ -84,10 +87,17 @@ __global__ __launch_bounds__(BLOCK) void k_pass(Grid G, SetArgs<T> a, int v_is_s
         const int leader = __ffsll((long long)mask) - 1;
         const int cnt = __popcll(mask);
         const int my = __popcll(mask & ((1ull << lane) - 1ull));
-        unsigned int base = 0;
-        if (lane == leader) base = atomicAdd(&scnt, (unsigned int)cnt);
-        base = __shfl(base, leader, 64);
-        if (base + cnt <= SPEC_CAP) {                       // room in the workgroup's LDS buffer
+        unsigned int base = SPEC_CAP;
+        if (!cidx) {
+          if (lane == leader) base = atomicAdd(&scnt, (unsigned int)cnt);
+          base = __shfl(base, leader, 64);
+        }
+        if (cidx) {                                         // cardinality: (magnitude, index) pairs, few of them
+          unsigned long long gb = 0;
+          if (lane == leader) gb = atomicAdd(&ps->n_compact, (unsigned long long)cnt);
+          gb = __shfl(gb, leader, 64);
+          if (in) { compact[gb + my] = av; cidx[gb + my] = e; }
+        } else if (base + cnt <= SPEC_CAP) {                // room in the workgroup's LDS buffer
           if (in) sbuf[base + my] = av;
           if (lane == leader) atomicMax(&sused, base + (unsigned int)cnt);
         } else if (MODE == M_FIRST) {
@@ -105,7 +115,7 @@ __global__ __launch_bounds__(BLOCK) void k_pass(Grid G, SetArgs<T> a, int v_is_s
   if (SRC == 0) {
     for (long long e0 = (long long)blockIdx.x * BLOCK; e0 < len; e0 += (long long)NB * BLOCK) {
       const long long e = e0 + threadIdx.x;
-      body(e < len ? varr[e] : T(0));        // uniform trip count: every lane takes part in the ballots
+      body(e < len ? varr[e] : T(0), e);     // uniform trip count: every lane takes part in the ballots
     }
   } else {
     const bool ident = a.nblk == 0;
@@ -143,7 +153,7 @@ __global__ __launch_bounds__(BLOCK) void k_pass(Grid G, SetArgs<T> a, int v_is_s
           }
         }
 #pragma unroll
-        for (int k = 0; k < V; ++k) body(live ? out[k] : T(0));
+        for (int k = 0; k < V; ++k) body(live ? out[k] : T(0), e + k);
       }
     }
   }
@@ -172,7 +182,10 @@ __global__ __launch_bounds__(BLOCK) void k_pass(Grid G, SetArgs<T> a, int v_is_s
 }
 
 template <typename T>
-__global__ void k_ps_init(ProjScalars<T>* ps) {
+__global__ void k_ps_init(ProjScalars<T>* ps, long long* cidx) {
+  ps->cidx = cidx;
+  ps->c_lo = ps->c_hi = 0;
+  ps->tau_prev = T(0);
   ps->asum = ps->sumsq = 0;
   ps->vmax = T(0);
   ps->need = 0;
@@ -193,8 +206,8 @@ __global__ void k_ps_init(ProjScalars<T>* ps) {
   ps->quota = 0x7fffffffffffffffll;
 }
 template <typename T>
-void K<T>::ps_init(hipStream_t s, ProjScalars<T>* ps) {
-  hipLaunchKernelGGL((k_ps_init<T>), dim3(1), dim3(1), 0, s, ps);
+void K<T>::ps_init(hipStream_t s, ProjScalars<T>* ps, long long* cidx) {
+  hipLaunchKernelGGL((k_ps_init<T>), dim3(1), dim3(1), 0, s, ps, cidx);
   SIPX_HIP(hipGetLastError());
 }
 
@@ -426,6 +439,125 @@ __global__ __launch_bounds__(1024) void k_l1_solve(ProjScalars<T>* ps, T radius,
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Cardinality: tau = k-th largest magnitude.  Bracket (lo, hi] with C(lo) >= k > C(hi) from the probe counts,
+// refined by gated probe passes until it holds at most CARD_CAP magnitudes (or the passes run out).
+constexpr double CARD_CAP = 8192.0;
+constexpr int CARD_REFINES = 5;
+
+template <typename T, int STAGE>
+__global__ __launch_bounds__(1024) void k_card_decide(const double* __restrict__ partials,
+                                                      const T* __restrict__ maxpart, ProjScalars<T>* ps, long long k,
+                                                      long long true_len) {
+  if (STAGE == 1 && !(ps->need && ps->refine)) return;
+  __shared__ double red[PREP_SLOTS];
+  __shared__ T smax[16];
+  reduce_slots(partials, red);
+  T vmax = T(0);
+  if (STAGE == 0) {
+    for (int i = threadIdx.x; i < NB; i += 1024) vmax = maxpart[i] > vmax ? maxpart[i] : vmax;
+    vmax = wave_max<T>(vmax);
+    if ((threadIdx.x & 63) == 0) smax[threadIdx.x >> 6] = vmax;
+  }
+  __syncthreads();
+  if (threadIdx.x != 0) return;
+  if (STAGE == 0) {
+    for (int i = 0; i < 16; ++i) vmax = smax[i] > vmax ? smax[i] : vmax;
+    ps->vmax = vmax;
+    ps->asum = red[0];
+    ps->need = 0;
+    ps->refine = 0;
+    ps->spec_ok = 0;
+    ps->n_compact = 0;
+    ps->quota = 0x7fffffffffffffffll;
+    const double nnz = red[2];
+    if (k >= true_len || (double)k >= nnz) { ps->tau = T(0); return; }   // everything non-zero survives
+    if (k <= 0) { ps->tau = (T)INFINITY; return; }                       // nothing survives
+    ps->need = 1;
+    ps->lo = 0; ps->c_lo = nnz;
+    ps->hi = (double)vmax; ps->c_hi = 0;
+  }
+  double lo = ps->lo, hi = ps->hi, clo = ps->c_lo, chi = ps->c_hi;
+  for (int j = 0; j < L1_K; ++j) {
+    const double t = ps->t[j];
+    if (!(t < INFINITY) || !(t > lo) || !(t < hi)) continue;
+    const double C = red[3 + L1_K + j];
+    if (C >= (double)k) { lo = t; clo = C; }
+    else if (t < hi) { hi = t; chi = C; }
+  }
+  // second sweep: a probe accepted as `lo` early may lie above one accepted as `hi` later -- cannot happen,
+  // C is non-increasing in t, so the accepted lo's are all below the accepted hi's.
+  ps->lo = lo; ps->hi = hi; ps->c_lo = clo; ps->c_hi = chi;
+  if (clo - chi > CARD_CAP && hi > lo) {
+    ps->refine = 1;
+    for (int j = 0; j < L1_K; ++j) ps->t[j] = lo + (hi - lo) * (double)(j + 1) / (double)(L1_K + 1);
+  } else {
+    ps->refine = 0;
+  }
+}
+
+// Exact selection among the gathered (magnitude, index) pairs: tau = the (k - C(hi))-th largest of them
+// (binary search on the bit pattern, which is monotone for non-negative floats), then the index cut among
+// the entries equal to tau (stable sortperm: lowest indices win, project_cardinality!.jl:18-19).
+template <typename T>
+__global__ __launch_bounds__(1024) void k_card_select(ProjScalars<T>* ps, long long k, const T* __restrict__ compact) {
+  typedef typename std::conditional<sizeof(T) == 4, unsigned int, unsigned long long>::type U;
+  __shared__ double scnt[16];
+  __shared__ double sh_val;
+  auto count_block = [&](auto pred) -> double {     // number of gathered entries satisfying pred (block wide)
+    const long long n = (long long)ps->n_compact;
+    double c = 0;
+    for (long long e = threadIdx.x; e < n; e += 1024) c += pred(e) ? 1.0 : 0.0;
+    c = wave_sum(c);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) scnt[threadIdx.x >> 6] = c;
+    __syncthreads();
+    if (threadIdx.x == 0) { double s = 0; for (int i = 0; i < 16; ++i) s += scnt[i]; sh_val = s; }
+    __syncthreads();
+    return sh_val;
+  };
+  if (ps->need) {
+    const double kk = (double)k - ps->c_hi;          // rank inside the bracket, >= 1
+    const U* keys = reinterpret_cast<const U*>(compact);
+    U ans = 0;
+    for (int bit = (int)sizeof(U) * 8 - 2; bit >= 0; --bit) {     // sign bit is 0
+      const U cand = ans | ((U)1 << bit);
+      const double c = count_block([&](long long e) { return keys[e] >= cand; });
+      if (c >= kk) ans = cand;
+    }
+    const double c_gt = count_block([&](long long e) { return keys[e] > ans; });
+    const double c_eq = count_block([&](long long e) { return keys[e] == ans; });
+    const double quota = kk - c_gt;                  // how many entries equal to tau survive (>= 1)
+    long long cut = 0x7fffffffffffffffll;
+    if (c_eq > quota) {                              // partial tie: smallest index I with #{eq, idx <= I} >= quota
+      const long long* idx = ps->cidx;
+      long long lo = -1, hi = 0x3fffffffffffffffll;
+      while (hi - lo > 1) {
+        const long long mid = lo + (hi - lo) / 2;
+        const double c = count_block([&](long long e) { return keys[e] == ans && idx[e] <= mid; });
+        if (c >= quota) hi = mid; else lo = mid;
+      }
+      cut = hi;
+    }
+    if (threadIdx.x == 0) {
+      T tau;
+      memcpy(&tau, &ans, sizeof(T));
+      ps->tau = tau;
+      ps->quota = cut;
+      ps->dbg[0] = (double)ps->n_compact;
+    }
+  }
+  if (threadIdx.x == 0) {
+    const T tp = ps->need ? ps->tau : ps->tau_prev;
+    if (tp > T(0) && tp < (T)INFINITY) {
+      ps->tau_prev = tp;
+      const double m[L1_K] = {0.5, 0.9, 0.99, 0.999, 1.001, 1.01, 1.1, 2.0};
+      for (int j = 0; j < L1_K; ++j) ps->t[j] = (double)tp * m[j];
+    }
+    ps->n_compact = 0;
+  }
+}
+
 template <typename T, int SRC>
 static void launch_chain(hipStream_t s, const Grid& g, const SetArgs<T>& a, int v_is_s, const T* varr, long long len,
                          ProjScalars<T>* ps, double* partials, T* maxpart, T* compact, long long true_len) {
@@ -439,6 +571,19 @@ static void launch_chain(hipStream_t s, const Grid& g, const SetArgs<T>& a, int 
       hipLaunchKernelGGL((k_pass<T, 1, MODE, SRC>), dim3(NB), dim3(BLOCK), 0, s, g, a, v_is_s, varr, len, ps, compact, \
                          partials, maxpart);                                                                       \
   } while (0)
+  if (a.prox == PX_CARD) {
+    const long long kc = (long long)a.phi;
+    SIPX_PASS(M_FIRST);
+    hipLaunchKernelGGL((k_card_decide<T, 0>), dim3(1), dim3(1024), 0, s, partials, maxpart, ps, kc, true_len);
+    for (int r = 0; r < CARD_REFINES; ++r) {
+      SIPX_PASS(M_PROBE);
+      hipLaunchKernelGGL((k_card_decide<T, 1>), dim3(1), dim3(1024), 0, s, partials, maxpart, ps, kc, true_len);
+    }
+    SIPX_PASS(M_COMPACT);
+    hipLaunchKernelGGL((k_card_select<T>), dim3(1), dim3(1024), 0, s, ps, kc, compact);
+    SIPX_HIP(hipGetLastError());
+    return;
+  }
   SIPX_PASS(M_FIRST);
   hipLaunchKernelGGL((k_decide<T, 0>), dim3(1), dim3(1024), 0, s, partials, maxpart, ps, a.prox, a.plo, a.phi, true_len,
                      (a.flags & F_NOSPEC) ? 1 : 0);
@@ -487,7 +632,7 @@ void K<T>::proj_dist_set(hipStream_t s, const Grid& g, const SetArgs<T>& a, int 
 }
 
 #define SIPX_INST(T)                                                                                              \
-  template void K<T>::ps_init(hipStream_t, ProjScalars<T>*);                                                     \
+  template void K<T>::ps_init(hipStream_t, ProjScalars<T>*, long long*);                                                     \
   template void K<T>::proj_scalars_set(hipStream_t, const Grid&, const SetArgs<T>&, int, ProjScalars<T>*, double*, \
                                        T*, T*, long long);                                                       \
   template void K<T>::proj_scalars_arr(hipStream_t, long long, const T*, int, T, T, ProjScalars<T>*, double*, T*, \

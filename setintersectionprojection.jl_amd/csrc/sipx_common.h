@@ -61,9 +61,12 @@ struct ProjScalars {
   double hw;                 // relative half-width of the next speculative range
   int spec_ok, spec_overflow;
   double dbg[4];             // diagnostics of the last search: gathered count, overflow, spec_ok, Michelot iterations
-  // cardinality
+  // cardinality (keep the k largest magnitudes; ties at the threshold by lowest index)
   T tau;              // k-th largest magnitude
   long long quota;    // entries equal to tau are kept iff their padded index <= quota (idx cut)
+  long long* cidx;    // device buffer for the indices of the gathered magnitudes
+  double c_lo, c_hi;  // counts of |v| > lo and |v| > hi of the current bracket
+  T tau_prev;
 };
 
 template <typename T>
@@ -145,7 +148,7 @@ struct K {
   // ||P(v)-v||^2 and ||v||^2 of the set-produced vector into partial slots dst[0..NB), dst[NB..2NB)
   static void proj_dist_set(hipStream_t s, const Grid& g, const SetArgs<T>& a, int v_is_s, const ProjScalars<T>* ps,
                             double* dst);
-  static void ps_init(hipStream_t s, ProjScalars<T>* ps);
+  static void ps_init(hipStream_t s, ProjScalars<T>* ps, long long* cidx);
 };
 
 // ||P(v)-v||^2, ||v||^2 (slots 0,1) and v = P(v) over a padded vector (pads skipped)

@@ -82,6 +82,9 @@ def _problem(mod, n, h, TF, kinds, m, opt_kw=None):
         elif k == "annulus":
             nm = float(np.linalg.norm(m.astype(np.float64)))
             c.append(mod.set_definitions("annulus", "identity", 0.9 * nm, 0.98 * nm, ("matrix", "")))
+        elif k.startswith("card:"):
+            A = O.get_TD_operator(O.compgrid(h, n), k[5:], TF)[0]
+            c.append(mod.set_definitions("cardinality", k[5:], 0, int(0.3 * A.shape[0]), ("matrix", "")))
         elif k == "l2":
             nm = float(np.linalg.norm(m.astype(np.float64)))
             c.append(mod.set_definitions("l2", "identity", 0.0, 0.9 * nm, ("matrix", "")))
@@ -172,6 +175,25 @@ def test_projectors(sipx, TF):
     # prox_l2s known answers (test/test_prox_l2s!.jl)
 
 
+@pytest.mark.parametrize("TF", [np.float32, np.float64])
+def test_cardinality_projector(sipx, TF):
+    """test/test_projectors.jl:49-56 closed forms + stable tie breaking of sortperm(by=abs, rev=true)."""
+    g = sipx.compgrid((1.0, 1.0), (10, 10))
+    P = lambda k: sipx.Projector(sipx.set_definitions("cardinality", "identity", 0, k, ("matrix", "")), g, TF)
+    assert np.array_equal(P(2)(np.array([0, 0, 1, 2, 3], TF)), [0, 0, 0, 2, 3])
+    assert np.array_equal(P(2)(np.array([0, 0, -1, 2, -3], TF)), [0, 0, 0, 2, -3])
+    assert np.array_equal(P(1)(np.array([1, -1, 1], TF)), [1, 0, 0])                 # ties: lowest index survives
+    assert np.array_equal(P(3)(np.array([2, -2, 2, 2, -2, 1], TF)), [2, -2, 2, 0, 0, 0])
+    assert np.array_equal(P(7)(np.array([1, 0, 2], TF)), [1, 0, 2])                  # k >= length
+    assert np.array_equal(P(0)(np.array([1, 0, 2], TF)), [0, 0, 0])
+    rng = np.random.default_rng(21)
+    for n, k in ((1000, 100), (4099, 1), (200000, 60000), (300000, 299999)):
+        v = (rng.standard_normal(n) * np.exp(rng.standard_normal(n))).astype(TF)
+        v[rng.integers(0, n, n // 10)] = 0                                            # some exact zeros
+        v[rng.integers(0, n, n // 20)] = TF(0.5)                                      # and a big tie group
+        assert np.array_equal(P(k)(v.copy()), O.project_cardinality(v.copy(), k)), (n, k)
+
+
 # ---- one phase-level iteration in lock-step with the oracle -------------------------------------
 @pytest.mark.parametrize("TF", [np.float32, np.float64])
 @pytest.mark.parametrize("n,h", GRIDS[:3])
@@ -255,6 +277,7 @@ CASES = [
     ("2d-bounds-dz-tv", (40, 28), (1.0, 1.0), ["bounds", "bnd:D_z", "l1:TV"]),
     ("c3-3d-bounds-l1xyz", (16, 12, 8), (25.0, 25.0, 25.0), ["bounds", "l1:D_x", "l1:D_y", "l1:D_z"]),
     ("3d-odd-tv-annulus", (9, 7, 5), (25.0, 25.0, 25.0), ["bounds", "l1:TV", "annulus"]),
+    ("2d-nonconvex-cardinality", (32, 24), (1.0, 1.0), ["bounds", "card:D_z"]),
 ]
 
 
