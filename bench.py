@@ -88,8 +88,11 @@ def main():
             raise SystemExit("launch with: python -m torch.distributed.run --nnodes=1 --nproc-per-node N bench.py --gpus N")
     dist = None
     torch.cuda.set_device(local_rank)
-    if world > 1:
+    force_dist = bool(os.environ.get("SIPX_FORCE_DIST"))      # exercise the RCCL path even with one rank
+    if world > 1 or force_dist:
         import torch.distributed as dist
+        if force_dist and "MASTER_ADDR" not in os.environ:
+            os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="29533", RANK="0", WORLD_SIZE="1")
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     TF = np.float32
@@ -110,8 +113,30 @@ def main():
     p = len(A)
     owned = sharded.shard_sets(p, world, rank)
     ctx = sipx.host.build_context(m, AtA, A, prop, P, g, opt, device=local_rank, owned=owned)
-    comm = sharded.TorchComm(dist, torch.device("cuda", local_rank)) if world > 1 else sharded.LocalComm()
-    drv = sharded.PhaseDriver(ctx, opt, comm, owned, any(prop.ncvx[:len(P)]))
+    comm = sharded.TorchComm(dist, torch.device("cuda", local_rank)) if dist is not None else sharded.LocalComm()
+    native = dist is None        # one GPU: the native driver loop (sipx_parsdmm_begin/_steps); sharded: phase API
+
+    class NativeDriver:            # same stepping interface as sharded.PhaseDriver
+        def __init__(self):
+            ctx.parsdmm_begin(opt)
+            self.i = 0
+
+        def step(self):
+            self.i += 1
+            return ctx.parsdmm_steps(1)
+
+        def result_log(self):
+            return ctx.parsdmm_log()
+
+        @property
+        def cg_total(self):
+            return int(ctx._run[2]["cg_it"][:self.i].sum())
+
+        @property
+        def log(self):
+            return type("L", (), {k: v for k, v in ctx._run[2].items()})
+
+    drv = NativeDriver() if native else sharded.PhaseDriver(ctx, opt, comm, owned, any(prop.ncvx[:len(P)]))
 
     for _ in range(args.warmup):
         drv.step()
@@ -158,7 +183,8 @@ def main():
         "config": {"workload": f"{args.config}: {'x'.join(map(str, n))} Float32, sets {{{', '.join(kinds)}}} + distance term",
                    "grid": list(n), "sets": kinds, "parallelism": f"set-sharded x{world}" if world > 1 else "single GPU",
                    "cg_iterations_in_timed_steps": int(cg_its), "all_logs_finite": finite,
-                   "driver": "phase-level C ABI (sipx_rhs_compose/argmin_x/update_y_l/...)"},
+                   "driver": "native loop (sipx_parsdmm_begin/_steps)" if native else
+                             "phase-level C ABI (sipx_rhs_compose/argmin_x/update_y_l/...) + torch.distributed"},
         "roofline": {"bound": "hbm", "kernel": "k_cds<MODE=1> (cds_spmv + p.Ap partials)", "achieved": achieved,
                      "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                      "traffic": traffic, "traffic_source": traffic_src, "launches": int(launches), "avg_launch_ms": (kms / launches) if launches else None,
@@ -169,7 +195,7 @@ def main():
     ctx.close()
     if rank == 0:
         print(json.dumps(out))
-    if world > 1:
+    if dist is not None:
         dist.destroy_process_group()
 
 

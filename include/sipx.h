@@ -135,6 +135,10 @@ int sipx_download(sipx_ctx* ctx, void* x, void* const* l, void* const* y);
 
 /* ---- B. whole solve (src/PARSDMM.jl:97-257 restated natively) ---- */
 int sipx_parsdmm(sipx_ctx* ctx, const sipx_options* opt, sipx_log* log);
+/* the same solve advanced in pieces: begin, then up to nsteps iterations per call (done = 1 once a stop rule or maxit
+ * ended it; the log arrays given to _begin must stay alive) */
+int sipx_parsdmm_begin(sipx_ctx* ctx, const sipx_options* opt, sipx_log* log);
+int sipx_parsdmm_steps(sipx_ctx* ctx, int nsteps, int* done);
 
 /* ---- kernel-level entry points used by the parity tests and bench (same kernels as above) ---- */
 /* y = R x for an arbitrary CDS matrix (CDS_MVp_MT + fill!, src/CDS_MVp_MT.jl:9-25, src/argmin_x.jl:72-78) */

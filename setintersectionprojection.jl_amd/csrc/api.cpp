@@ -73,6 +73,14 @@ int sipx_adapt_rho_gamma(sipx_ctx* c, int adjust_rho, int adjust_gamma, double* 
 int sipx_q_update(sipx_ctx* c, const double* rho_new, const double* rho_old) { SIPX_TRY(c->e->q_update(rho_new, rho_old)) }
 int sipx_download(sipx_ctx* c, void* x, void* const* l, void* const* y) { SIPX_TRY(c->e->download(x, l, y)) }
 int sipx_parsdmm(sipx_ctx* c, const sipx_options* opt, sipx_log* log) { SIPX_TRY(c->e->parsdmm(opt, log)) }
+int sipx_parsdmm_begin(sipx_ctx* c, const sipx_options* opt, sipx_log* log) { SIPX_TRY(c->e->parsdmm_begin(opt, log)) }
+int sipx_parsdmm_steps(sipx_ctx* c, int nsteps, int* done) {
+  SIPX_TRY({
+    bool d = false;
+    for (int k = 0; k < nsteps && !d; ++k) d = c->e->parsdmm_step();
+    if (done) *done = d ? 1 : 0;
+  })
+}
 
 int sipx_cds_spmv(int dtype, int64_t N, int d, const void* R, const int64_t* off, const void* x, void* y, int device) {
   SIPX_TRY(sipx::cds_spmv_host(dtype, N, d, R, off, x, y, device))

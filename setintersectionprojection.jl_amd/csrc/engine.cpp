@@ -143,6 +143,7 @@ class Engine : public EngineBase {
     if (hres_) (void)hipHostFree(hres_);
     for (auto e : ev_) (void)hipEventDestroy(e);
     for (auto e : stat_ev_) (void)hipEventDestroy(e);
+    for (auto e : cg_ev_) if (e) (void)hipEventDestroy(e);
     (void)hipStreamDestroy(stream_);
   }
 
@@ -173,7 +174,7 @@ class Engine : public EngineBase {
       default: throw std::runtime_error("unknown projector kind");
     }
     if (ata_R) {
-      if (d_i < 1 || d_i > MAXD) throw std::runtime_error("AtA band count out of range");
+      if (d_i < 1 || d_i > 7) throw std::runtime_error("AtA band count out of range (1..7 bands per set)");
       s.ata_off.assign(ata_off, ata_off + d_i);
       s.host_ata.assign((const T*)ata_R, (const T*)ata_R + (size_t)G_.N * d_i);
     } else {
@@ -243,11 +244,12 @@ class Engine : public EngineBase {
     part_sets_ = dalloc<double>((size_t)p_n_ * SLOTS * NB);
     maxpart_ = dalloc<T>(NB);
     cg_dev_ = dalloc<CgState<T>>(1);
-    SIPX_HIP(hipHostMalloc((void**)&cg_host_, sizeof(CgState<T>), hipHostMallocDefault));
-    std::memset(cg_host_, 0, sizeof(CgState<T>));
+    SIPX_HIP(hipHostMalloc((void**)&cg_host_, 2 * sizeof(CgState<T>), hipHostMallocDefault));
+    std::memset(cg_host_, 0, 2 * sizeof(CgState<T>));
+    for (int k = 0; k < 2; ++k) SIPX_HIP(hipEventCreateWithFlags(&cg_ev_[k], hipEventDisableTiming));
     SIPX_HIP(hipHostMalloc((void**)&hres_, sizeof(double) * p_n_ * SLOTS, hipHostMallocDefault));
     std::memset(hres_, 0, sizeof(double) * p_n_ * SLOTS);
-    for (int k = 0; k < 8; ++k) {
+    for (int k = 0; k < 16; ++k) {      // two sets of section marks: a step never waits for its own timing
       hipEvent_t e;
       SIPX_HIP(hipEventCreate(&e));
       ev_.push_back(e);
@@ -256,14 +258,13 @@ class Engine : public EngineBase {
     const bool warm = !zero_ini_guess;     // PARSDMM_initialize.jl:304-313
     for (int i = 0; i < p_n_; ++i) {
       SetState<T>& s = sets_[i];
-      // AtA bands (every rank keeps them: Q is global)
-      s.ata = dalloc<T>((size_t)N * s.ata_off.size(), false);
+      // explicit AtA bands are kept on the device (every rank: Q is global); descriptor-generated
+      // ones are never stored -- the fused Q update regenerates their values on the fly
       if (!s.host_ata.empty()) {
+        s.ata = dalloc<T>((size_t)N * s.ata_off.size(), false);
         SIPX_HIP(hipMemcpy(s.ata, s.host_ata.data(), s.host_ata.size() * sizeof(T), hipMemcpyHostToDevice));
         s.host_ata.clear();
         s.host_ata.shrink_to_fit();
-      } else {
-        K<T>::gen_ata(stream_, G_, s.nblk, s.dir, s.ih, (int)s.ata_off.size(), s.ata_off.data(), s.ata);
       }
       if (!s.owned) continue;
       s.y = dalloc<T>(s.Mpad); s.l = dalloc<T>(s.Mpad);
@@ -342,18 +343,39 @@ class Engine : public EngineBase {
     K<T>::cg_begin(stream_, part_cg_, cg_dev_, cg_host_, it, x_, G_.N);
     SIPX_HIP(hipStreamSynchronize(stream_));
     if (cg_host_->flag == -9) SIPX_HIP(hipMemsetAsync(x_, 0, G_.N * sizeof(T), stream_));   // cg.jl:51
-    int iter = 0;
-    while (!cg_host_->done && iter < 1000) {      // maxIter=1000, argmin_x.jl:39
-      ++iter;
+    // CG iterations run one ahead of the host: iteration k+1 is enqueued before the outcome of k is known.
+    // Every kernel returns at once when the device-side `done` flag is set, so a speculative iteration
+    // past convergence costs five empty launches and the GPU never idles on a host round trip.
+    // The state is mirrored into two pinned slots by iteration parity (no torn reads).
+    auto enqueue = [&](int k) {
+      CgState<T>* mirror = cg_host_ + (k & 1);
       if (stats_on_) stat_mark();
       K<T>::spmv_dot(stream_, G_.N, Q_, cds_, p_, Ap_, part_cg_, cg_dev_);
       if (stats_on_) stat_mark();
-      K<T>::cg_fin_alpha(stream_, part_cg_, cg_dev_, cg_host_, iter);
+      K<T>::cg_fin_alpha(stream_, part_cg_, cg_dev_, mirror, k);
       K<T>::cg_update_xr(stream_, G_.N, x_, r_, p_, Ap_, part_cg_, cg_dev_);
-      K<T>::cg_fin_beta(stream_, part_cg_, cg_dev_, cg_host_);
+      K<T>::cg_fin_beta(stream_, part_cg_, cg_dev_, mirror);
       K<T>::cg_update_p(stream_, G_.N, p_, r_, cg_dev_);
-      SIPX_HIP(hipStreamSynchronize(stream_));
+      SIPX_HIP(hipEventRecord(cg_ev_[k & 1], stream_));
+    };
+    CgState<T> fin = cg_host_[0];
+    if (!fin.done) {
+      const int maxIter = 1000;                       // argmin_x.jl:39
+      int iter = 1;
+      enqueue(1);
+      for (;;) {
+        const bool ahead = iter < maxIter;
+        if (ahead) enqueue(iter + 1);
+        SIPX_HIP(hipEventSynchronize(cg_ev_[iter & 1]));
+        fin = cg_host_[iter & 1];
+        if (fin.done || iter == maxIter) {
+          if (ahead && stats_on_ && stat_used_ >= 2) stat_used_ -= 2;   // the empty speculative launch is not a sample
+          break;
+        }
+        ++iter;
+      }
     }
+    cg_host_[0] = fin;
     *tol_ref_io = (double)cg_host_->tol_ref;
     *cg_it = cg_host_->iters;
     *cg_relres = (double)cg_host_->res_last;
@@ -443,13 +465,13 @@ class Engine : public EngineBase {
 
   void q_update(const double* rho_new, const double* rho_old) override {
     need_final();
+    QArgs<T> a;
+    a.nsets = 0;
     for (int i = 0; i < p_n_; ++i) {
       if (rho_new[i] == rho_old[i]) continue;                       // ind_updated, PARSDMM.jl:230
-      const T alpha = (T)rho_new[i] - (T)rho_old[i];                // Q_update!.jl:47
-      const SetState<T>& s = sets_[i];
-      for (size_t j = 0; j < s.ata_off.size(); ++j)
-        K<T>::q_axpy(stream_, G_.N, Q_ + (size_t)q_col(s.ata_off[j]) * G_.N, s.ata + j * G_.N, alpha);
+      push_qset(a, sets_[i], (T)rho_new[i] - (T)rho_old[i]);        // Q_update!.jl:47
     }
+    K<T>::q_update(stream_, G_, cds_, a, Q_);
   }
 
   void download(void* x, void* const* l, void* const* y) override {
@@ -464,48 +486,71 @@ class Engine : public EngineBase {
   }
 
   // ------------------------------------------------------------------------------------------
-  // Whole solve: src/PARSDMM.jl:63-257 restated (serial path).
-  void parsdmm(const sipx_options* opt, sipx_log* log) override {
+  // Whole solve: src/PARSDMM.jl:63-257 restated (serial path).  begin / step so a caller can advance the
+  // solve iteration by iteration (bench warm-up + timed steps); sipx_parsdmm = begin + steps until done.
+  void parsdmm_begin(const sipx_options* opt, sipx_log* log) override {
     need_final();
     for (auto& s : sets_)
       if (!s.owned) throw std::runtime_error("sipx_parsdmm needs every set local; use the phase API when sharding");
-    const int maxit = opt->maxit, p = p_n_, pp = pp_n_;
-    const T evol_rel_tol = (T)opt->evol_rel_tol, feas_tol = (T)opt->feas_tol, obj_tol = (T)opt->obj_tol;   // convert_options!
-    bool adjust_rho = opt->adjust_rho, adjust_gamma = opt->adjust_gamma, adjust_feas_rho = opt->adjust_feasibility_rho;
-    int freq = opt->rho_update_frequency;
-    if (any_ncvx_) { freq = 3; adjust_gamma = false; }              // PARSDMM_initialize.jl:107-114
+    Run& R = run_;
+    R = Run();
+    R.log = log;
+    R.maxit = opt->maxit;
+    const int p = p_n_, pp = pp_n_;
+    R.evol_rel_tol = (T)opt->evol_rel_tol; R.feas_tol = (T)opt->feas_tol; R.obj_tol = (T)opt->obj_tol;   // convert_options!
+    R.adjust_rho = opt->adjust_rho; R.adjust_gamma = opt->adjust_gamma; R.adjust_feas_rho = opt->adjust_feasibility_rho;
+    R.freq = opt->rho_update_frequency;
+    if (any_ncvx_) { R.freq = 3; R.adjust_gamma = false; }            // PARSDMM_initialize.jl:107-114
     std::fill(log->timing_ms, log->timing_ms + 7, 0.0);
     log->stopped_feasible = 0;
     for (int i = 0; i < pp; ++i) log->set_feasibility[i] = feas_init_[i];   // :236
-    double maxf = julia_maximum(feas_init_.begin(), feas_init_.end());
-    if (pp > 0 && maxf < (double)feas_tol) {                          // :101-104, PARSDMM.jl:63-82
+    const double maxf = julia_maximum(feas_init_.begin(), feas_init_.end());
+    R.active = true;
+    if (pp > 0 && maxf < (double)R.feas_tol) {                        // :101-104, PARSDMM.jl:63-82
       SIPX_HIP(hipMemcpyAsync(x_, m_, G_.N * sizeof(T), hipMemcpyDeviceToDevice, stream_));
       SIPX_HIP(hipStreamSynchronize(stream_));
       log->n_iter = 1;
       log->n_feas_rows = 1;
       log->stopped_feasible = 1;
+      R.done = true;
       return;
     }
-    int counter = 2, ind_ref = maxit;
-    double tol_ref = 1.0;
-    std::vector<double> rho(p), gamma(p), rho_new(p), rpri(p), rdual(p), feas(std::max(pp, 1));
-    for (int i = 0; i < p; ++i) { rho[i] = (double)rho_[i]; gamma[i] = (double)gamma_[i]; }
-    auto t_mark = [&](int k) { SIPX_HIP(hipEventRecord(ev_[k], stream_)); };
-    log->n_iter = maxit;
-    log->n_feas_rows = counter;
-    for (int i = 1; i <= maxit; ++i) {
+    R.counter = 2;
+    R.ind_ref = R.maxit;
+    R.tol_ref = 1.0;
+    R.rho.resize(p); R.gamma.resize(p); R.rho_new.resize(p); R.rpri.resize(p); R.rdual.resize(p);
+    R.feas.resize(std::max(pp, 1));
+    for (int i = 0; i < p; ++i) { R.rho[i] = (double)rho_[i]; R.gamma[i] = (double)gamma_[i]; }
+    log->n_iter = R.maxit;
+    log->n_feas_rows = R.counter;
+    if (R.maxit < 1) R.done = true;
+  }
+
+  bool parsdmm_step() override {
+    Run& R = run_;
+    if (!R.active) throw std::runtime_error("sipx_parsdmm_steps: call sipx_parsdmm_begin first");
+    if (R.done) return true;
+    sipx_log* log = R.log;
+    const int p = p_n_, pp = pp_n_, maxit = R.maxit;
+    std::vector<double>&rho = R.rho, &gamma = R.gamma, &rho_new = R.rho_new, &rpri = R.rpri, &rdual = R.rdual, &feas = R.feas;
+    int& counter = R.counter;
+    const int i = ++R.i;
+    const int eset = (i & 1) * 8;
+    resolve_timing(log, i & 1);          // marks recorded two steps ago have long completed
+    auto t_mark = [&](int k) { SIPX_HIP(hipEventRecord(ev_[eset + k], stream_)); };
+    {
       t_mark(0);
       rhs_compose(rho.data());
       t_mark(1);
       int64_t cg_it; double relres; int flag;
-      argmin_x(i, &tol_ref, &cg_it, &relres, &flag);
+      argmin_x(i, &R.tol_ref, &cg_it, &relres, &flag);
       log->cg_it[i - 1] = cg_it;
       log->cg_relres[i - 1] = relres;
       t_mark(2);
       int flags = 0;
       if (i % 10 == 0) flags |= SIPX_YL_FEAS;
       if (i == 1) flags |= SIPX_YL_FIRST;
-      if ((adjust_rho || adjust_gamma) && i % freq == 0) flags |= SIPX_YL_BB;
+      if ((R.adjust_rho || R.adjust_gamma) && i % R.freq == 0) flags |= SIPX_YL_BB;
       update_y_l(i, flags, rho.data(), gamma.data(), rpri.data(), rdual.data(), feas.data());
       T sd = (T)rdual[0], sp = (T)rpri[0];
       for (int k = 0; k < p; ++k) {
@@ -527,7 +572,7 @@ class Engine : public EngineBase {
       bool stop = false;
       if (i > 6 && pp > 0) {
         const double* row = log->set_feasibility + (size_t)(counter - 2) * pp;
-        if (julia_maximum(row, row + pp) < (double)feas_tol) {
+        if (julia_maximum(row, row + pp) < (double)R.feas_tol) {
           double mx = -INFINITY; bool nan = false;
           for (int k = i - 6; k < i; ++k) {
             const T a = (T)log->obj[k], b = (T)log->obj[k - 1];
@@ -535,33 +580,36 @@ class Engine : public EngineBase {
             if (std::isnan(v)) nan = true;
             mx = std::max(mx, (double)v);
           }
-          if (!nan && mx < (double)obj_tol) stop = true;
+          if (!nan && mx < (double)R.obj_tol) stop = true;
         }
       }
-      if (i > 5 && julia_maximum(log->evol_x + (i - 6), log->evol_x + i) < (double)evol_rel_tol) stop = true;
-      if (i > 20 && adjust_rho) {
+      if (i > 5 && julia_maximum(log->evol_x + (i - 6), log->evol_x + i) < (double)R.evol_rel_tol) stop = true;
+      if (i > 20 && R.adjust_rho) {
         const int lo = std::max(i - 50, 1);
         if (log->r_pri_total[i - 1] > julia_maximum(log->r_pri_total + (lo - 1), log->r_pri_total + (i - 1))) {
-          adjust_rho = adjust_feas_rho = adjust_gamma = false;
-          ind_ref = i;
+          R.adjust_rho = R.adjust_feas_rho = R.adjust_gamma = false;
+          R.ind_ref = i;
         }
       }
-      if (!adjust_rho && i > ind_ref + 25) {
-        const int lo = std::max(ind_ref, std::max(i - 50, 1));
+      if (!R.adjust_rho && i > R.ind_ref + 25) {
+        const int lo = std::max(R.ind_ref, std::max(i - 50, 1));
         if (log->r_pri_total[i - 1] > julia_maximum(log->r_pri_total + (lo - 1), log->r_pri_total + (i - 1))) stop = true;
       }
       t_mark(4);
       if (stop) {
-        add_timing(log, 5);
+        ev_pending_[i & 1] = 5;
+        resolve_timing(log, 0);
+        resolve_timing(log, 1);
         log->n_iter = i;
         log->n_feas_rows = counter;
-        return;
+        R.done = true;
+        return true;
       }
       // ---- adjust rho and gamma (PARSDMM.jl:163-227); l_hat / snapshots were fused into update_y_l ----
       rho_new = rho;
-      if ((adjust_rho || adjust_gamma) && i % freq == 0)
-        adapt_rho_gamma(adjust_rho, adjust_gamma, rho_new.data(), gamma.data());
-      if (adjust_feas_rho && i % 10 == 0 && i > 10 && pp > 0) {       // :213-223
+      if ((R.adjust_rho || R.adjust_gamma) && i % R.freq == 0)
+        adapt_rho_gamma(R.adjust_rho, R.adjust_gamma, rho_new.data(), gamma.data());
+      if (R.adjust_feas_rho && i % 10 == 0 && i > 10 && pp > 0) {       // :213-223
         const double* row = log->set_feasibility + (size_t)(counter - 2) * pp;
         int arg = 0;
         bool found_nan = false;
@@ -577,11 +625,23 @@ class Engine : public EngineBase {
       q_update(rho_new.data(), rho.data());                            // :230-243
       rho = rho_new;
       t_mark(6);
-      add_timing(log, 7);
+      ev_pending_[i & 1] = 7;
     }
-    log->n_iter = maxit;
-    log->n_feas_rows = counter;
-    for (int i = 0; i < p; ++i) { rho_[i] = (T)rho[i]; gamma_[i] = (T)gamma[i]; }
+    if (i == maxit) {
+      resolve_timing(log, 0);
+      resolve_timing(log, 1);
+      log->n_iter = maxit;
+      log->n_feas_rows = counter;
+      for (int k = 0; k < p; ++k) { rho_[k] = (T)rho[k]; gamma_[k] = (T)gamma[k]; }
+      R.done = true;
+    }
+    return R.done;
+  }
+
+  void parsdmm(const sipx_options* opt, sipx_log* log) override {
+    parsdmm_begin(opt, log);
+    while (!parsdmm_step()) {
+    }
   }
 
   // ------------------------------------------------------------------------------------------
@@ -771,11 +831,26 @@ class Engine : public EngineBase {
     cds_.d = (int)seen.size();
     for (int b = 0; b < cds_.d; ++b) cds_.off[b] = seen[b];
     Q_ = dalloc<T>((size_t)G_.N * cds_.d);
-    for (int i = 0; i < p_n_; ++i) {
-      const SetState<T>& s = sets_[i];
-      for (size_t j = 0; j < s.ata_off.size(); ++j)
-        K<T>::q_axpy(stream_, G_.N, Q_ + (size_t)q_col(s.ata_off[j]) * G_.N, s.ata + j * G_.N, rho_[i]);
+    QArgs<T> a;
+    a.nsets = 0;
+    for (int i = 0; i < p_n_; ++i) push_qset(a, sets_[i], rho_[i]);   // Q = 0 + rho_1 AtA_1 + rho_2 AtA_2 + ...
+    K<T>::q_update(stream_, G_, cds_, a, Q_);
+  }
+
+  void push_qset(QArgs<T>& a, const SetState<T>& s, T alpha) {
+    if (s.ata_off.size() > 7) throw std::runtime_error("more than 7 bands in one set's AtA are not supported");
+    for (long long o : s.ata_off) (void)q_col(o);     // CDS_scaled_add!.jl:18-20: the diagonal must exist in Q
+    if (a.nsets == MAX_SETS) {                         // flush a full batch, keep the order
+      K<T>::q_update(stream_, G_, cds_, a, Q_);
+      a.nsets = 0;
     }
+    QSet<T>& q = a.s[a.nsets++];
+    q.alpha = alpha;
+    q.ata = s.ata;
+    q.nblk = s.nblk;
+    for (int k = 0; k < 3; ++k) { q.dir[k] = s.dir[k]; q.ih[k] = s.ih[k]; }
+    q.nband = (int)s.ata_off.size();
+    for (int k = 0; k < q.nband; ++k) q.off[k] = s.ata_off[k];
   }
 
   SetArgs<T> set_args(const SetState<T>& s, T rho, T gamma, int flags) const {
@@ -831,12 +906,15 @@ class Engine : public EngineBase {
     for_rows(s, [&](long long r, long long e) { rows[r] = pad[e]; });
   }
 
-  void add_timing(sipx_log* log, int nmarks) {
-    SIPX_HIP(hipEventSynchronize(ev_[nmarks - 1]));
+  void resolve_timing(sipx_log* log, int set) {
+    const int nmarks = ev_pending_[set];
+    if (!nmarks) return;
+    ev_pending_[set] = 0;
+    SIPX_HIP(hipEventSynchronize(ev_[set * 8 + nmarks - 1]));
     // sections: rhs(0-1) argmin x(1-2) y/l(2-3) stop(3-4) adjust(4-5) Q-update(5-6); [0] "initialization" is host-side
     for (int k = 1; k < nmarks; ++k) {
       float ms = 0;
-      SIPX_HIP(hipEventElapsedTime(&ms, ev_[k - 1], ev_[k]));
+      SIPX_HIP(hipEventElapsedTime(&ms, ev_[set * 8 + k - 1], ev_[set * 8 + k]));
       log->timing_ms[k] += ms;
     }
   }
@@ -847,6 +925,16 @@ class Engine : public EngineBase {
       dfree(p);
   }
 
+  struct Run {     // state of one whole solve (sipx_parsdmm_begin / _steps)
+    bool active = false, done = false;
+    sipx_log* log = nullptr;
+    int maxit = 0, freq = 2, counter = 2, ind_ref = 0, i = 0;
+    T evol_rel_tol = 0, feas_tol = 0, obj_tol = 0;
+    bool adjust_rho = true, adjust_gamma = true, adjust_feas_rho = true;
+    double tol_ref = 1.0;
+    std::vector<double> rho, gamma, rho_new, rpri, rdual, feas;
+  };
+  Run run_;
   int device_ = 0, ndim_ = 2;
   hipStream_t stream_ = nullptr;
   Grid G_;
@@ -866,8 +954,10 @@ class Engine : public EngineBase {
   CgState<T>*cg_dev_ = nullptr, *cg_host_ = nullptr;
   double* hres_ = nullptr;
   std::vector<hipEvent_t> ev_;
+  int ev_pending_[2] = {0, 0};
   double obj_ss_ = 0, evo_ss_ = 0, xx_ss_ = 0;
   bool have_log_sums_ = false;
+  hipEvent_t cg_ev_[2] = {nullptr, nullptr};
   std::vector<hipEvent_t> stat_ev_;
   size_t stat_used_ = 0;
   bool stats_on_ = false;

@@ -27,6 +27,8 @@ struct EngineBase {
   virtual void q_update(const double* rho_new, const double* rho_old) = 0;
   virtual void download(void* x, void* const* l, void* const* y) = 0;
   virtual void parsdmm(const sipx_options* opt, sipx_log* log) = 0;
+  virtual void parsdmm_begin(const sipx_options* opt, sipx_log* log) = 0;
+  virtual bool parsdmm_step() = 0;
   virtual void apply_op(int op, const void* x, void* s, bool adjoint) = 0;
   virtual void project(const sipx_set_desc* d, void* v, int64_t len) = 0;
   virtual void get_Q(void* Q, int64_t* offsets, int* d) = 0;

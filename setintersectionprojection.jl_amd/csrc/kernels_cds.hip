@@ -162,32 +162,79 @@ struct GenArgs {
   int nband;
   long long off[7];
 };
+// value of (A'A)[g, g+o] for a difference operator (identity when nblk == 0), accumulated in ascending row order of A
+template <typename T>
+__device__ __forceinline__ T ata_value(const Grid& G, int nblk, const int* dir, const T* ihs, long long o, const Coord& c) {
+  T val = (nblk == 0 && o == 0) ? T(1) : T(0);   // identity: AtA = I (precompute_distribute.jl:44-45)
+  for (int q = 0; q < nblk; ++q) {
+    const int d = dir[q];
+    const T ih = ihs[q], nih = -ih;
+    const int cc = coord_of(c, d);
+    const long long st = G.st[d];
+    if (o == 0) {
+      if (cc > 0) val = val + ih * ih;              // row g-st holds +ih in column g
+      if (cc < G.n[d] - 1) val = val + nih * nih;   // row g holds -ih in column g
+    } else if (o == st) {
+      if (cc < G.n[d] - 1) val = val + nih * ih;    // row g: A[g,g]*A[g,g+st]
+    } else if (o == -st) {
+      if (cc > 0) val = val + ih * nih;             // row g-st: A[.,g]*A[.,g-st]
+    }
+  }
+  return val;
+}
+
 template <typename T>
 __global__ __launch_bounds__(BLOCK) void k_gen_ata(Grid G, GenArgs a, T ih0, T ih1, T ih2, T* __restrict__ R) {
   const T ihs[3] = {ih0, ih1, ih2};
   for (long long g = (long long)blockIdx.x * BLOCK + threadIdx.x; g < G.N; g += (long long)NB * BLOCK) {
     const Coord c = coords(G, g);
-    for (int b = 0; b < a.nband; ++b) {
-      const long long o = a.off[b];
-      T val = (a.nblk == 0 && o == 0) ? T(1) : T(0);   // identity: AtA = I (precompute_distribute.jl:44-45)
-      for (int q = 0; q < a.nblk; ++q) {
-        const int dir = a.dir[q];
-        const T ih = ihs[q], nih = -ih;
-        const int cc = coord_of(c, dir);
-        const long long st = G.st[dir];
-        if (o == 0) {
-          if (cc > 0) val = val + ih * ih;            // row g-st holds +ih in column g
-          if (cc < G.n[dir] - 1) val = val + nih * nih;  // row g holds -ih in column g
-        } else if (o == st) {
-          if (cc < G.n[dir] - 1) val = val + nih * ih;   // row g: A[g,g]*A[g,g+st]
-        } else if (o == -st) {
-          if (cc > 0) val = val + ih * nih;            // row g-st: A[.,g]*A[.,g-st]
+    for (int b = 0; b < a.nband; ++b) R[(long long)b * G.N + g] = ata_value<T>(G, a.nblk, a.dir, ihs, a.off[b], c);
+  }
+}
+
+// Fused Q update: every band of Q is read and written once; the changed sets are applied in order
+// (Q_update!.jl:45-48), their band values regenerated on the fly unless explicit bands were supplied.
+template <typename T, int V>
+__global__ __launch_bounds__(BLOCK) void k_q_update(Grid G, CdsArgs q, QArgs<T> a, T* __restrict__ Q) {
+  const long long nvec = G.N / V;
+  for (long long vi = (long long)blockIdx.x * BLOCK + threadIdx.x; vi < nvec; vi += (long long)NB * BLOCK) {
+    const long long g = vi * V;
+    Coord c[V];
+#pragma unroll
+    for (int k = 0; k < V; ++k) { c[k] = coords(G, g); c[k].i += k; }
+    for (int b = 0; b < q.d; ++b) {
+      const long long o = q.off[b];
+      bool touched = false;
+      Vec<T, V> qv;
+      for (int si = 0; si < a.nsets; ++si) {
+        const QSet<T>& S = a.s[si];
+        int j = -1;
+        for (int t = 0; t < S.nband; ++t) if (S.off[t] == o) j = t;
+        if (j < 0) continue;
+        if (!touched) { qv = ldv<T, V>(Q + (long long)b * G.N + g); touched = true; }
+        if (S.ata) {
+          const Vec<T, V> av = ldv_nt<T, V>(S.ata + (long long)j * G.N + g);
+#pragma unroll
+          for (int k = 0; k < V; ++k) qv.v[k] = qv.v[k] + S.alpha * av.v[k];
+        } else {
+#pragma unroll
+          for (int k = 0; k < V; ++k) qv.v[k] = qv.v[k] + S.alpha * ata_value<T>(G, S.nblk, S.dir, S.ih, o, c[k]);
         }
       }
-      R[(long long)b * G.N + g] = val;
+      if (touched) stv<T, V>(Q + (long long)b * G.N + g, qv);
     }
   }
 }
+template <typename T>
+void K<T>::q_update(hipStream_t s, const Grid& g, const CdsArgs& q, const QArgs<T>& a, T* Q) {
+  if (a.nsets == 0) return;
+  if (g.n[0] % 4 == 0)
+    hipLaunchKernelGGL((k_q_update<T, 4>), dim3(NB), dim3(BLOCK), 0, s, g, q, a, Q);
+  else
+    hipLaunchKernelGGL((k_q_update<T, 1>), dim3(NB), dim3(BLOCK), 0, s, g, q, a, Q);
+  SIPX_HIP(hipGetLastError());
+}
+
 template <typename T>
 void K<T>::gen_ata(hipStream_t s, const Grid& g, int nblk, const int* dir, const T* ih, int nband, const long long* offs,
                    T* R) {
@@ -372,6 +419,7 @@ void K<T>::fin_sum(hipStream_t s, const double* partials, int nslots, double* ou
                                const CgState<T>*);                                                                    \
   template void K<T>::resid(hipStream_t, long long, const T*, const CdsArgs&, const T*, const T*, T*, T*, T*, double*); \
   template void K<T>::q_axpy(hipStream_t, long long, T*, const T*, T);                                               \
+  template void K<T>::q_update(hipStream_t, const Grid&, const CdsArgs&, const QArgs<T>&, T*);                        \
   template void K<T>::gen_ata(hipStream_t, const Grid&, int, const int*, const T*, int, const long long*, T*);       \
   template void K<T>::cg_begin(hipStream_t, double*, CgState<T>*, CgState<T>*, int, T*, long long);                  \
   template void K<T>::cg_fin_alpha(hipStream_t, double*, CgState<T>*, CgState<T>*, int);                             \

@@ -85,6 +85,24 @@ struct SetArgs {
   int vsrc;                             // 1: read v from scratch instead of recomputing it
 };
 
+// One changed set of a fused Q update: Q[:,col(off_j)] += alpha * AtA_i[:,j] (CDS_scaled_add!.jl:16-22).
+// ata == nullptr: the band values of A_i'A_i are regenerated from the operator descriptor.
+template <typename T>
+struct QSet {
+  T alpha;
+  const T* ata;
+  int nblk;
+  int dir[3];
+  T ih[3];
+  int nband;
+  long long off[7];
+};
+template <typename T>
+struct QArgs {
+  int nsets;
+  QSet<T> s[MAX_SETS];
+};
+
 template <typename T>
 struct RhsSet {
   const T *y, *l;
@@ -121,6 +139,7 @@ struct K {
   static void resid(hipStream_t s, long long N, const T* R, const CdsArgs& a, const T* x, const T* b, T* r, T* p,
                     T* xold, double* partials);
   static void q_axpy(hipStream_t s, long long N, T* Qband, const T* Aband, T alpha);
+  static void q_update(hipStream_t s, const Grid& g, const CdsArgs& q, const QArgs<T>& a, T* Q);
   static void gen_ata(hipStream_t s, const Grid& g, int nblk, const int* dir, const T* ih, int nband,
                       const long long* offs, T* R);
   // CG

@@ -27,7 +27,8 @@ LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "libsipx.so"
 EXPORTED_SYMBOLS = [
     "sipx_last_error", "sipx_create", "sipx_destroy", "sipx_add_set", "sipx_set_rows", "sipx_num_terms",
     "sipx_finalize", "sipx_rhs_compose", "sipx_argmin_x", "sipx_update_y_l", "sipx_log_scalars",
-    "sipx_adapt_rho_gamma", "sipx_q_update", "sipx_download", "sipx_parsdmm", "sipx_cds_spmv",
+    "sipx_adapt_rho_gamma", "sipx_q_update", "sipx_download", "sipx_parsdmm", "sipx_parsdmm_begin",
+    "sipx_parsdmm_steps", "sipx_cds_spmv",
     "sipx_apply_op", "sipx_apply_op_adj", "sipx_project", "sipx_get_Q", "sipx_time_spmv", "sipx_kernel_stats",
     "sipx_debug_proj",
     "sipx_stream",
@@ -501,7 +502,7 @@ class Context:
         _chk(lib().sipx_kernel_stats(self.h, int(enable), C.byref(n), C.byref(ms)))
         return n.value, ms.value
 
-    def parsdmm(self, options: PARSDMM_options):
+    def _log_struct(self, options: PARSDMM_options):
         maxit, p, pp = int(options.maxit), self.p, self.pp
         o = _Options(maxit, float(options.evol_rel_tol), float(options.feas_tol), float(options.obj_tol),
                      int(options.rho_update_frequency), int(options.adjust_rho), int(options.adjust_gamma),
@@ -513,14 +514,35 @@ class Context:
         lg = _Log()
         for k, a in arrs.items():
             setattr(lg, k, a.ctypes.data)
+        return o, lg, arrs
+
+    def _log_result(self, lg, arrs):
+        it, nf, pp = lg.n_iter, lg.n_feas_rows, self.pp
+        return log_type_PARSDMM(arrs["set_feasibility"][:nf, :pp], arrs["r_dual"][:it], arrs["r_pri"][:it],
+                                arrs["r_dual_total"][:it], arrs["r_pri_total"][:it], arrs["obj"][:it],
+                                arrs["evol_x"][:it], arrs["rho"][:it], arrs["gamma"][:it], arrs["cg_it"][:it],
+                                arrs["cg_relres"][:it],
+                                dict(zip(TIMING_SECTIONS, [t * 1e-3 for t in lg.timing_ms])))
+
+    def parsdmm(self, options: PARSDMM_options):
+        o, lg, arrs = self._log_struct(options)
         _chk(lib().sipx_parsdmm(self.h, C.byref(o), C.byref(lg)))
-        it, nf = lg.n_iter, lg.n_feas_rows
-        log = log_type_PARSDMM(arrs["set_feasibility"][:nf, :pp], arrs["r_dual"][:it], arrs["r_pri"][:it],
-                               arrs["r_dual_total"][:it], arrs["r_pri_total"][:it], arrs["obj"][:it],
-                               arrs["evol_x"][:it], arrs["rho"][:it], arrs["gamma"][:it], arrs["cg_it"][:it],
-                               arrs["cg_relres"][:it],
-                               dict(zip(TIMING_SECTIONS, [t * 1e-3 for t in lg.timing_ms])))
-        return log, bool(lg.stopped_feasible)
+        return self._log_result(lg, arrs), bool(lg.stopped_feasible)
+
+    # the same native solve advanced in pieces (sipx_parsdmm_begin / sipx_parsdmm_steps)
+    def parsdmm_begin(self, options: PARSDMM_options):
+        self._run = self._log_struct(options)            # keeps the log arrays alive
+        o, lg, arrs = self._run
+        _chk(lib().sipx_parsdmm_begin(self.h, C.byref(o), C.byref(lg)))
+
+    def parsdmm_steps(self, nsteps: int) -> bool:
+        done = C.c_int()
+        _chk(lib().sipx_parsdmm_steps(self.h, int(nsteps), C.byref(done)))
+        return bool(done.value)
+
+    def parsdmm_log(self):
+        o, lg, arrs = self._run
+        return self._log_result(lg, arrs)
 
 
 def build_context(m, AtA, TD_OP, set_Prop, P_sub, comp_grid, options, x=None, l=None, y=None, device=0,

@@ -121,7 +121,7 @@ class PhaseDriver:
                                     np.zeros(m), np.zeros(m), np.zeros((m, p)), np.zeros((m, p)),
                                     np.zeros(m, np.int64), np.zeros(m))
         feas0 = np.asarray(ctx.feasibility_initial, np.float64).copy()
-        if self.comm.world > 1:
+        if not isinstance(self.comm, LocalComm):
             feas0 = self.comm.allreduce_scalars(feas0)
         self.log.set_feasibility[0, :] = feas0
         self.stopped_feasible = bool(pp > 0 and _nanmax(feas0) < float(self.feas_tol))   # PARSDMM.jl:63-82
@@ -159,7 +159,7 @@ class PhaseDriver:
         self.i += 1
         i = self.i
         ctx.rhs_compose(self.rho)                                                    # PARSDMM.jl:101
-        if self.comm.world > 1:
+        if not isinstance(self.comm, LocalComm):
             self.comm.allreduce_rhs(ctx)
         self.tol_ref, cg_it, relres, _ = ctx.argmin_x(i, self.tol_ref)               # :106-107
         log.cg_it[i - 1], log.cg_relres[i - 1] = cg_it, relres
@@ -170,11 +170,11 @@ class PhaseDriver:
             flags |= YL_BB
         rp, rd, fe = ctx.update_y_l(i, flags, self.rho, self.gamma)                  # :133
         own_dist = bool(self.owned[p - 1]) or pp == p
-        obj, evol = ctx.log_scalars() if (own_dist or self.comm.world == 1) else (0.0, 0.0)
+        obj, evol = ctx.log_scalars() if (own_dist or isinstance(self.comm, LocalComm)) else (0.0, 0.0)
         rho_new, gam_new = self.rho.copy(), self.gamma.copy()
         if bb_due:                               # speculative: discarded if the stop rule freezes rho below
             rho_new, gam_new = ctx.adapt_rho_gamma(self.adjust_rho, self.adjust_gamma, self.rho, self.gamma)
-        if self.comm.world > 1:
+        if not isinstance(self.comm, LocalComm):
             own = np.asarray(self.owned, np.float64)
             lead = 1.0 if (own_dist and (pp < p or self.comm.rank == 0)) else 0.0
             pack = np.concatenate([rp * own, rd * own, fe * own[:pp], [obj * lead, evol * lead], rho_new * own,
