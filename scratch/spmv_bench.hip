@@ -4,6 +4,7 @@
 #include <cstdlib>
 #include <vector>
 #include <string>
+#include "../setintersectionprojection.jl_amd/csrc/kernels_cds.hip"
 
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); exit(1);} } while (0)
 
@@ -63,6 +64,38 @@ __global__ __launch_bounds__(256) void k_spmv(long long N, long long ldq, const 
   }
 }
 
+// branch-free variant: x carries a zero halo of max|off| on both sides, every band is one unconditional
+// (possibly 4-byte-aligned) dwordx4 load of x; out-of-range rows are masked by a select.
+typedef float vf4u __attribute__((ext_vector_type(4), aligned(4)));
+typedef float vf4a __attribute__((ext_vector_type(4)));
+template <int NTS>
+__global__ __launch_bounds__(256) void k_spmv_halo(long long N, long long ldq, const float* __restrict__ R, Offs a,
+                                                   const float* __restrict__ x, float* __restrict__ y) {
+  const long long nvec = N / 4;
+  for (long long vi = (long long)blockIdx.x * 256 + threadIdx.x; vi < nvec; vi += (long long)gridDim.x * 256) {
+    const long long r = vi * 4;
+    vf4a rv[7]; vf4u xv[7];
+#pragma unroll
+    for (int b = 0; b < 7; ++b) {
+      rv[b] = __builtin_nontemporal_load(reinterpret_cast<const vf4a*>(R + b * ldq + r));
+      xv[b] = *reinterpret_cast<const vf4u*>(x + r + a.o[b]);
+    }
+    float acc[4] = {0, 0, 0, 0};
+#pragma unroll
+    for (int b = 0; b < 7; ++b) {
+      const long long c = r + a.o[b];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const float t = acc[k] + rv[b][k] * xv[b][k];
+        acc[k] = (c + k >= 0 && c + k < N) ? t : acc[k];
+      }
+    }
+    vf4a o4 = {acc[0], acc[1], acc[2], acc[3]};
+    if (NTS) __builtin_nontemporal_store(o4, reinterpret_cast<vf4a*>(y + r));
+    else *reinterpret_cast<vf4a*>(y + r) = o4;
+  }
+}
+
 // pure streaming reference: y = sum of 7 bands * x (no shifted reads)
 __global__ __launch_bounds__(256) void k_stream(long long N, long long ldq, const float* __restrict__ R,
                                                 const float* __restrict__ x, float* __restrict__ y) {
@@ -107,11 +140,17 @@ int main(int argc, char** argv) {
   Offs a; long long offs[7] = {0, -1, 1, -n, n, -(long long)n * n, (long long)n * n};
   for (int i = 0; i < 7; ++i) a.o[i] = offs[i];
   const double bytes = 9.0 * N * 4;
-  for (long long pad : {0ll, 1024ll, 4096ll + 256ll}) {
+  for (long long pad : {0ll}) {
     const long long ldq = N + pad;
     float *R, *x, *y;
     CK(hipMalloc(&R, ldq * 7 * 4)); CK(hipMalloc(&x, N * 4)); CK(hipMalloc(&y, N * 4));
-    CK(hipMemset(R, 0, ldq * 7 * 4)); CK(hipMemset(x, 0, N * 4));
+    {   // random (non-zero) data: zero operands inflate clocks and bandwidth
+      std::vector<float> h((size_t)ldq * 7);
+      unsigned s = 12345u;
+      for (auto& v : h) { s = s * 1664525u + 1013904223u; v = (float)((s >> 8) & 0xffff) / 65536.0f - 0.5f; }
+      CK(hipMemcpy(R, h.data(), h.size() * 4, hipMemcpyHostToDevice));
+      CK(hipMemcpy(x, h.data(), (size_t)N * 4, hipMemcpyHostToDevice));
+    }
     printf("n=%d pad=%lld\n", n, pad);
     // copy 3N floats: source R[0,3N) -> destination R[4*ldq, 4*ldq+3N)  (inside the 7*ldq allocation)
     double t = timeit([&] { hipLaunchKernelGGL(k_copy, dim3(2048), dim3(256), 0, 0, 3 * N / 4, (const float4*)R, (float4*)(R + 4 * ldq)); });
@@ -129,6 +168,24 @@ int main(int argc, char** argv) {
       printf("  spmv gs nb=%d nt          : %.1f us  %.0f GB/s\n", nb, t * 1e3, bytes / t / 1e6); fflush(stdout);
       t = timeit([&] { hipLaunchKernelGGL((k_spmv<1, 1>), dim3(nb), dim3(256), 0, 0, N, ldq, R, a, x, y, 1); });
       printf("  spmv gs nb=%d nt remap    : %.1f us  %.0f GB/s\n", nb, t * 1e3, bytes / t / 1e6); fflush(stdout);
+    }
+    {
+      const long long H = (long long)n * n;      // halo = max |offset|
+      float* xh; CK(hipMalloc(&xh, (N + 2 * H) * 4)); CK(hipMemset(xh, 0, (N + 2 * H) * 4));
+      CK(hipMemcpy(xh + H, x, N * 4, hipMemcpyDeviceToDevice));
+      for (int nb : {1024, 2048, 4096}) {
+        t = timeit([&] { hipLaunchKernelGGL((k_spmv_halo<1>), dim3(nb), dim3(256), 0, 0, N, ldq, R, a, xh + H, y); });
+        printf("  spmv HALO nt nb=%d         : %.1f us  %.0f GB/s\n", nb, t * 1e3, bytes / t / 1e6); fflush(stdout);
+        t = timeit([&] { hipLaunchKernelGGL((k_spmv_halo<0>), dim3(nb), dim3(256), 0, 0, N, ldq, R, a, xh + H, y); });
+        printf("  spmv HALO nt-load nb=%d    : %.1f us  %.0f GB/s\n", nb, t * 1e3, bytes / t / 1e6); fflush(stdout);
+      }
+      CK(hipFree(xh));
+    }
+    {
+      sipx::CdsArgs ca; ca.d = 7; for (int i = 0; i < 7; ++i) ca.off[i] = a.o[i];
+      sipx::Grid gg; gg.N = N;
+      t = timeit([&] { sipx::K<float>::spmv(0, gg, N, R, ca, x, y); });
+      printf("  ENGINE k_cds MODE0         : %.1f us  %.0f GB/s\n", t * 1e3, bytes / t / 1e6); fflush(stdout);
     }
     {
       const int nb = (int)(N / 4 / 256);

@@ -100,6 +100,7 @@ struct SetState {
   bool ident = true, two_pass = false, is_dist = false, owned = true;
   T *y = nullptr, *l = nullptr, *dy = nullptr, *lh0 = nullptr, *y0 = nullptr, *s0 = nullptr, *l0 = nullptr;
   T *lb = nullptr, *ub = nullptr, *ata = nullptr;
+  std::vector<void*> halo_allocs;   // bases of the vectors allocated with a front halo
   ProjScalars<T>* ps = nullptr;    // scalars of prox_i (warm-started across iterations)
   ProjScalars<T>* psf = nullptr;   // scalars of the feasibility estimate P_i(A_i x)
   std::vector<long long> ata_off;
@@ -129,13 +130,13 @@ class Engine : public EngineBase {
     G_.st[0] = 1;
     G_.st[1] = G_.n[0];
     G_.st[2] = G_.n[0] * G_.n[1];
-    if (G_.N >= (1ll << 40)) throw std::runtime_error("grid too large");
+    if (G_.N >= (1ll << 31)) throw std::runtime_error("grids of 2^31 points or more are not supported");
   }
   ~Engine() override {
     (void)hipSetDevice(device_);
     (void)hipStreamSynchronize(stream_);
     for (auto& s : sets_) free_set(s);
-    for (void* p : {(void*)x_, (void*)xold_, (void*)rhs_, (void*)m_, (void*)r_, (void*)p_, (void*)Ap_, (void*)Q_,
+    for (void* p : {(void*)x_base_, (void*)xold_, (void*)rhs_, (void*)m_base_, (void*)r_, (void*)p_base_, (void*)Ap_, (void*)Q_,
                     (void*)scr_v_, (void*)scr_c_, (void*)scr_i_, (void*)part_cg_, (void*)part_tmp_, (void*)part_sets_,
                     (void*)maxpart_, (void*)cg_dev_})
       dfree(p);
@@ -231,8 +232,18 @@ class Engine : public EngineBase {
     if (any_ncvx_) g0 = T(0.75);
     std::fill(gamma_.begin(), gamma_.end(), g0);
 
-    x_ = dalloc<T>(N); xold_ = dalloc<T>(N); rhs_ = dalloc<T>(N); m_ = dalloc<T>(N);
-    r_ = dalloc<T>(N); p_ = dalloc<T>(N); Ap_ = dalloc<T>(N);
+    // Q offsets first: the SpMV inputs (x, p) carry a zero halo of max|offset| on both sides so that the
+    // kernels need no bounds checks on neighbour loads
+    plan_Q_offsets();
+    halo_ = 4;
+    for (int b = 0; b < cds_.d; ++b) halo_ = std::max<long long>(halo_, std::llabs(cds_.off[b]));
+    for (int a = 0; a < 3; ++a) halo_ = std::max<long long>(halo_, G_.st[a]);
+    halo_ = (halo_ + 3) / 4 * 4;
+    x_base_ = dalloc<T>(N + 2 * halo_); x_ = x_base_ + halo_;
+    p_base_ = dalloc<T>(N + 2 * halo_); p_ = p_base_ + halo_;
+    xold_ = dalloc<T>(N); rhs_ = dalloc<T>(N);
+    m_base_ = dalloc<T>(N + 2 * halo_); m_ = m_base_ + halo_;   // forward stencils of A m read past the end
+    r_ = dalloc<T>(N); Ap_ = dalloc<T>(N);
     SIPX_HIP(hipMemcpy(m_, m, N * sizeof(T), hipMemcpyHostToDevice));
     long long maxpad = N;
     for (auto& s : sets_) maxpad = std::max(maxpad, s.Mpad);
@@ -267,9 +278,15 @@ class Engine : public EngineBase {
         s.host_ata.shrink_to_fit();
       }
       if (!s.owned) continue;
-      s.y = dalloc<T>(s.Mpad); s.l = dalloc<T>(s.Mpad);
+      // vectors read through adjoint stencils (w[g - stride]) carry a zero front halo: no bounds checks in the kernels
+      auto halloc = [&](long long n) {
+        T* base = dalloc<T>(n + halo_);
+        s.halo_allocs.push_back(base);
+        return base + halo_;
+      };
+      s.y = halloc(s.Mpad); s.l = halloc(s.Mpad);
       s.lh0 = dalloc<T>(s.Mpad); s.y0 = dalloc<T>(s.Mpad); s.s0 = dalloc<T>(s.Mpad); s.l0 = dalloc<T>(s.Mpad);
-      if (!s.ident) s.dy = dalloc<T>(s.Mpad);
+      if (!s.ident) s.dy = halloc(s.Mpad);
       if (s.two_pass) {
         s.ps = dalloc<ProjScalars<T>>(1);
         s.psf = dalloc<ProjScalars<T>>(1);
@@ -649,8 +666,12 @@ class Engine : public EngineBase {
     SIPX_HIP(hipSetDevice(device_));
     SetState<T> s;
     configure_op(s, op);
-    T* dx = dalloc<T>(G_.N);
-    T* dv = dalloc<T>(s.Mpad);
+    long long H = 4;
+    for (int a = 0; a < 3; ++a) H = std::max<long long>(H, G_.st[a]);
+    H = (H + 3) / 4 * 4;
+    T* dxb = dalloc<T>(G_.N + 2 * H);
+    T* dvb = dalloc<T>(s.Mpad + H);
+    T *dx = dxb + H, *dv = dvb + H;
     if (!adjoint) {
       SIPX_HIP(hipMemcpy(dx, x, G_.N * sizeof(T), hipMemcpyHostToDevice));
       K<T>::fwd(stream_, G_, s.nblk, s.dir, s.ih, dx, dv);
@@ -661,8 +682,8 @@ class Engine : public EngineBase {
       SIPX_HIP(hipStreamSynchronize(stream_));
       SIPX_HIP(hipMemcpy(out, dx, G_.N * sizeof(T), hipMemcpyDeviceToHost));
     }
-    dfree(dx);
-    dfree(dv);
+    dfree(dxb);
+    dfree(dvb);
   }
 
   void project(const sipx_set_desc* d, void* v, int64_t len) override {
@@ -817,7 +838,7 @@ class Engine : public EngineBase {
                              "to have the same nonzero diagonals");   // CDS_scaled_add!.jl:18-20
   }
 
-  void assemble_Q() {      // PARSDMM_initialize.jl:216-230: first-seen offsets over a zero-padded table
+  void plan_Q_offsets() {  // PARSDMM_initialize.jl:216-221: first-seen offsets over a zero-padded table
     std::vector<long long> seen;
     auto see = [&](long long o) {
       if (std::find(seen.begin(), seen.end(), o) == seen.end()) seen.push_back(o);
@@ -830,6 +851,9 @@ class Engine : public EngineBase {
     if ((int)seen.size() > MAXD) throw std::runtime_error("Q has more bands than this build supports");
     cds_.d = (int)seen.size();
     for (int b = 0; b < cds_.d; ++b) cds_.off[b] = seen[b];
+  }
+
+  void assemble_Q() {      // PARSDMM_initialize.jl:222-230
     Q_ = dalloc<T>((size_t)G_.N * cds_.d);
     QArgs<T> a;
     a.nsets = 0;
@@ -920,8 +944,9 @@ class Engine : public EngineBase {
   }
 
   void free_set(SetState<T>& s) {
-    for (void* p : {(void*)s.y, (void*)s.l, (void*)s.dy, (void*)s.lh0, (void*)s.y0, (void*)s.s0, (void*)s.l0,
-                    (void*)s.lb, (void*)s.ub, (void*)s.ata, (void*)s.ps, (void*)s.psf})
+    for (void* p : s.halo_allocs) dfree(p);
+    for (void* p : {(void*)s.lh0, (void*)s.y0, (void*)s.s0, (void*)s.l0, (void*)s.lb, (void*)s.ub, (void*)s.ata,
+                    (void*)s.ps, (void*)s.psf})
       dfree(p);
   }
 
@@ -945,6 +970,8 @@ class Engine : public EngineBase {
   int p_n_ = 0, pp_n_ = 0;
   std::vector<T> rho_, gamma_;
   std::vector<double> feas_init_;
+  T *x_base_ = nullptr, *p_base_ = nullptr, *m_base_ = nullptr;
+  long long halo_ = 0;
   T *x_ = nullptr, *xold_ = nullptr, *rhs_ = nullptr, *m_ = nullptr, *r_ = nullptr, *p_ = nullptr, *Ap_ = nullptr;
   T *Q_ = nullptr, *scr_v_ = nullptr, *scr_c_ = nullptr, *maxpart_ = nullptr;
   long long* scr_i_ = nullptr;
@@ -976,8 +1003,12 @@ EngineBase* make_engine(int dtype, int ndim, const int64_t* n, const double* h, 
 template <typename T>
 static void cds_spmv_T(int64_t N, int d, const void* R, const int64_t* off, const void* x, void* y) {
   if (d < 1 || d > MAXD) throw std::runtime_error("cds_spmv: band count out of range");
+  long long H = 4;
+  for (int b = 0; b < d; ++b) H = std::max<long long>(H, std::llabs((long long)off[b]));
+  H = (H + 3) / 4 * 4;
   T* dR = dalloc<T>((size_t)N * d, false);
-  T* dx = dalloc<T>(N, false);
+  T* dxb = dalloc<T>(N + 2 * H);          // zero halo on both sides
+  T* dx = dxb + H;
   T* dy = dalloc<T>(N);
   SIPX_HIP(hipMemcpy(dR, R, (size_t)N * d * sizeof(T), hipMemcpyHostToDevice));
   SIPX_HIP(hipMemcpy(dx, x, N * sizeof(T), hipMemcpyHostToDevice));
@@ -989,7 +1020,7 @@ static void cds_spmv_T(int64_t N, int d, const void* R, const int64_t* off, cons
   K<T>::spmv(nullptr, g, N, dR, a, dx, dy);
   SIPX_HIP(hipDeviceSynchronize());
   SIPX_HIP(hipMemcpy(y, dy, N * sizeof(T), hipMemcpyDeviceToHost));
-  dfree(dR); dfree(dx); dfree(dy);
+  dfree(dR); dfree(dxb); dfree(dy);
 }
 
 void cds_spmv_host(int dtype, int64_t N, int d, const void* R, const int64_t* off, const void* x, void* y, int device) {

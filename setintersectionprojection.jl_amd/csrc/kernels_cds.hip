@@ -17,26 +17,42 @@
 namespace sipx {
 
 // acc[k] = sum_b R[r+k, b] * x[r+k+off_b], bands in order, rows clipped like CDS_MVp.jl:17-23.
+// BRANCH-FREE: x carries a halo of max|off| elements on both sides (engine allocation), so every band
+// is one unconditional band load + one unconditional (element-aligned) x load; rows whose column falls
+// outside [0,N) are masked by a select, which keeps the reference's "skip" semantics bit for bit.
+// All 2d loads of a row group are independent and issue back to back (measured +30% over the
+// bounds-checked version, profiles/r01_spmv_designspace_*.txt).
 template <typename T, int V, int D>
 __device__ __forceinline__ void cds_rows(long long N, const T* __restrict__ R, const CdsArgs& a,
                                          const T* __restrict__ x, long long r, T (&acc)[V]) {
   const int d = D ? D : a.d;
 #pragma unroll
   for (int k = 0; k < V; ++k) acc[k] = T(0);
+  if constexpr (D > 0) {
+    Vec<T, V> rv[D], xv[D];
 #pragma unroll
-  for (int b = 0; b < d; ++b) {
-    const long long o = a.off[b];
-    const Vec<T, V> rv = ldv_nt<T, V>(R + (long long)b * N + r);
-    const long long c = r + o;
-    if ((o % V) == 0 && c >= 0 && c + V <= N) {
-      const Vec<T, V> xv = ldv<T, V>(x + c);
+    for (int b = 0; b < D; ++b) {
+      rv[b] = ldv_nt<T, V>(R + (long long)b * N + r);
+      xv[b] = ldv_u<T, V>(x + r + a.off[b]);
+    }
 #pragma unroll
-      for (int k = 0; k < V; ++k) acc[k] = acc[k] + rv.v[k] * xv.v[k];
-    } else {
+    for (int b = 0; b < D; ++b) {
+      const long long c = r + a.off[b];
 #pragma unroll
       for (int k = 0; k < V; ++k) {
-        const long long cc = c + k;
-        if (cc >= 0 && cc < N) acc[k] = acc[k] + rv.v[k] * x[cc];
+        const T t = acc[k] + rv[b].v[k] * xv[b].v[k];
+        acc[k] = (c + k >= 0 && c + k < N) ? t : acc[k];
+      }
+    }
+  } else {
+    for (int b = 0; b < d; ++b) {
+      const long long c = r + a.off[b];
+      const Vec<T, V> rv = ldv_nt<T, V>(R + (long long)b * N + r);
+      const Vec<T, V> xv = ldv_u<T, V>(x + c);
+#pragma unroll
+      for (int k = 0; k < V; ++k) {
+        const T t = acc[k] + rv.v[k] * xv.v[k];
+        acc[k] = (c + k >= 0 && c + k < N) ? t : acc[k];
       }
     }
   }
@@ -52,7 +68,7 @@ __global__ __launch_bounds__(BLOCK) void k_cds(long long N, const T* __restrict_
   if (MODE == 1 && *done) return;
   const long long nvec = N / V;
   double acc0 = 0, acc1 = 0;
-  for (long long vi = (long long)blockIdx.x * BLOCK + threadIdx.x; vi < nvec; vi += (long long)NB * BLOCK) {
+  for (long long vi = (long long)blockIdx.x * BLOCK + threadIdx.x; vi < nvec; vi += (long long)gridDim.x * BLOCK) {
     const long long r = vi * V;
     T s[V];
     cds_rows<T, V, D>(N, R, a, x, r, s);
@@ -60,7 +76,7 @@ __global__ __launch_bounds__(BLOCK) void k_cds(long long N, const T* __restrict_
       Vec<T, V> o;
 #pragma unroll
       for (int k = 0; k < V; ++k) o.v[k] = s[k];
-      stv<T, V>(y + r, o);
+      stv_nt<T, V>(y + r, o);
     } else if (MODE == 1) {
       const Vec<T, V> pv = ldv<T, V>(x + r);
       Vec<T, V> o;
@@ -69,7 +85,7 @@ __global__ __launch_bounds__(BLOCK) void k_cds(long long N, const T* __restrict_
         o.v[k] = s[k];
         acc0 += (double)pv.v[k] * (double)s[k];
       }
-      stv<T, V>(y + r, o);
+      stv_nt<T, V>(y + r, o);
     } else {
       const Vec<T, V> bv = ldv<T, V>(b + r);
       const Vec<T, V> xv = ldv<T, V>(x + r);
@@ -99,7 +115,7 @@ static void launch_cds(hipStream_t s, long long N, const T* R, const CdsArgs& a,
                        T* xold, double* partials, const int* done) {
   if (a.d < 1 || a.d > MAXD) throw std::runtime_error("cds: band count out of range");
 #define SIPX_CDS(V, D) \
-  hipLaunchKernelGGL((k_cds<T, V, D, MODE>), dim3(NB), dim3(BLOCK), 0, s, N, R, a, x, y, b, pout, xold, partials, done)
+  hipLaunchKernelGGL((k_cds<T, V, D, MODE>), dim3(NB_7), dim3(BLOCK), 0, s, N, R, a, x, y, b, pout, xold, partials, done)
   if (N % 4 == 0) {
     switch (a.d) {
       case 1: SIPX_CDS(4, 1); break;
@@ -135,7 +151,7 @@ void K<T>::resid(hipStream_t s, long long N, const T* R, const CdsArgs& a, const
 template <typename T, int V>
 __global__ __launch_bounds__(BLOCK) void k_q_axpy(long long N, T* __restrict__ q, const T* __restrict__ a, T alpha) {
   const long long nvec = N / V;
-  for (long long vi = (long long)blockIdx.x * BLOCK + threadIdx.x; vi < nvec; vi += (long long)NB * BLOCK) {
+  for (long long vi = (long long)blockIdx.x * BLOCK + threadIdx.x; vi < nvec; vi += (long long)gridDim.x * BLOCK) {
     Vec<T, V> qv = ldv<T, V>(q + vi * V);
     const Vec<T, V> av = ldv<T, V>(a + vi * V);
 #pragma unroll
@@ -186,7 +202,7 @@ __device__ __forceinline__ T ata_value(const Grid& G, int nblk, const int* dir, 
 template <typename T>
 __global__ __launch_bounds__(BLOCK) void k_gen_ata(Grid G, GenArgs a, T ih0, T ih1, T ih2, T* __restrict__ R) {
   const T ihs[3] = {ih0, ih1, ih2};
-  for (long long g = (long long)blockIdx.x * BLOCK + threadIdx.x; g < G.N; g += (long long)NB * BLOCK) {
+  for (long long g = (long long)blockIdx.x * BLOCK + threadIdx.x; g < G.N; g += (long long)gridDim.x * BLOCK) {
     const Coord c = coords(G, g);
     for (int b = 0; b < a.nband; ++b) R[(long long)b * G.N + g] = ata_value<T>(G, a.nblk, a.dir, ihs, a.off[b], c);
   }
@@ -197,7 +213,7 @@ __global__ __launch_bounds__(BLOCK) void k_gen_ata(Grid G, GenArgs a, T ih0, T i
 template <typename T, int V>
 __global__ __launch_bounds__(BLOCK) void k_q_update(Grid G, CdsArgs q, QArgs<T> a, T* __restrict__ Q) {
   const long long nvec = G.N / V;
-  for (long long vi = (long long)blockIdx.x * BLOCK + threadIdx.x; vi < nvec; vi += (long long)NB * BLOCK) {
+  for (long long vi = (long long)blockIdx.x * BLOCK + threadIdx.x; vi < nvec; vi += (long long)gridDim.x * BLOCK) {
     const long long g = vi * V;
     Coord c[V];
 #pragma unroll
@@ -322,7 +338,7 @@ __global__ __launch_bounds__(BLOCK) void k_cg_update_xr(long long N, T* __restri
   const T alpha = st->alpha;
   const long long nvec = N / V;
   double acc[1] = {0};
-  for (long long vi = (long long)blockIdx.x * BLOCK + threadIdx.x; vi < nvec; vi += (long long)NB * BLOCK) {
+  for (long long vi = (long long)blockIdx.x * BLOCK + threadIdx.x; vi < nvec; vi += (long long)gridDim.x * BLOCK) {
     Vec<T, V> xv = ldv<T, V>(x + vi * V), rv = ldv<T, V>(r + vi * V);
     const Vec<T, V> pv = ldv<T, V>(p + vi * V), av = ldv<T, V>(Ap + vi * V);
 #pragma unroll
@@ -340,9 +356,9 @@ template <typename T>
 void K<T>::cg_update_xr(hipStream_t s, long long N, T* x, T* r, const T* p, const T* Ap, double* partials,
                         const CgState<T>* st) {
   if (N % 4 == 0)
-    hipLaunchKernelGGL((k_cg_update_xr<T, 4>), dim3(NB), dim3(BLOCK), 0, s, N, x, r, p, Ap, partials, st);
+    hipLaunchKernelGGL((k_cg_update_xr<T, 4>), dim3(NB_7), dim3(BLOCK), 0, s, N, x, r, p, Ap, partials, st);
   else
-    hipLaunchKernelGGL((k_cg_update_xr<T, 1>), dim3(NB), dim3(BLOCK), 0, s, N, x, r, p, Ap, partials, st);
+    hipLaunchKernelGGL((k_cg_update_xr<T, 1>), dim3(NB_7), dim3(BLOCK), 0, s, N, x, r, p, Ap, partials, st);
   SIPX_HIP(hipGetLastError());
 }
 
@@ -379,7 +395,7 @@ __global__ __launch_bounds__(BLOCK) void k_cg_update_p(long long N, T* __restric
   if (st->done) return;
   const T beta = st->beta;
   const long long nvec = N / V;
-  for (long long vi = (long long)blockIdx.x * BLOCK + threadIdx.x; vi < nvec; vi += (long long)NB * BLOCK) {
+  for (long long vi = (long long)blockIdx.x * BLOCK + threadIdx.x; vi < nvec; vi += (long long)gridDim.x * BLOCK) {
     Vec<T, V> pv = ldv<T, V>(p + vi * V);
     const Vec<T, V> rv = ldv<T, V>(r + vi * V);
 #pragma unroll

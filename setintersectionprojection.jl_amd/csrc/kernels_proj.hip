@@ -28,6 +28,7 @@
 namespace sipx {
 
 constexpr double L1_CAP = 131072.0;     // bracket population above which one more probe pass is run
+constexpr int L1_REFINES = 3;           // gated refinement passes enqueued per search
 constexpr int SPEC_CAP = 1024;           // per-workgroup LDS buffer of the speculative compaction
 constexpr int SL_ABOVE_S = PREP_SLOTS, SL_ABOVE_C = PREP_SLOTS + 1;   // partial slots of the fallback compaction
 enum { M_FIRST = 0, M_PROBE = 1, M_COMPACT = 2, M_DIST = 3 };
@@ -47,9 +48,11 @@ __global__ __launch_bounds__(BLOCK) void k_pass(Grid G, SetArgs<T> a, int v_is_s
   double acc[PREP_SLOTS];
 #pragma unroll
   for (int k = 0; k < PREP_SLOTS; ++k) acc[k] = 0;
-  double t[L1_K];
+  ProbeAcc<T> pa;
+  if ((a.prox == PX_L1 || a.prox == PX_CARD) && MODE <= M_PROBE) {
 #pragma unroll
-  for (int k = 0; k < L1_K; ++k) t[k] = ((a.prox == PX_L1 || a.prox == PX_CARD) && MODE <= M_PROBE) ? ps->t[k] : INFINITY;
+    for (int k = 0; k < L1_K; ++k) pa.t[k] = (T)ps->t[k];      // stored TF-rounded: exact
+  }
   double r_lo = 0, r_hi = -1;      // gather range (lo, hi]
   if (MODE == M_FIRST && a.prox == PX_L1 && !(a.flags & F_NOSPEC)) { r_lo = ps->spec_lo; r_hi = ps->spec_hi; }
   if (MODE == M_COMPACT) { r_lo = ps->lo; r_hi = ps->hi; }
@@ -67,7 +70,7 @@ __global__ __launch_bounds__(BLOCK) void k_pass(Grid G, SetArgs<T> a, int v_is_s
     const T av = fabs(x);
     const double ad = (double)av;
     if (MODE == M_FIRST || MODE == M_PROBE) {
-      probe_acc<T>(av, x, t, acc);
+      pa.add(av, x);
       vmax = av > vmax ? av : vmax;
     }
     if (MODE == M_COMPACT && ad > r_hi) {
@@ -113,7 +116,7 @@ __global__ __launch_bounds__(BLOCK) void k_pass(Grid G, SetArgs<T> a, int v_is_s
   };
 
   if (SRC == 0) {
-    for (long long e0 = (long long)blockIdx.x * BLOCK; e0 < len; e0 += (long long)NB * BLOCK) {
+    for (long long e0 = (long long)blockIdx.x * BLOCK; e0 < len; e0 += (long long)gridDim.x * BLOCK) {
       const long long e = e0 + threadIdx.x;
       body(e < len ? varr[e] : T(0), e);     // uniform trip count: every lane takes part in the ballots
     }
@@ -123,9 +126,9 @@ __global__ __launch_bounds__(BLOCK) void k_pass(Grid G, SetArgs<T> a, int v_is_s
     const bool relax = !(a.gamma == T(1));
     const T gam = a.gamma, omg = T(1) - a.gamma;
     const long long nvec = G.N / V;
-    const long long nit = (nvec + (long long)NB * BLOCK - 1) / ((long long)NB * BLOCK);
+    const long long nit = (nvec + (long long)gridDim.x * BLOCK - 1) / ((long long)gridDim.x * BLOCK);
     for (long long it = 0; it < nit; ++it) {
-      const long long vi = it * NB * BLOCK + (long long)blockIdx.x * BLOCK + threadIdx.x;
+      const long long vi = it * (long long)gridDim.x * BLOCK + (long long)blockIdx.x * BLOCK + threadIdx.x;
       const bool live = vi < nvec;
       const long long g = live ? vi * V : 0;
       const Coord c = coords(G, g);
@@ -159,6 +162,7 @@ __global__ __launch_bounds__(BLOCK) void k_pass(Grid G, SetArgs<T> a, int v_is_s
   }
 
   if (MODE == M_FIRST || MODE == M_PROBE) {
+    pa.to_slots(acc);
     block_reduce_store<PREP_SLOTS>(acc, partials, 0);
     if (MODE == M_FIRST) block_max_store<T>(vmax, maxpart);
   } else if (MODE == M_COMPACT) {
@@ -333,10 +337,12 @@ __global__ __launch_bounds__(1024) void k_decide(const double* __restrict__ part
       return;
     }
     ps->n_compact = 0;                                   // discard what the speculation gathered
-    if (Cl - Ch > L1_CAP) {                              // cold start: subdivide [lo, hi] once more
-      ps->refine = 1;
-      for (int k = 0; k < L1_K; ++k) ps->t[k] = lo + (hi - lo) * (double)k / (double)(L1_K - 1);
-    }
+  }
+  // cold start / theta moved far: while the bracket still holds too many magnitudes, subdivide it again
+  // (each gated refinement pass narrows it by >= L1_K-1 and by the Newton/secant step on top)
+  if (Cl - Ch > L1_CAP && hi > lo && (STAGE == 0 || ps->refine < L1_REFINES)) {
+    ps->refine = (STAGE == 0) ? 1 : ps->refine + 1;
+    for (int k = 0; k < L1_K; ++k) ps->t[k] = (double)(T)(lo + (hi - lo) * (double)k / (double)(L1_K - 1));
   } else {
     ps->refine = 0;
   }
@@ -425,12 +431,12 @@ __global__ __launch_bounds__(1024) void k_l1_solve(ProjScalars<T>* ps, T radius,
       ps->hw = hw;
       ps->theta_prev = theta;
       const double m[L1_K] = {-1.0, -0.25, -1.0 / 16, -1.0 / 64, 1.0 / 64, 1.0 / 16, 0.25, 1.0};
-      for (int k = 0; k < L1_K; ++k) ps->t[k] = theta * (1.0 + hw * m[k]);
+      for (int k = 0; k < L1_K; ++k) ps->t[k] = (double)(T)(theta * (1.0 + hw * m[k]));
       ps->spec_lo = ps->t[0];
       ps->spec_hi = ps->t[L1_K - 1];
     } else if (ps->theta_prev > 0) {            // inside the ball now: keep probing around the last theta
       const double m[L1_K] = {-1.0, -0.25, -1.0 / 16, -1.0 / 64, 1.0 / 64, 1.0 / 16, 0.25, 1.0};
-      for (int k = 0; k < L1_K; ++k) ps->t[k] = ps->theta_prev * (1.0 + ps->hw * m[k]);
+      for (int k = 0; k < L1_K; ++k) ps->t[k] = (double)(T)(ps->theta_prev * (1.0 + ps->hw * m[k]));
       ps->spec_lo = ps->t[0];
       ps->spec_hi = ps->t[L1_K - 1];
     }
@@ -490,7 +496,7 @@ __global__ __launch_bounds__(1024) void k_card_decide(const double* __restrict__
   ps->lo = lo; ps->hi = hi; ps->c_lo = clo; ps->c_hi = chi;
   if (clo - chi > CARD_CAP && hi > lo) {
     ps->refine = 1;
-    for (int j = 0; j < L1_K; ++j) ps->t[j] = lo + (hi - lo) * (double)(j + 1) / (double)(L1_K + 1);
+    for (int j = 0; j < L1_K; ++j) ps->t[j] = (double)(T)(lo + (hi - lo) * (double)(j + 1) / (double)(L1_K + 1));
   } else {
     ps->refine = 0;
   }
@@ -552,7 +558,7 @@ __global__ __launch_bounds__(1024) void k_card_select(ProjScalars<T>* ps, long l
     if (tp > T(0) && tp < (T)INFINITY) {
       ps->tau_prev = tp;
       const double m[L1_K] = {0.5, 0.9, 0.99, 0.999, 1.001, 1.01, 1.1, 2.0};
-      for (int j = 0; j < L1_K; ++j) ps->t[j] = (double)tp * m[j];
+      for (int j = 0; j < L1_K; ++j) ps->t[j] = (double)(T)((double)tp * m[j]);
     }
     ps->n_compact = 0;
   }
@@ -565,10 +571,10 @@ static void launch_chain(hipStream_t s, const Grid& g, const SetArgs<T>& a, int 
 #define SIPX_PASS(MODE)                                                                                            \
   do {                                                                                                             \
     if (vec)                                                                                                       \
-      hipLaunchKernelGGL((k_pass<T, 4, MODE, SRC>), dim3(NB), dim3(BLOCK), 0, s, g, a, v_is_s, varr, len, ps, compact, \
+      hipLaunchKernelGGL((k_pass<T, 4, MODE, SRC>), dim3(NB_7), dim3(BLOCK), 0, s, g, a, v_is_s, varr, len, ps, compact, \
                          partials, maxpart);                                                                       \
     else                                                                                                           \
-      hipLaunchKernelGGL((k_pass<T, 1, MODE, SRC>), dim3(NB), dim3(BLOCK), 0, s, g, a, v_is_s, varr, len, ps, compact, \
+      hipLaunchKernelGGL((k_pass<T, 1, MODE, SRC>), dim3(NB_7), dim3(BLOCK), 0, s, g, a, v_is_s, varr, len, ps, compact, \
                          partials, maxpart);                                                                       \
   } while (0)
   if (a.prox == PX_CARD) {
@@ -588,8 +594,10 @@ static void launch_chain(hipStream_t s, const Grid& g, const SetArgs<T>& a, int 
   hipLaunchKernelGGL((k_decide<T, 0>), dim3(1), dim3(1024), 0, s, partials, maxpart, ps, a.prox, a.plo, a.phi, true_len,
                      (a.flags & F_NOSPEC) ? 1 : 0);
   if (a.prox == PX_L1) {
-    SIPX_PASS(M_PROBE);
-    hipLaunchKernelGGL((k_decide<T, 1>), dim3(1), dim3(1024), 0, s, partials, maxpart, ps, a.prox, a.plo, a.phi, true_len, 0);
+    for (int r = 0; r < L1_REFINES; ++r) {
+      SIPX_PASS(M_PROBE);
+      hipLaunchKernelGGL((k_decide<T, 1>), dim3(1), dim3(1024), 0, s, partials, maxpart, ps, a.prox, a.plo, a.phi, true_len, 0);
+    }
     SIPX_PASS(M_COMPACT);
     hipLaunchKernelGGL((k_l1_solve<T>), dim3(1), dim3(1024), 0, s, ps, a.phi, compact, partials);
   }
@@ -623,10 +631,10 @@ void K<T>::proj_dist_set(hipStream_t s, const Grid& g, const SetArgs<T>& a, int 
   b.ps = ps;
   ProjScalars<T>* psm = const_cast<ProjScalars<T>*>(ps);
   if (g.n[0] % 4 == 0)
-    hipLaunchKernelGGL((k_pass<T, 4, M_DIST, 1>), dim3(NB), dim3(BLOCK), 0, s, g, b, v_is_s, (const T*)nullptr, 0ll, psm,
+    hipLaunchKernelGGL((k_pass<T, 4, M_DIST, 1>), dim3(NB_7), dim3(BLOCK), 0, s, g, b, v_is_s, (const T*)nullptr, 0ll, psm,
                        (T*)nullptr, dst, (T*)nullptr);
   else
-    hipLaunchKernelGGL((k_pass<T, 1, M_DIST, 1>), dim3(NB), dim3(BLOCK), 0, s, g, b, v_is_s, (const T*)nullptr, 0ll, psm,
+    hipLaunchKernelGGL((k_pass<T, 1, M_DIST, 1>), dim3(NB_7), dim3(BLOCK), 0, s, g, b, v_is_s, (const T*)nullptr, 0ll, psm,
                        (T*)nullptr, dst, (T*)nullptr);
   SIPX_HIP(hipGetLastError());
 }

@@ -27,7 +27,7 @@ namespace sipx {
 template <typename T, int V>
 __global__ __launch_bounds__(BLOCK) void k_rhs(Grid G, RhsArgs<T> a, T* __restrict__ rhs, int accumulate) {
   const long long nvec = G.N / V;
-  for (long long vi = (long long)blockIdx.x * BLOCK + threadIdx.x; vi < nvec; vi += (long long)NB * BLOCK) {
+  for (long long vi = (long long)blockIdx.x * BLOCK + threadIdx.x; vi < nvec; vi += (long long)gridDim.x * BLOCK) {
     const long long g = vi * V;
     const Coord c = coords(G, g);
     T out[V];
@@ -54,14 +54,13 @@ __global__ __launch_bounds__(BLOCK) void k_rhs(Grid G, RhsArgs<T> a, T* __restri
           const T* yb = S.y + (long long)q * G.N;
           const T* lb = S.l + (long long)q * G.N;
           auto wv = [&](long long e) {
-            const Vec<T, V> yv = ldv<T, V>(yb + e), lv = ldv<T, V>(lb + e);
+            const Vec<T, V> yv = ldv_u<T, V>(yb + e), lv = ldv_u<T, V>(lb + e);
             Vec<T, V> w;
 #pragma unroll
             for (int k = 0; k < V; ++k) w.v[k] = rho * yv.v[k] + lv.v[k];
             return w;
           };
-          auto w1 = [&](long long e) { return rho * yb[e] + lb[e]; };
-          adj_dir_acc<T, V>(G, g, c, S.dir[q], S.ih[q], t, wv, w1);
+          adj_dir_acc<T, V>(G, g, c, S.dir[q], S.ih[q], t, wv);
         }
       }
 #pragma unroll
@@ -100,7 +99,7 @@ __global__ __launch_bounds__(BLOCK) void k_yl(Grid G, SetArgs<T> a, double* __re
   const bool bb = (a.flags & F_BB) && !first;
   const bool dist = a.prox == PX_DIST;
   const long long nvec = G.N / V;
-  for (long long vi = (long long)blockIdx.x * BLOCK + threadIdx.x; vi < nvec; vi += (long long)NB * BLOCK) {
+  for (long long vi = (long long)blockIdx.x * BLOCK + threadIdx.x; vi < nvec; vi += (long long)gridDim.x * BLOCK) {
     const long long g = vi * V;
     const Coord c = coords(G, g);
     const Vec<T, V> xc = ldv<T, V>(a.x + g);
@@ -202,7 +201,7 @@ template <typename T, int V>
 __global__ __launch_bounds__(BLOCK) void k_adj_norm(Grid G, SetArgs<T> a, double* __restrict__ partials) {
   double acc[1] = {0};
   const long long nvec = G.N / V;
-  for (long long vi = (long long)blockIdx.x * BLOCK + threadIdx.x; vi < nvec; vi += (long long)NB * BLOCK) {
+  for (long long vi = (long long)blockIdx.x * BLOCK + threadIdx.x; vi < nvec; vi += (long long)gridDim.x * BLOCK) {
     const long long g = vi * V;
     const Coord c = coords(G, g);
     T t[V];
@@ -210,9 +209,8 @@ __global__ __launch_bounds__(BLOCK) void k_adj_norm(Grid G, SetArgs<T> a, double
     for (int k = 0; k < V; ++k) t[k] = T(0);
     for (int q = 0; q < a.nblk; ++q) {
       const T* wb = a.dy + (long long)q * G.N;
-      auto wv = [&](long long e) { return ldv<T, V>(wb + e); };
-      auto w1 = [&](long long e) { return wb[e]; };
-      adj_dir_acc<T, V>(G, g, c, a.dir[q], a.ih[q], t, wv, w1);
+      auto wv = [&](long long e) { return ldv_u<T, V>(wb + e); };
+      adj_dir_acc<T, V>(G, g, c, a.dir[q], a.ih[q], t, wv);
     }
 #pragma unroll
     for (int k = 0; k < V; ++k) acc[0] += (double)t[k] * (double)t[k];
@@ -239,7 +237,7 @@ __global__ __launch_bounds__(BLOCK) void k_fwd(Grid G, OpArgs o, T ih0, T ih1, T
                                                T* __restrict__ out) {
   const T ihs[3] = {ih0, ih1, ih2};
   const long long nvec = G.N / V;
-  for (long long vi = (long long)blockIdx.x * BLOCK + threadIdx.x; vi < nvec; vi += (long long)NB * BLOCK) {
+  for (long long vi = (long long)blockIdx.x * BLOCK + threadIdx.x; vi < nvec; vi += (long long)gridDim.x * BLOCK) {
     const long long g = vi * V;
     const Coord c = coords(G, g);
     const Vec<T, V> xc = ldv<T, V>(x + g);
@@ -276,7 +274,7 @@ __global__ __launch_bounds__(BLOCK) void k_adj(Grid G, OpArgs o, T ih0, T ih1, T
                                                T* __restrict__ out) {
   const T ihs[3] = {ih0, ih1, ih2};
   const long long nvec = G.N / V;
-  for (long long vi = (long long)blockIdx.x * BLOCK + threadIdx.x; vi < nvec; vi += (long long)NB * BLOCK) {
+  for (long long vi = (long long)blockIdx.x * BLOCK + threadIdx.x; vi < nvec; vi += (long long)gridDim.x * BLOCK) {
     const long long g = vi * V;
     const Coord c = coords(G, g);
     if (o.nblk == 0) {
@@ -288,9 +286,8 @@ __global__ __launch_bounds__(BLOCK) void k_adj(Grid G, OpArgs o, T ih0, T ih1, T
     for (int k = 0; k < V; ++k) t[k] = T(0);
     for (int q = 0; q < o.nblk; ++q) {
       const T* wb = v + (long long)q * G.N;
-      auto wv = [&](long long e) { return ldv<T, V>(wb + e); };
-      auto w1 = [&](long long e) { return wb[e]; };
-      adj_dir_acc<T, V>(G, g, c, o.dir[q], ihs[q], t, wv, w1);
+      auto wv = [&](long long e) { return ldv_u<T, V>(wb + e); };
+      adj_dir_acc<T, V>(G, g, c, o.dir[q], ihs[q], t, wv);
     }
     Vec<T, V> tv;
 #pragma unroll
@@ -337,7 +334,7 @@ __global__ __launch_bounds__(BLOCK) void k_proj(Grid G, ProjArgs<T> a, long long
                                                 double* __restrict__ partials) {
   double acc[2] = {0, 0};
   const ProxCtx<T> pc = make_prox<T>(a.prox, a.plo, a.phi, T(0), a.ps);
-  for (long long e = (long long)blockIdx.x * BLOCK + threadIdx.x; e < len; e += (long long)NB * BLOCK) {
+  for (long long e = (long long)blockIdx.x * BLOCK + threadIdx.x; e < len; e += (long long)gridDim.x * BLOCK) {
     if (!is_valid<T>(G, a, e)) continue;
     const T x = v[e];
     const T lb = a.prox == PX_BOUNDS_VEC ? a.lb[e] : T(0), ub = a.prox == PX_BOUNDS_VEC ? a.ub[e] : T(0);
@@ -360,7 +357,7 @@ __global__ __launch_bounds__(BLOCK) void k_log3(long long N, const T* __restrict
                                                 const T* __restrict__ xold, double* __restrict__ partials) {
   double acc[3] = {0, 0, 0};
   const long long nvec = N / V;
-  for (long long vi = (long long)blockIdx.x * BLOCK + threadIdx.x; vi < nvec; vi += (long long)NB * BLOCK) {
+  for (long long vi = (long long)blockIdx.x * BLOCK + threadIdx.x; vi < nvec; vi += (long long)gridDim.x * BLOCK) {
     const Vec<T, V> xv = ldv<T, V>(x + vi * V), mv = ldv<T, V>(m + vi * V), ov = ldv<T, V>(xold + vi * V);
 #pragma unroll
     for (int k = 0; k < V; ++k) {

@@ -9,6 +9,9 @@ namespace sipx {
 
 constexpr int BLOCK = 256;        // 4 waves of 64
 constexpr int NB = 2048;          // fixed grid of every streaming/reduction kernel (8 blocks per CU: measured +8% over 1024)
+// Kernels that need 65..72 VGPRs run 7 workgroups per CU: a grid of 2048 would leave a 256-workgroup tail at 1/7
+// occupancy, so those families launch 7*256 workgroups (their block partials beyond that stay zero).
+constexpr int NB_7 = 1792;
 constexpr int MAXD = 32;          // CDS bands held in kernel arguments
 constexpr int MAX_SETS = 16;      // sets fused in one rhs_compose launch
 constexpr int YL_SLOTS = 13;      // reductions produced by one y/l-update launch

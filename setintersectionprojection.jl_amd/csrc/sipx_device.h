@@ -41,6 +41,43 @@ __device__ __forceinline__ Vec<T, V> ldv_nt(const T* p) {
   }
   return r;
 }
+// Vector load that only needs element alignment (dwordx4 at any 4-byte boundary: gfx950 global loads are
+// unaligned-capable): neighbours of a CDS band / stencil are one unconditional load, no index arithmetic.
+template <typename T, int V>
+__device__ __forceinline__ Vec<T, V> ldv_u(const T* p) {
+  Vec<T, V> r;
+  if constexpr (V == 1) {
+    r.v[0] = *p;
+  } else {
+    typedef T vu __attribute__((ext_vector_type(V), aligned(sizeof(T))));
+    const vu t = *reinterpret_cast<const vu*>(p);
+#pragma unroll
+    for (int k = 0; k < V; ++k) r.v[k] = t[k];
+  }
+  return r;
+}
+template <typename T, int V>
+__device__ __forceinline__ void stv_nt(T* p, const Vec<T, V>& x) {
+  if constexpr (V == 1) {
+    __builtin_nontemporal_store(x.v[0], p);
+  } else if constexpr (sizeof(T) * V == 16) {
+    typedef T vt __attribute__((ext_vector_type(V)));
+    vt t;
+#pragma unroll
+    for (int k = 0; k < V; ++k) t[k] = x.v[k];
+    __builtin_nontemporal_store(t, reinterpret_cast<vt*>(p));
+  } else {
+    typedef T vh __attribute__((ext_vector_type(V / 2)));
+    vh a, b;
+#pragma unroll
+    for (int k = 0; k < V / 2; ++k) {
+      a[k] = x.v[k];
+      b[k] = x.v[V / 2 + k];
+    }
+    __builtin_nontemporal_store(a, reinterpret_cast<vh*>(p));
+    __builtin_nontemporal_store(b, reinterpret_cast<vh*>(p) + 1);
+  }
+}
 template <typename T, int V>
 __device__ __forceinline__ Vec<T, V> zerov() {
   Vec<T, V> z;
@@ -113,21 +150,37 @@ __device__ __forceinline__ void block_max_store(T vmax, T* __restrict__ maxpart)
   }
 }
 
-// One magnitude into the first-pass reductions of the two-pass projectors:
-// slot 0 ||v||_1, 1 ||v||_2^2, 2 nnz, 3.. S_k = sum(|v| > t_k), 3+L1_K.. C_k = count(|v| > t_k).
+// First-pass reductions of the two-pass projectors, kept cheap: sums in float64, counts in 32-bit
+// integers, threshold compares in the working precision (thresholds are stored TF-rounded).
+// Slot layout of the block partials: 0 ||v||_1, 1 ||v||_2^2, 2 nnz, 3.. S_k = sum(|v| > t_k),
+// 3+L1_K.. C_k = count(|v| > t_k).
 template <typename T>
-__device__ __forceinline__ void probe_acc(T av, T x, const double (&t)[L1_K], double (&acc)[PREP_SLOTS]) {
-  const double a = (double)av;
-  acc[0] += a;
-  acc[1] += (double)x * (double)x;
-  acc[2] += av > T(0) ? 1.0 : 0.0;
+struct ProbeAcc {
+  double asum = 0, sumsq = 0, S[L1_K];
+  unsigned int nnz = 0, C[L1_K];
+  T t[L1_K];
+  __device__ __forceinline__ ProbeAcc() {
 #pragma unroll
-  for (int k = 0; k < L1_K; ++k) {
-    const bool on = a > t[k];
-    acc[3 + k] += on ? a : 0.0;
-    acc[3 + L1_K + k] += on ? 1.0 : 0.0;
+    for (int k = 0; k < L1_K; ++k) { S[k] = 0; C[k] = 0; t[k] = (T)INFINITY; }
   }
-}
+  __device__ __forceinline__ void add(T av, T x) {
+    const double a = (double)av;
+    asum += a;
+    sumsq += (double)x * (double)x;
+    nnz += av > T(0) ? 1u : 0u;
+#pragma unroll
+    for (int k = 0; k < L1_K; ++k) {
+      const bool on = av > t[k];
+      S[k] += on ? a : 0.0;
+      C[k] += on ? 1u : 0u;
+    }
+  }
+  __device__ __forceinline__ void to_slots(double (&acc)[PREP_SLOTS]) const {
+    acc[0] = asum; acc[1] = sumsq; acc[2] = (double)nnz;
+#pragma unroll
+    for (int k = 0; k < L1_K; ++k) { acc[3 + k] = S[k]; acc[3 + L1_K + k] = (double)C[k]; }
+  }
+};
 
 template <typename T>
 __device__ __forceinline__ T eps_of();
@@ -143,23 +196,15 @@ __device__ __forceinline__ double jl_min(double a, double b) { return (a != a ||
 struct Coord {
   int i, j, k;
 };
-// Coordinates of linear index g (column-major, dim 1 fastest).
+// Coordinates of linear index g (column-major, dim 1 fastest).  N < 2^31 is enforced at sipx_create.
 __device__ __forceinline__ Coord coords(const Grid& G, long long g) {
   Coord c;
-  if (G.N < (1ll << 31)) {
-    unsigned u = (unsigned)g, n1 = (unsigned)G.n[0], n2 = (unsigned)G.n[1];
-    unsigned jk = u / n1;
-    c.i = (int)(u - jk * n1);
-    unsigned k = jk / n2;
-    c.j = (int)(jk - k * n2);
-    c.k = (int)k;
-  } else {
-    long long jk = g / G.n[0];
-    c.i = (int)(g - jk * G.n[0]);
-    long long k = jk / G.n[1];
-    c.j = (int)(jk - k * G.n[1]);
-    c.k = (int)k;
-  }
+  const unsigned u = (unsigned)g, n1 = (unsigned)G.n[0], n2 = (unsigned)G.n[1];
+  const unsigned jk = u / n1;
+  c.i = (int)(u - jk * n1);
+  const unsigned k = jk / n2;
+  c.j = (int)(jk - k * n2);
+  c.k = (int)k;
   return c;
 }
 __device__ __forceinline__ int coord_of(const Coord& c, int dir) { return dir == 0 ? c.i : (dir == 1 ? c.j : c.k); }
@@ -168,61 +213,45 @@ __device__ __forceinline__ int coord_of(const Coord& c, int dir) { return dir ==
 // s = (-ih)*x[g] + ih*x[g+stride], the two products of a CSC row in column order
 // (reference get_discrete_Grad.jl:22-23,58-60 + SparseArrays mul!).  Points on the last
 // hyper-plane along `dir` are pads of the padded layout: valid=false, s=0.
+// BRANCH-FREE for every direction: x carries an end halo of >= max stride elements (engine allocation),
+// the neighbour vector x[g+stride ..] is ONE unconditional element-aligned load (stride 1 included) and
+// validity is a select, so all loads of a work item issue back to back.
 template <typename T, int V>
 __device__ __forceinline__ void fwd_dir(const Grid& G, const T* __restrict__ x, const Vec<T, V>& xc, long long g,
                                         const Coord& c, int dir, T ih, T (&s)[V], bool (&valid)[V]) {
   const T nih = -ih;
-  if (dir == 0) {
-    T xn[V];
+  const long long st = dir == 0 ? 1 : (dir == 1 ? G.st[1] : G.st[2]);
+  const int nd = (int)(dir == 0 ? G.n[0] : (dir == 1 ? G.n[1] : G.n[2]));
+  const int cd = coord_of(c, dir);
+  const Vec<T, V> xn = ldv_u<T, V>(x + g + st);
 #pragma unroll
-    for (int k = 0; k < V - 1; ++k) xn[k] = xc.v[k + 1];
-    xn[V - 1] = (c.i + V < G.n[0]) ? x[g + V] : T(0);
-#pragma unroll
-    for (int k = 0; k < V; ++k) {
-      valid[k] = (c.i + k < G.n[0] - 1);
-      s[k] = valid[k] ? (nih * xc.v[k] + ih * xn[k]) : T(0);
-    }
-  } else {
-    const bool ok = coord_of(c, dir) < G.n[dir] - 1;
-    Vec<T, V> xn = ok ? ldv<T, V>(x + g + G.st[dir]) : zerov<T, V>();
-#pragma unroll
-    for (int k = 0; k < V; ++k) {
-      valid[k] = ok;
-      s[k] = ok ? (nih * xc.v[k] + ih * xn.v[k]) : T(0);
-    }
+  for (int k = 0; k < V; ++k) {
+    valid[k] = (cd + (dir == 0 ? k : 0)) < nd - 1;
+    const T d = nih * xc.v[k] + ih * xn.v[k];
+    s[k] = valid[k] ? d : T(0);
   }
 }
 
 // Adjoint of the forward difference along `dir`, accumulated into t[] at grid points g..g+V-1:
 // t += ih*w[g-stride] (if that row exists) ; t += (-ih)*w[g] (if row g exists) -- a CSC column
-// of D in ascending row order (SparseArrays mul!(tmp, A', v)).  W(e) loads the V values of w
-// at padded index e; W1(e) loads one.
-template <typename T, int V, typename WV, typename W1>
+// of D in ascending row order (SparseArrays mul!(tmp, A', v)).  W(e) loads the V values of w at padded
+// index e (any element alignment).  BRANCH-FREE: w carries a front halo of >= max stride elements.
+template <typename T, int V, typename WV>
 __device__ __forceinline__ void adj_dir_acc(const Grid& G, long long g, const Coord& c, int dir, T ih, T (&t)[V],
-                                            WV wv, W1 w1) {
+                                            WV wv) {
   const T nih = -ih;
-  Vec<T, V> wc = wv(g);
-  if (dir == 0) {
-    T wp[V];
-    wp[0] = (c.i > 0) ? w1(g - 1) : T(0);
+  const long long st = dir == 0 ? 1 : (dir == 1 ? G.st[1] : G.st[2]);
+  const int nd = (int)(dir == 0 ? G.n[0] : (dir == 1 ? G.n[1] : G.n[2]));
+  const int cd = coord_of(c, dir);
+  const Vec<T, V> wc = wv(g);
+  const Vec<T, V> wp = wv(g - st);
 #pragma unroll
-    for (int k = 1; k < V; ++k) wp[k] = wc.v[k - 1];
-#pragma unroll
-    for (int k = 0; k < V; ++k) {
-      if (c.i + k > 0) t[k] = t[k] + ih * wp[k];
-      if (c.i + k < G.n[0] - 1) t[k] = t[k] + nih * wc.v[k];
-    }
-  } else {
-    const int cc = coord_of(c, dir);
-    if (cc > 0) {
-      Vec<T, V> wp = wv(g - G.st[dir]);
-#pragma unroll
-      for (int k = 0; k < V; ++k) t[k] = t[k] + ih * wp.v[k];
-    }
-    if (cc < G.n[dir] - 1) {
-#pragma unroll
-      for (int k = 0; k < V; ++k) t[k] = t[k] + nih * wc.v[k];
-    }
+  for (int k = 0; k < V; ++k) {
+    const int ck = cd + (dir == 0 ? k : 0);
+    const T t1 = t[k] + ih * wp.v[k];
+    t[k] = (ck > 0) ? t1 : t[k];
+    const T t2 = t[k] + nih * wc.v[k];
+    t[k] = (ck < nd - 1) ? t2 : t[k];
   }
 }
 
