@@ -46,7 +46,11 @@ enum {
   SIPX_PROJ_L2          = 3, /* project_l2!(x, pmax)                      (projectors/project_l2!.jl:3-16) */
   SIPX_PROJ_ANNULUS     = 4, /* project_annulus!(x, pmin, pmax)           (projectors/project_annulus!.jl:3-21) */
   SIPX_PROJ_CARDINALITY = 5, /* project_cardinality!(x, k = pmax) vector  (projectors/project_cardinality!.jl:3-21) */
-  SIPX_PROJ_PROX_L1     = 6  /* prox_l1!(x, pmax)                         (src/prox_l1!.jl:8-10) */
+  SIPX_PROJ_PROX_L1     = 6, /* prox_l1!(x, pmax)                         (src/prox_l1!.jl:8-10) */
+  SIPX_PROJ_L1_DFT      = 7, /* x -> Re(F' project_l1_Duchi!(F x, pmax)), F = unitary DFT; op must be identity
+                                (src/get_projector.jl:29-35 with TD_OP "DFT", src/get_TD_operator.jl:45-47,80-82) */
+  SIPX_PROJ_RANK        = 8  /* project_rank!(x, r = pmax): matrix (2-D grid) or every z-slice (3-D, reserved = 2)
+                                (projectors/project_rank!.jl:3-48); op must be identity */
 };
 
 typedef struct {
@@ -56,7 +60,7 @@ typedef struct {
   const void* lb;    /* SIPX_PROJ_BOUNDS_VEC: host TF[M_i] (rows of A_i, reference order), else NULL */
   const void* ub;
   int32_t ncvx;      /* set_Prop.ncvx[i] (src/setup_constraints.jl:89-97) */
-  int32_t reserved;
+  int32_t reserved;  /* SIPX_PROJ_RANK on a 3-D grid: slice direction, 2 = ("slice","z") */
 } sipx_set_desc;
 
 /* PARSDMM_options (src/SetIntersectionProjection.jl:110-128); Blas_active / parallel / FL /

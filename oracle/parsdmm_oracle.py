@@ -270,6 +270,8 @@ def get_TD_operator(comp_grid, TD_type: str, TF):
     N = int(np.prod(n))
     if TD_type == "identity":
         return sp.identity(N, dtype=TF, format="csc"), True, False, n, True
+    if TD_type == "DFT":   # the transform is folded into the projector, TD_OP becomes I (setup_constraints.jl:76-80)
+        return sp.identity(N, dtype=TF, format="csc"), True, True, n, True
     A = get_discrete_Grad(n, h, TD_type, TF)
     if len(n) == 2:
         n1, n2 = n
@@ -458,9 +460,50 @@ def project_cardinality(x, k: int):
     return x
 
 
-def get_projector(constraint: set_definitions, TF) -> Callable:
+def project_rank(x, r: int, n, mode=("matrix", "")):
+    """src/projectors/project_rank!.jl:3-48: matrix, or every z-slice of a tensor (mode (slice, z))."""
+    TF = x.dtype.type
+    X = x.reshape(n, order="F")
+    slices = [X] if X.ndim == 2 else [X[:, :, i] for i in range(X.shape[2])]
+    if X.ndim == 3 and tuple(mode) != ("slice", "z"):
+        raise NotImplementedError("only (slice, z)")
+    for S in slices:
+        U, s, Vt = np.linalg.svd(S.astype(np.float64), full_matrices=False)
+        S[...] = ((U[:, :r] * s[:r]) @ Vt[:r, :]).astype(TF)
+    x[:] = X.reshape(-1, order="F")
+    return x
+
+
+def project_l1_dft(x, b, n):
+    """x -> Re(F' project_l1_Duchi!(F x, b)) with F the unitary DFT (src/get_projector.jl:29-35 with
+    A = joDFT, src/projectors/project_l1_Duchi!.jl:29-32,49 for complex input).  joDFT's normalisation
+    is not pinned by any reference test; unitary is assumed (the operator declares AtA_diag = true)."""
+    TF = x.dtype.type
+    Z = np.fft.fftn(x.reshape(n, order="F").astype(np.float64), norm="ortho")
+    a = np.abs(Z)
+    if not (a.sum() > float(b)):
+        return x      # inside the ball: F'F = I, return x untouched instead of an FFT round trip (pure rounding noise)
+    if True:
+        u = np.sort(a.ravel())[::-1]
+        cs = np.cumsum(u)
+        k = np.arange(1, len(u) + 1)
+        rho = np.nonzero(u > (cs - float(b)) / k)[0][-1]
+        theta = max(0.0, (cs[rho] - float(b)) / (rho + 1))
+        Z = np.where(a > 0, Z / np.maximum(a, 1e-300), 0) * np.maximum(a - theta, 0)
+    x[:] = np.real(np.fft.ifftn(Z, norm="ortho")).reshape(-1, order="F").astype(TF)
+    return x
+
+
+def get_projector(constraint: set_definitions, TF, comp_grid=None) -> Callable:
     """Banded-operator ("matrix"/"tensor" app_mode) branches of src/get_projector.jl:3-103."""
     st = constraint.set_type
+    n = tuple(int(v) for v in comp_grid.n) if comp_grid is not None else None
+    if n is not None and len(n) == 3 and n[2] == 1:
+        n = n[:2]
+    if constraint.TD_OP == "DFT" and st == "l1":
+        return lambda x: project_l1_dft(x, constraint.max, n)
+    if st == "rank":
+        return lambda x: project_rank(x, int(constraint.max), n, constraint.app_mode)
     if constraint.app_mode[0] not in ("matrix", "tensor"):
         raise NotImplementedError("fiber/slice app_modes are outside the round-1 scope")
     if st == "bounds":
@@ -496,7 +539,7 @@ def setup_constraints(constraint: List[set_definitions], comp_grid, TF):
         if c.set_type in ("l1", "l2") and c.app_mode[0] in ("slice", "fiber"):
             raise ValueError("l1 and l2 constraints only available for matrix or tensor mode, currently")
         A, AtA_diag, dense, TD_n, banded = get_TD_operator(comp_grid, c.TD_OP, TF)
-        P_sub.append(get_projector(c, TF))
+        P_sub.append(get_projector(c, TF, comp_grid))
         TD_OP.append(A)
         sp_.AtA_diag.append(AtA_diag); sp_.dense.append(dense); sp_.TD_n.append(TD_n)
         sp_.banded.append(banded); sp_.AtA_offsets.append(None)

@@ -2,6 +2,7 @@
 // kernels phase by phase, in the order of the reference's main loop (src/PARSDMM.jl:97-254).
 // No CPU fallback exists: every numerical step below is a kernel launch.
 #include "engine.h"
+#include "ext_proj.h"
 
 #include <algorithm>
 #include <chrono>
@@ -101,6 +102,9 @@ struct SetState {
   T *y = nullptr, *l = nullptr, *dy = nullptr, *lh0 = nullptr, *y0 = nullptr, *s0 = nullptr, *l0 = nullptr;
   T *lb = nullptr, *ub = nullptr, *ata = nullptr;
   std::vector<void*> halo_allocs;   // bases of the vectors allocated with a front halo
+  int ext_kind = 0, slice_dir = 2;   // library-backed projector (DFT-folded l1, slice rank)
+  double ext_pmax = 0;
+  std::shared_ptr<ExtProj<T>> ext;
   ProjScalars<T>* ps = nullptr;    // scalars of prox_i (warm-started across iterations)
   ProjScalars<T>* psf = nullptr;   // scalars of the feasibility estimate P_i(A_i x)
   std::vector<long long> ata_off;
@@ -137,7 +141,7 @@ class Engine : public EngineBase {
     (void)hipStreamSynchronize(stream_);
     for (auto& s : sets_) free_set(s);
     for (void* p : {(void*)x_base_, (void*)xold_, (void*)rhs_, (void*)m_base_, (void*)r_, (void*)p_base_, (void*)Ap_, (void*)Q_,
-                    (void*)scr_v_, (void*)scr_c_, (void*)scr_i_, (void*)part_cg_, (void*)part_tmp_, (void*)part_sets_,
+                    (void*)scr_v_, (void*)scr_c_, (void*)scr_i_, (void*)scr_w_, (void*)part_cg_, (void*)part_tmp_, (void*)part_sets_,
                     (void*)maxpart_, (void*)cg_dev_})
       dfree(p);
     if (cg_host_) (void)hipHostFree(cg_host_);
@@ -172,6 +176,16 @@ class Engine : public EngineBase {
       case SIPX_PROJ_L2:
       case SIPX_PROJ_ANNULUS: s.two_pass = true; break;
       case SIPX_PROJ_CARDINALITY: s.two_pass = true; need_idx_ = true; break;
+      case SIPX_PROJ_L1_DFT:
+      case SIPX_PROJ_RANK:
+        if (d->op != SIPX_OP_IDENTITY)
+          throw std::runtime_error("DFT-l1 and rank projectors act in their own domain: TD_OP must be the identity");
+        if (d->proj == SIPX_PROJ_L1_DFT && !(d->pmax > 0)) throw std::runtime_error("Radius of L1 ball is negative");
+        s.ext_kind = d->proj == SIPX_PROJ_L1_DFT ? EXT_L1_DFT : EXT_RANK;
+        s.slice_dir = d->reserved;
+        s.ext_pmax = d->pmax;
+        need_ext_ = true;
+        break;
       default: throw std::runtime_error("unknown projector kind");
     }
     if (ata_R) {
@@ -250,6 +264,7 @@ class Engine : public EngineBase {
     scr_v_ = dalloc<T>(maxpad);
     scr_c_ = dalloc<T>(maxpad);
     if (need_idx_) scr_i_ = dalloc<long long>(maxpad);
+    if (need_ext_) scr_w_ = dalloc<T>(maxpad);
     part_cg_ = dalloc<double>(2 * NB);
     part_tmp_ = dalloc<double>((size_t)(PREP_SLOTS + 2) * NB);
     part_sets_ = dalloc<double>((size_t)p_n_ * SLOTS * NB);
@@ -287,6 +302,7 @@ class Engine : public EngineBase {
       s.y = halloc(s.Mpad); s.l = halloc(s.Mpad);
       s.lh0 = dalloc<T>(s.Mpad); s.y0 = dalloc<T>(s.Mpad); s.s0 = dalloc<T>(s.Mpad); s.l0 = dalloc<T>(s.Mpad);
       if (!s.ident) s.dy = halloc(s.Mpad);
+      if (s.ext_kind) s.ext = std::make_shared<ExtProj<T>>(s.ext_kind, G_, ndim_, stream_, s.ext_pmax, s.slice_dir);
       if (s.two_pass) {
         s.ps = dalloc<ProjScalars<T>>(1);
         s.psf = dalloc<ProjScalars<T>>(1);
@@ -312,7 +328,11 @@ class Engine : public EngineBase {
       SetState<T>& s = sets_[i];
       if (!s.owned) continue;
       double* dst = part_sets_ + ((size_t)i * SLOTS + SL_FE2) * NB;
-      if (s.two_pass) {
+      if (s.ext_kind) {
+        SetArgs<T> a = set_args(s, rho_[i], gamma_[i], 0);
+        a.x = m_;
+        ext_feasibility(s, a, dst);
+      } else if (s.two_pass) {
         SetArgs<T> a = set_args(s, rho_[i], gamma_[i], 0);
         a.x = m_;                                              // s = A m produced on the fly
         K<T>::proj_scalars_set(stream_, G_, a, 1, s.psf, part_tmp_, maxpart_, scr_c_, s.Mtrue);
@@ -408,6 +428,11 @@ class Engine : public EngineBase {
       if (!s.owned) continue;
       SetArgs<T> a = set_args(s, (T)rho[i], (T)gamma[i], flags);
       double* part = part_sets_ + (size_t)i * SLOTS * NB;
+      if (s.ext_kind) {   // library-backed projector: materialise v, project it in place, hand y to the fused update
+        K<T>::store_v(stream_, G_, a, 0, scr_v_);
+        s.ext->project(scr_v_, false, part_tmp_, maxpart_, scr_c_);
+        a.vsrc = 2;
+      }
       if (s.two_pass) {   // threshold / scale of prox_i from one pass that produces v on the fly (nothing stored)
         SetArgs<T> ap = a;
         if (s.last_rho != a.rho || s.last_gamma != a.gamma) ap.flags |= F_NOSPEC;   // v rescaled: theta will jump
@@ -417,6 +442,7 @@ class Engine : public EngineBase {
       }
       K<T>::yl(stream_, G_, a, part);
       if (!s.ident) K<T>::adj_norm(stream_, G_, a, part + (size_t)SL_ADJ * NB);
+      if ((flags & SIPX_YL_FEAS) && s.ext_kind && i < pp_n_) ext_feasibility(s, a, part + (size_t)SL_FE2 * NB);
       if ((flags & SIPX_YL_FEAS) && s.two_pass && i < pp_n_) {
         // ||P_i(s) - s|| with s = A_i x produced on the fly; its own warm-started scalars (psf)
         K<T>::proj_scalars_set(stream_, G_, a, 1, s.psf, part_tmp_, maxpart_, scr_c_, s.Mtrue);
@@ -446,7 +472,8 @@ class Engine : public EngineBase {
         feas[i] = 0;
         if (!sets_[i].owned) continue;
         const double* h = hres_ + (size_t)i * SLOTS;
-        feas[i] = sets_[i].two_pass ? (double)feas_value(h[SL_FE2], h[SL_SS2]) : (double)feas_value(h[SL_FE], h[SL_SS]);
+        feas[i] = (sets_[i].two_pass || sets_[i].ext_kind) ? (double)feas_value(h[SL_FE2], h[SL_SS2])
+                                                            : (double)feas_value(h[SL_FE], h[SL_SS]);
       }
     }
   }
@@ -705,6 +732,17 @@ class Engine : public EngineBase {
       SIPX_HIP(hipMemcpy(ub, d->ub, len * sizeof(T), hipMemcpyHostToDevice));
     }
     if (prox == SIPX_PROJ_L1 && !(d->pmax > 0)) throw std::runtime_error("Radius of L1 ball is negative");
+    if (prox == SIPX_PROJ_L1_DFT || prox == SIPX_PROJ_RANK) {      // acts on the context grid
+      if (len != G_.N) throw std::runtime_error("DFT-l1 / rank projectors need a vector of the grid size");
+      {
+        ExtProj<T> ext(prox == SIPX_PROJ_L1_DFT ? EXT_L1_DFT : EXT_RANK, G_, ndim_, stream_, d->pmax, d->reserved);
+        ext.project(dv, false, part, mp, dc);
+        SIPX_HIP(hipStreamSynchronize(stream_));
+      }
+      SIPX_HIP(hipMemcpy(v, dv, len * sizeof(T), hipMemcpyDeviceToHost));
+      for (void* q : {(void*)dv, (void*)dc, (void*)part, (void*)mp, (void*)ps}) dfree(q);
+      return;
+    }
     const bool two = prox == SIPX_PROJ_L1 || prox == SIPX_PROJ_L2 || prox == SIPX_PROJ_ANNULUS || prox == SIPX_PROJ_CARDINALITY;
     long long* di = prox == SIPX_PROJ_CARDINALITY ? dalloc<long long>(len) : nullptr;
     if (two) {
@@ -895,6 +933,14 @@ class Engine : public EngineBase {
     return a;
   }
 
+  // ||P(s) - s||^2, ||s||^2 for a library-backed projector: s = A x materialised twice, one copy projected
+  void ext_feasibility(SetState<T>& s, const SetArgs<T>& a, double* dst) {
+    K<T>::store_v(stream_, G_, a, 1, scr_v_);
+    SIPX_HIP(hipMemcpyAsync(scr_w_, scr_v_, s.Mpad * sizeof(T), hipMemcpyDeviceToDevice, stream_));
+    s.ext->project(scr_v_, true, part_tmp_, maxpart_, scr_c_);
+    ext_dist2<T>(stream_, s.Mpad, scr_v_, scr_w_, dst);
+  }
+
   T feas_value(double fe, double ss) const {
     return (T)std::sqrt(fe) / ((T)std::sqrt(ss) + T(100) * std::numeric_limits<T>::epsilon());
   }
@@ -975,7 +1021,8 @@ class Engine : public EngineBase {
   T *x_ = nullptr, *xold_ = nullptr, *rhs_ = nullptr, *m_ = nullptr, *r_ = nullptr, *p_ = nullptr, *Ap_ = nullptr;
   T *Q_ = nullptr, *scr_v_ = nullptr, *scr_c_ = nullptr, *maxpart_ = nullptr;
   long long* scr_i_ = nullptr;
-  bool need_idx_ = false;
+  T* scr_w_ = nullptr;
+  bool need_idx_ = false, need_ext_ = false;
   CdsArgs cds_;
   double *part_cg_ = nullptr, *part_tmp_ = nullptr, *part_sets_ = nullptr;
   CgState<T>*cg_dev_ = nullptr, *cg_host_ = nullptr;

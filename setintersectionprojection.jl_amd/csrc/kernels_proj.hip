@@ -31,7 +31,7 @@ constexpr double L1_CAP = 131072.0;     // bracket population above which one mo
 constexpr int L1_REFINES = 3;           // gated refinement passes enqueued per search
 constexpr int SPEC_CAP = 1024;           // per-workgroup LDS buffer of the speculative compaction
 constexpr int SL_ABOVE_S = PREP_SLOTS, SL_ABOVE_C = PREP_SLOTS + 1;   // partial slots of the fallback compaction
-enum { M_FIRST = 0, M_PROBE = 1, M_COMPACT = 2, M_DIST = 3 };
+enum { M_FIRST = 0, M_PROBE = 1, M_COMPACT = 2, M_DIST = 3, M_STORE = 4 /* materialise v into `compact` */ };
 
 // One pass over the vector.  SRC 0: stored array (V == 1); SRC 1: produced on the fly by a set.
 template <typename T, int V, int MODE, int SRC>
@@ -39,7 +39,8 @@ __global__ __launch_bounds__(BLOCK) void k_pass(Grid G, SetArgs<T> a, int v_is_s
                                                 long long len, ProjScalars<T>* ps, T* __restrict__ compact,
                                                 double* __restrict__ partials, T* __restrict__ maxpart) {
   if (MODE == M_PROBE && !(ps->need && !ps->spec_ok && ps->refine)) return;
-  long long* const cidx = (MODE == M_COMPACT && a.prox == PX_CARD) ? ps->cidx : nullptr;
+  long long* cidx = nullptr;
+  if (MODE == M_COMPACT && a.prox == PX_CARD) cidx = ps->cidx;
   if (MODE == M_COMPACT && !(ps->need && !ps->spec_ok)) return;
   __shared__ T sbuf[(MODE == M_FIRST || MODE == M_COMPACT) ? SPEC_CAP : 1];
   __shared__ unsigned int scnt, sused;     // reserved / actually filled prefix of sbuf
@@ -66,7 +67,7 @@ __global__ __launch_bounds__(BLOCK) void k_pass(Grid G, SetArgs<T> a, int v_is_s
   if (MODE == M_DIST) pc = make_prox<T>(a.prox, a.plo, a.phi, T(0), ps);
   const int lane = threadIdx.x & 63;
 
-  auto body = [&](T x, long long e) {
+  auto body = [&](T x, long long e, bool live) {
     const T av = fabs(x);
     const double ad = (double)av;
     if (MODE == M_FIRST || MODE == M_PROBE) {
@@ -77,6 +78,7 @@ __global__ __launch_bounds__(BLOCK) void k_pass(Grid G, SetArgs<T> a, int v_is_s
       acc[0] += ad;
       acc[1] += 1.0;
     }
+    if (MODE == M_STORE && live) compact[e] = x;
     if (MODE == M_DIST) {
       const T pv = prox_apply<T>(pc, x, T(0), T(0), T(0), e);
       const T dlt = pv - x;
@@ -118,7 +120,7 @@ __global__ __launch_bounds__(BLOCK) void k_pass(Grid G, SetArgs<T> a, int v_is_s
   if (SRC == 0) {
     for (long long e0 = (long long)blockIdx.x * BLOCK; e0 < len; e0 += (long long)gridDim.x * BLOCK) {
       const long long e = e0 + threadIdx.x;
-      body(e < len ? varr[e] : T(0), e);     // uniform trip count: every lane takes part in the ballots
+      body(e < len ? varr[e] : T(0), e, e < len);   // uniform trip count: every lane takes part in the ballots
     }
   } else {
     const bool ident = a.nblk == 0;
@@ -156,7 +158,7 @@ __global__ __launch_bounds__(BLOCK) void k_pass(Grid G, SetArgs<T> a, int v_is_s
           }
         }
 #pragma unroll
-        for (int k = 0; k < V; ++k) body(live ? out[k] : T(0), e + k);
+        for (int k = 0; k < V; ++k) body(live ? out[k] : T(0), e + k, live);
       }
     }
   }
@@ -168,6 +170,7 @@ __global__ __launch_bounds__(BLOCK) void k_pass(Grid G, SetArgs<T> a, int v_is_s
   } else if (MODE == M_COMPACT) {
     double a2[2] = {acc[0], acc[1]};
     block_reduce_store<2>(a2, partials, SL_ABOVE_S);
+  } else if (MODE == M_STORE) {
   } else {
     double a2[2] = {acc[0], acc[1]};
     block_reduce_store<2>(a2, partials, 0);
@@ -625,6 +628,16 @@ void K<T>::proj_scalars_arr(hipStream_t s, long long len, const T* v, int prox, 
   launch_chain<T, 0>(s, g, a, 0, v, len, ps, partials, maxpart, compact, true_len);
 }
 template <typename T>
+void K<T>::store_v(hipStream_t s, const Grid& g, const SetArgs<T>& a, int v_is_s, T* out) {
+  if (g.n[0] % 4 == 0)
+    hipLaunchKernelGGL((k_pass<T, 4, M_STORE, 1>), dim3(NB_7), dim3(BLOCK), 0, s, g, a, v_is_s, (const T*)nullptr, 0ll,
+                       (ProjScalars<T>*)nullptr, out, (double*)nullptr, (T*)nullptr);
+  else
+    hipLaunchKernelGGL((k_pass<T, 1, M_STORE, 1>), dim3(NB_7), dim3(BLOCK), 0, s, g, a, v_is_s, (const T*)nullptr, 0ll,
+                       (ProjScalars<T>*)nullptr, out, (double*)nullptr, (T*)nullptr);
+  SIPX_HIP(hipGetLastError());
+}
+template <typename T>
 void K<T>::proj_dist_set(hipStream_t s, const Grid& g, const SetArgs<T>& a, int v_is_s, const ProjScalars<T>* ps,
                          double* dst) {
   SetArgs<T> b = a;
@@ -640,7 +653,8 @@ void K<T>::proj_dist_set(hipStream_t s, const Grid& g, const SetArgs<T>& a, int 
 }
 
 #define SIPX_INST(T)                                                                                              \
-  template void K<T>::ps_init(hipStream_t, ProjScalars<T>*, long long*);                                                     \
+  template void K<T>::ps_init(hipStream_t, ProjScalars<T>*, long long*);                                         \
+  template void K<T>::store_v(hipStream_t, const Grid&, const SetArgs<T>&, int, T*);                                                     \
   template void K<T>::proj_scalars_set(hipStream_t, const Grid&, const SetArgs<T>&, int, ProjScalars<T>*, double*, \
                                        T*, T*, long long);                                                       \
   template void K<T>::proj_scalars_arr(hipStream_t, long long, const T*, int, T, T, ProjScalars<T>*, double*, T*, \

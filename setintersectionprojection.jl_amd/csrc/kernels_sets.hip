@@ -130,7 +130,7 @@ __global__ __launch_bounds__(BLOCK) void k_yl(Grid G, SetArgs<T> a, double* __re
         const T yo = yv.v[k], lo = lv.v[k];
         const T xh = relax ? (gam * s[k] + omg * yo) : s[k];           // update_y_l.jl:72
         const T v = a.vsrc ? vv.v[k] : (xh - lo * a.rho1);              // :67 / :74
-        T y1 = prox_apply<T>(pc, v, lbv.v[k], ubv.v[k], mv.v[k], e + k);  // :68 / :75
+        T y1 = (a.vsrc == 2) ? vv.v[k] : prox_apply<T>(pc, v, lbv.v[k], ubv.v[k], mv.v[k], e + k);  // :68 / :75
         if (!valid[k]) y1 = T(0);
         const T rp = y1 - s[k];                                         // r_pri = -s + y   :69 / :76
         const T l1 = relax ? (lo + a.rho * (y1 - xh)) : (lo + a.rho * rp);  // :70 / :77

@@ -26,6 +26,7 @@ enum { F_FEAS = 1, F_BB = 2, F_FIRST = 4, F_NOSPEC = 8 /* rho/gamma just changed
 
 // internal prox kinds (public SIPX_PROJ_* plus the distance term)
 enum { PX_BOUNDS = 0, PX_BOUNDS_VEC = 1, PX_L1 = 2, PX_L2 = 3, PX_ANNULUS = 4, PX_CARD = 5, PX_PROX_L1 = 6,
+       PX_L1_DFT = 7, PX_RANK = 8,   // library-backed: y arrives precomputed (vsrc == 2)
        PX_DIST = 100 };
 
 struct Grid {
@@ -85,7 +86,7 @@ struct SetArgs {
   T plo, phi;
   const ProjScalars<T>* ps;
   int flags;
-  int vsrc;                             // 1: read v from scratch instead of recomputing it
+  int vsrc;                             // 1: read v from `v`; 2: read the already projected y from `v`
 };
 
 // One changed set of a fused Q update: Q[:,col(off_j)] += alpha * AtA_i[:,j] (CDS_scaled_add!.jl:16-22).
@@ -171,6 +172,8 @@ struct K {
   static void proj_dist_set(hipStream_t s, const Grid& g, const SetArgs<T>& a, int v_is_s, const ProjScalars<T>* ps,
                             double* dst);
   static void ps_init(hipStream_t s, ProjScalars<T>* ps, long long* cidx);
+  // out[e] = v (or s = A x when v_is_s) of the set, padded layout: input of the library-backed projectors
+  static void store_v(hipStream_t s, const Grid& g, const SetArgs<T>& a, int v_is_s, T* out);
 };
 
 // ||P(v)-v||^2, ||v||^2 (slots 0,1) and v = P(v) over a padded vector (pads skipped)

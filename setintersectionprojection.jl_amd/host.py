@@ -37,7 +37,8 @@ EXPORTED_SYMBOLS = [
 
 SIPX_F32, SIPX_F64 = 0, 1
 OPS = {"identity": 0, "D_x": 1, "D_y": 2, "D_z": 3, "TV": 4, "D2D": 4, "D3D": 4}
-PROJ = {"bounds": 0, "bounds_vec": 1, "l1": 2, "l2": 3, "annulus": 4, "cardinality": 5, "prox_l1": 6}
+PROJ = {"bounds": 0, "bounds_vec": 1, "l1": 2, "l2": 3, "annulus": 4, "cardinality": 5, "prox_l1": 6, "l1_dft": 7, "rank": 8}
+SPECIAL_OPERATORS = ("DFT", "DCT", "wavelet", "curvelet")     # src/setup_constraints.jl:54
 YL_FEAS, YL_BB, YL_FIRST = 1, 2, 4
 
 
@@ -236,11 +237,21 @@ class Projector:
         self.TF = np.dtype(TF).type
         self.comp_grid = comp_grid
         st = constraint.set_type
-        if constraint.app_mode[0] not in ("matrix", "tensor"):
+        if constraint.app_mode[0] not in ("matrix", "tensor") and st != "rank":
             raise SipxError("fiber/slice application modes are not part of this engine yet")
         self.lb = self.ub = None
         self.pmin = self.pmax = 0.0
-        if st == "bounds":
+        self.reserved = 0
+        if constraint.TD_OP in SPECIAL_OPERATORS:
+            if not (constraint.TD_OP == "DFT" and st == "l1"):
+                raise SipxError("of the orthogonal-transform sets only the l1 ball in the DFT domain is built")
+            self.kind, self.pmax = "l1_dft", float(constraint.max)
+        elif st == "rank":
+            n = tuple(int(v) for v in comp_grid.n)
+            if len(n) == 3 and n[2] > 1 and tuple(constraint.app_mode) != ("slice", "z"):
+                raise SipxError("rank constraints on a tensor: only mode (slice, z) is built")
+            self.kind, self.pmax, self.reserved = "rank", float(int(constraint.max)), 2
+        elif st == "bounds":
             if np.ndim(constraint.min) == 0:
                 self.kind, self.pmin, self.pmax = "bounds", float(constraint.min), float(constraint.max)
             else:
@@ -261,13 +272,14 @@ class Projector:
         d.op, d.proj = OPS[op], PROJ[self.kind]
         d.pmin, d.pmax = self.pmin, self.pmax
         d.lb, d.ub = _ptr(self.lb), _ptr(self.ub)
-        d.ncvx, d.reserved = int(bool(ncvx)), 0
+        d.ncvx, d.reserved = int(bool(ncvx)), int(self.reserved)
         return d
 
     def __call__(self, v):
         if v.dtype.type != self.TF or not v.flags.c_contiguous:
             raise SipxError("projector input must be a contiguous vector of the working precision")
-        ctx = Context(compgrid((1.0, 1.0), (max(len(v), 1), 1)), self.TF)
+        grid_kind = self.kind in ("l1_dft", "rank")
+        ctx = Context(self.comp_grid if grid_kind else compgrid((1.0, 1.0), (max(len(v), 1), 1)), self.TF)
         try:
             d = self.desc("identity", False)
             _chk(lib().sipx_project(ctx.h, C.byref(d), _ptr(v), C.c_int64(len(v))))
@@ -281,8 +293,10 @@ class Projector:
 # --------------------------------------------------------------------------------------------------
 def get_TD_operator(comp_grid, TD_type: str, TF):
     """src/get_TD_operator.jl:12-95 for the banded operators."""
-    A = TDOperator(TD_type, comp_grid, TF)
     n, _ = _grid(comp_grid)
+    if TD_type == "DFT":       # src/get_TD_operator.jl:45-47,80-82; setup_constraints.jl:76-80 swaps in the identity
+        return TDOperator("identity", comp_grid, TF), True, True, n, False
+    A = TDOperator(TD_type, comp_grid, TF)
     if TD_type == "identity":
         return A, True, False, n, True
     if len(n) == 2:
@@ -312,6 +326,7 @@ def setup_constraints(constraint: List[set_definitions], comp_grid, TF):
         if c.set_type in ("l1", "l2") and c.app_mode[0] in ("slice", "fiber"):
             raise SipxError("l1 and l2 constraints only available for matrix or tensor mode, currently")
         A, AtA_diag, dense, TD_n, banded = get_TD_operator(comp_grid, c.TD_OP, TF)
+        banded = True       # the engine keeps Q in CDS: a DFT set contributes the identity band like any orthogonal op
         P_sub.append(Projector(c, comp_grid, TF))
         TD_OP.append(A)
         prop.AtA_diag.append(AtA_diag); prop.dense.append(dense); prop.TD_n.append(TD_n)
