@@ -31,6 +31,10 @@ CONFIGS = {
     "c2": ((2048, 2048), (25.0, 6.0), ["bounds", "l1:TV"]),
     "c3-512": ((512, 512, 512), (25.0, 25.0, 25.0), ["bounds", "l1:D_x", "l1:D_y", "l1:D_z"]),
     "c3-small": ((64, 64, 64), (25.0, 25.0, 25.0), ["bounds", "l1:D_x", "l1:D_y", "l1:D_z"]),
+    # BASELINE configs[3] (SURVEY 8d "C4"): 8 constraint sets, two of them non-convex
+    "c4": ((512, 512, 512), (25.0, 25.0, 25.0), ["bounds", "l1:D_x", "l1:D_y", "l1:D_z", "annulus", "l1dft", "rank:32", "card:D_z"]),
+    "c4-256": ((256, 256, 256), (25.0, 25.0, 25.0), ["bounds", "l1:D_x", "l1:D_y", "l1:D_z", "annulus", "l1dft", "rank:32", "card:D_z"]),
+    "c4-small": ((64, 64, 64), (25.0, 25.0, 25.0), ["bounds", "l1:D_x", "l1:D_y", "l1:D_z", "annulus", "l1dft", "rank:8", "card:D_z"]),
 }
 
 
@@ -49,6 +53,17 @@ def build_problem(mod, n, h, kinds, m, TF, radius_of):
             c.append(mod.set_definitions("bounds", "identity", 1600.0, 3900.0, ("matrix", "")))
         elif k.startswith("l1:"):
             c.append(mod.set_definitions("l1", k[3:], 0.0, radius_of(k[3:]), ("matrix", "")))
+        elif k == "annulus":                       # [0.9 ||m||, 0.98 ||m||]
+            nm = float(np.linalg.norm(m.astype(np.float64)))
+            c.append(mod.set_definitions("annulus", "identity", 0.9 * nm, 0.98 * nm, ("matrix", "")))
+        elif k == "l1dft":                         # sigma = 0.5 ||F m||_1, F unitary
+            z = np.abs(np.fft.fftn(m.reshape(n, order="F"), norm="ortho"))
+            c.append(mod.set_definitions("l1", "DFT", 0.0, float(0.5 * z.astype(np.float64).sum()), ("matrix", "")))
+        elif k.startswith("rank:"):
+            c.append(mod.set_definitions("rank", "identity", 0, int(k[5:]), ("slice", "z") if len(n) == 3 else ("matrix", "")))
+        elif k.startswith("card:"):                # keep 10% of the entries of D m
+            rows = int(np.prod(n)) // n[-1] * (n[-1] - 1)
+            c.append(mod.set_definitions("cardinality", k[5:], 0, int(0.1 * rows), ("matrix", "")))
     return g, c
 
 
@@ -95,6 +110,7 @@ def main():
             os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="29533", RANK="0", WORLD_SIZE="1")
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
+    sipx.set_default_device(local_rank)
     TF = np.float32
     n, h, kinds = CONFIGS[args.config]
     N = int(np.prod(n))

@@ -65,6 +65,13 @@ class _Log(C.Structure):
 
 
 _lib = None
+_default_device = 0
+
+
+def set_default_device(device: int):
+    """GPU used by contexts that are created implicitly (operator products, stand-alone projector calls)."""
+    global _default_device
+    _default_device = int(device)
 
 
 def lib():
@@ -371,7 +378,8 @@ def PARSDMM_precompute_distribute(TD_OP, set_Prop, comp_grid, options):
 # engine handle (phase-level API, include/sipx.h section A)
 # --------------------------------------------------------------------------------------------------
 class Context:
-    def __init__(self, comp_grid, TF, device: int = 0):
+    def __init__(self, comp_grid, TF, device: Optional[int] = None):
+        device = _default_device if device is None else device
         self.TF = np.dtype(TF).type
         n, h = _grid(comp_grid)
         self.n, self.N = n, int(np.prod(n))
@@ -560,7 +568,7 @@ class Context:
         return self._log_result(lg, arrs)
 
 
-def build_context(m, AtA, TD_OP, set_Prop, P_sub, comp_grid, options, x=None, l=None, y=None, device=0,
+def build_context(m, AtA, TD_OP, set_Prop, P_sub, comp_grid, options, x=None, l=None, y=None, device=None,
                   owned=None) -> Context:
     """Everything PARSDMM_initialize allocates (src/PARSDMM_initialize.jl:117-230), on the device."""
     TF = np.dtype(m.dtype).type
@@ -588,7 +596,7 @@ def build_context(m, AtA, TD_OP, set_Prop, P_sub, comp_grid, options, x=None, l=
     return ctx
 
 
-def PARSDMM(m, AtA, TD_OP, set_Prop, P_sub, comp_grid, options, x=None, l=None, y=None, device=0):
+def PARSDMM(m, AtA, TD_OP, set_Prop, P_sub, comp_grid, options, x=None, l=None, y=None, device=None):
     """Drop-in for src/PARSDMM.jl:25-258 (serial path): returns (x, log_PARSDMM, l, y)."""
     ctx = build_context(m, AtA, TD_OP, set_Prop, P_sub, comp_grid, options, x, l, y, device)
     try:
@@ -605,7 +613,8 @@ def PARSDMM(m, AtA, TD_OP, set_Prop, P_sub, comp_grid, options, x=None, l=None, 
 # --------------------------------------------------------------------------------------------------
 # kernel-level helpers (parity tests / bench)
 # --------------------------------------------------------------------------------------------------
-def cds_spmv(R, offsets, x, device=0):
+def cds_spmv(R, offsets, x, device=None):
+    device = _default_device if device is None else device
     """y = A x for a CDS matrix (fill! + CDS_MVp_MT, src/argmin_x.jl:72-78)."""
     TF = x.dtype.type
     R = np.asfortranarray(R, dtype=TF)

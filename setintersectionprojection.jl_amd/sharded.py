@@ -230,6 +230,8 @@ def PARSDMM_sharded(m, AtA, TD_OP, set_Prop, P_sub, comp_grid, options, dist=Non
     rank = dist.get_rank() if dist is not None else 0
     p = len(TD_OP)
     owned = shard_sets(p, world, rank)
+    from .host import set_default_device
+    set_default_device(device)
     ctx = build_context(m, AtA, TD_OP, set_Prop, P_sub, comp_grid, options, x, l, y, device, owned)
     try:
         comm = TorchComm(dist, torch.device("cuda", device)) if world > 1 else LocalComm()
