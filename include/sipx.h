@@ -152,6 +152,10 @@ int sipx_apply_op(sipx_ctx* ctx, int op, const void* x, void* s);
 int sipx_apply_op_adj(sipx_ctx* ctx, int op, const void* v, void* t);
 /* in-place projector on a host vector of length len (src/projectors/project_X.jl) */
 int sipx_project(sipx_ctx* ctx, const sipx_set_desc* desc, void* v, int64_t len);
+/* nearest-neighbour resampling of an array of shape nc to shape nf, the grid transfer of PARSDMM_multi_level:
+ * out[k] = in[round(1 + (k-1)(nc-1)/(nf-1))] per axis (Interpolations.BSpline(Constant()) evaluated on
+ * range(1, stop=nc, length=nf); src/PARSDMM_multi_level.jl:41-45,61-65, src/interpolate_y_l.jl:32-88) */
+int sipx_resample_nn(int dtype, int ndim, const int64_t* nc, const int64_t* nf, const void* in, void* out, int device);
 /* Q as assembled / updated (N x d column-major) and its offsets */
 int sipx_get_Q(sipx_ctx* ctx, void* Q, int64_t* offsets, int* d);
 /* device-side timing of the dominant kernel: runs cds_spmv on Q `reps` times, returns avg ms (HIP events on the engine stream) */

@@ -85,6 +85,9 @@ int sipx_parsdmm_steps(sipx_ctx* c, int nsteps, int* done) {
 int sipx_cds_spmv(int dtype, int64_t N, int d, const void* R, const int64_t* off, const void* x, void* y, int device) {
   SIPX_TRY(sipx::cds_spmv_host(dtype, N, d, R, off, x, y, device))
 }
+int sipx_resample_nn(int dtype, int ndim, const int64_t* nc, const int64_t* nf, const void* in, void* out, int device) {
+  SIPX_TRY(sipx::resample_nn_host(dtype, ndim, nc, nf, in, out, device))
+}
 int sipx_apply_op(sipx_ctx* c, int op, const void* x, void* s) { SIPX_TRY(c->e->apply_op(op, x, s, false)) }
 int sipx_apply_op_adj(sipx_ctx* c, int op, const void* v, void* t) { SIPX_TRY(c->e->apply_op(op, v, t, true)) }
 int sipx_project(sipx_ctx* c, const sipx_set_desc* d, void* v, int64_t len) { SIPX_TRY(c->e->project(d, v, len)) }

@@ -1070,6 +1070,31 @@ static void cds_spmv_T(int64_t N, int d, const void* R, const int64_t* off, cons
   dfree(dR); dfree(dxb); dfree(dy);
 }
 
+template <typename T>
+static void resample_T(int ndim, const int64_t* nc, const int64_t* nf, const void* in, void* out) {
+  long long c[3] = {1, 1, 1}, f[3] = {1, 1, 1};
+  for (int q = 0; q < ndim && q < 3; ++q) { c[q] = nc[q]; f[q] = nf[q]; }
+  const long long Nc = c[0] * c[1] * c[2], Nf = f[0] * f[1] * f[2];
+  if (Nc < 1 || Nf < 1) throw std::runtime_error("resample: empty array");
+  T* di = dalloc<T>(Nc, false);
+  T* dout = dalloc<T>(Nf, false);
+  SIPX_HIP(hipMemcpy(di, in, Nc * sizeof(T), hipMemcpyHostToDevice));
+  resample_nn<T>(nullptr, c, f, di, dout);
+  SIPX_HIP(hipDeviceSynchronize());
+  SIPX_HIP(hipMemcpy(out, dout, Nf * sizeof(T), hipMemcpyDeviceToHost));
+  dfree(di); dfree(dout);
+}
+void resample_nn_host(int dtype, int ndim, const int64_t* nc, const int64_t* nf, const void* in, void* out, int device) {
+  int count = 0;
+  if (hipGetDeviceCount(&count) != hipSuccess || count <= 0)
+    throw std::runtime_error("libsipx: no HIP device visible -- this engine has no CPU fallback");
+  if (ndim < 1 || ndim > 3) throw std::runtime_error("resample: ndim must be 1..3");
+  SIPX_HIP(hipSetDevice(device));
+  if (dtype == SIPX_F32) resample_T<float>(ndim, nc, nf, in, out);
+  else if (dtype == SIPX_F64) resample_T<double>(ndim, nc, nf, in, out);
+  else throw std::runtime_error("dtype must be SIPX_F32 or SIPX_F64");
+}
+
 void cds_spmv_host(int dtype, int64_t N, int d, const void* R, const int64_t* off, const void* x, void* y, int device) {
   int count = 0;
   if (hipGetDeviceCount(&count) != hipSuccess || count <= 0)

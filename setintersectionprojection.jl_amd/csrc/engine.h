@@ -42,6 +42,7 @@ struct EngineBase {
 };
 
 EngineBase* make_engine(int dtype, int ndim, const int64_t* n, const double* h, int device);
+void resample_nn_host(int dtype, int ndim, const int64_t* nc, const int64_t* nf, const void* in, void* out, int device);
 void cds_spmv_host(int dtype, int64_t N, int d, const void* R, const int64_t* off, const void* x, void* y, int device);
 
 }  // namespace sipx

@@ -408,7 +408,39 @@ void proj_apply_grid(hipStream_t s, const Grid& g, int nblk, const int* dir, lon
   SIPX_HIP(hipGetLastError());
 }
 
+// ---------------------------------------------------------------------------------------------
+// Nearest-neighbour grid transfer of the multilevel scheme: sample position of fine index k (0-based) on an
+// axis is 1 + k (nc-1)/(nf-1) (1-based, range(1, stop=nc, length=nf)); BSpline(Constant()) rounds it to the
+// nearest grid point.  Exact integer arithmetic, no floating point.
+struct RsArgs {
+  long long nc[3], nf[3];
+};
+// nearest grid point of position 1 + k (nc-1)/(nf-1) on 1..nc, half-way positions go up
+// (Interpolations.jl 0.13 rounds with floor(x + 1/2) inside the axis), in exact integers
+__device__ __forceinline__ long long nn_index(long long k, long long nc, long long nf) {
+  if (nf <= 1 || nc <= 1) return 0;
+  const long long num = k * (nc - 1), den = nf - 1;
+  return (2 * num + den) / (2 * den);
+}
+template <typename T>
+__global__ __launch_bounds__(BLOCK) void k_resample(RsArgs a, const T* __restrict__ in, T* __restrict__ out) {
+  const long long tot = a.nf[0] * a.nf[1] * a.nf[2];
+  for (long long e = (long long)blockIdx.x * BLOCK + threadIdx.x; e < tot; e += (long long)gridDim.x * BLOCK) {
+    const long long i = e % a.nf[0], jk = e / a.nf[0], j = jk % a.nf[1], k = jk / a.nf[1];
+    const long long ci = nn_index(i, a.nc[0], a.nf[0]), cj = nn_index(j, a.nc[1], a.nf[1]), ck = nn_index(k, a.nc[2], a.nf[2]);
+    out[e] = in[ci + a.nc[0] * (cj + a.nc[1] * ck)];
+  }
+}
+template <typename T>
+void resample_nn(hipStream_t s, const long long* nc, const long long* nf, const T* in, T* out) {
+  RsArgs a;
+  for (int q = 0; q < 3; ++q) { a.nc[q] = nc[q]; a.nf[q] = nf[q]; }
+  hipLaunchKernelGGL((k_resample<T>), dim3(NB), dim3(BLOCK), 0, s, a, in, out);
+  SIPX_HIP(hipGetLastError());
+}
+
 #define SIPX_INST(T)                                                                                              \
+  template void resample_nn<T>(hipStream_t, const long long*, const long long*, const T*, T*);                   \
   template void K<T>::rhs_compose(hipStream_t, const Grid&, const RhsArgs<T>&, T*, int);                         \
   template void K<T>::yl(hipStream_t, const Grid&, const SetArgs<T>&, double*);                                  \
   template void K<T>::adj_norm(hipStream_t, const Grid&, const SetArgs<T>&, double*);                            \

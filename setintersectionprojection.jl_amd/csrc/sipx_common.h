@@ -184,6 +184,10 @@ template <typename T>
 void proj_apply_grid(hipStream_t s, const Grid& g, int nblk, const int* dir, long long len, T* v, int prox, T plo,
                      T phi, const T* lb, const T* ub, const ProjScalars<T>* ps);
 
+// nearest-neighbour grid transfer (multilevel): out (shape nf) <- in (shape nc)
+template <typename T>
+void resample_nn(hipStream_t s, const long long* nc, const long long* nf, const T* in, T* out);
+
 #define SIPX_HIP(expr)                                                                       \
   do {                                                                                       \
     hipError_t _e = (expr);                                                                  \

@@ -30,7 +30,7 @@ EXPORTED_SYMBOLS = [
     "sipx_adapt_rho_gamma", "sipx_q_update", "sipx_download", "sipx_parsdmm", "sipx_parsdmm_begin",
     "sipx_parsdmm_steps", "sipx_cds_spmv",
     "sipx_apply_op", "sipx_apply_op_adj", "sipx_project", "sipx_get_Q", "sipx_time_spmv", "sipx_kernel_stats",
-    "sipx_debug_proj",
+    "sipx_debug_proj", "sipx_resample_nn",
     "sipx_stream",
     "sipx_dev_rhs", "sipx_dev_x", "sipx_set_owned",
 ]
@@ -432,16 +432,24 @@ class Context:
         feas = np.zeros(max(npp, 1))
         keep = []
 
+        rows_all = list(self.rows) + ([] if feasibility_only else [self.N])
+
         def arr_list(lst):
             if lst is None or len(lst) == 0:
                 return None
+            if len(lst) != len(rows_all):
+                raise SipxError("warm start: l and y need one vector per term (sets plus the distance term)")
             ptrs = (C.c_void_p * len(lst))()
             for i, a in enumerate(lst):
                 a = np.ascontiguousarray(a, self.TF)
+                if a.shape != (rows_all[i],):
+                    raise SipxError(f"warm start: vector {i} has {a.shape} entries, operator {i} has {rows_all[i]} rows")
                 keep.append(a)
                 ptrs[i] = a.ctypes.data
             return ptrs
         x0a = None if x0 is None else np.ascontiguousarray(x0, self.TF)
+        if x0a is not None and x0a.shape != (self.N,):
+            raise SipxError("length of x does not match the grid")
         _chk(lib().sipx_finalize(self.h, _ptr(m), rho.ctypes.data_as(C.c_void_p), len(rho), C.c_double(gamma_ini),
                                  int(feasibility_only), int(zero_ini_guess), _ptr(x0a), arr_list(l0), arr_list(y0),
                                  feas.ctypes.data_as(C.c_void_p)))
@@ -624,6 +632,20 @@ def cds_spmv(R, offsets, x, device=None):
     _chk(lib().sipx_cds_spmv(_dtype_code(TF), C.c_int64(R.shape[0]), int(R.shape[1]), _ptr(R),
                              off.ctypes.data_as(C.c_void_p), _ptr(x), _ptr(y), device))
     return y
+
+
+def resample_nn(a, nc, nf, device=None):
+    """Nearest-neighbour grid transfer (Interpolations.BSpline(Constant()) on range(1, stop=nc, length=nf)), on the device."""
+    device = _default_device if device is None else device
+    a = np.ascontiguousarray(a)
+    TF = a.dtype.type
+    nc, nf = [int(v) for v in nc], [int(v) for v in nf]
+    if a.size != int(np.prod(nc)):
+        raise SipxError("resample: array size does not match its shape")
+    out = np.empty(int(np.prod(nf)), TF)
+    _chk(lib().sipx_resample_nn(_dtype_code(TF), len(nc), (C.c_int64 * len(nc))(*nc), (C.c_int64 * len(nf))(*nf),
+                                _ptr(a), _ptr(out), device))
+    return out
 
 
 def CDS_MVp(N, ndiags, R, offset, x, y):

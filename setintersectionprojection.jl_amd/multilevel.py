@@ -1,0 +1,108 @@
+"""Coarse-to-fine wrapper around the engine: host-side mirror of PARSDMM_multi_level
+(src/PARSDMM_multi_level.jl:8-89) with setup_multi_level_PARSDMM (src/setup_multi_level_PARSDMM.jl:7-137),
+constraint2coarse (src/constraint2coarse.jl:8-104) and interpolate_y_l (src/interpolate_y_l.jl:7-97).
+
+Every level is one native solve (sipx_parsdmm) warm-started through sipx_finalize(x0, l0, y0); the grid
+transfers run on the device (sipx_resample_nn).  PARITY UNPINNED for the transfers: the reference's
+multilevel test is disabled (test/runtests.jl:47) and no test fixes the tie rounding of
+Interpolations.BSpline(Constant()) (Interpolations.jl 0.13); half-way positions on range(1, stop=nc, length=nf)
+are taken to round up (floor(x + 1/2)).
+The TV branch of interpolate_y_l splits the multipliers with [D_x; D_y; D_z] block sizes although the
+storage order is [D_z; D_y; D_x] -- replicated as written.
+"""
+from __future__ import annotations
+
+import copy
+import math
+
+import numpy as np
+
+from . import host
+
+
+def constraint2coarse(constraint, comp_grid, cf):
+    n = tuple(int(v) for v in comp_grid.n)
+    dim3 = len(n) == 3 and n[2] > 1
+    for c in constraint:
+        if c.set_type == "rank":
+            c.max = min(c.max, min(n))
+        if c.set_type == "cardinality":
+            c.max = min(c.max, int(np.prod(n)))
+        if c.set_type == "l1":
+            c.max = c.max / (cf ** 3 if dim3 else cf ** 2)
+        if c.set_type == "l2":
+            c.max = c.max / (math.sqrt(cf ** 3) if dim3 else cf)
+        if c.set_type == "nuclear" and not dim3:
+            c.max = c.max / 2.7
+    return constraint
+
+
+def setup_multi_level_PARSDMM(m, n_levels, coarsening_factor, comp_grid, constraint, options):
+    TF = m.dtype.type
+    cf = coarsening_factor
+    P_sub, TD_OP, prop = host.setup_constraints(copy.deepcopy(constraint), comp_grid, TF)
+    TD_OP, AtA, l, y = host.PARSDMM_precompute_distribute(TD_OP, prop, comp_grid, options)
+    TD_OP_levels, AtA_levels, P_sub_levels, prop_levels, grid_levels = [TD_OP], [AtA], [P_sub], [prop], [comp_grid]
+    constraint_level = copy.deepcopy(constraint)
+    n0 = tuple(int(v) for v in comp_grid.n)
+    for i in range(2, n_levels + 1):
+        n = tuple(int(np.rint(v / cf ** (i - 1))) for v in n0)
+        d = tuple((a / b) * dd for a, b, dd in zip(n0, n, comp_grid.d))
+        g = host.compgrid(d, n)
+        constraint_level = constraint2coarse(constraint_level, g, cf)
+        P, A, pr = host.setup_constraints(copy.deepcopy(constraint_level), g, TF)
+        A, AtA_l, _, _ = host.PARSDMM_precompute_distribute(A, pr, g, options)
+        TD_OP_levels.append(A); AtA_levels.append(AtA_l); P_sub_levels.append(P); prop_levels.append(pr); grid_levels.append(g)
+    return TD_OP_levels, AtA_levels, P_sub_levels, prop_levels, grid_levels, constraint_level
+
+
+def interpolate_y_l(l, y, set_Prop_levels, comp_grid_levels, dim3, i):
+    nc = tuple(int(v) for v in comp_grid_levels[i + 1].n)
+    nf = tuple(int(v) for v in comp_grid_levels[i].n)
+    rs = host.resample_nn
+    for j in range(len(l)):
+        tag = set_Prop_levels[i].tag[j][1]
+        if tag in ("TV", "D2D", "D3D"):
+            if dim3:
+                shapes_c = [(nc[0] - 1, nc[1], nc[2]), (nc[0], nc[1] - 1, nc[2]), (nc[0], nc[1], nc[2] - 1)]
+                shapes_f = [(nf[0] - 1, nf[1], nf[2]), (nf[0], nf[1] - 1, nf[2]), (nf[0], nf[1], nf[2] - 1)]
+            else:
+                shapes_c = [(nc[0] - 1, nc[1]), (nc[0], nc[1] - 1)]
+                shapes_f = [(nf[0] - 1, nf[1]), (nf[0], nf[1] - 1)]
+            ends = np.cumsum([int(np.prod(s)) for s in shapes_c])
+            starts = np.concatenate(([0], ends[:-1]))
+            l[j] = np.concatenate([rs(l[j][a:b], sc, sf) for a, b, sc, sf in zip(starts, ends, shapes_c, shapes_f)])
+            y[j] = np.concatenate([rs(y[j][a:b], sc, sf) for a, b, sc, sf in zip(starts, ends, shapes_c, shapes_f)])
+        else:
+            tdn_f = tuple(int(v) for v in set_Prop_levels[i].TD_n[j])
+            tdn_c = tuple(int(v) for v in set_Prop_levels[i + 1].TD_n[j])
+            s = tuple(a - b for a, b in zip(nf, tdn_f))
+            fine = tuple(a - b for a, b in zip(nf, s))
+            l[j] = rs(l[j], tdn_c, fine)
+            y[j] = rs(y[j], tdn_c, fine)
+    return l, y
+
+
+def PARSDMM_multi_level(m, TD_OP_levels, AtA_levels, P_sub_levels, set_Prop_levels, comp_grid_levels, options,
+                        device=None):
+    n_levels = len(TD_OP_levels)
+    n0 = tuple(int(v) for v in comp_grid_levels[0].n)
+    dim3 = len(n0) == 3 and n0[2] > 1
+    rho_orig = list(options.rho_ini)
+    m_levels = [m] + [host.resample_nn(m, n0, tuple(int(v) for v in comp_grid_levels[i].n)) for i in range(1, n_levels)]
+    i = n_levels - 1
+    options.zero_ini_guess = True
+    x, log, l, y = host.PARSDMM(m_levels[i], AtA_levels[i], TD_OP_levels[i], set_Prop_levels[i], P_sub_levels[i],
+                                comp_grid_levels[i], options, device=device)
+    options.rho_ini = [float(v) for v in np.atleast_2d(log.rho)[-1, :]]
+    for i in range(n_levels - 2, -1, -1):
+        nc = tuple(int(v) for v in comp_grid_levels[i + 1].n)
+        nf = tuple(int(v) for v in comp_grid_levels[i].n)
+        x = host.resample_nn(x, nc, nf)
+        l, y = interpolate_y_l(list(l), list(y), set_Prop_levels, comp_grid_levels, dim3, i)
+        options.zero_ini_guess = False
+        x, log, l, y = host.PARSDMM(m_levels[i], AtA_levels[i], TD_OP_levels[i], set_Prop_levels[i], P_sub_levels[i],
+                                    comp_grid_levels[i], options, x, l, y, device=device)
+        options.rho_ini = [float(v) for v in np.atleast_2d(log.rho)[-1, :]]
+    options.rho_ini = rho_orig
+    return x, log, l, y

@@ -436,3 +436,33 @@ def test_sharded_two_ranks_on_one_gpu(sipx, tmp_path):
     assert np.array_equal(r0["cg_it"][:K], ls.cg_it[:K])
     assert np.allclose(r0["obj"][:K], ls.obj[:K], rtol=5e-4) and np.allclose(r0["r_pri"][:K], ls.r_pri[:K], rtol=5e-4, atol=1e-12)
     assert np.linalg.norm(r0["x"] - xs) / np.linalg.norm(xs) < 5e-4        # test/test_PARSDMM_parallel.jl:72
+
+
+# ---- multilevel (BASELINE config 5 pattern; parity unpinned in the reference, oracle == engine here) ----------
+def test_resample_nn_matches_oracle(sipx):
+    rng = np.random.default_rng(41)
+    for nc, nf in (((7, 5), (13, 9)), ((16, 12, 8), (8, 6, 4)), ((9, 7, 5), (17, 13, 9)), ((4, 4, 4), (9, 9, 9)), ((5,), (5,))):
+        a = rng.standard_normal(int(np.prod(nc)))
+        assert np.array_equal(sipx.host.resample_nn(a, nc, nf), O.resample_nn(a, nc, nf))
+
+
+@pytest.mark.parametrize("TF,n,h", [(np.float64, (32, 24), (25.0, 6.0)), (np.float32, (16, 16, 16), (25.0, 25.0, 25.0))])
+def test_multilevel_matches_oracle(sipx, TF, n, h):
+    from sipx import multilevel as ML
+    m = model(n, TF, seed=9)
+
+    def cons(mod):
+        TV = O.get_TD_operator(O.compgrid(h, n), "TV", TF)[0]
+        return [mod.set_definitions("bounds", "identity", 1600.0, 3900.0, ("matrix", "")),
+                mod.set_definitions("l1", "TV", 0.0, float(0.5 * np.abs(TV @ m).sum()), ("matrix", ""))]
+    oo = O.PARSDMM_options(FL=TF, maxit=40)
+    Lo = O.setup_multi_level_PARSDMM(m, 2, 2, O.compgrid(h, n), cons(O), oo)
+    xo, logo, lo, yo = O.PARSDMM_multi_level(m.copy(), *Lo[:5], oo)
+    os_ = sipx.PARSDMM_options(FL=TF, maxit=40)
+    Ls = ML.setup_multi_level_PARSDMM(m, 2, 2, sipx.compgrid(h, n), cons(sipx), os_)
+    assert [tuple(g.n) for g in Ls[4]] == [tuple(g.n) for g in Lo[4]]
+    xs, logs, ls, ys = ML.PARSDMM_multi_level(m.copy(), *Ls[:5], os_)
+    err = np.linalg.norm(xs.astype(np.float64) - xo) / np.linalg.norm(xo)
+    assert err < (5e-4 if TF == np.float32 else 1e-6), err
+    assert [len(v) for v in ys] == [len(v) for v in yo]
+    assert list(os_.rho_ini) == [10.0] or np.allclose(os_.rho_ini, 10.0)          # restored (PARSDMM_multi_level.jl:87)

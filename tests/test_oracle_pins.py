@@ -245,3 +245,33 @@ def test_converged_result_is_feasible():
     it = len(log.obj)
     assert log.r_pri.shape == (it, 4) and log.set_feasibility.shape[1] == 3
     assert log.cg_it[0] == 0 and np.isnan(log.evol_x[0])      # zero start: rhs==0 => cg flag -9
+
+
+def test_nearest_neighbour_index_rounds_half_up_on_the_julia_range():
+    # exact halves of 1 + k (nc-1)/(nf-1) are representable in float64, so floor(x + 0.5) on the float expression
+    # is the reference for the integer routine
+    for nc in range(1, 20):
+        for nf in range(1, 40):
+            k = np.arange(nf)
+            want = (np.floor(1 + k * (nc - 1) / (nf - 1) + 0.5) - 1).astype(np.int64) if nf > 1 and nc > 1 else np.zeros(nf, np.int64)
+            got = O._nn_index(nc, nf)
+            assert np.array_equal(got, want), (nc, nf)
+            assert got.min() >= 0 and got.max() <= nc - 1
+
+
+def test_resample_identity_and_coarsen_refine_shapes():
+    rng = np.random.default_rng(5)
+    a = rng.standard_normal(6 * 5 * 4)
+    assert np.array_equal(O.resample_nn(a, (6, 5, 4), (6, 5, 4)), a)
+    c = O.resample_nn(a, (6, 5, 4), (3, 3, 2))
+    assert c.shape == (18,)
+    A = a.reshape((6, 5, 4), order="F")
+    assert c.reshape((3, 3, 2), order="F")[2, 2, 1] == A[5, 4, 3] and c[0] == a[0]      # end points map to end points
+
+
+def test_constraint2coarse_scalings():
+    cs = [O.set_definitions("l1", "TV", 0.0, 8.0, ("matrix", "")), O.set_definitions("l2", "identity", 0.0, 4.0, ("matrix", "")),
+          O.set_definitions("cardinality", "identity", 0, 10 ** 9, ("matrix", "")), O.set_definitions("rank", "identity", 0, 99, ("matrix", "")),
+          O.set_definitions("nuclear", "identity", 0.0, 2.7, ("matrix", ""))]
+    out = O.constraint2coarse(cs, O.compgrid((1.0, 1.0), (10, 8)), 2)
+    assert [c.max for c in out[:4]] == [2.0, 2.0, 80, 8] and abs(out[4].max - 1.0) < 1e-15
