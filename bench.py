@@ -88,6 +88,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--config", default="c3", choices=sorted(CONFIGS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--q-mode", default="cds", choices=["cds", "stencil"],
+                    help="cds = the reference's banded Q (the contract workload); stencil = generated coefficients (SURVEY 8f-2)")
     args = ap.parse_args()
 
     import torch
@@ -125,6 +127,7 @@ def main():
     P, A, prop = sipx.setup_constraints(c, g, TF)
     maxit = args.warmup + args.steps + 1
     opt = bench_options(sipx, TF, maxit)
+    opt.Q_mode = args.q_mode
     A, AtA, l, y = sipx.PARSDMM_precompute_distribute(A, prop, g, opt)
     p = len(A)
     owned = sharded.shard_sets(p, world, rank)
@@ -182,11 +185,13 @@ def main():
     d = len(np.unique(np.concatenate([np.asarray(o) for o in prop.AtA_offsets])))
     w = np.dtype(TF).itemsize
     spmv_bytes = (d + 2) * N * w                 # B_spmv = (d+2) N w per launch
+    if args.q_mode == "stencil":
+        spmv_bytes = 2 * N * w                   # reads p, writes Ap; coefficients are generated
     achieved = (spmv_bytes / (kms / launches * 1e-3) / 1e9) if launches else 0.0
     # HBM traffic of the dominant kernel from the PMC counters: separate rocprofv3 --pmc passes, summarised in profiles/
     traffic, traffic_src = None, None
     pmc = os.path.join(ROOT, "profiles", "r01_c3_256_pmc.json")
-    if args.config == "c3" and os.path.exists(pmc):
+    if args.config == "c3" and args.q_mode == "cds" and os.path.exists(pmc):
         traffic = json.load(open(pmc))["dominant_kernel"]["hbm_bytes_per_launch_corrected"]
         traffic_src = "profiles/r01_c3_256_pmc.json (2*FETCH_SIZE + WRITE_SIZE, gfx950 correction)"
     log = drv.result_log()
@@ -197,11 +202,12 @@ def main():
         "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
         "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": f"{args.config}: {'x'.join(map(str, n))} Float32, sets {{{', '.join(kinds)}}} + distance term",
-                   "grid": list(n), "sets": kinds, "parallelism": f"set-sharded x{world}" if world > 1 else "single GPU",
+                   "grid": list(n), "sets": kinds, "q_mode": args.q_mode, "parallelism": f"set-sharded x{world}" if world > 1 else "single GPU",
                    "cg_iterations_in_timed_steps": int(cg_its), "all_logs_finite": finite,
                    "driver": "native loop (sipx_parsdmm_begin/_steps)" if native else
                              "phase-level C ABI (sipx_rhs_compose/argmin_x/update_y_l/...) + torch.distributed"},
-        "roofline": {"bound": "hbm", "kernel": "k_cds<MODE=1> (cds_spmv + p.Ap partials)", "achieved": achieved,
+        "roofline": {"bound": "hbm", "kernel": "k_cds<MODE=1> (cds_spmv + p.Ap partials)" if args.q_mode == "cds" else
+                     "k_sq<MODE=1> (stencil Q product + p.Ap partials)", "achieved": achieved,
                      "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                      "traffic": traffic, "traffic_source": traffic_src, "launches": int(launches), "avg_launch_ms": (kms / launches) if launches else None,
                      "algorithmic_bytes_per_launch": spmv_bytes},

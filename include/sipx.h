@@ -174,6 +174,16 @@ void* sipx_dev_x(sipx_ctx* ctx);
 /* restricts y/l work and rhs contributions to sets with owner[i] != 0 (set sharding); Q stays global */
 int sipx_set_owned(sipx_ctx* ctx, const int32_t* owned);
 
+/* How the x-step applies Q = sum_i rho_i A_i'A_i.  SIPX_Q_CDS (default): explicit bands in CDS storage, the
+ * reference's arithmetic (PARSDMM_initialize.jl:216-230, CDS_MVp_MT.jl:9-25, Q_update!.jl:45-48), (d+2) N w bytes per
+ * product.  SIPX_Q_STENCIL ("beyond CDS"): coefficients generated from rho_i, h and the boundary
+ * masks, 2 N w bytes per product and no Q_update! traffic; every set must use a descriptor-generated AtA
+ * (ata_R = NULL).  Results agree with the CDS mode to rounding, not bit for bit.  Call before sipx_finalize. */
+enum { SIPX_Q_CDS = 0, SIPX_Q_STENCIL = 1 };
+int sipx_set_q_mode(sipx_ctx* ctx, int mode);
+/* y = Q x (host TF[N] in and out) through the kernel the x-step uses, in either mode */
+int sipx_apply_Q(sipx_ctx* ctx, const void* x, void* y);
+
 #ifdef __cplusplus
 }
 #endif

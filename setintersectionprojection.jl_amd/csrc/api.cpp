@@ -101,5 +101,7 @@ void* sipx_stream(sipx_ctx* c) { return c->e->stream(); }
 void* sipx_dev_rhs(sipx_ctx* c) { return c->e->dev_rhs(); }
 void* sipx_dev_x(sipx_ctx* c) { return c->e->dev_x(); }
 int sipx_set_owned(sipx_ctx* c, const int32_t* owned) { SIPX_TRY(c->e->set_owned(owned)) }
+int sipx_set_q_mode(sipx_ctx* c, int mode) { SIPX_TRY(c->e->set_q_mode(mode)) }
+int sipx_apply_Q(sipx_ctx* c, const void* x, void* y) { SIPX_TRY(c->e->apply_Q(x, y)) }
 
 }  // extern "C"

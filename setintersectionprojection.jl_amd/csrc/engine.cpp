@@ -213,6 +213,12 @@ class Engine : public EngineBase {
     owned_.assign(owned, owned + sets_.size() + 1);
   }
 
+  void set_q_mode(int mode) override {
+    if (finalized_) throw std::runtime_error("sipx_set_q_mode must precede sipx_finalize");
+    if (mode != SIPX_Q_CDS && mode != SIPX_Q_STENCIL) throw std::runtime_error("unknown Q mode");
+    stencil_q_ = mode == SIPX_Q_STENCIL;
+  }
+
   // ------------------------------------------------------------------------------------------
   void finalize(const void* m, const double* rho_ini, int n_rho, double gamma_ini, int feasibility_only,
                 int zero_ini_guess, const void* x0, const void* const* l0, const void* const* y0,
@@ -376,7 +382,8 @@ class Engine : public EngineBase {
     need_final();
     cg_host_->tol_ref = (T)*tol_ref_io;     // pinned staging; the device mirror overwrites it after the copy (stream order)
     SIPX_HIP(hipMemcpyAsync(&cg_dev_->tol_ref, &cg_host_->tol_ref, sizeof(T), hipMemcpyHostToDevice, stream_));
-    K<T>::resid(stream_, G_.N, Q_, cds_, x_, rhs_, r_, p_, xold_, part_cg_);
+    if (stencil_q_) K<T>::sq_resid(stream_, G_, sq_, x_, rhs_, r_, p_, xold_, part_cg_);
+    else K<T>::resid(stream_, G_.N, Q_, cds_, x_, rhs_, r_, p_, xold_, part_cg_);
     K<T>::cg_begin(stream_, part_cg_, cg_dev_, cg_host_, it, x_, G_.N);
     SIPX_HIP(hipStreamSynchronize(stream_));
     if (cg_host_->flag == -9) SIPX_HIP(hipMemsetAsync(x_, 0, G_.N * sizeof(T), stream_));   // cg.jl:51
@@ -387,7 +394,8 @@ class Engine : public EngineBase {
     auto enqueue = [&](int k) {
       CgState<T>* mirror = cg_host_ + (k & 1);
       if (stats_on_) stat_mark();
-      K<T>::spmv_dot(stream_, G_.N, Q_, cds_, p_, Ap_, part_cg_, cg_dev_);
+      if (stencil_q_) K<T>::sq_spmv_dot(stream_, G_, sq_, p_, Ap_, part_cg_, cg_dev_);
+      else K<T>::spmv_dot(stream_, G_.N, Q_, cds_, p_, Ap_, part_cg_, cg_dev_);
       if (stats_on_) stat_mark();
       K<T>::cg_fin_alpha(stream_, part_cg_, cg_dev_, mirror, k);
       K<T>::cg_update_xr(stream_, G_.N, x_, r_, p_, Ap_, part_cg_, cg_dev_);
@@ -509,6 +517,10 @@ class Engine : public EngineBase {
 
   void q_update(const double* rho_new, const double* rho_old) override {
     need_final();
+    if (stencil_q_) {
+      stencil_weights(rho_new);
+      return;
+    }
     QArgs<T> a;
     a.nsets = 0;
     for (int i = 0; i < p_n_; ++i) {
@@ -761,7 +773,18 @@ class Engine : public EngineBase {
     SIPX_HIP(hipStreamSynchronize(stream_));
     if (d) *d = cds_.d;
     if (offsets) for (int b = 0; b < cds_.d; ++b) offsets[b] = cds_.off[b];
+    if (Q && stencil_q_) throw std::runtime_error("stencil Q mode stores no bands (use sipx_apply_Q)");
     if (Q) SIPX_HIP(hipMemcpy(Q, Q_, (size_t)G_.N * cds_.d * sizeof(T), hipMemcpyDeviceToHost));
+  }
+
+  void apply_Q(const void* x, void* y) override {     // y = Q x through the solver's own kernel (either mode)
+    need_final();
+    SIPX_HIP(hipStreamSynchronize(stream_));
+    SIPX_HIP(hipMemcpy(p_, x, G_.N * sizeof(T), hipMemcpyHostToDevice));
+    if (stencil_q_) K<T>::sq_spmv(stream_, G_, sq_, p_, Ap_);
+    else K<T>::spmv(stream_, G_, G_.N, Q_, cds_, p_, Ap_);
+    SIPX_HIP(hipStreamSynchronize(stream_));
+    SIPX_HIP(hipMemcpy(y, Ap_, G_.N * sizeof(T), hipMemcpyDeviceToHost));
   }
 
   double time_spmv(int reps) override {
@@ -769,9 +792,13 @@ class Engine : public EngineBase {
     hipEvent_t a, b;
     SIPX_HIP(hipEventCreate(&a));
     SIPX_HIP(hipEventCreate(&b));
-    K<T>::spmv(stream_, G_, G_.N, Q_, cds_, x_, Ap_);   // warm
+    auto one = [&]() {
+      if (stencil_q_) K<T>::sq_spmv(stream_, G_, sq_, x_, Ap_);
+      else K<T>::spmv(stream_, G_, G_.N, Q_, cds_, x_, Ap_);
+    };
+    one();   // warm
     SIPX_HIP(hipEventRecord(a, stream_));
-    for (int k = 0; k < reps; ++k) K<T>::spmv(stream_, G_, G_.N, Q_, cds_, x_, Ap_);
+    for (int k = 0; k < reps; ++k) one();
     SIPX_HIP(hipEventRecord(b, stream_));
     SIPX_HIP(hipEventSynchronize(b));
     float ms = 0;
@@ -891,7 +918,31 @@ class Engine : public EngineBase {
     for (int b = 0; b < cds_.d; ++b) cds_.off[b] = seen[b];
   }
 
+  // stencil mode: the whole of Q is four scalars, recomputed from the current rho (no update history)
+  void stencil_weights(const double* rho) {
+    double w0 = 0, w[3] = {0, 0, 0};
+    sq_.mask = 0;
+    for (int i = 0; i < p_n_; ++i) {
+      const SetState<T>& s = sets_[i];
+      const double r = (double)(T)rho[i];
+      if (s.nblk == 0) w0 += r;
+      for (int q = 0; q < s.nblk; ++q) {
+        w[s.dir[q]] += r * (double)(T)(s.ih[q] * s.ih[q]);
+        sq_.mask |= 1 << s.dir[q];
+      }
+    }
+    sq_.w0 = (T)w0;
+    for (int d = 0; d < 3; ++d) sq_.w[d] = (T)w[d];
+  }
+
   void assemble_Q() {      // PARSDMM_initialize.jl:222-230
+    if (stencil_q_) {
+      for (auto& s : sets_)
+        if (s.ata) throw std::runtime_error("stencil Q mode needs descriptor-generated AtA for every set (pass ata_R = NULL)");
+      std::vector<double> r(rho_.begin(), rho_.end());
+      stencil_weights(r.data());
+      return;
+    }
     Q_ = dalloc<T>((size_t)G_.N * cds_.d);
     QArgs<T> a;
     a.nsets = 0;
@@ -1024,6 +1075,8 @@ class Engine : public EngineBase {
   T* scr_w_ = nullptr;
   bool need_idx_ = false, need_ext_ = false;
   CdsArgs cds_;
+  StencilQ<T> sq_{};
+  bool stencil_q_ = false;
   double *part_cg_ = nullptr, *part_tmp_ = nullptr, *part_sets_ = nullptr;
   CgState<T>*cg_dev_ = nullptr, *cg_host_ = nullptr;
   double* hres_ = nullptr;

@@ -32,6 +32,7 @@ struct EngineBase {
   virtual void apply_op(int op, const void* x, void* s, bool adjoint) = 0;
   virtual void project(const sipx_set_desc* d, void* v, int64_t len) = 0;
   virtual void get_Q(void* Q, int64_t* offsets, int* d) = 0;
+  virtual void apply_Q(const void* x, void* y) = 0;
   virtual double time_spmv(int reps) = 0;
   virtual void kernel_stats(int enable, int64_t* launches, double* total_ms) = 0;
   virtual void debug_proj(int set, int which, double* out16) = 0;
@@ -39,6 +40,7 @@ struct EngineBase {
   virtual void* dev_rhs() = 0;
   virtual void* dev_x() = 0;
   virtual void set_owned(const int32_t* owned) = 0;
+  virtual void set_q_mode(int mode) = 0;
 };
 
 EngineBase* make_engine(int dtype, int ndim, const int64_t* n, const double* h, int device);

@@ -147,6 +147,107 @@ void K<T>::resid(hipStream_t s, long long N, const T* R, const CdsArgs& a, const
 }
 
 // ---------------------------------------------------------------------------------------------
+// Stencil form of Q = sum_i rho_i A_i'A_i for descriptor-generated sets (identity and forward differences):
+// (Qx)_c = w0 x_c + sum_dir w_dir [ (c_dir > 0)(x_c - x_{c-st}) + (c_dir < n_dir-1)(x_c - x_{c+st}) ],
+// w0 = sum of rho over identity sets, w_dir = sum of rho_i / h_dir^2 over the sets that difference along dir.
+// Reads x only: 2 N w algorithmic bytes instead of (d+2) N w, and Q_update! becomes four scalars.
+// NOT the reference's CDS arithmetic (coefficients are not rounded band by band, no update history):
+// a separate mode (sipx_set_q_mode), agreement with the CDS mode is at rounding level, not bit for bit.
+template <typename T, int V>
+__device__ __forceinline__ void stencil_rows(const Grid& G, const StencilQ<T>& q, const T* __restrict__ x, long long g,
+                                             const Vec<T, V>& xc, T (&acc)[V]) {
+  const Coord c = coords(G, g);
+#pragma unroll
+  for (int k = 0; k < V; ++k) acc[k] = q.w0 * xc.v[k];
+#pragma unroll
+  for (int dir = 0; dir < 3; ++dir) {
+    if (!(q.mask & (1 << dir))) continue;
+    const long long st = G.st[dir];
+    const int nd = (int)G.n[dir], cd = coord_of(c, dir);
+    const Vec<T, V> xm = ldv_u<T, V>(x + g - st), xp = ldv_u<T, V>(x + g + st);
+#pragma unroll
+    for (int k = 0; k < V; ++k) {
+      const int ck = cd + (dir == 0 ? k : 0);
+      const T a = xc.v[k] - xm.v[k], b = xc.v[k] - xp.v[k];
+      const T t = (ck > 0 ? a : T(0)) + (ck < nd - 1 ? b : T(0));
+      acc[k] = acc[k] + q.w[dir] * t;
+    }
+  }
+}
+
+template <typename T, int V, int MODE>
+__global__ __launch_bounds__(BLOCK) void k_sq(Grid G, StencilQ<T> q, const T* __restrict__ x, T* __restrict__ y,
+                                              const T* __restrict__ b, T* __restrict__ pout, T* __restrict__ xold,
+                                              double* __restrict__ partials, const int* __restrict__ done) {
+  if (MODE == 1 && *done) return;
+  const long long nvec = G.N / V;
+  double acc0 = 0, acc1 = 0;
+  for (long long vi = (long long)blockIdx.x * BLOCK + threadIdx.x; vi < nvec; vi += (long long)gridDim.x * BLOCK) {
+    const long long r = vi * V;
+    const Vec<T, V> xv = ldv<T, V>(x + r);
+    T s[V];
+    stencil_rows<T, V>(G, q, x, r, xv, s);
+    Vec<T, V> o;
+    if (MODE == 0) {
+#pragma unroll
+      for (int k = 0; k < V; ++k) o.v[k] = s[k];
+      stv_nt<T, V>(y + r, o);
+    } else if (MODE == 1) {
+#pragma unroll
+      for (int k = 0; k < V; ++k) {
+        o.v[k] = s[k];
+        acc0 += (double)xv.v[k] * (double)s[k];
+      }
+      stv_nt<T, V>(y + r, o);
+    } else {
+      const Vec<T, V> bv = ldv<T, V>(b + r);
+#pragma unroll
+      for (int k = 0; k < V; ++k) {
+        o.v[k] = bv.v[k] - s[k];
+        acc0 += (double)o.v[k] * (double)o.v[k];
+        acc1 += (double)bv.v[k] * (double)bv.v[k];
+      }
+      stv<T, V>(y + r, o);
+      stv<T, V>(pout + r, o);
+      stv<T, V>(xold + r, xv);
+    }
+  }
+  if (MODE == 1) {
+    double acc[1] = {acc0};
+    block_reduce_store<1>(acc, partials, 0);
+  } else if (MODE == 2) {
+    double acc[2] = {acc0, acc1};
+    block_reduce_store<2>(acc, partials, 0);
+  }
+}
+
+template <typename T, int MODE>
+static void launch_sq(hipStream_t s, const Grid& G, const StencilQ<T>& q, const T* x, T* y, const T* b, T* pout, T* xold,
+                      double* partials, const int* done) {
+  // NB_7 like every other kernel that writes the CG partials: block_sum_partials adds all NB entries of a slot, so the
+  // producers of one slot must cover the same block range (the tail NB_7..NB-1 stays zero from allocation)
+  if (G.N % 4 == 0 && G.n[0] % 4 == 0)
+    hipLaunchKernelGGL((k_sq<T, 4, MODE>), dim3(NB_7), dim3(BLOCK), 0, s, G, q, x, y, b, pout, xold, partials, done);
+  else
+    hipLaunchKernelGGL((k_sq<T, 1, MODE>), dim3(NB_7), dim3(BLOCK), 0, s, G, q, x, y, b, pout, xold, partials, done);
+  SIPX_HIP(hipGetLastError());
+}
+template <typename T>
+void K<T>::sq_spmv(hipStream_t s, const Grid& G, const StencilQ<T>& q, const T* x, T* y) {
+  launch_sq<T, 0>(s, G, q, x, y, nullptr, nullptr, nullptr, nullptr, nullptr);
+}
+template <typename T>
+void K<T>::sq_spmv_dot(hipStream_t s, const Grid& G, const StencilQ<T>& q, const T* p, T* Ap, double* partials,
+                       const CgState<T>* st) {
+  launch_sq<T, 1>(s, G, q, p, Ap, nullptr, nullptr, nullptr, partials, &st->done);
+}
+template <typename T>
+void K<T>::sq_resid(hipStream_t s, const Grid& G, const StencilQ<T>& q, const T* x, const T* b, T* r, T* p, T* xold,
+                    double* partials) {
+  launch_sq<T, 2>(s, G, q, x, r, b, p, xold, partials, nullptr);
+}
+
+// ---------------------------------------------------------------------------------------------
 // Q[:,c] += alpha * AtA_i[:,k]   (CDS_scaled_add!.jl:16-22; one band per launch)
 template <typename T, int V>
 __global__ __launch_bounds__(BLOCK) void k_q_axpy(long long N, T* __restrict__ q, const T* __restrict__ a, T alpha) {
@@ -435,6 +536,10 @@ void K<T>::fin_sum(hipStream_t s, const double* partials, int nslots, double* ou
                                const CgState<T>*);                                                                    \
   template void K<T>::resid(hipStream_t, long long, const T*, const CdsArgs&, const T*, const T*, T*, T*, T*, double*); \
   template void K<T>::q_axpy(hipStream_t, long long, T*, const T*, T);                                               \
+  template void K<T>::sq_spmv(hipStream_t, const Grid&, const StencilQ<T>&, const T*, T*);                           \
+  template void K<T>::sq_spmv_dot(hipStream_t, const Grid&, const StencilQ<T>&, const T*, T*, double*,               \
+                                  const CgState<T>*);                                                                 \
+  template void K<T>::sq_resid(hipStream_t, const Grid&, const StencilQ<T>&, const T*, const T*, T*, T*, T*, double*); \
   template void K<T>::q_update(hipStream_t, const Grid&, const CdsArgs&, const QArgs<T>&, T*);                        \
   template void K<T>::gen_ata(hipStream_t, const Grid&, int, const int*, const T*, int, const long long*, T*);       \
   template void K<T>::cg_begin(hipStream_t, double*, CgState<T>*, CgState<T>*, int, T*, long long);                  \

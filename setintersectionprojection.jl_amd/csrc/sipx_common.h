@@ -40,6 +40,14 @@ struct CdsArgs {
   long long off[MAXD];
 };
 
+// Q = sum_i rho_i A_i'A_i as stencil coefficients (sipx_set_q_mode(SIPX_Q_STENCIL)): w0 = sum of rho over identity
+// sets, w[dir] = sum of rho_i / h_dir^2 over sets differencing along dir, mask = directions present.
+template <typename T>
+struct StencilQ {
+  T w0, w[3];
+  int mask;
+};
+
 // Scalars of the non-elementwise projectors, produced on the device and consumed by k_yl.
 // The l1 part persists across PARSDMM iterations: the thresholds probed during the first pass
 // are centred on the previous iteration's theta (warm start).
@@ -142,6 +150,11 @@ struct K {
                        const CgState<T>* st);
   static void resid(hipStream_t s, long long N, const T* R, const CdsArgs& a, const T* x, const T* b, T* r, T* p,
                     T* xold, double* partials);
+  static void sq_spmv(hipStream_t s, const Grid& g, const StencilQ<T>& q, const T* x, T* y);
+  static void sq_spmv_dot(hipStream_t s, const Grid& g, const StencilQ<T>& q, const T* p, T* Ap, double* partials,
+                          const CgState<T>* st);
+  static void sq_resid(hipStream_t s, const Grid& g, const StencilQ<T>& q, const T* x, const T* b, T* r, T* p, T* xold,
+                       double* partials);
   static void q_axpy(hipStream_t s, long long N, T* Qband, const T* Aband, T alpha);
   static void q_update(hipStream_t s, const Grid& g, const CdsArgs& q, const QArgs<T>& a, T* Q);
   static void gen_ata(hipStream_t s, const Grid& g, int nblk, const int* dir, const T* ih, int nband,

@@ -30,7 +30,7 @@ EXPORTED_SYMBOLS = [
     "sipx_adapt_rho_gamma", "sipx_q_update", "sipx_download", "sipx_parsdmm", "sipx_parsdmm_begin",
     "sipx_parsdmm_steps", "sipx_cds_spmv",
     "sipx_apply_op", "sipx_apply_op_adj", "sipx_project", "sipx_get_Q", "sipx_time_spmv", "sipx_kernel_stats",
-    "sipx_debug_proj", "sipx_resample_nn",
+    "sipx_debug_proj", "sipx_resample_nn", "sipx_set_q_mode", "sipx_apply_Q",
     "sipx_stream",
     "sipx_dev_rhs", "sipx_dev_x", "sipx_set_owned",
 ]
@@ -40,6 +40,7 @@ OPS = {"identity": 0, "D_x": 1, "D_y": 2, "D_z": 3, "TV": 4, "D2D": 4, "D3D": 4}
 PROJ = {"bounds": 0, "bounds_vec": 1, "l1": 2, "l2": 3, "annulus": 4, "cardinality": 5, "prox_l1": 6, "l1_dft": 7, "rank": 8}
 SPECIAL_OPERATORS = ("DFT", "DCT", "wavelet", "curvelet")     # src/setup_constraints.jl:54
 YL_FEAS, YL_BB, YL_FIRST = 1, 2, 4
+Q_MODES = {"cds": 0, "stencil": 1}
 
 
 class SipxError(RuntimeError):
@@ -138,6 +139,7 @@ class PARSDMM_options:
     parallel: bool = False
     zero_ini_guess: bool = True
     Minkowski: bool = False
+    Q_mode: str = "cds"     # engine extension (not a reference field): "cds" = the reference's banded Q, "stencil" = sipx_set_q_mode(SIPX_Q_STENCIL)
 
 
 def default_PARSDMM_options(options: PARSDMM_options, TF) -> PARSDMM_options:
@@ -418,6 +420,19 @@ class Context:
         self.rows.append(int(r.value))
         return rc
 
+    def set_q_mode(self, mode: str):
+        if mode not in Q_MODES:
+            raise SipxError(f"unknown Q mode {mode!r} (cds | stencil)")
+        _chk(lib().sipx_set_q_mode(self.h, Q_MODES[mode]))
+
+    def apply_Q(self, x):
+        x = np.ascontiguousarray(x, self.TF)
+        if x.shape != (self.N,):
+            raise SipxError("length of x does not match the grid")
+        y = np.empty_like(x)
+        _chk(lib().sipx_apply_Q(self.h, _ptr(x), _ptr(y)))
+        return y
+
     def set_owned(self, owned: Sequence[int]):
         a = np.zeros(len(self.rows) + 1, np.int32)       # constraint sets + the distance term
         a[:len(owned)] = np.asarray(owned, np.int32)[:len(a)]
@@ -594,6 +609,7 @@ def build_context(m, AtA, TD_OP, set_Prop, P_sub, comp_grid, options, x=None, l=
             ctx.add_set(TD_OP[i], P_sub[i], set_Prop.ncvx[i], A, set_Prop.AtA_offsets[i] if A is not None else None)
         if owned is not None:
             ctx.set_owned(owned)
+        ctx.set_q_mode(getattr(options, "Q_mode", "cds"))
         rho_ini = [float(TF(r)) for r in options.rho_ini]                # convert_options!.jl:6-15
         feas0 = ctx.finalize(m, rho_ini, float(TF(options.gamma_ini)), options.feasibility_only,
                              options.zero_ini_guess, x, l, y)

@@ -466,3 +466,84 @@ def test_multilevel_matches_oracle(sipx, TF, n, h):
     assert err < (5e-4 if TF == np.float32 else 1e-6), err
     assert [len(v) for v in ys] == [len(v) for v in yo]
     assert list(os_.rho_ini) == [10.0] or np.allclose(os_.rho_ini, 10.0)          # restored (PARSDMM_multi_level.jl:87)
+
+
+# ---- stencil form of Q (sipx_set_q_mode(SIPX_Q_STENCIL)): rounding-level agreement with CDS --------
+@pytest.mark.parametrize("TF", [np.float32, np.float64])
+@pytest.mark.parametrize("n,h", GRIDS)
+def test_stencil_Q_matches_cds_Q(sipx, TF, n, h):
+    m = model(n, TF)
+    kinds = ["bounds", "l1:D_x", "l1:D_z", "l1:TV"]
+    gs, os_, Ps, As, props, AtAs = _problem(sipx, n, h, TF, kinds, m)
+    rho = [3.0, 0.5, 7.0, 11.0, 2.0]
+    os_.rho_ini = rho
+    x = np.random.default_rng(3).standard_normal(m.size).astype(TF)
+    out = {}
+    for mode in ("cds", "stencil"):
+        os_.Q_mode = mode
+        ctx = sipx.host.build_context(m, AtAs, As, props, Ps, gs, os_)
+        y0 = ctx.apply_Q(x)
+        ctx.q_update([3.0, 0.25, 7.0, 12.5, 1.0], rho)
+        out[mode] = (y0, ctx.apply_Q(x))
+        if mode == "stencil":
+            with pytest.raises(sipx.SipxError, match="stores no bands"):
+                ctx.get_Q()
+        ctx.close()
+    eps = np.finfo(TF).eps
+    for a, b in zip(out["cds"], out["stencil"]):
+        scale = np.abs(a).max()
+        assert np.abs(a.astype(np.float64) - b).max() <= 16 * eps * scale
+
+
+def test_stencil_Q_refuses_explicit_bands(sipx):
+    TF = np.float32
+    n, h = (16, 12), (1.0, 1.0)
+    m = model(n, TF)
+    go, oo, Po, Ao, propo, AtAo = _problem(O, n, h, TF, ["bounds", "l1:TV"], m)
+    gs, os_, Ps, As, props, AtAs = _problem(sipx, n, h, TF, ["bounds", "l1:TV"], m)
+    os_.Q_mode = "stencil"
+    with pytest.raises(sipx.SipxError, match="descriptor-generated"):
+        sipx.host.build_context(m, AtAo, As, propo, Ps, gs, os_)
+
+
+@pytest.mark.parametrize("TF", [np.float32, np.float64])
+@pytest.mark.parametrize("name,n,h,kinds", CASES[:4])
+def test_parsdmm_stencil_mode_matches_oracle(sipx, TF, name, n, h, kinds):
+    m = model(n, TF, seed=len(kinds))
+    kw = dict(maxit=60)
+    go, oo, Po, Ao, propo, AtAo = _problem(O, n, h, TF, kinds, m, kw)
+    gs, os_, Ps, As, props, AtAs = _problem(sipx, n, h, TF, kinds, m, kw)
+    os_.Q_mode = "stencil"
+    xo, lo, _, _ = O.PARSDMM(m.copy(), AtAo, Ao, propo, Po, go, oo)
+    xs, ls, _, _ = sipx.PARSDMM(m.copy(), AtAs, As, props, Ps, gs, os_)
+    K = min(4, len(lo.obj), len(ls.obj))
+    rt = 1e-3 if TF == np.float32 else 1e-7
+    for f in ("obj", "r_pri_total", "rho"):
+        a, b = np.asarray(getattr(ls, f))[:K], np.asarray(getattr(lo, f))[:K]
+        assert np.allclose(a, b, rtol=rt, atol=1e-12), (f, a, b)
+    err = np.linalg.norm(xs.astype(np.float64) - xo) / np.linalg.norm(xo)
+    assert err < (5e-4 if TF == np.float32 else 1e-6), err
+
+
+def test_stencil_mode_agrees_with_cds_mode_when_every_block_has_work(sipx):
+    # 128^3 / 4 = 2048 * 256 vectors: every block of the widest launch is active, so the CG partial sums of the two
+    # modes must cover the same block range (regression: a 2048-block producer next to 1792-block producers)
+    TF, n, h = np.float32, (128, 128, 128), (25.0, 25.0, 25.0)
+    m = model(n, TF, seed=2)
+    rows = {}
+    for mode in ("cds", "stencil"):
+        g = sipx.compgrid(h, n)
+        c = [sipx.set_definitions("bounds", "identity", 1600.0, 3900.0, ("matrix", ""))]
+        for k in ("D_x", "D_z"):
+            s = sipx.get_TD_operator(g, k, TF)[0] @ m
+            c.append(sipx.set_definitions("l1", k, 0.0, float(0.5 * np.abs(s.astype(np.float64)).sum()), ("matrix", "")))
+        P, A, prop = sipx.setup_constraints(c, g, TF)
+        opt = sipx.PARSDMM_options(FL=TF, maxit=12)
+        opt.Q_mode = mode
+        A, AtA, l, y = sipx.PARSDMM_precompute_distribute(A, prop, g, opt)
+        x, log, _, _ = sipx.PARSDMM(m.copy(), AtA, A, prop, P, g, opt)
+        rows[mode] = (x, log)
+    (xc, lc), (xs, ls) = rows["cds"], rows["stencil"]
+    assert np.isfinite(ls.obj).all() and ls.cg_it.max() < 50
+    assert np.array_equal(lc.cg_it, ls.cg_it)
+    assert np.linalg.norm(xc.astype(np.float64) - xs) / np.linalg.norm(xc.astype(np.float64)) < 1e-4
