@@ -83,6 +83,15 @@ def interpolate_y_l(l, y, set_Prop_levels, comp_grid_levels, dim3, i):
     return l, y
 
 
+def _carry_rho(options, log):
+    """options.rho_ini = log.rho[end, :] (PARSDMM_multi_level.jl:57,83).  DEVIATION: when a level returned through
+    the feasible-input exit (PARSDMM.jl:63-82) its one log row of rho is all zero and the reference would start the
+    next level with rho = 0 (Q = 0, 1/rho = Inf, NaN iterates); the previous rho_ini is kept instead."""
+    last = [float(v) for v in np.atleast_2d(log.rho)[-1, :]]
+    if all(v > 0 for v in last):
+        options.rho_ini = last
+
+
 def PARSDMM_multi_level(m, TD_OP_levels, AtA_levels, P_sub_levels, set_Prop_levels, comp_grid_levels, options,
                         device=None):
     n_levels = len(TD_OP_levels)
@@ -94,7 +103,7 @@ def PARSDMM_multi_level(m, TD_OP_levels, AtA_levels, P_sub_levels, set_Prop_leve
     options.zero_ini_guess = True
     x, log, l, y = host.PARSDMM(m_levels[i], AtA_levels[i], TD_OP_levels[i], set_Prop_levels[i], P_sub_levels[i],
                                 comp_grid_levels[i], options, device=device)
-    options.rho_ini = [float(v) for v in np.atleast_2d(log.rho)[-1, :]]
+    _carry_rho(options, log)
     for i in range(n_levels - 2, -1, -1):
         nc = tuple(int(v) for v in comp_grid_levels[i + 1].n)
         nf = tuple(int(v) for v in comp_grid_levels[i].n)
@@ -103,6 +112,6 @@ def PARSDMM_multi_level(m, TD_OP_levels, AtA_levels, P_sub_levels, set_Prop_leve
         options.zero_ini_guess = False
         x, log, l, y = host.PARSDMM(m_levels[i], AtA_levels[i], TD_OP_levels[i], set_Prop_levels[i], P_sub_levels[i],
                                     comp_grid_levels[i], options, x, l, y, device=device)
-        options.rho_ini = [float(v) for v in np.atleast_2d(log.rho)[-1, :]]
+        _carry_rho(options, log)
     options.rho_ini = rho_orig
     return x, log, l, y

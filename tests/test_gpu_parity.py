@@ -547,3 +547,25 @@ def test_stencil_mode_agrees_with_cds_mode_when_every_block_has_work(sipx):
     assert np.isfinite(ls.obj).all() and ls.cg_it.max() < 50
     assert np.array_equal(lc.cg_it, ls.cg_it)
     assert np.linalg.norm(xc.astype(np.float64) - xs) / np.linalg.norm(xc.astype(np.float64)) < 1e-4
+
+
+def test_multilevel_survives_a_feasible_coarse_level(sipx):
+    # a coarse level that is already feasible returns through the early exit with an all-zero rho log row
+    # (PARSDMM.jl:63-82); the next level must not start from rho = 0 (documented deviation in multilevel._carry_rho)
+    from sipx import multilevel as ML
+    TF, n, h = np.float64, (32, 32, 32), (25.0, 25.0, 25.0)
+    rng = np.random.default_rng(5)
+    m = (1500 + 2500 * np.linspace(0, 1, n[2])[None, None, :] + 150 * rng.standard_normal(n)).astype(TF).reshape(-1, order="F")
+    res = {}
+    for name, mod, ml in (("oracle", O, O), ("sipx", sipx, ML)):
+        g = mod.compgrid(h, n)
+        s = O.get_TD_operator(O.compgrid(h, n), "TV", TF)[0] @ m
+        c = [mod.set_definitions("bounds", "identity", 1600.0, 3900.0, ("tensor", "")),
+             mod.set_definitions("l1", "TV", 0.0, float(0.5 * np.abs(s).sum()), ("tensor", ""))]
+        opt = mod.PARSDMM_options(FL=TF, maxit=8)
+        L = ml.setup_multi_level_PARSDMM(m, 2, 2, g, c, opt)
+        x, log, _, _ = ml.PARSDMM_multi_level(m.copy(), *L[:5], opt)
+        res[name] = (x, log)
+    (xo, lo), (xs, ls) = res["oracle"], res["sipx"]
+    assert np.isfinite(xs).all() and (ls.rho[0] > 0).all() and ls.cg_it.max() < 100
+    assert np.linalg.norm(xs - xo) / np.linalg.norm(xo) < 1e-6
