@@ -37,30 +37,45 @@ enum { SIPX_F32 = 0, SIPX_F64 = 1 };
  * 2-D grids: D_x = dim 1, D_z = dim 2 (pass n3 = 1); TV = [D_z; D_x] (2-D), [D_z; D_y; D_x] (3-D). */
 enum { SIPX_OP_IDENTITY = 0, SIPX_OP_DX = 1, SIPX_OP_DY = 2, SIPX_OP_DZ = 3, SIPX_OP_TV = 4 };
 
-/* Projector descriptor replacing the opaque closure P_sub[i] (src/get_projector.jl:3-103),
- * "matrix"/"tensor" application mode. */
+/* Projector descriptor replacing the opaque closure P_sub[i] (src/get_projector.jl:3-103). */
 enum {
   SIPX_PROJ_BOUNDS      = 0, /* project_bounds!(x, LB, UB) scalar bounds  (projectors/project_bounds!.jl:3-12)  */
-  SIPX_PROJ_BOUNDS_VEC  = 1, /* per-element bounds lb/ub                  (projectors/project_bounds!.jl:14-25) */
+  SIPX_PROJ_BOUNDS_VEC  = 1, /* mode WHOLE: per-element bounds lb/ub TF[M_i]           (project_bounds!.jl:14-25);
+                                mode FIBER: per-fiber bounds lb/ub TF[TD_n[dir]]       (project_bounds!.jl:38-88) */
   SIPX_PROJ_L1          = 2, /* project_l1_Duchi!(x, pmax)                (projectors/project_l1_Duchi!.jl:21-52) */
   SIPX_PROJ_L2          = 3, /* project_l2!(x, pmax)                      (projectors/project_l2!.jl:3-16) */
   SIPX_PROJ_ANNULUS     = 4, /* project_annulus!(x, pmin, pmax)           (projectors/project_annulus!.jl:3-21) */
-  SIPX_PROJ_CARDINALITY = 5, /* project_cardinality!(x, k = pmax) vector  (projectors/project_cardinality!.jl:3-21) */
+  SIPX_PROJ_CARDINALITY = 5, /* project_cardinality!(x, k = pmax): whole vector, per fiber or per slice
+                                (projectors/project_cardinality!.jl:3-146) */
   SIPX_PROJ_PROX_L1     = 6, /* prox_l1!(x, pmax)                         (src/prox_l1!.jl:8-10) */
   SIPX_PROJ_L1_DFT      = 7, /* x -> Re(F' project_l1_Duchi!(F x, pmax)), F = unitary DFT; op must be identity
                                 (src/get_projector.jl:29-35 with TD_OP "DFT", src/get_TD_operator.jl:45-47,80-82) */
-  SIPX_PROJ_RANK        = 8  /* project_rank!(x, r = pmax): matrix (2-D grid) or every z-slice (3-D, reserved = 2)
-                                (projectors/project_rank!.jl:3-48); op must be identity */
+  SIPX_PROJ_RANK        = 8, /* project_rank!(x, r = pmax): matrix (2-D grid, mode WHOLE) or every slice orthogonal to dir
+                                (3-D, mode SLICE)   (projectors/project_rank!.jl:3-48) */
+  SIPX_PROJ_NUCLEAR     = 9, /* project_nuclear!(x, sigma = pmax), same modes as RANK (projectors/project_nuclear!.jl:3-62) */
+  SIPX_PROJ_HISTOGRAM   = 10,/* project_histogram_relaxed!(x, lb, ub): lb/ub ascending TF[M_i]
+                                (projectors/project_histogram_relaxed.jl:9-27) */
+  SIPX_PROJ_SUBSPACE    = 11 /* project_subspace!(x, A, orth): whole vector, fibers of a matrix (2-D) or slices of a
+                                tensor (3-D)  (projectors/project_subspace!.jl:10-125); op must be identity */
 };
+/* constraint.app_mode (set_definitions): ("matrix"|"tensor", _) = WHOLE, ("fiber", d), ("slice", d).
+ * dir is the 0-based array dimension: "x" = 0, "y" = 1, "z" = 2 on a 3-D grid, "z" = 1 on a 2-D grid. */
+enum { SIPX_MODE_WHOLE = 0, SIPX_MODE_FIBER = 1, SIPX_MODE_SLICE = 2 };
 
 typedef struct {
   int32_t op;        /* SIPX_OP_*   */
   int32_t proj;      /* SIPX_PROJ_* */
   double pmin, pmax; /* constraint[i].min / .max (set_definitions, src/SetIntersectionProjection.jl:142-149) */
-  const void* lb;    /* SIPX_PROJ_BOUNDS_VEC: host TF[M_i] (rows of A_i, reference order), else NULL */
+  const void* lb;    /* BOUNDS_VEC / HISTOGRAM: host TF vectors (see the kinds above), else NULL */
   const void* ub;
   int32_t ncvx;      /* set_Prop.ncvx[i] (src/setup_constraints.jl:89-97) */
-  int32_t reserved;  /* SIPX_PROJ_RANK on a 3-D grid: slice direction, 2 = ("slice","z") */
+  int32_t reserved;  /* 0 */
+  int32_t mode;      /* SIPX_MODE_* */
+  int32_t dir;       /* direction of the fibers / normal of the slices */
+  const void* basis; /* SUBSPACE: host TF[basis_rows x basis_cols], column-major (constraint.custom_TD_OP[1]) */
+  int64_t basis_rows;
+  int32_t basis_cols;
+  int32_t basis_orth;/* constraint.custom_TD_OP[2]: A'A = I */
 } sipx_set_desc;
 
 /* PARSDMM_options (src/SetIntersectionProjection.jl:110-128); Blas_active / parallel / FL /

@@ -460,17 +460,147 @@ def project_cardinality(x, k: int):
     return x
 
 
-def project_rank(x, r: int, n, mode=("matrix", "")):
-    """src/projectors/project_rank!.jl:3-48: matrix, or every z-slice of a tensor (mode (slice, z))."""
+def _slices(X, mode):
+    """Views of the slices of a tensor in the reference's order: (slice, x) -> X[i,:,:], y -> X[:,i,:], z -> X[:,:,i]."""
+    if mode[0] != "slice":
+        raise ValueError("mode[1] for rank / nuclear norm projections can only be: slice")
+    ax = {"x": 0, "y": 1, "z": 2}[mode[1]]
+    return [np.take(X, i, axis=ax) for i in range(X.shape[ax])], ax
+
+
+def _per_slice(x, n, mode, fun):
     TF = x.dtype.type
-    X = x.reshape(n, order="F")
-    slices = [X] if X.ndim == 2 else [X[:, :, i] for i in range(X.shape[2])]
-    if X.ndim == 3 and tuple(mode) != ("slice", "z"):
-        raise NotImplementedError("only (slice, z)")
-    for S in slices:
-        U, s, Vt = np.linalg.svd(S.astype(np.float64), full_matrices=False)
-        S[...] = ((U[:, :r] * s[:r]) @ Vt[:r, :]).astype(TF)
+    X = x.reshape(n, order="F").copy(order="F")
+    if X.ndim == 2:
+        X[...] = fun(X.astype(np.float64)).astype(TF)
+    else:
+        sl, ax = _slices(X, mode)
+        for i, S in enumerate(sl):
+            idx = [slice(None)] * 3
+            idx[ax] = i
+            X[tuple(idx)] = fun(S.astype(np.float64)).astype(TF)
     x[:] = X.reshape(-1, order="F")
+    return x
+
+
+def project_rank(x, r: int, n, mode=("matrix", "")):
+    """src/projectors/project_rank!.jl:3-48: matrix, or every x / y / z slice of a tensor."""
+    def trunc(S):
+        U, s, Vt = np.linalg.svd(S, full_matrices=False)
+        return (U[:, :r] * s[:r]) @ Vt[:r, :]
+    return _per_slice(x, n, mode, trunc)
+
+
+def project_nuclear(x, sigma, n, mode=("matrix", "")):
+    """src/projectors/project_nuclear!.jl:3-62: singular values projected onto the l1 ball of radius sigma."""
+    TF = x.dtype.type
+
+    def shrink(S):
+        U, s, Vt = np.linalg.svd(S, full_matrices=False)
+        if s.sum() <= float(sigma):
+            return S          # inside the ball: U*S*Vt is S up to rounding (project_nuclear!.jl:19-23); returned untouched
+        s = project_l1_Duchi(s.astype(TF), TF(sigma)).astype(np.float64)
+        return (U * s) @ Vt
+    return _per_slice(x, n, mode, shrink)
+
+
+def project_bounds_mode(x, LB, UB, n, mode):
+    """src/projectors/project_bounds!.jl:38-88: bounds per fiber; x is reshaped to n (= TD_n).
+    Note the order min(max(x, LB), UB) (the vector method clips with UB first)."""
+    X = x.reshape(n, order="F")
+    if mode[0] == "slice":
+        raise ValueError("bound constraints per slice of a tensor currently not implemented, yet...")
+    ax = {"x": 0, "y": 1, "z": X.ndim - 1}[mode[1]]
+    if X.ndim == 2 and mode[1] == "y":
+        raise ValueError("2-D models: fiber modes are x and z")
+    shp = [1] * X.ndim
+    shp[ax] = X.shape[ax]
+    L, U = np.asarray(LB).reshape(shp), np.asarray(UB).reshape(shp)
+    x[:] = np.minimum(np.maximum(X, L), U).reshape(-1, order="F")
+    return x
+
+
+def _card_cols(M, k):
+    """every column of M (segment-major copy): zero all but the k largest magnitudes, ties to the earlier index."""
+    L = M.shape[0]
+    if k >= L:
+        return M
+    order = np.argsort(-np.abs(M), axis=0, kind="stable")     # sortperm(by=abs, rev=true) is stable
+    drop = order[k:, :]
+    np.put_along_axis(M, drop, 0, axis=0)
+    return M
+
+
+def project_cardinality_mode(x, k: int, n, mode):
+    """src/projectors/project_cardinality!.jl:23-146: cardinality per fiber (2-D: x, z; 3-D: x, y, z) or per slice."""
+    X = x.reshape(n, order="F").copy(order="F")
+    if X.ndim == 2:
+        if mode[0] != "fiber" or mode[1] not in ("x", "z"):
+            raise ValueError("for 2D models, the mode of application for project_cardinality! needs to be (fiber,x) or (fiber,z)")
+        if mode[1] == "x":
+            X = _card_cols(X, k)
+        else:
+            X = _card_cols(np.ascontiguousarray(X.T), k).T
+    else:
+        n1, n2, n3 = X.shape
+        ax = {"x": 0, "y": 1, "z": 2}[mode[1]]
+        if mode[0] == "fiber":
+            Y = np.moveaxis(X, ax, 0).reshape(X.shape[ax], -1).copy()
+            Y = _card_cols(Y, k)
+            rest = [d for i, d in enumerate(X.shape) if i != ax]
+            X = np.moveaxis(Y.reshape([X.shape[ax]] + rest), 0, ax)
+        else:   # slice: permutedims [2,3,1] / [1,3,2] / identity, column-major reshape -> remaining dims, lower one fastest
+            perm = {0: (1, 2, 0), 1: (0, 2, 1), 2: (0, 1, 2)}[ax]
+            Y = np.transpose(X, perm)
+            shp = Y.shape
+            Y = _card_cols(Y.reshape(shp[0] * shp[1], shp[2], order="F").copy(), k)
+            X = np.transpose(Y.reshape(shp, order="F"), np.argsort(perm))
+    x[:] = np.asarray(X).reshape(-1, order="F")
+    return x
+
+
+def project_histogram_relaxed(x, LB, UB):
+    """src/projectors/project_histogram_relaxed.jl:9-27: j-th smallest entry clipped to [LB[j], UB[j]] (UB first)."""
+    idx = np.argsort(x, kind="stable")
+    v = x[idx]
+    v = np.maximum(LB, np.minimum(v, UB))
+    x[idx] = v
+    return x
+
+
+def project_subspace(x, A, orth: bool, n=None, mode=("matrix", "")):
+    """src/projectors/project_subspace!.jl:10-125 (float64 arithmetic, rounded once)."""
+    TF = x.dtype.type
+    A = np.asarray(A, np.float64)
+
+    def P(M):
+        t = A.T @ M
+        if not orth:
+            t = np.linalg.solve(A.T @ A, t)
+        return A @ t
+    if mode[0] in ("matrix", "tensor"):
+        x[:] = P(x.astype(np.float64)).astype(TF)
+        return x
+    X = x.reshape(n, order="F").astype(np.float64)
+    if X.ndim == 2:
+        if mode[0] == "slice":
+            raise ValueError("mode[1] for project_subspace! must be: fiber")
+        if mode[1] == "x":
+            X = P(X)
+        elif mode[1] == "z":
+            X = P(X.T).T
+        else:
+            raise ValueError("mode[2] for project_subspace! with 2D array input must be: x, or z")
+    else:
+        if mode[0] != "slice":
+            raise ValueError("for 3D models, the mode of application for project_subspace! needs to be (slice,x) or (slice,y) or (slice,z)")
+        ax = {"x": 0, "y": 1, "z": 2}[mode[1]]
+        perm = {0: (1, 2, 0), 1: (0, 2, 1), 2: (0, 1, 2)}[ax]
+        Y = np.transpose(X, perm)
+        shp = Y.shape
+        Y = P(Y.reshape(shp[0] * shp[1], shp[2], order="F"))
+        X = np.transpose(Y.reshape(shp, order="F"), np.argsort(perm))
+    x[:] = X.reshape(-1, order="F").astype(TF)
     return x
 
 
@@ -494,20 +624,36 @@ def project_l1_dft(x, b, n):
     return x
 
 
-def get_projector(constraint: set_definitions, TF, comp_grid=None) -> Callable:
-    """Banded-operator ("matrix"/"tensor" app_mode) branches of src/get_projector.jl:3-103."""
+def get_projector(constraint: set_definitions, TF, comp_grid=None, TD_n=None) -> Callable:
+    """src/get_projector.jl:3-103 for the banded operators (and the DFT-folded l1 ball)."""
     st = constraint.set_type
     n = tuple(int(v) for v in comp_grid.n) if comp_grid is not None else None
     if n is not None and len(n) == 3 and n[2] == 1:
         n = n[:2]
+    tdn = tuple(int(v) for v in TD_n) if TD_n is not None else n
+    mode = tuple(constraint.app_mode)
+    whole = mode[0] in ("matrix", "tensor")
     if constraint.TD_OP == "DFT" and st == "l1":
         return lambda x: project_l1_dft(x, constraint.max, n)
     if st == "rank":
-        return lambda x: project_rank(x, int(constraint.max), n, constraint.app_mode)
-    if constraint.app_mode[0] not in ("matrix", "tensor"):
-        raise NotImplementedError("fiber/slice app_modes are outside the round-1 scope")
+        return lambda x: project_rank(x, int(constraint.max), tdn, mode)
+    if st == "nuclear":
+        return lambda x: project_nuclear(x, constraint.max, tdn, mode)
+    if st == "subspace":
+        A, orth = constraint.custom_TD_OP
+        return lambda x: project_subspace(x, A, bool(orth), n, mode)
+    if st == "histogram":
+        return lambda x: project_histogram_relaxed(x, constraint.min, constraint.max)
     if st == "bounds":
-        return lambda x: project_bounds(x, constraint.min, constraint.max)
+        if whole:
+            return lambda x: project_bounds(x, constraint.min, constraint.max)
+        return lambda x: project_bounds_mode(x, constraint.min, constraint.max, tdn, mode)
+    if st == "cardinality":
+        if whole:
+            return lambda x: project_cardinality(x, int(constraint.max))
+        return lambda x: project_cardinality_mode(x, int(constraint.max), tdn, mode)
+    if not whole:
+        raise NotImplementedError(f"{st} with app_mode {mode}")
     if st == "prox_l1":
         return lambda x: prox_l1(x, constraint.max)
     if st == "l1":
@@ -516,8 +662,6 @@ def get_projector(constraint: set_definitions, TF, comp_grid=None) -> Callable:
         return lambda x: project_l2(x, constraint.max)
     if st == "annulus":
         return lambda x: project_annulus(x, constraint.min, constraint.max)
-    if st == "cardinality":
-        return lambda x: project_cardinality(x, int(constraint.max))
     raise NotImplementedError(st)
 
 
@@ -536,10 +680,14 @@ def setup_constraints(constraint: List[set_definitions], comp_grid, TF):
                 c.min, c.max = TF(c.min), TF(c.max)                     # :32-38
         else:
             c.min, c.max = np.asarray(c.min, TF), np.asarray(c.max, TF)   # :39-42
+        if c.set_type in ("nuclear", "rank") and c.app_mode[0] in ("matrix", "tensor") and len(comp_grid.n) == 3 \
+                and comp_grid.n[2] > 1:
+            raise ValueError("requested rank or nuclear norm constraints on a tensor, use mode=(slice,x) e.t.c. to "
+                             "define constraints per slice")                                  # :60-62
         if c.set_type in ("l1", "l2") and c.app_mode[0] in ("slice", "fiber"):
             raise ValueError("l1 and l2 constraints only available for matrix or tensor mode, currently")
         A, AtA_diag, dense, TD_n, banded = get_TD_operator(comp_grid, c.TD_OP, TF)
-        P_sub.append(get_projector(c, TF, comp_grid))
+        P_sub.append(get_projector(c, TF, comp_grid, TD_n))
         TD_OP.append(A)
         sp_.AtA_diag.append(AtA_diag); sp_.dense.append(dense); sp_.TD_n.append(TD_n)
         sp_.banded.append(banded); sp_.AtA_offsets.append(None)

@@ -102,8 +102,9 @@ struct SetState {
   T *y = nullptr, *l = nullptr, *dy = nullptr, *lh0 = nullptr, *y0 = nullptr, *s0 = nullptr, *l0 = nullptr;
   T *lb = nullptr, *ub = nullptr, *ata = nullptr;
   std::vector<void*> halo_allocs;   // bases of the vectors allocated with a front halo
-  int ext_kind = 0, slice_dir = 2;   // library-backed projector (DFT-folded l1, slice rank)
-  double ext_pmax = 0;
+  int ext_kind = 0;                  // projector acting on a materialised vector (ext_proj.h)
+  ExtSpec spec;
+  std::vector<T> host_basis;
   std::shared_ptr<ExtProj<T>> ext;
   ProjScalars<T>* ps = nullptr;    // scalars of prox_i (warm-started across iterations)
   ProjScalars<T>* psf = nullptr;   // scalars of the feasibility estimate P_i(A_i x)
@@ -157,37 +158,7 @@ class Engine : public EngineBase {
     if (finalized_) throw std::runtime_error("sipx_add_set after sipx_finalize");
     SetState<T> s;
     configure_op(s, d->op);
-    s.prox = d->proj;
-    s.ncvx = d->ncvx;
-    s.plo = (T)d->pmin;
-    s.phi = (T)d->pmax;
-    switch (d->proj) {
-      case SIPX_PROJ_BOUNDS:
-      case SIPX_PROJ_PROX_L1: break;
-      case SIPX_PROJ_BOUNDS_VEC:
-        if (!d->lb || !d->ub) throw std::runtime_error("per-element bounds need lb and ub");
-        s.host_lb.assign((const T*)d->lb, (const T*)d->lb + s.Mtrue);
-        s.host_ub.assign((const T*)d->ub, (const T*)d->ub + s.Mtrue);
-        break;
-      case SIPX_PROJ_L1:
-        if (!(d->pmax > 0)) throw std::runtime_error("Radius of L1 ball is negative");   // project_l1_Duchi!.jl:22
-        s.two_pass = true;
-        break;
-      case SIPX_PROJ_L2:
-      case SIPX_PROJ_ANNULUS: s.two_pass = true; break;
-      case SIPX_PROJ_CARDINALITY: s.two_pass = true; need_idx_ = true; break;
-      case SIPX_PROJ_L1_DFT:
-      case SIPX_PROJ_RANK:
-        if (d->op != SIPX_OP_IDENTITY)
-          throw std::runtime_error("DFT-l1 and rank projectors act in their own domain: TD_OP must be the identity");
-        if (d->proj == SIPX_PROJ_L1_DFT && !(d->pmax > 0)) throw std::runtime_error("Radius of L1 ball is negative");
-        s.ext_kind = d->proj == SIPX_PROJ_L1_DFT ? EXT_L1_DFT : EXT_RANK;
-        s.slice_dir = d->reserved;
-        s.ext_pmax = d->pmax;
-        need_ext_ = true;
-        break;
-      default: throw std::runtime_error("unknown projector kind");
-    }
+    configure_proj(s, d);
     if (ata_R) {
       if (d_i < 1 || d_i > 7) throw std::runtime_error("AtA band count out of range (1..7 bands per set)");
       s.ata_off.assign(ata_off, ata_off + d_i);
@@ -308,7 +279,15 @@ class Engine : public EngineBase {
       s.y = halloc(s.Mpad); s.l = halloc(s.Mpad);
       s.lh0 = dalloc<T>(s.Mpad); s.y0 = dalloc<T>(s.Mpad); s.s0 = dalloc<T>(s.Mpad); s.l0 = dalloc<T>(s.Mpad);
       if (!s.ident) s.dy = halloc(s.Mpad);
-      if (s.ext_kind) s.ext = std::make_shared<ExtProj<T>>(s.ext_kind, G_, ndim_, stream_, s.ext_pmax, s.slice_dir);
+      if (s.ext_kind) {
+        s.spec.lb = s.host_lb.empty() ? nullptr : s.host_lb.data();
+        s.spec.ub = s.host_ub.empty() ? nullptr : s.host_ub.data();
+        s.spec.basis = s.host_basis.empty() ? nullptr : s.host_basis.data();
+        s.ext = std::make_shared<ExtProj<T>>(s.spec, stream_);
+        if (s.ext_kind == EXT_HISTOGRAM) { s.host_lb.clear(); s.host_ub.clear(); }
+        s.host_basis.clear();
+        s.host_basis.shrink_to_fit();
+      }
       if (s.two_pass) {
         s.ps = dalloc<ProjScalars<T>>(1);
         s.psf = dalloc<ProjScalars<T>>(1);
@@ -738,21 +717,34 @@ class Engine : public EngineBase {
     SIPX_HIP(hipMemcpy(dv, v, len * sizeof(T), hipMemcpyHostToDevice));
     const int prox = d->proj;
     const T plo = (T)d->pmin, phi = (T)d->pmax;
-    if (prox == SIPX_PROJ_BOUNDS_VEC) {
+    if (prox == SIPX_PROJ_BOUNDS_VEC && d->mode == SIPX_MODE_WHOLE) {
+      if (!d->lb || !d->ub) throw std::runtime_error("per-element bounds need lb and ub");
       lb = dalloc<T>(len); ub = dalloc<T>(len);
       SIPX_HIP(hipMemcpy(lb, d->lb, len * sizeof(T), hipMemcpyHostToDevice));
       SIPX_HIP(hipMemcpy(ub, d->ub, len * sizeof(T), hipMemcpyHostToDevice));
     }
     if (prox == SIPX_PROJ_L1 && !(d->pmax > 0)) throw std::runtime_error("Radius of L1 ball is negative");
-    if (prox == SIPX_PROJ_L1_DFT || prox == SIPX_PROJ_RANK) {      // acts on the context grid
-      if (len != G_.N) throw std::runtime_error("DFT-l1 / rank projectors need a vector of the grid size");
-      {
-        ExtProj<T> ext(prox == SIPX_PROJ_L1_DFT ? EXT_L1_DFT : EXT_RANK, G_, ndim_, stream_, d->pmax, d->reserved);
+    if (d->mode != SIPX_MODE_WHOLE || prox == SIPX_PROJ_L1_DFT || prox >= SIPX_PROJ_RANK) {   // acts on the context grid
+      if (len != G_.N) throw std::runtime_error("this projector / application mode needs a vector of the grid size");
+      SetState<T> st;
+      configure_op(st, SIPX_OP_IDENTITY);
+      configure_proj(st, d);
+      if (st.ext_kind) {
+        st.spec.lb = st.host_lb.empty() ? nullptr : st.host_lb.data();
+        st.spec.ub = st.host_ub.empty() ? nullptr : st.host_ub.data();
+        st.spec.basis = st.host_basis.empty() ? nullptr : st.host_basis.data();
+        ExtProj<T> ext(st.spec, stream_);
         ext.project(dv, false, part, mp, dc);
-        SIPX_HIP(hipStreamSynchronize(stream_));
+      } else {                                   // per-fiber bounds, expanded by configure_proj
+        lb = dalloc<T>(len); ub = dalloc<T>(len);
+        SIPX_HIP(hipMemcpy(lb, st.host_lb.data(), len * sizeof(T), hipMemcpyHostToDevice));
+        SIPX_HIP(hipMemcpy(ub, st.host_ub.data(), len * sizeof(T), hipMemcpyHostToDevice));
+        proj_apply_grid<T>(stream_, g1, 0, nullptr, len, dv, st.prox, st.plo, st.phi, lb, ub, nullptr);
       }
+      SIPX_HIP(hipStreamSynchronize(stream_));
       SIPX_HIP(hipMemcpy(v, dv, len * sizeof(T), hipMemcpyDeviceToHost));
-      for (void* q : {(void*)dv, (void*)dc, (void*)part, (void*)mp, (void*)ps}) dfree(q);
+      for (void* q : {(void*)dv, (void*)dc, (void*)part, (void*)mp, (void*)ps, (void*)lb, (void*)ub})
+        if (q) dfree(q);
       return;
     }
     const bool two = prox == SIPX_PROJ_L1 || prox == SIPX_PROJ_L2 || prox == SIPX_PROJ_ANNULUS || prox == SIPX_PROJ_CARDINALITY;
@@ -761,7 +753,7 @@ class Engine : public EngineBase {
       K<T>::ps_init(stream_, ps, di);
       K<T>::proj_scalars_arr(stream_, len, dv, prox, plo, phi, ps, part, mp, dc, len);
     }
-    proj_apply_grid<T>(stream_, g1, 0, nullptr, len, dv, prox, plo, phi, lb, ub, two ? ps : nullptr);
+    proj_apply_grid<T>(stream_, g1, 0, nullptr, len, dv, prox, prox == SIPX_PROJ_BOUNDS_VEC ? T(0) : plo, phi, lb, ub, two ? ps : nullptr);
     SIPX_HIP(hipStreamSynchronize(stream_));
     SIPX_HIP(hipMemcpy(v, dv, len * sizeof(T), hipMemcpyDeviceToHost));
     for (void* q : {(void*)dv, (void*)dc, (void*)lb, (void*)ub, (void*)part, (void*)mp, (void*)ps, (void*)di})
@@ -854,6 +846,112 @@ class Engine : public EngineBase {
   void need_final() const {
     if (!finalized_) throw std::runtime_error("call sipx_finalize first");
     SIPX_HIP(hipSetDevice(device_));
+  }
+
+  // projector part of a set descriptor: validation (the reference's error messages) + routing
+  void configure_proj(SetState<T>& s, const sipx_set_desc* d) {
+    s.prox = d->proj;
+    s.ncvx = d->ncvx;
+    s.plo = (T)d->pmin;
+    s.phi = (T)d->pmax;
+    const int mode = d->mode, dir = d->dir;
+    if (mode != SIPX_MODE_WHOLE && mode != SIPX_MODE_FIBER && mode != SIPX_MODE_SLICE)
+      throw std::runtime_error("unknown application mode");
+    if (mode != SIPX_MODE_WHOLE) {
+      if (dir < 0 || dir >= ndim_) throw std::runtime_error("application mode: direction out of range for this grid");
+      if (s.nblk > 1) throw std::runtime_error("fiber / slice modes need an operator with one block (identity, D_x, D_y, D_z)");
+    }
+    auto ext = [&](int kind) {
+      if (s.nblk > 1) throw std::runtime_error("this projector needs an operator with one block (identity, D_x, D_y, D_z)");
+      s.ext_kind = kind;
+      s.spec.kind = kind;
+      s.spec.ndim = ndim_;
+      s.spec.G = G_;
+      for (int a = 0; a < 3; ++a) s.spec.dims[a] = G_.n[a];
+      if (s.nblk == 1) s.spec.dims[s.dir[0]] -= 1;           // TD_n of a difference operator (get_TD_operator.jl)
+      s.spec.mode = mode;
+      s.spec.dir = dir;
+      s.spec.pmin = d->pmin;
+      s.spec.pmax = d->pmax;
+      s.prox = PX_EXT;
+      need_ext_ = true;
+    };
+    switch (d->proj) {
+      case SIPX_PROJ_BOUNDS:
+        if (mode != SIPX_MODE_WHOLE) throw std::runtime_error("scalar bounds apply to the whole array (use per-fiber vectors)");
+        break;
+      case SIPX_PROJ_PROX_L1:
+        if (mode != SIPX_MODE_WHOLE) throw std::runtime_error("prox_l1 applies to the whole array");
+        break;
+      case SIPX_PROJ_BOUNDS_VEC:
+        if (!d->lb || !d->ub) throw std::runtime_error("per-element bounds need lb and ub");
+        if (mode == SIPX_MODE_SLICE)
+          throw std::runtime_error("bound constraints per slice of a tensor currently not implemented, yet...");   // project_bounds!.jl:83
+        if (mode == SIPX_MODE_FIBER) {      // bounds per fiber: expanded to one bound per row of A_i (reference order)
+          long long dims[3] = {G_.n[0], G_.n[1], G_.n[2]};
+          if (s.nblk == 1) dims[s.dir[0]] -= 1;
+          const T *LB = (const T*)d->lb, *UB = (const T*)d->ub;
+          s.host_lb.resize(s.Mtrue);
+          s.host_ub.resize(s.Mtrue);
+          long long r = 0;
+          for (long long k = 0; k < dims[2]; ++k)
+            for (long long j = 0; j < dims[1]; ++j)
+              for (long long i = 0; i < dims[0]; ++i, ++r) {
+                const long long c = dir == 0 ? i : (dir == 1 ? j : k);
+                s.host_lb[r] = LB[c];
+                s.host_ub[r] = UB[c];
+              }
+          s.plo = T(1);                       // min(max(x, LB), UB): the fiber methods clip with LB first (project_bounds!.jl:47,65)
+        } else {
+          s.host_lb.assign((const T*)d->lb, (const T*)d->lb + s.Mtrue);
+          s.host_ub.assign((const T*)d->ub, (const T*)d->ub + s.Mtrue);
+          s.plo = T(0);
+        }
+        break;
+      case SIPX_PROJ_L1:
+        if (mode != SIPX_MODE_WHOLE)
+          throw std::runtime_error("l1 and l2 constraints only available for matrix or tensor mode, currently");   // setup_constraints.jl:65-67
+        if (!(d->pmax > 0)) throw std::runtime_error("Radius of L1 ball is negative");   // project_l1_Duchi!.jl:22
+        s.two_pass = true;
+        break;
+      case SIPX_PROJ_L2:
+        if (mode != SIPX_MODE_WHOLE)
+          throw std::runtime_error("l1 and l2 constraints only available for matrix or tensor mode, currently");
+        s.two_pass = true;
+        break;
+      case SIPX_PROJ_ANNULUS:
+        if (mode != SIPX_MODE_WHOLE) throw std::runtime_error("annulus constraints apply to the whole array");
+        s.two_pass = true;
+        break;
+      case SIPX_PROJ_CARDINALITY:
+        if (mode == SIPX_MODE_WHOLE) { s.two_pass = true; need_idx_ = true; }
+        else ext(EXT_CARD_SEG);
+        break;
+      case SIPX_PROJ_L1_DFT:
+        if (d->op != SIPX_OP_IDENTITY || mode != SIPX_MODE_WHOLE)
+          throw std::runtime_error("the DFT-l1 projector acts in its own domain: TD_OP must be the identity, mode matrix/tensor");
+        if (!(d->pmax > 0)) throw std::runtime_error("Radius of L1 ball is negative");
+        ext(EXT_L1_DFT);
+        break;
+      case SIPX_PROJ_RANK: ext(EXT_RANK); break;
+      case SIPX_PROJ_NUCLEAR: ext(EXT_NUCLEAR); break;
+      case SIPX_PROJ_HISTOGRAM:
+        if (!d->lb || !d->ub) throw std::runtime_error("histogram constraints need sorted lb and ub vectors");
+        ext(EXT_HISTOGRAM);
+        s.host_lb.assign((const T*)d->lb, (const T*)d->lb + s.Mtrue);     // kept on the host until the ExtProj is built
+        s.host_ub.assign((const T*)d->ub, (const T*)d->ub + s.Mtrue);
+        break;
+      case SIPX_PROJ_SUBSPACE:
+        if (d->op != SIPX_OP_IDENTITY) throw std::runtime_error("subspace constraints act on the model itself: TD_OP must be the identity");
+        if (!d->basis || d->basis_cols < 1 || d->basis_rows < 1) throw std::runtime_error("subspace constraints need the matrix A");
+        ext(EXT_SUBSPACE);
+        s.host_basis.assign((const T*)d->basis, (const T*)d->basis + (size_t)d->basis_rows * d->basis_cols);
+        s.spec.basis_rows = d->basis_rows;
+        s.spec.basis_cols = d->basis_cols;
+        s.spec.basis_orth = d->basis_orth;
+        break;
+      default: throw std::runtime_error("unknown projector kind");
+    }
   }
 
   void configure_op(SetState<T>& s, int op) const {

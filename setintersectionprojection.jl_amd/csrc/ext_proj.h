@@ -1,10 +1,27 @@
-// Projectors backed by a library transform (hipFFT / rocSOLVER); see ext_proj.hip.
+// Projectors that act on a materialised vector v (one block of the padded layout): library transforms
+// (hipFFT / rocSOLVER / rocBLAS / hipCUB sort) and the per-fiber / per-slice selections; see ext_proj.hip.
 #pragma once
 #include "sipx_common.h"
 
 namespace sipx {
 
-enum { EXT_L1_DFT = 1, EXT_RANK = 2 };
+enum { EXT_L1_DFT = 1, EXT_RANK = 2, EXT_NUCLEAR = 3, EXT_CARD_SEG = 4, EXT_HISTOGRAM = 5, EXT_SUBSPACE = 6 };
+
+// What an ExtProj acts on: the valid extents `dims` (TD_n of the operator) inside the padded grid G (strides G.st),
+// split into segments by the application mode (whole array, fibers along `dir`, slices orthogonal to `dir`).
+struct ExtSpec {
+  int kind = 0;
+  int ndim = 3;
+  Grid G;
+  long long dims[3] = {1, 1, 1};
+  int mode = 0, dir = 2;          // SIPX_MODE_*, 0-based direction
+  double pmin = 0, pmax = 0;
+  const void* lb = nullptr;       // EXT_HISTOGRAM: host TF[prod(dims)], ascending
+  const void* ub = nullptr;
+  const void* basis = nullptr;    // EXT_SUBSPACE: host TF[basis_rows x basis_cols], column-major
+  long long basis_rows = 0;
+  int basis_cols = 0, basis_orth = 0;
+};
 
 template <typename T>
 struct ExtImpl;
@@ -12,10 +29,10 @@ struct ExtImpl;
 template <typename T>
 class ExtProj {
  public:
-  ExtProj(int kind, const Grid& G, int ndim, hipStream_t stream, double pmax, int slice_dir);
+  ExtProj(const ExtSpec& spec, hipStream_t stream);
   ~ExtProj();
   ExtProj(const ExtProj&) = delete;
-  // v <- P(v) in place (N reals); feas selects the warm-start state of the feasibility estimate
+  // v <- P(v) in place (padded layout, G.N entries); feas selects the warm-start state of the feasibility estimate
   void project(T* v, bool feas, double* partials, T* maxpart, T* compact);
 
  private:

@@ -10,13 +10,17 @@
 //   slice / matrix rank  x[:,:,i] <- U_r S_r V_r'      reference: projectors/project_rank!.jl:3-48
 //       rocSOLVER batched SVD + rocBLAS batched GEMM: the one unit of the path that is not
 //       bandwidth bound, so it is a library call, not a hand-written kernel.
+#include <hipcub/hipcub.hpp>
 #include <hipfft/hipfft.h>
 #include <rocblas/rocblas.h>
 #include <rocsolver/rocsolver.h>
 
+#include <cmath>
 #include <stdexcept>
 #include <string>
+#include <vector>
 
+#include "../../include/sipx.h"
 #include "ext_proj.h"
 #include "sipx_device.h"
 
@@ -80,25 +84,198 @@ __global__ __launch_bounds__(BLOCK) void k_scale_cols(int m, int r, int ldu, lon
     U[b * strideU + (long long)j * ldu + i] *= S[b * strideS + j];
   }
 }
-// slice-wise widening / narrowing between the TF tensor (slice stride strideA) and a dense float64 batch
-template <typename T>
-__global__ __launch_bounds__(BLOCK) void k_widen(int m, int n, long long strideA, int batch, const T* __restrict__ v,
-                                                 double* __restrict__ A) {
-  const long long sA = (long long)m * n, tot = sA * batch;
+// ------------------------------------------------------------------------------------------------
+// Segments of the padded array: the whole valid block, its fibers along one direction, or its slices.
+// Element t of segment s lives at seg_addr(s, t); t runs in the reference's order (lower dimension fastest:
+// reshape / permutedims of project_cardinality!.jl:111-120, project_subspace!.jl:91-100, view(x,i,:,:) etc.).
+struct SegMap {
+  long long nseg, L;
+  long long SA, sSa, sSb;            // s -> (s % SA) * sSa + (s / SA) * sSb
+  long long LA, LB, sTa, sTb, sTc;   // t = ta + LA * (tb + LB * tc) -> ta * sTa + tb * sTb + tc * sTc
+};
+__device__ __forceinline__ long long seg_addr(const SegMap& m, long long s, long long t) {
+  const long long ta = t % m.LA, r = t / m.LA, tb = r % m.LB, tc = r / m.LB;
+  return (s % m.SA) * m.sSa + (s / m.SA) * m.sSb + ta * m.sTa + tb * m.sTb + tc * m.sTc;
+}
+static SegMap make_segmap(const ExtSpec& sp) {
+  SegMap m{};
+  const long long* d = sp.dims;
+  const long long* st = sp.G.st;
+  m.SA = 1; m.LA = 1; m.LB = 1;
+  if (sp.mode == SIPX_MODE_WHOLE) {
+    m.nseg = 1; m.L = d[0] * d[1] * d[2];
+    m.LA = d[0]; m.LB = d[1]; m.sTa = st[0]; m.sTb = st[1]; m.sTc = st[2];
+  } else {
+    const int dir = sp.dir;
+    if (dir < 0 || dir > 2) throw std::runtime_error("application mode: direction out of range");
+    const int a = dir == 0 ? 1 : 0, b = dir == 2 ? 1 : 2;
+    if (sp.mode == SIPX_MODE_FIBER) {
+      m.L = d[dir]; m.LA = d[dir]; m.sTa = st[dir];
+      m.SA = d[a]; m.sSa = st[a]; m.sSb = st[b]; m.nseg = d[a] * d[b];
+    } else if (sp.mode == SIPX_MODE_SLICE) {
+      m.LA = d[a]; m.LB = d[b]; m.sTa = st[a]; m.sTb = st[b]; m.L = d[a] * d[b];
+      m.SA = d[dir]; m.sSa = st[dir]; m.nseg = d[dir];
+    } else {
+      throw std::runtime_error("unknown application mode");
+    }
+  }
+  return m;
+}
+
+// dense[s * L + t] <- v[seg_addr(s, t)] and back (U = double for the SVD path, T otherwise).  `flag` (optional):
+// segments with flag[s] == 0 are left untouched by the scatter.
+template <typename T, typename U>
+__global__ __launch_bounds__(BLOCK) void k_seg_gather(SegMap m, const T* __restrict__ v, U* __restrict__ dense) {
+  const long long tot = m.nseg * m.L;
   for (long long e = (long long)blockIdx.x * BLOCK + threadIdx.x; e < tot; e += (long long)gridDim.x * BLOCK) {
-    const long long b = e / sA, r = e - b * sA;
-    A[e] = (double)v[b * strideA + r];
+    const long long s = e / m.L, t = e - s * m.L;
+    dense[e] = (U)v[seg_addr(m, s, t)];
+  }
+}
+template <typename T, typename U>
+__global__ __launch_bounds__(BLOCK) void k_seg_scatter(SegMap m, const U* __restrict__ dense, T* __restrict__ v,
+                                                       const int* __restrict__ flag) {
+  const long long tot = m.nseg * m.L;
+  for (long long e = (long long)blockIdx.x * BLOCK + threadIdx.x; e < tot; e += (long long)gridDim.x * BLOCK) {
+    const long long s = e / m.L, t = e - s * m.L;
+    if (flag && !flag[s]) continue;
+    v[seg_addr(m, s, t)] = (T)dense[e];
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Cardinality per segment (project_cardinality!.jl:23-146): keep the k entries of largest magnitude of every fiber /
+// slice, zero the rest; equal magnitudes keep the earlier entry (sortperm(by=abs, rev=true) is stable).
+// One workgroup per segment: radix select on the magnitude bit pattern (8 bits a pass, histogram in LDS),
+// then one ordered pass that resolves the tie cut with wave ballots.
+template <typename T> struct KeyOf;
+template <> struct KeyOf<float> { using U = unsigned int; };
+template <> struct KeyOf<double> { using U = unsigned long long; };
+__device__ __forceinline__ unsigned int abs_key(float v) { return __float_as_uint(v) & 0x7fffffffu; }
+__device__ __forceinline__ unsigned long long abs_key(double v) {
+  return (unsigned long long)__double_as_longlong(v) & 0x7fffffffffffffffull;
+}
+template <typename T>
+__global__ __launch_bounds__(BLOCK) void k_seg_card(SegMap m, T* __restrict__ v, long long k) {
+  using U = typename KeyOf<T>::U;
+  constexpr int BITS = (int)sizeof(U) * 8;
+  __shared__ unsigned int hist[256];
+  __shared__ U s_prefix;
+  __shared__ long long s_kk, s_run;
+  __shared__ unsigned int s_wtot[BLOCK / 64];
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  if (k >= m.L) return;                                   // sort_ind[k+1:end] is empty
+  for (long long s = blockIdx.x; s < m.nseg; s += gridDim.x) {
+    U prefix = 0, mask = 0;
+    long long kk = k;
+    if (k > 0) {
+      for (int shift = BITS - 8; shift >= 0; shift -= 8) {
+        hist[tid] = 0;                                    // BLOCK == 256 bins
+        __syncthreads();
+        for (long long t = tid; t < m.L; t += BLOCK) {
+          const U key = abs_key(v[seg_addr(m, s, t)]);
+          if ((key & mask) == prefix) atomicAdd(&hist[(unsigned)(key >> shift) & 255u], 1u);
+        }
+        __syncthreads();
+        if (tid == 0) {
+          long long cum = 0;
+          int b = 255;
+          for (; b > 0; --b) {
+            if (cum + hist[b] >= kk) break;
+            cum += hist[b];
+          }
+          s_prefix = prefix | ((U)b << shift);
+          s_kk = kk - cum;
+        }
+        __syncthreads();
+        prefix = s_prefix;
+        kk = s_kk;
+        mask |= (U)255 << shift;
+      }
+    }
+    // prefix = k-th largest magnitude, kk = how many entries equal to it survive (the earliest ones)
+    if (tid == 0) s_run = 0;
+    __syncthreads();
+    for (long long c0 = 0; c0 < m.L; c0 += BLOCK) {
+      const long long t = c0 + tid;
+      const bool live = t < m.L;
+      const long long addr = live ? seg_addr(m, s, t) : 0;
+      const U key = live ? abs_key(v[addr]) : 0;
+      const bool eq = live && k > 0 && key == prefix, gt = live && k > 0 && key > prefix;
+      const unsigned long long bal = __ballot(eq);
+      const unsigned rank = __popcll(bal & ((1ull << lane) - 1ull));
+      if (lane == 0) s_wtot[w] = (unsigned)__popcll(bal);
+      __syncthreads();
+      long long off = s_run;
+      for (int i = 0; i < w; ++i) off += s_wtot[i];
+      const bool keep = gt || (eq && off + rank < kk);
+      if (live && !keep) v[addr] = T(0);
+      __syncthreads();
+      if (tid == 0) {
+        long long tot = 0;
+        for (int i = 0; i < BLOCK / 64; ++i) tot += s_wtot[i];
+        s_run += tot;
+      }
+      __syncthreads();
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Singular values of every slice projected onto the l1 ball of radius sigma (project_nuclear!.jl:19-20,40-41 with
+// project_l1_Duchi!.jl:23,40-46 on the descending values).  flag[b] = 1 when slice b changed.
+__global__ void k_nuc_shrink(int kmin, int batch, double sigma, double* __restrict__ S, int* __restrict__ flag) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= batch) return;
+  double* s = S + (long long)b * kmin;
+  double sum = 0;
+  for (int j = 0; j < kmin; ++j) sum += s[j];
+  if (sum <= sigma) {                       // norm(v, 1) <= b && return v
+    flag[b] = 0;
+    return;
+  }
+  int rho = 0;
+  double cum = 0;
+  for (;;) {                                // while u[rho+1] > (sv[rho+1] - b)/(rho+1) && rho+1 < lv
+    const double nxt = cum + s[rho];
+    if (s[rho] > (nxt - sigma) / (double)(rho + 1) && rho + 1 < kmin) {
+      cum = nxt;
+      ++rho;
+    } else {
+      break;
+    }
+  }
+  if (rho == 0) { rho = 1; cum = s[0]; }    // rho = max(1, rho)
+  double theta = (cum - sigma) / (double)rho;
+  theta = theta > 0 ? theta : 0;
+  for (int j = 0; j < kmin; ++j) {
+    const double t = s[j] - theta;
+    s[j] = t > 0 ? t : 0;
+  }
+  flag[b] = 1;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Relaxed histogram (project_histogram_relaxed.jl:9-27): the j-th smallest entry is clipped to [LB[j], UB[j]].
+template <typename T>
+__global__ __launch_bounds__(BLOCK) void k_hist_gather(SegMap m, const T* __restrict__ v, T* __restrict__ keys,
+                                                       unsigned int* __restrict__ idx) {
+  for (long long t = (long long)blockIdx.x * BLOCK + threadIdx.x; t < m.L; t += (long long)gridDim.x * BLOCK) {
+    keys[t] = v[seg_addr(m, 0, t)];
+    idx[t] = (unsigned int)t;
   }
 }
 template <typename T>
-__global__ __launch_bounds__(BLOCK) void k_narrow(int m, int n, long long strideA, int batch, const double* __restrict__ A,
-                                                  T* __restrict__ v) {
-  const long long sA = (long long)m * n, tot = sA * batch;
-  for (long long e = (long long)blockIdx.x * BLOCK + threadIdx.x; e < tot; e += (long long)gridDim.x * BLOCK) {
-    const long long b = e / sA, r = e - b * sA;
-    v[b * strideA + r] = (T)A[e];
+__global__ __launch_bounds__(BLOCK) void k_hist_apply(SegMap m, const T* __restrict__ keys, const unsigned int* __restrict__ idx,
+                                                      const T* __restrict__ lb, const T* __restrict__ ub, T* __restrict__ v) {
+  for (long long j = (long long)blockIdx.x * BLOCK + threadIdx.x; j < m.L; j += (long long)gridDim.x * BLOCK) {
+    T x = keys[j];
+    x = x < ub[j] ? x : ub[j];              // min(x, UB) first, then max(LB, x)
+    x = lb[j] > x ? lb[j] : x;
+    v[seg_addr(m, 0, (long long)idx[j])] = x;
   }
 }
+
 // sum (a-b)^2 and sum b^2 into partial slots 0,1
 template <typename T>
 __global__ __launch_bounds__(BLOCK) void k_dist2(long long N, const T* __restrict__ a, const T* __restrict__ b,
@@ -120,10 +297,10 @@ void ext_dist2(hipStream_t s, long long N, const T* projected, const T* original
 // ------------------------------------------------------------------------------------------------
 template <typename T>
 struct ExtImpl {
-  int kind = 0;
-  Grid G;
-  int ndim = 3;
+  ExtSpec sp;
+  SegMap map{};
   hipStream_t stream = nullptr;
+  std::vector<void*> owned;       // device allocations
   // DFT
   hipfftHandle plan = 0;
   bool have_plan = false;
@@ -131,12 +308,28 @@ struct ExtImpl {
   T* mag = nullptr;
   ProjScalars<T>*ps = nullptr, *psf = nullptr;
   T radius_raw = 0;
-  // rank
+  // rank / nuclear
   rocblas_handle blas = nullptr;
   int r = 0, m = 0, n = 0, batch = 1;
-  long long strideA = 0;
   double *Ad = nullptr, *Ud = nullptr, *Sd = nullptr, *Vd = nullptr, *Ed = nullptr;
   rocblas_int* info = nullptr;
+  int* flag = nullptr;
+  // histogram
+  T *keys_in = nullptr, *keys_out = nullptr, *lb = nullptr, *ub = nullptr;
+  unsigned int *idx_in = nullptr, *idx_out = nullptr;
+  void* sort_tmp = nullptr;
+  size_t sort_bytes = 0;
+  // subspace
+  T *basis = nullptr, *gram_inv = nullptr, *X = nullptr, *t1 = nullptr, *t2 = nullptr;
+  int cols = 0;
+
+  template <typename Q>
+  Q* alloc(size_t count) {
+    void* p = nullptr;
+    SIPX_HIP(hipMalloc(&p, sizeof(Q) * (count ? count : 1)));
+    owned.push_back(p);
+    return (Q*)p;
+  }
 };
 
 static void fft_check(hipfftResult r, const char* what) {
@@ -146,67 +339,180 @@ static void blas_check(rocblas_status r, const char* what) {
   if (r != rocblas_status_success) throw std::runtime_error(std::string("rocBLAS/rocSOLVER: ") + what + " failed (" + std::to_string((int)r) + ")");
 }
 
+// inverse of the r x r Gram matrix A'A in float64 (Gauss-Jordan, partial pivoting); A is L x r column-major
 template <typename T>
-ExtProj<T>::ExtProj(int kind, const Grid& G, int ndim, hipStream_t stream, double pmax, int slice_dir) {
+static std::vector<double> gram_inverse(const T* A, long long L, int r) {
+  std::vector<double> G((size_t)r * r, 0.0), I((size_t)r * r, 0.0);
+  for (int i = 0; i < r; ++i)
+    for (int j = i; j < r; ++j) {
+      double acc = 0;
+      const T *ai = A + (size_t)i * L, *aj = A + (size_t)j * L;
+      for (long long k = 0; k < L; ++k) acc += (double)ai[k] * (double)aj[k];
+      G[(size_t)i * r + j] = G[(size_t)j * r + i] = acc;
+    }
+  for (int i = 0; i < r; ++i) I[(size_t)i * r + i] = 1.0;
+  for (int c = 0; c < r; ++c) {
+    int piv = c;
+    for (int i = c + 1; i < r; ++i)
+      if (std::fabs(G[(size_t)i * r + c]) > std::fabs(G[(size_t)piv * r + c])) piv = i;
+    if (G[(size_t)piv * r + c] == 0.0) throw std::runtime_error("subspace: the columns of A are linearly dependent");
+    if (piv != c)
+      for (int j = 0; j < r; ++j) {
+        std::swap(G[(size_t)piv * r + j], G[(size_t)c * r + j]);
+        std::swap(I[(size_t)piv * r + j], I[(size_t)c * r + j]);
+      }
+    const double d = 1.0 / G[(size_t)c * r + c];
+    for (int j = 0; j < r; ++j) { G[(size_t)c * r + j] *= d; I[(size_t)c * r + j] *= d; }
+    for (int i = 0; i < r; ++i) {
+      if (i == c) continue;
+      const double f = G[(size_t)i * r + c];
+      if (f == 0.0) continue;
+      for (int j = 0; j < r; ++j) { G[(size_t)i * r + j] -= f * G[(size_t)c * r + j]; I[(size_t)i * r + j] -= f * I[(size_t)c * r + j]; }
+    }
+  }
+  return I;     // symmetric: row- and column-major coincide up to rounding; used as column-major below
+}
+
+template <typename T>
+ExtProj<T>::ExtProj(const ExtSpec& spec, hipStream_t stream) {
   impl_ = new ExtImpl<T>();
   ExtImpl<T>& I = *impl_;
-  I.kind = kind;
-  I.G = G;
-  I.ndim = ndim;
+  try {
+  I.sp = spec;
   I.stream = stream;
+  const Grid& G = spec.G;
   const long long N = G.N;
+  const int kind = spec.kind;
   if (kind == EXT_L1_DFT) {
-    if (!(pmax > 0)) throw std::runtime_error("Radius of L1 ball is negative");
+    if (!(spec.pmax > 0)) throw std::runtime_error("Radius of L1 ball is negative");
     const hipfftType ty = sizeof(T) == 4 ? HIPFFT_C2C : HIPFFT_Z2Z;
-    if (ndim == 2) fft_check(hipfftPlan2d(&I.plan, (int)G.n[1], (int)G.n[0], ty), "plan2d");   // slowest dimension first
+    if (spec.ndim == 2) fft_check(hipfftPlan2d(&I.plan, (int)G.n[1], (int)G.n[0], ty), "plan2d");   // slowest dimension first
     else fft_check(hipfftPlan3d(&I.plan, (int)G.n[2], (int)G.n[1], (int)G.n[0], ty), "plan3d");
     I.have_plan = true;
     fft_check(hipfftSetStream(I.plan, stream), "set stream");
-    SIPX_HIP(hipMalloc(&I.z, sizeof(Cplx<T>) * N));
-    SIPX_HIP(hipMalloc(&I.mag, sizeof(T) * N));
-    SIPX_HIP(hipMalloc(&I.ps, sizeof(ProjScalars<T>)));
-    SIPX_HIP(hipMalloc(&I.psf, sizeof(ProjScalars<T>)));
+    I.z = I.template alloc<Cplx<T>>(N);
+    I.mag = I.template alloc<T>(N);
+    I.ps = I.template alloc<ProjScalars<T>>(1);
+    I.psf = I.template alloc<ProjScalars<T>>(1);
     K<T>::ps_init(stream, I.ps, nullptr);
     K<T>::ps_init(stream, I.psf, nullptr);
-    I.radius_raw = (T)(pmax * sqrt((double)N));       // ||F_unitary v||_1 <= b  <=>  ||FFT v||_1 <= b sqrt(N)
-  } else if (kind == EXT_RANK) {
-    I.r = (int)pmax;
-    if (ndim == 2) { I.m = (int)G.n[0]; I.n = (int)G.n[1]; I.batch = 1; I.strideA = N; }
-    else if (slice_dir == 2) { I.m = (int)G.n[0]; I.n = (int)G.n[1]; I.batch = (int)G.n[2]; I.strideA = G.n[0] * G.n[1]; }
-    else throw std::runtime_error("rank constraints: only matrices and (slice, z) of a tensor are built");
+    I.radius_raw = (T)(spec.pmax * sqrt((double)N));       // ||F_unitary v||_1 <= b  <=>  ||FFT v||_1 <= b sqrt(N)
+  } else if (kind == EXT_RANK || kind == EXT_NUCLEAR) {
+    ExtSpec sp = spec;
+    if (sp.mode == SIPX_MODE_WHOLE) {                      // a matrix: one "slice" orthogonal to the unit third dimension
+      if (sp.dims[2] != 1)
+        throw std::runtime_error("requested rank or nuclear norm constraints on a tensor, use mode=(slice,x) e.t.c. to "
+                                 "define constraints per slice");                       // setup_constraints.jl:60-62
+      sp.mode = SIPX_MODE_SLICE;
+      sp.dir = 2;
+    } else if (sp.mode != SIPX_MODE_SLICE) {
+      throw std::runtime_error("mode[1] for rank / nuclear norm projections can only be: slice");
+    }
+    I.map = make_segmap(sp);
+    I.m = (int)I.map.LA; I.n = (int)I.map.LB; I.batch = (int)I.map.nseg;
     const int k = I.m < I.n ? I.m : I.n;
-    if (I.r < 1 || I.r >= k) throw std::runtime_error("rank constraint needs 1 <= r < min(n1, n2)");
+    if (kind == EXT_RANK) {
+      I.r = (int)spec.pmax;
+      if (I.r < 1) throw std::runtime_error("rank constraint needs r >= 1");
+      if (I.r > k) I.r = k;                                // U[:,1:r] with r = min(n1,n2): the projection is the identity
+    } else if (!(spec.pmax > 0)) {
+      throw std::runtime_error("Radius of L1 ball is negative");                        // project_l1_Duchi!.jl:22 on F.S
+    }
     blas_check(rocblas_create_handle(&I.blas), "create handle");
     blas_check(rocblas_set_stream(I.blas, stream), "set stream");
-    SIPX_HIP(hipMalloc(&I.Ad, sizeof(double) * (size_t)I.m * I.n * I.batch));
-    SIPX_HIP(hipMalloc(&I.Ud, sizeof(double) * (size_t)I.m * k * I.batch));
-    SIPX_HIP(hipMalloc(&I.Vd, sizeof(double) * (size_t)k * I.n * I.batch));
-    SIPX_HIP(hipMalloc(&I.Sd, sizeof(double) * (size_t)k * I.batch));
-    SIPX_HIP(hipMalloc(&I.Ed, sizeof(double) * (size_t)I.batch));
-    SIPX_HIP(hipMalloc(&I.info, sizeof(rocblas_int) * 2 * I.batch));   // info + n_sweeps
+    I.Ad = I.template alloc<double>((size_t)I.m * I.n * I.batch);
+    I.Ud = I.template alloc<double>((size_t)I.m * k * I.batch);
+    I.Vd = I.template alloc<double>((size_t)k * I.n * I.batch);
+    I.Sd = I.template alloc<double>((size_t)k * I.batch);
+    I.Ed = I.template alloc<double>((size_t)I.batch);
+    I.info = I.template alloc<rocblas_int>((size_t)2 * I.batch);   // info + n_sweeps
+    I.flag = I.template alloc<int>((size_t)I.batch);
+  } else if (kind == EXT_CARD_SEG) {
+    if (spec.mode != SIPX_MODE_FIBER && spec.mode != SIPX_MODE_SLICE)
+      throw std::runtime_error("segmented cardinality needs a fiber or slice mode");
+    if (spec.ndim == 2 && spec.mode != SIPX_MODE_FIBER)
+      throw std::runtime_error("for 2D models, the mode of application for project_cardinality! needs to be (fiber,x) or "
+                               "(fiber,z). Or, provide the model as a vector");       // project_cardinality!.jl:57
+    if (spec.pmax < 0) throw std::runtime_error("cardinality must be non-negative");
+    I.map = make_segmap(spec);
+  } else if (kind == EXT_HISTOGRAM) {
+    if (spec.mode != SIPX_MODE_WHOLE) throw std::runtime_error("histogram constraints act on the whole vector");
+    if (!spec.lb || !spec.ub) throw std::runtime_error("histogram constraints need sorted lb and ub vectors");
+    I.map = make_segmap(spec);
+    const long long M = I.map.L;
+    I.keys_in = I.template alloc<T>(M); I.keys_out = I.template alloc<T>(M);
+    I.idx_in = I.template alloc<unsigned int>(M); I.idx_out = I.template alloc<unsigned int>(M);
+    I.lb = I.template alloc<T>(M); I.ub = I.template alloc<T>(M);
+    SIPX_HIP(hipMemcpy(I.lb, spec.lb, sizeof(T) * M, hipMemcpyHostToDevice));
+    SIPX_HIP(hipMemcpy(I.ub, spec.ub, sizeof(T) * M, hipMemcpyHostToDevice));
+    SIPX_HIP(hipcub::DeviceRadixSort::SortPairs(nullptr, I.sort_bytes, I.keys_in, I.keys_out, I.idx_in, I.idx_out, (int)M, 0,
+                                                (int)sizeof(T) * 8, stream));
+    I.sort_tmp = I.template alloc<char>(I.sort_bytes);
+  } else if (kind == EXT_SUBSPACE) {
+    ExtSpec sp = spec;
+    if (spec.ndim == 2 && spec.mode == SIPX_MODE_SLICE) throw std::runtime_error("mode[1] for project_subspace! must be: fiber");
+    if (spec.ndim == 3 && spec.mode == SIPX_MODE_FIBER)
+      throw std::runtime_error("for 3D models, the mode of application for project_subspace! needs to be (slice,x) or "
+                               "(slice,y) or (slice,z)");                              // project_subspace!.jl:121
+    I.map = make_segmap(sp);
+    if (!spec.basis || spec.basis_cols < 1) throw std::runtime_error("subspace constraints need the matrix A");
+    if (spec.basis_rows != I.map.L) throw std::runtime_error("subspace: rows of A do not match the length of what it projects");
+    I.cols = spec.basis_cols;
+    const long long L = I.map.L;
+    I.basis = I.template alloc<T>((size_t)L * I.cols);
+    SIPX_HIP(hipMemcpy(I.basis, spec.basis, sizeof(T) * (size_t)L * I.cols, hipMemcpyHostToDevice));
+    if (!spec.basis_orth) {
+      std::vector<double> Gi = gram_inverse<T>((const T*)spec.basis, L, I.cols);
+      std::vector<T> Gt(Gi.begin(), Gi.end());
+      I.gram_inv = I.template alloc<T>((size_t)I.cols * I.cols);
+      SIPX_HIP(hipMemcpy(I.gram_inv, Gt.data(), sizeof(T) * Gt.size(), hipMemcpyHostToDevice));
+    }
+    I.X = I.template alloc<T>((size_t)L * I.map.nseg);
+    I.t1 = I.template alloc<T>((size_t)I.cols * I.map.nseg);
+    I.t2 = I.template alloc<T>((size_t)I.cols * I.map.nseg);
+    blas_check(rocblas_create_handle(&I.blas), "create handle");
+    blas_check(rocblas_set_stream(I.blas, stream), "set stream");
   } else {
     throw std::runtime_error("unknown external projector");
+  }
+  } catch (...) {
+    this->~ExtProj();
+    impl_ = nullptr;
+    throw;
   }
 }
 
 template <typename T>
 ExtProj<T>::~ExtProj() {
+  if (!impl_) return;
   ExtImpl<T>& I = *impl_;
   if (I.have_plan) (void)hipfftDestroy(I.plan);
   if (I.blas) (void)rocblas_destroy_handle(I.blas);
-  for (void* p : {(void*)I.z, (void*)I.mag, (void*)I.ps, (void*)I.psf, (void*)I.Ad, (void*)I.Ud, (void*)I.Sd, (void*)I.Vd, (void*)I.Ed,
-                  (void*)I.info})
+  for (void* p : I.owned)
     if (p) (void)hipFree(p);
   delete impl_;
+  impl_ = nullptr;
+}
+
+static rocblas_status gemm_T(rocblas_handle h, rocblas_operation ta, rocblas_operation tb, int m, int n, int k, const float* A,
+                             int lda, const float* B, int ldb, float* C, int ldc) {
+  const float one = 1.f, zero = 0.f;
+  return rocblas_sgemm(h, ta, tb, m, n, k, &one, A, lda, B, ldb, &zero, C, ldc);
+}
+static rocblas_status gemm_T(rocblas_handle h, rocblas_operation ta, rocblas_operation tb, int m, int n, int k, const double* A,
+                             int lda, const double* B, int ldb, double* C, int ldc) {
+  const double one = 1.0, zero = 0.0;
+  return rocblas_dgemm(h, ta, tb, m, n, k, &one, A, lda, B, ldb, &zero, C, ldc);
 }
 
 // v <- P(v) in place.  `feas` selects the independent warm-start state used for the feasibility estimate.
 template <typename T>
 void ExtProj<T>::project(T* v, bool feas, double* partials, T* maxpart, T* compact) {
   ExtImpl<T>& I = *impl_;
-  const long long N = I.G.N;
+  const long long N = I.sp.G.N;
   hipStream_t s = I.stream;
-  if (I.kind == EXT_L1_DFT) {
+  const int kind = I.sp.kind;
+  if (kind == EXT_L1_DFT) {
     ProjScalars<T>* ps = feas ? I.psf : I.ps;
     hipLaunchKernelGGL((k_pack<T>), dim3(NB), dim3(BLOCK), 0, s, N, v, I.z);
     if (sizeof(T) == 4) fft_check(hipfftExecC2C(I.plan, (hipfftComplex*)I.z, (hipfftComplex*)I.z, HIPFFT_FORWARD), "forward");
@@ -217,28 +523,53 @@ void ExtProj<T>::project(T* v, bool feas, double* partials, T* maxpart, T* compa
     if (sizeof(T) == 4) fft_check(hipfftExecC2C(I.plan, (hipfftComplex*)I.z, (hipfftComplex*)I.z, HIPFFT_BACKWARD), "inverse");
     else fft_check(hipfftExecZ2Z(I.plan, (hipfftDoubleComplex*)I.z, (hipfftDoubleComplex*)I.z, HIPFFT_BACKWARD), "inverse");
     hipLaunchKernelGGL((k_unpack<T>), dim3(NB), dim3(BLOCK), 0, s, N, I.z, v, (T)(1.0 / (double)N), ps);
-    SIPX_HIP(hipGetLastError());
-  } else {
+  } else if (kind == EXT_RANK || kind == EXT_NUCLEAR) {
     // Batched Jacobi SVD in float64 whatever TF is: rocSOLVER's gesvdj works on A'A (condition number squared), so
     // float32 input is widened first and the truncated product is rounded back once.  Measured ~2x faster than the
     // QR-iteration gesvd on 256 slices of 256x256 and as accurate as LAPACK on the float32 data.
     const int k = I.m < I.n ? I.m : I.n;
+    if (kind == EXT_RANK && I.r >= k) return;              // nothing to truncate
     const long long sU = (long long)I.m * k, sV = (long long)k * I.n, sA = (long long)I.m * I.n;
-    const long long tot = sA * I.batch;
-    hipLaunchKernelGGL((k_widen<T>), dim3(NB), dim3(BLOCK), 0, s, I.m, I.n, I.strideA, I.batch, v, I.Ad);
+    hipLaunchKernelGGL((k_seg_gather<T, double>), dim3(NB), dim3(BLOCK), 0, s, I.map, v, I.Ad);
     blas_check(rocsolver_dgesvdj_strided_batched(I.blas, rocblas_svect_singular, rocblas_svect_singular, I.m, I.n, I.Ad,
                                                  I.m, sA, 0.0, I.Ed, 100, I.info + I.batch, I.Sd, k, I.Ud, I.m, sU, I.Vd,
                                                  k, sV, I.info, I.batch),
                "gesvdj");
-    hipLaunchKernelGGL((k_scale_cols<double>), dim3(NB), dim3(BLOCK), 0, s, I.m, I.r, I.m, sU, (long long)k, I.batch, I.Ud, I.Sd);
+    int inner = I.r;
+    const int* flag = nullptr;
+    if (kind == EXT_NUCLEAR) {     // slices already inside the ball keep their values bit for bit (flag = 0)
+      hipLaunchKernelGGL(k_nuc_shrink, dim3((I.batch + 63) / 64), dim3(64), 0, s, k, I.batch, I.sp.pmax, I.Sd, I.flag);
+      inner = k;
+      flag = I.flag;
+    }
+    hipLaunchKernelGGL((k_scale_cols<double>), dim3(NB), dim3(BLOCK), 0, s, I.m, inner, I.m, sU, (long long)k, I.batch, I.Ud, I.Sd);
     const double one = 1.0, zero = 0.0;
-    blas_check(rocblas_dgemm_strided_batched(I.blas, rocblas_operation_none, rocblas_operation_none, I.m, I.n, I.r, &one,
+    blas_check(rocblas_dgemm_strided_batched(I.blas, rocblas_operation_none, rocblas_operation_none, I.m, I.n, inner, &one,
                                              I.Ud, I.m, sU, I.Vd, k, sV, &zero, I.Ad, I.m, sA, I.batch),
                "gemm");
-    hipLaunchKernelGGL((k_narrow<T>), dim3(NB), dim3(BLOCK), 0, s, I.m, I.n, I.strideA, I.batch, I.Ad, v);
-    (void)tot;
-    SIPX_HIP(hipGetLastError());
+    hipLaunchKernelGGL((k_seg_scatter<T, double>), dim3(NB), dim3(BLOCK), 0, s, I.map, I.Ad, v, flag);
+  } else if (kind == EXT_CARD_SEG) {
+    const long long nb = I.map.nseg < (long long)NB * 4 ? I.map.nseg : (long long)NB * 4;
+    hipLaunchKernelGGL((k_seg_card<T>), dim3((unsigned)nb), dim3(BLOCK), 0, s, I.map, v, (long long)I.sp.pmax);
+  } else if (kind == EXT_HISTOGRAM) {
+    const long long M = I.map.L;
+    hipLaunchKernelGGL((k_hist_gather<T>), dim3(NB), dim3(BLOCK), 0, s, I.map, v, I.keys_in, I.idx_in);
+    SIPX_HIP(hipcub::DeviceRadixSort::SortPairs(I.sort_tmp, I.sort_bytes, I.keys_in, I.keys_out, I.idx_in, I.idx_out, (int)M, 0,
+                                                (int)sizeof(T) * 8, s));
+    hipLaunchKernelGGL((k_hist_apply<T>), dim3(NB), dim3(BLOCK), 0, s, I.map, I.keys_out, I.idx_out, I.lb, I.ub, v);
+  } else if (kind == EXT_SUBSPACE) {       // x .= A*(A'*x)  or  A*((A'*A)\(A'*x))   project_subspace!.jl:15-19
+    const int L = (int)I.map.L, ns = (int)I.map.nseg, r = I.cols;
+    hipLaunchKernelGGL((k_seg_gather<T, T>), dim3(NB), dim3(BLOCK), 0, s, I.map, v, I.X);
+    blas_check(gemm_T(I.blas, rocblas_operation_transpose, rocblas_operation_none, r, ns, L, I.basis, L, I.X, L, I.t1, r), "gemm A'x");
+    T* t = I.t1;
+    if (I.gram_inv) {
+      blas_check(gemm_T(I.blas, rocblas_operation_none, rocblas_operation_none, r, ns, r, I.gram_inv, r, I.t1, r, I.t2, r), "gemm G t");
+      t = I.t2;
+    }
+    blas_check(gemm_T(I.blas, rocblas_operation_none, rocblas_operation_none, L, ns, r, I.basis, L, t, r, I.X, L), "gemm A t");
+    hipLaunchKernelGGL((k_seg_scatter<T, T>), dim3(NB), dim3(BLOCK), 0, s, I.map, I.X, v, (const int*)nullptr);
   }
+  SIPX_HIP(hipGetLastError());
 }
 
 template class ExtProj<float>;

@@ -26,7 +26,7 @@ enum { F_FEAS = 1, F_BB = 2, F_FIRST = 4, F_NOSPEC = 8 /* rho/gamma just changed
 
 // internal prox kinds (public SIPX_PROJ_* plus the distance term)
 enum { PX_BOUNDS = 0, PX_BOUNDS_VEC = 1, PX_L1 = 2, PX_L2 = 3, PX_ANNULUS = 4, PX_CARD = 5, PX_PROX_L1 = 6,
-       PX_L1_DFT = 7, PX_RANK = 8,   // library-backed: y arrives precomputed (vsrc == 2)
+       PX_EXT = 8,                   // acts on a materialised vector (ext_proj.h): y arrives precomputed (vsrc == 2)
        PX_DIST = 100 };
 
 struct Grid {

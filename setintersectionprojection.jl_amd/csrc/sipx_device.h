@@ -302,8 +302,12 @@ __device__ __forceinline__ T prox_apply(const ProxCtx<T>& c, T v, T lb, T ub, T 
       T t = v < c.phi ? v : c.phi;
       return c.plo > t ? c.plo : t;
     }
-    case PX_BOUNDS_VEC: {                   // project_bounds!.jl:21-22
-      T t = v < ub ? v : ub;
+    case PX_BOUNDS_VEC: {
+      if (c.plo != T(0)) {                  // per-fiber bounds: min(max(x, LB), UB)    project_bounds!.jl:47,51,65
+        T t = v > lb ? v : lb;
+        return t < ub ? t : ub;
+      }
+      T t = v < ub ? v : ub;                // project_bounds!.jl:21-22
       return lb > t ? lb : t;
     }
     case PX_DIST:                           // (x*rho + m) / (rho + 1.0): Float64 division  prox_l2s!.jl:4

@@ -37,7 +37,9 @@ EXPORTED_SYMBOLS = [
 
 SIPX_F32, SIPX_F64 = 0, 1
 OPS = {"identity": 0, "D_x": 1, "D_y": 2, "D_z": 3, "TV": 4, "D2D": 4, "D3D": 4}
-PROJ = {"bounds": 0, "bounds_vec": 1, "l1": 2, "l2": 3, "annulus": 4, "cardinality": 5, "prox_l1": 6, "l1_dft": 7, "rank": 8}
+PROJ = {"bounds": 0, "bounds_vec": 1, "l1": 2, "l2": 3, "annulus": 4, "cardinality": 5, "prox_l1": 6, "l1_dft": 7, "rank": 8,
+        "nuclear": 9, "histogram": 10, "subspace": 11}
+MODES = {"matrix": 0, "tensor": 0, "fiber": 1, "slice": 2}
 SPECIAL_OPERATORS = ("DFT", "DCT", "wavelet", "curvelet")     # src/setup_constraints.jl:54
 YL_FEAS, YL_BB, YL_FIRST = 1, 2, 4
 Q_MODES = {"cds": 0, "stencil": 1}
@@ -49,7 +51,9 @@ class SipxError(RuntimeError):
 
 class _SetDesc(C.Structure):
     _fields_ = [("op", C.c_int32), ("proj", C.c_int32), ("pmin", C.c_double), ("pmax", C.c_double),
-                ("lb", C.c_void_p), ("ub", C.c_void_p), ("ncvx", C.c_int32), ("reserved", C.c_int32)]
+                ("lb", C.c_void_p), ("ub", C.c_void_p), ("ncvx", C.c_int32), ("reserved", C.c_int32),
+                ("mode", C.c_int32), ("dir", C.c_int32), ("basis", C.c_void_p), ("basis_rows", C.c_int64),
+                ("basis_cols", C.c_int32), ("basis_orth", C.c_int32)]
 
 
 class _Options(C.Structure):
@@ -210,6 +214,7 @@ class TDOperator:
                             "get_TD_operator(comp_grid,TD_type,TF) for options")
         self.kind, self.comp_grid, self.TF, self.adjoint = kind, comp_grid, np.dtype(TF).type, adjoint
         n, _ = _grid(comp_grid)
+        self.n = n
         N = int(np.prod(n))
         if kind == "identity":
             rows = N
@@ -246,20 +251,27 @@ class Projector:
         self.TF = np.dtype(TF).type
         self.comp_grid = comp_grid
         st = constraint.set_type
-        if constraint.app_mode[0] not in ("matrix", "tensor") and st != "rank":
-            raise SipxError("fiber/slice application modes are not part of this engine yet")
-        self.lb = self.ub = None
+        n, _ = _grid(comp_grid)
+        am = tuple(constraint.app_mode)
+        if am[0] not in MODES:
+            raise SipxError(f"unknown application mode {am!r}")
+        self.mode, self.dir = MODES[am[0]], 0
+        if self.mode:
+            dirs = {"x": 0, "z": len(n) - 1} if len(n) == 2 else {"x": 0, "y": 1, "z": 2}
+            if am[1] not in dirs:
+                raise SipxError(f"application mode {am!r}: direction must be one of {sorted(dirs)} on this grid")
+            self.dir = dirs[am[1]]
+        self.lb = self.ub = self.basis = None
+        self.basis_orth = False
         self.pmin = self.pmax = 0.0
-        self.reserved = 0
         if constraint.TD_OP in SPECIAL_OPERATORS:
             if not (constraint.TD_OP == "DFT" and st == "l1"):
                 raise SipxError("of the orthogonal-transform sets only the l1 ball in the DFT domain is built")
             self.kind, self.pmax = "l1_dft", float(constraint.max)
         elif st == "rank":
-            n = tuple(int(v) for v in comp_grid.n)
-            if len(n) == 3 and n[2] > 1 and tuple(constraint.app_mode) != ("slice", "z"):
-                raise SipxError("rank constraints on a tensor: only mode (slice, z) is built")
-            self.kind, self.pmax, self.reserved = "rank", float(int(constraint.max)), 2
+            self.kind, self.pmax = "rank", float(int(constraint.max))
+        elif st == "nuclear":
+            self.kind, self.pmax = "nuclear", float(constraint.max)
         elif st == "bounds":
             if np.ndim(constraint.min) == 0:
                 self.kind, self.pmin, self.pmax = "bounds", float(constraint.min), float(constraint.max)
@@ -267,29 +279,63 @@ class Projector:
                 self.kind = "bounds_vec"
                 self.lb = np.ascontiguousarray(constraint.min, self.TF)
                 self.ub = np.ascontiguousarray(constraint.max, self.TF)
+        elif st == "histogram":
+            self.kind = "histogram"
+            self.lb = np.ascontiguousarray(constraint.min, self.TF)
+            self.ub = np.ascontiguousarray(constraint.max, self.TF)
+        elif st == "subspace":
+            A, orth = constraint.custom_TD_OP
+            self.kind = "subspace"
+            self.basis = np.asfortranarray(A, dtype=self.TF)
+            if self.basis.ndim != 2:
+                raise SipxError("subspace constraints need a matrix A in custom_TD_OP[0]")
+            self.basis_orth = bool(orth)
         elif st in ("l1", "l2", "prox_l1"):
             self.kind, self.pmax = st, float(constraint.max)
         elif st == "annulus":
             self.kind, self.pmin, self.pmax = st, float(constraint.min), float(constraint.max)
         elif st == "cardinality":
-            self.kind, self.pmax = st, float(constraint.max)
+            self.kind, self.pmax = st, float(int(constraint.max))
         else:
-            raise SipxError(f"set type {st!r} is outside the hot-path scope of this engine")
+            raise SipxError(f"set type {st!r} is not part of this engine")
+
+    def check_rows(self, op: "TDOperator"):
+        """Host-side shape checks of the vectors the descriptor points at (the engine reads them unchecked)."""
+        n = list(op.n)
+        if op.kind in ("D_x", "D_y", "D_z"):
+            n[{"D_x": 0, "D_y": 1, "D_z": len(n) - 1}[op.kind]] -= 1
+        rows = op.shape[0]
+        if self.kind == "bounds_vec":
+            if self.mode == MODES["slice"]:
+                raise SipxError("bound constraints per slice of a tensor currently not implemented, yet...")
+            want = n[self.dir] if self.mode == MODES["fiber"] else rows
+            if self.lb.shape != (want,) or self.ub.shape != (want,):
+                raise SipxError(f"bounds vectors need {want} entries for this operator / application mode")
+        if self.kind == "histogram" and (self.lb.shape != (rows,) or self.ub.shape != (rows,)):
+            raise SipxError(f"histogram bounds need {rows} sorted entries")
 
     def desc(self, op: str, ncvx: bool) -> _SetDesc:
         d = _SetDesc()
         d.op, d.proj = OPS[op], PROJ[self.kind]
         d.pmin, d.pmax = self.pmin, self.pmax
         d.lb, d.ub = _ptr(self.lb), _ptr(self.ub)
-        d.ncvx, d.reserved = int(bool(ncvx)), int(self.reserved)
+        d.ncvx, d.reserved = int(bool(ncvx)), 0
+        d.mode, d.dir = self.mode, self.dir
+        if self.basis is not None:
+            d.basis, d.basis_rows, d.basis_cols = _ptr(self.basis), self.basis.shape[0], self.basis.shape[1]
+            d.basis_orth = int(self.basis_orth)
         return d
 
     def __call__(self, v):
         if v.dtype.type != self.TF or not v.flags.c_contiguous:
             raise SipxError("projector input must be a contiguous vector of the working precision")
-        grid_kind = self.kind in ("l1_dft", "rank")
+        grid_kind = self.mode != 0 or self.kind in ("l1_dft", "rank", "nuclear", "histogram", "subspace")
         ctx = Context(self.comp_grid if grid_kind else compgrid((1.0, 1.0), (max(len(v), 1), 1)), self.TF)
         try:
+            if grid_kind:
+                self.check_rows(TDOperator("identity", self.comp_grid, self.TF))
+            elif self.kind == "bounds_vec" and (self.lb.shape != v.shape or self.ub.shape != v.shape):
+                raise SipxError("bounds vectors must match the projected vector")
             d = self.desc("identity", False)
             _chk(lib().sipx_project(ctx.h, C.byref(d), _ptr(v), C.c_int64(len(v))))
         finally:
@@ -405,6 +451,7 @@ class Context:
             pass
 
     def add_set(self, op: TDOperator, proj: Projector, ncvx=False, AtA=None, AtA_offsets=None) -> int:
+        proj.check_rows(op)
         d = proj.desc(op.kind, ncvx)
         self._keep.append(proj)
         if AtA is not None:

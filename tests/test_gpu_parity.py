@@ -94,6 +94,39 @@ def _problem(mod, n, h, TF, kinds, m, opt_kw=None):
         elif k == "l2":
             nm = float(np.linalg.norm(m.astype(np.float64)))
             c.append(mod.set_definitions("l2", "identity", 0.0, 0.9 * nm, ("matrix", "")))
+        elif k.startswith("cardf:"):          # cardf:<op>:<fiber|slice>:<dir>: keep 30% of every fiber / slice
+            _, opn, md, d = k.split(":")
+            tdn = O.get_TD_operator(O.compgrid(h, n), opn, TF)[3]
+            ax = {"x": 0, "y": 1, "z": len(n) - 1}[d]
+            L = tdn[ax] if md == "fiber" else int(np.prod(tdn)) // tdn[ax]
+            c.append(mod.set_definitions("cardinality", opn, 0, max(1, int(0.3 * L)), (md, d)))
+        elif k.startswith("nuc:"):            # nuclear norm of every slice (or of the 2-D model): half the mean value
+            d = k[4:]
+            X = m.astype(np.float64).reshape(n, order="F")
+            if len(n) == 2:
+                sig, mode = 0.5 * np.linalg.svd(X, compute_uv=False).sum(), ("matrix", "")
+            else:
+                ax = {"x": 0, "y": 1, "z": 2}[d]
+                sig = 0.5 * np.mean([np.linalg.svd(np.take(X, i, axis=ax), compute_uv=False).sum() for i in range(n[ax])])
+                mode = ("slice", d)
+            c.append(mod.set_definitions("nuclear", "identity", 0.0, float(sig), mode))
+        elif k == "hist":                     # relaxed histogram of the model: sorted values of a smoother model +- 50
+            ref = np.sort(0.5 * (m.astype(np.float64) + np.mean(m)))
+            c.append(mod.set_definitions("histogram", "identity", (ref - 50).astype(TF), (ref + 50).astype(TF), ("matrix", "")))
+        elif k.startswith("bndf:"):           # bounds per depth level (fiber along the last dimension)
+            d = k[5:]
+            ax = {"x": 0, "y": 1, "z": len(n) - 1}[d]
+            lo = np.linspace(1600.0, 2200.0, n[ax]).astype(TF)
+            c.append(mod.set_definitions("bounds", "identity", lo, (lo + 1500).astype(TF), ("fiber", d)))
+        elif k.startswith("sub:"):            # subspace spanned by 6 smooth vectors, per fiber (2-D) / slice (3-D)
+            d = k[4:]
+            ax = {"x": 0, "y": 1, "z": len(n) - 1}[d]
+            L = n[ax] if len(n) == 2 else int(np.prod(n)) // n[ax]
+            t = np.linspace(0, 1, L)
+            A = np.stack([np.cos(np.pi * q * t) for q in range(6)], axis=1).astype(TF)
+            sd = mod.set_definitions("subspace", "identity", 0, 0, ("fiber" if len(n) == 2 else "slice", d))
+            sd.custom_TD_OP = (A, False)
+            c.append(sd)
     P, A, prop = mod.setup_constraints(c, g, TF)
     A, AtA, l, y = mod.PARSDMM_precompute_distribute(A, prop, g, opt)
     return g, opt, P, A, prop, AtA
@@ -312,6 +345,13 @@ CASES = [
     ("3d-dft-l1", (16, 12, 8), (25.0, 25.0, 25.0), ["bounds", "l1dft"]),
     ("3d-slice-rank", (16, 12, 8), (25.0, 25.0, 25.0), ["bounds", "rank:3"]),
     ("2d-rank", (32, 24), (25.0, 6.0), ["bounds", "rank:4", "l1:TV"]),
+    ("3d-card-fiber-Dz", (16, 12, 8), (25.0, 25.0, 25.0), ["bounds", "cardf:D_z:fiber:x"]),
+    ("3d-card-slice-Dy", (16, 12, 8), (25.0, 25.0, 25.0), ["bounds", "cardf:D_y:slice:z"]),
+    ("3d-nuclear-slice-x", (16, 12, 8), (25.0, 25.0, 25.0), ["bounds", "nuc:x", "l1:D_z"]),
+    ("2d-nuclear", (32, 24), (25.0, 6.0), ["bounds", "nuc:"]),
+    ("3d-histogram-bounds-fiber", (16, 12, 8), (25.0, 25.0, 25.0), ["bndf:z", "hist"]),
+    ("2d-subspace", (32, 24), (25.0, 6.0), ["bounds", "sub:z"]),
+    ("3d-subspace-slice", (16, 12, 8), (25.0, 25.0, 25.0), ["bounds", "sub:x", "l1:D_z"]),
 ]
 
 
@@ -320,6 +360,8 @@ CASES = [
 def test_parsdmm_matches_oracle(sipx, TF, name, n, h, kinds):
     m = model(n, TF, seed=len(kinds))
     kw = dict(maxit=60)
+    if any(k.startswith("sub:") for k in kinds):
+        kw["feas_tol"] = 1e-3          # the smooth model is within the default 5e-2 of the subspace already
     go, oo, Po, Ao, propo, AtAo = _problem(O, n, h, TF, kinds, m, kw)
     gs, os_, Ps, As, props, AtAs = _problem(sipx, n, h, TF, kinds, m, kw)
     xo, lo, l_o, y_o = O.PARSDMM(m.copy(), AtAo, Ao, propo, Po, go, oo)
@@ -338,7 +380,12 @@ def test_parsdmm_matches_oracle(sipx, TF, name, n, h, kinds):
         np.allclose(ls.set_feasibility[0], lo.set_feasibility[0], rtol=rt)
     # solution level: the reference's own serial/parallel tolerance for Float32, tighter for Float64
     err = np.linalg.norm(xs.astype(np.float64) - xo) / np.linalg.norm(xo)
-    assert err < (5e-4 if TF == np.float32 else 1e-6), err
+    tol64 = 1e-6
+    if any(k.startswith("sub:") for k in kinds):
+        # once y lies in the subspace, P(s) - s is pure GEMM rounding noise and the BB ratios built from it differ between
+        # two correct implementations; the traces agree for the first iterations (above) and the solutions to 1e-3
+        tol64 = 1e-3
+    assert err < (5e-4 if TF == np.float32 else tol64), err
     # log bookkeeping (PARSDMM.jl:261-278)
     it = len(ls.obj)
     p = len(kinds) + 1
@@ -569,3 +616,116 @@ def test_multilevel_survives_a_feasible_coarse_level(sipx):
     (xo, lo), (xs, ls) = res["oracle"], res["sipx"]
     assert np.isfinite(xs).all() and (ls.rho[0] > 0).all() and ls.cg_it.max() < 100
     assert np.linalg.norm(xs - xo) / np.linalg.norm(xo) < 1e-6
+
+
+# ---- remaining get_projector branches: fiber / slice modes, nuclear, histogram, subspace ----------
+def _proj(sipx, st, n, TF, mn, mx, mode, custom=((), False)):
+    c = sipx.set_definitions(st, "identity", mn, mx, mode)
+    c.custom_TD_OP = custom
+    return sipx.host.Projector(c, sipx.compgrid(tuple(1.0 for _ in n), n), TF)
+
+
+@pytest.mark.parametrize("TF", [np.float32, np.float64])
+def test_cardinality_fiber_and_slice_modes(sipx, TF):
+    rng = np.random.default_rng(21)
+    cases = [((10, 12, 9), ("fiber", "x"), 7), ((10, 12, 9), ("fiber", "y"), 6), ((10, 12, 9), ("fiber", "z"), 4),
+             ((10, 12, 9), ("slice", "x"), 7), ((10, 12, 9), ("slice", "y"), 6), ((10, 12, 9), ("slice", "z"), 5),
+             ((50, 100), ("fiber", "x"), 7), ((50, 100), ("fiber", "z"), 11), ((300, 4), ("fiber", "x"), 290),
+             ((8, 6, 5), ("fiber", "x"), 0), ((8, 6, 5), ("fiber", "z"), 5), ((40, 40, 3), ("slice", "z"), 1000)]
+    for n, mode, k in cases:
+        v = rng.standard_normal(int(np.prod(n))).astype(TF)
+        v[rng.integers(0, v.size, v.size // 5)] = TF(0.5)          # plenty of exact ties
+        v[rng.integers(0, v.size, v.size // 5)] = TF(-0.5)
+        want = O.project_cardinality_mode(v.copy(), k, n, mode)
+        got = _proj(sipx, "cardinality", n, TF, 0, k, mode)(v.copy())
+        assert np.array_equal(got, want), (n, mode, k)
+
+
+@pytest.mark.parametrize("TF", [np.float32, np.float64])
+def test_bounds_fiber_modes(sipx, TF):
+    rng = np.random.default_rng(22)
+    for n, d in (((6, 5, 4), "x"), ((6, 5, 4), "y"), ((6, 5, 4), "z"), ((9, 7), "x"), ((9, 7), "z")):
+        ax = {"x": 0, "y": 1, "z": len(n) - 1}[d]
+        LB = (-rng.random(n[ax])).astype(TF); UB = rng.random(n[ax]).astype(TF)
+        v = (3 * rng.standard_normal(int(np.prod(n)))).astype(TF)
+        want = O.project_bounds_mode(v.copy(), LB, UB, n, ("fiber", d))
+        got = _proj(sipx, "bounds", n, TF, LB, UB, ("fiber", d))(v.copy())
+        assert np.array_equal(got, want), (n, d)
+    with pytest.raises(sipx.SipxError, match="per slice"):
+        _proj(sipx, "bounds", (6, 5, 4), TF, np.zeros(4, TF), np.ones(4, TF), ("slice", "z"))(np.zeros(120, TF))
+    with pytest.raises(sipx.SipxError, match="entries"):
+        _proj(sipx, "bounds", (6, 5, 4), TF, np.zeros(3, TF), np.ones(3, TF), ("fiber", "z"))(np.zeros(120, TF))
+
+
+@pytest.mark.parametrize("TF", [np.float32, np.float64])
+def test_rank_and_nuclear_slice_modes(sipx, TF):
+    rng = np.random.default_rng(23)
+    tol = 2e-5 if TF == np.float32 else 1e-11
+    n = (14, 12, 9)
+    for d, r in (("x", 7), ("y", 6), ("z", 5)):
+        v = rng.standard_normal(int(np.prod(n))).astype(TF)
+        want = O.project_rank(v.copy(), r, n, ("slice", d))
+        got = _proj(sipx, "rank", n, TF, 0, r, ("slice", d))(v.copy())
+        assert np.linalg.norm(got.astype(np.float64) - want) <= tol * np.linalg.norm(want), ("rank", d)
+        want = O.project_nuclear(v.copy(), TF(3.5), n, ("slice", d))
+        got = _proj(sipx, "nuclear", n, TF, 0.0, 3.5, ("slice", d))(v.copy())
+        assert np.linalg.norm(got.astype(np.float64) - want) <= tol * np.linalg.norm(want), ("nuclear", d)
+        ax = {"x": 0, "y": 1, "z": 2}[d]
+        G = got.astype(np.float64).reshape(n, order="F")
+        for i in range(n[ax]):
+            assert abs(np.linalg.svd(np.take(G, i, axis=ax), compute_uv=False).sum() - 3.5) < 3.5 * 50 * tol
+    for shp in ((30, 12), (12, 30), (20, 20)):
+        X = rng.standard_normal(shp).astype(TF)
+        nn = float(np.linalg.svd(X.astype(np.float64), compute_uv=False).sum())
+        v = X.reshape(-1, order="F").copy()
+        assert np.array_equal(_proj(sipx, "nuclear", shp, TF, 0.0, 1.1 * nn, ("matrix", ""))(v.copy()), v)   # inside: untouched
+        got = _proj(sipx, "nuclear", shp, TF, 0.0, 0.5 * nn, ("matrix", ""))(v.copy())
+        want = O.project_nuclear(v.copy(), TF(0.5 * nn), shp)
+        assert np.linalg.norm(got.astype(np.float64) - want) <= tol * np.linalg.norm(want)
+    # r = min(n1, n2): the projection is the identity (constraint2coarse clips r to min(n))
+    v = rng.standard_normal(20 * 12).astype(TF)
+    assert np.array_equal(_proj(sipx, "rank", (20, 12), TF, 0, 12, ("matrix", ""))(v.copy()), v)
+
+
+@pytest.mark.parametrize("TF", [np.float32, np.float64])
+def test_histogram_projector(sipx, TF):
+    rng = np.random.default_rng(24)
+    for M in (100, 4097):
+        LB = np.sort(rng.standard_normal(M)).astype(TF); UB = (LB + TF(0.7)).astype(TF)
+        v = rng.standard_normal(M).astype(TF)
+        v[:10] = v[10:20]                                  # ties: the stable order decides who gets which bound
+        want = O.project_histogram_relaxed(v.copy(), LB, UB)
+        got = _proj(sipx, "histogram", (M, 1), TF, LB, UB, ("matrix", ""))(v.copy())
+        assert np.array_equal(got, want)
+        ref = np.sort(rng.standard_normal(M)).astype(TF)
+        got = _proj(sipx, "histogram", (M, 1), TF, ref, ref, ("matrix", ""))(rng.standard_normal(M).astype(TF))
+        assert np.array_equal(np.sort(got), ref)           # test_projectors.jl:276-280
+
+
+@pytest.mark.parametrize("TF", [np.float32, np.float64])
+def test_subspace_projector(sipx, TF):
+    rng = np.random.default_rng(25)
+    tol = 5e-5 if TF == np.float32 else 1e-11
+
+    def close(a, b):
+        return np.linalg.norm(a.astype(np.float64) - b) <= tol * max(np.linalg.norm(b), 1e-30)
+    M = rng.standard_normal((40, 12)).astype(TF)
+    U = np.linalg.svd(M.astype(np.float64), full_matrices=False)[0].astype(TF)
+    v = rng.standard_normal(40).astype(TF)
+    for A, orth in ((U, True), (M, False)):
+        want = O.project_subspace(v.astype(np.float64), A.astype(np.float64), orth)
+        assert close(_proj(sipx, "subspace", (40, 1), TF, 0, 0, ("matrix", ""), (A, orth))(v.copy()), want)
+    X = rng.standard_normal((40, 5)).astype(TF)
+    want = O.project_subspace(X.reshape(-1, order="F").astype(np.float64), M.astype(np.float64), False, (40, 5), ("fiber", "x"))
+    assert close(_proj(sipx, "subspace", (40, 5), TF, 0, 0, ("fiber", "x"), (M, False))(X.reshape(-1, order="F").copy()), want)
+    M2 = rng.standard_normal((23, 8)).astype(TF)
+    X = rng.standard_normal((5, 23)).astype(TF)
+    want = O.project_subspace(X.reshape(-1, order="F").astype(np.float64), M2.astype(np.float64), False, (5, 23), ("fiber", "z"))
+    assert close(_proj(sipx, "subspace", (5, 23), TF, 0, 0, ("fiber", "z"), (M2, False))(X.reshape(-1, order="F").copy()), want)
+    for d, shp in (("z", (6, 7, 5)), ("y", (6, 5, 7)), ("x", (5, 6, 7))):
+        Mb = rng.standard_normal((42, 4)).astype(TF)
+        X = rng.standard_normal(shp).astype(TF)
+        want = O.project_subspace(X.reshape(-1, order="F").astype(np.float64), Mb.astype(np.float64), False, shp, ("slice", d))
+        assert close(_proj(sipx, "subspace", shp, TF, 0, 0, ("slice", d), (Mb, False))(X.reshape(-1, order="F").copy()), want), d
+    with pytest.raises(sipx.SipxError, match="rows of A"):
+        _proj(sipx, "subspace", (40, 5), TF, 0, 0, ("fiber", "z"), (M, False))(np.zeros(200, TF))

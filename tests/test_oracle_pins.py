@@ -275,3 +275,120 @@ def test_constraint2coarse_scalings():
           O.set_definitions("nuclear", "identity", 0.0, 2.7, ("matrix", ""))]
     out = O.constraint2coarse(cs, O.compgrid((1.0, 1.0), (10, 8)), 2)
     assert [c.max for c in out[:4]] == [2.0, 2.0, 80, 8] and abs(out[4].max - 1.0) < 1e-15
+
+
+# ---- the remaining get_projector branches, pinned by the properties test/test_projectors.jl:58-330 checks -------------
+def test_cardinality_per_fiber_and_slice_counts():
+    rng = np.random.default_rng(11)
+    for mode, k, view in ((("fiber", "x"), 7, lambda X, i, j: X[:, i, j]), (("fiber", "y"), 6, lambda X, i, j: X[i, :, j]),
+                          (("fiber", "z"), 4, lambda X, i, j: X[i, j, :])):
+        n = (10, 12, 9)
+        x = rng.standard_normal(int(np.prod(n)))
+        x0 = x.copy()
+        O.project_cardinality_mode(x, k, n, mode)
+        X, X0 = x.reshape(n, order="F"), x0.reshape(n, order="F")
+        ax = {"x": 0, "y": 1, "z": 2}[mode[1]]
+        dims = [d for a, d in enumerate(n) if a != ax]
+        for i in range(dims[0]):
+            for j in range(dims[1]):
+                f, f0 = view(X, i, j), view(X0, i, j)
+                assert np.count_nonzero(f) == k                                       # test_projectors.jl:70-80
+                keep = np.argsort(-np.abs(f0), kind="stable")[:k]
+                assert np.array_equal(f[keep], f0[keep])
+    for d, k in (("x", 7), ("y", 6), ("z", 5)):
+        n = (10, 12, 9)
+        x = rng.standard_normal(int(np.prod(n)))
+        O.project_cardinality_mode(x, k, n, ("slice", d))
+        X = x.reshape(n, order="F")
+        ax = {"x": 0, "y": 1, "z": 2}[d]
+        assert all(np.count_nonzero(np.take(X, i, axis=ax)) == k for i in range(n[ax]))   # :83-93
+    X = rng.standard_normal((50, 100))
+    x = X.reshape(-1, order="F").copy()
+    O.project_cardinality_mode(x, 11, (50, 100), ("fiber", "z"))
+    assert all(np.count_nonzero(x.reshape((50, 100), order="F")[i, :]) == 11 for i in range(50))   # :64-67
+
+
+def test_cardinality_tie_goes_to_the_earlier_entry():
+    x = np.array([1.0, -2.0, 2.0, 0.5, 2.0, -2.0])
+    O.project_cardinality_mode(x, 2, (6, 1), ("fiber", "x"))
+    assert np.array_equal(x, [0, -2.0, 2.0, 0, 0, 0])
+
+
+def test_rank_and_nuclear_per_slice_properties():
+    rng = np.random.default_rng(12)
+    n = (14, 12, 9)
+    for d, r in (("x", 7), ("y", 6), ("z", 5)):
+        x = rng.standard_normal(int(np.prod(n)))
+        O.project_rank(x, r, n, ("slice", d))
+        X = x.reshape(n, order="F")
+        ax = {"x": 0, "y": 1, "z": 2}[d]
+        assert all(np.linalg.matrix_rank(np.take(X, i, axis=ax)) == r for i in range(n[ax]))   # test_projectors.jl:145-156
+        x = rng.standard_normal(int(np.prod(n)))
+        O.project_nuclear(x, 1.234, n, ("slice", d))
+        X = x.reshape(n, order="F")
+        for i in range(n[ax]):
+            nn = np.linalg.svd(np.take(X, i, axis=ax), compute_uv=False).sum()
+            assert abs(nn - 1.234) < 1e-12                                              # :206-217
+    for shp in ((30, 12), (12, 30), (20, 20)):
+        X = rng.standard_normal(shp)
+        nn = np.linalg.svd(X, compute_uv=False).sum()
+        x = X.reshape(-1, order="F").copy()
+        x0 = x.copy()
+        O.project_nuclear(x, 1.1 * nn, shp)
+        assert np.allclose(x, x0, rtol=1e-13, atol=1e-13)                               # :173-181 (untouched up to SVD round trip)
+        O.project_nuclear(x, 0.5 * nn, shp)
+        assert abs(np.linalg.svd(x.reshape(shp, order="F"), compute_uv=False).sum() - 0.5 * nn) < 1e-11   # :183-204
+
+
+def test_subspace_closed_forms():
+    rng = np.random.default_rng(13)
+    M = rng.standard_normal((40, 12))
+    U = np.linalg.svd(M, full_matrices=False)[0]
+    x = rng.standard_normal(40); y = x.copy()
+    assert np.allclose(O.project_subspace(x, U, True), U @ (U.T @ y), rtol=1e-13)        # test_projectors.jl:221-227
+    x = y.copy()
+    ref = M @ np.linalg.solve(M.T @ M, M.T @ y)
+    assert np.allclose(O.project_subspace(x, M, False), ref, rtol=1e-12)                 # :229-234
+    X = rng.standard_normal((40, 5)); x = X.reshape(-1, order="F").copy()
+    O.project_subspace(x, M, False, (40, 5), ("fiber", "x"))
+    assert np.allclose(x.reshape((40, 5), order="F"), M @ np.linalg.solve(M.T @ M, M.T @ X), rtol=1e-12)   # :236-241
+    M2 = rng.standard_normal((23, 8))
+    X = rng.standard_normal((5, 23)); x = X.reshape(-1, order="F").copy()
+    O.project_subspace(x, M2, False, (5, 23), ("fiber", "z"))
+    assert np.allclose(x.reshape((5, 23), order="F"), (M2 @ np.linalg.solve(M2.T @ M2, M2.T @ X.T)).T, rtol=1e-12)   # :243-248
+    for d, shp in (("z", (6, 7, 5)), ("y", (6, 5, 7)), ("x", (5, 6, 7))):
+        Mb = rng.standard_normal((42, 4))
+        X = rng.standard_normal(shp); x = X.reshape(-1, order="F").copy()
+        O.project_subspace(x, Mb, False, shp, ("slice", d))
+        Xp = x.reshape(shp, order="F")
+        ax = {"x": 0, "y": 1, "z": 2}[d]
+        for i in range(5):
+            v = np.take(X, i, axis=ax).reshape(-1, order="F")
+            assert np.allclose(np.take(Xp, i, axis=ax).reshape(-1, order="F"), Mb @ np.linalg.solve(Mb.T @ Mb, Mb.T @ v), rtol=1e-11)  # :250-272
+
+
+def test_histogram_properties():
+    rng = np.random.default_rng(14)
+    ref = np.sort(rng.standard_normal(100))
+    x = rng.standard_normal(100)
+    O.project_histogram_relaxed(x, ref, ref)
+    assert np.array_equal(np.sort(x), ref)                                             # test_projectors.jl:276-280
+    LB = np.sort(rng.standard_normal(100)); UB = LB + 0.7
+    x = rng.standard_normal(100); x0 = x.copy()
+    O.project_histogram_relaxed(x, LB, UB)
+    xs = np.sort(x)
+    assert (xs <= UB).all() and (xs >= LB).all()                                       # :282-289
+
+
+def test_bounds_per_fiber():
+    rng = np.random.default_rng(15)
+    n = (6, 5, 4)
+    for d in ("x", "y", "z"):
+        ax = {"x": 0, "y": 1, "z": 2}[d]
+        LB = -rng.random(n[ax]); UB = rng.random(n[ax])
+        x = 3 * rng.standard_normal(int(np.prod(n)))
+        O.project_bounds_mode(x, LB, UB, n, ("fiber", d))
+        X = np.moveaxis(x.reshape(n, order="F"), ax, 0)
+        assert (X <= UB[:, None, None]).all() and (X >= LB[:, None, None]).all()
+    with pytest.raises(ValueError):
+        O.project_bounds_mode(np.zeros(120), np.zeros(4), np.ones(4), n, ("slice", "z"))
