@@ -76,6 +76,12 @@ typedef struct {
   int64_t basis_rows;
   int32_t basis_cols;
   int32_t basis_orth;/* constraint.custom_TD_OP[2]: A'A = I */
+  int32_t component; /* Minkowski sets (src/PARSDMM_precompute_distribute_Minkowski.jl:6-173): 0 = ordinary set; 1 = the set
+                        constrains the first component u (TD_OP = [A 0]); 2 = the second component v ([0 A]); 3 = their sum
+                        u + v ([A A]).  Either every set of a context names a component or none does.  With components the
+                        unknown is x = [u; v] (2N entries in x0 / sipx_download / sipx_apply_Q), the distance term is
+                        1/2 ||u + v - m||^2, and Q is the 2N x 2N CDS matrix of the reference. */
+  int32_t pad_;
 } sipx_set_desc;
 
 /* PARSDMM_options (src/SetIntersectionProjection.jl:110-128); Blas_active / parallel / FL /

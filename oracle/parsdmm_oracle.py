@@ -613,13 +613,8 @@ def project_l1_dft(x, b, n):
     a = np.abs(Z)
     if not (a.sum() > float(b)):
         return x      # inside the ball: F'F = I, return x untouched instead of an FFT round trip (pure rounding noise)
-    if True:
-        u = np.sort(a.ravel())[::-1]
-        cs = np.cumsum(u)
-        k = np.arange(1, len(u) + 1)
-        rho = np.nonzero(u > (cs - float(b)) / k)[0][-1]
-        theta = max(0.0, (cs[rho] - float(b)) / (rho + 1))
-        Z = np.where(a > 0, Z / np.maximum(a, 1e-300), 0) * np.maximum(a - theta, 0)
+    theta = float(l1ball_theta_duchi(a.reshape(-1, order="F"), float(b)))       # the same scan, incl. its lv-1 cap (:42)
+    Z = np.where(a > 0, Z / np.maximum(a, 1e-300), 0) * np.maximum(a - theta, 0)
     x[:] = np.real(np.fft.ifftn(Z, norm="ortho")).reshape(-1, order="F").astype(TF)
     return x
 
@@ -731,6 +726,40 @@ def PARSDMM_precompute_distribute(TD_OP, set_Prop, comp_grid, options):
 # --------------------------------------------------------------------------------------
 # iteration-body steps
 # --------------------------------------------------------------------------------------
+
+
+def PARSDMM_precompute_distribute_Minkowski(TD_OP_c1, TD_OP_c2, TD_OP_sum, prop_c1, prop_c2, prop_sum, comp_grid, options):
+    """src/PARSDMM_precompute_distribute_Minkowski.jl:6-173 (banded operators) -> (TD_OP, set_Prop, AtA, l, y)."""
+    import copy
+    TF = np.dtype(options.FL).type
+    N = int(np.prod([int(v) for v in comp_grid.n]))
+    Z = sp.csc_matrix((N, N), dtype=TF)
+    I = sp.identity(N, dtype=TF, format="csc")
+    AtA = []
+    for ops, prop, where in ((TD_OP_c1, prop_c1, 1), (TD_OP_c2, prop_c2, 2), (TD_OP_sum, prop_sum, 3)):
+        for i, A in enumerate(ops):
+            B = I if (prop.dense[i] and prop.AtA_diag[i]) else ata_ordered(A, TF)          # :36-47
+            blocks = {1: [[B, Z], [Z, Z]], 2: [[Z, Z], [Z, B]], 3: [[B, B], [B, B]]}[where]
+            AtA.append(sp.bmat(blocks, format="csc", dtype=TF))
+    TD_OP = ([sp.hstack([A, sp.csc_matrix(A.shape, dtype=TF)], format="csc") for A in TD_OP_c1] +          # :91-103
+             [sp.hstack([sp.csc_matrix(A.shape, dtype=TF), A], format="csc") for A in TD_OP_c2] +
+             [sp.hstack([A, A], format="csc") for A in TD_OP_sum])
+    prop = copy.deepcopy(prop_c1)
+    for other in (prop_c2, prop_sum):
+        for f in ("AtA_diag", "AtA_offsets", "TD_n", "banded", "dense", "ncvx", "tag"):
+            getattr(prop, f).extend(copy.deepcopy(getattr(other, f)))
+    if not options.feasibility_only:                                                       # :106-116
+        TD_OP.append(sp.hstack([I, I], format="csc"))
+        prop.TD_n.append(tuple(int(v) for v in comp_grid.n)); prop.AtA_offsets.append(np.array([0], np.int64))
+        prop.banded.append(True); prop.AtA_diag.append(False); prop.dense.append(False)
+        prop.ncvx.append(False); prop.tag.append(("distance squared", "identity", "matrix", ""))
+        AtA.append(sp.bmat([[I, I], [I, I]], format="csc", dtype=TF))
+    s_ = len(TD_OP)
+    for i in range(s_):                                                                    # :139-146
+        AtA[i], prop.AtA_offsets[i] = mat2CDS(AtA[i], TF)
+    y = [np.zeros(TD_OP[i].shape[0], TF) for i in range(s_)]
+    l = [np.zeros(TD_OP[i].shape[0], TF) for i in range(s_)]
+    return TD_OP, prop, AtA, l, y
 
 
 def rhs_compose(l, y, rho, TD_OP, p, N, only=None):
@@ -961,9 +990,17 @@ def PARSDMM(m, AtA, TD_OP, set_Prop, P_sub, comp_grid, options, x=None, l=None, 
     rho_update_frequency = int(o.rho_update_frequency)
     adjust_rho, adjust_gamma, adjust_feasibility_rho = o.adjust_rho, o.adjust_gamma, o.adjust_feasibility_rho
     feasibility_only = o.feasibility_only
+    mink = bool(getattr(o, "Minkowski", False))
     N = len(m)
     if x is None:
         x = np.zeros(N, TF)
+    if mink:                                                                         # PARSDMM_initialize.jl:31-37
+        if o.zero_ini_guess:
+            N = 2 * len(x)
+        else:
+            assert len(x) == 2 * len(m)
+            N = len(x)
+    m_ext = np.concatenate([m, np.zeros(len(m), TF)]) if mink else m                 # :85-87
     # ---- PARSDMM_initialize (src/PARSDMM_initialize.jl:30-313) ----
     p = len(TD_OP)
     pp = p if feasibility_only else p - 1
@@ -977,7 +1014,7 @@ def PARSDMM(m, AtA, TD_OP, set_Prop, P_sub, comp_grid, options, x=None, l=None, 
     eps = np.finfo(TF).eps
     feasibility_initial = np.zeros(len(P_sub), TF)
     for ii in range(len(P_sub)):                                                     # :97-99
-        Am = csc_mul(TD_OP[ii], m)
+        Am = csc_mul(TD_OP[ii], m_ext)
         feasibility_initial[ii] = TF(nrm2(P_sub[ii](Am.copy()) - Am, TF) / TF(nrm2(Am, TF) + TF(100) * eps))
     stop = bool(_nanmax(feasibility_initial) < o.feas_tol)                           # :101-104
     gamma_ini = TF(o.gamma_ini)
@@ -1006,9 +1043,13 @@ def PARSDMM(m, AtA, TD_OP, set_Prop, P_sub, comp_grid, options, x=None, l=None, 
         x[:] = 0
     # ---- back in PARSDMM ----
     if stop:                                                                         # PARSDMM.jl:63-82
-        x[:] = m
+        x[:len(m)] = m
+        if mink and len(x) == len(m):
+            x = np.concatenate([x, np.zeros(len(x), TF)])
         _truncate_log(log, 1, 1)
         return x, log, l, y
+    if mink and len(x) == len(m):                                                    # :84-89
+        x = np.concatenate([x, np.zeros(len(m), TF)])
     counter = 2                                                                      # :91
     x_solve_tol_ref = TF(1.0)                                                        # :93
     for i in range(1, maxit + 1):                                                    # :97
@@ -1020,8 +1061,8 @@ def PARSDMM(m, AtA, TD_OP, set_Prop, P_sub, comp_grid, options, x=None, l=None, 
                              counter, x_hat, r_pri, s, feasibility_only)             # :133
         log.r_dual_total[i - 1] = _seq_sum(log.r_dual[i - 1, :], TF)                 # :134
         log.r_pri_total[i - 1] = _seq_sum(log.r_pri[i - 1, :], TF)                   # :138
-        nd = nrm2(x - m, TF)
-        log.obj[i - 1] = TF(0.5) * TF(nd * nd)                                       # :140
+        nd = nrm2((csc_mul(TD_OP[-1], x) if mink else x) - m, TF)                    # :139-143
+        log.obj[i - 1] = TF(0.5) * TF(nd * nd)
         with np.errstate(all="ignore"):
             log.evol_x[i - 1] = TF(nrm2(x_old - x, TF) / nrm2(x, TF))                # :145
         log.rho[i - 1, :] = rho; log.gamma[i - 1, :] = gamma                         # :146-147

@@ -6,7 +6,7 @@ The directory name carries a dot, so load it with ``__graft_entry__.load_package
 calling it without a GPU, raises -- there is no CPU fallback.
 """
 from .host import (  # noqa: F401
-    PARSDMM, PARSDMM_options, PARSDMM_precompute_distribute, Context, SipxError, TDOperator,
+    PARSDMM, PARSDMM_options, PARSDMM_precompute_distribute, PARSDMM_precompute_distribute_Minkowski, Context, SipxError, TDOperator,
     Projector, compgrid, default_PARSDMM_options, get_TD_operator, lib, log_type_PARSDMM,
     set_definitions, set_properties, setup_constraints, cds_spmv, CDS_MVp, LIB_PATH, EXPORTED_SYMBOLS,
     set_default_device, resample_nn,

@@ -93,6 +93,7 @@ void bb_rule(T d_dHh_dlh, T n_d_H_hat, T n_d_l_hat, T n_d_l, T n_d_G_hat, T d_dG
 template <typename T>
 struct SetState {
   int op = 0, prox = 0, nblk = 0, ncvx = 0;
+  int comp = 0;                      // Minkowski component: 0 none, 1 = [A 0], 2 = [0 A], 3 = [A A]
   int dir[3] = {0, 0, 0};
   T ih[3] = {0, 0, 0};
   long long Mtrue = 0, Mpad = 0;
@@ -141,7 +142,7 @@ class Engine : public EngineBase {
     (void)hipSetDevice(device_);
     (void)hipStreamSynchronize(stream_);
     for (auto& s : sets_) free_set(s);
-    for (void* p : {(void*)x_base_, (void*)xold_, (void*)rhs_, (void*)m_base_, (void*)r_, (void*)p_base_, (void*)Ap_, (void*)Q_,
+    for (void* p : {(void*)w_base_, (void*)x_base_, (void*)xold_, (void*)rhs_, (void*)m_base_, (void*)r_, (void*)p_base_, (void*)Ap_, (void*)Q_,
                     (void*)scr_v_, (void*)scr_c_, (void*)scr_i_, (void*)scr_w_, (void*)part_cg_, (void*)part_tmp_, (void*)part_sets_,
                     (void*)maxpart_, (void*)cg_dev_})
       dfree(p);
@@ -159,6 +160,7 @@ class Engine : public EngineBase {
     SetState<T> s;
     configure_op(s, d->op);
     configure_proj(s, d);
+    if (ata_R && s.comp) throw std::runtime_error("Minkowski sets use descriptor-generated AtA (pass ata_R = NULL)");
     if (ata_R) {
       if (d_i < 1 || d_i > 7) throw std::runtime_error("AtA band count out of range (1..7 bands per set)");
       s.ata_off.assign(ata_off, ata_off + d_i);
@@ -207,6 +209,19 @@ class Engine : public EngineBase {
       sets_.push_back(std::move(s));
     }
     p_n_ = (int)sets_.size();
+    {
+      int with = 0;
+      for (int i = 0; i < pp_n_; ++i) with += sets_[i].comp != 0;
+      if (with != 0 && with != pp_n_) throw std::runtime_error("either every set names its Minkowski component or none does");
+      mk_ = with > 0;
+      if (mk_ && !feasibility_only_) sets_.back().comp = 3;        // distance term [I I]
+      if (mk_ && stencil_q_) throw std::runtime_error("the stencil form of Q is not available for Minkowski sets");
+      if (mk_ && !owned_.empty()) throw std::runtime_error("set sharding is not available for Minkowski sets");
+      if (mk_)
+        for (auto& st : sets_) st.ata_off = default_ata_offsets(st);
+    }
+    Nx_ = mk_ ? 2 * G_.N : G_.N;
+    if (Nx_ >= (1ll << 31)) throw std::runtime_error("2^31 unknowns or more are not supported");
     if (p_n_ > 99) throw std::runtime_error("at most 99 sets (PARSDMM_initialize.jl:217)");
     if (!owned_.empty())
       for (int i = 0; i < p_n_; ++i) sets_[i].owned = owned_[i] != 0;
@@ -230,11 +245,12 @@ class Engine : public EngineBase {
     for (int b = 0; b < cds_.d; ++b) halo_ = std::max<long long>(halo_, std::llabs(cds_.off[b]));
     for (int a = 0; a < 3; ++a) halo_ = std::max<long long>(halo_, G_.st[a]);
     halo_ = (halo_ + 3) / 4 * 4;
-    x_base_ = dalloc<T>(N + 2 * halo_); x_ = x_base_ + halo_;
-    p_base_ = dalloc<T>(N + 2 * halo_); p_ = p_base_ + halo_;
-    xold_ = dalloc<T>(N); rhs_ = dalloc<T>(N);
+    x_base_ = dalloc<T>(Nx_ + 2 * halo_); x_ = x_base_ + halo_;
+    p_base_ = dalloc<T>(Nx_ + 2 * halo_); p_ = p_base_ + halo_;
+    xold_ = dalloc<T>(Nx_); rhs_ = dalloc<T>(Nx_);
+    if (mk_) { w_base_ = dalloc<T>(N + 2 * halo_); w_ = w_base_ + halo_; }   // u + v, read through the stencils
     m_base_ = dalloc<T>(N + 2 * halo_); m_ = m_base_ + halo_;   // forward stencils of A m read past the end
-    r_ = dalloc<T>(N); Ap_ = dalloc<T>(N);
+    r_ = dalloc<T>(Nx_); Ap_ = dalloc<T>(Nx_);
     SIPX_HIP(hipMemcpy(m_, m, N * sizeof(T), hipMemcpyHostToDevice));
     long long maxpad = N;
     for (auto& s : sets_) maxpad = std::max(maxpad, s.Mpad);
@@ -244,14 +260,14 @@ class Engine : public EngineBase {
     if (need_ext_) scr_w_ = dalloc<T>(maxpad);
     part_cg_ = dalloc<double>(2 * NB);
     part_tmp_ = dalloc<double>((size_t)(PREP_SLOTS + 2) * NB);
-    part_sets_ = dalloc<double>((size_t)p_n_ * SLOTS * NB);
-    maxpart_ = dalloc<T>(NB);
+    part_sets_ = dalloc<double>((size_t)(p_n_ + 1) * SLOTS * NB);   // + one group of slots for whole-x sums
+    maxpart_ = dalloc<T>(2 * NB);     // per-block max | per-block smallest non-zero magnitude
     cg_dev_ = dalloc<CgState<T>>(1);
     SIPX_HIP(hipHostMalloc((void**)&cg_host_, 2 * sizeof(CgState<T>), hipHostMallocDefault));
     std::memset(cg_host_, 0, 2 * sizeof(CgState<T>));
     for (int k = 0; k < 2; ++k) SIPX_HIP(hipEventCreateWithFlags(&cg_ev_[k], hipEventDisableTiming));
-    SIPX_HIP(hipHostMalloc((void**)&hres_, sizeof(double) * p_n_ * SLOTS, hipHostMallocDefault));
-    std::memset(hres_, 0, sizeof(double) * p_n_ * SLOTS);
+    SIPX_HIP(hipHostMalloc((void**)&hres_, sizeof(double) * (p_n_ + 1) * SLOTS, hipHostMallocDefault));
+    std::memset(hres_, 0, sizeof(double) * (p_n_ + 1) * SLOTS);
     for (int k = 0; k < 16; ++k) {      // two sets of section marks: a step never waits for its own timing
       hipEvent_t e;
       SIPX_HIP(hipEventCreate(&e));
@@ -302,7 +318,7 @@ class Engine : public EngineBase {
       if (warm && l0 && l0[i]) upload_rows(s, (const T*)l0[i], s.l);
       if (warm && y0 && y0[i]) upload_rows(s, (const T*)y0[i], s.y);
     }
-    if (warm && x0) SIPX_HIP(hipMemcpy(x_, x0, N * sizeof(T), hipMemcpyHostToDevice));
+    if (warm && x0) SIPX_HIP(hipMemcpy(x_, x0, Nx_ * sizeof(T), hipMemcpyHostToDevice));   // Minkowski: [u; v], 2N entries
 
     assemble_Q();
     finalized_ = true;
@@ -313,17 +329,19 @@ class Engine : public EngineBase {
       SetState<T>& s = sets_[i];
       if (!s.owned) continue;
       double* dst = part_sets_ + ((size_t)i * SLOTS + SL_FE2) * NB;
+      // Minkowski: TD_OP[i] * [m; 0] = A m for components 1 and 3, A 0 = 0 for component 2 (w_ is still all zero here)
+      const T* mm = s.comp == 2 ? w_ : m_;
       if (s.ext_kind) {
         SetArgs<T> a = set_args(s, rho_[i], gamma_[i], 0);
-        a.x = m_;
+        a.x = mm;
         ext_feasibility(s, a, dst);
       } else if (s.two_pass) {
         SetArgs<T> a = set_args(s, rho_[i], gamma_[i], 0);
-        a.x = m_;                                              // s = A m produced on the fly
+        a.x = mm;                                              // s = A m produced on the fly
         K<T>::proj_scalars_set(stream_, G_, a, 1, s.psf, part_tmp_, maxpart_, scr_c_, s.Mtrue);
         K<T>::proj_dist_set(stream_, G_, a, 1, s.psf, dst);
       } else {
-        K<T>::fwd(stream_, G_, s.nblk, s.dir, s.ih, m_, scr_v_);
+        K<T>::fwd(stream_, G_, s.nblk, s.dir, s.ih, mm, scr_v_);
         proj_dist_grid<T>(stream_, G_, s.nblk, s.dir, s.Mpad, scr_v_, s.prox, s.plo, s.phi, s.lb, s.ub, nullptr, dst);
       }
     }
@@ -340,6 +358,30 @@ class Engine : public EngineBase {
   // ------------------------------------------------------------------------------------------
   void rhs_compose(const double* rho) override {
     need_final();
+    if (mk_) {    // rhs = sum_i [A 0]'w_i / [0 A]'w_i / [A A]'w_i, w_i = rho_i y_i + l_i, sets added in order per half
+      for (int half = 0; half < 2; ++half) {
+        T* out = rhs_ + (long long)half * G_.N;
+        int launched = 0;
+        for (int pass = 0; pass < 2; ++pass) {            // own component first (it precedes the sum sets in TD_OP order)
+          RhsArgs<T> a;
+          a.nsets = 0;
+          for (int i = 0; i < p_n_; ++i) {
+            const SetState<T>& s = sets_[i];
+            if (s.comp != (pass == 0 ? half + 1 : 3)) continue;
+            RhsSet<T>& r = a.s[a.nsets++];
+            r.y = s.y; r.l = s.l; r.rho = (T)rho[i]; r.nblk = s.nblk;
+            for (int q = 0; q < 3; ++q) { r.dir[q] = s.dir[q]; r.ih[q] = s.ih[q]; }
+            if (a.nsets == MAX_SETS) {
+              K<T>::rhs_compose(stream_, G_, a, out, launched++ > 0);
+              a.nsets = 0;
+            }
+          }
+          if (a.nsets > 0) K<T>::rhs_compose(stream_, G_, a, out, launched++ > 0);
+        }
+        if (launched == 0) SIPX_HIP(hipMemsetAsync(out, 0, G_.N * sizeof(T), stream_));
+      }
+      return;
+    }
     RhsArgs<T> a;
     a.nsets = 0;
     int launched = 0;
@@ -362,10 +404,10 @@ class Engine : public EngineBase {
     cg_host_->tol_ref = (T)*tol_ref_io;     // pinned staging; the device mirror overwrites it after the copy (stream order)
     SIPX_HIP(hipMemcpyAsync(&cg_dev_->tol_ref, &cg_host_->tol_ref, sizeof(T), hipMemcpyHostToDevice, stream_));
     if (stencil_q_) K<T>::sq_resid(stream_, G_, sq_, x_, rhs_, r_, p_, xold_, part_cg_);
-    else K<T>::resid(stream_, G_.N, Q_, cds_, x_, rhs_, r_, p_, xold_, part_cg_);
-    K<T>::cg_begin(stream_, part_cg_, cg_dev_, cg_host_, it, x_, G_.N);
+    else K<T>::resid(stream_, Nx_, Q_, cds_, x_, rhs_, r_, p_, xold_, part_cg_);
+    K<T>::cg_begin(stream_, part_cg_, cg_dev_, cg_host_, it, x_, Nx_);
     SIPX_HIP(hipStreamSynchronize(stream_));
-    if (cg_host_->flag == -9) SIPX_HIP(hipMemsetAsync(x_, 0, G_.N * sizeof(T), stream_));   // cg.jl:51
+    if (cg_host_->flag == -9) SIPX_HIP(hipMemsetAsync(x_, 0, Nx_ * sizeof(T), stream_));   // cg.jl:51
     // CG iterations run one ahead of the host: iteration k+1 is enqueued before the outcome of k is known.
     // Every kernel returns at once when the device-side `done` flag is set, so a speculative iteration
     // past convergence costs five empty launches and the GPU never idles on a host round trip.
@@ -374,12 +416,12 @@ class Engine : public EngineBase {
       CgState<T>* mirror = cg_host_ + (k & 1);
       if (stats_on_) stat_mark();
       if (stencil_q_) K<T>::sq_spmv_dot(stream_, G_, sq_, p_, Ap_, part_cg_, cg_dev_);
-      else K<T>::spmv_dot(stream_, G_.N, Q_, cds_, p_, Ap_, part_cg_, cg_dev_);
+      else K<T>::spmv_dot(stream_, Nx_, Q_, cds_, p_, Ap_, part_cg_, cg_dev_);
       if (stats_on_) stat_mark();
       K<T>::cg_fin_alpha(stream_, part_cg_, cg_dev_, mirror, k);
-      K<T>::cg_update_xr(stream_, G_.N, x_, r_, p_, Ap_, part_cg_, cg_dev_);
+      K<T>::cg_update_xr(stream_, Nx_, x_, r_, p_, Ap_, part_cg_, cg_dev_);
       K<T>::cg_fin_beta(stream_, part_cg_, cg_dev_, mirror);
-      K<T>::cg_update_p(stream_, G_.N, p_, r_, cg_dev_);
+      K<T>::cg_update_p(stream_, Nx_, p_, r_, cg_dev_);
       SIPX_HIP(hipEventRecord(cg_ev_[k & 1], stream_));
     };
     CgState<T> fin = cg_host_[0];
@@ -410,10 +452,12 @@ class Engine : public EngineBase {
                   double* feas) override {
     need_final();
     (void)it;
+    if (mk_) K<T>::sum_uv(stream_, G_.N, x_, x_ + G_.N, w_);
     for (int i = 0; i < p_n_; ++i) {
       SetState<T>& s = sets_[i];
       if (!s.owned) continue;
       SetArgs<T> a = set_args(s, (T)rho[i], (T)gamma[i], flags);
+      if (mk_) a.x = s.comp == 1 ? x_ : (s.comp == 2 ? x_ + G_.N : w_);
       double* part = part_sets_ + (size_t)i * SLOTS * NB;
       if (s.ext_kind) {   // library-backed projector: materialise v, project it in place, hand y to the fused update
         K<T>::store_v(stream_, G_, a, 0, scr_v_);
@@ -436,7 +480,9 @@ class Engine : public EngineBase {
         K<T>::proj_dist_set(stream_, G_, a, 1, s.psf, part + (size_t)SL_FE2 * NB);
       }
     }
-    K<T>::fin_sum(stream_, part_sets_, p_n_ * SLOTS, nullptr, hres_);
+    // Minkowski: evol_x runs over all 2N unknowns (PARSDMM.jl:145); the distance-term kernel only saw u + v
+    if (mk_) K<T>::log3(stream_, Nx_, x_, (const T*)nullptr, xold_, part_sets_ + (size_t)p_n_ * SLOTS * NB);
+    K<T>::fin_sum(stream_, part_sets_, (p_n_ + (mk_ ? 1 : 0)) * SLOTS, nullptr, hres_);
     SIPX_HIP(hipStreamSynchronize(stream_));
     have_log_sums_ = false;
     for (int i = 0; i < p_n_; ++i) {
@@ -447,10 +493,12 @@ class Engine : public EngineBase {
       const double* h = hres_ + (size_t)i * SLOTS;
       std::copy(h, h + SLOTS, s.sums);
       if (r_pri) r_pri[i] = (double)(T)std::sqrt(h[SL_RPRI]);                                   // update_y_l.jl:81
-      if (r_dual) r_dual[i] = (double)((T)rho[i] * (T)std::sqrt(s.ident ? h[SL_DY] : h[SL_ADJ]));  // :84
+      // :84; in Minkowski mode [A A]'d = [A'd; A'd] doubles the sum of squares
+      if (r_dual) r_dual[i] = (double)((T)rho[i] * (T)std::sqrt((s.comp == 3 ? 2.0 : 1.0) * (s.ident ? h[SL_DY] : h[SL_ADJ])));
       s.bb_valid = (flags & (SIPX_YL_BB | SIPX_YL_FIRST)) != 0;
       if (s.is_dist) {
-        obj_ss_ = h[SL_OBJ]; evo_ss_ = h[SL_EVO]; xx_ss_ = h[SL_XX];
+        obj_ss_ = h[SL_OBJ]; evo_ss_ = h[SL_EVO]; xx_ss_ = h[SL_XX];     // obj = 1/2 ||TD_OP[end] x - m||^2  PARSDMM.jl:139-143
+        if (mk_) { evo_ss_ = hres_[(size_t)p_n_ * SLOTS + SL_EVO]; xx_ss_ = hres_[(size_t)p_n_ * SLOTS + SL_XX]; }
         have_log_sums_ = true;
       }
     }
@@ -468,10 +516,12 @@ class Engine : public EngineBase {
   void log_scalars(double* obj, double* evol_x) override {
     need_final();
     if (!have_log_sums_) {
-      K<T>::log3(stream_, G_.N, x_, m_, xold_, part_sets_);
-      K<T>::fin_sum(stream_, part_sets_, SLOTS, nullptr, hres_);
+      K<T>::log3(stream_, G_.N, mk_ ? w_ : x_, m_, xold_, part_sets_);
+      if (mk_) K<T>::log3(stream_, Nx_, x_, (const T*)nullptr, xold_, part_sets_ + (size_t)SLOTS * NB);
+      K<T>::fin_sum(stream_, part_sets_, (mk_ ? 2 : 1) * SLOTS, nullptr, hres_);
       SIPX_HIP(hipStreamSynchronize(stream_));
       obj_ss_ = hres_[SL_OBJ]; evo_ss_ = hres_[SL_EVO]; xx_ss_ = hres_[SL_XX];
+      if (mk_) { evo_ss_ = hres_[SLOTS + SL_EVO]; xx_ss_ = hres_[SLOTS + SL_XX]; }
     }
     const T nd = (T)std::sqrt(obj_ss_);
     *obj = (double)(T(0.5) * (nd * nd));                                   // PARSDMM.jl:140
@@ -500,6 +550,12 @@ class Engine : public EngineBase {
       stencil_weights(rho_new);
       return;
     }
+    if (mk_) {
+      std::vector<T> al(p_n_);
+      for (int i = 0; i < p_n_; ++i) al[i] = rho_new[i] == rho_old[i] ? T(0) : (T)rho_new[i] - (T)rho_old[i];
+      mk_q_update(al);
+      return;
+    }
     QArgs<T> a;
     a.nsets = 0;
     for (int i = 0; i < p_n_; ++i) {
@@ -512,7 +568,7 @@ class Engine : public EngineBase {
   void download(void* x, void* const* l, void* const* y) override {
     need_final();
     SIPX_HIP(hipStreamSynchronize(stream_));
-    if (x) SIPX_HIP(hipMemcpy(x, x_, G_.N * sizeof(T), hipMemcpyDeviceToHost));
+    if (x) SIPX_HIP(hipMemcpy(x, x_, Nx_ * sizeof(T), hipMemcpyDeviceToHost));
     for (int i = 0; i < p_n_; ++i) {
       if (!sets_[i].owned) continue;
       if (l && l[i]) download_rows(sets_[i], sets_[i].l, (T*)l[i]);
@@ -543,6 +599,7 @@ class Engine : public EngineBase {
     R.active = true;
     if (pp > 0 && maxf < (double)R.feas_tol) {                        // :101-104, PARSDMM.jl:63-82
       SIPX_HIP(hipMemcpyAsync(x_, m_, G_.N * sizeof(T), hipMemcpyDeviceToDevice, stream_));
+      if (mk_) SIPX_HIP(hipMemsetAsync(x_ + G_.N, 0, G_.N * sizeof(T), stream_));      // x = [m; 0]  PARSDMM.jl:64-69
       SIPX_HIP(hipStreamSynchronize(stream_));
       log->n_iter = 1;
       log->n_feas_rows = 1;
@@ -712,7 +769,7 @@ class Engine : public EngineBase {
     T* dc = dalloc<T>(len);
     T *lb = nullptr, *ub = nullptr;
     double* part = dalloc<double>((size_t)(PREP_SLOTS + 2) * NB);
-    T* mp = dalloc<T>(NB);
+    T* mp = dalloc<T>(2 * NB);
     ProjScalars<T>* ps = dalloc<ProjScalars<T>>(1);
     SIPX_HIP(hipMemcpy(dv, v, len * sizeof(T), hipMemcpyHostToDevice));
     const int prox = d->proj;
@@ -766,17 +823,17 @@ class Engine : public EngineBase {
     if (d) *d = cds_.d;
     if (offsets) for (int b = 0; b < cds_.d; ++b) offsets[b] = cds_.off[b];
     if (Q && stencil_q_) throw std::runtime_error("stencil Q mode stores no bands (use sipx_apply_Q)");
-    if (Q) SIPX_HIP(hipMemcpy(Q, Q_, (size_t)G_.N * cds_.d * sizeof(T), hipMemcpyDeviceToHost));
+    if (Q) SIPX_HIP(hipMemcpy(Q, Q_, (size_t)Nx_ * cds_.d * sizeof(T), hipMemcpyDeviceToHost));
   }
 
   void apply_Q(const void* x, void* y) override {     // y = Q x through the solver's own kernel (either mode)
     need_final();
     SIPX_HIP(hipStreamSynchronize(stream_));
-    SIPX_HIP(hipMemcpy(p_, x, G_.N * sizeof(T), hipMemcpyHostToDevice));
+    SIPX_HIP(hipMemcpy(p_, x, Nx_ * sizeof(T), hipMemcpyHostToDevice));
     if (stencil_q_) K<T>::sq_spmv(stream_, G_, sq_, p_, Ap_);
-    else K<T>::spmv(stream_, G_, G_.N, Q_, cds_, p_, Ap_);
+    else K<T>::spmv(stream_, G_, Nx_, Q_, cds_, p_, Ap_);
     SIPX_HIP(hipStreamSynchronize(stream_));
-    SIPX_HIP(hipMemcpy(y, Ap_, G_.N * sizeof(T), hipMemcpyDeviceToHost));
+    SIPX_HIP(hipMemcpy(y, Ap_, Nx_ * sizeof(T), hipMemcpyDeviceToHost));
   }
 
   double time_spmv(int reps) override {
@@ -786,7 +843,7 @@ class Engine : public EngineBase {
     SIPX_HIP(hipEventCreate(&b));
     auto one = [&]() {
       if (stencil_q_) K<T>::sq_spmv(stream_, G_, sq_, x_, Ap_);
-      else K<T>::spmv(stream_, G_, G_.N, Q_, cds_, x_, Ap_);
+      else K<T>::spmv(stream_, G_, Nx_, Q_, cds_, x_, Ap_);
     };
     one();   // warm
     SIPX_HIP(hipEventRecord(a, stream_));
@@ -854,6 +911,8 @@ class Engine : public EngineBase {
     s.ncvx = d->ncvx;
     s.plo = (T)d->pmin;
     s.phi = (T)d->pmax;
+    if (d->component < 0 || d->component > 3) throw std::runtime_error("Minkowski component must be 0, 1, 2 or 3");
+    s.comp = d->component;
     const int mode = d->mode, dir = d->dir;
     if (mode != SIPX_MODE_WHOLE && mode != SIPX_MODE_FIBER && mode != SIPX_MODE_SLICE)
       throw std::runtime_error("unknown application mode");
@@ -991,6 +1050,14 @@ class Engine : public EngineBase {
     }
     std::sort(o.begin(), o.end());
     o.erase(std::unique(o.begin(), o.end()), o.end());
+    if (s.comp == 3) {     // [B B; B B]: every diagonal of B also shifted by -N and +N (mat2CDS of the 2N x 2N block matrix)
+      std::vector<long long> all;
+      for (long long sh : {-G_.N, 0ll, G_.N})
+        for (long long v : o) all.push_back(v + sh);
+      std::sort(all.begin(), all.end());
+      all.erase(std::unique(all.begin(), all.end()), all.end());
+      return all;
+    }
     return o;
   }
 
@@ -1041,11 +1108,37 @@ class Engine : public EngineBase {
       stencil_weights(r.data());
       return;
     }
-    Q_ = dalloc<T>((size_t)G_.N * cds_.d);
+    Q_ = dalloc<T>((size_t)Nx_ * cds_.d);
+    if (mk_) {
+      std::vector<T> al(rho_.begin(), rho_.end());
+      mk_q_update(al);
+      return;
+    }
     QArgs<T> a;
     a.nsets = 0;
     for (int i = 0; i < p_n_; ++i) push_qset(a, sets_[i], rho_[i]);   // Q = 0 + rho_1 AtA_1 + rho_2 AtA_2 + ...
     K<T>::q_update(stream_, G_, cds_, a, Q_);
+  }
+
+  // Minkowski mode: Q[:, b] += alpha_i AtA_i[:, b] for the sets with alpha_i != 0, batches of MAX_SETS in set order
+  void mk_q_update(const std::vector<T>& alpha) {
+    MkArgs<T> a;
+    a.nsets = 0;
+    for (int i = 0; i < p_n_; ++i) {
+      if (alpha[i] == T(0)) continue;
+      const SetState<T>& s = sets_[i];
+      for (long long o : s.ata_off) (void)q_col(o);
+      MkSet<T>& m = a.s[a.nsets++];
+      m.alpha = alpha[i];
+      m.nblk = s.nblk;
+      m.comp = s.comp;
+      for (int k = 0; k < 3; ++k) { m.dir[k] = s.dir[k]; m.ih[k] = s.ih[k]; }
+      if (a.nsets == MAX_SETS) {
+        K<T>::q_update_mk(stream_, G_, cds_, a, Q_);
+        a.nsets = 0;
+      }
+    }
+    K<T>::q_update_mk(stream_, G_, cds_, a, Q_);
   }
 
   void push_qset(QArgs<T>& a, const SetState<T>& s, T alpha) {
@@ -1173,6 +1266,9 @@ class Engine : public EngineBase {
   T* scr_w_ = nullptr;
   bool need_idx_ = false, need_ext_ = false;
   CdsArgs cds_;
+  bool mk_ = false;               // Minkowski mode: unknowns [u; v]
+  long long Nx_ = 0;              // number of unknowns (N, or 2N in Minkowski mode)
+  T *w_base_ = nullptr, *w_ = nullptr;
   StencilQ<T> sq_{};
   bool stencil_q_ = false;
   double *part_cg_ = nullptr, *part_tmp_ = nullptr, *part_sets_ = nullptr;

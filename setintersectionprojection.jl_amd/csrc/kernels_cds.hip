@@ -352,6 +352,39 @@ void K<T>::q_update(hipStream_t s, const Grid& g, const CdsArgs& q, const QArgs<
   SIPX_HIP(hipGetLastError());
 }
 
+// Minkowski mode: Q is 2N x d.  Row g = (block row br, local point gl), band offset O -> column (bc, cl); the entry of
+// set i is (A_i'A_i)[gl, cl] when block (br, bc) of its AtA is populated ([B 0;0 0], [0 0;0 B] or [B B;B B]).
+// Q[:, b] += alpha_i * AtA_i[:, b] for every listed set (assembly: alpha = rho; update: alpha = delta rho).
+template <typename T>
+__global__ __launch_bounds__(BLOCK) void k_q_update_mk(Grid G, CdsArgs q, MkArgs<T> a, T* __restrict__ Q) {
+  const long long N = G.N, Nx = 2 * G.N;
+  for (long long g = (long long)blockIdx.x * BLOCK + threadIdx.x; g < Nx; g += (long long)gridDim.x * BLOCK) {
+    const int br = g >= N;
+    const long long gl = g - (long long)br * N;
+    const Coord c = coords(G, gl);
+    for (int b = 0; b < q.d; ++b) {
+      const long long cc = g + q.off[b];
+      if (cc < 0 || cc >= Nx) continue;
+      const int bc = cc >= N;
+      const long long o = (cc - (long long)bc * N) - gl;
+      T qv = Q[(long long)b * Nx + g];
+      for (int si = 0; si < a.nsets; ++si) {
+        const MkSet<T>& S = a.s[si];
+        const bool pop = S.comp == 3 || (S.comp == 1 && br == 0 && bc == 0) || (S.comp == 2 && br == 1 && bc == 1);
+        if (!pop) continue;
+        qv = qv + S.alpha * ata_value<T>(G, S.nblk, S.dir, S.ih, o, c);
+      }
+      Q[(long long)b * Nx + g] = qv;
+    }
+  }
+}
+template <typename T>
+void K<T>::q_update_mk(hipStream_t s, const Grid& g, const CdsArgs& q, const MkArgs<T>& a, T* Q) {
+  if (a.nsets == 0) return;
+  hipLaunchKernelGGL((k_q_update_mk<T>), dim3(NB), dim3(BLOCK), 0, s, g, q, a, Q);
+  SIPX_HIP(hipGetLastError());
+}
+
 template <typename T>
 void K<T>::gen_ata(hipStream_t s, const Grid& g, int nblk, const int* dir, const T* ih, int nband, const long long* offs,
                    T* R) {
@@ -536,6 +569,7 @@ void K<T>::fin_sum(hipStream_t s, const double* partials, int nslots, double* ou
                                const CgState<T>*);                                                                    \
   template void K<T>::resid(hipStream_t, long long, const T*, const CdsArgs&, const T*, const T*, T*, T*, T*, double*); \
   template void K<T>::q_axpy(hipStream_t, long long, T*, const T*, T);                                               \
+  template void K<T>::q_update_mk(hipStream_t, const Grid&, const CdsArgs&, const MkArgs<T>&, T*);                    \
   template void K<T>::sq_spmv(hipStream_t, const Grid&, const StencilQ<T>&, const T*, T*);                           \
   template void K<T>::sq_spmv_dot(hipStream_t, const Grid&, const StencilQ<T>&, const T*, T*, double*,               \
                                   const CgState<T>*);                                                                 \

@@ -58,7 +58,7 @@ __global__ __launch_bounds__(BLOCK) void k_pass(Grid G, SetArgs<T> a, int v_is_s
   if (MODE == M_FIRST && a.prox == PX_L1 && !(a.flags & F_NOSPEC)) { r_lo = ps->spec_lo; r_hi = ps->spec_hi; }
   if (MODE == M_COMPACT) { r_lo = ps->lo; r_hi = ps->hi; }
   const bool gather = r_hi > r_lo;
-  T vmax = T(0);
+  T vmax = T(0), vminp = (T)INFINITY;     // largest magnitude, smallest non-zero magnitude
   if (MODE == M_FIRST || MODE == M_COMPACT) {
     if (threadIdx.x == 0) { scnt = 0; sused = 0; sovf = 0; }
     __syncthreads();
@@ -73,6 +73,7 @@ __global__ __launch_bounds__(BLOCK) void k_pass(Grid G, SetArgs<T> a, int v_is_s
     if (MODE == M_FIRST || MODE == M_PROBE) {
       pa.add(av, x);
       vmax = av > vmax ? av : vmax;
+      if (MODE == M_FIRST) vminp = (av > T(0) && av < vminp) ? av : vminp;
     }
     if (MODE == M_COMPACT && ad > r_hi) {
       acc[0] += ad;
@@ -166,7 +167,10 @@ __global__ __launch_bounds__(BLOCK) void k_pass(Grid G, SetArgs<T> a, int v_is_s
   if (MODE == M_FIRST || MODE == M_PROBE) {
     pa.to_slots(acc);
     block_reduce_store<PREP_SLOTS>(acc, partials, 0);
-    if (MODE == M_FIRST) block_max_store<T>(vmax, maxpart);
+    if (MODE == M_FIRST) {
+      block_max_store<T>(vmax, maxpart);
+      block_min_store<T>(vminp, maxpart + NB);      // second half of the array
+    }
   } else if (MODE == M_COMPACT) {
     double a2[2] = {acc[0], acc[1]};
     block_reduce_store<2>(a2, partials, SL_ABOVE_S);
@@ -256,16 +260,23 @@ __global__ __launch_bounds__(1024) void k_decide(const double* __restrict__ part
   __shared__ double red[PREP_SLOTS];
   __shared__ T smax[16];
   reduce_slots(partials, red);
-  T vmax = T(0);
+  __shared__ T smin[16];
+  T vmax = T(0), vmin = (T)INFINITY;
   if (STAGE == 0) {
-    for (int i = threadIdx.x; i < NB; i += 1024) vmax = maxpart[i] > vmax ? maxpart[i] : vmax;
+    for (int i = threadIdx.x; i < NB; i += 1024) {
+      vmax = maxpart[i] > vmax ? maxpart[i] : vmax;
+      const T mn = maxpart[NB + i];                 // 0 = slot of a workgroup that was not launched (grid of NB_7)
+      vmin = (mn > T(0) && mn < vmin) ? mn : vmin;
+    }
     vmax = wave_max<T>(vmax);
-    if ((threadIdx.x & 63) == 0) smax[threadIdx.x >> 6] = vmax;
+    vmin = -wave_max<T>(-vmin);
+    if ((threadIdx.x & 63) == 0) { smax[threadIdx.x >> 6] = vmax; smin[threadIdx.x >> 6] = vmin; }
   }
   __syncthreads();
   if (threadIdx.x != 0) return;
   if (STAGE == 0) {
-    for (int i = 0; i < 16; ++i) vmax = smax[i] > vmax ? smax[i] : vmax;
+    for (int i = 0; i < 16; ++i) { vmax = smax[i] > vmax ? smax[i] : vmax; vmin = smin[i] < vmin ? smin[i] : vmin; }
+    ps->vmin = vmin;
     ps->asum = red[0];
     ps->sumsq = red[1];
     ps->vmax = vmax;
@@ -356,7 +367,7 @@ __global__ __launch_bounds__(1024) void k_decide(const double* __restrict__ part
 // Then prepares the next call: probes and speculative range centred on the new theta.
 template <typename T>
 __global__ __launch_bounds__(1024) void k_l1_solve(ProjScalars<T>* ps, T radius, const T* __restrict__ compact,
-                                                   const double* __restrict__ partials) {
+                                                   const double* __restrict__ partials, long long true_len) {
   __shared__ double ssum[16];
   __shared__ double scnt[16];
   __shared__ double sh_theta, sh_sa, sh_ca;
@@ -407,6 +418,7 @@ __global__ __launch_bounds__(1024) void k_l1_solve(ProjScalars<T>* ps, T radius,
         if (tot > 0) tn = (sa + S - b) / tot;
         sh_done = (Cc == cprev || !(tot > 0)) ? 1 : 0;
         sh_theta = tn > theta ? tn : theta;
+        sh_sa = sa; sh_ca = tot;                     // sh_ca: size of the active set at the last evaluated theta
         scnt[0] = Cc;
       }
       __syncthreads();
@@ -418,6 +430,11 @@ __global__ __launch_bounds__(1024) void k_l1_solve(ProjScalars<T>* ps, T radius,
   }
   if (threadIdx.x == 0) {
     if (need) {
+      // The reference's scan `while u[rho+1] > (sv[rho+1]-b)/(rho+1) && rho+1 < lv` (project_l1_Duchi!.jl:42) never lets
+      // the active set reach the whole vector: when every entry would stay active it stops at lv-1 and thresholds with
+      // theta = (||v||_1 - min|v| - b) / (lv - 1).  Replicated (all entries active => none is zero => the smallest
+      // non-zero magnitude of the first pass is min|v|).
+      if (sh_ca >= (double)true_len && true_len > 1) theta = (ps->asum - (double)ps->vmin - (double)radius) / (double)(true_len - 1);
       const T th = (T)theta;
       ps->theta = th > T(0) ? th : T(0);       // theta = max(0, .)   project_l1_Duchi!.jl:46
     }
@@ -602,7 +619,7 @@ static void launch_chain(hipStream_t s, const Grid& g, const SetArgs<T>& a, int 
       hipLaunchKernelGGL((k_decide<T, 1>), dim3(1), dim3(1024), 0, s, partials, maxpart, ps, a.prox, a.plo, a.phi, true_len, 0);
     }
     SIPX_PASS(M_COMPACT);
-    hipLaunchKernelGGL((k_l1_solve<T>), dim3(1), dim3(1024), 0, s, ps, a.phi, compact, partials);
+    hipLaunchKernelGGL((k_l1_solve<T>), dim3(1), dim3(1024), 0, s, ps, a.phi, compact, partials, true_len);
   }
 #undef SIPX_PASS
   SIPX_HIP(hipGetLastError());

@@ -358,7 +358,8 @@ __global__ __launch_bounds__(BLOCK) void k_log3(long long N, const T* __restrict
   double acc[3] = {0, 0, 0};
   const long long nvec = N / V;
   for (long long vi = (long long)blockIdx.x * BLOCK + threadIdx.x; vi < nvec; vi += (long long)gridDim.x * BLOCK) {
-    const Vec<T, V> xv = ldv<T, V>(x + vi * V), mv = ldv<T, V>(m + vi * V), ov = ldv<T, V>(xold + vi * V);
+    const Vec<T, V> xv = ldv<T, V>(x + vi * V), ov = ldv<T, V>(xold + vi * V);
+    const Vec<T, V> mv = m ? ldv<T, V>(m + vi * V) : xv;        // m == nullptr: only the evol_x sums are wanted
 #pragma unroll
     for (int k = 0; k < V; ++k) {
       const T d = xv.v[k] - mv.v[k], e = ov.v[k] - xv.v[k];
@@ -375,6 +376,18 @@ void K<T>::log3(hipStream_t s, long long N, const T* x, const T* m, const T* xol
     hipLaunchKernelGGL((k_log3<T, 4>), dim3(NB), dim3(BLOCK), 0, s, N, x, m, xold, partials);
   else
     hipLaunchKernelGGL((k_log3<T, 1>), dim3(NB), dim3(BLOCK), 0, s, N, x, m, xold, partials);
+  SIPX_HIP(hipGetLastError());
+}
+
+// w = u + v (Minkowski mode: TD_OP_sum[i] * x = A (u + v))
+template <typename T>
+__global__ __launch_bounds__(BLOCK) void k_sum_uv(long long N, const T* __restrict__ u, const T* __restrict__ v,
+                                                  T* __restrict__ w) {
+  for (long long e = (long long)blockIdx.x * BLOCK + threadIdx.x; e < N; e += (long long)gridDim.x * BLOCK) w[e] = u[e] + v[e];
+}
+template <typename T>
+void K<T>::sum_uv(hipStream_t s, long long N, const T* u, const T* v, T* w) {
+  hipLaunchKernelGGL((k_sum_uv<T>), dim3(NB), dim3(BLOCK), 0, s, N, u, v, w);
   SIPX_HIP(hipGetLastError());
 }
 
@@ -441,6 +454,7 @@ void resample_nn(hipStream_t s, const long long* nc, const long long* nf, const 
 
 #define SIPX_INST(T)                                                                                              \
   template void resample_nn<T>(hipStream_t, const long long*, const long long*, const T*, T*);                   \
+  template void K<T>::sum_uv(hipStream_t, long long, const T*, const T*, T*);                                      \
   template void K<T>::rhs_compose(hipStream_t, const Grid&, const RhsArgs<T>&, T*, int);                         \
   template void K<T>::yl(hipStream_t, const Grid&, const SetArgs<T>&, double*);                                  \
   template void K<T>::adj_norm(hipStream_t, const Grid&, const SetArgs<T>&, double*);                            \

@@ -56,6 +56,7 @@ struct ProjScalars {
   double asum;        // ||v||_1
   double sumsq;       // ||v||_2^2
   T vmax;             // max |v|
+  T vmin;             // smallest non-zero |v| (only meaningful when every entry is active, see k_l1_solve)
   int need;           // 1: outside the set, threshold/scale below is active
   T theta;            // l1: soft threshold
   T scale;            // l2 / annulus: multiplier
@@ -99,6 +100,21 @@ struct SetArgs {
 
 // One changed set of a fused Q update: Q[:,col(off_j)] += alpha * AtA_i[:,j] (CDS_scaled_add!.jl:16-22).
 // ata == nullptr: the band values of A_i'A_i are regenerated from the operator descriptor.
+// Minkowski mode (PARSDMM_precompute_distribute_Minkowski.jl): unknowns x = [u; v], every operator is one block row
+// [A 0] (component 1), [0 A] (component 2) or [A A] (component 3, also the distance term [I I]).
+template <typename T>
+struct MkSet {
+  T alpha;
+  int nblk, comp;
+  int dir[3];
+  T ih[3];
+};
+template <typename T>
+struct MkArgs {
+  int nsets;
+  MkSet<T> s[MAX_SETS];
+};
+
 template <typename T>
 struct QSet {
   T alpha;
@@ -173,6 +189,8 @@ struct K {
   static void fwd(hipStream_t s, const Grid& g, int nblk, const int* dir, const T* ih, const T* x, T* out);
   static void adj(hipStream_t s, const Grid& g, int nblk, const int* dir, const T* ih, const T* v, T* out);
   static void log3(hipStream_t s, long long N, const T* x, const T* m, const T* xold, double* partials);
+  static void q_update_mk(hipStream_t s, const Grid& g, const CdsArgs& q, const MkArgs<T>& a, T* Q);
+  static void sum_uv(hipStream_t s, long long N, const T* u, const T* v, T* w);
   static void fin_sum(hipStream_t s, const double* partials, int nslots, double* out_dev, double* out_host);
   // Scalars of the two-pass projectors (l1 threshold, l2 / annulus scale) of a vector that is either
   // produced on the fly by a set (v = x_hat - l/rho, or s = A x when v_is_s) or stored in an array.

@@ -150,6 +150,25 @@ __device__ __forceinline__ void block_max_store(T vmax, T* __restrict__ maxpart)
   }
 }
 
+// Per-block min of a positive value (INFINITY = none) -> minpart[blockIdx.x].
+template <typename T>
+__device__ __forceinline__ void block_min_store(T vmin, T* __restrict__ minpart) {
+  __shared__ T smin[BLOCK / 64];
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    const T o = __shfl_xor(vmin, off, 64);
+    vmin = o < vmin ? o : vmin;
+  }
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) smin[threadIdx.x >> 6] = vmin;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    T m = smin[0];
+    for (int i = 1; i < BLOCK / 64; ++i) m = smin[i] < m ? smin[i] : m;
+    minpart[blockIdx.x] = m;
+  }
+}
+
 // First-pass reductions of the two-pass projectors, kept cheap: sums in float64, counts in 32-bit
 // integers, threshold compares in the working precision (thresholds are stored TF-rounded).
 // Slot layout of the block partials: 0 ||v||_1, 1 ||v||_2^2, 2 nnz, 3.. S_k = sum(|v| > t_k),

@@ -53,7 +53,7 @@ class _SetDesc(C.Structure):
     _fields_ = [("op", C.c_int32), ("proj", C.c_int32), ("pmin", C.c_double), ("pmax", C.c_double),
                 ("lb", C.c_void_p), ("ub", C.c_void_p), ("ncvx", C.c_int32), ("reserved", C.c_int32),
                 ("mode", C.c_int32), ("dir", C.c_int32), ("basis", C.c_void_p), ("basis_rows", C.c_int64),
-                ("basis_cols", C.c_int32), ("basis_orth", C.c_int32)]
+                ("basis_cols", C.c_int32), ("basis_orth", C.c_int32), ("component", C.c_int32), ("pad_", C.c_int32)]
 
 
 class _Options(C.Structure):
@@ -208,7 +208,7 @@ def _grid(comp_grid):
 class TDOperator:
     """Matrix-free stand-in for the SparseMatrixCSC a difference/identity TD_OP is in the reference."""
 
-    def __init__(self, kind: str, comp_grid, TF, adjoint=False):
+    def __init__(self, kind: str, comp_grid, TF, adjoint=False, component=0):
         if kind not in OPS:
             raise SipxError("provided an unknown transform domain operator. check function "
                             "get_TD_operator(comp_grid,TD_type,TF) for options")
@@ -222,16 +222,28 @@ class TDOperator:
             dirs = {"D_x": [0], "D_y": [1], "D_z": [len(n) - 1], "TV": list(range(len(n))), "D2D": list(range(len(n))),
                     "D3D": list(range(len(n)))}[kind]
             rows = sum(N // n[a] * (n[a] - 1) for a in dirs)
-        self.shape = (N, rows) if adjoint else (rows, N)
+        # Minkowski block rows [A 0] (1), [0 A] (2), [A A] (3) act on [u; v]  (PARSDMM_precompute_distribute_Minkowski.jl:91-103)
+        self.component = int(component)
+        cols = 2 * N if self.component else N
+        self.shape = (cols, rows) if adjoint else (rows, cols)
 
     @property
     def T(self):
-        return TDOperator(self.kind, self.comp_grid, self.TF, not self.adjoint)
+        return TDOperator(self.kind, self.comp_grid, self.TF, not self.adjoint, self.component)
 
     def __matmul__(self, v):
         v = np.ascontiguousarray(v, dtype=self.TF)
         if v.shape != (self.shape[1],):
             raise SipxError("dimension mismatch")
+        if self.component:
+            plain = TDOperator(self.kind, self.comp_grid, self.TF, self.adjoint)
+            N = int(np.prod(self.n))
+            if self.adjoint:
+                t = plain @ v
+                z = np.zeros(N, self.TF)
+                return np.concatenate([t if self.component in (1, 3) else z, t if self.component in (2, 3) else z])
+            u, w = v[:N], v[N:]
+            return plain @ (u if self.component == 1 else (w if self.component == 2 else (u + w).astype(self.TF)))
         out = np.empty(self.shape[0], self.TF)
         ctx = Context(self.comp_grid, self.TF)
         try:
@@ -422,6 +434,38 @@ def PARSDMM_precompute_distribute(TD_OP, set_Prop, comp_grid, options):
     return TD_OP, AtA, l, y
 
 
+def PARSDMM_precompute_distribute_Minkowski(TD_OP_c1, TD_OP_c2, TD_OP_sum, set_Prop_c1, set_Prop_c2, set_Prop_sum,
+                                           comp_grid, options):
+    """src/PARSDMM_precompute_distribute_Minkowski.jl:6-173 -> (TD_OP, set_Prop, AtA, l, y): the operators become the
+    block rows [A 0], [0 A], [A A] acting on x = [u; v], the distance term [I I] is appended; AtA[i] = None (the 2N x 2N
+    CDS bands are generated on the device)."""
+    import copy
+    TF = np.dtype(options.FL).type
+    n, _ = _grid(comp_grid)
+    groups = ((TD_OP_c1, 1), (TD_OP_c2, 2), (TD_OP_sum, 3))
+    TD_OP = [TDOperator(A.kind, comp_grid, TF, component=c) for ops, c in groups for A in ops]
+    prop = copy.deepcopy(set_Prop_c1)
+    for other in (set_Prop_c2, set_Prop_sum):
+        for f in ("AtA_diag", "AtA_offsets", "TD_n", "banded", "dense", "ncvx", "tag"):
+            getattr(prop, f).extend(copy.deepcopy(getattr(other, f)))
+    if not options.feasibility_only:
+        TD_OP.append(TDOperator("identity", comp_grid, TF, component=3))
+        prop.TD_n.append(n); prop.AtA_offsets.append(np.array([0], np.int64))
+        prop.banded.append(True); prop.AtA_diag.append(False); prop.dense.append(False)
+        prop.ncvx.append(False); prop.tag.append(("distance squared", "identity", "matrix", ""))
+    s = len(TD_OP)
+    N = int(np.prod(n))
+    for i in range(s):
+        kind, comp = TD_OP[i].kind, TD_OP[i].component
+        dirs = {"identity": [], "D_x": [0], "D_y": [1], "D_z": [len(n) - 1]}.get(kind, list(range(len(n))))
+        base = sorted({0} | {int(np.prod(n[:a])) for a in dirs} | {-int(np.prod(n[:a])) for a in dirs})
+        off = sorted({o + sh for o in base for sh in (-N, 0, N)}) if comp == 3 else base
+        prop.AtA_offsets[i] = np.array(off, np.int64)
+    y = [np.zeros(TD_OP[i].shape[0], TF) for i in range(s)]
+    l = [np.zeros(TD_OP[i].shape[0], TF) for i in range(s)]
+    return TD_OP, prop, [None] * s, l, y
+
+
 # --------------------------------------------------------------------------------------------------
 # engine handle (phase-level API, include/sipx.h section A)
 # --------------------------------------------------------------------------------------------------
@@ -431,6 +475,7 @@ class Context:
         self.TF = np.dtype(TF).type
         n, h = _grid(comp_grid)
         self.n, self.N = n, int(np.prod(n))
+        self.Nx = self.N                         # unknowns: 2N once a Minkowski component is added
         self.h = C.c_void_p()
         na = (C.c_int64 * len(n))(*n)
         ha = (C.c_double * len(n))(*h)
@@ -453,6 +498,9 @@ class Context:
     def add_set(self, op: TDOperator, proj: Projector, ncvx=False, AtA=None, AtA_offsets=None) -> int:
         proj.check_rows(op)
         d = proj.desc(op.kind, ncvx)
+        d.component = int(getattr(op, "component", 0))
+        if d.component:
+            self.Nx = 2 * self.N
         self._keep.append(proj)
         if AtA is not None:
             R = np.asfortranarray(AtA, dtype=self.TF)
@@ -474,8 +522,8 @@ class Context:
 
     def apply_Q(self, x):
         x = np.ascontiguousarray(x, self.TF)
-        if x.shape != (self.N,):
-            raise SipxError("length of x does not match the grid")
+        if x.shape != (self.Nx,):
+            raise SipxError("length of x does not match the number of unknowns")
         y = np.empty_like(x)
         _chk(lib().sipx_apply_Q(self.h, _ptr(x), _ptr(y)))
         return y
@@ -510,7 +558,7 @@ class Context:
                 ptrs[i] = a.ctypes.data
             return ptrs
         x0a = None if x0 is None else np.ascontiguousarray(x0, self.TF)
-        if x0a is not None and x0a.shape != (self.N,):
+        if x0a is not None and x0a.shape != (self.Nx,):
             raise SipxError("length of x does not match the grid")
         _chk(lib().sipx_finalize(self.h, _ptr(m), rho.ctypes.data_as(C.c_void_p), len(rho), C.c_double(gamma_ini),
                                  int(feasibility_only), int(zero_ini_guess), _ptr(x0a), arr_list(l0), arr_list(y0),
@@ -556,7 +604,7 @@ class Context:
         _chk(lib().sipx_q_update(self.h, a.ctypes.data_as(C.c_void_p), b.ctypes.data_as(C.c_void_p)))
 
     def download(self, want_ly=True):
-        x = np.empty(self.N, self.TF)
+        x = np.empty(self.Nx, self.TF)
         l = [np.zeros(r, self.TF) for r in self.rows] if want_ly else None
         y = [np.zeros(r, self.TF) for r in self.rows] if want_ly else None
 
@@ -574,7 +622,7 @@ class Context:
         d = C.c_int()
         offs = np.zeros(32, np.int64)
         _chk(lib().sipx_get_Q(self.h, None, offs.ctypes.data_as(C.c_void_p), C.byref(d)))
-        Q = np.empty((self.N, d.value), self.TF, order="F")
+        Q = np.empty((self.Nx, d.value), self.TF, order="F")
         _chk(lib().sipx_get_Q(self.h, _ptr(Q), offs.ctypes.data_as(C.c_void_p), C.byref(d)))
         return Q, offs[:d.value].copy()
 
@@ -658,8 +706,9 @@ def build_context(m, AtA, TD_OP, set_Prop, P_sub, comp_grid, options, x=None, l=
             ctx.set_owned(owned)
         ctx.set_q_mode(getattr(options, "Q_mode", "cds"))
         rho_ini = [float(TF(r)) for r in options.rho_ini]                # convert_options!.jl:6-15
+        zero = bool(options.zero_ini_guess)                               # x, l, y are zero-filled then (PARSDMM_initialize.jl:304-313)
         feas0 = ctx.finalize(m, rho_ini, float(TF(options.gamma_ini)), options.feasibility_only,
-                             options.zero_ini_guess, x, l, y)
+                             zero, None if zero else x, None if zero else l, None if zero else y)
         ctx.feasibility_initial = feas0
     except Exception:
         ctx.close()
@@ -675,7 +724,7 @@ def PARSDMM(m, AtA, TD_OP, set_Prop, P_sub, comp_grid, options, x=None, l=None, 
         xo, lo, yo = ctx.download()
     finally:
         ctx.close()
-    if x is not None:
+    if x is not None and len(x) == len(xo):
         x[:] = xo                         # the reference overwrites the x argument in place
         xo = x
     return xo, log, lo, yo

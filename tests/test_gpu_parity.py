@@ -91,6 +91,8 @@ def _problem(mod, n, h, TF, kinds, m, opt_kw=None):
         elif k.startswith("rank:"):
             mode = ("matrix", "") if len(n) == 2 else ("slice", "z")
             c.append(mod.set_definitions("rank", "identity", 0, int(k[5:]), mode))
+        elif k.startswith("l1id:"):           # l1 ball on the model itself: every entry stays active (lv-1 cap of the scan)
+            c.append(mod.set_definitions("l1", "identity", 0.0, float(k[5:]) * float(np.abs(m.astype(np.float64)).sum()), ("matrix", "")))
         elif k == "l2":
             nm = float(np.linalg.norm(m.astype(np.float64)))
             c.append(mod.set_definitions("l2", "identity", 0.0, 0.9 * nm, ("matrix", "")))
@@ -345,6 +347,7 @@ CASES = [
     ("3d-dft-l1", (16, 12, 8), (25.0, 25.0, 25.0), ["bounds", "l1dft"]),
     ("3d-slice-rank", (16, 12, 8), (25.0, 25.0, 25.0), ["bounds", "rank:3"]),
     ("2d-rank", (32, 24), (25.0, 6.0), ["bounds", "rank:4", "l1:TV"]),
+    ("2d-l1-identity-all-active", (32, 24), (25.0, 6.0), ["bounds", "l1id:0.9"]),
     ("3d-card-fiber-Dz", (16, 12, 8), (25.0, 25.0, 25.0), ["bounds", "cardf:D_z:fiber:x"]),
     ("3d-card-slice-Dy", (16, 12, 8), (25.0, 25.0, 25.0), ["bounds", "cardf:D_y:slice:z"]),
     ("3d-nuclear-slice-x", (16, 12, 8), (25.0, 25.0, 25.0), ["bounds", "nuc:x", "l1:D_z"]),
@@ -729,3 +732,96 @@ def test_subspace_projector(sipx, TF):
         assert close(_proj(sipx, "subspace", shp, TF, 0, 0, ("slice", d), (Mb, False))(X.reshape(-1, order="F").copy()), want), d
     with pytest.raises(sipx.SipxError, match="rows of A"):
         _proj(sipx, "subspace", (40, 5), TF, 0, 0, ("fiber", "z"), (M, False))(np.zeros(200, TF))
+
+
+# ---- Minkowski sets: x = [u; v], operators [A 0] / [0 A] / [A A]; parity unpinned in the reference
+# (no test exercises PARSDMM_precompute_distribute_Minkowski.jl), oracle == engine here --------------------------------
+def _minkowski_problem(mod, n, h, TF, m, maxit=40, feasibility_only=False):
+    g = mod.compgrid(h, n)
+    opt = mod.PARSDMM_options(FL=TF, maxit=maxit, feasibility_only=feasibility_only)
+    opt.Minkowski = True
+    Og = O.compgrid(h, n)
+    TV = O.get_TD_operator(Og, "TV", TF)[0]
+    Dz = O.get_TD_operator(Og, "D_z", TF)[0]
+    smooth = np.sort(m)      # not used as data, only to scale the radii
+    c1 = [mod.set_definitions("bounds", "identity", 1400.0, 4100.0, ("matrix", "")),
+          mod.set_definitions("l1", "TV", 0.0, float(0.25 * np.abs(TV @ m).sum()), ("matrix", ""))]
+    c2 = [mod.set_definitions("bounds", "identity", -300.0, 300.0, ("matrix", "")),
+          mod.set_definitions("l1", "identity", 0.0, float(0.02 * np.abs(m).sum()), ("matrix", ""))]
+    cs = [mod.set_definitions("bounds", "identity", 1600.0, 3900.0, ("matrix", "")),
+          mod.set_definitions("bounds", "D_z", float(0.5 * (Dz @ m).min()), float(0.5 * (Dz @ m).max()), ("matrix", ""))]
+    del smooth
+    P1, A1, p1 = mod.setup_constraints(c1, g, TF)
+    P2, A2, p2 = mod.setup_constraints(c2, g, TF)
+    P3, A3, p3 = mod.setup_constraints(cs, g, TF)
+    TD_OP, prop, AtA, l, y = mod.PARSDMM_precompute_distribute_Minkowski(A1, A2, A3, p1, p2, p3, g, opt)
+    return g, opt, P1 + P2 + P3, TD_OP, prop, AtA
+
+
+@pytest.mark.parametrize("TF", [np.float32, np.float64])
+@pytest.mark.parametrize("n,h", [((32, 24), (25.0, 6.0)), ((12, 10, 8), (25.0, 25.0, 25.0)), ((9, 7, 2), (1.0, 1.0, 1.0))])
+def test_minkowski_Q_bitexact(sipx, TF, n, h):
+    m = model(n, TF, seed=4)
+    go, oo, Po, Ao, propo, AtAo = _minkowski_problem(O, n, h, TF, m)
+    gs, os_, Ps, As, props, AtAs = _minkowski_problem(sipx, n, h, TF, m)
+    rho = [3.0, 0.5, 7.0, 11.0, 2.0, 1.5, 4.0]
+    os_.rho_ini = rho
+    assert all(np.array_equal(a, b) for a, b in zip(props.AtA_offsets, propo.AtA_offsets))
+    Qo, offo = O.assemble_Q(AtAo, propo.AtA_offsets, np.array(rho, TF), TF)
+    ctx = sipx.host.build_context(m, AtAs, As, props, Ps, gs, os_)
+    Q, off = ctx.get_Q()
+    assert np.array_equal(off, offo) and Q.shape == Qo.shape == (2 * m.size, len(offo))
+    assert np.array_equal(Q, Qo)
+    x = np.random.default_rng(1).standard_normal(2 * m.size).astype(TF)
+    assert np.array_equal(ctx.apply_Q(x), O.Ax_CDS(x, Qo, offo))
+    rho_new = [3.0, 0.25, 7.0, 12.5, 2.0, 1.0, 8.0]
+    ctx.q_update(rho_new, rho)
+    Q2, _ = ctx.get_Q()
+    ctx.close()
+
+    class L: pass
+    log = L(); log.rho = np.array([rho])
+    Qr = O.Q_update(Qo.copy(order="F"), AtAo, propo, np.array(rho_new, TF), [1, 3, 5, 6], log, 0, offo)
+    assert np.array_equal(Q2, Qr)
+
+
+@pytest.mark.parametrize("TF", [np.float32, np.float64])
+@pytest.mark.parametrize("n,h", [((32, 24), (25.0, 6.0)), ((12, 10, 8), (25.0, 25.0, 25.0))])
+def test_minkowski_parsdmm_matches_oracle(sipx, TF, n, h):
+    m = model(n, TF, seed=4)
+    go, oo, Po, Ao, propo, AtAo = _minkowski_problem(O, n, h, TF, m)
+    gs, os_, Ps, As, props, AtAs = _minkowski_problem(sipx, n, h, TF, m)
+    xo, lo, l_o, y_o = O.PARSDMM(m.copy(), AtAo, Ao, propo, Po, go, oo)
+    xs, ls, l_s, y_s = sipx.PARSDMM(m.copy(), AtAs, As, props, Ps, gs, os_)
+    assert xs.shape == xo.shape == (2 * m.size,)
+    K = min(6, len(lo.obj), len(ls.obj))
+    rt = 5e-4 if TF == np.float32 else 1e-8
+    assert np.array_equal(ls.cg_it[:K], lo.cg_it[:K])
+    for f in ("obj", "evol_x", "r_pri_total", "r_dual_total", "rho", "gamma"):
+        a, b = np.asarray(getattr(ls, f))[1:K], np.asarray(getattr(lo, f))[1:K]
+        assert np.allclose(a, b, rtol=rt, atol=1e-12), (f, a, b)
+    assert np.allclose(ls.set_feasibility[0], lo.set_feasibility[0], rtol=rt)
+    scale = np.linalg.norm(xo[:m.size] + xo[m.size:])
+    err = np.linalg.norm(xs.astype(np.float64) - xo) / scale
+    assert err < (5e-4 if TF == np.float32 else 1e-6), err
+    assert [len(v) for v in y_s] == [len(v) for v in y_o]
+    # warm restart from the result: x0 carries both components
+    os_.zero_ini_guess = False; oo.zero_ini_guess = False
+    os_.maxit = oo.maxit = 5
+    x2o, l2o, _, _ = O.PARSDMM(m.copy(), AtAo, Ao, propo, Po, go, oo, xo.copy(), l_o, y_o)
+    x2s, l2s, _, _ = sipx.PARSDMM(m.copy(), AtAs, As, props, Ps, gs, os_, xs.copy(), l_s, y_s)
+    assert np.linalg.norm(x2s.astype(np.float64) - x2o) / scale < (1e-3 if TF == np.float32 else 1e-5)
+
+
+@pytest.mark.parametrize("TF", [np.float32, np.float64])
+def test_l1_projector_when_every_entry_stays_active(sipx, TF):
+    # project_l1_Duchi!.jl:42: the scan stops at lv-1, so theta = (||v||_1 - min|v| - b)/(lv-1) when nothing is zeroed
+    rng = np.random.default_rng(31)
+    for M in (5, 64, 1000):
+        v = (rng.uniform(2.0, 3.0, M) * rng.choice([-1.0, 1.0], M)).astype(TF)
+        b = 0.8 * float(np.abs(v.astype(np.float64)).sum())
+        want = O.project_l1_Duchi(v.copy(), TF(b))
+        c = sipx.set_definitions("l1", "identity", 0.0, b, ("matrix", ""))
+        got = sipx.host.Projector(c, sipx.compgrid((1.0, 1.0), (M, 1)), TF)(v.copy())
+        assert np.count_nonzero(want) >= M - 1
+        assert np.allclose(got, want, rtol=(2e-5 if TF == np.float32 else 1e-12), atol=0), M
