@@ -825,3 +825,95 @@ def test_l1_projector_when_every_entry_stays_active(sipx, TF):
         got = sipx.host.Projector(c, sipx.compgrid((1.0, 1.0), (M, 1)), TF)(v.copy())
         assert np.count_nonzero(want) >= M - 1
         assert np.allclose(got, want, rtol=(2e-5 if TF == np.float32 else 1e-12), atol=0), M
+
+
+# ---- BASELINE.json full sizes: size-independent properties (no oracle run at these sizes) -------------------------------
+def _c3_problem(sipx, n, TF, q_mode="cds", maxit=12, rho=None):
+    h = (25.0,) * len(n)
+    rng = np.random.default_rng(20240601 + 3)
+    z = np.linspace(0.0, 1.0, n[-1]).reshape((1,) * (len(n) - 1) + (-1,))
+    m = (1500.0 + 2500.0 * z + 150.0 * rng.standard_normal(n)).astype(TF).reshape(-1, order="F")
+    g = sipx.compgrid(h, n)
+    ops = ("D_x", "D_y", "D_z") if len(n) == 3 else ("TV",)
+    c = [sipx.set_definitions("bounds", "identity", 1600.0, 3900.0, ("matrix", ""))]
+    for k in ops:
+        s = sipx.get_TD_operator(g, k, TF)[0] @ m
+        c.append(sipx.set_definitions("l1", k, 0.0, float(0.5 * np.abs(s.astype(np.float64)).sum()), ("matrix", "")))
+    P, A, prop = sipx.setup_constraints(c, g, TF)
+    opt = sipx.PARSDMM_options(FL=TF, maxit=maxit)
+    opt.Q_mode = q_mode
+    if rho is not None:
+        opt.rho_ini = rho
+    A, AtA, l, y = sipx.PARSDMM_precompute_distribute(A, prop, g, opt)
+    return m, g, opt, P, A, prop, AtA
+
+
+@pytest.mark.parametrize("n", [(256, 256, 256), (2048, 2048)])
+def test_full_size_Q_properties(sipx, n):
+    # BASELINE configs[2] / configs[1]: Q = sum rho_i A_i'A_i is symmetric, annihilates constants up to the identity
+    # sets' share, and its CDS and stencil forms agree
+    TF = np.float32
+    p = len(n) + 2
+    rho = [3.0, 0.5, 7.0, 11.0, 2.0][:p] if len(n) == 3 else [3.0, 0.5, 2.0]
+    out = {}
+    rng = np.random.default_rng(7)
+    N = int(np.prod(n))
+    x = rng.standard_normal(N).astype(TF); y = rng.standard_normal(N).astype(TF)
+    for mode in ("cds", "stencil"):
+        m, g, opt, P, A, prop, AtA = _c3_problem(sipx, n, TF, mode, rho=rho)
+        ctx = sipx.host.build_context(m, AtA, A, prop, P, g, opt)
+        Qx, Qy, Q1 = ctx.apply_Q(x), ctx.apply_Q(y), ctx.apply_Q(np.ones(N, TF))
+        ctx.close()
+        out[mode] = Qx
+        sym = abs(np.dot(Qx.astype(np.float64), y) - np.dot(x.astype(np.float64), Qy))
+        assert sym <= 1e-5 * np.linalg.norm(Qx.astype(np.float64)) * np.linalg.norm(y.astype(np.float64))
+        w0 = rho[0] + rho[-1]                                   # identity sets: bounds and the distance term
+        assert np.abs(Q1 - w0).max() <= 1e-4 * max(rho)         # difference operators annihilate constants
+    d = np.abs(out["cds"].astype(np.float64) - out["stencil"]).max()
+    assert d <= 32 * np.finfo(TF).eps * np.abs(out["cds"]).max()
+
+
+def test_full_size_c3_solver_properties(sipx):
+    # BASELINE configs[2], 256^3 Float32: finite logs, zero-start conventions, feasibility improves, x stays within the
+    # bounds' reach, warm restart continues the solve, a feasible model is returned untouched
+    TF, n = np.float32, (256, 256, 256)
+    m, g, opt, P, A, prop, AtA = _c3_problem(sipx, n, TF, maxit=30)
+    x, log, l, y = sipx.PARSDMM(m.copy(), AtA, A, prop, P, g, opt)
+    it = len(log.obj)
+    assert it == 30 or it > 6
+    assert np.isfinite(log.obj).all() and np.isfinite(log.r_pri).all() and np.isfinite(log.r_dual).all()
+    assert np.isnan(log.evol_x[0]) and log.cg_it[0] == 0 and (log.cg_it[1:] >= 1).all() and log.cg_it.max() < 20
+    assert log.r_pri.shape == (it, 5) and log.set_feasibility.shape[1] == 4
+    f0, f1 = log.set_feasibility[0], log.set_feasibility[min(2, len(log.set_feasibility) - 2)]
+    assert (f1[1:] < f0[1:]).all()                                  # the three l1 sets get closer to feasible
+    assert [len(v) for v in y] == [op.shape[0] for op in A]
+    assert np.isfinite(x).all() and x.min() > 1000 and x.max() < 4500
+    # projector idempotence at full size: the l1 projection of y_2 (already inside its ball) changes nothing
+    assert np.array_equal(P[1](y[1].copy()), y[1]) or np.abs(y[1]).sum() > float(P[1].pmax)
+    # a model that is feasible for every set comes back untouched (PARSDMM.jl:63-82)
+    flat = np.full(m.size, 2500.0, TF)
+    xf, logf, _, _ = sipx.PARSDMM(flat.copy(), AtA, A, prop, P, g, opt)
+    assert np.array_equal(xf, flat) and len(logf.obj) == 1
+
+
+@pytest.mark.parametrize("TF", [np.float32])
+def test_full_size_projector_properties(sipx, TF):
+    # 256^3 entries: l1 norm equals the radius, cardinality keeps exactly k entries, both are idempotent
+    rng = np.random.default_rng(11)
+    M = 256 ** 3
+    v = rng.standard_normal(M).astype(TF)
+    b = 0.234 * float(np.abs(v.astype(np.float64)).sum())
+    g1 = sipx.compgrid((1.0, 1.0), (M, 1))
+    Pl1 = sipx.host.Projector(sipx.set_definitions("l1", "identity", 0.0, b, ("matrix", "")), g1, TF)
+    w = Pl1(v.copy())
+    assert abs(float(np.abs(w.astype(np.float64)).sum()) - b) <= 2e-6 * b          # test_projectors.jl:27-29
+    assert np.array_equal(np.sign(w[w != 0]), np.sign(v[w != 0]))
+    w2 = Pl1(w.copy())
+    assert np.abs(w2 - w).max() <= 1e-6 * np.abs(w).max()
+    k = M // 10
+    Pc = sipx.host.Projector(sipx.set_definitions("cardinality", "identity", 0, k, ("matrix", "")), g1, TF)
+    u = Pc(v.copy())
+    assert np.count_nonzero(u) == k                                               # test_projectors.jl:44-46
+    kept = u != 0
+    assert np.abs(v[~kept]).max() <= np.abs(v[kept]).min() and np.array_equal(u[kept], v[kept])
+    assert np.array_equal(Pc(u.copy()), u)
