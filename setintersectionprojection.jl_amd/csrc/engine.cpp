@@ -1206,16 +1206,38 @@ class Engine : public EngineBase {
           }
     }
   }
+  // Import / export between the reference's row order (host) and the padded layout (device): one contiguous PCIe
+  // copy plus a device gather / scatter per operator block (the pads keep the zeros they were allocated with).
   void upload_rows(const SetState<T>& s, const T* rows, T* dev) const {
-    std::vector<T> pad((size_t)s.Mpad, T(0));
-    for_rows(s, [&](long long r, long long e) { pad[e] = rows[r]; });
-    SIPX_HIP(hipMemcpy(dev, pad.data(), pad.size() * sizeof(T), hipMemcpyHostToDevice));
+    if (s.ident) {
+      SIPX_HIP(hipMemcpy(dev, rows, (size_t)G_.N * sizeof(T), hipMemcpyHostToDevice));
+      return;
+    }
+    T* tmp = dalloc<T>(s.Mtrue, false);
+    SIPX_HIP(hipMemcpy(tmp, rows, (size_t)s.Mtrue * sizeof(T), hipMemcpyHostToDevice));
+    long long r0 = 0;
+    for (int q = 0; q < s.nblk; ++q) {
+      K<T>::rows_unpack(stream_, G_, s.dir[q], s.blk_rows[q], tmp + r0, dev + (long long)q * G_.N);
+      r0 += s.blk_rows[q];
+    }
+    SIPX_HIP(hipStreamSynchronize(stream_));
+    dfree(tmp);
   }
   void download_rows(const SetState<T>& s, const T* dev, T* rows) const {
-    std::vector<T> pad((size_t)s.Mpad);
     SIPX_HIP(hipStreamSynchronize(stream_));
-    SIPX_HIP(hipMemcpy(pad.data(), dev, pad.size() * sizeof(T), hipMemcpyDeviceToHost));
-    for_rows(s, [&](long long r, long long e) { rows[r] = pad[e]; });
+    if (s.ident) {
+      SIPX_HIP(hipMemcpy(rows, dev, (size_t)G_.N * sizeof(T), hipMemcpyDeviceToHost));
+      return;
+    }
+    T* tmp = dalloc<T>(s.Mtrue, false);
+    long long r0 = 0;
+    for (int q = 0; q < s.nblk; ++q) {
+      K<T>::rows_pack(stream_, G_, s.dir[q], s.blk_rows[q], dev + (long long)q * G_.N, tmp + r0);
+      r0 += s.blk_rows[q];
+    }
+    SIPX_HIP(hipStreamSynchronize(stream_));
+    SIPX_HIP(hipMemcpy(rows, tmp, (size_t)s.Mtrue * sizeof(T), hipMemcpyDeviceToHost));
+    dfree(tmp);
   }
 
   void resolve_timing(sipx_log* log, int set) {

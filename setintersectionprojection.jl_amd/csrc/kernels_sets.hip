@@ -379,6 +379,32 @@ void K<T>::log3(hipStream_t s, long long N, const T* x, const T* m, const T* xol
   SIPX_HIP(hipGetLastError());
 }
 
+// Reference row order <-> padded layout of one operator block (difference along `dir`, or dir < 0 for the identity):
+// row r = (i, j, k) column-major over the block's own extents (n with n[dir]-1) lives at padded entry i + n1 (j + n2 k).
+// PACK: rows[r] = pad[e];  otherwise pad[e] = rows[r] (the pads keep their zeros).
+template <typename T, bool PACK>
+__global__ __launch_bounds__(BLOCK) void k_rows(Grid G, int dir, long long nrows, T* __restrict__ rows, T* __restrict__ pad) {
+  long long d0 = G.n[0], d1 = G.n[1];
+  if (dir == 0) d0 -= 1;
+  if (dir == 1) d1 -= 1;
+  for (long long r = (long long)blockIdx.x * BLOCK + threadIdx.x; r < nrows; r += (long long)gridDim.x * BLOCK) {
+    const long long i = r % d0, t = r / d0, j = t % d1, k = t / d1;
+    const long long e = i + G.n[0] * (j + G.n[1] * k);
+    if (PACK) rows[r] = pad[e];
+    else pad[e] = rows[r];
+  }
+}
+template <typename T>
+void K<T>::rows_pack(hipStream_t s, const Grid& g, int dir, long long nrows, const T* pad, T* rows) {
+  hipLaunchKernelGGL((k_rows<T, true>), dim3(NB), dim3(BLOCK), 0, s, g, dir, nrows, rows, const_cast<T*>(pad));
+  SIPX_HIP(hipGetLastError());
+}
+template <typename T>
+void K<T>::rows_unpack(hipStream_t s, const Grid& g, int dir, long long nrows, const T* rows, T* pad) {
+  hipLaunchKernelGGL((k_rows<T, false>), dim3(NB), dim3(BLOCK), 0, s, g, dir, nrows, const_cast<T*>(rows), pad);
+  SIPX_HIP(hipGetLastError());
+}
+
 // w = u + v (Minkowski mode: TD_OP_sum[i] * x = A (u + v))
 template <typename T>
 __global__ __launch_bounds__(BLOCK) void k_sum_uv(long long N, const T* __restrict__ u, const T* __restrict__ v,
@@ -455,6 +481,8 @@ void resample_nn(hipStream_t s, const long long* nc, const long long* nf, const 
 #define SIPX_INST(T)                                                                                              \
   template void resample_nn<T>(hipStream_t, const long long*, const long long*, const T*, T*);                   \
   template void K<T>::sum_uv(hipStream_t, long long, const T*, const T*, T*);                                      \
+  template void K<T>::rows_pack(hipStream_t, const Grid&, int, long long, const T*, T*);                           \
+  template void K<T>::rows_unpack(hipStream_t, const Grid&, int, long long, const T*, T*);                         \
   template void K<T>::rhs_compose(hipStream_t, const Grid&, const RhsArgs<T>&, T*, int);                         \
   template void K<T>::yl(hipStream_t, const Grid&, const SetArgs<T>&, double*);                                  \
   template void K<T>::adj_norm(hipStream_t, const Grid&, const SetArgs<T>&, double*);                            \

@@ -191,6 +191,8 @@ struct K {
   static void log3(hipStream_t s, long long N, const T* x, const T* m, const T* xold, double* partials);
   static void q_update_mk(hipStream_t s, const Grid& g, const CdsArgs& q, const MkArgs<T>& a, T* Q);
   static void sum_uv(hipStream_t s, long long N, const T* u, const T* v, T* w);
+  static void rows_pack(hipStream_t s, const Grid& g, int dir, long long nrows, const T* pad, T* rows);
+  static void rows_unpack(hipStream_t s, const Grid& g, int dir, long long nrows, const T* rows, T* pad);
   static void fin_sum(hipStream_t s, const double* partials, int nslots, double* out_dev, double* out_host);
   // Scalars of the two-pass projectors (l1 threshold, l2 / annulus scale) of a vector that is either
   // produced on the fly by a set (v = x_hat - l/rho, or s = A x when v_is_s) or stored in an array.
