@@ -1,0 +1,25 @@
+import sys, numpy as np
+sys.path.insert(0, '.')
+from __graft_entry__ import load_package
+sipx = load_package()
+import importlib
+spec = importlib.util.spec_from_file_location("tg", "tests/test_gpu_parity.py"); tg = importlib.util.module_from_spec(spec); spec.loader.exec_module(tg)
+TF = np.float32
+n = (256, 256, 256) if len(sys.argv) < 2 else tuple(int(v) for v in sys.argv[1].split("x"))
+m, g, opt, P, A, prop, AtA = tg._c3_problem(sipx, n, TF, maxit=40)
+opt.evol_rel_tol = opt.feas_tol = opt.obj_tol = 0.0
+ctx = sipx.host.build_context(m, AtA, A, prop, P, g, opt)
+ctx.parsdmm_begin(opt)
+prev = [0, 0, 0]
+for it in range(1, 36):
+    ctx.parsdmm_steps(1)
+    th = [ctx.debug_proj(s, 0) for s in (1, 2, 3)]
+    rho = ctx._run[2]["rho"][it - 1]
+    line = []
+    for k, d in enumerate(th):
+        t = d["theta"]
+        rel = (t / prev[k] - 1) if prev[k] > 0 else float("nan")
+        line.append("th %.3e (%+.3f) ok %d ov %d n %d hw %.0e" % (t, rel, d["spec_ok"], d["overflow"], d["gathered"], d["hw"]))
+        prev[k] = t if t > 0 else prev[k]
+    print(it, "rho", np.round(rho, 3), " | ".join(line), flush=True)
+ctx.close()

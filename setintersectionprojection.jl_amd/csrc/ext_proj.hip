@@ -255,6 +255,56 @@ __global__ void k_nuc_shrink(int kmin, int batch, double sigma, double* __restri
   flag[b] = 1;
 }
 
+// Gram route (Float32 models): W = ascending eigenvalues of X'X (or XX'), sigma_j = sqrt(W_j).  F_j = shrunk(sigma_j)/sigma_j
+// for the nuclear-norm ball (same scan as k_nuc_shrink on the descending values), flag[b] = 0 when slice b is inside it.
+__global__ void k_nuc_factors(int kmin, int batch, double sigma, const double* __restrict__ W, double* __restrict__ F,
+                              int* __restrict__ flag) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= batch) return;
+  const double* w = W + (long long)b * kmin;
+  double* f = F + (long long)b * kmin;
+  auto sv = [&](int j) {                     // j-th largest singular value
+    const double l = w[kmin - 1 - j];
+    return l > 0 ? sqrt(l) : 0.0;
+  };
+  double sum = 0;
+  for (int j = 0; j < kmin; ++j) sum += sv(j);
+  if (sum <= sigma) {
+    flag[b] = 0;
+    for (int j = 0; j < kmin; ++j) f[j] = 1.0;
+    return;
+  }
+  int rho = 0;
+  double cum = 0;
+  for (;;) {
+    const double nxt = cum + sv(rho);
+    if (sv(rho) > (nxt - sigma) / (double)(rho + 1) && rho + 1 < kmin) {
+      cum = nxt;
+      ++rho;
+    } else {
+      break;
+    }
+  }
+  if (rho == 0) { rho = 1; cum = sv(0); }
+  double theta = (cum - sigma) / (double)rho;
+  theta = theta > 0 ? theta : 0;
+  for (int j = 0; j < kmin; ++j) {           // f is indexed like W (ascending)
+    const double l = w[j], sg = l > 0 ? sqrt(l) : 0.0, t = sg - theta;
+    f[j] = (sg > 0 && t > 0) ? t / sg : 0.0;
+  }
+  flag[b] = 1;
+}
+// Gs[:, j] = G[:, j] * F[j] for every slice (k x k eigenvector matrices)
+__global__ __launch_bounds__(BLOCK) void k_scale_eigvecs(int k, int batch, const double* __restrict__ G, const double* __restrict__ F,
+                                                         double* __restrict__ Gs) {
+  const long long tot = (long long)batch * k * k;
+  for (long long e = (long long)blockIdx.x * BLOCK + threadIdx.x; e < tot; e += (long long)gridDim.x * BLOCK) {
+    const long long b = e / ((long long)k * k);
+    const int j = (int)((e / k) % k);
+    Gs[e] = G[e] * F[b * k + j];
+  }
+}
+
 // ------------------------------------------------------------------------------------------------
 // Relaxed histogram (project_histogram_relaxed.jl:9-27): the j-th smallest entry is clipped to [LB[j], UB[j]].
 template <typename T>
@@ -312,6 +362,8 @@ struct ExtImpl {
   rocblas_handle blas = nullptr;
   int r = 0, m = 0, n = 0, batch = 1;
   double *Ad = nullptr, *Ud = nullptr, *Sd = nullptr, *Vd = nullptr, *Ed = nullptr;
+  double *Gd = nullptr, *Gs = nullptr, *Wd = nullptr;     // Gram route: eigenvectors, scaled copy, eigenvalues
+  bool gram = false;
   rocblas_int* info = nullptr;
   int* flag = nullptr;
   // histogram
@@ -420,11 +472,20 @@ ExtProj<T>::ExtProj(const ExtSpec& spec, hipStream_t stream) {
     }
     blas_check(rocblas_create_handle(&I.blas), "create handle");
     blas_check(rocblas_set_stream(I.blas, stream), "set stream");
+    // Float32 models take the Gram route (eigenvectors of the smaller of X'X and XX', 12-24x faster than the Jacobi SVD
+    // on 256..512-sized slices); its error eps64 * cond^2 stays far below Float32 resolution.  Float64 models keep the
+    // one-sided Jacobi SVD, which works on the columns of X itself.
+    I.gram = sizeof(T) == 4;
     I.Ad = I.template alloc<double>((size_t)I.m * I.n * I.batch);
     I.Ud = I.template alloc<double>((size_t)I.m * k * I.batch);
     I.Vd = I.template alloc<double>((size_t)k * I.n * I.batch);
     I.Sd = I.template alloc<double>((size_t)k * I.batch);
-    I.Ed = I.template alloc<double>((size_t)I.batch);
+    I.Ed = I.template alloc<double>((size_t)(I.gram ? k : 1) * I.batch);
+    if (I.gram) {
+      I.Gd = I.template alloc<double>((size_t)k * k * I.batch);
+      I.Wd = I.template alloc<double>((size_t)k * I.batch);
+      if (kind == EXT_NUCLEAR) I.Gs = I.template alloc<double>((size_t)k * k * I.batch);
+    }
     I.info = I.template alloc<rocblas_int>((size_t)2 * I.batch);   // info + n_sweeps
     I.flag = I.template alloc<int>((size_t)I.batch);
   } else if (kind == EXT_CARD_SEG) {
@@ -531,6 +592,41 @@ void ExtProj<T>::project(T* v, bool feas, double* partials, T* maxpart, T* compa
     if (kind == EXT_RANK && I.r >= k) return;              // nothing to truncate
     const long long sU = (long long)I.m * k, sV = (long long)k * I.n, sA = (long long)I.m * I.n;
     hipLaunchKernelGGL((k_seg_gather<T, double>), dim3(NB), dim3(BLOCK), 0, s, I.map, v, I.Ad);
+    if (I.gram) {
+      const double one = 1.0, zero = 0.0;
+      const long long sG = (long long)k * k;
+      const bool right = I.n <= I.m;          // eigenvectors of X'X (right singular vectors) or of XX' (left ones)
+      const auto N_ = rocblas_operation_none, T_ = rocblas_operation_transpose;
+      if (right)
+        blas_check(rocblas_dgemm_strided_batched(I.blas, T_, N_, k, k, I.m, &one, I.Ad, I.m, sA, I.Ad, I.m, sA, &zero, I.Gd, k, sG, I.batch), "gram");
+      else
+        blas_check(rocblas_dgemm_strided_batched(I.blas, N_, T_, k, k, I.n, &one, I.Ad, I.m, sA, I.Ad, I.m, sA, &zero, I.Gd, k, sG, I.batch), "gram");
+      blas_check(rocsolver_dsyevd_strided_batched(I.blas, rocblas_evect_original, rocblas_fill_upper, k, I.Gd, k, sG, I.Wd, k, I.Ed, k,
+                                                  I.info, I.batch),
+                 "syevd");
+      const int* flag = nullptr;
+      int inner = I.r;
+      const double* Esel = I.Gd + (long long)(k - I.r) * k;     // eigenvalues ascend: the last r columns span the top-r space
+      const double* Escl = Esel;
+      if (kind == EXT_NUCLEAR) {
+        hipLaunchKernelGGL(k_nuc_factors, dim3((I.batch + 63) / 64), dim3(64), 0, s, k, I.batch, I.sp.pmax, I.Wd, I.Sd, I.flag);
+        hipLaunchKernelGGL(k_scale_eigvecs, dim3(NB), dim3(BLOCK), 0, s, k, I.batch, I.Gd, I.Sd, I.Gs);
+        flag = I.flag;
+        inner = k;
+        Esel = I.Gd;
+        Escl = I.Gs;
+      }
+      if (right) {       // X <- (X * Escl) * Esel'
+        blas_check(rocblas_dgemm_strided_batched(I.blas, N_, N_, I.m, inner, k, &one, I.Ad, I.m, sA, Escl, k, sG, &zero, I.Ud, I.m, sU, I.batch), "gemm X V");
+        blas_check(rocblas_dgemm_strided_batched(I.blas, N_, T_, I.m, I.n, inner, &one, I.Ud, I.m, sU, Esel, k, sG, &zero, I.Ad, I.m, sA, I.batch), "gemm (XV) V'");
+      } else {           // X <- Escl * (Esel' * X)
+        blas_check(rocblas_dgemm_strided_batched(I.blas, T_, N_, inner, I.n, k, &one, Esel, k, sG, I.Ad, I.m, sA, &zero, I.Vd, k, sV, I.batch), "gemm U' X");
+        blas_check(rocblas_dgemm_strided_batched(I.blas, N_, N_, I.m, I.n, inner, &one, Escl, k, sG, I.Vd, k, sV, &zero, I.Ad, I.m, sA, I.batch), "gemm U (U'X)");
+      }
+      hipLaunchKernelGGL((k_seg_scatter<T, double>), dim3(NB), dim3(BLOCK), 0, s, I.map, I.Ad, v, flag);
+      SIPX_HIP(hipGetLastError());
+      return;
+    }
     blas_check(rocsolver_dgesvdj_strided_batched(I.blas, rocblas_svect_singular, rocblas_svect_singular, I.m, I.n, I.Ad,
                                                  I.m, sA, 0.0, I.Ed, 100, I.info + I.batch, I.Sd, k, I.Ud, I.m, sU, I.Vd,
                                                  k, sV, I.info, I.batch),
