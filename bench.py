@@ -106,7 +106,13 @@ def main():
     dist = None
     torch.cuda.set_device(local_rank)
     force_dist = bool(os.environ.get("SIPX_FORCE_DIST"))      # exercise the RCCL path even with one rank
+    saved_stdout = None
     if world > 1 or force_dist:
+        # RCCL prints a version banner on the C-level stdout when its first communicator comes up; the contract is ONE
+        # JSON line on stdout, so fd 1 points at stderr until the warm-up (first collectives) is over
+        sys.stdout.flush()
+        saved_stdout = os.dup(1)
+        os.dup2(2, 1)
         import torch.distributed as dist
         if force_dist and "MASTER_ADDR" not in os.environ:
             os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="29533", RANK="0", WORLD_SIZE="1")
@@ -159,6 +165,11 @@ def main():
 
     for _ in range(args.warmup):
         drv.step()
+    if saved_stdout is not None:
+        torch.cuda.synchronize()
+        sys.stdout.flush()
+        os.dup2(saved_stdout, 1)
+        os.close(saved_stdout)
     ctx.kernel_stats(True)
     cg0 = drv.cg_total
     if world > 1:

@@ -7,6 +7,7 @@
 #include <algorithm>
 #include <chrono>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <limits>
 
@@ -34,7 +35,6 @@ inline void dfree(void* p) {
   if (p) (void)hipFree(p);
 }
 
-inline double jmax_nan(double a, double b) { return (std::isnan(a) || std::isnan(b)) ? NAN : std::max(a, b); }
 
 // Julia maximum(): NaN-propagating
 template <typename It>
@@ -114,6 +114,13 @@ struct SetState {
   double sums[SLOTS] = {0};
   bool bb_valid = false;
   T last_rho = T(-1), last_gamma = T(-1);   // parameters of the previous y/l update (speculation of the l1 search)
+  // y/l updates of different sets are independent (the reference runs them on separate workers): the sets are dealt onto
+  // a small pool of HIP streams, each with private search scratch, so the one-workgroup decide / solve kernels of one l1
+  // search overlap with the streaming passes of another set instead of leaving the GPU idle
+  hipStream_t st = nullptr;
+  hipEvent_t ev = nullptr;
+  double* ptmp = nullptr;
+  T *mpart = nullptr, *cbuf = nullptr;
 };
 
 }  // namespace
@@ -125,6 +132,13 @@ class Engine : public EngineBase {
     if (ndim != 2 && ndim != 3) throw std::runtime_error("ndim must be 2 or 3");
     SIPX_HIP(hipSetDevice(device));
     SIPX_HIP(hipStreamCreateWithFlags(&stream_, hipStreamNonBlocking));
+    SIPX_HIP(hipEventCreateWithFlags(&ev_fork_, hipEventDisableTiming));
+    {
+      const char* e = std::getenv("SIPX_SERIAL_SETS");
+      set_streams_ = !(e && e[0] == '1');
+      const char* k = std::getenv("SIPX_SET_STREAMS");
+      if (k && std::atoi(k) > 0) n_set_streams_ = std::atoi(k);
+    }
     ndim_ = ndim;
     for (int a = 0; a < 3; ++a) {
       G_.n[a] = a < ndim ? n[a] : 1;
@@ -151,6 +165,8 @@ class Engine : public EngineBase {
     for (auto e : ev_) (void)hipEventDestroy(e);
     for (auto e : stat_ev_) (void)hipEventDestroy(e);
     for (auto e : cg_ev_) if (e) (void)hipEventDestroy(e);
+    for (hipStream_t q : pool_) (void)hipStreamDestroy(q);
+    if (ev_fork_) (void)hipEventDestroy(ev_fork_);
     (void)hipStreamDestroy(stream_);
   }
 
@@ -310,6 +326,20 @@ class Engine : public EngineBase {
         K<T>::ps_init(stream_, s.ps, scr_i_);
         K<T>::ps_init(stream_, s.psf, scr_i_);
       }
+      if (set_streams_ && !s.ext_kind && s.prox != PX_CARD) {     // those two share the engine-wide scratch: main stream
+        if ((int)pool_.size() < n_set_streams_) {
+          hipStream_t q;
+          SIPX_HIP(hipStreamCreateWithFlags(&q, hipStreamNonBlocking));
+          pool_.push_back(q);
+        }
+        s.st = pool_[pool_next_++ % pool_.size()];
+        SIPX_HIP(hipEventCreateWithFlags(&s.ev, hipEventDisableTiming));
+        if (s.two_pass) {
+          s.ptmp = dalloc<double>((size_t)(PREP_SLOTS + 2) * NB);
+          s.mpart = dalloc<T>(2 * NB);
+          s.cbuf = dalloc<T>(s.Mpad);
+        }
+      }
       if (s.prox == SIPX_PROJ_BOUNDS_VEC) {
         s.lb = dalloc<T>(s.Mpad); s.ub = dalloc<T>(s.Mpad);
         upload_rows(s, s.host_lb.data(), s.lb);
@@ -453,33 +483,42 @@ class Engine : public EngineBase {
     need_final();
     (void)it;
     if (mk_) K<T>::sum_uv(stream_, G_.N, x_, x_ + G_.N, w_);
+    if (set_streams_) SIPX_HIP(hipEventRecord(ev_fork_, stream_));     // x (and u + v) are final: the sets may start
     for (int i = 0; i < p_n_; ++i) {
       SetState<T>& s = sets_[i];
       if (!s.owned) continue;
       SetArgs<T> a = set_args(s, (T)rho[i], (T)gamma[i], flags);
       if (mk_) a.x = s.comp == 1 ? x_ : (s.comp == 2 ? x_ + G_.N : w_);
       double* part = part_sets_ + (size_t)i * SLOTS * NB;
+      hipStream_t q = s.st ? s.st : stream_;
+      double* ptmp = s.ptmp ? s.ptmp : part_tmp_;
+      T* mpart = s.mpart ? s.mpart : maxpart_;
+      T* cbuf = s.cbuf ? s.cbuf : scr_c_;
+      if (s.st) SIPX_HIP(hipStreamWaitEvent(s.st, ev_fork_, 0));
       if (s.ext_kind) {   // library-backed projector: materialise v, project it in place, hand y to the fused update
-        K<T>::store_v(stream_, G_, a, 0, scr_v_);
-        s.ext->project(scr_v_, false, part_tmp_, maxpart_, scr_c_);
+        K<T>::store_v(q, G_, a, 0, scr_v_);
+        s.ext->project(scr_v_, false, ptmp, mpart, cbuf);
         a.vsrc = 2;
       }
       if (s.two_pass) {   // threshold / scale of prox_i from one pass that produces v on the fly (nothing stored)
         SetArgs<T> ap = a;
         if (s.last_rho != a.rho || s.last_gamma != a.gamma) ap.flags |= F_NOSPEC;   // v rescaled: theta will jump
-        K<T>::proj_scalars_set(stream_, G_, ap, 0, s.ps, part_tmp_, maxpart_, scr_c_, s.Mtrue);
+        K<T>::proj_scalars_set(q, G_, ap, 0, s.ps, ptmp, mpart, cbuf, s.Mtrue);
         s.last_rho = a.rho;
         s.last_gamma = a.gamma;
       }
-      K<T>::yl(stream_, G_, a, part);
-      if (!s.ident) K<T>::adj_norm(stream_, G_, a, part + (size_t)SL_ADJ * NB);
+      K<T>::yl(q, G_, a, part);
+      if (!s.ident) K<T>::adj_norm(q, G_, a, part + (size_t)SL_ADJ * NB);
       if ((flags & SIPX_YL_FEAS) && s.ext_kind && i < pp_n_) ext_feasibility(s, a, part + (size_t)SL_FE2 * NB);
       if ((flags & SIPX_YL_FEAS) && s.two_pass && i < pp_n_) {
         // ||P_i(s) - s|| with s = A_i x produced on the fly; its own warm-started scalars (psf)
-        K<T>::proj_scalars_set(stream_, G_, a, 1, s.psf, part_tmp_, maxpart_, scr_c_, s.Mtrue);
-        K<T>::proj_dist_set(stream_, G_, a, 1, s.psf, part + (size_t)SL_FE2 * NB);
+        K<T>::proj_scalars_set(q, G_, a, 1, s.psf, ptmp, mpart, cbuf, s.Mtrue);
+        K<T>::proj_dist_set(q, G_, a, 1, s.psf, part + (size_t)SL_FE2 * NB);
       }
+      if (s.st) SIPX_HIP(hipEventRecord(s.ev, s.st));
     }
+    for (int i = 0; i < p_n_; ++i)                                      // join: the reductions below see every set
+      if (sets_[i].owned && sets_[i].st) SIPX_HIP(hipStreamWaitEvent(stream_, sets_[i].ev, 0));
     // Minkowski: evol_x runs over all 2N unknowns (PARSDMM.jl:145); the distance-term kernel only saw u + v
     if (mk_) K<T>::log3(stream_, Nx_, x_, (const T*)nullptr, xold_, part_sets_ + (size_t)p_n_ * SLOTS * NB);
     K<T>::fin_sum(stream_, part_sets_, (p_n_ + (mk_ ? 1 : 0)) * SLOTS, nullptr, hres_);
@@ -1187,25 +1226,6 @@ class Engine : public EngineBase {
     return (T)std::sqrt(fe) / ((T)std::sqrt(ss) + T(100) * std::numeric_limits<T>::epsilon());
   }
 
-  // reference row order <-> padded layout (host side; only at import/export)
-  template <typename F>
-  void for_rows(const SetState<T>& s, F f) const {
-    if (s.ident) {
-      for (long long g = 0; g < G_.N; ++g) f(g, g);
-      return;
-    }
-    long long r = 0;
-    for (int q = 0; q < s.nblk; ++q) {
-      const int a = s.dir[q];
-      const long long base = (long long)q * G_.N;
-      for (long long k = 0; k < G_.n[2]; ++k)
-        for (long long j = 0; j < G_.n[1]; ++j)
-          for (long long i = 0; i < G_.n[0]; ++i) {
-            const long long c = a == 0 ? i : (a == 1 ? j : k);
-            if (c < G_.n[a] - 1) f(r++, base + i + G_.n[0] * (j + G_.n[1] * k));
-          }
-    }
-  }
   // Import / export between the reference's row order (host) and the padded layout (device): one contiguous PCIe
   // copy plus a device gather / scatter per operator block (the pads keep the zeros they were allocated with).
   void upload_rows(const SetState<T>& s, const T* rows, T* dev) const {
@@ -1254,6 +1274,9 @@ class Engine : public EngineBase {
   }
 
   void free_set(SetState<T>& s) {
+    if (s.st) (void)hipStreamSynchronize(s.st);
+    if (s.ev) (void)hipEventDestroy(s.ev);
+    for (void* p : {(void*)s.ptmp, (void*)s.mpart, (void*)s.cbuf}) dfree(p);
     for (void* p : s.halo_allocs) dfree(p);
     for (void* p : {(void*)s.lh0, (void*)s.y0, (void*)s.s0, (void*)s.l0, (void*)s.lb, (void*)s.ub, (void*)s.ata,
                     (void*)s.ps, (void*)s.psf})
@@ -1288,6 +1311,10 @@ class Engine : public EngineBase {
   T* scr_w_ = nullptr;
   bool need_idx_ = false, need_ext_ = false;
   CdsArgs cds_;
+  bool set_streams_ = true;       // SIPX_SERIAL_SETS=1 keeps every set on the engine stream (A/B measurements)
+  hipEvent_t ev_fork_ = nullptr;
+  std::vector<hipStream_t> pool_;   // streams the sets are dealt onto, round robin
+  int n_set_streams_ = 2, pool_next_ = 0;   // measured: 2 beats 1 by 1-4 %, 3+ lose again at 512^3 (streaming passes collide)
   bool mk_ = false;               // Minkowski mode: unknowns [u; v]
   long long Nx_ = 0;              // number of unknowns (N, or 2N in Minkowski mode)
   T *w_base_ = nullptr, *w_ = nullptr;
