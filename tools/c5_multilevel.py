@@ -1,7 +1,7 @@
 """BASELINE config 5 pattern: Float64, {bounds, l1 on TV}, 3 levels, coarsening factor 2 (test_scaling_3D.jl:144-145)."""
 import sys, time, json
 import numpy as np
-sys.path.insert(0, '.')
+sys.path.insert(0, __import__('os').path.dirname(__import__('os').path.dirname(__import__('os').path.abspath(__file__))))
 from __graft_entry__ import load_package
 sipx = load_package()
 from sipx import multilevel as ML
