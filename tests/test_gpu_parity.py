@@ -917,3 +917,30 @@ def test_full_size_projector_properties(sipx, TF):
     kept = u != 0
     assert np.abs(v[~kept]).max() <= np.abs(v[kept]).min() and np.array_equal(u[kept], v[kept])
     assert np.array_equal(Pc(u.copy()), u)
+
+
+# ---- long solves: the stop rules (stop_PARSDMM.jl:23-52), incl. the rho/gamma freeze of rule 3 and the final stop of rule 4 ----
+@pytest.mark.parametrize("name,n,h,kinds,kw", [
+    ("tight-tolerances", (32, 24), (25.0, 6.0), ["bounds", "l1:TV"], dict(maxit=400, evol_rel_tol=1e-9, feas_tol=1e-9, obj_tol=1e-9)),
+    ("default-tolerances", (16, 12, 8), (25.0, 25.0, 25.0), ["bounds", "l1:D_x", "l1:D_z"], dict(maxit=400)),
+    ("feasibility-only", (32, 24), (25.0, 6.0), ["bounds", "l1:TV"], dict(maxit=200, feasibility_only=True)),
+])
+def test_long_solves_stop_like_the_oracle(sipx, name, n, h, kinds, kw):
+    TF = np.float64
+    m = model(n, TF, seed=3)
+    go, oo, Po, Ao, propo, AtAo = _problem(O, n, h, TF, kinds, m, kw)
+    gs, os_, Ps, As, props, AtAs = _problem(sipx, n, h, TF, kinds, m, kw)
+    xo, lo, l_o, y_o = O.PARSDMM(m.copy(), AtAo, Ao, propo, Po, go, oo)
+    xs, ls, l_s, y_s = sipx.PARSDMM(m.copy(), AtAs, As, props, Ps, gs, os_)
+    p = len(Ao)
+    assert ls.r_pri.shape[1] == p == len(y_s) and ls.set_feasibility.shape[1] == len(kinds)
+    # same stopping iteration (the BB rule can flip a threshold late in a long run: allow a few iterations of slack)
+    assert abs(len(ls.obj) - len(lo.obj)) <= max(3, len(lo.obj) // 20), (len(ls.obj), len(lo.obj))
+    K = min(len(ls.obj), len(lo.obj), 40)
+    assert np.array_equal(ls.cg_it[:K], lo.cg_it[:K])
+    assert np.allclose(ls.rho[:K], lo.rho[:K], rtol=1e-6) and np.allclose(ls.gamma[:K], lo.gamma[:K], rtol=1e-6)
+    assert np.allclose(ls.obj[:K], lo.obj[:K], rtol=1e-6)
+    err = np.linalg.norm(xs - xo) / np.linalg.norm(xo)
+    assert err < 1e-5, err
+    if kw.get("feasibility_only"):
+        assert len(Ps) == p                      # no distance term appended (PARSDMM_precompute_distribute.jl:17-26)
