@@ -208,6 +208,26 @@ def main():
     log = drv.result_log()
     finite = bool(np.isfinite(log.obj).all() and np.isfinite(log.r_pri_total).all())
 
+    # Whole-iteration roofline with SURVEY 8(d)'s algorithmic bytes: B_rhs + B_resid0 + k B_cg_iter + B_yl + B_log
+    # (+ B_adapt + B_Q when rho / gamma are re-adapted, + B_feas every 10th iteration), summed over the timed steps.
+    rows = [int(op.shape[0]) for op in A]
+    d_i = [len(np.asarray(o)) for o in prop.AtA_offsets]
+    pp = len(P)
+    i0 = args.warmup + 1
+    it_bytes = 0.0
+    for i in range(i0, i0 + args.steps):                       # 1-based PARSDMM iteration numbers of the timed steps
+        k = int(log.cg_it[i - 1])
+        b = (sum(2 * r for r in rows) + N) + (d + 4) * N + k * ((d + 2) * N + 9 * N) + sum(N + 7 * r for r in rows) + 3 * N
+        if i % int(opt.rho_update_frequency) == 0:
+            b += sum(13 * r for r in rows)
+        if i < len(log.rho):
+            changed = np.nonzero(np.asarray(log.rho[i]) != np.asarray(log.rho[i - 1]))[0]
+            b += sum(3 * d_i[j] * N for j in changed)
+        if i % 10 == 0:
+            b += sum(2 * r for r in rows[:pp])
+        it_bytes += b * w
+    it_gbs = it_bytes / dt / 1e9 / max(world, 1)                # per GPU: every rank moves (at most) its share plus the x-step
+
     out = {
         "metric": "PARSDMM iterations/sec", "value": args.steps / dt, "unit": "it/s", "n_gpus": world,
         "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
@@ -222,6 +242,10 @@ def main():
                      "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                      "traffic": traffic, "traffic_source": traffic_src, "launches": int(launches), "avg_launch_ms": (kms / launches) if launches else None,
                      "algorithmic_bytes_per_launch": spmv_bytes},
+        "iteration_roofline": {"bound": "hbm", "achieved": it_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                               "frac": it_gbs / HBM_PEAK_GBS, "algorithmic_bytes_per_step": it_bytes / args.steps,
+                               "definition": "SURVEY 8(d) B_iter summed over the timed steps / wall time" +
+                                             ("" if world == 1 else " / n_gpus (the replicated x-step is not counted twice)")},
     }
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(args.config, n, h, kinds)
