@@ -238,7 +238,11 @@ def main():
                    "driver": "native loop (sipx_parsdmm_begin/_steps)" if native else
                              "phase-level C ABI (sipx_rhs_compose/argmin_x/update_y_l/...) + torch.distributed"},
         "roofline": {"bound": "hbm", "kernel": "k_cds<MODE=1> (cds_spmv + p.Ap partials)" if args.q_mode == "cds" else
-                     "k_sq<MODE=1> (stencil Q product + p.Ap partials)", "achieved": achieved,
+                     "k_sq<MODE=1> (stencil Q product + p.Ap partials)",
+                     "algorithmic_bytes_definition": "SURVEY 8(d): B_spmv = (d+2) N w (d bands + x read, y written)"
+                     if args.q_mode == "cds" else "2 N w (p read, Ap written)",
+                     "bands_from_hbm": (int((d + 1) // 2) if not os.environ.get("SIPX_CDS_FULL") else int(d)) if args.q_mode == "cds" else 0,
+                     "bytes_with_symmetric_band_read": int(((d + 1) // 2 + 2) * N * w) if args.q_mode == "cds" else None, "achieved": achieved,
                      "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                      "traffic": traffic, "traffic_source": traffic_src, "launches": int(launches), "avg_launch_ms": (kms / launches) if launches else None,
                      "algorithmic_bytes_per_launch": spmv_bytes},

@@ -136,6 +136,8 @@ class Engine : public EngineBase {
     {
       const char* e = std::getenv("SIPX_SERIAL_SETS");
       set_streams_ = !(e && e[0] == '1');
+      const char* f = std::getenv("SIPX_CDS_FULL");
+      cds_full_ = f && f[0] == '1';
       const char* k = std::getenv("SIPX_SET_STREAMS");
       if (k && std::atoi(k) > 0) n_set_streams_ = std::atoi(k);
     }
@@ -1120,6 +1122,37 @@ class Engine : public EngineBase {
     if ((int)seen.size() > MAXD) throw std::runtime_error("Q has more bands than this build supports");
     cds_.d = (int)seen.size();
     for (int b = 0; b < cds_.d; ++b) cds_.off[b] = seen[b];
+    // symmetric read of Q (CdsArgs::sym): every negative band needs its positive partner, at a band index >= 1 so that
+    // the shifted address never leaves the allocation; explicit AtA bands must be symmetric bit for bit
+    bool ok = !cds_full_;
+    for (int b = 0; b < cds_.d && ok; ++b) {
+      cds_.partner[b] = b;
+      if (cds_.off[b] >= 0) continue;
+      int pb = -1;
+      for (int c = 0; c < cds_.d; ++c)
+        if (cds_.off[c] == -cds_.off[b]) pb = c;
+      if (pb < 1) ok = false;
+      else cds_.partner[b] = pb;
+    }
+    for (auto& s : sets_) ok = ok && (s.host_ata.empty() || explicit_bands_symmetric(s));
+    cds_.sym = ok ? 1 : 0;
+  }
+
+  bool explicit_bands_symmetric(const SetState<T>& s) const {
+    const long long N = G_.N;
+    for (size_t b = 0; b < s.ata_off.size(); ++b) {
+      const long long o = s.ata_off[b];
+      if (o >= 0) continue;
+      long long pb = -1;
+      for (size_t c = 0; c < s.ata_off.size(); ++c)
+        if (s.ata_off[c] == -o) pb = (long long)c;
+      if (pb < 0) return false;
+      const T* lo = s.host_ata.data() + b * (size_t)N;
+      const T* up = s.host_ata.data() + (size_t)pb * (size_t)N;
+      for (long long r = -o; r < N; ++r)
+        if (std::memcmp(&lo[r], &up[r + o], sizeof(T)) != 0) return false;
+    }
+    return true;
   }
 
   // stencil mode: the whole of Q is four scalars, recomputed from the current rho (no update history)
@@ -1311,6 +1344,7 @@ class Engine : public EngineBase {
   T* scr_w_ = nullptr;
   bool need_idx_ = false, need_ext_ = false;
   CdsArgs cds_;
+  bool cds_full_ = false;         // SIPX_CDS_FULL=1: read all d bands of Q (no symmetric partner reads)
   bool set_streams_ = true;       // SIPX_SERIAL_SETS=1 keeps every set on the engine stream (A/B measurements)
   hipEvent_t ev_fork_ = nullptr;
   std::vector<hipStream_t> pool_;   // streams the sets are dealt onto, round robin

@@ -32,7 +32,14 @@ __device__ __forceinline__ void cds_rows(long long N, const T* __restrict__ R, c
     Vec<T, V> rv[D], xv[D];
 #pragma unroll
     for (int b = 0; b < D; ++b) {
-      rv[b] = ldv_nt<T, V>(R + (long long)b * N + r);
+      if (a.sym) {
+        // the positive bands are read twice (here and |o| rows further on): ordinary loads keep them in cache; the
+        // negative ones are the partner shifted by o (rows r + o < 0 are masked below, the address stays inside Q)
+        rv[b] = a.off[b] >= 0 ? ldv<T, V>(R + (long long)b * N + r)
+                              : ldv_u<T, V>(R + (long long)a.partner[b] * N + r + a.off[b]);
+      } else {
+        rv[b] = ldv_nt<T, V>(R + (long long)b * N + r);
+      }
       xv[b] = ldv_u<T, V>(x + r + a.off[b]);
     }
 #pragma unroll
@@ -47,7 +54,9 @@ __device__ __forceinline__ void cds_rows(long long N, const T* __restrict__ R, c
   } else {
     for (int b = 0; b < d; ++b) {
       const long long c = r + a.off[b];
-      const Vec<T, V> rv = ldv_nt<T, V>(R + (long long)b * N + r);
+      const Vec<T, V> rv = !a.sym ? ldv_nt<T, V>(R + (long long)b * N + r)
+                                  : (a.off[b] >= 0 ? ldv<T, V>(R + (long long)b * N + r)
+                                                   : ldv_u<T, V>(R + (long long)a.partner[b] * N + c));
       const Vec<T, V> xv = ldv_u<T, V>(x + c);
 #pragma unroll
       for (int k = 0; k < V; ++k) {

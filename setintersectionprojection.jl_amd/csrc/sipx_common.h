@@ -38,6 +38,11 @@ struct Grid {
 struct CdsArgs {
   int d;
   long long off[MAXD];
+  // Q = sum rho_i A_i'A_i is symmetric bit for bit (Q[r, r-o] and Q[r-o, r] are the same products summed in the same
+  // order), so a band with a negative offset never has to come from HBM: its entry at row r is the entry of the partner
+  // band (+|o|) at row r-|o|, which the sweep loaded a moment ago.  sym = 1: read negative bands through `partner`.
+  int sym = 0;
+  int partner[MAXD] = {};
 };
 
 // Q = sum_i rho_i A_i'A_i as stencil coefficients (sipx_set_q_mode(SIPX_Q_STENCIL)): w0 = sum of rho over identity

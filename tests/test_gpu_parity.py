@@ -944,3 +944,49 @@ def test_long_solves_stop_like_the_oracle(sipx, name, n, h, kinds, kw):
     assert err < 1e-5, err
     if kw.get("feasibility_only"):
         assert len(Ps) == p                      # no distance term appended (PARSDMM_precompute_distribute.jl:17-26)
+
+
+# ---- symmetric band read of the SpMV (negative bands = shifted positive partners) ---------------------------------------
+@pytest.mark.parametrize("TF", [np.float32, np.float64])
+@pytest.mark.parametrize("n,h", GRIDS)
+def test_symmetric_band_read_is_bit_identical(sipx, TF, n, h, monkeypatch):
+    m = model(n, TF)
+    kinds = ["bounds", "l1:D_x", "l1:D_z", "l1:TV"]
+    go, oo, Po, Ao, propo, AtAo = _problem(O, n, h, TF, kinds, m)
+    gs, os_, Ps, As, props, AtAs = _problem(sipx, n, h, TF, kinds, m)
+    rho = [3.0, 0.5, 7.0, 11.0, 2.0]
+    os_.rho_ini = rho
+    x = np.random.default_rng(9).standard_normal(m.size).astype(TF)
+    Qo, offo = O.assemble_Q(AtAo, propo.AtA_offsets, np.array(rho, TF), TF)
+    want = O.Ax_CDS(x, Qo, offo)
+    out = {}
+    for full in ("0", "1"):
+        monkeypatch.setenv("SIPX_CDS_FULL", full)
+        ctx = sipx.host.build_context(m, AtAs, As, props, Ps, gs, os_)
+        y0 = ctx.apply_Q(x)
+        ctx.q_update([3.0, 0.25, 7.0, 12.5, 1.0], rho)
+        out[full] = (y0, ctx.apply_Q(x))
+        Q, off = ctx.get_Q()
+        ctx.close()
+        # the stored matrix itself is symmetric bit for bit, before and after the incremental update
+        for b, o in enumerate(off):
+            if o < 0:
+                pb = list(off).index(-o)
+                assert np.array_equal(Q[-o:, b], Q[:o, pb])
+    assert np.array_equal(out["0"][0], want) and np.array_equal(out["1"][0], want)
+    assert np.array_equal(out["0"][1], out["1"][1])
+
+
+def test_asymmetric_explicit_bands_fall_back_to_the_full_read(sipx):
+    TF, n, h = np.float64, (16, 12), (1.0, 1.0)
+    m = model(n, TF)
+    go, oo, Po, Ao, propo, AtAo = _problem(O, n, h, TF, ["bounds", "l1:TV"], m)
+    gs, os_, Ps, As, props, AtAs = _problem(sipx, n, h, TF, ["bounds", "l1:TV"], m)
+    bad = [np.array(a, order="F", copy=True) for a in AtAo]
+    bad[1][5, 0] += 0.125                      # one entry of the most negative band: A'A no longer symmetric
+    Qo, offo = O.assemble_Q(bad, propo.AtA_offsets, np.full(3, 10.0, TF), TF)
+    x = np.random.default_rng(2).standard_normal(m.size).astype(TF)
+    ctx = sipx.host.build_context(m, bad, As, propo, Ps, gs, os_)
+    y = ctx.apply_Q(x)
+    ctx.close()
+    assert np.array_equal(y, O.Ax_CDS(x, Qo, offo))
