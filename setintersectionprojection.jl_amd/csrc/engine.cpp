@@ -864,6 +864,10 @@ class Engine : public EngineBase {
     if (d) *d = cds_.d;
     if (offsets) for (int b = 0; b < cds_.d; ++b) offsets[b] = cds_.off[b];
     if (Q && stencil_q_) throw std::runtime_error("stencil Q mode stores no bands (use sipx_apply_Q)");
+    if (Q && cds_.sym) {      // the negative bands are not maintained while solving: rebuild them from their partners
+      K<T>::mirror_bands(stream_, Nx_, cds_, Q_);
+      SIPX_HIP(hipStreamSynchronize(stream_));
+    }
     if (Q) SIPX_HIP(hipMemcpy(Q, Q_, (size_t)Nx_ * cds_.d * sizeof(T), hipMemcpyDeviceToHost));
   }
 

@@ -330,6 +330,7 @@ __global__ __launch_bounds__(BLOCK) void k_q_update(Grid G, CdsArgs q, QArgs<T> 
     for (int k = 0; k < V; ++k) { c[k] = coords(G, g); c[k].i += k; }
     for (int b = 0; b < q.d; ++b) {
       const long long o = q.off[b];
+      if (q.sym && o < 0) continue;            // never read by the SpMV: rebuilt from the partner band on demand (k_mirror_bands)
       bool touched = false;
       Vec<T, V> qv;
       for (int si = 0; si < a.nsets; ++si) {
@@ -361,6 +362,24 @@ void K<T>::q_update(hipStream_t s, const Grid& g, const CdsArgs& q, const QArgs<
   SIPX_HIP(hipGetLastError());
 }
 
+// Negative bands of the symmetric Q from their partners: Q[r, r+o] = Q[r+o, r] for o < 0, zero where r+o < 0
+// (mat2CDS.jl:24-28).  Only needed when the bands themselves are handed out (sipx_get_Q).
+template <typename T>
+__global__ __launch_bounds__(BLOCK) void k_mirror_bands(long long N, CdsArgs q, T* __restrict__ Q) {
+  for (long long r = (long long)blockIdx.x * BLOCK + threadIdx.x; r < N; r += (long long)gridDim.x * BLOCK) {
+    for (int b = 0; b < q.d; ++b) {
+      const long long o = q.off[b];
+      if (o >= 0) continue;
+      Q[(long long)b * N + r] = (r + o >= 0) ? Q[(long long)q.partner[b] * N + r + o] : T(0);
+    }
+  }
+}
+template <typename T>
+void K<T>::mirror_bands(hipStream_t s, long long N, const CdsArgs& q, T* Q) {
+  hipLaunchKernelGGL((k_mirror_bands<T>), dim3(NB), dim3(BLOCK), 0, s, N, q, Q);
+  SIPX_HIP(hipGetLastError());
+}
+
 // Minkowski mode: Q is 2N x d.  Row g = (block row br, local point gl), band offset O -> column (bc, cl); the entry of
 // set i is (A_i'A_i)[gl, cl] when block (br, bc) of its AtA is populated ([B 0;0 0], [0 0;0 B] or [B B;B B]).
 // Q[:, b] += alpha_i * AtA_i[:, b] for every listed set (assembly: alpha = rho; update: alpha = delta rho).
@@ -372,6 +391,7 @@ __global__ __launch_bounds__(BLOCK) void k_q_update_mk(Grid G, CdsArgs q, MkArgs
     const long long gl = g - (long long)br * N;
     const Coord c = coords(G, gl);
     for (int b = 0; b < q.d; ++b) {
+      if (q.sym && q.off[b] < 0) continue;
       const long long cc = g + q.off[b];
       if (cc < 0 || cc >= Nx) continue;
       const int bc = cc >= N;
@@ -579,6 +599,7 @@ void K<T>::fin_sum(hipStream_t s, const double* partials, int nslots, double* ou
   template void K<T>::resid(hipStream_t, long long, const T*, const CdsArgs&, const T*, const T*, T*, T*, T*, double*); \
   template void K<T>::q_axpy(hipStream_t, long long, T*, const T*, T);                                               \
   template void K<T>::q_update_mk(hipStream_t, const Grid&, const CdsArgs&, const MkArgs<T>&, T*);                    \
+  template void K<T>::mirror_bands(hipStream_t, long long, const CdsArgs&, T*);                                       \
   template void K<T>::sq_spmv(hipStream_t, const Grid&, const StencilQ<T>&, const T*, T*);                           \
   template void K<T>::sq_spmv_dot(hipStream_t, const Grid&, const StencilQ<T>&, const T*, T*, double*,               \
                                   const CgState<T>*);                                                                 \

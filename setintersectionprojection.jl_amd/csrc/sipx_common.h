@@ -195,6 +195,7 @@ struct K {
   static void adj(hipStream_t s, const Grid& g, int nblk, const int* dir, const T* ih, const T* v, T* out);
   static void log3(hipStream_t s, long long N, const T* x, const T* m, const T* xold, double* partials);
   static void q_update_mk(hipStream_t s, const Grid& g, const CdsArgs& q, const MkArgs<T>& a, T* Q);
+  static void mirror_bands(hipStream_t s, long long N, const CdsArgs& q, T* Q);
   static void sum_uv(hipStream_t s, long long N, const T* u, const T* v, T* w);
   static void rows_pack(hipStream_t s, const Grid& g, int dir, long long nrows, const T* pad, T* rows);
   static void rows_unpack(hipStream_t s, const Grid& g, int dir, long long nrows, const T* rows, T* pad);
