@@ -1,0 +1,120 @@
+"""Property-based parity of the stand-alone projectors (sipx_project) against the oracle on adversarial small vectors:
+zeros, exact ties, repeated magnitudes, single entries, radii at / beyond the norm."""
+import numpy as np
+import pytest
+from hypothesis import HealthCheck, given, settings, strategies as st
+
+from oracle import parsdmm_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+vals = st.sampled_from([0.0, -0.0, 0.5, -0.5, 1.0, -1.0, 2.0, 3.25, -3.25, 1e-3, -7.0, 100.0])
+
+
+def vec(TF):
+    return st.lists(st.one_of(vals, st.floats(-50, 50, allow_nan=False, width=32)), min_size=1, max_size=300).map(
+        lambda v: np.asarray(v, TF))
+
+
+def proj(sipx, st_, M, TF, mn, mx):
+    c = sipx.set_definitions(st_, "identity", mn, mx, ("matrix", ""))
+    return sipx.host.Projector(c, sipx.compgrid((1.0, 1.0), (M, 1)), TF)
+
+
+SET = settings(max_examples=120, deadline=None, suppress_health_check=[HealthCheck.function_scoped_fixture])
+
+
+@pytest.mark.parametrize("TF", [np.float32, np.float64])
+def test_l1_ball_matches_oracle(sipx, TF):
+    @SET
+    @given(v=vec(TF), frac=st.sampled_from([0.01, 0.3, 0.5, 0.999, 1.0, 1.5]))
+    def run(v, frac):
+        a = float(np.abs(v.astype(np.float64)).sum())
+        if a == 0:
+            return
+        b = TF(frac * a)
+        if not b > 0:
+            return
+        want = O.project_l1_Duchi(v.copy(), b)
+        got = proj(sipx, "l1", len(v), TF, 0.0, float(b))(v.copy())
+        tol = 3e-5 if TF == np.float32 else 1e-11
+        assert np.allclose(got, want, rtol=tol, atol=tol * max(1.0, float(np.abs(v).max()))), (v, frac)
+    run()
+
+
+@pytest.mark.parametrize("TF", [np.float32, np.float64])
+def test_cardinality_matches_oracle_exactly(sipx, TF):
+    @SET
+    @given(v=vec(TF), k=st.integers(0, 320))
+    def run(v, k):
+        want = O.project_cardinality(v.copy(), k)
+        got = proj(sipx, "cardinality", len(v), TF, 0, k)(v.copy())
+        assert np.array_equal(got, want), (v, k)
+    run()
+
+
+@pytest.mark.parametrize("TF", [np.float32, np.float64])
+def test_l2_annulus_bounds_match_oracle(sipx, TF):
+    @SET
+    @given(v=vec(TF), lo=st.sampled_from([0.0, 0.5, 2.0]), span=st.sampled_from([0.0, 0.25, 10.0]))
+    def run(v, lo, span):
+        hi = lo + span
+        tol = 1e-6 if TF == np.float32 else 1e-14
+        if hi > 0:
+            want = O.project_l2(v.copy(), TF(hi))
+            assert np.allclose(proj(sipx, "l2", len(v), TF, 0.0, hi)(v.copy()), want, rtol=tol, atol=tol)
+        want = O.project_annulus(v.copy(), TF(lo), TF(hi))
+        assert np.allclose(proj(sipx, "annulus", len(v), TF, lo, hi)(v.copy()), want, rtol=tol, atol=tol)
+        want = O.project_bounds(v.copy(), TF(-lo), TF(hi))
+        assert np.array_equal(proj(sipx, "bounds", len(v), TF, -lo, hi)(v.copy()), want)
+    run()
+
+
+shape3 = st.tuples(st.integers(1, 9), st.integers(1, 8), st.integers(2, 7))
+shape2 = st.tuples(st.integers(1, 40), st.integers(2, 30))
+
+
+def _mode_proj(sipx, st_, n, TF, mn, mx, mode):
+    c = sipx.set_definitions(st_, "identity", mn, mx, mode)
+    return sipx.host.Projector(c, sipx.compgrid(tuple(1.0 for _ in n), n), TF)
+
+
+@pytest.mark.parametrize("TF", [np.float32, np.float64])
+def test_segmented_cardinality_and_bounds_match_oracle_exactly(sipx, TF):
+    @SET
+    @given(n=st.one_of(shape3, shape2), md=st.sampled_from(["fiber", "slice"]), d=st.sampled_from(["x", "y", "z"]),
+           k=st.integers(0, 40), seed=st.integers(0, 2 ** 16))
+    def run(n, md, d, k, seed):
+        if len(n) == 2 and (md == "slice" or d == "y"):
+            return
+        rng = np.random.default_rng(seed)
+        N = int(np.prod(n))
+        v = rng.choice(np.asarray([0.0, 0.5, -0.5, 1.0, 2.0, -2.0, 3.0], TF), N).astype(TF)
+        v[rng.integers(0, N, max(1, N // 3))] = rng.standard_normal(max(1, N // 3)).astype(TF)
+        want = O.project_cardinality_mode(v.copy(), k, n, (md, d))
+        got = _mode_proj(sipx, "cardinality", n, TF, 0, k, (md, d))(v.copy())
+        assert np.array_equal(got, want), (n, md, d, k)
+        if md == "fiber":
+            ax = {"x": 0, "y": 1, "z": len(n) - 1}[d]
+            lb = np.sort(rng.standard_normal(n[ax])).astype(TF) - TF(0.5)
+            ub = (lb + TF(0.75)).astype(TF)
+            want = O.project_bounds_mode(v.copy(), lb, ub, n, ("fiber", d))
+            got = _mode_proj(sipx, "bounds", n, TF, lb, ub, ("fiber", d))(v.copy())
+            assert np.array_equal(got, want), (n, d)
+    run()
+
+
+@pytest.mark.parametrize("TF", [np.float32, np.float64])
+def test_histogram_matches_oracle_exactly(sipx, TF):
+    @SET
+    @given(M=st.integers(1, 400), seed=st.integers(0, 2 ** 16), w=st.sampled_from([0.0, 0.3, 5.0]))
+    def run(M, seed, w):
+        rng = np.random.default_rng(seed)
+        v = rng.choice(np.asarray([0.0, -0.0, 0.5, 0.5, -1.0, 2.0], TF), M).astype(TF)
+        v[rng.integers(0, M, max(1, M // 2))] = rng.standard_normal(max(1, M // 2)).astype(TF)
+        lb = np.sort(rng.standard_normal(M)).astype(TF)
+        ub = (lb + TF(w)).astype(TF)
+        want = O.project_histogram_relaxed(v.copy(), lb, ub)
+        got = _mode_proj(sipx, "histogram", (M, 1), TF, lb, ub, ("matrix", ""))(v.copy())
+        assert np.array_equal(got, want), (M, seed, w)
+    run()
