@@ -21,7 +21,9 @@ def proj(sipx, st_, M, TF, mn, mx):
     return sipx.host.Projector(c, sipx.compgrid((1.0, 1.0), (M, 1)), TF)
 
 
-SET = settings(max_examples=120, deadline=None, suppress_health_check=[HealthCheck.function_scoped_fixture])
+# derandomize: the same examples on every run (the round-end GPU run must not depend on a random draw)
+SET = settings(max_examples=120, deadline=None, derandomize=True, database=None,
+               suppress_health_check=[HealthCheck.function_scoped_fixture])
 
 
 @pytest.mark.parametrize("TF", [np.float32, np.float64])
@@ -130,7 +132,8 @@ def test_random_small_problems_match_oracle(sipx):
     pool2 = ["bounds", "l1:D_x", "l1:D_z", "l1:TV", "annulus", "bnd:D_z", "l2"]
     pool3 = pool2 + ["l1:D_y"]
 
-    @settings(max_examples=150, deadline=None, suppress_health_check=[HealthCheck.function_scoped_fixture])
+    @settings(max_examples=150, deadline=None, derandomize=True, database=None,
+              suppress_health_check=[HealthCheck.function_scoped_fixture])
     @given(ndim=st.sampled_from([2, 3]), dims=st.tuples(st.integers(2, 13), st.integers(2, 11), st.integers(2, 7)),
            picks=st.lists(st.integers(0, 7), min_size=1, max_size=4, unique=True), seed=st.integers(0, 1000),
            TF=st.sampled_from([np.float32, np.float64]))
