@@ -173,3 +173,22 @@ def test_two_rank_sharding_matches_serial(TF, tmp_path):
     assert np.allclose(r0["r_pri"][:K], lo.r_pri[:K], rtol=rt, atol=1e-12)      # r_pri of every set reaches every rank
     err = np.linalg.norm(r0["x"].astype(np.float64) - xo) / np.linalg.norm(xo)
     assert err < (5e-4 if TF == np.float32 else 1e-6), err
+
+
+def test_more_ranks_than_terms(tmp_path):
+    """8 GPUs, 5 terms: some ranks own no set at all and only take part in the collectives and the replicated x-step.
+    Rehearsed with 6 gloo ranks on 4 terms."""
+    TF, world = np.float64, 6
+    port = 31500 + (os.getpid() % 2000)
+    mp.spawn(_worker, args=(world, port, TF, str(tmp_path)), nprocs=world, join=True)
+    rs = [np.load(tmp_path / f"r{r}.npz") for r in range(world)]
+    for r in rs[1:]:
+        for k in rs[0].files:
+            assert np.array_equal(rs[0][k], r[k], equal_nan=True), k
+    m, g, opt, P, A, prop, AtA = _setup(TF)
+    assert len(A) < world
+    xo, lo, _, _ = O.PARSDMM(m.copy(), AtA, A, prop, P, g, O.PARSDMM_options(FL=TF, maxit=45))
+    K = min(8, len(lo.obj), len(rs[0]["obj"]))
+    assert np.array_equal(rs[0]["cg_it"][:K], lo.cg_it[:K]) and np.allclose(rs[0]["obj"][:K], lo.obj[:K], rtol=1e-9)
+    err = np.linalg.norm(rs[0]["x"] - xo) / np.linalg.norm(xo)
+    assert err < 1e-6, err
