@@ -445,7 +445,7 @@ def test_converged_result_is_feasible(sipx):
 
 
 # ---- set-sharded path on the real engine: 2 ranks sharing the one GPU, gloo collectives ----------
-def _sharded_worker(rank, world, port, out):
+def _sharded_worker(rank, world, port, out, kinds):
     import os
     import sys
     import torch.distributed as dist
@@ -462,25 +462,30 @@ def _sharded_worker(rank, world, port, out):
         TF = np.float32
         n, h = (32, 24, 16), (25.0, 25.0, 25.0)
         m = model(n, TF, seed=5)
-        gs, os_, Ps, As, props, AtAs = _problem(sipx, n, h, TF, ["bounds", "l1:D_x", "l1:D_y", "l1:D_z"], m, dict(maxit=40))
+        gs, os_, Ps, As, props, AtAs = _problem(sipx, n, h, TF, kinds, m, dict(maxit=40))
         x, log, l, y = sharded.PARSDMM_sharded(m.copy(), AtAs, As, props, Ps, gs, os_, dist=dist, device=0)
         np.savez(os.path.join(out, f"r{rank}.npz"), x=x, obj=log.obj, cg_it=log.cg_it, rho=log.rho, r_pri=log.r_pri)
     finally:
         dist.destroy_process_group()
 
 
-def test_sharded_two_ranks_on_one_gpu(sipx, tmp_path):
+# the pytest process holds the GPU too and a box allows 6 processes on it: 4 ranks at most.  4 ranks on 3 terms: one rank
+# owns no set at all (the 8-GPU / 5-term case in small)
+@pytest.mark.parametrize("world,kinds", [(2, ["bounds", "l1:D_x", "l1:D_y", "l1:D_z"]), (4, ["bounds", "l1:D_z"])])
+def test_sharded_ranks_on_one_gpu(sipx, tmp_path, world, kinds):
     import os
     import torch.multiprocessing as mp
-    port = 29600 + (os.getpid() % 2000)
-    mp.spawn(_sharded_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
-    r0, r1 = np.load(tmp_path / "r0.npz"), np.load(tmp_path / "r1.npz")
-    for k in r0.files:
-        assert np.array_equal(r0[k], r1[k], equal_nan=True), k
+    port = 29600 + (os.getpid() % 2000) + 11 * world
+    mp.spawn(_sharded_worker, args=(world, port, str(tmp_path), kinds), nprocs=world, join=True)
+    r0 = np.load(tmp_path / "r0.npz")
+    for r in range(1, world):
+        r1 = np.load(tmp_path / f"r{r}.npz")
+        for k in r0.files:
+            assert np.array_equal(r0[k], r1[k], equal_nan=True), k
     TF = np.float32
     n, h = (32, 24, 16), (25.0, 25.0, 25.0)
     m = model(n, TF, seed=5)
-    gs, os_, Ps, As, props, AtAs = _problem(sipx, n, h, TF, ["bounds", "l1:D_x", "l1:D_y", "l1:D_z"], m, dict(maxit=40))
+    gs, os_, Ps, As, props, AtAs = _problem(sipx, n, h, TF, kinds, m, dict(maxit=40))
     xs, ls, _, _ = sipx.PARSDMM(m.copy(), AtAs, As, props, Ps, gs, os_)
     K = min(8, len(ls.obj), len(r0["obj"]))
     assert np.array_equal(r0["cg_it"][:K], ls.cg_it[:K])
