@@ -27,8 +27,8 @@
 
 namespace sipx {
 
-constexpr double L1_CAP = 131072.0;     // bracket population above which one more probe pass is run
-constexpr int L1_REFINES = 3;           // gated refinement passes enqueued per search
+constexpr double L1_CAP = 131072.0;     // bracket population above which one more probe pass is run (floor; scales with the length)
+constexpr int L1_REFINES = 1;           // gated refinement passes enqueued per search
 constexpr int SPEC_CAP = 1024;           // per-workgroup LDS buffer of the speculative compaction
 constexpr int SL_ABOVE_S = PREP_SLOTS, SL_ABOVE_C = PREP_SLOTS + 1;   // partial slots of the fallback compaction
 enum { M_FIRST = 0, M_PROBE = 1, M_COMPACT = 2, M_DIST = 3, M_STORE = 4 /* materialise v into `compact` */ };
@@ -354,7 +354,10 @@ __global__ __launch_bounds__(1024) void k_decide(const double* __restrict__ part
   }
   // cold start / theta moved far: while the bracket still holds too many magnitudes, subdivide it again
   // (each gated refinement pass narrows it by >= L1_K-1 and by the Newton/secant step on top)
-  if (Cl - Ch > L1_CAP && hi > lo && (STAGE == 0 || ps->refine < L1_REFINES)) {
+  // one more probe pass costs a full sweep of the vector, gathering a larger bracket costs the one-workgroup solve a
+  // longer scan: the break-even population grows with the length (measured at 256^3 and 512^3)
+  const double cap = fmax(L1_CAP, (double)true_len / 32.0);
+  if (Cl - Ch > cap && hi > lo && (STAGE == 0 || ps->refine < L1_REFINES)) {
     ps->refine = (STAGE == 0) ? 1 : ps->refine + 1;
     for (int k = 0; k < L1_K; ++k) ps->t[k] = (double)(T)(lo + (hi - lo) * (double)k / (double)(L1_K - 1));
   } else {

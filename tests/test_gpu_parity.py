@@ -452,7 +452,9 @@ def _sharded_worker(rank, world, port, out, kinds):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")          # the container hostname may not resolve
+    import datetime
+    dist.init_process_group("gloo", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=180))
     try:
         root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
         sys.path.insert(0, root)
@@ -471,6 +473,7 @@ def _sharded_worker(rank, world, port, out, kinds):
 
 # the pytest process holds the GPU too and a box allows 6 processes on it: 4 ranks at most.  4 ranks on 3 terms: one rank
 # owns no set at all (the 8-GPU / 5-term case in small)
+@pytest.mark.timeout(400)
 @pytest.mark.parametrize("world,kinds", [(2, ["bounds", "l1:D_x", "l1:D_y", "l1:D_z"]), (4, ["bounds", "l1:D_z"])])
 def test_sharded_ranks_on_one_gpu(sipx, tmp_path, world, kinds):
     import os

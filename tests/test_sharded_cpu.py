@@ -142,7 +142,9 @@ def test_phase_driver_equals_oracle_loop(sipx, TF):
 def _worker(rank, world, port, TF, out):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")          # the container hostname may not resolve
+    import datetime
+    dist.init_process_group("gloo", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=180))
     try:
         from __graft_entry__ import load_package
         load_package()
