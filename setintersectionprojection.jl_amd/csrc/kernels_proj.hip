@@ -356,7 +356,7 @@ __global__ __launch_bounds__(1024) void k_decide(const double* __restrict__ part
   // (each gated refinement pass narrows it by >= L1_K-1 and by the Newton/secant step on top)
   // one more probe pass costs a full sweep of the vector, gathering a larger bracket costs the one-workgroup solve a
   // longer scan: the break-even population grows with the length (measured at 256^3 and 512^3)
-  const double cap = fmax(L1_CAP, (double)true_len / 32.0);
+  const double cap = fmax(L1_CAP, (double)true_len / 8.0);
   if (Cl - Ch > cap && hi > lo && (STAGE == 0 || ps->refine < L1_REFINES)) {
     ps->refine = (STAGE == 0) ? 1 : ps->refine + 1;
     for (int k = 0; k < L1_K; ++k) ps->t[k] = (double)(T)(lo + (hi - lo) * (double)k / (double)(L1_K - 1));
