@@ -30,6 +30,7 @@ CONFIGS = {
     "c3": ((256, 256, 256), (25.0, 25.0, 25.0), ["bounds", "l1:D_x", "l1:D_y", "l1:D_z"]),
     "c2": ((2048, 2048), (25.0, 6.0), ["bounds", "l1:TV"]),
     "c3-512": ((512, 512, 512), (25.0, 25.0, 25.0), ["bounds", "l1:D_x", "l1:D_y", "l1:D_z"]),
+    "c3-768": ((768, 768, 768), (25.0, 25.0, 25.0), ["bounds", "l1:D_x", "l1:D_y", "l1:D_z"]),     # ~90 GB of device state
     "c3-small": ((64, 64, 64), (25.0, 25.0, 25.0), ["bounds", "l1:D_x", "l1:D_y", "l1:D_z"]),
     # BASELINE configs[3] (SURVEY 8d "C4"): 8 constraint sets, two of them non-convex
     "c4": ((512, 512, 512), (25.0, 25.0, 25.0), ["bounds", "l1:D_x", "l1:D_y", "l1:D_z", "annulus", "l1dft", "rank:32", "card:D_z"]),
