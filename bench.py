@@ -89,6 +89,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--config", default="c3", choices=sorted(CONFIGS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--dtype", default="f32", choices=["f32", "f64"],
+                    help="f32 = the contract workload; f64 = the same sets in Float64 (BASELINE config 5 computes in Float64)")
     ap.add_argument("--q-mode", default="cds", choices=["cds", "stencil"],
                     help="cds = the reference's banded Q (the contract workload); stencil = generated coefficients (SURVEY 8f-2)")
     args = ap.parse_args()
@@ -120,7 +122,7 @@ def main():
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     sipx.set_default_device(local_rank)
-    TF = np.float32
+    TF = np.float32 if args.dtype == "f32" else np.float64
     n, h, kinds = CONFIGS[args.config]
     N = int(np.prod(n))
     m = synthetic_model(n, TF, 20240601 + 3)
@@ -203,7 +205,7 @@ def main():
     # HBM traffic of the dominant kernel from the PMC counters: separate rocprofv3 --pmc passes, summarised in profiles/
     traffic, traffic_src = None, None
     pmc = os.path.join(ROOT, "profiles", "r01_c3_256_pmc.json")
-    if args.config == "c3" and args.q_mode == "cds" and os.path.exists(pmc):
+    if args.config == "c3" and args.q_mode == "cds" and args.dtype == "f32" and os.path.exists(pmc):
         traffic = json.load(open(pmc))["dominant_kernel"]["hbm_bytes_per_launch_corrected"]
         traffic_src = "profiles/r01_c3_256_pmc.json (2*FETCH_SIZE + WRITE_SIZE, gfx950 correction)"
     log = drv.result_log()
@@ -232,8 +234,8 @@ def main():
     out = {
         "metric": "PARSDMM iterations/sec", "value": args.steps / dt, "unit": "it/s", "n_gpus": world,
         "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
-        "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-        "config": {"workload": f"{args.config}: {'x'.join(map(str, n))} Float32, sets {{{', '.join(kinds)}}} + distance term",
+        "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+        "config": {"workload": f"{args.config}: {'x'.join(map(str, n))} {'Float32' if args.dtype == 'f32' else 'Float64'}, sets {{{', '.join(kinds)}}} + distance term",
                    "grid": list(n), "sets": kinds, "q_mode": args.q_mode, "parallelism": f"set-sharded x{world}" if world > 1 else "single GPU",
                    "cg_iterations_in_timed_steps": int(cg_its), "all_logs_finite": finite,
                    "driver": "native loop (sipx_parsdmm_begin/_steps)" if native else
@@ -252,7 +254,7 @@ def main():
                                "definition": "SURVEY 8(d) B_iter summed over the timed steps / wall time" +
                                              ("" if world == 1 else " / n_gpus (the replicated x-step is not counted twice)")},
     }
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+    if rank == 0 and world == 1 and not args.no_cpu_baseline and args.dtype == "f32":
         out["cpu_baseline"] = cpu_baseline(args.config, n, h, kinds)
     ctx.close()
     if rank == 0:
