@@ -734,8 +734,8 @@ def PARSDMM(m, AtA, TD_OP, set_Prop, P_sub, comp_grid, options, x=None, l=None, 
 # kernel-level helpers (parity tests / bench)
 # --------------------------------------------------------------------------------------------------
 def cds_spmv(R, offsets, x, device=None):
-    device = _default_device if device is None else device
     """y = A x for a CDS matrix (fill! + CDS_MVp_MT, src/argmin_x.jl:72-78)."""
+    device = _default_device if device is None else device
     TF = x.dtype.type
     R = np.asfortranarray(R, dtype=TF)
     off = np.ascontiguousarray(offsets, np.int64)

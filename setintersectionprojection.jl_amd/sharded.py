@@ -17,7 +17,6 @@ All ranks see identical reduced data, hence take identical decisions.
 """
 from __future__ import annotations
 
-import math
 from typing import List, Optional, Sequence
 
 import numpy as np
