@@ -55,8 +55,11 @@ enum {
   SIPX_PROJ_NUCLEAR     = 9, /* project_nuclear!(x, sigma = pmax), same modes as RANK (projectors/project_nuclear!.jl:3-62) */
   SIPX_PROJ_HISTOGRAM   = 10,/* project_histogram_relaxed!(x, lb, ub): lb/ub ascending TF[M_i]
                                 (projectors/project_histogram_relaxed.jl:9-27) */
-  SIPX_PROJ_SUBSPACE    = 11 /* project_subspace!(x, A, orth): whole vector, fibers of a matrix (2-D) or slices of a
+  SIPX_PROJ_SUBSPACE    = 11,/* project_subspace!(x, A, orth): whole vector, fibers of a matrix (2-D) or slices of a
                                 tensor (3-D)  (projectors/project_subspace!.jl:10-125); op must be identity */
+  SIPX_PROJ_BOUNDS_DFT  = 12 /* x -> Re(F' (ub .* (F x))), F = unitary DFT: bounds in the Fourier domain with a binary lower
+                                bound of zeros and a mask ub TF[N] in the transform's element order
+                                (project_bounds!.jl:27-36 under get_projector.jl:8-9 with TD_OP "DFT"); op must be identity */
 };
 /* constraint.app_mode (set_definitions): ("matrix"|"tensor", _) = WHOLE, ("fiber", d), ("slice", d).
  * dir is the 0-based array dimension: "x" = 0, "y" = 1, "z" = 2 on a 3-D grid, "z" = 1 on a 2-D grid. */

@@ -619,6 +619,17 @@ def project_l1_dft(x, b, n):
     return x
 
 
+def project_bounds_dft(x, UB, n):
+    """x -> Re(F' (UB .* F x)), F the unitary DFT: project_bounds! on a complex vector with binary bounds
+    (src/projectors/project_bounds!.jl:27-36) under src/get_projector.jl:8-9 with TD_OP = "DFT" (joDFT normalisation
+    unpinned, unitary assumed as for project_l1_dft)."""
+    TF = x.dtype.type
+    Z = np.fft.fftn(x.reshape(n, order="F").astype(np.float64), norm="ortho")
+    Z = Z * np.asarray(UB, np.float64).reshape(n, order="F")
+    x[:] = np.real(np.fft.ifftn(Z, norm="ortho")).reshape(-1, order="F").astype(TF)
+    return x
+
+
 def get_projector(constraint: set_definitions, TF, comp_grid=None, TD_n=None) -> Callable:
     """src/get_projector.jl:3-103 for the banded operators (and the DFT-folded l1 ball)."""
     st = constraint.set_type
@@ -630,6 +641,8 @@ def get_projector(constraint: set_definitions, TF, comp_grid=None, TD_n=None) ->
     whole = mode[0] in ("matrix", "tensor")
     if constraint.TD_OP == "DFT" and st == "l1":
         return lambda x: project_l1_dft(x, constraint.max, n)
+    if constraint.TD_OP == "DFT" and st == "bounds":
+        return lambda x: project_bounds_dft(x, constraint.max, n)
     if st == "rank":
         return lambda x: project_rank(x, int(constraint.max), tdn, mode)
     if st == "nuclear":

@@ -822,7 +822,7 @@ class Engine : public EngineBase {
       SIPX_HIP(hipMemcpy(ub, d->ub, len * sizeof(T), hipMemcpyHostToDevice));
     }
     if (prox == SIPX_PROJ_L1 && !(d->pmax > 0)) throw std::runtime_error("Radius of L1 ball is negative");
-    if (d->mode != SIPX_MODE_WHOLE || prox == SIPX_PROJ_L1_DFT || prox >= SIPX_PROJ_RANK) {   // acts on the context grid
+    if (d->mode != SIPX_MODE_WHOLE || prox == SIPX_PROJ_L1_DFT || prox >= SIPX_PROJ_RANK) {   // incl. SIPX_PROJ_BOUNDS_DFT   // acts on the context grid
       if (len != G_.N) throw std::runtime_error("this projector / application mode needs a vector of the grid size");
       SetState<T> st;
       configure_op(st, SIPX_OP_IDENTITY);
@@ -1036,6 +1036,13 @@ class Engine : public EngineBase {
           throw std::runtime_error("the DFT-l1 projector acts in its own domain: TD_OP must be the identity, mode matrix/tensor");
         if (!(d->pmax > 0)) throw std::runtime_error("Radius of L1 ball is negative");
         ext(EXT_L1_DFT);
+        break;
+      case SIPX_PROJ_BOUNDS_DFT:
+        if (d->op != SIPX_OP_IDENTITY || mode != SIPX_MODE_WHOLE)
+          throw std::runtime_error("bounds in the DFT domain act in their own domain: TD_OP must be the identity, mode matrix/tensor");
+        if (!d->ub) throw std::runtime_error("bounds in the DFT domain need the mask vector (constraint.max)");
+        ext(EXT_DFT_MASK);
+        s.host_ub.assign((const T*)d->ub, (const T*)d->ub + G_.N);
         break;
       case SIPX_PROJ_RANK: ext(EXT_RANK); break;
       case SIPX_PROJ_NUCLEAR: ext(EXT_NUCLEAR); break;

@@ -5,7 +5,7 @@
 
 namespace sipx {
 
-enum { EXT_L1_DFT = 1, EXT_RANK = 2, EXT_NUCLEAR = 3, EXT_CARD_SEG = 4, EXT_HISTOGRAM = 5, EXT_SUBSPACE = 6 };
+enum { EXT_L1_DFT = 1, EXT_RANK = 2, EXT_NUCLEAR = 3, EXT_CARD_SEG = 4, EXT_HISTOGRAM = 5, EXT_SUBSPACE = 6, EXT_DFT_MASK = 7 };
 
 // What an ExtProj acts on: the valid extents `dims` (TD_n of the operator) inside the padded grid G (strides G.st),
 // split into segments by the application mode (whole array, fibers along `dir`, slices orthogonal to `dir`).

@@ -61,6 +61,21 @@ __global__ __launch_bounds__(BLOCK) void k_csoft(long long N, Cplx<T>* __restric
     z[e] = c;
   }
 }
+// z <- z .* mask: project_bounds! on a complex vector with binary bounds (project_bounds!.jl:27-36: x .= x .* UB)
+template <typename T>
+__global__ __launch_bounds__(BLOCK) void k_cmask(long long N, Cplx<T>* __restrict__ z, const T* __restrict__ mask) {
+  for (long long e = (long long)blockIdx.x * BLOCK + threadIdx.x; e < N; e += (long long)gridDim.x * BLOCK) {
+    Cplx<T> c = z[e];
+    c.re = c.re * mask[e];
+    c.im = c.im * mask[e];
+    z[e] = c;
+  }
+}
+template <typename T>
+__global__ __launch_bounds__(BLOCK) void k_unpack_all(long long N, const Cplx<T>* __restrict__ z, T* __restrict__ v, T scale) {
+  for (long long e = (long long)blockIdx.x * BLOCK + threadIdx.x; e < N; e += (long long)gridDim.x * BLOCK)
+    v[e] = z[e].re * scale;
+}
 // v <- Re(z)/N -- skipped when v already lies inside the ball: F'F = I, so the reference's round trip
 // A'*(A*x) (get_projector.jl:31) only adds FFT rounding noise there; v is returned bit for bit instead
 // (the noise would otherwise be amplified by the BB rule: l = rho*(y - s) would be pure rounding error).
@@ -435,7 +450,17 @@ ExtProj<T>::ExtProj(const ExtSpec& spec, hipStream_t stream) {
   const Grid& G = spec.G;
   const long long N = G.N;
   const int kind = spec.kind;
-  if (kind == EXT_L1_DFT) {
+  if (kind == EXT_DFT_MASK) {
+    if (!spec.ub) throw std::runtime_error("bounds in the DFT domain need the mask vector (constraint.max)");
+    const hipfftType ty = sizeof(T) == 4 ? HIPFFT_C2C : HIPFFT_Z2Z;
+    if (spec.ndim == 2) fft_check(hipfftPlan2d(&I.plan, (int)G.n[1], (int)G.n[0], ty), "plan2d");
+    else fft_check(hipfftPlan3d(&I.plan, (int)G.n[2], (int)G.n[1], (int)G.n[0], ty), "plan3d");
+    I.have_plan = true;
+    fft_check(hipfftSetStream(I.plan, stream), "set stream");
+    I.z = I.template alloc<Cplx<T>>(N);
+    I.mag = I.template alloc<T>(N);                      // the mask
+    SIPX_HIP(hipMemcpy(I.mag, spec.ub, sizeof(T) * N, hipMemcpyHostToDevice));
+  } else if (kind == EXT_L1_DFT) {
     if (!(spec.pmax > 0)) throw std::runtime_error("Radius of L1 ball is negative");
     const hipfftType ty = sizeof(T) == 4 ? HIPFFT_C2C : HIPFFT_Z2Z;
     if (spec.ndim == 2) fft_check(hipfftPlan2d(&I.plan, (int)G.n[1], (int)G.n[0], ty), "plan2d");   // slowest dimension first
@@ -573,7 +598,15 @@ void ExtProj<T>::project(T* v, bool feas, double* partials, T* maxpart, T* compa
   const long long N = I.sp.G.N;
   hipStream_t s = I.stream;
   const int kind = I.sp.kind;
-  if (kind == EXT_L1_DFT) {
+  if (kind == EXT_DFT_MASK) {       // x -> Re(F' (UB .* F x)); the unitary factors of F and F' cancel into 1/N
+    hipLaunchKernelGGL((k_pack<T>), dim3(NB), dim3(BLOCK), 0, s, N, v, I.z);
+    if (sizeof(T) == 4) fft_check(hipfftExecC2C(I.plan, (hipfftComplex*)I.z, (hipfftComplex*)I.z, HIPFFT_FORWARD), "forward");
+    else fft_check(hipfftExecZ2Z(I.plan, (hipfftDoubleComplex*)I.z, (hipfftDoubleComplex*)I.z, HIPFFT_FORWARD), "forward");
+    hipLaunchKernelGGL((k_cmask<T>), dim3(NB), dim3(BLOCK), 0, s, N, I.z, I.mag);
+    if (sizeof(T) == 4) fft_check(hipfftExecC2C(I.plan, (hipfftComplex*)I.z, (hipfftComplex*)I.z, HIPFFT_BACKWARD), "inverse");
+    else fft_check(hipfftExecZ2Z(I.plan, (hipfftDoubleComplex*)I.z, (hipfftDoubleComplex*)I.z, HIPFFT_BACKWARD), "inverse");
+    hipLaunchKernelGGL((k_unpack_all<T>), dim3(NB), dim3(BLOCK), 0, s, N, I.z, v, (T)(1.0 / (double)N));
+  } else if (kind == EXT_L1_DFT) {
     ProjScalars<T>* ps = feas ? I.psf : I.ps;
     hipLaunchKernelGGL((k_pack<T>), dim3(NB), dim3(BLOCK), 0, s, N, v, I.z);
     if (sizeof(T) == 4) fft_check(hipfftExecC2C(I.plan, (hipfftComplex*)I.z, (hipfftComplex*)I.z, HIPFFT_FORWARD), "forward");

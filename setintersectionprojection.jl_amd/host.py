@@ -38,7 +38,7 @@ EXPORTED_SYMBOLS = [
 SIPX_F32, SIPX_F64 = 0, 1
 OPS = {"identity": 0, "D_x": 1, "D_y": 2, "D_z": 3, "TV": 4, "D2D": 4, "D3D": 4}
 PROJ = {"bounds": 0, "bounds_vec": 1, "l1": 2, "l2": 3, "annulus": 4, "cardinality": 5, "prox_l1": 6, "l1_dft": 7, "rank": 8,
-        "nuclear": 9, "histogram": 10, "subspace": 11}
+        "nuclear": 9, "histogram": 10, "subspace": 11, "bounds_dft": 12}
 MODES = {"matrix": 0, "tensor": 0, "fiber": 1, "slice": 2}
 SPECIAL_OPERATORS = ("DFT", "DCT", "wavelet", "curvelet")     # src/setup_constraints.jl:54
 YL_FEAS, YL_BB, YL_FIRST = 1, 2, 4
@@ -277,9 +277,16 @@ class Projector:
         self.basis_orth = False
         self.pmin = self.pmax = 0.0
         if constraint.TD_OP in SPECIAL_OPERATORS:
-            if not (constraint.TD_OP == "DFT" and st == "l1"):
-                raise SipxError("of the orthogonal-transform sets only the l1 ball in the DFT domain is built")
-            self.kind, self.pmax = "l1_dft", float(constraint.max)
+            if constraint.TD_OP == "DFT" and st == "l1":
+                self.kind, self.pmax = "l1_dft", float(constraint.max)
+            elif constraint.TD_OP == "DFT" and st == "bounds" and np.ndim(constraint.min) == 1:
+                lb = np.asarray(constraint.min)
+                ub = np.ascontiguousarray(constraint.max, self.TF)
+                if np.any(lb != 0) or len(np.unique(ub)) != 2:        # project_bounds!.jl:31-32 (@assert)
+                    raise SipxError("bounds in the DFT domain: LB must be all zeros and UB a two-valued mask")
+                self.kind, self.ub = "bounds_dft", ub
+            else:
+                raise SipxError("of the orthogonal-transform sets only the l1 ball and masking bounds in the DFT domain are built")
         elif st == "rank":
             self.kind, self.pmax = "rank", float(int(constraint.max))
         elif st == "nuclear":
@@ -323,6 +330,8 @@ class Projector:
             want = n[self.dir] if self.mode == MODES["fiber"] else rows
             if self.lb.shape != (want,) or self.ub.shape != (want,):
                 raise SipxError(f"bounds vectors need {want} entries for this operator / application mode")
+        if self.kind == "bounds_dft" and self.ub.shape != (rows,):
+            raise SipxError(f"the DFT-domain mask needs {rows} entries")
         if self.kind == "histogram" and (self.lb.shape != (rows,) or self.ub.shape != (rows,)):
             raise SipxError(f"histogram bounds need {rows} sorted entries")
 
@@ -341,7 +350,7 @@ class Projector:
     def __call__(self, v):
         if v.dtype.type != self.TF or not v.flags.c_contiguous:
             raise SipxError("projector input must be a contiguous vector of the working precision")
-        grid_kind = self.mode != 0 or self.kind in ("l1_dft", "rank", "nuclear", "histogram", "subspace")
+        grid_kind = self.mode != 0 or self.kind in ("l1_dft", "bounds_dft", "rank", "nuclear", "histogram", "subspace")
         ctx = Context(self.comp_grid if grid_kind else compgrid((1.0, 1.0), (max(len(v), 1), 1)), self.TF)
         try:
             if grid_kind:

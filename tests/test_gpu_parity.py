@@ -88,6 +88,10 @@ def _problem(mod, n, h, TF, kinds, m, opt_kw=None):
         elif k == "l1dft":
             Z = np.abs(np.fft.fftn(m.reshape(n, order="F").astype(np.float64), norm="ortho"))
             c.append(mod.set_definitions("l1", "DFT", 0.0, float(0.25 * Z.sum()), ("matrix", "")))
+        elif k == "dftmask":                  # low-pass mask in the Fourier domain (symmetric, so the result stays real)
+            f = np.meshgrid(*[np.minimum(np.arange(d), d - np.arange(d)) / (d / 2) for d in n], indexing="ij")
+            keep = (sum(v ** 2 for v in f) <= 0.6 ** 2).astype(TF).reshape(-1, order="F")
+            c.append(mod.set_definitions("bounds", "DFT", np.zeros(m.size, TF), keep, ("matrix", "")))
         elif k.startswith("rank:"):
             mode = ("matrix", "") if len(n) == 2 else ("slice", "z")
             c.append(mod.set_definitions("rank", "identity", 0, int(k[5:]), mode))
@@ -346,6 +350,7 @@ CASES = [
     ("2d-nonconvex-cardinality", (32, 24), (1.0, 1.0), ["bounds", "card:D_z"]),
     ("3d-dft-l1", (16, 12, 8), (25.0, 25.0, 25.0), ["bounds", "l1dft"]),
     ("3d-slice-rank", (16, 12, 8), (25.0, 25.0, 25.0), ["bounds", "rank:3"]),
+    ("3d-dft-lowpass-mask", (16, 12, 8), (25.0, 25.0, 25.0), ["bounds", "dftmask", "l1:D_z"]),
     ("2d-rank", (32, 24), (25.0, 6.0), ["bounds", "rank:4", "l1:TV"]),
     ("2d-l1-identity-all-active", (32, 24), (25.0, 6.0), ["bounds", "l1id:0.9"]),
     ("3d-card-fiber-Dz", (16, 12, 8), (25.0, 25.0, 25.0), ["bounds", "cardf:D_z:fiber:x"]),
@@ -998,3 +1003,20 @@ def test_asymmetric_explicit_bands_fall_back_to_the_full_read(sipx):
     y = ctx.apply_Q(x)
     ctx.close()
     assert np.array_equal(y, O.Ax_CDS(x, Qo, offo))
+
+
+@pytest.mark.parametrize("TF", [np.float32, np.float64])
+def test_dft_domain_mask_projector(sipx, TF):
+    rng = np.random.default_rng(17)
+    for n in ((16, 12, 8), (32, 24)):
+        N = int(np.prod(n))
+        v = rng.standard_normal(N).astype(TF)
+        mask = (rng.random(N) < 0.4).astype(TF)
+        want = O.project_bounds_dft(v.copy(), mask, n)
+        c = sipx.set_definitions("bounds", "DFT", np.zeros(N, TF), mask, ("matrix", ""))
+        got = sipx.host.Projector(c, sipx.compgrid(tuple(1.0 for _ in n), n), TF)(v.copy())
+        tol = 5e-6 if TF == np.float32 else 1e-13
+        assert np.abs(got.astype(np.float64) - want).max() <= tol * max(1.0, np.abs(want).max())
+    with pytest.raises(sipx.SipxError, match="two-valued mask"):
+        sipx.host.Projector(sipx.set_definitions("bounds", "DFT", np.zeros(8, TF), np.arange(8).astype(TF), ("matrix", "")),
+                            sipx.compgrid((1.0, 1.0), (4, 2)), TF)
