@@ -643,6 +643,24 @@ def get_projector(constraint: set_definitions, TF, comp_grid=None, TD_n=None) ->
         return lambda x: project_l1_dft(x, constraint.max, n)
     if constraint.TD_OP == "DFT" and st == "bounds":
         return lambda x: project_bounds_dft(x, constraint.max, n)
+    if constraint.TD_OP == "DFT" and st in ("l2", "annulus"):
+        def through_dft(x):                                  # literal x -> Re(F' P(F x)) with the unitary DFT
+            TFx = x.dtype.type
+            Z = np.fft.fftn(x.reshape(n, order="F").astype(np.float64), norm="ortho").reshape(-1, order="F")
+            nz = float(np.sqrt((np.abs(Z) ** 2).sum()))
+            if st == "l2":
+                Z = Z if nz <= float(constraint.max) else Z * (float(constraint.max) / nz)
+            else:
+                lo, hi = float(constraint.min), float(constraint.max)
+                if nz > hi:
+                    Z = Z * (hi / nz)
+                elif nz < lo and nz > 0:
+                    Z = Z * (lo / nz)
+                elif nz < lo:
+                    Z = np.full_like(Z, lo / np.sqrt(len(Z)))
+            x[:] = np.real(np.fft.ifftn(Z.reshape(n, order="F"), norm="ortho")).reshape(-1, order="F").astype(TFx)
+            return x
+        return through_dft
     if st == "rank":
         return lambda x: project_rank(x, int(constraint.max), tdn, mode)
     if st == "nuclear":

@@ -285,8 +285,15 @@ class Projector:
                 if np.any(lb != 0) or len(np.unique(ub)) != 2:        # project_bounds!.jl:31-32 (@assert)
                     raise SipxError("bounds in the DFT domain: LB must be all zeros and UB a two-valued mask")
                 self.kind, self.ub = "bounds_dft", ub
+            elif constraint.TD_OP == "DFT" and st in ("l2", "annulus"):
+                # ||F x||_2 = ||x||_2 for the unitary DFT and the projection is a rescaling (or, for the zero vector of an
+                # annulus, a constant fill whose DC-only spectrum transforms back to a constant): x -> Re(F' P(F x)) is
+                # P applied to x itself, without the FFT round trip of get_projector.jl:39,47
+                self.kind, self.pmax = st, float(constraint.max)
+                self.pmin = float(constraint.min) if st == "annulus" else 0.0
             else:
-                raise SipxError("of the orthogonal-transform sets only the l1 ball and masking bounds in the DFT domain are built")
+                raise SipxError("of the orthogonal-transform sets only the l1 ball, masking bounds, the l2 ball and the annulus "
+                                "in the DFT domain are built")
         elif st == "rank":
             self.kind, self.pmax = "rank", float(int(constraint.max))
         elif st == "nuclear":

@@ -1020,3 +1020,18 @@ def test_dft_domain_mask_projector(sipx, TF):
     with pytest.raises(sipx.SipxError, match="two-valued mask"):
         sipx.host.Projector(sipx.set_definitions("bounds", "DFT", np.zeros(8, TF), np.arange(8).astype(TF), ("matrix", "")),
                             sipx.compgrid((1.0, 1.0), (4, 2)), TF)
+
+
+@pytest.mark.parametrize("TF", [np.float32, np.float64])
+def test_l2_and_annulus_behind_the_dft_equal_the_plain_projectors(sipx, TF):
+    rng = np.random.default_rng(18)
+    n = (16, 12, 8)
+    N = int(np.prod(n))
+    v = rng.standard_normal(N).astype(TF)
+    nv = float(np.linalg.norm(v.astype(np.float64)))
+    g_o, g_s = O.compgrid((1.0,) * 3, n), sipx.compgrid((1.0,) * 3, n)
+    for st_, lo, hi in (("l2", 0.0, 0.5 * nv), ("l2", 0.0, 2.0 * nv), ("annulus", 1.5 * nv, 2.0 * nv), ("annulus", 0.2 * nv, 0.7 * nv)):
+        want = O.get_projector(O.set_definitions(st_, "DFT", lo, hi, ("tensor", "")), TF, g_o)(v.copy())
+        got = sipx.host.Projector(sipx.set_definitions(st_, "DFT", lo, hi, ("tensor", "")), g_s, TF)(v.copy())
+        tol = 5e-6 if TF == np.float32 else 1e-12
+        assert np.abs(got.astype(np.float64) - want).max() <= tol * np.abs(want).max(), (st_, lo, hi)
