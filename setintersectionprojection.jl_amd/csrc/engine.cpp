@@ -100,7 +100,12 @@ struct SetState {
   long long blk_rows[3] = {0, 0, 0};
   T plo = 0, phi = 0;
   bool ident = true, two_pass = false, is_dist = false, owned = true;
+  // y, l: the arrays holding the current iterate; y0, l0: the other pair.  The snapshot (y_0, l_0) of the BB rule lives
+  // in whichever pair `snap` names: on a snapshot iteration the update is written over the old snapshot (after it has
+  // been read), on the others into the pair that is not the snapshot -- the reference's copies y_0 <- y, l_0 <- l never
+  // happen (PARSDMM.jl:174-177,200-203).
   T *y = nullptr, *l = nullptr, *dy = nullptr, *lh0 = nullptr, *y0 = nullptr, *s0 = nullptr, *l0 = nullptr;
+  int snap = -1;                     // -1: no snapshot yet; 0: (y, l) is also the snapshot; 1: (y0, l0) is
   T *lb = nullptr, *ub = nullptr, *ata = nullptr;
   std::vector<void*> halo_allocs;   // bases of the vectors allocated with a front halo
   int ext_kind = 0;                  // projector acting on a materialised vector (ext_proj.h)
@@ -311,7 +316,8 @@ class Engine : public EngineBase {
         return base + halo_;
       };
       s.y = halloc(s.Mpad); s.l = halloc(s.Mpad);
-      s.lh0 = dalloc<T>(s.Mpad); s.y0 = dalloc<T>(s.Mpad); s.s0 = dalloc<T>(s.Mpad); s.l0 = dalloc<T>(s.Mpad);
+      s.lh0 = dalloc<T>(s.Mpad); s.s0 = dalloc<T>(s.Mpad);
+      s.y0 = halloc(s.Mpad); s.l0 = halloc(s.Mpad);       // take turns with y, l as the current iterate: same halo
       if (!s.ident) s.dy = halloc(s.Mpad);
       if (s.ext_kind) {
         s.spec.lb = s.host_lb.empty() ? nullptr : s.host_lb.data();
@@ -497,6 +503,14 @@ class Engine : public EngineBase {
       T* mpart = s.mpart ? s.mpart : maxpart_;
       T* cbuf = s.cbuf ? s.cbuf : scr_c_;
       if (s.st) SIPX_HIP(hipStreamWaitEvent(s.st, ev_fork_, 0));
+      // where y_new, l_new go (see SetState): snapshot iterations overwrite the old snapshot, the others stay off it
+      const bool snapshot = (flags & (SIPX_YL_BB | SIPX_YL_FIRST)) != 0;
+      const bool first = (flags & SIPX_YL_FIRST) != 0;
+      bool to_other;
+      if (snapshot) to_other = !first && s.snap != 0;     // first: in place, (y, l) becomes the snapshot; no snapshot yet:
+      else to_other = s.snap == 0;                        // the zero-filled other pair stands in for it, as before
+      a.yo = to_other ? s.y0 : s.y;
+      a.lo = to_other ? s.l0 : s.l;
       if (s.ext_kind) {   // library-backed projector: materialise v, project it in place, hand y to the fused update
         K<T>::store_v(q, G_, a, 0, scr_v_);
         s.ext->project(scr_v_, false, ptmp, mpart, cbuf);
@@ -517,6 +531,9 @@ class Engine : public EngineBase {
         K<T>::proj_scalars_set(q, G_, a, 1, s.psf, ptmp, mpart, cbuf, s.Mtrue);
         K<T>::proj_dist_set(q, G_, a, 1, s.psf, part + (size_t)SL_FE2 * NB);
       }
+      if (to_other) { std::swap(s.y, s.y0); std::swap(s.l, s.l0); }     // (y, l) always names the current iterate
+      if (snapshot) s.snap = 0;
+      else if (to_other && s.snap == 0) s.snap = 1;
       if (s.st) SIPX_HIP(hipEventRecord(s.ev, s.st));
     }
     for (int i = 0; i < p_n_; ++i)                                      // join: the reductions below see every set
@@ -1242,7 +1259,10 @@ class Engine : public EngineBase {
 
   SetArgs<T> set_args(const SetState<T>& s, T rho, T gamma, int flags) const {
     SetArgs<T> a;
-    a.y = s.y; a.l = s.l; a.dy = s.dy; a.lh0 = s.lh0; a.y0 = s.y0; a.s0 = s.s0; a.l0 = s.l0;
+    a.y = s.y; a.l = s.l; a.dy = s.dy; a.lh0 = s.lh0; a.s0 = s.s0;
+    a.y0 = s.snap == 0 ? s.y : s.y0;          // the snapshot pair (the zero-filled other pair before the first snapshot)
+    a.l0 = s.snap == 0 ? s.l : s.l0;
+    a.yo = s.y; a.lo = s.l;
     a.v = scr_v_;
     a.x = x_; a.m = m_; a.xold = xold_; a.lb = s.lb; a.ub = s.ub;
     a.nblk = s.nblk;
@@ -1322,7 +1342,7 @@ class Engine : public EngineBase {
     if (s.ev) (void)hipEventDestroy(s.ev);
     for (void* p : {(void*)s.ptmp, (void*)s.mpart, (void*)s.cbuf}) dfree(p);
     for (void* p : s.halo_allocs) dfree(p);
-    for (void* p : {(void*)s.lh0, (void*)s.y0, (void*)s.s0, (void*)s.l0, (void*)s.lb, (void*)s.ub, (void*)s.ata,
+    for (void* p : {(void*)s.lh0, (void*)s.s0, (void*)s.lb, (void*)s.ub, (void*)s.ata,
                     (void*)s.ps, (void*)s.psf})
       dfree(p);
   }

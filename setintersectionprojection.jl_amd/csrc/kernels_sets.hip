@@ -175,13 +175,11 @@ __global__ __launch_bounds__(BLOCK) void k_yl(Grid G, SetArgs<T> a, double* __re
         Vec<T, V> sv;
 #pragma unroll
         for (int k = 0; k < V; ++k) sv.v[k] = s[k];
-        stv<T, V>(a.lh0 + e, lh);
-        stv<T, V>(a.y0 + e, yn);
-        stv<T, V>(a.s0 + e, sv);
-        stv<T, V>(a.l0 + e, ln);
+        stv<T, V>(a.lh0 + e, lh);          // y_0 <- y and l_0 <- l need no copy: on these iterations the update below
+        stv<T, V>(a.s0 + e, sv);           // is written into the snapshot arrays themselves (engine, update_y_l)
       }
-      stv<T, V>(a.y + e, yn);
-      stv<T, V>(a.l + e, ln);
+      stv<T, V>(a.yo + e, yn);
+      stv<T, V>(a.lo + e, ln);
       if (!ident) stv<T, V>(a.dy + e, dyv);
     }
   }

@@ -89,7 +89,8 @@ struct ProjScalars {
 
 template <typename T>
 struct SetArgs {
-  T *y, *l, *dy, *lh0, *y0, *s0, *l0;   // per-set state, padded layout nblk*N
+  T *y, *l, *dy, *lh0, *y0, *s0, *l0;   // per-set state, padded layout nblk*N (y, l: current = y_old, l_old on entry)
+  T *yo, *lo;                           // where the updated y, l go: y/l themselves, or the array holding the snapshot y0/l0
   T* v;                                 // scratch (v = x_hat - l/rho) for two-pass projectors
   const T *x, *m, *xold, *lb, *ub;
   int nblk;
