@@ -734,9 +734,13 @@ def build_context(m, AtA, TD_OP, set_Prop, P_sub, comp_grid, options, x=None, l=
 
 def PARSDMM(m, AtA, TD_OP, set_Prop, P_sub, comp_grid, options, x=None, l=None, y=None, device=None):
     """Drop-in for src/PARSDMM.jl:25-258 (serial path): returns (x, log_PARSDMM, l, y)."""
+    import time
+    t0 = time.perf_counter()
     ctx = build_context(m, AtA, TD_OP, set_Prop, P_sub, comp_grid, options, x, l, y, device)
+    t_init = time.perf_counter() - t0
     try:
         log, _ = ctx.parsdmm(options)
+        log.timing[TIMING_SECTIONS[0]] = t_init          # "initialization": PARSDMM_initialize (src/PARSDMM.jl:40)
         xo, lo, yo = ctx.download()
     finally:
         ctx.close()
