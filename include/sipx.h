@@ -64,6 +64,7 @@ enum {
 /* constraint.app_mode (set_definitions): ("matrix"|"tensor", _) = WHOLE, ("fiber", d), ("slice", d).
  * dir is the 0-based array dimension: "x" = 0, "y" = 1, "z" = 2 on a 3-D grid, "z" = 1 on a 2-D grid. */
 enum { SIPX_MODE_WHOLE = 0, SIPX_MODE_FIBER = 1, SIPX_MODE_SLICE = 2 };
+enum { SIPX_TRANSFORM_NONE = 0, SIPX_TRANSFORM_DCT = 1 };
 
 typedef struct {
   int32_t op;        /* SIPX_OP_*   */
@@ -84,7 +85,10 @@ typedef struct {
                         u + v ([A A]).  Either every set of a context names a component or none does.  With components the
                         unknown is x = [u; v] (2N entries in x0 / sipx_download / sipx_apply_Q), the distance term is
                         1/2 ||u + v - m||^2, and Q is the 2N x 2N CDS matrix of the reference. */
-  int32_t pad_;
+  int32_t transform; /* SIPX_TRANSFORM_*: an orthogonal transform folded into the projector, x -> A' P(A x) with TD_OP = I
+                        (src/get_projector.jl: the branches `constraint.TD_OP in special_operator_list`,
+                        src/setup_constraints.jl:54,76-80).  DCT = orthonormal DCT-II along every grid dimension; proj must be
+                        BOUNDS, BOUNDS_VEC, L1 or CARDINALITY (mode WHOLE), op the identity.  The DFT has its own kinds above. */
 } sipx_set_desc;
 
 /* PARSDMM_options (src/SetIntersectionProjection.jl:110-128); Blas_active / parallel / FL /

@@ -270,7 +270,7 @@ def get_TD_operator(comp_grid, TD_type: str, TF):
     N = int(np.prod(n))
     if TD_type == "identity":
         return sp.identity(N, dtype=TF, format="csc"), True, False, n, True
-    if TD_type == "DFT":   # the transform is folded into the projector, TD_OP becomes I (setup_constraints.jl:76-80)
+    if TD_type in ("DFT", "DCT"):   # the transform is folded into the projector, TD_OP becomes I (setup_constraints.jl:76-80)
         return sp.identity(N, dtype=TF, format="csc"), True, True, n, True
     A = get_discrete_Grad(n, h, TD_type, TF)
     if len(n) == 2:
@@ -639,6 +639,31 @@ def get_projector(constraint: set_definitions, TF, comp_grid=None, TD_n=None) ->
     tdn = tuple(int(v) for v in TD_n) if TD_n is not None else n
     mode = tuple(constraint.app_mode)
     whole = mode[0] in ("matrix", "tensor")
+    if constraint.TD_OP == "DCT":
+        # x -> C' P(C x), C the orthonormal DCT-II along every dimension (joDCT normalisation unpinned, orthonormal assumed)
+        import scipy.fft as sfft
+        if st == "l1":
+            inner = lambda c: project_l1_Duchi(c, constraint.max)
+        elif st == "cardinality":
+            inner = lambda c: project_cardinality(c, int(constraint.max))
+        elif st == "bounds":
+            inner = lambda c: project_bounds(c, constraint.min, constraint.max)
+        elif st == "l2":
+            inner = lambda c: project_l2(c, constraint.max)
+        elif st == "annulus":
+            inner = lambda c: project_annulus(c, constraint.min, constraint.max)
+        else:
+            raise NotImplementedError(f"{st} behind the DCT")
+
+        def through_dct(x):
+            TFx = x.dtype.type
+            c = sfft.dctn(x.reshape(n, order="F").astype(np.float64), norm="ortho").reshape(-1, order="F").astype(TFx)
+            if st == "l1" and asum(c, TFx) <= TFx(constraint.max):
+                return x                                       # inside the ball: C'C = I, x returned untouched
+            c = inner(c)
+            x[:] = sfft.idctn(c.astype(np.float64).reshape(n, order="F"), norm="ortho").reshape(-1, order="F").astype(TFx)
+            return x
+        return through_dct
     if constraint.TD_OP == "DFT" and st == "l1":
         return lambda x: project_l1_dft(x, constraint.max, n)
     if constraint.TD_OP == "DFT" and st == "bounds":

@@ -832,14 +832,14 @@ class Engine : public EngineBase {
     SIPX_HIP(hipMemcpy(dv, v, len * sizeof(T), hipMemcpyHostToDevice));
     const int prox = d->proj;
     const T plo = (T)d->pmin, phi = (T)d->pmax;
-    if (prox == SIPX_PROJ_BOUNDS_VEC && d->mode == SIPX_MODE_WHOLE) {
+    if (prox == SIPX_PROJ_BOUNDS_VEC && d->mode == SIPX_MODE_WHOLE && d->transform == SIPX_TRANSFORM_NONE) {
       if (!d->lb || !d->ub) throw std::runtime_error("per-element bounds need lb and ub");
       lb = dalloc<T>(len); ub = dalloc<T>(len);
       SIPX_HIP(hipMemcpy(lb, d->lb, len * sizeof(T), hipMemcpyHostToDevice));
       SIPX_HIP(hipMemcpy(ub, d->ub, len * sizeof(T), hipMemcpyHostToDevice));
     }
     if (prox == SIPX_PROJ_L1 && !(d->pmax > 0)) throw std::runtime_error("Radius of L1 ball is negative");
-    if (d->mode != SIPX_MODE_WHOLE || prox == SIPX_PROJ_L1_DFT || prox >= SIPX_PROJ_RANK) {   // incl. SIPX_PROJ_BOUNDS_DFT   // acts on the context grid
+    if (d->mode != SIPX_MODE_WHOLE || d->transform != SIPX_TRANSFORM_NONE || prox == SIPX_PROJ_L1_DFT || prox >= SIPX_PROJ_RANK) {   // incl. SIPX_PROJ_BOUNDS_DFT   // acts on the context grid
       if (len != G_.N) throw std::runtime_error("this projector / application mode needs a vector of the grid size");
       SetState<T> st;
       configure_op(st, SIPX_OP_IDENTITY);
@@ -997,6 +997,24 @@ class Engine : public EngineBase {
       s.prox = PX_EXT;
       need_ext_ = true;
     };
+    if (d->transform == SIPX_TRANSFORM_DCT) {      // x -> C' P(C x): P acts on the DCT coefficients (ext_proj.hip)
+      if (d->op != SIPX_OP_IDENTITY || mode != SIPX_MODE_WHOLE)
+        throw std::runtime_error("sets behind the DCT act in their own domain: TD_OP must be the identity, mode matrix/tensor");
+      if (d->proj != SIPX_PROJ_BOUNDS && d->proj != SIPX_PROJ_BOUNDS_VEC && d->proj != SIPX_PROJ_L1 &&
+          d->proj != SIPX_PROJ_CARDINALITY)
+        throw std::runtime_error("behind the DCT: bounds, the l1 ball and cardinality are built (l2 / annulus commute with it)");
+      if (d->proj == SIPX_PROJ_L1 && !(d->pmax > 0)) throw std::runtime_error("Radius of L1 ball is negative");
+      if (d->proj == SIPX_PROJ_BOUNDS_VEC) {
+        if (!d->lb || !d->ub) throw std::runtime_error("per-element bounds need lb and ub");
+        s.host_lb.assign((const T*)d->lb, (const T*)d->lb + G_.N);
+        s.host_ub.assign((const T*)d->ub, (const T*)d->ub + G_.N);
+      }
+      ext(EXT_DCT);
+      s.spec.inner = d->proj;
+      return;
+    } else if (d->transform != SIPX_TRANSFORM_NONE) {
+      throw std::runtime_error("unknown transform");
+    }
     switch (d->proj) {
       case SIPX_PROJ_BOUNDS:
         if (mode != SIPX_MODE_WHOLE) throw std::runtime_error("scalar bounds apply to the whole array (use per-fiber vectors)");

@@ -5,7 +5,7 @@
 
 namespace sipx {
 
-enum { EXT_L1_DFT = 1, EXT_RANK = 2, EXT_NUCLEAR = 3, EXT_CARD_SEG = 4, EXT_HISTOGRAM = 5, EXT_SUBSPACE = 6, EXT_DFT_MASK = 7 };
+enum { EXT_L1_DFT = 1, EXT_RANK = 2, EXT_NUCLEAR = 3, EXT_CARD_SEG = 4, EXT_HISTOGRAM = 5, EXT_SUBSPACE = 6, EXT_DFT_MASK = 7, EXT_DCT = 8 };
 
 // What an ExtProj acts on: the valid extents `dims` (TD_n of the operator) inside the padded grid G (strides G.st),
 // split into segments by the application mode (whole array, fibers along `dir`, slices orthogonal to `dir`).
@@ -16,6 +16,7 @@ struct ExtSpec {
   long long dims[3] = {1, 1, 1};
   int mode = 0, dir = 2;          // SIPX_MODE_*, 0-based direction
   double pmin = 0, pmax = 0;
+  int inner = 0;                  // EXT_DCT: the SIPX_PROJ_* kind applied to the transform coefficients
   const void* lb = nullptr;       // EXT_HISTOGRAM: host TF[prod(dims)], ascending
   const void* ub = nullptr;
   const void* basis = nullptr;    // EXT_SUBSPACE: host TF[basis_rows x basis_cols], column-major

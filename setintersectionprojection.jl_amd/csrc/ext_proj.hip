@@ -379,6 +379,10 @@ struct ExtImpl {
   double *Ad = nullptr, *Ud = nullptr, *Sd = nullptr, *Vd = nullptr, *Ed = nullptr;
   double *Gd = nullptr, *Gs = nullptr, *Wd = nullptr;     // Gram route: eigenvectors, scaled copy, eigenvalues
   bool gram = false;
+  // DCT: orthonormal DCT-II matrices per dimension, two work arrays, inner projector state
+  T* Cm[3] = {nullptr, nullptr, nullptr};
+  T *W1 = nullptr, *W2 = nullptr, *dlb = nullptr, *dub = nullptr;
+  long long* cidx = nullptr;
   rocblas_int* info = nullptr;
   int* flag = nullptr;
   // histogram
@@ -513,6 +517,38 @@ ExtProj<T>::ExtProj(const ExtSpec& spec, hipStream_t stream) {
     }
     I.info = I.template alloc<rocblas_int>((size_t)2 * I.batch);   // info + n_sweeps
     I.flag = I.template alloc<int>((size_t)I.batch);
+  } else if (kind == EXT_DCT) {
+    // Orthonormal DCT-II along every dimension as dense n_d x n_d matrices (built in float64, rounded to TF once):
+    // C[k, i] = s_k cos(pi (2i+1) k / (2n)), s_0 = sqrt(1/n), s_k = sqrt(2/n).  joDCT's normalisation is not pinned by any
+    // reference test; orthonormal is assumed (the operator declares AtA_diag, get_TD_operator.jl:49-51,84-86).
+    const double PI = 3.14159265358979323846;
+    for (int a = 0; a < spec.ndim; ++a) {
+      const int n = (int)G.n[a];
+      std::vector<T> C((size_t)n * n);
+      for (int i = 0; i < n; ++i)
+        for (int k = 0; k < n; ++k)
+          C[(size_t)i * n + k] = (T)((k == 0 ? std::sqrt(1.0 / n) : std::sqrt(2.0 / n)) * std::cos(PI * (2.0 * i + 1.0) * k / (2.0 * n)));
+      I.Cm[a] = I.template alloc<T>((size_t)n * n);      // column-major n x n: element (k, i) at k + n i
+      SIPX_HIP(hipMemcpy(I.Cm[a], C.data(), sizeof(T) * C.size(), hipMemcpyHostToDevice));
+    }
+    I.W1 = I.template alloc<T>(N);
+    I.W2 = I.template alloc<T>(N);
+    blas_check(rocblas_create_handle(&I.blas), "create handle");
+    blas_check(rocblas_set_stream(I.blas, stream), "set stream");
+    const int in = spec.inner;
+    if (in == SIPX_PROJ_L1 || in == SIPX_PROJ_CARDINALITY) {
+      I.ps = I.template alloc<ProjScalars<T>>(1);
+      I.psf = I.template alloc<ProjScalars<T>>(1);
+      if (in == SIPX_PROJ_CARDINALITY) I.cidx = I.template alloc<long long>(N);
+      K<T>::ps_init(stream, I.ps, I.cidx);
+      K<T>::ps_init(stream, I.psf, I.cidx);
+    }
+    if (in == SIPX_PROJ_BOUNDS_VEC) {
+      if (!spec.lb || !spec.ub) throw std::runtime_error("per-element bounds need lb and ub");
+      I.dlb = I.template alloc<T>(N); I.dub = I.template alloc<T>(N);
+      SIPX_HIP(hipMemcpy(I.dlb, spec.lb, sizeof(T) * N, hipMemcpyHostToDevice));
+      SIPX_HIP(hipMemcpy(I.dub, spec.ub, sizeof(T) * N, hipMemcpyHostToDevice));
+    }
   } else if (kind == EXT_CARD_SEG) {
     if (spec.mode != SIPX_MODE_FIBER && spec.mode != SIPX_MODE_SLICE)
       throw std::runtime_error("segmented cardinality needs a fiber or slice mode");
@@ -589,6 +625,24 @@ static rocblas_status gemm_T(rocblas_handle h, rocblas_operation ta, rocblas_ope
                              int lda, const double* B, int ldb, double* C, int ldc) {
   const double one = 1.0, zero = 0.0;
   return rocblas_dgemm(h, ta, tb, m, n, k, &one, A, lda, B, ldb, &zero, C, ldc);
+}
+
+static rocblas_status gemm_sb(rocblas_handle h, rocblas_operation ta, rocblas_operation tb, int m, int n, int k, const float* A,
+                              int lda, long long sa, const float* B, int ldb, long long sb, float* C, int ldc, long long sc, int batch) {
+  const float one = 1.f, zero = 0.f;
+  return rocblas_sgemm_strided_batched(h, ta, tb, m, n, k, &one, A, lda, sa, B, ldb, sb, &zero, C, ldc, sc, batch);
+}
+static rocblas_status gemm_sb(rocblas_handle h, rocblas_operation ta, rocblas_operation tb, int m, int n, int k, const double* A,
+                              int lda, long long sa, const double* B, int ldb, long long sb, double* C, int ldc, long long sc, int batch) {
+  const double one = 1.0, zero = 0.0;
+  return rocblas_dgemm_strided_batched(h, ta, tb, m, n, k, &one, A, lda, sa, B, ldb, sb, &zero, C, ldc, sc, batch);
+}
+// dst <- src when the last search found v outside the set (ps->need), or always when ps == nullptr
+template <typename T>
+__global__ __launch_bounds__(BLOCK) void k_copy_if_needed(long long N, const T* __restrict__ src, T* __restrict__ dst,
+                                                          const ProjScalars<T>* __restrict__ ps) {
+  if (ps && !ps->need) return;
+  for (long long e = (long long)blockIdx.x * BLOCK + threadIdx.x; e < N; e += (long long)gridDim.x * BLOCK) dst[e] = src[e];
 }
 
 // v <- P(v) in place.  `feas` selects the independent warm-start state used for the feasibility estimate.
@@ -677,6 +731,43 @@ void ExtProj<T>::project(T* v, bool feas, double* partials, T* maxpart, T* compa
                                              I.Ud, I.m, sU, I.Vd, k, sV, &zero, I.Ad, I.m, sA, I.batch),
                "gemm");
     hipLaunchKernelGGL((k_seg_scatter<T, double>), dim3(NB), dim3(BLOCK), 0, s, I.map, I.Ad, v, flag);
+  } else if (kind == EXT_DCT) {
+    const Grid& G = I.sp.G;
+    const int n1 = (int)G.n[0], n2 = (int)G.n[1], n3 = (int)G.n[2];
+    const auto N_ = rocblas_operation_none, T_ = rocblas_operation_transpose;
+    const long long s12 = (long long)n1 * n2;
+    // forward: coefficients = C1 X C2' (per z plane) ... C3' ; ping-pong between v / W1 / W2
+    blas_check(gemm_T(I.blas, N_, N_, n1, n2 * n3, n1, I.Cm[0], n1, v, n1, I.W1, n1), "dct dim 1");
+    T *cur = I.W1, *oth = I.W2;
+    if (n2 > 1) {
+      blas_check(gemm_sb(I.blas, N_, T_, n1, n2, n2, cur, n1, s12, I.Cm[1], n2, 0, oth, n1, s12, n3), "dct dim 2");
+      std::swap(cur, oth);
+    }
+    if (n3 > 1) {
+      blas_check(gemm_T(I.blas, N_, T_, (int)s12, n3, n3, cur, (int)s12, I.Cm[2], n3, oth, (int)s12), "dct dim 3");
+      std::swap(cur, oth);
+    }
+    // the inner projector on the coefficient array
+    const int in = I.sp.inner;
+    const bool two = in == SIPX_PROJ_L1 || in == SIPX_PROJ_CARDINALITY;
+    ProjScalars<T>* ps = two ? (feas ? I.psf : I.ps) : nullptr;
+    Grid g1;
+    g1.n[0] = N; g1.n[1] = 1; g1.n[2] = 1; g1.N = N; g1.st[0] = 1; g1.st[1] = N; g1.st[2] = N;
+    if (two) K<T>::proj_scalars_arr(s, N, cur, in, (T)I.sp.pmin, (T)I.sp.pmax, ps, partials, maxpart, compact, N);
+    proj_apply_grid<T>(s, g1, 0, nullptr, N, cur, in, in == SIPX_PROJ_BOUNDS_VEC ? T(0) : (T)I.sp.pmin, (T)I.sp.pmax, I.dlb, I.dub, ps);
+    // inverse (transposed matrices, reverse order)
+    if (n3 > 1) {
+      blas_check(gemm_T(I.blas, N_, N_, (int)s12, n3, n3, cur, (int)s12, I.Cm[2], n3, oth, (int)s12), "idct dim 3");
+      std::swap(cur, oth);
+    }
+    if (n2 > 1) {
+      blas_check(gemm_sb(I.blas, N_, N_, n1, n2, n2, cur, n1, s12, I.Cm[1], n2, 0, oth, n1, s12, n3), "idct dim 2");
+      std::swap(cur, oth);
+    }
+    blas_check(gemm_T(I.blas, T_, N_, n1, n2 * n3, n1, I.Cm[0], n1, cur, n1, oth, n1), "idct dim 1");
+    // C'C = I: inside the l1 ball the round trip only adds rounding noise -- v is kept bit for bit there (as for the DFT)
+    hipLaunchKernelGGL((k_copy_if_needed<T>), dim3(NB), dim3(BLOCK), 0, s, N, oth, v,
+                       in == SIPX_PROJ_L1 ? (const ProjScalars<T>*)ps : (const ProjScalars<T>*)nullptr);
   } else if (kind == EXT_CARD_SEG) {
     const long long nb = I.map.nseg < (long long)NB * 4 ? I.map.nseg : (long long)NB * 4;
     hipLaunchKernelGGL((k_seg_card<T>), dim3((unsigned)nb), dim3(BLOCK), 0, s, I.map, v, (long long)I.sp.pmax);

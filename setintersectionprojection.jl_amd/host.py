@@ -40,6 +40,7 @@ OPS = {"identity": 0, "D_x": 1, "D_y": 2, "D_z": 3, "TV": 4, "D2D": 4, "D3D": 4}
 PROJ = {"bounds": 0, "bounds_vec": 1, "l1": 2, "l2": 3, "annulus": 4, "cardinality": 5, "prox_l1": 6, "l1_dft": 7, "rank": 8,
         "nuclear": 9, "histogram": 10, "subspace": 11, "bounds_dft": 12}
 MODES = {"matrix": 0, "tensor": 0, "fiber": 1, "slice": 2}
+TRANSFORMS = {"DCT": 1}
 SPECIAL_OPERATORS = ("DFT", "DCT", "wavelet", "curvelet")     # src/setup_constraints.jl:54
 YL_FEAS, YL_BB, YL_FIRST = 1, 2, 4
 Q_MODES = {"cds": 0, "stencil": 1}
@@ -53,7 +54,7 @@ class _SetDesc(C.Structure):
     _fields_ = [("op", C.c_int32), ("proj", C.c_int32), ("pmin", C.c_double), ("pmax", C.c_double),
                 ("lb", C.c_void_p), ("ub", C.c_void_p), ("ncvx", C.c_int32), ("reserved", C.c_int32),
                 ("mode", C.c_int32), ("dir", C.c_int32), ("basis", C.c_void_p), ("basis_rows", C.c_int64),
-                ("basis_cols", C.c_int32), ("basis_orth", C.c_int32), ("component", C.c_int32), ("pad_", C.c_int32)]
+                ("basis_cols", C.c_int32), ("basis_orth", C.c_int32), ("component", C.c_int32), ("transform", C.c_int32)]
 
 
 class _Options(C.Structure):
@@ -276,7 +277,26 @@ class Projector:
         self.lb = self.ub = self.basis = None
         self.basis_orth = False
         self.pmin = self.pmax = 0.0
-        if constraint.TD_OP in SPECIAL_OPERATORS:
+        self.transform = 0
+        if constraint.TD_OP == "DCT":
+            # x -> C' P(C x) with the orthonormal DCT-II (get_projector.jl, special_operator_list branches); the l2 ball and
+            # the annulus commute with an orthogonal transform and are applied to x itself
+            if st in ("l2", "annulus"):
+                self.kind, self.pmax = st, float(constraint.max)
+                self.pmin = float(constraint.min) if st == "annulus" else 0.0
+            elif st in ("l1", "cardinality"):
+                self.kind, self.pmax, self.transform = st, float(constraint.max), TRANSFORMS["DCT"]
+            elif st == "bounds" and np.ndim(constraint.min) == 0:
+                self.kind, self.pmin, self.pmax, self.transform = "bounds", float(constraint.min), float(constraint.max), TRANSFORMS["DCT"]
+            elif st == "bounds":
+                self.kind, self.transform = "bounds_vec", TRANSFORMS["DCT"]
+                self.lb = np.ascontiguousarray(constraint.min, self.TF)
+                self.ub = np.ascontiguousarray(constraint.max, self.TF)
+            else:
+                raise SipxError(f"set type {st!r} behind the DCT is not built")
+            if self.mode:
+                raise SipxError("sets behind the DCT apply to the whole array (matrix / tensor mode)")
+        elif constraint.TD_OP in SPECIAL_OPERATORS:
             if constraint.TD_OP == "DFT" and st == "l1":
                 self.kind, self.pmax = "l1_dft", float(constraint.max)
             elif constraint.TD_OP == "DFT" and st == "bounds" and np.ndim(constraint.min) == 1:
@@ -349,6 +369,7 @@ class Projector:
         d.lb, d.ub = _ptr(self.lb), _ptr(self.ub)
         d.ncvx, d.reserved = int(bool(ncvx)), 0
         d.mode, d.dir = self.mode, self.dir
+        d.transform = self.transform
         if self.basis is not None:
             d.basis, d.basis_rows, d.basis_cols = _ptr(self.basis), self.basis.shape[0], self.basis.shape[1]
             d.basis_orth = int(self.basis_orth)
@@ -357,7 +378,7 @@ class Projector:
     def __call__(self, v):
         if v.dtype.type != self.TF or not v.flags.c_contiguous:
             raise SipxError("projector input must be a contiguous vector of the working precision")
-        grid_kind = self.mode != 0 or self.kind in ("l1_dft", "bounds_dft", "rank", "nuclear", "histogram", "subspace")
+        grid_kind = self.mode != 0 or self.transform != 0 or self.kind in ("l1_dft", "bounds_dft", "rank", "nuclear", "histogram", "subspace")
         ctx = Context(self.comp_grid if grid_kind else compgrid((1.0, 1.0), (max(len(v), 1), 1)), self.TF)
         try:
             if grid_kind:
@@ -377,7 +398,7 @@ class Projector:
 def get_TD_operator(comp_grid, TD_type: str, TF):
     """src/get_TD_operator.jl:12-95 for the banded operators."""
     n, _ = _grid(comp_grid)
-    if TD_type == "DFT":       # src/get_TD_operator.jl:45-47,80-82; setup_constraints.jl:76-80 swaps in the identity
+    if TD_type in ("DFT", "DCT"):   # src/get_TD_operator.jl:45-51,80-86; setup_constraints.jl:76-80 swaps in the identity
         return TDOperator("identity", comp_grid, TF), True, True, n, False
     A = TDOperator(TD_type, comp_grid, TF)
     if TD_type == "identity":

@@ -88,6 +88,10 @@ def _problem(mod, n, h, TF, kinds, m, opt_kw=None):
         elif k == "l1dft":
             Z = np.abs(np.fft.fftn(m.reshape(n, order="F").astype(np.float64), norm="ortho"))
             c.append(mod.set_definitions("l1", "DFT", 0.0, float(0.25 * Z.sum()), ("matrix", "")))
+        elif k == "l1dct":
+            import scipy.fft as sfft
+            Z = np.abs(sfft.dctn(m.reshape(n, order="F").astype(np.float64), norm="ortho"))
+            c.append(mod.set_definitions("l1", "DCT", 0.0, float(0.5 * Z.sum()), ("matrix", "")))
         elif k == "dftmask":                  # low-pass mask in the Fourier domain (symmetric, so the result stays real)
             f = np.meshgrid(*[np.minimum(np.arange(d), d - np.arange(d)) / (d / 2) for d in n], indexing="ij")
             keep = (sum(v ** 2 for v in f) <= 0.6 ** 2).astype(TF).reshape(-1, order="F")
@@ -351,6 +355,7 @@ CASES = [
     ("3d-dft-l1", (16, 12, 8), (25.0, 25.0, 25.0), ["bounds", "l1dft"]),
     ("3d-slice-rank", (16, 12, 8), (25.0, 25.0, 25.0), ["bounds", "rank:3"]),
     ("3d-dft-lowpass-mask", (16, 12, 8), (25.0, 25.0, 25.0), ["bounds", "dftmask", "l1:D_z"]),
+    ("3d-dct-l1", (16, 12, 8), (25.0, 25.0, 25.0), ["bounds", "l1dct"]),
     ("2d-rank", (32, 24), (25.0, 6.0), ["bounds", "rank:4", "l1:TV"]),
     ("2d-l1-identity-all-active", (32, 24), (25.0, 6.0), ["bounds", "l1id:0.9"]),
     ("3d-card-fiber-Dz", (16, 12, 8), (25.0, 25.0, 25.0), ["bounds", "cardf:D_z:fiber:x"]),
@@ -1035,3 +1040,31 @@ def test_l2_and_annulus_behind_the_dft_equal_the_plain_projectors(sipx, TF):
         got = sipx.host.Projector(sipx.set_definitions(st_, "DFT", lo, hi, ("tensor", "")), g_s, TF)(v.copy())
         tol = 5e-6 if TF == np.float32 else 1e-12
         assert np.abs(got.astype(np.float64) - want).max() <= tol * np.abs(want).max(), (st_, lo, hi)
+
+
+# ---- sets behind the DCT (orthogonal transform folded into the projector; joDCT normalisation unpinned) ---------------
+@pytest.mark.parametrize("TF", [np.float32, np.float64])
+def test_dct_domain_projectors(sipx, TF):
+    import scipy.fft as sfft
+    rng = np.random.default_rng(19)
+    tol = 2e-5 if TF == np.float32 else 1e-11
+    for n in ((16, 12, 8), (32, 24), (9, 7, 5)):
+        N = int(np.prod(n))
+        g_o, g_s = O.compgrid((1.0,) * len(n), n), sipx.compgrid((1.0,) * len(n), n)
+        v = rng.standard_normal(N).astype(TF)
+        c = sfft.dctn(v.astype(np.float64).reshape(n, order="F"), norm="ortho").reshape(-1, order="F")
+        lbv = (-0.3 - rng.random(N)).astype(TF); ubv = (0.2 + rng.random(N)).astype(TF)
+        cases = [("l1", 0.0, 0.3 * float(np.abs(c).sum())), ("l1", 0.0, 2.0 * float(np.abs(c).sum())), ("bounds", -0.4, 0.6),
+                 ("bounds", lbv, ubv), ("cardinality", 0, N // 5), ("l2", 0.0, 0.5 * float(np.linalg.norm(c))),
+                 ("annulus", 1.2 * float(np.linalg.norm(c)), 2.0 * float(np.linalg.norm(c)))]
+        for st_, lo, hi in cases:
+            want = O.get_projector(O.set_definitions(st_, "DCT", lo, hi, ("matrix", "")), TF, g_o)(v.copy())
+            got = sipx.host.Projector(sipx.set_definitions(st_, "DCT", lo, hi, ("matrix", "")), g_s, TF)(v.copy())
+            if st_ == "cardinality" and TF == np.float32:
+                # the k-th largest coefficient is decided on TF-rounded transforms: allow a swap of near-equal entries
+                assert np.linalg.norm(got.astype(np.float64) - want) <= 1e-3 * np.linalg.norm(want), (n, st_)
+            else:
+                assert np.abs(got.astype(np.float64) - want).max() <= tol * max(1.0, np.abs(want).max()), (n, st_, np.ndim(lo))
+        if True:      # inside the l1 ball: returned bit for bit
+            big = sipx.set_definitions("l1", "DCT", 0.0, 2.0 * float(np.abs(c).sum()), ("matrix", ""))
+            assert np.array_equal(sipx.host.Projector(big, g_s, TF)(v.copy()), v)
