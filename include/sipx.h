@@ -35,7 +35,9 @@ enum { SIPX_F32 = 0, SIPX_F64 = 1 };
  * get_TD_operator / get_discrete_Grad (src/get_TD_operator.jl:12-95, src/get_discrete_Grad.jl:16-76);
  * the shim maps set_Prop.tag[i][2] ("identity","D_x","D_y","D_z","TV") + comp_grid.n/.d to it.
  * 2-D grids: D_x = dim 1, D_z = dim 2 (pass n3 = 1); TV = [D_z; D_x] (2-D), [D_z; D_y; D_x] (3-D). */
-enum { SIPX_OP_IDENTITY = 0, SIPX_OP_DX = 1, SIPX_OP_DY = 2, SIPX_OP_DZ = 3, SIPX_OP_TV = 4 };
+enum { SIPX_OP_IDENTITY = 0, SIPX_OP_DX = 1, SIPX_OP_DY = 2, SIPX_OP_DZ = 3, SIPX_OP_TV = 4,
+       SIPX_OP_CSC = 5 /* a caller-supplied sparse matrix (constraint.custom_TD_OP[1], setup_constraints.jl:70-72): the
+                          SparseMatrixCSC arrays in sipx_set_desc.csc_*, 0-based; AtA must be passed explicitly in CDS */ };
 
 /* Projector descriptor replacing the opaque closure P_sub[i] (src/get_projector.jl:3-103). */
 enum {
@@ -85,10 +87,15 @@ typedef struct {
                         u + v ([A A]).  Either every set of a context names a component or none does.  With components the
                         unknown is x = [u; v] (2N entries in x0 / sipx_download / sipx_apply_Q), the distance term is
                         1/2 ||u + v - m||^2, and Q is the 2N x 2N CDS matrix of the reference. */
+  const int64_t* csc_colptr; /* SIPX_OP_CSC: colptr[N+1], rowval[nnz] (0-based, ascending inside a column), nzval TF[nnz] */
+  const int64_t* csc_rowval;
+  const void* csc_nzval;
+  int64_t csc_rows;          /* rows of the matrix = length of y_i, l_i */
   int32_t transform; /* SIPX_TRANSFORM_*: an orthogonal transform folded into the projector, x -> A' P(A x) with TD_OP = I
                         (src/get_projector.jl: the branches `constraint.TD_OP in special_operator_list`,
                         src/setup_constraints.jl:54,76-80).  DCT = orthonormal DCT-II along every grid dimension; proj must be
                         BOUNDS, BOUNDS_VEC, L1 or CARDINALITY (mode WHOLE), op the identity.  The DFT has its own kinds above. */
+  int32_t pad_;
 } sipx_set_desc;
 
 /* PARSDMM_options (src/SetIntersectionProjection.jl:110-128); Blas_active / parallel / FL /

@@ -738,6 +738,11 @@ def setup_constraints(constraint: List[set_definitions], comp_grid, TF):
         if c.set_type in ("l1", "l2") and c.app_mode[0] in ("slice", "fiber"):
             raise ValueError("l1 and l2 constraints only available for matrix or tensor mode, currently")
         A, AtA_diag, dense, TD_n, banded = get_TD_operator(comp_grid, c.TD_OP, TF)
+        cust = c.custom_TD_OP[0] if c.set_type != "subspace" else ()
+        if not (isinstance(cust, (tuple, list)) and len(cust) == 0):      # :70-72  A = constraint[i].custom_TD_OP[1]
+            A = sp.csc_matrix(cust, dtype=TF)
+            A.sort_indices()
+            AtA_diag, dense = False, False
         P_sub.append(get_projector(c, TF, comp_grid, TD_n))
         TD_OP.append(A)
         sp_.AtA_diag.append(AtA_diag); sp_.dense.append(dense); sp_.TD_n.append(TD_n)

@@ -93,6 +93,14 @@ void bb_rule(T d_dHh_dlh, T n_d_H_hat, T n_d_l_hat, T n_d_l, T n_d_G_hat, T d_dG
 template <typename T>
 struct SetState {
   int op = 0, prox = 0, nblk = 0, ncvx = 0;
+  // caller-supplied sparse operator (SIPX_OP_CSC): CSC for the adjoint, a CSR copy for the forward product; s = A x is
+  // materialised in sbuf and every set kernel then runs in its identity shape on a 1-D grid of M entries
+  bool custom = false;
+  std::vector<long long> h_colptr, h_rowval;
+  std::vector<T> h_nzval;
+  long long *d_colptr = nullptr, *d_rowval = nullptr, *d_rowptr = nullptr, *d_colidx = nullptr;
+  T *d_nzval = nullptr, *d_rval = nullptr, *sbuf = nullptr;
+  Grid gm;                           // the 1-D "grid" of the M rows
   int comp = 0;                      // Minkowski component: 0 none, 1 = [A 0], 2 = [0 A], 3 = [A A]
   int dir[3] = {0, 0, 0};
   T ih[3] = {0, 0, 0};
@@ -181,11 +189,15 @@ class Engine : public EngineBase {
   int add_set(const sipx_set_desc* d, const void* ata_R, const int64_t* ata_off, int d_i) override {
     if (finalized_) throw std::runtime_error("sipx_add_set after sipx_finalize");
     SetState<T> s;
-    configure_op(s, d->op);
+    if (d->op == SIPX_OP_CSC) configure_custom(s, d);
+    else configure_op(s, d->op);
     configure_proj(s, d);
+    if (s.custom && !ata_R) throw std::runtime_error("a custom sparse operator needs its A'A in CDS (ata_R, ata_off)");
+    if (s.custom && (s.comp || s.ext_kind))
+      throw std::runtime_error("custom sparse operators: Minkowski components and library-backed projectors are not available");
     if (ata_R && s.comp) throw std::runtime_error("Minkowski sets use descriptor-generated AtA (pass ata_R = NULL)");
     if (ata_R) {
-      if (d_i < 1 || d_i > 7) throw std::runtime_error("AtA band count out of range (1..7 bands per set)");
+      if (d_i < 1 || d_i > 9) throw std::runtime_error("AtA band count out of range (1..9 bands per set)");
       s.ata_off.assign(ata_off, ata_off + d_i);
       s.host_ata.assign((const T*)ata_R, (const T*)ata_R + (size_t)G_.N * d_i);
     } else {
@@ -319,6 +331,7 @@ class Engine : public EngineBase {
       s.lh0 = dalloc<T>(s.Mpad); s.s0 = dalloc<T>(s.Mpad);
       s.y0 = halloc(s.Mpad); s.l0 = halloc(s.Mpad);       // take turns with y, l as the current iterate: same halo
       if (!s.ident) s.dy = halloc(s.Mpad);
+      if (s.custom) upload_custom(s);
       if (s.ext_kind) {
         s.spec.lb = s.host_lb.empty() ? nullptr : s.host_lb.data();
         s.spec.ub = s.host_ub.empty() ? nullptr : s.host_ub.data();
@@ -373,6 +386,16 @@ class Engine : public EngineBase {
         SetArgs<T> a = set_args(s, rho_[i], gamma_[i], 0);
         a.x = mm;
         ext_feasibility(s, a, dst);
+      } else if (s.custom) {                                   // s = A m materialised, then as for an identity set
+        K<T>::csr_spmv(stream_, s.Mtrue, s.d_rowptr, s.d_colidx, s.d_rval, mm, s.sbuf);
+        if (s.two_pass) {
+          SetArgs<T> a = set_args(s, rho_[i], gamma_[i], 0);
+          a.x = s.sbuf;
+          K<T>::proj_scalars_set(stream_, s.gm, a, 1, s.psf, part_tmp_, maxpart_, scr_c_, s.Mtrue);
+          K<T>::proj_dist_set(stream_, s.gm, a, 1, s.psf, dst);
+        } else {
+          proj_dist_grid<T>(stream_, s.gm, 0, s.dir, s.Mpad, s.sbuf, s.prox, s.plo, s.phi, s.lb, s.ub, nullptr, dst);
+        }
       } else if (s.two_pass) {
         SetArgs<T> a = set_args(s, rho_[i], gamma_[i], 0);
         a.x = mm;                                              // s = A m produced on the fly
@@ -425,7 +448,7 @@ class Engine : public EngineBase {
     int launched = 0;
     for (int i = 0; i < p_n_; ++i) {
       const SetState<T>& s = sets_[i];
-      if (!s.owned) continue;
+      if (!s.owned || s.custom) continue;
       RhsSet<T>& r = a.s[a.nsets++];
       r.y = s.y; r.l = s.l; r.rho = (T)rho[i]; r.nblk = s.nblk;
       for (int q = 0; q < 3; ++q) { r.dir[q] = s.dir[q]; r.ih[q] = s.ih[q]; }
@@ -435,6 +458,11 @@ class Engine : public EngineBase {
       }
     }
     if (a.nsets > 0 || launched == 0) K<T>::rhs_compose(stream_, G_, a, rhs_, launched > 0);
+    for (int i = 0; i < p_n_; ++i) {       // caller-supplied sparse operators: rhs += A_i'(rho_i y_i + l_i), one launch each
+      const SetState<T>& s = sets_[i];
+      if (s.owned && s.custom)
+        K<T>::csc_adj_rhs(stream_, G_.N, s.d_colptr, s.d_rowval, s.d_nzval, s.y, s.l, (T)rho[i], rhs_, 1);
+    }
   }
 
   void argmin_x(int it, double* tol_ref_io, int64_t* cg_it, double* cg_relres, int* cg_flag) override {
@@ -511,6 +539,12 @@ class Engine : public EngineBase {
       else to_other = s.snap == 0;                        // the zero-filled other pair stands in for it, as before
       a.yo = to_other ? s.y0 : s.y;
       a.lo = to_other ? s.l0 : s.l;
+      const Grid& gs = s.custom ? s.gm : G_;
+      if (s.custom) {     // s = A x once, then the identity-shaped kernels on the M entries of s
+        K<T>::csr_spmv(q, s.Mtrue, s.d_rowptr, s.d_colidx, s.d_rval, a.x, s.sbuf);
+        a.x = s.sbuf;
+        a.flags |= F_STORE_DY;
+      }
       if (s.ext_kind) {   // library-backed projector: materialise v, project it in place, hand y to the fused update
         K<T>::store_v(q, G_, a, 0, scr_v_);
         s.ext->project(scr_v_, false, ptmp, mpart, cbuf);
@@ -519,17 +553,18 @@ class Engine : public EngineBase {
       if (s.two_pass) {   // threshold / scale of prox_i from one pass that produces v on the fly (nothing stored)
         SetArgs<T> ap = a;
         if (s.last_rho != a.rho || s.last_gamma != a.gamma) ap.flags |= F_NOSPEC;   // v rescaled: theta will jump
-        K<T>::proj_scalars_set(q, G_, ap, 0, s.ps, ptmp, mpart, cbuf, s.Mtrue);
+        K<T>::proj_scalars_set(q, gs, ap, 0, s.ps, ptmp, mpart, cbuf, s.Mtrue);
         s.last_rho = a.rho;
         s.last_gamma = a.gamma;
       }
-      K<T>::yl(q, G_, a, part);
-      if (!s.ident) K<T>::adj_norm(q, G_, a, part + (size_t)SL_ADJ * NB);
+      K<T>::yl(q, gs, a, part);
+      if (s.custom) K<T>::csc_adj_norm(q, G_.N, s.d_colptr, s.d_rowval, s.d_nzval, s.dy, part + (size_t)SL_ADJ * NB);
+      else if (!s.ident) K<T>::adj_norm(q, G_, a, part + (size_t)SL_ADJ * NB);
       if ((flags & SIPX_YL_FEAS) && s.ext_kind && i < pp_n_) ext_feasibility(s, a, part + (size_t)SL_FE2 * NB);
       if ((flags & SIPX_YL_FEAS) && s.two_pass && i < pp_n_) {
         // ||P_i(s) - s|| with s = A_i x produced on the fly; its own warm-started scalars (psf)
-        K<T>::proj_scalars_set(q, G_, a, 1, s.psf, ptmp, mpart, cbuf, s.Mtrue);
-        K<T>::proj_dist_set(q, G_, a, 1, s.psf, part + (size_t)SL_FE2 * NB);
+        K<T>::proj_scalars_set(q, gs, a, 1, s.psf, ptmp, mpart, cbuf, s.Mtrue);
+        K<T>::proj_dist_set(q, gs, a, 1, s.psf, part + (size_t)SL_FE2 * NB);
       }
       if (to_other) { std::swap(s.y, s.y0); std::swap(s.l, s.l0); }     // (y, l) always names the current iterate
       if (snapshot) s.snap = 0;
@@ -1100,6 +1135,56 @@ class Engine : public EngineBase {
     }
   }
 
+  // SIPX_OP_CSC: validate the SparseMatrixCSC arrays and keep host copies until sipx_finalize
+  void configure_custom(SetState<T>& s, const sipx_set_desc* d) const {
+    const long long N = G_.N, M = d->csc_rows;
+    if (!d->csc_colptr || !d->csc_rowval || !d->csc_nzval || M < 1) throw std::runtime_error("custom operator: CSC arrays missing");
+    const long long nnz = d->csc_colptr[N];
+    if (d->csc_colptr[0] != 0 || nnz < 0) throw std::runtime_error("custom operator: colptr must start at 0 (0-based arrays)");
+    for (long long j = 0; j < N; ++j) {
+      if (d->csc_colptr[j + 1] < d->csc_colptr[j]) throw std::runtime_error("custom operator: colptr must be non-decreasing");
+      for (long long k = d->csc_colptr[j]; k < d->csc_colptr[j + 1]; ++k) {
+        const long long r = d->csc_rowval[k];
+        if (r < 0 || r >= M) throw std::runtime_error("custom operator: row index out of range");
+        if (k > d->csc_colptr[j] && r <= d->csc_rowval[k - 1]) throw std::runtime_error("custom operator: rows must ascend inside a column");
+      }
+    }
+    s.op = SIPX_OP_CSC;
+    s.custom = true;
+    s.nblk = 0;                       // the set kernels see an identity over M entries
+    s.ident = false;
+    s.Mtrue = s.Mpad = M;
+    s.h_colptr.assign(d->csc_colptr, d->csc_colptr + N + 1);
+    s.h_rowval.assign(d->csc_rowval, d->csc_rowval + nnz);
+    s.h_nzval.assign((const T*)d->csc_nzval, (const T*)d->csc_nzval + nnz);
+    s.gm.n[0] = M; s.gm.n[1] = 1; s.gm.n[2] = 1; s.gm.N = M; s.gm.st[0] = 1; s.gm.st[1] = M; s.gm.st[2] = M;
+  }
+  // device copies: CSC as given, and the CSR view (rows ascending, columns ascending inside a row: a counting sort by row
+  // of the column-major entries keeps that order) for s = A x
+  void upload_custom(SetState<T>& s) {
+    const long long N = G_.N, M = s.Mtrue, nnz = (long long)s.h_rowval.size();
+    std::vector<long long> rowptr(M + 1, 0), colidx(nnz);
+    std::vector<T> rval(nnz);
+    for (long long k = 0; k < nnz; ++k) rowptr[s.h_rowval[k] + 1]++;
+    for (long long r = 0; r < M; ++r) rowptr[r + 1] += rowptr[r];
+    std::vector<long long> next(rowptr.begin(), rowptr.end() - 1);
+    for (long long j = 0; j < N; ++j)
+      for (long long k = s.h_colptr[j]; k < s.h_colptr[j + 1]; ++k) {
+        const long long q = next[s.h_rowval[k]]++;
+        colidx[q] = j;
+        rval[q] = s.h_nzval[k];
+      }
+    auto up = [&](auto*& dst, const auto& src) {
+      using E = typename std::remove_reference<decltype(src)>::type::value_type;
+      dst = dalloc<E>(src.size(), false);
+      SIPX_HIP(hipMemcpy(dst, src.data(), src.size() * sizeof(E), hipMemcpyHostToDevice));
+    };
+    up(s.d_colptr, s.h_colptr); up(s.d_rowval, s.h_rowval); up(s.d_nzval, s.h_nzval);
+    up(s.d_rowptr, rowptr); up(s.d_colidx, colidx); up(s.d_rval, rval);
+    s.sbuf = dalloc<T>(M);
+    s.h_colptr.clear(); s.h_rowval.clear(); s.h_nzval.clear();
+  }
+
   void configure_op(SetState<T>& s, int op) const {
     s.op = op;
     const int zdir = ndim_ == 2 ? 1 : 2;
@@ -1260,7 +1345,7 @@ class Engine : public EngineBase {
   }
 
   void push_qset(QArgs<T>& a, const SetState<T>& s, T alpha) {
-    if (s.ata_off.size() > 7) throw std::runtime_error("more than 7 bands in one set's AtA are not supported");
+    if (s.ata_off.size() > 9) throw std::runtime_error("more than 9 bands in one set's AtA are not supported");
     for (long long o : s.ata_off) (void)q_col(o);     // CDS_scaled_add!.jl:18-20: the diagonal must exist in Q
     if (a.nsets == MAX_SETS) {                         // flush a full batch, keep the order
       K<T>::q_update(stream_, G_, cds_, a, Q_);
@@ -1311,8 +1396,8 @@ class Engine : public EngineBase {
   // Import / export between the reference's row order (host) and the padded layout (device): one contiguous PCIe
   // copy plus a device gather / scatter per operator block (the pads keep the zeros they were allocated with).
   void upload_rows(const SetState<T>& s, const T* rows, T* dev) const {
-    if (s.ident) {
-      SIPX_HIP(hipMemcpy(dev, rows, (size_t)G_.N * sizeof(T), hipMemcpyHostToDevice));
+    if (s.ident || s.custom) {
+      SIPX_HIP(hipMemcpy(dev, rows, (size_t)s.Mtrue * sizeof(T), hipMemcpyHostToDevice));
       return;
     }
     T* tmp = dalloc<T>(s.Mtrue, false);
@@ -1327,8 +1412,8 @@ class Engine : public EngineBase {
   }
   void download_rows(const SetState<T>& s, const T* dev, T* rows) const {
     SIPX_HIP(hipStreamSynchronize(stream_));
-    if (s.ident) {
-      SIPX_HIP(hipMemcpy(rows, dev, (size_t)G_.N * sizeof(T), hipMemcpyDeviceToHost));
+    if (s.ident || s.custom) {
+      SIPX_HIP(hipMemcpy(rows, dev, (size_t)s.Mtrue * sizeof(T), hipMemcpyDeviceToHost));
       return;
     }
     T* tmp = dalloc<T>(s.Mtrue, false);
@@ -1358,7 +1443,9 @@ class Engine : public EngineBase {
   void free_set(SetState<T>& s) {
     if (s.st) (void)hipStreamSynchronize(s.st);
     if (s.ev) (void)hipEventDestroy(s.ev);
-    for (void* p : {(void*)s.ptmp, (void*)s.mpart, (void*)s.cbuf}) dfree(p);
+    for (void* p : {(void*)s.ptmp, (void*)s.mpart, (void*)s.cbuf, (void*)s.d_colptr, (void*)s.d_rowval, (void*)s.d_rowptr,
+                    (void*)s.d_colidx, (void*)s.d_nzval, (void*)s.d_rval, (void*)s.sbuf})
+      dfree(p);
     for (void* p : s.halo_allocs) dfree(p);
     for (void* p : {(void*)s.lh0, (void*)s.s0, (void*)s.lb, (void*)s.ub, (void*)s.ata,
                     (void*)s.ps, (void*)s.psf})

@@ -180,7 +180,7 @@ __global__ __launch_bounds__(BLOCK) void k_yl(Grid G, SetArgs<T> a, double* __re
       }
       stv<T, V>(a.yo + e, yn);
       stv<T, V>(a.lo + e, ln);
-      if (!ident) stv<T, V>(a.dy + e, dyv);
+      if (!ident || (a.flags & F_STORE_DY)) stv<T, V>(a.dy + e, dyv);
     }
   }
   block_reduce_store<YL_SLOTS>(acc, partials, 0);
@@ -403,6 +403,54 @@ void K<T>::rows_unpack(hipStream_t s, const Grid& g, int dir, long long nrows, c
   SIPX_HIP(hipGetLastError());
 }
 
+// ---- caller-supplied sparse operator (constraint.custom_TD_OP): rows have a handful of entries, one thread per row / column.
+// The accumulation orders are those of Julia's CSC kernels: A*x adds the products of a row in ascending column order,
+// A'*w those of a column in ascending row order (SparseArrays mul!).
+template <typename T>
+__global__ __launch_bounds__(BLOCK) void k_csr_spmv(long long M, const long long* __restrict__ rowptr, const long long* __restrict__ col,
+                                                    const T* __restrict__ val, const T* __restrict__ x, T* __restrict__ out) {
+  for (long long r = (long long)blockIdx.x * BLOCK + threadIdx.x; r < M; r += (long long)gridDim.x * BLOCK) {
+    T acc = T(0);
+    for (long long k = rowptr[r]; k < rowptr[r + 1]; ++k) acc = acc + val[k] * x[col[k]];
+    out[r] = acc;
+  }
+}
+template <typename T, int MODE>
+__global__ __launch_bounds__(BLOCK) void k_csc_adj(long long N, const long long* __restrict__ colptr, const long long* __restrict__ row,
+                                                   const T* __restrict__ val, const T* __restrict__ y, const T* __restrict__ l,
+                                                   T rho, T* __restrict__ out, int accumulate, double* __restrict__ partials) {
+  double acc[1] = {0};
+  for (long long j = (long long)blockIdx.x * BLOCK + threadIdx.x; j < N; j += (long long)gridDim.x * BLOCK) {
+    T t = T(0);
+    for (long long k = colptr[j]; k < colptr[j + 1]; ++k) {
+      const long long r = row[k];
+      const T w = MODE == 0 ? (rho * y[r] + l[r]) : y[r];        // MODE 1: y carries y - y_old
+      t = t + val[k] * w;
+    }
+    if (MODE == 0) out[j] = accumulate ? out[j] + t : t;
+    else acc[0] += (double)t * (double)t;
+  }
+  if (MODE == 1) block_reduce_store<1>(acc, partials, 0);
+}
+template <typename T>
+void K<T>::csr_spmv(hipStream_t s, long long M, const long long* rowptr, const long long* col, const T* val, const T* x, T* out) {
+  hipLaunchKernelGGL((k_csr_spmv<T>), dim3(NB), dim3(BLOCK), 0, s, M, rowptr, col, val, x, out);
+  SIPX_HIP(hipGetLastError());
+}
+template <typename T>
+void K<T>::csc_adj_rhs(hipStream_t s, long long N, const long long* colptr, const long long* row, const T* val, const T* y,
+                       const T* l, T rho, T* out, int accumulate) {
+  hipLaunchKernelGGL((k_csc_adj<T, 0>), dim3(NB), dim3(BLOCK), 0, s, N, colptr, row, val, y, l, rho, out, accumulate, (double*)nullptr);
+  SIPX_HIP(hipGetLastError());
+}
+template <typename T>
+void K<T>::csc_adj_norm(hipStream_t s, long long N, const long long* colptr, const long long* row, const T* val, const T* dy,
+                        double* partials) {
+  hipLaunchKernelGGL((k_csc_adj<T, 1>), dim3(NB), dim3(BLOCK), 0, s, N, colptr, row, val, dy, (const T*)nullptr, T(0), (T*)nullptr, 0,
+                     partials);
+  SIPX_HIP(hipGetLastError());
+}
+
 // w = u + v (Minkowski mode: TD_OP_sum[i] * x = A (u + v))
 template <typename T>
 __global__ __launch_bounds__(BLOCK) void k_sum_uv(long long N, const T* __restrict__ u, const T* __restrict__ v,
@@ -479,6 +527,11 @@ void resample_nn(hipStream_t s, const long long* nc, const long long* nf, const 
 #define SIPX_INST(T)                                                                                              \
   template void resample_nn<T>(hipStream_t, const long long*, const long long*, const T*, T*);                   \
   template void K<T>::sum_uv(hipStream_t, long long, const T*, const T*, T*);                                      \
+  template void K<T>::csr_spmv(hipStream_t, long long, const long long*, const long long*, const T*, const T*, T*);  \
+  template void K<T>::csc_adj_rhs(hipStream_t, long long, const long long*, const long long*, const T*, const T*,    \
+                                  const T*, T, T*, int);                                                             \
+  template void K<T>::csc_adj_norm(hipStream_t, long long, const long long*, const long long*, const T*, const T*,   \
+                                   double*);                                                                         \
   template void K<T>::rows_pack(hipStream_t, const Grid&, int, long long, const T*, T*);                           \
   template void K<T>::rows_unpack(hipStream_t, const Grid&, int, long long, const T*, T*);                         \
   template void K<T>::rhs_compose(hipStream_t, const Grid&, const RhsArgs<T>&, T*, int);                         \

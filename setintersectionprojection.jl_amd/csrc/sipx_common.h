@@ -22,7 +22,8 @@ constexpr int PREP_SLOTS = 3 + 2 * L1_K;   // ||v||_1, ||v||_2^2, nnz, S_k, C_k
 enum { SL_RPRI = 0, SL_DY = 1, SL_HL = 2, SL_HH = 3, SL_LH = 4, SL_DL = 5, SL_GG = 6, SL_GL = 7,
        SL_FE = 8, SL_SS = 9, SL_OBJ = 10, SL_EVO = 11, SL_XX = 12 };
 
-enum { F_FEAS = 1, F_BB = 2, F_FIRST = 4, F_NOSPEC = 8 /* rho/gamma just changed: skip the speculative gather */ };
+enum { F_FEAS = 1, F_BB = 2, F_FIRST = 4, F_NOSPEC = 8 /* rho/gamma just changed: skip the speculative gather */,
+       F_STORE_DY = 16 /* identity-shaped pass over a materialised s = A x (custom sparse operator): keep y - y_old */ };
 
 // internal prox kinds (public SIPX_PROJ_* plus the distance term)
 enum { PX_BOUNDS = 0, PX_BOUNDS_VEC = 1, PX_L1 = 2, PX_L2 = 3, PX_ANNULUS = 4, PX_CARD = 5, PX_PROX_L1 = 6,
@@ -129,7 +130,7 @@ struct QSet {
   int dir[3];
   T ih[3];
   int nband;
-  long long off[7];
+  long long off[9];
 };
 template <typename T>
 struct QArgs {
@@ -198,6 +199,12 @@ struct K {
   static void q_update_mk(hipStream_t s, const Grid& g, const CdsArgs& q, const MkArgs<T>& a, T* Q);
   static void mirror_bands(hipStream_t s, long long N, const CdsArgs& q, T* Q);
   static void sum_uv(hipStream_t s, long long N, const T* u, const T* v, T* w);
+  // caller-supplied sparse operator: s = A x (CSR view), out (+)= A'(rho y + l), partial sum of (A' dy)^2
+  static void csr_spmv(hipStream_t s, long long M, const long long* rowptr, const long long* col, const T* val, const T* x, T* out);
+  static void csc_adj_rhs(hipStream_t s, long long N, const long long* colptr, const long long* row, const T* val, const T* y,
+                          const T* l, T rho, T* out, int accumulate);
+  static void csc_adj_norm(hipStream_t s, long long N, const long long* colptr, const long long* row, const T* val, const T* dy,
+                           double* partials);
   static void rows_pack(hipStream_t s, const Grid& g, int dir, long long nrows, const T* pad, T* rows);
   static void rows_unpack(hipStream_t s, const Grid& g, int dir, long long nrows, const T* rows, T* pad);
   static void fin_sum(hipStream_t s, const double* partials, int nslots, double* out_dev, double* out_host);

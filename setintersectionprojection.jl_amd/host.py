@@ -36,7 +36,7 @@ EXPORTED_SYMBOLS = [
 ]
 
 SIPX_F32, SIPX_F64 = 0, 1
-OPS = {"identity": 0, "D_x": 1, "D_y": 2, "D_z": 3, "TV": 4, "D2D": 4, "D3D": 4}
+OPS = {"identity": 0, "D_x": 1, "D_y": 2, "D_z": 3, "TV": 4, "D2D": 4, "D3D": 4, "custom": 5}
 PROJ = {"bounds": 0, "bounds_vec": 1, "l1": 2, "l2": 3, "annulus": 4, "cardinality": 5, "prox_l1": 6, "l1_dft": 7, "rank": 8,
         "nuclear": 9, "histogram": 10, "subspace": 11, "bounds_dft": 12}
 MODES = {"matrix": 0, "tensor": 0, "fiber": 1, "slice": 2}
@@ -54,7 +54,9 @@ class _SetDesc(C.Structure):
     _fields_ = [("op", C.c_int32), ("proj", C.c_int32), ("pmin", C.c_double), ("pmax", C.c_double),
                 ("lb", C.c_void_p), ("ub", C.c_void_p), ("ncvx", C.c_int32), ("reserved", C.c_int32),
                 ("mode", C.c_int32), ("dir", C.c_int32), ("basis", C.c_void_p), ("basis_rows", C.c_int64),
-                ("basis_cols", C.c_int32), ("basis_orth", C.c_int32), ("component", C.c_int32), ("transform", C.c_int32)]
+                ("basis_cols", C.c_int32), ("basis_orth", C.c_int32), ("component", C.c_int32),
+                ("csc_colptr", C.c_void_p), ("csc_rowval", C.c_void_p), ("csc_nzval", C.c_void_p), ("csc_rows", C.c_int64),
+                ("transform", C.c_int32), ("pad_", C.c_int32)]
 
 
 class _Options(C.Structure):
@@ -257,6 +259,46 @@ class TDOperator:
     __mul__ = __matmul__
 
 
+class CustomOperator:
+    """A caller-supplied sparse TD_OP (constraint.custom_TD_OP[1], src/setup_constraints.jl:70-72): kept as a scipy CSC
+    matrix on the host, shipped to the engine as SIPX_OP_CSC.  Behaves like the matrix for `@` and `.T` (host arithmetic,
+    used by setup code only)."""
+    kind = "custom"
+    component = 0
+
+    def __init__(self, A, comp_grid, TF):
+        import scipy.sparse as sp
+        self.TF = np.dtype(TF).type
+        self.comp_grid = comp_grid
+        self.n, _ = _grid(comp_grid)
+        A = sp.csc_matrix(A, dtype=self.TF)
+        A.sort_indices()
+        if A.shape[1] != int(np.prod(self.n)):
+            raise SipxError("custom TD_OP: the number of columns must equal the number of grid points")
+        self.A = A
+        self.shape = A.shape
+
+    @property
+    def T(self):
+        return self.A.T.tocsc()
+
+    def __matmul__(self, v):
+        return (self.A @ np.asarray(v, self.TF)).astype(self.TF)
+
+    def ata_cds(self):
+        """mat2CDS(TD_OP' * TD_OP) (PARSDMM_precompute_distribute.jl:52-59, mat2CDS.jl:7-32) in the working precision."""
+        G = (self.A.T @ self.A).tocsc().astype(self.TF)
+        G.sort_indices()
+        N = G.shape[0]
+        coo = G.tocoo()
+        offs = np.unique(coo.col.astype(np.int64) - coo.row.astype(np.int64))
+        R = np.zeros((N, len(offs)), self.TF, order="F")
+        col = {int(o): b for b, o in enumerate(offs)}
+        for r, c, v in zip(coo.row, coo.col, coo.data):
+            R[r, col[int(c) - int(r)]] = v
+        return R, offs.astype(np.int64)
+
+
 class Projector:
     """Descriptor of P_sub[i] (src/get_projector.jl:3-103); calling it projects in place on the device."""
 
@@ -348,6 +390,9 @@ class Projector:
     def check_rows(self, op: "TDOperator"):
         """Host-side shape checks of the vectors the descriptor points at (the engine reads them unchecked)."""
         n = list(op.n)
+        if op.kind == "custom" and (self.mode or self.transform or self.kind in ("l1_dft", "bounds_dft", "rank", "nuclear",
+                                                                                     "histogram", "subspace")):
+            raise SipxError("custom sparse operators take the whole-array projectors only")
         if op.kind in ("D_x", "D_y", "D_z"):
             n[{"D_x": 0, "D_y": 1, "D_z": len(n) - 1}[op.kind]] -= 1
         rows = op.shape[0]
@@ -430,6 +475,10 @@ def setup_constraints(constraint: List[set_definitions], comp_grid, TF):
         if c.set_type in ("l1", "l2") and c.app_mode[0] in ("slice", "fiber"):
             raise SipxError("l1 and l2 constraints only available for matrix or tensor mode, currently")
         A, AtA_diag, dense, TD_n, banded = get_TD_operator(comp_grid, c.TD_OP, TF)
+        cust = c.custom_TD_OP[0] if c.set_type != "subspace" else ()
+        if not (isinstance(cust, (tuple, list)) and len(cust) == 0):          # setup_constraints.jl:70-72
+            A = CustomOperator(cust, comp_grid, TF)
+            AtA_diag, dense = False, False
         banded = True       # the engine keeps Q in CDS: a DFT set contributes the identity band like any orthogonal op
         P_sub.append(Projector(c, comp_grid, TF))
         TD_OP.append(A)
@@ -462,6 +511,9 @@ def PARSDMM_precompute_distribute(TD_OP, set_Prop, comp_grid, options):
     st = {1: 1, 2: n[0], 3: n[0] * n[1] if len(n) > 2 else None}
     for i in range(p):
         kind = TD_OP[i].kind
+        if kind == "custom":
+            AtA[i], set_Prop.AtA_offsets[i] = TD_OP[i].ata_cds()
+            continue
         dirs = {"identity": [], "D_x": [0], "D_y": [1], "D_z": [len(n) - 1]}.get(kind, list(range(len(n))))
         strides = [int(np.prod(n[:a])) for a in dirs]
         set_Prop.AtA_offsets[i] = np.array(sorted({0} | {s for s in strides} | {-s for s in strides}), np.int64)
@@ -538,6 +590,14 @@ class Context:
         d.component = int(getattr(op, "component", 0))
         if d.component:
             self.Nx = 2 * self.N
+        if op.kind == "custom":
+            if AtA is None:
+                raise SipxError("a custom sparse operator needs its AtA (PARSDMM_precompute_distribute computes it)")
+            cp = np.ascontiguousarray(op.A.indptr, np.int64); ri = np.ascontiguousarray(op.A.indices, np.int64)
+            nz = np.ascontiguousarray(op.A.data, self.TF)
+            self._keep += [cp, ri, nz]
+            d.csc_colptr, d.csc_rowval, d.csc_nzval = cp.ctypes.data, ri.ctypes.data, nz.ctypes.data
+            d.csc_rows = int(op.A.shape[0])
         self._keep.append(proj)
         if AtA is not None:
             R = np.asfortranarray(AtA, dtype=self.TF)

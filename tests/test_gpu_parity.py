@@ -1068,3 +1068,54 @@ def test_dct_domain_projectors(sipx, TF):
         if True:      # inside the l1 ball: returned bit for bit
             big = sipx.set_definitions("l1", "DCT", 0.0, 2.0 * float(np.abs(c).sum()), ("matrix", ""))
             assert np.array_equal(sipx.host.Projector(big, g_s, TF)(v.copy()), v)
+
+
+# ---- caller-supplied sparse TD_OP (constraint.custom_TD_OP, setup_constraints.jl:70-72), e.g. the reference's own D_xz ------
+def _custom_problem(mod, n, h, TF, m, which, maxit=40):
+    import scipy.sparse as sp
+    g = mod.compgrid(h, n)
+    Og = O.compgrid(h, n)
+    Dx = O.get_TD_operator(Og, "D_x", TF)[0]
+    Dz1 = O.get_TD_operator(O.compgrid(h, (n[0] - 1, n[1])), "D_z", TF)[0]      # get_TD_operator.jl:66-70 (D_xz = D_z * D_x)
+    Dxz = sp.csc_matrix(Dz1 @ Dx, dtype=TF)
+    Dxz.sort_indices()
+    s = Dxz @ m
+    c = [mod.set_definitions("bounds", "identity", 1600.0, 3900.0, ("matrix", ""))]
+    if which == "l1":
+        sd = mod.set_definitions("l1", "identity", 0.0, float(0.4 * np.abs(s).sum()), ("matrix", ""))
+    else:
+        sd = mod.set_definitions("bounds", "identity", float(0.3 * s.min()), float(0.3 * s.max()), ("matrix", ""))
+    sd.custom_TD_OP = (Dxz, False)
+    c.append(sd)
+    opt = mod.PARSDMM_options(FL=TF, maxit=maxit)
+    P, A, prop = mod.setup_constraints(c, g, TF)
+    A, AtA, l, y = mod.PARSDMM_precompute_distribute(A, prop, g, opt)
+    return g, opt, P, A, prop, AtA, Dxz
+
+
+@pytest.mark.parametrize("TF", [np.float32, np.float64])
+@pytest.mark.parametrize("which", ["l1", "bounds"])
+def test_custom_sparse_operator_matches_oracle(sipx, TF, which):
+    n, h = (30, 22), (25.0, 6.0)
+    m = model(n, TF, seed=6)
+    go, oo, Po, Ao, propo, AtAo, Dxz = _custom_problem(O, n, h, TF, m, which)
+    gs, os_, Ps, As, props, AtAs, _ = _custom_problem(sipx, n, h, TF, m, which)
+    assert As[1].kind == "custom" and As[1].shape == Dxz.shape and len(props.AtA_offsets[1]) == 9
+    assert np.array_equal(props.AtA_offsets[1], propo.AtA_offsets[1])
+    xo, lo, l_o, y_o = O.PARSDMM(m.copy(), AtAo, Ao, propo, Po, go, oo)
+    # (a) A'A handed over explicitly, as a binding that reuses the reference's own setup would: lock-step
+    AtA_explicit = [None, AtAo[1], None]
+    xs, ls, l_s, y_s = sipx.PARSDMM(m.copy(), AtA_explicit, As, props, Ps, gs, os_)
+    K = min(6, len(lo.obj), len(ls.obj))
+    rt = 5e-4 if TF == np.float32 else 1e-8
+    assert np.array_equal(ls.cg_it[:K], lo.cg_it[:K])
+    for f in ("obj", "r_pri_total", "r_dual_total", "rho", "gamma"):
+        a, b = np.asarray(getattr(ls, f))[:K], np.asarray(getattr(lo, f))[:K]
+        assert np.allclose(a, b, rtol=rt, atol=1e-12), (f, a, b)
+    assert np.allclose(ls.set_feasibility[0], lo.set_feasibility[0], rtol=rt)
+    err = np.linalg.norm(xs.astype(np.float64) - xo) / np.linalg.norm(xo)
+    assert err < (5e-4 if TF == np.float32 else 1e-6), err
+    assert [len(v) for v in y_s] == [len(v) for v in y_o] == [m.size, Dxz.shape[0], m.size]
+    # (b) A'A computed by the host mirror (scipy product: summation order unpinned): same solution to tolerance
+    xs2, ls2, _, _ = sipx.PARSDMM(m.copy(), AtAs, As, props, Ps, gs, os_)
+    assert np.linalg.norm(xs2.astype(np.float64) - xo) / np.linalg.norm(xo) < (1e-3 if TF == np.float32 else 1e-5)
