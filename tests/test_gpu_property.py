@@ -129,13 +129,14 @@ def test_random_small_problems_match_oracle(sipx):
     spec = importlib.util.spec_from_file_location("tg", os.path.join(os.path.dirname(__file__), "test_gpu_parity.py"))
     tg = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(tg)
-    pool2 = ["bounds", "l1:D_x", "l1:D_z", "l1:TV", "annulus", "bnd:D_z", "l2"]
-    pool3 = pool2 + ["l1:D_y"]
+    pool2 = ["bounds", "l1:D_x", "l1:D_z", "l1:TV", "annulus", "bnd:D_z", "l2", "card:D_z", "l1dft", "l1dct", "hist", "nuc:"]
+    pool3 = ["bounds", "l1:D_x", "l1:D_z", "l1:TV", "annulus", "bnd:D_z", "l2", "l1:D_y", "card:D_z", "l1dft", "l1dct", "hist",
+             "nuc:z", "cardf:D_y:slice:z", "cardf:identity:fiber:x", "bndf:z"]
 
-    @settings(max_examples=150, deadline=None, derandomize=True, database=None,
+    @settings(max_examples=60, deadline=None, derandomize=True, database=None,
               suppress_health_check=[HealthCheck.function_scoped_fixture])
-    @given(ndim=st.sampled_from([2, 3]), dims=st.tuples(st.integers(2, 13), st.integers(2, 11), st.integers(2, 7)),
-           picks=st.lists(st.integers(0, 7), min_size=1, max_size=4, unique=True), seed=st.integers(0, 1000),
+    @given(ndim=st.sampled_from([2, 3]), dims=st.tuples(st.integers(3, 13), st.integers(3, 11), st.integers(3, 7)),
+           picks=st.lists(st.integers(0, 15), min_size=1, max_size=4, unique=True), seed=st.integers(0, 1000),
            TF=st.sampled_from([np.float32, np.float64]))
     def run(ndim, dims, picks, seed, TF):
         n = dims[:ndim]
@@ -150,6 +151,8 @@ def test_random_small_problems_match_oracle(sipx):
         xo, lo, _, _ = O.PARSDMM(m.copy(), AtAo, Ao, propo, Po, go, oo)
         xs, ls, _, _ = sipx.PARSDMM(m.copy(), AtAs, As, props, Ps, gs, os_)
         K = min(5, len(lo.obj), len(ls.obj))
+        if TF == np.float32 and any(k in ("hist",) or k.startswith("card") for k in kinds):
+            K = min(K, 3)      # order-based projectors are discontinuous: a Float32 rounding difference can swap two entries
         rt = 1e-3 if TF == np.float32 else 1e-7
         assert np.array_equal(ls.cg_it[:K], lo.cg_it[:K]), (n, kinds)
         for f in ("obj", "r_pri_total", "rho"):
