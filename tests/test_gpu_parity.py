@@ -1119,3 +1119,26 @@ def test_custom_sparse_operator_matches_oracle(sipx, TF, which):
     # (b) A'A computed by the host mirror (scipy product: summation order unpinned): same solution to tolerance
     xs2, ls2, _, _ = sipx.PARSDMM(m.copy(), AtAs, As, props, Ps, gs, os_)
     assert np.linalg.norm(xs2.astype(np.float64) - xo) / np.linalg.norm(xo) < (1e-3 if TF == np.float32 else 1e-5)
+
+
+def test_stepwise_driver_equals_whole_solve(sipx):
+    """sipx_parsdmm_begin / sipx_parsdmm_steps (what bench.py drives) == sipx_parsdmm, bit for bit."""
+    TF, n, h = np.float32, (24, 20, 12), (25.0, 25.0, 25.0)
+    kinds = ["bounds", "l1:D_x", "l1:D_z", "annulus"]
+    m = model(n, TF, seed=8)
+    gs, os_, Ps, As, props, AtAs = _problem(sipx, n, h, TF, kinds, m, dict(maxit=35))
+    x1, log1, l1, y1 = sipx.PARSDMM(m.copy(), AtAs, As, props, Ps, gs, os_)
+    ctx = sipx.host.build_context(m, AtAs, As, props, Ps, gs, os_)
+    ctx.parsdmm_begin(os_)
+    done, steps = False, 0
+    while not done:
+        done = ctx.parsdmm_steps(3 if steps % 2 else 1)      # uneven chunks
+        steps += 1
+        assert steps < 100
+    log2 = ctx.parsdmm_log()
+    x2, l2, y2 = ctx.download()
+    ctx.close()
+    assert len(log2.obj) == len(log1.obj)
+    assert np.array_equal(x1, x2) and all(np.array_equal(a, b) for a, b in zip(y1, y2)) and all(np.array_equal(a, b) for a, b in zip(l1, l2))
+    for f in ("obj", "evol_x", "r_pri", "r_dual", "rho", "gamma", "cg_it", "cg_relres", "set_feasibility"):
+        assert np.array_equal(np.asarray(getattr(log1, f)), np.asarray(getattr(log2, f)), equal_nan=True), f
