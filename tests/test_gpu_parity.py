@@ -1142,3 +1142,55 @@ def test_stepwise_driver_equals_whole_solve(sipx):
     assert np.array_equal(x1, x2) and all(np.array_equal(a, b) for a, b in zip(y1, y2)) and all(np.array_equal(a, b) for a, b in zip(l1, l2))
     for f in ("obj", "evol_x", "r_pri", "r_dual", "rho", "gamma", "cg_it", "cg_relres", "set_feasibility"):
         assert np.array_equal(np.asarray(getattr(log1, f)), np.asarray(getattr(log2, f)), equal_nan=True), f
+
+
+# ---- test/test_setup_constraints.jl: the same properties, through setup_constraints -> P_sub[i] -----------------------
+@pytest.mark.parametrize("which", ["oracle", "sipx"])
+def test_setup_constraints_projectors_have_the_reference_properties(sipx, which):
+    mod = O if which == "oracle" else sipx
+    TF = np.float64
+    rng = np.random.default_rng(33)
+    g2, g3 = mod.compgrid((1.0, 1.0), (20, 31)), mod.compgrid((1.0, 1.0, 1.0), (10, 12, 6))
+    N2, N3 = 20 * 31, 10 * 12 * 6
+
+    def P(st, lo, hi, mode, grid, custom=((), False)):
+        c = mod.set_definitions(st, "identity", lo, hi, mode)
+        c.custom_TD_OP = custom
+        return mod.setup_constraints([c], grid, TF)[0][0]
+
+    x = rng.standard_normal(N2)
+    y = P("bounds", -0.11, 0.01, ("matrix", ""), g2)(x.copy())
+    assert y.max() <= 0.01 and y.min() >= -0.11                                            # :13-26
+    lo, hi = rng.standard_normal(N2) - 10, rng.standard_normal(N2) + 10
+    y = P("bounds", lo, hi, ("matrix", ""), g2)(100 * rng.standard_normal(N2))
+    assert (y <= hi).all() and (y >= lo).all()                                             # :28-42
+    assert np.array_equal(P("l1", 0, 2 * np.abs(x).sum(), ("matrix", ""), g2)(x.copy()), x)   # :45-59
+    y = P("l1", 0, 0.234 * np.abs(x).sum(), ("matrix", ""), g2)(x.copy())
+    assert abs(np.abs(y).sum() - 0.234 * np.abs(x).sum()) < 1e-10 * np.abs(x).sum()        # :61-74
+    assert np.count_nonzero(P("cardinality", 0, 5, ("matrix", ""), g2)(x.copy())) == 5      # :77-91
+    X = P("cardinality", 0, 7, ("fiber", "x"), g2)(x.copy()).reshape((20, 31), order="F")
+    assert all(np.count_nonzero(X[:, i]) == 7 for i in range(31))                           # :108-120
+    X = P("cardinality", 0, 11, ("fiber", "z"), g2)(x.copy()).reshape((20, 31), order="F")
+    assert all(np.count_nonzero(X[i, :]) == 11 for i in range(20))                          # :123-135
+    x3 = rng.standard_normal(N3)
+    for d, ax, k in (("x", 0, 7), ("y", 1, 6), ("z", 2, 5)):
+        X = P("cardinality", 0, k, ("slice", d), g3)(x3.copy()).reshape((10, 12, 6), order="F")
+        assert all(np.count_nonzero(np.take(X, i, axis=ax)) == k for i in range(X.shape[ax]))   # :181-221
+        X = P("rank", 0, 3, ("slice", d), g3)(x3.copy()).reshape((10, 12, 6), order="F")
+        assert all(np.linalg.matrix_rank(np.take(X, i, axis=ax)) == 3 for i in range(X.shape[ax]))   # :289-329
+        X = P("nuclear", 0.0, 1.234, ("slice", d), g3)(x3.copy()).reshape((10, 12, 6), order="F")
+        assert all(abs(np.linalg.svd(np.take(X, i, axis=ax), compute_uv=False).sum() - 1.234) < 1e-9
+                   for i in range(X.shape[ax]))                                                  # :369-409
+    y = P("l2", 0, 0.123, ("matrix", ""), g2)(x.copy())
+    assert abs(np.linalg.norm(y) - 0.123) < 1e-12                                           # :224-237
+    assert np.linalg.matrix_rank(P("rank", 0, 12, ("matrix", ""), g2)(x.copy()).reshape((20, 31), order="F")) == 12   # :273-286
+    M = rng.standard_normal((20, 7))
+    y = P("subspace", 0, 0, ("fiber", "x"), g2, (M, False))(x.copy())
+    Xr = x.reshape((20, 31), order="F")
+    assert np.allclose(y.reshape((20, 31), order="F"), M @ np.linalg.solve(M.T @ M, M.T @ Xr), rtol=1e-9, atol=1e-11)   # :448-462
+    ref = np.sort(rng.standard_normal(N2))
+    assert np.array_equal(np.sort(P("histogram", ref, ref, ("matrix", ""), g2)(x.copy())), ref)   # :482-495
+    with pytest.raises(Exception):
+        mod.setup_constraints([mod.set_definitions("rank", "identity", 0, 3, ("tensor", ""))], g3, TF)   # setup_constraints.jl:60-62
+    with pytest.raises(Exception):
+        mod.setup_constraints([mod.set_definitions("l1", "identity", 0, 1.0, ("fiber", "x"))], g2, TF)   # :65-67
