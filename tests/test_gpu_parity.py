@@ -1194,3 +1194,26 @@ def test_setup_constraints_projectors_have_the_reference_properties(sipx, which)
         mod.setup_constraints([mod.set_definitions("rank", "identity", 0, 3, ("tensor", ""))], g3, TF)   # setup_constraints.jl:60-62
     with pytest.raises(Exception):
         mod.setup_constraints([mod.set_definitions("l1", "identity", 0, 1.0, ("fiber", "x"))], g2, TF)   # :65-67
+
+
+@pytest.mark.parametrize("which", ["oracle", "sipx"])
+def test_single_nuclear_norm_set_reaches_the_closed_form(sipx, which):
+    """test/test_PARSDMM.jl:192-242: one nuclear-norm set on the identity, tolerances 10 eps, maxit 2500:
+    PARSDMM(m) agrees with project_nuclear!(m) to 1e-9 and is feasible to 2 feas_tol."""
+    mod = O if which == "oracle" else sipx
+    TF = np.float64
+    n = (100, 201)
+    rng = np.random.default_rng(44)
+    m = rng.standard_normal(n[0] * n[1])
+    tau = 0.54321
+    closed = O.project_nuclear(m.copy(), tau, n)
+    g = mod.compgrid((1.0, 1.0), n)
+    c = [mod.set_definitions("nuclear", "identity", 0.0, tau, ("matrix", ""))]
+    eps = float(np.finfo(TF).eps)
+    opt = mod.PARSDMM_options(FL=TF, maxit=2500, obj_tol=10 * eps, feas_tol=10 * eps, evol_rel_tol=10 * eps, Blas_active=False)
+    P, A, prop = mod.setup_constraints(c, g, TF)
+    A, AtA, l, y = mod.PARSDMM_precompute_distribute(A, prop, g, opt)
+    x, log, _, _ = mod.PARSDMM(m.copy(), AtA, A, prop, P, g, opt)
+    assert np.linalg.norm(x - closed) / np.linalg.norm(closed) <= 1e-9
+    px = P[0](x.copy())
+    assert np.linalg.norm(px - x) / np.linalg.norm(x) <= 2.0 * 10 * eps + 1e-13
