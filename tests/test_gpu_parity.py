@@ -484,7 +484,8 @@ def _sharded_worker(rank, world, port, out, kinds):
 # the pytest process holds the GPU too and a box allows 6 processes on it: 4 ranks at most.  4 ranks on 3 terms: one rank
 # owns no set at all (the 8-GPU / 5-term case in small)
 @pytest.mark.timeout(400)
-@pytest.mark.parametrize("world,kinds", [(2, ["bounds", "l1:D_x", "l1:D_y", "l1:D_z"]), (4, ["bounds", "l1:D_z"])])
+@pytest.mark.parametrize("world,kinds", [(2, ["bounds", "l1:D_x", "l1:D_y", "l1:D_z"]), (4, ["bounds", "l1:D_z"]),
+                                         (2, ["l1:TV"]), (2, ["l1dft"])])     # the last two: test_PARSDMM_parallel.jl:13-66, 69-121
 def test_sharded_ranks_on_one_gpu(sipx, tmp_path, world, kinds):
     import os
     import torch.multiprocessing as mp
