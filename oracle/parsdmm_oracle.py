@@ -272,6 +272,12 @@ def get_TD_operator(comp_grid, TD_type: str, TF):
         return sp.identity(N, dtype=TF, format="csc"), True, False, n, True
     if TD_type in ("DFT", "DCT"):   # the transform is folded into the projector, TD_OP becomes I (setup_constraints.jl:76-80)
         return sp.identity(N, dtype=TF, format="csc"), True, True, n, True
+    if TD_type == "D_xz" and len(n) == 2:      # src/get_TD_operator.jl:66-70: D_z on the (n1-1, n2) grid of D_x's output
+        Dx = get_discrete_Grad(n, h, "D_x", TF)
+        Dz = get_discrete_Grad((n[0] - 1, n[1]), h, "D_z", TF)
+        A = sp.csc_matrix(Dz @ Dx, dtype=TF)
+        A.sort_indices()
+        return A, False, False, (n[0] - 1, n[1] - 1), True
     A = get_discrete_Grad(n, h, TD_type, TF)
     if len(n) == 2:
         n1, n2 = n

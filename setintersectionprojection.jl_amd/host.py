@@ -445,6 +445,21 @@ def get_TD_operator(comp_grid, TD_type: str, TF):
     n, _ = _grid(comp_grid)
     if TD_type in ("DFT", "DCT"):   # src/get_TD_operator.jl:45-51,80-86; setup_constraints.jl:76-80 swaps in the identity
         return TDOperator("identity", comp_grid, TF), True, True, n, False
+    if TD_type == "D_xz":      # src/get_TD_operator.jl:66-70 (2-D only): TD_OP = D_z * D_x, shipped as a sparse matrix
+        if len(n) != 2:
+            raise SipxError("provided an unknown transform domain operator. check function "
+                            "get_TD_operator(comp_grid,TD_type,TF) for options")
+        import scipy.sparse as sp
+        TFt = np.dtype(TF).type
+        _, h = _grid(comp_grid)
+
+        def fwd(k, hk):       # (k-1) x k forward difference with entries -+fl(1/h)   (get_discrete_Grad.jl:22-23)
+            ih = TFt(1) / TFt(hk)
+            return sp.diags([np.full(k - 1, -ih, TFt), np.full(k - 1, ih, TFt)], [0, 1], shape=(k - 1, k), dtype=TFt, format="csc")
+        n1, n2 = n
+        Dx = sp.kron(sp.identity(n2, dtype=TFt, format="csc"), fwd(n1, h[0]), format="csc")            # on (n1, n2)
+        Dz = sp.kron(fwd(n2, h[1]), sp.identity(n1 - 1, dtype=TFt, format="csc"), format="csc")        # on (n1-1, n2)
+        return CustomOperator((Dz @ Dx).astype(TFt), comp_grid, TF), False, False, (n1 - 1, n2 - 1), True
     A = TDOperator(TD_type, comp_grid, TF)
     if TD_type == "identity":
         return A, True, False, n, True

@@ -1218,3 +1218,30 @@ def test_single_nuclear_norm_set_reaches_the_closed_form(sipx, which):
     assert np.linalg.norm(x - closed) / np.linalg.norm(closed) <= 1e-9
     px = P[0](x.copy())
     assert np.linalg.norm(px - x) / np.linalg.norm(x) <= 2.0 * 10 * eps + 1e-13
+
+
+@pytest.mark.parametrize("TF", [np.float32, np.float64])
+def test_named_D_xz_operator(sipx, TF):
+    """TD_OP = "D_xz" (get_TD_operator.jl:66-70, 2-D only) goes through the sparse-operator path."""
+    n, h = (30, 22), (25.0, 6.0)
+    m = model(n, TF, seed=7)
+    Ao = O.get_TD_operator(O.compgrid(h, n), "D_xz", TF)[0]
+    As = sipx.get_TD_operator(sipx.compgrid(h, n), "D_xz", TF)[0]
+    assert As.A.shape == Ao.shape == ((n[0] - 1) * (n[1] - 1), n[0] * n[1])
+    assert np.array_equal(As.A.toarray(), Ao.toarray())                      # same rounded entries +-fl(1/h1) fl(1/h2)
+    res = {}
+    for name, mod in (("o", O), ("s", sipx)):
+        g = mod.compgrid(h, n)
+        c = [mod.set_definitions("bounds", "identity", 1600.0, 3900.0, ("matrix", "")),
+             mod.set_definitions("l1", "D_xz", 0.0, float(0.4 * np.abs(Ao @ m).sum()), ("matrix", ""))]
+        opt = mod.PARSDMM_options(FL=TF, maxit=40)
+        P, A, prop = mod.setup_constraints(c, g, TF)
+        A, AtA, l, y = mod.PARSDMM_precompute_distribute(A, prop, g, opt)
+        res[name] = mod.PARSDMM(m.copy(), AtA, A, prop, P, g, opt)
+    (xo, lo, _, _), (xs, ls, _, _) = res["o"], res["s"]
+    K = min(5, len(lo.obj), len(ls.obj))
+    assert np.array_equal(ls.cg_it[:K], lo.cg_it[:K])
+    assert np.allclose(ls.obj[:K], lo.obj[:K], rtol=1e-3 if TF == np.float32 else 1e-7)
+    assert np.linalg.norm(xs.astype(np.float64) - xo) / np.linalg.norm(xo) < (1e-3 if TF == np.float32 else 1e-5)
+    with pytest.raises(sipx.SipxError):
+        sipx.get_TD_operator(sipx.compgrid((1.0,) * 3, (4, 4, 4)), "D_xz", TF)
