@@ -552,7 +552,8 @@ class Engine : public EngineBase {
       }
       if (s.two_pass) {   // threshold / scale of prox_i from one pass that produces v on the fly (nothing stored)
         SetArgs<T> ap = a;
-        if (s.last_rho != a.rho || s.last_gamma != a.gamma) ap.flags |= F_NOSPEC;   // v rescaled: theta will jump
+        if (a.prox == PX_L1 && s.last_rho > T(0) && s.last_rho != a.rho)            // v rescaled: theta moves like 1/rho
+          K<T>::ps_rescale(q, s.ps, (double)s.last_rho / (double)a.rho);
         K<T>::proj_scalars_set(q, gs, ap, 0, s.ps, ptmp, mpart, cbuf, s.Mtrue);
         s.last_rho = a.rho;
         s.last_gamma = a.gamma;

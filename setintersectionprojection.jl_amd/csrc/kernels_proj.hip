@@ -18,6 +18,7 @@
 //            exact theta in float64.
 //   project_l2!        src/projectors/project_l2!.jl:3-16
 //   project_annulus!   src/projectors/project_annulus!.jl:3-21
+#include <cstdlib>
 #include <cstring>
 #include <stdexcept>
 #include <string>
@@ -30,6 +31,14 @@ namespace sipx {
 constexpr double L1_CAP = 131072.0;     // bracket population above which one more probe pass is run (floor; scales with the length)
 constexpr int L1_REFINES = 1;           // gated refinement passes enqueued per search
 constexpr int SPEC_CAP = 1024;           // per-workgroup LDS buffer of the speculative compaction
+// Probe thresholds of the next call, as multiples of the half-width hw around the predicted theta: the two inner probes
+// are the edges of the speculative gather range, the outer ones catch a theta that moved further (geometric spacing, so one
+// pass brackets it between neighbouring probes whatever the size of the move up to 64 hw).
+constexpr int L1_WIN_LO = 3, L1_WIN_HI = 4;
+__device__ __forceinline__ double l1_probe_mult(int k) {
+  const double m[L1_K] = {-64.0, -16.0, -4.0, -1.0, 1.0, 4.0, 16.0, 64.0};
+  return m[k];
+}
 constexpr int SL_ABOVE_S = PREP_SLOTS, SL_ABOVE_C = PREP_SLOTS + 1;   // partial slots of the fallback compaction
 enum { M_FIRST = 0, M_PROBE = 1, M_COMPACT = 2, M_DIST = 3, M_STORE = 4 /* materialise v into `compact` */ };
 
@@ -255,7 +264,7 @@ __device__ __forceinline__ void reduce_slots(const double* __restrict__ partials
 template <typename T, int STAGE>
 __global__ __launch_bounds__(1024) void k_decide(const double* __restrict__ partials, const T* __restrict__ maxpart,
                                                  ProjScalars<T>* ps, int prox, T pmin, T pmax, long long true_len,
-                                                 int nospec) {
+                                                 int nospec, double capdiv) {
   if (STAGE == 1 && !(ps->need && !ps->spec_ok && ps->refine)) return;
   __shared__ double red[PREP_SLOTS];
   __shared__ T smax[16];
@@ -342,12 +351,12 @@ __global__ __launch_bounds__(1024) void k_decide(const double* __restrict__ part
   ps->lo = lo;
   ps->hi = hi;
   if (STAGE == 0) {
-    // speculative gather usable?  range edges are probes 0 and L1_K-1, so (S,C) above it are known
+    // speculative gather usable?  range edges are probes L1_WIN_LO and L1_WIN_HI, so (S,C) above it are known
     const bool spec = !nospec && ps->spec_hi > ps->spec_lo && !ps->spec_overflow && lo >= ps->spec_lo && hi <= ps->spec_hi;
     if (spec) {
       ps->spec_ok = 1;
-      ps->s_above = red[3 + L1_K - 1];
-      ps->c_above = red[3 + 2 * L1_K - 1];
+      ps->s_above = red[3 + L1_WIN_HI];
+      ps->c_above = red[3 + L1_K + L1_WIN_HI];
       return;
     }
     ps->n_compact = 0;                                   // discard what the speculation gathered
@@ -356,8 +365,12 @@ __global__ __launch_bounds__(1024) void k_decide(const double* __restrict__ part
   // (each gated refinement pass narrows it by >= L1_K-1 and by the Newton/secant step on top)
   // one more probe pass costs a full sweep of the vector, gathering a larger bracket costs the one-workgroup solve a
   // longer scan: the break-even population grows with the length (measured at 256^3 and 512^3)
-  const double cap = fmax(L1_CAP, (double)true_len / 8.0);
-  if (Cl - Ch > cap && hi > lo && (STAGE == 0 || ps->refine < L1_REFINES)) {
+  const double cap = fmax(L1_CAP, (double)true_len / capdiv);
+  // population of the tightened bracket (lo, hi]: the count between the two probes, scaled by the share of the interval
+  // that is left (factor 2 for a density that is not flat).  A wrong guess only costs time: the gather never drops.
+  double pop = Cl - Ch;
+  if (th > tl) pop *= fmin(1.0, 2.0 * (hi - lo) / (th - tl));
+  if (pop > cap && hi > lo && (STAGE == 0 || ps->refine < L1_REFINES)) {
     ps->refine = (STAGE == 0) ? 1 : ps->refine + 1;
     for (int k = 0; k < L1_K; ++k) ps->t[k] = (double)(T)(lo + (hi - lo) * (double)k / (double)(L1_K - 1));
   } else {
@@ -404,9 +417,28 @@ __global__ __launch_bounds__(1024) void k_l1_solve(ProjScalars<T>* ps, T radius,
     double cprev = -1;
     for (int it = 0; it < 200; ++it) {
       double s = 0, c = 0;
-      for (long long e = threadIdx.x; e < n; e += 1024) {
-        const double av = (double)compact[e];
-        if (av > theta) { s += av; c += 1.0; }
+      {   // one workgroup streams the gathered values: 16-byte loads, four in flight per thread
+        const long long nv = n / 4;
+        for (long long i0 = threadIdx.x; i0 < nv; i0 += 4 * 1024) {
+          Vec<T, 4> q[4];
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            const long long i = i0 + (long long)u * 1024;
+            if (i < nv) q[u] = ldv_u<T, 4>(compact + 4 * i);
+            else { q[u].v[0] = q[u].v[1] = q[u].v[2] = q[u].v[3] = T(0); }     // magnitudes are >= 0 = not above theta >= 0
+          }
+#pragma unroll
+          for (int u = 0; u < 4; ++u)
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+              const double av = (double)q[u].v[k];
+              if (av > theta) { s += av; c += 1.0; }
+            }
+        }
+        for (long long e = 4 * nv + threadIdx.x; e < n; e += 1024) {
+          const double av = (double)compact[e];
+          if (av > theta) { s += av; c += 1.0; }
+        }
       }
       s = wave_sum(s);
       c = wave_sum(c);
@@ -453,15 +485,13 @@ __global__ __launch_bounds__(1024) void k_l1_solve(ProjScalars<T>* ps, T radius,
       }
       ps->hw = hw;
       ps->theta_prev = theta;
-      const double m[L1_K] = {-1.0, -0.25, -1.0 / 16, -1.0 / 64, 1.0 / 64, 1.0 / 16, 0.25, 1.0};
-      for (int k = 0; k < L1_K; ++k) ps->t[k] = (double)(T)(theta * (1.0 + hw * m[k]));
-      ps->spec_lo = ps->t[0];
-      ps->spec_hi = ps->t[L1_K - 1];
+      for (int k = 0; k < L1_K; ++k) ps->t[k] = (double)(T)(theta * (1.0 + hw * l1_probe_mult(k)));
+      ps->spec_lo = ps->t[L1_WIN_LO];
+      ps->spec_hi = ps->t[L1_WIN_HI];
     } else if (ps->theta_prev > 0) {            // inside the ball now: keep probing around the last theta
-      const double m[L1_K] = {-1.0, -0.25, -1.0 / 16, -1.0 / 64, 1.0 / 64, 1.0 / 16, 0.25, 1.0};
-      for (int k = 0; k < L1_K; ++k) ps->t[k] = (double)(T)(ps->theta_prev * (1.0 + ps->hw * m[k]));
-      ps->spec_lo = ps->t[0];
-      ps->spec_hi = ps->t[L1_K - 1];
+      for (int k = 0; k < L1_K; ++k) ps->t[k] = (double)(T)(ps->theta_prev * (1.0 + ps->hw * l1_probe_mult(k)));
+      ps->spec_lo = ps->t[L1_WIN_LO];
+      ps->spec_hi = ps->t[L1_WIN_HI];
     }
     ps->n_compact = 0;
     ps->spec_overflow = 0;
@@ -587,10 +617,28 @@ __global__ __launch_bounds__(1024) void k_card_select(ProjScalars<T>* ps, long l
   }
 }
 
+// v = x_hat - l/rho: where the multiplier term dominates, theta moves like 1/rho when rho is changed.  Re-centre the
+// probes of the coming call on the scaled prediction (and widen the range: the prediction is good to a few percent).
+template <typename T>
+__global__ void k_ps_rescale(ProjScalars<T>* ps, double factor) {
+  if (!(ps->theta_prev > 0)) return;
+  ps->theta_prev *= factor;
+  ps->hw = 1e-2;
+  for (int k = 0; k < L1_K; ++k) ps->t[k] = (double)(T)(ps->theta_prev * (1.0 + ps->hw * l1_probe_mult(k)));
+  ps->spec_lo = ps->t[L1_WIN_LO];
+  ps->spec_hi = ps->t[L1_WIN_HI];
+}
+template <typename T>
+void K<T>::ps_rescale(hipStream_t s, ProjScalars<T>* ps, double factor) {
+  hipLaunchKernelGGL((k_ps_rescale<T>), dim3(1), dim3(1), 0, s, ps, factor);
+  SIPX_HIP(hipGetLastError());
+}
+
 template <typename T, int SRC>
 static void launch_chain(hipStream_t s, const Grid& g, const SetArgs<T>& a, int v_is_s, const T* varr, long long len,
                          ProjScalars<T>* ps, double* partials, T* maxpart, T* compact, long long true_len) {
   const bool vec = SRC == 1 && g.n[0] % 4 == 0;
+  static const double capdiv = [] { const char* e = getenv("SIPX_L1_CAPDIV"); return e ? atof(e) : 64.0; }();
 #define SIPX_PASS(MODE)                                                                                            \
   do {                                                                                                             \
     if (vec)                                                                                                       \
@@ -615,11 +663,11 @@ static void launch_chain(hipStream_t s, const Grid& g, const SetArgs<T>& a, int 
   }
   SIPX_PASS(M_FIRST);
   hipLaunchKernelGGL((k_decide<T, 0>), dim3(1), dim3(1024), 0, s, partials, maxpart, ps, a.prox, a.plo, a.phi, true_len,
-                     (a.flags & F_NOSPEC) ? 1 : 0);
+                     (a.flags & F_NOSPEC) ? 1 : 0, capdiv);
   if (a.prox == PX_L1) {
     for (int r = 0; r < L1_REFINES; ++r) {
       SIPX_PASS(M_PROBE);
-      hipLaunchKernelGGL((k_decide<T, 1>), dim3(1), dim3(1024), 0, s, partials, maxpart, ps, a.prox, a.plo, a.phi, true_len, 0);
+      hipLaunchKernelGGL((k_decide<T, 1>), dim3(1), dim3(1024), 0, s, partials, maxpart, ps, a.prox, a.plo, a.phi, true_len, 0, capdiv);
     }
     SIPX_PASS(M_COMPACT);
     hipLaunchKernelGGL((k_l1_solve<T>), dim3(1), dim3(1024), 0, s, ps, a.phi, compact, partials, true_len);
@@ -674,6 +722,7 @@ void K<T>::proj_dist_set(hipStream_t s, const Grid& g, const SetArgs<T>& a, int 
 
 #define SIPX_INST(T)                                                                                              \
   template void K<T>::ps_init(hipStream_t, ProjScalars<T>*, long long*);                                         \
+  template void K<T>::ps_rescale(hipStream_t, ProjScalars<T>*, double);                                          \
   template void K<T>::store_v(hipStream_t, const Grid&, const SetArgs<T>&, int, T*);                                                     \
   template void K<T>::proj_scalars_set(hipStream_t, const Grid&, const SetArgs<T>&, int, ProjScalars<T>*, double*, \
                                        T*, T*, long long);                                                       \

@@ -211,6 +211,7 @@ struct K {
   // Scalars of the two-pass projectors (l1 threshold, l2 / annulus scale) of a vector that is either
   // produced on the fly by a set (v = x_hat - l/rho, or s = A x when v_is_s) or stored in an array.
   // Enqueues: first pass (sums + probe + speculative compaction), bracket, gated refinement / compaction, solve.
+  static void ps_rescale(hipStream_t s, ProjScalars<T>* ps, double factor);
   static void proj_scalars_set(hipStream_t s, const Grid& g, const SetArgs<T>& a, int v_is_s, ProjScalars<T>* ps,
                                double* partials, T* maxpart, T* compact, long long true_len);
   static void proj_scalars_arr(hipStream_t s, long long len, const T* v, int prox, T pmin, T pmax, ProjScalars<T>* ps,

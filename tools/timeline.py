@@ -1,0 +1,67 @@
+"""Where does the wall time of an iteration go?  Reads a rocprofv3 --kernel-trace CSV and, over the dispatches of the
+last `frac` of the run (the timed steps), reports
+  * the union of all kernel intervals (GPU busy) and the gaps between them (launch / host latency),
+  * the time during which ONLY one-workgroup kernels (decide / solve / finalize) are running: latency-bound tail,
+  * per kernel: launches, median / mean duration of the launches that did work (>= 5 us).
+
+usage: python tools/timeline.py <dir with *_kernel_trace.csv> [frac=0.6]"""
+import csv
+import glob
+import os
+import statistics
+import sys
+
+SMALL = ("k_decide", "k_l1_solve", "k_fin", "k_cg_fin", "k_cg_begin", "k_card_decide", "k_card_select", "k_ps_init",
+         "k_stop", "k_bb", "k_log")
+
+
+def main():
+    src = sys.argv[1]
+    frac = float(sys.argv[2]) if len(sys.argv) > 2 else 0.6
+    files = glob.glob(os.path.join(src, "**", "*kernel_trace.csv"), recursive=True)
+    rows = []
+    for f in files:
+        for r in csv.DictReader(open(f)):
+            rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r.get("Kernel_Name") or r.get("Name")))
+    rows.sort()
+    rows = rows[int(len(rows) * (1 - frac)):]
+    t0, t1 = rows[0][0], max(r[1] for r in rows)
+    # sweep
+    ev = []
+    for s, e, n in rows:
+        small = any(k in n for k in SMALL)
+        ev.append((s, 1, small))
+        ev.append((e, -1, small))
+    ev.sort()
+    busy = small_only = 0
+    nbig = nsmall = 0
+    last = ev[0][0]
+    for t, d, small in ev:
+        if nbig + nsmall > 0:
+            busy += t - last
+            if nbig == 0:
+                small_only += t - last
+        last = t
+        if small:
+            nsmall += d
+        else:
+            nbig += d
+    wall = t1 - t0
+    print(f"window {wall/1e6:.2f} ms, {len(rows)} dispatches")
+    print(f"GPU busy (union)        {busy/1e6:8.2f} ms  {100*busy/wall:5.1f} %")
+    print(f"  only 1-workgroup work {small_only/1e6:8.2f} ms  {100*small_only/wall:5.1f} %")
+    print(f"idle gaps               {(wall-busy)/1e6:8.2f} ms  {100*(wall-busy)/wall:5.1f} %")
+    per = {}
+    for s, e, n in rows:
+        per.setdefault(n.split("(")[0][:60], []).append((e - s) * 1e-3)
+    out = []
+    for n, d in per.items():
+        w = [v for v in d if v >= 5.0] or d
+        out.append((sum(d), n, len(d), len(w), statistics.median(w), sum(w) / len(w)))
+    out.sort(reverse=True)
+    for tot, n, c, cw, med, mean in out[:24]:
+        print(f"{n:60s} n={c:4d} work={cw:4d} median={med:8.1f}us mean={mean:8.1f}us total={tot/1e3:7.2f}ms")
+
+
+if __name__ == "__main__":
+    main()
