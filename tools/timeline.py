@@ -51,6 +51,20 @@ def main():
     print(f"GPU busy (union)        {busy/1e6:8.2f} ms  {100*busy/wall:5.1f} %")
     print(f"  only 1-workgroup work {small_only/1e6:8.2f} ms  {100*small_only/wall:5.1f} %")
     print(f"idle gaps               {(wall-busy)/1e6:8.2f} ms  {100*(wall-busy)/wall:5.1f} %")
+    # idle gaps by the pair of kernels around them
+    gaps = {}
+    cur_end, cur_name = rows[0][1], rows[0][2]
+    for s, e, n in rows[1:]:
+        if s > cur_end:
+            key = (cur_name.split("(")[0].replace("void sipx::", "")[:34], n.split("(")[0].replace("void sipx::", "")[:34])
+            g = gaps.setdefault(key, [0, 0.0])
+            g[0] += 1
+            g[1] += (s - cur_end) * 1e-3
+        if e > cur_end:
+            cur_end, cur_name = e, n
+    print("idle gaps by (kernel before -> kernel after):")
+    for (a, b), (c, t) in sorted(gaps.items(), key=lambda kv: -kv[1][1])[:14]:
+        print(f"  {a:34s} -> {b:34s} n={c:4d} total={t/1e3:6.2f}ms avg={t/c:6.1f}us")
     per = {}
     for s, e, n in rows:
         per.setdefault(n.split("(")[0][:60], []).append((e - s) * 1e-3)
