@@ -13,6 +13,11 @@
 #include <string>
 
 #include "sipx_device.h"
+// Workgroups of the kernels that write the CG partials: three per compute unit (768 on MI355X).  Measured against 512 ...
+// 1792: whole multiples of the CU count win over the in-between sizes, and 3 per CU is +1 % at 256^3, +4 % at 512^3 over
+// the 7 per CU the other stencil kernels use.  One value for every producer of a partial slot (block_sum_partials adds
+// all NB entries; the tail stays zero from allocation).
+#define SIPX_CG_GRID launch_blocks(3)
 
 namespace sipx {
 
@@ -124,7 +129,7 @@ static void launch_cds(hipStream_t s, long long N, const T* R, const CdsArgs& a,
                        T* xold, double* partials, const int* done) {
   if (a.d < 1 || a.d > MAXD) throw std::runtime_error("cds: band count out of range");
 #define SIPX_CDS(V, D) \
-  hipLaunchKernelGGL((k_cds<T, V, D, MODE>), dim3(NB_7), dim3(BLOCK), 0, s, N, R, a, x, y, b, pout, xold, partials, done)
+  hipLaunchKernelGGL((k_cds<T, V, D, MODE>), dim3(SIPX_CG_GRID), dim3(BLOCK), 0, s, N, R, a, x, y, b, pout, xold, partials, done)
   if (N % 4 == 0) {
     switch (a.d) {
       case 1: SIPX_CDS(4, 1); break;
@@ -236,9 +241,9 @@ static void launch_sq(hipStream_t s, const Grid& G, const StencilQ<T>& q, const 
   // NB_7 like every other kernel that writes the CG partials: block_sum_partials adds all NB entries of a slot, so the
   // producers of one slot must cover the same block range (the tail NB_7..NB-1 stays zero from allocation)
   if (G.N % 4 == 0 && G.n[0] % 4 == 0)
-    hipLaunchKernelGGL((k_sq<T, 4, MODE>), dim3(NB_7), dim3(BLOCK), 0, s, G, q, x, y, b, pout, xold, partials, done);
+    hipLaunchKernelGGL((k_sq<T, 4, MODE>), dim3(SIPX_CG_GRID), dim3(BLOCK), 0, s, G, q, x, y, b, pout, xold, partials, done);
   else
-    hipLaunchKernelGGL((k_sq<T, 1, MODE>), dim3(NB_7), dim3(BLOCK), 0, s, G, q, x, y, b, pout, xold, partials, done);
+    hipLaunchKernelGGL((k_sq<T, 1, MODE>), dim3(SIPX_CG_GRID), dim3(BLOCK), 0, s, G, q, x, y, b, pout, xold, partials, done);
   SIPX_HIP(hipGetLastError());
 }
 template <typename T>
@@ -519,9 +524,9 @@ template <typename T>
 void K<T>::cg_update_xr(hipStream_t s, long long N, T* x, T* r, const T* p, const T* Ap, double* partials,
                         const CgState<T>* st) {
   if (N % 4 == 0)
-    hipLaunchKernelGGL((k_cg_update_xr<T, 4>), dim3(NB_7), dim3(BLOCK), 0, s, N, x, r, p, Ap, partials, st);
+    hipLaunchKernelGGL((k_cg_update_xr<T, 4>), dim3(SIPX_CG_GRID), dim3(BLOCK), 0, s, N, x, r, p, Ap, partials, st);
   else
-    hipLaunchKernelGGL((k_cg_update_xr<T, 1>), dim3(NB_7), dim3(BLOCK), 0, s, N, x, r, p, Ap, partials, st);
+    hipLaunchKernelGGL((k_cg_update_xr<T, 1>), dim3(SIPX_CG_GRID), dim3(BLOCK), 0, s, N, x, r, p, Ap, partials, st);
   SIPX_HIP(hipGetLastError());
 }
 

@@ -39,6 +39,9 @@ __device__ __forceinline__ double l1_probe_mult(int k) {
   const double m[L1_K] = {-64.0, -16.0, -4.0, -1.0, 1.0, 4.0, 16.0, 64.0};
   return m[k];
 }
+// Workgroups of every k_pass launch (the only producers of the search's partial slots): five per compute unit, the
+// occupancy of the first pass, so the grid is resident in one round (+1 % at 256^3 over seven per CU).
+#define SIPX_PASS_GRID launch_blocks(5)
 constexpr int SL_ABOVE_S = PREP_SLOTS, SL_ABOVE_C = PREP_SLOTS + 1;   // partial slots of the fallback compaction
 enum { M_FIRST = 0, M_PROBE = 1, M_COMPACT = 2, M_DIST = 3, M_STORE = 4 /* materialise v into `compact` */ };
 
@@ -642,10 +645,10 @@ static void launch_chain(hipStream_t s, const Grid& g, const SetArgs<T>& a, int 
 #define SIPX_PASS(MODE)                                                                                            \
   do {                                                                                                             \
     if (vec)                                                                                                       \
-      hipLaunchKernelGGL((k_pass<T, 4, MODE, SRC>), dim3(NB_7), dim3(BLOCK), 0, s, g, a, v_is_s, varr, len, ps, compact, \
+      hipLaunchKernelGGL((k_pass<T, 4, MODE, SRC>), dim3(SIPX_PASS_GRID), dim3(BLOCK), 0, s, g, a, v_is_s, varr, len, ps, compact, \
                          partials, maxpart);                                                                       \
     else                                                                                                           \
-      hipLaunchKernelGGL((k_pass<T, 1, MODE, SRC>), dim3(NB_7), dim3(BLOCK), 0, s, g, a, v_is_s, varr, len, ps, compact, \
+      hipLaunchKernelGGL((k_pass<T, 1, MODE, SRC>), dim3(SIPX_PASS_GRID), dim3(BLOCK), 0, s, g, a, v_is_s, varr, len, ps, compact, \
                          partials, maxpart);                                                                       \
   } while (0)
   if (a.prox == PX_CARD) {

@@ -12,6 +12,18 @@ constexpr int NB = 2048;          // fixed grid of every streaming/reduction ker
 // Kernels that need 65..72 VGPRs run 7 workgroups per CU: a grid of 2048 would leave a 256-workgroup tail at 1/7
 // occupancy, so those families launch 7*256 workgroups (their block partials beyond that stay zero).
 constexpr int NB_7 = 1792;
+// per_cu workgroups on every compute unit of the current device, within the partial arrays (<= NB_7).  The value is fixed
+// for the life of the process (one process drives one GPU), so every producer of a partial slot covers the same range.
+inline int launch_blocks(int per_cu) {
+  static const int cus = [] {
+    int dev = 0, n = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0)
+      n = 256;
+    return n;
+  }();
+  const int g = per_cu * cus;
+  return g < 256 ? 256 : (g > NB_7 ? NB_7 : g);
+}
 constexpr int MAXD = 32;          // CDS bands held in kernel arguments
 constexpr int MAX_SETS = 16;      // sets fused in one rhs_compose launch
 constexpr int YL_SLOTS = 13;      // reductions produced by one y/l-update launch

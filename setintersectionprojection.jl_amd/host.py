@@ -21,7 +21,7 @@ from typing import Any, List, Optional, Sequence, Tuple
 
 import numpy as np
 
-LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "libsipx.so")
+LIB_PATH = os.environ.get("SIPX_LIBRARY") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "libsipx.so")
 
 # every entry point declared in include/sipx.h
 EXPORTED_SYMBOLS = [
