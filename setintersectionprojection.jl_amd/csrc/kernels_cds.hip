@@ -15,8 +15,7 @@
 #include "sipx_device.h"
 // Workgroups of the kernels that write the CG partials: three per compute unit (768 on MI355X).  Measured against 512 ...
 // 1792: whole multiples of the CU count win over the in-between sizes, and 3 per CU is +1 % at 256^3, +4 % at 512^3 over
-// the 7 per CU the other stencil kernels use.  One value for every producer of a partial slot (block_sum_partials adds
-// all NB entries; the tail stays zero from allocation).
+// the 7 per CU the other stencil kernels use.
 #define SIPX_CG_GRID launch_blocks(3)
 
 namespace sipx {
@@ -238,12 +237,12 @@ __global__ __launch_bounds__(BLOCK) void k_sq(Grid G, StencilQ<T> q, const T* __
 template <typename T, int MODE>
 static void launch_sq(hipStream_t s, const Grid& G, const StencilQ<T>& q, const T* x, T* y, const T* b, T* pout, T* xold,
                       double* partials, const int* done) {
-  // NB_7 like every other kernel that writes the CG partials: block_sum_partials adds all NB entries of a slot, so the
-  // producers of one slot must cover the same block range (the tail NB_7..NB-1 stays zero from allocation)
+  // the stencil form streams 2N values and wants the larger grid (43 us at 3 workgroups per CU, 32 us at 7; 256^3);
+  // block_reduce_store clears the partial entries beyond a launch's grid, so it may differ from cg_update_xr's
   if (G.N % 4 == 0 && G.n[0] % 4 == 0)
-    hipLaunchKernelGGL((k_sq<T, 4, MODE>), dim3(SIPX_CG_GRID), dim3(BLOCK), 0, s, G, q, x, y, b, pout, xold, partials, done);
+    hipLaunchKernelGGL((k_sq<T, 4, MODE>), dim3(NB_7), dim3(BLOCK), 0, s, G, q, x, y, b, pout, xold, partials, done);
   else
-    hipLaunchKernelGGL((k_sq<T, 1, MODE>), dim3(SIPX_CG_GRID), dim3(BLOCK), 0, s, G, q, x, y, b, pout, xold, partials, done);
+    hipLaunchKernelGGL((k_sq<T, 1, MODE>), dim3(NB_7), dim3(BLOCK), 0, s, G, q, x, y, b, pout, xold, partials, done);
   SIPX_HIP(hipGetLastError());
 }
 template <typename T>

@@ -12,8 +12,7 @@ constexpr int NB = 2048;          // fixed grid of every streaming/reduction ker
 // Kernels that need 65..72 VGPRs run 7 workgroups per CU: a grid of 2048 would leave a 256-workgroup tail at 1/7
 // occupancy, so those families launch 7*256 workgroups (their block partials beyond that stay zero).
 constexpr int NB_7 = 1792;
-// per_cu workgroups on every compute unit of the current device, within the partial arrays (<= NB_7).  The value is fixed
-// for the life of the process (one process drives one GPU), so every producer of a partial slot covers the same range.
+// per_cu workgroups on every compute unit of the current device, within the partial arrays (<= NB_7).
 inline int launch_blocks(int per_cu) {
   static const int cus = [] {
     int dev = 0, n = 0;

@@ -117,7 +117,11 @@ __device__ __forceinline__ void block_reduce_store(double (&acc)[K], double* __r
     double s = 0;
 #pragma unroll
     for (int i = 0; i < BLOCK / 64; ++i) s += sm[threadIdx.x][i];
-    partials[(long long)(slot0 + threadIdx.x) * NB + blockIdx.x] = s;
+    double* row = partials + (long long)(slot0 + threadIdx.x) * NB;
+    row[blockIdx.x] = s;
+    // the consumers add all NB entries of a slot: clear the ones no workgroup of this launch owns, so kernels with
+    // different grids may write the same slot at different times
+    for (int j = blockIdx.x + gridDim.x; j < NB; j += gridDim.x) row[j] = 0.0;
   }
 }
 
@@ -147,6 +151,7 @@ __device__ __forceinline__ void block_max_store(T vmax, T* __restrict__ maxpart)
     T m = smax[0];
     for (int i = 1; i < BLOCK / 64; ++i) m = smax[i] > m ? smax[i] : m;
     maxpart[blockIdx.x] = m;
+    for (int j = blockIdx.x + gridDim.x; j < NB; j += gridDim.x) maxpart[j] = T(0);
   }
 }
 
@@ -166,6 +171,7 @@ __device__ __forceinline__ void block_min_store(T vmin, T* __restrict__ minpart)
     T m = smin[0];
     for (int i = 1; i < BLOCK / 64; ++i) m = smin[i] < m ? smin[i] : m;
     minpart[blockIdx.x] = m;
+    for (int j = blockIdx.x + gridDim.x; j < NB; j += gridDim.x) minpart[j] = T(0);      // 0 = no entry (ignored by the reader)
   }
 }
 
