@@ -476,7 +476,7 @@ class Engine : public EngineBase {
     if (cg_host_->flag == -9) SIPX_HIP(hipMemsetAsync(x_, 0, Nx_ * sizeof(T), stream_));   // cg.jl:51
     // CG iterations run one ahead of the host: iteration k+1 is enqueued before the outcome of k is known.
     // Every kernel returns at once when the device-side `done` flag is set, so a speculative iteration
-    // past convergence costs five empty launches and the GPU never idles on a host round trip.
+    // past convergence costs three empty launches and the GPU never idles on a host round trip.
     // The state is mirrored into two pinned slots by iteration parity (no torn reads).
     auto enqueue = [&](int k) {
       CgState<T>* mirror = cg_host_ + (k & 1);
@@ -484,10 +484,8 @@ class Engine : public EngineBase {
       if (stencil_q_) K<T>::sq_spmv_dot(stream_, G_, sq_, p_, Ap_, part_cg_, cg_dev_);
       else K<T>::spmv_dot(stream_, Nx_, Q_, cds_, p_, Ap_, part_cg_, cg_dev_);
       if (stats_on_) stat_mark();
-      K<T>::cg_fin_alpha(stream_, part_cg_, cg_dev_, mirror, k);
-      K<T>::cg_update_xr(stream_, Nx_, x_, r_, p_, Ap_, part_cg_, cg_dev_);
-      K<T>::cg_fin_beta(stream_, part_cg_, cg_dev_, mirror);
-      K<T>::cg_update_p(stream_, Nx_, p_, r_, cg_dev_);
+      K<T>::cg_update_xr(stream_, Nx_, x_, r_, p_, Ap_, part_cg_, cg_dev_, mirror, k);
+      K<T>::cg_update_p(stream_, Nx_, p_, r_, part_cg_, cg_dev_, mirror);
       SIPX_HIP(hipEventRecord(cg_ev_[k & 1], stream_));
     };
     CgState<T> fin = cg_host_[0];

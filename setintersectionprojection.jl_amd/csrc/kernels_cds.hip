@@ -472,37 +472,33 @@ void K<T>::cg_begin(hipStream_t s, double* partials, CgState<T>* st, CgState<T>*
   SIPX_HIP(hipGetLastError());
 }
 
-template <typename T>
-__global__ __launch_bounds__(BLOCK) void k_cg_fin_alpha(const double* __restrict__ partials, CgState<T>* st,
-                                                        CgState<T>* host, int iter) {
+// The scalar steps of an iteration are folded into the vector kernels that consume them: every workgroup sums the
+// block partials of the dot product itself (same fixed order, so all of them and the former one-workgroup kernel
+// get the same bits), and workgroup 0 records the state.  Two launches and two dependent round trips fewer per iteration.
+//
+// alpha = dot(r,z) / dot(p,Ap) ; x += alpha p ; r -= alpha Ap ; partial ||r||^2 (slot 1)   (cg.jl:83-100)
+template <typename T, int V>
+__global__ __launch_bounds__(BLOCK) void k_cg_update_xr(long long N, T* __restrict__ x, T* __restrict__ r,
+                                                        const T* __restrict__ p, const T* __restrict__ Ap,
+                                                        double* __restrict__ partials, CgState<T>* __restrict__ st,
+                                                        CgState<T>* __restrict__ host, int iter) {
   if (st->done) return;
   const double pAp = block_sum_partials(partials);
-  if (threadIdx.x == 0) {
+  const T gamma = st->rr;                   // dot(r,z), cg.jl:86 (not written by this kernel)
+  const T alpha = gamma / (T)pAp;           // cg.jl:88
+  const bool bad = (isinf(alpha) && alpha > T(0)) || alpha < T(0);   // alpha==Inf || alpha<0, cg.jl:91-93
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
     st->iters = iter;                       // lastIter, cg.jl:83
-    st->gamma = st->rr;                     // dot(r,z), cg.jl:86
-    const T alpha = st->gamma / (T)pAp;     // cg.jl:88
+    st->gamma = gamma;
     st->alpha = alpha;
-    if ((isinf(alpha) && alpha > T(0)) || alpha < T(0)) {  // alpha==Inf || alpha<0, cg.jl:91-93
+    if (bad) {
       st->flag = -2;
       st->done = 1;
       st->res_last = T(0);
       *host = *st;
     }
   }
-}
-template <typename T>
-void K<T>::cg_fin_alpha(hipStream_t s, double* partials, CgState<T>* st, CgState<T>* host, int iter) {
-  hipLaunchKernelGGL((k_cg_fin_alpha<T>), dim3(1), dim3(BLOCK), 0, s, partials, st, host, iter);
-  SIPX_HIP(hipGetLastError());
-}
-
-// x += alpha p ; r -= alpha Ap ; partial ||r||^2   (cg.jl:95-100)
-template <typename T, int V>
-__global__ __launch_bounds__(BLOCK) void k_cg_update_xr(long long N, T* __restrict__ x, T* __restrict__ r,
-                                                        const T* __restrict__ p, const T* __restrict__ Ap,
-                                                        double* __restrict__ partials, const CgState<T>* __restrict__ st) {
-  if (st->done) return;
-  const T alpha = st->alpha;
+  if (bad) return;
   const long long nvec = N / V;
   double acc[1] = {0};
   for (long long vi = (long long)blockIdx.x * BLOCK + threadIdx.x; vi < nvec; vi += (long long)gridDim.x * BLOCK) {
@@ -517,50 +513,44 @@ __global__ __launch_bounds__(BLOCK) void k_cg_update_xr(long long N, T* __restri
     stv<T, V>(x + vi * V, xv);
     stv<T, V>(r + vi * V, rv);
   }
-  block_reduce_store<1>(acc, partials, 0);
+  block_reduce_store<1>(acc, partials, 1);    // its own slot: other workgroups may still be reading slot 0
 }
 template <typename T>
 void K<T>::cg_update_xr(hipStream_t s, long long N, T* x, T* r, const T* p, const T* Ap, double* partials,
-                        const CgState<T>* st) {
+                        CgState<T>* st, CgState<T>* host, int iter) {
   if (N % 4 == 0)
-    hipLaunchKernelGGL((k_cg_update_xr<T, 4>), dim3(SIPX_CG_GRID), dim3(BLOCK), 0, s, N, x, r, p, Ap, partials, st);
+    hipLaunchKernelGGL((k_cg_update_xr<T, 4>), dim3(SIPX_CG_GRID), dim3(BLOCK), 0, s, N, x, r, p, Ap, partials, st, host, iter);
   else
-    hipLaunchKernelGGL((k_cg_update_xr<T, 1>), dim3(SIPX_CG_GRID), dim3(BLOCK), 0, s, N, x, r, p, Ap, partials, st);
+    hipLaunchKernelGGL((k_cg_update_xr<T, 1>), dim3(SIPX_CG_GRID), dim3(BLOCK), 0, s, N, x, r, p, Ap, partials, st, host, iter);
   SIPX_HIP(hipGetLastError());
 }
 
-template <typename T>
-__global__ __launch_bounds__(BLOCK) void k_cg_fin_beta(const double* __restrict__ partials, CgState<T>* st,
-                                                       CgState<T>* host) {
+// resvec[iter] = ||r|| / nr0, stop test, beta = dot(z,r) / gamma ; p = r + beta p   (cg.jl:100-114)
+template <typename T, int V>
+__global__ __launch_bounds__(BLOCK) void k_cg_update_p(long long N, T* __restrict__ p, const T* __restrict__ r,
+                                                       const double* __restrict__ partials, CgState<T>* __restrict__ st,
+                                                       CgState<T>* __restrict__ host) {
+  // `done` may be raised by workgroup 0 of this very launch: a workgroup that starts late and sees it returns, which is
+  // what it would have decided from the partials anyway
   if (st->done) return;
-  const double ss = block_sum_partials(partials);
-  if (threadIdx.x == 0) {
-    const T rr = (T)ss;
-    const T res = (T)sqrt(ss) / st->nr0;    // resvec[iter] = norm(r)/nr0, cg.jl:100
+  const double ss = block_sum_partials(partials + NB);
+  const T rr = (T)ss;
+  const T res = (T)sqrt(ss) / st->nr0;      // cg.jl:100
+  const bool conv = res <= st->tol;         // cg.jl:104-106
+  const T beta = rr / st->gamma;            // cg.jl:110 (gamma: written by the previous kernel)
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
     st->ss = ss;
     st->res_last = res;
-    if (res <= st->tol) {                   // cg.jl:104-106
+    if (conv) {
       st->flag = 0;
       st->done = 1;
     } else {
-      st->beta = rr / st->gamma;            // dot(z,r)/gamma, cg.jl:110
+      st->beta = beta;
     }
     st->rr = rr;
     *host = *st;
   }
-}
-template <typename T>
-void K<T>::cg_fin_beta(hipStream_t s, double* partials, CgState<T>* st, CgState<T>* host) {
-  hipLaunchKernelGGL((k_cg_fin_beta<T>), dim3(1), dim3(BLOCK), 0, s, partials, st, host);
-  SIPX_HIP(hipGetLastError());
-}
-
-// p = r + beta p   (axpby!, cg.jl:114)
-template <typename T, int V>
-__global__ __launch_bounds__(BLOCK) void k_cg_update_p(long long N, T* __restrict__ p, const T* __restrict__ r,
-                                                       const CgState<T>* __restrict__ st) {
-  if (st->done) return;
-  const T beta = st->beta;
+  if (conv) return;
   const long long nvec = N / V;
   for (long long vi = (long long)blockIdx.x * BLOCK + threadIdx.x; vi < nvec; vi += (long long)gridDim.x * BLOCK) {
     Vec<T, V> pv = ldv<T, V>(p + vi * V);
@@ -571,11 +561,12 @@ __global__ __launch_bounds__(BLOCK) void k_cg_update_p(long long N, T* __restric
   }
 }
 template <typename T>
-void K<T>::cg_update_p(hipStream_t s, long long N, T* p, const T* r, const CgState<T>* st) {
+void K<T>::cg_update_p(hipStream_t s, long long N, T* p, const T* r, const double* partials, CgState<T>* st,
+                       CgState<T>* host) {
   if (N % 4 == 0)
-    hipLaunchKernelGGL((k_cg_update_p<T, 4>), dim3(NB), dim3(BLOCK), 0, s, N, p, r, st);
+    hipLaunchKernelGGL((k_cg_update_p<T, 4>), dim3(NB), dim3(BLOCK), 0, s, N, p, r, partials, st, host);
   else
-    hipLaunchKernelGGL((k_cg_update_p<T, 1>), dim3(NB), dim3(BLOCK), 0, s, N, p, r, st);
+    hipLaunchKernelGGL((k_cg_update_p<T, 1>), dim3(NB), dim3(BLOCK), 0, s, N, p, r, partials, st, host);
   SIPX_HIP(hipGetLastError());
 }
 
@@ -611,10 +602,9 @@ void K<T>::fin_sum(hipStream_t s, const double* partials, int nslots, double* ou
   template void K<T>::q_update(hipStream_t, const Grid&, const CdsArgs&, const QArgs<T>&, T*);                        \
   template void K<T>::gen_ata(hipStream_t, const Grid&, int, const int*, const T*, int, const long long*, T*);       \
   template void K<T>::cg_begin(hipStream_t, double*, CgState<T>*, CgState<T>*, int, T*, long long);                  \
-  template void K<T>::cg_fin_alpha(hipStream_t, double*, CgState<T>*, CgState<T>*, int);                             \
-  template void K<T>::cg_update_xr(hipStream_t, long long, T*, T*, const T*, const T*, double*, const CgState<T>*);  \
-  template void K<T>::cg_fin_beta(hipStream_t, double*, CgState<T>*, CgState<T>*);                                   \
-  template void K<T>::cg_update_p(hipStream_t, long long, T*, const T*, const CgState<T>*);                          \
+  template void K<T>::cg_update_xr(hipStream_t, long long, T*, T*, const T*, const T*, double*, CgState<T>*,         \
+                                   CgState<T>*, int);                                                                \
+  template void K<T>::cg_update_p(hipStream_t, long long, T*, const T*, const double*, CgState<T>*, CgState<T>*);    \
   template void K<T>::fin_sum(hipStream_t, const double*, int, double*, double*);
 SIPX_INST(float)
 SIPX_INST(double)

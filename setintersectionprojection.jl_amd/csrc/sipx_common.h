@@ -195,11 +195,10 @@ struct K {
                       const long long* offs, T* R);
   // CG
   static void cg_begin(hipStream_t s, double* partials, CgState<T>* st, CgState<T>* host, int it_outer, T* x, long long N);
-  static void cg_fin_alpha(hipStream_t s, double* partials, CgState<T>* st, CgState<T>* host, int iter);
   static void cg_update_xr(hipStream_t s, long long N, T* x, T* r, const T* p, const T* Ap, double* partials,
-                           const CgState<T>* st);
-  static void cg_fin_beta(hipStream_t s, double* partials, CgState<T>* st, CgState<T>* host);
-  static void cg_update_p(hipStream_t s, long long N, T* p, const T* r, const CgState<T>* st);
+                           CgState<T>* st, CgState<T>* host, int iter);
+  static void cg_update_p(hipStream_t s, long long N, T* p, const T* r, const double* partials, CgState<T>* st,
+                          CgState<T>* host);
   // sets
   static void rhs_compose(hipStream_t s, const Grid& g, const RhsArgs<T>& a, T* rhs, int accumulate);
   static void yl(hipStream_t s, const Grid& g, const SetArgs<T>& a, double* partials);
