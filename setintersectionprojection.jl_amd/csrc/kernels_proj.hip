@@ -234,48 +234,60 @@ void K<T>::ps_init(hipStream_t s, ProjScalars<T>* ps, long long* cidx) {
   SIPX_HIP(hipGetLastError());
 }
 
-// Sums of all PREP_SLOTS partial slots by one 1024-thread workgroup: every thread issues its
-// PREP_SLOTS*NB/1024 independent loads up front (two per slot), then the slots are reduced wave -> LDS.
+// Sums of all PREP_SLOTS partial slots by one workgroup of NT threads.  The loads of CH slots are issued together
+// (four at NT = 256), then the slots are reduced wave -> LDS.  The decision kernels run beside the streaming passes of the
+// other set stream: a 256-thread workgroup finds a free slot on a busy CU much sooner than a 1024-thread one (+1.8 % at
+// 256^3), which outweighs its slower reduction.
+#ifndef SIPX_DECIDE_NT
+#define SIPX_DECIDE_NT 256
+#endif
+template <int NT>
 __device__ __forceinline__ void reduce_slots(const double* __restrict__ partials, double* red /*LDS, PREP_SLOTS*/) {
-  static_assert(NB % 1024 == 0, "NB must be a multiple of the reducing workgroup");
-  constexpr int PER = NB / 1024;
-  __shared__ double sm[PREP_SLOTS][16];
-  double v[PREP_SLOTS];
-#pragma unroll
-  for (int k = 0; k < PREP_SLOTS; ++k) {
-    double a = 0;
-#pragma unroll
-    for (int j = 0; j < PER; ++j) a += partials[(long long)k * NB + j * 1024 + threadIdx.x];
-    v[k] = a;
-  }
+  static_assert(NB % NT == 0, "NB must be a multiple of the reducing workgroup");
+  constexpr int PER = NB / NT, NW = NT / 64, CH = NT >= 1024 ? PREP_SLOTS : (NT >= 512 ? 8 : 4);
+  __shared__ double sm[PREP_SLOTS][NW];
   const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+#pragma unroll 1
+  for (int k0 = 0; k0 < PREP_SLOTS; k0 += CH) {
+    double v[CH];
 #pragma unroll
-  for (int k = 0; k < PREP_SLOTS; ++k) {
-    const double r = wave_sum(v[k]);
-    if (lane == 0) sm[k][w] = r;
+    for (int c = 0; c < CH; ++c) {
+      double a = 0;
+      if (k0 + c < PREP_SLOTS) {
+#pragma unroll
+        for (int j = 0; j < PER; ++j) a += partials[(long long)(k0 + c) * NB + j * NT + threadIdx.x];
+      }
+      v[c] = a;
+    }
+#pragma unroll
+    for (int c = 0; c < CH; ++c) {
+      const double r = wave_sum(v[c]);
+      if (lane == 0 && k0 + c < PREP_SLOTS) sm[k0 + c][w] = r;
+    }
   }
   __syncthreads();
   if (threadIdx.x < PREP_SLOTS) {
     double r = 0;
 #pragma unroll
-    for (int i = 0; i < 16; ++i) r += sm[threadIdx.x][i];
+    for (int i = 0; i < NW; ++i) r += sm[threadIdx.x][i];
     red[threadIdx.x] = r;
   }
 }
 
 // Scalar decisions after a probe pass.  STAGE 0: after the first pass; STAGE 1: after the gated refinement.
 template <typename T, int STAGE>
-__global__ __launch_bounds__(1024) void k_decide(const double* __restrict__ partials, const T* __restrict__ maxpart,
+__global__ __launch_bounds__(SIPX_DECIDE_NT) void k_decide(const double* __restrict__ partials, const T* __restrict__ maxpart,
                                                  ProjScalars<T>* ps, int prox, T pmin, T pmax, long long true_len,
                                                  int nospec, double capdiv) {
   if (STAGE == 1 && !(ps->need && !ps->spec_ok && ps->refine)) return;
+  constexpr int NT = SIPX_DECIDE_NT;
   __shared__ double red[PREP_SLOTS];
-  __shared__ T smax[16];
-  reduce_slots(partials, red);
-  __shared__ T smin[16];
+  __shared__ T smax[NT / 64];
+  reduce_slots<NT>(partials, red);
+  __shared__ T smin[NT / 64];
   T vmax = T(0), vmin = (T)INFINITY;
   if (STAGE == 0) {
-    for (int i = threadIdx.x; i < NB; i += 1024) {
+    for (int i = threadIdx.x; i < NB; i += NT) {
       vmax = maxpart[i] > vmax ? maxpart[i] : vmax;
       const T mn = maxpart[NB + i];                 // 0 = slot of a workgroup that was not launched (grid of NB_7)
       vmin = (mn > T(0) && mn < vmin) ? mn : vmin;
@@ -287,7 +299,7 @@ __global__ __launch_bounds__(1024) void k_decide(const double* __restrict__ part
   __syncthreads();
   if (threadIdx.x != 0) return;
   if (STAGE == 0) {
-    for (int i = 0; i < 16; ++i) { vmax = smax[i] > vmax ? smax[i] : vmax; vmin = smin[i] < vmin ? smin[i] : vmin; }
+    for (int i = 0; i < NT / 64; ++i) { vmax = smax[i] > vmax ? smax[i] : vmax; vmin = smin[i] < vmin ? smin[i] : vmin; }
     ps->vmin = vmin;
     ps->asum = red[0];
     ps->sumsq = red[1];
@@ -384,11 +396,15 @@ __global__ __launch_bounds__(1024) void k_decide(const double* __restrict__ part
 // Michelot's iteration on the gathered magnitudes: theta <- (S_above + S_in(>theta) - b) / (C_above + C_in(>theta)),
 // monotone from the bracket's lower end, exact after finitely many steps (stops when the active count repeats).
 // Then prepares the next call: probes and speculative range centred on the new theta.
+#ifndef SIPX_SOLVE_NT
+#define SIPX_SOLVE_NT 1024
+#endif
 template <typename T>
-__global__ __launch_bounds__(1024) void k_l1_solve(ProjScalars<T>* ps, T radius, const T* __restrict__ compact,
+__global__ __launch_bounds__(SIPX_SOLVE_NT) void k_l1_solve(ProjScalars<T>* ps, T radius, const T* __restrict__ compact,
                                                    const double* __restrict__ partials, long long true_len) {
-  __shared__ double ssum[16];
-  __shared__ double scnt[16];
+  constexpr int NT = SIPX_SOLVE_NT;
+  __shared__ double ssum[NT / 64];
+  __shared__ double scnt[NT / 64];
   __shared__ double sh_theta, sh_sa, sh_ca;
   __shared__ int sh_done;
   const int need = ps->need;
@@ -399,7 +415,7 @@ __global__ __launch_bounds__(1024) void k_l1_solve(ProjScalars<T>* ps, T radius,
       if (threadIdx.x == 0) { sh_sa = ps->s_above; sh_ca = ps->c_above; }
     } else {   // (S,C) above the bracket: block partials of the fallback compaction pass
       double s = 0, c = 0;
-      for (int i = threadIdx.x; i < NB; i += 1024) {
+      for (int i = threadIdx.x; i < NB; i += NT) {
         s += partials[(long long)SL_ABOVE_S * NB + i];
         c += partials[(long long)SL_ABOVE_C * NB + i];
       }
@@ -409,7 +425,7 @@ __global__ __launch_bounds__(1024) void k_l1_solve(ProjScalars<T>* ps, T radius,
       __syncthreads();
       if (threadIdx.x == 0) {
         double S = 0, Cc = 0;
-        for (int i = 0; i < 16; ++i) { S += ssum[i]; Cc += scnt[i]; }
+        for (int i = 0; i < NT / 64; ++i) { S += ssum[i]; Cc += scnt[i]; }
         sh_sa = S; sh_ca = Cc;
       }
     }
@@ -422,11 +438,11 @@ __global__ __launch_bounds__(1024) void k_l1_solve(ProjScalars<T>* ps, T radius,
       double s = 0, c = 0;
       {   // one workgroup streams the gathered values: 16-byte loads, four in flight per thread
         const long long nv = n / 4;
-        for (long long i0 = threadIdx.x; i0 < nv; i0 += 4 * 1024) {
+        for (long long i0 = threadIdx.x; i0 < nv; i0 += 4 * NT) {
           Vec<T, 4> q[4];
 #pragma unroll
           for (int u = 0; u < 4; ++u) {
-            const long long i = i0 + (long long)u * 1024;
+            const long long i = i0 + (long long)u * NT;
             if (i < nv) q[u] = ldv_u<T, 4>(compact + 4 * i);
             else { q[u].v[0] = q[u].v[1] = q[u].v[2] = q[u].v[3] = T(0); }     // magnitudes are >= 0 = not above theta >= 0
           }
@@ -438,7 +454,7 @@ __global__ __launch_bounds__(1024) void k_l1_solve(ProjScalars<T>* ps, T radius,
               if (av > theta) { s += av; c += 1.0; }
             }
         }
-        for (long long e = 4 * nv + threadIdx.x; e < n; e += 1024) {
+        for (long long e = 4 * nv + threadIdx.x; e < n; e += NT) {
           const double av = (double)compact[e];
           if (av > theta) { s += av; c += 1.0; }
         }
@@ -450,7 +466,7 @@ __global__ __launch_bounds__(1024) void k_l1_solve(ProjScalars<T>* ps, T radius,
       __syncthreads();
       if (threadIdx.x == 0) {
         double S = 0, Cc = 0;
-        for (int i = 0; i < 16; ++i) { S += ssum[i]; Cc += scnt[i]; }
+        for (int i = 0; i < NT / 64; ++i) { S += ssum[i]; Cc += scnt[i]; }
         const double tot = ca + Cc;
         double tn = theta;
         if (tot > 0) tn = (sa + S - b) / tot;
@@ -514,7 +530,7 @@ __global__ __launch_bounds__(1024) void k_card_decide(const double* __restrict__
   if (STAGE == 1 && !(ps->need && ps->refine)) return;
   __shared__ double red[PREP_SLOTS];
   __shared__ T smax[16];
-  reduce_slots(partials, red);
+  reduce_slots<1024>(partials, red);
   T vmax = T(0);
   if (STAGE == 0) {
     for (int i = threadIdx.x; i < NB; i += 1024) vmax = maxpart[i] > vmax ? maxpart[i] : vmax;
@@ -665,15 +681,15 @@ static void launch_chain(hipStream_t s, const Grid& g, const SetArgs<T>& a, int 
     return;
   }
   SIPX_PASS(M_FIRST);
-  hipLaunchKernelGGL((k_decide<T, 0>), dim3(1), dim3(1024), 0, s, partials, maxpart, ps, a.prox, a.plo, a.phi, true_len,
+  hipLaunchKernelGGL((k_decide<T, 0>), dim3(1), dim3(SIPX_DECIDE_NT), 0, s, partials, maxpart, ps, a.prox, a.plo, a.phi, true_len,
                      (a.flags & F_NOSPEC) ? 1 : 0, capdiv);
   if (a.prox == PX_L1) {
     for (int r = 0; r < L1_REFINES; ++r) {
       SIPX_PASS(M_PROBE);
-      hipLaunchKernelGGL((k_decide<T, 1>), dim3(1), dim3(1024), 0, s, partials, maxpart, ps, a.prox, a.plo, a.phi, true_len, 0, capdiv);
+      hipLaunchKernelGGL((k_decide<T, 1>), dim3(1), dim3(SIPX_DECIDE_NT), 0, s, partials, maxpart, ps, a.prox, a.plo, a.phi, true_len, 0, capdiv);
     }
     SIPX_PASS(M_COMPACT);
-    hipLaunchKernelGGL((k_l1_solve<T>), dim3(1), dim3(1024), 0, s, ps, a.phi, compact, partials, true_len);
+    hipLaunchKernelGGL((k_l1_solve<T>), dim3(1), dim3(SIPX_SOLVE_NT), 0, s, ps, a.phi, compact, partials, true_len);
   }
 #undef SIPX_PASS
   SIPX_HIP(hipGetLastError());
