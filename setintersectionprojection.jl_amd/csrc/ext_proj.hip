@@ -16,6 +16,9 @@
 #include <rocsolver/rocsolver.h>
 
 #include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
 #include <stdexcept>
 #include <string>
 #include <vector>
@@ -359,6 +362,98 @@ void ext_dist2(hipStream_t s, long long N, const T* projected, const T* original
   SIPX_HIP(hipGetLastError());
 }
 
+// ---- block subspace iteration on the Gram matrices (rank projection, see ExtProj::project) ----
+// Columns of Y (k x b per matrix) scaled to unit length; a column that vanished against the largest one (rank of the
+// matrix below b) is replaced by fixed pseudo-random numbers so that the Cholesky factor of Y'Y exists.
+__global__ __launch_bounds__(BLOCK) void k_sub_normalize(int k, int b, int batch, double* __restrict__ Y) {
+  __shared__ double sm[BLOCK / 64];
+  __shared__ double s_norm[64];      // b <= 64 is enforced by the caller
+  const int l = blockIdx.x;
+  double* Yl = Y + (long long)l * k * b;
+  for (int j = 0; j < b; ++j) {
+    double a = 0;
+    for (int i = threadIdx.x; i < k; i += BLOCK) a += Yl[(long long)j * k + i] * Yl[(long long)j * k + i];
+    a = wave_sum(a);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = a;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      double t = 0;
+      for (int w = 0; w < BLOCK / 64; ++w) t += sm[w];
+      s_norm[j] = sqrt(t);
+    }
+  }
+  __syncthreads();
+  double mx = 0;
+  for (int j = 0; j < b; ++j) mx = s_norm[j] > mx ? s_norm[j] : mx;
+  for (int j = 0; j < b; ++j) {
+    const double nj = s_norm[j];
+    if (nj > 1e-13 * mx && nj > 0) {
+      const double inv = 1.0 / nj;
+      for (int i = threadIdx.x; i < k; i += BLOCK) Yl[(long long)j * k + i] *= inv;
+    } else {
+      for (int i = threadIdx.x; i < k; i += BLOCK) {
+        unsigned h = (unsigned)(i * 2654435761u) ^ (unsigned)((j + 1) * 40503u) ^ (unsigned)(l * 69069u);
+        h ^= h >> 15; h *= 2246822519u; h ^= h >> 13;
+        Yl[(long long)j * k + i] = ((double)(h >> 8) / 16777216.0 - 0.5) / sqrt((double)k / 12.0);
+      }
+    }
+  }
+}
+// Largest residual of the top-r Ritz pairs, relative to the largest Ritz value: max_j ||(G Q) z_j - theta_j x_j|| / theta_max,
+// with ZH = (G Q) Z and X = Q Z given (k x b per matrix, Ritz values ascending).  res[0] collects the maximum over the
+// batch (bit pattern of a non-negative double), res[1] is raised when a factorisation failed or a value is not finite.
+__global__ __launch_bounds__(BLOCK) void k_sub_residual(int k, int b, int r, int batch, const double* __restrict__ ZH,
+                                                        const double* __restrict__ X, const double* __restrict__ W, int ldw,
+                                                        const rocblas_int* __restrict__ info_chol,
+                                                        const rocblas_int* __restrict__ info_eig, unsigned long long* res) {
+  __shared__ double sm[BLOCK / 64];
+  const int l = blockIdx.x;
+  const double tmax = W[(long long)l * ldw + b - 1];
+  double worst = 0;
+  for (int j = b - r; j < b; ++j) {
+    const double th = W[(long long)l * ldw + j];
+    const double* z = ZH + ((long long)l * b + j) * k;
+    const double* x = X + ((long long)l * b + j) * k;
+    double a = 0;
+    for (int i = threadIdx.x; i < k; i += BLOCK) {
+      const double d = z[i] - th * x[i];
+      a += d * d;
+    }
+    a = wave_sum(a);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = a;
+    __syncthreads();
+    double t = 0;
+    for (int w = 0; w < BLOCK / 64; ++w) t += sm[w];
+    const double rel = sqrt(t) / tmax;
+    worst = rel > worst ? rel : worst;
+  }
+  if (threadIdx.x == 0) {
+    const bool bad = info_chol[l] != 0 || info_eig[l] != 0 || !(tmax > 0) || !(worst == worst) || isinf(worst);
+    if (bad) atomicMax(res + 1, 1ull);
+    else atomicMax(res, (unsigned long long)__double_as_longlong(worst));
+  }
+}
+// After a full decomposition (eigenvalues ascending, k per matrix): the contraction factor subspace iteration on b vectors
+// would see for the top-r space, theta_{b+1} / theta_r, maximum over the batch -> res[0] (bit pattern).
+__global__ void k_sub_ratio(int k, int b, int r, int batch, const double* __restrict__ W, unsigned long long* res) {
+  const int l = blockIdx.x * blockDim.x + threadIdx.x;
+  if (l >= batch) return;
+  const double tr = W[(long long)l * k + k - r], tb = W[(long long)l * k + k - b - 1];
+  double q = (tr > 0 && tb >= 0) ? tb / tr : 1.0;
+  if (!(q == q) || q > 1.0) q = 1.0;
+  atomicMax(res, (unsigned long long)__double_as_longlong(q));
+}
+// The last b eigenvector columns of the full decomposition (k x k per matrix) become the next warm start.
+__global__ __launch_bounds__(BLOCK) void k_sub_keep(int k, int b, int batch, const double* __restrict__ E, double* __restrict__ X) {
+  const long long per = (long long)k * b, total = per * batch;
+  for (long long e = (long long)blockIdx.x * BLOCK + threadIdx.x; e < total; e += (long long)gridDim.x * BLOCK) {
+    const long long l = e / per, o = e - l * per;
+    X[e] = E[l * (long long)k * k + (long long)(k - b) * k + o];
+  }
+}
+
 // ------------------------------------------------------------------------------------------------
 template <typename T>
 struct ExtImpl {
@@ -379,6 +474,13 @@ struct ExtImpl {
   double *Ad = nullptr, *Ud = nullptr, *Sd = nullptr, *Vd = nullptr, *Ed = nullptr;
   double *Gd = nullptr, *Gs = nullptr, *Wd = nullptr;     // Gram route: eigenvectors, scaled copy, eigenvalues
   bool gram = false;
+  // rank, Gram route: warm-started block subspace iteration (top-r invariant subspace of the Gram matrices)
+  int sub_b = 0;                                   // block size r + 16 (0 = route not used)
+  double *Xs[2] = {nullptr, nullptr};              // Ritz vectors of the previous call (y update / feasibility estimate)
+  bool sub_have[2] = {false, false}, sub_try[2] = {false, false};
+  double *Qs = nullptr, *Zs = nullptr, *Hs = nullptr, *Ws = nullptr, *Es = nullptr;
+  unsigned long long* sub_res = nullptr;           // device: bit pattern of the largest relative residual, failure flag
+  unsigned long long* sub_res_host = nullptr;      // pinned
   // DCT: orthonormal DCT-II matrices per dimension, two work arrays, inner projector state
   T* Cm[3] = {nullptr, nullptr, nullptr};
   T *W1 = nullptr, *W2 = nullptr, *dlb = nullptr, *dub = nullptr;
@@ -514,8 +616,22 @@ ExtProj<T>::ExtProj(const ExtSpec& spec, hipStream_t stream) {
       I.Gd = I.template alloc<double>((size_t)k * k * I.batch);
       I.Wd = I.template alloc<double>((size_t)k * I.batch);
       if (kind == EXT_NUCLEAR) I.Gs = I.template alloc<double>((size_t)k * k * I.batch);
+      const char* sub_e = getenv("SIPX_RANK_SUBSPACE");      // read per projector: 0 keeps the full decomposition every call
+      const int sub_env = sub_e ? atoi(sub_e) : 1;
+      if (kind == EXT_RANK && sub_env && (I.r + 16) * 4 <= k && I.r + 16 <= 64) {      // worth it only for r << k
+        I.sub_b = I.r + 16;
+        const size_t nb = (size_t)k * I.sub_b * I.batch;
+        for (int w = 0; w < 2; ++w) I.Xs[w] = I.template alloc<double>(nb);
+        I.Qs = I.template alloc<double>(nb);
+        I.Zs = I.template alloc<double>(nb);
+        I.Hs = I.template alloc<double>((size_t)I.sub_b * I.sub_b * I.batch);
+        I.Ws = I.template alloc<double>((size_t)I.sub_b * I.batch);
+        I.Es = I.template alloc<double>((size_t)I.sub_b * I.batch);
+        I.sub_res = I.template alloc<unsigned long long>(2);
+        SIPX_HIP(hipHostMalloc((void**)&I.sub_res_host, 2 * sizeof(unsigned long long), hipHostMallocDefault));
+      }
     }
-    I.info = I.template alloc<rocblas_int>((size_t)2 * I.batch);   // info + n_sweeps
+    I.info = I.template alloc<rocblas_int>((size_t)3 * I.batch);   // info, n_sweeps / second info, sweeps of the Ritz solver
     I.flag = I.template alloc<int>((size_t)I.batch);
   } else if (kind == EXT_DCT) {
     // Orthonormal DCT-II along every dimension as dense n_d x n_d matrices (built in float64, rounded to TF once):
@@ -610,6 +726,7 @@ ExtProj<T>::~ExtProj() {
   ExtImpl<T>& I = *impl_;
   if (I.have_plan) (void)hipfftDestroy(I.plan);
   if (I.blas) (void)rocblas_destroy_handle(I.blas);
+  if (I.sub_res_host) (void)hipHostFree(I.sub_res_host);
   for (void* p : I.owned)
     if (p) (void)hipFree(p);
   delete impl_;
@@ -688,12 +805,89 @@ void ExtProj<T>::project(T* v, bool feas, double* partials, T* maxpart, T* compa
         blas_check(rocblas_dgemm_strided_batched(I.blas, T_, N_, k, k, I.m, &one, I.Ad, I.m, sA, I.Ad, I.m, sA, &zero, I.Gd, k, sG, I.batch), "gram");
       else
         blas_check(rocblas_dgemm_strided_batched(I.blas, N_, T_, k, k, I.n, &one, I.Ad, I.m, sA, I.Ad, I.m, sA, &zero, I.Gd, k, sG, I.batch), "gram");
-      blas_check(rocsolver_dsyevd_strided_batched(I.blas, rocblas_evect_original, rocblas_fill_upper, k, I.Gd, k, sG, I.Wd, k, I.Ed, k,
-                                                  I.info, I.batch),
-                 "syevd");
+      // Rank projection: only the span of the top-r eigenvectors is needed, and it moves little from one PARSDMM
+      // iteration to the next.  Block subspace iteration with Rayleigh-Ritz on b = r + 16 vectors, started from the
+      // previous call's Ritz vectors, is accepted when every top-r pair has a residual below 1e-12 theta_max (far inside
+      // Float32 resolution of the projected slice); otherwise -- first call, slow contraction, a failed factorisation --
+      // the full decomposition below runs as before and provides the next warm start.
+      const int w = feas ? 1 : 0;
+      bool sub_ok = false;
+      const int b = I.sub_b;
+      const long long sX = (long long)k * b, sH = (long long)b * b;
+      if (b > 0 && I.sub_have[w] && I.sub_try[w]) {
+        const char* dbg_e = getenv("SIPX_EXT_DEBUG");
+        const int dbg = dbg_e ? atoi(dbg_e) : 0;
+        const int max_it = 8;
+        const double tol = 1e-12;
+        double prev = -1;
+        double* X = I.Xs[w];
+        for (int it = 0; it < max_it; ++it) {
+          blas_check(rocblas_dgemm_strided_batched(I.blas, N_, N_, k, b, k, &one, I.Gd, k, sG, X, k, sX, &zero, I.Qs, k, sX, I.batch), "G X");
+          hipLaunchKernelGGL(k_sub_normalize, dim3(I.batch), dim3(BLOCK), 0, s, k, b, I.batch, I.Qs);
+          blas_check(rocblas_dgemm_strided_batched(I.blas, T_, N_, b, b, k, &one, I.Qs, k, sX, I.Qs, k, sX, &zero, I.Hs, b, sH, I.batch), "Y'Y");
+          blas_check(rocsolver_dpotrf_strided_batched(I.blas, rocblas_fill_upper, b, I.Hs, b, sH, I.info, I.batch), "potrf");
+          blas_check(rocblas_dtrsm_strided_batched(I.blas, rocblas_side_right, rocblas_fill_upper, N_, rocblas_diagonal_non_unit, k, b, &one,
+                                                   I.Hs, b, sH, I.Qs, k, sX, I.batch), "trsm");          // Qs: orthonormal basis
+          blas_check(rocblas_dgemm_strided_batched(I.blas, N_, N_, k, b, k, &one, I.Gd, k, sG, I.Qs, k, sX, &zero, I.Zs, k, sX, I.batch), "G Q");
+          blas_check(rocblas_dgemm_strided_batched(I.blas, T_, N_, b, b, k, &one, I.Qs, k, sX, I.Zs, k, sX, &zero, I.Hs, b, sH, I.batch), "Q'GQ");
+          // b x b Ritz problem: one-kernel Jacobi (the divide-and-conquer driver applies its b-1 reflectors one launch at a
+          // time, 50 ms for 256 matrices of 48 x 48)
+          blas_check(rocsolver_dsyevj_strided_batched(I.blas, rocblas_esort_ascending, rocblas_evect_original, rocblas_fill_upper, b, I.Hs,
+                                                      b, sH, 0.0, I.Es, 100, I.info + 2 * I.batch, I.Ws, b, I.info + I.batch, I.batch),
+                     "syevj (Ritz)");
+          blas_check(rocblas_dgemm_strided_batched(I.blas, N_, N_, k, b, b, &one, I.Qs, k, sX, I.Hs, b, sH, &zero, X, k, sX, I.batch), "Q Z");
+          blas_check(rocblas_dgemm_strided_batched(I.blas, N_, N_, k, b, b, &one, I.Zs, k, sX, I.Hs, b, sH, &zero, I.Qs, k, sX, I.batch), "(GQ) Z");
+          SIPX_HIP(hipMemsetAsync(I.sub_res, 0, 2 * sizeof(unsigned long long), s));
+          hipLaunchKernelGGL(k_sub_residual, dim3(I.batch), dim3(BLOCK), 0, s, k, b, I.r, I.batch, I.Qs, X, I.Ws, b, I.info,
+                             I.info + I.batch, I.sub_res);
+          SIPX_HIP(hipMemcpyAsync(I.sub_res_host, I.sub_res, 2 * sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
+          SIPX_HIP(hipStreamSynchronize(s));
+          double res;
+          std::memcpy(&res, &I.sub_res_host[0], sizeof(double));
+          const bool failed = I.sub_res_host[1] != 0;
+          if (dbg) fprintf(stderr, "[sipx rank] subspace it %d: residual %.3e%s\n", it + 1, res, failed ? " (failed)" : "");
+          if (failed) break;
+          if (res <= tol) { sub_ok = true; break; }
+          if (prev > 0) {                       // contraction observed so far: give up when the budget cannot suffice
+            const double c = res / prev;
+            if (!(c < 1.0)) break;
+            const double need = std::log(tol / res) / std::log(c);
+            if (need > (double)(max_it - 1 - it)) break;
+          }
+          prev = res;
+        }
+        if (dbg) fprintf(stderr, "[sipx rank] %s\n", sub_ok ? "subspace accepted" : "full decomposition");
+      }
+      const double* Esel;
+      long long ldsel_stride;
+      if (sub_ok) {
+        Esel = I.Xs[w] + (long long)(b - I.r) * k;       // Ritz values ascend: the last r columns span the top-r space
+        ldsel_stride = sX;
+      } else {
+        blas_check(rocsolver_dsyevd_strided_batched(I.blas, rocblas_evect_original, rocblas_fill_upper, k, I.Gd, k, sG, I.Wd, k, I.Ed, k,
+                                                    I.info, I.batch),
+                   "syevd");
+        Esel = I.Gd + (long long)(k - I.r) * k;           // eigenvalues ascend: the last r columns span the top-r space
+        ldsel_stride = sG;
+        if (b > 0) {
+          // keep the top-b eigenvectors as the next warm start, and decide from the spectrum whether to use them: the
+          // iteration contracts by theta_{b+1} / theta_r per step, so a truncation inside a flat part of the spectrum
+          // (ratio near 1) would never get there and the attempt is not made
+          hipLaunchKernelGGL(k_sub_keep, dim3(NB), dim3(BLOCK), 0, s, k, b, I.batch, I.Gd, I.Xs[w]);
+          SIPX_HIP(hipMemsetAsync(I.sub_res, 0, 2 * sizeof(unsigned long long), s));
+          hipLaunchKernelGGL(k_sub_ratio, dim3((I.batch + 63) / 64), dim3(64), 0, s, k, b, I.r, I.batch, I.Wd, I.sub_res);
+          SIPX_HIP(hipMemcpyAsync(I.sub_res_host, I.sub_res, 2 * sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
+          SIPX_HIP(hipStreamSynchronize(s));
+          double q;
+          std::memcpy(&q, &I.sub_res_host[0], sizeof(double));
+          I.sub_have[w] = true;
+          I.sub_try[w] = q < 0.25;
+          const char* dbg_e = getenv("SIPX_EXT_DEBUG");
+          if (dbg_e && atoi(dbg_e)) fprintf(stderr, "[sipx rank] theta_{b+1}/theta_r = %.3e -> %s\n", q, I.sub_try[w] ? "subspace next" : "full next");
+        }
+      }
       const int* flag = nullptr;
       int inner = I.r;
-      const double* Esel = I.Gd + (long long)(k - I.r) * k;     // eigenvalues ascend: the last r columns span the top-r space
       const double* Escl = Esel;
       if (kind == EXT_NUCLEAR) {
         hipLaunchKernelGGL(k_nuc_factors, dim3((I.batch + 63) / 64), dim3(64), 0, s, k, I.batch, I.sp.pmax, I.Wd, I.Sd, I.flag);
@@ -702,13 +896,14 @@ void ExtProj<T>::project(T* v, bool feas, double* partials, T* maxpart, T* compa
         inner = k;
         Esel = I.Gd;
         Escl = I.Gs;
+        ldsel_stride = sG;
       }
       if (right) {       // X <- (X * Escl) * Esel'
-        blas_check(rocblas_dgemm_strided_batched(I.blas, N_, N_, I.m, inner, k, &one, I.Ad, I.m, sA, Escl, k, sG, &zero, I.Ud, I.m, sU, I.batch), "gemm X V");
-        blas_check(rocblas_dgemm_strided_batched(I.blas, N_, T_, I.m, I.n, inner, &one, I.Ud, I.m, sU, Esel, k, sG, &zero, I.Ad, I.m, sA, I.batch), "gemm (XV) V'");
+        blas_check(rocblas_dgemm_strided_batched(I.blas, N_, N_, I.m, inner, k, &one, I.Ad, I.m, sA, Escl, k, ldsel_stride, &zero, I.Ud, I.m, sU, I.batch), "gemm X V");
+        blas_check(rocblas_dgemm_strided_batched(I.blas, N_, T_, I.m, I.n, inner, &one, I.Ud, I.m, sU, Esel, k, ldsel_stride, &zero, I.Ad, I.m, sA, I.batch), "gemm (XV) V'");
       } else {           // X <- Escl * (Esel' * X)
-        blas_check(rocblas_dgemm_strided_batched(I.blas, T_, N_, inner, I.n, k, &one, Esel, k, sG, I.Ad, I.m, sA, &zero, I.Vd, k, sV, I.batch), "gemm U' X");
-        blas_check(rocblas_dgemm_strided_batched(I.blas, N_, N_, I.m, I.n, inner, &one, Escl, k, sG, I.Vd, k, sV, &zero, I.Ad, I.m, sA, I.batch), "gemm U (U'X)");
+        blas_check(rocblas_dgemm_strided_batched(I.blas, T_, N_, inner, I.n, k, &one, Esel, k, ldsel_stride, I.Ad, I.m, sA, &zero, I.Vd, k, sV, I.batch), "gemm U' X");
+        blas_check(rocblas_dgemm_strided_batched(I.blas, N_, N_, I.m, I.n, inner, &one, Escl, k, ldsel_stride, I.Vd, k, sV, &zero, I.Ad, I.m, sA, I.batch), "gemm U (U'X)");
       }
       hipLaunchKernelGGL((k_seg_scatter<T, double>), dim3(NB), dim3(BLOCK), 0, s, I.map, I.Ad, v, flag);
       SIPX_HIP(hipGetLastError());

@@ -1245,3 +1245,44 @@ def test_named_D_xz_operator(sipx, TF):
     assert np.linalg.norm(xs.astype(np.float64) - xo) / np.linalg.norm(xo) < (1e-3 if TF == np.float32 else 1e-5)
     with pytest.raises(sipx.SipxError):
         sipx.get_TD_operator(sipx.compgrid((1.0,) * 3, (4, 4, 4)), "D_xz", TF)
+
+
+def test_rank_projection_subspace_route(sipx, capfd, monkeypatch):
+    """Inside a solve the slice-rank projector (Float32, Gram route) restarts a block subspace iteration from the previous
+    call's Ritz vectors and accepts it when the top-r residuals are below 1e-12 theta_max (ext_proj.hip); the iterates must
+    agree with the full decomposition of every call and with the oracle's LAPACK SVD."""
+    TF = np.float32
+    n, h = (96, 96, 5), (10.0, 10.0, 10.0)
+    rng = np.random.default_rng(77)
+    m3 = np.zeros(n)
+    for k in range(n[2]):                                   # rank-3 slices + a little noise, velocity-like range
+        U, V = rng.standard_normal((n[0], 3)), rng.standard_normal((3, n[1]))
+        m3[:, :, k] = 2500.0 + 300.0 * (U @ V) / 3.0 + 2.0 * rng.standard_normal(n[:2])
+    m = m3.reshape(-1, order="F").astype(TF)
+
+    def solve(mod):
+        g = mod.compgrid(h, n)
+        c = [mod.set_definitions("bounds", "identity", 1000.0, 4500.0, ("matrix", "")),
+             mod.set_definitions("rank", "identity", 0, 4, ("slice", "z"))]
+        opt = mod.PARSDMM_options(FL=TF, maxit=16)
+        opt.evol_rel_tol = opt.feas_tol = opt.obj_tol = 0.0          # run all iterations
+        P, A, prop = mod.setup_constraints(c, g, TF)
+        A, AtA, l, y = mod.PARSDMM_precompute_distribute(A, prop, g, opt)
+        return mod.PARSDMM(m.copy(), AtA, A, prop, P, g, opt)
+
+    monkeypatch.setenv("SIPX_EXT_DEBUG", "1")
+    capfd.readouterr()
+    xs, ls, _, _ = solve(sipx)
+    err = capfd.readouterr().err
+    assert err.count("subspace accepted") >= 5, err[-2000:]           # the warm-started route carried most iterations
+    monkeypatch.setenv("SIPX_EXT_DEBUG", "0")
+    monkeypatch.setenv("SIPX_RANK_SUBSPACE", "0")
+    xf, lf, _, _ = solve(sipx)
+    monkeypatch.delenv("SIPX_RANK_SUBSPACE")
+    assert "subspace" not in capfd.readouterr().err
+    xo, lo, _, _ = solve(O)
+    nrm = np.linalg.norm(xo)
+    assert np.linalg.norm(xs.astype(np.float64) - xf.astype(np.float64)) / nrm < 2e-6
+    assert np.linalg.norm(xs.astype(np.float64) - xo) / nrm < 1e-4
+    K = min(len(ls.obj), len(lo.obj), 8)
+    assert np.allclose(ls.obj[:K], lo.obj[:K], rtol=2e-3)
