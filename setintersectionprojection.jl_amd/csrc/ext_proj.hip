@@ -400,13 +400,29 @@ __global__ __launch_bounds__(BLOCK) void k_sub_normalize(int k, int b, int batch
     }
   }
 }
+// ||G_l||_F^2 of every matrix of the batch (one workgroup each).
+__global__ __launch_bounds__(BLOCK) void k_sub_fro(int k, const double* __restrict__ G, double* __restrict__ fro2) {
+  __shared__ double sm[BLOCK / 64];
+  const double* Gl = G + (long long)blockIdx.x * k * k;
+  double a = 0;
+  for (long long i = threadIdx.x; i < (long long)k * k; i += BLOCK) a += Gl[i] * Gl[i];
+  a = wave_sum(a);
+  if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = a;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double t = 0;
+    for (int w = 0; w < BLOCK / 64; ++w) t += sm[w];
+    fro2[blockIdx.x] = t;
+  }
+}
 // Largest residual of the top-r Ritz pairs, relative to the largest Ritz value: max_j ||(G Q) z_j - theta_j x_j|| / theta_max,
 // with ZH = (G Q) Z and X = Q Z given (k x b per matrix, Ritz values ascending).  res[0] collects the maximum over the
 // batch (bit pattern of a non-negative double), res[1] is raised when a factorisation failed or a value is not finite.
 __global__ __launch_bounds__(BLOCK) void k_sub_residual(int k, int b, int r, int batch, const double* __restrict__ ZH,
                                                         const double* __restrict__ X, const double* __restrict__ W, int ldw,
                                                         const rocblas_int* __restrict__ info_chol,
-                                                        const rocblas_int* __restrict__ info_eig, unsigned long long* res) {
+                                                        const rocblas_int* __restrict__ info_eig,
+                                                        const double* __restrict__ fro2, unsigned long long* res) {
   __shared__ double sm[BLOCK / 64];
   const int l = blockIdx.x;
   const double tmax = W[(long long)l * ldw + b - 1];
@@ -430,9 +446,23 @@ __global__ __launch_bounds__(BLOCK) void k_sub_residual(int k, int b, int r, int
     worst = rel > worst ? rel : worst;
   }
   if (threadIdx.x == 0) {
-    const bool bad = info_chol[l] != 0 || info_eig[l] != 0 || !(tmax > 0) || !(worst == worst) || isinf(worst);
-    if (bad) atomicMax(res + 1, 1ull);
-    else atomicMax(res, (unsigned long long)__double_as_longlong(worst));
+    // Certificate that no eigenvalue above the r-th Ritz value hides outside the converged pairs.  With P the projector
+    // on the subspace, ||G||_F^2 = ||H||_F^2 + 2 ||(I-P) G P||_F^2 + ||(I-P) G (I-P)||_F^2 and ||H||_F^2 = sum of the
+    // squared Ritz values, so rest = ||G||_F^2 - sum theta^2 bounds both the coupling (<= sqrt(rest/2)) and everything
+    // in the complement (<= sqrt(rest)).  Once the top-r pairs are eigenpairs, the other eigenvalues of G are those of the
+    // block [guard Ritz part, coupling; coupling', complement] <= max(theta_{r+1}, sqrt(rest)) + sqrt(rest/2).
+    double ritz2 = 0;
+    for (int j = 0; j < b; ++j) ritz2 += W[(long long)l * ldw + j] * W[(long long)l * ldw + j];
+    const double rest = fmax(fro2[l] - ritz2, 0.0) + 1e-12 * fro2[l];
+    const double others = fmax(W[(long long)l * ldw + b - r - 1], sqrt(rest)) + sqrt(0.5 * rest);
+    const bool hidden = !(others < W[(long long)l * ldw + b - r]);
+    const unsigned long long bad = (info_chol[l] != 0 ? 1ull : 0ull) | (info_eig[l] != 0 ? 2ull : 0ull) | (!(tmax > 0) ? 4ull : 0ull) |
+                                   ((!(worst == worst) || isinf(worst)) ? 8ull : 0ull) | (hidden ? 16ull : 0ull);
+    if (bad & 15ull) atomicOr(res + 1, bad);     // 1: Cholesky, 2: Ritz solver, 4: no positive Ritz value, 8: not finite
+    else {
+      if (hidden) atomicOr(res + 1, 16ull);      // 16: not certified (yet): fine while the residual is still above the tolerance
+      atomicMax(res, (unsigned long long)__double_as_longlong(worst));
+    }
   }
 }
 // After a full decomposition (eigenvalues ascending, k per matrix): the contraction factor subspace iteration on b vectors
@@ -478,7 +508,7 @@ struct ExtImpl {
   int sub_b = 0;                                   // block size r + 16 (0 = route not used)
   double *Xs[2] = {nullptr, nullptr};              // Ritz vectors of the previous call (y update / feasibility estimate)
   bool sub_have[2] = {false, false}, sub_try[2] = {false, false};
-  double *Qs = nullptr, *Zs = nullptr, *Hs = nullptr, *Ws = nullptr, *Es = nullptr;
+  double *Qs = nullptr, *Zs = nullptr, *Hs = nullptr, *Ws = nullptr, *Es = nullptr, *Fro = nullptr;
   unsigned long long* sub_res = nullptr;           // device: bit pattern of the largest relative residual, failure flag
   unsigned long long* sub_res_host = nullptr;      // pinned
   // DCT: orthonormal DCT-II matrices per dimension, two work arrays, inner projector state
@@ -627,6 +657,7 @@ ExtProj<T>::ExtProj(const ExtSpec& spec, hipStream_t stream) {
         I.Hs = I.template alloc<double>((size_t)I.sub_b * I.sub_b * I.batch);
         I.Ws = I.template alloc<double>((size_t)I.sub_b * I.batch);
         I.Es = I.template alloc<double>((size_t)I.sub_b * I.batch);
+        I.Fro = I.template alloc<double>((size_t)I.batch);
         I.sub_res = I.template alloc<unsigned long long>(2);
         SIPX_HIP(hipHostMalloc((void**)&I.sub_res_host, 2 * sizeof(unsigned long long), hipHostMallocDefault));
       }
@@ -821,6 +852,7 @@ void ExtProj<T>::project(T* v, bool feas, double* partials, T* maxpart, T* compa
         const double tol = 1e-12;
         double prev = -1;
         double* X = I.Xs[w];
+        hipLaunchKernelGGL(k_sub_fro, dim3(I.batch), dim3(BLOCK), 0, s, k, I.Gd, I.Fro);
         for (int it = 0; it < max_it; ++it) {
           blas_check(rocblas_dgemm_strided_batched(I.blas, N_, N_, k, b, k, &one, I.Gd, k, sG, X, k, sX, &zero, I.Qs, k, sX, I.batch), "G X");
           hipLaunchKernelGGL(k_sub_normalize, dim3(I.batch), dim3(BLOCK), 0, s, k, b, I.batch, I.Qs);
@@ -839,15 +871,16 @@ void ExtProj<T>::project(T* v, bool feas, double* partials, T* maxpart, T* compa
           blas_check(rocblas_dgemm_strided_batched(I.blas, N_, N_, k, b, b, &one, I.Zs, k, sX, I.Hs, b, sH, &zero, I.Qs, k, sX, I.batch), "(GQ) Z");
           SIPX_HIP(hipMemsetAsync(I.sub_res, 0, 2 * sizeof(unsigned long long), s));
           hipLaunchKernelGGL(k_sub_residual, dim3(I.batch), dim3(BLOCK), 0, s, k, b, I.r, I.batch, I.Qs, X, I.Ws, b, I.info,
-                             I.info + I.batch, I.sub_res);
+                             I.info + I.batch, I.Fro, I.sub_res);
           SIPX_HIP(hipMemcpyAsync(I.sub_res_host, I.sub_res, 2 * sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
           SIPX_HIP(hipStreamSynchronize(s));
           double res;
           std::memcpy(&res, &I.sub_res_host[0], sizeof(double));
-          const bool failed = I.sub_res_host[1] != 0;
-          if (dbg) fprintf(stderr, "[sipx rank] subspace it %d: residual %.3e%s\n", it + 1, res, failed ? " (failed)" : "");
+          const bool failed = (I.sub_res_host[1] & 15ull) != 0;
+          const bool certified = (I.sub_res_host[1] & 16ull) == 0;
+          if (dbg) fprintf(stderr, "[sipx rank] subspace it %d: residual %.3e fail-bits %llu\n", it + 1, res, I.sub_res_host[1]);
           if (failed) break;
-          if (res <= tol) { sub_ok = true; break; }
+          if (res <= tol) { sub_ok = certified; break; }     // converged pairs that might not be the largest: decompose fully
           if (prev > 0) {                       // contraction observed so far: give up when the budget cannot suffice
             const double c = res / prev;
             if (!(c < 1.0)) break;
