@@ -86,11 +86,28 @@ __device__ __forceinline__ Vec<T, V> zerov() {
   return z;
 }
 
-// 64-lane butterfly-free reduction (fixed order => deterministic).
+// One DPP hop of a float64 (two dwords); lanes without a source receive +0.0.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ double dpp_hop(double v) {
+  const long long b = __double_as_longlong(v);
+  const int lo = __builtin_amdgcn_update_dpp(0, (int)(b & 0xffffffffll), CTRL, ROW_MASK, 0xf, false);
+  const int hi = __builtin_amdgcn_update_dpp(0, (int)(b >> 32), CTRL, ROW_MASK, 0xf, false);
+  return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
+}
+// Sum over the 64 lanes in a fixed order (deterministic), returned to every lane.  DPP moves inside the vector ALU
+// (quad swaps, row rotations, then the row totals are chained through lanes 15/31/47 into lane 63) instead of six
+// ds_bpermute round trips with their index arithmetic: the epilogue of a 13- or 19-slot kernel is a third as long.
 __device__ __forceinline__ double wave_sum(double v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
-  return v;
+  v += dpp_hop<0xb1, 0xf>(v);      // quad_perm:[1,0,3,2]
+  v += dpp_hop<0x4e, 0xf>(v);      // quad_perm:[2,3,0,1]
+  v += dpp_hop<0x124, 0xf>(v);     // row_ror:4
+  v += dpp_hop<0x128, 0xf>(v);     // row_ror:8   -> every lane holds the total of its row of 16
+  v += dpp_hop<0x142, 0xa>(v);     // row_bcast:15 into rows 1 and 3
+  v += dpp_hop<0x143, 0xc>(v);     // row_bcast:31 into rows 2 and 3 -> lane 63 holds the wave total
+  const long long b = __double_as_longlong(v);
+  const int lo = __builtin_amdgcn_readlane((int)(b & 0xffffffffll), 63);
+  const int hi = __builtin_amdgcn_readlane((int)(b >> 32), 63);
+  return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
 }
 template <typename T>
 __device__ __forceinline__ T wave_max(T v) {
@@ -107,10 +124,12 @@ template <int K>
 __device__ __forceinline__ void block_reduce_store(double (&acc)[K], double* __restrict__ partials, int slot0) {
   __shared__ double sm[K][BLOCK / 64];
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  double v[K];
 #pragma unroll
-  for (int k = 0; k < K; ++k) {
-    double v = wave_sum(acc[k]);
-    if (lane == 0) sm[k][w] = v;
+  for (int k = 0; k < K; ++k) v[k] = wave_sum(acc[k]);
+  if (lane == 0) {
+#pragma unroll
+    for (int k = 0; k < K; ++k) sm[k][w] = v[k];
   }
   __syncthreads();
   if (threadIdx.x < K) {
