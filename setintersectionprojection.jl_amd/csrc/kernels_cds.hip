@@ -128,7 +128,7 @@ static void launch_cds(hipStream_t s, long long N, const T* R, const CdsArgs& a,
                        T* xold, double* partials, const int* done) {
   if (a.d < 1 || a.d > MAXD) throw std::runtime_error("cds: band count out of range");
 #define SIPX_CDS(V, D) \
-  hipLaunchKernelGGL((k_cds<T, V, D, MODE>), dim3(SIPX_CG_GRID), dim3(BLOCK), 0, s, N, R, a, x, y, b, pout, xold, partials, done)
+  hipLaunchKernelGGL((k_cds<T, V, D, MODE>), dim3(fit_grid(N / V, SIPX_CG_GRID)), dim3(BLOCK), 0, s, N, R, a, x, y, b, pout, xold, partials, done)
   if (N % 4 == 0) {
     switch (a.d) {
       case 1: SIPX_CDS(4, 1); break;
@@ -519,9 +519,9 @@ template <typename T>
 void K<T>::cg_update_xr(hipStream_t s, long long N, T* x, T* r, const T* p, const T* Ap, double* partials,
                         CgState<T>* st, CgState<T>* host, int iter) {
   if (N % 4 == 0)
-    hipLaunchKernelGGL((k_cg_update_xr<T, 4>), dim3(SIPX_CG_GRID), dim3(BLOCK), 0, s, N, x, r, p, Ap, partials, st, host, iter);
+    hipLaunchKernelGGL((k_cg_update_xr<T, 4>), dim3(fit_grid(N / 4, SIPX_CG_GRID)), dim3(BLOCK), 0, s, N, x, r, p, Ap, partials, st, host, iter);
   else
-    hipLaunchKernelGGL((k_cg_update_xr<T, 1>), dim3(SIPX_CG_GRID), dim3(BLOCK), 0, s, N, x, r, p, Ap, partials, st, host, iter);
+    hipLaunchKernelGGL((k_cg_update_xr<T, 1>), dim3(fit_grid(N, SIPX_CG_GRID)), dim3(BLOCK), 0, s, N, x, r, p, Ap, partials, st, host, iter);
   SIPX_HIP(hipGetLastError());
 }
 
@@ -564,9 +564,9 @@ template <typename T>
 void K<T>::cg_update_p(hipStream_t s, long long N, T* p, const T* r, const double* partials, CgState<T>* st,
                        CgState<T>* host) {
   if (N % 4 == 0)
-    hipLaunchKernelGGL((k_cg_update_p<T, 4>), dim3(NB), dim3(BLOCK), 0, s, N, p, r, partials, st, host);
+    hipLaunchKernelGGL((k_cg_update_p<T, 4>), dim3(fit_grid(N / 4, NB)), dim3(BLOCK), 0, s, N, p, r, partials, st, host);
   else
-    hipLaunchKernelGGL((k_cg_update_p<T, 1>), dim3(NB), dim3(BLOCK), 0, s, N, p, r, partials, st, host);
+    hipLaunchKernelGGL((k_cg_update_p<T, 1>), dim3(fit_grid(N, NB)), dim3(BLOCK), 0, s, N, p, r, partials, st, host);
   SIPX_HIP(hipGetLastError());
 }
 

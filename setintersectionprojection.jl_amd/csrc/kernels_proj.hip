@@ -661,10 +661,10 @@ static void launch_chain(hipStream_t s, const Grid& g, const SetArgs<T>& a, int 
 #define SIPX_PASS(MODE)                                                                                            \
   do {                                                                                                             \
     if (vec)                                                                                                       \
-      hipLaunchKernelGGL((k_pass<T, 4, MODE, SRC>), dim3(SIPX_PASS_GRID), dim3(BLOCK), 0, s, g, a, v_is_s, varr, len, ps, compact, \
+      hipLaunchKernelGGL((k_pass<T, 4, MODE, SRC>), dim3(fit_grid(g.N / 4, SIPX_PASS_GRID)), dim3(BLOCK), 0, s, g, a, v_is_s, varr, len, ps, compact, \
                          partials, maxpart);                                                                       \
     else                                                                                                           \
-      hipLaunchKernelGGL((k_pass<T, 1, MODE, SRC>), dim3(SIPX_PASS_GRID), dim3(BLOCK), 0, s, g, a, v_is_s, varr, len, ps, compact, \
+      hipLaunchKernelGGL((k_pass<T, 1, MODE, SRC>), dim3(fit_grid(SRC == 0 ? len : g.N, SIPX_PASS_GRID)), dim3(BLOCK), 0, s, g, a, v_is_s, varr, len, ps, compact, \
                          partials, maxpart);                                                                       \
   } while (0)
   if (a.prox == PX_CARD) {

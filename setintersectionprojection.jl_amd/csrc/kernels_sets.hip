@@ -75,9 +75,9 @@ __global__ __launch_bounds__(BLOCK) void k_rhs(Grid G, RhsArgs<T> a, T* __restri
 template <typename T>
 void K<T>::rhs_compose(hipStream_t s, const Grid& g, const RhsArgs<T>& a, T* rhs, int accumulate) {
   if (g.n[0] % 4 == 0)
-    hipLaunchKernelGGL((k_rhs<T, 4>), dim3(NB), dim3(BLOCK), 0, s, g, a, rhs, accumulate);
+    hipLaunchKernelGGL((k_rhs<T, 4>), dim3(fit_grid(g.N / 4, NB)), dim3(BLOCK), 0, s, g, a, rhs, accumulate);
   else
-    hipLaunchKernelGGL((k_rhs<T, 1>), dim3(NB), dim3(BLOCK), 0, s, g, a, rhs, accumulate);
+    hipLaunchKernelGGL((k_rhs<T, 1>), dim3(fit_grid(g.N, NB)), dim3(BLOCK), 0, s, g, a, rhs, accumulate);
   SIPX_HIP(hipGetLastError());
 }
 
@@ -188,9 +188,9 @@ __global__ __launch_bounds__(BLOCK) void k_yl(Grid G, SetArgs<T> a, double* __re
 template <typename T>
 void K<T>::yl(hipStream_t s, const Grid& g, const SetArgs<T>& a, double* partials) {
   if (g.n[0] % 4 == 0)
-    hipLaunchKernelGGL((k_yl<T, 4>), dim3(NB), dim3(BLOCK), 0, s, g, a, partials);
+    hipLaunchKernelGGL((k_yl<T, 4>), dim3(fit_grid(g.N / 4, NB)), dim3(BLOCK), 0, s, g, a, partials);
   else
-    hipLaunchKernelGGL((k_yl<T, 1>), dim3(NB), dim3(BLOCK), 0, s, g, a, partials);
+    hipLaunchKernelGGL((k_yl<T, 1>), dim3(fit_grid(g.N, NB)), dim3(BLOCK), 0, s, g, a, partials);
   SIPX_HIP(hipGetLastError());
 }
 
@@ -218,9 +218,9 @@ __global__ __launch_bounds__(BLOCK) void k_adj_norm(Grid G, SetArgs<T> a, double
 template <typename T>
 void K<T>::adj_norm(hipStream_t s, const Grid& g, const SetArgs<T>& a, double* partials) {
   if (g.n[0] % 4 == 0)
-    hipLaunchKernelGGL((k_adj_norm<T, 4>), dim3(NB), dim3(BLOCK), 0, s, g, a, partials);
+    hipLaunchKernelGGL((k_adj_norm<T, 4>), dim3(fit_grid(g.N / 4, NB)), dim3(BLOCK), 0, s, g, a, partials);
   else
-    hipLaunchKernelGGL((k_adj_norm<T, 1>), dim3(NB), dim3(BLOCK), 0, s, g, a, partials);
+    hipLaunchKernelGGL((k_adj_norm<T, 1>), dim3(fit_grid(g.N, NB)), dim3(BLOCK), 0, s, g, a, partials);
   SIPX_HIP(hipGetLastError());
 }
 

@@ -13,6 +13,12 @@ constexpr int NB = 2048;          // fixed grid of every streaming/reduction ker
 // occupancy, so those families launch 7*256 workgroups (their block partials beyond that stay zero).
 constexpr int NB_7 = 1792;
 // per_cu workgroups on every compute unit of the current device, within the partial arrays (<= NB_7).
+// Grid of a grid-stride kernel over nvec thread-iterations: no more workgroups than there is work for (every workgroup
+// pays the reduction epilogue; at 64^3 an eighth of 2048 workgroups has anything to do), at most `cap`.
+inline int fit_grid(long long nvec, int cap) {
+  const long long need = (nvec + BLOCK - 1) / BLOCK;
+  return (int)(need < 1 ? 1 : (need < cap ? need : cap));
+}
 inline int launch_blocks(int per_cu) {
   static const int cus = [] {
     int dev = 0, n = 0;
