@@ -289,7 +289,7 @@ __global__ __launch_bounds__(SIPX_DECIDE_NT) void k_decide(const double* __restr
   if (STAGE == 0) {
     for (int i = threadIdx.x; i < NB; i += NT) {
       vmax = maxpart[i] > vmax ? maxpart[i] : vmax;
-      const T mn = maxpart[NB + i];                 // 0 = slot of a workgroup that was not launched (grid of NB_7)
+      const T mn = maxpart[NB + i];                 // 0 = entry beyond the pass's grid, or a workgroup that saw no non-zero magnitude
       vmin = (mn > T(0) && mn < vmin) ? mn : vmin;
     }
     vmax = wave_max<T>(vmax);

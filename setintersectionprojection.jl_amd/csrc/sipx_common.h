@@ -10,7 +10,7 @@ namespace sipx {
 constexpr int BLOCK = 256;        // 4 waves of 64
 constexpr int NB = 2048;          // fixed grid of every streaming/reduction kernel (8 blocks per CU: measured +8% over 1024)
 // Kernels that need 65..72 VGPRs run 7 workgroups per CU: a grid of 2048 would leave a 256-workgroup tail at 1/7
-// occupancy, so those families launch 7*256 workgroups (their block partials beyond that stay zero).
+// occupancy, so those families launch 7*256 workgroups (block_reduce_store clears the partial entries beyond a launch's grid).
 constexpr int NB_7 = 1792;
 // per_cu workgroups on every compute unit of the current device, within the partial arrays (<= NB_7).
 // Grid of a grid-stride kernel over nvec thread-iterations: no more workgroups than there is work for (every workgroup
@@ -39,7 +39,7 @@ constexpr int PREP_SLOTS = 3 + 2 * L1_K;   // ||v||_1, ||v||_2^2, nnz, S_k, C_k
 enum { SL_RPRI = 0, SL_DY = 1, SL_HL = 2, SL_HH = 3, SL_LH = 4, SL_DL = 5, SL_GG = 6, SL_GL = 7,
        SL_FE = 8, SL_SS = 9, SL_OBJ = 10, SL_EVO = 11, SL_XX = 12 };
 
-enum { F_FEAS = 1, F_BB = 2, F_FIRST = 4, F_NOSPEC = 8 /* rho/gamma just changed: skip the speculative gather */,
+enum { F_FEAS = 1, F_BB = 2, F_FIRST = 4, F_NOSPEC = 8 /* skip the speculative gather of the l1 search (not set by the engine at present) */,
        F_STORE_DY = 16 /* identity-shaped pass over a materialised s = A x (custom sparse operator): keep y - y_old */ };
 
 // internal prox kinds (public SIPX_PROJ_* plus the distance term)
