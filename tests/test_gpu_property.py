@@ -21,8 +21,13 @@ def proj(sipx, st_, M, TF, mn, mx):
     return sipx.host.Projector(c, sipx.compgrid((1.0, 1.0), (M, 1)), TF)
 
 
-# derandomize: the same examples on every run (the round-end GPU run must not depend on a random draw)
-SET = settings(max_examples=120, deadline=None, derandomize=True, database=None,
+# derandomize: the same examples on every run (the round-end GPU run must not depend on a random draw).
+# SIPX_FUZZ_RANDOM=1 [SIPX_FUZZ_SCALE=k] draws fresh examples (k times as many) for an exploratory run.
+import os  # noqa: E402
+
+_RANDOM = bool(os.environ.get("SIPX_FUZZ_RANDOM"))
+_SCALE = int(os.environ.get("SIPX_FUZZ_SCALE", "1"))
+SET = settings(max_examples=120 * _SCALE, deadline=None, derandomize=not _RANDOM, database=None,
                suppress_health_check=[HealthCheck.function_scoped_fixture])
 
 
@@ -133,7 +138,7 @@ def test_random_small_problems_match_oracle(sipx):
     pool3 = ["bounds", "l1:D_x", "l1:D_z", "l1:TV", "annulus", "bnd:D_z", "l2", "l1:D_y", "card:D_z", "l1dft", "l1dct", "hist",
              "nuc:z", "cardf:D_y:slice:z", "cardf:identity:fiber:x", "bndf:z"]
 
-    @settings(max_examples=60, deadline=None, derandomize=True, database=None,
+    @settings(max_examples=60 * _SCALE, deadline=None, derandomize=not _RANDOM, database=None,
               suppress_health_check=[HealthCheck.function_scoped_fixture])
     @given(ndim=st.sampled_from([2, 3]), dims=st.tuples(st.integers(3, 13), st.integers(3, 11), st.integers(3, 7)),
            picks=st.lists(st.integers(0, 15), min_size=1, max_size=4, unique=True), seed=st.integers(0, 1000),
