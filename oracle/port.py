@@ -89,7 +89,7 @@ def time_baseline(name, n, h, kinds, budget_s=20.0):
             s = sum(np.abs(np.diff(M3, axis=a)).sum() / h[a] for a in axes)
             sets.append(("l1", op, 0.0, 0.5 * s))
     # one bounded run (operator / AtA setup is not timed): about 10-30 s of iteration-loop work
-    iters = int(min(25, max(3, round(budget_s * 1.0e7 / int(np.prod(n))))))
+    iters = int(min(25, max(3, round(budget_s * 2.1e7 / int(np.prod(n))))))     # 256^3: the 25 iterations the GPU run covers (5 warm-up + 20 timed), ~10 s
     r = run(n, h, sets, m, iters, 0.0, 0.0, 0.0, nthreads=nthreads)
     return {"value": r["n_iter"] / r["loop_seconds"], "unit": "it/s", "cores": nthreads, "kind": "port",
             "sample": f"same workload ({name}: {'x'.join(map(str, n))} f32, same sets and model), first {r['n_iter']} "
