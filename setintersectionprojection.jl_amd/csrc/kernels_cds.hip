@@ -17,6 +17,9 @@
 // 1792: whole multiples of the CU count win over the in-between sizes, and 3 per CU is +1 % at 256^3, +4 % at 512^3 over
 // the 7 per CU the other stencil kernels use.
 #define SIPX_CG_GRID launch_blocks(3)
+#ifndef SIPX_F64_VEC
+#define SIPX_F64_VEC 2
+#endif
 
 namespace sipx {
 
@@ -129,13 +132,15 @@ static void launch_cds(hipStream_t s, long long N, const T* R, const CdsArgs& a,
   if (a.d < 1 || a.d > MAXD) throw std::runtime_error("cds: band count out of range");
 #define SIPX_CDS(V, D) \
   hipLaunchKernelGGL((k_cds<T, V, D, MODE>), dim3(fit_grid(N / V, SIPX_CG_GRID)), dim3(BLOCK), 0, s, N, R, a, x, y, b, pout, xold, partials, done)
+  // 16 bytes per thread and band: four floats or two doubles (four doubles leave the 7-band kernel 3 waves per SIMD)
+  constexpr int VW = sizeof(T) == 8 ? SIPX_F64_VEC : 4;
   if (N % 4 == 0) {
     switch (a.d) {
-      case 1: SIPX_CDS(4, 1); break;
-      case 3: SIPX_CDS(4, 3); break;
-      case 5: SIPX_CDS(4, 5); break;
-      case 7: SIPX_CDS(4, 7); break;
-      default: SIPX_CDS(4, 0); break;
+      case 1: SIPX_CDS(VW, 1); break;
+      case 3: SIPX_CDS(VW, 3); break;
+      case 5: SIPX_CDS(VW, 5); break;
+      case 7: SIPX_CDS(VW, 7); break;
+      default: SIPX_CDS(VW, 0); break;
     }
   } else {
     SIPX_CDS(1, 0);

@@ -18,6 +18,9 @@
 #include <string>
 
 #include "sipx_device.h"
+#ifndef SIPX_F64_VEC
+#define SIPX_F64_VEC 2
+#endif
 
 namespace sipx {
 
@@ -187,8 +190,9 @@ __global__ __launch_bounds__(BLOCK) void k_yl(Grid G, SetArgs<T> a, double* __re
 }
 template <typename T>
 void K<T>::yl(hipStream_t s, const Grid& g, const SetArgs<T>& a, double* partials) {
+  constexpr int VW = sizeof(T) == 8 ? SIPX_F64_VEC : 4;      // four doubles per thread spill registers at 3 waves per SIMD
   if (g.n[0] % 4 == 0)
-    hipLaunchKernelGGL((k_yl<T, 4>), dim3(fit_grid(g.N / 4, NB)), dim3(BLOCK), 0, s, g, a, partials);
+    hipLaunchKernelGGL((k_yl<T, VW>), dim3(fit_grid(g.N / VW, NB)), dim3(BLOCK), 0, s, g, a, partials);
   else
     hipLaunchKernelGGL((k_yl<T, 1>), dim3(fit_grid(g.N, NB)), dim3(BLOCK), 0, s, g, a, partials);
   SIPX_HIP(hipGetLastError());
