@@ -161,8 +161,10 @@ __global__ __launch_bounds__(BLOCK) void k_yl(Grid G, SetArgs<T> a, double* __re
         }
       }
       if (bb) {                                                          // adapt_rho_gamma.jl:41-53
-        const Vec<T, V> a0 = ldv<T, V>(a.lh0 + e), b0 = ldv<T, V>(a.y0 + e), c0 = ldv<T, V>(a.s0 + e),
-                        d0 = ldv<T, V>(a.l0 + e);
+        // the snapshot arrays are touched once every rho_update_frequency iterations: streaming loads and stores keep them
+        // from evicting the vectors the next kernels re-read (+2 % at 256^3)
+        const Vec<T, V> a0 = ldv_nt<T, V>(a.lh0 + e), b0 = ldv_nt<T, V>(a.y0 + e), c0 = ldv_nt<T, V>(a.s0 + e),
+                        d0 = ldv_nt<T, V>(a.l0 + e);
 #pragma unroll
         for (int k = 0; k < V; ++k) {
           const T dlh = lh.v[k] - a0.v[k], dH = s[k] - c0.v[k], dl = ln.v[k] - d0.v[k], dG = -(yn.v[k] - b0.v[k]);
@@ -178,11 +180,11 @@ __global__ __launch_bounds__(BLOCK) void k_yl(Grid G, SetArgs<T> a, double* __re
         Vec<T, V> sv;
 #pragma unroll
         for (int k = 0; k < V; ++k) sv.v[k] = s[k];
-        stv<T, V>(a.lh0 + e, lh);          // y_0 <- y and l_0 <- l need no copy: on these iterations the update below
-        stv<T, V>(a.s0 + e, sv);           // is written into the snapshot arrays themselves (engine, update_y_l)
+        stv_nt<T, V>(a.lh0 + e, lh);       // y_0 <- y and l_0 <- l need no copy: on these iterations the update below
+        stv_nt<T, V>(a.s0 + e, sv);        // is written into the snapshot arrays themselves (engine, update_y_l)
       }
-      stv<T, V>(a.yo + e, yn);
-      stv<T, V>(a.lo + e, ln);
+      stv_nt<T, V>(a.yo + e, yn);        // streaming stores: +1 % at 256^3 over cached ones
+      stv_nt<T, V>(a.lo + e, ln);
       if (!ident || (a.flags & F_STORE_DY)) stv<T, V>(a.dy + e, dyv);
     }
   }
