@@ -508,7 +508,7 @@ __global__ __launch_bounds__(BLOCK) void k_cg_update_xr(long long N, T* __restri
   double acc[1] = {0};
   for (long long vi = (long long)blockIdx.x * BLOCK + threadIdx.x; vi < nvec; vi += (long long)gridDim.x * BLOCK) {
     Vec<T, V> xv = ldv<T, V>(x + vi * V), rv = ldv<T, V>(r + vi * V);
-    const Vec<T, V> pv = ldv<T, V>(p + vi * V), av = ldv<T, V>(Ap + vi * V);
+    const Vec<T, V> pv = ldv<T, V>(p + vi * V), av = ldv_nt<T, V>(Ap + vi * V);     // Ap: written and read once per iteration
 #pragma unroll
     for (int k = 0; k < V; ++k) {
       xv.v[k] = xv.v[k] + alpha * pv.v[k];
