@@ -467,11 +467,9 @@ class Engine : public EngineBase {
 
   void argmin_x(int it, double* tol_ref_io, int64_t* cg_it, double* cg_relres, int* cg_flag) override {
     need_final();
-    cg_host_->tol_ref = (T)*tol_ref_io;     // pinned staging; the device mirror overwrites it after the copy (stream order)
-    SIPX_HIP(hipMemcpyAsync(&cg_dev_->tol_ref, &cg_host_->tol_ref, sizeof(T), hipMemcpyHostToDevice, stream_));
     if (stencil_q_) K<T>::sq_resid(stream_, G_, sq_, x_, rhs_, r_, p_, xold_, part_cg_);
     else K<T>::resid(stream_, Nx_, Q_, cds_, x_, rhs_, r_, p_, xold_, part_cg_);
-    K<T>::cg_begin(stream_, part_cg_, cg_dev_, cg_host_, it, x_, Nx_);
+    K<T>::cg_begin(stream_, part_cg_, cg_dev_, cg_host_, it, (T)*tol_ref_io);
     SIPX_HIP(hipStreamSynchronize(stream_));
     if (cg_host_->flag == -9) SIPX_HIP(hipMemsetAsync(x_, 0, Nx_ * sizeof(T), stream_));   // cg.jl:51
     // CG iterations run one ahead of the host: iteration k+1 is enqueued before the outcome of k is known.

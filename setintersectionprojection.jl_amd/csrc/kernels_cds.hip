@@ -441,14 +441,14 @@ void K<T>::gen_ata(hipStream_t s, const Grid& g, int nblk, const int* dir, const
 // the reference's scalar logic and mirrors the state into pinned host memory.
 template <typename T>
 __global__ __launch_bounds__(BLOCK) void k_cg_begin(const double* __restrict__ partials, CgState<T>* st,
-                                                    CgState<T>* host, int it_outer) {
+                                                    CgState<T>* host, int it_outer, T tol_ref) {
   const double ss_r = block_sum_partials(partials);
   const double ss_b = block_sum_partials(partials + NB);
   if (threadIdx.x == 0) {
     const T nr0 = (T)sqrt(ss_b), nres = (T)sqrt(ss_r);
-    // argmin_x.jl:33-37 -- the 0.1 factor is a Float64 literal
+    // argmin_x.jl:33-37 -- the 0.1 factor is a Float64 literal; x_solve_tol_ref arrives as a kernel argument
     const double cand = jl_max(0.1 * (double)nres / (double)nr0, (double)(T(10) * eps_of<T>()));
-    const T tol = (it_outer < 3) ? (T)cand : (T)jl_min(cand, (double)st->tol_ref);
+    const T tol = (it_outer < 3) ? (T)cand : (T)jl_min(cand, (double)tol_ref);
     st->tol = tol;
     st->tol_ref = tol;
     st->nr0 = nr0;
@@ -472,8 +472,8 @@ __global__ __launch_bounds__(BLOCK) void k_cg_begin(const double* __restrict__ p
   }
 }
 template <typename T>
-void K<T>::cg_begin(hipStream_t s, double* partials, CgState<T>* st, CgState<T>* host, int it_outer, T*, long long) {
-  hipLaunchKernelGGL((k_cg_begin<T>), dim3(1), dim3(BLOCK), 0, s, partials, st, host, it_outer);
+void K<T>::cg_begin(hipStream_t s, double* partials, CgState<T>* st, CgState<T>* host, int it_outer, T tol_ref) {
+  hipLaunchKernelGGL((k_cg_begin<T>), dim3(1), dim3(BLOCK), 0, s, partials, st, host, it_outer, tol_ref);
   SIPX_HIP(hipGetLastError());
 }
 
@@ -606,7 +606,7 @@ void K<T>::fin_sum(hipStream_t s, const double* partials, int nslots, double* ou
   template void K<T>::sq_resid(hipStream_t, const Grid&, const StencilQ<T>&, const T*, const T*, T*, T*, T*, double*); \
   template void K<T>::q_update(hipStream_t, const Grid&, const CdsArgs&, const QArgs<T>&, T*);                        \
   template void K<T>::gen_ata(hipStream_t, const Grid&, int, const int*, const T*, int, const long long*, T*);       \
-  template void K<T>::cg_begin(hipStream_t, double*, CgState<T>*, CgState<T>*, int, T*, long long);                  \
+  template void K<T>::cg_begin(hipStream_t, double*, CgState<T>*, CgState<T>*, int, T);                               \
   template void K<T>::cg_update_xr(hipStream_t, long long, T*, T*, const T*, const T*, double*, CgState<T>*,         \
                                    CgState<T>*, int);                                                                \
   template void K<T>::cg_update_p(hipStream_t, long long, T*, const T*, const double*, CgState<T>*, CgState<T>*);    \

@@ -200,7 +200,7 @@ struct K {
   static void gen_ata(hipStream_t s, const Grid& g, int nblk, const int* dir, const T* ih, int nband,
                       const long long* offs, T* R);
   // CG
-  static void cg_begin(hipStream_t s, double* partials, CgState<T>* st, CgState<T>* host, int it_outer, T* x, long long N);
+  static void cg_begin(hipStream_t s, double* partials, CgState<T>* st, CgState<T>* host, int it_outer, T tol_ref);
   static void cg_update_xr(hipStream_t s, long long N, T* x, T* r, const T* p, const T* Ap, double* partials,
                            CgState<T>* st, CgState<T>* host, int iter);
   static void cg_update_p(hipStream_t s, long long N, T* p, const T* r, const double* partials, CgState<T>* st,
