@@ -467,8 +467,10 @@ class Engine : public EngineBase {
 
   void argmin_x(int it, double* tol_ref_io, int64_t* cg_it, double* cg_relres, int* cg_flag) override {
     need_final();
-    if (stencil_q_) K<T>::sq_resid(stream_, G_, sq_, x_, rhs_, r_, p_, xold_, part_cg_);
-    else K<T>::resid(stream_, Nx_, Q_, cds_, x_, rhs_, r_, p_, xold_, part_cg_);
+    // the initial residual goes straight into the p buffer (p_1 = r_0, cg.jl:57): the first iteration reads it from there
+    // as both r and p and writes r_1 into the r buffer, so the copy p <- r is never made
+    if (stencil_q_) K<T>::sq_resid(stream_, G_, sq_, x_, rhs_, p_, (T*)nullptr, xold_, part_cg_);
+    else K<T>::resid(stream_, Nx_, Q_, cds_, x_, rhs_, p_, (T*)nullptr, xold_, part_cg_);
     K<T>::cg_begin(stream_, part_cg_, cg_dev_, cg_host_, it, (T)*tol_ref_io);
     SIPX_HIP(hipStreamSynchronize(stream_));
     if (cg_host_->flag == -9) SIPX_HIP(hipMemsetAsync(x_, 0, Nx_ * sizeof(T), stream_));   // cg.jl:51
@@ -482,7 +484,7 @@ class Engine : public EngineBase {
       if (stencil_q_) K<T>::sq_spmv_dot(stream_, G_, sq_, p_, Ap_, part_cg_, cg_dev_);
       else K<T>::spmv_dot(stream_, Nx_, Q_, cds_, p_, Ap_, part_cg_, cg_dev_);
       if (stats_on_) stat_mark();
-      K<T>::cg_update_xr(stream_, Nx_, x_, r_, p_, Ap_, part_cg_, cg_dev_, mirror, k);
+      K<T>::cg_update_xr(stream_, Nx_, x_, k == 1 ? p_ : r_, r_, p_, Ap_, part_cg_, cg_dev_, mirror, k);
       K<T>::cg_update_p(stream_, Nx_, p_, r_, part_cg_, cg_dev_, mirror);
       SIPX_HIP(hipEventRecord(cg_ev_[k & 1], stream_));
     };

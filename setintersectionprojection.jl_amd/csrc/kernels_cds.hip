@@ -113,7 +113,7 @@ __global__ __launch_bounds__(BLOCK) void k_cds(long long N, const T* __restrict_
         acc1 += (double)bv.v[k] * (double)bv.v[k];
       }
       stv<T, V>(y + r, o);
-      stv<T, V>(pout + r, o);
+      if (pout) stv<T, V>(pout + r, o);
       stv<T, V>(xold + r, xv);
     }
   }
@@ -226,7 +226,7 @@ __global__ __launch_bounds__(BLOCK) void k_sq(Grid G, StencilQ<T> q, const T* __
         acc1 += (double)bv.v[k] * (double)bv.v[k];
       }
       stv<T, V>(y + r, o);
-      stv<T, V>(pout + r, o);
+      if (pout) stv<T, V>(pout + r, o);
       stv<T, V>(xold + r, xv);
     }
   }
@@ -483,8 +483,8 @@ void K<T>::cg_begin(hipStream_t s, double* partials, CgState<T>* st, CgState<T>*
 //
 // alpha = dot(r,z) / dot(p,Ap) ; x += alpha p ; r -= alpha Ap ; partial ||r||^2 (slot 1)   (cg.jl:83-100)
 template <typename T, int V>
-__global__ __launch_bounds__(BLOCK) void k_cg_update_xr(long long N, T* __restrict__ x, T* __restrict__ r,
-                                                        const T* __restrict__ p, const T* __restrict__ Ap,
+__global__ __launch_bounds__(BLOCK) void k_cg_update_xr(long long N, T* __restrict__ x, const T* r_in, T* r,
+                                                        const T* p, const T* __restrict__ Ap,
                                                         double* __restrict__ partials, CgState<T>* __restrict__ st,
                                                         CgState<T>* __restrict__ host, int iter) {
   if (st->done) return;
@@ -507,7 +507,7 @@ __global__ __launch_bounds__(BLOCK) void k_cg_update_xr(long long N, T* __restri
   const long long nvec = N / V;
   double acc[1] = {0};
   for (long long vi = (long long)blockIdx.x * BLOCK + threadIdx.x; vi < nvec; vi += (long long)gridDim.x * BLOCK) {
-    Vec<T, V> xv = ldv<T, V>(x + vi * V), rv = ldv<T, V>(r + vi * V);
+    Vec<T, V> xv = ldv<T, V>(x + vi * V), rv = ldv<T, V>(r_in + vi * V);     // r_in == p on the first iteration (p_1 = r_0)
     const Vec<T, V> pv = ldv<T, V>(p + vi * V), av = ldv_nt<T, V>(Ap + vi * V);     // Ap: written and read once per iteration
 #pragma unroll
     for (int k = 0; k < V; ++k) {
@@ -521,12 +521,12 @@ __global__ __launch_bounds__(BLOCK) void k_cg_update_xr(long long N, T* __restri
   block_reduce_store<1>(acc, partials, 1);    // its own slot: other workgroups may still be reading slot 0
 }
 template <typename T>
-void K<T>::cg_update_xr(hipStream_t s, long long N, T* x, T* r, const T* p, const T* Ap, double* partials,
+void K<T>::cg_update_xr(hipStream_t s, long long N, T* x, const T* r_in, T* r, const T* p, const T* Ap, double* partials,
                         CgState<T>* st, CgState<T>* host, int iter) {
   if (N % 4 == 0)
-    hipLaunchKernelGGL((k_cg_update_xr<T, 4>), dim3(fit_grid(N / 4, SIPX_CG_GRID)), dim3(BLOCK), 0, s, N, x, r, p, Ap, partials, st, host, iter);
+    hipLaunchKernelGGL((k_cg_update_xr<T, 4>), dim3(fit_grid(N / 4, SIPX_CG_GRID)), dim3(BLOCK), 0, s, N, x, r_in, r, p, Ap, partials, st, host, iter);
   else
-    hipLaunchKernelGGL((k_cg_update_xr<T, 1>), dim3(fit_grid(N, SIPX_CG_GRID)), dim3(BLOCK), 0, s, N, x, r, p, Ap, partials, st, host, iter);
+    hipLaunchKernelGGL((k_cg_update_xr<T, 1>), dim3(fit_grid(N, SIPX_CG_GRID)), dim3(BLOCK), 0, s, N, x, r_in, r, p, Ap, partials, st, host, iter);
   SIPX_HIP(hipGetLastError());
 }
 
@@ -607,7 +607,7 @@ void K<T>::fin_sum(hipStream_t s, const double* partials, int nslots, double* ou
   template void K<T>::q_update(hipStream_t, const Grid&, const CdsArgs&, const QArgs<T>&, T*);                        \
   template void K<T>::gen_ata(hipStream_t, const Grid&, int, const int*, const T*, int, const long long*, T*);       \
   template void K<T>::cg_begin(hipStream_t, double*, CgState<T>*, CgState<T>*, int, T);                               \
-  template void K<T>::cg_update_xr(hipStream_t, long long, T*, T*, const T*, const T*, double*, CgState<T>*,         \
+  template void K<T>::cg_update_xr(hipStream_t, long long, T*, const T*, T*, const T*, const T*, double*, CgState<T>*, \
                                    CgState<T>*, int);                                                                \
   template void K<T>::cg_update_p(hipStream_t, long long, T*, const T*, const double*, CgState<T>*, CgState<T>*);    \
   template void K<T>::fin_sum(hipStream_t, const double*, int, double*, double*);

@@ -201,7 +201,7 @@ struct K {
                       const long long* offs, T* R);
   // CG
   static void cg_begin(hipStream_t s, double* partials, CgState<T>* st, CgState<T>* host, int it_outer, T tol_ref);
-  static void cg_update_xr(hipStream_t s, long long N, T* x, T* r, const T* p, const T* Ap, double* partials,
+  static void cg_update_xr(hipStream_t s, long long N, T* x, const T* r_in, T* r, const T* p, const T* Ap, double* partials,
                            CgState<T>* st, CgState<T>* host, int iter);
   static void cg_update_p(hipStream_t s, long long N, T* p, const T* r, const double* partials, CgState<T>* st,
                           CgState<T>* host);
