@@ -4,8 +4,10 @@
  * This is the drop-in boundary for ONE hot path of slimgroup/SetIntersectionProjection.jl:
  * the PARSDMM iteration body behind
  *     PARSDMM(m, AtA, TD_OP, set_Prop, P_sub, comp_grid, options[, x, l, y]) -> (x, log, l, y)
- * (reference src/PARSDMM.jl:25-35,257).  Plain pointers and sizes only; every function
- * returns 0 on success, non-zero on error (text via sipx_last_error()).  Host arrays are
+ * (reference src/PARSDMM.jl:25-35,257).  Plain pointers and sizes only; every function that
+ * returns int returns 0 on success and non-zero on error (text via sipx_last_error()) -- with ONE
+ * exception, sipx_add_set, which returns the index (>= 0) of the set it added and -1 on error.
+ * Host arrays are
  * copied in / copied out; the library never keeps a caller pointer after a call returns
  * (reference ownership model: Julia owns every array).
  *
@@ -136,7 +138,9 @@ void sipx_destroy(sipx_ctx* ctx);
 
 /* Adds constraint set i (call in TD_OP order).  ata_R / ata_off / d_i = AtA[i] in CDS (N x d_i,
  * column-major) with set_Prop.AtA_offsets[i] (src/PARSDMM_precompute_distribute.jl:52-59); pass
- * ata_R = NULL to have the bands generated on the device from the operator descriptor. */
+ * ata_R = NULL to have the bands generated on the device from the operator descriptor.
+ * RETURN VALUE (unlike every other entry): the 0-based index of the new set (the i of y_i / l_i, of the rho / gamma /
+ * r_pri arrays and of sipx_set_rows) on success, -1 on error -- test `rc < 0`, not `rc != 0`. */
 int sipx_add_set(sipx_ctx* ctx, const sipx_set_desc* desc, const void* ata_R, const int64_t* ata_off, int d_i);
 
 /* Rows of A_i (length of y_i / l_i) for set i; i = number of constraint sets addresses the
@@ -206,6 +210,11 @@ void* sipx_stream(sipx_ctx* ctx);
 /* device pointers of rhs / x (TF[N]) for in-place collectives on the sharded path */
 void* sipx_dev_rhs(sipx_ctx* ctx);
 void* sipx_dev_x(sipx_ctx* ctx);
+/* rhs as composed by the last sipx_rhs_compose (host TF[N]; TF[2N] in Minkowski mode)           (src/rhs_compose.jl:24-36) */
+int sipx_get_rhs(sipx_ctx* ctx, void* rhs);
+/* x = (x*rho + m) / (rho + 1.0) on host vectors of length n, through the device function the y/l update applies for the
+ * distance term (src/prox_l2s!.jl:3-6: numerator in TF, division in Float64) */
+int sipx_prox_l2s(int dtype, int64_t n, void* x, double rho, const void* m, int device);
 /* restricts y/l work and rhs contributions to sets with owner[i] != 0 (set sharding); Q stays global */
 int sipx_set_owned(sipx_ctx* ctx, const int32_t* owned);
 

@@ -48,6 +48,9 @@ int sipx_add_set(sipx_ctx* c, const sipx_set_desc* d, const void* R, const int64
   } catch (const std::exception& ex) {
     g_err = ex.what();
     return -1;
+  } catch (...) {
+    g_err = "unknown error";
+    return -1;
   }
 }
 int sipx_set_rows(sipx_ctx* c, int set, int64_t* rows) { SIPX_TRY(*rows = c->e->set_rows(set)) }
@@ -100,6 +103,10 @@ int sipx_debug_proj(sipx_ctx* c, int set, int which, double* out16) { SIPX_TRY(c
 void* sipx_stream(sipx_ctx* c) { return c->e->stream(); }
 void* sipx_dev_rhs(sipx_ctx* c) { return c->e->dev_rhs(); }
 void* sipx_dev_x(sipx_ctx* c) { return c->e->dev_x(); }
+int sipx_get_rhs(sipx_ctx* c, void* rhs) { SIPX_TRY(c->e->get_rhs(rhs)) }
+int sipx_prox_l2s(int dtype, int64_t n, void* x, double rho, const void* m, int device) {
+  SIPX_TRY(sipx::prox_l2s_host(dtype, n, x, rho, m, device))
+}
 int sipx_set_owned(sipx_ctx* c, const int32_t* owned) { SIPX_TRY(c->e->set_owned(owned)) }
 int sipx_set_q_mode(sipx_ctx* c, int mode) { SIPX_TRY(c->e->set_q_mode(mode)) }
 int sipx_apply_Q(sipx_ctx* c, const void* x, void* y) { SIPX_TRY(c->e->apply_Q(x, y)) }

@@ -786,6 +786,9 @@ class Engine : public EngineBase {
         resolve_timing(log, 1);
         log->n_iter = i;
         log->n_feas_rows = counter;
+        // Q holds sum_i rho_i AtA_i for the rho of THIS iteration (the update below has not run): a later solve on the
+        // same context must start from these values, as after the maxit exit
+        for (int k = 0; k < p; ++k) { rho_[k] = (T)rho[k]; gamma_[k] = (T)gamma[k]; }
         R.done = true;
         return true;
       }
@@ -985,6 +988,11 @@ class Engine : public EngineBase {
   void* stream() override { return (void*)stream_; }
   void* dev_rhs() override { return rhs_; }
   void* dev_x() override { return x_; }
+  void get_rhs(void* out) override {
+    need_final();
+    SIPX_HIP(hipStreamSynchronize(stream_));
+    SIPX_HIP(hipMemcpy(out, rhs_, Nx_ * sizeof(T), hipMemcpyDeviceToHost));
+  }
 
  private:
   void stat_mark() {
@@ -1557,6 +1565,28 @@ void resample_nn_host(int dtype, int ndim, const int64_t* nc, const int64_t* nf,
   SIPX_HIP(hipSetDevice(device));
   if (dtype == SIPX_F32) resample_T<float>(ndim, nc, nf, in, out);
   else if (dtype == SIPX_F64) resample_T<double>(ndim, nc, nf, in, out);
+  else throw std::runtime_error("dtype must be SIPX_F32 or SIPX_F64");
+}
+
+template <typename T>
+static void prox_l2s_T(int64_t n, void* x, double rho, const void* m) {
+  T* dx = dalloc<T>(n, false);
+  T* dm = dalloc<T>(n, false);
+  SIPX_HIP(hipMemcpy(dx, x, n * sizeof(T), hipMemcpyHostToDevice));
+  SIPX_HIP(hipMemcpy(dm, m, n * sizeof(T), hipMemcpyHostToDevice));
+  prox_l2s_dev<T>(nullptr, n, dx, dm, (T)rho);
+  SIPX_HIP(hipDeviceSynchronize());
+  SIPX_HIP(hipMemcpy(x, dx, n * sizeof(T), hipMemcpyDeviceToHost));
+  dfree(dx); dfree(dm);
+}
+void prox_l2s_host(int dtype, int64_t n, void* x, double rho, const void* m, int device) {
+  int count = 0;
+  if (hipGetDeviceCount(&count) != hipSuccess || count <= 0)
+    throw std::runtime_error("libsipx: no HIP device visible -- this engine has no CPU fallback");
+  if (n < 1) return;
+  SIPX_HIP(hipSetDevice(device));
+  if (dtype == SIPX_F32) prox_l2s_T<float>(n, x, rho, m);
+  else if (dtype == SIPX_F64) prox_l2s_T<double>(n, x, rho, m);
   else throw std::runtime_error("dtype must be SIPX_F32 or SIPX_F64");
 }
 

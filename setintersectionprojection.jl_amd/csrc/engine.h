@@ -39,12 +39,14 @@ struct EngineBase {
   virtual void* stream() = 0;
   virtual void* dev_rhs() = 0;
   virtual void* dev_x() = 0;
+  virtual void get_rhs(void* out) = 0;
   virtual void set_owned(const int32_t* owned) = 0;
   virtual void set_q_mode(int mode) = 0;
 };
 
 EngineBase* make_engine(int dtype, int ndim, const int64_t* n, const double* h, int device);
 void resample_nn_host(int dtype, int ndim, const int64_t* nc, const int64_t* nf, const void* in, void* out, int device);
+void prox_l2s_host(int dtype, int64_t n, void* x, double rho, const void* m, int device);
 void cds_spmv_host(int dtype, int64_t N, int d, const void* R, const int64_t* off, const void* x, void* y, int device);
 
 }  // namespace sipx

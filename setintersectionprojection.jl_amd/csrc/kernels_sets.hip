@@ -530,7 +530,21 @@ void resample_nn(hipStream_t s, const long long* nc, const long long* nf, const 
   SIPX_HIP(hipGetLastError());
 }
 
+// x = (x*rho + m) / (rho + 1.0) through the same device function k_yl applies for the distance term (prox_l2s!.jl:3-6)
+template <typename T>
+__global__ __launch_bounds__(BLOCK) void k_prox_l2s(long long n, T* __restrict__ x, const T* __restrict__ m, T rho) {
+  const ProxCtx<T> pc = make_prox<T>(PX_DIST, T(0), T(0), rho, nullptr);
+  for (long long e = (long long)blockIdx.x * BLOCK + threadIdx.x; e < n; e += (long long)gridDim.x * BLOCK)
+    x[e] = prox_apply<T>(pc, x[e], T(0), T(0), m[e], e);
+}
+template <typename T>
+void prox_l2s_dev(hipStream_t s, long long n, T* x, const T* m, T rho) {
+  hipLaunchKernelGGL((k_prox_l2s<T>), dim3(fit_grid(n, NB)), dim3(BLOCK), 0, s, n, x, m, rho);
+  SIPX_HIP(hipGetLastError());
+}
+
 #define SIPX_INST(T)                                                                                              \
+  template void prox_l2s_dev<T>(hipStream_t, long long, T*, const T*, T);                                         \
   template void resample_nn<T>(hipStream_t, const long long*, const long long*, const T*, T*);                   \
   template void K<T>::sum_uv(hipStream_t, long long, const T*, const T*, T*);                                      \
   template void K<T>::csr_spmv(hipStream_t, long long, const long long*, const long long*, const T*, const T*, T*);  \

@@ -248,6 +248,10 @@ template <typename T>
 void proj_apply_grid(hipStream_t s, const Grid& g, int nblk, const int* dir, long long len, T* v, int prox, T plo,
                      T phi, const T* lb, const T* ub, const ProjScalars<T>* ps);
 
+// x = prox_l2s(x, rho, m) element-wise (the distance term's prox, prox_l2s!.jl:3-6)
+template <typename T>
+void prox_l2s_dev(hipStream_t s, long long n, T* x, const T* m, T rho);
+
 // nearest-neighbour grid transfer (multilevel): out (shape nf) <- in (shape nc)
 template <typename T>
 void resample_nn(hipStream_t s, const long long* nc, const long long* nf, const T* in, T* out);

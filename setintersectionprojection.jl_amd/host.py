@@ -32,7 +32,7 @@ EXPORTED_SYMBOLS = [
     "sipx_apply_op", "sipx_apply_op_adj", "sipx_project", "sipx_get_Q", "sipx_time_spmv", "sipx_kernel_stats",
     "sipx_debug_proj", "sipx_resample_nn", "sipx_set_q_mode", "sipx_apply_Q",
     "sipx_stream",
-    "sipx_dev_rhs", "sipx_dev_x", "sipx_set_owned",
+    "sipx_dev_rhs", "sipx_dev_x", "sipx_set_owned", "sipx_get_rhs", "sipx_prox_l2s",
 ]
 
 SIPX_F32, SIPX_F64 = 0, 1
@@ -730,6 +730,12 @@ class Context:
         _chk(lib().sipx_download(self.h, _ptr(x), ptrs(l), ptrs(y)))
         return x, l, y
 
+    def get_rhs(self):
+        """rhs of the last rhs_compose (src/rhs_compose.jl:24-36), copied to the host."""
+        rhs = np.empty(self.Nx, self.TF)
+        _chk(lib().sipx_get_rhs(self.h, _ptr(rhs)))
+        return rhs
+
     def get_Q(self):
         d = C.c_int()
         offs = np.zeros(32, np.int64)
@@ -860,6 +866,17 @@ def cds_spmv(R, offsets, x, device=None):
     _chk(lib().sipx_cds_spmv(_dtype_code(TF), C.c_int64(R.shape[0]), int(R.shape[1]), _ptr(R),
                              off.ctypes.data_as(C.c_void_p), _ptr(x), _ptr(y), device))
     return y
+
+
+def prox_l2s(x, rho, m, device=None):
+    """x = (x*rho + m) / (rho + 1.0) in place (src/prox_l2s!.jl:3-6), on the device."""
+    device = _default_device if device is None else device
+    TF = x.dtype.type
+    if not x.flags.c_contiguous or m.dtype != x.dtype or m.shape != x.shape:
+        raise SipxError("prox_l2s: x and m must be contiguous vectors of one precision and length")
+    m = np.ascontiguousarray(m)
+    _chk(lib().sipx_prox_l2s(_dtype_code(TF), C.c_int64(x.size), _ptr(x), C.c_double(float(rho)), _ptr(m), device))
+    return x
 
 
 def resample_nn(a, nc, nf, device=None):

@@ -226,7 +226,35 @@ def test_projectors(sipx, TF):
     v = np.array([3, 3, 3, 3, -3, 1, 0, 0], TF)
     P = sipx.Projector(sipx.set_definitions("l1", "identity", 0.0, 5.0, ("matrix", "")), g, TF)
     assert np.allclose(P(v.copy()), O.project_l1_Duchi(v.copy(), TF(5.0)), rtol=1e-6)
-    # prox_l2s known answers (test/test_prox_l2s!.jl)
+
+
+@pytest.mark.parametrize("TF", [np.float32, np.float64])
+def test_prox_l1(sipx, TF):
+    """SIPX_PROJ_PROX_L1 == prox_l1!(x, rho): soft threshold at 1/rho (src/prox_l1!.jl:8-10, get_projector.jl:21-27)."""
+    g = sipx.compgrid((1.0, 1.0), (10, 10))
+    rng = np.random.default_rng(61)
+    for n, rho in ((5, 2.0), (1000, 0.7), (4099, 3.0), (200000, 11.0)):
+        v = (rng.standard_normal(n) * np.exp(rng.standard_normal(n))).astype(TF)
+        v[::7] = 0
+        P = sipx.Projector(sipx.set_definitions("prox_l1", "identity", 0.0, rho, ("matrix", "")), g, TF)
+        assert np.array_equal(P(v.copy()), O.prox_l1(v.copy(), TF(rho))), (n, rho)
+    # closed forms: threshold 1/rho = 1/2
+    P = sipx.Projector(sipx.set_definitions("prox_l1", "identity", 0.0, 2.0, ("matrix", "")), g, TF)
+    assert np.array_equal(P(np.array([3, -3, 0.25, -0.25, 0.5, 0], TF)), np.array([2.5, -2.5, 0, 0, 0, 0], TF))
+
+
+@pytest.mark.parametrize("TF", [np.float32, np.float64])
+def test_prox_l2s_known_answers(sipx, TF):
+    """test/test_prox_l2s!.jl:4-19 on the HIP path: rho = 0 returns m; (x, m, rho) = (2, 1, 3) gives 7/4; random inputs
+    bit for bit against the oracle (numerator in TF, division in Float64)."""
+    rng = np.random.default_rng(62)
+    x, m = rng.standard_normal(100).astype(TF), rng.standard_normal(100).astype(TF)
+    assert np.array_equal(sipx.prox_l2s(x.copy(), 0.0, m), m)                                  # :4-8
+    assert np.array_equal(sipx.prox_l2s(np.full(10, 2, TF), 3.0, np.ones(10, TF)), np.full(10, 7 / 4, TF))   # :15-19
+    for n, rho in ((1000, 0.3), (4099, 10.0), (200001, 1234.5)):
+        x = (1500 + 900 * rng.standard_normal(n)).astype(TF)
+        m = (1500 + 900 * rng.standard_normal(n)).astype(TF)
+        assert np.array_equal(sipx.prox_l2s(x.copy(), rho, m), O.prox_l2s(x.copy(), TF(rho), m)), (n, rho)
 
 
 @pytest.mark.parametrize("TF", [np.float32, np.float64])
@@ -292,9 +320,10 @@ def test_phases_lockstep(sipx, TF, n, h):
     os_.zero_ini_guess = False
     os_.rho_ini = [float(r) for r in rho]
     ctx = sipx.host.build_context(m, AtAs, As, props, Ps, gs, os_, x=x0, l=l0, y=y0)
-    # rhs_compose: bit exact
+    # rhs_compose: bit exact (src/rhs_compose.jl:24-36; every entry is a short sum of products added in set order)
     ctx.rhs_compose(rho)
     rhs = O.rhs_compose(l0, y0, rho, Ao, p, N)
+    assert np.array_equal(ctx.get_rhs(), rhs)
     # x-minimisation
     Qo, offo = O.assemble_Q(AtAo, propo.AtA_offsets, rho, TF)
     xo, it_o, relres_o, tol_o = O.argmin_x(Qo, rhs, x0.copy(), TF(1.0), 1, offo)
@@ -336,6 +365,8 @@ def test_phases_lockstep(sipx, TF, n, h):
         l_hat[ii][:] = l_old[ii] + TF(rho[ii]) * (-s[ii] + y_old[ii])
         l_hat_0[ii][:] = l_hat[ii]; y_0[ii][:] = y[ii]; s_0[ii][:] = s[ii]; l_0[ii][:] = l[ii]
     ctx.rhs_compose(rho)
+    rhs2 = O.rhs_compose(ls, ys, rho, Ao, p, N)          # from the engine's own y, l (the l1 set agrees to rounding only)
+    assert np.array_equal(ctx.get_rhs(), rhs2)
     rhs2 = O.rhs_compose(l, y, rho, Ao, p, N)
     x2, *_ = O.argmin_x(Qo, rhs2, xs.copy(), TF(tol), 2, offo)
     ctx.argmin_x(2, tol)
@@ -351,6 +382,7 @@ def test_phases_lockstep(sipx, TF, n, h):
 
 
 # ---- whole solve --------------------------------------------------------------------------------
+C4_KINDS = ["bounds", "l1:D_x", "l1:D_y", "l1:D_z", "annulus", "l1dft", "rank:3", "card:D_z"]
 CASES = [
     ("c1-2d-bounds-tv", (32, 24), (25.0, 6.0), ["bounds", "l1:TV"]),
     ("2d-bounds-dz-tv", (40, 28), (1.0, 1.0), ["bounds", "bnd:D_z", "l1:TV"]),
@@ -370,7 +402,37 @@ CASES = [
     ("3d-histogram-bounds-fiber", (16, 12, 8), (25.0, 25.0, 25.0), ["bndf:z", "hist"]),
     ("2d-subspace", (32, 24), (25.0, 6.0), ["bounds", "sub:z"]),
     ("3d-subspace-slice", (16, 12, 8), (25.0, 25.0, 25.0), ["bounds", "sub:x", "l1:D_z"]),
+    # BASELINE configs[3] (C4): the full 8-set list, two of the sets non-convex
+    ("c4-3d-eight-sets", (16, 12, 8), (25.0, 25.0, 25.0), C4_KINDS),
 ]
+
+
+# (case, dtype) -> (bound on the relative end-point difference, why).  Only cases whose rho traces separate are looked
+# up here; every other case is held to 5e-4 (Float32) / 1e-6 (Float64).
+DOCUMENTED_EXCEPTIONS = {
+    # Two non-convex sets (slice rank, cardinality): the Float32 rho traces separate at iteration 16 (a BB threshold
+    # flip), after which the cardinality projector keeps a different support in the two runs -- the problem has no
+    # unique solution and 60 iterations do not converge it.  Measured 3.9e-3.  In Float64 the same case stays in
+    # lock-step with the oracle for all 60 iterations and ends within 1e-6 (held to that by this very test).
+    ("c4-3d-eight-sets", "f32"): (1e-2, "non-convex sets, support of the cardinality projector differs after the separation"),
+}
+
+
+def _record_separation(key, sep, n_engine, n_oracle, err):
+    """Which parametrisations separate from the oracle's trace, and where: printed (pytest -rP / -s) and appended to
+    gpurun_out/parity_separations.jsonl so the list in DESIGN.md can be checked against a run."""
+    import json
+    import os
+    rec = {"case": key[0], "dtype": key[1], "first_iteration_with_different_rho_or_cg_it": None if sep is None else sep + 1,
+           "iterations_engine": n_engine, "iterations_oracle": n_oracle, "rel_diff_x": float(err)}
+    print("trace separation:", json.dumps(rec))
+    out = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
+    try:
+        os.makedirs(out, exist_ok=True)
+        with open(os.path.join(out, "parity_separations.jsonl"), "a") as f:
+            f.write(json.dumps(rec) + "\n")
+    except OSError:
+        pass
 
 
 @pytest.mark.parametrize("TF", [np.float32, np.float64])
@@ -403,17 +465,27 @@ def test_parsdmm_matches_oracle(sipx, TF, name, n, h, kinds):
         # once y lies in the subspace, P(s) - s is pure GEMM rounding noise and the BB ratios built from it differ between
         # two correct implementations; the traces agree for the first iterations (above) and the solutions to 1e-3
         tol64 = 1e-3
-    # The BB rule divides rounding noise by rounding noise once a set is exactly feasible (its multiplier is a rounding
-    # residue, so sum(dG*dl) / (|dG| |dl|) is the correlation of noise): whether that crosses the reliability threshold
-    # depends on the summation order of the reductions, in the reference as much as here.  The strict end-point
-    # tolerance applies while the rho traces never separate; otherwise both runs must still have arrived at the same
-    # point to within what the stopping rule resolves.
-    same = len(ls.obj) == len(lo.obj) and np.array_equal(ls.cg_it, lo.cg_it) and np.allclose(ls.rho, lo.rho, rtol=1e-5)
-    if same:
-        assert err < (5e-4 if TF == np.float32 else tol64), err
-    else:
-        assert err < 0.15, err
+    # Traces are compared up to the first iteration at which the two rho histories differ (a threshold flip of the BB
+    # rule: once a set is exactly feasible its multiplier is a rounding residue and sum(dG*dl) / (|dG| |dl|) is the
+    # correlation of noise, so which side of eps_correlation it falls on depends on the summation order of the
+    # reductions -- in the reference as much as here).  After a separation the end points must still agree to the
+    # reference's own serial-vs-parallel tolerance (test/test_PARSDMM_parallel.jl:72), unless the case is listed in
+    # DOCUMENTED_EXCEPTIONS with the reason and its own measured bound.
+    Kc = min(len(ls.obj), len(lo.obj))
+    sep = next((k for k in range(Kc) if ls.cg_it[k] != lo.cg_it[k] or not np.allclose(ls.rho[k], lo.rho[k], rtol=1e-5)), None)
+    upto = Kc if sep is None else sep
+    for f in ("obj", "r_pri_total", "rho", "gamma"):
+        a, b = np.asarray(getattr(ls, f))[:upto], np.asarray(getattr(lo, f))[:upto]
+        assert np.allclose(a, b, rtol=(2e-3 if TF == np.float32 else 1e-6), atol=1e-12), (f, upto)
+    key = (name, "f32" if TF == np.float32 else "f64")
+    tol = 5e-4 if TF == np.float32 else tol64
+    if sep is not None or len(ls.obj) != len(lo.obj):
+        tol = max(tol, 5e-4)
+        _record_separation(key, sep, len(ls.obj), len(lo.obj), err)
+        if key in DOCUMENTED_EXCEPTIONS:
+            tol = DOCUMENTED_EXCEPTIONS[key][0]
         assert julia_max(ls.set_feasibility[-1]) <= max(julia_max(lo.set_feasibility[-1]), float(os_.feas_tol))
+    assert err < tol, (key, sep, err)
     # log bookkeeping (PARSDMM.jl:261-278)
     it = len(ls.obj)
     p = len(kinds) + 1
@@ -1301,3 +1373,104 @@ def test_rank_projection_subspace_route(sipx, capfd, monkeypatch):
     assert np.linalg.norm(xs.astype(np.float64) - xo) / nrm < 1e-4
     K = min(len(ls.obj), len(lo.obj), 8)
     assert np.allclose(ls.obj[:K], lo.obj[:K], rtol=2e-3)
+
+
+# ---- BASELINE configs[3] (C4): 8 constraint sets, two of them non-convex ------------------------------------------------
+@pytest.mark.parametrize("TF", [np.float32, np.float64])
+def test_c4_nonconvex_switches_and_lockstep(sipx, TF):
+    """The full C4 set list {bounds, l1 D_x / D_y / D_z, annulus, l1-DFT, slice rank, cardinality on D_z} against the
+    oracle: a non-convex set switches the solve to rho_update_frequency = 3, gamma = 0.75 and adjust_gamma = false
+    (src/PARSDMM_initialize.jl:107-114) whatever the options say."""
+    n, h = (16, 12, 8), (25.0, 25.0, 25.0)
+    m = model(n, TF, seed=4)
+    kw = dict(maxit=45, rho_update_frequency=2, gamma_ini=1.0, adjust_gamma=True)
+    go, oo, Po, Ao, propo, AtAo = _problem(O, n, h, TF, C4_KINDS, m, kw)
+    gs, os_, Ps, As, props, AtAs = _problem(sipx, n, h, TF, C4_KINDS, m, kw)
+    assert list(props.ncvx) == list(propo.ncvx) and sum(bool(v) for v in props.ncvx) == 2       # rank, cardinality
+    xo, lo, _, _ = O.PARSDMM(m.copy(), AtAo, Ao, propo, Po, go, oo)
+    xs, ls, l_s, y_s = sipx.PARSDMM(m.copy(), AtAs, As, props, Ps, gs, os_)
+    it = len(ls.obj)
+    assert it > 12 and ls.r_pri.shape == (it, 9) and ls.set_feasibility.shape[1] == 8
+    assert np.all(ls.gamma == 0.75) and np.all(lo.gamma == 0.75)                  # gamma fixed, never adapted
+    # rho may only change after iterations that are multiples of 3 (BB rule) or of 10 beyond the 10th (feasibility
+    # doubling, src/PARSDMM.jl:213-223): row i+1 differs from row i only then
+    for log in (ls, lo):
+        for i in range(1, len(log.obj)):                       # i = 1-based number of the iteration that made the change
+            if not np.array_equal(log.rho[i], log.rho[i - 1]):
+                assert i % 3 == 0 or (i % 10 == 0 and i > 10), i
+    assert any(not np.array_equal(ls.rho[i], ls.rho[i - 1]) for i in range(1, it))      # and it does adapt
+    K = min(9, it, len(lo.obj))
+    rt = 5e-4 if TF == np.float32 else 1e-8
+    assert np.array_equal(ls.cg_it[:K], lo.cg_it[:K])
+    for f in ("obj", "r_pri", "r_dual", "rho", "gamma", "evol_x"):
+        a, b = np.asarray(getattr(ls, f))[:K], np.asarray(getattr(lo, f))[:K]
+        assert np.allclose(a, b, rtol=rt, atol=1e-10, equal_nan=True), (f, a, b)
+    assert np.allclose(ls.set_feasibility[0], lo.set_feasibility[0], rtol=rt, atol=1e-12)
+
+
+@pytest.mark.timeout(900)
+@pytest.mark.parametrize("n,maxit", [((256, 256, 256), 24), ((512, 512, 512), 12)])
+def test_full_size_c4_solver_properties(sipx, n, maxit):
+    """C4 at BASELINE's sizes (bench.py's c4-256 / c4 set lists, 512^3 = configs[3] itself): finite logs, the non-convex
+    switches, set feasibilities that come down, per-set vector lengths."""
+    import bench
+    TF = np.float32
+    kinds = bench.CONFIGS["c4"][2]
+    m = bench.synthetic_model(n, TF, 20240601 + 3)
+    gsx = sipx.compgrid((25.0, 25.0, 25.0), n)
+
+    def radius_of(opname):
+        sv = sipx.get_TD_operator(gsx, opname, TF)[0] @ m
+        return float(0.5 * np.abs(sv.astype(np.float64)).sum())
+    g, c = bench.build_problem(sipx, n, (25.0, 25.0, 25.0), kinds, m, TF, radius_of)
+    P, A, prop = sipx.setup_constraints(c, g, TF)
+    opt = sipx.PARSDMM_options(FL=TF, maxit=maxit, evol_rel_tol=0.0, feas_tol=0.0, obj_tol=0.0)
+    A, AtA, l, y = sipx.PARSDMM_precompute_distribute(A, prop, g, opt)
+    x, log, l, y = sipx.PARSDMM(m.copy(), AtA, A, prop, P, g, opt)
+    assert len(log.obj) == maxit and log.r_pri.shape == (maxit, 9) and log.set_feasibility.shape[1] == 8
+    for f in ("obj", "r_pri", "r_dual", "rho", "cg_relres"):
+        assert np.isfinite(np.asarray(getattr(log, f))).all(), f
+    assert np.isfinite(log.evol_x[1:]).all() and np.isfinite(x).all()
+    assert np.all(log.gamma == 0.75)
+    for i in range(1, maxit):
+        if not np.array_equal(log.rho[i], log.rho[i - 1]):
+            assert i % 3 == 0 or (i % 10 == 0 and i > 10), i
+    f0, f1 = log.set_feasibility[0], log.set_feasibility[1]          # initial, and after 10 iterations
+    assert np.isfinite(f1).all()
+    # decreasing feasibility: the worst set improves, and so do at least six of the eight (the annulus is entered from
+    # inside its outer radius and moves outward first: 0.020 -> 0.032 at both sizes)
+    assert julia_max(f1) < julia_max(f0) and (f1 < f0).sum() >= 6, (f0, f1)
+    assert [len(v) for v in y] == [op.shape[0] for op in A]
+
+
+# ---- a second solve on one context after a stop-rule exit (sequential solves per handle, include/sipx.h) ----------------
+def test_second_solve_after_stop_rule_exit_continues_with_the_current_rho(sipx):
+    """After a stop-rule exit Q holds sum_i rho_last_i AtA_i; the next solve on the same context has to start from that
+    rho (as after the maxit exit), i.e. equal a fresh context warm-started from the downloaded x, l, y with rho_last."""
+    TF, n, h = np.float64, (24, 20, 12), (25.0, 25.0, 25.0)
+    kinds = ["bounds", "bnd:D_z", "bnd:D_x"]                       # element-wise sets: no order-dependent reductions in y, l
+    m = model(n, TF, seed=11)
+    for stop_kw in (dict(maxit=200, evol_rel_tol=2e-3), dict(maxit=9)):        # stop-rule exit, maxit exit
+        gs, os_, Ps, As, props, AtAs = _problem(sipx, n, h, TF, kinds, m, dict(adjust_gamma=False, **stop_kw))
+        ctx = sipx.host.build_context(m, AtAs, As, props, Ps, gs, os_)
+        log1, _ = ctx.parsdmm(os_)
+        if "evol_rel_tol" in stop_kw:
+            assert 6 < len(log1.obj) < 200                                      # it was the stop rule
+        x1, l1, y1 = ctx.download()
+        rho_last = np.array(log1.rho[-1])
+        assert not np.allclose(rho_last, 10.0)                                   # rho did move away from rho_ini
+        o2 = sipx.PARSDMM_options(FL=TF, maxit=8, evol_rel_tol=0.0, feas_tol=0.0, obj_tol=0.0, adjust_gamma=False)
+        log2, _ = ctx.parsdmm(o2)
+        x2, _, _ = ctx.download()
+        ctx.close()
+        if "evol_rel_tol" in stop_kw:
+            assert np.array_equal(log2.rho[0], rho_last)
+        o3 = sipx.PARSDMM_options(FL=TF, maxit=8, evol_rel_tol=0.0, feas_tol=0.0, obj_tol=0.0, adjust_gamma=False,
+                                  zero_ini_guess=False, rho_ini=[float(r) for r in np.array(log2.rho[0])])
+        ctx3 = sipx.host.build_context(m, AtAs, As, props, Ps, gs, o3, x=x1, l=l1, y=y1)
+        log3, _ = ctx3.parsdmm(o3)
+        x3, _, _ = ctx3.download()
+        ctx3.close()
+        assert np.array_equal(log2.cg_it, log3.cg_it)
+        assert np.allclose(log2.obj, log3.obj, rtol=1e-9) and np.allclose(log2.r_pri, log3.r_pri, rtol=1e-6, atol=1e-12)
+        assert np.linalg.norm(x2 - x3) <= 1e-9 * np.linalg.norm(x3)
