@@ -218,6 +218,46 @@ int sipx_prox_l2s(int dtype, int64_t n, void* x, double rho, const void* m, int 
 /* restricts y/l work and rhs contributions to sets with owner[i] != 0 (set sharding); Q stays global */
 int sipx_set_owned(sipx_ctx* ctx, const int32_t* owned);
 
+/* ---- sharded solve: one process per GPU ----
+ * Replaces the reference's parallel mode (one Julia worker per set, src/PARSDMM.jl:114-131,183-197; the (+) reduction of
+ * the partial right-hand sides, src/rhs_compose.jl:17-20; x shipped to every worker, src/update_y_l_parallel.jl:6-90).
+ * With a communicator attached (before sipx_finalize) a context is one RANK of the solve:
+ *   - the y/l work and the rhs contributions of the sets are split over the ranks (sipx_set_owned; default: set i on rank
+ *     i mod world),
+ *   - sipx_rhs_compose ends with a reduce-scatter of the partial rhs by z-slab (slabs of ceil(n_last / world) planes),
+ *   - sipx_argmin_x runs CG on the rank's slab of rows of Q (one halo plane from each neighbour per product, the dot
+ *     products through an all-reduce of the float64 block partials) and ends with an all-gather of x,
+ *   - sipx_update_y_l ends with one all-reduce of the packed per-set sums, so every rank returns the r_pri / r_dual /
+ *     feasibility of every set and takes the same rho / gamma / stop decisions; sipx_parsdmm runs the whole loop that way.
+ * Every rank must make the same sequence of calls.  Q is maintained for the slab rows only (sipx_get_Q refuses), x is
+ * complete on every rank, y_i / l_i live on the owner.  Not available with Minkowski components, the stencil form of Q or
+ * operators whose A'A reaches further than one plane of the grid.
+ *
+ * sipx_set_comm_rccl: collectives by RCCL on the engine's own streams.  id128 = the 128-byte ncclUniqueId that rank 0
+ * obtained from sipx_rccl_unique_id and the host side handed to every rank (torch.distributed store, MPI, a file ...). */
+int sipx_rccl_unique_id(void* id128);
+int sipx_set_comm_rccl(sipx_ctx* ctx, const void* id128, int world, int rank);
+/* sipx_set_comm: the same operations supplied by the caller.  Each callback enqueues its operation on `stream`
+ * (a hipStream_t; or completes it before returning) and returns 0 on success; dtype is SIPX_F32 / SIPX_F64; all buffers are
+ * device memory.  In place on `buf` of world * chunk elements:
+ *   allreduce_sum:      buf[0 .. count) <- sum over ranks (identical bits on every rank)
+ *   reduce_scatter_sum: buf[rank*chunk .. (rank+1)*chunk) <- sum over ranks of that range
+ *   allgather:          buf[r*chunk .. (r+1)*chunk) <- that range of rank r, for every r
+ *   halo_exchange:      send `count` elements to, and receive as many from, rank prev and rank next (-1 = no neighbour) */
+typedef struct {
+  void* user;
+  int32_t world, rank;
+  int (*allreduce_sum)(void* user, void* buf, int64_t count, int32_t dtype, void* stream);
+  int (*reduce_scatter_sum)(void* user, void* buf, int64_t chunk, int32_t dtype, void* stream);
+  int (*allgather)(void* user, void* buf, int64_t chunk, int32_t dtype, void* stream);
+  int (*halo_exchange)(void* user, const void* send_prev, void* recv_prev, int32_t prev, const void* send_next, void* recv_next,
+                       int32_t next, int64_t count, int32_t dtype, void* stream);
+} sipx_comm;
+int sipx_set_comm(sipx_ctx* ctx, const sipx_comm* comm);
+/* this rank's slab of the x-step: rows [row0, row1) of Q / entries of x, and the elements per rank (chunk) of the padded
+ * exchange buffers; without a communicator row0 = 0, row1 = chunk = N */
+int sipx_slab(sipx_ctx* ctx, int64_t* row0, int64_t* row1, int64_t* chunk);
+
 /* How the x-step applies Q = sum_i rho_i A_i'A_i.  SIPX_Q_CDS (default): explicit bands in CDS storage, the
  * reference's arithmetic (PARSDMM_initialize.jl:216-230, CDS_MVp_MT.jl:9-25, Q_update!.jl:45-48), (d+2) N w bytes per
  * product.  SIPX_Q_STENCIL ("beyond CDS"): coefficients generated from rho_i, h and the boundary

@@ -2,6 +2,7 @@
 // every entry returns 0 / non-zero and leaves the text in sipx_last_error().
 #include <string>
 
+#include "comm.h"
 #include "engine.h"
 
 struct sipx_ctx {
@@ -108,6 +109,17 @@ int sipx_prox_l2s(int dtype, int64_t n, void* x, double rho, const void* m, int 
   SIPX_TRY(sipx::prox_l2s_host(dtype, n, x, rho, m, device))
 }
 int sipx_set_owned(sipx_ctx* c, const int32_t* owned) { SIPX_TRY(c->e->set_owned(owned)) }
+int sipx_rccl_unique_id(void* id128) { SIPX_TRY(sipx::rccl_unique_id(id128)) }
+int sipx_set_comm_rccl(sipx_ctx* c, const void* id128, int world, int rank) {
+  SIPX_TRY(c->e->set_comm(sipx::make_rccl_comm(id128, world, rank)))
+}
+int sipx_set_comm(sipx_ctx* c, const sipx_comm* comm) {
+  SIPX_TRY({
+    if (!comm) throw std::runtime_error("null communicator");
+    c->e->set_comm(sipx::make_callback_comm(comm));
+  })
+}
+int sipx_slab(sipx_ctx* c, int64_t* row0, int64_t* row1, int64_t* chunk) { SIPX_TRY(c->e->slab(row0, row1, chunk)) }
 int sipx_set_q_mode(sipx_ctx* c, int mode) { SIPX_TRY(c->e->set_q_mode(mode)) }
 int sipx_apply_Q(sipx_ctx* c, const void* x, void* y) { SIPX_TRY(c->e->apply_Q(x, y)) }
 

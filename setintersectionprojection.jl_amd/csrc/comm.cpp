@@ -1,0 +1,163 @@
+// Collectives of the sharded solve: RCCL (native, over xGMI) and caller-supplied callbacks.  See comm.h.
+#include "comm.h"
+
+#include <dlfcn.h>
+#include <rccl/rccl.h>
+
+#include <cstring>
+#include <mutex>
+#include <stdexcept>
+#include <string>
+
+namespace sipx {
+
+namespace {
+
+// librccl.so.1 is looked up at run time: the dynamic loader hands back the copy that is already mapped when the host
+// process has one (PyTorch ships its own under the same soname, next to the HIP runtime it was built against), so the
+// engine never mixes two RCCL builds; a process that never shards never loads the library at all.
+struct RcclApi {
+  void* h = nullptr;
+  decltype(&ncclGetUniqueId) GetUniqueId = nullptr;
+  decltype(&ncclCommInitRank) CommInitRank = nullptr;
+  decltype(&ncclCommDestroy) CommDestroy = nullptr;
+  decltype(&ncclAllReduce) AllReduce = nullptr;
+  decltype(&ncclReduceScatter) ReduceScatter = nullptr;
+  decltype(&ncclAllGather) AllGather = nullptr;
+  decltype(&ncclSend) Send = nullptr;
+  decltype(&ncclRecv) Recv = nullptr;
+  decltype(&ncclGroupStart) GroupStart = nullptr;
+  decltype(&ncclGroupEnd) GroupEnd = nullptr;
+  decltype(&ncclGetErrorString) GetErrorString = nullptr;
+};
+
+const RcclApi& rccl() {
+  static RcclApi api;
+  static std::once_flag once;
+  std::call_once(once, [] {
+    for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
+      api.h = dlopen(name, RTLD_NOW | RTLD_LOCAL);
+      if (api.h) break;
+    }
+    if (!api.h) return;
+    auto sym = [&](auto& fn, const char* n) { fn = reinterpret_cast<std::decay_t<decltype(fn)>>(dlsym(api.h, n)); };
+    sym(api.GetUniqueId, "ncclGetUniqueId");
+    sym(api.CommInitRank, "ncclCommInitRank");
+    sym(api.CommDestroy, "ncclCommDestroy");
+    sym(api.AllReduce, "ncclAllReduce");
+    sym(api.ReduceScatter, "ncclReduceScatter");
+    sym(api.AllGather, "ncclAllGather");
+    sym(api.Send, "ncclSend");
+    sym(api.Recv, "ncclRecv");
+    sym(api.GroupStart, "ncclGroupStart");
+    sym(api.GroupEnd, "ncclGroupEnd");
+    sym(api.GetErrorString, "ncclGetErrorString");
+  });
+  if (!api.h || !api.GetUniqueId || !api.CommInitRank || !api.CommDestroy || !api.AllReduce || !api.ReduceScatter ||
+      !api.AllGather || !api.Send || !api.Recv || !api.GroupStart || !api.GroupEnd)
+    throw std::runtime_error("libsipx: librccl.so.1 could not be loaded -- the sharded solve needs RCCL");
+  return api;
+}
+
+void nccl_check(ncclResult_t r, const char* what) {
+  if (r == ncclSuccess) return;
+  const RcclApi& a = rccl();
+  throw std::runtime_error(std::string(what) + ": " + (a.GetErrorString ? a.GetErrorString(r) : "RCCL error"));
+}
+
+inline ncclDataType_t nccl_type(int dtype) { return dtype == SIPX_F64 ? ncclDouble : ncclFloat; }
+inline size_t type_size(int dtype) { return dtype == SIPX_F64 ? 8 : 4; }
+
+class RcclComm : public Comm {
+ public:
+  RcclComm(const void* id, int world_, int rank_) {
+    world = world_;
+    rank = rank_;
+    if (world < 1 || rank < 0 || rank >= world) throw std::runtime_error("RCCL communicator: rank / world out of range");
+    ncclUniqueId uid;
+    std::memcpy(&uid, id, sizeof(uid));
+    nccl_check(rccl().CommInitRank(&comm_, world, uid, rank), "ncclCommInitRank");
+  }
+  ~RcclComm() override {
+    if (comm_) (void)rccl().CommDestroy(comm_);
+  }
+  const char* kind() const override { return "rccl"; }
+  void allreduce_sum(void* buf, size_t count, int dtype, hipStream_t s) override {
+    nccl_check(rccl().AllReduce(buf, buf, count, nccl_type(dtype), ncclSum, comm_, s), "ncclAllReduce");
+  }
+  void reduce_scatter_sum(void* buf, size_t chunk, int dtype, hipStream_t s) override {
+    // in place: recvbuff == sendbuff + rank * recvcount
+    char* b = static_cast<char*>(buf);
+    nccl_check(rccl().ReduceScatter(b, b + (size_t)rank * chunk * type_size(dtype), chunk, nccl_type(dtype), ncclSum, comm_, s),
+               "ncclReduceScatter");
+  }
+  void allgather(void* buf, size_t chunk, int dtype, hipStream_t s) override {
+    // in place: sendbuff == recvbuff + rank * sendcount
+    char* b = static_cast<char*>(buf);
+    nccl_check(rccl().AllGather(b + (size_t)rank * chunk * type_size(dtype), b, chunk, nccl_type(dtype), comm_, s), "ncclAllGather");
+  }
+  void halo_exchange(const void* send_prev, void* recv_prev, int prev, const void* send_next, void* recv_next, int next,
+                     size_t count, int dtype, hipStream_t s) override {
+    if (prev < 0 && next < 0) return;
+    const RcclApi& a = rccl();
+    // one group: the four transfers (two per neighbour) progress together over the direct xGMI links
+    nccl_check(a.GroupStart(), "ncclGroupStart");
+    if (prev >= 0) {
+      nccl_check(a.Send(send_prev, count, nccl_type(dtype), prev, comm_, s), "ncclSend");
+      nccl_check(a.Recv(recv_prev, count, nccl_type(dtype), prev, comm_, s), "ncclRecv");
+    }
+    if (next >= 0) {
+      nccl_check(a.Send(send_next, count, nccl_type(dtype), next, comm_, s), "ncclSend");
+      nccl_check(a.Recv(recv_next, count, nccl_type(dtype), next, comm_, s), "ncclRecv");
+    }
+    nccl_check(a.GroupEnd(), "ncclGroupEnd");
+  }
+
+ private:
+  ncclComm_t comm_ = nullptr;
+};
+
+class CallbackComm : public Comm {
+ public:
+  explicit CallbackComm(const sipx_comm* cb) : cb_(*cb) {
+    world = cb->world;
+    rank = cb->rank;
+    if (world < 1 || rank < 0 || rank >= world) throw std::runtime_error("sipx_comm: rank / world out of range");
+    if (!cb->allreduce_sum || !cb->reduce_scatter_sum || !cb->allgather || !cb->halo_exchange)
+      throw std::runtime_error("sipx_comm: every operation must be supplied");
+  }
+  const char* kind() const override { return "callback"; }
+  void allreduce_sum(void* buf, size_t count, int dtype, hipStream_t s) override {
+    chk(cb_.allreduce_sum(cb_.user, buf, (int64_t)count, dtype, (void*)s), "allreduce_sum");
+  }
+  void reduce_scatter_sum(void* buf, size_t chunk, int dtype, hipStream_t s) override {
+    chk(cb_.reduce_scatter_sum(cb_.user, buf, (int64_t)chunk, dtype, (void*)s), "reduce_scatter_sum");
+  }
+  void allgather(void* buf, size_t chunk, int dtype, hipStream_t s) override {
+    chk(cb_.allgather(cb_.user, buf, (int64_t)chunk, dtype, (void*)s), "allgather");
+  }
+  void halo_exchange(const void* send_prev, void* recv_prev, int prev, const void* send_next, void* recv_next, int next,
+                     size_t count, int dtype, hipStream_t s) override {
+    if (prev < 0 && next < 0) return;
+    chk(cb_.halo_exchange(cb_.user, send_prev, recv_prev, prev, send_next, recv_next, next, (int64_t)count, dtype, (void*)s),
+        "halo_exchange");
+  }
+
+ private:
+  static void chk(int rc, const char* what) {
+    if (rc != 0) throw std::runtime_error(std::string("sipx_comm callback failed: ") + what);
+  }
+  sipx_comm cb_;
+};
+
+}  // namespace
+
+Comm* make_rccl_comm(const void* unique_id, int world, int rank) { return new RcclComm(unique_id, world, rank); }
+void rccl_unique_id(void* out128) {
+  ncclUniqueId id;
+  nccl_check(rccl().GetUniqueId(&id), "ncclGetUniqueId");
+  std::memcpy(out128, &id, sizeof(id));
+}
+Comm* make_callback_comm(const sipx_comm* cb) { return new CallbackComm(cb); }
+
+}  // namespace sipx

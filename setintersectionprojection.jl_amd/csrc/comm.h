@@ -1,0 +1,38 @@
+// Collectives of the sharded solve.  The reference's parallel mode moves data between Julia workers through
+// DistributedArrays / @spawnat (src/PARSDMM.jl:114-131, src/rhs_compose.jl:17-20, src/update_y_l_parallel.jl:6-90); here one
+// process drives one GPU and the engine itself enqueues the collectives on its HIP streams:
+//   * RcclComm     -- RCCL (librccl.so.1, looked up with dlopen so that a single-GPU user never loads it) over xGMI: the
+//                     production path, communicator built from an ncclUniqueId the host side distributes;
+//   * CallbackComm -- the same three operations supplied by the caller as C function pointers (sipx_comm in sipx.h): what
+//                     the test harness uses to run several ranks on one GPU over gloo, and what a host that already owns a
+//                     communicator (torch.distributed, MPI) would plug in.
+// All operations are IN PLACE on a buffer of world * chunk elements and are enqueued on the given stream.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stddef.h>
+
+#include "../../include/sipx.h"
+
+namespace sipx {
+
+struct Comm {
+  int world = 1, rank = 0;
+  virtual ~Comm() {}
+  virtual const char* kind() const = 0;
+  // buf[0 .. count) <- sum over ranks, identical bits on every rank
+  virtual void allreduce_sum(void* buf, size_t count, int dtype, hipStream_t s) = 0;
+  // buf[rank*chunk .. (rank+1)*chunk) <- sum over ranks of that range; the rest of buf is scratch afterwards
+  virtual void reduce_scatter_sum(void* buf, size_t chunk, int dtype, hipStream_t s) = 0;
+  // buf[r*chunk .. (r+1)*chunk) <- rank r's range, for every r
+  virtual void allgather(void* buf, size_t chunk, int dtype, hipStream_t s) = 0;
+  // neighbour exchange of the slab CG: send `count` elements to / receive from rank `prev` and rank `next` (-1: no such
+  // neighbour); the four buffers are distinct device ranges
+  virtual void halo_exchange(const void* send_prev, void* recv_prev, int prev, const void* send_next, void* recv_next, int next,
+                             size_t count, int dtype, hipStream_t s) = 0;
+};
+
+Comm* make_rccl_comm(const void* unique_id, int world, int rank);
+void rccl_unique_id(void* out128);
+Comm* make_callback_comm(const sipx_comm* cb);
+
+}  // namespace sipx

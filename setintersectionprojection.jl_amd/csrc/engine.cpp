@@ -2,6 +2,7 @@
 // kernels phase by phase, in the order of the reference's main loop (src/PARSDMM.jl:97-254).
 // No CPU fallback exists: every numerical step below is a kernel launch.
 #include "engine.h"
+#include "comm.h"
 #include "ext_proj.h"
 
 #include <algorithm>
@@ -173,8 +174,14 @@ class Engine : public EngineBase {
     for (auto& s : sets_) free_set(s);
     for (void* p : {(void*)w_base_, (void*)x_base_, (void*)xold_, (void*)rhs_, (void*)m_base_, (void*)r_, (void*)p_base_, (void*)Ap_, (void*)Q_,
                     (void*)scr_v_, (void*)scr_c_, (void*)scr_i_, (void*)scr_w_, (void*)part_cg_, (void*)part_tmp_, (void*)part_sets_,
-                    (void*)maxpart_, (void*)cg_dev_})
+                    (void*)maxpart_, (void*)cg_dev_, (void*)dres_})
       dfree(p);
+    comm_.reset();
+    if (cstream_) (void)hipStreamDestroy(cstream_);
+    for (auto e : ev_c_) if (e) (void)hipEventDestroy(e);
+    if (ev_sums_) (void)hipEventDestroy(ev_sums_);
+    if (ev_cgb_) (void)hipEventDestroy(ev_cgb_);
+    if (ticket_) (void)hipHostFree((void*)ticket_);
     if (cg_host_) (void)hipHostFree(cg_host_);
     if (hres_) (void)hipHostFree(hres_);
     for (auto e : ev_) (void)hipEventDestroy(e);
@@ -221,6 +228,18 @@ class Engine : public EngineBase {
     owned_.assign(owned, owned + sets_.size() + 1);
   }
 
+  void set_comm(Comm* c) override {
+    std::unique_ptr<Comm> hold(c);
+    if (finalized_) throw std::runtime_error("the communicator must be attached before sipx_finalize");
+    comm_ = std::move(hold);
+  }
+  void slab(int64_t* row0, int64_t* row1, int64_t* chunk) override {
+    need_final();
+    if (row0) *row0 = r0_;
+    if (row1) *row1 = r1_;
+    if (chunk) *chunk = comm_ ? chunk_ : Nx_;
+  }
+
   void set_q_mode(int mode) override {
     if (finalized_) throw std::runtime_error("sipx_set_q_mode must precede sipx_finalize");
     if (mode != SIPX_Q_CDS && mode != SIPX_Q_STENCIL) throw std::runtime_error("unknown Q mode");
@@ -258,6 +277,14 @@ class Engine : public EngineBase {
     Nx_ = mk_ ? 2 * G_.N : G_.N;
     if (Nx_ >= (1ll << 31)) throw std::runtime_error("2^31 unknowns or more are not supported");
     if (p_n_ > 99) throw std::runtime_error("at most 99 sets (PARSDMM_initialize.jl:217)");
+    if (comm_) {                            // this context is one rank of a sharded solve
+      if (mk_) throw std::runtime_error("the sharded solve is not available for Minkowski sets");
+      if (stencil_q_) throw std::runtime_error("the sharded solve needs the CDS form of Q");
+      if (owned_.empty()) {                 // PARSDMM_initialize.jl:78-80 deals one set per worker; here round robin
+        owned_.resize(p_n_);
+        for (int i = 0; i < p_n_; ++i) owned_[i] = (i % comm_->world) == comm_->rank;
+      }
+    }
     if (!owned_.empty())
       for (int i = 0; i < p_n_; ++i) sets_[i].owned = owned_[i] != 0;
     const long long N = G_.N;
@@ -280,9 +307,33 @@ class Engine : public EngineBase {
     for (int b = 0; b < cds_.d; ++b) halo_ = std::max<long long>(halo_, std::llabs(cds_.off[b]));
     for (int a = 0; a < 3; ++a) halo_ = std::max<long long>(halo_, G_.st[a]);
     halo_ = (halo_ + 3) / 4 * 4;
-    x_base_ = dalloc<T>(Nx_ + 2 * halo_); x_ = x_base_ + halo_;
+    r0_ = 0; r1_ = Nx_;
+    long long Npad = Nx_;
+    if (comm_) {
+      // z-slabs of the x-step: ceil(n_last / world) planes per rank (the last ranks may hold fewer, or none); the exchange
+      // buffers (rhs, x) are padded to world equal chunks, the pad stays zero
+      const long long nlast = G_.n[ndim_ - 1];
+      plane_ = N / nlast;
+      long long maxoff = 0;
+      for (int b = 0; b < cds_.d; ++b) maxoff = std::max<long long>(maxoff, std::llabs(cds_.off[b]));
+      if (maxoff > plane_) throw std::runtime_error("the sharded solve needs operators whose A'A reaches no further than one plane of the grid");
+      const long long planes = (nlast + comm_->world - 1) / comm_->world;
+      chunk_ = planes * plane_;
+      Npad = chunk_ * comm_->world;
+      r0_ = std::min<long long>(N, (long long)comm_->rank * chunk_);
+      r1_ = std::min<long long>(N, (long long)(comm_->rank + 1) * chunk_);
+      prev_ = (r0_ > 0 && r0_ < N) ? comm_->rank - 1 : -1;
+      next_ = (r1_ < N && r1_ > r0_) ? comm_->rank + 1 : -1;
+      qr0_ = r1_ > r0_ ? std::max<long long>(0, r0_ - maxoff) : 0;      // the symmetric read reaches |offset| rows back
+      qr1_ = r1_ > r0_ ? r1_ : 0;
+      SIPX_HIP(hipStreamCreateWithFlags(&cstream_, hipStreamNonBlocking));
+      for (auto& e : ev_c_) SIPX_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    } else {
+      qr0_ = 0; qr1_ = N;
+    }
+    x_base_ = dalloc<T>(Npad + 2 * halo_); x_ = x_base_ + halo_;
     p_base_ = dalloc<T>(Nx_ + 2 * halo_); p_ = p_base_ + halo_;
-    xold_ = dalloc<T>(Nx_); rhs_ = dalloc<T>(Nx_);
+    xold_ = dalloc<T>(Nx_); rhs_ = dalloc<T>(Npad);
     if (mk_) { w_base_ = dalloc<T>(N + 2 * halo_); w_ = w_base_ + halo_; }   // u + v, read through the stencils
     m_base_ = dalloc<T>(N + 2 * halo_); m_ = m_base_ + halo_;   // forward stencils of A m read past the end
     r_ = dalloc<T>(Nx_); Ap_ = dalloc<T>(Nx_);
@@ -298,12 +349,17 @@ class Engine : public EngineBase {
     part_sets_ = dalloc<double>((size_t)(p_n_ + 1) * SLOTS * NB);   // + one group of slots for whole-x sums
     maxpart_ = dalloc<T>(2 * NB);     // per-block max | per-block smallest non-zero magnitude
     cg_dev_ = dalloc<CgState<T>>(1);
+    dres_ = dalloc<double>((size_t)(p_n_ + 1) * SLOTS);
     SIPX_HIP(hipHostMalloc((void**)&cg_host_, 2 * sizeof(CgState<T>), hipHostMallocDefault));
     std::memset(cg_host_, 0, 2 * sizeof(CgState<T>));
+    SIPX_HIP(hipHostMalloc((void**)&ticket_, 64, hipHostMallocDefault));
+    std::memset((void*)ticket_, 0xff, 64);
     for (int k = 0; k < 2; ++k) SIPX_HIP(hipEventCreateWithFlags(&cg_ev_[k], hipEventDisableTiming));
+    SIPX_HIP(hipEventCreateWithFlags(&ev_cgb_, hipEventDisableTiming));
+    SIPX_HIP(hipEventCreateWithFlags(&ev_sums_, hipEventDisableTiming));
     SIPX_HIP(hipHostMalloc((void**)&hres_, sizeof(double) * (p_n_ + 1) * SLOTS, hipHostMallocDefault));
     std::memset(hres_, 0, sizeof(double) * (p_n_ + 1) * SLOTS);
-    for (int k = 0; k < 16; ++k) {      // two sets of section marks: a step never waits for its own timing
+    for (int k = 0; k < 2 * 2 * NSEC; ++k) {      // two sets of section marks: a step never waits for its own timing
       hipEvent_t e;
       SIPX_HIP(hipEventCreate(&e));
       ev_.push_back(e);
@@ -406,10 +462,10 @@ class Engine : public EngineBase {
         proj_dist_grid<T>(stream_, G_, s.nblk, s.dir, s.Mpad, scr_v_, s.prox, s.plo, s.phi, s.lb, s.ub, nullptr, dst);
       }
     }
-    K<T>::fin_sum(stream_, part_sets_, p_n_ * SLOTS, nullptr, hres_);
+    reduce_set_sums(p_n_ * SLOTS);
     SIPX_HIP(hipStreamSynchronize(stream_));
     for (int i = 0; i < pp_n_; ++i) {
-      if (!sets_[i].owned) continue;
+      if (!sets_[i].owned && !comm_) continue;     // sharded: the all-reduced sums of every set are here
       feas_init_[i] = (double)feas_value(hres_[i * SLOTS + SL_FE2], hres_[i * SLOTS + SL_SS2]);
     }
     if (feasibility_initial)
@@ -463,49 +519,77 @@ class Engine : public EngineBase {
       if (s.owned && s.custom)
         K<T>::csc_adj_rhs(stream_, G_.N, s.d_colptr, s.d_rowval, s.d_nzval, s.y, s.l, (T)rho[i], rhs_, 1);
     }
+    if (comm_) {
+      // the (+) reduction of the partial right-hand sides (rhs_compose.jl:17-20), delivered by z-slab: every rank receives
+      // the rows its part of the x-step needs.  It runs on the communication stream; whatever the engine stream is given
+      // next (the Q update, the log-only kernels of the previous y/l update) overlaps with it, argmin_x joins.
+      SIPX_HIP(hipEventRecord(ev_c_[0], stream_));
+      SIPX_HIP(hipStreamWaitEvent(cstream_, ev_c_[0], 0));
+      comm_->reduce_scatter_sum(rhs_, (size_t)chunk_, dtype_code(), cstream_);
+      SIPX_HIP(hipEventRecord(ev_c_[1], cstream_));
+      rs_pending_ = true;
+    }
   }
 
   void argmin_x(int it, double* tol_ref_io, int64_t* cg_it, double* cg_relres, int* cg_flag) override {
     need_final();
+    if (rs_pending_) {                       // the reduce-scatter of rhs (communication stream) has to have landed
+      SIPX_HIP(hipStreamWaitEvent(stream_, ev_c_[1], 0));
+      rs_pending_ = false;
+    }
+    const long long r0 = r0_, r1 = r1_, nloc = r1 - r0;      // rows of this rank's part of the x-step (all of them unless sharded)
+    const int dt = dtype_code();
     // the initial residual goes straight into the p buffer (p_1 = r_0, cg.jl:57): the first iteration reads it from there
     // as both r and p and writes r_1 into the r buffer, so the copy p <- r is never made
     if (stencil_q_) K<T>::sq_resid(stream_, G_, sq_, x_, rhs_, p_, (T*)nullptr, xold_, part_cg_);
-    else K<T>::resid(stream_, Nx_, Q_, cds_, x_, rhs_, p_, (T*)nullptr, xold_, part_cg_);
-    K<T>::cg_begin(stream_, part_cg_, cg_dev_, cg_host_, it, (T)*tol_ref_io);
-    SIPX_HIP(hipStreamSynchronize(stream_));
-    if (cg_host_->flag == -9) SIPX_HIP(hipMemsetAsync(x_, 0, Nx_ * sizeof(T), stream_));   // cg.jl:51
-    // CG iterations run one ahead of the host: iteration k+1 is enqueued before the outcome of k is known.
-    // Every kernel returns at once when the device-side `done` flag is set, so a speculative iteration
-    // past convergence costs three empty launches and the GPU never idles on a host round trip.
-    // The state is mirrored into two pinned slots by iteration parity (no torn reads).
+    else K<T>::resid(stream_, Nx_, r0, r1, Q_, cds_, x_, rhs_, p_, (T*)nullptr, xold_, part_cg_);
+    if (comm_) comm_->allreduce_sum(part_cg_, 2 * NB, SIPX_F64, stream_);      // ||r_0||^2, ||rhs||^2 block partials
+    const unsigned seq = ++cg_seq_;
+    K<T>::cg_begin(stream_, part_cg_, cg_dev_, cg_host_, it, (T)*tol_ref_io, seq, (unsigned long long*)ticket_);
+    SIPX_HIP(hipEventRecord(ev_cgb_, stream_));
+    // One CG iteration = (halo planes of p from the neighbours) -> product + p.Ap -> x, r update + ||r||^2 -> p update.
+    // The host enqueues iteration k+1 as soon as the ticket word says that k did not converge, which workgroup 0 of the
+    // p-update publishes before it starts streaming: the GPU does not idle on the round trip and nothing is launched
+    // for an iteration that does not run.
     auto enqueue = [&](int k) {
       CgState<T>* mirror = cg_host_ + (k & 1);
+      if (comm_)
+        comm_->halo_exchange(p_ + r0, p_ + r0 - plane_, prev_, p_ + r1 - plane_, p_ + r1, next_, (size_t)plane_, dt, stream_);
       if (stats_on_) stat_mark();
       if (stencil_q_) K<T>::sq_spmv_dot(stream_, G_, sq_, p_, Ap_, part_cg_, cg_dev_);
-      else K<T>::spmv_dot(stream_, Nx_, Q_, cds_, p_, Ap_, part_cg_, cg_dev_);
+      else K<T>::spmv_dot(stream_, Nx_, r0, r1, Q_, cds_, p_, Ap_, part_cg_, cg_dev_);
       if (stats_on_) stat_mark();
-      K<T>::cg_update_xr(stream_, Nx_, x_, k == 1 ? p_ : r_, r_, p_, Ap_, part_cg_, cg_dev_, mirror, k);
-      K<T>::cg_update_p(stream_, Nx_, p_, r_, part_cg_, cg_dev_, mirror);
+      if (comm_) comm_->allreduce_sum(part_cg_, NB, SIPX_F64, stream_);
+      K<T>::cg_update_xr(stream_, nloc, x_ + r0, (k == 1 ? p_ : r_) + r0, r_ + r0, p_ + r0, Ap_ + r0, part_cg_, cg_dev_, mirror, k,
+                         (unsigned long long*)ticket_);
+      if (comm_) comm_->allreduce_sum(part_cg_ + NB, NB, SIPX_F64, stream_);
+      K<T>::cg_update_p(stream_, nloc, p_ + r0, r_ + r0, part_cg_, cg_dev_, mirror, (unsigned long long*)ticket_);
       SIPX_HIP(hipEventRecord(cg_ev_[k & 1], stream_));
     };
-    CgState<T> fin = cg_host_[0];
-    if (!fin.done) {
+    bool done = wait_ticket(seq, 0, ev_cgb_, cg_host_);
+    CgState<T> fin;
+    if (done) {
+      SIPX_HIP(hipEventSynchronize(ev_cgb_));
+      fin = cg_host_[0];
+      if (fin.flag == -9) SIPX_HIP(hipMemsetAsync(x_ + r0, 0, nloc * sizeof(T), stream_));   // cg.jl:51
+    } else {
       const int maxIter = 1000;                       // argmin_x.jl:39
       int iter = 1;
       enqueue(1);
       for (;;) {
-        const bool ahead = iter < maxIter;
-        if (ahead) enqueue(iter + 1);
-        SIPX_HIP(hipEventSynchronize(cg_ev_[iter & 1]));
-        fin = cg_host_[iter & 1];
-        if (fin.done || iter == maxIter) {
-          if (ahead && stats_on_ && stat_used_ >= 2) stat_used_ -= 2;   // the empty speculative launch is not a sample
-          break;
-        }
-        ++iter;
+        done = wait_ticket(seq, iter, cg_ev_[iter & 1], cg_host_ + (iter & 1));
+        if (done || iter == maxIter) break;
+        enqueue(++iter);
       }
+      SIPX_HIP(hipEventSynchronize(cg_ev_[iter & 1]));
+      fin = cg_host_[iter & 1];
     }
     cg_host_[0] = fin;
+    if (comm_) {
+      // obj / evol_x sums over the slab (x_old is only kept for the slab), then x is completed on every rank
+      K<T>::log3(stream_, nloc, x_ + r0, m_ + r0, xold_ + r0, part_sets_ + (size_t)p_n_ * SLOTS * NB);
+      comm_->allgather(x_, (size_t)chunk_, dt, stream_);
+    }
     *tol_ref_io = (double)cg_host_->tol_ref;
     *cg_it = cg_host_->iters;
     *cg_relres = (double)cg_host_->res_last;
@@ -574,14 +658,27 @@ class Engine : public EngineBase {
       if (sets_[i].owned && sets_[i].st) SIPX_HIP(hipStreamWaitEvent(stream_, sets_[i].ev, 0));
     // Minkowski: evol_x runs over all 2N unknowns (PARSDMM.jl:145); the distance-term kernel only saw u + v
     if (mk_) K<T>::log3(stream_, Nx_, x_, (const T*)nullptr, xold_, part_sets_ + (size_t)p_n_ * SLOTS * NB);
-    K<T>::fin_sum(stream_, part_sets_, (p_n_ + (mk_ ? 1 : 0)) * SLOTS, nullptr, hres_);
-    SIPX_HIP(hipStreamSynchronize(stream_));
+    reduce_set_sums((p_n_ + ((mk_ || comm_) ? 1 : 0)) * SLOTS);
+    SIPX_HIP(hipEventRecord(ev_sums_, stream_));
+    sums_flags_ = flags;
+    sums_pending_ = true;
+    if (!defer_sums_) collect_set_sums(rho, r_pri, r_dual, feas);
+  }
+
+  // second half of update_y_l: waits for the reduced sums and turns them into the per-set scalars.  The whole-solve loop
+  // calls it late (defer_sums_), after it has queued the work of the next iteration that cannot depend on them.
+  void collect_set_sums(const double* rho, double* r_pri, double* r_dual, double* feas) {
+    if (!sums_pending_) throw std::runtime_error("no y/l update is pending");
+    sums_pending_ = false;
+    const int flags = sums_flags_;
+    SIPX_HIP(hipEventSynchronize(ev_sums_));
     have_log_sums_ = false;
+    const bool all = comm_ != nullptr;       // sharded: the all-reduced sums of every set are here, on every rank
     for (int i = 0; i < p_n_; ++i) {
       SetState<T>& s = sets_[i];
       if (r_pri) r_pri[i] = 0;
       if (r_dual) r_dual[i] = 0;
-      if (!s.owned) continue;
+      if (!s.owned && !all) continue;
       const double* h = hres_ + (size_t)i * SLOTS;
       std::copy(h, h + SLOTS, s.sums);
       if (r_pri) r_pri[i] = (double)(T)std::sqrt(h[SL_RPRI]);                                   // update_y_l.jl:81
@@ -594,10 +691,15 @@ class Engine : public EngineBase {
         have_log_sums_ = true;
       }
     }
+    if (all) {                               // the slab sums of argmin_x: the distance-term kernel saw x_old on its own slab only
+      const double* g = hres_ + (size_t)p_n_ * SLOTS;
+      obj_ss_ = g[SL_OBJ]; evo_ss_ = g[SL_EVO]; xx_ss_ = g[SL_XX];
+      have_log_sums_ = true;
+    }
     if ((flags & SIPX_YL_FEAS) && feas) {
       for (int i = 0; i < pp_n_; ++i) {
         feas[i] = 0;
-        if (!sets_[i].owned) continue;
+        if (!sets_[i].owned && !all) continue;
         const double* h = hres_ + (size_t)i * SLOTS;
         feas[i] = (sets_[i].two_pass || sets_[i].ext_kind) ? (double)feas_value(h[SL_FE2], h[SL_SS2])
                                                             : (double)feas_value(h[SL_FE], h[SL_SS]);
@@ -624,7 +726,7 @@ class Engine : public EngineBase {
     need_final();
     for (int i = 0; i < p_n_; ++i) {
       SetState<T>& s = sets_[i];
-      if (!s.owned) continue;
+      if (!s.owned && !comm_) continue;
       if (!s.bb_valid)
         throw std::runtime_error("sipx_adapt_rho_gamma: call sipx_update_y_l with SIPX_YL_BB (or _FIRST) first");
       T rho = (T)rho_io[i], gamma = (T)gamma_io[i];
@@ -654,7 +756,7 @@ class Engine : public EngineBase {
       if (rho_new[i] == rho_old[i]) continue;                       // ind_updated, PARSDMM.jl:230
       push_qset(a, sets_[i], (T)rho_new[i] - (T)rho_old[i]);        // Q_update!.jl:47
     }
-    K<T>::q_update(stream_, G_, cds_, a, Q_);
+    K<T>::q_update(stream_, G_, qr0_, qr1_, cds_, a, Q_);
   }
 
   void download(void* x, void* const* l, void* const* y) override {
@@ -674,7 +776,7 @@ class Engine : public EngineBase {
   void parsdmm_begin(const sipx_options* opt, sipx_log* log) override {
     need_final();
     for (auto& s : sets_)
-      if (!s.owned) throw std::runtime_error("sipx_parsdmm needs every set local; use the phase API when sharding");
+      if (!s.owned && !comm_) throw std::runtime_error("sipx_parsdmm needs every set local, or a communicator (sipx_set_comm*)");
     Run& R = run_;
     R = Run();
     R.log = log;
@@ -719,23 +821,53 @@ class Engine : public EngineBase {
     std::vector<double>&rho = R.rho, &gamma = R.gamma, &rho_new = R.rho_new, &rpri = R.rpri, &rdual = R.rdual, &feas = R.feas;
     int& counter = R.counter;
     const int i = ++R.i;
-    const int eset = (i & 1) * 8;
-    resolve_timing(log, i & 1);          // marks recorded two steps ago have long completed
-    auto t_mark = [&](int k) { SIPX_HIP(hipEventRecord(ev_[eset + k], stream_)); };
+    const int par = i & 1;
+    resolve_timing(log, par);            // marks recorded two steps ago have long completed
+    // GPU sections are bracketed by event pairs (a section may be queued out of the reference's order, see below), the two
+    // host-only sections (stop rule, rho / gamma rules) are timed on the host clock
+    auto sec_begin = [&](int k) { SIPX_HIP(hipEventRecord(ev_[(par * NSEC + k) * 2], stream_)); };
+    auto sec_end = [&](int k) { SIPX_HIP(hipEventRecord(ev_[(par * NSEC + k) * 2 + 1], stream_)); ev_mask_[par] |= 1u << k; };
+    using clk = std::chrono::steady_clock;
+    auto ms_since = [](clk::time_point t0) { return std::chrono::duration<double, std::milli>(clk::now() - t0).count(); };
+    // can the rules at the end of iteration `it` change rho?  If not, the right-hand side of iteration it+1 is known as soon
+    // as the y/l kernels of `it` are queued
+    auto rho_may_change = [&](int it) {
+      return ((R.adjust_rho || R.adjust_gamma) && it % R.freq == 0) || (R.adjust_feas_rho && it % 10 == 0 && it > 10 && pp > 0);
+    };
     {
-      t_mark(0);
-      rhs_compose(rho.data());
-      t_mark(1);
+      if (!R.rhs_ready) {
+        sec_begin(SEC_RHS0);
+        rhs_compose(rho.data());
+        sec_end(SEC_RHS0);
+      }
+      R.rhs_ready = false;
+      sec_begin(SEC_X);
       int64_t cg_it; double relres; int flag;
       argmin_x(i, &R.tol_ref, &cg_it, &relres, &flag);
       log->cg_it[i - 1] = cg_it;
       log->cg_relres[i - 1] = relres;
-      t_mark(2);
+      sec_end(SEC_X);
       int flags = 0;
       if (i % 10 == 0) flags |= SIPX_YL_FEAS;
       if (i == 1) flags |= SIPX_YL_FIRST;
       if ((R.adjust_rho || R.adjust_gamma) && i % R.freq == 0) flags |= SIPX_YL_BB;
+      sec_begin(SEC_YL);
+      defer_sums_ = true;                  // queue the kernels and the reduction of their sums, collect them further down
       update_y_l(i, flags, rho.data(), gamma.data(), rpri.data(), rdual.data(), feas.data());
+      defer_sums_ = false;
+      sec_end(SEC_YL);
+      // Software pipeline: nothing the GPU is given next may depend on the sums the host is about to read.  When the rules
+      // below cannot touch rho, rhs_{i+1} = sum_i A_i'(rho_i y_i + l_i) (and, sharded, its reduce-scatter on the
+      // communication stream) is queued now and runs while the host waits for the sums and evaluates the stop rule.  A
+      // stop leaves x, y, l as they are: rhs is scratch.
+      if (i < maxit && !rho_may_change(i)) {
+        sec_begin(SEC_RHS1);
+        rhs_compose(rho.data());
+        sec_end(SEC_RHS1);
+        R.rhs_ready = true;
+      }
+      collect_set_sums(rho.data(), rpri.data(), rdual.data(), feas.data());
+      auto t_host = clk::now();
       T sd = (T)rdual[0], sp = (T)rpri[0];
       for (int k = 0; k < p; ++k) {
         log->r_pri[(size_t)(i - 1) * p + k] = rpri[k];
@@ -751,7 +883,8 @@ class Engine : public EngineBase {
         counter += 1;
       }
       log_scalars(&log->obj[i - 1], &log->evol_x[i - 1]);
-      t_mark(3);
+      log->timing_ms[3] += ms_since(t_host);                          // bookkeeping of the y/l section
+      t_host = clk::now();
       // ---- stop_PARSDMM.jl:23-52 ----
       bool stop = false;
       if (i > 6 && pp > 0) {
@@ -779,19 +912,12 @@ class Engine : public EngineBase {
         const int lo = std::max(R.ind_ref, std::max(i - 50, 1));
         if (log->r_pri_total[i - 1] > julia_maximum(log->r_pri_total + (lo - 1), log->r_pri_total + (i - 1))) stop = true;
       }
-      t_mark(4);
+      log->timing_ms[4] += ms_since(t_host);
       if (stop) {
-        ev_pending_[i & 1] = 5;
-        resolve_timing(log, 0);
-        resolve_timing(log, 1);
-        log->n_iter = i;
-        log->n_feas_rows = counter;
-        // Q holds sum_i rho_i AtA_i for the rho of THIS iteration (the update below has not run): a later solve on the
-        // same context must start from these values, as after the maxit exit
-        for (int k = 0; k < p; ++k) { rho_[k] = (T)rho[k]; gamma_[k] = (T)gamma[k]; }
-        R.done = true;
+        finish_solve(log, i, counter, rho, gamma);
         return true;
       }
+      t_host = clk::now();
       // ---- adjust rho and gamma (PARSDMM.jl:163-227); l_hat / snapshots were fused into update_y_l ----
       rho_new = rho;
       if ((R.adjust_rho || R.adjust_gamma) && i % R.freq == 0)
@@ -808,21 +934,37 @@ class Engine : public EngineBase {
       }
       for (int k = 0; k < p; ++k)                                      // :226
         rho_new[k] = (double)std::max(std::min((T)rho_new[k], T(1e4)), T(1e-2));
-      t_mark(5);
+      log->timing_ms[5] += ms_since(t_host);
+      if (R.rhs_ready && rho_new != rho) throw std::runtime_error("internal: rho changed under a right-hand side queued ahead");
+      if (i < maxit && !R.rhs_ready) {     // rho is final now; queued ahead of the Q update so that, sharded, the
+        sec_begin(SEC_RHS1);               // reduce-scatter (communication stream) runs beside it
+        rhs_compose(rho_new.data());
+        sec_end(SEC_RHS1);
+        R.rhs_ready = true;
+      }
+      sec_begin(SEC_Q);
       q_update(rho_new.data(), rho.data());                            // :230-243
+      sec_end(SEC_Q);
       rho = rho_new;
-      t_mark(6);
-      ev_pending_[i & 1] = 7;
     }
-    if (i == maxit) {
-      resolve_timing(log, 0);
-      resolve_timing(log, 1);
-      log->n_iter = maxit;
-      log->n_feas_rows = counter;
-      for (int k = 0; k < p; ++k) { rho_[k] = (T)rho[k]; gamma_[k] = (T)gamma[k]; }
-      R.done = true;
-    }
+    if (i == maxit) finish_solve(log, maxit, counter, rho, gamma);
     return R.done;
+  }
+
+  // common exit of the whole solve (stop rule or maxit): timing resolved, logs truncated, and the context left so that a
+  // later solve on it continues from here -- Q holds sum_i rho_i AtA_i for exactly these rho
+  void finish_solve(sipx_log* log, int n_iter, int counter, const std::vector<double>& rho, const std::vector<double>& gamma) {
+    if (rs_pending_) {                      // a right-hand side queued ahead: let its exchange finish before anyone touches rhs
+      SIPX_HIP(hipStreamWaitEvent(stream_, ev_c_[1], 0));
+      rs_pending_ = false;
+    }
+    resolve_timing(log, 0);
+    resolve_timing(log, 1);
+    log->n_iter = n_iter;
+    log->n_feas_rows = counter;
+    for (int k = 0; k < p_n_; ++k) { rho_[k] = (T)rho[k]; gamma_[k] = (T)gamma[k]; }
+    run_.rhs_ready = false;
+    run_.done = true;
   }
 
   void parsdmm(const sipx_options* opt, sipx_log* log) override {
@@ -918,6 +1060,7 @@ class Engine : public EngineBase {
     if (d) *d = cds_.d;
     if (offsets) for (int b = 0; b < cds_.d; ++b) offsets[b] = cds_.off[b];
     if (Q && stencil_q_) throw std::runtime_error("stencil Q mode stores no bands (use sipx_apply_Q)");
+    if (Q && comm_ && comm_->world > 1) throw std::runtime_error("a sharded context maintains its slab of Q only");
     if (Q && cds_.sym) {      // the negative bands are not maintained while solving: rebuild them from their partners
       K<T>::mirror_bands(stream_, Nx_, cds_, Q_);
       SIPX_HIP(hipStreamSynchronize(stream_));
@@ -927,6 +1070,7 @@ class Engine : public EngineBase {
 
   void apply_Q(const void* x, void* y) override {     // y = Q x through the solver's own kernel (either mode)
     need_final();
+    if (comm_ && comm_->world > 1) throw std::runtime_error("a sharded context maintains its slab of Q only");
     SIPX_HIP(hipStreamSynchronize(stream_));
     SIPX_HIP(hipMemcpy(p_, x, Nx_ * sizeof(T), hipMemcpyHostToDevice));
     if (stencil_q_) K<T>::sq_spmv(stream_, G_, sq_, p_, Ap_);
@@ -1327,7 +1471,7 @@ class Engine : public EngineBase {
     QArgs<T> a;
     a.nsets = 0;
     for (int i = 0; i < p_n_; ++i) push_qset(a, sets_[i], rho_[i]);   // Q = 0 + rho_1 AtA_1 + rho_2 AtA_2 + ...
-    K<T>::q_update(stream_, G_, cds_, a, Q_);
+    K<T>::q_update(stream_, G_, qr0_, qr1_, cds_, a, Q_);
   }
 
   // Minkowski mode: Q[:, b] += alpha_i AtA_i[:, b] for the sets with alpha_i != 0, batches of MAX_SETS in set order
@@ -1355,7 +1499,7 @@ class Engine : public EngineBase {
     if (s.ata_off.size() > 9) throw std::runtime_error("more than 9 bands in one set's AtA are not supported");
     for (long long o : s.ata_off) (void)q_col(o);     // CDS_scaled_add!.jl:18-20: the diagonal must exist in Q
     if (a.nsets == MAX_SETS) {                         // flush a full batch, keep the order
-      K<T>::q_update(stream_, G_, cds_, a, Q_);
+      K<T>::q_update(stream_, G_, qr0_, qr1_, cds_, a, Q_);
       a.nsets = 0;
     }
     QSet<T>& q = a.s[a.nsets++];
@@ -1434,17 +1578,56 @@ class Engine : public EngineBase {
     dfree(tmp);
   }
 
-  void resolve_timing(sipx_log* log, int set) {
-    const int nmarks = ev_pending_[set];
-    if (!nmarks) return;
-    ev_pending_[set] = 0;
-    SIPX_HIP(hipEventSynchronize(ev_[set * 8 + nmarks - 1]));
-    // sections: rhs(0-1) argmin x(1-2) y/l(2-3) stop(3-4) adjust(4-5) Q-update(5-6); [0] "initialization" is host-side
-    for (int k = 1; k < nmarks; ++k) {
+  void resolve_timing(sipx_log* log, int par) {
+    const unsigned mask = ev_mask_[par];
+    if (!mask) return;
+    ev_mask_[par] = 0;
+    // timing_ms: [0] initialization (host side) [1] rhs [2] argmin x [3] y/l update [4] stop rule [5] rho / gamma rules [6] Q update
+    static const int slot[NSEC] = {1, 2, 3, 1, 6};
+    for (int k = 0; k < NSEC; ++k) {
+      if (!(mask & (1u << k))) continue;
+      hipEvent_t b = ev_[(par * NSEC + k) * 2], e = ev_[(par * NSEC + k) * 2 + 1];
+      SIPX_HIP(hipEventSynchronize(e));
       float ms = 0;
-      SIPX_HIP(hipEventElapsedTime(&ms, ev_[set * 8 + k - 1], ev_[set * 8 + k]));
-      log->timing_ms[k] += ms;
+      SIPX_HIP(hipEventElapsedTime(&ms, b, e));
+      log->timing_ms[slot[k]] += ms;
     }
+  }
+
+  int dtype_code() const { return sizeof(T) == 8 ? SIPX_F64 : SIPX_F32; }
+
+  // partials of the per-set slots -> hres_ (pinned).  Sharded: summed over the ranks on the way (sets a rank does not own
+  // contribute the zeros their slots were allocated with), so every rank reads the sums of every set.
+  void reduce_set_sums(int nslots) {
+    if (comm_) {
+      K<T>::fin_sum(stream_, part_sets_, nslots, dres_, nullptr);
+      comm_->allreduce_sum(dres_, (size_t)nslots, SIPX_F64, stream_);
+      SIPX_HIP(hipMemcpyAsync(hres_, dres_, sizeof(double) * nslots, hipMemcpyDeviceToHost, stream_));
+    } else {
+      K<T>::fin_sum(stream_, part_sets_, nslots, nullptr, hres_);
+    }
+  }
+
+  // Verdict of CG iteration `iter` of solve `seq`: spins on the ticket word (published by the device as soon as it is
+  // known) and falls back on the completion of the iteration's kernels, after which the mirror is final.
+  bool wait_ticket(unsigned seq, int iter, hipEvent_t ev, const CgState<T>* mirror) {
+    const unsigned long long want = ((unsigned long long)seq << 32) | ((unsigned long long)(unsigned)iter << 1);
+    bool polled = false;
+    bool done;
+    for (;;) {
+      unsigned long long t = __atomic_load_n(ticket_, __ATOMIC_ACQUIRE);
+      if ((t & ~1ull) == want) { done = (t & 1ull) != 0; break; }
+      const hipError_t q = hipEventQuery(ev);
+      if (q == hipSuccess) {
+        t = __atomic_load_n(ticket_, __ATOMIC_ACQUIRE);
+        done = ((t & ~1ull) == want) ? (t & 1ull) != 0 : mirror->done != 0;
+        break;
+      }
+      if (q != hipErrorNotReady) SIPX_HIP(q);
+      polled = true;
+    }
+    if (polled) (void)hipGetLastError();      // hipErrorNotReady is not an error: keep it out of the launch checks
+    return done;
   }
 
   void free_set(SetState<T>& s) {
@@ -1466,8 +1649,10 @@ class Engine : public EngineBase {
     T evol_rel_tol = 0, feas_tol = 0, obj_tol = 0;
     bool adjust_rho = true, adjust_gamma = true, adjust_feas_rho = true;
     double tol_ref = 1.0;
+    bool rhs_ready = false;        // the right-hand side of the coming iteration is already queued
     std::vector<double> rho, gamma, rho_new, rpri, rdual, feas;
   };
+  enum { SEC_RHS0 = 0, SEC_X = 1, SEC_YL = 2, SEC_RHS1 = 3, SEC_Q = 4, NSEC = 5 };
   Run run_;
   int device_ = 0, ndim_ = 2;
   hipStream_t stream_ = nullptr;
@@ -1501,7 +1686,20 @@ class Engine : public EngineBase {
   CgState<T>*cg_dev_ = nullptr, *cg_host_ = nullptr;
   double* hres_ = nullptr;
   std::vector<hipEvent_t> ev_;
-  int ev_pending_[2] = {0, 0};
+  unsigned ev_mask_[2] = {0, 0};
+  // sharded solve: communicator, this rank's slab [r0_, r1_) of the x-step, rows of Q it maintains
+  std::unique_ptr<Comm> comm_;
+  long long plane_ = 0, chunk_ = 0, r0_ = 0, r1_ = 0, qr0_ = 0, qr1_ = 0;
+  int prev_ = -1, next_ = -1;
+  hipStream_t cstream_ = nullptr;           // communication stream: the reduce-scatter of rhs runs beside the engine stream
+  hipEvent_t ev_c_[2] = {nullptr, nullptr};
+  bool rs_pending_ = false;
+  double* dres_ = nullptr;                  // device copy of the reduced per-set sums (all-reduce buffer)
+  hipEvent_t ev_sums_ = nullptr, ev_cgb_ = nullptr;
+  bool sums_pending_ = false, defer_sums_ = false;
+  int sums_flags_ = 0;
+  volatile unsigned long long* ticket_ = nullptr;   // pinned: verdict of the latest CG iteration (publish_ticket)
+  unsigned cg_seq_ = 0;
   double obj_ss_ = 0, evo_ss_ = 0, xx_ss_ = 0;
   bool have_log_sums_ = false;
   hipEvent_t cg_ev_[2] = {nullptr, nullptr};

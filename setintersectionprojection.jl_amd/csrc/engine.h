@@ -10,6 +10,8 @@
 
 namespace sipx {
 
+struct Comm;
+
 struct EngineBase {
   virtual ~EngineBase() {}
   virtual int add_set(const sipx_set_desc* d, const void* ata_R, const int64_t* ata_off, int d_i) = 0;
@@ -42,6 +44,8 @@ struct EngineBase {
   virtual void get_rhs(void* out) = 0;
   virtual void set_owned(const int32_t* owned) = 0;
   virtual void set_q_mode(int mode) = 0;
+  virtual void set_comm(Comm* c) = 0;       // takes ownership
+  virtual void slab(int64_t* row0, int64_t* row1, int64_t* chunk) = 0;
 };
 
 EngineBase* make_engine(int dtype, int ndim, const int64_t* n, const double* h, int device);

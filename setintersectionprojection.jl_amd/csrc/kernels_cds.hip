@@ -77,14 +77,16 @@ __device__ __forceinline__ void cds_rows(long long N, const T* __restrict__ R, c
 // MODE 0: y = Qx.  MODE 1: Ap = Qp and partial(p.Ap) (cg.jl:85-88).
 // MODE 2: r = b - Qx, p = r, x_old = x, partials ||r||^2, ||b||^2 (argmin_x.jl:34 + cg.jl:52-58 + PARSDMM.jl:106).
 template <typename T, int V, int D, int MODE>
-__global__ __launch_bounds__(BLOCK) void k_cds(long long N, const T* __restrict__ R, CdsArgs a,
+__global__ __launch_bounds__(BLOCK) void k_cds(long long N, long long r0, long long r1, const T* __restrict__ R, CdsArgs a,
                                                const T* __restrict__ x, T* __restrict__ y, const T* __restrict__ b,
                                                T* __restrict__ pout, T* __restrict__ xold, double* __restrict__ partials,
                                                const int* __restrict__ done) {
   if (MODE == 1 && *done) return;
-  const long long nvec = N / V;
+  // rows [r0, r1) of the N x N matrix (the whole matrix, or the z-slab this rank owns in the sharded x-step): indices and
+  // boundary masks stay global, only the sweep is restricted
+  const long long nvec = r1 / V;
   double acc0 = 0, acc1 = 0;
-  for (long long vi = (long long)blockIdx.x * BLOCK + threadIdx.x; vi < nvec; vi += (long long)gridDim.x * BLOCK) {
+  for (long long vi = r0 / V + (long long)blockIdx.x * BLOCK + threadIdx.x; vi < nvec; vi += (long long)gridDim.x * BLOCK) {
     const long long r = vi * V;
     T s[V];
     cds_rows<T, V, D>(N, R, a, x, r, s);
@@ -114,7 +116,7 @@ __global__ __launch_bounds__(BLOCK) void k_cds(long long N, const T* __restrict_
       }
       stv<T, V>(y + r, o);
       if (pout) stv<T, V>(pout + r, o);
-      stv<T, V>(xold + r, xv);
+      if (xold) stv<T, V>(xold + r, xv);
     }
   }
   if (MODE == 1) {
@@ -127,14 +129,15 @@ __global__ __launch_bounds__(BLOCK) void k_cds(long long N, const T* __restrict_
 }
 
 template <typename T, int MODE>
-static void launch_cds(hipStream_t s, long long N, const T* R, const CdsArgs& a, const T* x, T* y, const T* b, T* pout,
-                       T* xold, double* partials, const int* done) {
+static void launch_cds(hipStream_t s, long long N, long long r0, long long r1, const T* R, const CdsArgs& a, const T* x, T* y,
+                       const T* b, T* pout, T* xold, double* partials, const int* done) {
   if (a.d < 1 || a.d > MAXD) throw std::runtime_error("cds: band count out of range");
+  if (r0 < 0 || r1 > N || r0 > r1) throw std::runtime_error("cds: row range outside the matrix");
 #define SIPX_CDS(V, D) \
-  hipLaunchKernelGGL((k_cds<T, V, D, MODE>), dim3(fit_grid(N / V, SIPX_CG_GRID)), dim3(BLOCK), 0, s, N, R, a, x, y, b, pout, xold, partials, done)
+  hipLaunchKernelGGL((k_cds<T, V, D, MODE>), dim3(fit_grid((r1 - r0) / V, SIPX_CG_GRID)), dim3(BLOCK), 0, s, N, r0, r1, R, a, x, y, b, pout, xold, partials, done)
   // 16 bytes per thread and band: four floats or two doubles (four doubles leave the 7-band kernel 3 waves per SIMD)
   constexpr int VW = sizeof(T) == 8 ? SIPX_F64_VEC : 4;
-  if (N % 4 == 0) {
+  if (N % 4 == 0 && r0 % 4 == 0 && r1 % 4 == 0) {
     switch (a.d) {
       case 1: SIPX_CDS(VW, 1); break;
       case 3: SIPX_CDS(VW, 3); break;
@@ -151,17 +154,17 @@ static void launch_cds(hipStream_t s, long long N, const T* R, const CdsArgs& a,
 
 template <typename T>
 void K<T>::spmv(hipStream_t s, const Grid&, long long N, const T* R, const CdsArgs& a, const T* x, T* y) {
-  launch_cds<T, 0>(s, N, R, a, x, y, nullptr, nullptr, nullptr, nullptr, nullptr);
+  launch_cds<T, 0>(s, N, 0, N, R, a, x, y, nullptr, nullptr, nullptr, nullptr, nullptr);
 }
 template <typename T>
-void K<T>::spmv_dot(hipStream_t s, long long N, const T* R, const CdsArgs& a, const T* p, T* Ap, double* partials,
-                    const CgState<T>* st) {
-  launch_cds<T, 1>(s, N, R, a, p, Ap, nullptr, nullptr, nullptr, partials, &st->done);
+void K<T>::spmv_dot(hipStream_t s, long long N, long long r0, long long r1, const T* R, const CdsArgs& a, const T* p, T* Ap,
+                    double* partials, const CgState<T>* st) {
+  launch_cds<T, 1>(s, N, r0, r1, R, a, p, Ap, nullptr, nullptr, nullptr, partials, &st->done);
 }
 template <typename T>
-void K<T>::resid(hipStream_t s, long long N, const T* R, const CdsArgs& a, const T* x, const T* b, T* r, T* p, T* xold,
-                 double* partials) {
-  launch_cds<T, 2>(s, N, R, a, x, r, b, p, xold, partials, nullptr);
+void K<T>::resid(hipStream_t s, long long N, long long r0, long long r1, const T* R, const CdsArgs& a, const T* x, const T* b,
+                 T* r, T* p, T* xold, double* partials) {
+  launch_cds<T, 2>(s, N, r0, r1, R, a, x, r, b, p, xold, partials, nullptr);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -330,9 +333,9 @@ __global__ __launch_bounds__(BLOCK) void k_gen_ata(Grid G, GenArgs a, T ih0, T i
 // Fused Q update: every band of Q is read and written once; the changed sets are applied in order
 // (Q_update!.jl:45-48), their band values regenerated on the fly unless explicit bands were supplied.
 template <typename T, int V>
-__global__ __launch_bounds__(BLOCK) void k_q_update(Grid G, CdsArgs q, QArgs<T> a, T* __restrict__ Q) {
-  const long long nvec = G.N / V;
-  for (long long vi = (long long)blockIdx.x * BLOCK + threadIdx.x; vi < nvec; vi += (long long)gridDim.x * BLOCK) {
+__global__ __launch_bounds__(BLOCK) void k_q_update(Grid G, long long r0, long long r1, CdsArgs q, QArgs<T> a, T* __restrict__ Q) {
+  const long long nvec = r1 / V;      // rows [r0, r1): the whole of Q, or the rows this rank's slab of the x-step reads
+  for (long long vi = r0 / V + (long long)blockIdx.x * BLOCK + threadIdx.x; vi < nvec; vi += (long long)gridDim.x * BLOCK) {
     const long long g = vi * V;
     Coord c[V];
 #pragma unroll
@@ -362,12 +365,13 @@ __global__ __launch_bounds__(BLOCK) void k_q_update(Grid G, CdsArgs q, QArgs<T> 
   }
 }
 template <typename T>
-void K<T>::q_update(hipStream_t s, const Grid& g, const CdsArgs& q, const QArgs<T>& a, T* Q) {
-  if (a.nsets == 0) return;
-  if (g.n[0] % 4 == 0)
-    hipLaunchKernelGGL((k_q_update<T, 4>), dim3(NB), dim3(BLOCK), 0, s, g, q, a, Q);
+void K<T>::q_update(hipStream_t s, const Grid& g, long long r0, long long r1, const CdsArgs& q, const QArgs<T>& a, T* Q) {
+  if (a.nsets == 0 || r1 <= r0) return;
+  if (r0 < 0 || r1 > g.N) throw std::runtime_error("q_update: row range outside the matrix");
+  if (g.n[0] % 4 == 0 && r0 % 4 == 0 && r1 % 4 == 0)
+    hipLaunchKernelGGL((k_q_update<T, 4>), dim3(fit_grid((r1 - r0) / 4, NB)), dim3(BLOCK), 0, s, g, r0, r1, q, a, Q);
   else
-    hipLaunchKernelGGL((k_q_update<T, 1>), dim3(NB), dim3(BLOCK), 0, s, g, q, a, Q);
+    hipLaunchKernelGGL((k_q_update<T, 1>), dim3(fit_grid(r1 - r0, NB)), dim3(BLOCK), 0, s, g, r0, r1, q, a, Q);
   SIPX_HIP(hipGetLastError());
 }
 
@@ -439,9 +443,19 @@ void K<T>::gen_ata(hipStream_t s, const Grid& g, int nblk, const int* dir, const
 // ---------------------------------------------------------------------------------------------
 // CG scalar steps: one 256-thread block sums the block partials in fixed order, thread 0 applies
 // the reference's scalar logic and mirrors the state into pinned host memory.
+// The host decides whether another CG iteration is enqueued from ONE 8-byte word in pinned memory, written with a
+// system-scope release store as soon as the verdict of an iteration is known (workgroup 0 of k_cg_update_p, before its
+// streaming loop): (seq << 32) | (iter << 1) | done.  The next product is then queued while this kernel is still
+// streaming, and no launch is ever made for an iteration that does not run (rocprofv3's per-kernel averages hold work only).
+__device__ __forceinline__ void publish_ticket(unsigned long long* ticket, unsigned seq, int iter, int done) {
+  const unsigned long long v = ((unsigned long long)seq << 32) | ((unsigned long long)(unsigned)iter << 1) | (done ? 1ull : 0ull);
+  __hip_atomic_store(ticket, v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
 template <typename T>
 __global__ __launch_bounds__(BLOCK) void k_cg_begin(const double* __restrict__ partials, CgState<T>* st,
-                                                    CgState<T>* host, int it_outer, T tol_ref) {
+                                                    CgState<T>* host, int it_outer, T tol_ref, unsigned seq,
+                                                    unsigned long long* ticket) {
   const double ss_r = block_sum_partials(partials);
   const double ss_b = block_sum_partials(partials + NB);
   if (threadIdx.x == 0) {
@@ -460,6 +474,7 @@ __global__ __launch_bounds__(BLOCK) void k_cg_begin(const double* __restrict__ p
     st->flag = -1;
     st->done = 0;
     st->it_outer = it_outer;
+    st->seq = seq;
     if (nr0 == T(0)) {            // cg.jl:51  -> x = zeros, flag -9, iter 0
       st->flag = -9;
       st->done = 1;
@@ -469,11 +484,13 @@ __global__ __launch_bounds__(BLOCK) void k_cg_begin(const double* __restrict__ p
       st->iters = 1;
     }
     *host = *st;
+    publish_ticket(ticket, seq, 0, st->done);
   }
 }
 template <typename T>
-void K<T>::cg_begin(hipStream_t s, double* partials, CgState<T>* st, CgState<T>* host, int it_outer, T tol_ref) {
-  hipLaunchKernelGGL((k_cg_begin<T>), dim3(1), dim3(BLOCK), 0, s, partials, st, host, it_outer, tol_ref);
+void K<T>::cg_begin(hipStream_t s, double* partials, CgState<T>* st, CgState<T>* host, int it_outer, T tol_ref, unsigned seq,
+                    unsigned long long* ticket) {
+  hipLaunchKernelGGL((k_cg_begin<T>), dim3(1), dim3(BLOCK), 0, s, partials, st, host, it_outer, tol_ref, seq, ticket);
   SIPX_HIP(hipGetLastError());
 }
 
@@ -486,7 +503,8 @@ template <typename T, int V>
 __global__ __launch_bounds__(BLOCK) void k_cg_update_xr(long long N, T* __restrict__ x, const T* r_in, T* r,
                                                         const T* p, const T* __restrict__ Ap,
                                                         double* __restrict__ partials, CgState<T>* __restrict__ st,
-                                                        CgState<T>* __restrict__ host, int iter) {
+                                                        CgState<T>* __restrict__ host, int iter,
+                                                        unsigned long long* ticket) {
   if (st->done) return;
   const double pAp = block_sum_partials(partials);
   const T gamma = st->rr;                   // dot(r,z), cg.jl:86 (not written by this kernel)
@@ -501,6 +519,7 @@ __global__ __launch_bounds__(BLOCK) void k_cg_update_xr(long long N, T* __restri
       st->done = 1;
       st->res_last = T(0);
       *host = *st;
+      publish_ticket(ticket, st->seq, iter, 1);
     }
   }
   if (bad) return;
@@ -522,11 +541,11 @@ __global__ __launch_bounds__(BLOCK) void k_cg_update_xr(long long N, T* __restri
 }
 template <typename T>
 void K<T>::cg_update_xr(hipStream_t s, long long N, T* x, const T* r_in, T* r, const T* p, const T* Ap, double* partials,
-                        CgState<T>* st, CgState<T>* host, int iter) {
-  if (N % 4 == 0)
-    hipLaunchKernelGGL((k_cg_update_xr<T, 4>), dim3(fit_grid(N / 4, SIPX_CG_GRID)), dim3(BLOCK), 0, s, N, x, r_in, r, p, Ap, partials, st, host, iter);
+                        CgState<T>* st, CgState<T>* host, int iter, unsigned long long* ticket) {
+  if (N % 4 == 0 && aligned16(x, r_in, r, p, Ap))
+    hipLaunchKernelGGL((k_cg_update_xr<T, 4>), dim3(fit_grid(N / 4, SIPX_CG_GRID)), dim3(BLOCK), 0, s, N, x, r_in, r, p, Ap, partials, st, host, iter, ticket);
   else
-    hipLaunchKernelGGL((k_cg_update_xr<T, 1>), dim3(fit_grid(N, SIPX_CG_GRID)), dim3(BLOCK), 0, s, N, x, r_in, r, p, Ap, partials, st, host, iter);
+    hipLaunchKernelGGL((k_cg_update_xr<T, 1>), dim3(fit_grid(N, SIPX_CG_GRID)), dim3(BLOCK), 0, s, N, x, r_in, r, p, Ap, partials, st, host, iter, ticket);
   SIPX_HIP(hipGetLastError());
 }
 
@@ -534,7 +553,7 @@ void K<T>::cg_update_xr(hipStream_t s, long long N, T* x, const T* r_in, T* r, c
 template <typename T, int V>
 __global__ __launch_bounds__(BLOCK) void k_cg_update_p(long long N, T* __restrict__ p, const T* __restrict__ r,
                                                        const double* __restrict__ partials, CgState<T>* __restrict__ st,
-                                                       CgState<T>* __restrict__ host) {
+                                                       CgState<T>* __restrict__ host, unsigned long long* ticket) {
   // `done` may be raised by workgroup 0 of this very launch: a workgroup that starts late and sees it returns, which is
   // what it would have decided from the partials anyway
   if (st->done) return;
@@ -554,6 +573,7 @@ __global__ __launch_bounds__(BLOCK) void k_cg_update_p(long long N, T* __restric
     }
     st->rr = rr;
     *host = *st;
+    publish_ticket(ticket, st->seq, st->iters, conv ? 1 : 0);
   }
   if (conv) return;
   const long long nvec = N / V;
@@ -567,11 +587,11 @@ __global__ __launch_bounds__(BLOCK) void k_cg_update_p(long long N, T* __restric
 }
 template <typename T>
 void K<T>::cg_update_p(hipStream_t s, long long N, T* p, const T* r, const double* partials, CgState<T>* st,
-                       CgState<T>* host) {
-  if (N % 4 == 0)
-    hipLaunchKernelGGL((k_cg_update_p<T, 4>), dim3(fit_grid(N / 4, NB)), dim3(BLOCK), 0, s, N, p, r, partials, st, host);
+                       CgState<T>* host, unsigned long long* ticket) {
+  if (N % 4 == 0 && aligned16(p, r))
+    hipLaunchKernelGGL((k_cg_update_p<T, 4>), dim3(fit_grid(N / 4, NB)), dim3(BLOCK), 0, s, N, p, r, partials, st, host, ticket);
   else
-    hipLaunchKernelGGL((k_cg_update_p<T, 1>), dim3(fit_grid(N, NB)), dim3(BLOCK), 0, s, N, p, r, partials, st, host);
+    hipLaunchKernelGGL((k_cg_update_p<T, 1>), dim3(fit_grid(N, NB)), dim3(BLOCK), 0, s, N, p, r, partials, st, host, ticket);
   SIPX_HIP(hipGetLastError());
 }
 
@@ -594,9 +614,10 @@ void K<T>::fin_sum(hipStream_t s, const double* partials, int nslots, double* ou
 // explicit instantiation of the members defined in this file
 #define SIPX_INST(T)                                                                                                  \
   template void K<T>::spmv(hipStream_t, const Grid&, long long, const T*, const CdsArgs&, const T*, T*);             \
-  template void K<T>::spmv_dot(hipStream_t, long long, const T*, const CdsArgs&, const T*, T*, double*,              \
-                               const CgState<T>*);                                                                    \
-  template void K<T>::resid(hipStream_t, long long, const T*, const CdsArgs&, const T*, const T*, T*, T*, T*, double*); \
+  template void K<T>::spmv_dot(hipStream_t, long long, long long, long long, const T*, const CdsArgs&, const T*, T*, \
+                               double*, const CgState<T>*);                                                           \
+  template void K<T>::resid(hipStream_t, long long, long long, long long, const T*, const CdsArgs&, const T*, const T*, T*, \
+                            T*, T*, double*);                                                                         \
   template void K<T>::q_axpy(hipStream_t, long long, T*, const T*, T);                                               \
   template void K<T>::q_update_mk(hipStream_t, const Grid&, const CdsArgs&, const MkArgs<T>&, T*);                    \
   template void K<T>::mirror_bands(hipStream_t, long long, const CdsArgs&, T*);                                       \
@@ -604,12 +625,13 @@ void K<T>::fin_sum(hipStream_t s, const double* partials, int nslots, double* ou
   template void K<T>::sq_spmv_dot(hipStream_t, const Grid&, const StencilQ<T>&, const T*, T*, double*,               \
                                   const CgState<T>*);                                                                 \
   template void K<T>::sq_resid(hipStream_t, const Grid&, const StencilQ<T>&, const T*, const T*, T*, T*, T*, double*); \
-  template void K<T>::q_update(hipStream_t, const Grid&, const CdsArgs&, const QArgs<T>&, T*);                        \
+  template void K<T>::q_update(hipStream_t, const Grid&, long long, long long, const CdsArgs&, const QArgs<T>&, T*);  \
   template void K<T>::gen_ata(hipStream_t, const Grid&, int, const int*, const T*, int, const long long*, T*);       \
-  template void K<T>::cg_begin(hipStream_t, double*, CgState<T>*, CgState<T>*, int, T);                               \
+  template void K<T>::cg_begin(hipStream_t, double*, CgState<T>*, CgState<T>*, int, T, unsigned, unsigned long long*);  \
   template void K<T>::cg_update_xr(hipStream_t, long long, T*, const T*, T*, const T*, const T*, double*, CgState<T>*, \
-                                   CgState<T>*, int);                                                                \
-  template void K<T>::cg_update_p(hipStream_t, long long, T*, const T*, const double*, CgState<T>*, CgState<T>*);    \
+                                   CgState<T>*, int, unsigned long long*);                                           \
+  template void K<T>::cg_update_p(hipStream_t, long long, T*, const T*, const double*, CgState<T>*, CgState<T>*,     \
+                                  unsigned long long*);                                                              \
   template void K<T>::fin_sum(hipStream_t, const double*, int, double*, double*);
 SIPX_INST(float)
 SIPX_INST(double)

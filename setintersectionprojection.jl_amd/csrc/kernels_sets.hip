@@ -376,7 +376,7 @@ __global__ __launch_bounds__(BLOCK) void k_log3(long long N, const T* __restrict
 }
 template <typename T>
 void K<T>::log3(hipStream_t s, long long N, const T* x, const T* m, const T* xold, double* partials) {
-  if (N % 4 == 0)
+  if (N % 4 == 0 && aligned16(x, m, xold))
     hipLaunchKernelGGL((k_log3<T, 4>), dim3(NB), dim3(BLOCK), 0, s, N, x, m, xold, partials);
   else
     hipLaunchKernelGGL((k_log3<T, 1>), dim3(NB), dim3(BLOCK), 0, s, N, x, m, xold, partials);

@@ -19,6 +19,11 @@ inline int fit_grid(long long nvec, int cap) {
   const long long need = (nvec + BLOCK - 1) / BLOCK;
   return (int)(need < 1 ? 1 : (need < cap ? need : cap));
 }
+// the 16-byte vector paths need 16-byte aligned bases (pointers shifted to a slab of rows may not be)
+template <typename... P>
+inline bool aligned16(const P*... p) {
+  return (((reinterpret_cast<uintptr_t>(p) & 15u) == 0) && ...);
+}
 inline int launch_blocks(int per_cu) {
   static const int cus = [] {
     int dev = 0, n = 0;
@@ -179,6 +184,7 @@ struct CgState {
   int done, flag, iters;
   T tol_ref;        // x_solve_tol_ref chain (argmin_x.jl:33-37)
   int it_outer;
+  unsigned seq;     // number of this solve (ticket word, see publish_ticket)
 };
 
 // ---- launchers (explicitly instantiated for float and double in the .hip files) ----
@@ -186,25 +192,27 @@ template <typename T>
 struct K {
   // CDS
   static void spmv(hipStream_t s, const Grid& g, long long N, const T* R, const CdsArgs& a, const T* x, T* y);
-  static void spmv_dot(hipStream_t s, long long N, const T* R, const CdsArgs& a, const T* p, T* Ap, double* partials,
-                       const CgState<T>* st);
-  static void resid(hipStream_t s, long long N, const T* R, const CdsArgs& a, const T* x, const T* b, T* r, T* p,
-                    T* xold, double* partials);
+  // rows [r0, r1) of the product only (the z-slab of a sharded x-step; 0, N for the whole matrix); xold may be NULL
+  static void spmv_dot(hipStream_t s, long long N, long long r0, long long r1, const T* R, const CdsArgs& a, const T* p, T* Ap,
+                       double* partials, const CgState<T>* st);
+  static void resid(hipStream_t s, long long N, long long r0, long long r1, const T* R, const CdsArgs& a, const T* x, const T* b,
+                    T* r, T* p, T* xold, double* partials);
   static void sq_spmv(hipStream_t s, const Grid& g, const StencilQ<T>& q, const T* x, T* y);
   static void sq_spmv_dot(hipStream_t s, const Grid& g, const StencilQ<T>& q, const T* p, T* Ap, double* partials,
                           const CgState<T>* st);
   static void sq_resid(hipStream_t s, const Grid& g, const StencilQ<T>& q, const T* x, const T* b, T* r, T* p, T* xold,
                        double* partials);
   static void q_axpy(hipStream_t s, long long N, T* Qband, const T* Aband, T alpha);
-  static void q_update(hipStream_t s, const Grid& g, const CdsArgs& q, const QArgs<T>& a, T* Q);
+  static void q_update(hipStream_t s, const Grid& g, long long r0, long long r1, const CdsArgs& q, const QArgs<T>& a, T* Q);
   static void gen_ata(hipStream_t s, const Grid& g, int nblk, const int* dir, const T* ih, int nband,
                       const long long* offs, T* R);
   // CG
-  static void cg_begin(hipStream_t s, double* partials, CgState<T>* st, CgState<T>* host, int it_outer, T tol_ref);
+  static void cg_begin(hipStream_t s, double* partials, CgState<T>* st, CgState<T>* host, int it_outer, T tol_ref,
+                       unsigned seq, unsigned long long* ticket);
   static void cg_update_xr(hipStream_t s, long long N, T* x, const T* r_in, T* r, const T* p, const T* Ap, double* partials,
-                           CgState<T>* st, CgState<T>* host, int iter);
+                           CgState<T>* st, CgState<T>* host, int iter, unsigned long long* ticket);
   static void cg_update_p(hipStream_t s, long long N, T* p, const T* r, const double* partials, CgState<T>* st,
-                          CgState<T>* host);
+                          CgState<T>* host, unsigned long long* ticket);
   // sets
   static void rhs_compose(hipStream_t s, const Grid& g, const RhsArgs<T>& a, T* rhs, int accumulate);
   static void yl(hipStream_t s, const Grid& g, const SetArgs<T>& a, double* partials);

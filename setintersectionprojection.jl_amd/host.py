@@ -33,6 +33,7 @@ EXPORTED_SYMBOLS = [
     "sipx_debug_proj", "sipx_resample_nn", "sipx_set_q_mode", "sipx_apply_Q",
     "sipx_stream",
     "sipx_dev_rhs", "sipx_dev_x", "sipx_set_owned", "sipx_get_rhs", "sipx_prox_l2s",
+    "sipx_rccl_unique_id", "sipx_set_comm_rccl", "sipx_set_comm", "sipx_slab",
 ]
 
 SIPX_F32, SIPX_F64 = 0, 1
@@ -730,6 +731,12 @@ class Context:
         _chk(lib().sipx_download(self.h, _ptr(x), ptrs(l), ptrs(y)))
         return x, l, y
 
+    def slab(self):
+        """(row0, row1, chunk): this rank's rows of the x-step and the elements per rank of the padded exchange buffers."""
+        a, b, c = C.c_int64(), C.c_int64(), C.c_int64()
+        _chk(lib().sipx_slab(self.h, C.byref(a), C.byref(b), C.byref(c)))
+        return a.value, b.value, c.value
+
     def get_rhs(self):
         """rhs of the last rhs_compose (src/rhs_compose.jl:24-36), copied to the host."""
         rhs = np.empty(self.Nx, self.TF)
@@ -805,8 +812,9 @@ class Context:
 
 
 def build_context(m, AtA, TD_OP, set_Prop, P_sub, comp_grid, options, x=None, l=None, y=None, device=None,
-                  owned=None) -> Context:
-    """Everything PARSDMM_initialize allocates (src/PARSDMM_initialize.jl:117-230), on the device."""
+                  owned=None, attach=None) -> Context:
+    """Everything PARSDMM_initialize allocates (src/PARSDMM_initialize.jl:117-230), on the device.  `attach(ctx)` is called
+    before sipx_finalize: where a rank of a sharded solve is given its communicator (sharded.attach_comm)."""
     TF = np.dtype(m.dtype).type
     if not (np.isrealobj(m) and (x is None or np.isrealobj(x))):
         raise SipxError("input for PARSDMM is not real")                 # src/PARSDMM.jl:50-52
@@ -822,6 +830,8 @@ def build_context(m, AtA, TD_OP, set_Prop, P_sub, comp_grid, options, x=None, l=
             ctx.add_set(TD_OP[i], P_sub[i], set_Prop.ncvx[i], A, set_Prop.AtA_offsets[i] if A is not None else None)
         if owned is not None:
             ctx.set_owned(owned)
+        if attach is not None:
+            attach(ctx)
         ctx.set_q_mode(getattr(options, "Q_mode", "cds"))
         rho_ini = [float(TF(r)) for r in options.rho_ini]                # convert_options!.jl:6-15
         zero = bool(options.zero_ini_guess)                               # x, l, y are zero-filled then (PARSDMM_initialize.jl:304-313)

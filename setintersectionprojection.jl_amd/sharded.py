@@ -1,22 +1,27 @@
-"""Phase-level PARSDMM driver: the reference's main loop (src/PARSDMM.jl:97-254) restated over
-the phase entry points of the C ABI -- exactly what a Julia shim keeping PARSDMM.jl's own loop
-would ccall -- plus the set-sharded multi-GPU mode.
+"""Sharded PARSDMM: one process per GPU.
 
-Sharding (reference parallel mode: one worker per set, src/PARSDMM.jl:114-131,183-197;
-SURVEY 8e).  One process per GPU.  Rank r owns the sets {i : i mod world == r} (their y_i, l_i,
-snapshots and projector).  Per iteration:
-  1. every rank forms the partial rhs of its own sets,
-  2. ONE all-reduce (RCCL over xGMI) sums the N-vector rhs in place      [rhs_compose.jl:17-20],
-  3. every rank runs the same warm-started CG on the replicated Q, so x never has to be
-     broadcast (the reference ships x to every worker each iteration, PARSDMM.jl:117-119),
-  4. every rank updates its own sets; the per-set scalars (r_pri, r_dual, feasibility,
-     obj/evol, adapted rho/gamma) travel in one small all-reduce of a packed vector in which
-     non-owners contribute zeros  [the reference fetches whole r_pri vectors, PARSDMM.jl:122-125],
-  5. stop rule, rho heuristics and the Q update are replicated scalar / local work.
-All ranks see identical reduced data, hence take identical decisions.
+The reference's parallel mode gives every constraint set its own Julia worker, sums the partial
+right-hand sides with a (+) reduction and ships x to every worker (src/PARSDMM.jl:114-131,183-197,
+src/rhs_compose.jl:17-20, src/update_y_l_parallel.jl:6-90); its x-step stays on the master.  Here a
+rank is one GPU and the ENGINE enqueues the collectives itself (csrc/comm.cpp, csrc/engine.cpp):
+
+  1. every rank forms the partial rhs of the sets it owns (set i lives on rank i mod world),
+  2. reduce-scatter of rhs by z-slab: rank r receives the summed rows of ITS slab of the grid,
+  3. CG on the slab rows of Q: one halo plane of p from each neighbour per product, the dot products
+     through an all-reduce of the float64 block partials (identical bits on every rank, hence
+     identical decisions); x is completed with an all-gather,
+  4. every rank updates its own sets; ONE all-reduce of the packed per-set sums gives every rank the
+     r_pri / r_dual / feasibility / Barzilai-Borwein sums of every set,
+  5. stop rule, rho / gamma rules and the Q update (slab rows only) are replicated scalar / local work.
+
+This module is the host side: the communicator a context is given (native RCCL, or torch.distributed
+collectives handed to the engine as C callbacks -- what the tests use to run several ranks on ONE
+GPU over gloo), and the phase-level driver that restates the reference's main loop over the phase
+entry points of the C ABI (what a Julia shim keeping PARSDMM.jl's own loop would ccall).
 """
 from __future__ import annotations
 
+import ctypes as C
 from typing import List, Optional, Sequence
 
 import numpy as np
@@ -27,6 +32,15 @@ from .host import YL_BB, YL_FEAS, YL_FIRST, TIMING_SECTIONS, log_type_PARSDMM
 def shard_sets(p: int, world: int, rank: int) -> List[int]:
     """owned[i] = 1 iff term i (constraint sets, then the distance term) lives on `rank`."""
     return [1 if (i % world) == rank else 0 for i in range(p)]
+
+
+def slab_partition(n_last: int, plane: int, world: int):
+    """The engine's z-slabs of the x-step: ceil(n_last / world) planes per rank; returns (chunk, [(row0, row1)] per rank).
+    Ranks past the end of the grid hold an empty slab; the exchange buffers are padded to world * chunk elements."""
+    planes = -(-n_last // world)
+    chunk = planes * plane
+    N = n_last * plane
+    return chunk, [(min(N, r * chunk), min(N, (r + 1) * chunk)) for r in range(world)]
 
 
 def _nanmax(v) -> float:
@@ -40,70 +54,163 @@ def _argmax_julia(row) -> int:
     return int(nan[0]) if len(nan) else int(np.argmax(row))
 
 
-class LocalComm:
-    """world == 1: nothing to exchange."""
-    world, rank = 1, 0
-
-    def allreduce_rhs(self, ctx):
-        pass
-
-    def allreduce_scalars(self, vec: np.ndarray) -> np.ndarray:
-        return vec
+class _SipxComm(C.Structure):
+    """sipx_comm of include/sipx.h."""
+    _AR = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_void_p)
+    _HX = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_int32, C.c_int64,
+                      C.c_int32, C.c_void_p)
+    _fields_ = [("user", C.c_void_p), ("world", C.c_int32), ("rank", C.c_int32), ("allreduce_sum", _AR),
+                ("reduce_scatter_sum", _AR), ("allgather", _AR), ("halo_exchange", _HX)]
 
 
 class TorchComm:
-    """torch.distributed collectives (backend "nccl" is RCCL on ROCm).  The engine's HIP stream is
-    made torch's current stream while a collective is enqueued, so kernels and collectives are
-    ordered on the device without host synchronisation."""
+    """The four collectives of the sharded solve over torch.distributed.
+
+    * backend "nccl" (= RCCL on ROCm): device buffers of the engine are aliased as tensors and the collectives are
+      enqueued with the engine's HIP stream as torch's current stream -- no host synchronisation;
+    * backend "gloo": the buffer is staged through the host (stream synchronised first).  This is how the tests run
+      several ranks on ONE GPU, and how the CPU tests drive the same class on numpy arrays.
+    The tensor-level methods are usable on their own (CPU tests); ``c_struct()`` wraps them as the sipx_comm callbacks.
+    """
 
     def __init__(self, dist, device=None):
         import torch
         self.torch, self.dist = torch, dist
         self.world, self.rank = dist.get_world_size(), dist.get_rank()
         self.device = device
-        self._rhs = None
-        self._ext = None
+        self.nccl = dist.get_backend() == "nccl"
+        self._keep = None
+        self.calls = {"allreduce": 0, "reduce_scatter": 0, "allgather": 0, "halo": 0}
 
-    def _bind(self, ctx):
-        torch = self.torch
-        if self._rhs is not None:
-            return
-        if hasattr(ctx, "rhs_host_view"):          # CPU stand-in engine of the gloo tests
-            self._rhs = torch.from_numpy(ctx.rhs_host_view())
-            return
-        from .host import lib
-
-        class _Alias:                              # device buffer of the engine as a tensor, zero copy
-            def __init__(self, ptr, n, TF):
-                self.__cuda_array_interface__ = {"shape": (n,), "typestr": np.dtype(TF).str, "data": (ptr, False),
-                                                 "version": 2}
-        self._rhs = torch.as_tensor(_Alias(lib().sipx_dev_rhs(ctx.h), ctx.N, ctx.TF), device=self.device)
-        self._ext = torch.cuda.ExternalStream(lib().sipx_stream(ctx.h), device=self.device)
-
-    def allreduce_rhs(self, ctx):
-        self._bind(ctx)
-        if self._ext is not None:
-            with self.torch.cuda.stream(self._ext):
-                self.dist.all_reduce(self._rhs)
-        else:
-            self.dist.all_reduce(self._rhs)
-
-    def allreduce_scalars(self, vec: np.ndarray) -> np.ndarray:
-        t = self.torch.from_numpy(np.ascontiguousarray(vec, np.float64))
-        if self.device is not None:
-            t = t.to(self.device)
+    # ---- tensor level (in place) ---------------------------------------------------------------------------------
+    def allreduce_sum_(self, t):
+        self.calls["allreduce"] += 1
         self.dist.all_reduce(t)
-        return t.cpu().numpy()
+
+    def reduce_scatter_sum_(self, t, chunk):
+        """t[rank*chunk:(rank+1)*chunk] <- sum over ranks of that range."""
+        self.calls["reduce_scatter"] += 1
+        mine = t[self.rank * chunk:(self.rank + 1) * chunk]
+        if self.nccl:
+            self.dist.reduce_scatter_tensor(mine, t)
+        else:                                  # gloo has no reduce-scatter: reduce everything, keep the own range
+            self.dist.all_reduce(t)
+
+    def allgather_(self, t, chunk):
+        """t[r*chunk:(r+1)*chunk] <- that range of rank r."""
+        self.calls["allgather"] += 1
+        mine = t[self.rank * chunk:(self.rank + 1) * chunk]
+        if self.nccl:
+            self.dist.all_gather_into_tensor(t, mine)
+        else:
+            parts = [self.torch.empty_like(mine) for _ in range(self.world)]
+            self.dist.all_gather(parts, mine.clone())
+            for r, v in enumerate(parts):
+                t[r * chunk:(r + 1) * chunk] = v
+
+    def halo_exchange(self, send_prev, recv_prev, prev, send_next, recv_next, nxt):
+        self.calls["halo"] += 1
+        ops = []
+        P2P = self.dist.P2POp
+        if prev >= 0:
+            ops += [P2P(self.dist.isend, send_prev.contiguous(), prev), P2P(self.dist.irecv, recv_prev, prev)]
+        if nxt >= 0:
+            ops += [P2P(self.dist.isend, send_next.contiguous(), nxt), P2P(self.dist.irecv, recv_next, nxt)]
+        if ops:
+            for w in self.dist.batch_isend_irecv(ops):
+                w.wait()
+
+    # ---- C callbacks ------------------------------------------------------------------------------------------------
+    def _alias(self, ptr, count, dtype):
+        torch = self.torch
+        TF = np.float64 if dtype == 1 else np.float32
+
+        class _A:
+            __cuda_array_interface__ = {"shape": (int(count),), "typestr": np.dtype(TF).str, "data": (int(ptr), False), "version": 2}
+        return torch.as_tensor(_A(), device=self.device)
+
+    def _run(self, stream, bufs, fn):
+        """bufs: [(ptr, count, dtype, is_output)] device ranges; fn(tensors) performs the operation in place."""
+        torch = self.torch
+        ext = torch.cuda.ExternalStream(int(stream) if stream else 0, device=self.device)
+        dev = [self._alias(p, n, dt) if p else None for p, n, dt, _ in bufs]
+        if self.nccl:
+            with torch.cuda.stream(ext):
+                fn(dev)
+            return
+        ext.synchronize()
+        host = [None if t is None else t.cpu() for t in dev]
+        fn(host)
+        for (p, n, dt, out), d, h in zip(bufs, dev, host):
+            if out and d is not None:
+                d.copy_(h)
+        torch.cuda.synchronize(self.device)
+
+    def c_struct(self) -> _SipxComm:
+        def guard(f):
+            def g(*a):
+                try:
+                    f(*a)
+                    return 0
+                except Exception:                      # an exception must not cross the C boundary
+                    import traceback
+                    traceback.print_exc()
+                    return 1
+            return g
+
+        def ar(user, buf, count, dtype, stream):
+            self._run(stream, [(buf, count, dtype, True)], lambda t: self.allreduce_sum_(t[0]))
+
+        def rs(user, buf, chunk, dtype, stream):
+            self._run(stream, [(buf, chunk * self.world, dtype, True)], lambda t: self.reduce_scatter_sum_(t[0], chunk))
+
+        def ag(user, buf, chunk, dtype, stream):
+            self._run(stream, [(buf, chunk * self.world, dtype, True)], lambda t: self.allgather_(t[0], chunk))
+
+        def hx(user, sp, rp, prev, sn, rn, nxt, count, dtype, stream):
+            self._run(stream, [(sp if prev >= 0 else None, count, dtype, False), (rp if prev >= 0 else None, count, dtype, True),
+                               (sn if nxt >= 0 else None, count, dtype, False), (rn if nxt >= 0 else None, count, dtype, True)],
+                      lambda t: self.halo_exchange(t[0], t[1], prev, t[2], t[3], nxt))
+        cs = _SipxComm(None, self.world, self.rank, _SipxComm._AR(guard(ar)), _SipxComm._AR(guard(rs)), _SipxComm._AR(guard(ag)),
+                       _SipxComm._HX(guard(hx)))
+        self._keep = cs                                   # the engine holds the function pointers
+        return cs
+
+
+def attach_comm(ctx, dist, device=None, mode: Optional[str] = None):
+    """Gives a context (before finalize) the communicator of this rank.  mode "rccl": RCCL inside the engine, the
+    ncclUniqueId travels through torch.distributed; mode "torch": torch.distributed collectives as callbacks (any
+    backend).  Default: "rccl" when the process group is nccl, else "torch".  Returns what must stay alive with the context."""
+    import os
+    import torch
+    from .host import lib, _chk
+    mode = mode or os.environ.get("SIPX_COMM") or ("rccl" if dist.get_backend() == "nccl" else "torch")
+    world, rank = dist.get_world_size(), dist.get_rank()
+    if mode == "rccl":
+        uid = (C.c_char * 128)()
+        if rank == 0:
+            _chk(lib().sipx_rccl_unique_id(uid))
+        box = [bytes(uid.raw)]
+        dist.broadcast_object_list(box, src=0, device=device if dist.get_backend() == "nccl" else None)
+        _chk(lib().sipx_set_comm_rccl(ctx.h, box[0], world, rank))
+        return None
+    if mode != "torch":
+        raise ValueError(f"unknown communicator mode {mode!r}")
+    comm = TorchComm(dist, device if device is not None else torch.device("cuda", 0))
+    cs = comm.c_struct()
+    _chk(lib().sipx_set_comm(ctx.h, C.byref(cs)))
+    return comm
 
 
 class PhaseDriver:
-    """One PARSDMM solve advanced iteration by iteration (``step()``), serial or set-sharded."""
+    """One PARSDMM solve advanced iteration by iteration (``step()``) over the phase entry points -- the reference's main
+    loop (src/PARSDMM.jl:97-254) as a Julia shim would keep it.  The context may be a rank of a sharded solve: its phase
+    calls then contain the collectives and return the scalars of every set, so nothing here knows about ranks."""
 
-    def __init__(self, ctx, options, comm=None, owned: Optional[Sequence[int]] = None, any_ncvx=False):
-        self.ctx, self.o, self.comm = ctx, options, comm or LocalComm()
+    def __init__(self, ctx, options, any_ncvx=False):
+        self.ctx, self.o = ctx, options
         TF = self.TF = ctx.TF
         self.p, self.pp = ctx.p, ctx.pp
-        self.owned = list(owned) if owned is not None else [1] * self.p
         self.maxit = int(options.maxit)
         self.evol_rel_tol, self.feas_tol, self.obj_tol = TF(options.evol_rel_tol), TF(options.feas_tol), TF(options.obj_tol)
         self.adjust_rho, self.adjust_gamma = bool(options.adjust_rho), bool(options.adjust_gamma)
@@ -120,8 +227,6 @@ class PhaseDriver:
                                     np.zeros(m), np.zeros(m), np.zeros((m, p)), np.zeros((m, p)),
                                     np.zeros(m, np.int64), np.zeros(m))
         feas0 = np.asarray(ctx.feasibility_initial, np.float64).copy()
-        if not isinstance(self.comm, LocalComm):
-            feas0 = self.comm.allreduce_scalars(feas0)
         self.log.set_feasibility[0, :] = feas0
         self.stopped_feasible = bool(pp > 0 and _nanmax(feas0) < float(self.feas_tol))   # PARSDMM.jl:63-82
         self.counter, self.ind_ref, self.tol_ref, self.i = 2, self.maxit, 1.0, 0
@@ -158,8 +263,6 @@ class PhaseDriver:
         self.i += 1
         i = self.i
         ctx.rhs_compose(self.rho)                                                    # PARSDMM.jl:101
-        if not isinstance(self.comm, LocalComm):
-            self.comm.allreduce_rhs(ctx)
         self.tol_ref, cg_it, relres, _ = ctx.argmin_x(i, self.tol_ref)               # :106-107
         log.cg_it[i - 1], log.cg_relres[i - 1] = cg_it, relres
         self.cg_total += int(cg_it)
@@ -168,20 +271,7 @@ class PhaseDriver:
         if bb_due:
             flags |= YL_BB
         rp, rd, fe = ctx.update_y_l(i, flags, self.rho, self.gamma)                  # :133
-        own_dist = bool(self.owned[p - 1]) or pp == p
-        obj, evol = ctx.log_scalars() if (own_dist or isinstance(self.comm, LocalComm)) else (0.0, 0.0)
-        rho_new, gam_new = self.rho.copy(), self.gamma.copy()
-        if bb_due:                               # speculative: discarded if the stop rule freezes rho below
-            rho_new, gam_new = ctx.adapt_rho_gamma(self.adjust_rho, self.adjust_gamma, self.rho, self.gamma)
-        if not isinstance(self.comm, LocalComm):
-            own = np.asarray(self.owned, np.float64)
-            lead = 1.0 if (own_dist and (pp < p or self.comm.rank == 0)) else 0.0
-            pack = np.concatenate([rp * own, rd * own, fe * own[:pp], [obj * lead, evol * lead], rho_new * own,
-                                   gam_new * own])
-            pack = self.comm.allreduce_scalars(pack)
-            rp, rd, fe = pack[:p], pack[p:2 * p], pack[2 * p:2 * p + pp]
-            obj, evol = pack[2 * p + pp], pack[2 * p + pp + 1]
-            rho_new, gam_new = pack[2 * p + pp + 2:3 * p + pp + 2], pack[3 * p + pp + 2:]
+        obj, evol = ctx.log_scalars()
         log.r_pri[i - 1], log.r_dual[i - 1] = rp, rd
         sp, sd = TF(rp[0]), TF(rd[0])
         for k in range(1, p):
@@ -197,7 +287,7 @@ class PhaseDriver:
             return True
         rho = self.rho.copy()
         if bb_due and (self.adjust_rho or self.adjust_gamma):                        # :182-207
-            rho, self.gamma = rho_new, gam_new
+            rho, self.gamma = ctx.adapt_rho_gamma(self.adjust_rho, self.adjust_gamma, self.rho, self.gamma)
         if self.adjust_feas_rho and i % 10 == 0 and i > 10 and pp > 0:                # :213-223
             k = _argmax_julia(log.set_feasibility[self.counter - 2, :])
             rho[k] = float(TF(2.0) * TF(rho[k]))
@@ -220,27 +310,34 @@ class PhaseDriver:
                                 log.cg_it[:i], log.cg_relres[:i], dict.fromkeys(TIMING_SECTIONS, float("nan")))
 
 
-def PARSDMM_sharded(m, AtA, TD_OP, set_Prop, P_sub, comp_grid, options, dist=None, device=0, x=None, l=None, y=None):
-    """PARSDMM with the constraint sets sharded over the ranks of ``dist`` (torch.distributed, one
-    process per GPU).  Returns (x, log, l, y); l/y hold the locally owned sets, zeros elsewhere."""
-    from .host import build_context
-    import torch
+def PARSDMM_sharded(m, AtA, TD_OP, set_Prop, P_sub, comp_grid, options, dist=None, device=0, x=None, l=None, y=None,
+                    comm_mode: Optional[str] = None, phase_driver: bool = False):
+    """PARSDMM as one rank of a sharded solve over ``dist`` (torch.distributed, one process per GPU).  Returns
+    (x, log, l, y); x and the log are complete and identical on every rank, l / y hold the locally owned sets (zeros
+    elsewhere).  phase_driver=True runs the loop over the phase entry points instead of sipx_parsdmm."""
+    from .host import build_context, set_default_device
     world = dist.get_world_size() if dist is not None else 1
     rank = dist.get_rank() if dist is not None else 0
     p = len(TD_OP)
     owned = shard_sets(p, world, rank)
-    from .host import set_default_device
     set_default_device(device)
-    ctx = build_context(m, AtA, TD_OP, set_Prop, P_sub, comp_grid, options, x, l, y, device, owned)
+    import torch
+    keep = []
+    attach = None
+    if dist is not None:
+        attach = lambda ctx: keep.append(attach_comm(ctx, dist, torch.device("cuda", device), comm_mode))
+    ctx = build_context(m, AtA, TD_OP, set_Prop, P_sub, comp_grid, options, x, l, y, device, owned, attach)
     try:
-        comm = TorchComm(dist, torch.device("cuda", device)) if world > 1 else LocalComm()
-        drv = PhaseDriver(ctx, options, comm, owned, any(set_Prop.ncvx[:len(P_sub)]))
-        if drv.stopped_feasible:
-            xo = np.array(m, copy=True)
-            return xo, drv.result_log(), None, None
-        while not drv.step():
-            pass
+        if phase_driver:
+            drv = PhaseDriver(ctx, options, any(set_Prop.ncvx[:len(P_sub)]))
+            while not drv.step():
+                pass
+            log, feasible = drv.result_log(), drv.stopped_feasible
+        else:
+            log, feasible = ctx.parsdmm(options)
+        if feasible:
+            return np.array(m, copy=True), log, None, None
         xo, lo, yo = ctx.download()
     finally:
         ctx.close()
-    return xo, drv.result_log(), lo, yo
+    return xo, log, lo, yo

@@ -541,17 +541,21 @@ def test_converged_result_is_feasible(sipx):
         assert f <= 1.5 * float(os_.feas_tol), (i, f)
 
 
-# ---- set-sharded path on the real engine: 2 ranks sharing the one GPU, gloo collectives ----------
-def _sharded_worker(rank, world, port, out, kinds):
+# ---- sharded solve on the real engine: several ranks sharing the one GPU, the engine's collectives over gloo ----------
+def _sharded_worker(rank, world, port, out, kinds, n, backend, mode, phase):
     import os
     import sys
+    import torch
     import torch.distributed as dist
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")          # the container hostname may not resolve
     import datetime
-    dist.init_process_group("gloo", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=180))
+    kw = dict(device_id=torch.device("cuda", 0)) if backend == "nccl" else {}
+    if backend == "nccl":
+        torch.cuda.set_device(0)
+    dist.init_process_group(backend, rank=rank, world_size=world, timeout=datetime.timedelta(seconds=180), **kw)
     try:
         root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
         sys.path.insert(0, root)
@@ -559,39 +563,89 @@ def _sharded_worker(rank, world, port, out, kinds):
         sipx = load_package()
         from sipx import sharded
         TF = np.float32
-        n, h = (32, 24, 16), (25.0, 25.0, 25.0)
+        h = (25.0, 25.0, 25.0)[:len(n)]
         m = model(n, TF, seed=5)
         gs, os_, Ps, As, props, AtAs = _problem(sipx, n, h, TF, kinds, m, dict(maxit=40))
-        x, log, l, y = sharded.PARSDMM_sharded(m.copy(), AtAs, As, props, Ps, gs, os_, dist=dist, device=0)
-        np.savez(os.path.join(out, f"r{rank}.npz"), x=x, obj=log.obj, cg_it=log.cg_it, rho=log.rho, r_pri=log.r_pri)
+        x, log, l, y = sharded.PARSDMM_sharded(m.copy(), AtAs, As, props, Ps, gs, os_, dist=dist, device=0, comm_mode=mode,
+                                               phase_driver=phase)
+        owned = sharded.shard_sets(len(As), world, rank)
+        np.savez(os.path.join(out, f"r{rank}.npz"), x=x, obj=log.obj, evol_x=log.evol_x, cg_it=log.cg_it, rho=log.rho, gamma=log.gamma,
+                 r_pri=log.r_pri, r_dual=log.r_dual, feas=log.set_feasibility, cg_relres=log.cg_relres)
+        np.savez(os.path.join(out, f"yl{rank}.npz"), **{f"y{i}": y[i] for i in range(len(y)) if owned[i]},
+                 **{f"l{i}": l[i] for i in range(len(l)) if owned[i]})
     finally:
         dist.destroy_process_group()
 
 
-# the pytest process holds the GPU too and a box allows 6 processes on it: 4 ranks at most.  4 ranks on 3 terms: one rank
-# owns no set at all (the 8-GPU / 5-term case in small)
+# The pytest process holds the GPU too and a box allows 6 processes on it: 4 ranks at most.  The x-step runs on z-slabs:
+# 16 planes over 2 / 4 ranks (even), over 3 ranks (6, 6, 4: ragged), 5 planes over 4 ranks (2, 2, 1 and an EMPTY slab), a
+# 2-D grid (slabs of rows); 4 ranks on 3 terms: one rank owns no set (the 8-GPU / 5-term case in small).
+SHARDED = [
+    (2, ["bounds", "l1:D_x", "l1:D_y", "l1:D_z"], (32, 24, 16), False),
+    (4, ["bounds", "l1:D_z"], (32, 24, 16), False),
+    (3, ["bounds", "l1:D_x", "l1:D_y", "l1:D_z"], (32, 24, 16), False),
+    (4, ["bounds", "l1:D_z", "l1:D_x"], (12, 10, 5), False),
+    (2, ["l1:TV"], (32, 24, 16), False),              # test/test_PARSDMM_parallel.jl:13-66
+    (2, ["l1dft"], (32, 24, 16), False),              # test/test_PARSDMM_parallel.jl:69-121
+    (2, ["bounds", "l1:TV"], (64, 48), False),        # 2-D
+    (2, ["bounds", "l1:D_x", "l1:D_y", "l1:D_z"], (32, 24, 16), True),      # the loop kept on the host, phase entry points
+]
+
+
 @pytest.mark.timeout(400)
-@pytest.mark.parametrize("world,kinds", [(2, ["bounds", "l1:D_x", "l1:D_y", "l1:D_z"]), (4, ["bounds", "l1:D_z"]),
-                                         (2, ["l1:TV"]), (2, ["l1dft"])])     # the last two: test_PARSDMM_parallel.jl:13-66, 69-121
-def test_sharded_ranks_on_one_gpu(sipx, tmp_path, world, kinds):
+@pytest.mark.parametrize("world,kinds,n,phase", SHARDED)
+def test_sharded_ranks_on_one_gpu(sipx, tmp_path, world, kinds, n, phase):
+    """Serial == sharded to the reference's own tolerance (test/test_PARSDMM_parallel.jl:72,121: 5e-4 on x); every rank ends
+    with identical x and logs; r_dual is filled (the reference's parallel mode leaves it zero)."""
     import os
     import torch.multiprocessing as mp
     port = 29600 + (os.getpid() % 2000) + 11 * world
-    mp.spawn(_sharded_worker, args=(world, port, str(tmp_path), kinds), nprocs=world, join=True)
+    mp.spawn(_sharded_worker, args=(world, port, str(tmp_path), kinds, n, "gloo", "torch", phase), nprocs=world, join=True)
     r0 = np.load(tmp_path / "r0.npz")
     for r in range(1, world):
         r1 = np.load(tmp_path / f"r{r}.npz")
         for k in r0.files:
             assert np.array_equal(r0[k], r1[k], equal_nan=True), k
     TF = np.float32
-    n, h = (32, 24, 16), (25.0, 25.0, 25.0)
+    h = (25.0, 25.0, 25.0)[:len(n)]
     m = model(n, TF, seed=5)
     gs, os_, Ps, As, props, AtAs = _problem(sipx, n, h, TF, kinds, m, dict(maxit=40))
-    xs, ls, _, _ = sipx.PARSDMM(m.copy(), AtAs, As, props, Ps, gs, os_)
+    xs, ls, l_s, y_s = sipx.PARSDMM(m.copy(), AtAs, As, props, Ps, gs, os_)
     K = min(8, len(ls.obj), len(r0["obj"]))
     assert np.array_equal(r0["cg_it"][:K], ls.cg_it[:K])
     assert np.allclose(r0["obj"][:K], ls.obj[:K], rtol=5e-4) and np.allclose(r0["r_pri"][:K], ls.r_pri[:K], rtol=5e-4, atol=1e-12)
+    assert np.allclose(r0["r_dual"][:K], ls.r_dual[:K], rtol=2e-3, atol=1e-10) and (r0["r_dual"][1:K] > 0).any()
+    assert np.allclose(r0["evol_x"][1:K], ls.evol_x[1:K], rtol=5e-4) and np.allclose(r0["rho"][:K], ls.rho[:K], rtol=5e-4)
+    assert np.allclose(r0["feas"][0], ls.set_feasibility[0], rtol=1e-5)
     assert np.linalg.norm(r0["x"] - xs) / np.linalg.norm(xs) < 5e-4        # test/test_PARSDMM_parallel.jl:72
+    if len(r0["obj"]) == len(ls.obj) and np.array_equal(r0["cg_it"], ls.cg_it):      # same trajectory: the owners' y, l too
+        for r in range(world):
+            yl = np.load(tmp_path / f"yl{r}.npz")
+            for k in yl.files:
+                i = int(k[1:])
+                ref = (y_s if k[0] == "y" else l_s)[i]
+                # a multiplier of a set that is not active is a rounding residue of size rho * eps * |y|: that is its scale
+                scale = max(np.linalg.norm(ref), float(ls.rho.max()) * np.finfo(TF).eps * np.linalg.norm(y_s[i]))
+                assert np.linalg.norm(yl[k] - ref) <= 5e-4 * scale, (r, k)
+
+
+def test_sharded_one_rank_through_rccl(sipx, tmp_path):
+    """The engine's native RCCL communicator (librccl looked up at run time, ncclUniqueId through torch.distributed) with
+    a world of one: every collective of the sharded loop is issued; the result equals the plain solve bit for bit except
+    for the obj / evol_x sums, which are taken over the slab in a separate pass."""
+    import os
+    import torch.multiprocessing as mp
+    kinds, n = ["bounds", "l1:D_x", "l1:D_z"], (32, 24, 16)
+    port = 31100 + (os.getpid() % 2000)
+    mp.spawn(_sharded_worker, args=(1, port, str(tmp_path), kinds, n, "nccl", "rccl", False), nprocs=1, join=True)
+    r0 = np.load(tmp_path / "r0.npz")
+    TF = np.float32
+    m = model(n, TF, seed=5)
+    gs, os_, Ps, As, props, AtAs = _problem(sipx, n, (25.0, 25.0, 25.0), TF, kinds, m, dict(maxit=40))
+    xs, ls, _, _ = sipx.PARSDMM(m.copy(), AtAs, As, props, Ps, gs, os_)
+    assert len(r0["obj"]) == len(ls.obj) and np.array_equal(r0["cg_it"], ls.cg_it)
+    assert np.array_equal(r0["x"], xs) and np.array_equal(r0["r_pri"], ls.r_pri) and np.array_equal(r0["rho"], ls.rho)
+    assert np.allclose(r0["obj"], ls.obj, rtol=1e-6)
 
 
 # ---- multilevel (BASELINE config 5 pattern; parity unpinned in the reference, oracle == engine here) ----------
