@@ -187,7 +187,7 @@ class Engine : public EngineBase {
     for (auto e : ev_) (void)hipEventDestroy(e);
     for (auto e : stat_ev_) (void)hipEventDestroy(e);
     for (auto e : cg_ev_) if (e) (void)hipEventDestroy(e);
-    for (hipStream_t q : pool_) (void)hipStreamDestroy(q);
+    for (hipStream_t q : pool_) if (q != stream_) (void)hipStreamDestroy(q);
     if (ev_fork_) (void)hipEventDestroy(ev_fork_);
     (void)hipStreamDestroy(stream_);
   }
@@ -359,7 +359,7 @@ class Engine : public EngineBase {
     SIPX_HIP(hipEventCreateWithFlags(&ev_sums_, hipEventDisableTiming));
     SIPX_HIP(hipHostMalloc((void**)&hres_, sizeof(double) * (p_n_ + 1) * SLOTS, hipHostMallocDefault));
     std::memset(hres_, 0, sizeof(double) * (p_n_ + 1) * SLOTS);
-    for (int k = 0; k < 2 * 2 * NSEC; ++k) {      // two sets of section marks: a step never waits for its own timing
+    for (int k = 0; k < 2 * MAXMARK; ++k) {      // two sets of section marks: a step never waits for its own timing
       hipEvent_t e;
       SIPX_HIP(hipEventCreate(&e));
       ev_.push_back(e);
@@ -405,8 +405,10 @@ class Engine : public EngineBase {
       }
       if (set_streams_ && !s.ext_kind && s.prox != PX_CARD) {     // those two share the engine-wide scratch: main stream
         if ((int)pool_.size() < n_set_streams_) {
-          hipStream_t q;
-          SIPX_HIP(hipStreamCreateWithFlags(&q, hipStreamNonBlocking));
+          // the engine stream itself is the first of the set streams: the set dealt onto it starts right behind the x-step,
+          // with no cross-stream dependency (about 20 us) on the critical path; that of the others hides behind its work
+          hipStream_t q = stream_;
+          if (!pool_.empty()) SIPX_HIP(hipStreamCreateWithFlags(&q, hipStreamNonBlocking));
           pool_.push_back(q);
         }
         s.st = pool_[pool_next_++ % pool_.size()];
@@ -546,7 +548,6 @@ class Engine : public EngineBase {
     if (comm_) comm_->allreduce_sum(part_cg_, 2 * NB, SIPX_F64, stream_);      // ||r_0||^2, ||rhs||^2 block partials
     const unsigned seq = ++cg_seq_;
     K<T>::cg_begin(stream_, part_cg_, cg_dev_, cg_host_, it, (T)*tol_ref_io, seq, (unsigned long long*)ticket_);
-    SIPX_HIP(hipEventRecord(ev_cgb_, stream_));
     // One CG iteration = (halo planes of p from the neighbours) -> product + p.Ap -> x, r update + ||r||^2 -> p update.
     // The host enqueues iteration k+1 as soon as the ticket word says that k did not converge, which workgroup 0 of the
     // p-update publishes before it starts streaming: the GPU does not idle on the round trip and nothing is launched
@@ -564,25 +565,28 @@ class Engine : public EngineBase {
                          (unsigned long long*)ticket_);
       if (comm_) comm_->allreduce_sum(part_cg_ + NB, NB, SIPX_F64, stream_);
       K<T>::cg_update_p(stream_, nloc, p_ + r0, r_ + r0, part_cg_, cg_dev_, mirror, (unsigned long long*)ticket_);
-      SIPX_HIP(hipEventRecord(cg_ev_[k & 1], stream_));
     };
-    bool done = wait_ticket(seq, 0, ev_cgb_, cg_host_);
+    // (no event is recorded inside this loop: a record costs the stream about 5 us, more than the p-update of a small grid)
+    // The first iteration is queued before the verdict of k_cg_begin is back: it is almost always needed, and its kernels
+    // return at once on the device-side `done` flag when it is not (zero right-hand side, cg.jl:51; x already solves the
+    // system to the tolerance, cg.jl:73-76) -- such a launch is not counted as a sample of the dominant kernel.
+    const size_t stat0 = stat_used_;
+    enqueue(1);
+    bool done = wait_ticket(seq, 0, cg_host_);
     CgState<T> fin;
     if (done) {
-      SIPX_HIP(hipEventSynchronize(ev_cgb_));
       fin = cg_host_[0];
+      stat_used_ = stat0;
       if (fin.flag == -9) SIPX_HIP(hipMemsetAsync(x_ + r0, 0, nloc * sizeof(T), stream_));   // cg.jl:51
     } else {
       const int maxIter = 1000;                       // argmin_x.jl:39
       int iter = 1;
-      enqueue(1);
       for (;;) {
-        done = wait_ticket(seq, iter, cg_ev_[iter & 1], cg_host_ + (iter & 1));
+        done = wait_ticket(seq, iter, cg_host_ + (iter & 1));
         if (done || iter == maxIter) break;
         enqueue(++iter);
       }
-      SIPX_HIP(hipEventSynchronize(cg_ev_[iter & 1]));
-      fin = cg_host_[iter & 1];
+      fin = cg_host_[iter & 1];         // written before the ticket (release / acquire): complete
     }
     cg_host_[0] = fin;
     if (comm_) {
@@ -612,7 +616,7 @@ class Engine : public EngineBase {
       double* ptmp = s.ptmp ? s.ptmp : part_tmp_;
       T* mpart = s.mpart ? s.mpart : maxpart_;
       T* cbuf = s.cbuf ? s.cbuf : scr_c_;
-      if (s.st) SIPX_HIP(hipStreamWaitEvent(s.st, ev_fork_, 0));
+      if (s.st && s.st != stream_) SIPX_HIP(hipStreamWaitEvent(s.st, ev_fork_, 0));
       // where y_new, l_new go (see SetState): snapshot iterations overwrite the old snapshot, the others stay off it
       const bool snapshot = (flags & (SIPX_YL_BB | SIPX_YL_FIRST)) != 0;
       const bool first = (flags & SIPX_YL_FIRST) != 0;
@@ -652,17 +656,26 @@ class Engine : public EngineBase {
       if (to_other) { std::swap(s.y, s.y0); std::swap(s.l, s.l0); }     // (y, l) always names the current iterate
       if (snapshot) s.snap = 0;
       else if (to_other && s.snap == 0) s.snap = 1;
-      if (s.st) SIPX_HIP(hipEventRecord(s.ev, s.st));
     }
-    for (int i = 0; i < p_n_; ++i)                                      // join: the reductions below see every set
-      if (sets_[i].owned && sets_[i].st) SIPX_HIP(hipStreamWaitEvent(stream_, sets_[i].ev, 0));
+    for (size_t k = 0; k < pool_.size(); ++k) {                         // join: the reductions below see every set
+      if (pool_[k] == stream_) continue;
+      SetState<T>* last = nullptr;                                      // (one event per set stream: after its last set)
+      for (int i = 0; i < p_n_; ++i)
+        if (sets_[i].owned && sets_[i].st == pool_[k]) last = &sets_[i];
+      if (!last) continue;
+      SIPX_HIP(hipEventRecord(last->ev, last->st));
+      SIPX_HIP(hipStreamWaitEvent(stream_, last->ev, 0));
+    }
     // Minkowski: evol_x runs over all 2N unknowns (PARSDMM.jl:145); the distance-term kernel only saw u + v
     if (mk_) K<T>::log3(stream_, Nx_, x_, (const T*)nullptr, xold_, part_sets_ + (size_t)p_n_ * SLOTS * NB);
     reduce_set_sums((p_n_ + ((mk_ || comm_) ? 1 : 0)) * SLOTS);
-    SIPX_HIP(hipEventRecord(ev_sums_, stream_));
     sums_flags_ = flags;
     sums_pending_ = true;
-    if (!defer_sums_) collect_set_sums(rho, r_pri, r_dual, feas);
+    if (!defer_sums_) {
+      SIPX_HIP(hipEventRecord(ev_sums_, stream_));
+      sums_event_ = ev_sums_;
+      collect_set_sums(rho, r_pri, r_dual, feas);
+    }
   }
 
   // second half of update_y_l: waits for the reduced sums and turns them into the per-set scalars.  The whole-solve loop
@@ -671,7 +684,7 @@ class Engine : public EngineBase {
     if (!sums_pending_) throw std::runtime_error("no y/l update is pending");
     sums_pending_ = false;
     const int flags = sums_flags_;
-    SIPX_HIP(hipEventSynchronize(ev_sums_));
+    SIPX_HIP(hipEventSynchronize(sums_event_));
     have_log_sums_ = false;
     const bool all = comm_ != nullptr;       // sharded: the all-reduced sums of every set are here, on every rank
     for (int i = 0; i < p_n_; ++i) {
@@ -823,10 +836,14 @@ class Engine : public EngineBase {
     const int i = ++R.i;
     const int par = i & 1;
     resolve_timing(log, par);            // marks recorded two steps ago have long completed
-    // GPU sections are bracketed by event pairs (a section may be queued out of the reference's order, see below), the two
-    // host-only sections (stop rule, rho / gamma rules) are timed on the host clock
-    auto sec_begin = [&](int k) { SIPX_HIP(hipEventRecord(ev_[(par * NSEC + k) * 2], stream_)); };
-    auto sec_end = [&](int k) { SIPX_HIP(hipEventRecord(ev_[(par * NSEC + k) * 2 + 1], stream_)); ev_mask_[par] |= 1u << k; };
+    // Section timing: ONE chain of marks on the engine stream (a record costs the stream about 5 us); the time between two
+    // consecutive marks goes to the section named at the later one (-1: a mark that only opens an interval), four marks per
+    // step in the common path.  The two host-only sections (stop rule, rho / gamma rules) use the host clock.
+    auto mark = [&](int section) {
+      if (nmark_[par] >= MAXMARK) return;
+      SIPX_HIP(hipEventRecord(ev_[par * MAXMARK + nmark_[par]], stream_));
+      mark_sec_[par][nmark_[par]++] = section;
+    };
     using clk = std::chrono::steady_clock;
     auto ms_since = [](clk::time_point t0) { return std::chrono::duration<double, std::milli>(clk::now() - t0).count(); };
     // can the rules at the end of iteration `it` change rho?  If not, the right-hand side of iteration it+1 is known as soon
@@ -835,35 +852,33 @@ class Engine : public EngineBase {
       return ((R.adjust_rho || R.adjust_gamma) && it % R.freq == 0) || (R.adjust_feas_rho && it % 10 == 0 && it > 10 && pp > 0);
     };
     {
+      mark(-1);
       if (!R.rhs_ready) {
-        sec_begin(SEC_RHS0);
         rhs_compose(rho.data());
-        sec_end(SEC_RHS0);
+        mark(1);
       }
       R.rhs_ready = false;
-      sec_begin(SEC_X);
       int64_t cg_it; double relres; int flag;
       argmin_x(i, &R.tol_ref, &cg_it, &relres, &flag);
       log->cg_it[i - 1] = cg_it;
       log->cg_relres[i - 1] = relres;
-      sec_end(SEC_X);
+      mark(2);
       int flags = 0;
       if (i % 10 == 0) flags |= SIPX_YL_FEAS;
       if (i == 1) flags |= SIPX_YL_FIRST;
       if ((R.adjust_rho || R.adjust_gamma) && i % R.freq == 0) flags |= SIPX_YL_BB;
-      sec_begin(SEC_YL);
       defer_sums_ = true;                  // queue the kernels and the reduction of their sums, collect them further down
       update_y_l(i, flags, rho.data(), gamma.data(), rpri.data(), rdual.data(), feas.data());
       defer_sums_ = false;
-      sec_end(SEC_YL);
+      mark(3);                             // also the event the host waits on for the sums
+      sums_event_ = ev_[par * MAXMARK + nmark_[par] - 1];
       // Software pipeline: nothing the GPU is given next may depend on the sums the host is about to read.  When the rules
       // below cannot touch rho, rhs_{i+1} = sum_i A_i'(rho_i y_i + l_i) (and, sharded, its reduce-scatter on the
       // communication stream) is queued now and runs while the host waits for the sums and evaluates the stop rule.  A
       // stop leaves x, y, l as they are: rhs is scratch.
       if (i < maxit && !rho_may_change(i)) {
-        sec_begin(SEC_RHS1);
         rhs_compose(rho.data());
-        sec_end(SEC_RHS1);
+        mark(1);
         R.rhs_ready = true;
       }
       collect_set_sums(rho.data(), rpri.data(), rdual.data(), feas.data());
@@ -936,15 +951,18 @@ class Engine : public EngineBase {
         rho_new[k] = (double)std::max(std::min((T)rho_new[k], T(1e4)), T(1e-2));
       log->timing_ms[5] += ms_since(t_host);
       if (R.rhs_ready && rho_new != rho) throw std::runtime_error("internal: rho changed under a right-hand side queued ahead");
+      bool changed = false;
+      for (int k = 0; k < p; ++k) changed |= rho_new[k] != rho[k];
+      if ((i < maxit && !R.rhs_ready) || changed) mark(-1);           // the stream sat idle while the host decided
       if (i < maxit && !R.rhs_ready) {     // rho is final now; queued ahead of the Q update so that, sharded, the
-        sec_begin(SEC_RHS1);               // reduce-scatter (communication stream) runs beside it
-        rhs_compose(rho_new.data());
-        sec_end(SEC_RHS1);
+        rhs_compose(rho_new.data());       // reduce-scatter (communication stream) runs beside it
+        mark(1);
         R.rhs_ready = true;
       }
-      sec_begin(SEC_Q);
-      q_update(rho_new.data(), rho.data());                            // :230-243
-      sec_end(SEC_Q);
+      if (changed) {
+        q_update(rho_new.data(), rho.data());                          // :230-243
+        mark(6);
+      }
       rho = rho_new;
     }
     if (i == maxit) finish_solve(log, maxit, counter, rho, gamma);
@@ -1579,18 +1597,21 @@ class Engine : public EngineBase {
   }
 
   void resolve_timing(sipx_log* log, int par) {
-    const unsigned mask = ev_mask_[par];
-    if (!mask) return;
-    ev_mask_[par] = 0;
+    const int n = nmark_[par];
+    if (!n) return;
+    nmark_[par] = 0;
     // timing_ms: [0] initialization (host side) [1] rhs [2] argmin x [3] y/l update [4] stop rule [5] rho / gamma rules [6] Q update
-    static const int slot[NSEC] = {1, 2, 3, 1, 6};
-    for (int k = 0; k < NSEC; ++k) {
-      if (!(mask & (1u << k))) continue;
-      hipEvent_t b = ev_[(par * NSEC + k) * 2], e = ev_[(par * NSEC + k) * 2 + 1];
-      SIPX_HIP(hipEventSynchronize(e));
-      float ms = 0;
-      SIPX_HIP(hipEventElapsedTime(&ms, b, e));
-      log->timing_ms[slot[k]] += ms;
+    SIPX_HIP(hipEventSynchronize(ev_[par * MAXMARK + n - 1]));
+    hipEvent_t prev = nullptr;
+    for (int k = 0; k < n; ++k) {
+      hipEvent_t e = ev_[par * MAXMARK + k];
+      const int sec = mark_sec_[par][k];
+      if (sec >= 0 && prev) {
+        float ms = 0;
+        if (hipEventElapsedTime(&ms, prev, e) == hipSuccess) log->timing_ms[sec] += ms;
+        else (void)hipGetLastError();
+      }
+      prev = e;
     }
   }
 
@@ -1608,26 +1629,25 @@ class Engine : public EngineBase {
     }
   }
 
-  // Verdict of CG iteration `iter` of solve `seq`: spins on the ticket word (published by the device as soon as it is
-  // known) and falls back on the completion of the iteration's kernels, after which the mirror is final.
-  bool wait_ticket(unsigned seq, int iter, hipEvent_t ev, const CgState<T>* mirror) {
+  // Verdict of CG iteration `iter` of solve `seq`: spins on the ticket word, which the device publishes as soon as the
+  // verdict is known (and after the state mirror, so that is complete too).  Every enqueued iteration publishes one; should
+  // the stream nevertheless run dry without it (a faulted kernel), the mirror decides.
+  bool wait_ticket(unsigned seq, int iter, const CgState<T>* mirror) {
     const unsigned long long want = ((unsigned long long)seq << 32) | ((unsigned long long)(unsigned)iter << 1);
-    bool polled = false;
-    bool done;
-    for (;;) {
+    for (unsigned spins = 1;; ++spins) {
       unsigned long long t = __atomic_load_n(ticket_, __ATOMIC_ACQUIRE);
-      if ((t & ~1ull) == want) { done = (t & 1ull) != 0; break; }
-      const hipError_t q = hipEventQuery(ev);
-      if (q == hipSuccess) {
-        t = __atomic_load_n(ticket_, __ATOMIC_ACQUIRE);
-        done = ((t & ~1ull) == want) ? (t & 1ull) != 0 : mirror->done != 0;
-        break;
+      if ((t & ~1ull) == want) return (t & 1ull) != 0;
+      if ((spins & 0xfff) == 0) {
+        const hipError_t q = hipStreamQuery(stream_);
+        if (q == hipSuccess) {
+          t = __atomic_load_n(ticket_, __ATOMIC_ACQUIRE);
+          if ((t & ~1ull) == want) return (t & 1ull) != 0;
+          return mirror->done != 0;
+        }
+        if (q != hipErrorNotReady) SIPX_HIP(q);
+        (void)hipGetLastError();        // hipErrorNotReady is not an error: keep it out of the launch checks
       }
-      if (q != hipErrorNotReady) SIPX_HIP(q);
-      polled = true;
     }
-    if (polled) (void)hipGetLastError();      // hipErrorNotReady is not an error: keep it out of the launch checks
-    return done;
   }
 
   void free_set(SetState<T>& s) {
@@ -1652,7 +1672,7 @@ class Engine : public EngineBase {
     bool rhs_ready = false;        // the right-hand side of the coming iteration is already queued
     std::vector<double> rho, gamma, rho_new, rpri, rdual, feas;
   };
-  enum { SEC_RHS0 = 0, SEC_X = 1, SEC_YL = 2, SEC_RHS1 = 3, SEC_Q = 4, NSEC = 5 };
+  enum { MAXMARK = 8 };
   Run run_;
   int device_ = 0, ndim_ = 2;
   hipStream_t stream_ = nullptr;
@@ -1686,7 +1706,9 @@ class Engine : public EngineBase {
   CgState<T>*cg_dev_ = nullptr, *cg_host_ = nullptr;
   double* hres_ = nullptr;
   std::vector<hipEvent_t> ev_;
-  unsigned ev_mask_[2] = {0, 0};
+  int nmark_[2] = {0, 0};
+  int mark_sec_[2][MAXMARK];
+  hipEvent_t sums_event_ = nullptr;
   // sharded solve: communicator, this rank's slab [r0_, r1_) of the x-step, rows of Q it maintains
   std::unique_ptr<Comm> comm_;
   long long plane_ = 0, chunk_ = 0, r0_ = 0, r1_ = 0, qr0_ = 0, qr1_ = 0;
