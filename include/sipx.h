@@ -176,6 +176,12 @@ int sipx_q_update(sipx_ctx* ctx, const double* rho_new, const double* rho_old);
 /* copy out x, l[i], y[i] (any pointer may be NULL)                     (src/PARSDMM.jl:257) */
 int sipx_download(sipx_ctx* ctx, void* x, void* const* l, void* const* y);
 
+/* Multilevel (src/PARSDMM_multi_level.jl:61-83, src/interpolate_y_l.jl:16-94): warm start of a finalized context on a finer
+ * grid from a solved context on a coarser one, DEVICE TO DEVICE -- x, every l_i and y_i are resampled (nearest neighbour,
+ * the set-by-set block arithmetic of interpolate_y_l) without visiting the host.  Both contexts hold the same sets, in the
+ * same precision, on the same device.  Overwrites whatever start sipx_finalize gave the fine context. */
+int sipx_warm_start_from(sipx_ctx* fine, sipx_ctx* coarse);
+
 /* ---- B. whole solve (src/PARSDMM.jl:97-257 restated natively) ---- */
 int sipx_parsdmm(sipx_ctx* ctx, const sipx_options* opt, sipx_log* log);
 /* the same solve advanced in pieces: begin, then up to nsteps iterations per call (done = 1 once a stop rule or maxit

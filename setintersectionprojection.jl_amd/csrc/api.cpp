@@ -76,6 +76,12 @@ int sipx_adapt_rho_gamma(sipx_ctx* c, int adjust_rho, int adjust_gamma, double* 
 }
 int sipx_q_update(sipx_ctx* c, const double* rho_new, const double* rho_old) { SIPX_TRY(c->e->q_update(rho_new, rho_old)) }
 int sipx_download(sipx_ctx* c, void* x, void* const* l, void* const* y) { SIPX_TRY(c->e->download(x, l, y)) }
+int sipx_warm_start_from(sipx_ctx* fine, sipx_ctx* coarse) {
+  SIPX_TRY({
+    if (!fine || !coarse) throw std::runtime_error("null context");
+    fine->e->warm_start_from(coarse->e);
+  })
+}
 int sipx_parsdmm(sipx_ctx* c, const sipx_options* opt, sipx_log* log) { SIPX_TRY(c->e->parsdmm(opt, log)) }
 int sipx_parsdmm_begin(sipx_ctx* c, const sipx_options* opt, sipx_log* log) { SIPX_TRY(c->e->parsdmm_begin(opt, log)) }
 int sipx_parsdmm_steps(sipx_ctx* c, int nsteps, int* done) {

@@ -772,6 +772,74 @@ class Engine : public EngineBase {
     K<T>::q_update(stream_, G_, qr0_, qr1_, cds_, a, Q_);
   }
 
+  // Warm start of this (finer) level from a solved coarser one, device to device: x by nearest-neighbour resampling of the
+  // grid (PARSDMM_multi_level.jl:61-67), l_i and y_i set by set as interpolate_y_l does (interpolate_y_l.jl:16-94) -- a
+  // single-block operator resamples its TD_n-shaped array; TV splits its rows into chunks of the sizes of [D_x; D_y; D_z]
+  // blocks (although the storage is [D_z; D_y; D_x]: replicated as written) and resamples each.  The reference's row
+  // order is recovered from / restored to the padded layout by the pack / unpack kernels of the import / export path.
+  void warm_start_from(EngineBase* coarse_base) override {
+    need_final();
+    auto* c = dynamic_cast<Engine<T>*>(coarse_base);
+    if (!c || !c->finalized_) throw std::runtime_error("warm start: the coarse context must be a finalized context of the same precision");
+    if (c->device_ != device_) throw std::runtime_error("warm start: both levels must live on one device");
+    if (c->p_n_ != p_n_ || c->ndim_ != ndim_ || mk_ || c->mk_) throw std::runtime_error("warm start: the two levels must hold the same sets");
+    if (comm_ || c->comm_) throw std::runtime_error("warm start between levels is not available for sharded contexts");
+    SIPX_HIP(hipStreamSynchronize(c->stream_));
+    long long nc[3], nf[3];
+    for (int a = 0; a < 3; ++a) { nc[a] = c->G_.n[a]; nf[a] = G_.n[a]; }
+    resample_nn<T>(stream_, nc, nf, c->x_, x_);
+    long long maxc = 1, maxf = 1;
+    for (int i = 0; i < p_n_; ++i) { maxc = std::max(maxc, c->sets_[i].Mtrue); maxf = std::max(maxf, sets_[i].Mtrue); }
+    T* rc = dalloc<T>(maxc, false);
+    T* rf = dalloc<T>(maxf, false);
+    for (int i = 0; i < p_n_; ++i) {
+      SetState<T>&f = sets_[i], &g = c->sets_[i];
+      if (f.custom || g.custom || f.nblk != g.nblk) throw std::runtime_error("warm start: operator kinds differ between the levels");
+      if (!f.owned || !g.owned) continue;
+      // chunk shapes on both levels
+      int nchunk = 1;
+      long long sc[3][3], sf[3][3];
+      for (int a = 0; a < 3; ++a) { sc[0][a] = nc[a]; sf[0][a] = nf[a]; }
+      if (f.nblk == 1) { sc[0][f.dir[0]] -= 1; sf[0][f.dir[0]] -= 1; }        // TD_n of the operator (get_TD_operator.jl)
+      if (f.nblk >= 2) {                                                        // interpolate_y_l.jl:21-30,53-57
+        nchunk = f.nblk;
+        for (int q = 0; q < nchunk; ++q)
+          for (int a = 0; a < 3; ++a) { sc[q][a] = nc[a] - (a == q ? 1 : 0); sf[q][a] = nf[a] - (a == q ? 1 : 0); }   // chunk q: D_x-, D_y-, D_z-sized
+      }
+      for (int which = 0; which < 2; ++which) {
+        const T* src = which ? g.y : g.l;
+        T* dst = which ? f.y : f.l;
+        const T* rows_c = src;
+        if (!g.ident) {                                                          // padded -> reference row order
+          long long r0 = 0;
+          for (int q = 0; q < g.nblk; ++q) {
+            K<T>::rows_pack(stream_, c->G_, g.dir[q], g.blk_rows[q], src + (long long)q * c->G_.N, rc + r0);
+            r0 += g.blk_rows[q];
+          }
+          rows_c = rc;
+        }
+        T* rows_f = f.ident ? dst : rf;
+        long long oc = 0, of = 0;
+        for (int q = 0; q < nchunk; ++q) {
+          resample_nn<T>(stream_, sc[q], sf[q], rows_c + oc, rows_f + of);
+          oc += sc[q][0] * sc[q][1] * sc[q][2];
+          of += sf[q][0] * sf[q][1] * sf[q][2];
+        }
+        if (oc != g.Mtrue || of != f.Mtrue) throw std::runtime_error("warm start: chunk sizes do not add up to the rows of the operator");
+        if (!f.ident) {
+          long long r0 = 0;
+          for (int q = 0; q < f.nblk; ++q) {
+            K<T>::rows_unpack(stream_, G_, f.dir[q], f.blk_rows[q], rf + r0, dst + (long long)q * G_.N);
+            r0 += f.blk_rows[q];
+          }
+        }
+      }
+    }
+    SIPX_HIP(hipStreamSynchronize(stream_));
+    dfree(rc);
+    dfree(rf);
+  }
+
   void download(void* x, void* const* l, void* const* y) override {
     need_final();
     SIPX_HIP(hipStreamSynchronize(stream_));

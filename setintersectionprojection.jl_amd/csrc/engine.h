@@ -28,6 +28,7 @@ struct EngineBase {
   virtual void adapt_rho_gamma(int adjust_rho, int adjust_gamma, double* rho_io, double* gamma_io) = 0;
   virtual void q_update(const double* rho_new, const double* rho_old) = 0;
   virtual void download(void* x, void* const* l, void* const* y) = 0;
+  virtual void warm_start_from(EngineBase* coarse) = 0;
   virtual void parsdmm(const sipx_options* opt, sipx_log* log) = 0;
   virtual void parsdmm_begin(const sipx_options* opt, sipx_log* log) = 0;
   virtual bool parsdmm_step() = 0;

@@ -33,7 +33,7 @@ EXPORTED_SYMBOLS = [
     "sipx_debug_proj", "sipx_resample_nn", "sipx_set_q_mode", "sipx_apply_Q",
     "sipx_stream",
     "sipx_dev_rhs", "sipx_dev_x", "sipx_set_owned", "sipx_get_rhs", "sipx_prox_l2s",
-    "sipx_rccl_unique_id", "sipx_set_comm_rccl", "sipx_set_comm", "sipx_slab",
+    "sipx_rccl_unique_id", "sipx_set_comm_rccl", "sipx_set_comm", "sipx_slab", "sipx_warm_start_from",
 ]
 
 SIPX_F32, SIPX_F64 = 0, 1
@@ -730,6 +730,10 @@ class Context:
             return a
         _chk(lib().sipx_download(self.h, _ptr(x), ptrs(l), ptrs(y)))
         return x, l, y
+
+    def warm_start_from(self, coarse: "Context"):
+        """x, l, y of this (finer) level from a solved coarser context, resampled on the device (sipx_warm_start_from)."""
+        _chk(lib().sipx_warm_start_from(self.h, coarse.h))
 
     def slab(self):
         """(row0, row1, chunk): this rank's rows of the x-step and the elements per rank of the padded exchange buffers."""

@@ -2,8 +2,9 @@
 (src/PARSDMM_multi_level.jl:8-89) with setup_multi_level_PARSDMM (src/setup_multi_level_PARSDMM.jl:7-137),
 constraint2coarse (src/constraint2coarse.jl:8-104) and interpolate_y_l (src/interpolate_y_l.jl:7-97).
 
-Every level is one native solve (sipx_parsdmm) warm-started through sipx_finalize(x0, l0, y0); the grid
-transfers run on the device (sipx_resample_nn).  PARITY UNPINNED for the transfers: the reference's
+Every level is one native solve (sipx_parsdmm) on its own context; x, l and y pass from a level to the next finer one
+ON THE DEVICE (sipx_warm_start_from: the coarse context stays alive until the fine one has taken its start from it), nothing
+visits the host between levels.  PARITY UNPINNED for the transfers: the reference's
 multilevel test is disabled (test/runtests.jl:47) and no test fixes the tie rounding of
 Interpolations.BSpline(Constant()) (Interpolations.jl 0.13); half-way positions on range(1, stop=nc, length=nf)
 are taken to round up (floor(x + 1/2)).
@@ -93,25 +94,58 @@ def _carry_rho(options, log):
 
 
 def PARSDMM_multi_level(m, TD_OP_levels, AtA_levels, P_sub_levels, set_Prop_levels, comp_grid_levels, options,
-                        device=None):
+                        device=None, timings=None, host_transfers=False):
+    """src/PARSDMM_multi_level.jl:8-89.  `timings` (a dict) receives per-level wall times: context set-up, the device-side
+    warm start, the solve, its iteration count.  host_transfers=True keeps the round-1 path (download, resample through
+    host.resample_nn / interpolate_y_l, upload at sipx_finalize) for A/B comparison."""
+    import time
     n_levels = len(TD_OP_levels)
     n0 = tuple(int(v) for v in comp_grid_levels[0].n)
     dim3 = len(n0) == 3 and n0[2] > 1
     rho_orig = list(options.rho_ini)
     m_levels = [m] + [host.resample_nn(m, n0, tuple(int(v) for v in comp_grid_levels[i].n)) for i in range(1, n_levels)]
-    i = n_levels - 1
-    options.zero_ini_guess = True
-    x, log, l, y = host.PARSDMM(m_levels[i], AtA_levels[i], TD_OP_levels[i], set_Prop_levels[i], P_sub_levels[i],
-                                comp_grid_levels[i], options, device=device)
-    _carry_rho(options, log)
-    for i in range(n_levels - 2, -1, -1):
-        nc = tuple(int(v) for v in comp_grid_levels[i + 1].n)
-        nf = tuple(int(v) for v in comp_grid_levels[i].n)
-        x = host.resample_nn(x, nc, nf)
-        l, y = interpolate_y_l(list(l), list(y), set_Prop_levels, comp_grid_levels, dim3, i)
-        options.zero_ini_guess = False
-        x, log, l, y = host.PARSDMM(m_levels[i], AtA_levels[i], TD_OP_levels[i], set_Prop_levels[i], P_sub_levels[i],
-                                    comp_grid_levels[i], options, x, l, y, device=device)
-        _carry_rho(options, log)
-    options.rho_ini = rho_orig
+    rec = timings if timings is not None else {}
+    rec["levels"] = []
+    prev = None
+    x = l = y = None
+    log = None
+    try:
+        for i in range(n_levels - 1, -1, -1):
+            t0 = time.perf_counter()
+            first = i == n_levels - 1
+            options.zero_ini_guess = first or not host_transfers            # PARSDMM_multi_level.jl:53,81 (device path: start set below)
+            if host_transfers and not first:
+                nc = tuple(int(v) for v in comp_grid_levels[i + 1].n)
+                nf = tuple(int(v) for v in comp_grid_levels[i].n)
+                x = host.resample_nn(x, nc, nf)
+                l, y = interpolate_y_l(list(l), list(y), set_Prop_levels, comp_grid_levels, dim3, i)
+                options.zero_ini_guess = False
+            ctx = host.build_context(m_levels[i], AtA_levels[i], TD_OP_levels[i], set_Prop_levels[i], P_sub_levels[i],
+                                     comp_grid_levels[i], options, x if host_transfers else None, l if host_transfers else None,
+                                     y if host_transfers else None, device)
+            t1 = time.perf_counter()
+            if prev is not None:
+                ctx.warm_start_from(prev)                                    # x, l_i, y_i: coarse -> fine on the device
+                prev.close()
+                prev = None
+            t2 = time.perf_counter()
+            log, feasible = ctx.parsdmm(options)
+            t3 = time.perf_counter()
+            rec["levels"].append({"grid": [int(v) for v in comp_grid_levels[i].n], "context_s": t1 - t0, "warm_start_s": t2 - t1,
+                                  "solve_s": t3 - t2, "iterations": int(len(log.obj)), "cg_iterations": int(np.sum(log.cg_it))})
+            _carry_rho(options, log)                                         # :57,83
+            if host_transfers:
+                x, l, y = ctx.download()
+                ctx.close()
+            else:
+                prev = ctx
+        if not host_transfers:
+            t0 = time.perf_counter()
+            x, l, y = prev.download()
+            rec["download_s"] = time.perf_counter() - t0
+    finally:
+        if prev is not None:
+            prev.close()
+        options.rho_ini = rho_orig                                           # :87
+        options.zero_ini_guess = n_levels == 1                               # :53,81 leave it false after a warm-started level
     return x, log, l, y

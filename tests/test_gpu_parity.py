@@ -678,6 +678,33 @@ def test_multilevel_matches_oracle(sipx, TF, n, h):
     assert list(os_.rho_ini) == [10.0] or np.allclose(os_.rho_ini, 10.0)          # restored (PARSDMM_multi_level.jl:87)
 
 
+@pytest.mark.parametrize("TF,n,h,levels", [(np.float64, (32, 24), (25.0, 6.0), 2), (np.float32, (16, 16, 16), (25.0, 25.0, 25.0), 2),
+                                           (np.float64, (22, 18, 14), (25.0, 20.0, 10.0), 3)])
+def test_multilevel_device_transfers_equal_host_transfers(sipx, TF, n, h, levels):
+    """sipx_warm_start_from (x, l, y resampled from context to context on the device) == the round-1 path (download,
+    resample through sipx_resample_nn and the host interpolate_y_l, upload at sipx_finalize): the same integer index
+    arithmetic either way, so the warm starts and hence the solves agree bit for bit."""
+    from sipx import multilevel as ML
+    m = model(n, TF, seed=10)
+    TV = O.get_TD_operator(O.compgrid(h, n), "TV", TF)[0]
+    Dz = O.get_TD_operator(O.compgrid(h, n), "D_z", TF)[0]
+    s = Dz @ m
+    cons = lambda: [sipx.set_definitions("bounds", "identity", 1600.0, 3900.0, ("matrix", "")),
+                    sipx.set_definitions("bounds", "D_z", float(0.5 * s.min()), float(0.5 * s.max()), ("matrix", "")),
+                    sipx.set_definitions("l1", "TV", 0.0, float(0.5 * np.abs(TV @ m).sum()), ("matrix", ""))]
+    out = []
+    for host_path in (True, False):
+        opt = sipx.PARSDMM_options(FL=TF, maxit=25)
+        L = ML.setup_multi_level_PARSDMM(m, levels, 2, sipx.compgrid(h, n), cons(), opt)
+        T = {}
+        x, log, l, y = ML.PARSDMM_multi_level(m.copy(), *L[:5], opt, timings=T, host_transfers=host_path)
+        assert len(T["levels"]) == levels and [v["grid"] for v in T["levels"]][-1] == list(n)
+        out.append((x, log, l, y))
+    (xa, la, l_a, y_a), (xb, lb, l_b, y_b) = out
+    assert np.array_equal(xa, xb) and np.array_equal(la.obj, lb.obj) and np.array_equal(la.cg_it, lb.cg_it)
+    assert all(np.array_equal(a, b) for a, b in zip(y_a, y_b)) and all(np.array_equal(a, b) for a, b in zip(l_a, l_b))
+
+
 # ---- stencil form of Q (sipx_set_q_mode(SIPX_Q_STENCIL), SURVEY 8f rank 2): rounding-level agreement with CDS --------
 @pytest.mark.parametrize("TF", [np.float32, np.float64])
 @pytest.mark.parametrize("n,h", GRIDS)

@@ -20,9 +20,17 @@ del s
 opt = sipx.PARSDMM_options(FL=TF, maxit=maxit, evol_rel_tol=10 * np.finfo(TF).eps)
 L = ML.setup_multi_level_PARSDMM(m, 3, 2, g, c, opt)
 t1 = time.perf_counter()
-x, log, l, y = ML.PARSDMM_multi_level(m, *L[:5], opt)
+host_path = len(sys.argv) > 3 and sys.argv[3] == "host"
+T = {}
+x, log, l, y = ML.PARSDMM_multi_level(m, *L[:5], opt, timings=T, host_transfers=host_path)
 t2 = time.perf_counter()
-print(json.dumps({"grid": n, "levels": [list(gg.n) for gg in L[4]], "setup_s": t1 - t0, "solve_s": t2 - t1,
-                  "finest_iterations": int(len(log.obj)), "finest_cg": int(np.sum(log.cg_it)),
+fin = T["levels"][-1]
+print(json.dumps({"grid": n, "levels": [list(gg.n) for gg in L[4]], "transfers": "host (round-1 path)" if host_path else "device (sipx_warm_start_from)",
+                  "setup_s": t1 - t0, "whole_solve_s": t2 - t1,
+                  "solve_only_s": sum(v["solve_s"] for v in T["levels"]), "warm_start_total_s": sum(v["warm_start_s"] for v in T["levels"]),
+                  "context_total_s": sum(v["context_s"] for v in T["levels"]), "download_s": T.get("download_s"),
+                  "per_level": T["levels"],
+                  "finest_iterations": fin["iterations"], "finest_cg": fin["cg_iterations"],
+                  "finest_level_it_per_s": fin["iterations"] / fin["solve_s"],
                   "obj_last": float(log.obj[-1]), "feas_last": [float(v) for v in log.set_feasibility[-1]],
                   "finite": bool(np.isfinite(x).all())}))
