@@ -393,6 +393,36 @@ __global__ __launch_bounds__(SIPX_DECIDE_NT) void k_decide(const double* __restr
   }
 }
 
+// Double-double accumulation (Knuth's TwoSum): the gathered magnitudes arrive in an order that changes from run to run (they
+// are compacted through atomics), and a plain float64 sum of them would change in its last bits with that order -- and the
+// threshold, and every y, l and x after it, with it.  Carried as (hi, lo) pairs the sum is good to ~1e-32 relative whatever
+// the order, so its rounding to float64 is the same in every run (short of the exact sum sitting on a rounding boundary).
+struct DD {
+  double hi, lo;
+};
+__device__ __forceinline__ DD dd_add(DD a, double b) {
+  const double s = a.hi + b, bb = s - a.hi;
+  const double e = (a.hi - (s - bb)) + (b - bb);
+  return DD{s, a.lo + e};
+}
+__device__ __forceinline__ DD dd_add(DD a, DD b) {
+  const double s = a.hi + b.hi, bb = s - a.hi;
+  const double e = (a.hi - (s - bb)) + (b.hi - bb);
+  const double lo = (a.lo + b.lo) + e;
+  const double hi = s + lo;                   // renormalise
+  return DD{hi, lo - (hi - s)};
+}
+__device__ __forceinline__ double shfl_xor_f64(double v, int m) {
+  const long long b = __double_as_longlong(v);
+  const int lo = __shfl_xor((int)(b & 0xffffffffll), m, 64), hi = __shfl_xor((int)(b >> 32), m, 64);
+  return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
+}
+__device__ __forceinline__ DD wave_sum_dd(DD v) {
+#pragma unroll
+  for (int m = 1; m < 64; m <<= 1) v = dd_add(v, DD{shfl_xor_f64(v.hi, m), shfl_xor_f64(v.lo, m)});
+  return v;
+}
+
 // Michelot's iteration on the gathered magnitudes: theta <- (S_above + S_in(>theta) - b) / (C_above + C_in(>theta)),
 // monotone from the bracket's lower end, exact after finitely many steps (stops when the active count repeats).
 // Then prepares the next call: probes and speculative range centred on the new theta.
@@ -404,6 +434,7 @@ __global__ __launch_bounds__(SIPX_SOLVE_NT) void k_l1_solve(ProjScalars<T>* ps, 
                                                    const double* __restrict__ partials, long long true_len) {
   constexpr int NT = SIPX_SOLVE_NT;
   __shared__ double ssum[NT / 64];
+  __shared__ double ssum_lo[NT / 64];
   __shared__ double scnt[NT / 64];
   __shared__ double sh_theta, sh_sa, sh_ca;
   __shared__ int sh_done;
@@ -435,7 +466,8 @@ __global__ __launch_bounds__(SIPX_SOLVE_NT) void k_l1_solve(ProjScalars<T>* ps, 
     theta = ps->lo;
     double cprev = -1;
     for (int it = 0; it < 200; ++it) {
-      double s = 0, c = 0;
+      DD s = {0.0, 0.0};
+      double c = 0;
       {   // one workgroup streams the gathered values: 16-byte loads, four in flight per thread
         const long long nv = n / 4;
         for (long long i0 = threadIdx.x; i0 < nv; i0 += 4 * NT) {
@@ -451,22 +483,24 @@ __global__ __launch_bounds__(SIPX_SOLVE_NT) void k_l1_solve(ProjScalars<T>* ps, 
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
               const double av = (double)q[u].v[k];
-              if (av > theta) { s += av; c += 1.0; }
+              if (av > theta) { s = dd_add(s, av); c += 1.0; }
             }
         }
         for (long long e = 4 * nv + threadIdx.x; e < n; e += NT) {
           const double av = (double)compact[e];
-          if (av > theta) { s += av; c += 1.0; }
+          if (av > theta) { s = dd_add(s, av); c += 1.0; }
         }
       }
-      s = wave_sum(s);
+      s = wave_sum_dd(s);
       c = wave_sum(c);
       __syncthreads();
-      if ((threadIdx.x & 63) == 0) { ssum[threadIdx.x >> 6] = s; scnt[threadIdx.x >> 6] = c; }
+      if ((threadIdx.x & 63) == 0) { ssum[threadIdx.x >> 6] = s.hi; ssum_lo[threadIdx.x >> 6] = s.lo; scnt[threadIdx.x >> 6] = c; }
       __syncthreads();
       if (threadIdx.x == 0) {
-        double S = 0, Cc = 0;
-        for (int i = 0; i < NT / 64; ++i) { S += ssum[i]; Cc += scnt[i]; }
+        DD Sd = {0.0, 0.0};
+        double Cc = 0;
+        for (int i = 0; i < NT / 64; ++i) { Sd = dd_add(Sd, DD{ssum[i], ssum_lo[i]}); Cc += scnt[i]; }
+        const double S = Sd.hi + Sd.lo;
         const double tot = ca + Cc;
         double tn = theta;
         if (tot > 0) tn = (sa + S - b) / tot;

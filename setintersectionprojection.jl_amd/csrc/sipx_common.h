@@ -56,6 +56,24 @@ struct Grid {
   long long n[3];     // n1 (fastest), n2, n3 (1 for 2-D)
   long long N;        // n1*n2*n3
   long long st[3];    // strides 1, n1, n1*n2
+  // Division of a linear index (< 2^31) by n1 and by n2 as a multiply-high and a shift (Granlund-Montgomery): for
+  // 2^(l-1) < d <= 2^l, m = floor(2^(31+l) / d) + 1 gives floor(u / d) = mulhi(u, m) >> (l - 1) for every u < 2^31.
+  // m == 0: not set up (grids built ad hoc for one-off kernels): the kernels divide.  The stencil kernels take the
+  // coordinates of every vector they touch; a hardware-free 32-bit division costs ~25 VALU instructions each.
+  unsigned m1 = 0, s1 = 0, m2 = 0, s2 = 0;
+  void set_fast_div() {
+    auto magic = [](long long d, unsigned& m, unsigned& sh) {
+      m = 0; sh = 0;
+      if (d < 2 || d >= (1ll << 31)) return;          // d == 1 and oversize: plain division
+      int l = 0;
+      while ((1ll << l) < d) ++l;
+      const unsigned long long q = ((unsigned long long)1 << (31 + l)) / (unsigned long long)d + 1ull;
+      m = (unsigned)q;
+      sh = (unsigned)(l - 1);
+    };
+    magic(n[0], m1, s1);
+    magic(n[1], m2, s2);
+  }
 };
 
 struct CdsArgs {

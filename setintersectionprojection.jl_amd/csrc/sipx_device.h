@@ -244,9 +244,9 @@ struct Coord {
 __device__ __forceinline__ Coord coords(const Grid& G, long long g) {
   Coord c;
   const unsigned u = (unsigned)g, n1 = (unsigned)G.n[0], n2 = (unsigned)G.n[1];
-  const unsigned jk = u / n1;
+  const unsigned jk = G.m1 ? (__umulhi(u, G.m1) >> G.s1) : u / n1;
   c.i = (int)(u - jk * n1);
-  const unsigned k = jk / n2;
+  const unsigned k = G.m2 ? (__umulhi(jk, G.m2) >> G.s2) : jk / n2;
   c.j = (int)(jk - k * n2);
   c.k = (int)k;
   return c;

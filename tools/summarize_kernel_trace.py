@@ -1,7 +1,7 @@
 """Summarise a rocprofv3 --kernel-trace CSV: per-kernel launch count / average duration, and for the dominant kernel
-(k_cds<MODE 1>) the average over the launches that did work.  CG iterations are enqueued one ahead of the host
-(engine.cpp, argmin_x): the speculative launch past convergence returns at once and would otherwise drag the average
-of the same kernel name down; those early exits (< 5 us) are listed separately.
+(k_cds<MODE 1>) the average over the launches that did work.  Since round 2 the engine launches a CG iteration only once
+the verdict of the one before it is back (ticket word, engine.cpp argmin_x), so there are no launches that return at once
+and rocprofv3's own --stats row needs no post-processing; launches under 5 us are still listed separately as a check.
 
 usage: python tools/summarize_kernel_trace.py <dir with *_kernel_trace.csv> <out.json>"""
 import csv
@@ -38,7 +38,7 @@ def main():
                                   "early_exit_launches": len(d) - len(work),
                                   "avg_us_with_work": sum(work) / max(len(work), 1),
                                   "avg_us_all": sum(d) / len(d),
-                                  "note": "early exits = speculative CG iteration enqueued past convergence (returns on the device-side done flag)"}
+                                  "note": "early exits = launches under 5 us; none are expected (no CG iteration is launched past convergence)"}
     json.dump(res, open(out, "w"), indent=1)
     print(json.dumps(res.get("dominant_kernel", {}), indent=1))
 
