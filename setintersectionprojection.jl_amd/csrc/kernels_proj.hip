@@ -227,6 +227,7 @@ __global__ void k_ps_init(ProjScalars<T>* ps, long long* cidx) {
   ps->spec_ok = ps->spec_overflow = 0;
   ps->tau = T(0);
   ps->quota = 0x7fffffffffffffffll;
+  ps->coop_arrive = ps->coop_finish = ps->coop_abort = 0;
 }
 template <typename T>
 void K<T>::ps_init(hipStream_t s, ProjScalars<T>* ps, long long* cidx) {
@@ -274,32 +275,49 @@ __device__ __forceinline__ void reduce_slots(const double* __restrict__ partials
   }
 }
 
-// Scalar decisions after a probe pass.  STAGE 0: after the first pass; STAGE 1: after the gated refinement.
+// The PREP_SLOTS sums of a probe pass, one workgroup per slot (fixed order), plus one workgroup for the largest and the
+// smallest non-zero magnitude.  A single workgroup summing all 19 x 2048 partials took 33 us at 256^3 and 135 us at 512^3
+// (its dependent batches of loads queue behind the streaming passes of the other set stream); spread over 20 workgroups
+// every load of a slot is in flight at once.
 template <typename T, int STAGE>
-__global__ __launch_bounds__(SIPX_DECIDE_NT) void k_decide(const double* __restrict__ partials, const T* __restrict__ maxpart,
-                                                 ProjScalars<T>* ps, int prox, T pmin, T pmax, long long true_len,
-                                                 int nospec, double capdiv) {
+__global__ __launch_bounds__(BLOCK) void k_slot_sums(const double* __restrict__ partials, const T* __restrict__ maxpart,
+                                                     ProjScalars<T>* ps) {
   if (STAGE == 1 && !(ps->need && !ps->spec_ok && ps->refine)) return;
-  constexpr int NT = SIPX_DECIDE_NT;
-  __shared__ double red[PREP_SLOTS];
-  __shared__ T smax[NT / 64];
-  reduce_slots<NT>(partials, red);
-  __shared__ T smin[NT / 64];
+  if (blockIdx.x < PREP_SLOTS) {
+    const double v = block_sum_partials(partials + (long long)blockIdx.x * NB);
+    if (threadIdx.x == 0) ps->red[blockIdx.x] = v;
+    return;
+  }
+  __shared__ T smax[BLOCK / 64], smin[BLOCK / 64];
+  T vmax = T(0), vmin = (T)INFINITY;
+  for (int i = threadIdx.x; i < NB; i += BLOCK) {
+    vmax = maxpart[i] > vmax ? maxpart[i] : vmax;
+    const T mn = maxpart[NB + i];                 // 0 = entry beyond the pass's grid, or a workgroup that saw no non-zero magnitude
+    vmin = (mn > T(0) && mn < vmin) ? mn : vmin;
+  }
+  vmax = wave_max<T>(vmax);
+  vmin = -wave_max<T>(-vmin);
+  if ((threadIdx.x & 63) == 0) { smax[threadIdx.x >> 6] = vmax; smin[threadIdx.x >> 6] = vmin; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    for (int i = 0; i < BLOCK / 64; ++i) { vmax = smax[i] > vmax ? smax[i] : vmax; vmin = smin[i] < vmin ? smin[i] : vmin; }
+    ps->rmax = vmax;
+    ps->rmin = vmin;
+  }
+}
+
+// Scalar decisions after a probe pass (one thread; the sums come from k_slot_sums).  STAGE 0: after the first pass;
+// STAGE 1: after the gated refinement.
+template <typename T, int STAGE>
+__global__ __launch_bounds__(64) void k_decide(ProjScalars<T>* ps, int prox, T pmin, T pmax, long long true_len,
+                                               int nospec, double capdiv) {
+  if (STAGE == 1 && !(ps->need && !ps->spec_ok && ps->refine)) return;
+  if (threadIdx.x != 0) return;
+  const double* red = ps->red;
   T vmax = T(0), vmin = (T)INFINITY;
   if (STAGE == 0) {
-    for (int i = threadIdx.x; i < NB; i += NT) {
-      vmax = maxpart[i] > vmax ? maxpart[i] : vmax;
-      const T mn = maxpart[NB + i];                 // 0 = entry beyond the pass's grid, or a workgroup that saw no non-zero magnitude
-      vmin = (mn > T(0) && mn < vmin) ? mn : vmin;
-    }
-    vmax = wave_max<T>(vmax);
-    vmin = -wave_max<T>(-vmin);
-    if ((threadIdx.x & 63) == 0) { smax[threadIdx.x >> 6] = vmax; smin[threadIdx.x >> 6] = vmin; }
-  }
-  __syncthreads();
-  if (threadIdx.x != 0) return;
-  if (STAGE == 0) {
-    for (int i = 0; i < NT / 64; ++i) { vmax = smax[i] > vmax ? smax[i] : vmax; vmin = smin[i] < vmin ? smin[i] : vmin; }
+    vmax = ps->rmax;
+    vmin = ps->rmin;
     ps->vmin = vmin;
     ps->asum = red[0];
     ps->sumsq = red[1];
@@ -429,6 +447,19 @@ __device__ __forceinline__ DD wave_sum_dd(DD v) {
 #ifndef SIPX_SOLVE_NT
 #define SIPX_SOLVE_NT 1024
 #endif
+// COOPERATIVE SWEEPS.  The kernel is launched with SOLVE_G workgroups.  A small gather (the rule while the speculation holds) is
+// handled by workgroup 0 alone, the others return at once.  From SOLVE_COOP_MIN gathered values on, every sweep of the
+// iteration is split over the workgroups: each sums its slice, publishes (hi, lo, count) in its slot of a double-buffered
+// scratch inside ProjScalars, arrives at a counter and waits for the others (agent-scope release / acquire; the spin is
+// bounded and leaves through an abort flag), then ALL of them add the SOLVE_G partials in slot order and take the same step.
+// One workgroup streaming 2 M magnitudes per sweep took up to 1 ms at 512^3; split 32 ways the sweep is bandwidth-trivial,
+// which is what lets the bracket be gathered earlier instead of being refined by one more full pass over v (L1 cap).
+// The workgroup that finishes last writes theta and prepares the next call (nobody may reset the state while another
+// workgroup has yet to read it).
+constexpr int SOLVE_G = 32;
+constexpr long long SOLVE_COOP_MIN = 1ll << 17;
+static_assert(SOLVE_G <= SIPX_SOLVE_SLOTS, "ProjScalars holds SIPX_SOLVE_SLOTS cooperative slots");
+
 template <typename T>
 __global__ __launch_bounds__(SIPX_SOLVE_NT) void k_l1_solve(ProjScalars<T>* ps, T radius, const T* __restrict__ compact,
                                                    const double* __restrict__ partials, long long true_len) {
@@ -439,6 +470,10 @@ __global__ __launch_bounds__(SIPX_SOLVE_NT) void k_l1_solve(ProjScalars<T>* ps, 
   __shared__ double sh_theta, sh_sa, sh_ca;
   __shared__ int sh_done;
   const int need = ps->need;
+  const int G = (int)gridDim.x, wg = (int)blockIdx.x;
+  const long long n_all = need ? (long long)ps->n_compact : 0;
+  const bool coop = G > 1 && n_all >= SOLVE_COOP_MIN;
+  if (!coop && wg != 0) return;
   double theta = 0;
   int iters_done = 0;
   if (need) {
@@ -461,16 +496,20 @@ __global__ __launch_bounds__(SIPX_SOLVE_NT) void k_l1_solve(ProjScalars<T>* ps, 
       }
     }
     __syncthreads();
-    const long long n = (long long)ps->n_compact;
+    // this workgroup's slice of the gathered values (all of them unless the sweeps are shared), in vectors of four
+    const long long nv_all = n_all / 4;
+    const long long per = coop ? (nv_all + G - 1) / G : nv_all;
+    const long long v0 = coop ? (long long)wg * per : 0, v1 = coop ? (v0 + per < nv_all ? v0 + per : nv_all) : nv_all;
+    const bool tail_owner = !coop || wg == G - 1;
     const double sa = sh_sa, ca = sh_ca, b = (double)radius;
     theta = ps->lo;
     double cprev = -1;
     for (int it = 0; it < 200; ++it) {
       DD s = {0.0, 0.0};
       double c = 0;
-      {   // one workgroup streams the gathered values: 16-byte loads, four in flight per thread
-        const long long nv = n / 4;
-        for (long long i0 = threadIdx.x; i0 < nv; i0 += 4 * NT) {
+      {   // 16-byte loads, four in flight per thread
+        const long long nv = v1;
+        for (long long i0 = v0 + threadIdx.x; i0 < nv; i0 += 4 * NT) {
           Vec<T, 4> q[4];
 #pragma unroll
           for (int u = 0; u < 4; ++u) {
@@ -486,10 +525,11 @@ __global__ __launch_bounds__(SIPX_SOLVE_NT) void k_l1_solve(ProjScalars<T>* ps, 
               if (av > theta) { s = dd_add(s, av); c += 1.0; }
             }
         }
-        for (long long e = 4 * nv + threadIdx.x; e < n; e += NT) {
-          const double av = (double)compact[e];
-          if (av > theta) { s = dd_add(s, av); c += 1.0; }
-        }
+        if (tail_owner)
+          for (long long e = 4 * nv_all + threadIdx.x; e < n_all; e += NT) {
+            const double av = (double)compact[e];
+            if (av > theta) { s = dd_add(s, av); c += 1.0; }
+          }
       }
       s = wave_sum_dd(s);
       c = wave_sum(c);
@@ -500,11 +540,36 @@ __global__ __launch_bounds__(SIPX_SOLVE_NT) void k_l1_solve(ProjScalars<T>* ps, 
         DD Sd = {0.0, 0.0};
         double Cc = 0;
         for (int i = 0; i < NT / 64; ++i) { Sd = dd_add(Sd, DD{ssum[i], ssum_lo[i]}); Cc += scnt[i]; }
+        if (coop) {        // publish this workgroup's share, wait for the others, add all shares in slot order
+          const int buf = it & 1;
+          __hip_atomic_store(&ps->coop_hi[buf][wg], Sd.hi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          __hip_atomic_store(&ps->coop_lo[buf][wg], Sd.lo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          __hip_atomic_store(&ps->coop_c[buf][wg], Cc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          __hip_atomic_fetch_add(&ps->coop_arrive, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+          const unsigned want = (unsigned)G * (unsigned)(it + 1);
+          unsigned spins = 0;
+          while (__hip_atomic_load(&ps->coop_arrive, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < want) {
+            if (__hip_atomic_load(&ps->coop_abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) break;
+            if (++spins > 8000000u) {      // several seconds: something is wrong -- leave, flagged, rather than hang
+              __hip_atomic_store(&ps->coop_abort, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+              break;
+            }
+            __builtin_amdgcn_s_sleep(4);
+          }
+          Sd = DD{0.0, 0.0};
+          Cc = 0;
+          for (int k = 0; k < G; ++k) {
+            Sd = dd_add(Sd, DD{__hip_atomic_load(&ps->coop_hi[buf][k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT),
+                               __hip_atomic_load(&ps->coop_lo[buf][k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)});
+            Cc += __hip_atomic_load(&ps->coop_c[buf][k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          }
+        }
         const double S = Sd.hi + Sd.lo;
         const double tot = ca + Cc;
         double tn = theta;
         if (tot > 0) tn = (sa + S - b) / tot;
         sh_done = (Cc == cprev || !(tot > 0)) ? 1 : 0;
+        if (coop && __hip_atomic_load(&ps->coop_abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) sh_done = 1;
         sh_theta = tn > theta ? tn : theta;
         sh_sa = sa; sh_ca = tot;                     // sh_ca: size of the active set at the last evaluated theta
         scnt[0] = Cc;
@@ -517,6 +582,14 @@ __global__ __launch_bounds__(SIPX_SOLVE_NT) void k_l1_solve(ProjScalars<T>* ps, 
     }
   }
   if (threadIdx.x == 0) {
+    if (coop) {     // only the workgroup that finishes last may write the result and reset the state
+      const unsigned t = __hip_atomic_fetch_add(&ps->coop_finish, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+      if (t != (unsigned)G - 1u) return;
+      ps->dbg[3] = ps->coop_abort ? -1.0 : 0.0;
+      ps->coop_arrive = 0;
+      ps->coop_finish = 0;
+      ps->coop_abort = 0;
+    }
     if (need) {
       // The reference's scan `while u[rho+1] > (sv[rho+1]-b)/(rho+1) && rho+1 < lv` (project_l1_Duchi!.jl:42) never lets
       // the active set reach the whole vector: when every entry would stay active it stops at lv-1 and thresholds with
@@ -526,7 +599,8 @@ __global__ __launch_bounds__(SIPX_SOLVE_NT) void k_l1_solve(ProjScalars<T>* ps, 
       const T th = (T)theta;
       ps->theta = th > T(0) ? th : T(0);       // theta = max(0, .)   project_l1_Duchi!.jl:46
     }
-    ps->dbg[0] = (double)ps->n_compact; ps->dbg[1] = ps->spec_overflow; ps->dbg[2] = ps->spec_ok; ps->dbg[3] = iters_done;
+    ps->dbg[0] = (double)ps->n_compact; ps->dbg[1] = ps->spec_overflow; ps->dbg[2] = ps->spec_ok;
+    ps->dbg[3] = (coop && ps->dbg[3] < 0) ? -1.0 : (double)iters_done;       // -1: a cooperative sweep was abandoned
     // ---- state for the next call ----
     if (need && theta > 0) {
       double hw = ps->hw;
@@ -715,15 +789,16 @@ static void launch_chain(hipStream_t s, const Grid& g, const SetArgs<T>& a, int 
     return;
   }
   SIPX_PASS(M_FIRST);
-  hipLaunchKernelGGL((k_decide<T, 0>), dim3(1), dim3(SIPX_DECIDE_NT), 0, s, partials, maxpart, ps, a.prox, a.plo, a.phi, true_len,
-                     (a.flags & F_NOSPEC) ? 1 : 0, capdiv);
+  hipLaunchKernelGGL((k_slot_sums<T, 0>), dim3(PREP_SLOTS + 1), dim3(BLOCK), 0, s, partials, maxpart, ps);
+  hipLaunchKernelGGL((k_decide<T, 0>), dim3(1), dim3(64), 0, s, ps, a.prox, a.plo, a.phi, true_len, (a.flags & F_NOSPEC) ? 1 : 0, capdiv);
   if (a.prox == PX_L1) {
     for (int r = 0; r < L1_REFINES; ++r) {
       SIPX_PASS(M_PROBE);
-      hipLaunchKernelGGL((k_decide<T, 1>), dim3(1), dim3(SIPX_DECIDE_NT), 0, s, partials, maxpart, ps, a.prox, a.plo, a.phi, true_len, 0, capdiv);
+      hipLaunchKernelGGL((k_slot_sums<T, 1>), dim3(PREP_SLOTS), dim3(BLOCK), 0, s, partials, maxpart, ps);
+      hipLaunchKernelGGL((k_decide<T, 1>), dim3(1), dim3(64), 0, s, ps, a.prox, a.plo, a.phi, true_len, 0, capdiv);
     }
     SIPX_PASS(M_COMPACT);
-    hipLaunchKernelGGL((k_l1_solve<T>), dim3(1), dim3(SIPX_SOLVE_NT), 0, s, ps, a.phi, compact, partials, true_len);
+    hipLaunchKernelGGL((k_l1_solve<T>), dim3(SOLVE_G), dim3(SIPX_SOLVE_NT), 0, s, ps, a.phi, compact, partials, true_len);
   }
 #undef SIPX_PASS
   SIPX_HIP(hipGetLastError());

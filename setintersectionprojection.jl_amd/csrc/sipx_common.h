@@ -38,6 +38,7 @@ constexpr int MAXD = 32;          // CDS bands held in kernel arguments
 constexpr int MAX_SETS = 16;      // sets fused in one rhs_compose launch
 constexpr int YL_SLOTS = 13;      // reductions produced by one y/l-update launch
 constexpr int L1_K = 8;          // probe thresholds of the l1-ball threshold search
+#define SIPX_SOLVE_SLOTS 64      // most workgroups a cooperative k_l1_solve may be launched with
 constexpr int PREP_SLOTS = 3 + 2 * L1_K;   // ||v||_1, ||v||_2^2, nnz, S_k, C_k
 
 // reduction slots of k_yl (per set)
@@ -126,6 +127,12 @@ struct ProjScalars {
   long long* cidx;    // device buffer for the indices of the gathered magnitudes
   double c_lo, c_hi;  // counts of |v| > lo and |v| > hi of the current bracket
   T tau_prev;
+  // sums of the PREP_SLOTS partial slots of the last probe pass, its largest / smallest non-zero magnitude (k_slot_sums)
+  double red[PREP_SLOTS];
+  T rmax, rmin;
+  // cooperative sweeps of k_l1_solve: per-workgroup shares of (sum hi, sum lo, count), double buffered by iteration parity
+  double coop_hi[2][SIPX_SOLVE_SLOTS], coop_lo[2][SIPX_SOLVE_SLOTS], coop_c[2][SIPX_SOLVE_SLOTS];
+  unsigned coop_arrive, coop_finish, coop_abort;
 };
 
 template <typename T>

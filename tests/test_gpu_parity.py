@@ -1555,3 +1555,23 @@ def test_second_solve_after_stop_rule_exit_continues_with_the_current_rho(sipx):
         assert np.array_equal(log2.cg_it, log3.cg_it)
         assert np.allclose(log2.obj, log3.obj, rtol=1e-9) and np.allclose(log2.r_pri, log3.r_pri, rtol=1e-6, atol=1e-12)
         assert np.linalg.norm(x2 - x3) <= 1e-9 * np.linalg.norm(x3)
+
+
+@pytest.mark.parametrize("TF", [np.float32, np.float64])
+def test_l1_projector_with_a_large_gather(sipx, TF):
+    """Cold start on 3 M entries: the bracket of the threshold search holds far more than 2^17 magnitudes, so the sweeps of
+    k_l1_solve are shared by its 32 workgroups (counter barrier, double-double shares).  Against the oracle's sort-based
+    threshold; twice, bit for bit (the shares are added in slot order, whatever order the workgroups arrive in)."""
+    rng = np.random.default_rng(71)
+    n = 3_000_000
+    v = (rng.standard_normal(n) * np.exp(0.5 * rng.standard_normal(n))).astype(TF)
+    g = sipx.compgrid((1.0, 1.0), (10, 10))
+    for frac in (0.6, 0.05):
+        b = float(frac * np.abs(v.astype(np.float64)).sum())
+        P = sipx.Projector(sipx.set_definitions("l1", "identity", 0.0, b, ("matrix", "")), g, TF)
+        w1, w2 = P(v.copy()), P(v.copy())
+        assert np.array_equal(w1, w2)
+        ref = O.project_l1_Duchi(v.astype(np.float64), b)
+        tol = 2e-5 if TF == np.float32 else 1e-11
+        assert np.linalg.norm(w1 - ref) <= tol * np.linalg.norm(ref)
+        assert abs(np.abs(w1.astype(np.float64)).sum() - b) <= tol * b
