@@ -24,6 +24,7 @@ struct RcclApi {
   decltype(&ncclAllReduce) AllReduce = nullptr;
   decltype(&ncclReduceScatter) ReduceScatter = nullptr;
   decltype(&ncclAllGather) AllGather = nullptr;
+  decltype(&ncclBroadcast) Broadcast = nullptr;
   decltype(&ncclSend) Send = nullptr;
   decltype(&ncclRecv) Recv = nullptr;
   decltype(&ncclGroupStart) GroupStart = nullptr;
@@ -47,6 +48,7 @@ const RcclApi& rccl() {
     sym(api.AllReduce, "ncclAllReduce");
     sym(api.ReduceScatter, "ncclReduceScatter");
     sym(api.AllGather, "ncclAllGather");
+    sym(api.Broadcast, "ncclBroadcast");
     sym(api.Send, "ncclSend");
     sym(api.Recv, "ncclRecv");
     sym(api.GroupStart, "ncclGroupStart");
@@ -54,7 +56,7 @@ const RcclApi& rccl() {
     sym(api.GetErrorString, "ncclGetErrorString");
   });
   if (!api.h || !api.GetUniqueId || !api.CommInitRank || !api.CommDestroy || !api.AllReduce || !api.ReduceScatter ||
-      !api.AllGather || !api.Send || !api.Recv || !api.GroupStart || !api.GroupEnd)
+      !api.AllGather || !api.Broadcast || !api.Send || !api.Recv || !api.GroupStart || !api.GroupEnd)
     throw std::runtime_error("libsipx: librccl.so.1 could not be loaded -- the sharded solve needs RCCL");
   return api;
 }
@@ -112,6 +114,9 @@ class RcclComm : public Comm {
     }
     nccl_check(a.GroupEnd(), "ncclGroupEnd");
   }
+  void broadcast(void* buf, size_t count, int dtype, int root, hipStream_t s) override {
+    nccl_check(rccl().Broadcast(buf, buf, count, nccl_type(dtype), root, comm_, s), "ncclBroadcast");
+  }
 
  private:
   ncclComm_t comm_ = nullptr;
@@ -123,7 +128,7 @@ class CallbackComm : public Comm {
     world = cb->world;
     rank = cb->rank;
     if (world < 1 || rank < 0 || rank >= world) throw std::runtime_error("sipx_comm: rank / world out of range");
-    if (!cb->allreduce_sum || !cb->reduce_scatter_sum || !cb->allgather || !cb->halo_exchange)
+    if (!cb->allreduce_sum || !cb->reduce_scatter_sum || !cb->allgather || !cb->halo_exchange || !cb->broadcast)
       throw std::runtime_error("sipx_comm: every operation must be supplied");
   }
   const char* kind() const override { return "callback"; }
@@ -141,6 +146,9 @@ class CallbackComm : public Comm {
     if (prev < 0 && next < 0) return;
     chk(cb_.halo_exchange(cb_.user, send_prev, recv_prev, prev, send_next, recv_next, next, (int64_t)count, dtype, (void*)s),
         "halo_exchange");
+  }
+  void broadcast(void* buf, size_t count, int dtype, int root, hipStream_t s) override {
+    chk(cb_.broadcast(cb_.user, buf, (int64_t)count, dtype, root, (void*)s), "broadcast");
   }
 
  private:

@@ -118,6 +118,10 @@ struct SetState {
   T *lb = nullptr, *ub = nullptr, *ata = nullptr;
   std::vector<void*> halo_allocs;   // bases of the vectors allocated with a front halo
   int ext_kind = 0;                  // projector acting on a materialised vector (ext_proj.h)
+  // Sharded solve: a rank / nuclear-norm set on the slices orthogonal to the last grid dimension is projected by ALL ranks,
+  // each factorising the slices of its z-slab (`ext` is then built for the slab on every rank, owner or not)
+  bool dist_ext = false;
+  int owner_rank = 0;
   ExtSpec spec;
   std::vector<T> host_basis;
   std::shared_ptr<ExtProj<T>> ext;
@@ -341,6 +345,20 @@ class Engine : public EngineBase {
     SIPX_HIP(hipMemcpy(m_, m, N * sizeof(T), hipMemcpyHostToDevice));
     long long maxpad = N;
     for (auto& s : sets_) maxpad = std::max(maxpad, s.Mpad);
+    if (comm_) {
+      for (int i = 0; i < p_n_; ++i) {
+        SetState<T>& s = sets_[i];
+        s.owner_rank = i % comm_->world;
+        const bool sliced = (s.ext_kind == EXT_RANK || s.ext_kind == EXT_NUCLEAR) && s.spec.mode == SIPX_MODE_SLICE &&
+                            s.spec.dir == ndim_ - 1 && s.ident;
+        if (!sliced) continue;
+        if (s.owned != (s.owner_rank == comm_->rank))
+          throw std::runtime_error("a slice-wise rank / nuclear set is projected by all ranks: it needs the default set ownership (set i on rank i mod world)");
+        s.dist_ext = true;
+        need_ext_ = true;
+        maxpad = std::max(maxpad, Npad);            // v travels through the padded exchange layout of x
+      }
+    }
     scr_v_ = dalloc<T>(maxpad);
     scr_c_ = dalloc<T>(maxpad);
     if (need_idx_) scr_i_ = dalloc<long long>(maxpad);
@@ -377,6 +395,14 @@ class Engine : public EngineBase {
         s.host_ata.clear();
         s.host_ata.shrink_to_fit();
       }
+      if (s.dist_ext && r1_ > r0_) {              // this rank's share of the slices: the projector on the slab grid
+        ExtSpec sp = s.spec;
+        const long long planes = (r1_ - r0_) / plane_;
+        sp.G.n[ndim_ - 1] = planes;
+        sp.G.N = planes * plane_;
+        sp.dims[ndim_ - 1] = planes;
+        s.ext = std::make_shared<ExtProj<T>>(sp, stream_);
+      }
       if (!s.owned) continue;
       // vectors read through adjoint stencils (w[g - stride]) carry a zero front halo: no bounds checks in the kernels
       auto halloc = [&](long long n) {
@@ -389,7 +415,7 @@ class Engine : public EngineBase {
       s.y0 = halloc(s.Mpad); s.l0 = halloc(s.Mpad);       // take turns with y, l as the current iterate: same halo
       if (!s.ident) s.dy = halloc(s.Mpad);
       if (s.custom) upload_custom(s);
-      if (s.ext_kind) {
+      if (s.ext_kind && !s.dist_ext) {
         s.spec.lb = s.host_lb.empty() ? nullptr : s.host_lb.data();
         s.spec.ub = s.host_ub.empty() ? nullptr : s.host_ub.data();
         s.spec.basis = s.host_basis.empty() ? nullptr : s.host_basis.data();
@@ -437,6 +463,10 @@ class Engine : public EngineBase {
     feas_init_.assign(pp_n_, 0.0);
     for (int i = 0; i < pp_n_; ++i) {
       SetState<T>& s = sets_[i];
+      if (s.dist_ext) {                         // every rank: its slab of slices
+        dist_feasibility(s, m_, part_sets_ + ((size_t)i * SLOTS + SL_FE2) * NB);
+        continue;
+      }
       if (!s.owned) continue;
       double* dst = part_sets_ + ((size_t)i * SLOTS + SL_FE2) * NB;
       // Minkowski: TD_OP[i] * [m; 0] = A m for components 1 and 3, A 0 = 0 for component 2 (w_ is still all zero here)
@@ -615,7 +645,7 @@ class Engine : public EngineBase {
     if (set_streams_) SIPX_HIP(hipEventRecord(ev_fork_, stream_));     // x (and u + v) are final: the sets may start
     for (int i = 0; i < p_n_; ++i) {
       SetState<T>& s = sets_[i];
-      if (!s.owned) continue;
+      if (!s.owned || s.dist_ext) continue;
       SetArgs<T> a = set_args(s, (T)rho[i], (T)gamma[i], flags);
       if (mk_) a.x = s.comp == 1 ? x_ : (s.comp == 2 ? x_ + G_.N : w_);
       double* part = part_sets_ + (size_t)i * SLOTS * NB;
@@ -663,6 +693,39 @@ class Engine : public EngineBase {
       if (to_other) { std::swap(s.y, s.y0); std::swap(s.l, s.l0); }     // (y, l) always names the current iterate
       if (snapshot) s.snap = 0;
       else if (to_other && s.snap == 0) s.snap = 1;
+    }
+    // Sets whose projector is shared by all ranks (slice-wise rank / nuclear norm), in set order on every rank, after the
+    // rank's own sets are queued: the owner materialises v = x_hat - l / rho and broadcasts it, every rank projects the
+    // slices of its slab, an all-gather returns P(v), the owner finishes the update with it.  (Engine stream: the
+    // collectives are ordered against the rank's other work; what runs on the second set stream overlaps.)
+    for (int i = 0; i < p_n_; ++i) {
+      SetState<T>& s = sets_[i];
+      if (!s.dist_ext) continue;
+      const int dt = dtype_code();
+      double* part = part_sets_ + (size_t)i * SLOTS * NB;
+      SetArgs<T> a;
+      bool to_other = false;
+      const bool snapshot = (flags & (SIPX_YL_BB | SIPX_YL_FIRST)) != 0;
+      if (s.owned) {
+        a = set_args(s, (T)rho[i], (T)gamma[i], flags);
+        const bool first = (flags & SIPX_YL_FIRST) != 0;
+        if (snapshot) to_other = !first && s.snap != 0;
+        else to_other = s.snap == 0;
+        a.yo = to_other ? s.y0 : s.y;
+        a.lo = to_other ? s.l0 : s.l;
+        K<T>::store_v(stream_, G_, a, 0, scr_v_);
+      }
+      comm_->broadcast(scr_v_, (size_t)G_.N, dt, s.owner_rank, stream_);
+      if (s.ext) s.ext->project(scr_v_ + r0_, false, part_tmp_, maxpart_, scr_c_);
+      comm_->allgather(scr_v_, (size_t)chunk_, dt, stream_);
+      if (s.owned) {
+        a.vsrc = 2;
+        K<T>::yl(stream_, G_, a, part);
+        if (to_other) { std::swap(s.y, s.y0); std::swap(s.l, s.l0); }
+        if (snapshot) s.snap = 0;
+        else if (to_other && s.snap == 0) s.snap = 1;
+      }
+      if ((flags & SIPX_YL_FEAS) && i < pp_n_) dist_feasibility(s, x_, part + (size_t)SL_FE2 * NB);
     }
     for (size_t k = 0; k < pool_.size(); ++k) {                         // join: the reductions below see every set
       if (pool_[k] == stream_) continue;
@@ -1643,6 +1706,18 @@ class Engine : public EngineBase {
     a.flags = flags;
     a.vsrc = 0;
     return a;
+  }
+
+  // The same for a set that all ranks project together (identity operator: s = src): this rank's slab of slices only, the
+  // partial sums of the ranks add up in the all-reduce of the packed per-set sums.
+  void dist_feasibility(SetState<T>& s, const T* src, double* dst) {
+    const long long nloc = r1_ - r0_;
+    if (nloc > 0) {
+      SIPX_HIP(hipMemcpyAsync(scr_v_ + r0_, src + r0_, nloc * sizeof(T), hipMemcpyDeviceToDevice, stream_));
+      SIPX_HIP(hipMemcpyAsync(scr_w_ + r0_, src + r0_, nloc * sizeof(T), hipMemcpyDeviceToDevice, stream_));
+      s.ext->project(scr_v_ + r0_, true, part_tmp_, maxpart_, scr_c_);
+    }
+    ext_dist2<T>(stream_, nloc, scr_v_ + r0_, scr_w_ + r0_, dst);
   }
 
   // ||P(s) - s||^2, ||s||^2 for a library-backed projector: s = A x materialised twice, one copy projected

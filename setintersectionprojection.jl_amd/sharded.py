@@ -59,8 +59,9 @@ class _SipxComm(C.Structure):
     _AR = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_void_p)
     _HX = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_int32, C.c_int64,
                       C.c_int32, C.c_void_p)
+    _BC = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_void_p)
     _fields_ = [("user", C.c_void_p), ("world", C.c_int32), ("rank", C.c_int32), ("allreduce_sum", _AR),
-                ("reduce_scatter_sum", _AR), ("allgather", _AR), ("halo_exchange", _HX)]
+                ("reduce_scatter_sum", _AR), ("allgather", _AR), ("halo_exchange", _HX), ("broadcast", _BC)]
 
 
 class TorchComm:
@@ -80,7 +81,7 @@ class TorchComm:
         self.device = device
         self.nccl = dist.get_backend() == "nccl"
         self._keep = None
-        self.calls = {"allreduce": 0, "reduce_scatter": 0, "allgather": 0, "halo": 0}
+        self.calls = {"allreduce": 0, "reduce_scatter": 0, "allgather": 0, "halo": 0, "broadcast": 0}
 
     # ---- tensor level (in place) ---------------------------------------------------------------------------------
     def allreduce_sum_(self, t):
@@ -119,6 +120,10 @@ class TorchComm:
         if ops:
             for w in self.dist.batch_isend_irecv(ops):
                 w.wait()
+
+    def broadcast_(self, t, root):
+        self.calls["broadcast"] += 1
+        self.dist.broadcast(t, src=root)
 
     # ---- C callbacks ------------------------------------------------------------------------------------------------
     def _alias(self, ptr, count, dtype):
@@ -171,8 +176,10 @@ class TorchComm:
             self._run(stream, [(sp if prev >= 0 else None, count, dtype, False), (rp if prev >= 0 else None, count, dtype, True),
                                (sn if nxt >= 0 else None, count, dtype, False), (rn if nxt >= 0 else None, count, dtype, True)],
                       lambda t: self.halo_exchange(t[0], t[1], prev, t[2], t[3], nxt))
+        def bc(user, buf, count, dtype, root, stream):
+            self._run(stream, [(buf, count, dtype, True)], lambda t: self.broadcast_(t[0], root))
         cs = _SipxComm(None, self.world, self.rank, _SipxComm._AR(guard(ar)), _SipxComm._AR(guard(rs)), _SipxComm._AR(guard(ag)),
-                       _SipxComm._HX(guard(hx)))
+                       _SipxComm._HX(guard(hx)), _SipxComm._BC(guard(bc)))
         self._keep = cs                                   # the engine holds the function pointers
         return cs
 
