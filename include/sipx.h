@@ -236,8 +236,8 @@ int sipx_set_owned(sipx_ctx* ctx, const int32_t* owned);
  *   - sipx_update_y_l ends with one all-reduce of the packed per-set sums, so every rank returns the r_pri / r_dual /
  *     feasibility of every set and takes the same rho / gamma / stop decisions; sipx_parsdmm runs the whole loop that way.
  *   - a rank / nuclear-norm set on the slices orthogonal to the last grid dimension (project_rank!.jl:23-47 applied slice
- *     by slice) is projected by ALL ranks: the owner broadcasts v, every rank factorises the slices of its slab, an
- *     all-gather returns the projected v (the one set of BASELINE config 4 that outweighs all others together).
+ *     by slice) is projected by ALL ranks: the owner scatters v by slab, every rank factorises the slices of its slab, a
+ *     gather returns the projected v (the one set of BASELINE config 4 that outweighs all others together).
  * Every rank must make the same sequence of calls.  Q is maintained for the slab rows only (sipx_get_Q refuses), x is
  * complete on every rank, y_i / l_i live on the owner.  Not available with Minkowski components, the stencil form of Q or
  * operators whose A'A reaches further than one plane of the grid.
@@ -253,7 +253,8 @@ int sipx_set_comm_rccl(sipx_ctx* ctx, const void* id128, int world, int rank);
  *   reduce_scatter_sum: buf[rank*chunk .. (rank+1)*chunk) <- sum over ranks of that range
  *   allgather:          buf[r*chunk .. (r+1)*chunk) <- that range of rank r, for every r
  *   halo_exchange:      send `count` elements to, and receive as many from, rank prev and rank next (-1 = no neighbour)
- *   broadcast:          buf[0 .. count) of rank `root` to every rank */
+ *   scatter / gather:   in place on world * chunk elements: rank r receives buf[r*chunk .. (r+1)*chunk) of rank `root`, or
+ *                       rank `root` receives that range of every rank r */
 typedef struct {
   void* user;
   int32_t world, rank;
@@ -262,7 +263,8 @@ typedef struct {
   int (*allgather)(void* user, void* buf, int64_t chunk, int32_t dtype, void* stream);
   int (*halo_exchange)(void* user, const void* send_prev, void* recv_prev, int32_t prev, const void* send_next, void* recv_next,
                        int32_t next, int64_t count, int32_t dtype, void* stream);
-  int (*broadcast)(void* user, void* buf, int64_t count, int32_t dtype, int32_t root, void* stream);
+  int (*scatter)(void* user, void* buf, int64_t chunk, int32_t dtype, int32_t root, void* stream);
+  int (*gather)(void* user, void* buf, int64_t chunk, int32_t dtype, int32_t root, void* stream);
 } sipx_comm;
 int sipx_set_comm(sipx_ctx* ctx, const sipx_comm* comm);
 /* this rank's slab of the x-step: rows [row0, row1) of Q / entries of x, and the elements per rank (chunk) of the padded

@@ -117,7 +117,10 @@ int sipx_prox_l2s(int dtype, int64_t n, void* x, double rho, const void* m, int 
 int sipx_set_owned(sipx_ctx* c, const int32_t* owned) { SIPX_TRY(c->e->set_owned(owned)) }
 int sipx_rccl_unique_id(void* id128) { SIPX_TRY(sipx::rccl_unique_id(id128)) }
 int sipx_set_comm_rccl(sipx_ctx* c, const void* id128, int world, int rank) {
-  SIPX_TRY(c->e->set_comm(sipx::make_rccl_comm(id128, world, rank)))
+  SIPX_TRY({
+    c->e->bind_device();      // ncclCommInitRank binds the communicator to the current device
+    c->e->set_comm(sipx::make_rccl_comm(id128, world, rank));
+  })
 }
 int sipx_set_comm(sipx_ctx* c, const sipx_comm* comm) {
   SIPX_TRY({

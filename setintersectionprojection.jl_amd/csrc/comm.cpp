@@ -24,7 +24,6 @@ struct RcclApi {
   decltype(&ncclAllReduce) AllReduce = nullptr;
   decltype(&ncclReduceScatter) ReduceScatter = nullptr;
   decltype(&ncclAllGather) AllGather = nullptr;
-  decltype(&ncclBroadcast) Broadcast = nullptr;
   decltype(&ncclSend) Send = nullptr;
   decltype(&ncclRecv) Recv = nullptr;
   decltype(&ncclGroupStart) GroupStart = nullptr;
@@ -48,7 +47,6 @@ const RcclApi& rccl() {
     sym(api.AllReduce, "ncclAllReduce");
     sym(api.ReduceScatter, "ncclReduceScatter");
     sym(api.AllGather, "ncclAllGather");
-    sym(api.Broadcast, "ncclBroadcast");
     sym(api.Send, "ncclSend");
     sym(api.Recv, "ncclRecv");
     sym(api.GroupStart, "ncclGroupStart");
@@ -56,7 +54,7 @@ const RcclApi& rccl() {
     sym(api.GetErrorString, "ncclGetErrorString");
   });
   if (!api.h || !api.GetUniqueId || !api.CommInitRank || !api.CommDestroy || !api.AllReduce || !api.ReduceScatter ||
-      !api.AllGather || !api.Broadcast || !api.Send || !api.Recv || !api.GroupStart || !api.GroupEnd)
+      !api.AllGather || !api.Send || !api.Recv || !api.GroupStart || !api.GroupEnd)
     throw std::runtime_error("libsipx: librccl.so.1 could not be loaded -- the sharded solve needs RCCL");
   return api;
 }
@@ -114,11 +112,29 @@ class RcclComm : public Comm {
     }
     nccl_check(a.GroupEnd(), "ncclGroupEnd");
   }
-  void broadcast(void* buf, size_t count, int dtype, int root, hipStream_t s) override {
-    nccl_check(rccl().Broadcast(buf, buf, count, nccl_type(dtype), root, comm_, s), "ncclBroadcast");
-  }
+  // one group of point-to-point transfers: the root talks to its seven peers over seven links at once
+  void scatter(void* buf, size_t chunk, int dtype, int root, hipStream_t s) override { fan(buf, chunk, dtype, root, s, true); }
+  void gather(void* buf, size_t chunk, int dtype, int root, hipStream_t s) override { fan(buf, chunk, dtype, root, s, false); }
 
  private:
+  void fan(void* buf, size_t chunk, int dtype, int root, hipStream_t s, bool out) {
+    if (world == 1) return;
+    const RcclApi& a = rccl();
+    char* b = static_cast<char*>(buf);
+    const size_t bytes = chunk * type_size(dtype);
+    nccl_check(a.GroupStart(), "ncclGroupStart");
+    if (rank == root) {
+      for (int p = 0; p < world; ++p) {
+        if (p == root) continue;
+        if (out) nccl_check(a.Send(b + (size_t)p * bytes, chunk, nccl_type(dtype), p, comm_, s), "ncclSend");
+        else nccl_check(a.Recv(b + (size_t)p * bytes, chunk, nccl_type(dtype), p, comm_, s), "ncclRecv");
+      }
+    } else {
+      if (out) nccl_check(a.Recv(b + (size_t)rank * bytes, chunk, nccl_type(dtype), root, comm_, s), "ncclRecv");
+      else nccl_check(a.Send(b + (size_t)rank * bytes, chunk, nccl_type(dtype), root, comm_, s), "ncclSend");
+    }
+    nccl_check(a.GroupEnd(), "ncclGroupEnd");
+  }
   ncclComm_t comm_ = nullptr;
 };
 
@@ -128,7 +144,7 @@ class CallbackComm : public Comm {
     world = cb->world;
     rank = cb->rank;
     if (world < 1 || rank < 0 || rank >= world) throw std::runtime_error("sipx_comm: rank / world out of range");
-    if (!cb->allreduce_sum || !cb->reduce_scatter_sum || !cb->allgather || !cb->halo_exchange || !cb->broadcast)
+    if (!cb->allreduce_sum || !cb->reduce_scatter_sum || !cb->allgather || !cb->halo_exchange || !cb->scatter || !cb->gather)
       throw std::runtime_error("sipx_comm: every operation must be supplied");
   }
   const char* kind() const override { return "callback"; }
@@ -147,8 +163,11 @@ class CallbackComm : public Comm {
     chk(cb_.halo_exchange(cb_.user, send_prev, recv_prev, prev, send_next, recv_next, next, (int64_t)count, dtype, (void*)s),
         "halo_exchange");
   }
-  void broadcast(void* buf, size_t count, int dtype, int root, hipStream_t s) override {
-    chk(cb_.broadcast(cb_.user, buf, (int64_t)count, dtype, root, (void*)s), "broadcast");
+  void scatter(void* buf, size_t chunk, int dtype, int root, hipStream_t s) override {
+    chk(cb_.scatter(cb_.user, buf, (int64_t)chunk, dtype, root, (void*)s), "scatter");
+  }
+  void gather(void* buf, size_t chunk, int dtype, int root, hipStream_t s) override {
+    chk(cb_.gather(cb_.user, buf, (int64_t)chunk, dtype, root, (void*)s), "gather");
   }
 
  private:

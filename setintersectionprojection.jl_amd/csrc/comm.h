@@ -29,8 +29,10 @@ struct Comm {
   // neighbour); the four buffers are distinct device ranges
   virtual void halo_exchange(const void* send_prev, void* recv_prev, int prev, const void* send_next, void* recv_next, int next,
                              size_t count, int dtype, hipStream_t s) = 0;
-  // buf[0 .. count) of rank `root` to every rank (in place)
-  virtual void broadcast(void* buf, size_t count, int dtype, int root, hipStream_t s) = 0;
+  // in place on world * chunk elements: rank r receives buf[r*chunk .. (r+1)*chunk) of rank `root` (scatter), or rank `root`
+  // receives that range from every rank r (gather); the root's own range stays where it is
+  virtual void scatter(void* buf, size_t chunk, int dtype, int root, hipStream_t s) = 0;
+  virtual void gather(void* buf, size_t chunk, int dtype, int root, hipStream_t s) = 0;
 };
 
 Comm* make_rccl_comm(const void* unique_id, int world, int rank);

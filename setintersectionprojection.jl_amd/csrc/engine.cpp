@@ -238,6 +238,7 @@ class Engine : public EngineBase {
     if (finalized_) throw std::runtime_error("the communicator must be attached before sipx_finalize");
     comm_ = std::move(hold);
   }
+  void bind_device() override { SIPX_HIP(hipSetDevice(device_)); }
   void slab(int64_t* row0, int64_t* row1, int64_t* chunk) override {
     need_final();
     if (row0) *row0 = r0_;
@@ -695,8 +696,9 @@ class Engine : public EngineBase {
       else if (to_other && s.snap == 0) s.snap = 1;
     }
     // Sets whose projector is shared by all ranks (slice-wise rank / nuclear norm), in set order on every rank, after the
-    // rank's own sets are queued: the owner materialises v = x_hat - l / rho and broadcasts it, every rank projects the
-    // slices of its slab, an all-gather returns P(v), the owner finishes the update with it.  (Engine stream: the
+    // rank's own sets are queued: the owner materialises v = x_hat - l / rho and scatters it by slab (seven links at once:
+    // 7/8 of N w bytes leave it, a broadcast would move seven times that), every rank projects the slices of its slab, a
+    // gather returns P(v), the owner finishes the update with it.  (Engine stream: the
     // collectives are ordered against the rank's other work; what runs on the second set stream overlaps.)
     for (int i = 0; i < p_n_; ++i) {
       SetState<T>& s = sets_[i];
@@ -715,9 +717,9 @@ class Engine : public EngineBase {
         a.lo = to_other ? s.l0 : s.l;
         K<T>::store_v(stream_, G_, a, 0, scr_v_);
       }
-      comm_->broadcast(scr_v_, (size_t)G_.N, dt, s.owner_rank, stream_);
+      comm_->scatter(scr_v_, (size_t)chunk_, dt, s.owner_rank, stream_);
       if (s.ext) s.ext->project(scr_v_ + r0_, false, part_tmp_, maxpart_, scr_c_);
-      comm_->allgather(scr_v_, (size_t)chunk_, dt, stream_);
+      comm_->gather(scr_v_, (size_t)chunk_, dt, s.owner_rank, stream_);
       if (s.owned) {
         a.vsrc = 2;
         K<T>::yl(stream_, G_, a, part);

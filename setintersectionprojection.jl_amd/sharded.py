@@ -61,7 +61,7 @@ class _SipxComm(C.Structure):
                       C.c_int32, C.c_void_p)
     _BC = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_void_p)
     _fields_ = [("user", C.c_void_p), ("world", C.c_int32), ("rank", C.c_int32), ("allreduce_sum", _AR),
-                ("reduce_scatter_sum", _AR), ("allgather", _AR), ("halo_exchange", _HX), ("broadcast", _BC)]
+                ("reduce_scatter_sum", _AR), ("allgather", _AR), ("halo_exchange", _HX), ("scatter", _BC), ("gather", _BC)]
 
 
 class TorchComm:
@@ -81,7 +81,7 @@ class TorchComm:
         self.device = device
         self.nccl = dist.get_backend() == "nccl"
         self._keep = None
-        self.calls = {"allreduce": 0, "reduce_scatter": 0, "allgather": 0, "halo": 0, "broadcast": 0}
+        self.calls = {"allreduce": 0, "reduce_scatter": 0, "allgather": 0, "halo": 0, "scatter": 0, "gather": 0}
 
     # ---- tensor level (in place) ---------------------------------------------------------------------------------
     def allreduce_sum_(self, t):
@@ -121,9 +121,30 @@ class TorchComm:
             for w in self.dist.batch_isend_irecv(ops):
                 w.wait()
 
-    def broadcast_(self, t, root):
-        self.calls["broadcast"] += 1
-        self.dist.broadcast(t, src=root)
+    def scatter_(self, t, chunk, root):
+        """rank r receives t[r*chunk:(r+1)*chunk] of rank `root` (in place; the root keeps its own range)."""
+        self.calls["scatter"] += 1
+        self._fan(t, chunk, root, True)
+
+    def gather_(self, t, chunk, root):
+        """rank `root` receives t[r*chunk:(r+1)*chunk] of every rank r (in place)."""
+        self.calls["gather"] += 1
+        self._fan(t, chunk, root, False)
+
+    def _fan(self, t, chunk, root, out):
+        if self.world == 1:
+            return
+        P2P, ops = self.dist.P2POp, []
+        if self.rank == root:
+            for p in range(self.world):
+                if p != root:
+                    v = t[p * chunk:(p + 1) * chunk]
+                    ops.append(P2P(self.dist.isend if out else self.dist.irecv, v, p))
+        else:
+            v = t[self.rank * chunk:(self.rank + 1) * chunk]
+            ops.append(P2P(self.dist.irecv if out else self.dist.isend, v, root))
+        for w in self.dist.batch_isend_irecv(ops):
+            w.wait()
 
     # ---- C callbacks ------------------------------------------------------------------------------------------------
     def _alias(self, ptr, count, dtype):
@@ -176,10 +197,13 @@ class TorchComm:
             self._run(stream, [(sp if prev >= 0 else None, count, dtype, False), (rp if prev >= 0 else None, count, dtype, True),
                                (sn if nxt >= 0 else None, count, dtype, False), (rn if nxt >= 0 else None, count, dtype, True)],
                       lambda t: self.halo_exchange(t[0], t[1], prev, t[2], t[3], nxt))
-        def bc(user, buf, count, dtype, root, stream):
-            self._run(stream, [(buf, count, dtype, True)], lambda t: self.broadcast_(t[0], root))
+        def sc(user, buf, chunk, dtype, root, stream):
+            self._run(stream, [(buf, chunk * self.world, dtype, True)], lambda t: self.scatter_(t[0], chunk, root))
+
+        def ga(user, buf, chunk, dtype, root, stream):
+            self._run(stream, [(buf, chunk * self.world, dtype, True)], lambda t: self.gather_(t[0], chunk, root))
         cs = _SipxComm(None, self.world, self.rank, _SipxComm._AR(guard(ar)), _SipxComm._AR(guard(rs)), _SipxComm._AR(guard(ag)),
-                       _SipxComm._HX(guard(hx)), _SipxComm._BC(guard(bc)))
+                       _SipxComm._HX(guard(hx)), _SipxComm._BC(guard(sc)), _SipxComm._BC(guard(ga)))
         self._keep = cs                                   # the engine holds the function pointers
         return cs
 

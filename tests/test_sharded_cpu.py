@@ -290,7 +290,15 @@ def _collectives_worker(rank, world, port, out):
         comm.halo_exchange(buf[1], buf[0], prev, buf[2], buf[3], nxt)
         ok &= bool((buf[0] == (10.0 * (rank - 1) + 2 if prev >= 0 else -1.0)).all())
         ok &= bool((buf[3] == (10.0 * (rank + 1) + 1 if nxt >= 0 else -1.0)).all())
-        ok &= comm.calls == {"allreduce": 1, "reduce_scatter": 1, "allgather": 1, "halo": 1, "broadcast": 0}
+        t = torch.arange(world * chunk, dtype=torch.float64) * (100.0 if rank == 1 else 1.0)     # scatter from rank 1
+        comm.scatter_(t, chunk, 1)
+        ok &= np.array_equal(t.numpy()[sl], (np.arange(world * chunk) * 100.0)[sl])
+        t = torch.zeros(world * chunk, dtype=torch.float64)
+        t[sl] = float(rank + 7)
+        comm.gather_(t, chunk, 2)                                                                 # gather to rank 2
+        if rank == 2:
+            ok &= np.array_equal(t.numpy(), np.repeat(np.arange(7, 7 + world, dtype=np.float64), chunk))
+        ok &= comm.calls == {"allreduce": 1, "reduce_scatter": 1, "allgather": 1, "halo": 1, "scatter": 1, "gather": 1}
         open(os.path.join(out, f"ok{rank}"), "w").write(str(bool(ok)))
     finally:
         dist.destroy_process_group()

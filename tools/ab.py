@@ -14,7 +14,7 @@ for r in range(rounds):
         env = dict(os.environ)
         if v != "base":
             env["SIPX_LIBRARY"] = os.path.join(root, "setintersectionprojection.jl_amd", f"libsipx_{v}.so")
-        out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--no-cpu-baseline", "--config", config] + extra,
+        out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--no-cpu-baseline", "--no-c4", "--config", config] + extra,
                              env=env, capture_output=True, text=True, timeout=300)
         if out.returncode != 0:
             print(v, "FAILED", out.stderr[-400:], flush=True)
