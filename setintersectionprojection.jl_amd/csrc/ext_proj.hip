@@ -475,13 +475,31 @@ __global__ void k_sub_ratio(int k, int b, int r, int batch, const double* __rest
   if (!(q == q) || q > 1.0) q = 1.0;
   atomicMax(res, (unsigned long long)__double_as_longlong(q));
 }
-// The last b eigenvector columns of the full decomposition (k x k per matrix) become the next warm start.
-__global__ __launch_bounds__(BLOCK) void k_sub_keep(int k, int b, int batch, const double* __restrict__ E, double* __restrict__ X) {
+// The last b eigenvector columns of the full decomposition (k x k per matrix) become the next warm start -- unless the
+// factorisation of that matrix did not converge (info != 0): its previous warm start stays.
+__global__ __launch_bounds__(BLOCK) void k_sub_keep(int k, int b, int batch, const double* __restrict__ E, double* __restrict__ X,
+                                                    const rocblas_int* __restrict__ info) {
   const long long per = (long long)k * b, total = per * batch;
   for (long long e = (long long)blockIdx.x * BLOCK + threadIdx.x; e < total; e += (long long)gridDim.x * BLOCK) {
     const long long l = e / per, o = e - l * per;
+    if (info[l] != 0) continue;
     X[e] = E[l * (long long)k * k + (long long)(k - b) * k + o];
   }
+}
+// status words of a batched factorisation OR-ed into one flag (read by the host at the NEXT call of the projector: a
+// projection built on a factorisation that did not converge must not go unnoticed)
+// resid / smax given (one-sided Jacobi SVD): info = 1 there only says that the sweeps stopped short of the requested
+// (machine-precision) tolerance; it counts as a failure when the off-diagonal mass it reports is not negligible against the
+// largest singular value squared, or anything is not finite.
+__global__ void k_info_or(int batch, const rocblas_int* __restrict__ info, int* __restrict__ fail, const double* __restrict__ resid,
+                          const double* __restrict__ S, int k) {
+  const int l = blockIdx.x * blockDim.x + threadIdx.x;
+  if (l >= batch || info[l] == 0) return;
+  if (resid) {
+    const double s0 = S[(long long)l * k], r = resid[l];
+    if (r == r && s0 == s0 && r <= 1e-9 * s0 * s0) return;
+  }
+  atomicOr(fail, 1);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -517,6 +535,32 @@ struct ExtImpl {
   long long* cidx = nullptr;
   rocblas_int* info = nullptr;
   int* flag = nullptr;
+  // status of the batched factorisations: OR of info != 0, copied to pinned memory behind the call, looked at by the next one
+  int* fail = nullptr;
+  int* fail_host = nullptr;
+  hipEvent_t fail_ev = nullptr;
+  bool fail_pending = false;
+  void note_status(hipStream_t s, const double* resid = nullptr, const double* S = nullptr, int k = 0) {
+    if (!fail) {
+      SIPX_HIP(hipMalloc((void**)&fail, sizeof(int)));
+      owned.push_back(fail);
+      SIPX_HIP(hipHostMalloc((void**)&fail_host, sizeof(int), hipHostMallocDefault));
+      SIPX_HIP(hipEventCreateWithFlags(&fail_ev, hipEventDisableTiming));
+    }
+    SIPX_HIP(hipMemsetAsync(fail, 0, sizeof(int), s));
+    hipLaunchKernelGGL(k_info_or, dim3((batch + 63) / 64), dim3(64), 0, s, batch, info, fail, resid, S, k);
+    SIPX_HIP(hipMemcpyAsync(fail_host, fail, sizeof(int), hipMemcpyDeviceToHost, s));
+    SIPX_HIP(hipEventRecord(fail_ev, s));
+    fail_pending = true;
+  }
+  void check_status() {
+    if (!fail_pending) return;
+    fail_pending = false;
+    SIPX_HIP(hipEventSynchronize(fail_ev));
+    if (*fail_host != 0)
+      throw std::runtime_error("rank / nuclear projector: the batched eigen / singular value decomposition did not converge on some slice "
+                               "(rocSOLVER info != 0) in the previous call");
+  }
   // histogram
   T *keys_in = nullptr, *keys_out = nullptr, *lb = nullptr, *ub = nullptr;
   unsigned int *idx_in = nullptr, *idx_out = nullptr;
@@ -758,6 +802,8 @@ ExtProj<T>::~ExtProj() {
   if (I.have_plan) (void)hipfftDestroy(I.plan);
   if (I.blas) (void)rocblas_destroy_handle(I.blas);
   if (I.sub_res_host) (void)hipHostFree(I.sub_res_host);
+  if (I.fail_host) (void)hipHostFree(I.fail_host);
+  if (I.fail_ev) (void)hipEventDestroy(I.fail_ev);
   for (void* p : I.owned)
     if (p) (void)hipFree(p);
   delete impl_;
@@ -820,6 +866,7 @@ void ExtProj<T>::project(T* v, bool feas, double* partials, T* maxpart, T* compa
     else fft_check(hipfftExecZ2Z(I.plan, (hipfftDoubleComplex*)I.z, (hipfftDoubleComplex*)I.z, HIPFFT_BACKWARD), "inverse");
     hipLaunchKernelGGL((k_unpack<T>), dim3(NB), dim3(BLOCK), 0, s, N, I.z, v, (T)(1.0 / (double)N), ps);
   } else if (kind == EXT_RANK || kind == EXT_NUCLEAR) {
+    I.check_status();
     // Batched Jacobi SVD in float64 whatever TF is: rocSOLVER's gesvdj works on A'A (condition number squared), so
     // float32 input is widened first and the truncated product is rounded back once.  Measured ~2x faster than the
     // QR-iteration gesvd on 256 slices of 256x256 and as accurate as LAPACK on the float32 data.
@@ -900,13 +947,14 @@ void ExtProj<T>::project(T* v, bool feas, double* partials, T* maxpart, T* compa
         blas_check(rocsolver_dsyevd_strided_batched(I.blas, rocblas_evect_original, rocblas_fill_upper, k, I.Gd, k, sG, I.Wd, k, I.Ed, k,
                                                     I.info, I.batch),
                    "syevd");
+        I.note_status(s);
         Esel = I.Gd + (long long)(k - I.r) * k;           // eigenvalues ascend: the last r columns span the top-r space
         ldsel_stride = sG;
         if (b > 0) {
           // keep the top-b eigenvectors as the next warm start, and decide from the spectrum whether to use them: the
           // iteration contracts by theta_{b+1} / theta_r per step, so a truncation inside a flat part of the spectrum
           // (ratio near 1) would never get there and the attempt is not made
-          hipLaunchKernelGGL(k_sub_keep, dim3(NB), dim3(BLOCK), 0, s, k, b, I.batch, I.Gd, I.Xs[w]);
+          hipLaunchKernelGGL(k_sub_keep, dim3(NB), dim3(BLOCK), 0, s, k, b, I.batch, I.Gd, I.Xs[w], I.info);
           SIPX_HIP(hipMemsetAsync(I.sub_res, 0, 2 * sizeof(unsigned long long), s));
           hipLaunchKernelGGL(k_sub_ratio, dim3((I.batch + 63) / 64), dim3(64), 0, s, k, b, I.r, I.batch, I.Wd, I.sub_res);
           SIPX_HIP(hipMemcpyAsync(I.sub_res_host, I.sub_res, 2 * sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
@@ -946,6 +994,7 @@ void ExtProj<T>::project(T* v, bool feas, double* partials, T* maxpart, T* compa
                                                  I.m, sA, 0.0, I.Ed, 100, I.info + I.batch, I.Sd, k, I.Ud, I.m, sU, I.Vd,
                                                  k, sV, I.info, I.batch),
                "gesvdj");
+    I.note_status(s, I.Ed, I.Sd, k);
     int inner = I.r;
     const int* flag = nullptr;
     if (kind == EXT_NUCLEAR) {     // slices already inside the ball keep their values bit for bit (flag = 0)
