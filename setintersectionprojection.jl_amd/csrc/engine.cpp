@@ -509,6 +509,10 @@ class Engine : public EngineBase {
   // ------------------------------------------------------------------------------------------
   void rhs_compose(const double* rho) override {
     need_final();
+    if (rs_pending_) {          // a right-hand side that was never consumed: let its exchange finish before rhs is rewritten
+      SIPX_HIP(hipStreamWaitEvent(stream_, ev_c_[1], 0));
+      rs_pending_ = false;
+    }
     if (mk_) {    // rhs = sum_i [A 0]'w_i / [0 A]'w_i / [A A]'w_i, w_i = rho_i y_i + l_i, sets added in order per half
       for (int half = 0; half < 2; ++half) {
         T* out = rhs_ + (long long)half * G_.N;

@@ -30,7 +30,15 @@ namespace sipx {
 
 constexpr double L1_CAP = 131072.0;     // bracket population above which one more probe pass is run (floor; scales with the length)
 constexpr int L1_REFINES = 1;           // gated refinement passes enqueued per search
-constexpr int SPEC_CAP = 1024;           // per-workgroup LDS buffer of the speculative compaction
+#ifndef SIPX_SPEC_CAP
+#define SIPX_SPEC_CAP 1024
+#endif
+constexpr int SPEC_CAP = SIPX_SPEC_CAP;  // per-workgroup LDS buffer of the speculative compaction
+// largest relative half-width of the speculative range (SIPX_L1_HWMAX overrides; A/B switch)
+static double l1_hw_max() {
+  static const double v = [] { const char* e = getenv("SIPX_L1_HWMAX"); return e ? atof(e) : 1e-2; }();
+  return v;
+}
 // Probe thresholds of the next call, as multiples of the half-width hw around the predicted theta: the two inner probes
 // are the edges of the speculative gather range, the outer ones catch a theta that moved further (geometric spacing, so one
 // pass brackets it between neighbouring probes whatever the size of the move up to 64 hw).
@@ -462,7 +470,7 @@ static_assert(SOLVE_G <= SIPX_SOLVE_SLOTS, "ProjScalars holds SIPX_SOLVE_SLOTS c
 
 template <typename T>
 __global__ __launch_bounds__(SIPX_SOLVE_NT) void k_l1_solve(ProjScalars<T>* ps, T radius, const T* __restrict__ compact,
-                                                   const double* __restrict__ partials, long long true_len) {
+                                                   const double* __restrict__ partials, long long true_len, double hw_max) {
   constexpr int NT = SIPX_SOLVE_NT;
   __shared__ double ssum[NT / 64];
   __shared__ double ssum_lo[NT / 64];
@@ -607,7 +615,7 @@ __global__ __launch_bounds__(SIPX_SOLVE_NT) void k_l1_solve(ProjScalars<T>* ps, 
       if (ps->theta_prev > 0) {
         const double d = fabs(theta / ps->theta_prev - 1.0);
         hw = 3.0 * d;                                  // theta moves slowly while rho, gamma stay put
-        hw = hw < 1e-3 ? 1e-3 : (hw > 1e-2 ? 1e-2 : hw);
+        hw = hw < 1e-3 ? 1e-3 : (hw > hw_max ? hw_max : hw);
         if (ps->spec_overflow) hw = ps->hw * 0.5;      // the last range gathered too much
       }
       ps->hw = hw;
@@ -747,17 +755,17 @@ __global__ __launch_bounds__(1024) void k_card_select(ProjScalars<T>* ps, long l
 // v = x_hat - l/rho: where the multiplier term dominates, theta moves like 1/rho when rho is changed.  Re-centre the
 // probes of the coming call on the scaled prediction (and widen the range: the prediction is good to a few percent).
 template <typename T>
-__global__ void k_ps_rescale(ProjScalars<T>* ps, double factor) {
+__global__ void k_ps_rescale(ProjScalars<T>* ps, double factor, double hw_max) {
   if (!(ps->theta_prev > 0)) return;
   ps->theta_prev *= factor;
-  ps->hw = 1e-2;
+  ps->hw = hw_max;
   for (int k = 0; k < L1_K; ++k) ps->t[k] = (double)(T)(ps->theta_prev * (1.0 + ps->hw * l1_probe_mult(k)));
   ps->spec_lo = ps->t[L1_WIN_LO];
   ps->spec_hi = ps->t[L1_WIN_HI];
 }
 template <typename T>
 void K<T>::ps_rescale(hipStream_t s, ProjScalars<T>* ps, double factor) {
-  hipLaunchKernelGGL((k_ps_rescale<T>), dim3(1), dim3(1), 0, s, ps, factor);
+  hipLaunchKernelGGL((k_ps_rescale<T>), dim3(1), dim3(1), 0, s, ps, factor, l1_hw_max());
   SIPX_HIP(hipGetLastError());
 }
 
@@ -798,7 +806,7 @@ static void launch_chain(hipStream_t s, const Grid& g, const SetArgs<T>& a, int 
       hipLaunchKernelGGL((k_decide<T, 1>), dim3(1), dim3(64), 0, s, ps, a.prox, a.plo, a.phi, true_len, 0, capdiv);
     }
     SIPX_PASS(M_COMPACT);
-    hipLaunchKernelGGL((k_l1_solve<T>), dim3(SOLVE_G), dim3(SIPX_SOLVE_NT), 0, s, ps, a.phi, compact, partials, true_len);
+    hipLaunchKernelGGL((k_l1_solve<T>), dim3(SOLVE_G), dim3(SIPX_SOLVE_NT), 0, s, ps, a.phi, compact, partials, true_len, l1_hw_max());
   }
 #undef SIPX_PASS
   SIPX_HIP(hipGetLastError());
