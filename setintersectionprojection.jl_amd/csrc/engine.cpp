@@ -1309,6 +1309,8 @@ class Engine : public EngineBase {
     o[0] = h.need; o[1] = h.theta; o[2] = h.theta_prev; o[3] = h.hw; o[4] = h.spec_lo; o[5] = h.spec_hi; o[6] = h.lo;
     o[7] = h.hi; o[8] = h.asum; o[9] = h.vmax; o[10] = h.dbg[0]; o[11] = h.dbg[1]; o[12] = h.dbg[2]; o[13] = h.dbg[3];
     o[14] = h.refine;
+    o[15] = h.lean;
+    o[15] = h.lean;
   }
 
   void* stream() override { return (void*)stream_; }

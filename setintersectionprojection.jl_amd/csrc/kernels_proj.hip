@@ -35,6 +35,10 @@ constexpr int L1_REFINES = 1;           // gated refinement passes enqueued per 
 #endif
 constexpr int SPEC_CAP = SIPX_SPEC_CAP;  // per-workgroup LDS buffer of the speculative compaction
 // largest relative half-width of the speculative range (SIPX_L1_HWMAX overrides; A/B switch)
+static int l1_lean_on() {       // SIPX_L1_LEAN=0: every first pass evaluates all eight probes (A/B switch)
+  static const int v = [] { const char* e = getenv("SIPX_L1_LEAN"); return e ? atoi(e) : 1; }();
+  return v;
+}
 static double l1_hw_max() {
   static const double v = [] { const char* e = getenv("SIPX_L1_HWMAX"); return e ? atof(e) : 1e-2; }();
   return v;
@@ -78,6 +82,7 @@ __global__ __launch_bounds__(BLOCK) void k_pass(Grid G, SetArgs<T> a, int v_is_s
   if (MODE == M_FIRST && a.prox == PX_L1 && !(a.flags & F_NOSPEC)) { r_lo = ps->spec_lo; r_hi = ps->spec_hi; }
   if (MODE == M_COMPACT) { r_lo = ps->lo; r_hi = ps->hi; }
   const bool gather = r_hi > r_lo;
+  const bool lean = MODE == M_FIRST && a.prox == PX_L1 && gather && ps->lean != 0;
   T vmax = T(0), vminp = (T)INFINITY;     // largest magnitude, smallest non-zero magnitude
   if (MODE == M_FIRST || MODE == M_COMPACT) {
     if (threadIdx.x == 0) { scnt = 0; sused = 0; sovf = 0; }
@@ -90,7 +95,10 @@ __global__ __launch_bounds__(BLOCK) void k_pass(Grid G, SetArgs<T> a, int v_is_s
   auto body = [&](T x, long long e, bool live) {
     const T av = fabs(x);
     const double ad = (double)av;
-    if (MODE == M_FIRST || MODE == M_PROBE) {
+    if (MODE == M_FIRST && lean) {                // uniform: the whole launch takes one side
+      pa.add_lean(av, L1_WIN_LO, L1_WIN_HI);
+      vminp = (av > T(0) && av < vminp) ? av : vminp;
+    } else if (MODE == M_FIRST || MODE == M_PROBE) {
       pa.add(av, x);
       vmax = av > vmax ? av : vmax;
       if (MODE == M_FIRST) vminp = (av > T(0) && av < vminp) ? av : vminp;
@@ -232,6 +240,7 @@ __global__ void k_ps_init(ProjScalars<T>* ps, long long* cidx) {
   ps->spec_hi = -1;
   ps->s_above = ps->c_above = 0;
   ps->hw = 1e-2;
+  ps->lean = 0;
   ps->spec_ok = ps->spec_overflow = 0;
   ps->tau = T(0);
   ps->quota = 0x7fffffffffffffffll;
@@ -356,6 +365,48 @@ __global__ __launch_bounds__(64) void k_decide(ProjScalars<T>* ps, int prox, T p
     if (!ps->need) {
       ps->n_compact = 0;
       ps->spec_overflow = 0;
+      ps->lean = 0;
+      return;
+    }
+    if (ps->lean) {
+      // LEAN first pass: only (S, C) at the two edges of the speculative range are known.  theta* lies inside iff
+      // f(spec_lo) >= 0 > f(spec_hi); then the bracket is tightened by the Newton / secant steps as usual and the gathered
+      // magnitudes are all that is needed.  Otherwise the root left the range: one-sided geometric probes for the refinement
+      // pass (the same number of sweeps as a failed speculation of the full pass), and the next first pass is a full one.
+      const double b = (double)pmax;
+      const double t3 = ps->t[L1_WIN_LO], t4 = ps->t[L1_WIN_HI];
+      const double S3 = red[3 + L1_WIN_LO], C3 = red[3 + L1_K + L1_WIN_LO], S4 = red[3 + L1_WIN_HI], C4 = red[3 + L1_K + L1_WIN_HI];
+      const double f3 = S3 - t3 * C3 - b, f4 = S4 - t4 * C4 - b;
+      ps->lean = 0;
+      if (f3 >= 0 && f4 < 0 && !ps->spec_overflow && !nospec) {
+        double thN = C3 > 0 ? (S3 - b) / C3 : t3;
+        if (!(thN >= t3)) thN = t3;
+        double thS = t3 + f3 * (t4 - t3) / (f3 - f4);
+        if (!(thS <= t4)) thS = t4;
+        if (!(thS >= thN)) thS = t4;
+        double lo = thN * (1.0 - 1e-9), hi = thS * (1.0 + 1e-9) + 1e-300;
+        ps->lo = lo > t3 ? lo : t3;
+        ps->hi = hi < t4 ? hi : t4;
+        ps->spec_ok = 1;
+        ps->s_above = S4;
+        ps->c_above = C4;
+        ps->vmax = (T)INFINITY;                              // not measured by a lean pass (unused on this route)
+        return;
+      }
+      ps->n_compact = 0;                                     // discard what the speculation gathered
+      ps->refine = 1;
+      ps->vmax = (T)ps->asum;                                // a valid upper bound of every magnitude
+      if (f4 >= 0) {                                         // theta* >= spec_hi: geometric probes above it
+        ps->lo = t4;
+        ps->hi = ps->asum;
+        double step = (t4 - t3) > 0 ? (t4 - t3) : t4 * 1e-3;
+        for (int k = 0; k < L1_K; ++k) { step *= 4.0; ps->t[k] = (double)(T)(t4 + step); }
+      } else {                                               // theta* < spec_lo: geometric probes below it
+        ps->lo = 0;
+        ps->hi = t3;
+        double step = (t4 - t3) > 0 ? (t4 - t3) : t3 * 1e-3;
+        for (int k = L1_K - 1; k >= 0; --k) { step *= 4.0; const double t = t3 - step; ps->t[k] = t > 0 ? (double)(T)t : 0.0; }
+      }
       return;
     }
   } else {
@@ -470,7 +521,8 @@ static_assert(SOLVE_G <= SIPX_SOLVE_SLOTS, "ProjScalars holds SIPX_SOLVE_SLOTS c
 
 template <typename T>
 __global__ __launch_bounds__(SIPX_SOLVE_NT) void k_l1_solve(ProjScalars<T>* ps, T radius, const T* __restrict__ compact,
-                                                   const double* __restrict__ partials, long long true_len, double hw_max) {
+                                                   const double* __restrict__ partials, long long true_len, double hw_max,
+                                                   int lean_on) {
   constexpr int NT = SIPX_SOLVE_NT;
   __shared__ double ssum[NT / 64];
   __shared__ double ssum_lo[NT / 64];
@@ -610,6 +662,8 @@ __global__ __launch_bounds__(SIPX_SOLVE_NT) void k_l1_solve(ProjScalars<T>* ps, 
     ps->dbg[0] = (double)ps->n_compact; ps->dbg[1] = ps->spec_overflow; ps->dbg[2] = ps->spec_ok;
     ps->dbg[3] = (coop && ps->dbg[3] < 0) ? -1.0 : (double)iters_done;       // -1: a cooperative sweep was abandoned
     // ---- state for the next call ----
+    // a search that the speculative gather settled is followed by a LEAN first pass (two probes instead of eight)
+    ps->lean = (lean_on && need && theta > 0 && ps->spec_ok && !ps->spec_overflow && sh_ca < (double)true_len) ? 1 : 0;
     if (need && theta > 0) {
       double hw = ps->hw;
       if (ps->theta_prev > 0) {
@@ -806,7 +860,7 @@ static void launch_chain(hipStream_t s, const Grid& g, const SetArgs<T>& a, int 
       hipLaunchKernelGGL((k_decide<T, 1>), dim3(1), dim3(64), 0, s, ps, a.prox, a.plo, a.phi, true_len, 0, capdiv);
     }
     SIPX_PASS(M_COMPACT);
-    hipLaunchKernelGGL((k_l1_solve<T>), dim3(SOLVE_G), dim3(SIPX_SOLVE_NT), 0, s, ps, a.phi, compact, partials, true_len, l1_hw_max());
+    hipLaunchKernelGGL((k_l1_solve<T>), dim3(SOLVE_G), dim3(SIPX_SOLVE_NT), 0, s, ps, a.phi, compact, partials, true_len, l1_hw_max(), l1_lean_on());
   }
 #undef SIPX_PASS
   SIPX_HIP(hipGetLastError());

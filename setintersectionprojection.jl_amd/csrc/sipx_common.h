@@ -130,6 +130,7 @@ struct ProjScalars {
   // sums of the PREP_SLOTS partial slots of the last probe pass, its largest / smallest non-zero magnitude (k_slot_sums)
   double red[PREP_SLOTS];
   T rmax, rmin;
+  int lean;           // the coming first pass evaluates the two edge probes of the speculative range only (k_pass M_FIRST)
   // cooperative sweeps of k_l1_solve: per-workgroup shares of (sum hi, sum lo, count), double buffered by iteration parity
   double coop_hi[2][SIPX_SOLVE_SLOTS], coop_lo[2][SIPX_SOLVE_SLOTS], coop_c[2][SIPX_SOLVE_SLOTS];
   unsigned coop_arrive, coop_finish, coop_abort;

@@ -219,6 +219,19 @@ struct ProbeAcc {
       C[k] += on ? 1u : 0u;
     }
   }
+  // LEAN first pass (the speculation has been holding): only ||v||_1 and the two probes at the edges of the speculative
+  // range -- a fifth of the arithmetic; the other slots are left at zero and must not be read by the decision
+  __device__ __forceinline__ void add_lean(T av, int k_lo, int k_hi) {
+    const double a = (double)av;
+    asum += a;
+#pragma unroll
+    for (int k = 0; k < L1_K; ++k) {
+      if (k != k_lo && k != k_hi) continue;
+      const bool on = av > t[k];
+      S[k] += on ? a : 0.0;
+      C[k] += on ? 1u : 0u;
+    }
+  }
   __device__ __forceinline__ void to_slots(double (&acc)[PREP_SLOTS]) const {
     acc[0] = asum; acc[1] = sumsq; acc[2] = (double)nnz;
 #pragma unroll

@@ -764,7 +764,7 @@ class Context:
         out = np.zeros(16)
         _chk(lib().sipx_debug_proj(self.h, int(set_index), int(which), out.ctypes.data_as(C.c_void_p)))
         keys = ("need", "theta", "theta_prev", "hw", "spec_lo", "spec_hi", "lo", "hi", "asum", "vmax", "gathered",
-                "overflow", "spec_ok", "michelot_its", "refine")
+                "overflow", "spec_ok", "michelot_its", "refine", "lean")
         return dict(zip(keys, out))
 
     def kernel_stats(self, enable: bool):
