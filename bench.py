@@ -208,8 +208,12 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
+        steps_asked = steps
         for k in range(steps):
-            ctx.parsdmm_steps(1)
+            ended = ctx.parsdmm_steps(1)
+            if ended and k + 1 < steps:          # stop rules 3 / 4 of stop_PARSDMM do not depend on the tolerances: a very
+                steps = k + 1                    # long run may end by itself; time what was executed
+                break
             if os.environ.get("SIPX_BENCH_DEBUG"):
                 i = warmup + k
                 print(i + 1, "cg", logs["cg_it"][i], "obj %.4e" % logs["obj"][i], "rpri", logs["r_pri"][i], "rho", logs["rho"][i],
@@ -224,6 +228,9 @@ def main():
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
             dt = float(tt.item())
         log = ctx.parsdmm_log()
+        if steps != steps_asked:
+            print(f"bench: the solve stopped by itself after {warmup + steps} iterations; {steps} of the {steps_asked} requested steps were timed",
+                  file=sys.stderr)
         cg_its = int(np.asarray(log.cg_it)[warmup:warmup + steps].sum())
         row0, row1, _ = ctx.slab()
         d = len(np.unique(np.concatenate([np.asarray(o) for o in prop.AtA_offsets])))
