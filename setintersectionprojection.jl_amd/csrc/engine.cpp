@@ -189,6 +189,7 @@ class Engine : public EngineBase {
     if (ticket_) (void)hipHostFree((void*)ticket_);
     if (cg_host_) (void)hipHostFree(cg_host_);
     if (hres_) (void)hipHostFree(hres_);
+    if (hlean_) (void)hipHostFree((void*)hlean_);
     for (auto e : ev_) (void)hipEventDestroy(e);
     for (auto e : stat_ev_) (void)hipEventDestroy(e);
     for (auto e : cg_ev_) if (e) (void)hipEventDestroy(e);
@@ -379,6 +380,14 @@ class Engine : public EngineBase {
     SIPX_HIP(hipEventCreateWithFlags(&ev_sums_, hipEventDisableTiming));
     SIPX_HIP(hipHostMalloc((void**)&hres_, sizeof(double) * (p_n_ + 1) * SLOTS, hipHostMallocDefault));
     std::memset(hres_, 0, sizeof(double) * (p_n_ + 1) * SLOTS);
+    SIPX_HIP(hipHostMalloc((void**)&hlean_, sizeof(int) * (p_n_ + 1), hipHostMallocDefault));
+    std::memset((void*)hlean_, 0, sizeof(int) * (p_n_ + 1));
+    {
+      const char* e = std::getenv("SIPX_L1_SAMPLE");
+      l1_sample_ = !(e && e[0] == '0');
+      const char* r = std::getenv("SIPX_L1_SAMPLE_RUNS");       // tests: sample small grids too
+      l1_sample_runs_ = r ? std::atoll(r) : 0;
+    }
     for (int k = 0; k < 2 * MAXMARK; ++k) {      // two sets of section marks: a step never waits for its own timing
       hipEvent_t e;
       SIPX_HIP(hipEventCreate(&e));
@@ -680,9 +689,17 @@ class Engine : public EngineBase {
       }
       if (s.two_pass) {   // threshold / scale of prox_i from one pass that produces v on the fly (nothing stored)
         SetArgs<T> ap = a;
-        if (a.prox == PX_L1 && s.last_rho > T(0) && s.last_rho != a.rho)            // v rescaled: theta moves like 1/rho
+        const bool rescaled = a.prox == PX_L1 && s.last_rho > T(0) && s.last_rho != a.rho;
+        if (rescaled)                                                               // v rescaled: theta moves like 1/rho
           K<T>::ps_rescale(q, s.ps, (double)s.last_rho / (double)a.rho);
-        K<T>::proj_scalars_set(q, gs, ap, 0, s.ps, ptmp, mpart, cbuf, s.Mtrue);
+        // Sampled prediction of theta in front of the search (kernels_proj.hip, k_sample) when the previous search of this
+        // set asked for it (theta moved, fallback sweeps were needed) or rho was changed: its verdict sits in pinned memory, written by k_l1_solve before the sums of that
+        // iteration reached the host.  (A stale word costs time only: the kernels check the device-side state themselves.)
+        SampleCtl ctl;
+        ctl.host_want = (int*)hlean_ + i;
+        ctl.runs = l1_sample_runs_;
+        ctl.enable = l1_sample_ && a.prox == PX_L1 && !s.custom && (rescaled || hlean_[i] != 0);
+        K<T>::proj_scalars_set(q, gs, ap, 0, s.ps, ptmp, mpart, cbuf, s.Mtrue, ctl);
         s.last_rho = a.rho;
         s.last_gamma = a.gamma;
       }
@@ -1301,7 +1318,7 @@ class Engine : public EngineBase {
     need_final();
     for (int k = 0; k < 16; ++k) o[k] = 0;
     if (set < 0 || set >= p_n_) throw std::runtime_error("set index out of range");
-    const ProjScalars<T>* d = which ? sets_[set].psf : sets_[set].ps;
+    const ProjScalars<T>* d = (which & 1) ? sets_[set].psf : sets_[set].ps;
     if (!d) return;
     ProjScalars<T> h;
     SIPX_HIP(hipStreamSynchronize(stream_));
@@ -1309,8 +1326,8 @@ class Engine : public EngineBase {
     o[0] = h.need; o[1] = h.theta; o[2] = h.theta_prev; o[3] = h.hw; o[4] = h.spec_lo; o[5] = h.spec_hi; o[6] = h.lo;
     o[7] = h.hi; o[8] = h.asum; o[9] = h.vmax; o[10] = h.dbg[0]; o[11] = h.dbg[1]; o[12] = h.dbg[2]; o[13] = h.dbg[3];
     o[14] = h.refine;
-    o[15] = h.lean;
-    o[15] = h.lean;
+    o[15] = h.lean + 2 * h.dbg_sampled;
+    if (which & 2) { o[4] = h.samp_theta; o[5] = h.samp_lo; o[6] = h.samp_hi; o[7] = h.samp_c; }     // the sampled prediction
   }
 
   void* stream() override { return (void*)stream_; }
@@ -1890,6 +1907,9 @@ class Engine : public EngineBase {
   double *part_cg_ = nullptr, *part_tmp_ = nullptr, *part_sets_ = nullptr;
   CgState<T>*cg_dev_ = nullptr, *cg_host_ = nullptr;
   double* hres_ = nullptr;
+  volatile int* hlean_ = nullptr;     // per set: the coming l1 search wants a sampled prediction (written by k_l1_solve)
+  long long l1_sample_runs_ = 0;
+  bool l1_sample_ = true;             // SIPX_L1_SAMPLE=0: no sampled prediction of theta (A/B switch)
   std::vector<hipEvent_t> ev_;
   int nmark_[2] = {0, 0};
   int mark_sec_[2][MAXMARK];

@@ -55,7 +55,8 @@ __device__ __forceinline__ double l1_probe_mult(int k) {
 // occupancy of the first pass, so the grid is resident in one round (+1 % at 256^3 over seven per CU).
 #define SIPX_PASS_GRID launch_blocks(5)
 constexpr int SL_ABOVE_S = PREP_SLOTS, SL_ABOVE_C = PREP_SLOTS + 1;   // partial slots of the fallback compaction
-enum { M_FIRST = 0, M_PROBE = 1, M_COMPACT = 2, M_DIST = 3, M_STORE = 4 /* materialise v into `compact` */ };
+enum { M_FIRST = 0, M_PROBE = 1, M_COMPACT = 2, M_DIST = 3, M_STORE = 4 /* materialise v into `compact` */,
+       M_LEAN = 5 /* first pass with the two edge probes of the speculative range only (a kernel of its own: 52 instead of 113 VGPRs) */ };
 
 // One pass over the vector.  SRC 0: stored array (V == 1); SRC 1: produced on the fly by a set.
 template <typename T, int V, int MODE, int SRC>
@@ -66,7 +67,8 @@ __global__ __launch_bounds__(BLOCK) void k_pass(Grid G, SetArgs<T> a, int v_is_s
   long long* cidx = nullptr;
   if (MODE == M_COMPACT && a.prox == PX_CARD) cidx = ps->cidx;
   if (MODE == M_COMPACT && !(ps->need && !ps->spec_ok)) return;
-  __shared__ T sbuf[(MODE == M_FIRST || MODE == M_COMPACT) ? SPEC_CAP : 1];
+  constexpr bool GATHERS = MODE == M_FIRST || MODE == M_COMPACT || MODE == M_LEAN;
+  __shared__ T sbuf[GATHERS ? SPEC_CAP : 1];
   __shared__ unsigned int scnt, sused;     // reserved / actually filled prefix of sbuf
   __shared__ int sovf;
   __shared__ unsigned long long sbase;
@@ -74,17 +76,21 @@ __global__ __launch_bounds__(BLOCK) void k_pass(Grid G, SetArgs<T> a, int v_is_s
 #pragma unroll
   for (int k = 0; k < PREP_SLOTS; ++k) acc[k] = 0;
   ProbeAcc<T> pa;
-  if ((a.prox == PX_L1 || a.prox == PX_CARD) && MODE <= M_PROBE) {
+  if ((a.prox == PX_L1 || a.prox == PX_CARD) && (MODE <= M_PROBE || MODE == M_LEAN)) {
 #pragma unroll
     for (int k = 0; k < L1_K; ++k) pa.t[k] = (T)ps->t[k];      // stored TF-rounded: exact
   }
   double r_lo = 0, r_hi = -1;      // gather range (lo, hi]
-  if (MODE == M_FIRST && a.prox == PX_L1 && !(a.flags & F_NOSPEC)) { r_lo = ps->spec_lo; r_hi = ps->spec_hi; }
+  if ((MODE == M_FIRST || MODE == M_LEAN) && a.prox == PX_L1 && !(a.flags & F_NOSPEC)) { r_lo = ps->spec_lo; r_hi = ps->spec_hi; }
   if (MODE == M_COMPACT) { r_lo = ps->lo; r_hi = ps->hi; }
   const bool gather = r_hi > r_lo;
-  const bool lean = MODE == M_FIRST && a.prox == PX_L1 && gather && ps->lean != 0;
+  // The first pass of an l1 search is one of two kernels, launched back to back: the LEAN one when the previous search (or the
+  // sampled estimate) announced that the speculative range will hold theta, the full one otherwise; the other returns here.
+  const bool lean = (MODE == M_FIRST || MODE == M_LEAN) && a.prox == PX_L1 && gather && ps->lean != 0;
+  if (MODE == M_FIRST && lean) return;
+  if (MODE == M_LEAN && !lean) return;
   T vmax = T(0), vminp = (T)INFINITY;     // largest magnitude, smallest non-zero magnitude
-  if (MODE == M_FIRST || MODE == M_COMPACT) {
+  if (GATHERS) {
     if (threadIdx.x == 0) { scnt = 0; sused = 0; sovf = 0; }
     __syncthreads();
   }
@@ -95,7 +101,7 @@ __global__ __launch_bounds__(BLOCK) void k_pass(Grid G, SetArgs<T> a, int v_is_s
   auto body = [&](T x, long long e, bool live) {
     const T av = fabs(x);
     const double ad = (double)av;
-    if (MODE == M_FIRST && lean) {                // uniform: the whole launch takes one side
+    if (MODE == M_LEAN) {
       pa.add_lean(av, L1_WIN_LO, L1_WIN_HI);
       vminp = (av > T(0) && av < vminp) ? av : vminp;
     } else if (MODE == M_FIRST || MODE == M_PROBE) {
@@ -114,7 +120,7 @@ __global__ __launch_bounds__(BLOCK) void k_pass(Grid G, SetArgs<T> a, int v_is_s
       acc[0] += (double)dlt * (double)dlt;
       acc[1] += (double)x * (double)x;
     }
-    if ((MODE == M_FIRST || MODE == M_COMPACT) && gather) {
+    if (GATHERS && gather) {
       const bool in = ad > r_lo && ad <= r_hi;
       const unsigned long long mask = __ballot(in);
       if (mask) {
@@ -134,7 +140,7 @@ __global__ __launch_bounds__(BLOCK) void k_pass(Grid G, SetArgs<T> a, int v_is_s
         } else if (base + cnt <= SPEC_CAP) {                // room in the workgroup's LDS buffer
           if (in) sbuf[base + my] = av;
           if (lane == leader) atomicMax(&sused, base + (unsigned int)cnt);
-        } else if (MODE == M_FIRST) {
+        } else if (MODE == M_FIRST || MODE == M_LEAN) {
           sovf = 1;                                         // speculation gathered too much: give it up
         } else {                                            // fallback compaction never drops: go to global memory
           unsigned long long gb = 0;
@@ -199,6 +205,12 @@ __global__ __launch_bounds__(BLOCK) void k_pass(Grid G, SetArgs<T> a, int v_is_s
       block_max_store<T>(vmax, maxpart);
       block_min_store<T>(vminp, maxpart + NB);      // second half of the array
     }
+  } else if (MODE == M_LEAN) {
+    // only ||v||_1 and (S, C) at the two edges of the speculative range: the decision of a lean pass reads nothing else
+    double a5[5] = {pa.asum, pa.S[L1_WIN_LO], pa.S[L1_WIN_HI], (double)pa.C[L1_WIN_LO], (double)pa.C[L1_WIN_HI]};
+    const int slots[5] = {0, 3 + L1_WIN_LO, 3 + L1_WIN_HI, 3 + L1_K + L1_WIN_LO, 3 + L1_K + L1_WIN_HI};
+    block_reduce_store_at<5>(a5, partials, slots);
+    block_min_store<T>(vminp, maxpart + NB);
   } else if (MODE == M_COMPACT) {
     double a2[2] = {acc[0], acc[1]};
     block_reduce_store<2>(a2, partials, SL_ABOVE_S);
@@ -207,13 +219,13 @@ __global__ __launch_bounds__(BLOCK) void k_pass(Grid G, SetArgs<T> a, int v_is_s
     double a2[2] = {acc[0], acc[1]};
     block_reduce_store<2>(a2, partials, 0);
   }
-  if ((MODE == M_FIRST || MODE == M_COMPACT) && gather) {   // flush the workgroup's buffer: one global atomic
+  if (GATHERS && gather) {   // flush the workgroup's buffer: one global atomic
     __syncthreads();
     // reservations grow monotonically, so the stored entries form the prefix [0, sused)
     const unsigned int cnt = sused;
     if (threadIdx.x == 0) {
       sbase = cnt ? atomicAdd(&ps->n_compact, (unsigned long long)cnt) : 0ull;
-      if (MODE == M_FIRST && sovf) atomicOr(&ps->spec_overflow, 1);
+      if ((MODE == M_FIRST || MODE == M_LEAN) && sovf) atomicOr(&ps->spec_overflow, 1);
     }
     __syncthreads();
     for (unsigned int i = threadIdx.x; i < cnt; i += BLOCK) compact[sbase + i] = sbuf[i];
@@ -245,6 +257,12 @@ __global__ void k_ps_init(ProjScalars<T>* ps, long long* cidx) {
   ps->tau = T(0);
   ps->quota = 0x7fffffffffffffffll;
   ps->coop_arrive = ps->coop_finish = ps->coop_abort = 0;
+  for (int j = 0; j < SAMPLE_BINS; ++j) ps->hist[j] = 0;
+  ps->sampled = ps->dbg_sampled = ps->want_sample = 0;
+  ps->samp_ticket = 0;
+  ps->rescaled = 0;
+  ps->resc_bad = 1;
+  ps->samp_theta = 0;
 }
 template <typename T>
 void K<T>::ps_init(hipStream_t s, ProjScalars<T>* ps, long long* cidx) {
@@ -470,6 +488,291 @@ __global__ __launch_bounds__(64) void k_decide(ProjScalars<T>* ps, int prox, T p
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// SAMPLED PREDICTION of theta.  While rho and gamma are still being adapted, theta moves by up to a factor of three from one
+// PARSDMM iteration to the next: the speculative gather around the previous theta fails and the search pays two more sweeps
+// of the vector (refinement + compaction, 6 N w bytes per set).  A sweep over a SAMPLE of the vector (every stride-th chunk
+// of 1024 grid points, chunk chosen by a hash inside its group so that no lattice direction is favoured; about a million
+// entries) costs a hundredth of that and predicts theta to a few tenths of a percent: the sampled magnitudes go into a
+// histogram (bin key = leading bits of the floating-point pattern, 256 bins per octave, 8 octaves around the old prediction;
+// counts and FIXED-POINT sums through integer atomics, so the totals do not depend on the order of arrival), a one-workgroup
+// kernel takes suffix sums and finds the bin in which f_sample(t) = sum(max(|v|-t,0)) - b n_sample/n changes sign.  (S, C) at
+// the bin's edges are exact for the sample, so its root lies between the Newton step from the lower edge and the secant
+// (f is convex) whatever the density inside the bin does -- near convergence the magnitudes pile up right at theta.  That
+// interval, widened by four standard deviations of the sampling error sqrt(sum_sample max(|v|-theta,0)^2) / C, becomes the
+// speculative range of the first pass, which is then a lean one.  Nothing of the result depends on the sample: a miss is
+// caught by the pass's own bracket test and costs the fallback sweeps it would have cost anyway.
+template <typename T>
+struct KeyBits;
+template <>
+struct KeyBits<float> {
+  typedef unsigned int U;
+  static constexpr int SH = 23 - SAMPLE_MBITS;
+  static constexpr long long KEY_INF = 0xffll << SAMPLE_MBITS;
+  static __device__ __forceinline__ long long key(float v) { return (long long)(__float_as_uint(v) >> SH); }
+  static __device__ __forceinline__ double edge(long long k) { return (double)__uint_as_float((unsigned int)k << SH); }
+};
+template <>
+struct KeyBits<double> {
+  typedef unsigned long long U;
+  static constexpr int SH = 52 - SAMPLE_MBITS;
+  static constexpr long long KEY_INF = 0x7ffll << SAMPLE_MBITS;
+  static __device__ __forceinline__ long long key(double v) { return (long long)((unsigned long long)__double_as_longlong(v) >> SH); }
+  static __device__ __forceinline__ double edge(long long k) { return __longlong_as_double((long long)((unsigned long long)k << SH)); }
+};
+template <typename T>
+__device__ __forceinline__ long long sample_key_lo(const ProjScalars<T>* ps) {
+  long long k = KeyBits<T>::key((T)ps->theta_prev) - SAMPLE_BINS / 2;
+  k = k < 1 ? 1 : k;
+  const long long kmax = KeyBits<T>::KEY_INF - SAMPLE_BINS - 1;
+  return k > kmax ? kmax : k;
+}
+constexpr double SAMPLE_FIX = 1048576.0;          // 2^SAMPLE_VAL_BITS
+
+constexpr int SAMPLE_NT = 512;                   // threads of a k_sample workgroup
+constexpr int SAMPLE_WG = 256;                   // workgroups of k_sample (each merges its LDS histogram into the global one)
+constexpr int SAMPLE_RUN = 16;                   // lanes (x V grid points) of one sampled run: 64 consecutive entries.  Neighbouring
+                                                 // entries are correlated, so many short runs beat few long ones
+// A histogram bin is ONE 64-bit word: the count in the upper SAMPLE_CNT_BITS bits, the fixed-point sum of the magnitudes below
+// (top edge of the range = 2^SAMPLE_VAL_BITS: at most 2^SAMPLE_CNT_BITS values fit without a carry into the count) -- one LDS
+// atomic per sampled entry, one global atomic per non-empty bin and workgroup.
+constexpr int SAMPLE_CNT_BITS = 22, SAMPLE_VAL_BITS = 20;
+static_assert(SAMPLE_CNT_BITS + SAMPLE_CNT_BITS + SAMPLE_VAL_BITS <= 64, "sum field must hold 2^CNT values of 2^VAL");
+constexpr unsigned long long SAMPLE_SUM_MASK = (1ull << (64 - SAMPLE_CNT_BITS)) - 1ull;
+
+// Second half of the sampled prediction, run by the workgroup of k_sample that finishes last: suffix sums over the bins,
+// the bin of the sample's root, its Newton / secant bounds, the sampling error, the probes of the coming first pass.
+// Everything the other workgroups contributed was written with device-scope atomics and is read with device-scope loads.
+template <typename T>
+__device__ __forceinline__ void sample_decide(ProjScalars<T>* ps, double* __restrict__ partials, int nwg, T radius,
+                                              long long true_len, double hw_max, int lean_on, double gather_cap, double* sS,
+                                              double* sC) {
+  constexpr int NT = SAMPLE_NT, PER = SAMPLE_BINS / NT, NW = NT / 64;
+  static_assert(SAMPLE_BINS % NT == 0 && NW <= 16, "bins per thread");
+  __shared__ int sh_bin, sh_ok;
+  __shared__ double sh_thN, sh_thS, sh_cact, sh_lo, sh_hi;
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int j0 = threadIdx.x * PER;
+  // all loads first: this thread's bins, its share of the three partial sums of the nwg workgroups
+  unsigned long long word[PER];
+#pragma unroll
+  for (int i = 0; i < PER; ++i) word[i] = __hip_atomic_load(&ps->hist[j0 + i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  double v[3] = {0, 0, 0};
+  for (int i = threadIdx.x; i < nwg; i += NT)
+#pragma unroll
+    for (int k = 0; k < 3; ++k) v[k] += __hip_atomic_load(&partials[(long long)k * NB + i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+  for (int i = 0; i < PER; ++i) __hip_atomic_store(&ps->hist[j0 + i], 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next search
+  const long long key_lo = sample_key_lo<T>(ps);
+  const double fscale = SAMPLE_FIX / KeyBits<T>::edge(key_lo + SAMPLE_BINS);
+  double cnt[PER], sum[PER];
+  double tS = 0, tC = 0;
+#pragma unroll
+  for (int i = 0; i < PER; ++i) {
+    cnt[i] = (double)(word[i] >> (64 - SAMPLE_CNT_BITS));
+    sum[i] = (double)(word[i] & SAMPLE_SUM_MASK) / fscale;
+    tS += sum[i];
+    tC += cnt[i];
+  }
+#pragma unroll
+  for (int k = 0; k < 3; ++k) v[k] = wave_sum(v[k]);
+  double sufS = tS, sufC = tC;                  // inclusive suffix sums inside the wave (fixed order)
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    const double aS = __shfl_down(sufS, d, 64), aC = __shfl_down(sufC, d, 64);
+    if (lane + d < 64) { sufS += aS; sufC += aC; }
+  }
+  const double exS = __shfl_down(sufS, 1, 64), exC = __shfl_down(sufC, 1, 64);     // of the lanes above this one
+  if (lane == 0) { sS[wv] = sufS; sC[wv] = sufC; sS[16 + wv] = v[0]; sS[32 + wv] = v[1]; sS[48 + wv] = v[2]; }
+  if (threadIdx.x == 0) { sh_bin = SAMPLE_BINS; sh_ok = 0; }
+  __syncthreads();
+  double S_top = 0, C_top = 0, n_val = 0;       // above the histogram's range; valid entries sampled
+  for (int i = 0; i < NW; ++i) { S_top += sS[16 + i]; C_top += sS[32 + i]; n_val += sS[48 + i]; }
+  // (sum, count) of the sampled magnitudes above the upper edge of this thread's last bin
+  double Sab = S_top + (lane < 63 ? exS : 0.0), Cab = C_top + (lane < 63 ? exC : 0.0);
+  for (int i = NW - 1; i > wv; --i) { Sab += sS[i]; Cab += sC[i]; }
+  const double bs = (double)radius * (n_val / (double)true_len);          // the ball's radius, scaled to the sample
+  double e_up = KeyBits<T>::edge(key_lo + j0 + PER);
+  double f_up = Sab - e_up * Cab - bs;
+  int my_bin = SAMPLE_BINS;
+  double r_thN = 0, r_thS = 0, r_cact = 0;
+#pragma unroll
+  for (int i = PER - 1; i >= 0; --i) {
+    Sab += sum[i];
+    Cab += cnt[i];
+    const double e_lo = KeyBits<T>::edge(key_lo + j0 + i);
+    const double f_lo = Sab - e_lo * Cab - bs;
+    if (f_lo >= 0 && f_up < 0) {
+      my_bin = j0 + i;
+      double thN = Cab > 0 ? (Sab - bs) / Cab : e_lo;                     // Newton from the lower edge: <= root
+      thN = thN < e_lo ? e_lo : (thN > e_up ? e_up : thN);
+      double thS = e_lo + f_lo * (e_up - e_lo) / (f_lo - f_up);           // secant: >= root
+      thS = thS < thN ? thN : (thS > e_up ? e_up : thS);
+      r_thN = thN; r_thS = thS; r_cact = Cab - 0.5 * cnt[i];
+    }
+    e_up = e_lo;
+    f_up = f_lo;
+  }
+  if (my_bin < SAMPLE_BINS) atomicMin(&sh_bin, my_bin);
+  __syncthreads();
+  if (sh_bin == SAMPLE_BINS) return;            // the sample's root is outside the histogram: keep the old prediction
+  if (my_bin == sh_bin) { sh_thN = r_thN; sh_thS = r_thS; sh_cact = r_cact; }
+  __syncthreads();
+  // sampling error of the root: sqrt(sum over the active sample of (|v| - theta)^2) / C, from the bins above the root's
+  const double th = 0.5 * (sh_thN + sh_thS);
+  double q = 0;
+#pragma unroll
+  for (int i = 0; i < PER; ++i) {
+    if (j0 + i > sh_bin) {
+      const double mid = 0.5 * (KeyBits<T>::edge(key_lo + j0 + i) + KeyBits<T>::edge(key_lo + j0 + i + 1)) - th;
+      q += cnt[i] * mid * mid;
+    }
+  }
+  q = wave_sum(q);
+  if (lane == 0) sC[wv] = q;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const double c_act = sh_cact;
+    if (th > 0 && c_act >= 16.0) {
+      double Q = 0;
+      for (int i = 0; i < NW; ++i) Q += sC[i];
+      if (C_top > 0) { const double mt = S_top / C_top - th; Q += C_top * mt * mt; }
+      double m = 4.0 * sqrt(Q) / (c_act * th);        // four standard deviations, relative
+      m = m < 5e-4 ? 5e-4 : (m > 0.5 ? 0.5 : m);
+      sh_lo = sh_thN * (1.0 - m);
+      sh_hi = sh_thS * (1.0 + m);
+      sh_ok = 1;
+    }
+  }
+  __syncthreads();
+  if (!sh_ok) return;
+  // How many magnitudes of the WHOLE vector will the range (lo, hi] gather?  The bins it touches, scaled by the sampling
+  // ratio.  The relative width does not matter (when theta is small against the spread of the values its sampling error is
+  // several percent, yet few values lie that close to it): the capacity of the speculative gather does.
+  double gcnt = 0;
+#pragma unroll
+  for (int i = 0; i < PER; ++i) {
+    const double e0 = KeyBits<T>::edge(key_lo + j0 + i), e1 = KeyBits<T>::edge(key_lo + j0 + i + 1);
+    if (e1 > sh_lo && e0 <= sh_hi) gcnt += cnt[i];
+  }
+  gcnt = wave_sum(gcnt);
+  if (lane == 0) sS[wv] = gcnt;
+  __syncthreads();
+  if (threadIdx.x != 0) return;
+  double G = 0;
+  for (int i = 0; i < NW; ++i) G += sS[i];
+  G *= (double)true_len / n_val;
+  double lo = sh_lo, hi = sh_hi;
+  if (G > gather_cap) {            // shrink towards the Newton / secant interval (a miss only costs the fallback sweeps)
+    const double f = gather_cap / G;
+    lo = sh_thN - (sh_thN - lo) * f;
+    hi = sh_thS + (hi - sh_thS) * f;
+  }
+  const double c_act = sh_cact;
+  const double ctr = 0.5 * (lo + hi);
+  double hw = (hi - lo) / (2.0 * ctr);
+  hw = hw < 1e-3 ? 1e-3 : hw;
+  ps->hw = hw < hw_max ? hw : hw_max;      // (the next search's own rule starts from a range of the usual width)
+  for (int k = 0; k < L1_K; ++k) {
+    const double t = ctr * (1.0 + hw * l1_probe_mult(k));
+    ps->t[k] = t > 0 ? (double)(T)t : 0.0;
+  }
+  ps->spec_lo = ps->t[L1_WIN_LO];
+  ps->spec_hi = ps->t[L1_WIN_HI];
+  ps->lean = lean_on ? 1 : 0;
+  ps->sampled = 1;
+  ps->samp_theta = th;
+  ps->samp_lo = sh_thN; ps->samp_hi = sh_thS; ps->samp_c = c_act;
+}
+
+template <typename T, int V>
+__global__ __launch_bounds__(SAMPLE_NT) void k_sample(Grid G, SetArgs<T> a, ProjScalars<T>* ps, double* __restrict__ partials,
+                                                      long long nchunks, long long nsamp, unsigned int stride, long long true_len,
+                                                      double hw_max, int lean_on, double gather_cap) {
+  if (!ps->want_sample || !(ps->theta_prev > 0)) return;
+  constexpr int NT = SAMPLE_NT;
+  __shared__ unsigned long long hs[SAMPLE_BINS];
+  __shared__ double sS[NT], sC[NT];
+  __shared__ unsigned int sh_ticket;
+  for (int j = threadIdx.x; j < SAMPLE_BINS; j += NT) hs[j] = 0;
+  __syncthreads();
+  const long long key_lo = sample_key_lo<T>(ps);
+  const double fscale = SAMPLE_FIX / KeyBits<T>::edge(key_lo + SAMPLE_BINS);
+  double acc[3] = {0, 0, 0};      // sum and count of the sampled magnitudes above the histogram's range, valid entries sampled
+  const bool ident = a.nblk == 0;
+  const int nb = ident ? 1 : a.nblk;
+  const bool relax = !(a.gamma == T(1));
+  const T gam = a.gamma, omg = T(1) - a.gamma;
+  const long long nvec = G.N / V;
+  // sampled run u of SAMPLE_RUN lanes -> run u * stride + hash(u) mod stride of the vector (one out of every `stride` runs,
+  // chosen by a hash so that no lattice direction of the grid is favoured)
+  const long long total = nsamp * SAMPLE_RUN;      // lanes to process
+  for (long long t0 = (long long)blockIdx.x * NT; t0 < total; t0 += (long long)gridDim.x * NT) {
+    const long long t = t0 + threadIdx.x;
+    const long long u = t / SAMPLE_RUN;
+    long long ru = u * stride + (long long)((unsigned int)(((unsigned long long)u * 2654435761ull) >> 13) % stride);
+    if (ru >= nchunks) ru = u * stride;
+    const long long vi = t < total ? ru * SAMPLE_RUN + (t % SAMPLE_RUN) : nvec;
+    const bool live = vi < nvec;
+    const long long g = live ? vi * V : 0;
+    const Coord cd = coords(G, g);
+    const Vec<T, V> xc = ldv<T, V>(a.x + g);
+    for (int q = 0; q < nb; ++q) {
+      const long long e = (long long)q * G.N + g;
+      T s[V];
+      bool valid[V];
+      if (ident) {
+#pragma unroll
+        for (int k = 0; k < V; ++k) { s[k] = xc.v[k]; valid[k] = true; }
+      } else {
+        fwd_dir<T, V>(G, a.x, xc, g, cd, a.dir[q], a.ih[q], s, valid);
+      }
+      const Vec<T, V> yv = ldv<T, V>(a.y + e), lv = ldv<T, V>(a.l + e);
+#pragma unroll
+      for (int k = 0; k < V; ++k) {
+        if (!(live && valid[k])) continue;
+        const T xh = relax ? (gam * s[k] + omg * yv.v[k]) : s[k];       // update_y_l.jl:72
+        const T av = fabs(xh - lv.v[k] * a.rho1);                       // :67 / :74
+        acc[2] += 1.0;
+        const long long j = KeyBits<T>::key(av) - key_lo;
+        if (j >= SAMPLE_BINS) {
+          acc[0] += (double)av;
+          acc[1] += 1.0;
+        } else if (j >= 0) {
+          atomicAdd(&hs[j], (1ull << (64 - SAMPLE_CNT_BITS)) + (unsigned long long)((double)av * fscale + 0.5));
+        }
+      }
+    }
+  }
+  // this workgroup's three sums -> partials[k * NB + blockIdx.x] (fixed order)
+#pragma unroll
+  for (int k = 0; k < 3; ++k) acc[k] = wave_sum(acc[k]);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) { sS[threadIdx.x >> 6] = acc[0]; sC[threadIdx.x >> 6] = acc[1]; sS[64 + (threadIdx.x >> 6)] = acc[2]; }
+  __syncthreads();
+  // What leaves the workgroup goes through DEVICE-SCOPE ATOMICS (performed at the coherence point, not in this XCD's L2), so no
+  // cache write-back / invalidation is needed to hand it to the workgroup that decides: a __threadfence() pair here flushes
+  // the L2 of work the other set stream left dirty and cost 15 of the kernel's 40 us.
+  if (threadIdx.x == 0) {
+    double t0 = 0, t1 = 0, t2 = 0;
+    for (int i = 0; i < NT / 64; ++i) { t0 += sS[i]; t1 += sC[i]; t2 += sS[64 + i]; }
+    __hip_atomic_store(&partials[blockIdx.x], t0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(&partials[NB + blockIdx.x], t1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(&partials[2 * NB + blockIdx.x], t2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  for (int j = threadIdx.x; j < SAMPLE_BINS; j += NT)
+    if (hs[j]) __hip_atomic_fetch_add(&ps->hist[j], hs[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  // every thread waits until its own atomics have been performed, then the workgroup takes a ticket: the one that arrives last
+  // finds every other one's contribution in place and decides
+  __builtin_amdgcn_s_waitcnt(0);
+  __syncthreads();
+  if (threadIdx.x == 0) sh_ticket = __hip_atomic_fetch_add(&ps->samp_ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  __syncthreads();
+  if (sh_ticket != gridDim.x - 1) return;
+  if (threadIdx.x == 0) __hip_atomic_store(&ps->samp_ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  sample_decide<T>(ps, partials, (int)gridDim.x, a.phi, true_len, hw_max, lean_on, gather_cap, sS, sC);
+}
+
 // Double-double accumulation (Knuth's TwoSum): the gathered magnitudes arrive in an order that changes from run to run (they
 // are compacted through atomics), and a plain float64 sum of them would change in its last bits with that order -- and the
 // threshold, and every y, l and x after it, with it.  Carried as (hi, lo) pairs the sum is good to ~1e-32 relative whatever
@@ -522,7 +825,7 @@ static_assert(SOLVE_G <= SIPX_SOLVE_SLOTS, "ProjScalars holds SIPX_SOLVE_SLOTS c
 template <typename T>
 __global__ __launch_bounds__(SIPX_SOLVE_NT) void k_l1_solve(ProjScalars<T>* ps, T radius, const T* __restrict__ compact,
                                                    const double* __restrict__ partials, long long true_len, double hw_max,
-                                                   int lean_on) {
+                                                   int lean_on, int* host_want) {
   constexpr int NT = SIPX_SOLVE_NT;
   __shared__ double ssum[NT / 64];
   __shared__ double ssum_lo[NT / 64];
@@ -664,10 +967,18 @@ __global__ __launch_bounds__(SIPX_SOLVE_NT) void k_l1_solve(ProjScalars<T>* ps, 
     // ---- state for the next call ----
     // a search that the speculative gather settled is followed by a LEAN first pass (two probes instead of eight)
     ps->lean = (lean_on && need && theta > 0 && ps->spec_ok && !ps->spec_overflow && sh_ca < (double)true_len) ? 1 : 0;
+    ps->want_sample = 0;
     if (need && theta > 0) {
       double hw = ps->hw;
       if (ps->theta_prev > 0) {
         const double d = fabs(theta / ps->theta_prev - 1.0);
+        // theta moved by more than a third of the widest speculative range (or the last search needed its fallback sweeps):
+        // the coming prediction is not to be trusted -- a sampled estimate first (k_sample), when the caller provides for it
+        ps->want_sample = (3.0 * d > hw_max || !ps->lean) ? 1 : 0;
+        // this search followed a change of rho: was theta_prev * rho_old / rho_new (k_ps_rescale) good to the range it gets?
+        // Early on it is not (theta is set by x_hat, not by l / rho) and the sampled estimate is; late it is, and then more
+        // accurate than a sample, whose error grows as theta shrinks against the spread of the values
+        if (ps->rescaled) ps->resc_bad = d > hw_max ? 1 : 0;
         hw = 3.0 * d;                                  // theta moves slowly while rho, gamma stay put
         hw = hw < 1e-3 ? 1e-3 : (hw > hw_max ? hw_max : hw);
         if (ps->spec_overflow) hw = ps->hw * 0.5;      // the last range gathered too much
@@ -684,6 +995,10 @@ __global__ __launch_bounds__(SIPX_SOLVE_NT) void k_l1_solve(ProjScalars<T>* ps, 
     }
     ps->n_compact = 0;
     ps->spec_overflow = 0;
+    ps->dbg_sampled = ps->sampled;
+    ps->sampled = 0;
+    ps->rescaled = 0;
+    if (host_want) __hip_atomic_store(host_want, ps->want_sample, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
   }
 }
 
@@ -813,6 +1128,8 @@ __global__ void k_ps_rescale(ProjScalars<T>* ps, double factor, double hw_max) {
   if (!(ps->theta_prev > 0)) return;
   ps->theta_prev *= factor;
   ps->hw = hw_max;
+  ps->rescaled = 1;
+  if (ps->resc_bad) ps->want_sample = 1;   // the last such prediction missed the range: sample
   for (int k = 0; k < L1_K; ++k) ps->t[k] = (double)(T)(ps->theta_prev * (1.0 + ps->hw * l1_probe_mult(k)));
   ps->spec_lo = ps->t[L1_WIN_LO];
   ps->spec_hi = ps->t[L1_WIN_HI];
@@ -825,8 +1142,21 @@ void K<T>::ps_rescale(hipStream_t s, ProjScalars<T>* ps, double factor) {
 
 template <typename T, int SRC>
 static void launch_chain(hipStream_t s, const Grid& g, const SetArgs<T>& a, int v_is_s, const T* varr, long long len,
-                         ProjScalars<T>* ps, double* partials, T* maxpart, T* compact, long long true_len) {
+                         ProjScalars<T>* ps, double* partials, T* maxpart, T* compact, long long true_len,
+                         SampleCtl ctl = SampleCtl()) {
   const bool vec = SRC == 1 && g.n[0] % 4 == 0;
+  if (SRC == 1 && vec && ctl.enable && a.prox == PX_L1 && !v_is_s) {
+    // about a million grid points (times the operator's blocks); not worth it when that is more than a quarter of the vector
+    const long long nchunks = (g.N / 4 + SAMPLE_RUN - 1) / SAMPLE_RUN;          // runs of 64 grid points
+    const long long target = ctl.runs > 0 ? ctl.runs : (g.N >= (1ll << 26) ? 32768 : 16384);   // one or two million sampled points
+    const long long stride = nchunks / target;
+    if (stride >= 4) {
+      const long long nsamp = nchunks / stride;
+      hipLaunchKernelGGL((k_sample<T, 4>), dim3((unsigned)(nsamp < SAMPLE_WG ? nsamp : SAMPLE_WG)), dim3(SAMPLE_NT), 0, s, g, a, ps, partials,
+                         nchunks, nsamp, (unsigned int)stride, true_len, l1_hw_max(), l1_lean_on(),
+                         0.2 * (double)fit_grid(g.N / 4, SIPX_PASS_GRID) * (double)SPEC_CAP);     // a fifth of the LDS buffers of the pass
+    }
+  }
   static const double capdiv = [] { const char* e = getenv("SIPX_L1_CAPDIV"); return e ? atof(e) : 64.0; }();
 #define SIPX_PASS(MODE)                                                                                            \
   do {                                                                                                             \
@@ -851,6 +1181,7 @@ static void launch_chain(hipStream_t s, const Grid& g, const SetArgs<T>& a, int 
     return;
   }
   SIPX_PASS(M_FIRST);
+  if (a.prox == PX_L1 && !(a.flags & F_NOSPEC)) SIPX_PASS(M_LEAN);
   hipLaunchKernelGGL((k_slot_sums<T, 0>), dim3(PREP_SLOTS + 1), dim3(BLOCK), 0, s, partials, maxpart, ps);
   hipLaunchKernelGGL((k_decide<T, 0>), dim3(1), dim3(64), 0, s, ps, a.prox, a.plo, a.phi, true_len, (a.flags & F_NOSPEC) ? 1 : 0, capdiv);
   if (a.prox == PX_L1) {
@@ -860,7 +1191,8 @@ static void launch_chain(hipStream_t s, const Grid& g, const SetArgs<T>& a, int 
       hipLaunchKernelGGL((k_decide<T, 1>), dim3(1), dim3(64), 0, s, ps, a.prox, a.plo, a.phi, true_len, 0, capdiv);
     }
     SIPX_PASS(M_COMPACT);
-    hipLaunchKernelGGL((k_l1_solve<T>), dim3(SOLVE_G), dim3(SIPX_SOLVE_NT), 0, s, ps, a.phi, compact, partials, true_len, l1_hw_max(), l1_lean_on());
+    hipLaunchKernelGGL((k_l1_solve<T>), dim3(SOLVE_G), dim3(SIPX_SOLVE_NT), 0, s, ps, a.phi, compact, partials, true_len, l1_hw_max(), l1_lean_on(),
+                       ctl.host_want);
   }
 #undef SIPX_PASS
   SIPX_HIP(hipGetLastError());
@@ -868,10 +1200,10 @@ static void launch_chain(hipStream_t s, const Grid& g, const SetArgs<T>& a, int 
 
 template <typename T>
 void K<T>::proj_scalars_set(hipStream_t s, const Grid& g, const SetArgs<T>& a, int v_is_s, ProjScalars<T>* ps,
-                            double* partials, T* maxpart, T* compact, long long true_len) {
+                            double* partials, T* maxpart, T* compact, long long true_len, SampleCtl ctl) {
   SetArgs<T> b = a;
   b.ps = ps;
-  launch_chain<T, 1>(s, g, b, v_is_s, nullptr, 0, ps, partials, maxpart, compact, true_len);
+  launch_chain<T, 1>(s, g, b, v_is_s, nullptr, 0, ps, partials, maxpart, compact, true_len, ctl);
 }
 template <typename T>
 void K<T>::proj_scalars_arr(hipStream_t s, long long len, const T* v, int prox, T pmin, T pmax, ProjScalars<T>* ps,
@@ -915,7 +1247,7 @@ void K<T>::proj_dist_set(hipStream_t s, const Grid& g, const SetArgs<T>& a, int 
   template void K<T>::ps_rescale(hipStream_t, ProjScalars<T>*, double);                                          \
   template void K<T>::store_v(hipStream_t, const Grid&, const SetArgs<T>&, int, T*);                                                     \
   template void K<T>::proj_scalars_set(hipStream_t, const Grid&, const SetArgs<T>&, int, ProjScalars<T>*, double*, \
-                                       T*, T*, long long);                                                       \
+                                       T*, T*, long long, SampleCtl);                                                     \
   template void K<T>::proj_scalars_arr(hipStream_t, long long, const T*, int, T, T, ProjScalars<T>*, double*, T*, \
                                        T*, long long);                                                           \
   template void K<T>::proj_dist_set(hipStream_t, const Grid&, const SetArgs<T>&, int, const ProjScalars<T>*, double*);

@@ -40,6 +40,11 @@ constexpr int YL_SLOTS = 13;      // reductions produced by one y/l-update launc
 constexpr int L1_K = 8;          // probe thresholds of the l1-ball threshold search
 #define SIPX_SOLVE_SLOTS 64      // most workgroups a cooperative k_l1_solve may be launched with
 constexpr int PREP_SLOTS = 3 + 2 * L1_K;   // ||v||_1, ||v||_2^2, nnz, S_k, C_k
+// Sampled prediction of the l1 threshold (k_sample / k_sample_decide): histogram of the sampled magnitudes over
+// SAMPLE_BINS bins of 2^-SAMPLE_MBITS of an octave each (the bin key is the leading bits of the floating-point pattern),
+// centred on the predicted theta
+constexpr int SAMPLE_BINS = 1024;
+constexpr int SAMPLE_MBITS = 7;
 
 // reduction slots of k_yl (per set)
 enum { SL_RPRI = 0, SL_DY = 1, SL_HL = 2, SL_HH = 3, SL_LH = 4, SL_DL = 5, SL_GG = 6, SL_GL = 7,
@@ -134,6 +139,24 @@ struct ProjScalars {
   // cooperative sweeps of k_l1_solve: per-workgroup shares of (sum hi, sum lo, count), double buffered by iteration parity
   double coop_hi[2][SIPX_SOLVE_SLOTS], coop_lo[2][SIPX_SOLVE_SLOTS], coop_c[2][SIPX_SOLVE_SLOTS];
   unsigned coop_arrive, coop_finish, coop_abort;
+  // sampled prediction: per bin, count and fixed-point sum of the sampled magnitudes packed in one word (integer atomics:
+  // the totals do not depend on the order of arrival); zero between searches
+  unsigned long long hist[SAMPLE_BINS];
+  unsigned samp_ticket;   // arrivals of k_sample's workgroups (the last one decides)
+  int rescaled, resc_bad;   // the coming search follows k_ps_rescale; the last rescaled prediction missed its range
+  int want_sample;    // the prediction of the coming search is not trusted (theta moved, or rho was changed): sample first
+  int sampled;        // the probes of the coming first pass were centred by k_sample_decide (diagnostics: dbg_sampled)
+  int dbg_sampled;
+  double samp_theta;  // the sampled estimate itself
+  double samp_lo, samp_hi, samp_c;   // diagnostics: Newton / secant bounds of the sample's root, active sample count
+};
+
+// Optional sampled prediction in front of an l1 search (see k_sample): host-side switch and the pinned word through which
+// k_l1_solve tells the host whether the coming search wants it (ProjScalars::want_sample)
+struct SampleCtl {
+  int enable = 0;
+  long long runs = 0;      // sampled runs of 64 grid points (0: 16384, 32768 from 2^26 grid points on)
+  int* host_want = nullptr;
 };
 
 template <typename T>
@@ -263,7 +286,7 @@ struct K {
   // Enqueues: first pass (sums + probe + speculative compaction), bracket, gated refinement / compaction, solve.
   static void ps_rescale(hipStream_t s, ProjScalars<T>* ps, double factor);
   static void proj_scalars_set(hipStream_t s, const Grid& g, const SetArgs<T>& a, int v_is_s, ProjScalars<T>* ps,
-                               double* partials, T* maxpart, T* compact, long long true_len);
+                               double* partials, T* maxpart, T* compact, long long true_len, SampleCtl ctl = SampleCtl());
   static void proj_scalars_arr(hipStream_t s, long long len, const T* v, int prox, T pmin, T pmax, ProjScalars<T>* ps,
                                double* partials, T* maxpart, T* compact, long long true_len);
   // ||P(v)-v||^2 and ||v||^2 of the set-produced vector into partial slots dst[0..NB), dst[NB..2NB)

@@ -144,6 +144,32 @@ __device__ __forceinline__ void block_reduce_store(double (&acc)[K], double* __r
   }
 }
 
+// The same for K slots that are not neighbours: slot numbers in `slots`.
+template <int K>
+__device__ __forceinline__ void block_reduce_store_at(double (&acc)[K], double* __restrict__ partials, const int (&slots)[K]) {
+  __shared__ double sm[K][BLOCK / 64];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  double v[K];
+#pragma unroll
+  for (int k = 0; k < K; ++k) v[k] = wave_sum(acc[k]);
+  if (lane == 0) {
+#pragma unroll
+    for (int k = 0; k < K; ++k) sm[k][w] = v[k];
+  }
+  __syncthreads();
+  if (threadIdx.x < K) {
+    double s = 0;
+#pragma unroll
+    for (int i = 0; i < BLOCK / 64; ++i) s += sm[threadIdx.x][i];
+    int slot = slots[0];
+#pragma unroll
+    for (int k = 1; k < K; ++k) slot = threadIdx.x == k ? slots[k] : slot;
+    double* row = partials + (long long)slot * NB;
+    row[blockIdx.x] = s;
+    for (int j = blockIdx.x + gridDim.x; j < NB; j += gridDim.x) row[j] = 0.0;
+  }
+}
+
 // Sum of the NB partials of one slot by one 256-thread block (fixed order).
 __device__ __forceinline__ double block_sum_partials(const double* __restrict__ p) {
   __shared__ double sm[BLOCK / 64];

@@ -765,7 +765,10 @@ class Context:
         _chk(lib().sipx_debug_proj(self.h, int(set_index), int(which), out.ctypes.data_as(C.c_void_p)))
         keys = ("need", "theta", "theta_prev", "hw", "spec_lo", "spec_hi", "lo", "hi", "asum", "vmax", "gathered",
                 "overflow", "spec_ok", "michelot_its", "refine", "lean")
-        return dict(zip(keys, out))
+        d = dict(zip(keys, out))
+        d["sampled"] = float(int(d["lean"]) >> 1)      # the probes of the last search were centred by the sampled estimate
+        d["lean"] = float(int(d["lean"]) & 1)
+        return d
 
     def kernel_stats(self, enable: bool):
         n, ms = C.c_int64(), C.c_double()

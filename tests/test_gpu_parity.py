@@ -1587,3 +1587,35 @@ def test_l1_projector_with_a_large_gather(sipx, TF):
         tol = 2e-5 if TF == np.float32 else 1e-11
         assert np.linalg.norm(w1 - ref) <= tol * np.linalg.norm(ref)
         assert abs(np.abs(w1.astype(np.float64)).sum() - b) <= tol * b
+
+
+@pytest.mark.parametrize("TF", [np.float32, np.float64])
+def test_sampled_prediction_of_the_l1_threshold_changes_nothing(sipx, TF, monkeypatch):
+    """The sampled estimate of theta (k_sample: histogram of every 16th run of 64 entries, Newton / secant bounds of the
+    sample's root) only places the speculative range of the first pass; theta itself stays the exact fixed point.  On a grid
+    small enough for the oracle, with the sample forced on (SIPX_L1_SAMPLE_RUNS: large grids sample by themselves): the solve
+    with and without it must agree to rounding of the one float64 sum whose split between 'above the range' and 'gathered'
+    differs, every search after the cold ones must have used the estimate at least once, and both must agree with the oracle
+    as the unsampled path does."""
+    n = (64, 48, 40)
+    m, g, opt, P, A, prop, AtA = _c3_problem(sipx, n, TF, maxit=24)
+    res = {}
+    for tag, env in (("off", {"SIPX_L1_SAMPLE": "0"}), ("on", {"SIPX_L1_SAMPLE": "1", "SIPX_L1_SAMPLE_RUNS": "96"})):
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        ctx = sipx.host.build_context(m, AtA, A, prop, P, g, opt)
+        ctx.parsdmm_begin(opt)
+        used = 0
+        for it in range(24):
+            ctx.parsdmm_steps(1)
+            used += sum(int(ctx.debug_proj(s, 0)["sampled"]) for s in (1, 2, 3))
+        x, _, _ = ctx.download()
+        log = ctx._run[2]
+        res[tag] = (x.astype(np.float64), np.array(log["rho"]), np.array(log["r_pri"]), used)
+        ctx.close()
+    assert res["off"][3] == 0 and res["on"][3] >= 12
+    tol = 2e-6 if TF == np.float32 else 1e-12
+    # the same rho history (no threshold of the Barzilai-Borwein rule flipped), to the rounding theta carries
+    assert np.allclose(res["on"][1], res["off"][1], rtol=50 * tol, atol=0)
+    assert np.allclose(res["on"][2], res["off"][2], rtol=50 * tol, atol=0)
+    assert np.linalg.norm(res["on"][0] - res["off"][0]) <= tol * np.linalg.norm(res["off"][0])

@@ -20,7 +20,10 @@ for it in range(1, NIT):
     for k, d in enumerate(th):
         t = d["theta"]
         rel = (t / prev[k] - 1) if prev[k] > 0 else float("nan")
-        line.append("th %.3e (%+.4f) ok %d ov %d n %d hw %.0e its %d rf %d ln %d" % (t, rel, d["spec_ok"], d["overflow"], d["gathered"], d["hw"], d["michelot_its"], d["refine"], d["lean"]))
+        line.append("th %.3e (%+.4f) ok %d ov %d n %d hw %.0e its %d rf %d ln %d sm %d" % (t, rel, d["spec_ok"], d["overflow"], d["gathered"], d["hw"], d["michelot_its"], d["refine"], d["lean"], d["sampled"]))
+        if d["sampled"]:
+            d2 = ctx.debug_proj((1, 2, 3)[k], 2)
+            line[-1] += " est %.4e [%.4e %.4e] c %d" % (d2["spec_lo"], d2["spec_hi"], d2["lo"], d2["hi"])
         prev[k] = t if t > 0 else prev[k]
     print(it, "rho", np.round(rho, 3), " | ".join(line), flush=True)
 ctx.close()
