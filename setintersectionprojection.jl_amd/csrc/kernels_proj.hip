@@ -1150,7 +1150,8 @@ static void launch_chain(hipStream_t s, const Grid& g, const SetArgs<T>& a, int 
     const long long nchunks = (g.N / 4 + SAMPLE_RUN - 1) / SAMPLE_RUN;          // runs of 64 grid points
     const long long target = ctl.runs > 0 ? ctl.runs : (g.N >= (1ll << 26) ? 32768 : 16384);   // one or two million sampled points
     const long long stride = nchunks / target;
-    if (stride >= 4) {
+    // (below 2^24 grid points the extra launch costs more than the sweeps it saves: 2048^2 loses 3 %; a test may force it)
+    if (stride >= 4 && (g.N >= (1ll << 24) || ctl.runs > 0)) {
       const long long nsamp = nchunks / stride;
       hipLaunchKernelGGL((k_sample<T, 4>), dim3((unsigned)(nsamp < SAMPLE_WG ? nsamp : SAMPLE_WG)), dim3(SAMPLE_NT), 0, s, g, a, ps, partials,
                          nchunks, nsamp, (unsigned int)stride, true_len, l1_hw_max(), l1_lean_on(),
