@@ -6,9 +6,10 @@ set -> logs -> stop rule -> rho/gamma adaptation -> Q update) on the configurati
 is quoted on: 3-D 256^3 Float32, sets {bounds on I, l1-ball on D_x, D_y, D_z} + the distance
 term (BASELINE.json configs[2]; SURVEY 8d "C3").  Inputs are resident in HBM before the timed
 region.  With --gpus N>1 (run plainly: the script spawns its own N ranks; or under torch.distributed.run)
-the constraint sets are sharded over the ranks and the x-step runs on z-slabs (one process per GPU,
-RCCL reduce-scatter of the right-hand side, slab CG, all-gather of x): the same projection problem,
-so scaling is "strong".
+the SAME projection problem is divided over the ranks (one process per GPU, RCCL inside the engine), so
+scaling is "strong": the headline set list is decomposed by z-slab for the whole iteration (--decomp
+slab: every rank holds every set, halo planes and small all-reduces only); set lists with a transform
+or a factorisation (the c4 leg) are sharded by constraint set, the x-step on z-slabs (--decomp sets).
 
 Prints ONE JSON line (rank 0).  roofline = the dominant kernel (cds_spmv fused with the CG dot
 product), timed with HIP events on the engine stream over the timed steps; cpu_baseline = the
@@ -128,6 +129,9 @@ def main():
     ap.add_argument("--no-c4", action="store_true", help="skip the short leg on BASELINE config 4 (512^3, eight sets) that follows the default run")
     ap.add_argument("--dtype", default="f32", choices=["f32", "f64"],
                     help="f32 = the contract workload; f64 = the same sets in Float64 (BASELINE config 5 computes in Float64)")
+    ap.add_argument("--decomp", default="auto", choices=["auto", "sets", "slab"],
+                    help="with more than one rank: sets = the reference's split by constraint set (x-step on z-slabs); slab = the WHOLE "
+                         "iteration on z-slabs (every rank holds every set; no N-vector crosses the fabric); auto = slab where the sets allow it")
     ap.add_argument("--q-mode", default="cds", choices=["cds", "stencil"],
                     help="cds = the reference's banded Q (the contract workload); stencil = generated coefficients (SURVEY 8f-2)")
     args = ap.parse_args()
@@ -195,8 +199,14 @@ def main():
         owned = sharded.shard_sets(p, world, rank)
         keep = []
         attach = None
+        slab = (dist is not None and args.decomp != "sets" and args.q_mode == "cds" and sharded.slab_decomposable(P, A))
+        if args.decomp == "slab" and dist is not None and not slab:
+            raise SystemExit(f"--decomp slab: the sets of {config} cannot be decomposed by slab")
         if dist is not None:
-            attach = lambda cx: keep.append(sharded.attach_comm(cx, dist, torch.device("cuda", local_rank)))
+            def attach(cx):
+                keep.append(sharded.attach_comm(cx, dist, torch.device("cuda", local_rank)))
+                if slab:
+                    cx.set_decomp("slab")
         ctx = sipx.host.build_context(m, AtA, A, prop, P, g, opt, device=local_rank, owned=owned, attach=attach)
         ctx.parsdmm_begin(opt)
         logs = ctx._run[2]
@@ -282,8 +292,11 @@ def main():
             "value": steps / dt, "ms_per_step": dt / steps * 1e3,
             "config": {"workload": f"{config}: {'x'.join(map(str, n))} {'Float32' if args.dtype == 'f32' else 'Float64'}, sets {{{', '.join(kinds)}}} + distance term",
                        "grid": list(n), "sets": kinds, "q_mode": args.q_mode,
-                       "parallelism": (f"sets sharded over {world} ranks (set i on rank i mod {world}); x-step on z-slabs: reduce-scatter(rhs) -> "
-                                       "slab CG (halo plane per product, all-reduced dot partials) -> all-gather(x)") if world > 1 else "single GPU",
+                       "parallelism": ((f"whole iteration on z-slabs over {world} ranks (every rank holds every set): slab CG (halo plane per "
+                                        "product, all-reduced dot partials), one halo plane of x per neighbour, threshold searches with all-reduced "
+                                        "probe sums and all-gathered bracket, one all-reduce of the per-set sums; no N-vector exchange") if slab else
+                                       (f"sets sharded over {world} ranks (set i on rank i mod {world}); x-step on z-slabs: reduce-scatter(rhs) -> "
+                                        "slab CG (halo plane per product, all-reduced dot partials) -> all-gather(x)")) if world > 1 else "single GPU",
                        "cg_iterations_in_timed_steps": cg_its, "all_logs_finite": finite,
                        "driver": "native loop (sipx_parsdmm_begin/_steps)" + (", collectives inside the engine (RCCL)" if dist is not None else "")},
             "roofline": {"bound": "hbm", "kernel": "k_cds<MODE=1> (cds_spmv + p.Ap partials)" if args.q_mode == "cds" else
@@ -314,10 +327,10 @@ def main():
         "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
         "config": r["config"], "roofline": r["roofline"], "iteration_roofline": r["iteration_roofline"],
     }
-    if world == 1 and args.config == "c3" and args.dtype == "f32" and not args.no_512:
+    if args.config == "c3" and args.dtype == "f32" and not args.no_512:
         # the honest HBM point (Q = 3.5 GiB, nothing fits the 256 MiB Infinity Cache): a short run of the same sets at 512^3
         r5 = measure("c3-512", 10, 5)
-        out["c3_512"] = {"value": r5["value"], "unit": "it/s", "ms_per_step": r5["ms_per_step"], "steps": 10, "warmup": 5,
+        out["c3_512"] = {"value": r5["value"], "unit": "it/s", "ms_per_step": r5["ms_per_step"], "steps": 10, "warmup": 5, "n_gpus": world,
                          "config": r5["config"], "roofline": r5["roofline"], "iteration_roofline": r5["iteration_roofline"]}
     if args.config == "c3" and args.dtype == "f32" and args.q_mode == "cds" and not args.no_c4:
         # BASELINE configs[3]: 512^3, the eight constraint sets + distance term, at every N (the scaling target of the

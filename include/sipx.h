@@ -245,6 +245,18 @@ int sipx_set_owned(sipx_ctx* ctx, const int32_t* owned);
  * sipx_set_comm_rccl: collectives by RCCL on the engine's own streams.  id128 = the 128-byte ncclUniqueId that rank 0
  * obtained from sipx_rccl_unique_id and the host side handed to every rank (torch.distributed store, MPI, a file ...). */
 int sipx_rccl_unique_id(void* id128);
+/* sipx_set_decomp (before sipx_finalize, with a communicator attached): how the ranks divide the work.
+ *   SIPX_DECOMP_SETS (default): by constraint set, as described above -- the reference's own split.
+ *   SIPX_DECOMP_SLAB: by z-slab of the grid, for the WHOLE iteration: every rank holds every set and works on its planes of
+ *     the (globally indexed) arrays.  No N-vector crosses the fabric: the right-hand side needs no reduction, x no all-gather
+ *     (one halo plane to each neighbour instead), the threshold searches all-reduce their 19 probe sums and all-gather the few
+ *     magnitudes inside the final bracket, and every per-set sum goes through the one all-reduce of sipx_update_y_l.  For
+ *     sets whose projector only needs sums over the grid: bounds, l1 / l2 ball, annulus, prox_l1 on the identity or on
+ *     D_x / D_y / D_z / TV (sipx_finalize refuses others).  sipx_set_owned is ignored; sipx_download is then a collective
+ *     (every rank calls it: it gathers the slabs of x, y_i, l_i). */
+#define SIPX_DECOMP_SETS 0
+#define SIPX_DECOMP_SLAB 1
+int sipx_set_decomp(sipx_ctx* ctx, int mode);
 int sipx_set_comm_rccl(sipx_ctx* ctx, const void* id128, int world, int rank);
 /* sipx_set_comm: the same operations supplied by the caller.  Each callback enqueues its operation on `stream`
  * (a hipStream_t; or completes it before returning) and returns 0 on success; dtype is SIPX_F32 / SIPX_F64; all buffers are

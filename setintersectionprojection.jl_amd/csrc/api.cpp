@@ -130,6 +130,7 @@ int sipx_set_comm(sipx_ctx* c, const sipx_comm* comm) {
 }
 int sipx_slab(sipx_ctx* c, int64_t* row0, int64_t* row1, int64_t* chunk) { SIPX_TRY(c->e->slab(row0, row1, chunk)) }
 int sipx_set_q_mode(sipx_ctx* c, int mode) { SIPX_TRY(c->e->set_q_mode(mode)) }
+int sipx_set_decomp(sipx_ctx* c, int mode) { SIPX_TRY(c->e->set_decomp(mode)) }
 int sipx_apply_Q(sipx_ctx* c, const void* x, void* y) { SIPX_TRY(c->e->apply_Q(x, y)) }
 
 }  // extern "C"

@@ -179,7 +179,7 @@ class Engine : public EngineBase {
     for (auto& s : sets_) free_set(s);
     for (void* p : {(void*)w_base_, (void*)x_base_, (void*)xold_, (void*)rhs_, (void*)m_base_, (void*)r_, (void*)p_base_, (void*)Ap_, (void*)Q_,
                     (void*)scr_v_, (void*)scr_c_, (void*)scr_i_, (void*)scr_w_, (void*)part_cg_, (void*)part_tmp_, (void*)part_sets_,
-                    (void*)maxpart_, (void*)cg_dev_, (void*)dres_})
+                    (void*)maxpart_, (void*)cg_dev_, (void*)dres_, (void*)gbuf_, (void*)stage_})
       dfree(p);
     comm_.reset();
     if (cstream_) (void)hipStreamDestroy(cstream_);
@@ -232,6 +232,12 @@ class Engine : public EngineBase {
   void set_owned(const int32_t* owned) override {
     if (finalized_) throw std::runtime_error("sipx_set_owned must precede sipx_finalize");
     owned_.assign(owned, owned + sets_.size() + 1);
+  }
+
+  void set_decomp(int mode) override {
+    if (finalized_) throw std::runtime_error("sipx_set_decomp must precede sipx_finalize");
+    if (mode != SIPX_DECOMP_SETS && mode != SIPX_DECOMP_SLAB) throw std::runtime_error("unknown decomposition");
+    slab_req_ = mode == SIPX_DECOMP_SLAB;
   }
 
   void set_comm(Comm* c) override {
@@ -294,6 +300,20 @@ class Engine : public EngineBase {
     }
     if (!owned_.empty())
       for (int i = 0; i < p_n_; ++i) sets_[i].owned = owned_[i] != 0;
+    // Slab decomposition of the WHOLE iteration (sipx_set_decomp): every rank holds every set and works on its z-slab of the
+    // globally indexed arrays; no N-vector crosses the fabric any more.  For the sets whose projector needs no
+    // more than sums over the grid: element-wise ones, l1 / l2 balls and the annulus on the identity or D_x / D_y / D_z / TV.
+    slab_ = slab_req_ && comm_ != nullptr;
+    if (slab_) {
+      if (mk_ || stencil_q_) throw std::runtime_error("the slab decomposition is not available for Minkowski contexts or the stencil form of Q");
+      for (int i = 0; i < p_n_; ++i) {
+        const SetState<T>& s = sets_[i];
+        if (s.custom || s.ext_kind || s.prox == PX_CARD)
+          throw std::runtime_error("the slab decomposition needs sets whose projector works on sums over the grid (set " + std::to_string(i) + " does not): use the set decomposition");
+        sets_[i].owned = true;
+      }
+      set_streams_ = false;        // one stream: the collectives inside the threshold searches are issued in one order on every rank
+    }
     const long long N = G_.N;
     // rho, gamma (PARSDMM_initialize.jl:58-63,107-114,159)
     rho_.resize(p_n_);
@@ -338,6 +358,15 @@ class Engine : public EngineBase {
     } else {
       qr0_ = 0; qr1_ = N;
     }
+    Gr_ = G_;
+    Gyl_ = G_;
+    if (slab_) {
+      Gr_.e0 = r0_; Gr_.e1 = r1_;
+      // k_yl recomputes the last plane of the rank below (y, l of a difference along the slab direction are read one plane
+      // back by the adjoint stencils): bit for bit what that rank computes, instead of an exchange of y, l and y - y_old
+      Gyl_.e0 = (prev_ >= 0) ? r0_ - plane_ : r0_; Gyl_.e1 = r1_; Gyl_.s0 = r0_;
+      if (r1_ <= r0_) { Gr_.e0 = Gr_.e1 = 0; Gyl_.e0 = Gyl_.e1 = 0; }
+    }
     x_base_ = dalloc<T>(Npad + 2 * halo_); x_ = x_base_ + halo_;
     p_base_ = dalloc<T>(Nx_ + 2 * halo_); p_ = p_base_ + halo_;
     xold_ = dalloc<T>(Nx_); rhs_ = dalloc<T>(Npad);
@@ -360,6 +389,22 @@ class Engine : public EngineBase {
         need_ext_ = true;
         maxpad = std::max(maxpad, Npad);            // v travels through the padded exchange layout of x
       }
+    }
+    if (slab_) {
+      maxpad = std::max(maxpad, Npad);              // slabs of y, l are gathered through the padded exchange layout at download
+      hooks_.world = comm_->world; hooks_.rank = comm_->rank; hooks_.user = comm_.get();
+      hooks_.allreduce_sum = [](void* u, double* buf, size_t n, hipStream_t q) { static_cast<Comm*>(u)->allreduce_sum(buf, n, SIPX_F64, q); };
+      hooks_.allgather = [](void* u, void* buf, size_t chunk, int f64, hipStream_t q) {
+        static_cast<Comm*>(u)->allgather(buf, chunk, f64 ? SIPX_F64 : SIPX_F32, q);
+      };
+      hooks_.gcap = std::min<long long>(1ll << 18, (maxpad + 3) / 4 * 4);
+      int n2 = 0, nl1 = 0;
+      for (auto& s : sets_) { n2 += s.two_pass ? 1 : 0; nl1 += (s.two_pass && s.prox == PX_L1) ? 1 : 0; }
+      // the searches of all sets run in lock step: one staging buffer for their sums (one all-reduce per stage), one exchange
+      // buffer with a segment per l1 set and rank (one all-gather)
+      gbuf_ = dalloc<T>((size_t)comm_->world * std::max(nl1, 1) * (hooks_.gcap + GATHER_HDR));
+      hooks_.gbuf = gbuf_;
+      stage_ = dalloc<double>((size_t)std::max(n2, 1) * (PREP_SLOTS + 1 + 2 * comm_->world));
     }
     scr_v_ = dalloc<T>(maxpad);
     scr_c_ = dalloc<T>(maxpad);
@@ -440,6 +485,11 @@ class Engine : public EngineBase {
         K<T>::ps_init(stream_, s.ps, scr_i_);
         K<T>::ps_init(stream_, s.psf, scr_i_);
       }
+      if (slab_ && s.two_pass) {        // searches in lock step: every set keeps its own partial slots and gather buffer
+        s.ptmp = dalloc<double>((size_t)(PREP_SLOTS + 2) * NB);
+        s.mpart = dalloc<T>(2 * NB);
+        s.cbuf = dalloc<T>(s.Mpad);
+      }
       if (set_streams_ && !s.ext_kind && s.prox != PX_CARD) {     // those two share the engine-wide scratch: main stream
         if ((int)pool_.size() < n_set_streams_) {
           // the engine stream itself is the first of the set streams: the set dealt onto it starts right behind the x-step,
@@ -478,6 +528,7 @@ class Engine : public EngineBase {
         continue;
       }
       if (!s.owned) continue;
+      if (slab_ && !s.two_pass && comm_->rank != 0) continue;      // an element-wise set: rank 0 takes the whole grid (one-off)
       double* dst = part_sets_ + ((size_t)i * SLOTS + SL_FE2) * NB;
       // Minkowski: TD_OP[i] * [m; 0] = A m for components 1 and 3, A 0 = 0 for component 2 (w_ is still all zero here)
       const T* mm = s.comp == 2 ? w_ : m_;
@@ -498,8 +549,8 @@ class Engine : public EngineBase {
       } else if (s.two_pass) {
         SetArgs<T> a = set_args(s, rho_[i], gamma_[i], 0);
         a.x = mm;                                              // s = A m produced on the fly
-        K<T>::proj_scalars_set(stream_, G_, a, 1, s.psf, part_tmp_, maxpart_, scr_c_, s.Mtrue);
-        K<T>::proj_dist_set(stream_, G_, a, 1, s.psf, dst);
+        K<T>::proj_scalars_set(stream_, Gr_, a, 1, s.psf, part_tmp_, maxpart_, scr_c_, s.Mtrue, SampleCtl(), hooks());
+        K<T>::proj_dist_set(stream_, Gr_, a, 1, s.psf, dst);
       } else {
         K<T>::fwd(stream_, G_, s.nblk, s.dir, s.ih, mm, scr_v_);
         proj_dist_grid<T>(stream_, G_, s.nblk, s.dir, s.Mpad, scr_v_, s.prox, s.plo, s.phi, s.lb, s.ub, nullptr, dst);
@@ -556,17 +607,17 @@ class Engine : public EngineBase {
       r.y = s.y; r.l = s.l; r.rho = (T)rho[i]; r.nblk = s.nblk;
       for (int q = 0; q < 3; ++q) { r.dir[q] = s.dir[q]; r.ih[q] = s.ih[q]; }
       if (a.nsets == MAX_SETS) {
-        K<T>::rhs_compose(stream_, G_, a, rhs_, launched++ > 0);
+        K<T>::rhs_compose(stream_, Gr_, a, rhs_, launched++ > 0);
         a.nsets = 0;
       }
     }
-    if (a.nsets > 0 || launched == 0) K<T>::rhs_compose(stream_, G_, a, rhs_, launched > 0);
+    if (a.nsets > 0 || launched == 0) K<T>::rhs_compose(stream_, Gr_, a, rhs_, launched > 0);
     for (int i = 0; i < p_n_; ++i) {       // caller-supplied sparse operators: rhs += A_i'(rho_i y_i + l_i), one launch each
       const SetState<T>& s = sets_[i];
       if (s.owned && s.custom)
         K<T>::csc_adj_rhs(stream_, G_.N, s.d_colptr, s.d_rowval, s.d_nzval, s.y, s.l, (T)rho[i], rhs_, 1);
     }
-    if (comm_) {
+    if (comm_ && !slab_) {
       // the (+) reduction of the partial right-hand sides (rhs_compose.jl:17-20), delivered by z-slab: every rank receives
       // the rows its part of the x-step needs.  It runs on the communication stream; whatever the engine stream is given
       // next (the Q update, the log-only kernels of the previous y/l update) overlaps with it, argmin_x joins.
@@ -643,7 +694,10 @@ class Engine : public EngineBase {
     if (comm_) {
       // obj / evol_x sums over the slab (x_old is only kept for the slab), then x is completed on every rank
       K<T>::log3(stream_, nloc, x_ + r0, m_ + r0, xold_ + r0, part_sets_ + (size_t)p_n_ * SLOTS * NB);
-      comm_->allgather(x_, (size_t)chunk_, dt, stream_);
+      if (slab_)       // the planes of x next to the slab: forward differences read one plane up, the recomputed plane below needs one down
+        comm_->halo_exchange(x_ + r0, x_ + r0 - plane_, prev_, x_ + r1 - plane_, x_ + r1, next_, (size_t)plane_, dt, stream_);
+      else
+        comm_->allgather(x_, (size_t)chunk_, dt, stream_);
     }
     *tol_ref_io = (double)cg_host_->tol_ref;
     *cg_it = cg_host_->iters;
@@ -657,6 +711,40 @@ class Engine : public EngineBase {
     (void)it;
     if (mk_) K<T>::sum_uv(stream_, G_.N, x_, x_ + G_.N, w_);
     if (set_streams_) SIPX_HIP(hipEventRecord(ev_fork_, stream_));     // x (and u + v) are final: the sets may start
+    if (slab_) {
+      // Slab-decomposed iteration: the threshold / scale searches of ALL sets in lock step -- every rank sweeps its planes,
+      // ONE all-reduce makes the probe sums of all sets global (twice: first pass, gated refinement), ONE all-gather strings
+      // the gathered magnitudes of all l1 sets together; every rank then solves the same small problems (same bits).
+      std::vector<int> tp;
+      for (int i = 0; i < p_n_; ++i)
+        if (sets_[i].two_pass) tp.push_back(i);
+      if (!tp.empty()) {
+        const size_t RS = (size_t)(PREP_SLOTS + 1 + 2 * comm_->world);
+        const long long seg = hooks_.gcap + GATHER_HDR;
+        int nl1 = 0;
+        for (int i : tp) nl1 += sets_[i].prox == PX_L1 ? 1 : 0;
+        const long long chunk = (long long)std::max(nl1, 1) * seg;
+        std::vector<SetArgs<T>> args(tp.size());
+        std::vector<T*> gseg(tp.size(), nullptr);
+        int k1 = 0;
+        for (size_t j = 0; j < tp.size(); ++j) {
+          SetState<T>& s = sets_[tp[j]];
+          args[j] = set_args(s, (T)rho[tp[j]], (T)gamma[tp[j]], flags);
+          if (s.prox == PX_L1) gseg[j] = gbuf_ + (long long)(k1++) * seg;
+          if (s.prox == PX_L1 && s.last_rho > T(0) && s.last_rho != args[j].rho)      // v rescaled: theta moves like 1/rho
+            K<T>::ps_rescale(stream_, s.ps, (double)s.last_rho / (double)args[j].rho);
+        }
+        for (int stage = 0; stage < 4; ++stage) {
+          for (size_t j = 0; j < tp.size(); ++j) {
+            SetState<T>& s = sets_[tp[j]];
+            K<T>::proj_scalars_stage(stage, stream_, Gr_, args[j], 0, s.ps, s.ptmp, s.mpart, s.cbuf, s.Mtrue, SampleCtl(), &hooks_,
+                                     stage_ + j * RS, gseg[j], chunk);
+          }
+          if (stage < 2 && (stage == 0 || nl1 > 0)) comm_->allreduce_sum(stage_, tp.size() * RS, SIPX_F64, stream_);
+          if (stage == 2 && nl1 > 0) comm_->allgather(gbuf_, (size_t)chunk, dtype_code(), stream_);
+        }
+      }
+    }
     for (int i = 0; i < p_n_; ++i) {
       SetState<T>& s = sets_[i];
       if (!s.owned || s.dist_ext) continue;
@@ -676,7 +764,8 @@ class Engine : public EngineBase {
       else to_other = s.snap == 0;                        // the zero-filled other pair stands in for it, as before
       a.yo = to_other ? s.y0 : s.y;
       a.lo = to_other ? s.l0 : s.l;
-      const Grid& gs = s.custom ? s.gm : G_;
+      const Grid& gs = s.custom ? s.gm : Gr_;          // (the rank's slab when the whole iteration is slab-decomposed)
+      const Grid& gy = s.custom ? s.gm : Gyl_;
       if (s.custom) {     // s = A x once, then the identity-shaped kernels on the M entries of s
         K<T>::csr_spmv(q, s.Mtrue, s.d_rowptr, s.d_colidx, s.d_rval, a.x, s.sbuf);
         a.x = s.sbuf;
@@ -687,7 +776,10 @@ class Engine : public EngineBase {
         s.ext->project(scr_v_, false, ptmp, mpart, cbuf);
         a.vsrc = 2;
       }
-      if (s.two_pass) {   // threshold / scale of prox_i from one pass that produces v on the fly (nothing stored)
+      if (s.two_pass && slab_) {          // (searched above, in lock step with the other sets)
+        s.last_rho = a.rho;
+        s.last_gamma = a.gamma;
+      } else if (s.two_pass) {   // threshold / scale of prox_i from one pass that produces v on the fly (nothing stored)
         SetArgs<T> ap = a;
         const bool rescaled = a.prox == PX_L1 && s.last_rho > T(0) && s.last_rho != a.rho;
         if (rescaled)                                                               // v rescaled: theta moves like 1/rho
@@ -698,18 +790,18 @@ class Engine : public EngineBase {
         SampleCtl ctl;
         ctl.host_want = (int*)hlean_ + i;
         ctl.runs = l1_sample_runs_;
-        ctl.enable = l1_sample_ && a.prox == PX_L1 && !s.custom && (rescaled || hlean_[i] != 0);
-        K<T>::proj_scalars_set(q, gs, ap, 0, s.ps, ptmp, mpart, cbuf, s.Mtrue, ctl);
+        ctl.enable = l1_sample_ && !slab_ && a.prox == PX_L1 && !s.custom && (rescaled || hlean_[i] != 0);
+        K<T>::proj_scalars_set(q, gs, ap, 0, s.ps, ptmp, mpart, cbuf, s.Mtrue, ctl, hooks());
         s.last_rho = a.rho;
         s.last_gamma = a.gamma;
       }
-      K<T>::yl(q, gs, a, part);
+      K<T>::yl(q, gy, a, part);
       if (s.custom) K<T>::csc_adj_norm(q, G_.N, s.d_colptr, s.d_rowval, s.d_nzval, s.dy, part + (size_t)SL_ADJ * NB);
-      else if (!s.ident) K<T>::adj_norm(q, G_, a, part + (size_t)SL_ADJ * NB);
+      else if (!s.ident) K<T>::adj_norm(q, gs, a, part + (size_t)SL_ADJ * NB);
       if ((flags & SIPX_YL_FEAS) && s.ext_kind && i < pp_n_) ext_feasibility(s, a, part + (size_t)SL_FE2 * NB);
       if ((flags & SIPX_YL_FEAS) && s.two_pass && i < pp_n_) {
         // ||P_i(s) - s|| with s = A_i x produced on the fly; its own warm-started scalars (psf)
-        K<T>::proj_scalars_set(q, gs, a, 1, s.psf, ptmp, mpart, cbuf, s.Mtrue);
+        K<T>::proj_scalars_set(q, gs, a, 1, s.psf, ptmp, mpart, cbuf, s.Mtrue, SampleCtl(), hooks());
         K<T>::proj_dist_set(q, gs, a, 1, s.psf, part + (size_t)SL_FE2 * NB);
       }
       if (to_other) { std::swap(s.y, s.y0); std::swap(s.l, s.l0); }     // (y, l) always names the current iterate
@@ -935,6 +1027,22 @@ class Engine : public EngineBase {
 
   void download(void* x, void* const* l, void* const* y) override {
     need_final();
+    if (slab_) {       // every rank holds its planes only: complete x and the requested y, l (a collective: every rank calls it)
+      const int dt = dtype_code();
+      if (x) comm_->allgather(x_, (size_t)chunk_, dt, stream_);
+      for (int i = 0; i < p_n_; ++i)
+        for (int which = 0; which < 2; ++which) {
+          if (!((which ? y : l) && (which ? y : l)[i])) continue;
+          T* arr = which ? sets_[i].y : sets_[i].l;
+          const int nb = sets_[i].nblk > 0 ? sets_[i].nblk : 1;
+          for (int q = 0; q < nb; ++q) {
+            T* blk = arr + (long long)q * G_.N;
+            if (r1_ > r0_) SIPX_HIP(hipMemcpyAsync(scr_v_ + r0_, blk + r0_, (r1_ - r0_) * sizeof(T), hipMemcpyDeviceToDevice, stream_));
+            comm_->allgather(scr_v_, (size_t)chunk_, dt, stream_);
+            SIPX_HIP(hipMemcpyAsync(blk, scr_v_, G_.N * sizeof(T), hipMemcpyDeviceToDevice, stream_));
+          }
+        }
+    }
     SIPX_HIP(hipStreamSynchronize(stream_));
     if (x) SIPX_HIP(hipMemcpy(x, x_, Nx_ * sizeof(T), hipMemcpyDeviceToHost));
     for (int i = 0; i < p_n_; ++i) {
@@ -1927,6 +2035,14 @@ class Engine : public EngineBase {
   int sums_flags_ = 0;
   volatile unsigned long long* ticket_ = nullptr;   // pinned: verdict of the latest CG iteration (publish_ticket)
   unsigned cg_seq_ = 0;
+  // slab decomposition of the whole iteration (sipx_set_decomp): the grids the set kernels are launched on, the collectives
+  // of the threshold searches, the exchange buffer of their gathered magnitudes
+  bool slab_req_ = false, slab_ = false;
+  Grid Gr_, Gyl_;
+  ChainHooks hooks_;
+  T* gbuf_ = nullptr;
+  double* stage_ = nullptr;
+  const ChainHooks* hooks() const { return slab_ ? &hooks_ : nullptr; }
   double obj_ss_ = 0, evo_ss_ = 0, xx_ss_ = 0;
   bool have_log_sums_ = false;
   hipEvent_t cg_ev_[2] = {nullptr, nullptr};

@@ -45,6 +45,7 @@ struct EngineBase {
   virtual void get_rhs(void* out) = 0;
   virtual void set_owned(const int32_t* owned) = 0;
   virtual void set_q_mode(int mode) = 0;
+  virtual void set_decomp(int mode) = 0;
   virtual void set_comm(Comm* c) = 0;       // takes ownership
   virtual void bind_device() = 0;           // makes the context's GPU the calling thread's current device
   virtual void slab(int64_t* row0, int64_t* row1, int64_t* chunk) = 0;

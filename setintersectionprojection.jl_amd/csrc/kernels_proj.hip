@@ -162,10 +162,11 @@ __global__ __launch_bounds__(BLOCK) void k_pass(Grid G, SetArgs<T> a, int v_is_s
     const int nb = ident ? 1 : a.nblk;
     const bool relax = !(a.gamma == T(1));
     const T gam = a.gamma, omg = T(1) - a.gamma;
-    const long long nvec = G.N / V;
-    const long long nit = (nvec + (long long)gridDim.x * BLOCK - 1) / ((long long)gridDim.x * BLOCK);
+    long long v0, nvec;                      // this launch's share of the grid (all of it unless slab-decomposed)
+    vec_range<V>(G, v0, nvec);
+    const long long nit = (nvec - v0 + (long long)gridDim.x * BLOCK - 1) / ((long long)gridDim.x * BLOCK);
     for (long long it = 0; it < nit; ++it) {
-      const long long vi = it * (long long)gridDim.x * BLOCK + (long long)blockIdx.x * BLOCK + threadIdx.x;
+      const long long vi = v0 + it * (long long)gridDim.x * BLOCK + (long long)blockIdx.x * BLOCK + threadIdx.x;
       const bool live = vi < nvec;
       const long long g = live ? vi * V : 0;
       const Coord c = coords(G, g);
@@ -260,6 +261,9 @@ __global__ void k_ps_init(ProjScalars<T>* ps, long long* cidx) {
   for (int j = 0; j < SAMPLE_BINS; ++j) ps->hist[j] = 0;
   ps->sampled = ps->dbg_sampled = ps->want_sample = 0;
   ps->samp_ticket = 0;
+  ps->gather_overflow = 0;
+  ps->ovf = 0;
+  for (int r = 0; r < 2 * SIPX_MAX_WORLD; ++r) ps->mm[r] = 0;
   ps->rescaled = 0;
   ps->resc_bad = 1;
   ps->samp_theta = 0;
@@ -316,11 +320,16 @@ __device__ __forceinline__ void reduce_slots(const double* __restrict__ partials
 // every load of a slot is in flight at once.
 template <typename T, int STAGE>
 __global__ __launch_bounds__(BLOCK) void k_slot_sums(const double* __restrict__ partials, const T* __restrict__ maxpart,
-                                                     ProjScalars<T>* ps) {
-  if (STAGE == 1 && !(ps->need && !ps->spec_ok && ps->refine)) return;
+                                                     ProjScalars<T>* ps, int rank, int world, double* __restrict__ reg) {
+  // reg: PREP_SLOTS sums | ovf | (max, min) per rank -- ps->red / ovf / mm themselves, or this set's region of the staging
+  // buffer that one all-reduce makes global for all sets of a slab-decomposed iteration
+  if (STAGE == 1 && !(ps->need && !ps->spec_ok && ps->refine)) {
+    // (slab-decomposed: the all-reduce that follows runs regardless; it then sums stale values nobody reads)
+    return;
+  }
   if (blockIdx.x < PREP_SLOTS) {
     const double v = block_sum_partials(partials + (long long)blockIdx.x * NB);
-    if (threadIdx.x == 0) ps->red[blockIdx.x] = v;
+    if (threadIdx.x == 0) reg[blockIdx.x] = v;
     return;
   }
   __shared__ T smax[BLOCK / 64], smin[BLOCK / 64];
@@ -336,8 +345,11 @@ __global__ __launch_bounds__(BLOCK) void k_slot_sums(const double* __restrict__ 
   __syncthreads();
   if (threadIdx.x == 0) {
     for (int i = 0; i < BLOCK / 64; ++i) { vmax = smax[i] > vmax ? smax[i] : vmax; vmin = smin[i] < vmin ? smin[i] : vmin; }
-    ps->rmax = vmax;
-    ps->rmin = vmin;
+    double* mm = reg + PREP_SLOTS + 1;
+    for (int r = 0; r < 2 * world; ++r) mm[r] = 0.0;
+    mm[2 * rank] = (double)vmax;
+    mm[2 * rank + 1] = (vmin < (T)INFINITY) ? (double)vmin : 0.0;     // 0 = this rank saw no non-zero magnitude
+    reg[PREP_SLOTS] = ps->spec_overflow ? 1.0 : 0.0;
   }
 }
 
@@ -345,14 +357,19 @@ __global__ __launch_bounds__(BLOCK) void k_slot_sums(const double* __restrict__ 
 // STAGE 1: after the gated refinement.
 template <typename T, int STAGE>
 __global__ __launch_bounds__(64) void k_decide(ProjScalars<T>* ps, int prox, T pmin, T pmax, long long true_len,
-                                               int nospec, double capdiv) {
+                                               int nospec, double capdiv, int world, double cap_max, const double* __restrict__ reg) {
   if (STAGE == 1 && !(ps->need && !ps->spec_ok && ps->refine)) return;
   if (threadIdx.x != 0) return;
-  const double* red = ps->red;
+  const double* red = reg;
   T vmax = T(0), vmin = (T)INFINITY;
   if (STAGE == 0) {
-    vmax = ps->rmax;
-    vmin = ps->rmin;
+    const double* mm = reg + PREP_SLOTS + 1;
+    for (int r = 0; r < world; ++r) {              // (one rank unless slab-decomposed: then red, ovf, mm are all-reduced sums)
+      const T mx = (T)mm[2 * r], mn = (T)mm[2 * r + 1];
+      vmax = mx > vmax ? mx : vmax;
+      vmin = (mn > T(0) && mn < vmin) ? mn : vmin;
+    }
+    ps->spec_overflow = reg[PREP_SLOTS] > 0 ? 1 : 0;
     ps->vmin = vmin;
     ps->asum = red[0];
     ps->sumsq = red[1];
@@ -396,7 +413,7 @@ __global__ __launch_bounds__(64) void k_decide(ProjScalars<T>* ps, int prox, T p
       const double S3 = red[3 + L1_WIN_LO], C3 = red[3 + L1_K + L1_WIN_LO], S4 = red[3 + L1_WIN_HI], C4 = red[3 + L1_K + L1_WIN_HI];
       const double f3 = S3 - t3 * C3 - b, f4 = S4 - t4 * C4 - b;
       ps->lean = 0;
-      if (f3 >= 0 && f4 < 0 && !ps->spec_overflow && !nospec) {
+      if (f3 >= 0 && f4 < 0 && !ps->spec_overflow && !nospec && !(cap_max > 0 && C3 - C4 > cap_max)) {
         double thN = C3 > 0 ? (S3 - b) / C3 : t3;
         if (!(thN >= t3)) thN = t3;
         double thS = t3 + f3 * (t4 - t3) / (f3 - f4);
@@ -462,7 +479,9 @@ __global__ __launch_bounds__(64) void k_decide(ProjScalars<T>* ps, int prox, T p
   ps->hi = hi;
   if (STAGE == 0) {
     // speculative gather usable?  range edges are probes L1_WIN_LO and L1_WIN_HI, so (S,C) above it are known
-    const bool spec = !nospec && ps->spec_hi > ps->spec_lo && !ps->spec_overflow && lo >= ps->spec_lo && hi <= ps->spec_hi;
+    // (slab-decomposed: what the range gathered over all ranks, C(spec_lo) - C(spec_hi), has to fit a rank's exchange segment)
+    const bool spec = !nospec && ps->spec_hi > ps->spec_lo && !ps->spec_overflow && lo >= ps->spec_lo && hi <= ps->spec_hi &&
+                      !(cap_max > 0 && red[3 + L1_K + L1_WIN_LO] - red[3 + L1_K + L1_WIN_HI] > cap_max);
     if (spec) {
       ps->spec_ok = 1;
       ps->s_above = red[3 + L1_WIN_HI];
@@ -475,7 +494,8 @@ __global__ __launch_bounds__(64) void k_decide(ProjScalars<T>* ps, int prox, T p
   // (each gated refinement pass narrows it by >= L1_K-1 and by the Newton/secant step on top)
   // one more probe pass costs a full sweep of the vector, gathering a larger bracket costs the one-workgroup solve a
   // longer scan: the break-even population grows with the length (measured at 256^3 and 512^3)
-  const double cap = fmax(L1_CAP, (double)true_len / capdiv);
+  double cap = fmax(L1_CAP, (double)true_len / capdiv);
+  if (cap_max > 0 && cap > cap_max) cap = cap_max;
   // population of the tightened bracket (lo, hi]: the count between the two probes, scaled by the share of the interval
   // that is left (factor 2 for a density that is not flat).  A wrong guess only costs time: the gather never drops.
   double pop = Cl - Ch;
@@ -703,7 +723,8 @@ __global__ __launch_bounds__(SAMPLE_NT) void k_sample(Grid G, SetArgs<T> a, Proj
   const int nb = ident ? 1 : a.nblk;
   const bool relax = !(a.gamma == T(1));
   const T gam = a.gamma, omg = T(1) - a.gamma;
-  const long long nvec = G.N / V;
+  long long v0, nvec;
+  vec_range<V>(G, v0, nvec);
   // sampled run u of SAMPLE_RUN lanes -> run u * stride + hash(u) mod stride of the vector (one out of every `stride` runs,
   // chosen by a hash so that no lattice direction of the grid is favoured)
   const long long total = nsamp * SAMPLE_RUN;      // lanes to process
@@ -712,7 +733,7 @@ __global__ __launch_bounds__(SAMPLE_NT) void k_sample(Grid G, SetArgs<T> a, Proj
     const long long u = t / SAMPLE_RUN;
     long long ru = u * stride + (long long)((unsigned int)(((unsigned long long)u * 2654435761ull) >> 13) % stride);
     if (ru >= nchunks) ru = u * stride;
-    const long long vi = t < total ? ru * SAMPLE_RUN + (t % SAMPLE_RUN) : nvec;
+    const long long vi = t < total ? v0 + ru * SAMPLE_RUN + (t % SAMPLE_RUN) : nvec;
     const bool live = vi < nvec;
     const long long g = live ? vi * V : 0;
     const Coord cd = coords(G, g);
@@ -961,6 +982,7 @@ __global__ __launch_bounds__(SIPX_SOLVE_NT) void k_l1_solve(ProjScalars<T>* ps, 
       if (sh_ca >= (double)true_len && true_len > 1) theta = (ps->asum - (double)ps->vmin - (double)radius) / (double)(true_len - 1);
       const T th = (T)theta;
       ps->theta = th > T(0) ? th : T(0);       // theta = max(0, .)   project_l1_Duchi!.jl:46
+      if (ps->gather_overflow) ps->theta = (T)NAN;     // slab-decomposed: a rank's share did not fit its exchange segment
     }
     ps->dbg[0] = (double)ps->n_compact; ps->dbg[1] = ps->spec_overflow; ps->dbg[2] = ps->spec_ok;
     ps->dbg[3] = (coop && ps->dbg[3] < 0) ? -1.0 : (double)iters_done;       // -1: a cooperative sweep was abandoned
@@ -1121,6 +1143,64 @@ __global__ __launch_bounds__(1024) void k_card_select(ProjScalars<T>* ps, long l
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Slab-decomposed grid: every rank has gathered the magnitudes of ITS planes that fall into the bracket.  k_gather_pack puts
+// them, behind a header (count, and the rank's (S, C) above the bracket from the fallback compaction), into the rank's
+// segment of the exchange buffer; after the all-gather k_gather_unpack strings the segments together in `compact` again, in
+// rank order, adds up the headers and leaves everything as k_l1_solve expects it from a single rank -- every rank then solves
+// the same problem and arrives at the same theta, bit for bit (the sum of the gathered values is order-independent).
+template <typename T>
+__global__ __launch_bounds__(BLOCK) void k_gather_pack(ProjScalars<T>* ps, const T* __restrict__ compact,
+                                                       const double* __restrict__ partials, T* __restrict__ seg, long long gcap) {
+  const bool active = ps->need != 0;
+  const long long n = active ? (long long)ps->n_compact : 0;
+  if (blockIdx.x == 0) {
+    double sa = 0, ca = 0;
+    if (active && !ps->spec_ok) {               // block partials of the compaction pass of this rank
+      sa = block_sum_partials(partials + (long long)SL_ABOVE_S * NB);
+      ca = block_sum_partials(partials + (long long)SL_ABOVE_C * NB);
+    }
+    if (threadIdx.x == 0) {
+      double* h = reinterpret_cast<double*>(seg);
+      h[0] = n <= gcap ? (double)n : -1.0;      // -1: more than the segment holds
+      h[1] = sa;
+      h[2] = ca;
+    }
+  }
+  const long long m = n <= gcap ? n : 0;
+  for (long long i = (long long)blockIdx.x * BLOCK + threadIdx.x; i < m; i += (long long)gridDim.x * BLOCK) seg[GATHER_HDR + i] = compact[i];
+}
+
+template <typename T>
+__global__ __launch_bounds__(BLOCK) void k_gather_unpack(ProjScalars<T>* ps, T* __restrict__ compact, double* __restrict__ partials,
+                                                         const T* __restrict__ gseg0, long long chunk, int world, long long compact_len) {
+  // gseg0: this set's segment in rank 0's chunk of the exchange buffer; rank r's is `chunk` elements further per rank
+  long long off = 0;
+  double sa = 0, ca = 0;
+  bool bad = false;
+  for (int r = 0; r < world; ++r) {
+    const double* h = reinterpret_cast<const double*>(gseg0 + (long long)r * chunk);
+    const long long n = (long long)h[0];
+    if (n < 0 || off + n > compact_len) { bad = true; break; }
+    sa += h[1];
+    ca += h[2];
+    const T* v = gseg0 + (long long)r * chunk + GATHER_HDR;
+    for (long long i = (long long)blockIdx.x * BLOCK + threadIdx.x; i < n; i += (long long)gridDim.x * BLOCK) compact[off + i] = v[i];
+    off += n;
+  }
+  if (blockIdx.x == 0) {
+    // (S, C) above the bracket, as the block partials k_l1_solve adds up: the totals in entry 0, zeros behind
+    for (int i = threadIdx.x; i < NB; i += BLOCK) {
+      partials[(long long)SL_ABOVE_S * NB + i] = i == 0 ? sa : 0.0;
+      partials[(long long)SL_ABOVE_C * NB + i] = i == 0 ? ca : 0.0;
+    }
+    if (threadIdx.x == 0) {
+      ps->n_compact = bad ? 0ull : (unsigned long long)off;
+      if (bad) ps->gather_overflow = 1;
+    }
+  }
+}
+
 // v = x_hat - l/rho: where the multiplier term dominates, theta moves like 1/rho when rho is changed.  Re-centre the
 // probes of the coming call on the scaled prediction (and widen the range: the prediction is good to a few percent).
 template <typename T>
@@ -1140,35 +1220,86 @@ void K<T>::ps_rescale(hipStream_t s, ProjScalars<T>* ps, double factor) {
   SIPX_HIP(hipGetLastError());
 }
 
+// One search = four stages; on a slab-decomposed grid a collective sits between consecutive stages (and the engine runs the
+// stages of ALL its sets in lock step, so that ONE all-reduce / all-gather serves them all):
+//   0  [sampled prediction,] first pass (full or lean) + sums of its partial slots            -> all-reduce of the region
+//   1  bracket decision; l1: gated refinement pass + sums                                        -> all-reduce of the region
+//   2  l1: decision, gated compaction pass, the rank's gathered magnitudes into its segment      -> all-gather of the segments
+//   3  l1: segments strung together, solve
+// reg: where the sums go (ps->red itself, or the set's region of the staging buffer); gseg0 / chunk: the set's segment in
+// rank 0's chunk of the exchange buffer and the distance to the next rank's.
 template <typename T, int SRC>
-static void launch_chain(hipStream_t s, const Grid& g, const SetArgs<T>& a, int v_is_s, const T* varr, long long len,
-                         ProjScalars<T>* ps, double* partials, T* maxpart, T* compact, long long true_len,
-                         SampleCtl ctl = SampleCtl()) {
+static void chain_stage(int stage, hipStream_t s, const Grid& g, const SetArgs<T>& a, int v_is_s, const T* varr, long long len,
+                        ProjScalars<T>* ps, double* partials, T* maxpart, T* compact, long long true_len, SampleCtl ctl,
+                        const ChainHooks* hk, long long compact_len, double* reg, T* gseg0, long long chunk) {
+  const int world = hk ? hk->world : 1, rank = hk ? hk->rank : 0;
+  const double cap_max = hk ? 0.5 * (double)hk->gcap : 0.0;
   const bool vec = SRC == 1 && g.n[0] % 4 == 0;
-  if (SRC == 1 && vec && ctl.enable && a.prox == PX_L1 && !v_is_s) {
-    // about a million grid points (times the operator's blocks); not worth it when that is more than a quarter of the vector
-    const long long nchunks = (g.N / 4 + SAMPLE_RUN - 1) / SAMPLE_RUN;          // runs of 64 grid points
-    const long long target = ctl.runs > 0 ? ctl.runs : (g.N >= (1ll << 26) ? 32768 : 16384);   // one or two million sampled points
-    const long long stride = nchunks / target;
-    // (below 2^24 grid points the extra launch costs more than the sweeps it saves: 2048^2 loses 3 %; a test may force it)
-    if (stride >= 4 && (g.N >= (1ll << 24) || ctl.runs > 0)) {
-      const long long nsamp = nchunks / stride;
-      hipLaunchKernelGGL((k_sample<T, 4>), dim3((unsigned)(nsamp < SAMPLE_WG ? nsamp : SAMPLE_WG)), dim3(SAMPLE_NT), 0, s, g, a, ps, partials,
-                         nchunks, nsamp, (unsigned int)stride, true_len, l1_hw_max(), l1_lean_on(),
-                         0.2 * (double)fit_grid(g.N / 4, SIPX_PASS_GRID) * (double)SPEC_CAP);     // a fifth of the LDS buffers of the pass
-    }
-  }
   static const double capdiv = [] { const char* e = getenv("SIPX_L1_CAPDIV"); return e ? atof(e) : 64.0; }();
 #define SIPX_PASS(MODE)                                                                                            \
   do {                                                                                                             \
     if (vec)                                                                                                       \
-      hipLaunchKernelGGL((k_pass<T, 4, MODE, SRC>), dim3(fit_grid(g.N / 4, SIPX_PASS_GRID)), dim3(BLOCK), 0, s, g, a, v_is_s, varr, len, ps, compact, \
+      hipLaunchKernelGGL((k_pass<T, 4, MODE, SRC>), dim3(fit_grid(range_len(g) / 4, SIPX_PASS_GRID)), dim3(BLOCK), 0, s, g, a, v_is_s, varr, len, ps, compact, \
                          partials, maxpart);                                                                       \
     else                                                                                                           \
-      hipLaunchKernelGGL((k_pass<T, 1, MODE, SRC>), dim3(fit_grid(SRC == 0 ? len : g.N, SIPX_PASS_GRID)), dim3(BLOCK), 0, s, g, a, v_is_s, varr, len, ps, compact, \
+      hipLaunchKernelGGL((k_pass<T, 1, MODE, SRC>), dim3(fit_grid(SRC == 0 ? len : range_len(g), SIPX_PASS_GRID)), dim3(BLOCK), 0, s, g, a, v_is_s, varr, len, ps, compact, \
                          partials, maxpart);                                                                       \
   } while (0)
+  if (stage == 0) {
+    if (SRC == 1 && vec && ctl.enable && a.prox == PX_L1 && !v_is_s) {
+      // about a million grid points (times the operator's blocks); not worth it when that is more than a quarter of the vector
+      const long long nchunks = (range_len(g) / 4 + SAMPLE_RUN - 1) / SAMPLE_RUN;  // runs of 64 grid points
+      const long long target = ctl.runs > 0 ? ctl.runs : (g.N >= (1ll << 26) ? 32768 : 16384);   // one or two million sampled points
+      const long long stride = nchunks / target;
+      // (below 2^24 grid points the extra launch costs more than the sweeps it saves: 2048^2 loses 3 %; a test may force it)
+      if (stride >= 4 && (g.N >= (1ll << 24) || ctl.runs > 0)) {
+        const long long nsamp = nchunks / stride;
+        hipLaunchKernelGGL((k_sample<T, 4>), dim3((unsigned)(nsamp < SAMPLE_WG ? nsamp : SAMPLE_WG)), dim3(SAMPLE_NT), 0, s, g, a, ps, partials,
+                           nchunks, nsamp, (unsigned int)stride, true_len, l1_hw_max(), l1_lean_on(),
+                           0.2 * (double)fit_grid(range_len(g) / 4, SIPX_PASS_GRID) * (double)SPEC_CAP);     // a fifth of the LDS buffers of the pass
+      }
+    }
+    SIPX_PASS(M_FIRST);
+    if (a.prox == PX_L1 && !(a.flags & F_NOSPEC)) SIPX_PASS(M_LEAN);
+    hipLaunchKernelGGL((k_slot_sums<T, 0>), dim3(PREP_SLOTS + 1), dim3(BLOCK), 0, s, partials, maxpart, ps, rank, world, reg);
+  } else if (stage == 1) {
+    hipLaunchKernelGGL((k_decide<T, 0>), dim3(1), dim3(64), 0, s, ps, a.prox, a.plo, a.phi, true_len, (a.flags & F_NOSPEC) ? 1 : 0, capdiv,
+                       world, cap_max, reg);
+    if (a.prox == PX_L1) {
+      SIPX_PASS(M_PROBE);
+      hipLaunchKernelGGL((k_slot_sums<T, 1>), dim3(PREP_SLOTS), dim3(BLOCK), 0, s, partials, maxpart, ps, rank, world, reg);
+    }
+  } else if (stage == 2) {
+    if (a.prox == PX_L1) {
+      hipLaunchKernelGGL((k_decide<T, 1>), dim3(1), dim3(64), 0, s, ps, a.prox, a.plo, a.phi, true_len, 0, capdiv, world, cap_max, reg);
+      SIPX_PASS(M_COMPACT);
+      if (hk) hipLaunchKernelGGL((k_gather_pack<T>), dim3(64), dim3(BLOCK), 0, s, ps, compact, partials, gseg0 + (long long)rank * chunk, hk->gcap);
+    }
+  } else if (a.prox == PX_L1) {
+    if (hk) hipLaunchKernelGGL((k_gather_unpack<T>), dim3(64), dim3(BLOCK), 0, s, ps, compact, partials, gseg0, chunk, world, compact_len);
+    hipLaunchKernelGGL((k_l1_solve<T>), dim3(hk ? 1 : SOLVE_G), dim3(SIPX_SOLVE_NT), 0, s, ps, a.phi, compact, partials, true_len, l1_hw_max(),
+                       l1_lean_on(), ctl.host_want);
+  }
+#undef SIPX_PASS
+  SIPX_HIP(hipGetLastError());
+}
+
+template <typename T, int SRC>
+static void launch_chain(hipStream_t s, const Grid& g, const SetArgs<T>& a, int v_is_s, const T* varr, long long len,
+                         ProjScalars<T>* ps, double* partials, T* maxpart, T* compact, long long true_len,
+                         SampleCtl ctl = SampleCtl(), const ChainHooks* hk = nullptr, long long compact_len = 0) {
+  if (hk && a.prox == PX_CARD) throw std::runtime_error("the cardinality search is not available on a slab-decomposed grid");
   if (a.prox == PX_CARD) {
+    const bool vec = SRC == 1 && g.n[0] % 4 == 0;
+#define SIPX_PASS(MODE)                                                                                            \
+  do {                                                                                                             \
+    if (vec)                                                                                                       \
+      hipLaunchKernelGGL((k_pass<T, 4, MODE, SRC>), dim3(fit_grid(range_len(g) / 4, SIPX_PASS_GRID)), dim3(BLOCK), 0, s, g, a, v_is_s, varr, len, ps, compact, \
+                         partials, maxpart);                                                                       \
+    else                                                                                                           \
+      hipLaunchKernelGGL((k_pass<T, 1, MODE, SRC>), dim3(fit_grid(SRC == 0 ? len : range_len(g), SIPX_PASS_GRID)), dim3(BLOCK), 0, s, g, a, v_is_s, varr, len, ps, compact, \
+                         partials, maxpart);                                                                       \
+  } while (0)
     const long long kc = (long long)a.phi;
     SIPX_PASS(M_FIRST);
     hipLaunchKernelGGL((k_card_decide<T, 0>), dim3(1), dim3(1024), 0, s, partials, maxpart, ps, kc, true_len);
@@ -1179,32 +1310,41 @@ static void launch_chain(hipStream_t s, const Grid& g, const SetArgs<T>& a, int 
     SIPX_PASS(M_COMPACT);
     hipLaunchKernelGGL((k_card_select<T>), dim3(1), dim3(1024), 0, s, ps, kc, compact);
     SIPX_HIP(hipGetLastError());
+#undef SIPX_PASS
     return;
   }
-  SIPX_PASS(M_FIRST);
-  if (a.prox == PX_L1 && !(a.flags & F_NOSPEC)) SIPX_PASS(M_LEAN);
-  hipLaunchKernelGGL((k_slot_sums<T, 0>), dim3(PREP_SLOTS + 1), dim3(BLOCK), 0, s, partials, maxpart, ps);
-  hipLaunchKernelGGL((k_decide<T, 0>), dim3(1), dim3(64), 0, s, ps, a.prox, a.plo, a.phi, true_len, (a.flags & F_NOSPEC) ? 1 : 0, capdiv);
-  if (a.prox == PX_L1) {
-    for (int r = 0; r < L1_REFINES; ++r) {
-      SIPX_PASS(M_PROBE);
-      hipLaunchKernelGGL((k_slot_sums<T, 1>), dim3(PREP_SLOTS), dim3(BLOCK), 0, s, partials, maxpart, ps);
-      hipLaunchKernelGGL((k_decide<T, 1>), dim3(1), dim3(64), 0, s, ps, a.prox, a.plo, a.phi, true_len, 0, capdiv);
-    }
-    SIPX_PASS(M_COMPACT);
-    hipLaunchKernelGGL((k_l1_solve<T>), dim3(SOLVE_G), dim3(SIPX_SOLVE_NT), 0, s, ps, a.phi, compact, partials, true_len, l1_hw_max(), l1_lean_on(),
-                       ctl.host_want);
-  }
-#undef SIPX_PASS
+  // the four stages back to back; on a slab-decomposed grid with this search's own collectives in between
+  static_assert(L1_REFINES == 1, "one refinement stage");
+  const int world = hk ? hk->world : 1;
+  const long long chunk = hk ? hk->gcap + GATHER_HDR : 0;
+  T* gb = hk ? static_cast<T*>(hk->gbuf) : nullptr;
+  double* reg = ps->red;                       // red, ovf, mm: adjacent doubles
+  chain_stage<T, SRC>(0, s, g, a, v_is_s, varr, len, ps, partials, maxpart, compact, true_len, ctl, hk, compact_len, reg, gb, chunk);
+  if (hk) hk->allreduce_sum(hk->user, reg, (size_t)(PREP_SLOTS + 1 + 2 * world), s);
+  chain_stage<T, SRC>(1, s, g, a, v_is_s, varr, len, ps, partials, maxpart, compact, true_len, ctl, hk, compact_len, reg, gb, chunk);
+  if (hk && a.prox == PX_L1) hk->allreduce_sum(hk->user, reg, (size_t)PREP_SLOTS, s);
+  chain_stage<T, SRC>(2, s, g, a, v_is_s, varr, len, ps, partials, maxpart, compact, true_len, ctl, hk, compact_len, reg, gb, chunk);
+  if (hk && a.prox == PX_L1) hk->allgather(hk->user, gb, (size_t)chunk, sizeof(T) == 8 ? 1 : 0, s);
+  chain_stage<T, SRC>(3, s, g, a, v_is_s, varr, len, ps, partials, maxpart, compact, true_len, ctl, hk, compact_len, reg, gb, chunk);
   SIPX_HIP(hipGetLastError());
 }
 
 template <typename T>
 void K<T>::proj_scalars_set(hipStream_t s, const Grid& g, const SetArgs<T>& a, int v_is_s, ProjScalars<T>* ps,
-                            double* partials, T* maxpart, T* compact, long long true_len, SampleCtl ctl) {
+                            double* partials, T* maxpart, T* compact, long long true_len, SampleCtl ctl, const ChainHooks* hooks) {
   SetArgs<T> b = a;
   b.ps = ps;
-  launch_chain<T, 1>(s, g, b, v_is_s, nullptr, 0, ps, partials, maxpart, compact, true_len, ctl);
+  launch_chain<T, 1>(s, g, b, v_is_s, nullptr, 0, ps, partials, maxpart, compact, true_len, ctl, hooks, (long long)a.nblk_or1() * g.N);
+}
+template <typename T>
+void K<T>::proj_scalars_stage(int stage, hipStream_t s, const Grid& g, const SetArgs<T>& a, int v_is_s, ProjScalars<T>* ps,
+                              double* partials, T* maxpart, T* compact, long long true_len, SampleCtl ctl, const ChainHooks* hooks,
+                              double* reg, T* gseg0, long long chunk) {
+  if (a.prox == PX_CARD) throw std::runtime_error("the cardinality search has no staged form");
+  SetArgs<T> b = a;
+  b.ps = ps;
+  chain_stage<T, 1>(stage, s, g, b, v_is_s, nullptr, 0, ps, partials, maxpart, compact, true_len, ctl, hooks,
+                    (long long)a.nblk_or1() * g.N, reg ? reg : ps->red, gseg0, chunk);
 }
 template <typename T>
 void K<T>::proj_scalars_arr(hipStream_t s, long long len, const T* v, int prox, T pmin, T pmax, ProjScalars<T>* ps,
@@ -1248,7 +1388,9 @@ void K<T>::proj_dist_set(hipStream_t s, const Grid& g, const SetArgs<T>& a, int 
   template void K<T>::ps_rescale(hipStream_t, ProjScalars<T>*, double);                                          \
   template void K<T>::store_v(hipStream_t, const Grid&, const SetArgs<T>&, int, T*);                                                     \
   template void K<T>::proj_scalars_set(hipStream_t, const Grid&, const SetArgs<T>&, int, ProjScalars<T>*, double*, \
-                                       T*, T*, long long, SampleCtl);                                                     \
+                                       T*, T*, long long, SampleCtl, const ChainHooks*);                                        \
+  template void K<T>::proj_scalars_stage(int, hipStream_t, const Grid&, const SetArgs<T>&, int, ProjScalars<T>*, double*, T*, T*,   \
+                                         long long, SampleCtl, const ChainHooks*, double*, T*, long long);                                                     \
   template void K<T>::proj_scalars_arr(hipStream_t, long long, const T*, int, T, T, ProjScalars<T>*, double*, T*, \
                                        T*, long long);                                                           \
   template void K<T>::proj_dist_set(hipStream_t, const Grid&, const SetArgs<T>&, int, const ProjScalars<T>*, double*);

@@ -29,8 +29,9 @@ namespace sipx {
 // (rhs_compose.jl:24-31); algorithmic bytes (sum_i 2 M_i + N) * w.
 template <typename T, int V>
 __global__ __launch_bounds__(BLOCK) void k_rhs(Grid G, RhsArgs<T> a, T* __restrict__ rhs, int accumulate) {
-  const long long nvec = G.N / V;
-  for (long long vi = (long long)blockIdx.x * BLOCK + threadIdx.x; vi < nvec; vi += (long long)gridDim.x * BLOCK) {
+  long long v0, nvec;
+  vec_range<V>(G, v0, nvec);
+  for (long long vi = v0 + (long long)blockIdx.x * BLOCK + threadIdx.x; vi < nvec; vi += (long long)gridDim.x * BLOCK) {
     const long long g = vi * V;
     const Coord c = coords(G, g);
     T out[V];
@@ -78,9 +79,9 @@ __global__ __launch_bounds__(BLOCK) void k_rhs(Grid G, RhsArgs<T> a, T* __restri
 template <typename T>
 void K<T>::rhs_compose(hipStream_t s, const Grid& g, const RhsArgs<T>& a, T* rhs, int accumulate) {
   if (g.n[0] % 4 == 0)
-    hipLaunchKernelGGL((k_rhs<T, 4>), dim3(fit_grid(g.N / 4, NB)), dim3(BLOCK), 0, s, g, a, rhs, accumulate);
+    hipLaunchKernelGGL((k_rhs<T, 4>), dim3(fit_grid(range_len(g) / 4, NB)), dim3(BLOCK), 0, s, g, a, rhs, accumulate);
   else
-    hipLaunchKernelGGL((k_rhs<T, 1>), dim3(fit_grid(g.N, NB)), dim3(BLOCK), 0, s, g, a, rhs, accumulate);
+    hipLaunchKernelGGL((k_rhs<T, 1>), dim3(fit_grid(range_len(g), NB)), dim3(BLOCK), 0, s, g, a, rhs, accumulate);
   SIPX_HIP(hipGetLastError());
 }
 
@@ -101,9 +102,11 @@ __global__ __launch_bounds__(BLOCK) void k_yl(Grid G, SetArgs<T> a, double* __re
   const bool first = (a.flags & F_FIRST) != 0;
   const bool bb = (a.flags & F_BB) && !first;
   const bool dist = a.prox == PX_DIST;
-  const long long nvec = G.N / V;
-  for (long long vi = (long long)blockIdx.x * BLOCK + threadIdx.x; vi < nvec; vi += (long long)gridDim.x * BLOCK) {
+  long long v0, nvec;
+  vec_range<V>(G, v0, nvec);
+  for (long long vi = v0 + (long long)blockIdx.x * BLOCK + threadIdx.x; vi < nvec; vi += (long long)gridDim.x * BLOCK) {
     const long long g = vi * V;
+    const bool summed = g >= G.s0;         // false on the recomputed plane in front of the rank's own slab
     const Coord c = coords(G, g);
     const Vec<T, V> xc = ldv<T, V>(a.x + g);
     for (int q = 0; q < nb; ++q) {
@@ -141,16 +144,16 @@ __global__ __launch_bounds__(BLOCK) void k_yl(Grid G, SetArgs<T> a, double* __re
         ln.v[k] = l1;
         dyv.v[k] = y1 - yo;                                             // x_hat = y - y_old  :82
         lh.v[k] = lo + a.rho * (yo - s[k]);                             // l_hat = l_old + rho(-s + y_old)  PARSDMM.jl:173
-        acc[SL_RPRI] += (double)rp * (double)rp;
-        if (ident) acc[SL_DY] += (double)dyv.v[k] * (double)dyv.v[k];
-        if (feas && valid[k]) {                                         // update_y_l.jl:90-99
+        if (summed) acc[SL_RPRI] += (double)rp * (double)rp;
+        if (ident && summed) acc[SL_DY] += (double)dyv.v[k] * (double)dyv.v[k];
+        if (feas && valid[k] && summed) {                               // update_y_l.jl:90-99
           const T ps = prox_apply<T>(pc, s[k], lbv.v[k], ubv.v[k], T(0), e + k);
           const T d = ps - s[k];
           acc[SL_FE] += (double)d * (double)d;
           acc[SL_SS] += (double)s[k] * (double)s[k];
         }
       }
-      if (dist) {                                                        // PARSDMM.jl:140,145
+      if (dist && summed) {                                              // PARSDMM.jl:140,145
         const Vec<T, V> xo = ldv<T, V>(a.xold + g);
 #pragma unroll
         for (int k = 0; k < V; ++k) {
@@ -167,6 +170,7 @@ __global__ __launch_bounds__(BLOCK) void k_yl(Grid G, SetArgs<T> a, double* __re
                         d0 = ldv_nt<T, V>(a.l0 + e);
 #pragma unroll
         for (int k = 0; k < V; ++k) {
+          if (!summed) continue;
           const T dlh = lh.v[k] - a0.v[k], dH = s[k] - c0.v[k], dl = ln.v[k] - d0.v[k], dG = -(yn.v[k] - b0.v[k]);
           acc[SL_HL] += (double)dH * (double)dlh;
           acc[SL_HH] += (double)dH * (double)dH;
@@ -194,9 +198,9 @@ template <typename T>
 void K<T>::yl(hipStream_t s, const Grid& g, const SetArgs<T>& a, double* partials) {
   constexpr int VW = sizeof(T) == 8 ? SIPX_F64_VEC : 4;      // four doubles per thread spill registers at 3 waves per SIMD
   if (g.n[0] % 4 == 0)
-    hipLaunchKernelGGL((k_yl<T, VW>), dim3(fit_grid(g.N / VW, NB)), dim3(BLOCK), 0, s, g, a, partials);
+    hipLaunchKernelGGL((k_yl<T, VW>), dim3(fit_grid(range_len(g) / VW, NB)), dim3(BLOCK), 0, s, g, a, partials);
   else
-    hipLaunchKernelGGL((k_yl<T, 1>), dim3(fit_grid(g.N, NB)), dim3(BLOCK), 0, s, g, a, partials);
+    hipLaunchKernelGGL((k_yl<T, 1>), dim3(fit_grid(range_len(g), NB)), dim3(BLOCK), 0, s, g, a, partials);
   SIPX_HIP(hipGetLastError());
 }
 
@@ -204,8 +208,9 @@ void K<T>::yl(hipStream_t s, const Grid& g, const SetArgs<T>& a, double* partial
 template <typename T, int V>
 __global__ __launch_bounds__(BLOCK) void k_adj_norm(Grid G, SetArgs<T> a, double* __restrict__ partials) {
   double acc[1] = {0};
-  const long long nvec = G.N / V;
-  for (long long vi = (long long)blockIdx.x * BLOCK + threadIdx.x; vi < nvec; vi += (long long)gridDim.x * BLOCK) {
+  long long v0, nvec;
+  vec_range<V>(G, v0, nvec);
+  for (long long vi = v0 + (long long)blockIdx.x * BLOCK + threadIdx.x; vi < nvec; vi += (long long)gridDim.x * BLOCK) {
     const long long g = vi * V;
     const Coord c = coords(G, g);
     T t[V];
@@ -224,9 +229,9 @@ __global__ __launch_bounds__(BLOCK) void k_adj_norm(Grid G, SetArgs<T> a, double
 template <typename T>
 void K<T>::adj_norm(hipStream_t s, const Grid& g, const SetArgs<T>& a, double* partials) {
   if (g.n[0] % 4 == 0)
-    hipLaunchKernelGGL((k_adj_norm<T, 4>), dim3(fit_grid(g.N / 4, NB)), dim3(BLOCK), 0, s, g, a, partials);
+    hipLaunchKernelGGL((k_adj_norm<T, 4>), dim3(fit_grid(range_len(g) / 4, NB)), dim3(BLOCK), 0, s, g, a, partials);
   else
-    hipLaunchKernelGGL((k_adj_norm<T, 1>), dim3(fit_grid(g.N, NB)), dim3(BLOCK), 0, s, g, a, partials);
+    hipLaunchKernelGGL((k_adj_norm<T, 1>), dim3(fit_grid(range_len(g), NB)), dim3(BLOCK), 0, s, g, a, partials);
   SIPX_HIP(hipGetLastError());
 }
 

@@ -39,6 +39,8 @@ constexpr int MAX_SETS = 16;      // sets fused in one rhs_compose launch
 constexpr int YL_SLOTS = 13;      // reductions produced by one y/l-update launch
 constexpr int L1_K = 8;          // probe thresholds of the l1-ball threshold search
 #define SIPX_SOLVE_SLOTS 64      // most workgroups a cooperative k_l1_solve may be launched with
+#define SIPX_MAX_WORLD 64        // most ranks of a slab-decomposed solve (per-rank max / min entries in ProjScalars)
+constexpr int GATHER_HDR = 8;    // TF elements in front of a rank's segment of gathered magnitudes (read as doubles: count, S_above, C_above)
 constexpr int PREP_SLOTS = 3 + 2 * L1_K;   // ||v||_1, ||v||_2^2, nnz, S_k, C_k
 // Sampled prediction of the l1 threshold (k_sample / k_sample_decide): histogram of the sampled magnitudes over
 // SAMPLE_BINS bins of 2^-SAMPLE_MBITS of an octave each (the bin key is the leading bits of the floating-point pattern),
@@ -67,6 +69,11 @@ struct Grid {
   // m == 0: not set up (grids built ad hoc for one-off kernels): the kernels divide.  The stencil kernels take the
   // coordinates of every vector they touch; a hardware-free 32-bit division costs ~25 VALU instructions each.
   unsigned m1 = 0, s1 = 0, m2 = 0, s2 = 0;
+  // Slab decomposition of a sharded solve (every rank works on the planes [e0, e1) of the GLOBALLY indexed arrays): the set
+  // kernels sweep the grid points e0 <= g < e1 only (e1 < 0: all N).  k_yl may be given one plane more at the front than the
+  // rank owns -- it recomputes the neighbour's last plane of y, l, bit for bit, instead of receiving it -- and adds only the
+  // points g >= s0 to its sums.
+  long long e0 = 0, e1 = -1, s0 = 0;
   void set_fast_div() {
     auto magic = [](long long d, unsigned& m, unsigned& sh) {
       m = 0; sh = 0;
@@ -81,6 +88,8 @@ struct Grid {
     magic(n[1], m2, s2);
   }
 };
+
+inline long long range_len(const Grid& g) { return (g.e1 < 0 ? g.N : g.e1) - g.e0; }     // grid points a launch sweeps
 
 struct CdsArgs {
   int d;
@@ -133,8 +142,12 @@ struct ProjScalars {
   double c_lo, c_hi;  // counts of |v| > lo and |v| > hi of the current bracket
   T tau_prev;
   // sums of the PREP_SLOTS partial slots of the last probe pass, its largest / smallest non-zero magnitude (k_slot_sums)
+  // On a slab-decomposed grid ONE all-reduce (sum) over red, ovf and mm makes them global: mm holds (largest, smallest
+  // non-zero) magnitude per rank in the rank's own two entries and zeros elsewhere -- keep the three adjacent
   double red[PREP_SLOTS];
-  T rmax, rmin;
+  double ovf;                                // > 0: the speculative gather of some rank overflowed its LDS buffers
+  double mm[2 * SIPX_MAX_WORLD];
+  int gather_overflow;                       // sticky: a rank gathered more magnitudes than the exchange buffer holds (theta = NaN)
   int lean;           // the coming first pass evaluates the two edge probes of the speculative range only (k_pass M_FIRST)
   // cooperative sweeps of k_l1_solve: per-workgroup shares of (sum hi, sum lo, count), double buffered by iteration parity
   double coop_hi[2][SIPX_SOLVE_SLOTS], coop_lo[2][SIPX_SOLVE_SLOTS], coop_c[2][SIPX_SOLVE_SLOTS];
@@ -153,6 +166,16 @@ struct ProjScalars {
 
 // Optional sampled prediction in front of an l1 search (see k_sample): host-side switch and the pinned word through which
 // k_l1_solve tells the host whether the coming search wants it (ProjScalars::want_sample)
+// Collectives of a threshold search on a slab-decomposed grid (every rank sweeps its planes; the engine supplies them)
+struct ChainHooks {
+  int world = 1, rank = 0;
+  void* user = nullptr;
+  void (*allreduce_sum)(void* user, double* buf, size_t count, hipStream_t s) = nullptr;            // in place
+  void (*allgather)(void* user, void* buf, size_t chunk, int dtype_is_f64, hipStream_t s) = nullptr;  // in place, chunk elements per rank
+  void* gbuf = nullptr;          // world * (gcap + GATHER_HDR) TF elements
+  long long gcap = 0;            // gathered magnitudes a rank may contribute
+};
+
 struct SampleCtl {
   int enable = 0;
   long long runs = 0;      // sampled runs of 64 grid points (0: 16384, 32768 from 2^26 grid points on)
@@ -174,6 +197,7 @@ struct SetArgs {
   const ProjScalars<T>* ps;
   int flags;
   int vsrc;                             // 1: read v from `v`; 2: read the already projected y from `v`
+  int nblk_or1() const { return nblk > 0 ? nblk : 1; }
 };
 
 // One changed set of a fused Q update: Q[:,col(off_j)] += alpha * AtA_i[:,j] (CDS_scaled_add!.jl:16-22).
@@ -286,7 +310,14 @@ struct K {
   // Enqueues: first pass (sums + probe + speculative compaction), bracket, gated refinement / compaction, solve.
   static void ps_rescale(hipStream_t s, ProjScalars<T>* ps, double factor);
   static void proj_scalars_set(hipStream_t s, const Grid& g, const SetArgs<T>& a, int v_is_s, ProjScalars<T>* ps,
-                               double* partials, T* maxpart, T* compact, long long true_len, SampleCtl ctl = SampleCtl());
+                               double* partials, T* maxpart, T* compact, long long true_len, SampleCtl ctl = SampleCtl(),
+                               const ChainHooks* hooks = nullptr);
+  // one stage (0..3) of the same search, for a caller that runs the searches of several sets in lock step with ONE collective
+  // between the stages (slab-decomposed iteration): reg = the set's region of the all-reduced staging buffer, gseg0 / chunk =
+  // its segment in rank 0's chunk of the exchange buffer and the distance to the next rank's
+  static void proj_scalars_stage(int stage, hipStream_t s, const Grid& g, const SetArgs<T>& a, int v_is_s, ProjScalars<T>* ps,
+                                 double* partials, T* maxpart, T* compact, long long true_len, SampleCtl ctl, const ChainHooks* hooks,
+                                 double* reg, T* gseg0, long long chunk);
   static void proj_scalars_arr(hipStream_t s, long long len, const T* v, int prox, T pmin, T pmax, ProjScalars<T>* ps,
                                double* partials, T* maxpart, T* compact, long long true_len);
   // ||P(v)-v||^2 and ||v||^2 of the set-produced vector into partial slots dst[0..NB), dst[NB..2NB)

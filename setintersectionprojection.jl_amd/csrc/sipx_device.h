@@ -279,6 +279,12 @@ __device__ __forceinline__ double jl_min(double a, double b) { return (a != a ||
 struct Coord {
   int i, j, k;
 };
+// vector range [v0, v1) of a launch over the grid (Grid::e0, e1; V divides both: planes are multiples of n1)
+template <int V>
+__device__ __forceinline__ void vec_range(const Grid& G, long long& v0, long long& v1) {
+  v0 = G.e0 / V;
+  v1 = (G.e1 < 0 ? G.N : G.e1) / V;
+}
 // Coordinates of linear index g (column-major, dim 1 fastest).  N < 2^31 is enforced at sipx_create.
 __device__ __forceinline__ Coord coords(const Grid& G, long long g) {
   Coord c;

@@ -33,7 +33,7 @@ EXPORTED_SYMBOLS = [
     "sipx_debug_proj", "sipx_resample_nn", "sipx_set_q_mode", "sipx_apply_Q",
     "sipx_stream",
     "sipx_dev_rhs", "sipx_dev_x", "sipx_set_owned", "sipx_get_rhs", "sipx_prox_l2s",
-    "sipx_rccl_unique_id", "sipx_set_comm_rccl", "sipx_set_comm", "sipx_slab", "sipx_warm_start_from",
+    "sipx_rccl_unique_id", "sipx_set_comm_rccl", "sipx_set_comm", "sipx_slab", "sipx_warm_start_from", "sipx_set_decomp",
 ]
 
 SIPX_F32, SIPX_F64 = 0, 1
@@ -640,6 +640,12 @@ class Context:
         y = np.empty_like(x)
         _chk(lib().sipx_apply_Q(self.h, _ptr(x), _ptr(y)))
         return y
+
+    def set_decomp(self, mode: str):
+        """"sets": the reference's split by constraint set; "slab": every rank works on its z-slab of every set (sipx.h)."""
+        if mode not in ("sets", "slab"):
+            raise SipxError(f"unknown decomposition {mode!r} (sets | slab)")
+        _chk(lib().sipx_set_decomp(self.h, 1 if mode == "slab" else 0))
 
     def set_owned(self, owned: Sequence[int]):
         a = np.zeros(len(self.rows) + 1, np.int32)       # constraint sets + the distance term

@@ -341,22 +341,43 @@ class PhaseDriver:
                                 log.cg_it[:i], log.cg_relres[:i], dict.fromkeys(TIMING_SECTIONS, float("nan")))
 
 
+def slab_decomposable(P_sub, TD_OP) -> bool:
+    """Can the WHOLE iteration be decomposed by z-slab (sipx_set_decomp(SIPX_DECOMP_SLAB))?  Only for sets whose projector
+    needs nothing but sums over the grid: bounds, l1 / l2 ball, annulus, prox_l1 applied to the whole vector, on the identity
+    or on D_x / D_y / D_z / TV (TD_OP: one operator per set, the distance term's identity may follow)."""
+    ok_kinds = {"bounds", "bounds_vec", "l1", "l2", "annulus", "prox_l1"}
+    ok_ops = {"identity", "D_x", "D_y", "D_z", "TV", "D2D", "D3D"}
+    for P, A in zip(P_sub, TD_OP):
+        if getattr(P, "kind", None) not in ok_kinds or getattr(P, "mode", 1) != 0 or getattr(P, "transform", 1) != 0:
+            return False
+        if getattr(A, "kind", None) not in ok_ops or getattr(A, "component", 0) != 0:
+            return False
+    return True
+
+
 def PARSDMM_sharded(m, AtA, TD_OP, set_Prop, P_sub, comp_grid, options, dist=None, device=0, x=None, l=None, y=None,
-                    comm_mode: Optional[str] = None, phase_driver: bool = False):
+                    comm_mode: Optional[str] = None, phase_driver: bool = False, decomp: str = "sets"):
     """PARSDMM as one rank of a sharded solve over ``dist`` (torch.distributed, one process per GPU).  Returns
-    (x, log, l, y); x and the log are complete and identical on every rank, l / y hold the locally owned sets (zeros
-    elsewhere).  phase_driver=True runs the loop over the phase entry points instead of sipx_parsdmm."""
+    (x, log, l, y); x and the log are complete and identical on every rank.  decomp "sets": the reference's split by
+    constraint set -- l / y hold the locally owned sets (zeros elsewhere); "slab": every rank works on its z-slab of every
+    set (sipx.h, sipx_set_decomp) -- l / y are complete on every rank; "auto": "slab" where the sets allow it.
+    phase_driver=True runs the loop over the phase entry points instead of sipx_parsdmm."""
     from .host import build_context, set_default_device
     world = dist.get_world_size() if dist is not None else 1
     rank = dist.get_rank() if dist is not None else 0
     p = len(TD_OP)
+    if decomp == "auto":
+        decomp = "slab" if (dist is not None and slab_decomposable(P_sub, TD_OP) and getattr(options, "Q_mode", "cds") == "cds") else "sets"
     owned = shard_sets(p, world, rank)
     set_default_device(device)
     import torch
     keep = []
     attach = None
     if dist is not None:
-        attach = lambda ctx: keep.append(attach_comm(ctx, dist, torch.device("cuda", device), comm_mode))
+        def attach(ctx):
+            keep.append(attach_comm(ctx, dist, torch.device("cuda", device), comm_mode))
+            if decomp == "slab":
+                ctx.set_decomp("slab")
     ctx = build_context(m, AtA, TD_OP, set_Prop, P_sub, comp_grid, options, x, l, y, device, owned, attach)
     try:
         if phase_driver:

@@ -544,7 +544,7 @@ def test_converged_result_is_feasible(sipx):
 
 
 # ---- sharded solve on the real engine: several ranks sharing the one GPU, the engine's collectives over gloo ----------
-def _sharded_worker(rank, world, port, out, kinds, n, backend, mode, phase):
+def _sharded_worker(rank, world, port, out, kinds, n, backend, mode, phase, decomp="sets"):
     import os
     import sys
     import torch
@@ -569,8 +569,8 @@ def _sharded_worker(rank, world, port, out, kinds, n, backend, mode, phase):
         m = model(n, TF, seed=5)
         gs, os_, Ps, As, props, AtAs = _problem(sipx, n, h, TF, kinds, m, dict(maxit=40))
         x, log, l, y = sharded.PARSDMM_sharded(m.copy(), AtAs, As, props, Ps, gs, os_, dist=dist, device=0, comm_mode=mode,
-                                               phase_driver=phase)
-        owned = sharded.shard_sets(len(As), world, rank)
+                                               phase_driver=phase, decomp=decomp)
+        owned = sharded.shard_sets(len(As), world, rank) if decomp == "sets" else [1] * len(As)
         np.savez(os.path.join(out, f"r{rank}.npz"), x=x, obj=log.obj, evol_x=log.evol_x, cg_it=log.cg_it, rho=log.rho, gamma=log.gamma,
                  r_pri=log.r_pri, r_dual=log.r_dual, feas=log.set_feasibility, cg_relres=log.cg_relres)
         np.savez(os.path.join(out, f"yl{rank}.npz"), **{f"y{i}": y[i] for i in range(len(y)) if owned[i]},
@@ -599,20 +599,45 @@ SHARDED = [
 ]
 
 
+# The WHOLE iteration on z-slabs (sipx_set_decomp(SIPX_DECOMP_SLAB)): every rank holds every set; even, ragged (6, 6, 4) and
+# empty slabs, a 2-D grid, TV (a z-block whose adjoint reads the recomputed plane below), the phase-level loop.
+SLAB = [
+    (2, ["bounds", "l1:D_x", "l1:D_y", "l1:D_z"], (32, 24, 16), False),
+    (3, ["bounds", "l1:D_x", "l1:D_y", "l1:D_z"], (32, 24, 16), False),
+    (4, ["bounds", "l1:D_z", "l1:D_x"], (12, 10, 5), False),
+    (2, ["l1:TV"], (32, 24, 16), False),
+    (2, ["bounds", "l1:TV"], (64, 48), False),
+    (4, ["bounds", "annulus", "l1:D_z"], (32, 24, 16), False),
+    (2, ["bounds", "l1:D_x", "l1:D_y", "l1:D_z"], (32, 24, 16), True),
+]
+
+
+@pytest.mark.timeout(400)
+@pytest.mark.parametrize("world,kinds,n,phase", SLAB)
+def test_slab_decomposed_ranks_on_one_gpu(sipx, tmp_path, world, kinds, n, phase):
+    """Serial == slab-decomposed to the reference's own serial-vs-parallel tolerance; every rank ends with identical x, y, l
+    and logs (the sums are all-reduced: identical bits, identical decisions)."""
+    test_sharded_ranks_on_one_gpu(sipx, tmp_path, world, kinds, n, phase, decomp="slab")
+
+
 @pytest.mark.timeout(400)
 @pytest.mark.parametrize("world,kinds,n,phase", SHARDED)
-def test_sharded_ranks_on_one_gpu(sipx, tmp_path, world, kinds, n, phase):
+def test_sharded_ranks_on_one_gpu(sipx, tmp_path, world, kinds, n, phase, decomp="sets"):
     """Serial == sharded to the reference's own tolerance (test/test_PARSDMM_parallel.jl:72,121: 5e-4 on x); every rank ends
     with identical x and logs; r_dual is filled (the reference's parallel mode leaves it zero)."""
     import os
     import torch.multiprocessing as mp
     port = 29600 + (os.getpid() % 2000) + 11 * world
-    mp.spawn(_sharded_worker, args=(world, port, str(tmp_path), kinds, n, "gloo", "torch", phase), nprocs=world, join=True)
+    mp.spawn(_sharded_worker, args=(world, port, str(tmp_path), kinds, n, "gloo", "torch", phase, decomp), nprocs=world, join=True)
     r0 = np.load(tmp_path / "r0.npz")
     for r in range(1, world):
         r1 = np.load(tmp_path / f"r{r}.npz")
         for k in r0.files:
             assert np.array_equal(r0[k], r1[k], equal_nan=True), k
+        if decomp == "slab":                      # y, l are complete (gathered) on every rank
+            a, b = np.load(tmp_path / "yl0.npz"), np.load(tmp_path / f"yl{r}.npz")
+            for k in a.files:
+                assert np.array_equal(a[k], b[k], equal_nan=True), k
     TF = np.float32
     h = (25.0, 25.0, 25.0)[:len(n)]
     m = model(n, TF, seed=5)
