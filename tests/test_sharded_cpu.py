@@ -381,3 +381,98 @@ def test_more_ranks_than_terms(tmp_path):
     assert np.array_equal(rs[0]["cg_it"][:K], lo.cg_it[:K]) and np.allclose(rs[0]["obj"][:K], lo.obj[:K], rtol=1e-9)
     err = np.linalg.norm(rs[0]["x"] - xo) / np.linalg.norm(xo)
     assert err < 1e-6, err
+
+
+# ---- slab decomposition of the whole iteration: the exchange steps of a threshold search --------------------------------
+def _slab_search_worker(rank, world, port, out):
+    """One l1 threshold search as the slab-decomposed iteration runs it (csrc/kernels_proj.hip, chain_stage): every rank sweeps
+    ITS planes of v, ONE all-reduce makes the probe sums global, the bracket decision is the same scalar code on every rank,
+    ONE all-gather strings the magnitudes inside the bracket together, every rank solves the same small problem.  numpy
+    stand-in for the kernels (test infrastructure), the product's communicator class for the two collectives."""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")
+    import datetime
+    dist.init_process_group("gloo", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=120))
+    try:
+        from __graft_entry__ import load_package
+        load_package()
+        from sipx import sharded
+        comm = sharded.TorchComm(dist)
+        rng = np.random.default_rng(11)
+        n_last, plane = 13, 40                                    # ragged slabs: ceil(13 / world) planes per rank
+        v = (rng.standard_normal(n_last * plane) * np.exp(rng.standard_normal(n_last * plane))).astype(np.float64)
+        b = 0.3 * np.abs(v).sum()
+        chunk, slabs = sharded.slab_partition(n_last, plane, world)
+        r0, r1 = slabs[rank]
+        mine = np.abs(v[r0:r1])
+        # stage 0: sums at eight probes (and ||v||_1, count) over the rank's planes, all-reduced
+        t = np.quantile(np.abs(v), [0.2, 0.4, 0.55, 0.7, 0.8, 0.9, 0.96, 0.99])        # any probes: the search does not depend on them
+        red = np.concatenate([[mine.sum(), float((mine > 0).sum())], [mine[mine > tk].sum() for tk in t],
+                              [float((mine > tk).sum()) for tk in t]])
+        red_t = torch.from_numpy(red)
+        comm.allreduce_sum_(red_t)
+        red = red_t.numpy()
+        S, C = red[2:10], red[10:18]
+        f = S - t * C - b
+        lo_k = max(k for k in range(8) if f[k] >= 0) if (f >= 0).any() else -1       # f decreases: bracket between two probes
+        lo = t[lo_k] if lo_k >= 0 else 0.0
+        hi = t[lo_k + 1] if lo_k + 1 < 8 else np.inf
+        s_above = S[lo_k + 1] if lo_k + 1 < 8 else 0.0
+        c_above = C[lo_k + 1] if lo_k + 1 < 8 else 0.0
+        # stage 2: the rank's magnitudes inside (lo, hi] into its segment (count in front), all-gathered
+        gcap = n_last * plane
+        seg = torch.zeros(world * (gcap + 1), dtype=torch.float64)
+        g = mine[(mine > lo) & (mine <= hi)]
+        seg[rank * (gcap + 1)] = float(len(g))
+        seg[rank * (gcap + 1) + 1:rank * (gcap + 1) + 1 + len(g)] = torch.from_numpy(g)
+        comm.allgather_(seg, gcap + 1)
+        seg = seg.numpy()
+        vals = np.concatenate([seg[r * (gcap + 1) + 1:r * (gcap + 1) + 1 + int(seg[r * (gcap + 1)])] for r in range(world)])
+        # stage 3: Michelot from the lower end of the bracket (kernels_proj.hip, k_l1_solve)
+        theta, cprev = lo, -1.0
+        for _ in range(200):
+            act = vals[vals > theta]
+            cnt = c_above + len(act)
+            tn = (s_above + math.fsum(act) - b) / cnt
+            if len(act) == cprev:
+                break
+            theta, cprev = max(tn, theta), len(act)
+        ref = O.project_l1_Duchi(v.copy(), b)
+        got = np.sign(v) * np.maximum(np.abs(v) - theta, 0.0)
+        ok = np.linalg.norm(got - ref) <= 1e-12 * np.linalg.norm(ref) and abs(np.abs(got).sum() - b) <= 1e-10 * b
+        ok &= comm.calls["allreduce"] == 1 and comm.calls["allgather"] == 1 and comm.calls["reduce_scatter"] == 0
+        np.save(os.path.join(out, f"theta{rank}.npy"), np.array([theta]))
+        open(os.path.join(out, f"ok{rank}"), "w").write(str(bool(ok)))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_slab_threshold_search_over_gloo(tmp_path, world):
+    """The exchange pattern of a slab-decomposed l1 search: one all-reduce + one all-gather, theta identical (bits) on every
+    rank and equal to the oracle's sort-based threshold."""
+    mp.spawn(_slab_search_worker, args=(world, 30900 + (os.getpid() % 2000) + world, str(tmp_path)), nprocs=world, join=True)
+    assert [open(tmp_path / f"ok{r}").read() for r in range(world)] == ["True"] * world
+    th = [np.load(tmp_path / f"theta{r}.npy") for r in range(world)]
+    assert all(np.array_equal(th[0], t) for t in th[1:])
+
+
+def test_slab_decomposable_classifier(sipx):
+    """Which set lists may be decomposed by slab for the whole iteration (sharded.slab_decomposable): C3 yes, C4 (DFT, slice
+    rank, cardinality) no."""
+    from sipx import sharded
+    TF = np.float32
+    g = sipx.compgrid((25.0, 25.0, 25.0), (8, 8, 8))
+
+    def build(defs):
+        P, A, prop = sipx.setup_constraints(defs, g, TF)
+        return P, A
+
+    sd = sipx.set_definitions
+    c3 = [sd("bounds", "identity", 0.0, 1.0, ("matrix", "")), sd("l1", "D_x", 0.0, 1.0, ("matrix", "")),
+          sd("l1", "D_z", 0.0, 1.0, ("matrix", "")), sd("annulus", "identity", 1.0, 2.0, ("matrix", "")), sd("l1", "TV", 0.0, 1.0, ("matrix", ""))]
+    assert sharded.slab_decomposable(*build(c3))
+    for bad in (sd("cardinality", "D_z", 0, 10, ("matrix", "")), sd("rank", "identity", 0, 2, ("slice", "z")),
+                sd("l1", "DFT", 0.0, 1.0, ("matrix", "")), sd("bounds", "identity", 0.0, 1.0, ("fiber", "z"))):
+        assert not sharded.slab_decomposable(*build(c3[:2] + [bad]))
