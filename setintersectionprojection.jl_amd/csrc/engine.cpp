@@ -179,7 +179,7 @@ class Engine : public EngineBase {
     for (auto& s : sets_) free_set(s);
     for (void* p : {(void*)w_base_, (void*)x_base_, (void*)xold_, (void*)rhs_, (void*)m_base_, (void*)r_, (void*)p_base_, (void*)Ap_, (void*)Q_,
                     (void*)scr_v_, (void*)scr_c_, (void*)scr_i_, (void*)scr_w_, (void*)part_cg_, (void*)part_tmp_, (void*)part_sets_,
-                    (void*)maxpart_, (void*)cg_dev_, (void*)dres_, (void*)gbuf_, (void*)stage_})
+                    (void*)maxpart_, (void*)cg_dev_, (void*)dres_, (void*)gbuf_, (void*)stage_, (void*)sstage_})
       dfree(p);
     comm_.reset();
     if (cstream_) (void)hipStreamDestroy(cstream_);
@@ -405,6 +405,7 @@ class Engine : public EngineBase {
       gbuf_ = dalloc<T>((size_t)comm_->world * std::max(nl1, 1) * (hooks_.gcap + GATHER_HDR));
       hooks_.gbuf = gbuf_;
       stage_ = dalloc<double>((size_t)std::max(n2, 1) * (PREP_SLOTS + 1 + 2 * comm_->world));
+      sstage_ = dalloc<double>((size_t)std::max(n2, 1) * (2 * SAMPLE_BINS + 3));
     }
     scr_v_ = dalloc<T>(maxpad);
     scr_c_ = dalloc<T>(maxpad);
@@ -734,10 +735,33 @@ class Engine : public EngineBase {
           if (s.prox == PX_L1 && s.last_rho > T(0) && s.last_rho != args[j].rho)      // v rescaled: theta moves like 1/rho
             K<T>::ps_rescale(stream_, s.ps, (double)s.last_rho / (double)args[j].rho);
         }
+        // sampled prediction of theta (kernels_proj.hip, k_sample) for the l1 sets whose last search asked for it: every rank
+        // samples its planes, ONE all-reduce adds the histograms (float64 holding exact integers), every rank decides alike
+        std::vector<SampleCtl> ctl(tp.size());
+        bool any_sample = false;
+        const size_t SS = (size_t)(2 * SAMPLE_BINS + 3);
+        for (size_t j = 0; j < tp.size(); ++j) {
+          SetState<T>& s = sets_[tp[j]];
+          ctl[j].host_want = (int*)hlean_ + tp[j];
+          ctl[j].runs = l1_sample_runs_;
+          const bool rescaled = s.prox == PX_L1 && s.last_rho > T(0) && s.last_rho != args[j].rho;
+          ctl[j].enable = l1_sample_ && s.prox == PX_L1 && (rescaled || hlean_[tp[j]] != 0);
+          any_sample |= ctl[j].enable != 0;
+        }
+        if (any_sample) {
+          for (int stage = 10; stage <= 11; ++stage) {
+            for (size_t j = 0; j < tp.size(); ++j)
+              if (ctl[j].enable)
+                K<T>::proj_scalars_stage(stage, stream_, Gr_, args[j], 0, sets_[tp[j]].ps, sets_[tp[j]].ptmp, sets_[tp[j]].mpart,
+                                         sets_[tp[j]].cbuf, sets_[tp[j]].Mtrue, ctl[j], &hooks_, sstage_ + j * SS, gseg[j], chunk);
+            if (stage == 10) comm_->allreduce_sum(sstage_, tp.size() * SS, SIPX_F64, stream_);
+          }
+        }
+        for (size_t j = 0; j < tp.size(); ++j) ctl[j].enable = 0;
         for (int stage = 0; stage < 4; ++stage) {
           for (size_t j = 0; j < tp.size(); ++j) {
             SetState<T>& s = sets_[tp[j]];
-            K<T>::proj_scalars_stage(stage, stream_, Gr_, args[j], 0, s.ps, s.ptmp, s.mpart, s.cbuf, s.Mtrue, SampleCtl(), &hooks_,
+            K<T>::proj_scalars_stage(stage, stream_, Gr_, args[j], 0, s.ps, s.ptmp, s.mpart, s.cbuf, s.Mtrue, ctl[j], &hooks_,
                                      stage_ + j * RS, gseg[j], chunk);
           }
           if (stage < 2 && (stage == 0 || nl1 > 0)) comm_->allreduce_sum(stage_, tp.size() * RS, SIPX_F64, stream_);
@@ -2041,7 +2065,7 @@ class Engine : public EngineBase {
   Grid Gr_, Gyl_;
   ChainHooks hooks_;
   T* gbuf_ = nullptr;
-  double* stage_ = nullptr;
+  double *stage_ = nullptr, *sstage_ = nullptr;
   const ChainHooks* hooks() const { return slab_ ? &hooks_ : nullptr; }
   double obj_ss_ = 0, evo_ss_ = 0, xx_ss_ = 0;
   bool have_log_sums_ = false;

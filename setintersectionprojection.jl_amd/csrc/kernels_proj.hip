@@ -566,7 +566,9 @@ constexpr unsigned long long SAMPLE_SUM_MASK = (1ull << (64 - SAMPLE_CNT_BITS)) 
 template <typename T>
 __device__ __forceinline__ void sample_decide(ProjScalars<T>* ps, double* __restrict__ partials, int nwg, T radius,
                                               long long true_len, double hw_max, int lean_on, double gather_cap, double* sS,
-                                              double* sC) {
+                                              double* sC, const double* __restrict__ dsrc = nullptr) {
+  // dsrc (slab-decomposed grid): counts [0, BINS), fixed-point sums [BINS, 2 BINS) and the three partial sums, all-reduced
+  // over the ranks as float64 (integers below 2^53: exact, whatever the order) -- instead of ps->hist and the partial slots
   constexpr int NT = SAMPLE_NT, PER = SAMPLE_BINS / NT, NW = NT / 64;
   static_assert(SAMPLE_BINS % NT == 0 && NW <= 16, "bins per thread");
   __shared__ int sh_bin, sh_ok;
@@ -575,22 +577,32 @@ __device__ __forceinline__ void sample_decide(ProjScalars<T>* ps, double* __rest
   const int j0 = threadIdx.x * PER;
   // all loads first: this thread's bins, its share of the three partial sums of the nwg workgroups
   unsigned long long word[PER];
-#pragma unroll
-  for (int i = 0; i < PER; ++i) word[i] = __hip_atomic_load(&ps->hist[j0 + i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  double dc[PER], dsum[PER];
   double v[3] = {0, 0, 0};
-  for (int i = threadIdx.x; i < nwg; i += NT)
+  if (dsrc) {
 #pragma unroll
-    for (int k = 0; k < 3; ++k) v[k] += __hip_atomic_load(&partials[(long long)k * NB + i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    for (int i = 0; i < PER; ++i) { dc[i] = dsrc[j0 + i]; dsum[i] = dsrc[SAMPLE_BINS + j0 + i]; word[i] = 0; }
+    if (threadIdx.x < 3) v[threadIdx.x] = dsrc[2 * SAMPLE_BINS + threadIdx.x];
+    // (thread k holds sum k: spread so that the wave sums below deliver all three)
+    const double a0 = threadIdx.x == 0 ? v[0] : 0.0, a1 = threadIdx.x == 1 ? v[1] : 0.0, a2 = threadIdx.x == 2 ? v[2] : 0.0;
+    v[0] = a0; v[1] = a1; v[2] = a2;
+  } else {
 #pragma unroll
-  for (int i = 0; i < PER; ++i) __hip_atomic_store(&ps->hist[j0 + i], 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next search
+    for (int i = 0; i < PER; ++i) word[i] = __hip_atomic_load(&ps->hist[j0 + i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    for (int i = threadIdx.x; i < nwg; i += NT)
+#pragma unroll
+      for (int k = 0; k < 3; ++k) v[k] += __hip_atomic_load(&partials[(long long)k * NB + i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+    for (int i = 0; i < PER; ++i) __hip_atomic_store(&ps->hist[j0 + i], 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next search
+  }
   const long long key_lo = sample_key_lo<T>(ps);
   const double fscale = SAMPLE_FIX / KeyBits<T>::edge(key_lo + SAMPLE_BINS);
   double cnt[PER], sum[PER];
   double tS = 0, tC = 0;
 #pragma unroll
   for (int i = 0; i < PER; ++i) {
-    cnt[i] = (double)(word[i] >> (64 - SAMPLE_CNT_BITS));
-    sum[i] = (double)(word[i] & SAMPLE_SUM_MASK) / fscale;
+    cnt[i] = dsrc ? dc[i] : (double)(word[i] >> (64 - SAMPLE_CNT_BITS));
+    sum[i] = (dsrc ? dsum[i] : (double)(word[i] & SAMPLE_SUM_MASK)) / fscale;
     tS += sum[i];
     tC += cnt[i];
   }
@@ -708,7 +720,7 @@ __device__ __forceinline__ void sample_decide(ProjScalars<T>* ps, double* __rest
 template <typename T, int V>
 __global__ __launch_bounds__(SAMPLE_NT) void k_sample(Grid G, SetArgs<T> a, ProjScalars<T>* ps, double* __restrict__ partials,
                                                       long long nchunks, long long nsamp, unsigned int stride, long long true_len,
-                                                      double hw_max, int lean_on, double gather_cap) {
+                                                      double hw_max, int lean_on, double gather_cap, double* __restrict__ defer_to) {
   if (!ps->want_sample || !(ps->theta_prev > 0)) return;
   constexpr int NT = SAMPLE_NT;
   __shared__ unsigned long long hs[SAMPLE_BINS];
@@ -791,7 +803,32 @@ __global__ __launch_bounds__(SAMPLE_NT) void k_sample(Grid G, SetArgs<T> a, Proj
   __syncthreads();
   if (sh_ticket != gridDim.x - 1) return;
   if (threadIdx.x == 0) __hip_atomic_store(&ps->samp_ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  if (defer_to) {
+    // slab-decomposed grid: this is one rank's share of the sample.  Counts, fixed-point sums and the three partial sums go out
+    // as float64 (exact integers), an all-reduce adds the ranks' shares, k_sample_decide2 takes it from there.
+    for (int j = threadIdx.x; j < SAMPLE_BINS; j += NT) {
+      const unsigned long long w = __hip_atomic_load(&ps->hist[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(&ps->hist[j], 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      defer_to[j] = (double)(w >> (64 - SAMPLE_CNT_BITS));
+      defer_to[SAMPLE_BINS + j] = (double)(w & SAMPLE_SUM_MASK);
+    }
+    if (threadIdx.x < 3) {
+      double t = 0;
+      for (int i = 0; i < (int)gridDim.x; ++i)
+        t += __hip_atomic_load(&partials[(long long)threadIdx.x * NB + i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      defer_to[2 * SAMPLE_BINS + threadIdx.x] = t;
+    }
+    return;
+  }
   sample_decide<T>(ps, partials, (int)gridDim.x, a.phi, true_len, hw_max, lean_on, gather_cap, sS, sC);
+}
+
+template <typename T>
+__global__ __launch_bounds__(SAMPLE_NT) void k_sample_decide2(ProjScalars<T>* ps, const double* __restrict__ dsrc, T radius,
+                                                              long long true_len, double hw_max, int lean_on, double gather_cap) {
+  if (!ps->want_sample || !(ps->theta_prev > 0)) return;
+  __shared__ double sS[SAMPLE_NT], sC[SAMPLE_NT];
+  sample_decide<T>(ps, nullptr, 0, radius, true_len, hw_max, lean_on, gather_cap, sS, sC, dsrc);
 }
 
 // Double-double accumulation (Knuth's TwoSum): the gathered magnitudes arrive in an order that changes from run to run (they
@@ -1245,19 +1282,31 @@ static void chain_stage(int stage, hipStream_t s, const Grid& g, const SetArgs<T
       hipLaunchKernelGGL((k_pass<T, 1, MODE, SRC>), dim3(fit_grid(SRC == 0 ? len : range_len(g), SIPX_PASS_GRID)), dim3(BLOCK), 0, s, g, a, v_is_s, varr, len, ps, compact, \
                          partials, maxpart);                                                                       \
   } while (0)
-  if (stage == 0) {
+  if (stage == 0 || stage == 10 || stage == 11) {
+    // stage 0: sampled prediction with the decision inside the kernel (one rank).  Slab-decomposed: stage 10 = this rank's
+    // share of the sample into the set's region `reg` of the sample staging buffer (2 SAMPLE_BINS + 3 doubles), an all-reduce
+    // of the caller, stage 11 = the decision on the summed histogram.
     if (SRC == 1 && vec && ctl.enable && a.prox == PX_L1 && !v_is_s) {
       // about a million grid points (times the operator's blocks); not worth it when that is more than a quarter of the vector
       const long long nchunks = (range_len(g) / 4 + SAMPLE_RUN - 1) / SAMPLE_RUN;  // runs of 64 grid points
-      const long long target = ctl.runs > 0 ? ctl.runs : (g.N >= (1ll << 26) ? 32768 : 16384);   // one or two million sampled points
+      long long target = ctl.runs > 0 ? ctl.runs : (g.N >= (1ll << 26) ? 32768 : 16384);   // one or two million sampled points
+      if (hk) target = std::max<long long>(target / hk->world, 16);                // ... over all ranks
       const long long stride = nchunks / target;
+      double gcap = 0.2 * (double)fit_grid(range_len(g) / 4, SIPX_PASS_GRID) * (double)SPEC_CAP * (double)world;   // a fifth of the LDS buffers of the pass
+      if (hk && gcap > 0.8 * cap_max) gcap = 0.8 * cap_max;
       // (below 2^24 grid points the extra launch costs more than the sweeps it saves: 2048^2 loses 3 %; a test may force it)
       if (stride >= 4 && (g.N >= (1ll << 24) || ctl.runs > 0)) {
         const long long nsamp = nchunks / stride;
-        hipLaunchKernelGGL((k_sample<T, 4>), dim3((unsigned)(nsamp < SAMPLE_WG ? nsamp : SAMPLE_WG)), dim3(SAMPLE_NT), 0, s, g, a, ps, partials,
-                           nchunks, nsamp, (unsigned int)stride, true_len, l1_hw_max(), l1_lean_on(),
-                           0.2 * (double)fit_grid(range_len(g) / 4, SIPX_PASS_GRID) * (double)SPEC_CAP);     // a fifth of the LDS buffers of the pass
+        if (stage != 11)
+          hipLaunchKernelGGL((k_sample<T, 4>), dim3((unsigned)(nsamp < SAMPLE_WG ? nsamp : SAMPLE_WG)), dim3(SAMPLE_NT), 0, s, g, a, ps, partials,
+                             nchunks, nsamp, (unsigned int)stride, true_len, l1_hw_max(), l1_lean_on(), gcap, stage == 10 ? reg : (double*)nullptr);
+        else
+          hipLaunchKernelGGL((k_sample_decide2<T>), dim3(1), dim3(SAMPLE_NT), 0, s, ps, reg, a.phi, true_len, l1_hw_max(), l1_lean_on(), gcap);
       }
+    }
+    if (stage != 0) {
+      SIPX_HIP(hipGetLastError());
+      return;
     }
     SIPX_PASS(M_FIRST);
     if (a.prox == PX_L1 && !(a.flags & F_NOSPEC)) SIPX_PASS(M_LEAN);

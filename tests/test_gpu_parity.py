@@ -613,6 +613,14 @@ SLAB = [
 
 
 @pytest.mark.timeout(400)
+def test_slab_decomposed_with_the_sampled_prediction(sipx, tmp_path, monkeypatch):
+    """The sampled prediction of theta inside the slab-decomposed iteration (every rank samples its planes, one all-reduce of
+    the histograms), forced on for a grid this small: same end point as the serial solve, identical on every rank."""
+    monkeypatch.setenv("SIPX_L1_SAMPLE_RUNS", "96")
+    test_sharded_ranks_on_one_gpu(sipx, tmp_path, 2, ["bounds", "l1:D_x", "l1:D_y", "l1:D_z"], (64, 48, 40), False, decomp="slab")
+
+
+@pytest.mark.timeout(400)
 @pytest.mark.parametrize("world,kinds,n,phase", SLAB)
 def test_slab_decomposed_ranks_on_one_gpu(sipx, tmp_path, world, kinds, n, phase):
     """Serial == slab-decomposed to the reference's own serial-vs-parallel tolerance; every rank ends with identical x, y, l
