@@ -397,7 +397,7 @@ class Engine : public EngineBase {
       hooks_.allgather = [](void* u, void* buf, size_t chunk, int f64, hipStream_t q) {
         static_cast<Comm*>(u)->allgather(buf, chunk, f64 ? SIPX_F64 : SIPX_F32, q);
       };
-      hooks_.gcap = std::min<long long>(1ll << 18, (maxpad + 3) / 4 * 4);
+      hooks_.gcap = std::min<long long>(1ll << 17, (maxpad + 3) / 4 * 4);      // (the all-gather moves whole segments: 512 KB per l1 set and rank)
       int n2 = 0, nl1 = 0;
       for (auto& s : sets_) { n2 += s.two_pass ? 1 : 0; nl1 += (s.two_pass && s.prox == PX_L1) ? 1 : 0; }
       // the searches of all sets run in lock step: one staging buffer for their sums (one all-reduce per stage), one exchange

@@ -1270,7 +1270,7 @@ static void chain_stage(int stage, hipStream_t s, const Grid& g, const SetArgs<T
                         ProjScalars<T>* ps, double* partials, T* maxpart, T* compact, long long true_len, SampleCtl ctl,
                         const ChainHooks* hk, long long compact_len, double* reg, T* gseg0, long long chunk) {
   const int world = hk ? hk->world : 1, rank = hk ? hk->rank : 0;
-  const double cap_max = hk ? 0.5 * (double)hk->gcap : 0.0;
+  const double cap_max = hk ? (double)hk->gcap : 0.0;      // what ALL ranks gather together fits one rank's segment
   const bool vec = SRC == 1 && g.n[0] % 4 == 0;
   static const double capdiv = [] { const char* e = getenv("SIPX_L1_CAPDIV"); return e ? atof(e) : 64.0; }();
 #define SIPX_PASS(MODE)                                                                                            \
