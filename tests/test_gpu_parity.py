@@ -544,7 +544,7 @@ def test_converged_result_is_feasible(sipx):
 
 
 # ---- sharded solve on the real engine: several ranks sharing the one GPU, the engine's collectives over gloo ----------
-def _sharded_worker(rank, world, port, out, kinds, n, backend, mode, phase, decomp="sets"):
+def _sharded_worker(rank, world, port, out, kinds, n, backend, mode, phase, decomp="sets", tf="f32"):
     import os
     import sys
     import torch
@@ -564,7 +564,7 @@ def _sharded_worker(rank, world, port, out, kinds, n, backend, mode, phase, deco
         from __graft_entry__ import load_package
         sipx = load_package()
         from sipx import sharded
-        TF = np.float32
+        TF = np.float32 if tf == "f32" else np.float64
         h = (25.0, 25.0, 25.0)[:len(n)]
         m = model(n, TF, seed=5)
         gs, os_, Ps, As, props, AtAs = _problem(sipx, n, h, TF, kinds, m, dict(maxit=40))
@@ -613,6 +613,11 @@ SLAB = [
 
 
 @pytest.mark.timeout(400)
+def test_slab_decomposed_in_float64(sipx, tmp_path):
+    test_sharded_ranks_on_one_gpu(sipx, tmp_path, 3, ["bounds", "l1:D_x", "l1:D_z", "annulus"], (32, 24, 16), False, decomp="slab", tf="f64")
+
+
+@pytest.mark.timeout(400)
 def test_slab_decomposed_with_the_sampled_prediction(sipx, tmp_path, monkeypatch):
     """The sampled prediction of theta inside the slab-decomposed iteration (every rank samples its planes, one all-reduce of
     the histograms), forced on for a grid this small: same end point as the serial solve, identical on every rank."""
@@ -630,13 +635,13 @@ def test_slab_decomposed_ranks_on_one_gpu(sipx, tmp_path, world, kinds, n, phase
 
 @pytest.mark.timeout(400)
 @pytest.mark.parametrize("world,kinds,n,phase", SHARDED)
-def test_sharded_ranks_on_one_gpu(sipx, tmp_path, world, kinds, n, phase, decomp="sets"):
+def test_sharded_ranks_on_one_gpu(sipx, tmp_path, world, kinds, n, phase, decomp="sets", tf="f32"):
     """Serial == sharded to the reference's own tolerance (test/test_PARSDMM_parallel.jl:72,121: 5e-4 on x); every rank ends
     with identical x and logs; r_dual is filled (the reference's parallel mode leaves it zero)."""
     import os
     import torch.multiprocessing as mp
     port = 29600 + (os.getpid() % 2000) + 11 * world
-    mp.spawn(_sharded_worker, args=(world, port, str(tmp_path), kinds, n, "gloo", "torch", phase, decomp), nprocs=world, join=True)
+    mp.spawn(_sharded_worker, args=(world, port, str(tmp_path), kinds, n, "gloo", "torch", phase, decomp, tf), nprocs=world, join=True)
     r0 = np.load(tmp_path / "r0.npz")
     for r in range(1, world):
         r1 = np.load(tmp_path / f"r{r}.npz")
@@ -646,7 +651,7 @@ def test_sharded_ranks_on_one_gpu(sipx, tmp_path, world, kinds, n, phase, decomp
             a, b = np.load(tmp_path / "yl0.npz"), np.load(tmp_path / f"yl{r}.npz")
             for k in a.files:
                 assert np.array_equal(a[k], b[k], equal_nan=True), k
-    TF = np.float32
+    TF = np.float32 if tf == "f32" else np.float64
     h = (25.0, 25.0, 25.0)[:len(n)]
     m = model(n, TF, seed=5)
     gs, os_, Ps, As, props, AtAs = _problem(sipx, n, h, TF, kinds, m, dict(maxit=40))
