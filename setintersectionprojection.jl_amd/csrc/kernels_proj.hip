@@ -28,6 +28,7 @@
 
 namespace sipx {
 
+constexpr long long SOLVE_COOP_MIN_DEFAULT = 1ll << 17;
 constexpr double L1_CAP = 131072.0;     // bracket population above which one more probe pass is run (floor; scales with the length)
 constexpr int L1_REFINES = 1;           // gated refinement passes enqueued per search
 #ifndef SIPX_SPEC_CAP
@@ -37,6 +38,10 @@ constexpr int SPEC_CAP = SIPX_SPEC_CAP;  // per-workgroup LDS buffer of the spec
 // largest relative half-width of the speculative range (SIPX_L1_HWMAX overrides; A/B switch)
 static int l1_lean_on() {       // SIPX_L1_LEAN=0: every first pass evaluates all eight probes (A/B switch)
   static const int v = [] { const char* e = getenv("SIPX_L1_LEAN"); return e ? atoi(e) : 1; }();
+  return v;
+}
+static long long solve_coop_min() {      // SIPX_SOLVE_COOP_MIN: gathered values from which the sweeps of the solve are shared (A/B switch)
+  static const long long v = [] { const char* e = getenv("SIPX_SOLVE_COOP_MIN"); return e ? atoll(e) : SOLVE_COOP_MIN_DEFAULT; }();
   return v;
 }
 static double l1_hw_max() {
@@ -877,13 +882,13 @@ __device__ __forceinline__ DD wave_sum_dd(DD v) {
 // The workgroup that finishes last writes theta and prepares the next call (nobody may reset the state while another
 // workgroup has yet to read it).
 constexpr int SOLVE_G = 32;
-constexpr long long SOLVE_COOP_MIN = 1ll << 17;
+constexpr long long SOLVE_COOP_MIN = 1ll << 17;      // (documentation of the default; see solve_coop_min())
 static_assert(SOLVE_G <= SIPX_SOLVE_SLOTS, "ProjScalars holds SIPX_SOLVE_SLOTS cooperative slots");
 
 template <typename T>
 __global__ __launch_bounds__(SIPX_SOLVE_NT) void k_l1_solve(ProjScalars<T>* ps, T radius, const T* __restrict__ compact,
                                                    const double* __restrict__ partials, long long true_len, double hw_max,
-                                                   int lean_on, int* host_want) {
+                                                   int lean_on, int* host_want, long long coop_min) {
   constexpr int NT = SIPX_SOLVE_NT;
   __shared__ double ssum[NT / 64];
   __shared__ double ssum_lo[NT / 64];
@@ -893,7 +898,7 @@ __global__ __launch_bounds__(SIPX_SOLVE_NT) void k_l1_solve(ProjScalars<T>* ps, 
   const int need = ps->need;
   const int G = (int)gridDim.x, wg = (int)blockIdx.x;
   const long long n_all = need ? (long long)ps->n_compact : 0;
-  const bool coop = G > 1 && n_all >= SOLVE_COOP_MIN;
+  const bool coop = G > 1 && n_all >= coop_min;
   if (!coop && wg != 0) return;
   double theta = 0;
   int iters_done = 0;
@@ -1029,6 +1034,7 @@ __global__ __launch_bounds__(SIPX_SOLVE_NT) void k_l1_solve(ProjScalars<T>* ps, 
     ps->want_sample = 0;
     if (need && theta > 0) {
       double hw = ps->hw;
+      if (!(ps->theta_prev > 0)) ps->want_sample = 1;      // the first theta of this set: nothing is known about how it moves
       if (ps->theta_prev > 0) {
         const double d = fabs(theta / ps->theta_prev - 1.0);
         // theta moved by more than a third of the widest speculative range (or the last search needed its fallback sweeps):
@@ -1327,7 +1333,7 @@ static void chain_stage(int stage, hipStream_t s, const Grid& g, const SetArgs<T
   } else if (a.prox == PX_L1) {
     if (hk) hipLaunchKernelGGL((k_gather_unpack<T>), dim3(64), dim3(BLOCK), 0, s, ps, compact, partials, gseg0, chunk, world, compact_len);
     hipLaunchKernelGGL((k_l1_solve<T>), dim3(hk ? 1 : SOLVE_G), dim3(SIPX_SOLVE_NT), 0, s, ps, a.phi, compact, partials, true_len, l1_hw_max(),
-                       l1_lean_on(), ctl.host_want);
+                       l1_lean_on(), ctl.host_want, solve_coop_min());
   }
 #undef SIPX_PASS
   SIPX_HIP(hipGetLastError());
