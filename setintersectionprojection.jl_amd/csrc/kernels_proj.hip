@@ -516,17 +516,19 @@ __global__ __launch_bounds__(64) void k_decide(ProjScalars<T>* ps, int prox, T p
 // ---------------------------------------------------------------------------------------------
 // SAMPLED PREDICTION of theta.  While rho and gamma are still being adapted, theta moves by up to a factor of three from one
 // PARSDMM iteration to the next: the speculative gather around the previous theta fails and the search pays two more sweeps
-// of the vector (refinement + compaction, 6 N w bytes per set).  A sweep over a SAMPLE of the vector (every stride-th chunk
-// of 1024 grid points, chunk chosen by a hash inside its group so that no lattice direction is favoured; about a million
-// entries) costs a hundredth of that and predicts theta to a few tenths of a percent: the sampled magnitudes go into a
-// histogram (bin key = leading bits of the floating-point pattern, 256 bins per octave, 8 octaves around the old prediction;
-// counts and FIXED-POINT sums through integer atomics, so the totals do not depend on the order of arrival), a one-workgroup
-// kernel takes suffix sums and finds the bin in which f_sample(t) = sum(max(|v|-t,0)) - b n_sample/n changes sign.  (S, C) at
+// of the vector (refinement + compaction, 6 N w bytes per set).  A sweep over a SAMPLE of the vector (every stride-th run of
+// 64 consecutive entries, the run inside its group chosen by a hash so that no lattice direction is favoured -- neighbouring
+// entries are correlated, so many short runs beat few long ones; about a million entries) costs a hundredth of that and
+// predicts theta to a few tenths of a percent: the sampled magnitudes go into a histogram (bin key = leading bits of the
+// floating-point pattern, 128 bins per octave, 8 octaves around the old prediction; count and FIXED-POINT sum packed in one
+// word and added through integer atomics, so the totals do not depend on the order of arrival), the workgroup that finishes
+// last takes suffix sums and finds the bin in which f_sample(t) = sum(max(|v|-t,0)) - b n_sample/n changes sign.  (S, C) at
 // the bin's edges are exact for the sample, so its root lies between the Newton step from the lower edge and the secant
 // (f is convex) whatever the density inside the bin does -- near convergence the magnitudes pile up right at theta.  That
 // interval, widened by four standard deviations of the sampling error sqrt(sum_sample max(|v|-theta,0)^2) / C, becomes the
-// speculative range of the first pass, which is then a lean one.  Nothing of the result depends on the sample: a miss is
-// caught by the pass's own bracket test and costs the fallback sweeps it would have cost anyway.
+// speculative range of the first pass (shrunk again if the bins it covers promise more than the gather can hold), which is
+// then a lean one.  Nothing of the result depends on the sample: a miss is caught by the pass's own bracket test and costs
+// the fallback sweeps it would have cost anyway.
 template <typename T>
 struct KeyBits;
 template <>

@@ -42,7 +42,7 @@ constexpr int L1_K = 8;          // probe thresholds of the l1-ball threshold se
 #define SIPX_MAX_WORLD 64        // most ranks of a slab-decomposed solve (per-rank max / min entries in ProjScalars)
 constexpr int GATHER_HDR = 8;    // TF elements in front of a rank's segment of gathered magnitudes (read as doubles: count, S_above, C_above)
 constexpr int PREP_SLOTS = 3 + 2 * L1_K;   // ||v||_1, ||v||_2^2, nnz, S_k, C_k
-// Sampled prediction of the l1 threshold (k_sample / k_sample_decide): histogram of the sampled magnitudes over
+// Sampled prediction of the l1 threshold (k_sample, sample_decide): histogram of the sampled magnitudes over
 // SAMPLE_BINS bins of 2^-SAMPLE_MBITS of an octave each (the bin key is the leading bits of the floating-point pattern),
 // centred on the predicted theta
 constexpr int SAMPLE_BINS = 1024;
@@ -158,7 +158,7 @@ struct ProjScalars {
   unsigned samp_ticket;   // arrivals of k_sample's workgroups (the last one decides)
   int rescaled, resc_bad;   // the coming search follows k_ps_rescale; the last rescaled prediction missed its range
   int want_sample;    // the prediction of the coming search is not trusted (theta moved, or rho was changed): sample first
-  int sampled;        // the probes of the coming first pass were centred by k_sample_decide (diagnostics: dbg_sampled)
+  int sampled;        // the probes of the coming first pass were centred by the sampled prediction (diagnostics: dbg_sampled)
   int dbg_sampled;
   double samp_theta;  // the sampled estimate itself
   double samp_lo, samp_hi, samp_c;   // diagnostics: Newton / secant bounds of the sample's root, active sample count
