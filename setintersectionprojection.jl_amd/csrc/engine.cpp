@@ -177,7 +177,7 @@ class Engine : public EngineBase {
     (void)hipSetDevice(device_);
     (void)hipStreamSynchronize(stream_);
     for (auto& s : sets_) free_set(s);
-    for (void* p : {(void*)w_base_, (void*)x_base_, (void*)xold_, (void*)rhs_, (void*)m_base_, (void*)r_, (void*)p_base_, (void*)Ap_, (void*)Q_,
+    for (void* p : {(void*)w_base_, (void*)x_base_, (void*)xold_, (void*)rhs_, (void*)m_base_, (void*)r_base_, (void*)p_base_, (void*)p2_base_, (void*)Ap_, (void*)Q_,
                     (void*)scr_v_, (void*)scr_c_, (void*)scr_i_, (void*)scr_w_, (void*)part_cg_, (void*)part_tmp_, (void*)part_sets_,
                     (void*)maxpart_, (void*)cg_dev_, (void*)dres_, (void*)gbuf_, (void*)stage_, (void*)sstage_})
       dfree(p);
@@ -372,7 +372,17 @@ class Engine : public EngineBase {
     xold_ = dalloc<T>(Nx_); rhs_ = dalloc<T>(Npad);
     if (mk_) { w_base_ = dalloc<T>(N + 2 * halo_); w_ = w_base_ + halo_; }   // u + v, read through the stencils
     m_base_ = dalloc<T>(N + 2 * halo_); m_ = m_base_ + halo_;   // forward stencils of A m read past the end
-    r_ = dalloc<T>(Nx_); Ap_ = dalloc<T>(Nx_);
+    r_base_ = dalloc<T>(Nx_ + 2 * halo_); r_ = r_base_ + halo_;      // (halo: the fused CG product reads r through the bands)
+    Ap_ = dalloc<T>(Nx_);
+    {
+      // CG iterations from the second on as ONE kernel (scalar step + product on p = r + beta p_old formed on the fly,
+      // k_cds_fused): one launch and a host round trip less per iteration -- what a launch-bound grid (2048^2) is made of --
+      // against a product that reads two vectors instead of one.  SIPX_CG_FUSED=0 / 1 forces it off / on.
+      const char* e = std::getenv("SIPX_CG_FUSED");
+      const bool small = Nx_ <= (1ll << 23);
+      cg_fused_ = !comm_ && !stencil_q_ && (e ? e[0] == '1' : small);
+      if (cg_fused_) { p2_base_ = dalloc<T>(Nx_ + 2 * halo_); p2_ = p2_base_ + halo_; }
+    }
     SIPX_HIP(hipMemcpy(m_, m, N * sizeof(T), hipMemcpyHostToDevice));
     long long maxpad = N;
     for (auto& s : sets_) maxpad = std::max(maxpad, s.Mpad);
@@ -663,6 +673,21 @@ class Engine : public EngineBase {
       if (comm_) comm_->allreduce_sum(part_cg_ + NB, NB, SIPX_F64, stream_);
       K<T>::cg_update_p(stream_, nloc, p_ + r0, r_ + r0, part_cg_, cg_dev_, mirror, (unsigned long long*)ticket_);
     };
+    // Fused form (cg_fused_): iteration 1 = product on p_1 (= r_0, in p_), x / r update, then the fused kernel of iteration 2
+    // queued at once; iteration k >= 2 = x / r update on the p_k and A p_k the fused kernel left, then the fused kernel of
+    // iteration k + 1.  p_k lives in p_ for odd k, in p2_ for even k.
+    auto enqueue_fused = [&](int k) {
+      CgState<T>* mirror = cg_host_ + (k & 1);
+      T* pk = (k & 1) ? p_ : p2_;
+      T* pn = (k & 1) ? p2_ : p_;
+      if (k == 1) {
+        if (stats_on_) stat_mark();
+        K<T>::spmv_dot(stream_, Nx_, r0, r1, Q_, cds_, p_, Ap_, part_cg_, cg_dev_);
+        if (stats_on_) stat_mark();
+      }
+      K<T>::cg_update_xr(stream_, nloc, x_, k == 1 ? p_ : r_, r_, pk, Ap_, part_cg_, cg_dev_, mirror, k, (unsigned long long*)ticket_);
+      K<T>::spmv_fused(stream_, Nx_, Q_, cds_, r_, pk, pn, Ap_, part_cg_, cg_dev_, mirror, (unsigned long long*)ticket_);
+    };
     // (no event is recorded inside this loop: a record costs the stream about 5 us, more than the p-update of a small grid)
     // The first iteration is queued before the verdict of k_cg_begin is back: it is almost always needed, and its kernels
     // return at once on the device-side `done` flag when it is not (zero right-hand side, cg.jl:51; x already solves the
@@ -671,7 +696,8 @@ class Engine : public EngineBase {
     // awaited first, so that rocprofv3's per-kernel averages hold launches with work only.
     const size_t stat0 = stat_used_;
     const bool ahead = it > 1;
-    if (ahead) enqueue(1);
+    auto enq = [&](int k) { if (cg_fused_) enqueue_fused(k); else enqueue(k); };
+    if (ahead) enq(1);
     bool done = wait_ticket(seq, 0, cg_host_);
     CgState<T> fin;
     if (done) {
@@ -681,13 +707,13 @@ class Engine : public EngineBase {
     } else {
       const int maxIter = 1000;                       // argmin_x.jl:39
       int iter = 1;
-      if (!ahead) enqueue(1);
+      if (!ahead) enq(1);
       // (Queueing iteration k+1 before the verdict of k -- under a kernel name of its own -- was measured on the small
       // grid where the p-update is shorter than the round trip, 2048^2: 1940 against 2040 it/s.  Not adopted.)
       for (;;) {
         done = wait_ticket(seq, iter, cg_host_ + (iter & 1));
         if (done || iter == maxIter) break;
-        enqueue(++iter);
+        enq(++iter);
       }
       fin = cg_host_[iter & 1];         // written before the ticket (release / acquire): complete
     }
@@ -2018,7 +2044,8 @@ class Engine : public EngineBase {
   int p_n_ = 0, pp_n_ = 0;
   std::vector<T> rho_, gamma_;
   std::vector<double> feas_init_;
-  T *x_base_ = nullptr, *p_base_ = nullptr, *m_base_ = nullptr;
+  T *x_base_ = nullptr, *p_base_ = nullptr, *m_base_ = nullptr, *r_base_ = nullptr, *p2_base_ = nullptr, *p2_ = nullptr;
+  bool cg_fused_ = false;
   long long halo_ = 0;
   T *x_ = nullptr, *xold_ = nullptr, *rhs_ = nullptr, *m_ = nullptr, *r_ = nullptr, *p_ = nullptr, *Ap_ = nullptr;
   T *Q_ = nullptr, *scr_v_ = nullptr, *scr_c_ = nullptr, *maxpart_ = nullptr;

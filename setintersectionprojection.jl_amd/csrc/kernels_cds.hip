@@ -29,9 +29,30 @@ namespace sipx {
 // outside [0,N) are masked by a select, which keeps the reference's "skip" semantics bit for bit.
 // All 2d loads of a row group are independent and issue back to back (measured +30% over the
 // bounds-checked version, profiles/r01_spmv_designspace_*.txt).
-template <typename T, int V, int D>
-__device__ __forceinline__ void cds_rows(long long N, const T* __restrict__ R, const CdsArgs& a,
-                                         const T* __restrict__ x, long long r, T (&acc)[V]) {
+// How the vector of a product is read at position c (element aligned): a stored array, or -- CG iterations from the second
+// on, on grids where it pays -- p_{k+1} = r_{k+1} + beta p_k formed on the fly from the two stored arrays (see k_cds_fused).
+template <typename T, int V>
+struct LoadStored {
+  const T* __restrict__ x;
+  __device__ __forceinline__ Vec<T, V> operator()(long long c) const { return ldv_u<T, V>(x + c); }
+};
+template <typename T, int V>
+struct LoadFused {
+  const T* __restrict__ r;
+  const T* __restrict__ p;
+  T beta;
+  __device__ __forceinline__ Vec<T, V> operator()(long long c) const {
+    const Vec<T, V> rv = ldv_u<T, V>(r + c), pv = ldv_u<T, V>(p + c);
+    Vec<T, V> o;
+#pragma unroll
+    for (int k = 0; k < V; ++k) o.v[k] = rv.v[k] + beta * pv.v[k];      // the arithmetic of k_cg_update_p (cg.jl:114)
+    return o;
+  }
+};
+
+template <typename T, int V, int D, typename XL>
+__device__ __forceinline__ void cds_rows(long long N, const T* __restrict__ R, const CdsArgs& a, const XL& xl, long long r,
+                                         T (&acc)[V]) {
   const int d = D ? D : a.d;
 #pragma unroll
   for (int k = 0; k < V; ++k) acc[k] = T(0);
@@ -47,7 +68,7 @@ __device__ __forceinline__ void cds_rows(long long N, const T* __restrict__ R, c
       } else {
         rv[b] = ldv_nt<T, V>(R + (long long)b * N + r);
       }
-      xv[b] = ldv_u<T, V>(x + r + a.off[b]);
+      xv[b] = xl(r + a.off[b]);
     }
 #pragma unroll
     for (int b = 0; b < D; ++b) {
@@ -64,7 +85,7 @@ __device__ __forceinline__ void cds_rows(long long N, const T* __restrict__ R, c
       const Vec<T, V> rv = !a.sym ? ldv_nt<T, V>(R + (long long)b * N + r)
                                   : (a.off[b] >= 0 ? ldv<T, V>(R + (long long)b * N + r)
                                                    : ldv_u<T, V>(R + (long long)a.partner[b] * N + c));
-      const Vec<T, V> xv = ldv_u<T, V>(x + c);
+      const Vec<T, V> xv = xl(c);
 #pragma unroll
       for (int k = 0; k < V; ++k) {
         const T t = acc[k] + rv.v[k] * xv.v[k];
@@ -89,7 +110,7 @@ __global__ __launch_bounds__(BLOCK) void k_cds(long long N, long long r0, long l
   for (long long vi = r0 / V + (long long)blockIdx.x * BLOCK + threadIdx.x; vi < nvec; vi += (long long)gridDim.x * BLOCK) {
     const long long r = vi * V;
     T s[V];
-    cds_rows<T, V, D>(N, R, a, x, r, s);
+    cds_rows<T, V, D>(N, R, a, LoadStored<T, V>{x}, r, s);
     if (MODE == 0) {
       Vec<T, V> o;
 #pragma unroll
@@ -595,6 +616,83 @@ void K<T>::cg_update_p(hipStream_t s, long long N, T* p, const T* r, const doubl
   SIPX_HIP(hipGetLastError());
 }
 
+// CG iterations from the second on, fused (grids where it pays, one rank): the scalar step that k_cg_update_p opens with
+// (resvec, stop test, beta; cg.jl:100-110) followed by the NEXT product taken directly on p_{k+1} = r_{k+1} + beta p_k, which
+// is formed on the fly wherever a band needs it (same arithmetic as k_cg_update_p, so the same bits) and stored once, by the
+// thread that owns the row.  One launch and the 3 N w bytes of the p-update less per iteration (the product reads r and p_k
+// instead of p_{k+1}: + 1 N w, and writes p_{k+1}: + 1 N w), and the kernel is queued right behind the x / r update without
+// waiting for the host: when the iteration it belongs to does not run it returns at once, as k_cg_update_p does when CG has
+// converged.  p_k and p_{k+1} live in two arrays that take turns (a neighbour may still need p_k after this row's p_{k+1} is out).
+// The 3 d loads of a row group cost registers (154 VGPRs at d = 5: three waves per SIMD; capping them at 128 / 96 spills and
+// loses what the fusion gains), so the kernel itself is no faster than product + p-update; what it saves is the launch and
+// the round trip: 2048^2 1990 -> 2057 it/s, 256^3 unchanged (there the unfused form stays the default).
+template <typename T, int V, int D>
+__global__ __launch_bounds__(BLOCK) void k_cds_fused(long long N, const T* __restrict__ R, CdsArgs a, const T* __restrict__ r,
+                                                     const T* __restrict__ p_old, T* __restrict__ p_new, T* __restrict__ Ap,
+                                                     double* __restrict__ partials, CgState<T>* __restrict__ st,
+                                                     CgState<T>* __restrict__ host, unsigned long long* ticket) {
+  if (st->done) return;
+  const double ss = block_sum_partials(partials + NB);
+  const T rr = (T)ss;
+  const T res = (T)sqrt(ss) / st->nr0;      // cg.jl:100
+  const bool conv = res <= st->tol;         // cg.jl:104-106
+  const T beta = rr / st->gamma;            // cg.jl:110 (gamma: written by the x / r update)
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    st->ss = ss;
+    st->res_last = res;
+    if (conv) {
+      st->flag = 0;
+      st->done = 1;
+    } else {
+      st->beta = beta;
+    }
+    st->rr = rr;
+    *host = *st;
+    publish_ticket(ticket, st->seq, st->iters, conv ? 1 : 0);
+  }
+  if (conv) return;
+  const LoadFused<T, V> xl{r, p_old, beta};
+  const long long nvec = N / V;
+  double acc0 = 0;
+  for (long long vi = (long long)blockIdx.x * BLOCK + threadIdx.x; vi < nvec; vi += (long long)gridDim.x * BLOCK) {
+    const long long row = vi * V;
+    T s[V];
+    cds_rows<T, V, D>(N, R, a, xl, row, s);
+    const Vec<T, V> pv = xl(row);
+    Vec<T, V> o;
+#pragma unroll
+    for (int k = 0; k < V; ++k) {
+      o.v[k] = s[k];
+      acc0 += (double)pv.v[k] * (double)s[k];
+    }
+    stv<T, V>(p_new + row, pv);
+    stv_nt<T, V>(Ap + row, o);
+  }
+  double acc[1] = {acc0};
+  block_reduce_store<1>(acc, partials, 0);
+}
+template <typename T>
+void K<T>::spmv_fused(hipStream_t s, long long N, const T* R, const CdsArgs& a, const T* r, const T* p_old, T* p_new, T* Ap,
+                      double* partials, CgState<T>* st, CgState<T>* host, unsigned long long* ticket) {
+  if (a.d < 1 || a.d > MAXD) throw std::runtime_error("cds: band count out of range");
+#define SIPX_CDSF(V, D) \
+  hipLaunchKernelGGL((k_cds_fused<T, V, D>), dim3(fit_grid(N / V, SIPX_CG_GRID)), dim3(BLOCK), 0, s, N, R, a, r, p_old, p_new, Ap, partials, st, host, ticket)
+  constexpr int VW = sizeof(T) == 8 ? SIPX_F64_VEC : 4;
+  if (N % 4 == 0) {
+    switch (a.d) {
+      case 1: SIPX_CDSF(VW, 1); break;
+      case 3: SIPX_CDSF(VW, 3); break;
+      case 5: SIPX_CDSF(VW, 5); break;
+      case 7: SIPX_CDSF(VW, 7); break;
+      default: SIPX_CDSF(VW, 0); break;
+    }
+  } else {
+    SIPX_CDSF(1, 0);
+  }
+#undef SIPX_CDSF
+  SIPX_HIP(hipGetLastError());
+}
+
 // ---------------------------------------------------------------------------------------------
 // out[slot] = sum of the NB partials of each slot (one block per slot, fixed order)
 __global__ __launch_bounds__(BLOCK) void k_fin_sum(const double* __restrict__ partials, double* __restrict__ out_dev,
@@ -616,6 +714,8 @@ void K<T>::fin_sum(hipStream_t s, const double* partials, int nslots, double* ou
   template void K<T>::spmv(hipStream_t, const Grid&, long long, const T*, const CdsArgs&, const T*, T*);             \
   template void K<T>::spmv_dot(hipStream_t, long long, long long, long long, const T*, const CdsArgs&, const T*, T*, \
                                double*, const CgState<T>*);                                                           \
+  template void K<T>::spmv_fused(hipStream_t, long long, const T*, const CdsArgs&, const T*, const T*, T*, T*, double*, \
+                                 CgState<T>*, CgState<T>*, unsigned long long*);                                      \
   template void K<T>::resid(hipStream_t, long long, long long, long long, const T*, const CdsArgs&, const T*, const T*, T*, \
                             T*, T*, double*);                                                                         \
   template void K<T>::q_axpy(hipStream_t, long long, T*, const T*, T);                                               \

@@ -270,6 +270,10 @@ struct K {
                        double* partials, const CgState<T>* st);
   static void resid(hipStream_t s, long long N, long long r0, long long r1, const T* R, const CdsArgs& a, const T* x, const T* b,
                     T* r, T* p, T* xold, double* partials);
+  // the scalar step of CG iteration k (stop test, beta) + the product of iteration k+1 on p = r + beta p_old formed on the fly
+  // (r, p_old carry a zero halo); writes p_new, Ap and the partials of p_new . Ap
+  static void spmv_fused(hipStream_t s, long long N, const T* R, const CdsArgs& a, const T* r, const T* p_old, T* p_new, T* Ap,
+                         double* partials, CgState<T>* st, CgState<T>* host, unsigned long long* ticket);
   static void sq_spmv(hipStream_t s, const Grid& g, const StencilQ<T>& q, const T* x, T* y);
   static void sq_spmv_dot(hipStream_t s, const Grid& g, const StencilQ<T>& q, const T* p, T* Ap, double* partials,
                           const CgState<T>* st);

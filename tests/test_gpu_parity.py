@@ -1657,3 +1657,22 @@ def test_sampled_prediction_of_the_l1_threshold_changes_nothing(sipx, TF, monkey
     assert np.allclose(res["on"][1], res["off"][1], rtol=50 * tol, atol=0)
     assert np.allclose(res["on"][2], res["off"][2], rtol=50 * tol, atol=0)
     assert np.linalg.norm(res["on"][0] - res["off"][0]) <= tol * np.linalg.norm(res["off"][0])
+
+
+@pytest.mark.parametrize("TF", [np.float32, np.float64])
+def test_fused_cg_iterations_are_bit_identical(sipx, TF, monkeypatch):
+    """CG iterations from the second on as one kernel (k_cds_fused: scalar step + product on p = r + beta p_old formed on the
+    fly; the default on grids up to 2^23 points) against the three-kernel form (SIPX_CG_FUSED=0): same arithmetic, so the same
+    bits -- x, the CG iteration counts and residuals, every log."""
+    n = (48, 40, 24)
+    m, g, opt, P, A, prop, AtA = _c3_problem(sipx, n, TF, maxit=30)
+    out = {}
+    for tag in ("0", "1"):
+        monkeypatch.setenv("SIPX_CG_FUSED", tag)
+        x, log, l, y = sipx.PARSDMM(m.copy(), AtA, A, prop, P, g, opt)
+        out[tag] = (x, log)
+    (x0, l0), (x1, l1) = out["0"], out["1"]
+    assert l0.cg_it.sum() > len(l0.cg_it)                       # iterations beyond the first did run
+    assert np.array_equal(l0.cg_it, l1.cg_it) and np.array_equal(l0.cg_relres, l1.cg_relres)
+    assert np.array_equal(x0, x1) and np.array_equal(l0.obj, l1.obj) and np.array_equal(l0.r_pri, l1.r_pri)
+    assert np.array_equal(l0.rho, l1.rho)
