@@ -312,7 +312,8 @@ class Engine : public EngineBase {
           throw std::runtime_error("the slab decomposition needs sets whose projector works on sums over the grid (set " + std::to_string(i) + " does not): use the set decomposition");
         sets_[i].owned = true;
       }
-      set_streams_ = false;        // one stream: the collectives inside the threshold searches are issued in one order on every rank
+      // (the searches with their collectives run on the engine stream, in one order on every rank; the y/l updates that
+      // follow have no collectives inside and are dealt onto the set streams as usual)
     }
     const long long N = G_.N;
     // rho, gamma (PARSDMM_initialize.jl:58-63,107-114,159)
@@ -501,6 +502,7 @@ class Engine : public EngineBase {
         s.mpart = dalloc<T>(2 * NB);
         s.cbuf = dalloc<T>(s.Mpad);
       }
+      const bool had_scratch = s.ptmp != nullptr;
       if (set_streams_ && !s.ext_kind && s.prox != PX_CARD) {     // those two share the engine-wide scratch: main stream
         if ((int)pool_.size() < n_set_streams_) {
           // the engine stream itself is the first of the set streams: the set dealt onto it starts right behind the x-step,
@@ -511,7 +513,7 @@ class Engine : public EngineBase {
         }
         s.st = pool_[pool_next_++ % pool_.size()];
         SIPX_HIP(hipEventCreateWithFlags(&s.ev, hipEventDisableTiming));
-        if (s.two_pass) {
+        if (s.two_pass && !had_scratch) {
           s.ptmp = dalloc<double>((size_t)(PREP_SLOTS + 2) * NB);
           s.mpart = dalloc<T>(2 * NB);
           s.cbuf = dalloc<T>(s.Mpad);
@@ -737,7 +739,7 @@ class Engine : public EngineBase {
     need_final();
     (void)it;
     if (mk_) K<T>::sum_uv(stream_, G_.N, x_, x_ + G_.N, w_);
-    if (set_streams_) SIPX_HIP(hipEventRecord(ev_fork_, stream_));     // x (and u + v) are final: the sets may start
+    if (set_streams_ && !slab_) SIPX_HIP(hipEventRecord(ev_fork_, stream_));     // x (and u + v) are final: the sets may start
     if (slab_) {
       // Slab-decomposed iteration: the threshold / scale searches of ALL sets in lock step -- every rank sweeps its planes,
       // ONE all-reduce makes the probe sums of all sets global (twice: first pass, gated refinement), ONE all-gather strings
@@ -795,6 +797,7 @@ class Engine : public EngineBase {
         }
       }
     }
+    if (set_streams_ && slab_) SIPX_HIP(hipEventRecord(ev_fork_, stream_));      // the searches are done: the updates may start
     for (int i = 0; i < p_n_; ++i) {
       SetState<T>& s = sets_[i];
       if (!s.owned || s.dist_ext) continue;
@@ -802,10 +805,12 @@ class Engine : public EngineBase {
       if (mk_) a.x = s.comp == 1 ? x_ : (s.comp == 2 ? x_ + G_.N : w_);
       double* part = part_sets_ + (size_t)i * SLOTS * NB;
       hipStream_t q = s.st ? s.st : stream_;
+      // slab-decomposed: a feasibility search carries collectives -- those stay on the engine stream, in one order on every rank
+      if (slab_ && (flags & SIPX_YL_FEAS) && s.two_pass && i < pp_n_) q = stream_;
       double* ptmp = s.ptmp ? s.ptmp : part_tmp_;
       T* mpart = s.mpart ? s.mpart : maxpart_;
       T* cbuf = s.cbuf ? s.cbuf : scr_c_;
-      if (s.st && s.st != stream_) SIPX_HIP(hipStreamWaitEvent(s.st, ev_fork_, 0));
+      if (q != stream_) SIPX_HIP(hipStreamWaitEvent(q, ev_fork_, 0));
       // where y_new, l_new go (see SetState): snapshot iterations overwrite the old snapshot, the others stay off it
       const bool snapshot = (flags & (SIPX_YL_BB | SIPX_YL_FIRST)) != 0;
       const bool first = (flags & SIPX_YL_FIRST) != 0;
