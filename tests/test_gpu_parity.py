@@ -1659,6 +1659,41 @@ def test_sampled_prediction_of_the_l1_threshold_changes_nothing(sipx, TF, monkey
     assert np.linalg.norm(res["on"][0] - res["off"][0]) <= tol * np.linalg.norm(res["off"][0])
 
 
+@pytest.mark.parametrize("kind", ["blocky", "spiky", "wide"])
+def test_sampled_prediction_on_hostile_models(sipx, kind, monkeypatch):
+    """Models that make a sampled estimate useless -- piecewise constant (almost every difference is zero, a few are huge),
+    a few spikes on a flat background, magnitudes spread over twenty octaves: whatever the estimate says, the end point must
+    be the one of the unsampled search (a miss only costs the fallback sweeps) and every log finite."""
+    TF, n = np.float32, (64, 48, 40)
+    rng = np.random.default_rng(3)
+    if kind == "blocky":
+        m = np.repeat(np.repeat(np.repeat(rng.uniform(1500, 4500, (8, 6, 5)), 8, 0), 8, 1), 8, 2)
+    elif kind == "spiky":
+        m = np.full(n, 2500.0)
+        m.reshape(-1)[rng.choice(m.size, 200, replace=False)] += rng.uniform(500, 2000, 200)
+    else:
+        m = 2500.0 + np.exp(rng.uniform(-20, 7, n)) * rng.choice([-1.0, 1.0], n)
+    m = m.astype(TF).reshape(-1, order="F")
+    h = (25.0, 25.0, 25.0)
+    g = sipx.compgrid(h, n)
+    c = [sipx.set_definitions("bounds", "identity", 1600.0, 4400.0, ("matrix", ""))]
+    for k in ("D_x", "D_z", "TV"):
+        s_ = sipx.get_TD_operator(g, k, TF)[0] @ m
+        c.append(sipx.set_definitions("l1", k, 0.0, float(0.3 * np.abs(s_.astype(np.float64)).sum()), ("matrix", "")))
+    P, A, prop = sipx.setup_constraints(c, g, TF)
+    opt = sipx.PARSDMM_options(FL=TF, maxit=30, evol_rel_tol=0.0, feas_tol=0.0, obj_tol=0.0)
+    A, AtA, l, y = sipx.PARSDMM_precompute_distribute(A, prop, g, opt)
+    out = {}
+    for tag, env in (("off", {"SIPX_L1_SAMPLE": "0"}), ("on", {"SIPX_L1_SAMPLE": "1", "SIPX_L1_SAMPLE_RUNS": "64"})):
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        x, log, _, _ = sipx.PARSDMM(m.copy(), AtA, A, prop, P, g, opt)
+        assert np.isfinite(log.obj).all() and np.isfinite(log.r_pri).all() and np.isfinite(x).all()
+        out[tag] = (x.astype(np.float64), log)
+    assert len(out["on"][1].obj) == len(out["off"][1].obj)
+    assert np.linalg.norm(out["on"][0] - out["off"][0]) <= 2e-6 * np.linalg.norm(out["off"][0])
+
+
 @pytest.mark.parametrize("TF", [np.float32, np.float64])
 def test_fused_cg_iterations_are_bit_identical(sipx, TF, monkeypatch):
     """CG iterations from the second on as one kernel (k_cds_fused: scalar step + product on p = r + beta p_old formed on the
