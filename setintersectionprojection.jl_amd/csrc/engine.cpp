@@ -1023,7 +1023,12 @@ class Engine : public EngineBase {
     if (!c || !c->finalized_) throw std::runtime_error("warm start: the coarse context must be a finalized context of the same precision");
     if (c->device_ != device_) throw std::runtime_error("warm start: both levels must live on one device");
     if (c->p_n_ != p_n_ || c->ndim_ != ndim_ || mk_ || c->mk_) throw std::runtime_error("warm start: the two levels must hold the same sets");
-    if (comm_ || c->comm_) throw std::runtime_error("warm start between levels is not available for sharded contexts");
+    if ((comm_ != nullptr) != (c->comm_ != nullptr) || (comm_ && !(slab_ && c->slab_)))
+      throw std::runtime_error("warm start between levels of a sharded solve needs both levels slab-decomposed (sipx_set_decomp)");
+    if (c->slab_) {      // the coarse iterate, whole on every rank (a collective); the resampling below is then local and the
+      std::vector<char> all(c->p_n_, 1);      // fine level starts from arrays that are complete -- slab, halo planes and all
+      c->gather_slabs(true, all, all);
+    }
     SIPX_HIP(hipStreamSynchronize(c->stream_));
     long long nc[3], nf[3];
     for (int a = 0; a < 3; ++a) { nc[a] = c->G_.n[a]; nf[a] = G_.n[a]; }
@@ -1080,23 +1085,31 @@ class Engine : public EngineBase {
     dfree(rf);
   }
 
+  // Slab-decomposed context: completes x and / or the y_i, l_i named on every rank from the ranks' slabs (all-gathers on the
+  // engine stream; afterwards the arrays are whole and identical everywhere).  A collective.
+  void gather_slabs(bool want_x, const std::vector<char>& want_l, const std::vector<char>& want_y) {
+    const int dt = dtype_code();
+    if (want_x) comm_->allgather(x_, (size_t)chunk_, dt, stream_);
+    for (int i = 0; i < p_n_; ++i)
+      for (int which = 0; which < 2; ++which) {
+        if (!(which ? want_y[i] : want_l[i])) continue;
+        T* arr = which ? sets_[i].y : sets_[i].l;
+        const int nb = sets_[i].nblk > 0 ? sets_[i].nblk : 1;
+        for (int q = 0; q < nb; ++q) {
+          T* blk = arr + (long long)q * G_.N;
+          if (r1_ > r0_) SIPX_HIP(hipMemcpyAsync(scr_v_ + r0_, blk + r0_, (r1_ - r0_) * sizeof(T), hipMemcpyDeviceToDevice, stream_));
+          comm_->allgather(scr_v_, (size_t)chunk_, dt, stream_);
+          SIPX_HIP(hipMemcpyAsync(blk, scr_v_, G_.N * sizeof(T), hipMemcpyDeviceToDevice, stream_));
+        }
+      }
+  }
+
   void download(void* x, void* const* l, void* const* y) override {
     need_final();
     if (slab_) {       // every rank holds its planes only: complete x and the requested y, l (a collective: every rank calls it)
-      const int dt = dtype_code();
-      if (x) comm_->allgather(x_, (size_t)chunk_, dt, stream_);
-      for (int i = 0; i < p_n_; ++i)
-        for (int which = 0; which < 2; ++which) {
-          if (!((which ? y : l) && (which ? y : l)[i])) continue;
-          T* arr = which ? sets_[i].y : sets_[i].l;
-          const int nb = sets_[i].nblk > 0 ? sets_[i].nblk : 1;
-          for (int q = 0; q < nb; ++q) {
-            T* blk = arr + (long long)q * G_.N;
-            if (r1_ > r0_) SIPX_HIP(hipMemcpyAsync(scr_v_ + r0_, blk + r0_, (r1_ - r0_) * sizeof(T), hipMemcpyDeviceToDevice, stream_));
-            comm_->allgather(scr_v_, (size_t)chunk_, dt, stream_);
-            SIPX_HIP(hipMemcpyAsync(blk, scr_v_, G_.N * sizeof(T), hipMemcpyDeviceToDevice, stream_));
-          }
-        }
+      std::vector<char> wl(p_n_, 0), wy(p_n_, 0);
+      for (int i = 0; i < p_n_; ++i) { wl[i] = l && l[i]; wy[i] = y && y[i]; }
+      gather_slabs(x != nullptr, wl, wy);
     }
     SIPX_HIP(hipStreamSynchronize(stream_));
     if (x) SIPX_HIP(hipMemcpy(x, x_, Nx_ * sizeof(T), hipMemcpyDeviceToHost));

@@ -94,11 +94,28 @@ def _carry_rho(options, log):
 
 
 def PARSDMM_multi_level(m, TD_OP_levels, AtA_levels, P_sub_levels, set_Prop_levels, comp_grid_levels, options,
-                        device=None, timings=None, host_transfers=False):
+                        device=None, timings=None, host_transfers=False, dist=None, comm_mode=None):
     """src/PARSDMM_multi_level.jl:8-89.  `timings` (a dict) receives per-level wall times: context set-up, the device-side
     warm start, the solve, its iteration count.  host_transfers=True keeps the round-1 path (download, resample through
-    host.resample_nn / interpolate_y_l, upload at sipx_finalize) for A/B comparison."""
+    host.resample_nn / interpolate_y_l, upload at sipx_finalize) for A/B comparison.
+    dist (torch.distributed, one process per GPU): every level is solved slab-decomposed over the ranks (sharded.py,
+    sipx_set_decomp -- the set lists of the multilevel examples, bounds and l1 / TV, allow it); between levels the coarse
+    slabs are all-gathered on the device and every rank resamples the whole iterate.  Every rank makes the same calls and
+    returns the same x, log, l, y."""
     import time
+    attach = None
+    keep = []
+    if dist is not None:
+        if host_transfers:
+            raise host.SipxError("the sharded multilevel solve passes the iterate between levels on the device")
+        from . import sharded
+        if not sharded.slab_decomposable(P_sub_levels[0], TD_OP_levels[0]):
+            raise host.SipxError("the sharded multilevel solve needs a set list that can be decomposed by slab (sharded.slab_decomposable)")
+        import torch
+
+        def attach(ctx):
+            keep.append(sharded.attach_comm(ctx, dist, torch.device("cuda", 0 if device is None else device), comm_mode))
+            ctx.set_decomp("slab")
     n_levels = len(TD_OP_levels)
     n0 = tuple(int(v) for v in comp_grid_levels[0].n)
     dim3 = len(n0) == 3 and n0[2] > 1
@@ -122,7 +139,7 @@ def PARSDMM_multi_level(m, TD_OP_levels, AtA_levels, P_sub_levels, set_Prop_leve
                 options.zero_ini_guess = False
             ctx = host.build_context(m_levels[i], AtA_levels[i], TD_OP_levels[i], set_Prop_levels[i], P_sub_levels[i],
                                      comp_grid_levels[i], options, x if host_transfers else None, l if host_transfers else None,
-                                     y if host_transfers else None, device)
+                                     y if host_transfers else None, device, None, attach)
             t1 = time.perf_counter()
             if prev is not None:
                 ctx.warm_start_from(prev)                                    # x, l_i, y_i: coarse -> fine on the device

@@ -1711,3 +1711,58 @@ def test_fused_cg_iterations_are_bit_identical(sipx, TF, monkeypatch):
     assert np.array_equal(l0.cg_it, l1.cg_it) and np.array_equal(l0.cg_relres, l1.cg_relres)
     assert np.array_equal(x0, x1) and np.array_equal(l0.obj, l1.obj) and np.array_equal(l0.r_pri, l1.r_pri)
     assert np.array_equal(l0.rho, l1.rho)
+
+
+# ---- BASELINE config 5 on more than one GPU: the multilevel wrapper over slab-decomposed levels ---------------------------
+def _ml_problem(sipx, n, h, TF, levels):
+    from sipx import multilevel as ML
+    m = model(n, TF, seed=9)
+    TV = O.get_TD_operator(O.compgrid(h, n), "TV", TF)[0]
+    cons = [sipx.set_definitions("bounds", "identity", 1600.0, 3900.0, ("matrix", "")),
+            sipx.set_definitions("l1", "TV", 0.0, float(0.5 * np.abs(TV @ m).sum()), ("matrix", ""))]
+    opt = sipx.PARSDMM_options(FL=TF, maxit=40)
+    L = ML.setup_multi_level_PARSDMM(m, levels, 2, sipx.compgrid(h, n), cons, opt)
+    return ML, m, opt, L
+
+
+def _ml_worker(rank, world, port, out, n, h, levels):
+    import os
+    import sys
+    import datetime
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")
+    dist.init_process_group("gloo", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=180))
+    try:
+        sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+        from __graft_entry__ import load_package
+        sipx = load_package()
+        ML, m, opt, L = _ml_problem(sipx, n, h, np.float32, levels)
+        x, log, l, y = ML.PARSDMM_multi_level(m.copy(), *L[:5], opt, device=0, dist=dist, comm_mode="torch")
+        np.savez(os.path.join(out, f"ml{rank}.npz"), x=x, obj=log.obj, cg_it=log.cg_it, rho=log.rho, **{f"y{i}": v for i, v in enumerate(y)},
+                 **{f"l{i}": v for i, v in enumerate(l)})
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(400)
+@pytest.mark.parametrize("world,n,h,levels", [(2, (32, 24, 16), (25.0, 25.0, 25.0), 2), (3, (24, 20, 20), (25.0, 20.0, 10.0), 3)])
+def test_multilevel_over_slab_decomposed_levels(sipx, tmp_path, world, n, h, levels):
+    """BASELINE config 5's pattern on more than one rank: every level solved slab-decomposed, the coarse slabs all-gathered on
+    the device before every rank resamples the whole iterate (sipx_warm_start_from).  Identical results on every rank; the
+    single-rank multilevel solve to the reference's serial-vs-parallel tolerance."""
+    import os
+    import torch.multiprocessing as mp
+    mp.spawn(_ml_worker, args=(world, 31700 + (os.getpid() % 2000) + world, str(tmp_path), n, h, levels), nprocs=world, join=True)
+    r0 = np.load(tmp_path / "ml0.npz")
+    for r in range(1, world):
+        r1 = np.load(tmp_path / f"ml{r}.npz")
+        for k in r0.files:
+            assert np.array_equal(r0[k], r1[k], equal_nan=True), k
+    ML, m, opt, L = _ml_problem(sipx, n, h, np.float32, levels)
+    xs, logs, ls, ys = ML.PARSDMM_multi_level(m.copy(), *L[:5], opt)
+    assert np.linalg.norm(r0["x"] - xs) <= 5e-4 * np.linalg.norm(xs)
+    K = min(6, len(logs.obj), len(r0["obj"]))
+    assert np.array_equal(r0["cg_it"][:K], logs.cg_it[:K]) and np.allclose(r0["obj"][:K], logs.obj[:K], rtol=5e-4)

@@ -1,6 +1,12 @@
-"""BASELINE config 5 pattern: Float64, {bounds, l1 on TV}, 3 levels, coarsening factor 2 (test_scaling_3D.jl:144-145)."""
-import sys, time, json
+"""BASELINE config 5 pattern: Float64, {bounds, l1 on TV}, 3 levels, coarsening factor 2 (test_scaling_3D.jl:144-145).
+usage: python tools/c5_multilevel.py [n=256] [maxit=30] [host]     one GPU (host: the round-1 path with host transfers)
+       python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 tools/c5_multilevel.py 512 30
+           one rank per GPU: every level slab-decomposed over the ranks (RCCL inside the engine); rank 0 prints the line
+       SIPX_FORCE_DIST=1 python tools/c5_multilevel.py ...           the same path with a world of one"""
+import os, sys, time, json
 import numpy as np
+if int(os.environ.get("WORLD_SIZE", "1")) > 1 or os.environ.get("SIPX_FORCE_DIST"):
+    import torch                       # before libsipx: torch brings its own HIP runtime and wants to initialise it first
 sys.path.insert(0, __import__('os').path.dirname(__import__('os').path.dirname(__import__('os').path.abspath(__file__))))
 from __graft_entry__ import load_package
 sipx = load_package()
@@ -22,10 +28,33 @@ L = ML.setup_multi_level_PARSDMM(m, 3, 2, g, c, opt)
 t1 = time.perf_counter()
 host_path = len(sys.argv) > 3 and sys.argv[3] == "host"
 T = {}
-x, log, l, y = ML.PARSDMM_multi_level(m, *L[:5], opt, timings=T, host_transfers=host_path)
+dist = None
+world, rank, local_rank = int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("RANK", "0")), int(os.environ.get("LOCAL_RANK", "0"))
+if world > 1 or os.environ.get("SIPX_FORCE_DIST"):
+    import torch
+    import torch.distributed as dist
+    if "MASTER_ADDR" not in os.environ:
+        os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="29544", RANK="0", WORLD_SIZE="1")
+    torch.cuda.set_device(local_rank)
+    sys.stdout.flush()
+    saved = os.dup(1)
+    os.dup2(2, 1)                      # RCCL's banner goes to stderr: ONE JSON line on stdout
+    dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    sipx.set_default_device(local_rank)
+t1 = time.perf_counter()
+x, log, l, y = ML.PARSDMM_multi_level(m, *L[:5], opt, device=local_rank, timings=T, host_transfers=host_path, dist=dist)
 t2 = time.perf_counter()
+if dist is not None:
+    import torch
+    torch.cuda.synchronize()
+    sys.stdout.flush()
+    os.dup2(saved, 1)
+    dist.destroy_process_group()
+    if rank != 0:
+        sys.exit(0)
 fin = T["levels"][-1]
 print(json.dumps({"grid": n, "levels": [list(gg.n) for gg in L[4]], "transfers": "host (round-1 path)" if host_path else "device (sipx_warm_start_from)",
+                  "n_gpus": world, "decomposition": "every level slab-decomposed over the ranks" if dist is not None else "single GPU",
                   "setup_s": t1 - t0, "whole_solve_s": t2 - t1,
                   "solve_only_s": sum(v["solve_s"] for v in T["levels"]), "warm_start_total_s": sum(v["warm_start_s"] for v in T["levels"]),
                   "context_total_s": sum(v["context_s"] for v in T["levels"]), "download_s": T.get("download_s"),

@@ -41,6 +41,7 @@ if [ -z "$LIGHT" ]; then
   $T python bench.py --no-cpu-baseline --no-c4 --config c4 --steps 6 --warmup 2 > $O/${R}_c4_512_bench.json 2>>$O/bench.err
   $T python tools/c5_multilevel.py 512 30 > $O/${R}_c5_512_f64_multilevel.json 2>>$O/bench.err
   $T python tools/c5_multilevel.py 512 30 host > $O/${R}_c5_512_f64_multilevel_host_transfers.json 2>>$O/bench.err
+  SIPX_FORCE_DIST=1 $T python tools/c5_multilevel.py 512 30 > $O/${R}_c5_512_f64_multilevel_rccl_world1_slab.json 2>>$O/bench.err
   SIPX_FORCE_DIST=1 $T python bench.py --no-cpu-baseline --no-512 --no-c4 --decomp sets > $O/${R}_c3_256_bench_rccl_world1.json 2>>$O/bench.err
   SIPX_FORCE_DIST=1 $T python bench.py --no-cpu-baseline --no-512 --no-c4 --decomp slab > $O/${R}_c3_256_bench_rccl_world1_slab.json 2>>$O/bench.err
 fi
