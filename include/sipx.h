@@ -179,7 +179,9 @@ int sipx_download(sipx_ctx* ctx, void* x, void* const* l, void* const* y);
 /* Multilevel (src/PARSDMM_multi_level.jl:61-83, src/interpolate_y_l.jl:16-94): warm start of a finalized context on a finer
  * grid from a solved context on a coarser one, DEVICE TO DEVICE -- x, every l_i and y_i are resampled (nearest neighbour,
  * the set-by-set block arithmetic of interpolate_y_l) without visiting the host.  Both contexts hold the same sets, in the
- * same precision, on the same device.  Overwrites whatever start sipx_finalize gave the fine context. */
+ * same precision, on the same device.  Overwrites whatever start sipx_finalize gave the fine context.  Ranks of a sharded
+ * solve: both contexts slab-decomposed (sipx_set_decomp); the call is then a collective -- the coarse slabs are all-gathered on
+ * the device and every rank resamples the whole iterate. */
 int sipx_warm_start_from(sipx_ctx* fine, sipx_ctx* coarse);
 
 /* ---- B. whole solve (src/PARSDMM.jl:97-257 restated natively) ---- */
