@@ -266,6 +266,7 @@ __global__ void k_ps_init(ProjScalars<T>* ps, long long* cidx) {
   for (int j = 0; j < SAMPLE_BINS; ++j) ps->hist[j] = 0;
   ps->sampled = ps->dbg_sampled = ps->want_sample = 0;
   ps->samp_ticket = 0;
+  ps->pass_ticket = 0;
   ps->gather_overflow = 0;
   ps->ovf = 0;
   for (int r = 0; r < 2 * SIPX_MAX_WORLD; ++r) ps->mm[r] = 0;
@@ -324,17 +325,48 @@ __device__ __forceinline__ void reduce_slots(const double* __restrict__ partials
 // (its dependent batches of loads queue behind the streaming passes of the other set stream); spread over 20 workgroups
 // every load of a slot is in flight at once.
 template <typename T, int STAGE>
+__device__ void decide_body(ProjScalars<T>* ps, int prox, T pmin, T pmax, long long true_len, int nospec, double capdiv, int world,
+                            double cap_max, const double* reg);
+struct DecideArgs {        // what the scalar decision needs besides the sums (k_slot_sums with FUSE: its last workgroup decides)
+  int prox, nospec;
+  double pmin, pmax, capdiv, cap_max;
+  long long true_len;
+};
+
+// FUSE (one rank: no all-reduce between the sums and the decision): every workgroup hands its value over with a device-scope
+// store, waits for it and takes a ticket; the workgroup that draws the last one reads them all back and its thread 0 takes
+// the scalar decision -- the launch of k_decide, about 6 us on the stream, is saved twice per search.
+template <typename T, int STAGE, bool FUSE>
 __global__ __launch_bounds__(BLOCK) void k_slot_sums(const double* __restrict__ partials, const T* __restrict__ maxpart,
-                                                     ProjScalars<T>* ps, int rank, int world, double* __restrict__ reg) {
+                                                     ProjScalars<T>* ps, int rank, int world, double* __restrict__ reg, DecideArgs da) {
   // reg: PREP_SLOTS sums | ovf | (max, min) per rank -- ps->red / ovf / mm themselves, or this set's region of the staging
   // buffer that one all-reduce makes global for all sets of a slab-decomposed iteration
   if (STAGE == 1 && !(ps->need && !ps->spec_ok && ps->refine)) {
     // (slab-decomposed: the all-reduce that follows runs regardless; it then sums stale values nobody reads)
     return;
   }
+  __shared__ double sreg[PREP_SLOTS + 1 + 2 * SIPX_MAX_WORLD];
+  __shared__ unsigned int sh_ticket;
+  auto finish = [&]() {      // FUSE: ticket; the last workgroup decides
+    __builtin_amdgcn_s_waitcnt(0);
+    __syncthreads();
+    if (threadIdx.x == 0) sh_ticket = __hip_atomic_fetch_add(&ps->pass_ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
+    if (sh_ticket != gridDim.x - 1) return;
+    const int nreg = PREP_SLOTS + 1 + 2 * world;
+    for (int i = threadIdx.x; i < nreg; i += BLOCK) sreg[i] = __hip_atomic_load(&reg[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
+    if (threadIdx.x != 0) return;
+    __hip_atomic_store(&ps->pass_ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    decide_body<T, STAGE>(ps, da.prox, (T)da.pmin, (T)da.pmax, da.true_len, da.nospec, da.capdiv, world, da.cap_max, sreg);
+  };
   if (blockIdx.x < PREP_SLOTS) {
     const double v = block_sum_partials(partials + (long long)blockIdx.x * NB);
-    if (threadIdx.x == 0) reg[blockIdx.x] = v;
+    if (threadIdx.x == 0) {
+      if (FUSE) __hip_atomic_store(&reg[blockIdx.x], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      else reg[blockIdx.x] = v;
+    }
+    if (FUSE) finish();
     return;
   }
   __shared__ T smax[BLOCK / 64], smin[BLOCK / 64];
@@ -351,20 +383,21 @@ __global__ __launch_bounds__(BLOCK) void k_slot_sums(const double* __restrict__ 
   if (threadIdx.x == 0) {
     for (int i = 0; i < BLOCK / 64; ++i) { vmax = smax[i] > vmax ? smax[i] : vmax; vmin = smin[i] < vmin ? smin[i] : vmin; }
     double* mm = reg + PREP_SLOTS + 1;
-    for (int r = 0; r < 2 * world; ++r) mm[r] = 0.0;
-    mm[2 * rank] = (double)vmax;
-    mm[2 * rank + 1] = (vmin < (T)INFINITY) ? (double)vmin : 0.0;     // 0 = this rank saw no non-zero magnitude
-    reg[PREP_SLOTS] = ps->spec_overflow ? 1.0 : 0.0;
+    for (int r = 0; r < 2 * world; ++r)
+      if (r != 2 * rank && r != 2 * rank + 1) __hip_atomic_store(&mm[r], 0.0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(&mm[2 * rank], (double)vmax, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(&mm[2 * rank + 1], (vmin < (T)INFINITY) ? (double)vmin : 0.0, __ATOMIC_RELAXED,
+                       __HIP_MEMORY_SCOPE_AGENT);                       // 0 = this rank saw no non-zero magnitude
+    __hip_atomic_store(&reg[PREP_SLOTS], ps->spec_overflow ? 1.0 : 0.0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
+  if (FUSE) finish();
 }
 
 // Scalar decisions after a probe pass (one thread; the sums come from k_slot_sums).  STAGE 0: after the first pass;
 // STAGE 1: after the gated refinement.
 template <typename T, int STAGE>
-__global__ __launch_bounds__(64) void k_decide(ProjScalars<T>* ps, int prox, T pmin, T pmax, long long true_len,
-                                               int nospec, double capdiv, int world, double cap_max, const double* __restrict__ reg) {
-  if (STAGE == 1 && !(ps->need && !ps->spec_ok && ps->refine)) return;
-  if (threadIdx.x != 0) return;
+__device__ void decide_body(ProjScalars<T>* ps, int prox, T pmin, T pmax, long long true_len, int nospec, double capdiv, int world,
+                            double cap_max, const double* reg) {
   const double* red = reg;
   T vmax = T(0), vmin = (T)INFINITY;
   if (STAGE == 0) {
@@ -512,6 +545,16 @@ __global__ __launch_bounds__(64) void k_decide(ProjScalars<T>* ps, int prox, T p
     ps->refine = 0;
   }
 }
+
+// the decision as a kernel of its own (slab-decomposed grid: an all-reduce sits between the sums and the decision)
+template <typename T, int STAGE>
+__global__ __launch_bounds__(64) void k_decide(ProjScalars<T>* ps, int prox, T pmin, T pmax, long long true_len,
+                                               int nospec, double capdiv, int world, double cap_max, const double* __restrict__ reg) {
+  if (STAGE == 1 && !(ps->need && !ps->spec_ok && ps->refine)) return;
+  if (threadIdx.x != 0) return;
+  decide_body<T, STAGE>(ps, prox, pmin, pmax, true_len, nospec, capdiv, world, cap_max, reg);
+}
+
 
 // ---------------------------------------------------------------------------------------------
 // SAMPLED PREDICTION of theta.  While rho and gamma are still being adapted, theta moves by up to a factor of three from one
@@ -1281,6 +1324,8 @@ static void chain_stage(int stage, hipStream_t s, const Grid& g, const SetArgs<T
   const double cap_max = hk ? (double)hk->gcap : 0.0;      // what ALL ranks gather together fits one rank's segment
   const bool vec = SRC == 1 && g.n[0] % 4 == 0;
   static const double capdiv = [] { const char* e = getenv("SIPX_L1_CAPDIV"); return e ? atof(e) : 64.0; }();
+  const DecideArgs da0{a.prox, (a.flags & F_NOSPEC) ? 1 : 0, (double)a.plo, (double)a.phi, capdiv, cap_max, true_len};
+  const DecideArgs da1{a.prox, 0, (double)a.plo, (double)a.phi, capdiv, cap_max, true_len};
 #define SIPX_PASS(MODE)                                                                                            \
   do {                                                                                                             \
     if (vec)                                                                                                       \
@@ -1318,17 +1363,22 @@ static void chain_stage(int stage, hipStream_t s, const Grid& g, const SetArgs<T
     }
     SIPX_PASS(M_FIRST);
     if (a.prox == PX_L1 && !(a.flags & F_NOSPEC)) SIPX_PASS(M_LEAN);
-    hipLaunchKernelGGL((k_slot_sums<T, 0>), dim3(PREP_SLOTS + 1), dim3(BLOCK), 0, s, partials, maxpart, ps, rank, world, reg);
+    // one rank: the last workgroup of the sums takes the decision (no k_decide launch); slab-decomposed: an all-reduce of the
+    // caller sits between the two
+    if (hk) hipLaunchKernelGGL((k_slot_sums<T, 0, false>), dim3(PREP_SLOTS + 1), dim3(BLOCK), 0, s, partials, maxpart, ps, rank, world, reg, da0);
+    else hipLaunchKernelGGL((k_slot_sums<T, 0, true>), dim3(PREP_SLOTS + 1), dim3(BLOCK), 0, s, partials, maxpart, ps, rank, world, reg, da0);
   } else if (stage == 1) {
-    hipLaunchKernelGGL((k_decide<T, 0>), dim3(1), dim3(64), 0, s, ps, a.prox, a.plo, a.phi, true_len, (a.flags & F_NOSPEC) ? 1 : 0, capdiv,
-                       world, cap_max, reg);
+    if (hk)
+      hipLaunchKernelGGL((k_decide<T, 0>), dim3(1), dim3(64), 0, s, ps, a.prox, a.plo, a.phi, true_len, (a.flags & F_NOSPEC) ? 1 : 0, capdiv,
+                         world, cap_max, reg);
     if (a.prox == PX_L1) {
       SIPX_PASS(M_PROBE);
-      hipLaunchKernelGGL((k_slot_sums<T, 1>), dim3(PREP_SLOTS), dim3(BLOCK), 0, s, partials, maxpart, ps, rank, world, reg);
+      if (hk) hipLaunchKernelGGL((k_slot_sums<T, 1, false>), dim3(PREP_SLOTS), dim3(BLOCK), 0, s, partials, maxpart, ps, rank, world, reg, da1);
+      else hipLaunchKernelGGL((k_slot_sums<T, 1, true>), dim3(PREP_SLOTS), dim3(BLOCK), 0, s, partials, maxpart, ps, rank, world, reg, da1);
     }
   } else if (stage == 2) {
     if (a.prox == PX_L1) {
-      hipLaunchKernelGGL((k_decide<T, 1>), dim3(1), dim3(64), 0, s, ps, a.prox, a.plo, a.phi, true_len, 0, capdiv, world, cap_max, reg);
+      if (hk) hipLaunchKernelGGL((k_decide<T, 1>), dim3(1), dim3(64), 0, s, ps, a.prox, a.plo, a.phi, true_len, 0, capdiv, world, cap_max, reg);
       SIPX_PASS(M_COMPACT);
       if (hk) hipLaunchKernelGGL((k_gather_pack<T>), dim3(64), dim3(BLOCK), 0, s, ps, compact, partials, gseg0 + (long long)rank * chunk, hk->gcap);
     }

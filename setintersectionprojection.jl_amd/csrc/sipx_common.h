@@ -155,6 +155,7 @@ struct ProjScalars {
   // sampled prediction: per bin, count and fixed-point sum of the sampled magnitudes packed in one word (integer atomics:
   // the totals do not depend on the order of arrival); zero between searches
   unsigned long long hist[SAMPLE_BINS];
+  unsigned pass_ticket;   // arrivals of the workgroups of k_slot_sums (one rank: the last one takes the scalar decision)
   unsigned samp_ticket;   // arrivals of k_sample's workgroups (the last one decides)
   int rescaled, resc_bad;   // the coming search follows k_ps_rescale; the last rescaled prediction missed its range
   int want_sample;    // the prediction of the coming search is not trusted (theta moved, or rho was changed): sample first
