@@ -1766,3 +1766,33 @@ def test_multilevel_over_slab_decomposed_levels(sipx, tmp_path, world, n, h, lev
     assert np.linalg.norm(r0["x"] - xs) <= 5e-4 * np.linalg.norm(xs)
     K = min(6, len(logs.obj), len(r0["obj"]))
     assert np.array_equal(r0["cg_it"][:K], logs.cg_it[:K]) and np.allclose(r0["obj"][:K], logs.obj[:K], rtol=5e-4)
+
+
+@pytest.mark.timeout(300)
+@pytest.mark.parametrize("dist_env", [None, "1"])
+def test_bench_contract_line(dist_env):
+    """bench.py prints ONE JSON line with the contract's fields (metric, value, unit, n_gpus, steps, warmup, ms_per_step,
+    higher_is_better, scaling, vs_baseline, dtype, data, config.workload, roofline, iteration_roofline) -- on one GPU, and
+    through the sharded code path (RCCL communicator with a world of one: both decompositions timed, the faster reported)."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ)
+    if dist_env:
+        env.update(SIPX_FORCE_DIST="1", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(32100 + os.getpid() % 2000), RANK="0", WORLD_SIZE="1")
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--config", "c3-small", "--steps", "4", "--warmup", "2",
+                        "--no-cpu-baseline", "--no-512", "--no-c4"], capture_output=True, text=True, timeout=280, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.strip().splitlines() if ln.strip()]
+    assert len(lines) == 1, r.stdout
+    d = json.loads(lines[0])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+              "dtype", "data", "config", "roofline", "iteration_roofline"):
+        assert k in d, k
+    assert d["n_gpus"] == 1 and d["steps"] == 4 and d["warmup"] == 2 and d["value"] > 0 and d["vs_baseline"] is None
+    assert "workload" in d["config"] and d["config"]["all_logs_finite"]
+    assert {"bound", "achieved", "peak", "unit", "frac", "traffic"} <= set(d["roofline"])
+    if dist_env:
+        assert d["other_decomposition"]["decomposition"] in ("slab", "sets") and d["other_decomposition"]["value"] > 0
