@@ -118,6 +118,63 @@ def spawn_ranks(n_gpus):
     return rc
 
 
+def comm_probe(dist, torch, world, rank):
+    """What the collectives of the two decompositions cost on THIS node (no multi-GPU box was available to the builder: these
+    numbers, printed with the bench line, are what the design of DESIGN.md 5 has to be calibrated against).  torch.distributed's
+    RCCL communicator on the same devices; microseconds per call, averaged over `reps` back-to-back calls."""
+    dev = torch.device("cuda", torch.cuda.current_device())
+    out = {}
+
+    def timed(name, fn, reps):
+        for _ in range(3):
+            fn()
+        torch.cuda.synchronize()
+        dist.barrier()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        t = torch.tensor([e0.elapsed_time(e1) * 1e3 / reps], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        out[name] = round(float(t.item()), 2)
+
+    small = torch.zeros(36, dtype=torch.float64, device=dev)
+    timed("allreduce_36_f64_us (probe sums of one set)", lambda: dist.all_reduce(small), 100)
+    part = torch.zeros(2048, dtype=torch.float64, device=dev)
+    timed("allreduce_2048_f64_us (dot partials of a CG step)", lambda: dist.all_reduce(part), 100)
+    hist = torch.zeros(3 * 2051, dtype=torch.float64, device=dev)
+    timed("allreduce_6153_f64_us (sampled histograms of three sets)", lambda: dist.all_reduce(hist), 50)
+    seg = 3 * (131072 + 8)
+    gbuf = torch.zeros(world * seg, dtype=torch.float32, device=dev)
+    timed("allgather_1.5MB_per_rank_us (bracket segments of three l1 sets)",
+          lambda: dist.all_gather_into_tensor(gbuf, gbuf[rank * seg:(rank + 1) * seg]), 50)
+    for plane, tag in ((256 * 256, "256^3"), (512 * 512, "512^3")):
+        sp, sn = torch.zeros(plane, device=dev), torch.zeros(plane, device=dev)
+        rp, rn = torch.zeros(plane, device=dev), torch.zeros(plane, device=dev)
+
+        def halo():
+            ops = []
+            if rank > 0:
+                ops += [dist.P2POp(dist.isend, sp, rank - 1), dist.P2POp(dist.irecv, rp, rank - 1)]
+            if rank < world - 1:
+                ops += [dist.P2POp(dist.isend, sn, rank + 1), dist.P2POp(dist.irecv, rn, rank + 1)]
+            if ops:
+                for w_ in dist.batch_isend_irecv(ops):
+                    w_.wait()
+        timed(f"halo_plane_{tag}_f32_us (one plane to each neighbour)", halo, 50)
+    n256 = 256 ** 3
+    chunk = -(-256 // world) * 256 * 256
+    big = torch.zeros(world * chunk, dtype=torch.float32, device=dev)
+    timed("reduce_scatter_256^3_f32_us (rhs of the set decomposition)",
+          lambda: dist.reduce_scatter_tensor(big[rank * chunk:(rank + 1) * chunk], big), 10)
+    timed("allgather_256^3_f32_us (x of the set decomposition)",
+          lambda: dist.all_gather_into_tensor(big, big[rank * chunk:(rank + 1) * chunk]), 10)
+    del big, n256
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -291,6 +348,8 @@ def main():
         frac_traffic = (traffic / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if (launches and traffic) else None
         return {
             "value": steps / dt, "ms_per_step": dt / steps * 1e3, "decomposition": ("slab" if slab else "sets") if dist is not None else None,
+            # log.timing of the whole run (warm-up included), per iteration: where the time of an iteration goes on this rank
+            "timing_ms_per_iteration": {k: round(float(v) * 1e3 / max(len(log.obj), 1), 4) for k, v in (log.timing or {}).items()},
             "config": {"workload": f"{config}: {'x'.join(map(str, n))} {'Float32' if args.dtype == 'f32' else 'Float64'}, sets {{{', '.join(kinds)}}} + distance term",
                        "grid": list(n), "sets": kinds, "q_mode": args.q_mode,
                        "parallelism": ((f"whole iteration on z-slabs over {world} ranks (every rank holds every set): slab CG (halo plane per "
@@ -330,13 +389,14 @@ def main():
         if r2["value"] > r["value"]:
             r, r2 = r2, r
         alt = {"decomposition": r2["decomposition"], "value": r2["value"], "ms_per_step": r2["ms_per_step"],
-               "parallelism": r2["config"]["parallelism"]}
+               "parallelism": r2["config"]["parallelism"], "timing_ms_per_iteration": r2["timing_ms_per_iteration"]}
     n, h, kinds = CONFIGS[args.config]
     out = {
         "metric": "PARSDMM iterations/sec", "value": r["value"], "unit": "it/s", "n_gpus": world,
         "steps": args.steps, "warmup": args.warmup, "ms_per_step": r["ms_per_step"],
         "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
         "config": r["config"], "roofline": r["roofline"], "iteration_roofline": r["iteration_roofline"],
+        "timing_ms_per_iteration": r["timing_ms_per_iteration"],
     }
     if alt is not None:
         out["other_decomposition"] = alt
@@ -352,6 +412,11 @@ def main():
         r4 = measure("c4", 6, 2)
         out["c4_512"] = {"value": r4["value"], "unit": "it/s", "ms_per_step": r4["ms_per_step"], "steps": 6, "warmup": 2, "n_gpus": world,
                          "scaling": "strong", "config": r4["config"]}
+    if dist is not None and (world > 1 or force_dist):
+        try:
+            out["comm_probe_us"] = comm_probe(dist, torch, world, rank)
+        except Exception as e:                                   # informative only: never fail the bench line over it
+            out["comm_probe_us"] = {"error": repr(e)}
     if rank == 0 and world == 1 and not args.no_cpu_baseline and args.dtype == "f32":
         out["cpu_baseline"] = cpu_baseline(args.config, n, h, kinds)
     if rank == 0:
