@@ -207,9 +207,17 @@ int sipx_resample_nn(int dtype, int ndim, const int64_t* nc, const int64_t* nf, 
 int sipx_get_Q(sipx_ctx* ctx, void* Q, int64_t* offsets, int* d);
 /* device-side timing of the dominant kernel: runs cds_spmv on Q `reps` times, returns avg ms (HIP events on the engine stream) */
 int sipx_time_spmv(sipx_ctx* ctx, int reps, double* avg_ms);
-/* HIP-event timing of every launch of the dominant kernel (cds_spmv fused with the CG dot product) on the engine
- * stream: enable=1 starts/clears the collection, enable=0 stops it; launches / total_ms report what was gathered. */
+/* HIP-event timing of the engine's kernels, bracketed on the stream each launch goes to.  launches / total_ms report what
+ * was gathered for the product of the CG iteration (cds_spmv fused with the dot product, src/CDS_MVp_MT.jl:9-25 + cg.jl:85-88)
+ * since the last call; `enable` then (re)starts the collection: 0 = off, 1 = that kernel only (two event records per CG
+ * iteration: cheap enough for a timed region), 2 = EVERY kernel (about 5 us per launch: for a window of its own). */
 int sipx_kernel_stats(sipx_ctx* ctx, int enable, int64_t* launches, double* total_ms);
+/* The same collection as a JSON text, one entry per kernel that ran: {"mode", "event_pair_overhead_ms", "kernels": [{"name",
+ * "launches", "total_ms", "bytes_survey" (SURVEY 8d's algorithmic bytes of the reference function the kernel replaces, summed
+ * over the launches), "bytes_moved" (what the kernel has to move at least), "gated" (some launches return at once on a
+ * device-side condition), "inclusive" (the interval contains other listed kernels)}]}.  The pointer stays valid until the next
+ * call on this context; NULL on error (sipx_last_error).  `enable` as above. */
+const char* sipx_kernel_stats_json(sipx_ctx* ctx, int enable);
 /* diagnostics: state of the projector-scalar search of set `set` (which = 0: prox, 1: feasibility) as 16 doubles:
  * need, theta, theta_prev, hw, spec_lo, spec_hi, lo, hi, asum, vmax, gathered, overflow, spec_ok, michelot_its, refine, 0 */
 int sipx_debug_proj(sipx_ctx* ctx, int set, int which, double* out16);
@@ -281,6 +289,11 @@ typedef struct {
   int (*gather)(void* user, void* buf, int64_t chunk, int32_t dtype, int32_t root, void* stream);
 } sipx_comm;
 int sipx_set_comm(sipx_ctx* ctx, const sipx_comm* comm);
+/* What the attached communicator itself reports: the ranks it spans and this rank's number in it (RCCL: ncclCommCount /
+ * ncclCommUserRank -- asked of the library, not echoed from sipx_set_comm_rccl's arguments), its version as text ("rccl
+ * 2.x.y" from ncclGetVersion, "callbacks (sipx_set_comm)", "none" without a communicator; version_len bytes incl. the
+ * terminator), and the decomposition in force (SIPX_DECOMP_*).  So that "did RCCL see N ranks" can be answered from a log. */
+int sipx_comm_info(sipx_ctx* ctx, int* nranks, int* rank, char* version, int version_len, int* decomposition);
 /* this rank's slab of the x-step: rows [row0, row1) of Q / entries of x, and the elements per rank (chunk) of the padded
  * exchange buffers; without a communicator row0 = 0, row1 = chunk = N */
 int sipx_slab(sipx_ctx* ctx, int64_t* row0, int64_t* row1, int64_t* chunk);

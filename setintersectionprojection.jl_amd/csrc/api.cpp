@@ -106,6 +106,17 @@ int sipx_time_spmv(sipx_ctx* c, int reps, double* avg_ms) { SIPX_TRY(*avg_ms = c
 int sipx_kernel_stats(sipx_ctx* c, int enable, int64_t* launches, double* total_ms) {
   SIPX_TRY(c->e->kernel_stats(enable, launches, total_ms))
 }
+const char* sipx_kernel_stats_json(sipx_ctx* c, int enable) {
+  try {
+    return c->e->kernel_stats_json(enable);
+  } catch (const std::exception& ex) {
+    g_err = ex.what();
+    return nullptr;
+  } catch (...) {
+    g_err = "unknown error";
+    return nullptr;
+  }
+}
 int sipx_debug_proj(sipx_ctx* c, int set, int which, double* out16) { SIPX_TRY(c->e->debug_proj(set, which, out16)) }
 void* sipx_stream(sipx_ctx* c) { return c->e->stream(); }
 void* sipx_dev_rhs(sipx_ctx* c) { return c->e->dev_rhs(); }
@@ -127,6 +138,9 @@ int sipx_set_comm(sipx_ctx* c, const sipx_comm* comm) {
     if (!comm) throw std::runtime_error("null communicator");
     c->e->set_comm(sipx::make_callback_comm(comm));
   })
+}
+int sipx_comm_info(sipx_ctx* c, int* nranks, int* rank, char* version, int version_len, int* decomposition) {
+  SIPX_TRY(c->e->comm_info(nranks, rank, version, version_len, decomposition))
 }
 int sipx_slab(sipx_ctx* c, int64_t* row0, int64_t* row1, int64_t* chunk) { SIPX_TRY(c->e->slab(row0, row1, chunk)) }
 int sipx_set_q_mode(sipx_ctx* c, int mode) { SIPX_TRY(c->e->set_q_mode(mode)) }

@@ -4,6 +4,7 @@
 #include <dlfcn.h>
 #include <rccl/rccl.h>
 
+#include <cstdio>
 #include <cstring>
 #include <mutex>
 #include <stdexcept>
@@ -29,6 +30,9 @@ struct RcclApi {
   decltype(&ncclGroupStart) GroupStart = nullptr;
   decltype(&ncclGroupEnd) GroupEnd = nullptr;
   decltype(&ncclGetErrorString) GetErrorString = nullptr;
+  decltype(&ncclCommCount) CommCount = nullptr;
+  decltype(&ncclCommUserRank) CommUserRank = nullptr;
+  decltype(&ncclGetVersion) GetVersion = nullptr;
 };
 
 const RcclApi& rccl() {
@@ -52,6 +56,9 @@ const RcclApi& rccl() {
     sym(api.GroupStart, "ncclGroupStart");
     sym(api.GroupEnd, "ncclGroupEnd");
     sym(api.GetErrorString, "ncclGetErrorString");
+    sym(api.CommCount, "ncclCommCount");
+    sym(api.CommUserRank, "ncclCommUserRank");
+    sym(api.GetVersion, "ncclGetVersion");
   });
   if (!api.h || !api.GetUniqueId || !api.CommInitRank || !api.CommDestroy || !api.AllReduce || !api.ReduceScatter ||
       !api.AllGather || !api.Send || !api.Recv || !api.GroupStart || !api.GroupEnd)
@@ -82,6 +89,21 @@ class RcclComm : public Comm {
     if (comm_) (void)rccl().CommDestroy(comm_);
   }
   const char* kind() const override { return "rccl"; }
+  // asked of RCCL itself (ncclCommCount / ncclCommUserRank / ncclGetVersion), not echoed from the constructor's arguments:
+  // "did RCCL see N ranks" has to be answerable from a bench line
+  void info(int* nranks, int* rank_out, char* version, size_t version_len) const override {
+    const RcclApi& a = rccl();
+    int n = -1, r = -1, v = 0;
+    if (a.CommCount) nccl_check(a.CommCount(comm_, &n), "ncclCommCount");
+    if (a.CommUserRank) nccl_check(a.CommUserRank(comm_, &r), "ncclCommUserRank");
+    if (a.GetVersion) nccl_check(a.GetVersion(&v), "ncclGetVersion");
+    if (nranks) *nranks = n;
+    if (rank_out) *rank_out = r;
+    if (version && version_len) {
+      // NCCL_VERSION_CODE: major * 10000 + minor * 100 + patch from 2.9 on
+      std::snprintf(version, version_len, "rccl %d.%d.%d", v / 10000, (v / 100) % 100, v % 100);
+    }
+  }
   void allreduce_sum(void* buf, size_t count, int dtype, hipStream_t s) override {
     nccl_check(rccl().AllReduce(buf, buf, count, nccl_type(dtype), ncclSum, comm_, s), "ncclAllReduce");
   }
@@ -148,6 +170,11 @@ class CallbackComm : public Comm {
       throw std::runtime_error("sipx_comm: every operation must be supplied");
   }
   const char* kind() const override { return "callback"; }
+  void info(int* nranks, int* rank_out, char* version, size_t version_len) const override {
+    if (nranks) *nranks = world;
+    if (rank_out) *rank_out = rank;
+    if (version && version_len) std::snprintf(version, version_len, "callbacks (sipx_set_comm)");
+  }
   void allreduce_sum(void* buf, size_t count, int dtype, hipStream_t s) override {
     chk(cb_.allreduce_sum(cb_.user, buf, (int64_t)count, dtype, (void*)s), "allreduce_sum");
   }

@@ -19,6 +19,8 @@ struct Comm {
   int world = 1, rank = 0;
   virtual ~Comm() {}
   virtual const char* kind() const = 0;
+  // what the communicator itself reports: ranks it spans, this rank's number in it, its library version ("" if none)
+  virtual void info(int* nranks, int* rank_out, char* version, size_t version_len) const = 0;
   // buf[0 .. count) <- sum over ranks, identical bits on every rank
   virtual void allreduce_sum(void* buf, size_t count, int dtype, hipStream_t s) = 0;
   // buf[rank*chunk .. (rank+1)*chunk) <- sum over ranks of that range; the rest of buf is scratch afterwards

@@ -8,16 +8,28 @@
 #include <algorithm>
 #include <chrono>
 #include <cmath>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <limits>
 
 namespace sipx {
 
+const LaunchObserver*& launch_observer() {
+  static thread_local const LaunchObserver* obs = nullptr;
+  return obs;
+}
+
 namespace {
 
-constexpr int SLOTS = 16;      // reduction slots per set: 0..12 k_yl, 13 ||A'dy||^2, 14/15 two-pass feasibility
-constexpr int SL_ADJ = 13, SL_FE2 = 14, SL_SS2 = 15;
+// installs a context's observer for the duration of one entry point (the launchers consult it through launch_observer())
+struct ObserverGuard {
+  const LaunchObserver* prev;
+  explicit ObserverGuard(const LaunchObserver* o) : prev(launch_observer()) { launch_observer() = o; }
+  ~ObserverGuard() { launch_observer() = prev; }
+};
+
+constexpr int SLOTS = SET_SLOTS;      // reduction slots per set: 0..12 k_yl, 13 ||A'dy||^2, 14/15 two-pass feasibility
 
 template <typename T>
 T* dalloc(size_t n, bool zero = true) {
@@ -190,6 +202,7 @@ class Engine : public EngineBase {
     if (cg_host_) (void)hipHostFree(cg_host_);
     if (hres_) (void)hipHostFree(hres_);
     if (hlean_) (void)hipHostFree((void*)hlean_);
+    if (hovf_) (void)hipHostFree((void*)hovf_);
     for (auto e : ev_) (void)hipEventDestroy(e);
     for (auto e : stat_ev_) (void)hipEventDestroy(e);
     for (auto e : cg_ev_) if (e) (void)hipEventDestroy(e);
@@ -244,6 +257,14 @@ class Engine : public EngineBase {
     std::unique_ptr<Comm> hold(c);
     if (finalized_) throw std::runtime_error("the communicator must be attached before sipx_finalize");
     comm_ = std::move(hold);
+  }
+  void comm_info(int* nranks, int* rank, char* version, int version_len, int* decomposition) override {
+    if (version && version_len > 0) version[0] = 0;
+    if (nranks) *nranks = 1;
+    if (rank) *rank = 0;
+    if (decomposition) *decomposition = (finalized_ ? slab_ : (slab_req_ && comm_)) ? SIPX_DECOMP_SLAB : SIPX_DECOMP_SETS;
+    if (comm_) comm_->info(nranks, rank, version, version_len > 0 ? (size_t)version_len : 0);
+    else if (version && version_len > 0) std::snprintf(version, (size_t)version_len, "none");
   }
   void bind_device() override { SIPX_HIP(hipSetDevice(device_)); }
   void slab(int64_t* row0, int64_t* row1, int64_t* chunk) override {
@@ -409,6 +430,8 @@ class Engine : public EngineBase {
         static_cast<Comm*>(u)->allgather(buf, chunk, f64 ? SIPX_F64 : SIPX_F32, q);
       };
       hooks_.gcap = std::min<long long>(1ll << 17, (maxpad + 3) / 4 * 4);      // (the all-gather moves whole segments: 512 KB per l1 set and rank)
+      if (const char* e = std::getenv("SIPX_GATHER_CAP"))                      // tests: a segment small enough to overflow
+        if (std::atoll(e) >= 4) hooks_.gcap = std::atoll(e) / 4 * 4;
       int n2 = 0, nl1 = 0;
       for (auto& s : sets_) { n2 += s.two_pass ? 1 : 0; nl1 += (s.two_pass && s.prox == PX_L1) ? 1 : 0; }
       // the searches of all sets run in lock step: one staging buffer for their sums (one all-reduce per stage), one exchange
@@ -439,6 +462,8 @@ class Engine : public EngineBase {
     std::memset(hres_, 0, sizeof(double) * (p_n_ + 1) * SLOTS);
     SIPX_HIP(hipHostMalloc((void**)&hlean_, sizeof(int) * (p_n_ + 1), hipHostMallocDefault));
     std::memset((void*)hlean_, 0, sizeof(int) * (p_n_ + 1));
+    SIPX_HIP(hipHostMalloc((void**)&hovf_, sizeof(int) * (p_n_ + 1), hipHostMallocDefault));
+    std::memset((void*)hovf_, 0, sizeof(int) * (p_n_ + 1));
     {
       const char* e = std::getenv("SIPX_L1_SAMPLE");
       l1_sample_ = !(e && e[0] == '0');
@@ -562,7 +587,9 @@ class Engine : public EngineBase {
       } else if (s.two_pass) {
         SetArgs<T> a = set_args(s, rho_[i], gamma_[i], 0);
         a.x = mm;                                              // s = A m produced on the fly
-        K<T>::proj_scalars_set(stream_, Gr_, a, 1, s.psf, part_tmp_, maxpart_, scr_c_, s.Mtrue, SampleCtl(), hooks());
+        SampleCtl cf;
+        cf.host_ovf = (int*)hovf_ + i;
+        K<T>::proj_scalars_set(stream_, Gr_, a, 1, s.psf, part_tmp_, maxpart_, scr_c_, s.Mtrue, cf, hooks());
         K<T>::proj_dist_set(stream_, Gr_, a, 1, s.psf, dst);
       } else {
         K<T>::fwd(stream_, G_, s.nblk, s.dir, s.ih, mm, scr_v_);
@@ -571,6 +598,12 @@ class Engine : public EngineBase {
     }
     reduce_set_sums(p_n_ * SLOTS);
     SIPX_HIP(hipStreamSynchronize(stream_));
+    for (int i = 0; i < p_n_ && slab_; ++i)
+      if (hovf_[i]) {
+        hovf_[i] = 0;
+        throw std::runtime_error("initial feasibility of set " + std::to_string(i) + ": the magnitudes inside the final bracket of the l1 search, gathered over all ranks, exceed the exchange segment of " +
+                                 std::to_string(hooks_.gcap) + " values per rank (slab decomposition) -- use the set decomposition for this problem");
+      }
     for (int i = 0; i < pp_n_; ++i) {
       if (!sets_[i].owned && !comm_) continue;     // sharded: the all-reduced sums of every set are here
       feas_init_[i] = (double)feas_value(hres_[i * SLOTS + SL_FE2], hres_[i * SLOTS + SL_SS2]);
@@ -582,6 +615,7 @@ class Engine : public EngineBase {
   // ------------------------------------------------------------------------------------------
   void rhs_compose(const double* rho) override {
     need_final();
+    ObserverGuard og(observer());
     if (rs_pending_) {          // a right-hand side that was never consumed: let its exchange finish before rhs is rewritten
       SIPX_HIP(hipStreamWaitEvent(stream_, ev_c_[1], 0));
       rs_pending_ = false;
@@ -644,6 +678,7 @@ class Engine : public EngineBase {
 
   void argmin_x(int it, double* tol_ref_io, int64_t* cg_it, double* cg_relres, int* cg_flag) override {
     need_final();
+    ObserverGuard og(observer());
     if (rs_pending_) {                       // the reduce-scatter of rhs (communication stream) has to have landed
       SIPX_HIP(hipStreamWaitEvent(stream_, ev_c_[1], 0));
       rs_pending_ = false;
@@ -665,10 +700,8 @@ class Engine : public EngineBase {
       CgState<T>* mirror = cg_host_ + (k & 1);
       if (comm_)
         comm_->halo_exchange(p_ + r0, p_ + r0 - plane_, prev_, p_ + r1 - plane_, p_ + r1, next_, (size_t)plane_, dt, stream_);
-      if (stats_on_) stat_mark();
       if (stencil_q_) K<T>::sq_spmv_dot(stream_, G_, sq_, p_, Ap_, part_cg_, cg_dev_);
       else K<T>::spmv_dot(stream_, Nx_, r0, r1, Q_, cds_, p_, Ap_, part_cg_, cg_dev_);
-      if (stats_on_) stat_mark();
       if (comm_) comm_->allreduce_sum(part_cg_, NB, SIPX_F64, stream_);
       K<T>::cg_update_xr(stream_, nloc, x_ + r0, (k == 1 ? p_ : r_) + r0, r_ + r0, p_ + r0, Ap_ + r0, part_cg_, cg_dev_, mirror, k,
                          (unsigned long long*)ticket_);
@@ -682,11 +715,7 @@ class Engine : public EngineBase {
       CgState<T>* mirror = cg_host_ + (k & 1);
       T* pk = (k & 1) ? p_ : p2_;
       T* pn = (k & 1) ? p2_ : p_;
-      if (k == 1) {
-        if (stats_on_) stat_mark();
-        K<T>::spmv_dot(stream_, Nx_, r0, r1, Q_, cds_, p_, Ap_, part_cg_, cg_dev_);
-        if (stats_on_) stat_mark();
-      }
+      if (k == 1) K<T>::spmv_dot(stream_, Nx_, r0, r1, Q_, cds_, p_, Ap_, part_cg_, cg_dev_);
       K<T>::cg_update_xr(stream_, nloc, x_, k == 1 ? p_ : r_, r_, pk, Ap_, part_cg_, cg_dev_, mirror, k, (unsigned long long*)ticket_);
       K<T>::spmv_fused(stream_, Nx_, Q_, cds_, r_, pk, pn, Ap_, part_cg_, cg_dev_, mirror, (unsigned long long*)ticket_);
     };
@@ -696,7 +725,7 @@ class Engine : public EngineBase {
     // system to the tolerance, cg.jl:73-76) -- such a launch is not counted as a sample of the dominant kernel.
     // The first outer iteration of a solve is the one place where that is common (zero start: rhs = 0): there the verdict is
     // awaited first, so that rocprofv3's per-kernel averages hold launches with work only.
-    const size_t stat0 = stat_used_;
+    const size_t stat0 = samples_.size();
     const bool ahead = it > 1;
     auto enq = [&](int k) { if (cg_fused_) enqueue_fused(k); else enqueue(k); };
     if (ahead) enq(1);
@@ -704,7 +733,7 @@ class Engine : public EngineBase {
     CgState<T> fin;
     if (done) {
       fin = cg_host_[0];
-      stat_used_ = stat0;
+      drop_samples_from(stat0);          // the iteration queued ahead returned at once: not a sample of its kernels
       if (fin.flag == -9) SIPX_HIP(hipMemsetAsync(x_ + r0, 0, nloc * sizeof(T), stream_));   // cg.jl:51
     } else {
       const int maxIter = 1000;                       // argmin_x.jl:39
@@ -737,6 +766,7 @@ class Engine : public EngineBase {
   void update_y_l(int it, int flags, const double* rho, const double* gamma, double* r_pri, double* r_dual,
                   double* feas) override {
     need_final();
+    ObserverGuard og(observer());
     (void)it;
     if (mk_) K<T>::sum_uv(stream_, G_.N, x_, x_ + G_.N, w_);
     if (set_streams_ && !slab_) SIPX_HIP(hipEventRecord(ev_fork_, stream_));     // x (and u + v) are final: the sets may start
@@ -771,6 +801,7 @@ class Engine : public EngineBase {
         for (size_t j = 0; j < tp.size(); ++j) {
           SetState<T>& s = sets_[tp[j]];
           ctl[j].host_want = (int*)hlean_ + tp[j];
+          ctl[j].host_ovf = (int*)hovf_ + tp[j];
           ctl[j].runs = l1_sample_runs_;
           const bool rescaled = s.prox == PX_L1 && s.last_rho > T(0) && s.last_rho != args[j].rho;
           ctl[j].enable = l1_sample_ && s.prox == PX_L1 && (rescaled || hlean_[tp[j]] != 0);
@@ -828,7 +859,10 @@ class Engine : public EngineBase {
       }
       if (s.ext_kind) {   // library-backed projector: materialise v, project it in place, hand y to the fused update
         K<T>::store_v(q, G_, a, 0, scr_v_);
-        s.ext->project(scr_v_, false, ptmp, mpart, cbuf);
+        {
+          ObsScope obs(KID_EXT, stream_, 0.0);
+          s.ext->project(scr_v_, false, ptmp, mpart, cbuf);
+        }
         a.vsrc = 2;
       }
       if (s.two_pass && slab_) {          // (searched above, in lock step with the other sets)
@@ -844,6 +878,7 @@ class Engine : public EngineBase {
         // iteration reached the host.  (A stale word costs time only: the kernels check the device-side state themselves.)
         SampleCtl ctl;
         ctl.host_want = (int*)hlean_ + i;
+        ctl.host_ovf = (int*)hovf_ + i;
         ctl.runs = l1_sample_runs_;
         ctl.enable = l1_sample_ && !slab_ && a.prox == PX_L1 && !s.custom && (rescaled || hlean_[i] != 0);
         K<T>::proj_scalars_set(q, gs, ap, 0, s.ps, ptmp, mpart, cbuf, s.Mtrue, ctl, hooks());
@@ -856,7 +891,9 @@ class Engine : public EngineBase {
       if ((flags & SIPX_YL_FEAS) && s.ext_kind && i < pp_n_) ext_feasibility(s, a, part + (size_t)SL_FE2 * NB);
       if ((flags & SIPX_YL_FEAS) && s.two_pass && i < pp_n_) {
         // ||P_i(s) - s|| with s = A_i x produced on the fly; its own warm-started scalars (psf)
-        K<T>::proj_scalars_set(q, gs, a, 1, s.psf, ptmp, mpart, cbuf, s.Mtrue, SampleCtl(), hooks());
+        SampleCtl cf;
+        cf.host_ovf = (int*)hovf_ + i;
+        K<T>::proj_scalars_set(q, gs, a, 1, s.psf, ptmp, mpart, cbuf, s.Mtrue, cf, hooks());
         K<T>::proj_dist_set(q, gs, a, 1, s.psf, part + (size_t)SL_FE2 * NB);
       }
       if (to_other) { std::swap(s.y, s.y0); std::swap(s.l, s.l0); }     // (y, l) always names the current iterate
@@ -886,7 +923,10 @@ class Engine : public EngineBase {
         K<T>::store_v(stream_, G_, a, 0, scr_v_);
       }
       comm_->scatter(scr_v_, (size_t)chunk_, dt, s.owner_rank, stream_);
-      if (s.ext) s.ext->project(scr_v_ + r0_, false, part_tmp_, maxpart_, scr_c_);
+      if (s.ext) {
+        ObsScope obs(KID_EXT, stream_, 0.0);
+        s.ext->project(scr_v_ + r0_, false, part_tmp_, maxpart_, scr_c_);
+      }
       comm_->gather(scr_v_, (size_t)chunk_, dt, s.owner_rank, stream_);
       if (s.owned) {
         a.vsrc = 2;
@@ -926,6 +966,17 @@ class Engine : public EngineBase {
     const int flags = sums_flags_;
     SIPX_HIP(hipEventSynchronize(sums_event_));
     have_log_sums_ = false;
+    if (slab_) {
+      // a threshold search whose final bracket, over all ranks, held more magnitudes than the exchange segments: every rank saw
+      // the same segment headers and raised its word, so every rank leaves here with the same error -- never with NaN iterates
+      for (int i = 0; i < p_n_; ++i) {
+        if (!hovf_[i]) continue;
+        for (int k = 0; k <= p_n_; ++k) hovf_[k] = 0;
+        throw std::runtime_error("l1 threshold search of set " + std::to_string(i) + ": the magnitudes inside the final bracket, gathered over all "
+                                 "ranks, exceed the exchange segment of " + std::to_string(hooks_.gcap) + " values per rank "
+                                 "(slab decomposition); the iterate of this step is not valid -- use the set decomposition for this problem");
+      }
+    }
     const bool all = comm_ != nullptr;       // sharded: the all-reduced sums of every set are here, on every rank
     for (int i = 0; i < p_n_; ++i) {
       SetState<T>& s = sets_[i];
@@ -962,6 +1013,7 @@ class Engine : public EngineBase {
 
   void log_scalars(double* obj, double* evol_x) override {
     need_final();
+    ObserverGuard og(observer());
     if (!have_log_sums_) {
       K<T>::log3(stream_, G_.N, mk_ ? w_ : x_, m_, xold_, part_sets_);
       if (mk_) K<T>::log3(stream_, Nx_, x_, (const T*)nullptr, xold_, part_sets_ + (size_t)SLOTS * NB);
@@ -993,6 +1045,7 @@ class Engine : public EngineBase {
 
   void q_update(const double* rho_new, const double* rho_old) override {
     need_final();
+    ObserverGuard og(observer());
     if (stencil_q_) {
       stencil_weights(rho_new);
       return;
@@ -1166,6 +1219,7 @@ class Engine : public EngineBase {
     Run& R = run_;
     if (!R.active) throw std::runtime_error("sipx_parsdmm_steps: call sipx_parsdmm_begin first");
     if (R.done) return true;
+    ObserverGuard og(observer());
     sipx_log* log = R.log;
     const int p = p_n_, pp = pp_n_, maxit = R.maxit;
     std::vector<double>&rho = R.rho, &gamma = R.gamma, &rho_new = R.rho_new, &rpri = R.rpri, &rdual = R.rdual, &feas = R.feas;
@@ -1186,6 +1240,8 @@ class Engine : public EngineBase {
     // can the rules at the end of iteration `it` change rho?  If not, the right-hand side of iteration it+1 is known as soon
     // as the y/l kernels of `it` are queued
     auto rho_may_change = [&](int it) {
+      for (int k = 0; k < p; ++k)          // the clamp to [1e-2, 1e4] runs every iteration (PARSDMM.jl:226): a rho_ini outside it changes at once
+        if ((T)rho[k] != std::max(std::min((T)rho[k], T(1e4)), T(1e-2))) return true;
       return ((R.adjust_rho || R.adjust_gamma) && it % R.freq == 0) || (R.adjust_feas_rho && it % 10 == 0 && it > 10 && pp > 0);
     };
     {
@@ -1455,38 +1511,40 @@ class Engine : public EngineBase {
     return (double)ms / reps;
   }
 
+  // Per-kernel statistics.  mode 0: off; 1: the product of the CG iteration only (k_cds<MODE=1> / k_sq<MODE=1>: what the
+  // bench line's `roofline` is measured on, inside the timed region -- two event records per CG iteration); 2: EVERY kernel
+  // the engine launches (two records around each: about 5 us per launch, so this mode is for a window of its own, not for
+  // the timed region).  Samples are bracketed on the stream the kernel is launched on.
   void kernel_stats(int enable, int64_t* launches, double* total_ms) override {
     need_final();
-    SIPX_HIP(hipStreamSynchronize(stream_));
-    double tot = 0;
-    for (size_t k = 0; k + 1 < stat_used_; k += 2) {
-      float ms = 0;
-      SIPX_HIP(hipEventElapsedTime(&ms, stat_ev_[k], stat_ev_[k + 1]));
-      tot += ms;
+    std::vector<KAgg> agg = aggregate_samples();
+    const KAgg& a = stencil_q_ ? agg[KID_SQ_DOT] : agg[KID_CDS_DOT];
+    if (launches) *launches = a.launches;
+    if (total_ms) *total_ms = a.ms;
+    start_stats(enable);
+  }
+  const char* kernel_stats_json(int enable) override {
+    need_final();
+    std::vector<KAgg> agg = aggregate_samples();
+    std::string& o = stats_json_;
+    o = "{\"mode\": " + std::to_string(stats_mode_) + ", \"event_pair_overhead_ms\": " + std::to_string(stat_pair_ms_) + ", \"kernels\": [";
+    bool first = true;
+    char buf[512];
+    for (int k = 0; k < KID_COUNT; ++k) {
+      if (!agg[k].launches) continue;
+      const bool gated = k == KID_PASS_FIRST || k == KID_PASS_LEAN || k == KID_PASS_PROBE || k == KID_PASS_COMPACT || k == KID_SAMPLE ||
+                         k == KID_DECIDE || k == KID_CDS_FUSED || k == KID_CG_XR || k == KID_CG_P || k == KID_SLOT_SUMS;
+      std::snprintf(buf, sizeof buf,
+                    "%s{\"name\": \"%s\", \"launches\": %lld, \"total_ms\": %.6f, \"bytes_survey\": %.0f, \"bytes_moved\": %.0f, "
+                    "\"gated\": %s, \"inclusive\": %s}",
+                    first ? "" : ", ", kernel_name(k), (long long)agg[k].launches, agg[k].ms, agg[k].bytes_survey, agg[k].bytes_moved,
+                    gated ? "true" : "false", k == KID_EXT ? "true" : "false");
+      o += buf;
+      first = false;
     }
-    // two records with nothing between them are still some microseconds apart on the stream's timeline; that share of
-    // every sample is not kernel time (calibrated below on the idle stream, when the collection is switched on)
-    tot -= (double)(stat_used_ / 2) * stat_pair_ms_;
-    if (launches) *launches = (int64_t)(stat_used_ / 2);
-    if (total_ms) *total_ms = tot > 0 ? tot : 0;
-    if (enable) {
-      stat_used_ = 0;
-      std::vector<float> gap;
-      for (int k = 0; k < 16; ++k) {
-        stat_mark();
-        stat_mark();
-      }
-      SIPX_HIP(hipStreamSynchronize(stream_));
-      for (size_t k = 0; k + 1 < stat_used_; k += 2) {
-        float ms = 0;
-        SIPX_HIP(hipEventElapsedTime(&ms, stat_ev_[k], stat_ev_[k + 1]));
-        gap.push_back(ms);
-      }
-      std::sort(gap.begin(), gap.end());
-      stat_pair_ms_ = gap[gap.size() / 2];
-      stat_used_ = 0;
-    }
-    stats_on_ = enable != 0;
+    o += "]}";
+    start_stats(enable);
+    return o.c_str();
   }
   double stat_pair_overhead_ms() const { return stat_pair_ms_; }
 
@@ -1516,14 +1574,80 @@ class Engine : public EngineBase {
   }
 
  private:
-  void stat_mark() {
-    if (stat_used_ == stat_ev_.size()) {
+  struct KSample { int kid; double bytes_survey, bytes_moved; };
+  struct KAgg { long long launches = 0; double ms = 0, bytes_survey = 0, bytes_moved = 0; };
+  hipEvent_t stat_event(size_t i) {
+    while (stat_ev_.size() <= i) {
       hipEvent_t e;
       SIPX_HIP(hipEventCreate(&e));
       stat_ev_.push_back(e);
     }
-    SIPX_HIP(hipEventRecord(stat_ev_[stat_used_++], stream_));
+    return stat_ev_[i];
   }
+  static void obs_begin(void* user, int kid, hipStream_t s, double bytes_survey, double bytes_moved) {
+    auto* e = static_cast<Engine<T>*>(user);
+    if (e->stats_mode_ == 0 || (e->stats_mode_ == 1 && kid != KID_CDS_DOT && kid != KID_SQ_DOT)) return;
+    const size_t i = e->samples_.size();
+    e->samples_.push_back(KSample{kid, bytes_survey, bytes_moved});
+    e->open_.push_back(i);
+    SIPX_HIP(hipEventRecord(e->stat_event(2 * i), s));
+  }
+  static void obs_end(void* user, int kid, hipStream_t s) {
+    auto* e = static_cast<Engine<T>*>(user);
+    if (e->stats_mode_ == 0 || (e->stats_mode_ == 1 && kid != KID_CDS_DOT && kid != KID_SQ_DOT)) return;
+    if (e->open_.empty()) return;
+    const size_t i = e->open_.back();
+    e->open_.pop_back();
+    if (i < e->samples_.size()) SIPX_HIP(hipEventRecord(e->stat_event(2 * i + 1), s));
+  }
+  void drop_samples_from(size_t n) {
+    if (n < samples_.size()) samples_.resize(n);
+    open_.clear();
+  }
+  void sync_all_streams() {
+    SIPX_HIP(hipStreamSynchronize(stream_));
+    for (hipStream_t q : pool_) if (q != stream_) SIPX_HIP(hipStreamSynchronize(q));
+    if (cstream_) SIPX_HIP(hipStreamSynchronize(cstream_));
+  }
+  std::vector<KAgg> aggregate_samples() {
+    sync_all_streams();
+    std::vector<KAgg> agg(KID_COUNT);
+    for (size_t i = 0; i < samples_.size(); ++i) {
+      float ms = 0;
+      if (hipEventElapsedTime(&ms, stat_ev_[2 * i], stat_ev_[2 * i + 1]) != hipSuccess) { (void)hipGetLastError(); continue; }
+      KAgg& a = agg[samples_[i].kid];
+      // two records with nothing between them are still some microseconds apart on the stream's timeline; that share of
+      // every sample is not kernel time (calibrated on the idle stream when the collection is switched on)
+      const double t = (double)ms - stat_pair_ms_;
+      a.launches += 1;
+      a.ms += t > 0 ? t : 0;
+      a.bytes_survey += samples_[i].bytes_survey;
+      a.bytes_moved += samples_[i].bytes_moved;
+    }
+    return agg;
+  }
+  void start_stats(int mode) {
+    samples_.clear();
+    open_.clear();
+    stats_mode_ = 0;
+    if (mode) {
+      std::vector<float> gap;
+      for (int k = 0; k < 16; ++k) {
+        SIPX_HIP(hipEventRecord(stat_event(2 * k), stream_));
+        SIPX_HIP(hipEventRecord(stat_event(2 * k + 1), stream_));
+      }
+      SIPX_HIP(hipStreamSynchronize(stream_));
+      for (int k = 0; k < 16; ++k) {
+        float ms = 0;
+        SIPX_HIP(hipEventElapsedTime(&ms, stat_ev_[2 * k], stat_ev_[2 * k + 1]));
+        gap.push_back(ms);
+      }
+      std::sort(gap.begin(), gap.end());
+      stat_pair_ms_ = gap[gap.size() / 2];
+    }
+    stats_mode_ = mode;
+  }
+  const LaunchObserver* observer() const { return stats_mode_ ? &obs_ : nullptr; }
 
   void need_final() const {
     if (!finalized_) throw std::runtime_error("call sipx_finalize first");
@@ -2085,6 +2209,7 @@ class Engine : public EngineBase {
   CgState<T>*cg_dev_ = nullptr, *cg_host_ = nullptr;
   double* hres_ = nullptr;
   volatile int* hlean_ = nullptr;     // per set: the coming l1 search wants a sampled prediction (written by k_l1_solve)
+  volatile int* hovf_ = nullptr;      // per set: the slab-decomposed search overflowed its exchange segments (k_gather_unpack)
   long long l1_sample_runs_ = 0;
   bool l1_sample_ = true;             // SIPX_L1_SAMPLE=0: no sampled prediction of theta (A/B switch)
   std::vector<hipEvent_t> ev_;
@@ -2115,9 +2240,12 @@ class Engine : public EngineBase {
   double obj_ss_ = 0, evo_ss_ = 0, xx_ss_ = 0;
   bool have_log_sums_ = false;
   hipEvent_t cg_ev_[2] = {nullptr, nullptr};
-  std::vector<hipEvent_t> stat_ev_;
-  size_t stat_used_ = 0;
-  bool stats_on_ = false;
+  std::vector<hipEvent_t> stat_ev_;       // events 2 i, 2 i + 1 bracket sample i
+  std::vector<KSample> samples_;
+  std::vector<size_t> open_;              // samples whose closing record is still to come (launch scopes may nest)
+  int stats_mode_ = 0;
+  LaunchObserver obs_{this, &Engine<T>::obs_begin, &Engine<T>::obs_end};
+  std::string stats_json_;
   double stat_pair_ms_ = 0;       // elapsed time between two adjacent event records (median of 16 on the idle stream)
 };
 

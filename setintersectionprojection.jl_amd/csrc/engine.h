@@ -38,6 +38,7 @@ struct EngineBase {
   virtual void apply_Q(const void* x, void* y) = 0;
   virtual double time_spmv(int reps) = 0;
   virtual void kernel_stats(int enable, int64_t* launches, double* total_ms) = 0;
+  virtual const char* kernel_stats_json(int enable) = 0;
   virtual void debug_proj(int set, int which, double* out16) = 0;
   virtual void* stream() = 0;
   virtual void* dev_rhs() = 0;
@@ -47,6 +48,7 @@ struct EngineBase {
   virtual void set_q_mode(int mode) = 0;
   virtual void set_decomp(int mode) = 0;
   virtual void set_comm(Comm* c) = 0;       // takes ownership
+  virtual void comm_info(int* nranks, int* rank, char* version, int version_len, int* decomposition) = 0;
   virtual void bind_device() = 0;           // makes the context's GPU the calling thread's current device
   virtual void slab(int64_t* row0, int64_t* row1, int64_t* chunk) = 0;
 };

@@ -154,6 +154,12 @@ static void launch_cds(hipStream_t s, long long N, long long r0, long long r1, c
                        const T* b, T* pout, T* xold, double* partials, const int* done) {
   if (a.d < 1 || a.d > MAXD) throw std::runtime_error("cds: band count out of range");
   if (r0 < 0 || r1 > N || r0 > r1) throw std::runtime_error("cds: row range outside the matrix");
+  // algorithmic bytes: SURVEY 8(d) counts all d bands + the vector read + the result written ((d+2) rows w; the residual form
+  // also reads b and writes x_old: +2); what has to move: only the bands with a non-negative offset under the symmetric read
+  int read_bands = a.d;
+  if (a.sym) { read_bands = 0; for (int b = 0; b < a.d; ++b) read_bands += a.off[b] >= 0 ? 1 : 0; }
+  const double rw = (double)(r1 - r0) * sizeof(T), extra = MODE == 2 ? 4.0 : 2.0;
+  ObsScope obs(MODE == 0 ? KID_CDS_SPMV : (MODE == 1 ? KID_CDS_DOT : KID_CDS_RESID), s, (a.d + extra) * rw, (read_bands + extra) * rw);
 #define SIPX_CDS(V, D) \
   hipLaunchKernelGGL((k_cds<T, V, D, MODE>), dim3(fit_grid((r1 - r0) / V, SIPX_CG_GRID)), dim3(BLOCK), 0, s, N, r0, r1, R, a, x, y, b, pout, xold, partials, done)
   // 16 bytes per thread and band: four floats or two doubles (four doubles leave the 7-band kernel 3 waves per SIMD)
@@ -266,6 +272,7 @@ __global__ __launch_bounds__(BLOCK) void k_sq(Grid G, StencilQ<T> q, const T* __
 template <typename T, int MODE>
 static void launch_sq(hipStream_t s, const Grid& G, const StencilQ<T>& q, const T* x, T* y, const T* b, T* pout, T* xold,
                       double* partials, const int* done) {
+  ObsScope obs(MODE == 0 ? KID_SQ_SPMV : (MODE == 1 ? KID_SQ_DOT : KID_SQ_RESID), s, (MODE == 2 ? 4.0 : 2.0) * (double)G.N * sizeof(T));
   // the stencil form streams 2N values and wants the larger grid (43 us at 3 workgroups per CU, 32 us at 7; 256^3);
   // block_reduce_store clears the partial entries beyond a launch's grid, so it may differ from cg_update_xr's
   if (G.N % 4 == 0 && G.n[0] % 4 == 0)
@@ -389,6 +396,20 @@ template <typename T>
 void K<T>::q_update(hipStream_t s, const Grid& g, long long r0, long long r1, const CdsArgs& q, const QArgs<T>& a, T* Q) {
   if (a.nsets == 0 || r1 <= r0) return;
   if (r0 < 0 || r1 > g.N) throw std::runtime_error("q_update: row range outside the matrix");
+  double touched = 0, survey = 0;        // bands of Q read and written once; SURVEY 8(d): B_Q = sum over changed sets of 3 d_i N w
+  for (int b = 0; b < q.d; ++b) {
+    if (q.sym && q.off[b] < 0) continue;
+    bool hit = false;
+    for (int si = 0; si < a.nsets; ++si)
+      for (int t = 0; t < a.s[si].nband; ++t) {
+        if (a.s[si].off[t] != q.off[b]) continue;
+        hit = true;
+        if (a.s[si].ata) touched += 1;
+      }
+    touched += hit ? 2 : 0;
+  }
+  for (int si = 0; si < a.nsets; ++si) survey += 3.0 * a.s[si].nband;
+  ObsScope obs(KID_Q_UPDATE, s, survey * (double)(r1 - r0) * sizeof(T), touched * (double)(r1 - r0) * sizeof(T));
   if (g.n[0] % 4 == 0 && r0 % 4 == 0 && r1 % 4 == 0)
     hipLaunchKernelGGL((k_q_update<T, 4>), dim3(fit_grid((r1 - r0) / 4, NB)), dim3(BLOCK), 0, s, g, r0, r1, q, a, Q);
   else
@@ -511,6 +532,7 @@ __global__ __launch_bounds__(BLOCK) void k_cg_begin(const double* __restrict__ p
 template <typename T>
 void K<T>::cg_begin(hipStream_t s, double* partials, CgState<T>* st, CgState<T>* host, int it_outer, T tol_ref, unsigned seq,
                     unsigned long long* ticket) {
+  ObsScope obs(KID_CG_BEGIN, s, 0.0);
   hipLaunchKernelGGL((k_cg_begin<T>), dim3(1), dim3(BLOCK), 0, s, partials, st, host, it_outer, tol_ref, seq, ticket);
   SIPX_HIP(hipGetLastError());
 }
@@ -563,6 +585,7 @@ __global__ __launch_bounds__(BLOCK) void k_cg_update_xr(long long N, T* __restri
 template <typename T>
 void K<T>::cg_update_xr(hipStream_t s, long long N, T* x, const T* r_in, T* r, const T* p, const T* Ap, double* partials,
                         CgState<T>* st, CgState<T>* host, int iter, unsigned long long* ticket) {
+  ObsScope obs(KID_CG_XR, s, 6.0 * (double)N * sizeof(T));        // x, r, p, Ap read; x, r written
   if (N % 4 == 0 && aligned16(x, r_in, r, p, Ap))
     hipLaunchKernelGGL((k_cg_update_xr<T, 4>), dim3(fit_grid(N / 4, SIPX_CG_GRID)), dim3(BLOCK), 0, s, N, x, r_in, r, p, Ap, partials, st, host, iter, ticket);
   else
@@ -609,6 +632,7 @@ __global__ __launch_bounds__(BLOCK) void k_cg_update_p(long long N, T* __restric
 template <typename T>
 void K<T>::cg_update_p(hipStream_t s, long long N, T* p, const T* r, const double* partials, CgState<T>* st,
                        CgState<T>* host, unsigned long long* ticket) {
+  ObsScope obs(KID_CG_P, s, 3.0 * (double)N * sizeof(T));         // r, p read; p written
   if (N % 4 == 0 && aligned16(p, r))
     hipLaunchKernelGGL((k_cg_update_p<T, 4>), dim3(fit_grid(N / 4, NB)), dim3(BLOCK), 0, s, N, p, r, partials, st, host, ticket);
   else
@@ -675,6 +699,9 @@ template <typename T>
 void K<T>::spmv_fused(hipStream_t s, long long N, const T* R, const CdsArgs& a, const T* r, const T* p_old, T* p_new, T* Ap,
                       double* partials, CgState<T>* st, CgState<T>* host, unsigned long long* ticket) {
   if (a.d < 1 || a.d > MAXD) throw std::runtime_error("cds: band count out of range");
+  int read_bands = a.d;
+  if (a.sym) { read_bands = 0; for (int b = 0; b < a.d; ++b) read_bands += a.off[b] >= 0 ? 1 : 0; }
+  ObsScope obs(KID_CDS_FUSED, s, (a.d + 4.0) * (double)N * sizeof(T), (read_bands + 4.0) * (double)N * sizeof(T));   // r, p_k read; p_k+1, Ap written
 #define SIPX_CDSF(V, D) \
   hipLaunchKernelGGL((k_cds_fused<T, V, D>), dim3(fit_grid(N / V, SIPX_CG_GRID)), dim3(BLOCK), 0, s, N, R, a, r, p_old, p_new, Ap, partials, st, host, ticket)
   constexpr int VW = sizeof(T) == 8 ? SIPX_F64_VEC : 4;
@@ -705,6 +732,7 @@ __global__ __launch_bounds__(BLOCK) void k_fin_sum(const double* __restrict__ pa
 }
 template <typename T>
 void K<T>::fin_sum(hipStream_t s, const double* partials, int nslots, double* out_dev, double* out_host) {
+  ObsScope obs(KID_FIN_SUM, s, (double)nslots * NB * sizeof(double));
   hipLaunchKernelGGL(k_fin_sum, dim3(nslots), dim3(BLOCK), 0, s, partials, out_dev, out_host);
   SIPX_HIP(hipGetLastError());
 }

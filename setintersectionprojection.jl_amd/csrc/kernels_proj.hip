@@ -28,6 +28,20 @@
 
 namespace sipx {
 
+// MEMORY-MODEL ASSUMPTION of the last-workgroup hand-offs in this file (k_slot_sums<FUSE>, k_sample, the coop_* publishing of
+// k_l1_solve): a workgroup publishes its values with RELAXED agent-scope atomic stores, waits for them with s_waitcnt(0), then
+// takes a ticket with a RELAXED agent-scope fetch-add; the workgroup that draws the last ticket reads the values back with
+// relaxed agent-scope atomic loads.  The HIP / LLVM memory model does not order relaxed operations on different addresses; the
+// hardware this file is written for does: on gfx950 (CDNA4) an agent-scope atomic store is performed at the coherence point
+// (sc1: write-through, it never sits dirty in the XCD's L2) and is counted in vmcnt, so s_waitcnt(0) before the ticket means
+// "my stores have been performed"; an agent-scope atomic load bypasses the non-coherent levels.  A release / acquire pair
+// instead would write back / invalidate the XCD's whole L2 -- which holds whatever the other set stream left dirty -- and cost
+// 15 of k_sample's 40 us (measured).  A target with a separate store counter or a different cache protocol must not
+// compile this as is:
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(__gfx950__)
+#error "kernels_proj.hip: the relaxed-atomics hand-offs assume gfx950 (see the comment above); port them to release/acquire first"
+#endif
+
 constexpr long long SOLVE_COOP_MIN_DEFAULT = 1ll << 17;
 constexpr double L1_CAP = 131072.0;     // bracket population above which one more probe pass is run (floor; scales with the length)
 constexpr int L1_REFINES = 1;           // gated refinement passes enqueued per search
@@ -1261,7 +1275,8 @@ __global__ __launch_bounds__(BLOCK) void k_gather_pack(ProjScalars<T>* ps, const
 
 template <typename T>
 __global__ __launch_bounds__(BLOCK) void k_gather_unpack(ProjScalars<T>* ps, T* __restrict__ compact, double* __restrict__ partials,
-                                                         const T* __restrict__ gseg0, long long chunk, int world, long long compact_len) {
+                                                         const T* __restrict__ gseg0, long long chunk, int world, long long compact_len,
+                                                         int* host_ovf) {
   // gseg0: this set's segment in rank 0's chunk of the exchange buffer; rank r's is `chunk` elements further per rank
   long long off = 0;
   double sa = 0, ca = 0;
@@ -1284,7 +1299,10 @@ __global__ __launch_bounds__(BLOCK) void k_gather_unpack(ProjScalars<T>* ps, T* 
     }
     if (threadIdx.x == 0) {
       ps->n_compact = bad ? 0ull : (unsigned long long)off;
-      if (bad) ps->gather_overflow = 1;
+      // every rank reads the same headers, so every rank takes the same verdict: theta = NaN for this search (k_l1_solve) and
+      // the host's pinned word raised -- the engine returns an error from the y/l update on every rank alike
+      ps->gather_overflow = bad ? 1 : 0;
+      if (bad && host_ovf) __hip_atomic_store(host_ovf, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     }
   }
 }
@@ -1304,8 +1322,21 @@ __global__ void k_ps_rescale(ProjScalars<T>* ps, double factor, double hw_max) {
 }
 template <typename T>
 void K<T>::ps_rescale(hipStream_t s, ProjScalars<T>* ps, double factor) {
+  ObsScope obs_(KID_PS_RESCALE, s, 0.0);
   hipLaunchKernelGGL((k_ps_rescale<T>), dim3(1), dim3(1), 0, s, ps, factor, l1_hw_max());
   SIPX_HIP(hipGetLastError());
+}
+
+// algorithmic bytes of one sweep of k_pass: x (+ y, l of every block unless the vector is s = A x itself), or the stored array
+template <typename T>
+static double pass_bytes(const Grid& g, const SetArgs<T>& a, int v_is_s, int src, long long len, bool stores) {
+  if (src == 0) return (double)len * sizeof(T);
+  const double n = (double)range_len(g), nb = a.nblk > 0 ? a.nblk : 1;
+  return (n + (v_is_s ? 0.0 : 2.0 * nb * n) + (stores ? nb * n : 0.0)) * sizeof(T);
+}
+constexpr int pass_kid(int mode) {
+  return mode == M_FIRST ? KID_PASS_FIRST : mode == M_LEAN ? KID_PASS_LEAN : mode == M_PROBE ? KID_PASS_PROBE
+       : mode == M_COMPACT ? KID_PASS_COMPACT : mode == M_DIST ? KID_PASS_DIST : KID_PASS_STORE;
 }
 
 // One search = four stages; on a slab-decomposed grid a collective sits between consecutive stages (and the engine runs the
@@ -1328,6 +1359,7 @@ static void chain_stage(int stage, hipStream_t s, const Grid& g, const SetArgs<T
   const DecideArgs da1{a.prox, 0, (double)a.plo, (double)a.phi, capdiv, cap_max, true_len};
 #define SIPX_PASS(MODE)                                                                                            \
   do {                                                                                                             \
+    ObsScope obs_(pass_kid(MODE), s, pass_bytes<T>(g, a, v_is_s, SRC, len, false));                                \
     if (vec)                                                                                                       \
       hipLaunchKernelGGL((k_pass<T, 4, MODE, SRC>), dim3(fit_grid(range_len(g) / 4, SIPX_PASS_GRID)), dim3(BLOCK), 0, s, g, a, v_is_s, varr, len, ps, compact, \
                          partials, maxpart);                                                                       \
@@ -1340,19 +1372,26 @@ static void chain_stage(int stage, hipStream_t s, const Grid& g, const SetArgs<T
     // share of the sample into the set's region `reg` of the sample staging buffer (2 SAMPLE_BINS + 3 doubles), an all-reduce
     // of the caller, stage 11 = the decision on the summed histogram.
     if (SRC == 1 && vec && ctl.enable && a.prox == PX_L1 && !v_is_s) {
-      // about a million grid points (times the operator's blocks); not worth it when that is more than a quarter of the vector
-      const long long nchunks = (range_len(g) / 4 + SAMPLE_RUN - 1) / SAMPLE_RUN;  // runs of 64 grid points
-      long long target = ctl.runs > 0 ? ctl.runs : (g.N >= (1ll << 26) ? 32768 : 16384);   // one or two million sampled points
-      if (hk) target = std::max<long long>(target / hk->world, 16);                // ... over all ranks
-      const long long stride = nchunks / target;
-      double gcap = 0.2 * (double)fit_grid(range_len(g) / 4, SIPX_PASS_GRID) * (double)SPEC_CAP * (double)world;   // a fifth of the LDS buffers of the pass
+      // about a million grid points (times the operator's blocks); not worth it when that is more than a quarter of the vector.
+      // Slab-decomposed grid: WHETHER the sample is taken, its stride and the capacity it plans for are functions of the
+      // whole grid and the number of ranks only -- a rank with a short (or empty) slab must take the same decisions as the
+      // others, or the all-reduced histogram mixes searches probing at different thresholds.  Such a rank launches the
+      // kernels all the same: with nothing to sample they write the zeros its share of the all-reduce has to hold.
+      const long long nchunks = (range_len(g) / 4 + SAMPLE_RUN - 1) / SAMPLE_RUN;  // runs of 64 grid points on this rank
+      const long long nchunks_all = hk ? (g.N / 4 + SAMPLE_RUN - 1) / SAMPLE_RUN : nchunks;
+      const long long target = ctl.runs > 0 ? ctl.runs : (g.N >= (1ll << 26) ? 32768 : 16384);   // one or two million sampled points, over all ranks
+      const long long stride = nchunks_all / target;
+      const long long per_rank = hk ? (g.N / world + 3) / 4 : range_len(g) / 4;     // vectors of a full slab
+      double gcap = 0.2 * (double)fit_grid(per_rank, SIPX_PASS_GRID) * (double)SPEC_CAP * (double)world;   // a fifth of the LDS buffers of the pass
       if (hk && gcap > 0.8 * cap_max) gcap = 0.8 * cap_max;
       // (below 2^24 grid points the extra launch costs more than the sweeps it saves: 2048^2 loses 3 %; a test may force it)
       if (stride >= 4 && (g.N >= (1ll << 24) || ctl.runs > 0)) {
-        const long long nsamp = nchunks / stride;
+        const long long nsamp = nchunks / stride;            // may be 0 on a short slab
+        ObsScope obs_(stage != 11 ? KID_SAMPLE : KID_DECIDE, s, 0.0);
         if (stage != 11)
-          hipLaunchKernelGGL((k_sample<T, 4>), dim3((unsigned)(nsamp < SAMPLE_WG ? nsamp : SAMPLE_WG)), dim3(SAMPLE_NT), 0, s, g, a, ps, partials,
-                             nchunks, nsamp, (unsigned int)stride, true_len, l1_hw_max(), l1_lean_on(), gcap, stage == 10 ? reg : (double*)nullptr);
+          hipLaunchKernelGGL((k_sample<T, 4>), dim3((unsigned)(nsamp < 1 ? 1 : (nsamp < SAMPLE_WG ? nsamp : SAMPLE_WG))), dim3(SAMPLE_NT), 0, s, g, a, ps,
+                             partials, nchunks, nsamp, (unsigned int)stride, true_len, l1_hw_max(), l1_lean_on(), gcap,
+                             stage == 10 ? reg : (double*)nullptr);
         else
           hipLaunchKernelGGL((k_sample_decide2<T>), dim3(1), dim3(SAMPLE_NT), 0, s, ps, reg, a.phi, true_len, l1_hw_max(), l1_lean_on(), gcap);
       }
@@ -1365,25 +1404,40 @@ static void chain_stage(int stage, hipStream_t s, const Grid& g, const SetArgs<T
     if (a.prox == PX_L1 && !(a.flags & F_NOSPEC)) SIPX_PASS(M_LEAN);
     // one rank: the last workgroup of the sums takes the decision (no k_decide launch); slab-decomposed: an all-reduce of the
     // caller sits between the two
+    ObsScope obs_(KID_SLOT_SUMS, s, 0.0);
     if (hk) hipLaunchKernelGGL((k_slot_sums<T, 0, false>), dim3(PREP_SLOTS + 1), dim3(BLOCK), 0, s, partials, maxpart, ps, rank, world, reg, da0);
     else hipLaunchKernelGGL((k_slot_sums<T, 0, true>), dim3(PREP_SLOTS + 1), dim3(BLOCK), 0, s, partials, maxpart, ps, rank, world, reg, da0);
   } else if (stage == 1) {
-    if (hk)
+    if (hk) {
+      ObsScope obs_(KID_DECIDE, s, 0.0);
       hipLaunchKernelGGL((k_decide<T, 0>), dim3(1), dim3(64), 0, s, ps, a.prox, a.plo, a.phi, true_len, (a.flags & F_NOSPEC) ? 1 : 0, capdiv,
                          world, cap_max, reg);
+    }
     if (a.prox == PX_L1) {
       SIPX_PASS(M_PROBE);
+      ObsScope obs_(KID_SLOT_SUMS, s, 0.0);
       if (hk) hipLaunchKernelGGL((k_slot_sums<T, 1, false>), dim3(PREP_SLOTS), dim3(BLOCK), 0, s, partials, maxpart, ps, rank, world, reg, da1);
       else hipLaunchKernelGGL((k_slot_sums<T, 1, true>), dim3(PREP_SLOTS), dim3(BLOCK), 0, s, partials, maxpart, ps, rank, world, reg, da1);
     }
   } else if (stage == 2) {
     if (a.prox == PX_L1) {
-      if (hk) hipLaunchKernelGGL((k_decide<T, 1>), dim3(1), dim3(64), 0, s, ps, a.prox, a.plo, a.phi, true_len, 0, capdiv, world, cap_max, reg);
+      if (hk) {
+        ObsScope obs_(KID_DECIDE, s, 0.0);
+        hipLaunchKernelGGL((k_decide<T, 1>), dim3(1), dim3(64), 0, s, ps, a.prox, a.plo, a.phi, true_len, 0, capdiv, world, cap_max, reg);
+      }
       SIPX_PASS(M_COMPACT);
-      if (hk) hipLaunchKernelGGL((k_gather_pack<T>), dim3(64), dim3(BLOCK), 0, s, ps, compact, partials, gseg0 + (long long)rank * chunk, hk->gcap);
+      if (hk) {
+        ObsScope obs_(KID_GATHER, s, 0.0);
+        hipLaunchKernelGGL((k_gather_pack<T>), dim3(64), dim3(BLOCK), 0, s, ps, compact, partials, gseg0 + (long long)rank * chunk, hk->gcap);
+      }
     }
   } else if (a.prox == PX_L1) {
-    if (hk) hipLaunchKernelGGL((k_gather_unpack<T>), dim3(64), dim3(BLOCK), 0, s, ps, compact, partials, gseg0, chunk, world, compact_len);
+    if (hk) {
+      ObsScope obs_(KID_GATHER, s, 0.0);
+      hipLaunchKernelGGL((k_gather_unpack<T>), dim3(64), dim3(BLOCK), 0, s, ps, compact, partials, gseg0, chunk, world, compact_len,
+                         ctl.host_ovf);
+    }
+    ObsScope obs_(KID_L1_SOLVE, s, 0.0);
     hipLaunchKernelGGL((k_l1_solve<T>), dim3(hk ? 1 : SOLVE_G), dim3(SIPX_SOLVE_NT), 0, s, ps, a.phi, compact, partials, true_len, l1_hw_max(),
                        l1_lean_on(), ctl.host_want, solve_coop_min());
   }
@@ -1400,6 +1454,7 @@ static void launch_chain(hipStream_t s, const Grid& g, const SetArgs<T>& a, int 
     const bool vec = SRC == 1 && g.n[0] % 4 == 0;
 #define SIPX_PASS(MODE)                                                                                            \
   do {                                                                                                             \
+    ObsScope obs_(pass_kid(MODE), s, pass_bytes<T>(g, a, v_is_s, SRC, len, false));                                \
     if (vec)                                                                                                       \
       hipLaunchKernelGGL((k_pass<T, 4, MODE, SRC>), dim3(fit_grid(range_len(g) / 4, SIPX_PASS_GRID)), dim3(BLOCK), 0, s, g, a, v_is_s, varr, len, ps, compact, \
                          partials, maxpart);                                                                       \
@@ -1409,13 +1464,14 @@ static void launch_chain(hipStream_t s, const Grid& g, const SetArgs<T>& a, int 
   } while (0)
     const long long kc = (long long)a.phi;
     SIPX_PASS(M_FIRST);
-    hipLaunchKernelGGL((k_card_decide<T, 0>), dim3(1), dim3(1024), 0, s, partials, maxpart, ps, kc, true_len);
+    { ObsScope obs_(KID_CARD, s, 0.0); hipLaunchKernelGGL((k_card_decide<T, 0>), dim3(1), dim3(1024), 0, s, partials, maxpart, ps, kc, true_len); }
     for (int r = 0; r < CARD_REFINES; ++r) {
       SIPX_PASS(M_PROBE);
+      ObsScope obs_(KID_CARD, s, 0.0);
       hipLaunchKernelGGL((k_card_decide<T, 1>), dim3(1), dim3(1024), 0, s, partials, maxpart, ps, kc, true_len);
     }
     SIPX_PASS(M_COMPACT);
-    hipLaunchKernelGGL((k_card_select<T>), dim3(1), dim3(1024), 0, s, ps, kc, compact);
+    { ObsScope obs_(KID_CARD, s, 0.0); hipLaunchKernelGGL((k_card_select<T>), dim3(1), dim3(1024), 0, s, ps, kc, compact); }
     SIPX_HIP(hipGetLastError());
 #undef SIPX_PASS
     return;
@@ -1467,6 +1523,7 @@ void K<T>::proj_scalars_arr(hipStream_t s, long long len, const T* v, int prox, 
 }
 template <typename T>
 void K<T>::store_v(hipStream_t s, const Grid& g, const SetArgs<T>& a, int v_is_s, T* out) {
+  ObsScope obs_(KID_PASS_STORE, s, pass_bytes<T>(g, a, v_is_s, 1, 0, true));
   if (g.n[0] % 4 == 0)
     hipLaunchKernelGGL((k_pass<T, 4, M_STORE, 1>), dim3(NB_7), dim3(BLOCK), 0, s, g, a, v_is_s, (const T*)nullptr, 0ll,
                        (ProjScalars<T>*)nullptr, out, (double*)nullptr, (T*)nullptr);
@@ -1481,6 +1538,7 @@ void K<T>::proj_dist_set(hipStream_t s, const Grid& g, const SetArgs<T>& a, int 
   SetArgs<T> b = a;
   b.ps = ps;
   ProjScalars<T>* psm = const_cast<ProjScalars<T>*>(ps);
+  ObsScope obs_(KID_PASS_DIST, s, pass_bytes<T>(g, a, v_is_s, 1, 0, false));
   if (g.n[0] % 4 == 0)
     hipLaunchKernelGGL((k_pass<T, 4, M_DIST, 1>), dim3(NB_7), dim3(BLOCK), 0, s, g, b, v_is_s, (const T*)nullptr, 0ll, psm,
                        (T*)nullptr, dst, (T*)nullptr);

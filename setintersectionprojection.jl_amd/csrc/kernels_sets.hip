@@ -78,6 +78,9 @@ __global__ __launch_bounds__(BLOCK) void k_rhs(Grid G, RhsArgs<T> a, T* __restri
 }
 template <typename T>
 void K<T>::rhs_compose(hipStream_t s, const Grid& g, const RhsArgs<T>& a, T* rhs, int accumulate) {
+  double vecs = 1.0 + (accumulate ? 1.0 : 0.0);      // (sum_i 2 M_i + N) w: y_i, l_i of every set read, rhs written (rhs_compose.jl:24-36)
+  for (int i = 0; i < a.nsets; ++i) vecs += 2.0 * (a.s[i].nblk > 0 ? a.s[i].nblk : 1);
+  ObsScope obs(KID_RHS, s, vecs * (double)range_len(g) * sizeof(T));
   if (g.n[0] % 4 == 0)
     hipLaunchKernelGGL((k_rhs<T, 4>), dim3(fit_grid(range_len(g) / 4, NB)), dim3(BLOCK), 0, s, g, a, rhs, accumulate);
   else
@@ -194,8 +197,26 @@ __global__ __launch_bounds__(BLOCK) void k_yl(Grid G, SetArgs<T> a, double* __re
   }
   block_reduce_store<YL_SLOTS>(acc, partials, 0);
 }
+// Algorithmic bytes of one y/l update: x (and its stencil neighbours, cached) + y, l read + y, l written = (N + 4 M) w;
+// + M w for y - y_old of a difference operator (read again by k_adj_norm); Barzilai-Borwein iterations read the four
+// snapshot arrays and rewrite two of them (+6 M; the first iteration only writes the two: +2 M); the distance term reads
+// m and x_old (+2 N); per-element bounds read lb, ub (+2 M); a materialised v / y arrives from an array (+M).
+template <typename T>
+double yl_bytes(const Grid& g, const SetArgs<T>& a) {
+  const double n = (double)range_len(g), nb = a.nblk > 0 ? a.nblk : 1, M = nb * n;
+  double v = n + 4.0 * M;
+  if (a.nblk > 0 || (a.flags & F_STORE_DY)) v += M;
+  const bool first = (a.flags & F_FIRST) != 0, bb = (a.flags & F_BB) && !first;
+  if (bb) v += 6.0 * M;
+  else if (first) v += 2.0 * M;
+  if (a.prox == PX_DIST) v += 2.0 * n;
+  if (a.prox == PX_BOUNDS_VEC) v += 2.0 * M;
+  if (a.vsrc) v += M;
+  return v * sizeof(T);
+}
 template <typename T>
 void K<T>::yl(hipStream_t s, const Grid& g, const SetArgs<T>& a, double* partials) {
+  ObsScope obs(KID_YL, s, yl_bytes<T>(g, a));
   constexpr int VW = sizeof(T) == 8 ? SIPX_F64_VEC : 4;      // four doubles per thread spill registers at 3 waves per SIMD
   if (g.n[0] % 4 == 0)
     hipLaunchKernelGGL((k_yl<T, VW>), dim3(fit_grid(range_len(g) / VW, NB)), dim3(BLOCK), 0, s, g, a, partials);
@@ -228,6 +249,7 @@ __global__ __launch_bounds__(BLOCK) void k_adj_norm(Grid G, SetArgs<T> a, double
 }
 template <typename T>
 void K<T>::adj_norm(hipStream_t s, const Grid& g, const SetArgs<T>& a, double* partials) {
+  ObsScope obs(KID_ADJ_NORM, s, (double)a.nblk * (double)range_len(g) * sizeof(T));
   if (g.n[0] % 4 == 0)
     hipLaunchKernelGGL((k_adj_norm<T, 4>), dim3(fit_grid(range_len(g) / 4, NB)), dim3(BLOCK), 0, s, g, a, partials);
   else
@@ -381,6 +403,7 @@ __global__ __launch_bounds__(BLOCK) void k_log3(long long N, const T* __restrict
 }
 template <typename T>
 void K<T>::log3(hipStream_t s, long long N, const T* x, const T* m, const T* xold, double* partials) {
+  ObsScope obs(KID_LOG3, s, (m ? 3.0 : 2.0) * (double)N * sizeof(T));
   if (N % 4 == 0 && aligned16(x, m, xold))
     hipLaunchKernelGGL((k_log3<T, 4>), dim3(NB), dim3(BLOCK), 0, s, N, x, m, xold, partials);
   else

@@ -48,9 +48,52 @@ constexpr int PREP_SLOTS = 3 + 2 * L1_K;   // ||v||_1, ||v||_2^2, nnz, S_k, C_k
 constexpr int SAMPLE_BINS = 1024;
 constexpr int SAMPLE_MBITS = 7;
 
+// ---- per-kernel statistics (sipx_kernel_stats / sipx_kernel_stats_json) -------------------------------------------------
+// Every launcher below opens an ObsScope; while the engine collects statistics it installs an observer that brackets the
+// launch with two HIP events on the launch's own stream and books the kernel's ALGORITHMIC bytes twice: `survey` = SURVEY
+// 8(d)'s count for the reference function the kernel replaces, `moved` = what this kernel has to move at least (they differ
+// where the kernel reads less than the reference's pass structure implies, e.g. the symmetric band read of k_cds).
+enum KernelId {
+  KID_CDS_SPMV = 0, KID_CDS_DOT, KID_CDS_RESID, KID_CDS_FUSED, KID_SQ_SPMV, KID_SQ_DOT, KID_SQ_RESID, KID_CG_BEGIN, KID_CG_XR, KID_CG_P,
+  KID_Q_UPDATE, KID_FIN_SUM, KID_RHS, KID_YL, KID_YL_MULTI, KID_ADJ_NORM, KID_LOG3, KID_PASS_FIRST, KID_PASS_LEAN, KID_PASS_PROBE,
+  KID_PASS_COMPACT, KID_PASS_DIST, KID_PASS_STORE, KID_PASS_MULTI, KID_SLOT_SUMS, KID_DECIDE, KID_SAMPLE, KID_L1_SOLVE, KID_GATHER,
+  KID_PS_RESCALE, KID_CARD, KID_EXT, KID_BB_RULE, KID_OTHER, KID_COUNT
+};
+inline const char* kernel_name(int k) {
+  static const char* const names[KID_COUNT] = {
+      "k_cds<MODE=0>", "k_cds<MODE=1>", "k_cds<MODE=2>", "k_cds_fused", "k_sq<MODE=0>", "k_sq<MODE=1>", "k_sq<MODE=2>", "k_cg_begin",
+      "k_cg_update_xr", "k_cg_update_p", "k_q_update", "k_fin_sum", "k_rhs", "k_yl", "k_yl_multi", "k_adj_norm", "k_log3",
+      "k_pass<M_FIRST>", "k_pass<M_LEAN>", "k_pass<M_PROBE>", "k_pass<M_COMPACT>", "k_pass<M_DIST>", "k_pass<M_STORE>", "k_pass_multi",
+      "k_slot_sums", "k_decide", "k_sample", "k_l1_solve", "k_gather_pack/unpack", "k_ps_rescale", "k_card_*", "ext_proj (library-backed)",
+      "k_bb_rule", "other"};
+  return (k >= 0 && k < KID_COUNT) ? names[k] : "?";
+}
+struct LaunchObserver {
+  void* user;
+  void (*begin)(void* user, int kid, hipStream_t s, double bytes_survey, double bytes_moved);
+  void (*end)(void* user, int kid, hipStream_t s);
+};
+// the observer of the calling host thread (a context is driven by one thread at a time); nullptr: nothing is recorded
+const LaunchObserver*& launch_observer();
+struct ObsScope {
+  const LaunchObserver* o;
+  int kid;
+  hipStream_t s;
+  ObsScope(int kid_, hipStream_t s_, double bytes_survey, double bytes_moved = -1.0) : o(launch_observer()), kid(kid_), s(s_) {
+    if (o) o->begin(o->user, kid, s, bytes_survey, bytes_moved < 0 ? bytes_survey : bytes_moved);
+  }
+  ~ObsScope() {
+    if (o) o->end(o->user, kid, s);
+  }
+  ObsScope(const ObsScope&) = delete;
+  ObsScope& operator=(const ObsScope&) = delete;
+};
+
 // reduction slots of k_yl (per set)
 enum { SL_RPRI = 0, SL_DY = 1, SL_HL = 2, SL_HH = 3, SL_LH = 4, SL_DL = 5, SL_GG = 6, SL_GL = 7,
-       SL_FE = 8, SL_SS = 9, SL_OBJ = 10, SL_EVO = 11, SL_XX = 12 };
+       SL_FE = 8, SL_SS = 9, SL_OBJ = 10, SL_EVO = 11, SL_XX = 12,
+       SL_ADJ = 13 /* ||A'(y - y_old)||^2 of a difference operator */, SL_FE2 = 14, SL_SS2 = 15 /* two-pass feasibility */ };
+constexpr int SET_SLOTS = 16;     // reduction slots per set in the engine's partial array: slot s of set i at ((i * SET_SLOTS + s) * NB)
 
 enum { F_FEAS = 1, F_BB = 2, F_FIRST = 4, F_NOSPEC = 8 /* skip the speculative gather of the l1 search (not set by the engine at present) */,
        F_STORE_DY = 16 /* identity-shaped pass over a materialised s = A x (custom sparse operator): keep y - y_old */ };
@@ -147,7 +190,7 @@ struct ProjScalars {
   double red[PREP_SLOTS];
   double ovf;                                // > 0: the speculative gather of some rank overflowed its LDS buffers
   double mm[2 * SIPX_MAX_WORLD];
-  int gather_overflow;                       // sticky: a rank gathered more magnitudes than the exchange buffer holds (theta = NaN)
+  int gather_overflow;                       // this search: the ranks gathered more magnitudes than the exchange segments hold (theta = NaN, the host is told)
   int lean;           // the coming first pass evaluates the two edge probes of the speculative range only (k_pass M_FIRST)
   // cooperative sweeps of k_l1_solve: per-workgroup shares of (sum hi, sum lo, count), double buffered by iteration parity
   double coop_hi[2][SIPX_SOLVE_SLOTS], coop_lo[2][SIPX_SOLVE_SLOTS], coop_c[2][SIPX_SOLVE_SLOTS];
@@ -181,6 +224,9 @@ struct SampleCtl {
   int enable = 0;
   long long runs = 0;      // sampled runs of 64 grid points (0: 16384, 32768 from 2^26 grid points on)
   int* host_want = nullptr;
+  // pinned word of the set (slab-decomposed grid): raised by k_gather_unpack when the magnitudes gathered inside the final
+  // bracket over all ranks did not fit the exchange segments -- the host turns it into an error return (never NaN iterates)
+  int* host_ovf = nullptr;
 };
 
 template <typename T>
@@ -199,6 +245,32 @@ struct SetArgs {
   int flags;
   int vsrc;                             // 1: read v from `v`; 2: read the already projected y from `v`
   int nblk_or1() const { return nblk > 0 ? nblk : 1; }
+};
+
+// ---- k_yl_multi: the y/l update of ALL sets in one z-marching sweep (kernels_multi.hip) --------------------------------------
+constexpr int MULTI_MAXB = 8;     // operator blocks (a set has one per difference direction; identity: one)
+template <typename T>
+struct MultiBlk {
+  const T *y, *l;                 // block q of the set's current iterate (base already offset by q * N)
+  T *yo, *lo;                     // where the update goes
+  const T *lb, *ub;               // per-element bounds (offset like y), else nullptr
+  const ProjScalars<T>* ps;
+  int dir;                        // -1: identity; 0 / 1 / 2: forward difference along that grid dimension
+  int set;                        // index of the set the block belongs to (its group of partial slots)
+  int first, last;                // first / last block of its set
+  int dist;                       // the distance term
+  T ih, rho, rho1, gamma;
+  int prox;
+  T plo, phi;
+};
+template <typename T>
+struct MultiArgs {
+  int nblk;
+  MultiBlk<T> b[MULTI_MAXB];
+  const T *x, *m, *xold;
+  T* rhs;                         // nullptr: no fused right-hand side
+  double* partials;               // the engine's per-set partial array (SET_SLOTS groups)
+  long long zlo, zhi;             // planes [zlo, zhi) of the last grid dimension (the rank's slab; the whole grid on one rank)
 };
 
 // One changed set of a fused Q update: Q[:,col(off_j)] += alpha * AtA_i[:,j] (CDS_scaled_add!.jl:16-22).
@@ -295,6 +367,9 @@ struct K {
   static void rhs_compose(hipStream_t s, const Grid& g, const RhsArgs<T>& a, T* rhs, int accumulate);
   static void yl(hipStream_t s, const Grid& g, const SetArgs<T>& a, double* partials);
   static void adj_norm(hipStream_t s, const Grid& g, const SetArgs<T>& a, double* partials);
+  // every set's y/l update (+ r_pri, r_dual sums, obj / evol sums, optionally rhs of the next iteration) in one sweep;
+  // returns false (nothing launched) when the block list does not fit the kernel's instantiations
+  static bool yl_multi(hipStream_t s, const Grid& g, const MultiArgs<T>& a);
   static void fwd(hipStream_t s, const Grid& g, int nblk, const int* dir, const T* ih, const T* x, T* out);
   static void adj(hipStream_t s, const Grid& g, int nblk, const int* dir, const T* ih, const T* v, T* out);
   static void log3(hipStream_t s, long long N, const T* x, const T* m, const T* xold, double* partials);

@@ -34,6 +34,7 @@ EXPORTED_SYMBOLS = [
     "sipx_stream",
     "sipx_dev_rhs", "sipx_dev_x", "sipx_set_owned", "sipx_get_rhs", "sipx_prox_l2s",
     "sipx_rccl_unique_id", "sipx_set_comm_rccl", "sipx_set_comm", "sipx_slab", "sipx_warm_start_from", "sipx_set_decomp",
+    "sipx_kernel_stats_json", "sipx_comm_info",
 ]
 
 SIPX_F32, SIPX_F64 = 0, 1
@@ -95,6 +96,8 @@ def lib():
         for name in ("sipx_stream", "sipx_dev_rhs", "sipx_dev_x"):
             getattr(L, name).restype = C.c_void_p
             getattr(L, name).argtypes = [C.c_void_p]
+        L.sipx_kernel_stats_json.restype = C.c_char_p
+        L.sipx_kernel_stats_json.argtypes = [C.c_void_p, C.c_int]
         L.sipx_destroy.restype = None
         L.sipx_destroy.argtypes = [C.c_void_p]
         _lib = L
@@ -776,10 +779,27 @@ class Context:
         d["lean"] = float(int(d["lean"]) & 1)
         return d
 
-    def kernel_stats(self, enable: bool):
+    def kernel_stats(self, enable):
+        """(launches, total ms) of the CG product since the last call; then (re)starts the collection: 0 / False = off,
+        1 / True = that kernel only, 2 = every kernel (sipx.h, sipx_kernel_stats)."""
         n, ms = C.c_int64(), C.c_double()
         _chk(lib().sipx_kernel_stats(self.h, int(enable), C.byref(n), C.byref(ms)))
         return n.value, ms.value
+
+    def kernel_stats_all(self, enable):
+        """Per-kernel statistics gathered since the last call, as a dict (sipx_kernel_stats_json); `enable` as above."""
+        import json
+        txt = lib().sipx_kernel_stats_json(self.h, int(enable))
+        if txt is None:
+            raise SipxError(lib().sipx_last_error().decode())
+        return json.loads(txt.decode())
+
+    def comm_info(self):
+        """What the attached communicator reports: {"nranks", "rank", "version", "decomposition"} (sipx_comm_info)."""
+        n, r, d = C.c_int(), C.c_int(), C.c_int()
+        ver = C.create_string_buffer(64)
+        _chk(lib().sipx_comm_info(self.h, C.byref(n), C.byref(r), ver, 64, C.byref(d)))
+        return {"nranks": n.value, "rank": r.value, "version": ver.value.decode(), "decomposition": "slab" if d.value == 1 else "sets"}
 
     def _log_struct(self, options: PARSDMM_options):
         maxit, p, pp = int(options.maxit), self.p, self.pp

@@ -1773,7 +1773,8 @@ def test_multilevel_over_slab_decomposed_levels(sipx, tmp_path, world, n, h, lev
 def test_bench_contract_line(dist_env):
     """bench.py prints ONE JSON line with the contract's fields (metric, value, unit, n_gpus, steps, warmup, ms_per_step,
     higher_is_better, scaling, vs_baseline, dtype, data, config.workload, roofline, iteration_roofline) -- on one GPU, and
-    through the sharded code path (RCCL communicator with a world of one: both decompositions timed, the faster reported)."""
+    through the sharded code path (RCCL communicator with a world of one: both decompositions timed and reported under fixed
+    keys, the headline always the slab decomposition; what RCCL itself reports about the communicator in every leg)."""
     import json
     import os
     import subprocess
@@ -1783,7 +1784,7 @@ def test_bench_contract_line(dist_env):
     if dist_env:
         env.update(SIPX_FORCE_DIST="1", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(32100 + os.getpid() % 2000), RANK="0", WORLD_SIZE="1")
     r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--config", "c3-small", "--steps", "4", "--warmup", "2",
-                        "--no-cpu-baseline", "--no-512", "--no-c4"], capture_output=True, text=True, timeout=280, env=env)
+                        "--no-cpu-baseline", "--no-512", "--no-c4", "--no-c5"], capture_output=True, text=True, timeout=280, env=env)
     assert r.returncode == 0, r.stderr[-2000:]
     lines = [ln for ln in r.stdout.strip().splitlines() if ln.strip()]
     assert len(lines) == 1, r.stdout
@@ -1793,6 +1794,15 @@ def test_bench_contract_line(dist_env):
         assert k in d, k
     assert d["n_gpus"] == 1 and d["steps"] == 4 and d["warmup"] == 2 and d["value"] > 0 and d["vs_baseline"] is None
     assert "workload" in d["config"] and d["config"]["all_logs_finite"]
-    assert {"bound", "achieved", "peak", "unit", "frac", "traffic"} <= set(d["roofline"])
+    assert {"bound", "achieved", "peak", "unit", "frac", "frac_survey", "traffic"} <= set(d["roofline"])
+    assert d["roofline"]["frac"] <= d["roofline"]["frac_survey"]                 # bytes that move <= SURVEY's count
+    dom = d["dominant_kernel"]
+    assert dom["kernel"].startswith("k_") and dom["launches"] > 0 and dom["avg_launch_ms"] > 0 and 0 < dom["frac"] < 1.2
+    assert any(r["kernel"] == dom["kernel"] for r in d["kernels"]) and len(d["libsipx_sha16"]) == 16
     if dist_env:
-        assert d["other_decomposition"]["decomposition"] in ("slab", "sets") and d["other_decomposition"]["value"] > 0
+        assert set(d["decompositions"]) == {"slab", "sets"} and d["decomposition"] == "slab" and d["faster_decomposition"] in ("slab", "sets")
+        assert d["value"] == d["decompositions"]["slab"]["value"]
+        for v in d["decompositions"].values():
+            assert v["value"] > 0 and v["comm"]["rccl_nranks"] == 1 and v["comm"]["rccl_version"].startswith("rccl ")
+    else:
+        assert d["comm"]["rccl_version"] == "none" and "decompositions" not in d

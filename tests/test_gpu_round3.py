@@ -1,0 +1,199 @@
+"""GPU tests added in round 3: per-kernel statistics, what the communicator reports, the slab-decomposed l1 search on ragged
+and empty slabs with the sampled prediction forced, the exchange-segment overflow as an ERROR (never NaN iterates), a rho_ini
+outside the clamp of src/PARSDMM.jl:226."""
+import os
+
+import numpy as np
+import pytest
+
+from oracle import parsdmm_oracle as O      # checker only
+from tests.test_gpu_parity import _problem, model
+
+pytestmark = pytest.mark.gpu
+
+
+def test_per_kernel_statistics(sipx):
+    """sipx_kernel_stats_json in mode 2: every kernel of an iteration shows up with launches, time and algorithmic bytes;
+    mode 1 records the CG product only; the byte counts are the ones DESIGN 3 states."""
+    TF, n, h = np.float32, (64, 48, 40), (25.0, 25.0, 25.0)
+    m = model(n, TF, seed=3)
+    g, opt, P, A, prop, AtA = _problem(sipx, n, h, TF, ["bounds", "l1:D_x", "l1:D_z"], m, dict(maxit=30, evol_rel_tol=0.0, feas_tol=0.0, obj_tol=0.0))
+    ctx = sipx.host.build_context(m, AtA, A, prop, P, g, opt)
+    try:
+        ctx.parsdmm_begin(opt)
+        ctx.parsdmm_steps(4)
+        ctx.kernel_stats(1)
+        ctx.parsdmm_steps(4)
+        st1 = ctx.kernel_stats_all(2)
+        assert [k["name"] for k in st1["kernels"]] == ["k_cds<MODE=1>"] and st1["mode"] == 1
+        cg4 = int(np.sum(ctx._run[2]["cg_it"][4:8]))
+        assert 0 < st1["kernels"][0]["launches"] <= cg4          # (an x-step that finds x good enough logs cg_it = 1 without a product, cg.jl:73-76)
+        ctx.parsdmm_steps(6)
+        st2 = ctx.kernel_stats_all(0)
+        names = {k["name"]: k for k in st2["kernels"]}
+        for want in ("k_cds<MODE=1>", "k_cds<MODE=2>", "k_cg_update_xr", "k_rhs", "k_yl", "k_adj_norm", "k_fin_sum", "k_l1_solve"):
+            assert want in names, (want, sorted(names))
+        N, w, d = int(np.prod(n)), 4, 5
+        cds = names["k_cds<MODE=1>"]
+        assert cds["bytes_survey"] == cds["launches"] * (d + 2) * N * w                 # (d + 2) N w
+        assert cds["bytes_moved"] == cds["launches"] * ((d + 1) // 2 + 2) * N * w       # bands with a non-negative offset only
+        assert names["k_yl"]["launches"] == 6 * 4 and names["k_rhs"]["launches"] == 6   # four terms, six iterations
+        assert names["k_rhs"]["bytes_moved"] == 6 * (2 * 4 + 1) * N * w                 # (sum 2 M_i + N) w on padded blocks
+        assert all(k["total_ms"] > 0 for k in st2["kernels"] if k["name"] in ("k_yl", "k_rhs", "k_cds<MODE=1>"))
+        assert ctx.kernel_stats_all(0)["kernels"] == []                                  # collection is off now
+        info = ctx.comm_info()
+        assert info == {"nranks": 1, "rank": 0, "version": "none", "decomposition": "sets"}
+    finally:
+        ctx.close()
+
+
+def _rccl_info_worker(rank, world, port, out):
+    import json
+    import sys
+    import torch
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", 0))
+    try:
+        from __graft_entry__ import load_package
+        sipx = load_package()
+        from sipx import sharded
+        TF, n, h = np.float32, (32, 24, 16), (25.0, 25.0, 25.0)
+        m = model(n, TF, seed=5)
+        g, opt, P, A, prop, AtA = _problem(sipx, n, h, TF, ["bounds", "l1:D_z"], m, dict(maxit=5))
+        keep = []
+
+        def attach(cx):
+            keep.append(sharded.attach_comm(cx, dist, torch.device("cuda", 0), "rccl"))
+            cx.set_decomp("slab")
+        ctx = sipx.host.build_context(m, AtA, A, prop, P, g, opt, device=0, owned=[1] * len(A), attach=attach)
+        info = ctx.comm_info()
+        ctx.close()
+        with open(os.path.join(out, "info.json"), "w") as f:
+            json.dump(info, f)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_comm_info_asks_rccl_itself(sipx, tmp_path):
+    import json
+    import torch.multiprocessing as mp
+    mp.spawn(_rccl_info_worker, args=(1, 31900 + os.getpid() % 1000, str(tmp_path)), nprocs=1, join=True)
+    info = json.load(open(tmp_path / "info.json"))
+    assert info["nranks"] == 1 and info["rank"] == 0 and info["decomposition"] == "slab"
+    assert info["version"].startswith("rccl ") and info["version"] != "rccl 0.0.0", info
+
+
+def _slab_worker(rank, world, port, out, kinds, n, env):
+    import sys
+    import datetime
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), **env)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")
+    dist.init_process_group("gloo", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=180))
+    try:
+        from __graft_entry__ import load_package
+        sipx = load_package()
+        from sipx import sharded
+        TF = np.float32
+        h = (25.0, 25.0, 25.0)[:len(n)]
+        m = model(n, TF, seed=5)
+        gs, os_, Ps, As, props, AtAs = _problem(sipx, n, h, TF, kinds, m, dict(maxit=40))
+        try:
+            x, log, l, y = sharded.PARSDMM_sharded(m.copy(), AtAs, As, props, Ps, gs, os_, dist=dist, device=0, comm_mode="torch", decomp="slab")
+            np.savez(os.path.join(out, f"r{rank}.npz"), x=x, obj=log.obj, cg_it=log.cg_it, rho=log.rho, r_pri=log.r_pri, err="")
+        except sipx.SipxError as e:
+            np.savez(os.path.join(out, f"r{rank}.npz"), err=str(e))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(400)
+def test_slab_gather_overflow_is_an_error_on_every_rank(sipx, tmp_path):
+    """An exchange segment too small for the bracket (forced: 32 values per rank): every rank returns the SAME error -- from the
+    first search that overflows, be it the initial feasibility estimate of sipx_finalize or a y/l update -- no NaN iterates, no
+    rank left waiting in a collective."""
+    import torch.multiprocessing as mp
+    world = 2
+    mp.spawn(_slab_worker, args=(world, 30200 + os.getpid() % 1000, str(tmp_path), ["bounds", "l1:D_x", "l1:D_z"], (32, 24, 16),
+                                 {"SIPX_GATHER_CAP": "32"}), nprocs=world, join=True)
+    errs = [str(np.load(tmp_path / f"r{r}.npz")["err"]) for r in range(world)]
+    assert errs[0] and errs[0] == errs[1], errs
+    assert "exchange segment" in errs[0] and ("l1 threshold search of set" in errs[0] or "initial feasibility of set" in errs[0])
+
+
+@pytest.mark.timeout(400)
+@pytest.mark.parametrize("world,n", [(4, (16, 12, 5)), (3, (16, 12, 5))])
+def test_sampled_prediction_on_ragged_and_empty_slabs(sipx, tmp_path, world, n):
+    """The sampled prediction forced on slabs of 2, 2, 1 planes and an EMPTY one (4 ranks; 2, 2, 1 for 3): whether the sample is
+    taken, its stride and its capacity are functions of the whole grid only, a rank with nothing to sample contributes zeros --
+    every rank ends with identical iterates, equal to the serial solve to the reference's tolerance."""
+    import torch.multiprocessing as mp
+    kinds = ["bounds", "l1:D_z", "l1:D_x"]
+    mp.spawn(_slab_worker, args=(world, 30700 + os.getpid() % 1000 + world, str(tmp_path), kinds, n, {"SIPX_L1_SAMPLE_RUNS": "3"}),
+             nprocs=world, join=True)
+    r0 = np.load(tmp_path / "r0.npz")
+    assert str(r0["err"]) == ""
+    for r in range(1, world):
+        r1 = np.load(tmp_path / f"r{r}.npz")
+        for k in ("x", "obj", "cg_it", "rho", "r_pri"):
+            assert np.array_equal(r0[k], r1[k], equal_nan=True), (r, k)
+    assert np.isfinite(r0["x"]).all() and np.isfinite(r0["obj"]).all()
+    TF, h = np.float32, (25.0, 25.0, 25.0)
+    m = model(n, TF, seed=5)
+    gs, os_, Ps, As, props, AtAs = _problem(sipx, n, h, TF, kinds, m, dict(maxit=40))
+    xs, ls, _, _ = sipx.PARSDMM(m.copy(), AtAs, As, props, Ps, gs, os_)
+    assert np.linalg.norm(r0["x"] - xs) / np.linalg.norm(xs) < 5e-4
+
+
+@pytest.mark.parametrize("rho_ini", [1e5, 1e-3])
+def test_rho_ini_outside_the_clamp(sipx, rho_ini):
+    """rho is clamped to [1e-2, 1e4] at the end of EVERY iteration (src/PARSDMM.jl:226): a rho_ini outside it changes after
+    iteration 1 whatever the adaptation rules say -- the pipelined loop must not have queued a right-hand side with the old
+    value.  Same logs as the oracle."""
+    TF, n, h = np.float64, (24, 18), (25.0, 6.0)
+    m = model(n, TF, seed=2)
+    kinds = ["bounds", "l1:TV"]
+    kw = dict(maxit=12, rho_ini=[rho_ini], adjust_rho=False, adjust_gamma=False, adjust_feasibility_rho=False)
+    go, oo, Po, Ao, po, AtAo = _problem(O, n, h, TF, kinds, m, kw)
+    xo, lo, _, _ = O.PARSDMM(m.copy(), AtAo, Ao, po, Po, go, oo)
+    gs, os_, Ps, As, ps_, AtAs = _problem(sipx, n, h, TF, kinds, m, kw)
+    xs, ls, _, _ = sipx.PARSDMM(m.copy(), AtAs, As, ps_, Ps, gs, os_)
+    assert len(ls.obj) == len(lo.obj)
+    assert np.array_equal(ls.rho, lo.rho) and ls.rho[0, 0] == rho_ini and ls.rho[1, 0] in (1e4, 1e-2)
+    assert np.allclose(ls.obj, lo.obj, rtol=1e-9) and np.array_equal(ls.cg_it, lo.cg_it)
+    assert np.linalg.norm(xs - xo) <= 1e-8 * np.linalg.norm(xo)
+
+
+def test_rhs_compose_reference_case_on_the_engine(sipx):
+    """test/test_rhs_compose.jl:1-38 through the HIP path: TD_OP = [2 speye(51000, 100000), speye(100000)] (the second one is the
+    distance term's identity here), rho = [1.234, 10.23432], Float64 -- k_rhs + the CSC adjoint of the caller-supplied operator
+    against the closed form the two scaled identities admit, to the reference's 10 eps."""
+    import scipy.sparse as sp
+    TF = np.float64
+    rng = np.random.default_rng(20240611)
+    n, h = (400, 250), (25.0, 6.0)
+    N = 100000
+    y = [rng.standard_normal(51000), rng.standard_normal(N)]
+    l = [rng.standard_normal(51000), rng.standard_normal(N)]
+    rho = [1.234, 10.23432]
+    A1 = sp.eye(51000, N, format="csc", dtype=TF) * 2.0
+    g = sipx.compgrid(h, n)
+    sd = sipx.set_definitions("bounds", "identity", -1e12, 1e12, ("matrix", ""))
+    sd.custom_TD_OP = (sp.csc_matrix(A1), False)
+    opt = sipx.PARSDMM_options(FL=TF, maxit=5)
+    P, A, prop = sipx.setup_constraints([sd], g, TF)
+    A, AtA, _, _ = sipx.PARSDMM_precompute_distribute(A, prop, g, opt)
+    opt.zero_ini_guess = False
+    ctx = sipx.host.build_context(rng.standard_normal(N), AtA, A, prop, P, g, opt, np.zeros(N), l, y)
+    try:
+        ctx.rhs_compose(rho)
+        rhs = ctx.get_rhs()
+    finally:
+        ctx.close()
+    want = rho[1] * y[1] + l[1]
+    want[:51000] += 2.0 * (rho[0] * y[0] + l[0])
+    assert np.linalg.norm(rhs - want) <= 10 * np.finfo(TF).eps * max(np.linalg.norm(rhs), np.linalg.norm(want))

@@ -264,3 +264,71 @@ def test_prox_l2s_literal():
     x, m = np.array([2.0]), np.array([1.0])
     O.prox_l2s(x, 3.0, m)
     assert x[0] == 7 / 4                                                     # :15-19 (2*3 + 1) / (3 + 1)
+
+
+# ---- test/test_rhs_compose.jl:1-38 ---------------------------------------------------------------------------------------
+def test_rhs_compose_literal():
+    """Same sizes and constants: y_1, l_1 in R^51000 behind TD_OP[1] = 2 * speye(51000, 100000), y_2, l_2 in R^100000 behind
+    speye(100000), rho = [1.234, 10.23432].  The loop-fusion form (what the oracle restates, rhs_compose.jl:31-35) against
+    the explicit-BLAS form (:24-30: temp = A'(rho y + l); axpy!(1, temp, rhs)) and against the parallel form (:17-20: the
+    (+) reduction of the per-set terms), each to 10 eps as the reference asserts (:36, :49)."""
+    TF = np.float64
+    rng = np.random.default_rng(20240611)
+    p, N = 2, 100000
+    y = [rng.standard_normal(51000), rng.standard_normal(100000)]
+    l = [rng.standard_normal(51000), rng.standard_normal(100000)]
+    rho = np.array([1.234, 10.23432])
+    TD_OP = [sp.eye(51000, 100000, format="csc", dtype=TF) * 2.0, sp.eye(100000, format="csc", dtype=TF)]
+    rhs = O.rhs_compose(l, y, rho, TD_OP, p, N)                                   # Blas_active = false
+    rhs_2 = np.zeros(N, TF)                                                       # Blas_active = true, restated literally
+    for ii in range(p):
+        temp = O.csc_mul_adj(TD_OP[ii], TF(rho[ii]) * y[ii] + l[ii])              # mul!(temp_array, TD_OP[ii]', rho[ii] .* y[ii] .+ l[ii])
+        rhs_2 = TF(1.0) * temp + rhs_2                                            # BLAS.axpy!(TF(1.0), temp_array, rhs)
+    assert isapprox(rhs, rhs_2, 10 * EPS)                                         # :36
+    rhs_3 = np.zeros(N, TF)                                                       # parallel = true: @distributed (+) over ii
+    for ii in range(p):
+        rhs_3 = rhs_3 + O.rhs_compose(l, y, rho, TD_OP, p, N, only=[ii])
+    assert isapprox(rhs, rhs_3, 10 * EPS)                                         # :49
+    # and the closed form the two scaled identities admit, entry by entry
+    want = rho[1] * y[1] + l[1]
+    want[:51000] += 2.0 * (rho[0] * y[0] + l[0])
+    assert isapprox(rhs, want, 10 * EPS)
+
+
+# ---- test/test_argmin_x.jl:21-59 -----------------------------------------------------------------------------------------
+def _spd_100(rng):
+    """A = sprandn(100, 100, 0.01) + I; A = A'A; while rank(A) < 100: A += I   (test_argmin_x.jl:4-8, 37-41)."""
+    A = sp.random(100, 100, density=0.01, random_state=rng, data_rvs=rng.standard_normal, format="csc") + sp.eye(100, format="csc")
+    A = (A.T @ A).tocsc()
+    while np.linalg.matrix_rank(A.toarray()) < 100:
+        A = A + sp.eye(100, format="csc")
+    return A
+
+
+def test_argmin_x_literal():
+    """Same sizes, tolerances and iteration numbers.  The reference test calls argmin_x with the CSC matrix (and, in its second
+    half, passes CDS offsets along); the path this repository restates and replaces is the CDS branch (argmin_x.jl:23-39), so
+    both halves run it on mat2CDS(A) -- the tolerance rule and cg are the same code for every storage format."""
+    nrm = np.linalg.norm
+    rng = np.random.default_rng(20240612)
+    for half in range(2):
+        A = _spd_100(rng)
+        xt = rng.standard_normal(100)
+        b = A @ xt
+        R, off = O.mat2CDS(A)
+        res = lambda x: nrm(A @ x - b) / nrm(b)
+        if half == 0:
+            x, it, relres, _ = O.argmin_x(R, b, np.zeros(100), 1e-5, 5, off)               # zero initial guess  :22-24
+            assert res(x) <= 1e-5
+            assert abs(res(x) - relres) <= 1e-5 * max(res(x), relres)                      # isapprox(..., relres, rtol = x_solve_tol_ref)
+            x2, it2, relres2, _ = O.argmin_x(R, b, xt + rng.standard_normal(100) * 1e-4, 1e-5, 5, off)   # good initial guess  :27-30
+            assert it2 < it
+            assert res(x2) <= 1e-5
+            assert abs(res(x2) - relres2) <= 1e-5 * max(res(x2), relres2)
+            x, it, relres, _ = O.argmin_x(R, b, np.zeros(100), 10 * EPS, 15, off)          # 10 eps reachable  :33-34
+            assert res(x) <= 20 * EPS
+        else:
+            x, it, relres, _ = O.argmin_x(R, b, np.zeros(100), 1e-5, 5, off)               # CDS  :46-50
+            assert res(x) <= 1e-5 and res(x) <= 2.0 * relres
+            x, it, relres, _ = O.argmin_x(R, b, np.zeros(100), 1e-10, 5, off)              # more accurate  :53-57
+            assert res(x) <= 1e-10 and res(x) <= 2.0 * relres
