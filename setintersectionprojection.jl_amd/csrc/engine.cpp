@@ -106,6 +106,7 @@ void bb_rule(T d_dHh_dlh, T n_d_H_hat, T n_d_l_hat, T n_d_l, T n_d_G_hat, T d_dG
 template <typename T>
 struct SetState {
   int op = 0, prox = 0, nblk = 0, ncvx = 0;
+  int nblk_or1() const { return nblk > 0 ? nblk : 1; }
   // caller-supplied sparse operator (SIPX_OP_CSC): CSC for the adjoint, a CSR copy for the forward product; s = A x is
   // materialised in sbuf and every set kernel then runs in its identity shape on a 1-D grid of M entries
   bool custom = false;
@@ -469,6 +470,8 @@ class Engine : public EngineBase {
       l1_sample_ = !(e && e[0] == '0');
       const char* r = std::getenv("SIPX_L1_SAMPLE_RUNS");       // tests: sample small grids too
       l1_sample_runs_ = r ? std::atoll(r) : 0;
+      const char* mu = std::getenv("SIPX_YL_MULTI");            // 0: one k_yl launch per set on every iteration (A/B switch, tests)
+      yl_multi_ = !(mu && mu[0] == '0');
     }
     for (int k = 0; k < 2 * MAXMARK; ++k) {      // two sets of section marks: a step never waits for its own timing
       hipEvent_t e;
@@ -768,6 +771,18 @@ class Engine : public EngineBase {
     need_final();
     ObserverGuard og(observer());
     (void)it;
+    rhs_fused_ = false;
+    if (update_all_sets_in_one_sweep(flags, rho, gamma)) {
+      reduce_set_sums(p_n_ * SLOTS);
+      sums_flags_ = flags;
+      sums_pending_ = true;
+      if (!defer_sums_) {
+        SIPX_HIP(hipEventRecord(ev_sums_, stream_));
+        sums_event_ = ev_sums_;
+        collect_set_sums(rho, r_pri, r_dual, feas);
+      }
+      return;
+    }
     if (mk_) K<T>::sum_uv(stream_, G_.N, x_, x_ + G_.N, w_);
     if (set_streams_ && !slab_) SIPX_HIP(hipEventRecord(ev_fork_, stream_));     // x (and u + v) are final: the sets may start
     if (slab_) {
@@ -956,6 +971,95 @@ class Engine : public EngineBase {
       sums_event_ = ev_sums_;
       collect_set_sums(rho, r_pri, r_dual, feas);
     }
+  }
+
+  // Iterations without Barzilai-Borwein sums, snapshots or feasibility estimates (flags == 0: every other iteration while rho
+  // and gamma are adapted, all of them once they are frozen): the threshold / scale searches of the two-pass sets as usual
+  // (on the set streams), then ONE sweep updates every set, forms the r_pri / r_dual / obj sums and -- when the caller has
+  // announced that rho cannot change before the next iteration (fuse_rhs_) -- writes the right-hand side of that iteration
+  // (kernels_multi.hip).  Returns false when this context / iteration does not qualify: the per-set path then runs.
+  bool update_all_sets_in_one_sweep(int flags, const double* rho, const double* gamma) {
+    if (!yl_multi_ || flags != 0 || mk_ || comm_) return false;
+    MultiArgs<T> ma;
+    ma.nblk = 0;
+    ma.rhs = nullptr;
+    ma.zlo = 0; ma.zhi = G_.n[ndim_ - 1]; ma.zsum = 0;
+    for (int i = 0; i < p_n_; ++i) {           // does the kernel have this block layout? (asked before any search is queued)
+      const SetState<T>& s = sets_[i];
+      if (!s.owned || s.custom || s.ext_kind || s.dist_ext) return false;
+      if (ma.nblk + s.nblk_or1() > MULTI_MAXB) return false;
+      for (int qb = 0; qb < s.nblk_or1(); ++qb) {
+        MultiBlk<T>& B = ma.b[ma.nblk++];
+        B.dir = s.nblk == 0 ? -1 : s.dir[qb];
+        B.last = qb == s.nblk_or1() - 1;
+        B.dist = s.is_dist ? 1 : 0;
+        B.prox = s.prox;
+      }
+    }
+    if (!K<T>::yl_multi(stream_, G_, ma, true)) return false;
+    if (set_streams_) SIPX_HIP(hipEventRecord(ev_fork_, stream_));       // x is final: the searches may start
+    ma.nblk = 0;
+    std::vector<char> to_other(p_n_, 0);
+    for (int i = 0; i < p_n_; ++i) {
+      SetState<T>& s = sets_[i];
+      SetArgs<T> a = set_args(s, (T)rho[i], (T)gamma[i], 0);
+      to_other[i] = s.snap == 0;                 // stay off the snapshot pair (see update_y_l)
+      if (s.two_pass) {
+        hipStream_t q = s.st ? s.st : stream_;
+        double* ptmp = s.ptmp ? s.ptmp : part_tmp_;
+        T* mpart = s.mpart ? s.mpart : maxpart_;
+        T* cbuf = s.cbuf ? s.cbuf : scr_c_;
+        if (q != stream_) SIPX_HIP(hipStreamWaitEvent(q, ev_fork_, 0));
+        const bool rescaled = a.prox == PX_L1 && s.last_rho > T(0) && s.last_rho != a.rho;
+        if (rescaled) K<T>::ps_rescale(q, s.ps, (double)s.last_rho / (double)a.rho);
+        SampleCtl ctl;
+        ctl.host_want = (int*)hlean_ + i;
+        ctl.host_ovf = (int*)hovf_ + i;
+        ctl.runs = l1_sample_runs_;
+        ctl.enable = l1_sample_ && a.prox == PX_L1 && (rescaled || hlean_[i] != 0);
+        K<T>::proj_scalars_set(q, Gr_, a, 0, s.ps, ptmp, mpart, cbuf, s.Mtrue, ctl, nullptr);
+        s.last_rho = a.rho;
+        s.last_gamma = a.gamma;
+      }
+      for (int qb = 0; qb < s.nblk_or1(); ++qb) {
+        MultiBlk<T>& B = ma.b[ma.nblk++];
+        const long long off = (long long)qb * G_.N;
+        B.y = s.y + off; B.l = s.l + off;
+        B.yo = (to_other[i] ? s.y0 : s.y) + off;
+        B.lo = (to_other[i] ? s.l0 : s.l) + off;
+        B.ps = s.ps;
+        B.dir = s.nblk == 0 ? -1 : s.dir[qb];
+        B.set = i;
+        B.first = qb == 0;
+        B.last = qb == s.nblk_or1() - 1;
+        B.dist = s.is_dist ? 1 : 0;
+        B.ih = s.nblk == 0 ? T(0) : s.ih[qb];
+        B.rho = a.rho; B.rho1 = a.rho1; B.gamma = a.gamma;
+        B.prox = s.prox; B.plo = s.plo; B.phi = s.phi;
+      }
+    }
+    for (size_t k = 0; k < pool_.size(); ++k) {                         // join: theta / scale of every set are known
+      if (pool_[k] == stream_) continue;
+      SetState<T>* last = nullptr;
+      for (int i = 0; i < p_n_; ++i)
+        if (sets_[i].two_pass && sets_[i].st == pool_[k]) last = &sets_[i];
+      if (!last) continue;
+      SIPX_HIP(hipEventRecord(last->ev, last->st));
+      SIPX_HIP(hipStreamWaitEvent(stream_, last->ev, 0));
+    }
+    ma.x = x_; ma.m = m_; ma.xold = xold_;
+    ma.rhs = fuse_rhs_ ? rhs_ : nullptr;
+    ma.partials = part_sets_;
+    if (!K<T>::yl_multi(stream_, G_, ma)) {
+      // (the searches have run and left theta / scale in place; the per-set path would repeat them: refuse up front instead)
+      throw std::runtime_error("internal: the fused y/l sweep refused a block list it was prepared for");
+    }
+    rhs_fused_ = ma.rhs != nullptr;
+    for (int i = 0; i < p_n_; ++i) {
+      SetState<T>& s = sets_[i];
+      if (to_other[i]) { std::swap(s.y, s.y0); std::swap(s.l, s.l0); s.snap = 1; }     // (y, l) always names the current iterate
+    }
+    return true;
   }
 
   // second half of update_y_l: waits for the reduced sums and turns them into the per-set scalars.  The whole-solve loop
@@ -1261,7 +1365,9 @@ class Engine : public EngineBase {
       if (i == 1) flags |= SIPX_YL_FIRST;
       if ((R.adjust_rho || R.adjust_gamma) && i % R.freq == 0) flags |= SIPX_YL_BB;
       defer_sums_ = true;                  // queue the kernels and the reduction of their sums, collect them further down
+      fuse_rhs_ = i < maxit && !rho_may_change(i);       // rhs_{i+1} may be formed by the sweep that forms y_{i+1}, l_{i+1}
       update_y_l(i, flags, rho.data(), gamma.data(), rpri.data(), rdual.data(), feas.data());
+      fuse_rhs_ = false;
       defer_sums_ = false;
       mark(3);                             // also the event the host waits on for the sums
       sums_event_ = ev_[par * MAXMARK + nmark_[par] - 1];
@@ -1269,7 +1375,9 @@ class Engine : public EngineBase {
       // below cannot touch rho, rhs_{i+1} = sum_i A_i'(rho_i y_i + l_i) (and, sharded, its reduce-scatter on the
       // communication stream) is queued now and runs while the host waits for the sums and evaluates the stop rule.  A
       // stop leaves x, y, l as they are: rhs is scratch.
-      if (i < maxit && !rho_may_change(i)) {
+      if (rhs_fused_) {
+        R.rhs_ready = true;                  // written by the y/l sweep itself (kernels_multi.hip)
+      } else if (i < maxit && !rho_may_change(i)) {
         rhs_compose(rho.data());
         mark(1);
         R.rhs_ready = true;
@@ -2212,6 +2320,9 @@ class Engine : public EngineBase {
   volatile int* hovf_ = nullptr;      // per set: the slab-decomposed search overflowed its exchange segments (k_gather_unpack)
   long long l1_sample_runs_ = 0;
   bool l1_sample_ = true;             // SIPX_L1_SAMPLE=0: no sampled prediction of theta (A/B switch)
+  bool yl_multi_ = true;              // SIPX_YL_MULTI=0: never take the one-sweep y/l update (A/B switch)
+  bool fuse_rhs_ = false;             // the whole-solve loop: rho cannot change before the next iteration, so the sweep may write its rhs
+  bool rhs_fused_ = false;            // ... and did
   std::vector<hipEvent_t> ev_;
   int nmark_[2] = {0, 0};
   int mark_sec_[2][MAXMARK];

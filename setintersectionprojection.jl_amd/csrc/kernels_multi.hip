@@ -9,69 +9,153 @@
 // 24 N w for the headline list (p = 5, M_i ~ N) against 30 + 3 + 11 = 44 N w of the three separate passes.
 //
 // The adjoint stencils of the residual norm and of the right-hand side need the NEW values of a set at the grid neighbours
-// g - stride.  A workgroup owns a tile of (4 LX) x TY grid points of a plane and marches along the last dimension:
+// g - stride.  A workgroup owns a tile of (V LX) x TY grid points of a plane and marches along the last dimension:
 //   -x neighbour: the lane to the left (one shuffle); at a tile edge inside the grid the one point is recomputed;
 //   -y neighbour: the thread one row up, through LDS (double buffered by plane parity: one barrier per plane); the row in
 //                 front of the tile is recomputed by the tile's first row of threads -- for the blocks that difference along
 //                 y only, 1 / TY of one block's work;
-//   -z neighbour: the same thread's values of the previous plane, kept in a private LDS slot; the plane in front of a chunk
-//                 of planes is recomputed once per chunk (this is also how a rank of a slab-decomposed solve obtains the last
-//                 plane of the rank below, bit for bit, without an exchange).
-// Recomputation is exact because the prox is element-wise once its scalars (theta, scale, tau) are known.  Every element
-// goes through the arithmetic of k_yl / k_rhs / k_adj_norm in the same order (-ffp-contract=off), so y, l and rhs are
-// bit-identical to the separate kernels; the float64 sums differ in their summation order only.
+//   -z neighbour: the same thread's values of the previous plane, kept in registers; the plane in front of a chunk of planes
+//                 is recomputed once per chunk.
+// Recomputation is exact because the prox is element-wise once its scalars (theta, scale) are known.  Every element goes
+// through the arithmetic of k_yl / k_rhs / k_adj_norm in the same order (-ffp-contract=off), so y, l and rhs are
+// bit-identical to the separate kernels (tested); the float64 sums differ in their summation order only.
+//
+// The kernel is COMPILED PER BLOCK LAYOUT (which block is an identity, a difference along x / y / z, the distance term; where
+// the sets end): a first version that took the layout at run time carried every variant of every block (24 000 instructions,
+// 256 VGPRs, one wave per SIMD) and was bound by instruction issue, not by memory.  The layouts of the BASELINE configurations
+// and of the common one- and two-operator lists are instantiated; any other list keeps the per-set kernels.
+#include <cstdlib>
 #include <stdexcept>
 #include <string>
+#include <type_traits>
 
 #include "sipx_device.h"
 
 namespace sipx {
 
+#ifndef SIPX_MULTI_PREFETCH
+#define SIPX_MULTI_PREFETCH 1
+#endif
+#ifndef SIPX_MULTI_VF
+#define SIPX_MULTI_VF 4          // points per thread, Float32 (Float64: half as many)
+#endif
+#ifndef SIPX_MULTI_WAVES
+#define SIPX_MULTI_WAVES 1       // waves per SIMD the register allocation aims at
+#endif
 constexpr int MULTI_NT = 256;
-constexpr int MULTI_YB = 2;       // blocks that difference along the tile's row dimension (LDS exchange slots)
-constexpr int MULTI_ZB = 2;       // blocks that difference along the march dimension (private LDS slots)
 
-// s = A x at V consecutive points of a line, then the element-wise update of update_y_l.jl:64-78 (the code of k_yl)
-template <typename T, int V>
-__device__ __forceinline__ void multi_block_update(const MultiBlk<T>& B, const ProxCtx<T>& pc, const Vec<T, V>& xc, const Vec<T, V>& xn,
-                                                   const bool (&valid)[V], const Vec<T, V>& yv, const Vec<T, V>& lv, const Vec<T, V>& lbv,
-                                                   const Vec<T, V>& ubv, const Vec<T, V>& mv, long long e, Vec<T, V>& yn, Vec<T, V>& ln,
-                                                   T (&s)[V], T (&rp)[V]) {
+// ---- block layouts: 4 bits per block, block 0 in the lowest nibble: kind (3 bits) | last block of its set (bit 3) ----
+enum { LK_I = 1, LK_X = 2, LK_Y = 3, LK_Z = 4, LK_D = 5 };      // identity / forward difference along x, y, z / distance term
+constexpr unsigned long long lay_blk(int kind, bool last) { return (unsigned long long)(kind | (last ? 8 : 0)); }
+constexpr unsigned long long lay_pack(unsigned long long b0, unsigned long long b1 = 0, unsigned long long b2 = 0, unsigned long long b3 = 0,
+                                      unsigned long long b4 = 0, unsigned long long b5 = 0, unsigned long long b6 = 0,
+                                      unsigned long long b7 = 0) {
+  return b0 | (b1 << 4) | (b2 << 8) | (b3 << 12) | (b4 << 16) | (b5 << 20) | (b6 << 24) | (b7 << 28);
+}
+constexpr int lay_kind(unsigned long long L, int b) { return (int)((L >> (4 * b)) & 7); }
+constexpr bool lay_last(unsigned long long L, int b) { return ((L >> (4 * b)) & 8) != 0; }
+constexpr bool lay_first(unsigned long long L, int b) { return b == 0 || lay_last(L, b - 1); }
+constexpr int lay_count(unsigned long long L) {
+  int n = 0;
+  while (n < MULTI_MAXB && lay_kind(L, n) != 0) ++n;
+  return n;
+}
+constexpr int lay_count_kind(unsigned long long L, int kind) {
+  int n = 0;
+  for (int b = 0; b < MULTI_MAXB; ++b) n += lay_kind(L, b) == kind;
+  return n;
+}
+constexpr int lay_index_among(unsigned long long L, int b, int kind) {      // how many blocks of `kind` precede block b
+  int n = 0;
+  for (int c = 0; c < b; ++c) n += lay_kind(L, c) == kind;
+  return n;
+}
+constexpr int lay_sets(unsigned long long L) {
+  int n = 0;
+  for (int b = 0; b < MULTI_MAXB; ++b) n += (lay_kind(L, b) != 0 && lay_last(L, b)) ? 1 : 0;
+  return n;
+}
+
+// The prox of a block in ONE branch-free form, so that the kernel carries no switch over projector kinds:
+//     y = clamp( fill ? scale : soft_threshold(v, theta) * scale, lo, hi )
+// where every factor a block does not use is an EXACT identity -- soft_threshold(v, 0) = v (signed zeros included), v * 1 = v,
+// clamping to (-inf, +inf) -- so each kind gets the bits of prox_apply: bounds (lo, hi), l1 ball / prox_l1 (theta), l2 ball /
+// annulus (scale, fill).  The distance term, (v rho + m) / (rho + 1) with its Float64 division (prox_l2s!.jl:4), is the one
+// other form.  Per-element bounds and cardinality are not taken by this kernel (the engine keeps the per-set kernels then).
+template <typename T>
+struct UniProx {
+  T lo, hi, theta, scale;
+  int fill;
+};
+template <typename T>
+__device__ __forceinline__ UniProx<T> make_uniprox(const MultiBlk<T>& B) {
+  UniProx<T> u;
+  u.lo = -(T)INFINITY; u.hi = (T)INFINITY; u.theta = T(0); u.scale = T(1); u.fill = 0;
+  if (B.prox == PX_BOUNDS) { u.lo = B.plo; u.hi = B.phi; }
+  if (B.prox == PX_L1) u.theta = B.ps->theta;
+  if (B.prox == PX_PROX_L1) u.theta = T(1) / B.phi;              // prox_l1!(x, constraint.max): threshold 1/rho
+  if (B.prox == PX_L2 || B.prox == PX_ANNULUS) { u.scale = B.ps->scale; u.fill = B.ps->fill; }
+  return u;
+}
+
+// s = A x at VV consecutive points of a line, then the element-wise update of update_y_l.jl:64-78 (the arithmetic of k_yl).
+// KIND is the block's compile-time kind; `valid`: the forward-difference row exists.
+template <typename T, int VV, int KIND>
+__device__ __forceinline__ void multi_block_update(const MultiBlk<T>& B, const UniProx<T>& pc, const Vec<T, VV>& xc, const Vec<T, VV>& xn,
+                                                   const bool (&valid)[VV], const Vec<T, VV>& yv, const Vec<T, VV>& lv, const Vec<T, VV>& mv,
+                                                   Vec<T, VV>& yn, Vec<T, VV>& ln, T (&rp)[VV]) {
   const bool relax = !(B.gamma == T(1));
   const T gam = B.gamma, omg = T(1) - B.gamma, nih = -B.ih;
 #pragma unroll
-  for (int k = 0; k < V; ++k) {
-    if (B.dir < 0) {
-      s[k] = xc.v[k];
+  for (int k = 0; k < VV; ++k) {
+    T s;
+    if constexpr (KIND == LK_I || KIND == LK_D) {
+      s = xc.v[k];
     } else {
       const T d = nih * xc.v[k] + B.ih * xn.v[k];              // fwd_dir: the two products of a CSC row in column order
-      s[k] = valid[k] ? d : T(0);
+      s = valid[k] ? d : T(0);
     }
     const T yo = yv.v[k], lo = lv.v[k];
-    const T xh = relax ? (gam * s[k] + omg * yo) : s[k];        // update_y_l.jl:72
+    const T xh = relax ? (gam * s + omg * yo) : s;              // update_y_l.jl:72
     const T v = xh - lo * B.rho1;                               // :67 / :74
-    T y1 = prox_apply<T>(pc, v, lbv.v[k], ubv.v[k], mv.v[k], e + k);   // :68 / :75
-    if (!valid[k]) y1 = T(0);
-    rp[k] = y1 - s[k];                                          // :69 / :76
+    T y1;
+    if constexpr (KIND == LK_D) {
+      y1 = (T)((double)(v * B.rho + mv.v[k]) / ((double)B.rho + 1.0));     // prox_l2s!.jl:4
+    } else {
+      const T t = soft_thr(v, pc.theta);                        // project_l1_Duchi!.jl:49, prox_l1!.jl:9
+      const T q = pc.fill ? pc.scale : t * pc.scale;            // project_l2!.jl / project_annulus!.jl:9-17
+      const T c = q < pc.hi ? q : pc.hi;                        // max(LB, min(x, UB))  project_bounds!.jl:9
+      y1 = pc.lo > c ? pc.lo : c;
+      if constexpr (KIND != LK_I) { if (!valid[k]) y1 = T(0); }
+    }
+    rp[k] = y1 - s;                                             // :69 / :76
     ln.v[k] = relax ? (lo + B.rho * (y1 - xh)) : (lo + B.rho * rp[k]);   // :70 / :77
     yn.v[k] = y1;
   }
 }
 
-template <typename T, int V, int NBLK>
-__global__ __launch_bounds__(MULTI_NT) void k_yl_multi(Grid G, MultiArgs<T> a, int lgLX, int tiles_x, int tiles_y, int zchunk,
+// compile-time loop: f(std::integral_constant<int, I>) for I = 0 .. N-1 (the block index selects code, not just data)
+template <int I, int N, typename F>
+__device__ __forceinline__ void static_for(F&& f) {
+  if constexpr (I < N) {
+    f(std::integral_constant<int, I>{});
+    static_for<I + 1, N>(f);
+  }
+}
+
+template <typename T, int V, unsigned long long L>
+__global__ __launch_bounds__(MULTI_NT, SIPX_MULTI_WAVES) void k_yl_multi(Grid G, MultiArgs<T> a, int lgLX, int tiles_x, int tiles_y, int zchunk,
                                                        long long items, long long jlo, long long jhi) {
-  __shared__ T ybuf[2][MULTI_YB][2][V][MULTI_NT];       // [plane parity][y block][w | dy][element][thread]
-  __shared__ T zbuf[MULTI_ZB][2][V][MULTI_NT];          // [z block][w | dy][element][thread]: the previous plane, private
+  constexpr int NBLK = lay_count(L), NY = lay_count_kind(L, LK_Y), NZ = lay_count_kind(L, LK_Z);
+  __shared__ T ybuf[2][NY > 0 ? NY : 1][2][V][MULTI_NT];       // [plane parity][y block][w | dy][element][thread]
   const int tid = threadIdx.x, LX = 1 << lgLX, tx = tid & (LX - 1), ty = tid >> lgLX, TY = MULTI_NT >> lgLX;
-  const long long n1 = G.n[0], n2 = G.n[1], n3 = G.n[2], st1 = G.st[1], st2 = G.st[2], N = G.N;
+  const long long n1 = G.n[0], n2 = G.n[1], n3 = G.n[2], st1 = G.st[1], st2 = G.st[2];
   const bool fuse_rhs = a.rhs != nullptr;
 
-  ProxCtx<T> pc[NBLK];
+  UniProx<T> pc[NBLK];
 #pragma unroll
-  for (int b = 0; b < NBLK; ++b)
-    if (b < a.nblk) pc[b] = make_prox<T>(a.b[b].prox, a.b[b].plo, a.b[b].phi, a.b[b].rho, a.b[b].ps);
-  double acc_rp[NBLK], acc_du[NBLK];
+  for (int b = 0; b < NBLK; ++b) pc[b] = make_uniprox<T>(a.b[b]);
+  double acc_rp[NBLK], acc_du[NBLK];      // r_pri sums per block (folded per set at the end); r_dual at a set's last block
 #pragma unroll
   for (int b = 0; b < NBLK; ++b) acc_rp[b] = acc_du[b] = 0;
   double acc_obj = 0, acc_evo = 0, acc_xx = 0;
@@ -83,141 +167,142 @@ __global__ __launch_bounds__(MULTI_NT) void k_yl_multi(Grid G, MultiArgs<T> a, i
     const long long i0 = ((long long)tile_x * LX + tx) * V, j = jlo + (long long)tile_y * TY + ty;
     const bool active = i0 < n1 && j < jhi;
     const long long k0 = a.zlo + zc * zchunk, k1 = (k0 + zchunk < a.zhi) ? k0 + zchunk : a.zhi;
-    const long long gj = active ? i0 + st1 * j : 0;           // inactive threads shadow point 0 of the plane (nothing stored)
-    // masks that do not change along the march
+    // Addresses = uniform base of the plane (scalar registers) + the thread's 32-bit offset inside the plane: one vector
+    // register serves every array (a 64-bit vector address per array cost 40 registers and as many 64-bit adds per plane)
+    const unsigned go = active ? (unsigned)(i0 + st1 * j) : 0u;       // inactive threads shadow point 0 of the plane (nothing stored)
     bool vx[V], mxm[V];                                        // forward-difference row exists / its left neighbour row exists (x)
 #pragma unroll
     for (int k = 0; k < V; ++k) { vx[k] = (i0 + k) < n1 - 1; mxm[k] = (i0 + k) > 0; }
     const bool vy = j < n2 - 1, mym = j > 0;
-    __syncthreads();                                           // the previous item's LDS traffic is over
+    if constexpr (NY > 0) __syncthreads();                     // the previous item's LDS traffic is over
 
-    // the previous plane of the blocks that difference along the march dimension (recomputed at the chunk's first plane)
-    {
-      int zi = 0;
-#pragma unroll
-      for (int b = 0; b < NBLK; ++b) {
-        if (b >= a.nblk || a.b[b].dir != 2) continue;
+    // the previous plane of the blocks that difference along the march dimension: registers, recomputed at a chunk's start
+    T zw[NZ > 0 ? NZ : 1][V], zd[NZ > 0 ? NZ : 1][V];
+    static_for<0, NBLK>([&](auto bc) {
+      constexpr int b = decltype(bc)::value;
+      if constexpr (lay_kind(L, b) == LK_Z) {
+        constexpr int zi = lay_index_among(L, b, LK_Z);
         const MultiBlk<T>& B = a.b[b];
-        Vec<T, V> w = zerov<T, V>(), d = zerov<T, V>();
+#pragma unroll
+        for (int k = 0; k < V; ++k) zw[zi][k] = zd[zi][k] = T(0);
         if (active && k0 > 0) {
-          const long long g = gj + st2 * (k0 - 1);
-          const Vec<T, V> xc = ldv<T, V>(a.x + g), xn = ldv_u<T, V>(a.x + g + st2);
-          const Vec<T, V> yv = ldv<T, V>(B.y + g), lv = ldv<T, V>(B.l + g);
-          Vec<T, V> lbv = zerov<T, V>(), ubv = zerov<T, V>();
-          if (B.prox == PX_BOUNDS_VEC) { lbv = ldv<T, V>(B.lb + g); ubv = ldv<T, V>(B.ub + g); }
+          const long long pz = st2 * (k0 - 1);
+          const Vec<T, V> xc = ldv<T, V>(a.x + pz + go), xn = ldv_u<T, V>(a.x + pz + st2 + go);
+          const Vec<T, V> yv = ldv<T, V>(B.y + pz + go), lv = ldv<T, V>(B.l + pz + go);
           bool valid[V];
 #pragma unroll
           for (int k = 0; k < V; ++k) valid[k] = true;        // plane k0 - 1 <= n3 - 2
           Vec<T, V> yn, ln;
-          T s[V], rp[V];
-          multi_block_update<T, V>(B, pc[b], xc, xn, valid, yv, lv, lbv, ubv, zerov<T, V>(), g, yn, ln, s, rp);
+          T rp[V];
+          multi_block_update<T, V, LK_Z>(B, pc[b], xc, xn, valid, yv, lv, zerov<T, V>(), yn, ln, rp);
 #pragma unroll
-          for (int k = 0; k < V; ++k) { w.v[k] = B.rho * yn.v[k] + ln.v[k]; d.v[k] = yn.v[k] - yv.v[k]; }
+          for (int k = 0; k < V; ++k) { zw[zi][k] = B.rho * yn.v[k] + ln.v[k]; zd[zi][k] = yn.v[k] - yv.v[k]; }
         }
-        if (zi < MULTI_ZB) {
-#pragma unroll
-          for (int k = 0; k < V; ++k) { zbuf[zi][0][k][tid] = w.v[k]; zbuf[zi][1][k][tid] = d.v[k]; }
-        }
-        ++zi;
       }
-    }
+    });
 
-    Vec<T, V> xnext = active ? ldv<T, V>(a.x + gj + st2 * k0) : zerov<T, V>();
+    Vec<T, V> xnext = active ? ldv<T, V>(a.x + st2 * k0 + go) : zerov<T, V>();
     for (long long kz = k0; kz < k1; ++kz) {
       const int par = (int)(kz & 1);
-      const long long g = gj + st2 * kz;
+      const long long pz = st2 * kz;                           // uniform: the plane's first point
       const Vec<T, V> xc = xnext;
       const bool vz = kz < n3 - 1, mzm = kz > 0;
+      const bool own = kz >= a.zsum;            // planes in front of zsum are recomputed for the rank below: stored, not summed
       Vec<T, V> xpx = zerov<T, V>(), xpy = zerov<T, V>();
-      if (active) {
-        xnext = ldv_u<T, V>(a.x + g + st2);                    // x carries an end halo of a plane: unconditional
-        xpx = ldv_u<T, V>(a.x + g + 1);
-        xpy = ldv_u<T, V>(a.x + g + st1);
-      }
-      // ---- phase A: the update of every block; w = rho y + l and y - y_old stay in registers -------------------------
-      T wv[NBLK][V], dv[NBLK][V];
-      int yi = 0;
+      // ---- all loads of the plane first: the stores of one block must not hold back the loads of the next --------------
+      Vec<T, V> yv[NBLK], lv[NBLK], mv = zerov<T, V>(), xo = zerov<T, V>();
 #pragma unroll
-      for (int b = 0; b < NBLK; ++b) {
+      for (int b = 0; b < NBLK; ++b) { yv[b] = zerov<T, V>(); lv[b] = zerov<T, V>(); }
+      if (active) {
+        xnext = ldv_u<T, V>(a.x + pz + st2 + go);              // x carries an end halo of a plane: unconditional
+        if constexpr (lay_count_kind(L, LK_X) > 0) xpx = ldv_u<T, V>(a.x + pz + 1 + go);
+        if constexpr (NY > 0) xpy = ldv_u<T, V>(a.x + pz + st1 + go);
+#if SIPX_MULTI_PREFETCH
+#pragma unroll
+        for (int b = 0; b < NBLK; ++b) {
+          yv[b] = ldv_nt<T, V>(a.b[b].y + pz + go);           // last use of the old iterate: streaming loads
+          lv[b] = ldv_nt<T, V>(a.b[b].l + pz + go);
+        }
+#endif
+        if constexpr (lay_count_kind(L, LK_D) > 0) { mv = ldv<T, V>(a.m + pz + go); xo = ldv<T, V>(a.xold + pz + go); }
+      }
+      // ---- phase A: the update of every block; w = rho y + l and y - y_old stay in registers ---------------------------
+      T wv[NBLK][V], dv[NBLK][V];
+      static_for<0, NBLK>([&](auto bc) {
+        constexpr int b = decltype(bc)::value;
+        constexpr int KIND = lay_kind(L, b);
+        const MultiBlk<T>& B = a.b[b];
 #pragma unroll
         for (int k = 0; k < V; ++k) wv[b][k] = dv[b][k] = T(0);
-        if (b >= a.nblk) continue;
-        const MultiBlk<T>& B = a.b[b];
         if (active) {
-          const long long e = g;                                // (block bases are already offset by q N)
-          const Vec<T, V> yv = ldv_nt<T, V>(B.y + e), lv = ldv_nt<T, V>(B.l + e);      // last use of the old iterate
-          Vec<T, V> lbv = zerov<T, V>(), ubv = zerov<T, V>(), mv = zerov<T, V>();
-          if (B.prox == PX_BOUNDS_VEC) { lbv = ldv<T, V>(B.lb + e); ubv = ldv<T, V>(B.ub + e); }
-          if (B.dist) mv = ldv<T, V>(a.m + g);
+#if !SIPX_MULTI_PREFETCH
+          yv[b] = ldv_nt<T, V>(B.y + pz + go);
+          lv[b] = ldv_nt<T, V>(B.l + pz + go);
+#endif
           bool valid[V];
 #pragma unroll
-          for (int k = 0; k < V; ++k) valid[k] = B.dir < 0 ? true : (B.dir == 0 ? vx[k] : (B.dir == 1 ? vy : vz));
-          const Vec<T, V>& xn = B.dir == 0 ? xpx : (B.dir == 1 ? xpy : xnext);
+          for (int k = 0; k < V; ++k) valid[k] = KIND == LK_X ? vx[k] : (KIND == LK_Y ? vy : (KIND == LK_Z ? vz : true));
+          const Vec<T, V>& xn = KIND == LK_X ? xpx : (KIND == LK_Y ? xpy : xnext);
           Vec<T, V> yn, ln;
-          T s[V], rp[V];
-          multi_block_update<T, V>(B, pc[b], xc, xn, valid, yv, lv, lbv, ubv, mv, B.set >= 0 ? (long long)(B.y - a.b[b].y) + e : e, yn, ln, s, rp);
-          stv_nt<T, V>(B.yo + e, yn);
-          stv_nt<T, V>(B.lo + e, ln);
+          T rp[V];
+          multi_block_update<T, V, KIND>(B, pc[b], xc, xn, valid, yv[b], lv[b], mv, yn, ln, rp);
+          stv_nt<T, V>(B.yo + pz + go, yn);
+          stv_nt<T, V>(B.lo + pz + go, ln);
 #pragma unroll
           for (int k = 0; k < V; ++k) {
             wv[b][k] = B.rho * yn.v[k] + ln.v[k];              // rhs_compose.jl:28-30 on the new iterate
-            dv[b][k] = yn.v[k] - yv.v[k];                      // x_hat = y - y_old  update_y_l.jl:82
-            acc_rp[b] += (double)rp[k] * (double)rp[k];
-            if (B.dir < 0) acc_du[b] += (double)dv[b][k] * (double)dv[b][k];
+            dv[b][k] = yn.v[k] - yv[b].v[k];                   // x_hat = y - y_old  update_y_l.jl:82
+            if (own) acc_rp[b] += (double)rp[k] * (double)rp[k];
+            if constexpr (KIND == LK_I || KIND == LK_D) { if (own) acc_du[b] += (double)dv[b][k] * (double)dv[b][k]; }
           }
-          if (B.dist) {                                         // PARSDMM.jl:140,145
-            const Vec<T, V> xo = ldv<T, V>(a.xold + g);
+          if constexpr (KIND == LK_D) {                         // PARSDMM.jl:140,145
+            if (own) {
 #pragma unroll
-            for (int k = 0; k < V; ++k) {
-              const T dd = xc.v[k] - mv.v[k], ev = xo.v[k] - xc.v[k];
-              acc_obj += (double)dd * (double)dd;
-              acc_evo += (double)ev * (double)ev;
-              acc_xx += (double)xc.v[k] * (double)xc.v[k];
+              for (int k = 0; k < V; ++k) {
+                const T dd = xc.v[k] - mv.v[k], ev = xo.v[k] - xc.v[k];
+                acc_obj += (double)dd * (double)dd;
+                acc_evo += (double)ev * (double)ev;
+                acc_xx += (double)xc.v[k] * (double)xc.v[k];
+              }
             }
           }
         }
-        if (B.dir == 1) {
-          if (yi < MULTI_YB) {
+        if constexpr (KIND == LK_Y) {
+          constexpr int yi = lay_index_among(L, b, LK_Y);
 #pragma unroll
-            for (int k = 0; k < V; ++k) { ybuf[par][yi][0][k][tid] = wv[b][k]; ybuf[par][yi][1][k][tid] = dv[b][k]; }
-          }
-          ++yi;
+          for (int k = 0; k < V; ++k) { ybuf[par][yi][0][k][tid] = wv[b][k]; ybuf[par][yi][1][k][tid] = dv[b][k]; }
         }
-      }
-      __syncthreads();
-      // ---- phase B: adjoint stencils on the new values -> r_dual sums and the right-hand side -------------------------
+      });
+      if constexpr (NY > 0) __syncthreads();
+      // ---- phase B: adjoint stencils on the new values -> r_dual sums and the right-hand side ---------------------------
       T out[V], tr[V], td[V];
 #pragma unroll
       for (int k = 0; k < V; ++k) out[k] = tr[k] = td[k] = T(0);
-      yi = 0;
-      int zi = 0;
-#pragma unroll
-      for (int b = 0; b < NBLK; ++b) {
-        if (b >= a.nblk) continue;
+      static_for<0, NBLK>([&](auto bc) {
+        constexpr int b = decltype(bc)::value;
+        constexpr int KIND = lay_kind(L, b);
         const MultiBlk<T>& B = a.b[b];
-        if (B.first) {
+        if constexpr (lay_first(L, b)) {
 #pragma unroll
           for (int k = 0; k < V; ++k) tr[k] = td[k] = T(0);
         }
-        if (B.dir < 0) {                                        // identity: t = rho y + l (k_rhs), no neighbour
+        if constexpr (KIND == LK_I || KIND == LK_D) {          // identity: t = rho y + l (k_rhs), no neighbour
 #pragma unroll
           for (int k = 0; k < V; ++k) tr[k] = wv[b][k];
         } else {
           T pw[V], pd[V];                                       // the values at g - stride
           bool mm[V], mc[V];                                    // that row exists / the row at g exists
-          if (B.dir == 0) {
+          if constexpr (KIND == LK_X) {
             // the lane to the left holds the point in front of this vector; at the left edge of a tile inside the grid the
             // one point is recomputed
             T lw = __shfl_up(wv[b][V - 1], 1, 64), ld = __shfl_up(dv[b][V - 1], 1, 64);
             if (tx == 0 && active && i0 > 0) {
-              const long long e1 = g - 1;
-              Vec<T, 1> x1, x2, y1v, l1v, lb1 = zerov<T, 1>(), ub1 = zerov<T, 1>(), yn1, ln1;
-              x1.v[0] = a.x[e1]; x2.v[0] = xc.v[0];
-              y1v.v[0] = B.y[e1]; l1v.v[0] = B.l[e1];
-              if (B.prox == PX_BOUNDS_VEC) { lb1.v[0] = B.lb[e1]; ub1.v[0] = B.ub[e1]; }
+              Vec<T, 1> x1, x2, y1v, l1v, yn1, ln1;
+              x1.v[0] = (a.x + pz - 1)[go]; x2.v[0] = xc.v[0];
+              y1v.v[0] = (B.y + pz - 1)[go]; l1v.v[0] = (B.l + pz - 1)[go];
               const bool v1[1] = {true};
-              T s1[1], rp1[1];
-              multi_block_update<T, 1>(B, pc[b], x1, x2, v1, y1v, l1v, lb1, ub1, zerov<T, 1>(), e1, yn1, ln1, s1, rp1);
+              T rp1[1];
+              multi_block_update<T, 1, LK_X>(B, pc[b], x1, x2, v1, y1v, l1v, zerov<T, 1>(), yn1, ln1, rp1);
               lw = B.rho * yn1.v[0] + ln1.v[0];
               ld = yn1.v[0] - y1v.v[0];
             }
@@ -228,46 +313,39 @@ __global__ __launch_bounds__(MULTI_NT) void k_yl_multi(Grid G, MultiArgs<T> a, i
               mm[k] = mxm[k];
               mc[k] = vx[k];
             }
-          } else if (B.dir == 1) {
+          } else if constexpr (KIND == LK_Y) {
+            constexpr int yi = lay_index_among(L, b, LK_Y);
             if (ty > 0) {
 #pragma unroll
-              for (int k = 0; k < V; ++k) {
-                pw[k] = yi < MULTI_YB ? ybuf[par][yi][0][k][tid - LX] : T(0);
-                pd[k] = yi < MULTI_YB ? ybuf[par][yi][1][k][tid - LX] : T(0);
-              }
+              for (int k = 0; k < V; ++k) { pw[k] = ybuf[par][yi][0][k][tid - LX]; pd[k] = ybuf[par][yi][1][k][tid - LX]; }
             } else {
 #pragma unroll
               for (int k = 0; k < V; ++k) pw[k] = pd[k] = T(0);
               if (active && mym) {                              // the row in front of the tile: recomputed
-                const long long e1 = g - st1;
-                const Vec<T, V> x1 = ldv<T, V>(a.x + e1), yv = ldv<T, V>(B.y + e1), lv = ldv<T, V>(B.l + e1);
-                Vec<T, V> lbv = zerov<T, V>(), ubv = zerov<T, V>(), yn, ln;
-                if (B.prox == PX_BOUNDS_VEC) { lbv = ldv<T, V>(B.lb + e1); ubv = ldv<T, V>(B.ub + e1); }
+                const Vec<T, V> x1 = ldv<T, V>(a.x + pz - st1 + go), yh = ldv<T, V>(B.y + pz - st1 + go), lh = ldv<T, V>(B.l + pz - st1 + go);
+                Vec<T, V> yn, ln;
                 bool valid[V];
 #pragma unroll
                 for (int k = 0; k < V; ++k) valid[k] = true;
-                T s1[V], rp1[V];
-                multi_block_update<T, V>(B, pc[b], x1, xc, valid, yv, lv, lbv, ubv, zerov<T, V>(), e1, yn, ln, s1, rp1);
+                T rp1[V];
+                multi_block_update<T, V, LK_Y>(B, pc[b], x1, xc, valid, yh, lh, zerov<T, V>(), yn, ln, rp1);
 #pragma unroll
-                for (int k = 0; k < V; ++k) { pw[k] = B.rho * yn.v[k] + ln.v[k]; pd[k] = yn.v[k] - yv.v[k]; }
+                for (int k = 0; k < V; ++k) { pw[k] = B.rho * yn.v[k] + ln.v[k]; pd[k] = yn.v[k] - yh.v[k]; }
               }
             }
 #pragma unroll
             for (int k = 0; k < V; ++k) { mm[k] = mym; mc[k] = vy; }
-            ++yi;
           } else {
+            constexpr int zi = lay_index_among(L, b, LK_Z);
 #pragma unroll
             for (int k = 0; k < V; ++k) {
-              pw[k] = zi < MULTI_ZB ? zbuf[zi][0][k][tid] : T(0);
-              pd[k] = zi < MULTI_ZB ? zbuf[zi][1][k][tid] : T(0);
+              pw[k] = zw[zi][k];
+              pd[k] = zd[zi][k];
               mm[k] = mzm;
               mc[k] = vz;
+              zw[zi][k] = wv[b][k];
+              zd[zi][k] = dv[b][k];
             }
-            if (zi < MULTI_ZB) {
-#pragma unroll
-              for (int k = 0; k < V; ++k) { zbuf[zi][0][k][tid] = wv[b][k]; zbuf[zi][1][k][tid] = dv[b][k]; }
-            }
-            ++zi;
           }
           // adj_dir_acc: t += ih w[g - st] (if that row exists); t += (-ih) w[g] (if row g exists)
           const T ih = B.ih, nih = -B.ih;
@@ -283,55 +361,50 @@ __global__ __launch_bounds__(MULTI_NT) void k_yl_multi(Grid G, MultiArgs<T> a, i
             td[k] = mc[k] ? d2 : td[k];
           }
         }
-        if (B.last) {
+        if constexpr (lay_last(L, b)) {
 #pragma unroll
           for (int k = 0; k < V; ++k) {
             out[k] = out[k] + tr[k];                            // sets added in order (rhs_compose.jl:24-31)
-            if (B.dir >= 0 && active) acc_du[b] += (double)td[k] * (double)td[k];
+            if constexpr (KIND != LK_I && KIND != LK_D) { if (active && own) acc_du[b] += (double)td[k] * (double)td[k]; }
           }
         }
-      }
-      if (fuse_rhs && active) {
+      });
+      if (fuse_rhs && active && own) {
         Vec<T, V> o;
 #pragma unroll
         for (int k = 0; k < V; ++k) o.v[k] = out[k];
-        stv<T, V>(a.rhs + g, o);
+        stv<T, V>(a.rhs + pz + go, o);
       }
     }
   }
-  // ---- sums: blocks of one set fold into the set's first block, then one block-wide reduction per slot ----------------
-  // flat slot index into the engine's partial array: set * SET_SLOTS + {SL_RPRI, SL_DY | SL_ADJ}, the distance term's three
-  constexpr int K = 2 * NBLK + 3;
+  // ---- sums: the blocks of a set fold into one r_pri sum; r_dual sits at the set's last block; one block-wide reduction
+  // per slot.  Flat slot index into the engine's partial array: set * SET_SLOTS + {SL_RPRI, SL_DY | SL_ADJ, SL_OBJ ...}
+  constexpr int NSETS = lay_sets(L);
+  constexpr bool HAS_D = lay_count_kind(L, LK_D) > 0;
+  constexpr int K = 2 * NSETS + (HAS_D ? 3 : 0);
   double acc[K];
   int slots[K];
-  const int scratch = a.nblk > 0 ? a.b[0].set * SET_SLOTS + SL_HL : SL_HL;      // unused entries: a slot nobody reads on these iterations
-#pragma unroll
-  for (int b = 0; b < NBLK; ++b) {
-    acc[2 * b] = acc[2 * b + 1] = 0;
-    slots[2 * b] = slots[2 * b + 1] = scratch;
+  {
+    double rp_set = 0;
+    static_for<0, NBLK>([&](auto bc) {
+      constexpr int b = decltype(bc)::value;
+      rp_set = lay_first(L, b) ? acc_rp[b] : rp_set + acc_rp[b];
+      if constexpr (lay_last(L, b)) {
+        constexpr int KIND = lay_kind(L, b);
+        constexpr int si = lay_sets(L & ((1ull << (4 * b)) - 1ull));         // sets that end before block b
+        acc[2 * si] = rp_set;
+        slots[2 * si] = a.b[b].set * SET_SLOTS + SL_RPRI;
+        acc[2 * si + 1] = acc_du[b];
+        slots[2 * si + 1] = a.b[b].set * SET_SLOTS + ((KIND == LK_I || KIND == LK_D) ? SL_DY : SL_ADJ);
+        if constexpr (KIND == LK_D) {
+          acc[2 * NSETS] = acc_obj; acc[2 * NSETS + 1] = acc_evo; acc[2 * NSETS + 2] = acc_xx;
+          slots[2 * NSETS] = a.b[b].set * SET_SLOTS + SL_OBJ;
+          slots[2 * NSETS + 1] = a.b[b].set * SET_SLOTS + SL_EVO;
+          slots[2 * NSETS + 2] = a.b[b].set * SET_SLOTS + SL_XX;
+        }
+      }
+    });
   }
-  int dist_set = -1;
-#pragma unroll
-  for (int b = 0; b < NBLK; ++b) {
-    if (b >= a.nblk) continue;
-    if (a.b[b].dist) dist_set = a.b[b].set;
-#pragma unroll
-    for (int b2 = 0; b2 < NBLK; ++b2) {          // the set's last block carries r_dual, its first collects r_pri
-      if (b2 < a.nblk && a.b[b2].set == a.b[b].set && a.b[b2].first) acc[2 * b2] += acc_rp[b];
-    }
-    if (a.b[b].last) {
-      acc[2 * b + 1] = acc_du[b];
-      slots[2 * b + 1] = a.b[b].set * SET_SLOTS + (a.b[b].dir < 0 ? SL_DY : SL_ADJ);
-    }
-    if (a.b[b].first) slots[2 * b] = a.b[b].set * SET_SLOTS + SL_RPRI;
-  }
-  acc[2 * NBLK] = acc_obj; acc[2 * NBLK + 1] = acc_evo; acc[2 * NBLK + 2] = acc_xx;
-  const int ds = dist_set >= 0 ? dist_set : (a.nblk > 0 ? a.b[0].set : 0);
-  slots[2 * NBLK] = ds * SET_SLOTS + (dist_set >= 0 ? SL_OBJ : SL_LH);
-  slots[2 * NBLK + 1] = ds * SET_SLOTS + (dist_set >= 0 ? SL_EVO : SL_DL);
-  slots[2 * NBLK + 2] = ds * SET_SLOTS + (dist_set >= 0 ? SL_XX : SL_GG);
-  // (several entries may name the scratch slot: they are written one after another by different threads of the epilogue --
-  // harmless, nobody reads it)
   __shared__ double sm[K][MULTI_NT / 64];
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
 #pragma unroll
@@ -353,7 +426,7 @@ __global__ __launch_bounds__(MULTI_NT) void k_yl_multi(Grid G, MultiArgs<T> a, i
   }
 }
 
-template <typename T, int V, int NBLK>
+template <typename T, int V, unsigned long long L>
 static void launch_multi(hipStream_t s, const Grid& g, const MultiArgs<T>& a, double bytes) {
   // tile geometry: LX lanes of V points along x (a power of two, at most a wave), TY = 256 / LX rows
   const long long nvx = g.n[0] / V;
@@ -370,44 +443,65 @@ static void launch_multi(hipStream_t s, const Grid& g, const MultiArgs<T>& a, do
   // chunks of planes: enough work items to fill the chip several times over, chunks long enough that the plane recomputed in
   // front of each stays a small share (<= 1 / 8 of one block's work)
   const long long planes = zhi - zlo;
+  static const long long zc_env = [] { const char* e = getenv("SIPX_MULTI_ZCHUNK"); return e ? atoll(e) : 0ll; }();
   long long want = (4ll * NB_7 + tiles - 1) / tiles;          // chunks per tile column for ~4 items per workgroup slot
   if (want < 1) want = 1;
   long long zchunk = (planes + want - 1) / want;
   if (zchunk < 8) zchunk = planes < 8 ? planes : 8;
+  if (zc_env > 0) zchunk = zc_env < planes ? zc_env : planes;
   const long long nchunks = (planes + zchunk - 1) / zchunk;
   const long long items = tiles * nchunks;
   const int grid = (int)(items < NB_7 ? items : NB_7);
   MultiArgs<T> b = a;
   b.zlo = zlo; b.zhi = zhi;
+  if (!three) b.zsum = 0;
   ObsScope obs(KID_YL_MULTI, s, bytes);
-  hipLaunchKernelGGL((k_yl_multi<T, V, NBLK>), dim3(grid), dim3(MULTI_NT), 0, s, g, b, lg, tiles_x, tiles_y, (int)zchunk, items, jlo, jhi);
+  hipLaunchKernelGGL((k_yl_multi<T, V, L>), dim3(grid), dim3(MULTI_NT), 0, s, g, b, lg, tiles_x, tiles_y, (int)zchunk, items, jlo, jhi);
   SIPX_HIP(hipGetLastError());
 }
 
+// the instantiated layouts (I = identity set, X / Y / Z = a set of one difference block, [..] = blocks of one set, D = distance)
+#define SIPX_LAYOUTS(F)                                                                                                          \
+  F(lay_pack(lay_blk(LK_I, 1), lay_blk(LK_X, 1), lay_blk(LK_Y, 1), lay_blk(LK_Z, 1), lay_blk(LK_D, 1)))   /* C3: I X Y Z D */        \
+  F(lay_pack(lay_blk(LK_I, 1), lay_blk(LK_Z, 0), lay_blk(LK_Y, 0), lay_blk(LK_X, 1), lay_blk(LK_D, 1)))   /* C5: I [Z Y X] D */      \
+  F(lay_pack(lay_blk(LK_I, 1), lay_blk(LK_Y, 0), lay_blk(LK_X, 1), lay_blk(LK_D, 1)))                     /* C2: I [Y X] D (2-D TV) */ \
+  F(lay_pack(lay_blk(LK_I, 1), lay_blk(LK_X, 1), lay_blk(LK_Z, 1), lay_blk(LK_D, 1)))                     /* I X Z D */             \
+  F(lay_pack(lay_blk(LK_I, 1), lay_blk(LK_Y, 1), lay_blk(LK_X, 1), lay_blk(LK_D, 1)))                     /* I Y X D (2-D D_z, D_x) */ \
+  F(lay_pack(lay_blk(LK_I, 1), lay_blk(LK_Z, 1), lay_blk(LK_D, 1)))                                       /* I Z D */               \
+  F(lay_pack(lay_blk(LK_I, 1), lay_blk(LK_Y, 1), lay_blk(LK_D, 1)))                                       /* I Y D */               \
+  F(lay_pack(lay_blk(LK_I, 1), lay_blk(LK_X, 1), lay_blk(LK_D, 1)))                                       /* I X D */               \
+  F(lay_pack(lay_blk(LK_I, 1), lay_blk(LK_Z, 0), lay_blk(LK_Y, 0), lay_blk(LK_X, 1), lay_blk(LK_I, 1), lay_blk(LK_D, 1)))   /* I [Z Y X] I D */ \
+  F(lay_pack(lay_blk(LK_I, 1), lay_blk(LK_D, 1)))                                                         /* I D */
+
 template <typename T>
-bool K<T>::yl_multi(hipStream_t s, const Grid& g, const MultiArgs<T>& a) {
-  constexpr int V = sizeof(T) == 8 ? 2 : 4;
+bool K<T>::yl_multi(hipStream_t s, const Grid& g, const MultiArgs<T>& a, bool probe_only) {
+  constexpr int V = sizeof(T) == 8 ? SIPX_MULTI_VF / 2 : SIPX_MULTI_VF;
   if (a.nblk < 1 || a.nblk > MULTI_MAXB || g.n[0] % V != 0) return false;
-  int ny = 0, nz = 0;
+  unsigned long long code = 0;
   for (int b = 0; b < a.nblk; ++b) {
-    ny += a.b[b].dir == 1;
-    nz += a.b[b].dir == 2;
+    const int px = a.b[b].prox;
+    if (!(px == PX_BOUNDS || px == PX_L1 || px == PX_PROX_L1 || px == PX_L2 || px == PX_ANNULUS || px == PX_DIST)) return false;
     if (a.b[b].dir == 2 && g.n[2] <= 1) return false;
+    const int kind = a.b[b].dist ? LK_D : (a.b[b].dir < 0 ? LK_I : (a.b[b].dir == 0 ? LK_X : (a.b[b].dir == 1 ? LK_Y : LK_Z)));
+    code |= lay_blk(kind, a.b[b].last != 0) << (4 * b);
   }
-  if (ny > MULTI_YB || nz > MULTI_ZB) return false;
   // algorithmic bytes: x, (m, x_old for the distance term) read; y, l of every block read and written; rhs written
   const bool three = g.n[2] > 1;
   const double pts = (double)(a.zhi - a.zlo) * (three ? (double)g.st[2] : (double)g.st[1]);
   double vecs = 1.0 + (a.rhs ? 1.0 : 0.0);
-  for (int b = 0; b < a.nblk; ++b) vecs += 4.0 + (a.b[b].dist ? 2.0 : 0.0) + (a.b[b].prox == PX_BOUNDS_VEC ? 2.0 : 0.0);
+  for (int b = 0; b < a.nblk; ++b) vecs += 4.0 + (a.b[b].dist ? 2.0 : 0.0);
   const double bytes = vecs * pts * sizeof(T);
-  if (a.nblk <= 4) launch_multi<T, V, 4>(s, g, a, bytes);
-  else if (a.nblk <= 6) launch_multi<T, V, 6>(s, g, a, bytes);
-  else launch_multi<T, V, 8>(s, g, a, bytes);
-  return true;
+#define SIPX_TRY_LAYOUT(LL)                                    \
+  if (code == (LL)) {                                          \
+    if (!probe_only) launch_multi<T, V, (LL)>(s, g, a, bytes); \
+    return true;                                               \
+  }
+  SIPX_LAYOUTS(SIPX_TRY_LAYOUT)
+#undef SIPX_TRY_LAYOUT
+  return false;
 }
 
-template bool K<float>::yl_multi(hipStream_t, const Grid&, const MultiArgs<float>&);
-template bool K<double>::yl_multi(hipStream_t, const Grid&, const MultiArgs<double>&);
+template bool K<float>::yl_multi(hipStream_t, const Grid&, const MultiArgs<float>&, bool);
+template bool K<double>::yl_multi(hipStream_t, const Grid&, const MultiArgs<double>&, bool);
 
 }  // namespace sipx

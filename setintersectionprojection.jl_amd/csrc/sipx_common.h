@@ -253,7 +253,6 @@ template <typename T>
 struct MultiBlk {
   const T *y, *l;                 // block q of the set's current iterate (base already offset by q * N)
   T *yo, *lo;                     // where the update goes
-  const T *lb, *ub;               // per-element bounds (offset like y), else nullptr
   const ProjScalars<T>* ps;
   int dir;                        // -1: identity; 0 / 1 / 2: forward difference along that grid dimension
   int set;                        // index of the set the block belongs to (its group of partial slots)
@@ -271,6 +270,8 @@ struct MultiArgs {
   T* rhs;                         // nullptr: no fused right-hand side
   double* partials;               // the engine's per-set partial array (SET_SLOTS groups)
   long long zlo, zhi;             // planes [zlo, zhi) of the last grid dimension (the rank's slab; the whole grid on one rank)
+  long long zsum;                 // first plane whose sums / rhs belong to this rank: the planes in front of it are the
+                                  // neighbour's last ones, recomputed (and stored) instead of being received
 };
 
 // One changed set of a fused Q update: Q[:,col(off_j)] += alpha * AtA_i[:,j] (CDS_scaled_add!.jl:16-22).
@@ -369,7 +370,8 @@ struct K {
   static void adj_norm(hipStream_t s, const Grid& g, const SetArgs<T>& a, double* partials);
   // every set's y/l update (+ r_pri, r_dual sums, obj / evol sums, optionally rhs of the next iteration) in one sweep;
   // returns false (nothing launched) when the block list does not fit the kernel's instantiations
-  static bool yl_multi(hipStream_t s, const Grid& g, const MultiArgs<T>& a);
+  // (probe_only: only say whether the list fits)
+  static bool yl_multi(hipStream_t s, const Grid& g, const MultiArgs<T>& a, bool probe_only = false);
   static void fwd(hipStream_t s, const Grid& g, int nblk, const int* dir, const T* ih, const T* x, T* out);
   static void adj(hipStream_t s, const Grid& g, int nblk, const int* dir, const T* ih, const T* v, T* out);
   static void log3(hipStream_t s, long long N, const T* x, const T* m, const T* xold, double* partials);

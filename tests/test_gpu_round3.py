@@ -12,9 +12,11 @@ from tests.test_gpu_parity import _problem, model
 pytestmark = pytest.mark.gpu
 
 
-def test_per_kernel_statistics(sipx):
+def test_per_kernel_statistics(sipx, monkeypatch):
     """sipx_kernel_stats_json in mode 2: every kernel of an iteration shows up with launches, time and algorithmic bytes;
-    mode 1 records the CG product only; the byte counts are the ones DESIGN 3 states."""
+    mode 1 records the CG product only; the byte counts are the ones DESIGN 3 states.  (With the separate per-set kernels:
+    SIPX_YL_MULTI=0; the one-sweep update has its own test below.)"""
+    monkeypatch.setenv("SIPX_YL_MULTI", "0")
     TF, n, h = np.float32, (64, 48, 40), (25.0, 25.0, 25.0)
     m = model(n, TF, seed=3)
     g, opt, P, A, prop, AtA = _problem(sipx, n, h, TF, ["bounds", "l1:D_x", "l1:D_z"], m, dict(maxit=30, evol_rel_tol=0.0, feas_tol=0.0, obj_tol=0.0))
@@ -197,3 +199,52 @@ def test_rhs_compose_reference_case_on_the_engine(sipx):
     want = rho[1] * y[1] + l[1]
     want[:51000] += 2.0 * (rho[0] * y[0] + l[0])
     assert np.linalg.norm(rhs - want) <= 10 * np.finfo(TF).eps * max(np.linalg.norm(rhs), np.linalg.norm(want))
+
+
+MULTI_CASES = [
+    # (grid, spacings, sets, precision, options, does the one-sweep kernel take this list?)
+    ((64, 48, 40), (25.0, 25.0, 25.0), ["bounds", "l1:D_x", "l1:D_y", "l1:D_z"], np.float32, {}, True),            # the headline list: I X Y Z D
+    ((64, 48, 40), (25.0, 25.0, 25.0), ["bounds", "l1:D_x", "l1:D_y", "l1:D_z"], np.float64, {}, True),
+    ((36, 20, 9), (25.0, 20.0, 10.0), ["bounds", "l1:TV", "annulus"], np.float32, {}, True),                         # ragged tiles; TV: three blocks of one set
+    ((36, 20, 9), (25.0, 20.0, 10.0), ["bounds", "l1:TV"], np.float64, {}, True),                                    # C5's list
+    ((520, 12, 6), (25.0, 25.0, 25.0), ["bounds", "l1:D_x", "l1:D_y", "l1:D_z"], np.float32, {}, True),              # two tiles along x: the recomputed point
+    ((36, 28, 30), (25.0, 25.0, 25.0), ["bounds", "l1:D_x", "l1:D_z"], np.float64, {}, True),                        # several chunks of planes: the recomputed plane
+    ((96, 80), (25.0, 6.0), ["bounds", "l1:TV"], np.float32, {}, True),                                              # 2-D (C2's list)
+    ((96, 80), (25.0, 6.0), ["bounds", "l1:D_z", "l1:D_x"], np.float64, {}, True),
+    ((40, 24, 16), (25.0, 25.0, 25.0), ["bounds", "l1:D_z"], np.float32, {"adjust_rho": False, "adjust_gamma": False}, True),   # every iteration qualifies
+    ((36, 20, 9), (25.0, 20.0, 10.0), ["l2", "l1:D_z", "bnd:D_y"], np.float64, {}, False),                           # a layout that is not instantiated: per-set kernels
+    ((96, 80), (25.0, 6.0), ["bounds", "l1:D_z", "card:D_x"], np.float64, {}, False),                                # cardinality: per-set kernels
+]
+
+
+@pytest.mark.parametrize("n,h,kinds,TF,okw,taken", MULTI_CASES)
+def test_one_sweep_update_is_bit_identical(sipx, monkeypatch, n, h, kinds, TF, okw, taken):
+    """k_yl_multi (one sweep: every set's y/l update + r_pri / r_dual / obj sums + the next right-hand side) against the
+    separate kernels (SIPX_YL_MULTI=0: k_yl per set, k_adj_norm, k_rhs): the same arithmetic per element, so x, every y_i and
+    l_i and the rho / gamma histories are IDENTICAL bit for bit; the float64 sums are taken in another order (1e-12)."""
+    m = model(n, TF, seed=7)
+    out = {}
+    for tag in ("0", "1"):
+        monkeypatch.setenv("SIPX_YL_MULTI", tag)
+        g, opt, P, A, prop, AtA = _problem(sipx, n, h, TF, kinds, m, dict(maxit=27, evol_rel_tol=0.0, feas_tol=0.0, obj_tol=0.0, **okw))
+        ctx = sipx.host.build_context(m, AtA, A, prop, P, g, opt)
+        try:
+            ctx.parsdmm_begin(opt)
+            ctx.parsdmm_steps(12)
+            ctx.kernel_stats(2)
+            ctx.parsdmm_steps(15)
+            names = {k["name"] for k in ctx.kernel_stats_all(0)["kernels"]}
+            log = ctx.parsdmm_log()
+            x, l, y = ctx.download()
+        finally:
+            ctx.close()
+        out[tag] = (x, l, y, log, names)
+    (x0, l0, y0, g0, k0), (x1, l1, y1, g1, k1) = out["0"], out["1"]
+    assert ("k_yl_multi" in k1) == taken and "k_yl_multi" not in k0
+    assert len(g0.obj) == len(g1.obj) == 27 and np.array_equal(g0.cg_it, g1.cg_it)
+    assert np.array_equal(x0, x1)
+    for a, b in zip(y0 + l0, y1 + l1):
+        assert np.array_equal(a, b)
+    assert np.array_equal(g0.rho, g1.rho) and np.array_equal(g0.gamma, g1.gamma)
+    for f in ("obj", "evol_x", "r_pri", "r_dual"):
+        assert np.allclose(getattr(g0, f), getattr(g1, f), rtol=1e-6 if TF == np.float32 else 1e-12, atol=0, equal_nan=True), f
