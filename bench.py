@@ -194,7 +194,8 @@ def dominant_kernel(per_kernel):
             row["note"] = "library-backed projector (hipFFT / rocSOLVER / rocBLAS calls): its interval contains other listed kernels; not a candidate"
         rows.append(row)
     dom = dict(next(r for r in rows if "library-backed" not in r.get("note", "")))
-    dom.update({"bound": "hbm", "peak": HBM_PEAK_GBS, "unit": "GB/s",
+    dom.update({"bound": "hbm" if dom["algorithmic_bytes_per_launch"] > 0 else "latency (a scalar / one-workgroup step: no algorithmic bytes)",
+                "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "achieved": (dom["frac"] or 0.0) * HBM_PEAK_GBS,
                 "definition": "largest total time among the engine's kernels in the statistics window that follows the timed steps "
                               "(HIP events around every launch on the launch's own stream; with two set streams a kernel's interval "

@@ -127,6 +127,7 @@ struct SetState {
   // been read), on the others into the pair that is not the snapshot -- the reference's copies y_0 <- y, l_0 <- l never
   // happen (PARSDMM.jl:174-177,200-203).
   T *y = nullptr, *l = nullptr, *dy = nullptr, *lh0 = nullptr, *y0 = nullptr, *s0 = nullptr, *l0 = nullptr;
+  T *y2 = nullptr, *l2 = nullptr;    // third pair of the one-sweep update (allocated on first need, see update_all_sets_in_one_sweep)
   int snap = -1;                     // -1: no snapshot yet; 0: (y, l) is also the snapshot; 1: (y0, l0) is
   T *lb = nullptr, *ub = nullptr, *ata = nullptr;
   std::vector<void*> halo_allocs;   // bases of the vectors allocated with a front halo
@@ -973,21 +974,29 @@ class Engine : public EngineBase {
     }
   }
 
-  // Iterations without Barzilai-Borwein sums, snapshots or feasibility estimates (flags == 0: every other iteration while rho
-  // and gamma are adapted, all of them once they are frozen): the threshold / scale searches of the two-pass sets as usual
-  // (on the set streams), then ONE sweep updates every set, forms the r_pri / r_dual / obj sums and -- when the caller has
-  // announced that rho cannot change before the next iteration (fuse_rhs_) -- writes the right-hand side of that iteration
-  // (kernels_multi.hip).  Returns false when this context / iteration does not qualify: the per-set path then runs.
+  // The y/l update of EVERY set in one sweep over the grid (kernels_multi.hip): the threshold / scale searches of the two-pass
+  // sets as usual (on the set streams), then one kernel updates all sets, forms the r_pri / r_dual / obj sums -- on
+  // Barzilai-Borwein iterations the six BB sums and the snapshot refresh, every tenth iteration the feasibility estimates of
+  // the element-wise sets -- and, when the caller has announced that rho cannot change before the next iteration (fuse_rhs_),
+  // writes the right-hand side of that iteration.  Returns false when this context / iteration does not qualify: the
+  // per-set path then runs.
+  // The sweep never updates in place (neighbouring tiles re-read the OLD y, l of a few points): it writes into the pair that
+  // holds the old snapshot (BB / first iteration: it is read first), into the free pair, or -- when both other pairs are
+  // taken, i.e. the snapshot must survive and sits in the other pair -- into a third pair, allocated on first need.
   bool update_all_sets_in_one_sweep(int flags, const double* rho, const double* gamma) {
-    if (!yl_multi_ || flags != 0 || mk_ || comm_) return false;
+    if (!yl_multi_ || mk_ || comm_) return false;
+    const bool first = (flags & SIPX_YL_FIRST) != 0, bb = (flags & SIPX_YL_BB) != 0 && !first, feas = (flags & SIPX_YL_FEAS) != 0;
     MultiArgs<T> ma;
     ma.nblk = 0;
     ma.rhs = nullptr;
+    ma.flags = flags;
     ma.zlo = 0; ma.zhi = G_.n[ndim_ - 1]; ma.zsum = 0;
     for (int i = 0; i < p_n_; ++i) {           // does the kernel have this block layout? (asked before any search is queued)
       const SetState<T>& s = sets_[i];
       if (!s.owned || s.custom || s.ext_kind || s.dist_ext) return false;
       if (ma.nblk + s.nblk_or1() > MULTI_MAXB) return false;
+      // (the sweep takes the feasibility estimate of an element-wise set on the identity only)
+      if (feas && i < pp_n_ && !s.two_pass && s.nblk > 0) return false;
       for (int qb = 0; qb < s.nblk_or1(); ++qb) {
         MultiBlk<T>& B = ma.b[ma.nblk++];
         B.dir = s.nblk == 0 ? -1 : s.dir[qb];
@@ -999,16 +1008,25 @@ class Engine : public EngineBase {
     if (!K<T>::yl_multi(stream_, G_, ma, true)) return false;
     if (set_streams_) SIPX_HIP(hipEventRecord(ev_fork_, stream_));       // x is final: the searches may start
     ma.nblk = 0;
-    std::vector<char> to_other(p_n_, 0);
+    std::vector<int> target(p_n_, 0);          // 0: the other pair (y0, l0); 2: the third pair
     for (int i = 0; i < p_n_; ++i) {
       SetState<T>& s = sets_[i];
-      SetArgs<T> a = set_args(s, (T)rho[i], (T)gamma[i], 0);
-      to_other[i] = s.snap == 0;                 // stay off the snapshot pair (see update_y_l)
+      SetArgs<T> a = set_args(s, (T)rho[i], (T)gamma[i], flags);
+      target[i] = (!first && !bb && s.snap == 1) ? 2 : 0;
+      if (target[i] == 2 && !s.y2) {
+        T* by = dalloc<T>(s.Mpad + halo_);
+        T* bl = dalloc<T>(s.Mpad + halo_);
+        s.halo_allocs.push_back(by);
+        s.halo_allocs.push_back(bl);
+        s.y2 = by + halo_;
+        s.l2 = bl + halo_;
+      }
+      hipStream_t q = s.st ? s.st : stream_;
+      double* ptmp = s.ptmp ? s.ptmp : part_tmp_;
+      T* mpart = s.mpart ? s.mpart : maxpart_;
+      T* cbuf = s.cbuf ? s.cbuf : scr_c_;
+      double* part = part_sets_ + (size_t)i * SLOTS * NB;
       if (s.two_pass) {
-        hipStream_t q = s.st ? s.st : stream_;
-        double* ptmp = s.ptmp ? s.ptmp : part_tmp_;
-        T* mpart = s.mpart ? s.mpart : maxpart_;
-        T* cbuf = s.cbuf ? s.cbuf : scr_c_;
         if (q != stream_) SIPX_HIP(hipStreamWaitEvent(q, ev_fork_, 0));
         const bool rescaled = a.prox == PX_L1 && s.last_rho > T(0) && s.last_rho != a.rho;
         if (rescaled) K<T>::ps_rescale(q, s.ps, (double)s.last_rho / (double)a.rho);
@@ -1020,19 +1038,27 @@ class Engine : public EngineBase {
         K<T>::proj_scalars_set(q, Gr_, a, 0, s.ps, ptmp, mpart, cbuf, s.Mtrue, ctl, nullptr);
         s.last_rho = a.rho;
         s.last_gamma = a.gamma;
+        if (feas && i < pp_n_) {               // ||P_i(s) - s|| with s = A_i x produced on the fly; its own warm-started scalars
+          K<T>::proj_scalars_set(q, Gr_, a, 1, s.psf, ptmp, mpart, cbuf, s.Mtrue, SampleCtl(), nullptr);
+          K<T>::proj_dist_set(q, Gr_, a, 1, s.psf, part + (size_t)SL_FE2 * NB);
+        }
       }
+      T* ty = target[i] == 2 ? s.y2 : s.y0;
+      T* tl = target[i] == 2 ? s.l2 : s.l0;
       for (int qb = 0; qb < s.nblk_or1(); ++qb) {
         MultiBlk<T>& B = ma.b[ma.nblk++];
         const long long off = (long long)qb * G_.N;
         B.y = s.y + off; B.l = s.l + off;
-        B.yo = (to_other[i] ? s.y0 : s.y) + off;
-        B.lo = (to_other[i] ? s.l0 : s.l) + off;
+        B.yo = ty + off; B.lo = tl + off;
+        B.lh0 = s.lh0 + off; B.s0 = s.s0 + off;
+        B.y0 = a.y0 + off; B.l0 = a.l0 + off;         // the snapshot pair (set_args)
         B.ps = s.ps;
         B.dir = s.nblk == 0 ? -1 : s.dir[qb];
         B.set = i;
         B.first = qb == 0;
         B.last = qb == s.nblk_or1() - 1;
         B.dist = s.is_dist ? 1 : 0;
+        B.feas_el = (i < pp_n_ && (s.prox == PX_BOUNDS || s.prox == PX_PROX_L1)) ? 1 : 0;
         B.ih = s.nblk == 0 ? T(0) : s.ih[qb];
         B.rho = a.rho; B.rho1 = a.rho1; B.gamma = a.gamma;
         B.prox = s.prox; B.plo = s.plo; B.phi = s.phi;
@@ -1050,14 +1076,17 @@ class Engine : public EngineBase {
     ma.x = x_; ma.m = m_; ma.xold = xold_;
     ma.rhs = fuse_rhs_ ? rhs_ : nullptr;
     ma.partials = part_sets_;
-    if (!K<T>::yl_multi(stream_, G_, ma)) {
-      // (the searches have run and left theta / scale in place; the per-set path would repeat them: refuse up front instead)
-      throw std::runtime_error("internal: the fused y/l sweep refused a block list it was prepared for");
-    }
+    if (!K<T>::yl_multi(stream_, G_, ma)) throw std::runtime_error("internal: the fused y/l sweep refused a block list it was prepared for");
     rhs_fused_ = ma.rhs != nullptr;
-    for (int i = 0; i < p_n_; ++i) {
+    for (int i = 0; i < p_n_; ++i) {           // (y, l) always names the current iterate; snap says where the snapshot sits
       SetState<T>& s = sets_[i];
-      if (to_other[i]) { std::swap(s.y, s.y0); std::swap(s.l, s.l0); s.snap = 1; }     // (y, l) always names the current iterate
+      if (target[i] == 2) {
+        std::swap(s.y, s.y2); std::swap(s.l, s.l2);                     // the snapshot stays in (y0, l0)
+      } else {
+        std::swap(s.y, s.y0); std::swap(s.l, s.l0);
+        if (first || bb) s.snap = 0;                                    // the pair just written IS the new snapshot
+        else if (s.snap == 0) s.snap = 1;                               // the snapshot stayed behind in what is now (y0, l0)
+      }
     }
     return true;
   }

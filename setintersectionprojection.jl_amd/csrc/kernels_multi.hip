@@ -103,7 +103,7 @@ __device__ __forceinline__ UniProx<T> make_uniprox(const MultiBlk<T>& B) {
 template <typename T, int VV, int KIND>
 __device__ __forceinline__ void multi_block_update(const MultiBlk<T>& B, const UniProx<T>& pc, const Vec<T, VV>& xc, const Vec<T, VV>& xn,
                                                    const bool (&valid)[VV], const Vec<T, VV>& yv, const Vec<T, VV>& lv, const Vec<T, VV>& mv,
-                                                   Vec<T, VV>& yn, Vec<T, VV>& ln, T (&rp)[VV]) {
+                                                   Vec<T, VV>& yn, Vec<T, VV>& ln, T (&rp)[VV], T (&sv)[VV]) {
   const bool relax = !(B.gamma == T(1));
   const T gam = B.gamma, omg = T(1) - B.gamma, nih = -B.ih;
 #pragma unroll
@@ -131,6 +131,7 @@ __device__ __forceinline__ void multi_block_update(const MultiBlk<T>& B, const U
     rp[k] = y1 - s;                                             // :69 / :76
     ln.v[k] = relax ? (lo + B.rho * (y1 - xh)) : (lo + B.rho * rp[k]);   // :70 / :77
     yn.v[k] = y1;
+    sv[k] = s;
   }
 }
 
@@ -143,11 +144,26 @@ __device__ __forceinline__ void static_for(F&& f) {
   }
 }
 
-template <typename T, int V, unsigned long long L>
+// FULL: the variant for iterations with Barzilai-Borwein sums (F_BB: the four snapshot arrays are read, l_hat_0 and s_0
+// rewritten, six more sums per set -- adapt_rho_gamma.jl:41-53, PARSDMM.jl:192-206), the first iteration (F_FIRST: snapshots
+// written, PARSDMM.jl:164-180) and / or feasibility estimates of the element-wise sets (F_FEAS, update_y_l.jl:90-99).  Its
+// eight extra sums per set live in per-thread LDS slots (as registers they would halve the occupancy of the plain variant).
+template <typename T, int V, unsigned long long L, bool FULL>
 __global__ __launch_bounds__(MULTI_NT, SIPX_MULTI_WAVES) void k_yl_multi(Grid G, MultiArgs<T> a, int lgLX, int tiles_x, int tiles_y, int zchunk,
                                                        long long items, long long jlo, long long jhi) {
   constexpr int NBLK = lay_count(L), NY = lay_count_kind(L, LK_Y), NZ = lay_count_kind(L, LK_Z);
+  constexpr int NSETS = lay_sets(L), NI = lay_count_kind(L, LK_I);
+  constexpr int NACC = FULL ? 6 * NSETS : 1;                    // the six BB sums of every set
+  // (summed over the four lanes of a quad first -- two DPP hops -- so that a slot per quad suffices: 15 KB instead of 60 KB,
+  // which decides whether two workgroups fit a compute unit)
+  __shared__ double lacc[NACC][MULTI_NT / 4];
   __shared__ T ybuf[2][NY > 0 ? NY : 1][2][V][MULTI_NT];       // [plane parity][y block][w | dy][element][thread]
+  const bool f_first = FULL && (a.flags & F_FIRST) != 0, f_bb = FULL && (a.flags & F_BB) != 0 && !f_first;
+  const bool f_feas = FULL && (a.flags & F_FEAS) != 0;
+  if constexpr (FULL) {
+#pragma unroll
+    for (int q = 0; q < NACC; ++q) lacc[q][threadIdx.x >> 2] = 0.0;   // a quad's slot is touched by its lane 0 only: no barrier needed
+  }
   const int tid = threadIdx.x, LX = 1 << lgLX, tx = tid & (LX - 1), ty = tid >> lgLX, TY = MULTI_NT >> lgLX;
   const long long n1 = G.n[0], n2 = G.n[1], n3 = G.n[2], st1 = G.st[1], st2 = G.st[2];
   const bool fuse_rhs = a.rhs != nullptr;
@@ -159,6 +175,9 @@ __global__ __launch_bounds__(MULTI_NT, SIPX_MULTI_WAVES) void k_yl_multi(Grid G,
 #pragma unroll
   for (int b = 0; b < NBLK; ++b) acc_rp[b] = acc_du[b] = 0;
   double acc_obj = 0, acc_evo = 0, acc_xx = 0;
+  double acc_fe[NI > 0 ? NI : 1], acc_ss[NI > 0 ? NI : 1];      // feasibility estimate of the element-wise identity sets (FULL)
+#pragma unroll
+  for (int q = 0; q < (NI > 0 ? NI : 1); ++q) acc_fe[q] = acc_ss[q] = 0;
 
   const long long tiles = (long long)tiles_x * tiles_y;
   for (long long item = blockIdx.x; item < items; item += gridDim.x) {
@@ -193,8 +212,8 @@ __global__ __launch_bounds__(MULTI_NT, SIPX_MULTI_WAVES) void k_yl_multi(Grid G,
 #pragma unroll
           for (int k = 0; k < V; ++k) valid[k] = true;        // plane k0 - 1 <= n3 - 2
           Vec<T, V> yn, ln;
-          T rp[V];
-          multi_block_update<T, V, LK_Z>(B, pc[b], xc, xn, valid, yv, lv, zerov<T, V>(), yn, ln, rp);
+          T rp[V], sv[V];
+          multi_block_update<T, V, LK_Z>(B, pc[b], xc, xn, valid, yv, lv, zerov<T, V>(), yn, ln, rp, sv);
 #pragma unroll
           for (int k = 0; k < V; ++k) { zw[zi][k] = B.rho * yn.v[k] + ln.v[k]; zd[zi][k] = yn.v[k] - yv.v[k]; }
         }
@@ -244,8 +263,62 @@ __global__ __launch_bounds__(MULTI_NT, SIPX_MULTI_WAVES) void k_yl_multi(Grid G,
           for (int k = 0; k < V; ++k) valid[k] = KIND == LK_X ? vx[k] : (KIND == LK_Y ? vy : (KIND == LK_Z ? vz : true));
           const Vec<T, V>& xn = KIND == LK_X ? xpx : (KIND == LK_Y ? xpy : xnext);
           Vec<T, V> yn, ln;
-          T rp[V];
-          multi_block_update<T, V, KIND>(B, pc[b], xc, xn, valid, yv[b], lv[b], mv, yn, ln, rp);
+          T rp[V], sv[V];
+          multi_block_update<T, V, KIND>(B, pc[b], xc, xn, valid, yv[b], lv[b], mv, yn, ln, rp, sv);
+          if constexpr (FULL) {
+            constexpr int si = lay_sets(L & ((1ull << (4 * b)) - 1ull));      // index of the block's set
+            Vec<T, V> lh, svv;
+#pragma unroll
+            for (int k = 0; k < V; ++k) {
+              lh.v[k] = lv[b].v[k] + B.rho * (yv[b].v[k] - sv[k]);           // l_hat = l_old + rho(-s + y_old)  PARSDMM.jl:173
+              svv.v[k] = sv[k];
+            }
+            if (f_bb) {                                                        // adapt_rho_gamma.jl:41-53
+              // (the snapshot arrays are touched once every rho_update_frequency iterations: streaming loads and stores)
+              const Vec<T, V> a0 = ldv_nt<T, V>(B.lh0 + pz + go), b0 = ldv_nt<T, V>(B.y0 + pz + go), c0 = ldv_nt<T, V>(B.s0 + pz + go),
+                              d0 = ldv_nt<T, V>(B.l0 + pz + go);
+              double q6[6] = {0, 0, 0, 0, 0, 0};
+#pragma unroll
+              for (int k = 0; k < V; ++k) {
+                const T dlh = lh.v[k] - a0.v[k], dH = sv[k] - c0.v[k], dl = ln.v[k] - d0.v[k], dG = -(yn.v[k] - b0.v[k]);
+                q6[0] += (double)dH * (double)dlh;
+                q6[1] += (double)dH * (double)dH;
+                q6[2] += (double)dlh * (double)dlh;
+                q6[3] += (double)dl * (double)dl;
+                q6[4] += (double)dG * (double)dG;
+                q6[5] += (double)dG * (double)dl;
+              }
+#pragma unroll
+              for (int q = 0; q < 6; ++q) {
+                double v = own ? q6[q] : 0.0;
+                v += dpp_hop<0xb1, 0xf>(v);        // quad_perm:[1,0,3,2]
+                v += dpp_hop<0x4e, 0xf>(v);        // quad_perm:[2,3,0,1]: every lane of the quad holds the quad's sum
+                if ((tid & 3) == 0) lacc[6 * si + q][tid >> 2] += v;
+              }
+            }
+            if (f_bb || f_first) {                                             // PARSDMM.jl:174-177, 200-203
+              stv_nt<T, V>(B.lh0 + pz + go, lh);     // y_0 <- y and l_0 <- l need no copy: the update below is written into
+              stv_nt<T, V>(B.s0 + pz + go, svv);     // the snapshot pair itself (engine)
+            }
+            if constexpr (KIND == LK_I) {
+              if (f_feas && B.feas_el && own) {                                // update_y_l.jl:90-99 (element-wise sets)
+                constexpr int ii = lay_index_among(L, b, LK_I);
+                double fe = 0, ss = 0;
+#pragma unroll
+                for (int k = 0; k < V; ++k) {
+                  const T t = soft_thr(sv[k], pc[b].theta);
+                  const T q = pc[b].fill ? pc[b].scale : t * pc[b].scale;
+                  const T c = q < pc[b].hi ? q : pc[b].hi;
+                  const T psv = pc[b].lo > c ? pc[b].lo : c;
+                  const T d = psv - sv[k];
+                  fe += (double)d * (double)d;
+                  ss += (double)sv[k] * (double)sv[k];
+                }
+                acc_fe[ii] += fe;
+                acc_ss[ii] += ss;
+              }
+            }
+          }
           stv_nt<T, V>(B.yo + pz + go, yn);
           stv_nt<T, V>(B.lo + pz + go, ln);
 #pragma unroll
@@ -301,8 +374,8 @@ __global__ __launch_bounds__(MULTI_NT, SIPX_MULTI_WAVES) void k_yl_multi(Grid G,
               x1.v[0] = (a.x + pz - 1)[go]; x2.v[0] = xc.v[0];
               y1v.v[0] = (B.y + pz - 1)[go]; l1v.v[0] = (B.l + pz - 1)[go];
               const bool v1[1] = {true};
-              T rp1[1];
-              multi_block_update<T, 1, LK_X>(B, pc[b], x1, x2, v1, y1v, l1v, zerov<T, 1>(), yn1, ln1, rp1);
+              T rp1[1], sv1[1];
+              multi_block_update<T, 1, LK_X>(B, pc[b], x1, x2, v1, y1v, l1v, zerov<T, 1>(), yn1, ln1, rp1, sv1);
               lw = B.rho * yn1.v[0] + ln1.v[0];
               ld = yn1.v[0] - y1v.v[0];
             }
@@ -327,8 +400,8 @@ __global__ __launch_bounds__(MULTI_NT, SIPX_MULTI_WAVES) void k_yl_multi(Grid G,
                 bool valid[V];
 #pragma unroll
                 for (int k = 0; k < V; ++k) valid[k] = true;
-                T rp1[V];
-                multi_block_update<T, V, LK_Y>(B, pc[b], x1, xc, valid, yh, lh, zerov<T, V>(), yn, ln, rp1);
+                T rp1[V], sv1[V];
+                multi_block_update<T, V, LK_Y>(B, pc[b], x1, xc, valid, yh, lh, zerov<T, V>(), yn, ln, rp1, sv1);
 #pragma unroll
                 for (int k = 0; k < V; ++k) { pw[k] = B.rho * yn.v[k] + ln.v[k]; pd[k] = yn.v[k] - yh.v[k]; }
               }
@@ -379,9 +452,9 @@ __global__ __launch_bounds__(MULTI_NT, SIPX_MULTI_WAVES) void k_yl_multi(Grid G,
   }
   // ---- sums: the blocks of a set fold into one r_pri sum; r_dual sits at the set's last block; one block-wide reduction
   // per slot.  Flat slot index into the engine's partial array: set * SET_SLOTS + {SL_RPRI, SL_DY | SL_ADJ, SL_OBJ ...}
-  constexpr int NSETS = lay_sets(L);
   constexpr bool HAS_D = lay_count_kind(L, LK_D) > 0;
-  constexpr int K = 2 * NSETS + (HAS_D ? 3 : 0);
+  constexpr int K0 = 2 * NSETS + (HAS_D ? 3 : 0);
+  constexpr int K = K0 + (FULL ? NACC + 2 * NI : 0);
   double acc[K];
   int slots[K];
   {
@@ -402,6 +475,20 @@ __global__ __launch_bounds__(MULTI_NT, SIPX_MULTI_WAVES) void k_yl_multi(Grid G,
           slots[2 * NSETS + 1] = a.b[b].set * SET_SLOTS + SL_EVO;
           slots[2 * NSETS + 2] = a.b[b].set * SET_SLOTS + SL_XX;
         }
+        if constexpr (FULL) {
+#pragma unroll
+          for (int q = 0; q < 6; ++q) {
+            acc[K0 + 6 * si + q] = (tid & 3) == 0 ? lacc[6 * si + q][tid >> 2] : 0.0;
+            slots[K0 + 6 * si + q] = a.b[b].set * SET_SLOTS + SL_HL + q;       // SL_HL, HH, LH, DL, GG, GL are consecutive
+          }
+        }
+      }
+      if constexpr (FULL && lay_kind(L, b) == LK_I) {
+        constexpr int ii = lay_index_among(L, b, LK_I);
+        acc[K0 + 6 * NSETS + 2 * ii] = acc_fe[ii];
+        acc[K0 + 6 * NSETS + 2 * ii + 1] = acc_ss[ii];
+        slots[K0 + 6 * NSETS + 2 * ii] = a.b[b].set * SET_SLOTS + SL_FE;
+        slots[K0 + 6 * NSETS + 2 * ii + 1] = a.b[b].set * SET_SLOTS + SL_SS;
       }
     });
   }
@@ -413,6 +500,7 @@ __global__ __launch_bounds__(MULTI_NT, SIPX_MULTI_WAVES) void k_yl_multi(Grid G,
     if (lane == 0) sm[k][w] = v;
   }
   __syncthreads();
+  static_assert(K <= MULTI_NT, "one thread per slot in the epilogue");
   if (threadIdx.x < K) {
     double s = 0;
 #pragma unroll
@@ -428,6 +516,7 @@ __global__ __launch_bounds__(MULTI_NT, SIPX_MULTI_WAVES) void k_yl_multi(Grid G,
 
 template <typename T, int V, unsigned long long L>
 static void launch_multi(hipStream_t s, const Grid& g, const MultiArgs<T>& a, double bytes) {
+  static_assert(SL_HH == SL_HL + 1 && SL_LH == SL_HL + 2 && SL_DL == SL_HL + 3 && SL_GG == SL_HL + 4 && SL_GL == SL_HL + 5, "BB slots");
   // tile geometry: LX lanes of V points along x (a power of two, at most a wave), TY = 256 / LX rows
   const long long nvx = g.n[0] / V;
   int lg = 0;
@@ -456,7 +545,10 @@ static void launch_multi(hipStream_t s, const Grid& g, const MultiArgs<T>& a, do
   b.zlo = zlo; b.zhi = zhi;
   if (!three) b.zsum = 0;
   ObsScope obs(KID_YL_MULTI, s, bytes);
-  hipLaunchKernelGGL((k_yl_multi<T, V, L>), dim3(grid), dim3(MULTI_NT), 0, s, g, b, lg, tiles_x, tiles_y, (int)zchunk, items, jlo, jhi);
+  if (a.flags)
+    hipLaunchKernelGGL((k_yl_multi<T, V, L, true>), dim3(grid), dim3(MULTI_NT), 0, s, g, b, lg, tiles_x, tiles_y, (int)zchunk, items, jlo, jhi);
+  else
+    hipLaunchKernelGGL((k_yl_multi<T, V, L, false>), dim3(grid), dim3(MULTI_NT), 0, s, g, b, lg, tiles_x, tiles_y, (int)zchunk, items, jlo, jhi);
   SIPX_HIP(hipGetLastError());
 }
 
@@ -489,7 +581,8 @@ bool K<T>::yl_multi(hipStream_t s, const Grid& g, const MultiArgs<T>& a, bool pr
   const bool three = g.n[2] > 1;
   const double pts = (double)(a.zhi - a.zlo) * (three ? (double)g.st[2] : (double)g.st[1]);
   double vecs = 1.0 + (a.rhs ? 1.0 : 0.0);
-  for (int b = 0; b < a.nblk; ++b) vecs += 4.0 + (a.b[b].dist ? 2.0 : 0.0);
+  const bool first = (a.flags & F_FIRST) != 0, bb = (a.flags & F_BB) != 0 && !first;
+  for (int b = 0; b < a.nblk; ++b) vecs += 4.0 + (a.b[b].dist ? 2.0 : 0.0) + (bb ? 6.0 : (first ? 2.0 : 0.0));
   const double bytes = vecs * pts * sizeof(T);
 #define SIPX_TRY_LAYOUT(LL)                                    \
   if (code == (LL)) {                                          \

@@ -252,12 +252,15 @@ constexpr int MULTI_MAXB = 8;     // operator blocks (a set has one per differen
 template <typename T>
 struct MultiBlk {
   const T *y, *l;                 // block q of the set's current iterate (base already offset by q * N)
-  T *yo, *lo;                     // where the update goes
+  T *yo, *lo;                     // where the update goes: never the arrays y, l themselves (neighbours re-read the old iterate)
+  T *lh0, *s0;                    // snapshots l_hat_0, s_0 (read and rewritten on Barzilai-Borwein iterations, written on the first)
+  const T *y0, *l0;               // the snapshot pair y_0, l_0
   const ProjScalars<T>* ps;
   int dir;                        // -1: identity; 0 / 1 / 2: forward difference along that grid dimension
   int set;                        // index of the set the block belongs to (its group of partial slots)
   int first, last;                // first / last block of its set
   int dist;                       // the distance term
+  int feas_el;                    // element-wise set (bounds, prox_l1): its feasibility estimate is taken in the sweep (F_FEAS)
   T ih, rho, rho1, gamma;
   int prox;
   T plo, phi;
@@ -269,6 +272,7 @@ struct MultiArgs {
   const T *x, *m, *xold;
   T* rhs;                         // nullptr: no fused right-hand side
   double* partials;               // the engine's per-set partial array (SET_SLOTS groups)
+  int flags;                      // F_FEAS | F_BB | F_FIRST (0: the lean variant)
   long long zlo, zhi;             // planes [zlo, zhi) of the last grid dimension (the rank's slab; the whole grid on one rank)
   long long zsum;                 // first plane whose sums / rhs belong to this rank: the planes in front of it are the
                                   // neighbour's last ones, recomputed (and stored) instead of being received

@@ -1797,7 +1797,7 @@ def test_bench_contract_line(dist_env):
     assert {"bound", "achieved", "peak", "unit", "frac", "frac_survey", "traffic"} <= set(d["roofline"])
     assert d["roofline"]["frac"] <= d["roofline"]["frac_survey"]                 # bytes that move <= SURVEY's count
     dom = d["dominant_kernel"]
-    assert dom["kernel"].startswith("k_") and dom["launches"] > 0 and dom["avg_launch_ms"] > 0 and 0 < dom["frac"] < 1.2
+    assert dom["kernel"].startswith("k_") and dom["launches"] > 0 and dom["avg_launch_ms"] > 0 and 0 <= dom["frac"] < 1.2      # (64^3: a one-workgroup step may lead)
     assert any(r["kernel"] == dom["kernel"] for r in d["kernels"]) and len(d["libsipx_sha16"]) == 16
     if dist_env:
         assert set(d["decompositions"]) == {"slab", "sets"} and d["decomposition"] == "slab" and d["faster_decomposition"] in ("slab", "sets")
