@@ -542,6 +542,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-512", action="store_true", help="skip the short 512^3 leg that follows the default 256^3 headline run")
     ap.add_argument("--no-c4", action="store_true", help="skip the short leg on BASELINE config 4 (512^3, eight sets) that follows the default run")
+    ap.add_argument("--no-kernel-table", action="store_true",
+                    help="skip the all-kernel statistics window that follows the timed steps (profiling runs: its event records would show up as gaps)")
     ap.add_argument("--no-c5", action="store_true", help="skip the leg on BASELINE config 5 (PARSDMM_multi_level, 512^3 Float64, 3 levels) that follows the default run")
     ap.add_argument("--dtype", default="f32", choices=["f32", "f64"],
                     help="f32 = the contract workload; f64 = the same sets in Float64 (BASELINE config 5 computes in Float64)")
@@ -662,9 +664,10 @@ def main():
         dt = time.perf_counter() - t0
         # the product of the CG iteration over the timed steps; then EVERY kernel over a window of its own (two event records
         # around each launch cost about 5 us: not something to have inside the timed region)
-        launches, kms = ctx.kernel_stats(2 if not ended else 0)
+        want_table = not ended and not args.no_kernel_table
+        launches, kms = ctx.kernel_stats(2 if want_table else 0)
         per_kernel = None
-        if not ended:
+        if want_table:
             for _ in range(stat_steps):
                 if ctx.parsdmm_steps(1):
                     break

@@ -2056,6 +2056,20 @@ class Engine : public EngineBase {
     }
     for (auto& s : sets_) ok = ok && (s.host_ata.empty() || explicit_bands_symmetric(s));
     cds_.sym = ok ? 1 : 0;
+    // the z-marching product (k_cds_march): the 7-band matrix of a 3-D grid in one of the two band orders it is compiled for
+    cds_.march = 0;
+    if (cds_.sym && cds_.d == 7 && ndim_ == 3 && !mk_) {
+      const long long s1 = G_.st[1], s2 = G_.st[2];
+      const long long o1[7] = {0, -1, 1, -s1, s1, -s2, s2}, o2[7] = {0, -s2, -s1, -1, 1, s1, s2};
+      bool m1 = true, m2 = true;
+      for (int b = 0; b < 7; ++b) { m1 = m1 && cds_.off[b] == o1[b]; m2 = m2 && cds_.off[b] == o2[b]; }
+      cds_.march = m1 ? 1 : (m2 ? 2 : 0);
+      const long long want[4] = {0, 1, s1, s2};
+      for (int q = 0; q < 4; ++q)
+        for (int b = 0; b < 7; ++b)
+          if (cds_.off[b] == want[q]) cds_.mb[q] = b;
+      for (int a = 0; a < 3; ++a) cds_.gn[a] = G_.n[a];
+    }
   }
 
   bool explicit_bands_symmetric(const SetState<T>& s) const {

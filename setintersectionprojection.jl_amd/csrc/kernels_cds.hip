@@ -9,6 +9,7 @@
 // reads every band once and writes y once: (d+2)*N*w algorithmic bytes.  Per row the products
 // are added band after band in Q_offsets order starting from 0, i.e. exactly the reference's
 // accumulation order, and -ffp-contract=off keeps mul and add separate like Julia does.
+#include <cstdlib>
 #include <stdexcept>
 #include <string>
 
@@ -149,6 +150,177 @@ __global__ __launch_bounds__(BLOCK) void k_cds(long long N, long long r0, long l
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Z-MARCHING product for the 7-band matrix of a 3-D grid (what north_star calls LDS-staged diagonal bands).  A workgroup owns
+// a tile of (V LX) x TY grid points of a plane and walks z: x of the planes k-1, k, k+1 and the +n1n2 band of plane k-1 stay
+// in registers, the +-1 neighbours come from the lanes next door (shuffles), the +-n1 neighbours and the +n1 band of the row
+// above go through LDS (one barrier per plane) -- every band value and every x crosses the fabric ONCE (plus the rows in
+// front of / behind a tile and one plane per chunk of planes), where k_cds relies on L2 / Infinity Cache for the shifted
+// re-reads (1.32 x the minimum at 512^3).  Products are added in the band order of Q_offsets with k_cds's masks, so the result
+// is bit-identical (tested, and compared bit for bit in tools/spmv_bench.hip: 512^3 670 -> 577 us, 256^3 80 -> 70 us).
+// role of a band: 0 diag, 1: -1, 2: +1, 3: -n1, 4: +n1, 5: -n1n2, 6: +n1n2
+constexpr int march_role(int ord, int b) {
+  constexpr int o1[7] = {0, 1, 2, 3, 4, 5, 6}, o2[7] = {0, 5, 3, 1, 2, 4, 6};
+  return ord == 1 ? o1[b] : o2[b];
+}
+constexpr int MARCH_NT = 512;
+template <typename T, int V, int ORD, int MODE>
+__global__ __launch_bounds__(MARCH_NT) void k_cds_march(long long n1, long long n2, long long n3, long long z0, long long z1, const T* __restrict__ R0,
+                                                        const T* __restrict__ R1, const T* __restrict__ R2, const T* __restrict__ R3,
+                                                        const T* __restrict__ x, T* __restrict__ y, const T* __restrict__ b,
+                                                        T* __restrict__ pout, T* __restrict__ xold, double* __restrict__ partials,
+                                                        const int* __restrict__ done, int lgLX, int tiles_x, int tiles_y, int zchunk,
+                                                        long long items) {
+  if (MODE == 1 && *done) return;
+  __shared__ T sx[2][V][MARCH_NT], sr[2][V][MARCH_NT];
+  const int tid = threadIdx.x, LX = 1 << lgLX, tx = tid & (LX - 1), ty = tid >> lgLX, TY = MARCH_NT >> lgLX;
+  const long long st1 = n1, st2 = n1 * n2, N = st2 * n3;
+  const long long tiles = (long long)tiles_x * tiles_y;
+  double acc0 = 0, acc1 = 0;
+  for (long long item = blockIdx.x; item < items; item += gridDim.x) {
+    const long long zc = item / tiles, tile = item - zc * tiles;
+    const int tile_y = (int)(tile / tiles_x), tile_x = (int)(tile - (long long)tile_y * tiles_x);
+    const long long i0 = ((long long)tile_x * LX + tx) * V, j = (long long)tile_y * TY + ty;
+    const bool active = i0 < n1 && j < n2;
+    const long long k0 = z0 + zc * zchunk, k1 = (k0 + zchunk < z1) ? k0 + zchunk : z1;
+    const unsigned go = active ? (unsigned)(i0 + st1 * j) : 0u;
+    __syncthreads();
+    Vec<T, V> xm = zerov<T, V>(), x0 = zerov<T, V>(), rzm = zerov<T, V>();
+    if (active) {
+      xm = ldv<T, V>(x + st2 * (k0 - 1) + go);                 // (x carries a halo of a plane on both sides)
+      x0 = ldv<T, V>(x + st2 * k0 + go);
+      if (k0 > 0) rzm = ldv<T, V>(R3 + st2 * (k0 - 1) + go);
+    }
+    for (long long kz = k0; kz < k1; ++kz) {
+      const int par = (int)(kz & 1);
+      const long long pz = st2 * kz;
+      Vec<T, V> xp = zerov<T, V>(), r0 = xp, r1 = xp, r2 = xp, r3 = xp, bv = xp;
+      if (active) {
+        xp = ldv<T, V>(x + pz + st2 + go);
+        r0 = ldv_nt<T, V>(R0 + pz + go);
+        r1 = ldv_nt<T, V>(R1 + pz + go);
+        r2 = ldv_nt<T, V>(R2 + pz + go);
+        r3 = ldv_nt<T, V>(R3 + pz + go);
+        if (MODE == 2) bv = ldv<T, V>(b + pz + go);
+      }
+#pragma unroll
+      for (int k = 0; k < V; ++k) { sx[par][k][tid] = x0.v[k]; sr[par][k][tid] = r2.v[k]; }
+      // the points next door along x: lanes, or (tile edge / wave edge) one element from memory
+      T xl = __shfl_up(x0.v[V - 1], 1, 64), xr = __shfl_down(x0.v[0], 1, 64), rl = __shfl_up(r1.v[V - 1], 1, 64);
+      const long long r = pz + go;               // row of element 0
+      if (active) {
+        if (tx == 0 || (tid & 63) == 0) { xl = x[r - 1]; rl = r > 0 ? R1[r - 1] : T(0); }
+        if (tx == LX - 1 || (tid & 63) == 63) xr = x[r + V];
+      }
+      __syncthreads();
+      if (active) {
+        Vec<T, V> xu = zerov<T, V>(), xd = xu, ru = xu;    // x of the row above (j - 1) / below (j + 1), +n1 band of the row above
+        if (ty > 0) {
+#pragma unroll
+          for (int k = 0; k < V; ++k) { xu.v[k] = sx[par][k][tid - LX]; ru.v[k] = sr[par][k][tid - LX]; }
+        } else {
+          xu = ldv<T, V>(x + r - st1);
+          if (r - st1 >= 0) ru = ldv<T, V>(R2 + r - st1);
+        }
+        if (ty < TY - 1 && j + 1 < n2) {
+#pragma unroll
+          for (int k = 0; k < V; ++k) xd.v[k] = sx[par][k][tid + LX];
+        } else {
+          xd = ldv<T, V>(x + r + st1);
+        }
+        Vec<T, V> o4;
+#pragma unroll
+        for (int k = 0; k < V; ++k) {
+          const long long rr = r + k;
+          // band value and vector entry of each role
+          const T rv[7] = {r0.v[k], k == 0 ? rl : r1.v[k - 1], r1.v[k], ru.v[k], r2.v[k], rzm.v[k], r3.v[k]};
+          const T xv[7] = {x0.v[k], k == 0 ? xl : x0.v[k - 1], k == V - 1 ? xr : x0.v[k + 1], xu.v[k], xd.v[k], xm.v[k], xp.v[k]};
+          const long long co[7] = {0, -1, 1, -st1, st1, -st2, st2};
+          T acc = T(0);
+#pragma unroll
+          for (int q = 0; q < 7; ++q) {
+            const int role = march_role(ORD, q);
+            const T t = acc + rv[role] * xv[role];
+            const long long c = rr + co[role];
+            acc = (c >= 0 && c < N) ? t : acc;
+          }
+          o4.v[k] = acc;
+        }
+        if (MODE == 0) {
+          stv_nt<T, V>(y + r, o4);
+        } else if (MODE == 1) {
+#pragma unroll
+          for (int k = 0; k < V; ++k) acc0 += (double)x0.v[k] * (double)o4.v[k];
+          stv_nt<T, V>(y + r, o4);
+        } else {
+          Vec<T, V> o;
+#pragma unroll
+          for (int k = 0; k < V; ++k) {
+            o.v[k] = bv.v[k] - o4.v[k];
+            acc0 += (double)o.v[k] * (double)o.v[k];
+            acc1 += (double)bv.v[k] * (double)bv.v[k];
+          }
+          stv<T, V>(y + r, o);
+          if (pout) stv<T, V>(pout + r, o);
+          if (xold) stv<T, V>(xold + r, x0);
+        }
+      }
+      xm = x0; x0 = xp; rzm = r3;
+    }
+  }
+  if (MODE != 0) {
+    // block-wide sums of 512 threads into the partial slots (block_reduce_store is written for 256)
+    __shared__ double sm[2][MARCH_NT / 64];
+    const double v0 = wave_sum(acc0), v1 = wave_sum(acc1);
+    __syncthreads();
+    if ((tid & 63) == 0) { sm[0][tid >> 6] = v0; sm[1][tid >> 6] = v1; }
+    __syncthreads();
+    if (tid < (MODE == 1 ? 1 : 2)) {
+      double s = 0;
+#pragma unroll
+      for (int i = 0; i < MARCH_NT / 64; ++i) s += sm[tid][i];
+      double* row = partials + (long long)tid * NB;
+      row[blockIdx.x] = s;
+      for (int jj = blockIdx.x + gridDim.x; jj < NB; jj += gridDim.x) row[jj] = 0.0;
+    }
+  }
+}
+
+// the march applies when the engine marked the matrix (CdsArgs::march) and the row range is whole planes; small grids, where
+// a launch would not fill the chip, keep k_cds
+template <typename T, int MODE>
+static bool try_march(hipStream_t s, long long N, long long r0, long long r1, const T* R, const CdsArgs& a, const T* x, T* y, const T* b,
+                      T* pout, T* xold, double* partials, const int* done) {
+  // SIPX_CDS_MARCH=0: never; =2: also on grids too small to fill the chip that way, in chunks of SIPX_CDS_MARCH_ZCHUNK planes (tests)
+  static const int sw = [] { const char* e = getenv("SIPX_CDS_MARCH"); return e ? atoi(e) : 1; }();
+  static const long long zc_env = [] { const char* e = getenv("SIPX_CDS_MARCH_ZCHUNK"); return e ? atoll(e) : 0ll; }();
+  if (sw == 0 || !a.march || !a.sym || a.d != 7) return false;
+  constexpr int V = sizeof(T) == 8 ? 2 : 4;
+  const long long n1 = a.gn[0], n2 = a.gn[1], n3 = a.gn[2], st2 = n1 * n2;
+  if (n1 % V != 0 || n1 * n2 * n3 != N || r0 % st2 != 0 || r1 % st2 != 0 || r1 <= r0) return false;
+  const long long nvx = n1 / V;
+  int lg = 0;
+  while ((1 << lg) < nvx && lg < 6) ++lg;
+  const int LX = 1 << lg, TY = MARCH_NT / LX;
+  const int tiles_x = (int)((nvx + LX - 1) / LX), tiles_y = (int)((n2 + TY - 1) / TY);
+  const long long tiles = (long long)tiles_x * tiles_y, planes = (r1 - r0) / st2;
+  long long zchunk = planes * tiles / 2048;       // aim at ~2048 work items, chunks of at least 16 planes (measured)
+  if (zchunk < 16) zchunk = 16;
+  if (sw == 2 && zc_env > 0) zchunk = zc_env;
+  if (zchunk > planes) zchunk = planes;
+  const long long nchunks = (planes + zchunk - 1) / zchunk, items = tiles * nchunks;
+  if (items < 384 && sw != 2) return false;
+  const int grid = (int)(items < NB ? items : NB);
+  const T *R0 = R + (long long)a.mb[0] * N, *R1 = R + (long long)a.mb[1] * N, *R2 = R + (long long)a.mb[2] * N, *R3 = R + (long long)a.mb[3] * N;
+#define SIPX_MARCH(ORD)                                                                                                              \
+  hipLaunchKernelGGL((k_cds_march<T, V, ORD, MODE>), dim3(grid), dim3(MARCH_NT), 0, s, n1, n2, n3, r0 / st2, r1 / st2, R0, R1, R2, R3, x, y, b, pout, \
+                     xold, partials, done, lg, tiles_x, tiles_y, (int)zchunk, items)
+  if (a.march == 1) SIPX_MARCH(1);
+  else SIPX_MARCH(2);
+#undef SIPX_MARCH
+  return true;
+}
+
 template <typename T, int MODE>
 static void launch_cds(hipStream_t s, long long N, long long r0, long long r1, const T* R, const CdsArgs& a, const T* x, T* y,
                        const T* b, T* pout, T* xold, double* partials, const int* done) {
@@ -160,6 +332,10 @@ static void launch_cds(hipStream_t s, long long N, long long r0, long long r1, c
   if (a.sym) { read_bands = 0; for (int b = 0; b < a.d; ++b) read_bands += a.off[b] >= 0 ? 1 : 0; }
   const double rw = (double)(r1 - r0) * sizeof(T), extra = MODE == 2 ? 4.0 : 2.0;
   ObsScope obs(MODE == 0 ? KID_CDS_SPMV : (MODE == 1 ? KID_CDS_DOT : KID_CDS_RESID), s, (a.d + extra) * rw, (read_bands + extra) * rw);
+  if (try_march<T, MODE>(s, N, r0, r1, R, a, x, y, b, pout, xold, partials, done)) {
+    SIPX_HIP(hipGetLastError());
+    return;
+  }
 #define SIPX_CDS(V, D) \
   hipLaunchKernelGGL((k_cds<T, V, D, MODE>), dim3(fit_grid((r1 - r0) / V, SIPX_CG_GRID)), dim3(BLOCK), 0, s, N, r0, r1, R, a, x, y, b, pout, xold, partials, done)
   // 16 bytes per thread and band: four floats or two doubles (four doubles leave the 7-band kernel 3 waves per SIMD)

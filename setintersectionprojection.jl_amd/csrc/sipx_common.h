@@ -142,6 +142,13 @@ struct CdsArgs {
   // band (+|o|) at row r-|o|, which the sweep loaded a moment ago.  sym = 1: read negative bands through `partner`.
   int sym = 0;
   int partner[MAXD] = {};
+  // z-marching product (k_cds_march): set by the engine when Q is the 7-band matrix of a 3-D grid, {0, +-1, +-n1, +-n1n2},
+  // read through the symmetric partners.  march = 0: not applicable; 1: bands in the order 0, -1, +1, -n1, +n1, -n1n2, +n1n2
+  // (identity set first, then D_x, D_y, D_z); 2: 0, -n1n2, -n1, -1, +1, +n1, +n1n2 (identity set, then TV).  The summation
+  // order of a row is the band order, so each order has its own instantiation.  mb[q]: band index of offset 0, +1, +n1, +n1n2.
+  int march = 0;
+  int mb[4] = {0, 0, 0, 0};
+  long long gn[3] = {0, 0, 0};
 };
 
 // Q = sum_i rho_i A_i'A_i as stencil coefficients (sipx_set_q_mode(SIPX_Q_STENCIL)): w0 = sum of rho over identity

@@ -261,3 +261,44 @@ def test_one_sweep_update_is_bit_identical(sipx, monkeypatch, n, h, kinds, TF, o
         assert np.allclose(g0.rho, g1.rho, rtol=1e-11) and np.allclose(g0.gamma, g1.gamma, rtol=1e-11)
     for f in ("obj", "evol_x", "r_pri", "r_dual", "set_feasibility"):
         assert np.allclose(getattr(g0, f), getattr(g1, f), rtol=1e-6 if TF == np.float32 else 1e-9, atol=0, equal_nan=True), f
+
+
+@pytest.mark.parametrize("TF", [np.float32, np.float64])
+@pytest.mark.parametrize("n,kinds", [((40, 24, 20), ["bounds", "l1:D_x", "l1:D_y", "l1:D_z"]),      # band order 0, -1, +1, -n1, +n1, -n1n2, +n1n2
+                                     ((36, 20, 9), ["bounds", "l1:TV"]),                              # band order 0, -n1n2, -n1, -1, +1, +n1, +n1n2
+                                     ((264, 10, 7), ["bounds", "l1:D_x", "l1:D_y", "l1:D_z"])])      # two tiles along x (Float32), ragged rows
+def test_z_marching_product_is_bit_identical(sipx, monkeypatch, TF, n, kinds):
+    """k_cds_march (x and the +n1n2 band of the previous plane in registers, rows through LDS: every band value crosses the
+    fabric once) against k_cds and against the oracle's CDS_MVp (src/CDS_MVp_MT_subfunc.jl:6-20: same summation order): y = Q x
+    bit for bit, before and after an incremental Q update; forced onto these small grids in chunks of 4 planes so that chunk
+    and tile edges are exercised.  A whole solve with it ends where the solve with k_cds ends."""
+    h = (25.0, 20.0, 10.0)
+    m = model(n, TF, seed=4)
+    go, oo, Po, Ao, propo, AtAo = _problem(O, n, h, TF, kinds, m)
+    p = len(Ao)
+    rho = list(np.linspace(0.5, 11.0, p))
+    x = np.random.default_rng(9).standard_normal(m.size).astype(TF)
+    Qo, offo = O.assemble_Q(AtAo, propo.AtA_offsets, np.array(rho, TF), TF)
+    want = O.Ax_CDS(x, Qo, offo)
+    out = {}
+    for sw in ("0", "2"):
+        monkeypatch.setenv("SIPX_CDS_MARCH", sw)
+        monkeypatch.setenv("SIPX_CDS_MARCH_ZCHUNK", "4")
+        gs, os_, Ps, As, props, AtAs = _problem(sipx, n, h, TF, kinds, m, dict(maxit=25))
+        os_.rho_ini = rho
+        ctx = sipx.host.build_context(m, AtAs, As, props, Ps, gs, os_)
+        y0 = ctx.apply_Q(x)
+        rho2 = [r * (1.5 if i % 2 else 0.75) for i, r in enumerate(rho)]
+        ctx.q_update(rho2, rho)
+        y1 = ctx.apply_Q(x)
+        ctx.kernel_stats(2)
+        log, _ = ctx.parsdmm(os_)
+        names = {k["name"] for k in ctx.kernel_stats_all(0)["kernels"]}
+        xs, _, _ = ctx.download()
+        ctx.close()
+        out[sw] = (y0, y1, xs, log)
+    assert np.array_equal(out["0"][0], want) and np.array_equal(out["2"][0], want)
+    assert np.array_equal(out["0"][1], out["2"][1])
+    (a0, a1, xa, la), (b0, b1, xb, lb) = out["0"], out["2"]
+    assert len(la.obj) == len(lb.obj) and np.array_equal(la.cg_it, lb.cg_it)
+    assert np.linalg.norm(xa.astype(np.float64) - xb) <= (2e-6 if TF == np.float32 else 1e-11) * np.linalg.norm(xa)
