@@ -131,6 +131,7 @@ struct SetState {
   int snap = -1;                     // -1: no snapshot yet; 0: (y, l) is also the snapshot; 1: (y0, l0) is
   T *lb = nullptr, *ub = nullptr, *ata = nullptr;
   std::vector<void*> halo_allocs;   // bases of the vectors allocated with a front halo
+  int searches_done = 0;             // slab-decomposed l1 searches of this set so far (sizes the refinement rounds)
   int ext_kind = 0;                  // projector acting on a materialised vector (ext_proj.h)
   // Sharded solve: a rank / nuclear-norm set on the slices orthogonal to the last grid dimension is projected by ALL ranks,
   // each factorising the slices of its z-slab (`ext` is then built for the slab on every rank, owner or not)
@@ -773,7 +774,11 @@ class Engine : public EngineBase {
     ObserverGuard og(observer());
     (void)it;
     rhs_fused_ = false;
-    if (update_all_sets_in_one_sweep(flags, rho, gamma)) {
+    MultiArgs<T> ma;
+    const bool sweep = sweep_applicable(flags, ma);
+    if (sweep && !slab_) {
+      sweep_searches(flags, rho, gamma);
+      sweep_launch(flags, rho, gamma, ma);
       reduce_set_sums(p_n_ * SLOTS);
       sums_flags_ = flags;
       sums_pending_ = true;
@@ -820,7 +825,7 @@ class Engine : public EngineBase {
           ctl[j].host_ovf = (int*)hovf_ + tp[j];
           ctl[j].runs = l1_sample_runs_;
           const bool rescaled = s.prox == PX_L1 && s.last_rho > T(0) && s.last_rho != args[j].rho;
-          ctl[j].enable = l1_sample_ && s.prox == PX_L1 && (rescaled || hlean_[tp[j]] != 0);
+          ctl[j].enable = l1_sample_ && s.prox == PX_L1 && (rescaled || (hlean_[tp[j]] & 0xff) != 0);
           any_sample |= ctl[j].enable != 0;
         }
         if (any_sample) {
@@ -833,19 +838,60 @@ class Engine : public EngineBase {
           }
         }
         for (size_t j = 0; j < tp.size(); ++j) ctl[j].enable = 0;
-        for (int stage = 0; stage < 4; ++stage) {
-          for (size_t j = 0; j < tp.size(); ++j) {
-            SetState<T>& s = sets_[tp[j]];
-            K<T>::proj_scalars_stage(stage, stream_, Gr_, args[j], 0, s.ps, s.ptmp, s.mpart, s.cbuf, s.Mtrue, ctl[j], &hooks_,
-                                     stage_ + j * RS, gseg[j], chunk);
+        // Refinement rounds (a gated probe pass + one all-reduce each): the bracket has to shrink until what it holds, over
+        // all ranks, fits the exchange segments -- a rank cannot keep what does not fit.  How many rounds are enqueued follows
+        // the previous search of each l1 set (pinned word written by k_l1_solve; the same on every rank): two more than it
+        // used, all of them while nothing is known (the first searches of a solve); a search that needs more ends in the
+        // error return of collect_set_sums, never in a wrong theta.
+        int rounds = 1;
+        for (size_t j = 0; j < tp.size(); ++j) {
+          SetState<T>& s = sets_[tp[j]];
+          if (s.prox != PX_L1) continue;
+          const int used = (hlean_[tp[j]] >> 8) & 0xff;
+          const int want = s.searches_done < 2 ? 6 : std::min(6, std::max(2, used + 2));
+          rounds = std::max(rounds, want);
+          s.searches_done += 1;
+        }
+        if (const char* e = std::getenv("SIPX_L1_ROUNDS_MIN")) rounds = std::min(6, std::max(rounds, std::atoi(e)));      // a problem whose brackets shrink slowly
+        if (const char* e = std::getenv("SIPX_L1_ROUNDS_MAX")) rounds = std::max(1, std::min(rounds, std::atoi(e)));      // tests: force an overflow
+        const int order[4] = {0, 1, 2, 3};
+        for (int si = 0; si < 4; ++si) {
+          const int stage = order[si];
+          const int reps = stage == 1 ? rounds : 1;
+          for (int rep = 0; rep < reps; ++rep) {
+            const int st = (stage == 1 && rep > 0) ? 4 : stage;
+            for (size_t j = 0; j < tp.size(); ++j) {
+              SetState<T>& s = sets_[tp[j]];
+              K<T>::proj_scalars_stage(st, stream_, Gr_, args[j], 0, s.ps, s.ptmp, s.mpart, s.cbuf, s.Mtrue, ctl[j], &hooks_,
+                                       stage_ + j * RS, gseg[j], chunk);
+            }
+            if (stage < 2 && (stage == 0 || nl1 > 0)) comm_->allreduce_sum(stage_, tp.size() * RS, SIPX_F64, stream_);
           }
-          if (stage < 2 && (stage == 0 || nl1 > 0)) comm_->allreduce_sum(stage_, tp.size() * RS, SIPX_F64, stream_);
           if (stage == 2 && nl1 > 0) comm_->allgather(gbuf_, (size_t)chunk, dtype_code(), stream_);
         }
       }
     }
-    if (set_streams_ && slab_) SIPX_HIP(hipEventRecord(ev_fork_, stream_));      // the searches are done: the updates may start
-    for (int i = 0; i < p_n_; ++i) {
+    if (slab_ && sweep) {
+      // slab-decomposed: the searches ran in lock step above; every set's update in one sweep over the rank's planes (plus
+      // the last plane of the rank below, recomputed), then the feasibility searches of the two-pass sets with their
+      // collectives, on the engine stream, in one order on every rank
+      for (int i = 0; i < p_n_; ++i)
+        if (sets_[i].two_pass) { sets_[i].last_rho = (T)rho[i]; sets_[i].last_gamma = (T)gamma[i]; }
+      sweep_launch(flags, rho, gamma, ma);
+      if (flags & SIPX_YL_FEAS)
+        for (int i = 0; i < pp_n_; ++i) {
+          SetState<T>& s = sets_[i];
+          if (!s.two_pass) continue;
+          SetArgs<T> a = set_args(s, (T)rho[i], (T)gamma[i], flags);
+          SampleCtl cf;
+          cf.host_ovf = (int*)hovf_ + i;
+          K<T>::proj_scalars_set(stream_, Gr_, a, 1, s.psf, s.ptmp ? s.ptmp : part_tmp_, s.mpart ? s.mpart : maxpart_, s.cbuf ? s.cbuf : scr_c_,
+                                 s.Mtrue, cf, hooks());
+          K<T>::proj_dist_set(stream_, Gr_, a, 1, s.psf, part_sets_ + ((size_t)i * SLOTS + SL_FE2) * NB);
+        }
+    }
+    if (set_streams_ && slab_ && !sweep) SIPX_HIP(hipEventRecord(ev_fork_, stream_));      // the searches are done: the updates may start
+    for (int i = 0; i < p_n_ && !(slab_ && sweep); ++i) {
       SetState<T>& s = sets_[i];
       if (!s.owned || s.dist_ext) continue;
       SetArgs<T> a = set_args(s, (T)rho[i], (T)gamma[i], flags);
@@ -896,7 +942,7 @@ class Engine : public EngineBase {
         ctl.host_want = (int*)hlean_ + i;
         ctl.host_ovf = (int*)hovf_ + i;
         ctl.runs = l1_sample_runs_;
-        ctl.enable = l1_sample_ && !slab_ && a.prox == PX_L1 && !s.custom && (rescaled || hlean_[i] != 0);
+        ctl.enable = l1_sample_ && !slab_ && a.prox == PX_L1 && !s.custom && (rescaled || (hlean_[i] & 0xff) != 0);
         K<T>::proj_scalars_set(q, gs, ap, 0, s.ps, ptmp, mpart, cbuf, s.Mtrue, ctl, hooks());
         s.last_rho = a.rho;
         s.last_gamma = a.gamma;
@@ -953,7 +999,7 @@ class Engine : public EngineBase {
       }
       if ((flags & SIPX_YL_FEAS) && i < pp_n_) dist_feasibility(s, x_, part + (size_t)SL_FE2 * NB);
     }
-    for (size_t k = 0; k < pool_.size(); ++k) {                         // join: the reductions below see every set
+    for (size_t k = 0; k < pool_.size() && !(slab_ && sweep); ++k) {   // join: the reductions below see every set
       if (pool_[k] == stream_) continue;
       SetState<T>* last = nullptr;                                      // (one event per set stream: after its last set)
       for (int i = 0; i < p_n_; ++i)
@@ -974,24 +1020,22 @@ class Engine : public EngineBase {
     }
   }
 
-  // The y/l update of EVERY set in one sweep over the grid (kernels_multi.hip): the threshold / scale searches of the two-pass
-  // sets as usual (on the set streams), then one kernel updates all sets, forms the r_pri / r_dual / obj sums -- on
-  // Barzilai-Borwein iterations the six BB sums and the snapshot refresh, every tenth iteration the feasibility estimates of
-  // the element-wise sets -- and, when the caller has announced that rho cannot change before the next iteration (fuse_rhs_),
-  // writes the right-hand side of that iteration.  Returns false when this context / iteration does not qualify: the
-  // per-set path then runs.
-  // The sweep never updates in place (neighbouring tiles re-read the OLD y, l of a few points): it writes into the pair that
-  // holds the old snapshot (BB / first iteration: it is read first), into the free pair, or -- when both other pairs are
-  // taken, i.e. the snapshot must survive and sits in the other pair -- into a third pair, allocated on first need.
-  bool update_all_sets_in_one_sweep(int flags, const double* rho, const double* gamma) {
-    if (!yl_multi_ || mk_ || comm_) return false;
-    const bool first = (flags & SIPX_YL_FIRST) != 0, bb = (flags & SIPX_YL_BB) != 0 && !first, feas = (flags & SIPX_YL_FEAS) != 0;
-    MultiArgs<T> ma;
+  // does the sweep take this context / iteration?  (asked before any search is queued; fills the layout part of `ma`)
+  bool sweep_applicable(int flags, MultiArgs<T>& ma) {
+    if (!yl_multi_ || mk_ || (comm_ && !slab_)) return false;
+    const bool feas = (flags & SIPX_YL_FEAS) != 0;
     ma.nblk = 0;
     ma.rhs = nullptr;
     ma.flags = flags;
-    ma.zlo = 0; ma.zhi = G_.n[ndim_ - 1]; ma.zsum = 0;
-    for (int i = 0; i < p_n_; ++i) {           // does the kernel have this block layout? (asked before any search is queued)
+    const long long nlast = G_.n[ndim_ - 1];
+    ma.zlo = 0; ma.zhi = nlast; ma.zsum = 0;
+    if (slab_) {                                // the rank's planes, plus the last plane of the rank below (recomputed, see Gyl_)
+      ma.zsum = r0_ / plane_;
+      ma.zlo = ma.zsum - ((prev_ >= 0 && r1_ > r0_) ? 1 : 0);
+      ma.zhi = r1_ / plane_;
+      if (r1_ <= r0_) ma.zlo = ma.zhi = ma.zsum = 0;
+    }
+    for (int i = 0; i < p_n_; ++i) {
       const SetState<T>& s = sets_[i];
       if (!s.owned || s.custom || s.ext_kind || s.dist_ext) return false;
       if (ma.nblk + s.nblk_or1() > MULTI_MAXB) return false;
@@ -1005,8 +1049,59 @@ class Engine : public EngineBase {
         B.prox = s.prox;
       }
     }
-    if (!K<T>::yl_multi(stream_, G_, ma, true)) return false;
+    return K<T>::yl_multi(stream_, G_, ma, true);
+  }
+
+  // one rank (or no communicator): the searches of the two-pass sets on the set streams, joined before the sweep
+  void sweep_searches(int flags, const double* rho, const double* gamma) {
+    const bool feas = (flags & SIPX_YL_FEAS) != 0;
     if (set_streams_) SIPX_HIP(hipEventRecord(ev_fork_, stream_));       // x is final: the searches may start
+    for (int i = 0; i < p_n_; ++i) {
+      SetState<T>& s = sets_[i];
+      if (!s.two_pass) continue;
+      SetArgs<T> a = set_args(s, (T)rho[i], (T)gamma[i], flags);
+      hipStream_t q = s.st ? s.st : stream_;
+      double* ptmp = s.ptmp ? s.ptmp : part_tmp_;
+      T* mpart = s.mpart ? s.mpart : maxpart_;
+      T* cbuf = s.cbuf ? s.cbuf : scr_c_;
+      double* part = part_sets_ + (size_t)i * SLOTS * NB;
+      if (q != stream_) SIPX_HIP(hipStreamWaitEvent(q, ev_fork_, 0));
+      const bool rescaled = a.prox == PX_L1 && s.last_rho > T(0) && s.last_rho != a.rho;
+      if (rescaled) K<T>::ps_rescale(q, s.ps, (double)s.last_rho / (double)a.rho);
+      SampleCtl ctl;
+      ctl.host_want = (int*)hlean_ + i;
+      ctl.host_ovf = (int*)hovf_ + i;
+      ctl.runs = l1_sample_runs_;
+      ctl.enable = l1_sample_ && a.prox == PX_L1 && (rescaled || (hlean_[i] & 0xff) != 0);
+      K<T>::proj_scalars_set(q, Gr_, a, 0, s.ps, ptmp, mpart, cbuf, s.Mtrue, ctl, nullptr);
+      s.last_rho = a.rho;
+      s.last_gamma = a.gamma;
+      if (feas && i < pp_n_) {                 // ||P_i(s) - s|| with s = A_i x produced on the fly; its own warm-started scalars
+        K<T>::proj_scalars_set(q, Gr_, a, 1, s.psf, ptmp, mpart, cbuf, s.Mtrue, SampleCtl(), nullptr);
+        K<T>::proj_dist_set(q, Gr_, a, 1, s.psf, part + (size_t)SL_FE2 * NB);
+      }
+    }
+    for (size_t k = 0; k < pool_.size(); ++k) {                         // join: theta / scale of every set are known
+      if (pool_[k] == stream_) continue;
+      SetState<T>* last = nullptr;
+      for (int i = 0; i < p_n_; ++i)
+        if (sets_[i].two_pass && sets_[i].st == pool_[k]) last = &sets_[i];
+      if (!last) continue;
+      SIPX_HIP(hipEventRecord(last->ev, last->st));
+      SIPX_HIP(hipStreamWaitEvent(stream_, last->ev, 0));
+    }
+  }
+
+  // The y/l update of EVERY set in one sweep over the grid (kernels_multi.hip), on the engine stream, once the threshold /
+  // scale of every two-pass set is known: one kernel updates all sets, forms the r_pri / r_dual / obj sums -- on
+  // Barzilai-Borwein iterations the six BB sums and the snapshot refresh, every tenth iteration the feasibility estimates of
+  // the element-wise sets -- and, when the caller has announced that rho cannot change before the next iteration (fuse_rhs_),
+  // writes the right-hand side of that iteration.
+  // The sweep never updates in place (neighbouring tiles re-read the OLD y, l of a few points): it writes into the pair that
+  // holds the old snapshot (BB / first iteration: it is read first), into the free pair, or -- when both other pairs are
+  // taken, i.e. the snapshot must survive and sits in the other pair -- into a third pair, allocated on first need.
+  void sweep_launch(int flags, const double* rho, const double* gamma, MultiArgs<T>& ma) {
+    const bool first = (flags & SIPX_YL_FIRST) != 0, bb = (flags & SIPX_YL_BB) != 0 && !first;
     ma.nblk = 0;
     std::vector<int> target(p_n_, 0);          // 0: the other pair (y0, l0); 2: the third pair
     for (int i = 0; i < p_n_; ++i) {
@@ -1020,28 +1115,6 @@ class Engine : public EngineBase {
         s.halo_allocs.push_back(bl);
         s.y2 = by + halo_;
         s.l2 = bl + halo_;
-      }
-      hipStream_t q = s.st ? s.st : stream_;
-      double* ptmp = s.ptmp ? s.ptmp : part_tmp_;
-      T* mpart = s.mpart ? s.mpart : maxpart_;
-      T* cbuf = s.cbuf ? s.cbuf : scr_c_;
-      double* part = part_sets_ + (size_t)i * SLOTS * NB;
-      if (s.two_pass) {
-        if (q != stream_) SIPX_HIP(hipStreamWaitEvent(q, ev_fork_, 0));
-        const bool rescaled = a.prox == PX_L1 && s.last_rho > T(0) && s.last_rho != a.rho;
-        if (rescaled) K<T>::ps_rescale(q, s.ps, (double)s.last_rho / (double)a.rho);
-        SampleCtl ctl;
-        ctl.host_want = (int*)hlean_ + i;
-        ctl.host_ovf = (int*)hovf_ + i;
-        ctl.runs = l1_sample_runs_;
-        ctl.enable = l1_sample_ && a.prox == PX_L1 && (rescaled || hlean_[i] != 0);
-        K<T>::proj_scalars_set(q, Gr_, a, 0, s.ps, ptmp, mpart, cbuf, s.Mtrue, ctl, nullptr);
-        s.last_rho = a.rho;
-        s.last_gamma = a.gamma;
-        if (feas && i < pp_n_) {               // ||P_i(s) - s|| with s = A_i x produced on the fly; its own warm-started scalars
-          K<T>::proj_scalars_set(q, Gr_, a, 1, s.psf, ptmp, mpart, cbuf, s.Mtrue, SampleCtl(), nullptr);
-          K<T>::proj_dist_set(q, Gr_, a, 1, s.psf, part + (size_t)SL_FE2 * NB);
-        }
       }
       T* ty = target[i] == 2 ? s.y2 : s.y0;
       T* tl = target[i] == 2 ? s.l2 : s.l0;
@@ -1064,15 +1137,6 @@ class Engine : public EngineBase {
         B.prox = s.prox; B.plo = s.plo; B.phi = s.phi;
       }
     }
-    for (size_t k = 0; k < pool_.size(); ++k) {                         // join: theta / scale of every set are known
-      if (pool_[k] == stream_) continue;
-      SetState<T>* last = nullptr;
-      for (int i = 0; i < p_n_; ++i)
-        if (sets_[i].two_pass && sets_[i].st == pool_[k]) last = &sets_[i];
-      if (!last) continue;
-      SIPX_HIP(hipEventRecord(last->ev, last->st));
-      SIPX_HIP(hipStreamWaitEvent(stream_, last->ev, 0));
-    }
     ma.x = x_; ma.m = m_; ma.xold = xold_;
     ma.rhs = fuse_rhs_ ? rhs_ : nullptr;
     ma.partials = part_sets_;
@@ -1088,7 +1152,6 @@ class Engine : public EngineBase {
         else if (s.snap == 0) s.snap = 1;                               // the snapshot stayed behind in what is now (y0, l0)
       }
     }
-    return true;
   }
 
   // second half of update_y_l: waits for the reduced sums and turns them into the per-set scalars.  The whole-solve loop
@@ -1107,7 +1170,8 @@ class Engine : public EngineBase {
         for (int k = 0; k <= p_n_; ++k) hovf_[k] = 0;
         throw std::runtime_error("l1 threshold search of set " + std::to_string(i) + ": the magnitudes inside the final bracket, gathered over all "
                                  "ranks, exceed the exchange segment of " + std::to_string(hooks_.gcap) + " values per rank "
-                                 "(slab decomposition); the iterate of this step is not valid -- use the set decomposition for this problem");
+                                 "(slab decomposition) after the refinement rounds that were enqueued; the iterate of this step is not valid -- set "
+                                 "SIPX_L1_ROUNDS_MIN (up to 6) or use the set decomposition for this problem");
       }
     }
     const bool all = comm_ != nullptr;       // sharded: the all-reduced sums of every set are here, on every rank

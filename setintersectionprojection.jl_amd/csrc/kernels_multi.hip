@@ -150,7 +150,7 @@ __device__ __forceinline__ void static_for(F&& f) {
 // eight extra sums per set live in per-thread LDS slots (as registers they would halve the occupancy of the plain variant).
 template <typename T, int V, unsigned long long L, bool FULL>
 __global__ __launch_bounds__(MULTI_NT, SIPX_MULTI_WAVES) void k_yl_multi(Grid G, MultiArgs<T> a, int lgLX, int tiles_x, int tiles_y, int zchunk,
-                                                       long long items, long long jlo, long long jhi) {
+                                                       long long items, long long jlo, long long jhi, long long jsum) {
   constexpr int NBLK = lay_count(L), NY = lay_count_kind(L, LK_Y), NZ = lay_count_kind(L, LK_Z);
   constexpr int NSETS = lay_sets(L), NI = lay_count_kind(L, LK_I);
   constexpr int NACC = FULL ? 6 * NSETS : 1;                    // the six BB sums of every set
@@ -226,7 +226,8 @@ __global__ __launch_bounds__(MULTI_NT, SIPX_MULTI_WAVES) void k_yl_multi(Grid G,
       const long long pz = st2 * kz;                           // uniform: the plane's first point
       const Vec<T, V> xc = xnext;
       const bool vz = kz < n3 - 1, mzm = kz > 0;
-      const bool own = kz >= a.zsum;            // planes in front of zsum are recomputed for the rank below: stored, not summed
+      // planes (2-D: rows) in front of zsum (jsum) are the last ones of the rank below, recomputed: stored, not summed
+      const bool own = kz >= a.zsum && j >= jsum;
       Vec<T, V> xpx = zerov<T, V>(), xpy = zerov<T, V>();
       // ---- all loads of the plane first: the stores of one block must not hold back the loads of the next --------------
       Vec<T, V> yv[NBLK], lv[NBLK], mv = zerov<T, V>(), xo = zerov<T, V>();
@@ -524,9 +525,10 @@ static void launch_multi(hipStream_t s, const Grid& g, const MultiArgs<T>& a, do
   const int LX = 1 << lg, TY = MULTI_NT / LX;
   const bool three = g.n[2] > 1;
   // rows of the plane this launch covers: all of them, or (2-D slab decomposition) the rank's rows
-  long long jlo = 0, jhi = g.n[1], zlo = a.zlo, zhi = a.zhi;
-  if (!three) { jlo = a.zlo; jhi = a.zhi; zlo = 0; zhi = 1; }
-  if (jhi <= jlo || zhi <= zlo) return;
+  long long jlo = 0, jhi = g.n[1], jsum = 0, zlo = a.zlo, zhi = a.zhi;
+  if (!three) { jlo = a.zlo; jhi = a.zhi; jsum = a.zsum; zlo = 0; zhi = 1; }
+  const bool empty = jhi <= jlo || zhi <= zlo;        // a rank without planes still clears its partial slots (one idle workgroup)
+  if (empty) { jhi = jlo + 1; zhi = zlo + 1; }
   const int tiles_x = (int)((nvx + LX - 1) / LX), tiles_y = (int)((jhi - jlo + TY - 1) / TY);
   const long long tiles = (long long)tiles_x * tiles_y;
   // chunks of planes: enough work items to fill the chip several times over, chunks long enough that the plane recomputed in
@@ -539,16 +541,17 @@ static void launch_multi(hipStream_t s, const Grid& g, const MultiArgs<T>& a, do
   if (zchunk < 8) zchunk = planes < 8 ? planes : 8;
   if (zc_env > 0) zchunk = zc_env < planes ? zc_env : planes;
   const long long nchunks = (planes + zchunk - 1) / zchunk;
-  const long long items = tiles * nchunks;
-  const int grid = (int)(items < NB_7 ? items : NB_7);
+  const long long items = empty ? 0 : tiles * nchunks;
+  const int grid = (int)(items < 1 ? 1 : (items < NB_7 ? items : NB_7));
   MultiArgs<T> b = a;
   b.zlo = zlo; b.zhi = zhi;
   if (!three) b.zsum = 0;
+  if (empty) { b.zlo = b.zhi = 0; }
   ObsScope obs(KID_YL_MULTI, s, bytes);
   if (a.flags)
-    hipLaunchKernelGGL((k_yl_multi<T, V, L, true>), dim3(grid), dim3(MULTI_NT), 0, s, g, b, lg, tiles_x, tiles_y, (int)zchunk, items, jlo, jhi);
+    hipLaunchKernelGGL((k_yl_multi<T, V, L, true>), dim3(grid), dim3(MULTI_NT), 0, s, g, b, lg, tiles_x, tiles_y, (int)zchunk, items, jlo, jhi, jsum);
   else
-    hipLaunchKernelGGL((k_yl_multi<T, V, L, false>), dim3(grid), dim3(MULTI_NT), 0, s, g, b, lg, tiles_x, tiles_y, (int)zchunk, items, jlo, jhi);
+    hipLaunchKernelGGL((k_yl_multi<T, V, L, false>), dim3(grid), dim3(MULTI_NT), 0, s, g, b, lg, tiles_x, tiles_y, (int)zchunk, items, jlo, jhi, jsum);
   SIPX_HIP(hipGetLastError());
 }
 

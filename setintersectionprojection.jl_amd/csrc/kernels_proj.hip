@@ -44,7 +44,8 @@ namespace sipx {
 
 constexpr long long SOLVE_COOP_MIN_DEFAULT = 1ll << 17;
 constexpr double L1_CAP = 131072.0;     // bracket population above which one more probe pass is run (floor; scales with the length)
-constexpr int L1_REFINES = 1;           // gated refinement passes enqueued per search
+constexpr int L1_REFINES = 1;           // gated refinement passes enqueued per search (one rank: the final gather never drops)
+constexpr int L1_REFINES_SLAB = 6;      // slab-decomposed: rounds the caller may enqueue until the bracket fits the exchange segments
 #ifndef SIPX_SPEC_CAP
 #define SIPX_SPEC_CAP 1024
 #endif
@@ -282,6 +283,7 @@ __global__ void k_ps_init(ProjScalars<T>* ps, long long* cidx) {
   ps->samp_ticket = 0;
   ps->pass_ticket = 0;
   ps->gather_overflow = 0;
+  ps->rounds_used = 0;
   ps->ovf = 0;
   for (int r = 0; r < 2 * SIPX_MAX_WORLD; ++r) ps->mm[r] = 0;
   ps->rescaled = 0;
@@ -431,6 +433,7 @@ __device__ void decide_body(ProjScalars<T>* ps, int prox, T pmin, T pmax, long l
     ps->scale = T(1);
     ps->fill = 0;
     ps->refine = 0;
+    ps->rounds_used = 0;
     ps->spec_ok = 0;
     if (prox == PX_L2) {
       const T nl2 = (T)sqrt(red[1]);                     // project_l2!.jl:8-13
@@ -482,6 +485,7 @@ __device__ void decide_body(ProjScalars<T>* ps, int prox, T pmin, T pmax, long l
       }
       ps->n_compact = 0;                                     // discard what the speculation gathered
       ps->refine = 1;
+      ps->rounds_used = 1;
       ps->vmax = (T)ps->asum;                                // a valid upper bound of every magnitude
       if (f4 >= 0) {                                         // theta* >= spec_hi: geometric probes above it
         ps->lo = t4;
@@ -551,9 +555,14 @@ __device__ void decide_body(ProjScalars<T>* ps, int prox, T pmin, T pmax, long l
   // population of the tightened bracket (lo, hi]: the count between the two probes, scaled by the share of the interval
   // that is left (factor 2 for a density that is not flat).  A wrong guess only costs time: the gather never drops.
   double pop = Cl - Ch;
-  if (th > tl) pop *= fmin(1.0, 2.0 * (hi - lo) / (th - tl));
-  if (pop > cap && hi > lo && (STAGE == 0 || ps->refine < L1_REFINES)) {
+  // Slab-decomposed (cap_max > 0): what the final bracket gathers over ALL ranks has to fit the exchange segments, and a
+  // rank cannot keep what does not fit -- so the count between the two bracketing probes is taken as it is (an upper bound of
+  // what (lo, hi] holds), and refinement goes on, round after round (as many as the caller enqueued), until it fits.
+  if (th > tl && !(cap_max > 0)) pop *= fmin(1.0, 2.0 * (hi - lo) / (th - tl));
+  const int max_refines = cap_max > 0 ? L1_REFINES_SLAB : L1_REFINES;
+  if (pop > cap && hi > lo && (STAGE == 0 || ps->refine < max_refines)) {
     ps->refine = (STAGE == 0) ? 1 : ps->refine + 1;
+    ps->rounds_used = ps->refine;
     for (int k = 0; k < L1_K; ++k) ps->t[k] = (double)(T)(lo + (hi - lo) * (double)k / (double)(L1_K - 1));
   } else {
     ps->refine = 0;
@@ -1122,7 +1131,7 @@ __global__ __launch_bounds__(SIPX_SOLVE_NT) void k_l1_solve(ProjScalars<T>* ps, 
     ps->dbg_sampled = ps->sampled;
     ps->sampled = 0;
     ps->rescaled = 0;
-    if (host_want) __hip_atomic_store(host_want, ps->want_sample, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    if (host_want) __hip_atomic_store(host_want, ps->want_sample | (ps->rounds_used << 8), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
   }
 }
 
@@ -1419,6 +1428,16 @@ static void chain_stage(int stage, hipStream_t s, const Grid& g, const SetArgs<T
       if (hk) hipLaunchKernelGGL((k_slot_sums<T, 1, false>), dim3(PREP_SLOTS), dim3(BLOCK), 0, s, partials, maxpart, ps, rank, world, reg, da1);
       else hipLaunchKernelGGL((k_slot_sums<T, 1, true>), dim3(PREP_SLOTS), dim3(BLOCK), 0, s, partials, maxpart, ps, rank, world, reg, da1);
     }
+  } else if (stage == 4) {      // slab-decomposed: one more gated refinement round (decision on the all-reduced sums, probe pass, sums)
+    if (a.prox == PX_L1 && hk) {
+      {
+        ObsScope obs_(KID_DECIDE, s, 0.0);
+        hipLaunchKernelGGL((k_decide<T, 1>), dim3(1), dim3(64), 0, s, ps, a.prox, a.plo, a.phi, true_len, 0, capdiv, world, cap_max, reg);
+      }
+      SIPX_PASS(M_PROBE);
+      ObsScope obs_(KID_SLOT_SUMS, s, 0.0);
+      hipLaunchKernelGGL((k_slot_sums<T, 1, false>), dim3(PREP_SLOTS), dim3(BLOCK), 0, s, partials, maxpart, ps, rank, world, reg, da1);
+    }
   } else if (stage == 2) {
     if (a.prox == PX_L1) {
       if (hk) {
@@ -1486,6 +1505,10 @@ static void launch_chain(hipStream_t s, const Grid& g, const SetArgs<T>& a, int 
   if (hk) hk->allreduce_sum(hk->user, reg, (size_t)(PREP_SLOTS + 1 + 2 * world), s);
   chain_stage<T, SRC>(1, s, g, a, v_is_s, varr, len, ps, partials, maxpart, compact, true_len, ctl, hk, compact_len, reg, gb, chunk);
   if (hk && a.prox == PX_L1) hk->allreduce_sum(hk->user, reg, (size_t)PREP_SLOTS, s);
+  for (int r = 1; hk && a.prox == PX_L1 && r < L1_REFINES_SLAB; ++r) {      // (searches with collectives of their own are rare: all rounds)
+    chain_stage<T, SRC>(4, s, g, a, v_is_s, varr, len, ps, partials, maxpart, compact, true_len, ctl, hk, compact_len, reg, gb, chunk);
+    hk->allreduce_sum(hk->user, reg, (size_t)PREP_SLOTS, s);
+  }
   chain_stage<T, SRC>(2, s, g, a, v_is_s, varr, len, ps, partials, maxpart, compact, true_len, ctl, hk, compact_len, reg, gb, chunk);
   if (hk && a.prox == PX_L1) hk->allgather(hk->user, gb, (size_t)chunk, sizeof(T) == 8 ? 1 : 0, s);
   chain_stage<T, SRC>(3, s, g, a, v_is_s, varr, len, ps, partials, maxpart, compact, true_len, ctl, hk, compact_len, reg, gb, chunk);

@@ -175,7 +175,8 @@ struct ProjScalars {
   // l1 search state
   double t[L1_K];     // probe thresholds (ascending; +inf = unused)
   double lo, hi;      // bracket: lo <= theta* < hi;  elements in (lo, hi] are compacted
-  int refine;         // 1: bracket still holds too many elements -> one more probe pass
+  int refine;         // > 0: bracket still holds too many elements -> one more probe pass (the number of the coming round)
+  int rounds_used;    // refinement rounds this search went through (the host sizes the next search's rounds by it, slab-decomposed)
   double theta_prev;  // last non-zero theta (centre of the next probe)
   unsigned long long n_compact;
   // speculative compaction fused into the first pass: magnitudes in (spec_lo, spec_hi] are gathered

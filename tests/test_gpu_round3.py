@@ -115,13 +115,13 @@ def _slab_worker(rank, world, port, out, kinds, n, env):
 
 @pytest.mark.timeout(400)
 def test_slab_gather_overflow_is_an_error_on_every_rank(sipx, tmp_path):
-    """An exchange segment too small for the bracket (forced: 32 values per rank): every rank returns the SAME error -- from the
-    first search that overflows, be it the initial feasibility estimate of sipx_finalize or a y/l update -- no NaN iterates, no
-    rank left waiting in a collective."""
+    """An exchange segment too small for the bracket (forced: 4 values per rank, and one refinement round where the engine
+    would enqueue up to six): every rank returns the SAME error from the y/l update whose search overflowed -- no NaN
+    iterates, no rank left waiting in a collective.  (The initial feasibility estimate runs all its rounds and fits.)"""
     import torch.multiprocessing as mp
     world = 2
     mp.spawn(_slab_worker, args=(world, 30200 + os.getpid() % 1000, str(tmp_path), ["bounds", "l1:D_x", "l1:D_z"], (32, 24, 16),
-                                 {"SIPX_GATHER_CAP": "32"}), nprocs=world, join=True)
+                                 {"SIPX_GATHER_CAP": "4", "SIPX_L1_ROUNDS_MAX": "1"}), nprocs=world, join=True)
     errs = [str(np.load(tmp_path / f"r{r}.npz")["err"]) for r in range(world)]
     assert errs[0] and errs[0] == errs[1], errs
     assert "exchange segment" in errs[0] and ("l1 threshold search of set" in errs[0] or "initial feasibility of set" in errs[0])
@@ -302,3 +302,24 @@ def test_z_marching_product_is_bit_identical(sipx, monkeypatch, TF, n, kinds):
     (a0, a1, xa, la), (b0, b1, xb, lb) = out["0"], out["2"]
     assert len(la.obj) == len(lb.obj) and np.array_equal(la.cg_it, lb.cg_it)
     assert np.linalg.norm(xa.astype(np.float64) - xb) <= (2e-6 if TF == np.float32 else 1e-11) * np.linalg.norm(xa)
+
+
+@pytest.mark.timeout(400)
+def test_slab_search_refines_until_the_bracket_fits(sipx, tmp_path):
+    """A tiny exchange segment (256 values per rank: 1 / 72 of the vector) with
+    every refinement round enqueued (SIPX_L1_ROUNDS_MIN=6; by default the engine enqueues two more than the previous search
+    of the set used): the searches narrow their brackets round by round (one all-reduce each) until they fit, then the usual
+    all-gather; the solve ends where the serial solve ends, identically on both ranks."""
+    import torch.multiprocessing as mp
+    world, kinds, n = 2, ["bounds", "l1:D_x", "l1:D_z"], (32, 24, 16)
+    mp.spawn(_slab_worker, args=(world, 30400 + os.getpid() % 1000, str(tmp_path), kinds, n, {"SIPX_GATHER_CAP": "256", "SIPX_L1_ROUNDS_MIN": "6"}),
+             nprocs=world, join=True)
+    r0, r1 = np.load(tmp_path / "r0.npz"), np.load(tmp_path / "r1.npz")
+    assert str(r0["err"]) == "" and str(r1["err"]) == ""
+    for k in ("x", "obj", "cg_it", "rho", "r_pri"):
+        assert np.array_equal(r0[k], r1[k], equal_nan=True), k
+    TF, h = np.float32, (25.0, 25.0, 25.0)
+    m = model(n, TF, seed=5)
+    gs, os_, Ps, As, props, AtAs = _problem(sipx, n, h, TF, kinds, m, dict(maxit=40))
+    xs, ls, _, _ = sipx.PARSDMM(m.copy(), AtAs, As, props, Ps, gs, os_)
+    assert np.linalg.norm(r0["x"] - xs) / np.linalg.norm(xs) < 5e-4
