@@ -117,6 +117,46 @@ function timer_from_sections(ms::NTuple{7,Float64}, ncalls::NTuple{7,Int})
     return to
 end
 
+# ---- options.parallel = true: one process per GPU, RCCL inside the engine (include/sipx.h, "sharded solve") ----------------
+# Launch (one node, 8 GPUs), every process running the SAME script:
+#     for r in 0:7:  SIPX_RANK=r SIPX_WORLD=8 SIPX_DEVICE=r SIPX_ID_FILE=/dev/shm/sipx.$JOB julia --project script.jl &
+# (or under mpiexec with SIPX_RANK / SIPX_WORLD taken from the MPI environment).  Rank 0 obtains the 128-byte ncclUniqueId
+# from the engine and publishes it through SIPX_ID_FILE; the others wait for the file.  SIPX_DECOMP=slab (default where the
+# set list allows it: bounds / l1 / l2 / annulus on the identity or D_x / D_y / D_z / TV) divides the WHOLE iteration by
+# z-slab; SIPX_DECOMP=sets is the reference's own split by constraint set.  Every rank returns the same x and log;
+# with the set decomposition l[i], y[i] are filled on the rank that owns set i only.
+localize(v) = (isdefined(Main, :DistributedArrays) && v isa Main.DistributedArrays.DArray) ? convert(Vector, v) : v
+
+function slab_decomposable(set_Prop)
+    for t in set_Prop.tag                       # (set_type, TD_OP, app_mode[1], app_mode[2])
+        (t[1] in ("bounds", "l1", "l2", "annulus", "prox_l1") && t[2] in ("identity", "D_x", "D_y", "D_z", "TV", "D2D", "D3D") &&
+         t[3] in ("matrix", "tensor")) || return false
+    end
+    return true
+end
+
+function attach_comm!(ctx, set_Prop)
+    world = parse(Int, ENV["SIPX_WORLD"]); rank = parse(Int, ENV["SIPX_RANK"])
+    idfile = ENV["SIPX_ID_FILE"]
+    id = zeros(UInt8, 128)
+    if rank == 0
+        check(ccall((:sipx_rccl_unique_id, libsipx), Cint, (Ptr{UInt8},), id))
+        write(idfile * ".tmp", id); mv(idfile * ".tmp", idfile; force=true)   # published atomically
+    else
+        while !isfile(idfile); sleep(0.01); end
+        id = read(idfile)
+    end
+    check(ccall((:sipx_set_comm_rccl, libsipx), Cint, (Ptr{Cvoid}, Ptr{UInt8}, Cint, Cint), ctx[], id, world, rank))
+    decomp = get(ENV, "SIPX_DECOMP", slab_decomposable(set_Prop) ? "slab" : "sets")
+    decomp == "slab" && check(ccall((:sipx_set_decomp, libsipx), Cint, (Ptr{Cvoid}, Cint), ctx[], 1))
+    # what RCCL itself reports (ncclCommCount / ncclCommUserRank / ncclGetVersion): worth one line in the job log
+    nr = Ref{Cint}(0); rk = Ref{Cint}(0); dc = Ref{Cint}(0); ver = zeros(UInt8, 64)
+    check(ccall((:sipx_comm_info, libsipx), Cint, (Ptr{Cvoid}, Ref{Cint}, Ref{Cint}, Ptr{UInt8}, Cint, Ref{Cint}), ctx[], nr, rk, ver, 64, dc))
+    rank == 0 && @info "sipx: sharded solve" ranks=nr[] version=unsafe_string(pointer(ver)) decomposition=(dc[] == 1 ? "slab" : "sets")
+    nr[] == world || error("RCCL sees $(nr[]) ranks, SIPX_WORLD says $world")
+    return nothing
+end
+
 function PARSDMM(m         ::Vector{TF},
                  AtA,
                  TD_OP,
@@ -134,7 +174,13 @@ function PARSDMM(m         ::Vector{TF},
     if isreal(m) == false || isreal(x) == false || isreal(l) == false || isreal(y) == false
         error("input for PARSDMM is not real")                              # src/PARSDMM.jl:50-52
     end
-    options.parallel && error("options.parallel: use one process per GPU with sipx_set_comm_rccl (INTEGRATION.md, section 5)")
+    # options.parallel = true (src/PARSDMM.jl:114-131: DArray TD_OP / P_sub, one Julia worker per set): here the solve is
+    # sharded over PROCESSES, one per GPU -- every process calls this same method with the same arguments (see
+    # attach_comm! below and INTEGRATION.md, section 5); distributed inputs are gathered, every rank builds every set.
+    if options.parallel
+        TD_OP = localize(TD_OP); P_sub = localize(P_sub); AtA = localize(AtA)
+        isempty(l) || (l = localize(l)); isempty(y) || (y = localize(y))
+    end
     p  = length(TD_OP)
     pp = options.feasibility_only ? p : p - 1                               # src/PARSDMM.jl:55-56
     length(P_sub) == pp || error("P_sub must hold one projector per constraint set")
@@ -145,7 +191,7 @@ function PARSDMM(m         ::Vector{TF},
 
     ctx = Ref{Ptr{Cvoid}}(C_NULL)
     check(ccall((:sipx_create, libsipx), Cint, (Ref{Ptr{Cvoid}}, Cint, Cint, Ptr{Int64}, Ptr{Float64}, Cint),
-                ctx, TF == Float32 ? 0 : 1, ndim, n, h, parse(Int, get(ENV, "SIPX_DEVICE", "0"))))
+                ctx, TF == Float32 ? 0 : 1, ndim, n, h, parse(Int, get(ENV, "SIPX_DEVICE", get(ENV, "SIPX_RANK", "0")))))
     keep = Any[]                                                            # arrays the descriptors point at, until finalize
     try
         for i in 1:pp
@@ -184,6 +230,8 @@ function PARSDMM(m         ::Vector{TF},
                         ctx[], d, AtA[i], off, size(AtA[i], 2))
             rc < 0 && check(1)                                               # sipx_add_set returns the set index, -1 on error
         end
+
+        options.parallel && attach_comm!(ctx, set_Prop)                      # before sipx_finalize: this context is one RANK
 
         # l, y as PARSDMM_initialize allocates them (src/PARSDMM_initialize.jl:120-127)
         if isempty(l); l = Vector{Vector{TF}}(undef, p); for i in 1:p; l[i] = zeros(TF, size(TD_OP[i], 1)); end; end
