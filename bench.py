@@ -648,16 +648,19 @@ def main():
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         steps_asked = steps
-        ended = False
-        for k in range(steps):
-            ended = ctx.parsdmm_steps(1)
-            if ended and k + 1 < steps:          # stop rules 3 / 4 of stop_PARSDMM do not depend on the tolerances: a very
-                steps = k + 1                    # long run may end by itself; time what was executed
-                break
-            if os.environ.get("SIPX_BENCH_DEBUG"):
+        if os.environ.get("SIPX_BENCH_DEBUG"):
+            ended = False
+            for k in range(steps):
+                ended = ctx.parsdmm_steps(1)
                 i = warmup + k
                 print(i + 1, "cg", logs["cg_it"][i], "obj %.4e" % logs["obj"][i], "rpri", logs["r_pri"][i], "rho", logs["rho"][i],
                       file=sys.stderr, flush=True)
+                if ended:
+                    break
+        else:
+            # ONE call for the K timed steps: the native loop runs them back to back, as sipx_parsdmm does in a real solve (a
+            # call per step from Python put 20-30 us of interpreter time between two iterations)
+            ended = ctx.parsdmm_steps(steps)
         torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
@@ -678,6 +681,10 @@ def main():
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
             dt = float(tt.item())
         log = ctx.parsdmm_log()
+        if ended and len(log.obj) < warmup + steps_asked + (stat_steps if want_table else 0):
+            # stop rules 3 / 4 of stop_PARSDMM do not depend on the tolerances: a very long run may end by itself; what was
+            # executed inside the timed region is what is reported
+            steps = max(1, min(steps_asked, len(log.obj) - warmup))
         if steps != steps_asked:
             print(f"bench: the solve stopped by itself after {warmup + steps} iterations; {steps} of the {steps_asked} requested steps were timed",
                   file=sys.stderr)

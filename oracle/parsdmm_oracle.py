@@ -1048,8 +1048,13 @@ def assemble_Q(AtA, AtA_offsets, rho, TF):
 
 
 def PARSDMM(m, AtA, TD_OP, set_Prop, P_sub, comp_grid, options, x=None, l=None, y=None,
-            trace: Optional[list] = None):
-    """src/PARSDMM.jl:25-258 serial CDS path.  Returns (x, log_PARSDMM, l, y)."""
+            trace: Optional[list] = None, replay=None):
+    """src/PARSDMM.jl:25-258 serial CDS path.  Returns (x, log_PARSDMM, l, y).
+    replay = (rho_rows, gamma_rows) -- NOT part of the reference, a device of the parity tests: the rho / gamma history of
+    ANOTHER run (its log.rho, log.gamma) is forced on this one -- after the rules of iteration i have run, rho and gamma
+    take the values that run logged for iteration i + 1.  A threshold flip of the Barzilai-Borwein rule (the correlation of
+    rounding noise falling on either side of 0.3) can then no longer separate the two runs, so everything ELSE -- operators,
+    the x-step, every projector, the multiplier updates -- is compared over the whole solve at the tight tolerance."""
     TF = m.dtype.type
     convert_options(options, TF)                                                     # :43
     o = options
@@ -1158,6 +1163,9 @@ def PARSDMM(m, AtA, TD_OP, set_Prop, P_sub, comp_grid, options, x=None, l=None, 
                 k = _julia_argmax(row)
                 rho[k] = TF(2.0) * rho[k]
         rho = np.maximum(np.minimum(rho, TF(1e4)), TF(1e-2))                         # :226 (new vector)
+        if replay is not None and i < len(replay[0]):                                # (test device, see the docstring)
+            rho = np.asarray(replay[0][i], np.float64).astype(TF)
+            gamma[:] = np.asarray(replay[1][i], np.float64).astype(TF)
         ind_updated = [int(k) for k in np.nonzero(rho.astype(np.float64) != log.rho[i - 1, :])[0]]   # :230
         Q = Q_update(Q, AtA, set_Prop, rho, ind_updated, log, i - 1, Q_offsets)      # :243
         if i == maxit:                                                               # :249-252

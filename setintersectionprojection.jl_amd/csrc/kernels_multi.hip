@@ -150,7 +150,7 @@ __device__ __forceinline__ void static_for(F&& f) {
 // eight extra sums per set live in per-thread LDS slots (as registers they would halve the occupancy of the plain variant).
 template <typename T, int V, unsigned long long L, bool FULL>
 __global__ __launch_bounds__(MULTI_NT, SIPX_MULTI_WAVES) void k_yl_multi(Grid G, MultiArgs<T> a, int lgLX, int tiles_x, int tiles_y, int zchunk,
-                                                       long long items, long long jlo, long long jhi, long long jsum) {
+                                                       long long items, long long jlo, long long jhi, long long jsum, int xsplit) {
   constexpr int NBLK = lay_count(L), NY = lay_count_kind(L, LK_Y), NZ = lay_count_kind(L, LK_Z);
   constexpr int NSETS = lay_sets(L), NI = lay_count_kind(L, LK_I);
   constexpr int NACC = FULL ? 6 * NSETS : 1;                    // the six BB sums of every set
@@ -183,7 +183,9 @@ __global__ __launch_bounds__(MULTI_NT, SIPX_MULTI_WAVES) void k_yl_multi(Grid G,
   for (long long item = blockIdx.x; item < items; item += gridDim.x) {
     const long long zc = item / tiles, tile = item - zc * tiles;
     const int tile_y = (int)(tile / tiles_x), tile_x = (int)(tile - (long long)tile_y * tiles_x);
-    const long long i0 = ((long long)tile_x * LX + tx) * V, j = jlo + (long long)tile_y * TY + ty;
+    // xsplit (2-D grids, marched along their second dimension): the TY "rows" of the tile are TY segments of ONE grid line
+    const long long i0 = xsplit ? (((long long)tile_x * TY + ty) * LX + tx) * V : ((long long)tile_x * LX + tx) * V;
+    const long long j = xsplit ? jlo + tile_y : jlo + (long long)tile_y * TY + ty;
     const bool active = i0 < n1 && j < jhi;
     const long long k0 = a.zlo + zc * zchunk, k1 = (k0 + zchunk < a.zhi) ? k0 + zchunk : a.zhi;
     // Addresses = uniform base of the plane (scalar registers) + the thread's 32-bit offset inside the plane: one vector
@@ -370,7 +372,7 @@ __global__ __launch_bounds__(MULTI_NT, SIPX_MULTI_WAVES) void k_yl_multi(Grid G,
             // the lane to the left holds the point in front of this vector; at the left edge of a tile inside the grid the
             // one point is recomputed
             T lw = __shfl_up(wv[b][V - 1], 1, 64), ld = __shfl_up(dv[b][V - 1], 1, 64);
-            if (tx == 0 && active && i0 > 0) {
+            if (tx == 0 && active && i0 > 0) {       // (xsplit: also the first lane of every segment inside the tile)
               Vec<T, 1> x1, x2, y1v, l1v, yn1, ln1;
               x1.v[0] = (a.x + pz - 1)[go]; x2.v[0] = xc.v[0];
               y1v.v[0] = (B.y + pz - 1)[go]; l1v.v[0] = (B.l + pz - 1)[go];
@@ -523,13 +525,16 @@ static void launch_multi(hipStream_t s, const Grid& g, const MultiArgs<T>& a, do
   int lg = 0;
   while ((1 << lg) < nvx && lg < 6) ++lg;
   const int LX = 1 << lg, TY = MULTI_NT / LX;
-  const bool three = g.n[2] > 1;
-  // rows of the plane this launch covers: all of them, or (2-D slab decomposition) the rank's rows
+  const bool three = g.n[1] > 1;       // (a 2-D grid arrives as (n1, 1, n2), see yl_multi)
+  // A 2-D grid (n1, n2) is marched along its SECOND dimension (the engine presents it as (n1, 1, n2): a difference along
+  // dimension 1 is then a Z block, no block needs the LDS row exchange), and the TY thread rows of a tile are TY segments of
+  // one grid line (xsplit).  3-D: rows [jlo, jhi) of every plane, planes [zlo, zhi) marched.
+  const int xsplit = three ? 0 : 1;
   long long jlo = 0, jhi = g.n[1], jsum = 0, zlo = a.zlo, zhi = a.zhi;
-  if (!three) { jlo = a.zlo; jhi = a.zhi; jsum = a.zsum; zlo = 0; zhi = 1; }
   const bool empty = jhi <= jlo || zhi <= zlo;        // a rank without planes still clears its partial slots (one idle workgroup)
   if (empty) { jhi = jlo + 1; zhi = zlo + 1; }
-  const int tiles_x = (int)((nvx + LX - 1) / LX), tiles_y = (int)((jhi - jlo + TY - 1) / TY);
+  const int tiles_x = xsplit ? (int)((nvx + (long long)LX * TY - 1) / ((long long)LX * TY)) : (int)((nvx + LX - 1) / LX);
+  const int tiles_y = xsplit ? 1 : (int)((jhi - jlo + TY - 1) / TY);
   const long long tiles = (long long)tiles_x * tiles_y;
   // chunks of planes: enough work items to fill the chip several times over, chunks long enough that the plane recomputed in
   // front of each stays a small share (<= 1 / 8 of one block's work)
@@ -545,13 +550,12 @@ static void launch_multi(hipStream_t s, const Grid& g, const MultiArgs<T>& a, do
   const int grid = (int)(items < 1 ? 1 : (items < NB_7 ? items : NB_7));
   MultiArgs<T> b = a;
   b.zlo = zlo; b.zhi = zhi;
-  if (!three) b.zsum = 0;
   if (empty) { b.zlo = b.zhi = 0; }
   ObsScope obs(KID_YL_MULTI, s, bytes);
   if (a.flags)
-    hipLaunchKernelGGL((k_yl_multi<T, V, L, true>), dim3(grid), dim3(MULTI_NT), 0, s, g, b, lg, tiles_x, tiles_y, (int)zchunk, items, jlo, jhi, jsum);
+    hipLaunchKernelGGL((k_yl_multi<T, V, L, true>), dim3(grid), dim3(MULTI_NT), 0, s, g, b, lg, tiles_x, tiles_y, (int)zchunk, items, jlo, jhi, jsum, xsplit);
   else
-    hipLaunchKernelGGL((k_yl_multi<T, V, L, false>), dim3(grid), dim3(MULTI_NT), 0, s, g, b, lg, tiles_x, tiles_y, (int)zchunk, items, jlo, jhi, jsum);
+    hipLaunchKernelGGL((k_yl_multi<T, V, L, false>), dim3(grid), dim3(MULTI_NT), 0, s, g, b, lg, tiles_x, tiles_y, (int)zchunk, items, jlo, jhi, jsum, xsplit);
   SIPX_HIP(hipGetLastError());
 }
 
@@ -559,9 +563,9 @@ static void launch_multi(hipStream_t s, const Grid& g, const MultiArgs<T>& a, do
 #define SIPX_LAYOUTS(F)                                                                                                          \
   F(lay_pack(lay_blk(LK_I, 1), lay_blk(LK_X, 1), lay_blk(LK_Y, 1), lay_blk(LK_Z, 1), lay_blk(LK_D, 1)))   /* C3: I X Y Z D */        \
   F(lay_pack(lay_blk(LK_I, 1), lay_blk(LK_Z, 0), lay_blk(LK_Y, 0), lay_blk(LK_X, 1), lay_blk(LK_D, 1)))   /* C5: I [Z Y X] D */      \
-  F(lay_pack(lay_blk(LK_I, 1), lay_blk(LK_Y, 0), lay_blk(LK_X, 1), lay_blk(LK_D, 1)))                     /* C2: I [Y X] D (2-D TV) */ \
+  F(lay_pack(lay_blk(LK_I, 1), lay_blk(LK_Z, 0), lay_blk(LK_X, 1), lay_blk(LK_D, 1)))                     /* C2: I [Z X] D (2-D TV, marched along dim 2) */ \
   F(lay_pack(lay_blk(LK_I, 1), lay_blk(LK_X, 1), lay_blk(LK_Z, 1), lay_blk(LK_D, 1)))                     /* I X Z D */             \
-  F(lay_pack(lay_blk(LK_I, 1), lay_blk(LK_Y, 1), lay_blk(LK_X, 1), lay_blk(LK_D, 1)))                     /* I Y X D (2-D D_z, D_x) */ \
+  F(lay_pack(lay_blk(LK_I, 1), lay_blk(LK_Z, 1), lay_blk(LK_X, 1), lay_blk(LK_D, 1)))                     /* I Z X D (2-D D_z, D_x) */ \
   F(lay_pack(lay_blk(LK_I, 1), lay_blk(LK_Z, 1), lay_blk(LK_D, 1)))                                       /* I Z D */               \
   F(lay_pack(lay_blk(LK_I, 1), lay_blk(LK_Y, 1), lay_blk(LK_D, 1)))                                       /* I Y D */               \
   F(lay_pack(lay_blk(LK_I, 1), lay_blk(LK_X, 1), lay_blk(LK_D, 1)))                                       /* I X D */               \
@@ -577,19 +581,25 @@ bool K<T>::yl_multi(hipStream_t s, const Grid& g, const MultiArgs<T>& a, bool pr
     const int px = a.b[b].prox;
     if (!(px == PX_BOUNDS || px == PX_L1 || px == PX_PROX_L1 || px == PX_L2 || px == PX_ANNULUS || px == PX_DIST)) return false;
     if (a.b[b].dir == 2 && g.n[2] <= 1) return false;
-    const int kind = a.b[b].dist ? LK_D : (a.b[b].dir < 0 ? LK_I : (a.b[b].dir == 0 ? LK_X : (a.b[b].dir == 1 ? LK_Y : LK_Z)));
+    const bool two_d = g.n[2] <= 1;
+    const int kind = a.b[b].dist ? LK_D : (a.b[b].dir < 0 ? LK_I : (a.b[b].dir == 0 ? LK_X : (a.b[b].dir == 1 ? (two_d ? LK_Z : LK_Y) : LK_Z)));
     code |= lay_blk(kind, a.b[b].last != 0) << (4 * b);
   }
   // algorithmic bytes: x, (m, x_old for the distance term) read; y, l of every block read and written; rhs written
   const bool three = g.n[2] > 1;
   const double pts = (double)(a.zhi - a.zlo) * (three ? (double)g.st[2] : (double)g.st[1]);
+  Grid gk = g;                      // the grid as the kernel walks it
+  if (!three) {
+    gk.n[1] = 1; gk.n[2] = g.n[1];
+    gk.st[1] = g.n[0]; gk.st[2] = g.n[0];
+  }
   double vecs = 1.0 + (a.rhs ? 1.0 : 0.0);
   const bool first = (a.flags & F_FIRST) != 0, bb = (a.flags & F_BB) != 0 && !first;
   for (int b = 0; b < a.nblk; ++b) vecs += 4.0 + (a.b[b].dist ? 2.0 : 0.0) + (bb ? 6.0 : (first ? 2.0 : 0.0));
   const double bytes = vecs * pts * sizeof(T);
 #define SIPX_TRY_LAYOUT(LL)                                    \
   if (code == (LL)) {                                          \
-    if (!probe_only) launch_multi<T, V, (LL)>(s, g, a, bytes); \
+    if (!probe_only) launch_multi<T, V, (LL)>(s, gk, a, bytes); \
     return true;                                               \
   }
   SIPX_LAYOUTS(SIPX_TRY_LAYOUT)

@@ -476,12 +476,20 @@ def test_parsdmm_matches_oracle(sipx, TF, name, n, h, kinds):
     Kc = min(len(ls.obj), len(lo.obj))
     sep = next((k for k in range(Kc) if ls.cg_it[k] != lo.cg_it[k] or not np.allclose(ls.rho[k], lo.rho[k], rtol=1e-5)), None)
     upto = Kc if sep is None else sep
-    for f in ("obj", "r_pri_total", "rho", "gamma"):
+    for f in ("obj", "r_pri_total", "rho", "gamma"):      # lock-step up to the first separation, at the reference's own tolerance
         a, b = np.asarray(getattr(ls, f))[:upto], np.asarray(getattr(lo, f))[:upto]
-        assert np.allclose(a, b, rtol=(2e-3 if TF == np.float32 else 1e-6), atol=1e-12), (f, upto)
+        assert np.allclose(a, b, rtol=(5e-4 if TF == np.float32 else 1e-6), atol=1e-12), (f, upto)
     key = (name, "f32" if TF == np.float32 else "f64")
     tol = 5e-4 if TF == np.float32 else tol64
     if sep is not None or len(ls.obj) != len(lo.obj):
+        # PRIMARY check after a separation: the oracle again with the ENGINE's rho / gamma history forced on it (replay), so
+        # that a flipped threshold of the BB rule cannot separate the two -- the end points then agree to the reference's
+        # serial-vs-parallel tolerance for EVERY case, the eight-set C4 list in Float32 included
+        gr, orr, Pr, Ar, propr, AtAr = _problem(O, n, h, TF, kinds, m, dict(kw, maxit=len(ls.obj)))
+        xr, lr, _, _ = O.PARSDMM(m.copy(), AtAr, Ar, propr, Pr, gr, orr, replay=(ls.rho, ls.gamma))
+        err_replay = np.linalg.norm(xs.astype(np.float64) - xr) / np.linalg.norm(xr)
+        assert err_replay < tol, (key, "replayed", sep, err_replay)
+        # SECONDARY: the free-running oracle (its own rho history from the separation on)
         tol = max(tol, 5e-4)
         _record_separation(key, sep, len(ls.obj), len(lo.obj), err)
         if key in DOCUMENTED_EXCEPTIONS:
@@ -668,6 +676,12 @@ def test_sharded_ranks_on_one_gpu(sipx, tmp_path, world, kinds, n, phase, decomp
     ncvx = any(k.startswith(("rank:", "card")) for k in kinds)
     # (measured: 9e-4 for {bounds, rank, l1}, 2e-2 for the eight-set C4 list, whose annulus leaves the scale of x loose)
     assert np.linalg.norm(r0["x"] - xs) / np.linalg.norm(xs) < (5e-2 if ncvx else 5e-4)
+    if ncvx:
+        # PRIMARY check for the non-convex lists: the oracle with the sharded run's own rho / gamma history forced on it
+        # (replay) -- no threshold flip of the BB rule can separate them, and the end points agree to the reference's 5e-4
+        go, oo, Po, Ao, propo, AtAo = _problem(O, n, h, TF, kinds, m, dict(maxit=len(r0["obj"])))
+        xr, _, _, _ = O.PARSDMM(m.copy(), AtAo, Ao, propo, Po, go, oo, replay=(r0["rho"], r0["gamma"]))
+        assert np.linalg.norm(r0["x"] - xr) / np.linalg.norm(xr) < 5e-4
     if not ncvx and len(r0["obj"]) == len(ls.obj) and np.array_equal(r0["cg_it"], ls.cg_it):      # same trajectory: the owners' y, l too
         for r in range(world):
             yl = np.load(tmp_path / f"yl{r}.npz")
