@@ -192,7 +192,7 @@ class Engine : public EngineBase {
     (void)hipSetDevice(device_);
     (void)hipStreamSynchronize(stream_);
     for (auto& s : sets_) free_set(s);
-    for (void* p : {(void*)w_base_, (void*)x_base_, (void*)xold_, (void*)rhs_, (void*)m_base_, (void*)r_base_, (void*)p_base_, (void*)p2_base_, (void*)Ap_, (void*)Q_,
+    for (void* p : {(void*)x0s_base_[0], (void*)x0s_base_[1], (void*)w_base_, (void*)x_base_, (void*)xold_, (void*)rhs_, (void*)m_base_, (void*)r_base_, (void*)p_base_, (void*)p2_base_, (void*)Ap_, (void*)Q_,
                     (void*)scr_v_, (void*)scr_c_, (void*)scr_i_, (void*)scr_w_, (void*)part_cg_, (void*)part_tmp_, (void*)part_sets_,
                     (void*)maxpart_, (void*)cg_dev_, (void*)dres_, (void*)gbuf_, (void*)stage_, (void*)sstage_})
       dfree(p);
@@ -409,6 +409,20 @@ class Engine : public EngineBase {
       if (cg_fused_) { p2_base_ = dalloc<T>(Nx_ + 2 * halo_); p2_ = p2_base_ + halo_; }
     }
     SIPX_HIP(hipMemcpy(m_, m, N * sizeof(T), hipMemcpyHostToDevice));
+    {
+      // x0 mode of the one-sweep update: when EVERY y/l update of this context goes through the sweep (its block layout is
+      // compiled in, no set needs the per-set kernels on feasibility iterations), s_0 = A x_0 is recomputed from a snapshot of
+      // x instead of being stored per set: two N-vectors instead of one M_i-vector per set, and 8 N w less traffic on every
+      // Barzilai-Borwein iteration of the headline list.  SIPX_X0_SNAPSHOT=0 keeps the per-set s_0 arrays (A/B switch, tests).
+      const char* e = std::getenv("SIPX_X0_SNAPSHOT");
+      const char* mu = std::getenv("SIPX_YL_MULTI");            // 0: one k_yl launch per set on every iteration (A/B switch, tests)
+      yl_multi_ = !(mu && mu[0] == '0');
+      MultiArgs<T> probe;
+      x0_mode_ = !(e && e[0] == '0') && sweep_applicable(SIPX_YL_FEAS | SIPX_YL_BB, probe, true);
+      if (x0_mode_) {
+        for (int k = 0; k < 2; ++k) { x0s_base_[k] = dalloc<T>(N + 2 * halo_); x0s_[k] = x0s_base_[k] + halo_; }
+      }
+    }
     long long maxpad = N;
     for (auto& s : sets_) maxpad = std::max(maxpad, s.Mpad);
     if (comm_) {
@@ -472,8 +486,6 @@ class Engine : public EngineBase {
       l1_sample_ = !(e && e[0] == '0');
       const char* r = std::getenv("SIPX_L1_SAMPLE_RUNS");       // tests: sample small grids too
       l1_sample_runs_ = r ? std::atoll(r) : 0;
-      const char* mu = std::getenv("SIPX_YL_MULTI");            // 0: one k_yl launch per set on every iteration (A/B switch, tests)
-      yl_multi_ = !(mu && mu[0] == '0');
     }
     for (int k = 0; k < 2 * MAXMARK; ++k) {      // two sets of section marks: a step never waits for its own timing
       hipEvent_t e;
@@ -508,7 +520,8 @@ class Engine : public EngineBase {
         return base + halo_;
       };
       s.y = halloc(s.Mpad); s.l = halloc(s.Mpad);
-      s.lh0 = dalloc<T>(s.Mpad); s.s0 = dalloc<T>(s.Mpad);
+      s.lh0 = dalloc<T>(s.Mpad);
+      if (!x0_mode_) s.s0 = dalloc<T>(s.Mpad);
       s.y0 = halloc(s.Mpad); s.l0 = halloc(s.Mpad);       // take turns with y, l as the current iterate: same halo
       if (!s.ident) s.dy = halloc(s.Mpad);
       if (s.custom) upload_custom(s);
@@ -776,6 +789,7 @@ class Engine : public EngineBase {
     rhs_fused_ = false;
     MultiArgs<T> ma;
     const bool sweep = sweep_applicable(flags, ma);
+    if (x0_mode_ && !sweep) throw std::runtime_error("internal: an x0-mode context met an update the one-sweep kernel does not take");
     if (sweep && !slab_) {
       sweep_searches(flags, rho, gamma);
       sweep_launch(flags, rho, gamma, ma);
@@ -1021,7 +1035,7 @@ class Engine : public EngineBase {
   }
 
   // does the sweep take this context / iteration?  (asked before any search is queued; fills the layout part of `ma`)
-  bool sweep_applicable(int flags, MultiArgs<T>& ma) {
+  bool sweep_applicable(int flags, MultiArgs<T>& ma, bool planning = false) {
     if (!yl_multi_ || mk_ || (comm_ && !slab_)) return false;
     const bool feas = (flags & SIPX_YL_FEAS) != 0;
     ma.nblk = 0;
@@ -1029,7 +1043,7 @@ class Engine : public EngineBase {
     ma.flags = flags;
     const long long nlast = G_.n[ndim_ - 1];
     ma.zlo = 0; ma.zhi = nlast; ma.zsum = 0;
-    if (slab_) {                                // the rank's planes, plus the last plane of the rank below (recomputed, see Gyl_)
+    if (slab_ && !planning) {                   // the rank's planes, plus the last plane of the rank below (recomputed, see Gyl_)
       ma.zsum = r0_ / plane_;
       ma.zlo = ma.zsum - ((prev_ >= 0 && r1_ > r0_) ? 1 : 0);
       ma.zhi = r1_ / plane_;
@@ -1138,10 +1152,15 @@ class Engine : public EngineBase {
       }
     }
     ma.x = x_; ma.m = m_; ma.xold = xold_;
+    ma.x0 = x0_mode_ ? x0s_[x0_cur_] : nullptr;
+    ma.x0w = x0_mode_ ? x0s_[x0_cur_ ^ 1] : nullptr;
     ma.rhs = fuse_rhs_ ? rhs_ : nullptr;
     ma.partials = part_sets_;
+    if (x0_mode_ && slab_ && (first || bb) && next_ >= 0 && r1_ > r0_)        // the plane behind the slab belongs to the snapshot too
+      SIPX_HIP(hipMemcpyAsync(x0s_[x0_cur_ ^ 1] + r1_, x_ + r1_, plane_ * sizeof(T), hipMemcpyDeviceToDevice, stream_));
     if (!K<T>::yl_multi(stream_, G_, ma)) throw std::runtime_error("internal: the fused y/l sweep refused a block list it was prepared for");
     rhs_fused_ = ma.rhs != nullptr;
+    if (x0_mode_ && (first || bb)) x0_cur_ ^= 1;
     for (int i = 0; i < p_n_; ++i) {           // (y, l) always names the current iterate; snap says where the snapshot sits
       SetState<T>& s = sets_[i];
       if (target[i] == 2) {
@@ -2428,6 +2447,9 @@ class Engine : public EngineBase {
   long long l1_sample_runs_ = 0;
   bool l1_sample_ = true;             // SIPX_L1_SAMPLE=0: no sampled prediction of theta (A/B switch)
   bool yl_multi_ = true;              // SIPX_YL_MULTI=0: never take the one-sweep y/l update (A/B switch)
+  bool x0_mode_ = false;              // s_0 = A x_0 recomputed from a snapshot of x (see finalize)
+  T *x0s_base_[2] = {nullptr, nullptr}, *x0s_[2] = {nullptr, nullptr};
+  int x0_cur_ = 0;
   bool fuse_rhs_ = false;             // the whole-solve loop: rho cannot change before the next iteration, so the sweep may write its rhs
   bool rhs_fused_ = false;            // ... and did
   std::vector<hipEvent_t> ev_;

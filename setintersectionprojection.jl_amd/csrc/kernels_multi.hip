@@ -148,7 +148,7 @@ __device__ __forceinline__ void static_for(F&& f) {
 // rewritten, six more sums per set -- adapt_rho_gamma.jl:41-53, PARSDMM.jl:192-206), the first iteration (F_FIRST: snapshots
 // written, PARSDMM.jl:164-180) and / or feasibility estimates of the element-wise sets (F_FEAS, update_y_l.jl:90-99).  Its
 // eight extra sums per set live in per-thread LDS slots (as registers they would halve the occupancy of the plain variant).
-template <typename T, int V, unsigned long long L, bool FULL>
+template <typename T, int V, unsigned long long L, bool FULL, bool X0>
 __global__ __launch_bounds__(MULTI_NT, SIPX_MULTI_WAVES) void k_yl_multi(Grid G, MultiArgs<T> a, int lgLX, int tiles_x, int tiles_y, int zchunk,
                                                        long long items, long long jlo, long long jhi, long long jsum, int xsplit) {
   constexpr int NBLK = lay_count(L), NY = lay_count_kind(L, LK_Y), NZ = lay_count_kind(L, LK_Z);
@@ -223,6 +223,10 @@ __global__ __launch_bounds__(MULTI_NT, SIPX_MULTI_WAVES) void k_yl_multi(Grid G,
     });
 
     Vec<T, V> xnext = active ? ldv<T, V>(a.x + st2 * k0 + go) : zerov<T, V>();
+    // x0 mode (a.x0 != nullptr): s_0 = A x_0 is RECOMPUTED from a snapshot of x (one array for all sets) instead of being kept
+    // per set -- the same arithmetic on the same x, so the same bits -- which saves reading and rewriting s_0 of every block
+    constexpr bool x0mode = FULL && X0;
+    Vec<T, V> x0next = (x0mode && f_bb && active) ? ldv<T, V>(a.x0 + st2 * k0 + go) : zerov<T, V>();
     for (long long kz = k0; kz < k1; ++kz) {
       const int par = (int)(kz & 1);
       const long long pz = st2 * kz;                           // uniform: the plane's first point
@@ -239,14 +243,24 @@ __global__ __launch_bounds__(MULTI_NT, SIPX_MULTI_WAVES) void k_yl_multi(Grid G,
         xnext = ldv_u<T, V>(a.x + pz + st2 + go);              // x carries an end halo of a plane: unconditional
         if constexpr (lay_count_kind(L, LK_X) > 0) xpx = ldv_u<T, V>(a.x + pz + 1 + go);
         if constexpr (NY > 0) xpy = ldv_u<T, V>(a.x + pz + st1 + go);
-#if SIPX_MULTI_PREFETCH
+        if constexpr (SIPX_MULTI_PREFETCH && !FULL) {
 #pragma unroll
-        for (int b = 0; b < NBLK; ++b) {
-          yv[b] = ldv_nt<T, V>(a.b[b].y + pz + go);           // last use of the old iterate: streaming loads
-          lv[b] = ldv_nt<T, V>(a.b[b].l + pz + go);
+          for (int b = 0; b < NBLK; ++b) {
+            yv[b] = ldv_nt<T, V>(a.b[b].y + pz + go);         // last use of the old iterate: streaming loads
+            lv[b] = ldv_nt<T, V>(a.b[b].l + pz + go);
+          }
         }
-#endif
         if constexpr (lay_count_kind(L, LK_D) > 0) { mv = ldv<T, V>(a.m + pz + go); xo = ldv<T, V>(a.xold + pz + go); }
+      }
+      Vec<T, V> x0c = x0next, x0px = zerov<T, V>(), x0py = zerov<T, V>();
+      if constexpr (FULL) {
+        if (x0mode && f_bb && active) {
+          x0next = ldv_u<T, V>(a.x0 + pz + st2 + go);
+          if constexpr (lay_count_kind(L, LK_X) > 0) x0px = ldv_u<T, V>(a.x0 + pz + 1 + go);
+          if constexpr (NY > 0) x0py = ldv_u<T, V>(a.x0 + pz + st1 + go);
+        }
+        // the new snapshot goes into the OTHER snapshot array: neighbouring threads, tiles and chunks still read the old one
+        if (x0mode && (f_bb || f_first) && active) stv_nt<T, V>(a.x0w + pz + go, xc);
       }
       // ---- phase A: the update of every block; w = rho y + l and y - y_old stay in registers ---------------------------
       T wv[NBLK][V], dv[NBLK][V];
@@ -257,10 +271,10 @@ __global__ __launch_bounds__(MULTI_NT, SIPX_MULTI_WAVES) void k_yl_multi(Grid G,
 #pragma unroll
         for (int k = 0; k < V; ++k) wv[b][k] = dv[b][k] = T(0);
         if (active) {
-#if !SIPX_MULTI_PREFETCH
-          yv[b] = ldv_nt<T, V>(B.y + pz + go);
-          lv[b] = ldv_nt<T, V>(B.l + pz + go);
-#endif
+          if constexpr (!SIPX_MULTI_PREFETCH || FULL) {       // (the variant with the snapshot arrays loads block by block: registers)
+            yv[b] = ldv_nt<T, V>(B.y + pz + go);
+            lv[b] = ldv_nt<T, V>(B.l + pz + go);
+          }
           bool valid[V];
 #pragma unroll
           for (int k = 0; k < V; ++k) valid[k] = KIND == LK_X ? vx[k] : (KIND == LK_Y ? vy : (KIND == LK_Z ? vz : true));
@@ -278,8 +292,22 @@ __global__ __launch_bounds__(MULTI_NT, SIPX_MULTI_WAVES) void k_yl_multi(Grid G,
             }
             if (f_bb) {                                                        // adapt_rho_gamma.jl:41-53
               // (the snapshot arrays are touched once every rho_update_frequency iterations: streaming loads and stores)
-              const Vec<T, V> a0 = ldv_nt<T, V>(B.lh0 + pz + go), b0 = ldv_nt<T, V>(B.y0 + pz + go), c0 = ldv_nt<T, V>(B.s0 + pz + go),
-                              d0 = ldv_nt<T, V>(B.l0 + pz + go);
+              const Vec<T, V> a0 = ldv_nt<T, V>(B.lh0 + pz + go), b0 = ldv_nt<T, V>(B.y0 + pz + go), d0 = ldv_nt<T, V>(B.l0 + pz + go);
+              Vec<T, V> c0;
+              if (x0mode) {                                  // s_0 = A x_0 at this point: fwd_dir on the snapshot
+                const Vec<T, V>& x0n = KIND == LK_X ? x0px : (KIND == LK_Y ? x0py : x0next);
+#pragma unroll
+                for (int k = 0; k < V; ++k) {
+                  if constexpr (KIND == LK_I || KIND == LK_D) {
+                    c0.v[k] = x0c.v[k];
+                  } else {
+                    const T d = (-B.ih) * x0c.v[k] + B.ih * x0n.v[k];
+                    c0.v[k] = valid[k] ? d : T(0);
+                  }
+                }
+              } else {
+                c0 = ldv_nt<T, V>(B.s0 + pz + go);
+              }
               double q6[6] = {0, 0, 0, 0, 0, 0};
 #pragma unroll
               for (int k = 0; k < V; ++k) {
@@ -301,7 +329,7 @@ __global__ __launch_bounds__(MULTI_NT, SIPX_MULTI_WAVES) void k_yl_multi(Grid G,
             }
             if (f_bb || f_first) {                                             // PARSDMM.jl:174-177, 200-203
               stv_nt<T, V>(B.lh0 + pz + go, lh);     // y_0 <- y and l_0 <- l need no copy: the update below is written into
-              stv_nt<T, V>(B.s0 + pz + go, svv);     // the snapshot pair itself (engine)
+              if (!x0mode) stv_nt<T, V>(B.s0 + pz + go, svv);     // the snapshot pair itself (engine)
             }
             if constexpr (KIND == LK_I) {
               if (f_feas && B.feas_el && own) {                                // update_y_l.jl:90-99 (element-wise sets)
@@ -552,10 +580,12 @@ static void launch_multi(hipStream_t s, const Grid& g, const MultiArgs<T>& a, do
   b.zlo = zlo; b.zhi = zhi;
   if (empty) { b.zlo = b.zhi = 0; }
   ObsScope obs(KID_YL_MULTI, s, bytes);
-  if (a.flags)
-    hipLaunchKernelGGL((k_yl_multi<T, V, L, true>), dim3(grid), dim3(MULTI_NT), 0, s, g, b, lg, tiles_x, tiles_y, (int)zchunk, items, jlo, jhi, jsum, xsplit);
+  if (a.flags && a.x0)
+    hipLaunchKernelGGL((k_yl_multi<T, V, L, true, true>), dim3(grid), dim3(MULTI_NT), 0, s, g, b, lg, tiles_x, tiles_y, (int)zchunk, items, jlo, jhi, jsum, xsplit);
+  else if (a.flags)
+    hipLaunchKernelGGL((k_yl_multi<T, V, L, true, false>), dim3(grid), dim3(MULTI_NT), 0, s, g, b, lg, tiles_x, tiles_y, (int)zchunk, items, jlo, jhi, jsum, xsplit);
   else
-    hipLaunchKernelGGL((k_yl_multi<T, V, L, false>), dim3(grid), dim3(MULTI_NT), 0, s, g, b, lg, tiles_x, tiles_y, (int)zchunk, items, jlo, jhi, jsum, xsplit);
+    hipLaunchKernelGGL((k_yl_multi<T, V, L, false, false>), dim3(grid), dim3(MULTI_NT), 0, s, g, b, lg, tiles_x, tiles_y, (int)zchunk, items, jlo, jhi, jsum, xsplit);
   SIPX_HIP(hipGetLastError());
 }
 
@@ -595,7 +625,9 @@ bool K<T>::yl_multi(hipStream_t s, const Grid& g, const MultiArgs<T>& a, bool pr
   }
   double vecs = 1.0 + (a.rhs ? 1.0 : 0.0);
   const bool first = (a.flags & F_FIRST) != 0, bb = (a.flags & F_BB) != 0 && !first;
-  for (int b = 0; b < a.nblk; ++b) vecs += 4.0 + (a.b[b].dist ? 2.0 : 0.0) + (bb ? 6.0 : (first ? 2.0 : 0.0));
+  const bool x0m = a.x0 != nullptr;       // s_0 recomputed from the snapshot of x: per block 4 (2) instead of 6 (3), + the snapshot itself
+  for (int b = 0; b < a.nblk; ++b) vecs += 4.0 + (a.b[b].dist ? 2.0 : 0.0) + (bb ? (x0m ? 4.0 : 6.0) : (first ? (x0m ? 1.0 : 2.0) : 0.0));
+  if (x0m) vecs += bb ? 2.0 : (first ? 1.0 : 0.0);
   const double bytes = vecs * pts * sizeof(T);
 #define SIPX_TRY_LAYOUT(LL)                                    \
   if (code == (LL)) {                                          \

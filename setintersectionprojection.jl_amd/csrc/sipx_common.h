@@ -278,6 +278,8 @@ struct MultiArgs {
   int nblk;
   MultiBlk<T> b[MULTI_MAXB];
   const T *x, *m, *xold;
+  const T* x0;                    // snapshot of x from which s_0 = A x_0 is recomputed (nullptr: s_0 is kept per set, MultiBlk::s0)
+  T* x0w;                         // where the new snapshot goes on BB / first iterations (the two arrays take turns)
   T* rhs;                         // nullptr: no fused right-hand side
   double* partials;               // the engine's per-set partial array (SET_SLOTS groups)
   int flags;                      // F_FEAS | F_BB | F_FIRST (0: the lean variant)
