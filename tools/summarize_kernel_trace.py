@@ -29,7 +29,7 @@ def main():
     tot = sum(r["total_us"] for r in summary)
     for r in summary:
         r["percent"] = 100.0 * r["total_us"] / tot
-    dom = [(n, d) for n, d in per.items() if "k_cds<" in n and ", 1>" in n.split("(")[0]]
+    dom = [(n, d) for n, d in per.items() if ("k_cds<" in n or "k_cds_march<" in n) and n.split("(")[0].rstrip().endswith(", 1>")]
     res = {"trace_files": [os.path.basename(f) for f in files], "kernels": summary[:40]}
     if dom:
         name, d = max(dom, key=lambda t: sum(t[1]))
