@@ -404,9 +404,16 @@ def comm_probe(dist, torch, world, rank, dev=None, scale=1):
     timed("allreduce_36_f64_us (probe sums of one set)", all_reduce_of(36, torch.float64), 100)
     timed("allreduce_2048_f64_us (dot partials of a CG step)", all_reduce_of(2048, torch.float64), 100)
     timed("allreduce_6153_f64_us (sampled histograms of three sets)", all_reduce_of(3 * 2051, torch.float64), 50)
-    timed("allgather_1.5MB_per_rank_us (bracket segments of three l1 sets)", gather_of(3 * (131072 + 8) // scale, torch.float32), 50)
+    timed("allgather_197KB_per_rank_us (speculative exchange of three l1 searches: sums + gathered magnitudes)",
+          gather_of(3 * (16384 + 48) // scale, torch.float32), 50)
+    timed("allgather_1.5MB_per_rank_us (fallback: bracket segments of three l1 sets)", gather_of(3 * (131072 + 8) // scale, torch.float32), 50)
     for n1, tag in ((256 // scale, "256^3"), (512 // scale, "512^3")):
         timed(f"halo_plane_{tag}_f32_us (one plane to each neighbour)", halo_of(n1 * n1), 50)
+
+        def both(n1=n1):          # what the engine issues as ONE RCCL group per CG iteration; here one after the other (an upper bound)
+            ar, halo = all_reduce_of(2048, torch.float64)(), halo_of(n1 * n1)()
+            return lambda: (ar(), halo())
+        timed(f"allreduce_2048_f64_then_halo_plane_{tag}_us (ungrouped upper bound of the grouped CG call)", both, 50)
     n1 = 256 // scale
     chunk = -(-n1 // world) * n1 * n1
     timed("reduce_scatter_256^3_f32_us (rhs of the set decomposition)", reduce_scatter_of(chunk, torch.float32), 10)
@@ -418,17 +425,19 @@ def comm_probe(dist, torch, world, rank, dev=None, scale=1):
 
 # Collectives of ONE PARSDMM iteration of the headline set list (C3: p = 5 terms, three l1 searches) with k CG iterations,
 # per decomposition, as the engine issues them -- what --dry-comm replays on dummy buffers.
-SLAB_SMALL_COLLECTIVES_AT_2_CG = 12        # DESIGN 5; the target of the fusion work is <= 6
+SLAB_SMALL_COLLECTIVES_AT_2_CG = 7         # DESIGN 5 (round 2: 12, then 13 with the refinement rounds of the exchange segments)
 
 
 def iteration_skeleton(decomp, k, world):
+    """Per CG iteration: all-reduce (p.Ap), then ONE grouped call {all-reduce (||r||^2), boundary planes of r}; before the first,
+    {all-reduce (||r_0||^2, ||rhs||^2), planes of r_0}.  Slab: the l1 searches of all sets through ONE all-gather (speculative
+    exchange; the fallback with its all-reduces is not part of the skeleton), no exchange of x."""
     NBp = 2048
-    cg = [("halo", "p"), ("allreduce", NBp), ("allreduce", NBp)] * k
+    cg = [("allreduce+halo", 2 * NBp)] + [("allreduce", NBp), ("allreduce+halo", NBp)] * k
     sums = ("allreduce", 6 * 16)
     if decomp == "sets":
-        return [("reduce_scatter", "N"), ("allreduce", 2 * NBp)] + cg + [("allgather", "N"), sums]
-    stage = 3 * (19 + 1 + 2 * world)
-    return [("allreduce", 2 * NBp)] + cg + [("halo", "x"), ("allreduce", stage), ("allreduce", stage), ("allgather", "segments"), sums]
+        return [("reduce_scatter", "N")] + cg + [("allgather", "N"), sums]
+    return cg + [("allgather", "fast_segments"), sums]
 
 
 def dry_comm(args):
@@ -468,14 +477,16 @@ def dry_comm(args):
     plane = n1 * n1
     chunk = -(-n1 // world) * plane
     bufs = {"N": torch.zeros(world * chunk, dtype=torch.float32, device=dev),
-            "segments": torch.zeros(world * 3 * ((131072 // scale) + 8), dtype=torch.float32, device=dev)}
+            "fast_segments": torch.zeros(world * 3 * ((16384 // scale) + 48), dtype=torch.float32, device=dev)}
     halo = [torch.zeros(plane, dtype=torch.float32, device=dev) for _ in range(4)]
     small = {}
 
     def run(op, arg):
-        if op == "allreduce":
+        if op in ("allreduce", "allreduce+halo"):
             t = small.setdefault(arg, torch.zeros(arg, dtype=torch.float64, device=dev))
             comm.allreduce_sum_(t)
+            if op == "allreduce+halo":          # (one ncclGroup in the engine)
+                comm.halo_exchange(halo[0], halo[1], rank - 1 if rank > 0 else -1, halo[2], halo[3], rank + 1 if rank < world - 1 else -1)
         elif op == "reduce_scatter":
             comm.reduce_scatter_sum_(bufs[arg], bufs[arg].numel() // world)
         elif op == "allgather":

@@ -5,6 +5,7 @@
 #include <rccl/rccl.h>
 
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 #include <stdexcept>
@@ -131,6 +132,28 @@ class RcclComm : public Comm {
     if (next >= 0) {
       nccl_check(a.Send(send_next, count, nccl_type(dtype), next, comm_, s), "ncclSend");
       nccl_check(a.Recv(recv_next, count, nccl_type(dtype), next, comm_, s), "ncclRecv");
+    }
+    nccl_check(a.GroupEnd(), "ncclGroupEnd");
+  }
+  // all-reduce + neighbour exchange in ONE group (RCCL's planner puts collective and point-to-point work of a group into one
+  // launch where the channels allow); SIPX_COMM_GROUP=0 issues them one after the other
+  void allreduce_with_halo(void* buf, size_t count, int red_dtype, const void* send_prev, void* recv_prev, int prev,
+                           const void* send_next, void* recv_next, int next, size_t hcount, int hdtype, hipStream_t s) override {
+    static const bool grouped = [] { const char* e = std::getenv("SIPX_COMM_GROUP"); return !(e && e[0] == '0'); }();
+    if (!grouped || (prev < 0 && next < 0)) {
+      Comm::allreduce_with_halo(buf, count, red_dtype, send_prev, recv_prev, prev, send_next, recv_next, next, hcount, hdtype, s);
+      return;
+    }
+    const RcclApi& a = rccl();
+    nccl_check(a.GroupStart(), "ncclGroupStart");
+    nccl_check(a.AllReduce(buf, buf, count, nccl_type(red_dtype), ncclSum, comm_, s), "ncclAllReduce");
+    if (prev >= 0) {
+      nccl_check(a.Send(send_prev, hcount, nccl_type(hdtype), prev, comm_, s), "ncclSend");
+      nccl_check(a.Recv(recv_prev, hcount, nccl_type(hdtype), prev, comm_, s), "ncclRecv");
+    }
+    if (next >= 0) {
+      nccl_check(a.Send(send_next, hcount, nccl_type(hdtype), next, comm_, s), "ncclSend");
+      nccl_check(a.Recv(recv_next, hcount, nccl_type(hdtype), next, comm_, s), "ncclRecv");
     }
     nccl_check(a.GroupEnd(), "ncclGroupEnd");
   }

@@ -31,6 +31,13 @@ struct Comm {
   // neighbour); the four buffers are distinct device ranges
   virtual void halo_exchange(const void* send_prev, void* recv_prev, int prev, const void* send_next, void* recv_next, int next,
                              size_t count, int dtype, hipStream_t s) = 0;
+  // the two at once, for steps whose all-reduce and neighbour exchange do not depend on each other (CG: ||r||^2 partials and
+  // the boundary planes of r): ONE call where the communicator can group them (RCCL: one ncclGroup, one launch), else in turn
+  virtual void allreduce_with_halo(void* buf, size_t count, int red_dtype, const void* send_prev, void* recv_prev, int prev,
+                                   const void* send_next, void* recv_next, int next, size_t hcount, int hdtype, hipStream_t s) {
+    allreduce_sum(buf, count, red_dtype, s);
+    halo_exchange(send_prev, recv_prev, prev, send_next, recv_next, next, hcount, hdtype, s);
+  }
   // in place on world * chunk elements: rank r receives buf[r*chunk .. (r+1)*chunk) of rank `root` (scatter), or rank `root`
   // receives that range from every rank r (gather); the root's own range stays where it is
   virtual void scatter(void* buf, size_t chunk, int dtype, int root, hipStream_t s) = 0;

@@ -194,7 +194,7 @@ class Engine : public EngineBase {
     for (auto& s : sets_) free_set(s);
     for (void* p : {(void*)x0s_base_[0], (void*)x0s_base_[1], (void*)w_base_, (void*)x_base_, (void*)xold_, (void*)rhs_, (void*)m_base_, (void*)r_base_, (void*)p_base_, (void*)p2_base_, (void*)Ap_, (void*)Q_,
                     (void*)scr_v_, (void*)scr_c_, (void*)scr_i_, (void*)scr_w_, (void*)part_cg_, (void*)part_tmp_, (void*)part_sets_,
-                    (void*)maxpart_, (void*)cg_dev_, (void*)dres_, (void*)gbuf_, (void*)stage_, (void*)sstage_})
+                    (void*)maxpart_, (void*)cg_dev_, (void*)gbuf_, (void*)stage_, (void*)sstage_, (void*)fbuf_})
       dfree(p);
     comm_.reset();
     if (cstream_) (void)hipStreamDestroy(cstream_);
@@ -206,6 +206,7 @@ class Engine : public EngineBase {
     if (hres_) (void)hipHostFree(hres_);
     if (hlean_) (void)hipHostFree((void*)hlean_);
     if (hovf_) (void)hipHostFree((void*)hovf_);
+    if (hverd_) (void)hipHostFree((void*)hverd_);
     for (auto e : ev_) (void)hipEventDestroy(e);
     for (auto e : stat_ev_) (void)hipEventDestroy(e);
     for (auto e : cg_ev_) if (e) (void)hipEventDestroy(e);
@@ -417,6 +418,7 @@ class Engine : public EngineBase {
       const char* e = std::getenv("SIPX_X0_SNAPSHOT");
       const char* mu = std::getenv("SIPX_YL_MULTI");            // 0: one k_yl launch per set on every iteration (A/B switch, tests)
       yl_multi_ = !(mu && mu[0] == '0');
+      if (const char* ra = std::getenv("SIPX_RESID_AHEAD")) resid_ahead_ = ra[0] != '0';      // A/B switch
       MultiArgs<T> probe;
       x0_mode_ = !(e && e[0] == '0') && sweep_applicable(SIPX_YL_FEAS | SIPX_YL_BB, probe, true);
       if (x0_mode_) {
@@ -455,6 +457,14 @@ class Engine : public EngineBase {
       // buffer with a segment per l1 set and rank (one all-gather)
       gbuf_ = dalloc<T>((size_t)comm_->world * std::max(nl1, 1) * (hooks_.gcap + GATHER_HDR));
       hooks_.gbuf = gbuf_;
+      // speculative exchange: a small segment per two-pass set and rank (header with the rank's sums + what its first pass
+      // gathered inside the speculative range: a few thousand magnitudes once theta moves slowly)
+      // (a rank's share of what the full-size segment holds, times two for uneven shares; at least 16 K values)
+      hooks_.fcap = std::min<long long>(hooks_.gcap, std::max<long long>(1ll << 14, (2 * hooks_.gcap / comm_->world + 3) / 4 * 4));
+      if (const char* e = std::getenv("SIPX_GATHER_FAST_CAP"))
+        if (std::atoll(e) >= 4) hooks_.fcap = std::min<long long>(hooks_.gcap, std::atoll(e) / 4 * 4);
+      if (const char* e = std::getenv("SIPX_SPEC_EXCHANGE")) spec_exchange_ = std::atoi(e) != 0;
+      fbuf_ = dalloc<T>((size_t)comm_->world * std::max(n2, 1) * (hooks_.fcap + fast_hdr<T>()));
       stage_ = dalloc<double>((size_t)std::max(n2, 1) * (PREP_SLOTS + 1 + 2 * comm_->world));
       sstage_ = dalloc<double>((size_t)std::max(n2, 1) * (2 * SAMPLE_BINS + 3));
     }
@@ -462,12 +472,13 @@ class Engine : public EngineBase {
     scr_c_ = dalloc<T>(maxpad);
     if (need_idx_) scr_i_ = dalloc<long long>(maxpad);
     if (need_ext_) scr_w_ = dalloc<T>(maxpad);
-    part_cg_ = dalloc<double>(2 * NB);
+    // (the reduced per-set sums sit right behind the CG partials: sharded, ONE all-reduce can carry both, see argmin_x_head)
+    part_cg_ = dalloc<double>(2 * NB + (size_t)(p_n_ + 1) * SLOTS);
     part_tmp_ = dalloc<double>((size_t)(PREP_SLOTS + 2) * NB);
     part_sets_ = dalloc<double>((size_t)(p_n_ + 1) * SLOTS * NB);   // + one group of slots for whole-x sums
     maxpart_ = dalloc<T>(2 * NB);     // per-block max | per-block smallest non-zero magnitude
     cg_dev_ = dalloc<CgState<T>>(1);
-    dres_ = dalloc<double>((size_t)(p_n_ + 1) * SLOTS);
+    dres_ = part_cg_ + 2 * NB;
     SIPX_HIP(hipHostMalloc((void**)&cg_host_, 2 * sizeof(CgState<T>), hipHostMallocDefault));
     std::memset(cg_host_, 0, 2 * sizeof(CgState<T>));
     SIPX_HIP(hipHostMalloc((void**)&ticket_, 64, hipHostMallocDefault));
@@ -481,6 +492,8 @@ class Engine : public EngineBase {
     std::memset((void*)hlean_, 0, sizeof(int) * (p_n_ + 1));
     SIPX_HIP(hipHostMalloc((void**)&hovf_, sizeof(int) * (p_n_ + 1), hipHostMallocDefault));
     std::memset((void*)hovf_, 0, sizeof(int) * (p_n_ + 1));
+    SIPX_HIP(hipHostMalloc((void**)&hverd_, sizeof(unsigned) * (p_n_ + 1), hipHostMallocDefault));
+    std::memset((void*)hverd_, 0, sizeof(unsigned) * (p_n_ + 1));
     {
       const char* e = std::getenv("SIPX_L1_SAMPLE");
       l1_sample_ = !(e && e[0] == '0');
@@ -634,6 +647,7 @@ class Engine : public EngineBase {
   void rhs_compose(const double* rho) override {
     need_final();
     ObserverGuard og(observer());
+    head_done_ = false;           // a residual product queued ahead belonged to the right-hand side that is replaced here
     if (rs_pending_) {          // a right-hand side that was never consumed: let its exchange finish before rhs is rewritten
       SIPX_HIP(hipStreamWaitEvent(stream_, ev_c_[1], 0));
       rs_pending_ = false;
@@ -694,37 +708,63 @@ class Engine : public EngineBase {
     }
   }
 
-  void argmin_x(int it, double* tol_ref_io, int64_t* cg_it, double* cg_relres, int* cg_flag) override {
-    need_final();
-    ObserverGuard og(observer());
+  // First part of the x-step: the residual product r_0 = rhs - Q x (which also keeps x_old and serves the tolerance chain), and,
+  // sharded, the grouped call that makes its sums global and hands the boundary planes of p_1 = r_0 to the neighbours.  The
+  // whole-solve loop queues it AHEAD -- right behind the y/l update of the previous iteration, before the host waits for that
+  // iteration's sums -- whenever the right-hand side is known by then (rho cannot change): the device runs the product while the
+  // host reads the sums and evaluates the stop rule (a stop leaves x, y, l untouched: p, x_old and the partials are scratch),
+  // and, sharded, the all-reduce of the per-set sums rides in the same call (dres_ sits behind part_cg_).
+  void argmin_x_head() {
     if (rs_pending_) {                       // the reduce-scatter of rhs (communication stream) has to have landed
       SIPX_HIP(hipStreamWaitEvent(stream_, ev_c_[1], 0));
       rs_pending_ = false;
     }
-    const long long r0 = r0_, r1 = r1_, nloc = r1 - r0;      // rows of this rank's part of the x-step (all of them unless sharded)
+    const long long r0 = r0_, r1 = r1_;
     const int dt = dtype_code();
     // the initial residual goes straight into the p buffer (p_1 = r_0, cg.jl:57): the first iteration reads it from there
     // as both r and p and writes r_1 into the r buffer, so the copy p <- r is never made
     if (stencil_q_) K<T>::sq_resid(stream_, G_, sq_, x_, rhs_, p_, (T*)nullptr, xold_, part_cg_);
     else K<T>::resid(stream_, Nx_, r0, r1, Q_, cds_, x_, rhs_, p_, (T*)nullptr, xold_, part_cg_);
-    if (comm_) comm_->allreduce_sum(part_cg_, 2 * NB, SIPX_F64, stream_);      // ||r_0||^2, ||rhs||^2 block partials
+    if (comm_) {         // ||r_0||^2, ||rhs||^2 block partials [+ the per-set sums of the y/l update queued just before]; p_1 = r_0 is in p_
+      comm_->allreduce_with_halo(part_cg_, (size_t)(2 * NB + merged_nslots_), SIPX_F64, p_ + r0, p_ + r0 - plane_, prev_, p_ + r1 - plane_,
+                                 p_ + r1, next_, (size_t)plane_, dt, stream_);
+      if (merged_nslots_ > 0) SIPX_HIP(hipMemcpyAsync(hres_, dres_, sizeof(double) * merged_nslots_, hipMemcpyDeviceToHost, stream_));
+      merged_nslots_ = 0;
+    }
+    head_done_ = true;
+  }
+
+  void argmin_x(int it, double* tol_ref_io, int64_t* cg_it, double* cg_relres, int* cg_flag) override {
+    need_final();
+    ObserverGuard og(observer());
+    if (!head_done_) argmin_x_head();
+    head_done_ = false;
+    const long long r0 = r0_, r1 = r1_, nloc = r1 - r0;      // rows of this rank's part of the x-step (all of them unless sharded)
+    const int dt = dtype_code();
+    // Sharded (either decomposition): the rows of the x-step are split by z-slab and a product needs the boundary planes of p
+    // from the two neighbours.  They are never sent: a rank keeps copies of the neighbours' boundary planes of p AND x and
+    // takes them through the same updates (x += alpha p, p = r + beta p: same scalars, same operands, same bits), which only
+    // needs the boundary planes of r -- and those do not depend on the all-reduce of ||r||^2 that follows the same kernel, so
+    // the two travel in ONE grouped call.  Per CG iteration: all-reduce (p.Ap), then {all-reduce (||r||^2) + planes of r};
+    // before the first: {all-reduce (||r_0||^2, ||rhs||^2) + planes of r_0 = p_1} (argmin_x_head); no exchange of x after the solve.
+    const long long hlo = (comm_ && prev_ >= 0) ? plane_ : 0, hhi = (comm_ && next_ >= 0) ? plane_ : 0;
     const unsigned seq = ++cg_seq_;
     K<T>::cg_begin(stream_, part_cg_, cg_dev_, cg_host_, it, (T)*tol_ref_io, seq, (unsigned long long*)ticket_);
-    // One CG iteration = (halo planes of p from the neighbours) -> product + p.Ap -> x, r update + ||r||^2 -> p update.
+    // One CG iteration = product + p.Ap -> x, r update + ||r||^2 -> p update.
     // The host enqueues iteration k+1 as soon as the ticket word says that k did not converge, which workgroup 0 of the
     // p-update publishes before it starts streaming: the GPU does not idle on the round trip and nothing is launched
     // for an iteration that does not run.
     auto enqueue = [&](int k) {
       CgState<T>* mirror = cg_host_ + (k & 1);
-      if (comm_)
-        comm_->halo_exchange(p_ + r0, p_ + r0 - plane_, prev_, p_ + r1 - plane_, p_ + r1, next_, (size_t)plane_, dt, stream_);
       if (stencil_q_) K<T>::sq_spmv_dot(stream_, G_, sq_, p_, Ap_, part_cg_, cg_dev_);
       else K<T>::spmv_dot(stream_, Nx_, r0, r1, Q_, cds_, p_, Ap_, part_cg_, cg_dev_);
       if (comm_) comm_->allreduce_sum(part_cg_, NB, SIPX_F64, stream_);
       K<T>::cg_update_xr(stream_, nloc, x_ + r0, (k == 1 ? p_ : r_) + r0, r_ + r0, p_ + r0, Ap_ + r0, part_cg_, cg_dev_, mirror, k,
-                         (unsigned long long*)ticket_);
-      if (comm_) comm_->allreduce_sum(part_cg_ + NB, NB, SIPX_F64, stream_);
-      K<T>::cg_update_p(stream_, nloc, p_ + r0, r_ + r0, part_cg_, cg_dev_, mirror, (unsigned long long*)ticket_);
+                         (unsigned long long*)ticket_, hlo, hhi);
+      if (comm_)
+        comm_->allreduce_with_halo(part_cg_ + NB, NB, SIPX_F64, r_ + r0, r_ + r0 - plane_, prev_, r_ + r1 - plane_, r_ + r1, next_,
+                                   (size_t)plane_, dt, stream_);
+      K<T>::cg_update_p(stream_, nloc, p_ + r0, r_ + r0, part_cg_, cg_dev_, mirror, (unsigned long long*)ticket_, hlo, hhi);
     };
     // Fused form (cg_fused_): iteration 1 = product on p_1 (= r_0, in p_), x / r update, then the fused kernel of iteration 2
     // queued at once; iteration k >= 2 = x / r update on the p_k and A p_k the fused kernel left, then the fused kernel of
@@ -752,7 +792,7 @@ class Engine : public EngineBase {
     if (done) {
       fin = cg_host_[0];
       drop_samples_from(stat0);          // the iteration queued ahead returned at once: not a sample of its kernels
-      if (fin.flag == -9) SIPX_HIP(hipMemsetAsync(x_ + r0, 0, nloc * sizeof(T), stream_));   // cg.jl:51
+      if (fin.flag == -9) SIPX_HIP(hipMemsetAsync(x_ + r0 - hlo, 0, (nloc + hlo + hhi) * sizeof(T), stream_));   // cg.jl:51 (the copies of the neighbours' planes too)
     } else {
       const int maxIter = 1000;                       // argmin_x.jl:39
       int iter = 1;
@@ -770,10 +810,9 @@ class Engine : public EngineBase {
     if (comm_) {
       // obj / evol_x sums over the slab (x_old is only kept for the slab), then x is completed on every rank
       K<T>::log3(stream_, nloc, x_ + r0, m_ + r0, xold_ + r0, part_sets_ + (size_t)p_n_ * SLOTS * NB);
-      if (slab_)       // the planes of x next to the slab: forward differences read one plane up, the recomputed plane below needs one down
-        comm_->halo_exchange(x_ + r0, x_ + r0 - plane_, prev_, x_ + r1 - plane_, x_ + r1, next_, (size_t)plane_, dt, stream_);
-      else
-        comm_->allgather(x_, (size_t)chunk_, dt, stream_);
+      // slab-decomposed: the planes of x next to the slab (forward differences read one plane up, the recomputed plane below
+      // needs one down) were kept current by the CG updates themselves -- nothing to exchange
+      if (!slab_) comm_->allgather(x_, (size_t)chunk_, dt, stream_);
     }
     *tol_ref_io = (double)cg_host_->tol_ref;
     *cg_it = cg_host_->iters;
@@ -868,6 +907,88 @@ class Engine : public EngineBase {
         }
         if (const char* e = std::getenv("SIPX_L1_ROUNDS_MIN")) rounds = std::min(6, std::max(rounds, std::atoi(e)));      // a problem whose brackets shrink slowly
         if (const char* e = std::getenv("SIPX_L1_ROUNDS_MAX")) rounds = std::max(1, std::min(rounds, std::atoi(e)));      // tests: force an overflow
+        if (spec_exchange_) {
+          // SPECULATIVE EXCHANGE (kernels_proj.hip, k_spec_pack): first pass of every set, then ONE all-gather carrying every
+          // rank's probe sums and the magnitudes it gathered inside the speculative range.  Every rank adds the sums up itself,
+          // decides, and -- when the range held theta, the rule once rho and gamma move slowly -- solves from the gathered values:
+          // one collective per iteration for all the searches.  Whether a set needs its fallback (refinement rounds with an
+          // all-reduce each, then the full-size exchange) the host reads from a pinned word per set; the decision kernel,
+          // the unpacking and the solve are queued before that wait, so the device does not idle on it.
+          const long long fseg = hooks_.fcap + fast_hdr<T>();
+          const long long fchunk = (long long)tp.size() * fseg;
+          const unsigned seq = ++spec_seq_ & 0x3fffffffu;
+          for (size_t j = 0; j < tp.size(); ++j) {
+            SetState<T>& s = sets_[tp[j]];
+            ctl[j].verdict = (unsigned*)hverd_ + tp[j];
+            ctl[j].seq = seq;
+            K<T>::proj_scalars_stage(0, stream_, Gr_, args[j], 0, s.ps, s.ptmp, s.mpart, s.cbuf, s.Mtrue, ctl[j], &hooks_,
+                                     stage_ + j * RS, gseg[j], chunk);
+            K<T>::proj_scalars_stage(5, stream_, Gr_, args[j], 0, s.ps, s.ptmp, s.mpart, s.cbuf, s.Mtrue, ctl[j], &hooks_,
+                                     stage_ + j * RS, fbuf_ + (long long)j * fseg, fchunk);
+          }
+          comm_->allgather(fbuf_, (size_t)fchunk, dtype_code(), stream_);
+          for (size_t j = 0; j < tp.size(); ++j) {
+            SetState<T>& s = sets_[tp[j]];
+            K<T>::proj_scalars_stage(6, stream_, Gr_, args[j], 0, s.ps, s.ptmp, s.mpart, s.cbuf, s.Mtrue, ctl[j], &hooks_,
+                                     stage_ + j * RS, fbuf_ + (long long)j * fseg, fchunk);
+          }
+          std::vector<size_t> fb;                  // the sets whose search goes on (the same on every rank)
+          bool refine = false;
+          for (size_t j = 0; j < tp.size(); ++j) {
+            const unsigned w = wait_verdict(hverd_ + tp[j], seq);
+            if (w & 1u) fb.push_back(j);
+            refine |= (w & 2u) != 0;
+          }
+          spec_searches_ += (long long)tp.size();
+          spec_fallbacks_ += (long long)fb.size();
+          static const bool spec_debug = std::getenv("SIPX_SPEC_DEBUG") != nullptr;
+          if (spec_debug) {
+            for (size_t j : fb) dump_ps(tp[j], stage_ + j * RS);
+            std::fprintf(stderr, "[sipx spec] it %d:", it);
+            for (size_t j = 0; j < tp.size(); ++j) std::fprintf(stderr, " set %d verdict %u", tp[j], (unsigned)(hverd_[tp[j]] & 3u));
+            std::fprintf(stderr, "\n");
+          }
+          if (!fb.empty()) {
+            // Fallback (the summed first-pass sums of every set are in its region of stage_, where k_spec_decide left them):
+            // refinement rounds -- gated probe pass, ONE all-reduce, decision -- for as long as some set's bracket holds more than
+            // the exchange segments take (the host reads that from the sets' pinned words after every round: exactly as many
+            // all-reduces as are needed, at most L1_REFINES_SLAB), then the compaction of every final bracket and the full-size
+            // all-gather.  The sets the exchange settled take no part.
+            int max_rounds = 6;
+            if (const char* e = std::getenv("SIPX_L1_ROUNDS_MAX")) max_rounds = std::max(0, std::min(6, std::atoi(e)));      // tests: force an overflow
+            for (int rep = 0; refine && rep < max_rounds; ++rep) {
+              const unsigned rseq = ++spec_seq_ & 0x3fffffffu;
+              for (size_t j : fb) {
+                SetState<T>& s = sets_[tp[j]];
+                K<T>::proj_scalars_stage(8, stream_, Gr_, args[j], 0, s.ps, s.ptmp, s.mpart, s.cbuf, s.Mtrue, ctl[j], &hooks_,
+                                         stage_ + j * RS, gseg[j], chunk);
+              }
+              comm_->allreduce_sum(stage_, tp.size() * RS, SIPX_F64, stream_);
+              for (size_t j : fb) {
+                SetState<T>& s = sets_[tp[j]];
+                ctl[j].seq = rseq;
+                K<T>::proj_scalars_stage(9, stream_, Gr_, args[j], 0, s.ps, s.ptmp, s.mpart, s.cbuf, s.Mtrue, ctl[j], &hooks_,
+                                         stage_ + j * RS, gseg[j], chunk);
+              }
+              refine = false;
+              for (size_t j : fb)
+                if (sets_[tp[j]].prox == PX_L1) refine |= (wait_verdict(hverd_ + tp[j], rseq) & 2u) != 0;
+              spec_rounds_ += 1;
+              if (spec_debug) {
+                std::fprintf(stderr, "[sipx spec]   round %d -> refine %d\n", rep + 1, (int)refine);
+                for (size_t j : fb) dump_ps(tp[j], stage_ + j * RS);
+              }
+            }
+            for (int stage : {12, 3}) {
+              for (size_t j : fb) {
+                SetState<T>& s = sets_[tp[j]];
+                K<T>::proj_scalars_stage(stage, stream_, Gr_, args[j], 0, s.ps, s.ptmp, s.mpart, s.cbuf, s.Mtrue, ctl[j], &hooks_,
+                                         stage_ + j * RS, gseg[j], chunk);
+              }
+              if (stage == 12) comm_->allgather(gbuf_, (size_t)chunk, dtype_code(), stream_);
+            }
+          }
+        } else {
         const int order[4] = {0, 1, 2, 3};
         for (int si = 0; si < 4; ++si) {
           const int stage = order[si];
@@ -882,6 +1003,7 @@ class Engine : public EngineBase {
             if (stage < 2 && (stage == 0 || nl1 > 0)) comm_->allreduce_sum(stage_, tp.size() * RS, SIPX_F64, stream_);
           }
           if (stage == 2 && nl1 > 0) comm_->allgather(gbuf_, (size_t)chunk, dtype_code(), stream_);
+        }
         }
       }
     }
@@ -1187,10 +1309,22 @@ class Engine : public EngineBase {
       for (int i = 0; i < p_n_; ++i) {
         if (!hovf_[i]) continue;
         for (int k = 0; k <= p_n_; ++k) hovf_[k] = 0;
+        ProjScalars<T> h;                    // what the search knew when it gave up (diagnostics): the update's search or the feasibility estimate's
+        SIPX_HIP(hipStreamSynchronize(stream_));
+        char dbg[512];
+        int at = 0;
+        for (const ProjScalars<T>* d : {sets_[i].ps, sets_[i].psf}) {
+          if (!d) continue;
+          SIPX_HIP(hipMemcpy(&h, d, sizeof(h), hipMemcpyDeviceToHost));
+          if (!h.gather_overflow) continue;
+          at += std::snprintf(dbg + at, sizeof dbg - at, " [%s: bracket (%.9g, %.9g], refinement rounds %d, ||v||_1 %.6g, radius %.6g, speculative range (%.9g, %.9g]]",
+                              d == sets_[i].ps ? "y/l update" : "feasibility estimate", h.lo, h.hi, h.rounds_used, h.asum, (double)sets_[i].phi, h.spec_lo, h.spec_hi);
+        }
+        dbg[at] = 0;
         throw std::runtime_error("l1 threshold search of set " + std::to_string(i) + ": the magnitudes inside the final bracket, gathered over all "
                                  "ranks, exceed the exchange segment of " + std::to_string(hooks_.gcap) + " values per rank "
-                                 "(slab decomposition) after the refinement rounds that were enqueued; the iterate of this step is not valid -- set "
-                                 "SIPX_L1_ROUNDS_MIN (up to 6) or use the set decomposition for this problem");
+                                 "(slab decomposition) after the refinement rounds of the search; the iterate of this step is not valid -- "
+                                 "use the set decomposition for this problem" + std::string(dbg));
       }
     }
     const bool all = comm_ != nullptr;       // sharded: the all-reduced sums of every set are here, on every rank
@@ -1398,6 +1532,7 @@ class Engine : public EngineBase {
       if (!s.owned && !comm_) throw std::runtime_error("sipx_parsdmm needs every set local, or a communicator (sipx_set_comm*)");
     Run& R = run_;
     R = Run();
+    head_done_ = false;
     R.log = log;
     R.maxit = opt->maxit;
     const int p = p_n_, pp = pp_n_;
@@ -1461,7 +1596,7 @@ class Engine : public EngineBase {
       return ((R.adjust_rho || R.adjust_gamma) && it % R.freq == 0) || (R.adjust_feas_rho && it % 10 == 0 && it > 10 && pp > 0);
     };
     {
-      mark(-1);
+      if (!head_done_) mark(-1);           // (head queued ahead: the interval since the last mark belongs to the x-step)
       if (!R.rhs_ready) {
         rhs_compose(rho.data());
         mark(1);
@@ -1477,10 +1612,13 @@ class Engine : public EngineBase {
       if (i == 1) flags |= SIPX_YL_FIRST;
       if ((R.adjust_rho || R.adjust_gamma) && i % R.freq == 0) flags |= SIPX_YL_BB;
       defer_sums_ = true;                  // queue the kernels and the reduction of their sums, collect them further down
-      fuse_rhs_ = i < maxit && !rho_may_change(i);       // rhs_{i+1} may be formed by the sweep that forms y_{i+1}, l_{i+1}
+      const bool rhs_known = i < maxit && !rho_may_change(i);
+      fuse_rhs_ = rhs_known;               // rhs_{i+1} may be formed by the sweep that forms y_{i+1}, l_{i+1}
+      merge_sums_ = rhs_known && resid_ahead_ && comm_ != nullptr;
       update_y_l(i, flags, rho.data(), gamma.data(), rpri.data(), rdual.data(), feas.data());
       fuse_rhs_ = false;
       defer_sums_ = false;
+      merge_sums_ = false;
       mark(3);                             // also the event the host waits on for the sums
       sums_event_ = ev_[par * MAXMARK + nmark_[par] - 1];
       // Software pipeline: nothing the GPU is given next may depend on the sums the host is about to read.  When the rules
@@ -1489,10 +1627,17 @@ class Engine : public EngineBase {
       // stop leaves x, y, l as they are: rhs is scratch.
       if (rhs_fused_) {
         R.rhs_ready = true;                  // written by the y/l sweep itself (kernels_multi.hip)
-      } else if (i < maxit && !rho_may_change(i)) {
+      } else if (rhs_known) {
         rhs_compose(rho.data());
         mark(1);
         R.rhs_ready = true;
+      }
+      if (R.rhs_ready && resid_ahead_) {     // ... and so is the residual product of the coming x-step
+        argmin_x_head();
+        if (comm_) {                         // (sharded: the sums arrive with the grouped call of the head)
+          mark(2);
+          sums_event_ = ev_[par * MAXMARK + nmark_[par] - 1];
+        }
       }
       collect_set_sums(rho.data(), rpri.data(), rdual.data(), feas.data());
       auto t_host = clk::now();
@@ -1596,6 +1741,7 @@ class Engine : public EngineBase {
     for (int k = 0; k < p_n_; ++k) { rho_[k] = (T)rho[k]; gamma_[k] = (T)gamma[k]; }
     run_.rhs_ready = false;
     run_.done = true;
+    head_done_ = false;
   }
 
   void parsdmm(const sipx_options* opt, sipx_log* log) override {
@@ -1762,7 +1908,10 @@ class Engine : public EngineBase {
       o += buf;
       first = false;
     }
-    o += "]}";
+    // slab-decomposed solve: threshold searches that went through the speculative exchange since the context was finalised,
+    // and how many of them needed their fallback (refinement rounds + full-size exchange)
+    o += "], \"slab_searches\": {\"speculative_exchange\": " + std::to_string(spec_searches_) + ", \"fallbacks\": " +
+         std::to_string(spec_fallbacks_) + ", \"refinement_rounds\": " + std::to_string(spec_rounds_) + "}}";
     start_stats(enable);
     return o.c_str();
   }
@@ -2349,7 +2498,10 @@ class Engine : public EngineBase {
   // partials of the per-set slots -> hres_ (pinned).  Sharded: summed over the ranks on the way (sets a rank does not own
   // contribute the zeros their slots were allocated with), so every rank reads the sums of every set.
   void reduce_set_sums(int nslots) {
-    if (comm_) {
+    if (comm_ && merge_sums_) {            // their all-reduce rides with the residual sums of the next x-step (argmin_x_head)
+      K<T>::fin_sum(stream_, part_sets_, nslots, dres_, nullptr);
+      merged_nslots_ = nslots;
+    } else if (comm_) {
       K<T>::fin_sum(stream_, part_sets_, nslots, dres_, nullptr);
       comm_->allreduce_sum(dres_, (size_t)nslots, SIPX_F64, stream_);
       SIPX_HIP(hipMemcpyAsync(hres_, dres_, sizeof(double) * nslots, hipMemcpyDeviceToHost, stream_));
@@ -2386,6 +2538,41 @@ class Engine : public EngineBase {
     }
   }
 
+  void dump_ps(int set, const double* reg) {       // SIPX_SPEC_DEBUG: the state of a search as the device sees it (synchronises)
+    ProjScalars<T> h;
+    double r[PREP_SLOTS + 1];
+    SIPX_HIP(hipStreamSynchronize(stream_));
+    SIPX_HIP(hipMemcpy(&h, sets_[set].ps, sizeof(h), hipMemcpyDeviceToHost));
+    SIPX_HIP(hipMemcpy(r, reg, sizeof(r), hipMemcpyDeviceToHost));
+    std::fprintf(stderr, "[sipx spec]     set %d: need %d spec_ok %d refine %d lean %d ovf %d bracket (%.9g, %.9g] spec (%.9g, %.9g] n_compact %llu t0 %.9g t7 %.9g\n"
+                 "[sipx spec]       S", set, h.need, h.spec_ok, h.refine, h.lean, h.spec_overflow, h.lo, h.hi, h.spec_lo, h.spec_hi,
+                 (unsigned long long)h.n_compact, h.t[0], h.t[L1_K - 1]);
+    for (int k = 0; k < L1_K; ++k) std::fprintf(stderr, " %.6g", r[3 + k]);
+    std::fprintf(stderr, " C");
+    for (int k = 0; k < L1_K; ++k) std::fprintf(stderr, " %.0f", r[3 + L1_K + k]);
+    std::fprintf(stderr, " asum %.6g ovf %.0f\n", r[0], r[PREP_SLOTS]);
+    std::fprintf(stderr, "[sipx spec]       theta %.9g theta_prev %.9g hw %.4g sampled %d samp_theta %.9g samp (%.9g, %.9g) samp_c %.0f want_sample %d rescaled %d\n",
+                 (double)h.theta, h.theta_prev, h.hw, h.sampled, h.samp_theta, h.samp_lo, h.samp_hi, h.samp_c, h.want_sample, h.rescaled);
+  }
+
+  // the word k_spec_decide publishes for a set: (seq << 2) | verdict bits
+  unsigned wait_verdict(volatile unsigned* word, unsigned seq) {
+    for (unsigned spins = 1;; ++spins) {
+      const unsigned w = __atomic_load_n((unsigned*)word, __ATOMIC_ACQUIRE);
+      if ((w >> 2) == seq) return w & 3u;
+      if ((spins & 0xfff) == 0) {
+        const hipError_t q = hipStreamQuery(stream_);
+        if (q == hipSuccess) {
+          const unsigned w2 = __atomic_load_n((unsigned*)word, __ATOMIC_ACQUIRE);
+          if ((w2 >> 2) == seq) return w2 & 3u;
+          throw std::runtime_error("internal: the stream ran dry without the verdict of a threshold search (a kernel faulted?)");
+        }
+        if (q != hipErrorNotReady) SIPX_HIP(q);
+        (void)hipGetLastError();
+      }
+    }
+  }
+
   void free_set(SetState<T>& s) {
     if (s.st) (void)hipStreamSynchronize(s.st);
     if (s.ev) (void)hipEventDestroy(s.ev);
@@ -2408,7 +2595,7 @@ class Engine : public EngineBase {
     bool rhs_ready = false;        // the right-hand side of the coming iteration is already queued
     std::vector<double> rho, gamma, rho_new, rpri, rdual, feas;
   };
-  enum { MAXMARK = 8 };
+  enum { MAXMARK = 12 };
   Run run_;
   int device_ = 0, ndim_ = 2;
   hipStream_t stream_ = nullptr;
@@ -2444,6 +2631,11 @@ class Engine : public EngineBase {
   double* hres_ = nullptr;
   volatile int* hlean_ = nullptr;     // per set: the coming l1 search wants a sampled prediction (written by k_l1_solve)
   volatile int* hovf_ = nullptr;      // per set: the slab-decomposed search overflowed its exchange segments (k_gather_unpack)
+  volatile unsigned* hverd_ = nullptr;   // per set: verdict of the speculative exchange of a slab-decomposed search (k_spec_decide)
+  unsigned spec_seq_ = 0;
+  long long spec_searches_ = 0, spec_fallbacks_ = 0, spec_rounds_ = 0;     // searches through the speculative exchange / of those, fallbacks / refinement rounds (all-reduces) of the fallbacks
+  bool spec_exchange_ = true;         // SIPX_SPEC_EXCHANGE=0: every search through (all-reduce, ..., all-gather), as before
+  T* fbuf_ = nullptr;                 // fast segments: world x two-pass sets x (fcap + header)
   long long l1_sample_runs_ = 0;
   bool l1_sample_ = true;             // SIPX_L1_SAMPLE=0: no sampled prediction of theta (A/B switch)
   bool yl_multi_ = true;              // SIPX_YL_MULTI=0: never take the one-sweep y/l update (A/B switch)
@@ -2466,6 +2658,10 @@ class Engine : public EngineBase {
   double* dres_ = nullptr;                  // device copy of the reduced per-set sums (all-reduce buffer)
   hipEvent_t ev_sums_ = nullptr, ev_cgb_ = nullptr;
   bool sums_pending_ = false, defer_sums_ = false;
+  bool head_done_ = false;            // the residual product of the coming x-step is queued already (argmin_x_head)
+  bool merge_sums_ = false;           // sharded whole-solve loop: the coming reduction of the set sums leaves its all-reduce to argmin_x_head
+  int merged_nslots_ = 0;
+  bool resid_ahead_ = true;           // SIPX_RESID_AHEAD=0: the residual product waits for the host's stop rule, as before
   int sums_flags_ = 0;
   volatile unsigned long long* ticket_ = nullptr;   // pinned: verdict of the latest CG iteration (publish_ticket)
   unsigned cg_seq_ = 0;

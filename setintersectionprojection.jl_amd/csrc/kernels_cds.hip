@@ -723,7 +723,7 @@ __global__ __launch_bounds__(BLOCK) void k_cg_update_xr(long long N, T* __restri
                                                         const T* p, const T* __restrict__ Ap,
                                                         double* __restrict__ partials, CgState<T>* __restrict__ st,
                                                         CgState<T>* __restrict__ host, int iter,
-                                                        unsigned long long* ticket) {
+                                                        unsigned long long* ticket, long long hlo, long long hhi) {
   if (st->done) return;
   const double pAp = block_sum_partials(partials);
   const T gamma = st->rr;                   // dot(r,z), cg.jl:86 (not written by this kernel)
@@ -756,16 +756,22 @@ __global__ __launch_bounds__(BLOCK) void k_cg_update_xr(long long N, T* __restri
     stv<T, V>(x + vi * V, xv);
     stv<T, V>(r + vi * V, rv);
   }
+  // sharded: the planes of x next to this rank's rows follow along (the neighbour's x += alpha p on the copies of x and p held
+  // here: same alpha, same operands, same bits), so that x never has to be exchanged after the solve
+  for (long long j = (long long)blockIdx.x * BLOCK + threadIdx.x; j < hlo + hhi; j += (long long)gridDim.x * BLOCK) {
+    const long long i = j < hlo ? j - hlo : N + (j - hlo);
+    x[i] = x[i] + alpha * p[i];
+  }
   block_reduce_store<1>(acc, partials, 1);    // its own slot: other workgroups may still be reading slot 0
 }
 template <typename T>
 void K<T>::cg_update_xr(hipStream_t s, long long N, T* x, const T* r_in, T* r, const T* p, const T* Ap, double* partials,
-                        CgState<T>* st, CgState<T>* host, int iter, unsigned long long* ticket) {
+                        CgState<T>* st, CgState<T>* host, int iter, unsigned long long* ticket, long long hlo, long long hhi) {
   ObsScope obs(KID_CG_XR, s, 6.0 * (double)N * sizeof(T));        // x, r, p, Ap read; x, r written
   if (N % 4 == 0 && aligned16(x, r_in, r, p, Ap))
-    hipLaunchKernelGGL((k_cg_update_xr<T, 4>), dim3(fit_grid(N / 4, SIPX_CG_GRID)), dim3(BLOCK), 0, s, N, x, r_in, r, p, Ap, partials, st, host, iter, ticket);
+    hipLaunchKernelGGL((k_cg_update_xr<T, 4>), dim3(fit_grid(N / 4, SIPX_CG_GRID)), dim3(BLOCK), 0, s, N, x, r_in, r, p, Ap, partials, st, host, iter, ticket, hlo, hhi);
   else
-    hipLaunchKernelGGL((k_cg_update_xr<T, 1>), dim3(fit_grid(N, SIPX_CG_GRID)), dim3(BLOCK), 0, s, N, x, r_in, r, p, Ap, partials, st, host, iter, ticket);
+    hipLaunchKernelGGL((k_cg_update_xr<T, 1>), dim3(fit_grid(N, SIPX_CG_GRID)), dim3(BLOCK), 0, s, N, x, r_in, r, p, Ap, partials, st, host, iter, ticket, hlo, hhi);
   SIPX_HIP(hipGetLastError());
 }
 
@@ -773,7 +779,8 @@ void K<T>::cg_update_xr(hipStream_t s, long long N, T* x, const T* r_in, T* r, c
 template <typename T, int V>
 __global__ __launch_bounds__(BLOCK) void k_cg_update_p(long long N, T* __restrict__ p, const T* __restrict__ r,
                                                        const double* __restrict__ partials, CgState<T>* __restrict__ st,
-                                                       CgState<T>* __restrict__ host, unsigned long long* ticket) {
+                                                       CgState<T>* __restrict__ host, unsigned long long* ticket,
+                                                       long long hlo, long long hhi) {
   // `done` may be raised by workgroup 0 of this very launch: a workgroup that starts late and sees it returns, which is
   // what it would have decided from the partials anyway
   if (st->done) return;
@@ -804,15 +811,20 @@ __global__ __launch_bounds__(BLOCK) void k_cg_update_p(long long N, T* __restric
     for (int k = 0; k < V; ++k) pv.v[k] = rv.v[k] + beta * pv.v[k];
     stv<T, V>(p + vi * V, pv);
   }
+  // sharded: the neighbours' boundary planes of p are formed here from their planes of r (received) and the copy of p_k
+  for (long long j = (long long)blockIdx.x * BLOCK + threadIdx.x; j < hlo + hhi; j += (long long)gridDim.x * BLOCK) {
+    const long long i = j < hlo ? j - hlo : N + (j - hlo);
+    p[i] = r[i] + beta * p[i];
+  }
 }
 template <typename T>
 void K<T>::cg_update_p(hipStream_t s, long long N, T* p, const T* r, const double* partials, CgState<T>* st,
-                       CgState<T>* host, unsigned long long* ticket) {
+                       CgState<T>* host, unsigned long long* ticket, long long hlo, long long hhi) {
   ObsScope obs(KID_CG_P, s, 3.0 * (double)N * sizeof(T));         // r, p read; p written
   if (N % 4 == 0 && aligned16(p, r))
-    hipLaunchKernelGGL((k_cg_update_p<T, 4>), dim3(fit_grid(N / 4, NB)), dim3(BLOCK), 0, s, N, p, r, partials, st, host, ticket);
+    hipLaunchKernelGGL((k_cg_update_p<T, 4>), dim3(fit_grid(N / 4, NB)), dim3(BLOCK), 0, s, N, p, r, partials, st, host, ticket, hlo, hhi);
   else
-    hipLaunchKernelGGL((k_cg_update_p<T, 1>), dim3(fit_grid(N, NB)), dim3(BLOCK), 0, s, N, p, r, partials, st, host, ticket);
+    hipLaunchKernelGGL((k_cg_update_p<T, 1>), dim3(fit_grid(N, NB)), dim3(BLOCK), 0, s, N, p, r, partials, st, host, ticket, hlo, hhi);
   SIPX_HIP(hipGetLastError());
 }
 
@@ -933,9 +945,9 @@ void K<T>::fin_sum(hipStream_t s, const double* partials, int nslots, double* ou
   template void K<T>::gen_ata(hipStream_t, const Grid&, int, const int*, const T*, int, const long long*, T*);       \
   template void K<T>::cg_begin(hipStream_t, double*, CgState<T>*, CgState<T>*, int, T, unsigned, unsigned long long*);  \
   template void K<T>::cg_update_xr(hipStream_t, long long, T*, const T*, T*, const T*, const T*, double*, CgState<T>*, \
-                                   CgState<T>*, int, unsigned long long*);                                           \
+                                   CgState<T>*, int, unsigned long long*, long long, long long);                     \
   template void K<T>::cg_update_p(hipStream_t, long long, T*, const T*, const double*, CgState<T>*, CgState<T>*,     \
-                                  unsigned long long*);                                                              \
+                                  unsigned long long*, long long, long long);                                        \
   template void K<T>::fin_sum(hipStream_t, const double*, int, double*, double*);
 SIPX_INST(float)
 SIPX_INST(double)

@@ -284,6 +284,7 @@ __global__ void k_ps_init(ProjScalars<T>* ps, long long* cidx) {
   ps->pass_ticket = 0;
   ps->gather_overflow = 0;
   ps->rounds_used = 0;
+  ps->br_tl = ps->br_Sl = ps->br_Cl = ps->br_th = ps->br_Sh = ps->br_Ch = 0;
   ps->ovf = 0;
   for (int r = 0; r < 2 * SIPX_MAX_WORLD; ++r) ps->mm[r] = 0;
   ps->rescaled = 0;
@@ -340,6 +341,26 @@ __device__ __forceinline__ void reduce_slots(const double* __restrict__ partials
 // smallest non-zero magnitude.  A single workgroup summing all 19 x 2048 partials took 33 us at 256^3 and 135 us at 512^3
 // (its dependent batches of loads queue behind the streaming passes of the other set stream); spread over 20 workgroups
 // every load of a slot is in flight at once.
+template <typename T>
+__device__ __forceinline__ T next_up(T v);
+template <>
+__device__ __forceinline__ float next_up<float>(float v) { return nextafterf(v, INFINITY); }
+template <>
+__device__ __forceinline__ double next_up<double>(double v) { return nextafter(v, (double)INFINITY); }
+// Probes of a refinement round: L1_K values spread over [lo, hi], each a TF number strictly above the one before and strictly
+// inside (tl, th) -- the bracket [lo, hi] left by the Newton / secant steps is often narrower than the spacing of TF numbers,
+// and probes that coincide (or fall on tl / th themselves) would not shrink anything.  Unused probes are +Inf (skipped).
+template <typename T>
+__device__ __forceinline__ void place_probes(ProjScalars<T>* ps, double lo, double hi, double tl, double th) {
+  T prev = (T)tl;
+  const T top = (T)th;
+  for (int k = 0; k < L1_K; ++k) {
+    T tc = (T)(lo + (hi - lo) * (double)k / (double)(L1_K - 1));
+    if (!(tc > prev)) tc = next_up<T>(prev);
+    if (tc < top) { ps->t[k] = (double)tc; prev = tc; }
+    else ps->t[k] = INFINITY;
+  }
+}
 template <typename T, int STAGE>
 __device__ void decide_body(ProjScalars<T>* ps, int prox, T pmin, T pmax, long long true_len, int nospec, double capdiv, int world,
                             double cap_max, const double* reg);
@@ -468,7 +489,7 @@ __device__ void decide_body(ProjScalars<T>* ps, int prox, T pmin, T pmax, long l
       const double S3 = red[3 + L1_WIN_LO], C3 = red[3 + L1_K + L1_WIN_LO], S4 = red[3 + L1_WIN_HI], C4 = red[3 + L1_K + L1_WIN_HI];
       const double f3 = S3 - t3 * C3 - b, f4 = S4 - t4 * C4 - b;
       ps->lean = 0;
-      if (f3 >= 0 && f4 < 0 && !ps->spec_overflow && !nospec && !(cap_max > 0 && C3 - C4 > cap_max)) {
+      if (f3 >= 0 && f4 < 0 && !ps->spec_overflow && !(nospec & 1) && !(cap_max > 0 && C3 - C4 > cap_max)) {
         double thN = C3 > 0 ? (S3 - b) / C3 : t3;
         if (!(thN >= t3)) thN = t3;
         double thS = t3 + f3 * (t4 - t3) / (f3 - f4);
@@ -484,19 +505,50 @@ __device__ void decide_body(ProjScalars<T>* ps, int prox, T pmin, T pmax, long l
         return;
       }
       ps->n_compact = 0;                                     // discard what the speculation gathered
+      ps->vmax = (T)ps->asum;                                // a valid upper bound of every magnitude
+      if (f3 >= 0 && f4 < 0 && !(nospec & 2)) {
+        // theta* IS inside the range, but what the range gathered cannot be used (an LDS buffer or an exchange segment overflowed,
+        // or it holds more than the caller can take): the bracket is the range tightened by the Newton / secant steps; it is
+        // gathered at once by the compaction pass if it is small enough, and subdivided by refinement rounds first if not
+        double thN = C3 > 0 ? (S3 - b) / C3 : t3;
+        if (!(thN >= t3)) thN = t3;
+        double thS = t3 + f3 * (t4 - t3) / (f3 - f4);
+        if (!(thS <= t4)) thS = t4;
+        if (!(thS >= thN)) thS = t4;
+        double lo = thN * (1.0 - 1e-9), hi = thS * (1.0 + 1e-9) + 1e-300;
+        lo = lo > t3 ? lo : t3;
+        hi = hi < t4 ? hi : t4;
+        ps->lo = lo;
+        ps->hi = hi;
+        double cap = fmax(L1_CAP, (double)true_len / capdiv);
+        if (cap_max > 0 && cap > cap_max) cap = cap_max;
+        double pop = C3 - C4;
+        if (t4 > t3 && !(cap_max > 0)) pop *= fmin(1.0, 2.0 * (hi - lo) / (t4 - t3));
+        ps->br_tl = t3; ps->br_Sl = S3; ps->br_Cl = C3; ps->br_th = t4; ps->br_Sh = S4; ps->br_Ch = C4;
+        if (next_up<T>((T)t3) >= (T)t4) {                    // no magnitude can lie strictly between: see the end of this function
+          ps->lo = ps->hi = t3;
+        } else if (pop > cap && hi > lo) {
+          ps->refine = 1;
+          ps->rounds_used = 1;
+          place_probes<T>(ps, lo, hi, t3, t4);
+        }
+        return;
+      }
       ps->refine = 1;
       ps->rounds_used = 1;
-      ps->vmax = (T)ps->asum;                                // a valid upper bound of every magnitude
       if (f4 >= 0) {                                         // theta* >= spec_hi: geometric probes above it
         ps->lo = t4;
         ps->hi = ps->asum;
         double step = (t4 - t3) > 0 ? (t4 - t3) : t4 * 1e-3;
         for (int k = 0; k < L1_K; ++k) { step *= 4.0; ps->t[k] = (double)(T)(t4 + step); }
+        ps->br_tl = t4; ps->br_Sl = S4; ps->br_Cl = C4; ps->br_th = ps->asum; ps->br_Sh = 0; ps->br_Ch = 0;
       } else {                                               // theta* < spec_lo: geometric probes below it
         ps->lo = 0;
         ps->hi = t3;
         double step = (t4 - t3) > 0 ? (t4 - t3) : t3 * 1e-3;
         for (int k = L1_K - 1; k >= 0; --k) { step *= 4.0; const double t = t3 - step; ps->t[k] = t > 0 ? (double)(T)t : 0.0; }
+        // (a lean pass does not count the non-zero entries: C(0) unknown until a probe below theta has been evaluated)
+        ps->br_tl = 0; ps->br_Sl = ps->asum; ps->br_Cl = -1.0; ps->br_th = t3; ps->br_Sh = S3; ps->br_Ch = C3;
       }
       return;
     }
@@ -504,28 +556,30 @@ __device__ void decide_body(ProjScalars<T>* ps, int prox, T pmin, T pmax, long l
     vmax = ps->vmax;
   }
   const double b = (double)pmax;
-  // candidates: virtual t=0 (S=||v||_1, C=nnz), the probes, virtual t=vmax (S=C=0)
-  double tl = 0, Sl = ps->asum, Cl = red[2], fl = ps->asum - b;
-  double th = (double)vmax, Ch = 0, fh = -b;
-  bool have_l = STAGE == 0, have_h = STAGE == 0;
-  if (STAGE == 1) { tl = ps->lo; th = ps->hi; fl = INFINITY; }
+  // The two probes that bracket theta*, with their exact (S, C): tl (f >= 0) and th (f < 0).  STAGE 0 starts from the virtual
+  // probes t = 0 (S = ||v||_1, C = nnz) and t = vmax (S = C = 0); a refinement round starts from the pair the previous decision
+  // left in ps->br_* -- so the bracket only ever shrinks and C(tl) - C(th) is the exact count of what lies in (tl, th].
+  double tl = 0, Sl = ps->asum, Cl = red[2];
+  double th = (double)vmax, Sh = 0, Ch = 0;
+  if (STAGE == 1) { tl = ps->br_tl; Sl = ps->br_Sl; Cl = ps->br_Cl; th = ps->br_th; Sh = ps->br_Sh; Ch = ps->br_Ch; }
   for (int k = 0; k < L1_K; ++k) {
     const double t = ps->t[k];
     if (!(t < INFINITY)) continue;
     const double S = red[3 + k], C = red[3 + L1_K + k];
     const double f = S - t * C - b;
     if (f >= 0) {
-      if (!have_l || t >= tl) { tl = t; Sl = S; Cl = C; fl = f; have_l = true; }
-    } else if (t < th || (!have_h && t <= th)) {
-      th = t; Ch = C; fh = f; have_h = true;
+      if (t >= tl) { tl = t; Sl = S; Cl = C; }
+    } else if (t <= th) {
+      th = t; Sh = S; Ch = C;
     }
   }
-  if (!have_l) { tl = 0; Sl = ps->asum; Cl = red[2]; fl = ps->asum - b; }
+  const bool know_l = Cl >= 0;                 // (C(0) is not known after a lean pass)
+  const double fl = know_l ? Sl - tl * Cl - b : INFINITY, fh = Sh - th * Ch - b;
   // Newton from the left (Michelot step) and secant from the right: theta* in [thN, thS]
-  double thN = Cl > 0 ? (Sl - b) / Cl : tl;
+  double thN = (know_l && Cl > 0) ? (Sl - b) / Cl : tl;
   if (!(thN >= tl)) thN = tl;
   double thS = th;
-  if (have_h && fl < INFINITY && fl - fh > 0) thS = tl + fl * (th - tl) / (fl - fh);
+  if (fl < INFINITY && fl - fh > 0) thS = tl + fl * (th - tl) / (fl - fh);
   if (!(thS <= th)) thS = th;
   if (!(thS >= thN)) thS = th;
   double lo = thN * (1.0 - 1e-9), hi = thS * (1.0 + 1e-9) + 1e-300;
@@ -533,10 +587,11 @@ __device__ void decide_body(ProjScalars<T>* ps, int prox, T pmin, T pmax, long l
   hi = hi < th ? hi : th;
   ps->lo = lo;
   ps->hi = hi;
+  ps->br_tl = tl; ps->br_Sl = Sl; ps->br_Cl = Cl; ps->br_th = th; ps->br_Sh = Sh; ps->br_Ch = Ch;
   if (STAGE == 0) {
     // speculative gather usable?  range edges are probes L1_WIN_LO and L1_WIN_HI, so (S,C) above it are known
     // (slab-decomposed: what the range gathered over all ranks, C(spec_lo) - C(spec_hi), has to fit a rank's exchange segment)
-    const bool spec = !nospec && ps->spec_hi > ps->spec_lo && !ps->spec_overflow && lo >= ps->spec_lo && hi <= ps->spec_hi &&
+    const bool spec = !(nospec & 1) && ps->spec_hi > ps->spec_lo && !ps->spec_overflow && lo >= ps->spec_lo && hi <= ps->spec_hi &&
                       !(cap_max > 0 && red[3 + L1_K + L1_WIN_LO] - red[3 + L1_K + L1_WIN_HI] > cap_max);
     if (spec) {
       ps->spec_ok = 1;
@@ -554,16 +609,22 @@ __device__ void decide_body(ProjScalars<T>* ps, int prox, T pmin, T pmax, long l
   if (cap_max > 0 && cap > cap_max) cap = cap_max;
   // population of the tightened bracket (lo, hi]: the count between the two probes, scaled by the share of the interval
   // that is left (factor 2 for a density that is not flat).  A wrong guess only costs time: the gather never drops.
-  double pop = Cl - Ch;
+  double pop = (know_l ? Cl : (double)true_len) - Ch;
   // Slab-decomposed (cap_max > 0): what the final bracket gathers over ALL ranks has to fit the exchange segments, and a
   // rank cannot keep what does not fit -- so the count between the two bracketing probes is taken as it is (an upper bound of
-  // what (lo, hi] holds), and refinement goes on, round after round (as many as the caller enqueued), until it fits.
+  // what (lo, hi] holds), and refinement goes on, round after round, until it fits.
   if (th > tl && !(cap_max > 0)) pop *= fmin(1.0, 2.0 * (hi - lo) / (th - tl));
   const int max_refines = cap_max > 0 ? L1_REFINES_SLAB : L1_REFINES;
-  if (pop > cap && hi > lo && (STAGE == 0 || ps->refine < max_refines)) {
+  if (know_l && next_up<T>((T)tl) >= (T)th) {
+    // tl and th are neighbours in TF: no magnitude lies strictly between them, so {|v| > t} is the same set for every t in
+    // [tl, th) and f is linear there -- its root, the Newton step from tl, IS theta*.  Nothing has to be gathered, however many
+    // magnitudes equal th (ties: no bracket could separate them): the compaction pass sums what lies above tl and gathers nothing.
+    ps->lo = ps->hi = tl;
+    ps->refine = 0;
+  } else if (pop > cap && hi > lo && (STAGE == 0 || ps->refine < max_refines)) {
     ps->refine = (STAGE == 0) ? 1 : ps->refine + 1;
     ps->rounds_used = ps->refine;
-    for (int k = 0; k < L1_K; ++k) ps->t[k] = (double)(T)(lo + (hi - lo) * (double)k / (double)(L1_K - 1));
+    place_probes<T>(ps, lo, hi, tl, th);
   } else {
     ps->refine = 0;
   }
@@ -578,6 +639,18 @@ __global__ __launch_bounds__(64) void k_decide(ProjScalars<T>* ps, int prox, T p
   decide_body<T, STAGE>(ps, prox, pmin, pmax, true_len, nospec, capdiv, world, cap_max, reg);
 }
 
+
+// ... and, in the fallback of a speculative exchange, with the verdict the host reads: does this set need another refinement round?
+template <typename T>
+__global__ __launch_bounds__(64) void k_decide_round(ProjScalars<T>* ps, int prox, T pmin, T pmax, long long true_len, double capdiv,
+                                                     int world, double cap_max, const double* __restrict__ reg, unsigned seq,
+                                                     unsigned* verdict) {
+  if (threadIdx.x != 0) return;
+  const bool live = ps->need && !ps->spec_ok && ps->refine;
+  if (live) decide_body<T, 1>(ps, prox, pmin, pmax, true_len, 0, capdiv, world, cap_max, reg);
+  const unsigned word = (seq << 2) | 1u | ((live && ps->refine) ? 2u : 0u);
+  __hip_atomic_store(verdict, word, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
 
 // ---------------------------------------------------------------------------------------------
 // SAMPLED PREDICTION of theta.  While rho and gamma are still being adapted, theta moves by up to a factor of three from one
@@ -956,8 +1029,11 @@ static_assert(SOLVE_G <= SIPX_SOLVE_SLOTS, "ProjScalars holds SIPX_SOLVE_SLOTS c
 template <typename T>
 __global__ __launch_bounds__(SIPX_SOLVE_NT) void k_l1_solve(ProjScalars<T>* ps, T radius, const T* __restrict__ compact,
                                                    const double* __restrict__ partials, long long true_len, double hw_max,
-                                                   int lean_on, int* host_want, long long coop_min) {
+                                                   int lean_on, int* host_want, long long coop_min, int only_if_settled) {
   constexpr int NT = SIPX_SOLVE_NT;
+  // (slab-decomposed, speculative exchange: queued before the host knows whether the search needs its fallback sweeps --
+  //  then this launch is not the one that solves it)
+  if (only_if_settled && ps->need && !ps->spec_ok) return;
   __shared__ double ssum[NT / 64];
   __shared__ double ssum_lo[NT / 64];
   __shared__ double scnt[NT / 64];
@@ -1316,6 +1392,88 @@ __global__ __launch_bounds__(BLOCK) void k_gather_unpack(ProjScalars<T>* ps, T* 
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Slab-decomposed grid, SPECULATIVE EXCHANGE: one all-gather instead of (all-reduce, all-reduce, ..., all-gather) whenever the
+// speculative range of the first pass holds theta -- which is the rule once rho and gamma have settled.  After its first pass a
+// rank knows its share of the probe sums and has gathered its magnitudes inside the speculative range; k_spec_pack puts both
+// into the rank's FAST segment (header: the PREP_SLOTS sums, overflow flag, largest / smallest non-zero magnitude, count; then
+// the values, at most `cap` of them).  After the all-gather every rank adds the headers up in rank order (k_spec_decide: the
+// same numbers in the same order on every rank, so the same decision, bit for bit), takes the first-pass decision on the sums
+// and -- when the range held theta -- strings the gathered values together (k_spec_unpack) and solves.  Otherwise (theta left
+// the range, the LDS buffers or a fast segment overflowed) the search falls back to its refinement rounds and the full-size
+// exchange; the host learns which from one pinned word per set and enqueues the collectives of the fallback only then.
+constexpr int FH_OVF = PREP_SLOTS, FH_MAX = PREP_SLOTS + 1, FH_MIN = PREP_SLOTS + 2, FH_CNT = PREP_SLOTS + 3;
+
+template <typename T>
+__global__ __launch_bounds__(BLOCK) void k_spec_pack(const ProjScalars<T>* ps, const double* __restrict__ reg, int rank, int is_l1,
+                                                     const T* __restrict__ compact, T* __restrict__ seg, long long cap) {
+  // reg: what k_slot_sums<0> left for this rank -- sums | ovf | (max, min) in the rank's own two entries
+  const long long n = is_l1 ? (long long)ps->n_compact : 0;
+  if (blockIdx.x == 0 && threadIdx.x < PREP_SLOTS + 4) {
+    double* h = reinterpret_cast<double*>(seg);
+    const int i = threadIdx.x;
+    double v;
+    if (i <= FH_OVF) v = reg[i];
+    else if (i == FH_MAX) v = reg[PREP_SLOTS + 1 + 2 * rank];
+    else if (i == FH_MIN) v = reg[PREP_SLOTS + 1 + 2 * rank + 1];
+    else v = n <= cap ? (double)n : -1.0;                  // -1: more than the fast segment holds
+    h[i] = v;
+  }
+  const long long m = n <= cap ? n : 0;
+  for (long long i = (long long)blockIdx.x * BLOCK + threadIdx.x; i < m; i += (long long)gridDim.x * BLOCK) seg[fast_hdr<T>() + i] = compact[i];
+}
+
+template <typename T>
+__global__ __launch_bounds__(64) void k_spec_decide(ProjScalars<T>* ps, DecideArgs da, int world, double* __restrict__ reg,
+                                                    const T* __restrict__ fseg0, long long fchunk, unsigned seq, unsigned* verdict) {
+  // reg (the set's region of the staging buffer) receives the summed header: the stages of the fallback read it there
+  __shared__ double sreg[PREP_SLOTS + 1 + 2 * SIPX_MAX_WORLD];
+  __shared__ double scount;
+  const int i = threadIdx.x;
+  if (i <= FH_OVF) {
+    double v = 0;
+    for (int r = 0; r < world; ++r) v += reinterpret_cast<const double*>(fseg0 + (long long)r * fchunk)[i];
+    sreg[i] = v;
+  }
+  if (i == FH_CNT) {
+    double tot = 0;
+    bool bad = false;
+    for (int r = 0; r < world; ++r) {
+      const double* h = reinterpret_cast<const double*>(fseg0 + (long long)r * fchunk);
+      sreg[PREP_SLOTS + 1 + 2 * r] = h[FH_MAX];
+      sreg[PREP_SLOTS + 1 + 2 * r + 1] = h[FH_MIN];
+      if (h[FH_CNT] < 0) bad = true; else tot += h[FH_CNT];
+    }
+    scount = bad ? -1.0 : tot;
+  }
+  __syncthreads();
+  if (i == 0 && scount < 0) sreg[FH_OVF] += 1.0;           // a fast segment overflowed: as if the speculation had
+  __syncthreads();
+  if (i < PREP_SLOTS + 1 + 2 * world) reg[i] = sreg[i];
+  if (i != 0) return;
+  decide_body<T, 0>(ps, da.prox, (T)da.pmin, (T)da.pmax, da.true_len, da.nospec, da.capdiv, world, da.cap_max, sreg);
+  const bool settled = !(da.prox == PX_L1 && ps->need && !ps->spec_ok);
+  if (da.prox == PX_L1 && ps->need && ps->spec_ok) ps->n_compact = (unsigned long long)scount;     // what k_spec_unpack strings together
+  ps->gather_overflow = 0;
+  // bit 0: the fallback has to run; bit 1: it starts with refinement rounds (else the bracket is gathered at once)
+  const unsigned word = (seq << 2) | (settled ? 0u : 1u) | ((!settled && ps->refine) ? 2u : 0u);
+  __hip_atomic_store(verdict, word, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
+template <typename T>
+__global__ __launch_bounds__(BLOCK) void k_spec_unpack(const ProjScalars<T>* ps, T* __restrict__ compact, const T* __restrict__ fseg0,
+                                                       long long fchunk, int world) {
+  if (!(ps->need && ps->spec_ok)) return;
+  long long off = 0;
+  for (int r = 0; r < world; ++r) {
+    const T* seg = fseg0 + (long long)r * fchunk;
+    const long long n = (long long)reinterpret_cast<const double*>(seg)[FH_CNT];
+    const T* v = seg + fast_hdr<T>();
+    for (long long i = (long long)blockIdx.x * BLOCK + threadIdx.x; i < n; i += (long long)gridDim.x * BLOCK) compact[off + i] = v[i];
+    off += n;
+  }
+}
+
 // v = x_hat - l/rho: where the multiplier term dominates, theta moves like 1/rho when rho is changed.  Re-centre the
 // probes of the coming call on the scaled prediction (and widen the range: the prediction is good to a few percent).
 template <typename T>
@@ -1364,7 +1522,8 @@ static void chain_stage(int stage, hipStream_t s, const Grid& g, const SetArgs<T
   const double cap_max = hk ? (double)hk->gcap : 0.0;      // what ALL ranks gather together fits one rank's segment
   const bool vec = SRC == 1 && g.n[0] % 4 == 0;
   static const double capdiv = [] { const char* e = getenv("SIPX_L1_CAPDIV"); return e ? atof(e) : 64.0; }();
-  const DecideArgs da0{a.prox, (a.flags & F_NOSPEC) ? 1 : 0, (double)a.plo, (double)a.phi, capdiv, cap_max, true_len};
+  static const int legacy_lean = [] { const char* e = getenv("SIPX_LEAN_LEGACY"); return (e && e[0] == '1') ? 2 : 0; }();     // bisecting aid
+  const DecideArgs da0{a.prox, ((a.flags & F_NOSPEC) ? 1 : 0) | legacy_lean, (double)a.plo, (double)a.phi, capdiv, cap_max, true_len};
   const DecideArgs da1{a.prox, 0, (double)a.plo, (double)a.phi, capdiv, cap_max, true_len};
 #define SIPX_PASS(MODE)                                                                                            \
   do {                                                                                                             \
@@ -1393,6 +1552,7 @@ static void chain_stage(int stage, hipStream_t s, const Grid& g, const SetArgs<T
       const long long per_rank = hk ? (g.N / world + 3) / 4 : range_len(g) / 4;     // vectors of a full slab
       double gcap = 0.2 * (double)fit_grid(per_rank, SIPX_PASS_GRID) * (double)SPEC_CAP * (double)world;   // a fifth of the LDS buffers of the pass
       if (hk && gcap > 0.8 * cap_max) gcap = 0.8 * cap_max;
+      if (hk && hk->fcap > 0 && gcap > 0.5 * (double)hk->fcap * (double)world) gcap = 0.5 * (double)hk->fcap * (double)world;   // the fast segments of the speculative exchange (margin: the ranks' shares are not equal)
       // (below 2^24 grid points the extra launch costs more than the sweeps it saves: 2048^2 loses 3 %; a test may force it)
       if (stride >= 4 && (g.N >= (1ll << 24) || ctl.runs > 0)) {
         const long long nsamp = nchunks / stride;            // may be 0 on a short slab
@@ -1416,10 +1576,40 @@ static void chain_stage(int stage, hipStream_t s, const Grid& g, const SetArgs<T
     ObsScope obs_(KID_SLOT_SUMS, s, 0.0);
     if (hk) hipLaunchKernelGGL((k_slot_sums<T, 0, false>), dim3(PREP_SLOTS + 1), dim3(BLOCK), 0, s, partials, maxpart, ps, rank, world, reg, da0);
     else hipLaunchKernelGGL((k_slot_sums<T, 0, true>), dim3(PREP_SLOTS + 1), dim3(BLOCK), 0, s, partials, maxpart, ps, rank, world, reg, da0);
-  } else if (stage == 1) {
-    if (hk) {
+  } else if (stage == 5) {      // speculative exchange: this rank's sums and speculatively gathered magnitudes into its fast segment
+    ObsScope obs_(KID_GATHER, s, 0.0);
+    hipLaunchKernelGGL((k_spec_pack<T>), dim3(16), dim3(BLOCK), 0, s, ps, reg, rank, a.prox == PX_L1 ? 1 : 0, compact, gseg0 + (long long)rank * chunk,
+                       hk->fcap);
+  } else if (stage == 6) {      // ... after the all-gather: decision on the summed headers, the values strung together, the solve
+    {
       ObsScope obs_(KID_DECIDE, s, 0.0);
-      hipLaunchKernelGGL((k_decide<T, 0>), dim3(1), dim3(64), 0, s, ps, a.prox, a.plo, a.phi, true_len, (a.flags & F_NOSPEC) ? 1 : 0, capdiv,
+      hipLaunchKernelGGL((k_spec_decide<T>), dim3(1), dim3(64), 0, s, ps, da0, world, reg, gseg0, chunk, ctl.seq, ctl.verdict);
+    }
+    if (a.prox == PX_L1) {
+      {
+        ObsScope obs_(KID_GATHER, s, 0.0);
+        hipLaunchKernelGGL((k_spec_unpack<T>), dim3(16), dim3(BLOCK), 0, s, ps, compact, gseg0, chunk, world);
+      }
+      ObsScope obs_(KID_L1_SOLVE, s, 0.0);
+      hipLaunchKernelGGL((k_l1_solve<T>), dim3(1), dim3(SIPX_SOLVE_NT), 0, s, ps, a.phi, compact, partials, true_len, l1_hw_max(), l1_lean_on(),
+                         ctl.host_want, solve_coop_min(), 1);
+    }
+  } else if (stage == 9) {      // fallback of a speculative exchange: decision on the all-reduced sums of a refinement round + verdict
+    if (a.prox == PX_L1) {
+      ObsScope obs_(KID_DECIDE, s, 0.0);
+      hipLaunchKernelGGL((k_decide_round<T>), dim3(1), dim3(64), 0, s, ps, a.prox, a.plo, a.phi, true_len, capdiv, world, cap_max, reg, ctl.seq,
+                         ctl.verdict);
+    }
+  } else if (stage == 12) {     // ... its bracket is final: gated compaction pass, the rank's magnitudes into its segment
+    if (a.prox == PX_L1) {
+      SIPX_PASS(M_COMPACT);
+      ObsScope obs_(KID_GATHER, s, 0.0);
+      hipLaunchKernelGGL((k_gather_pack<T>), dim3(64), dim3(BLOCK), 0, s, ps, compact, partials, gseg0 + (long long)rank * chunk, hk->gcap);
+    }
+  } else if (stage == 1 || stage == 8) {      // (8: a refinement round whose decision was taken already -- k_spec_decide, k_decide_round)
+    if (hk && stage == 1) {
+      ObsScope obs_(KID_DECIDE, s, 0.0);
+      hipLaunchKernelGGL((k_decide<T, 0>), dim3(1), dim3(64), 0, s, ps, a.prox, a.plo, a.phi, true_len, da0.nospec, capdiv,
                          world, cap_max, reg);
     }
     if (a.prox == PX_L1) {
@@ -1458,7 +1648,7 @@ static void chain_stage(int stage, hipStream_t s, const Grid& g, const SetArgs<T
     }
     ObsScope obs_(KID_L1_SOLVE, s, 0.0);
     hipLaunchKernelGGL((k_l1_solve<T>), dim3(hk ? 1 : SOLVE_G), dim3(SIPX_SOLVE_NT), 0, s, ps, a.phi, compact, partials, true_len, l1_hw_max(),
-                       l1_lean_on(), ctl.host_want, solve_coop_min());
+                       l1_lean_on(), ctl.host_want, solve_coop_min(), 0);
   }
 #undef SIPX_PASS
   SIPX_HIP(hipGetLastError());

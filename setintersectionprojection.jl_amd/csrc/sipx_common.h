@@ -42,6 +42,10 @@ constexpr int L1_K = 8;          // probe thresholds of the l1-ball threshold se
 #define SIPX_MAX_WORLD 64        // most ranks of a slab-decomposed solve (per-rank max / min entries in ProjScalars)
 constexpr int GATHER_HDR = 8;    // TF elements in front of a rank's segment of gathered magnitudes (read as doubles: count, S_above, C_above)
 constexpr int PREP_SLOTS = 3 + 2 * L1_K;   // ||v||_1, ||v||_2^2, nnz, S_k, C_k
+// header of a rank's FAST segment (speculative exchange of a slab-decomposed search), in TF elements: the PREP_SLOTS sums,
+// overflow flag, largest / smallest non-zero magnitude, count -- as doubles
+template <typename T>
+constexpr int fast_hdr() { return ((PREP_SLOTS + 4) * 8 / (int)sizeof(T) + 3) / 4 * 4; }
 // Sampled prediction of the l1 threshold (k_sample, sample_decide): histogram of the sampled magnitudes over
 // SAMPLE_BINS bins of 2^-SAMPLE_MBITS of an octave each (the bin key is the leading bits of the floating-point pattern),
 // centred on the predicted theta
@@ -191,6 +195,9 @@ struct ProjScalars {
   long long quota;    // entries equal to tau are kept iff their padded index <= quota (idx cut)
   long long* cidx;    // device buffer for the indices of the gathered magnitudes
   double c_lo, c_hi;  // counts of |v| > lo and |v| > hi of the current bracket
+  // l1 search: the two PROBES that bracket theta* (f(br_tl) >= 0 > f(br_th)) with their exact sums and counts, carried from
+  // one decision to the next so that refinement rounds only ever shrink the bracket (br_Cl < 0: count not known)
+  double br_tl, br_Sl, br_Cl, br_th, br_Sh, br_Ch;
   T tau_prev;
   // sums of the PREP_SLOTS partial slots of the last probe pass, its largest / smallest non-zero magnitude (k_slot_sums)
   // On a slab-decomposed grid ONE all-reduce (sum) over red, ovf and mm makes them global: mm holds (largest, smallest
@@ -226,6 +233,7 @@ struct ChainHooks {
   void (*allgather)(void* user, void* buf, size_t chunk, int dtype_is_f64, hipStream_t s) = nullptr;  // in place, chunk elements per rank
   void* gbuf = nullptr;          // world * (gcap + GATHER_HDR) TF elements
   long long gcap = 0;            // gathered magnitudes a rank may contribute
+  long long fcap = 0;            // ... to the speculative exchange (fast segments: what a settled search gathers is small)
 };
 
 struct SampleCtl {
@@ -235,6 +243,9 @@ struct SampleCtl {
   // pinned word of the set (slab-decomposed grid): raised by k_gather_unpack when the magnitudes gathered inside the final
   // bracket over all ranks did not fit the exchange segments -- the host turns it into an error return (never NaN iterates)
   int* host_ovf = nullptr;
+  // speculative exchange (slab-decomposed grid): pinned word of the set that k_spec_decide publishes, (seq << 2) | verdict bits
+  unsigned* verdict = nullptr;
+  unsigned seq = 0;
 };
 
 template <typename T>
@@ -375,9 +386,10 @@ struct K {
   static void cg_begin(hipStream_t s, double* partials, CgState<T>* st, CgState<T>* host, int it_outer, T tol_ref,
                        unsigned seq, unsigned long long* ticket);
   static void cg_update_xr(hipStream_t s, long long N, T* x, const T* r_in, T* r, const T* p, const T* Ap, double* partials,
-                           CgState<T>* st, CgState<T>* host, int iter, unsigned long long* ticket);
+                           CgState<T>* st, CgState<T>* host, int iter, unsigned long long* ticket, long long hlo = 0,
+                           long long hhi = 0);      // hlo / hhi: elements in front of / behind the range whose x (p) follows along
   static void cg_update_p(hipStream_t s, long long N, T* p, const T* r, const double* partials, CgState<T>* st,
-                          CgState<T>* host, unsigned long long* ticket);
+                          CgState<T>* host, unsigned long long* ticket, long long hlo = 0, long long hhi = 0);
   // sets
   static void rhs_compose(hipStream_t s, const Grid& g, const RhsArgs<T>& a, T* rhs, int accumulate);
   static void yl(hipStream_t s, const Grid& g, const SetArgs<T>& a, double* partials);

@@ -387,6 +387,10 @@ def PARSDMM_sharded(m, AtA, TD_OP, set_Prop, P_sub, comp_grid, options, dist=Non
             log, feasible = drv.result_log(), drv.stopped_feasible
         else:
             log, feasible = ctx.parsdmm(options)
+        try:        # slab-decomposed: how many threshold searches the speculative exchange settled (engine counters; diagnostics)
+            log.slab_searches = ctx.kernel_stats_all(0).get("slab_searches")
+        except Exception:
+            log.slab_searches = None
         if feasible:
             return np.array(m, copy=True), log, None, None
         xo, lo, yo = ctx.download()

@@ -106,7 +106,9 @@ def _slab_worker(rank, world, port, out, kinds, n, env):
         gs, os_, Ps, As, props, AtAs = _problem(sipx, n, h, TF, kinds, m, dict(maxit=40))
         try:
             x, log, l, y = sharded.PARSDMM_sharded(m.copy(), AtAs, As, props, Ps, gs, os_, dist=dist, device=0, comm_mode="torch", decomp="slab")
-            np.savez(os.path.join(out, f"r{rank}.npz"), x=x, obj=log.obj, cg_it=log.cg_it, rho=log.rho, r_pri=log.r_pri, err="")
+            ss = getattr(log, "slab_searches", None) or {}
+            np.savez(os.path.join(out, f"r{rank}.npz"), x=x, obj=log.obj, cg_it=log.cg_it, rho=log.rho, r_pri=log.r_pri, err="",
+                     searches=np.array([ss.get("speculative_exchange", -1), ss.get("fallbacks", -1)]))
         except sipx.SipxError as e:
             np.savez(os.path.join(out, f"r{rank}.npz"), err=str(e))
     finally:
@@ -323,3 +325,31 @@ def test_slab_search_refines_until_the_bracket_fits(sipx, tmp_path):
     gs, os_, Ps, As, props, AtAs = _problem(sipx, n, h, TF, kinds, m, dict(maxit=40))
     xs, ls, _, _ = sipx.PARSDMM(m.copy(), AtAs, As, props, Ps, gs, os_)
     assert np.linalg.norm(r0["x"] - xs) / np.linalg.norm(xs) < 5e-4
+
+
+@pytest.mark.timeout(600)
+def test_slab_searches_settle_in_one_exchange(sipx, tmp_path, monkeypatch):
+    """Slab-decomposed threshold searches through the speculative exchange (one all-gather carrying every rank's probe sums and the
+    magnitudes it gathered inside the speculative range): most searches of a solve are settled by it -- the fallback
+    (refinement rounds + full-size exchange) runs for the others -- and the iterates are the ones the staged protocol
+    (SIPX_SPEC_EXCHANGE=0: all-reduce, ..., all-gather for every search) arrives at, bit for bit, on every rank."""
+    import torch.multiprocessing as mp
+    world, kinds, n = 2, ["bounds", "l1:D_x", "l1:D_z"], (48, 32, 24)
+    res = {}
+    for tag, env in (("spec", {}), ("staged", {"SIPX_SPEC_EXCHANGE": "0"}), ("tiny", {"SIPX_GATHER_FAST_CAP": "8"})):
+        d = tmp_path / tag
+        d.mkdir()
+        mp.spawn(_slab_worker, args=(world, 30900 + os.getpid() % 1000 + len(res), str(d), kinds, n, env), nprocs=world, join=True)
+        r0, r1 = np.load(d / "r0.npz"), np.load(d / "r1.npz")
+        assert str(r0["err"]) == "" and str(r1["err"]) == ""
+        for k in ("x", "obj", "cg_it", "rho", "r_pri", "searches"):
+            assert np.array_equal(r0[k], r1[k], equal_nan=True), (tag, k)
+        res[tag] = r0
+    n_s, n_f = res["spec"]["searches"]
+    assert n_s > 0 and n_f < n_s, (n_s, n_f)                        # searches were settled by the exchange (while rho, gamma are
+                                                                     # still adapted theta leaves the range on many iterations)
+    assert res["staged"]["searches"][0] == 0
+    assert res["tiny"]["searches"][1] > n_f                          # fast segments of 8 values: (almost) every l1 search falls back ...
+    for k in ("x", "obj", "cg_it", "rho", "r_pri"):                  # ... and all three protocols end with the same bits
+        assert np.array_equal(res["spec"][k], res["staged"][k], equal_nan=True), k
+        assert np.array_equal(res["spec"][k], res["tiny"][k], equal_nan=True), k
