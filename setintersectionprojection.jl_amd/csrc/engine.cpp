@@ -166,6 +166,7 @@ class Engine : public EngineBase {
     SIPX_HIP(hipSetDevice(device));
     SIPX_HIP(hipStreamCreateWithFlags(&stream_, hipStreamNonBlocking));
     SIPX_HIP(hipEventCreateWithFlags(&ev_fork_, hipEventDisableTiming));
+    SIPX_HIP(hipEventCreateWithFlags(&ev_fork2_, hipEventDisableTiming));
     {
       const char* e = std::getenv("SIPX_SERIAL_SETS");
       set_streams_ = !(e && e[0] == '1');
@@ -212,6 +213,7 @@ class Engine : public EngineBase {
     for (auto e : cg_ev_) if (e) (void)hipEventDestroy(e);
     for (hipStream_t q : pool_) if (q != stream_) (void)hipStreamDestroy(q);
     if (ev_fork_) (void)hipEventDestroy(ev_fork_);
+    if (ev_fork2_) (void)hipEventDestroy(ev_fork2_);
     (void)hipStreamDestroy(stream_);
   }
 
@@ -421,6 +423,7 @@ class Engine : public EngineBase {
       if (const char* ra = std::getenv("SIPX_RESID_AHEAD")) resid_ahead_ = ra[0] != '0';      // A/B switch
       MultiArgs<T> probe;
       x0_mode_ = !(e && e[0] == '0') && sweep_applicable(SIPX_YL_FEAS | SIPX_YL_BB, probe, true);
+      for (const auto& st : sets_) slab_dist_logs_ |= slab_ && !mk_ && st.is_dist;
       if (x0_mode_) {
         for (int k = 0; k < 2; ++k) { x0s_base_[k] = dalloc<T>(N + 2 * halo_); x0s_[k] = x0s_base_[k] + halo_; }
       }
@@ -448,7 +451,9 @@ class Engine : public EngineBase {
       hooks_.allgather = [](void* u, void* buf, size_t chunk, int f64, hipStream_t q) {
         static_cast<Comm*>(u)->allgather(buf, chunk, f64 ? SIPX_F64 : SIPX_F32, q);
       };
-      hooks_.gcap = std::min<long long>(1ll << 17, (maxpad + 3) / 4 * 4);      // (the all-gather moves whole segments: 512 KB per l1 set and rank)
+      // what a search may gather inside its final bracket over ALL ranks (and the size of a rank's full-size exchange segment:
+      // the all-gather moves whole segments): 2^17 magnitudes up to 256^3, N / 512 above (512^3: 2^18), at most 2^20
+      hooks_.gcap = std::min<long long>(std::min<long long>(1ll << 20, std::max<long long>(1ll << 17, G_.N / 512)), (maxpad + 3) / 4 * 4);
       if (const char* e = std::getenv("SIPX_GATHER_CAP"))                      // tests: a segment small enough to overflow
         if (std::atoll(e) >= 4) hooks_.gcap = std::atoll(e) / 4 * 4;
       int n2 = 0, nl1 = 0;
@@ -728,7 +733,7 @@ class Engine : public EngineBase {
     if (comm_) {         // ||r_0||^2, ||rhs||^2 block partials [+ the per-set sums of the y/l update queued just before]; p_1 = r_0 is in p_
       comm_->allreduce_with_halo(part_cg_, (size_t)(2 * NB + merged_nslots_), SIPX_F64, p_ + r0, p_ + r0 - plane_, prev_, p_ + r1 - plane_,
                                  p_ + r1, next_, (size_t)plane_, dt, stream_);
-      if (merged_nslots_ > 0) SIPX_HIP(hipMemcpyAsync(hres_, dres_, sizeof(double) * merged_nslots_, hipMemcpyDeviceToHost, stream_));
+      if (merged_nslots_ > 0) K<T>::copy_f64(stream_, dres_, hres_, merged_nslots_);
       merged_nslots_ = 0;
     }
     head_done_ = true;
@@ -809,7 +814,9 @@ class Engine : public EngineBase {
     cg_host_[0] = fin;
     if (comm_) {
       // obj / evol_x sums over the slab (x_old is only kept for the slab), then x is completed on every rank
-      K<T>::log3(stream_, nloc, x_ + r0, m_ + r0, xold_ + r0, part_sets_ + (size_t)p_n_ * SLOTS * NB);
+      // (slab-decomposed with a distance term: the y/l update of that set forms the same three sums over the same rows -- x, m
+      //  and x_old of the slab -- and they travel in the same all-reduce; no pass of its own)
+      if (!slab_dist_logs_) K<T>::log3(stream_, nloc, x_ + r0, m_ + r0, xold_ + r0, part_sets_ + (size_t)p_n_ * SLOTS * NB);
       // slab-decomposed: the planes of x next to the slab (forward differences read one plane up, the recomputed plane below
       // needs one down) were kept current by the CG updates themselves -- nothing to exchange
       if (!slab_) comm_->allgather(x_, (size_t)chunk_, dt, stream_);
@@ -917,21 +924,43 @@ class Engine : public EngineBase {
           const long long fseg = hooks_.fcap + fast_hdr<T>();
           const long long fchunk = (long long)tp.size() * fseg;
           const unsigned seq = ++spec_seq_ & 0x3fffffffu;
+          // The sets' chains of small kernels (slot sums, packing; decision, unpacking, solve) run side by side on the set
+          // streams -- every set has its own partial slots, gather buffer and segments -- the collective itself on the engine stream.
+          auto fork = [&](hipEvent_t ev) { if (set_streams_) SIPX_HIP(hipEventRecord(ev, stream_)); };
+          auto join = [&]() {
+            for (size_t k = 0; k < pool_.size(); ++k) {
+              if (pool_[k] == stream_) continue;
+              SetState<T>* last = nullptr;
+              for (int i : tp)
+                if (sets_[i].st == pool_[k]) last = &sets_[i];
+              if (!last) continue;
+              SIPX_HIP(hipEventRecord(last->ev, last->st));
+              SIPX_HIP(hipStreamWaitEvent(stream_, last->ev, 0));
+            }
+          };
+          fork(ev_fork_);
           for (size_t j = 0; j < tp.size(); ++j) {
             SetState<T>& s = sets_[tp[j]];
+            hipStream_t q = (set_streams_ && s.st) ? s.st : stream_;
+            if (q != stream_) SIPX_HIP(hipStreamWaitEvent(q, ev_fork_, 0));
             ctl[j].verdict = (unsigned*)hverd_ + tp[j];
             ctl[j].seq = seq;
-            K<T>::proj_scalars_stage(0, stream_, Gr_, args[j], 0, s.ps, s.ptmp, s.mpart, s.cbuf, s.Mtrue, ctl[j], &hooks_,
+            K<T>::proj_scalars_stage(0, q, Gr_, args[j], 0, s.ps, s.ptmp, s.mpart, s.cbuf, s.Mtrue, ctl[j], &hooks_,
                                      stage_ + j * RS, gseg[j], chunk);
-            K<T>::proj_scalars_stage(5, stream_, Gr_, args[j], 0, s.ps, s.ptmp, s.mpart, s.cbuf, s.Mtrue, ctl[j], &hooks_,
+            K<T>::proj_scalars_stage(5, q, Gr_, args[j], 0, s.ps, s.ptmp, s.mpart, s.cbuf, s.Mtrue, ctl[j], &hooks_,
                                      stage_ + j * RS, fbuf_ + (long long)j * fseg, fchunk);
           }
+          join();
           comm_->allgather(fbuf_, (size_t)fchunk, dtype_code(), stream_);
+          fork(ev_fork2_);
           for (size_t j = 0; j < tp.size(); ++j) {
             SetState<T>& s = sets_[tp[j]];
-            K<T>::proj_scalars_stage(6, stream_, Gr_, args[j], 0, s.ps, s.ptmp, s.mpart, s.cbuf, s.Mtrue, ctl[j], &hooks_,
+            hipStream_t q = (set_streams_ && s.st) ? s.st : stream_;
+            if (q != stream_) SIPX_HIP(hipStreamWaitEvent(q, ev_fork2_, 0));
+            K<T>::proj_scalars_stage(6, q, Gr_, args[j], 0, s.ps, s.ptmp, s.mpart, s.cbuf, s.Mtrue, ctl[j], &hooks_,
                                      stage_ + j * RS, fbuf_ + (long long)j * fseg, fchunk);
           }
+          join();
           std::vector<size_t> fb;                  // the sets whose search goes on (the same on every rank)
           bool refine = false;
           for (size_t j = 0; j < tp.size(); ++j) {
@@ -1345,7 +1374,7 @@ class Engine : public EngineBase {
         have_log_sums_ = true;
       }
     }
-    if (all) {                               // the slab sums of argmin_x: the distance-term kernel saw x_old on its own slab only
+    if (all && !slab_dist_logs_) {           // the slab sums of argmin_x: the distance-term kernel saw x_old on its own slab only
       const double* g = hres_ + (size_t)p_n_ * SLOTS;
       obj_ss_ = g[SL_OBJ]; evo_ss_ = g[SL_EVO]; xx_ss_ = g[SL_XX];
       have_log_sums_ = true;
@@ -2504,7 +2533,7 @@ class Engine : public EngineBase {
     } else if (comm_) {
       K<T>::fin_sum(stream_, part_sets_, nslots, dres_, nullptr);
       comm_->allreduce_sum(dres_, (size_t)nslots, SIPX_F64, stream_);
-      SIPX_HIP(hipMemcpyAsync(hres_, dres_, sizeof(double) * nslots, hipMemcpyDeviceToHost, stream_));
+      K<T>::copy_f64(stream_, dres_, hres_, nslots);
     } else {
       K<T>::fin_sum(stream_, part_sets_, nslots, nullptr, hres_);
     }
@@ -2560,7 +2589,7 @@ class Engine : public EngineBase {
     for (unsigned spins = 1;; ++spins) {
       const unsigned w = __atomic_load_n((unsigned*)word, __ATOMIC_ACQUIRE);
       if ((w >> 2) == seq) return w & 3u;
-      if ((spins & 0xfff) == 0) {
+      if ((spins & 0x3ffff) == 0) {          // (a stream query costs the runtime tens of microseconds: rarely)
         const hipError_t q = hipStreamQuery(stream_);
         if (q == hipSuccess) {
           const unsigned w2 = __atomic_load_n((unsigned*)word, __ATOMIC_ACQUIRE);
@@ -2618,7 +2647,7 @@ class Engine : public EngineBase {
   CdsArgs cds_;
   bool cds_full_ = false;         // SIPX_CDS_FULL=1: read all d bands of Q (no symmetric partner reads)
   bool set_streams_ = true;       // SIPX_SERIAL_SETS=1 keeps every set on the engine stream (A/B measurements)
-  hipEvent_t ev_fork_ = nullptr;
+  hipEvent_t ev_fork_ = nullptr, ev_fork2_ = nullptr;
   std::vector<hipStream_t> pool_;   // streams the sets are dealt onto, round robin
   int n_set_streams_ = 2, pool_next_ = 0;   // measured: 2 beats 1 by 1-4 %, 3+ lose again at 512^3 (streaming passes collide)
   bool mk_ = false;               // Minkowski mode: unknowns [u; v]
@@ -2658,6 +2687,7 @@ class Engine : public EngineBase {
   double* dres_ = nullptr;                  // device copy of the reduced per-set sums (all-reduce buffer)
   hipEvent_t ev_sums_ = nullptr, ev_cgb_ = nullptr;
   bool sums_pending_ = false, defer_sums_ = false;
+  bool slab_dist_logs_ = false;       // slab-decomposed and a distance term among the sets: obj / evol_x sums come from its y/l update
   bool head_done_ = false;            // the residual product of the coming x-step is queued already (argmin_x_head)
   bool merge_sums_ = false;           // sharded whole-solve loop: the coming reduction of the set sums leaves its all-reduce to argmin_x_head
   int merged_nslots_ = 0;

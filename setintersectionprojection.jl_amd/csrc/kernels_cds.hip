@@ -925,6 +925,17 @@ void K<T>::fin_sum(hipStream_t s, const double* partials, int nslots, double* ou
   SIPX_HIP(hipGetLastError());
 }
 
+// n doubles from device memory into (pinned) host memory: what a hipMemcpyAsync would do through the copy engine, without its
+// set-up latency on the stream (sharded: the all-reduced per-set sums on their way to the host's rules)
+__global__ __launch_bounds__(BLOCK) void k_copy_f64(const double* __restrict__ src, double* __restrict__ dst, int n) {
+  for (int i = threadIdx.x; i < n; i += BLOCK) dst[i] = src[i];
+}
+template <typename T>
+void K<T>::copy_f64(hipStream_t s, const double* src, double* dst, int n) {
+  hipLaunchKernelGGL(k_copy_f64, dim3(1), dim3(BLOCK), 0, s, src, dst, n);
+  SIPX_HIP(hipGetLastError());
+}
+
 // explicit instantiation of the members defined in this file
 #define SIPX_INST(T)                                                                                                  \
   template void K<T>::spmv(hipStream_t, const Grid&, long long, const T*, const CdsArgs&, const T*, T*);             \
@@ -948,7 +959,8 @@ void K<T>::fin_sum(hipStream_t s, const double* partials, int nslots, double* ou
                                    CgState<T>*, int, unsigned long long*, long long, long long);                     \
   template void K<T>::cg_update_p(hipStream_t, long long, T*, const T*, const double*, CgState<T>*, CgState<T>*,     \
                                   unsigned long long*, long long, long long);                                        \
-  template void K<T>::fin_sum(hipStream_t, const double*, int, double*, double*);
+  template void K<T>::fin_sum(hipStream_t, const double*, int, double*, double*);                                   \
+  template void K<T>::copy_f64(hipStream_t, const double*, double*, int);
 SIPX_INST(float)
 SIPX_INST(double)
 

@@ -489,7 +489,9 @@ __device__ void decide_body(ProjScalars<T>* ps, int prox, T pmin, T pmax, long l
       const double S3 = red[3 + L1_WIN_LO], C3 = red[3 + L1_K + L1_WIN_LO], S4 = red[3 + L1_WIN_HI], C4 = red[3 + L1_K + L1_WIN_HI];
       const double f3 = S3 - t3 * C3 - b, f4 = S4 - t4 * C4 - b;
       ps->lean = 0;
-      if (f3 >= 0 && f4 < 0 && !ps->spec_overflow && !(nospec & 1) && !(cap_max > 0 && C3 - C4 > cap_max)) {
+      // (slab-decomposed: a range that holds more than the exchange takes counts as an overflow -- the next range is half as wide)
+      if (cap_max > 0 && C3 - C4 > cap_max) ps->spec_overflow = 1;
+      if (f3 >= 0 && f4 < 0 && !ps->spec_overflow && !(nospec & 1)) {
         double thN = C3 > 0 ? (S3 - b) / C3 : t3;
         if (!(thN >= t3)) thN = t3;
         double thS = t3 + f3 * (t4 - t3) / (f3 - f4);
@@ -591,8 +593,8 @@ __device__ void decide_body(ProjScalars<T>* ps, int prox, T pmin, T pmax, long l
   if (STAGE == 0) {
     // speculative gather usable?  range edges are probes L1_WIN_LO and L1_WIN_HI, so (S,C) above it are known
     // (slab-decomposed: what the range gathered over all ranks, C(spec_lo) - C(spec_hi), has to fit a rank's exchange segment)
-    const bool spec = !(nospec & 1) && ps->spec_hi > ps->spec_lo && !ps->spec_overflow && lo >= ps->spec_lo && hi <= ps->spec_hi &&
-                      !(cap_max > 0 && red[3 + L1_K + L1_WIN_LO] - red[3 + L1_K + L1_WIN_HI] > cap_max);
+    if (cap_max > 0 && red[3 + L1_K + L1_WIN_LO] - red[3 + L1_K + L1_WIN_HI] > cap_max) ps->spec_overflow = 1;
+    const bool spec = !(nospec & 1) && ps->spec_hi > ps->spec_lo && !ps->spec_overflow && lo >= ps->spec_lo && hi <= ps->spec_hi;
     if (spec) {
       ps->spec_ok = 1;
       ps->s_above = red[3 + L1_WIN_HI];
@@ -958,10 +960,22 @@ __global__ __launch_bounds__(SAMPLE_NT) void k_sample(Grid G, SetArgs<T> a, Proj
       defer_to[j] = (double)(w >> (64 - SAMPLE_CNT_BITS));
       defer_to[SAMPLE_BINS + j] = (double)(w & SAMPLE_SUM_MASK);
     }
-    if (threadIdx.x < 3) {
+    // the three partial sums of the workgroups: every thread one load (a single thread walking them took longer than the sampling)
+    double t3[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
       double t = 0;
-      for (int i = 0; i < (int)gridDim.x; ++i)
-        t += __hip_atomic_load(&partials[(long long)threadIdx.x * NB + i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      for (int i = threadIdx.x; i < (int)gridDim.x; i += NT)
+        t += __hip_atomic_load(&partials[(long long)k * NB + i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      t3[k] = wave_sum(t);
+    }
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) { sS[threadIdx.x >> 6] = t3[0]; sC[threadIdx.x >> 6] = t3[1]; sS[64 + (threadIdx.x >> 6)] = t3[2]; }
+    __syncthreads();
+    if (threadIdx.x < 3) {
+      const double* src = threadIdx.x == 0 ? sS : (threadIdx.x == 1 ? sC : sS + 64);
+      double t = 0;
+      for (int i = 0; i < NT / 64; ++i) t += src[i];
       defer_to[2 * SAMPLE_BINS + threadIdx.x] = t;
     }
     return;
@@ -1181,9 +1195,13 @@ __global__ __launch_bounds__(SIPX_SOLVE_NT) void k_l1_solve(ProjScalars<T>* ps, 
       if (!(ps->theta_prev > 0)) ps->want_sample = 1;      // the first theta of this set: nothing is known about how it moves
       if (ps->theta_prev > 0) {
         const double d = fabs(theta / ps->theta_prev - 1.0);
-        // theta moved by more than a third of the widest speculative range (or the last search needed its fallback sweeps):
-        // the coming prediction is not to be trusted -- a sampled estimate first (k_sample), when the caller provides for it
-        ps->want_sample = (3.0 * d > hw_max || !ps->lean) ? 1 : 0;
+        // theta moved by more than a third of the widest speculative range: the coming prediction is not to be trusted -- a
+        // sampled estimate first (k_sample), when the caller provides for it.  A search that needed its fallback sweeps although
+        // theta hardly moved asks for NO sample: the error of a sampled estimate is absolute (rms excess / sqrt(active sample),
+        // and the same from one iteration to the next because the sample is the same subset), so against a small theta it is
+        // percent while theta itself moves by hundredths of a percent -- there the previous theta is the better prediction
+        // (512^3, default window: searches of the D_x set missed their range on every iteration from 18 on, sampled each time).
+        ps->want_sample = (3.0 * d > hw_max) ? 1 : 0;
         // this search followed a change of rho: was theta_prev * rho_old / rho_new (k_ps_rescale) good to the range it gets?
         // Early on it is not (theta is set by x_hat, not by l / rho) and the sampled estimate is; late it is, and then more
         // accurate than a sample, whose error grows as theta shrinks against the spread of the values
@@ -1552,7 +1570,7 @@ static void chain_stage(int stage, hipStream_t s, const Grid& g, const SetArgs<T
       const long long per_rank = hk ? (g.N / world + 3) / 4 : range_len(g) / 4;     // vectors of a full slab
       double gcap = 0.2 * (double)fit_grid(per_rank, SIPX_PASS_GRID) * (double)SPEC_CAP * (double)world;   // a fifth of the LDS buffers of the pass
       if (hk && gcap > 0.8 * cap_max) gcap = 0.8 * cap_max;
-      if (hk && hk->fcap > 0 && gcap > 0.5 * (double)hk->fcap * (double)world) gcap = 0.5 * (double)hk->fcap * (double)world;   // the fast segments of the speculative exchange (margin: the ranks' shares are not equal)
+      if (hk && hk->fcap > 0 && gcap > 0.8 * (double)hk->fcap * (double)world) gcap = 0.8 * (double)hk->fcap * (double)world;   // the fast segments of the speculative exchange (margin: the ranks' shares are not equal)
       // (below 2^24 grid points the extra launch costs more than the sweeps it saves: 2048^2 loses 3 %; a test may force it)
       if (stride >= 4 && (g.N >= (1ll << 24) || ctl.runs > 0)) {
         const long long nsamp = nchunks / stride;            // may be 0 on a short slab

@@ -413,6 +413,7 @@ struct K {
   static void rows_pack(hipStream_t s, const Grid& g, int dir, long long nrows, const T* pad, T* rows);
   static void rows_unpack(hipStream_t s, const Grid& g, int dir, long long nrows, const T* rows, T* pad);
   static void fin_sum(hipStream_t s, const double* partials, int nslots, double* out_dev, double* out_host);
+  static void copy_f64(hipStream_t s, const double* src, double* dst, int n);      // device -> pinned host, by a kernel
   // Scalars of the two-pass projectors (l1 threshold, l2 / annulus scale) of a vector that is either
   // produced on the fly by a set (v = x_hat - l/rho, or s = A x when v_is_s) or stored in an array.
   // Enqueues: first pass (sums + probe + speculative compaction), bracket, gated refinement / compaction, solve.
