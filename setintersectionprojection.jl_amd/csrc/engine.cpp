@@ -915,108 +915,7 @@ class Engine : public EngineBase {
         if (const char* e = std::getenv("SIPX_L1_ROUNDS_MIN")) rounds = std::min(6, std::max(rounds, std::atoi(e)));      // a problem whose brackets shrink slowly
         if (const char* e = std::getenv("SIPX_L1_ROUNDS_MAX")) rounds = std::max(1, std::min(rounds, std::atoi(e)));      // tests: force an overflow
         if (spec_exchange_) {
-          // SPECULATIVE EXCHANGE (kernels_proj.hip, k_spec_pack): first pass of every set, then ONE all-gather carrying every
-          // rank's probe sums and the magnitudes it gathered inside the speculative range.  Every rank adds the sums up itself,
-          // decides, and -- when the range held theta, the rule once rho and gamma move slowly -- solves from the gathered values:
-          // one collective per iteration for all the searches.  Whether a set needs its fallback (refinement rounds with an
-          // all-reduce each, then the full-size exchange) the host reads from a pinned word per set; the decision kernel,
-          // the unpacking and the solve are queued before that wait, so the device does not idle on it.
-          const long long fseg = hooks_.fcap + fast_hdr<T>();
-          const long long fchunk = (long long)tp.size() * fseg;
-          const unsigned seq = ++spec_seq_ & 0x3fffffffu;
-          // The sets' chains of small kernels (slot sums, packing; decision, unpacking, solve) run side by side on the set
-          // streams -- every set has its own partial slots, gather buffer and segments -- the collective itself on the engine stream.
-          auto fork = [&](hipEvent_t ev) { if (set_streams_) SIPX_HIP(hipEventRecord(ev, stream_)); };
-          auto join = [&]() {
-            for (size_t k = 0; k < pool_.size(); ++k) {
-              if (pool_[k] == stream_) continue;
-              SetState<T>* last = nullptr;
-              for (int i : tp)
-                if (sets_[i].st == pool_[k]) last = &sets_[i];
-              if (!last) continue;
-              SIPX_HIP(hipEventRecord(last->ev, last->st));
-              SIPX_HIP(hipStreamWaitEvent(stream_, last->ev, 0));
-            }
-          };
-          fork(ev_fork_);
-          for (size_t j = 0; j < tp.size(); ++j) {
-            SetState<T>& s = sets_[tp[j]];
-            hipStream_t q = (set_streams_ && s.st) ? s.st : stream_;
-            if (q != stream_) SIPX_HIP(hipStreamWaitEvent(q, ev_fork_, 0));
-            ctl[j].verdict = (unsigned*)hverd_ + tp[j];
-            ctl[j].seq = seq;
-            K<T>::proj_scalars_stage(0, q, Gr_, args[j], 0, s.ps, s.ptmp, s.mpart, s.cbuf, s.Mtrue, ctl[j], &hooks_,
-                                     stage_ + j * RS, gseg[j], chunk);
-            K<T>::proj_scalars_stage(5, q, Gr_, args[j], 0, s.ps, s.ptmp, s.mpart, s.cbuf, s.Mtrue, ctl[j], &hooks_,
-                                     stage_ + j * RS, fbuf_ + (long long)j * fseg, fchunk);
-          }
-          join();
-          comm_->allgather(fbuf_, (size_t)fchunk, dtype_code(), stream_);
-          fork(ev_fork2_);
-          for (size_t j = 0; j < tp.size(); ++j) {
-            SetState<T>& s = sets_[tp[j]];
-            hipStream_t q = (set_streams_ && s.st) ? s.st : stream_;
-            if (q != stream_) SIPX_HIP(hipStreamWaitEvent(q, ev_fork2_, 0));
-            K<T>::proj_scalars_stage(6, q, Gr_, args[j], 0, s.ps, s.ptmp, s.mpart, s.cbuf, s.Mtrue, ctl[j], &hooks_,
-                                     stage_ + j * RS, fbuf_ + (long long)j * fseg, fchunk);
-          }
-          join();
-          std::vector<size_t> fb;                  // the sets whose search goes on (the same on every rank)
-          bool refine = false;
-          for (size_t j = 0; j < tp.size(); ++j) {
-            const unsigned w = wait_verdict(hverd_ + tp[j], seq);
-            if (w & 1u) fb.push_back(j);
-            refine |= (w & 2u) != 0;
-          }
-          spec_searches_ += (long long)tp.size();
-          spec_fallbacks_ += (long long)fb.size();
-          static const bool spec_debug = std::getenv("SIPX_SPEC_DEBUG") != nullptr;
-          if (spec_debug) {
-            for (size_t j : fb) dump_ps(tp[j], stage_ + j * RS);
-            std::fprintf(stderr, "[sipx spec] it %d:", it);
-            for (size_t j = 0; j < tp.size(); ++j) std::fprintf(stderr, " set %d verdict %u", tp[j], (unsigned)(hverd_[tp[j]] & 3u));
-            std::fprintf(stderr, "\n");
-          }
-          if (!fb.empty()) {
-            // Fallback (the summed first-pass sums of every set are in its region of stage_, where k_spec_decide left them):
-            // refinement rounds -- gated probe pass, ONE all-reduce, decision -- for as long as some set's bracket holds more than
-            // the exchange segments take (the host reads that from the sets' pinned words after every round: exactly as many
-            // all-reduces as are needed, at most L1_REFINES_SLAB), then the compaction of every final bracket and the full-size
-            // all-gather.  The sets the exchange settled take no part.
-            int max_rounds = 6;
-            if (const char* e = std::getenv("SIPX_L1_ROUNDS_MAX")) max_rounds = std::max(0, std::min(6, std::atoi(e)));      // tests: force an overflow
-            for (int rep = 0; refine && rep < max_rounds; ++rep) {
-              const unsigned rseq = ++spec_seq_ & 0x3fffffffu;
-              for (size_t j : fb) {
-                SetState<T>& s = sets_[tp[j]];
-                K<T>::proj_scalars_stage(8, stream_, Gr_, args[j], 0, s.ps, s.ptmp, s.mpart, s.cbuf, s.Mtrue, ctl[j], &hooks_,
-                                         stage_ + j * RS, gseg[j], chunk);
-              }
-              comm_->allreduce_sum(stage_, tp.size() * RS, SIPX_F64, stream_);
-              for (size_t j : fb) {
-                SetState<T>& s = sets_[tp[j]];
-                ctl[j].seq = rseq;
-                K<T>::proj_scalars_stage(9, stream_, Gr_, args[j], 0, s.ps, s.ptmp, s.mpart, s.cbuf, s.Mtrue, ctl[j], &hooks_,
-                                         stage_ + j * RS, gseg[j], chunk);
-              }
-              refine = false;
-              for (size_t j : fb)
-                if (sets_[tp[j]].prox == PX_L1) refine |= (wait_verdict(hverd_ + tp[j], rseq) & 2u) != 0;
-              spec_rounds_ += 1;
-              if (spec_debug) {
-                std::fprintf(stderr, "[sipx spec]   round %d -> refine %d\n", rep + 1, (int)refine);
-                for (size_t j : fb) dump_ps(tp[j], stage_ + j * RS);
-              }
-            }
-            for (int stage : {12, 3}) {
-              for (size_t j : fb) {
-                SetState<T>& s = sets_[tp[j]];
-                K<T>::proj_scalars_stage(stage, stream_, Gr_, args[j], 0, s.ps, s.ptmp, s.mpart, s.cbuf, s.Mtrue, ctl[j], &hooks_,
-                                         stage_ + j * RS, gseg[j], chunk);
-              }
-              if (stage == 12) comm_->allgather(gbuf_, (size_t)chunk, dtype_code(), stream_);
-            }
-          }
+          spec_exchange_searches(tp, args, ctl, gseg, chunk, 0, false, it);
         } else {
         const int order[4] = {0, 1, 2, 3};
         for (int si = 0; si < 4; ++si) {
@@ -1043,7 +942,31 @@ class Engine : public EngineBase {
       for (int i = 0; i < p_n_; ++i)
         if (sets_[i].two_pass) { sets_[i].last_rho = (T)rho[i]; sets_[i].last_gamma = (T)gamma[i]; }
       sweep_launch(flags, rho, gamma, ma);
-      if (flags & SIPX_YL_FEAS)
+      if ((flags & SIPX_YL_FEAS) && spec_exchange_) {
+        // the feasibility estimates ||P_i(A_i x) - A_i x|| of the two-pass sets: their searches (on v = A_i x itself, each set's
+        // second scalar state) in lock step through the same exchange -- one all-gather for all of them -- then the distances
+        std::vector<int> tf;
+        for (int i = 0; i < pp_n_; ++i)
+          if (sets_[i].two_pass) tf.push_back(i);
+        if (!tf.empty()) {
+          const long long seg = hooks_.gcap + GATHER_HDR;
+          int nl1 = 0;
+          for (int i = 0; i < p_n_; ++i) nl1 += (sets_[i].two_pass && sets_[i].prox == PX_L1) ? 1 : 0;
+          const long long chunk = (long long)std::max(nl1, 1) * seg;
+          std::vector<SetArgs<T>> fa(tf.size());
+          std::vector<SampleCtl> fc(tf.size());
+          std::vector<T*> fg(tf.size(), nullptr);
+          int k1 = 0;
+          for (size_t j = 0; j < tf.size(); ++j) {
+            fa[j] = set_args(sets_[tf[j]], (T)rho[tf[j]], (T)gamma[tf[j]], flags);
+            fc[j].host_ovf = (int*)hovf_ + tf[j];
+            if (sets_[tf[j]].prox == PX_L1) fg[j] = gbuf_ + (long long)(k1++) * seg;
+          }
+          spec_exchange_searches(tf, fa, fc, fg, chunk, 1, true, it);
+          for (size_t j = 0; j < tf.size(); ++j)
+            K<T>::proj_dist_set(stream_, Gr_, fa[j], 1, sets_[tf[j]].psf, part_sets_ + ((size_t)tf[j] * SLOTS + SL_FE2) * NB);
+        }
+      } else if (flags & SIPX_YL_FEAS) {
         for (int i = 0; i < pp_n_; ++i) {
           SetState<T>& s = sets_[i];
           if (!s.two_pass) continue;
@@ -1054,6 +977,7 @@ class Engine : public EngineBase {
                                  s.Mtrue, cf, hooks());
           K<T>::proj_dist_set(stream_, Gr_, a, 1, s.psf, part_sets_ + ((size_t)i * SLOTS + SL_FE2) * NB);
         }
+      }
     }
     if (set_streams_ && slab_ && !sweep) SIPX_HIP(hipEventRecord(ev_fork_, stream_));      // the searches are done: the updates may start
     for (int i = 0; i < p_n_ && !(slab_ && sweep); ++i) {
@@ -1215,6 +1139,118 @@ class Engine : public EngineBase {
       }
     }
     return K<T>::yl_multi(stream_, G_, ma, true);
+  }
+
+  // Threshold / scale searches of the two-pass sets `tp` of a slab-decomposed grid, all in lock step, through the SPECULATIVE
+  // EXCHANGE (used for the searches of the y/l update, feas_ps = false, and for those of the feasibility estimates, on the sets'
+  // second scalar state and v = A x itself).  gseg[j] / chunk: the set's segment in rank 0's chunk of the full-size exchange
+  // buffer; ctl[j]: the set's pinned words.
+  void spec_exchange_searches(const std::vector<int>& tp, std::vector<SetArgs<T>>& args, std::vector<SampleCtl>& ctl,
+                              const std::vector<T*>& gseg, long long chunk, int v_is_s, bool feas_ps, int it) {
+    const size_t RS = (size_t)(PREP_SLOTS + 1 + 2 * comm_->world);
+    auto PS = [&](int i) { return feas_ps ? sets_[i].psf : sets_[i].ps; };
+    // SPECULATIVE EXCHANGE (kernels_proj.hip, k_spec_pack): first pass of every set, then ONE all-gather carrying every
+    // rank's probe sums and the magnitudes it gathered inside the speculative range.  Every rank adds the sums up itself,
+    // decides, and -- when the range held theta, the rule once rho and gamma move slowly -- solves from the gathered values:
+    // one collective per iteration for all the searches.  Whether a set needs its fallback (refinement rounds with an
+    // all-reduce each, then the full-size exchange) the host reads from a pinned word per set; the decision kernel,
+    // the unpacking and the solve are queued before that wait, so the device does not idle on it.
+    const long long fseg = hooks_.fcap + fast_hdr<T>();
+    const long long fchunk = (long long)tp.size() * fseg;
+    const unsigned seq = ++spec_seq_ & 0x3fffffffu;
+    // The sets' chains of small kernels (slot sums, packing; decision, unpacking, solve) run side by side on the set
+    // streams -- every set has its own partial slots, gather buffer and segments -- the collective itself on the engine stream.
+    auto fork = [&](hipEvent_t ev) { if (set_streams_) SIPX_HIP(hipEventRecord(ev, stream_)); };
+    auto join = [&]() {
+      for (size_t k = 0; k < pool_.size(); ++k) {
+        if (pool_[k] == stream_) continue;
+        SetState<T>* last = nullptr;
+        for (int i : tp)
+          if (sets_[i].st == pool_[k]) last = &sets_[i];
+        if (!last) continue;
+        SIPX_HIP(hipEventRecord(last->ev, last->st));
+        SIPX_HIP(hipStreamWaitEvent(stream_, last->ev, 0));
+      }
+    };
+    fork(ev_fork_);
+    for (size_t j = 0; j < tp.size(); ++j) {
+      SetState<T>& s = sets_[tp[j]];
+      hipStream_t q = (set_streams_ && s.st) ? s.st : stream_;
+      if (q != stream_) SIPX_HIP(hipStreamWaitEvent(q, ev_fork_, 0));
+      ctl[j].verdict = (unsigned*)hverd_ + tp[j];
+      ctl[j].seq = seq;
+      K<T>::proj_scalars_stage(0, q, Gr_, args[j], v_is_s, PS(tp[j]), s.ptmp, s.mpart, s.cbuf, s.Mtrue, ctl[j], &hooks_,
+                               stage_ + j * RS, gseg[j], chunk);
+      K<T>::proj_scalars_stage(5, q, Gr_, args[j], v_is_s, PS(tp[j]), s.ptmp, s.mpart, s.cbuf, s.Mtrue, ctl[j], &hooks_,
+                               stage_ + j * RS, fbuf_ + (long long)j * fseg, fchunk);
+    }
+    join();
+    comm_->allgather(fbuf_, (size_t)fchunk, dtype_code(), stream_);
+    fork(ev_fork2_);
+    for (size_t j = 0; j < tp.size(); ++j) {
+      SetState<T>& s = sets_[tp[j]];
+      hipStream_t q = (set_streams_ && s.st) ? s.st : stream_;
+      if (q != stream_) SIPX_HIP(hipStreamWaitEvent(q, ev_fork2_, 0));
+      K<T>::proj_scalars_stage(6, q, Gr_, args[j], v_is_s, PS(tp[j]), s.ptmp, s.mpart, s.cbuf, s.Mtrue, ctl[j], &hooks_,
+                               stage_ + j * RS, fbuf_ + (long long)j * fseg, fchunk);
+    }
+    join();
+    std::vector<size_t> fb;                  // the sets whose search goes on (the same on every rank)
+    bool refine = false;
+    for (size_t j = 0; j < tp.size(); ++j) {
+      const unsigned w = wait_verdict(hverd_ + tp[j], seq);
+      if (w & 1u) fb.push_back(j);
+      refine |= (w & 2u) != 0;
+    }
+    spec_searches_ += (long long)tp.size();
+    spec_fallbacks_ += (long long)fb.size();
+    static const bool spec_debug = std::getenv("SIPX_SPEC_DEBUG") != nullptr;
+    if (spec_debug) {
+      for (size_t j : fb) dump_ps(tp[j], stage_ + j * RS);
+      std::fprintf(stderr, "[sipx spec] it %d:", it);
+      for (size_t j = 0; j < tp.size(); ++j) std::fprintf(stderr, " set %d verdict %u", tp[j], (unsigned)(hverd_[tp[j]] & 3u));
+      std::fprintf(stderr, "\n");
+    }
+    if (!fb.empty()) {
+      // Fallback (the summed first-pass sums of every set are in its region of stage_, where k_spec_decide left them):
+      // refinement rounds -- gated probe pass, ONE all-reduce, decision -- for as long as some set's bracket holds more than
+      // the exchange segments take (the host reads that from the sets' pinned words after every round: exactly as many
+      // all-reduces as are needed, at most L1_REFINES_SLAB), then the compaction of every final bracket and the full-size
+      // all-gather.  The sets the exchange settled take no part.
+      int max_rounds = 6;
+      if (const char* e = std::getenv("SIPX_L1_ROUNDS_MAX")) max_rounds = std::max(0, std::min(6, std::atoi(e)));      // tests: force an overflow
+      for (int rep = 0; refine && rep < max_rounds; ++rep) {
+        const unsigned rseq = ++spec_seq_ & 0x3fffffffu;
+        for (size_t j : fb) {
+          SetState<T>& s = sets_[tp[j]];
+          K<T>::proj_scalars_stage(8, stream_, Gr_, args[j], v_is_s, PS(tp[j]), s.ptmp, s.mpart, s.cbuf, s.Mtrue, ctl[j], &hooks_,
+                                   stage_ + j * RS, gseg[j], chunk);
+        }
+        comm_->allreduce_sum(stage_, tp.size() * RS, SIPX_F64, stream_);
+        for (size_t j : fb) {
+          SetState<T>& s = sets_[tp[j]];
+          ctl[j].seq = rseq;
+          K<T>::proj_scalars_stage(9, stream_, Gr_, args[j], v_is_s, PS(tp[j]), s.ptmp, s.mpart, s.cbuf, s.Mtrue, ctl[j], &hooks_,
+                                   stage_ + j * RS, gseg[j], chunk);
+        }
+        refine = false;
+        for (size_t j : fb)
+          if (sets_[tp[j]].prox == PX_L1) refine |= (wait_verdict(hverd_ + tp[j], rseq) & 2u) != 0;
+        spec_rounds_ += 1;
+        if (spec_debug) {
+          std::fprintf(stderr, "[sipx spec]   round %d -> refine %d\n", rep + 1, (int)refine);
+          for (size_t j : fb) dump_ps(tp[j], stage_ + j * RS);
+        }
+      }
+      for (int stage : {12, 3}) {
+        for (size_t j : fb) {
+          SetState<T>& s = sets_[tp[j]];
+          K<T>::proj_scalars_stage(stage, stream_, Gr_, args[j], v_is_s, PS(tp[j]), s.ptmp, s.mpart, s.cbuf, s.Mtrue, ctl[j], &hooks_,
+                                   stage_ + j * RS, gseg[j], chunk);
+        }
+        if (stage == 12) comm_->allgather(gbuf_, (size_t)chunk, dtype_code(), stream_);
+      }
+    }
   }
 
   // one rank (or no communicator): the searches of the two-pass sets on the set streams, joined before the sweep

@@ -508,7 +508,7 @@ __device__ void decide_body(ProjScalars<T>* ps, int prox, T pmin, T pmax, long l
       }
       ps->n_compact = 0;                                     // discard what the speculation gathered
       ps->vmax = (T)ps->asum;                                // a valid upper bound of every magnitude
-      if (f3 >= 0 && f4 < 0 && !(nospec & 2)) {
+      if (f3 >= 0 && f4 < 0) {
         // theta* IS inside the range, but what the range gathered cannot be used (an LDS buffer or an exchange segment overflowed,
         // or it holds more than the caller can take): the bracket is the range tightened by the Newton / secant steps; it is
         // gathered at once by the compaction pass if it is small enough, and subdivided by refinement rounds first if not
@@ -1540,8 +1540,7 @@ static void chain_stage(int stage, hipStream_t s, const Grid& g, const SetArgs<T
   const double cap_max = hk ? (double)hk->gcap : 0.0;      // what ALL ranks gather together fits one rank's segment
   const bool vec = SRC == 1 && g.n[0] % 4 == 0;
   static const double capdiv = [] { const char* e = getenv("SIPX_L1_CAPDIV"); return e ? atof(e) : 64.0; }();
-  static const int legacy_lean = [] { const char* e = getenv("SIPX_LEAN_LEGACY"); return (e && e[0] == '1') ? 2 : 0; }();     // bisecting aid
-  const DecideArgs da0{a.prox, ((a.flags & F_NOSPEC) ? 1 : 0) | legacy_lean, (double)a.plo, (double)a.phi, capdiv, cap_max, true_len};
+  const DecideArgs da0{a.prox, (a.flags & F_NOSPEC) ? 1 : 0, (double)a.plo, (double)a.phi, capdiv, cap_max, true_len};
   const DecideArgs da1{a.prox, 0, (double)a.plo, (double)a.phi, capdiv, cap_max, true_len};
 #define SIPX_PASS(MODE)                                                                                            \
   do {                                                                                                             \
