@@ -189,7 +189,9 @@ def dominant_kernel(per_kernel):
             row["survey_bytes_per_launch"] = k["bytes_survey"] / k["launches"]
             row["frac_survey"] = (k["bytes_survey"] / (k["total_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS) if k["total_ms"] > 0 else None
         if k["gated"]:
-            row["note"] = "some launches return at once on a device-side condition: their bytes are booked, their time is not spent"
+            row["noop_launches"] = int(k.get("noop_launches", 0))
+            row["note"] = ("some launches return at once on a device-side condition (noop_launches: those that finished sooner than "
+                           "their bytes could cross the fabric at twice the HBM peak): their bytes are not booked")
         if k["inclusive"]:
             row["note"] = "library-backed projector (hipFFT / rocSOLVER / rocBLAS calls): its interval contains other listed kernels; not a candidate"
         rows.append(row)
@@ -700,6 +702,14 @@ def main():
                                    "all-kernel statistics window / wall time of that window (the event records of the window cost "
                                    "a few percent) / peak: the bandwidth the iteration as BUILT sustains"}
         comm_info = ctx.comm_info()
+        # slab-decomposed: threshold searches that went through the speculative exchange since the context was built, how many of
+        # them needed their fallback, and the all-reduces (refinement rounds) those took -- the engine's own counters
+        searches = per_kernel.get("slab_searches") if per_kernel else None
+        if searches is None and dist is not None:
+            try:
+                searches = ctx.kernel_stats_all(0).get("slab_searches")
+            except Exception:
+                searches = None
         if world > 1:
             tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -763,7 +773,8 @@ def main():
         dominant, table = dominant_kernel(per_kernel)
         return {
             "comm": {"rccl_nranks": comm_info["nranks"], "rccl_rank": comm_info["rank"], "rccl_version": comm_info["version"],
-                     "decomposition": comm_info["decomposition"] if dist is not None else None},
+                     "decomposition": comm_info["decomposition"] if dist is not None else None,
+                     "slab_searches": searches if (dist is not None and slab) else None},
             "dominant_kernel": dominant, "kernels": table,
             "value": steps / dt, "ms_per_step": dt / steps * 1e3, "decomposition": ("slab" if slab else "sets") if dist is not None else None,
             # log.timing of the whole run (warm-up included), per iteration: where the time of an iteration goes on this rank

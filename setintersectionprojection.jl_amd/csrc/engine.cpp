@@ -1963,12 +1963,12 @@ class Engine : public EngineBase {
     char buf[512];
     for (int k = 0; k < KID_COUNT; ++k) {
       if (!agg[k].launches) continue;
-      const bool gated = k == KID_PASS_FIRST || k == KID_PASS_LEAN || k == KID_PASS_PROBE || k == KID_PASS_COMPACT || k == KID_SAMPLE ||
-                         k == KID_DECIDE || k == KID_CDS_FUSED || k == KID_CG_XR || k == KID_CG_P || k == KID_SLOT_SUMS;
+      const bool gated = gated_kernel(k);
       std::snprintf(buf, sizeof buf,
-                    "%s{\"name\": \"%s\", \"launches\": %lld, \"total_ms\": %.6f, \"bytes_survey\": %.0f, \"bytes_moved\": %.0f, "
-                    "\"gated\": %s, \"inclusive\": %s}",
-                    first ? "" : ", ", kernel_name(k), (long long)agg[k].launches, agg[k].ms, agg[k].bytes_survey, agg[k].bytes_moved,
+                    "%s{\"name\": \"%s\", \"launches\": %lld, \"noop_launches\": %lld, \"total_ms\": %.6f, \"bytes_survey\": %.0f, "
+                    "\"bytes_moved\": %.0f, \"gated\": %s, \"inclusive\": %s}",
+                    first ? "" : ", ", kernel_name(k), (long long)agg[k].launches, (long long)agg[k].noops, agg[k].ms, agg[k].bytes_survey,
+                    agg[k].bytes_moved,
                     gated ? "true" : "false", k == KID_EXT ? "true" : "false");
       o += buf;
       first = false;
@@ -2009,7 +2009,7 @@ class Engine : public EngineBase {
 
  private:
   struct KSample { int kid; double bytes_survey, bytes_moved; };
-  struct KAgg { long long launches = 0; double ms = 0, bytes_survey = 0, bytes_moved = 0; };
+  struct KAgg { long long launches = 0, noops = 0; double ms = 0, bytes_survey = 0, bytes_moved = 0; };
   hipEvent_t stat_event(size_t i) {
     while (stat_ev_.size() <= i) {
       hipEvent_t e;
@@ -2043,6 +2043,11 @@ class Engine : public EngineBase {
     for (hipStream_t q : pool_) if (q != stream_) SIPX_HIP(hipStreamSynchronize(q));
     if (cstream_) SIPX_HIP(hipStreamSynchronize(cstream_));
   }
+  // kernels some of whose launches return at once on a device-side condition
+  static bool gated_kernel(int k) {
+    return k == KID_PASS_FIRST || k == KID_PASS_LEAN || k == KID_PASS_PROBE || k == KID_PASS_COMPACT || k == KID_SAMPLE ||
+           k == KID_DECIDE || k == KID_CDS_FUSED || k == KID_CG_XR || k == KID_CG_P || k == KID_SLOT_SUMS;
+  }
   std::vector<KAgg> aggregate_samples() {
     sync_all_streams();
     std::vector<KAgg> agg(KID_COUNT);
@@ -2055,8 +2060,12 @@ class Engine : public EngineBase {
       const double t = (double)ms - stat_pair_ms_;
       a.launches += 1;
       a.ms += t > 0 ? t : 0;
-      a.bytes_survey += samples_[i].bytes_survey;
-      a.bytes_moved += samples_[i].bytes_moved;
+      // a gated launch (the pass of an l1 search that the device-side state did not ask for, a CG kernel past convergence) returns at
+      // once: a launch that finished sooner than its bytes could cross the fabric at twice the HBM peak did not move them
+      const bool noop = gated_kernel(samples_[i].kid) && samples_[i].bytes_moved > 0 && t * 1e-3 < samples_[i].bytes_moved / 16e12;
+      a.noops += noop ? 1 : 0;
+      a.bytes_survey += noop ? 0.0 : samples_[i].bytes_survey;
+      a.bytes_moved += noop ? 0.0 : samples_[i].bytes_moved;
     }
     return agg;
   }
