@@ -173,7 +173,7 @@ class Engine : public EngineBase {
       const char* f = std::getenv("SIPX_CDS_FULL");
       cds_full_ = f && f[0] == '1';
       const char* k = std::getenv("SIPX_SET_STREAMS");
-      if (k && std::atoi(k) > 0) n_set_streams_ = std::atoi(k);
+      if (k && std::atoi(k) > 0) { n_set_streams_ = std::atoi(k); set_streams_forced_ = true; }
     }
     ndim_ = ndim;
     for (int a = 0; a < 3; ++a) {
@@ -423,6 +423,18 @@ class Engine : public EngineBase {
       if (const char* ra = std::getenv("SIPX_RESID_AHEAD")) resid_ahead_ = ra[0] != '0';      // A/B switch
       MultiArgs<T> probe;
       x0_mode_ = !(e && e[0] == '0') && sweep_applicable(SIPX_YL_FEAS | SIPX_YL_BB, probe, true);
+      // Set streams when the sweep does the updates: all that runs on them is the threshold / scale searches, chains of short
+      // kernels whose latencies should overlap -- every searching set a stream of its own (up to three; one of them the engine
+      // stream, so that its search starts without a cross-stream dependency), the other sets on the engine stream.  256^3, C3:
+      // 715 -> 760 it/s with three instead of two; 512^3 unchanged; four lose (no search left on the engine stream); 2048^2 with
+      // its one searching set keeps two.  Without the sweep the per-set y/l kernels run there too: two streams, sets dealt round robin.
+      MultiArgs<T> probe2;
+      search_streams_ = !set_streams_forced_ && sweep_applicable(SIPX_YL_BB, probe2, true);
+      if (search_streams_) {
+        int ntp = 0;
+        for (const auto& st : sets_) ntp += st.two_pass ? 1 : 0;
+        n_set_streams_ = std::max(2, std::min(3, ntp));
+      }
       for (const auto& st : sets_) slab_dist_logs_ |= slab_ && !mk_ && st.is_dist;
       if (x0_mode_) {
         for (int k = 0; k < 2; ++k) { x0s_base_[k] = dalloc<T>(N + 2 * halo_); x0s_[k] = x0s_base_[k] + halo_; }
@@ -572,7 +584,16 @@ class Engine : public EngineBase {
           if (!pool_.empty()) SIPX_HIP(hipStreamCreateWithFlags(&q, hipStreamNonBlocking));
           pool_.push_back(q);
         }
-        s.st = pool_[pool_next_++ % pool_.size()];
+        if (search_streams_) {               // searching sets: streams 1, 2, 0, 1, ... ; the others: the engine stream
+          while ((int)pool_.size() < n_set_streams_) {
+            hipStream_t q2 = stream_;
+            if (!pool_.empty()) SIPX_HIP(hipStreamCreateWithFlags(&q2, hipStreamNonBlocking));
+            pool_.push_back(q2);
+          }
+          s.st = s.two_pass ? pool_[(size_t)(++search_next_) % pool_.size()] : pool_[0];
+        } else {
+          s.st = pool_[pool_next_++ % pool_.size()];
+        }
         SIPX_HIP(hipEventCreateWithFlags(&s.ev, hipEventDisableTiming));
         if (s.two_pass && !had_scratch) {
           s.ptmp = dalloc<double>((size_t)(PREP_SLOTS + 2) * NB);
@@ -2694,6 +2715,8 @@ class Engine : public EngineBase {
   bool set_streams_ = true;       // SIPX_SERIAL_SETS=1 keeps every set on the engine stream (A/B measurements)
   hipEvent_t ev_fork_ = nullptr, ev_fork2_ = nullptr;
   std::vector<hipStream_t> pool_;   // streams the sets are dealt onto, round robin
+  bool set_streams_forced_ = false, search_streams_ = false;
+  int search_next_ = 0;
   int n_set_streams_ = 2, pool_next_ = 0;   // measured: 2 beats 1 by 1-4 %, 3+ lose again at 512^3 (streaming passes collide)
   bool mk_ = false;               // Minkowski mode: unknowns [u; v]
   long long Nx_ = 0;              // number of unknowns (N, or 2N in Minkowski mode)
