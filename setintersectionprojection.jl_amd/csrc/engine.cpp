@@ -408,7 +408,9 @@ class Engine : public EngineBase {
       // against a product that reads two vectors instead of one.  SIPX_CG_FUSED=0 / 1 forces it off / on.
       const char* e = std::getenv("SIPX_CG_FUSED");
       const bool small = Nx_ <= (1ll << 23);
-      cg_fused_ = !comm_ && !stencil_q_ && (e ? e[0] == '1' : small);
+      // (the z-marching product has a fused form of its own, k_cds_march<MODE 3>: there the fusion also saves traffic -- 8 N w
+      //  instead of the 9 of product + p-update -- so it is the default at every size for the matrices the march takes)
+      cg_fused_ = !comm_ && !stencil_q_ && (e ? e[0] == '1' : (small || cds_.march != 0));
       if (cg_fused_) { p2_base_ = dalloc<T>(Nx_ + 2 * halo_); p2_ = p2_base_ + halo_; }
     }
     SIPX_HIP(hipMemcpy(m_, m, N * sizeof(T), hipMemcpyHostToDevice));

@@ -163,6 +163,7 @@ constexpr int march_role(int ord, int b) {
   constexpr int o1[7] = {0, 1, 2, 3, 4, 5, 6}, o2[7] = {0, 5, 3, 1, 2, 4, 6};
   return ord == 1 ? o1[b] : o2[b];
 }
+__device__ __forceinline__ void publish_ticket(unsigned long long* ticket, unsigned seq, int iter, int done);      // (defined with the CG scalar steps below)
 constexpr int MARCH_NT = 512;
 template <typename T, int V, int ORD, int MODE>
 __global__ __launch_bounds__(MARCH_NT) void k_cds_march(long long n1, long long n2, long long n3, long long z0, long long z1, const T* __restrict__ R0,
@@ -170,8 +171,40 @@ __global__ __launch_bounds__(MARCH_NT) void k_cds_march(long long n1, long long 
                                                         const T* __restrict__ x, T* __restrict__ y, const T* __restrict__ b,
                                                         T* __restrict__ pout, T* __restrict__ xold, double* __restrict__ partials,
                                                         const int* __restrict__ done, int lgLX, int tiles_x, int tiles_y, int zchunk,
-                                                        long long items) {
+                                                        long long items, CgState<T>* __restrict__ st, CgState<T>* __restrict__ host,
+                                                        unsigned long long* ticket) {
   if (MODE == 1 && *done) return;
+  // MODE 3 (fused CG iteration, see k_cds_fused): the scalar step of iteration k (resvec, stop test, beta) and the product of
+  // iteration k + 1 on p_{k+1} = r_{k+1} + beta p_k, formed wherever it is loaded (x = r_{k+1}, b = p_k; same arithmetic as
+  // k_cg_update_p) and stored once into pout by the thread that owns the point; 8 N w instead of the 9 of product + p-update
+  T beta = T(0);
+  if (MODE == 3) {
+    if (st->done) return;
+    const double ss = block_sum_partials_n<MARCH_NT>(partials + NB);
+    const T rr = (T)ss;
+    const T res = (T)sqrt(ss) / st->nr0;      // cg.jl:100
+    const bool conv = res <= st->tol;         // cg.jl:104-106
+    beta = rr / st->gamma;                    // cg.jl:110
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+      st->ss = ss;
+      st->res_last = res;
+      if (conv) { st->flag = 0; st->done = 1; } else { st->beta = beta; }
+      st->rr = rr;
+      *host = *st;
+      publish_ticket(ticket, st->seq, st->iters, conv ? 1 : 0);
+    }
+    if (conv) return;
+  }
+  auto ldx = [&](long long at) -> Vec<T, V> {          // V entries of the vector the product is taken on
+    Vec<T, V> v = ldv<T, V>(x + at);
+    if (MODE == 3) {
+      const Vec<T, V> pv = ldv<T, V>(b + at);
+#pragma unroll
+      for (int k = 0; k < V; ++k) v.v[k] = v.v[k] + beta * pv.v[k];
+    }
+    return v;
+  };
+  auto ldx1 = [&](long long at) -> T { return MODE == 3 ? x[at] + beta * b[at] : x[at]; };
   __shared__ T sx[2][V][MARCH_NT], sr[2][V][MARCH_NT];
   const int tid = threadIdx.x, LX = 1 << lgLX, tx = tid & (LX - 1), ty = tid >> lgLX, TY = MARCH_NT >> lgLX;
   const long long st1 = n1, st2 = n1 * n2, N = st2 * n3;
@@ -187,8 +220,8 @@ __global__ __launch_bounds__(MARCH_NT) void k_cds_march(long long n1, long long 
     __syncthreads();
     Vec<T, V> xm = zerov<T, V>(), x0 = zerov<T, V>(), rzm = zerov<T, V>();
     if (active) {
-      xm = ldv<T, V>(x + st2 * (k0 - 1) + go);                 // (x carries a halo of a plane on both sides)
-      x0 = ldv<T, V>(x + st2 * k0 + go);
+      xm = ldx(st2 * (k0 - 1) + go);                            // (x carries a halo of a plane on both sides)
+      x0 = ldx(st2 * k0 + go);
       if (k0 > 0) rzm = ldv<T, V>(R3 + st2 * (k0 - 1) + go);
     }
     for (long long kz = k0; kz < k1; ++kz) {
@@ -196,7 +229,7 @@ __global__ __launch_bounds__(MARCH_NT) void k_cds_march(long long n1, long long 
       const long long pz = st2 * kz;
       Vec<T, V> xp = zerov<T, V>(), r0 = xp, r1 = xp, r2 = xp, r3 = xp, bv = xp;
       if (active) {
-        xp = ldv<T, V>(x + pz + st2 + go);
+        xp = ldx(pz + st2 + go);
         r0 = ldv_nt<T, V>(R0 + pz + go);
         r1 = ldv_nt<T, V>(R1 + pz + go);
         r2 = ldv_nt<T, V>(R2 + pz + go);
@@ -209,8 +242,8 @@ __global__ __launch_bounds__(MARCH_NT) void k_cds_march(long long n1, long long 
       T xl = __shfl_up(x0.v[V - 1], 1, 64), xr = __shfl_down(x0.v[0], 1, 64), rl = __shfl_up(r1.v[V - 1], 1, 64);
       const long long r = pz + go;               // row of element 0
       if (active) {
-        if (tx == 0 || (tid & 63) == 0) { xl = x[r - 1]; rl = r > 0 ? R1[r - 1] : T(0); }
-        if (tx == LX - 1 || (tid & 63) == 63) xr = x[r + V];
+        if (tx == 0 || (tid & 63) == 0) { xl = ldx1(r - 1); rl = r > 0 ? R1[r - 1] : T(0); }
+        if (tx == LX - 1 || (tid & 63) == 63) xr = ldx1(r + V);
       }
       __syncthreads();
       if (active) {
@@ -219,14 +252,14 @@ __global__ __launch_bounds__(MARCH_NT) void k_cds_march(long long n1, long long 
 #pragma unroll
           for (int k = 0; k < V; ++k) { xu.v[k] = sx[par][k][tid - LX]; ru.v[k] = sr[par][k][tid - LX]; }
         } else {
-          xu = ldv<T, V>(x + r - st1);
+          xu = ldx(r - st1);
           if (r - st1 >= 0) ru = ldv<T, V>(R2 + r - st1);
         }
         if (ty < TY - 1 && j + 1 < n2) {
 #pragma unroll
           for (int k = 0; k < V; ++k) xd.v[k] = sx[par][k][tid + LX];
         } else {
-          xd = ldv<T, V>(x + r + st1);
+          xd = ldx(r + st1);
         }
         Vec<T, V> o4;
 #pragma unroll
@@ -248,10 +281,11 @@ __global__ __launch_bounds__(MARCH_NT) void k_cds_march(long long n1, long long 
         }
         if (MODE == 0) {
           stv_nt<T, V>(y + r, o4);
-        } else if (MODE == 1) {
+        } else if (MODE == 1 || MODE == 3) {
 #pragma unroll
           for (int k = 0; k < V; ++k) acc0 += (double)x0.v[k] * (double)o4.v[k];
           stv_nt<T, V>(y + r, o4);
+          if (MODE == 3) stv<T, V>(pout + r, x0);
         } else {
           Vec<T, V> o;
 #pragma unroll
@@ -275,7 +309,7 @@ __global__ __launch_bounds__(MARCH_NT) void k_cds_march(long long n1, long long 
     __syncthreads();
     if ((tid & 63) == 0) { sm[0][tid >> 6] = v0; sm[1][tid >> 6] = v1; }
     __syncthreads();
-    if (tid < (MODE == 1 ? 1 : 2)) {
+    if (tid < (MODE == 2 ? 2 : 1)) {
       double s = 0;
 #pragma unroll
       for (int i = 0; i < MARCH_NT / 64; ++i) s += sm[tid][i];
@@ -290,7 +324,8 @@ __global__ __launch_bounds__(MARCH_NT) void k_cds_march(long long n1, long long 
 // a launch would not fill the chip, keep k_cds
 template <typename T, int MODE>
 static bool try_march(hipStream_t s, long long N, long long r0, long long r1, const T* R, const CdsArgs& a, const T* x, T* y, const T* b,
-                      T* pout, T* xold, double* partials, const int* done) {
+                      T* pout, T* xold, double* partials, const int* done, CgState<T>* st = nullptr, CgState<T>* host = nullptr,
+                      unsigned long long* ticket = nullptr) {
   // SIPX_CDS_MARCH=0: never; =2: also on grids too small to fill the chip that way, in chunks of SIPX_CDS_MARCH_ZCHUNK planes (tests)
   static const int sw = [] { const char* e = getenv("SIPX_CDS_MARCH"); return e ? atoi(e) : 1; }();
   static const long long zc_env = [] { const char* e = getenv("SIPX_CDS_MARCH_ZCHUNK"); return e ? atoll(e) : 0ll; }();
@@ -314,7 +349,7 @@ static bool try_march(hipStream_t s, long long N, long long r0, long long r1, co
   const T *R0 = R + (long long)a.mb[0] * N, *R1 = R + (long long)a.mb[1] * N, *R2 = R + (long long)a.mb[2] * N, *R3 = R + (long long)a.mb[3] * N;
 #define SIPX_MARCH(ORD)                                                                                                              \
   hipLaunchKernelGGL((k_cds_march<T, V, ORD, MODE>), dim3(grid), dim3(MARCH_NT), 0, s, n1, n2, n3, r0 / st2, r1 / st2, R0, R1, R2, R3, x, y, b, pout, \
-                     xold, partials, done, lg, tiles_x, tiles_y, (int)zchunk, items)
+                     xold, partials, done, lg, tiles_x, tiles_y, (int)zchunk, items, st, host, ticket)
   if (a.march == 1) SIPX_MARCH(1);
   else SIPX_MARCH(2);
 #undef SIPX_MARCH
@@ -890,6 +925,10 @@ void K<T>::spmv_fused(hipStream_t s, long long N, const T* R, const CdsArgs& a, 
   int read_bands = a.d;
   if (a.sym) { read_bands = 0; for (int b = 0; b < a.d; ++b) read_bands += a.off[b] >= 0 ? 1 : 0; }
   ObsScope obs(KID_CDS_FUSED, s, (a.d + 4.0) * (double)N * sizeof(T), (read_bands + 4.0) * (double)N * sizeof(T));   // r, p_k read; p_k+1, Ap written
+  if (try_march<T, 3>(s, N, 0, N, R, a, r, Ap, p_old, p_new, nullptr, partials, nullptr, st, host, ticket)) {
+    SIPX_HIP(hipGetLastError());
+    return;
+  }
 #define SIPX_CDSF(V, D) \
   hipLaunchKernelGGL((k_cds_fused<T, V, D>), dim3(fit_grid(N / V, SIPX_CG_GRID)), dim3(BLOCK), 0, s, N, R, a, r, p_old, p_new, Ap, partials, st, host, ticket)
   constexpr int VW = sizeof(T) == 8 ? SIPX_F64_VEC : 4;

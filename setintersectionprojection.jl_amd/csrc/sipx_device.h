@@ -185,6 +185,25 @@ __device__ __forceinline__ double block_sum_partials(const double* __restrict__ 
   return s;
 }
 
+// The same sum, in the same order (hence the same bits), by a workgroup of NT >= BLOCK threads: the first BLOCK threads do
+// what block_sum_partials does, the others only keep the barriers company.
+template <int NT>
+__device__ __forceinline__ double block_sum_partials_n(const double* __restrict__ p) {
+  static_assert(NT >= BLOCK, "at least BLOCK threads");
+  __shared__ double sm[BLOCK / 64];
+  double v = 0;
+  if (threadIdx.x < BLOCK)
+    for (int i = threadIdx.x; i < NB; i += BLOCK) v += p[i];
+  v = wave_sum(v);
+  __syncthreads();
+  if (threadIdx.x < BLOCK && (threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = v;
+  __syncthreads();
+  double s = 0;
+#pragma unroll
+  for (int i = 0; i < BLOCK / 64; ++i) s += sm[i];
+  return s;
+}
+
 // Per-block max of a non-negative value -> maxpart[blockIdx.x].
 template <typename T>
 __device__ __forceinline__ void block_max_store(T vmax, T* __restrict__ maxpart) {

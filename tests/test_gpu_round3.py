@@ -353,3 +353,26 @@ def test_slab_searches_settle_in_one_exchange(sipx, tmp_path, monkeypatch):
     for k in ("x", "obj", "cg_it", "rho", "r_pri"):                  # ... and all three protocols end with the same bits
         assert np.array_equal(res["spec"][k], res["staged"][k], equal_nan=True), k
         assert np.array_equal(res["spec"][k], res["tiny"][k], equal_nan=True), k
+
+
+@pytest.mark.parametrize("TF,n", [(np.float32, (64, 40, 24)), (np.float64, (64, 40, 24)), (np.float32, (40, 24, 16))])
+def test_fused_z_marching_cg_iteration_is_bit_identical(sipx, monkeypatch, TF, n):
+    """The fused form of the z-marching product (k_cds_march<MODE 3>: the scalar step of CG iteration k and the product of iteration
+    k + 1 on p = r + beta p_old formed wherever it is loaded; the default wherever the march applies) against product + p-update
+    (SIPX_CG_FUSED=0), both with the march forced on a small grid in chunks of 5 planes (tile edges, chunk edges and the last,
+    shorter chunk inside the grid): same arithmetic, same summation order of the dot products -- the same bits in x, the CG
+    iteration counts and residuals and every log."""
+    from tests.test_gpu_parity import _c3_problem
+    m, g, opt, P, A, prop, AtA = _c3_problem(sipx, n, TF, maxit=30)
+    monkeypatch.setenv("SIPX_CDS_MARCH", "2")
+    monkeypatch.setenv("SIPX_CDS_MARCH_ZCHUNK", "5")
+    out = {}
+    for tag in ("0", "1"):
+        monkeypatch.setenv("SIPX_CG_FUSED", tag)
+        x, log, l, y = sipx.PARSDMM(m.copy(), AtA, A, prop, P, g, opt)
+        out[tag] = (x, log)
+    (x0, l0), (x1, l1) = out["0"], out["1"]
+    assert l0.cg_it.sum() > len(l0.cg_it)                       # iterations beyond the first did run
+    assert np.array_equal(l0.cg_it, l1.cg_it) and np.array_equal(l0.cg_relres, l1.cg_relres)
+    assert np.array_equal(x0, x1) and np.array_equal(l0.obj, l1.obj) and np.array_equal(l0.r_pri, l1.r_pri)
+    assert np.array_equal(l0.rho, l1.rho)
