@@ -10,7 +10,7 @@ src=$root/setintersectionprojection.jl_amd/csrc
 out=$(mktemp -d)
 FLAGS="-O3 --offload-arch=gfx950 -fPIC -std=c++17 -ffp-contract=off -munsafe-fp-atomics -Wno-pass-failed -Wno-unused-result $*"
 pids=()
-for f in kernels_cds.hip kernels_sets.hip kernels_proj.hip ext_proj.hip comm.cpp engine.cpp api.cpp; do
+for f in kernels_cds.hip kernels_sets.hip kernels_multi.hip kernels_proj.hip ext_proj.hip comm.cpp engine.cpp api.cpp; do
   hipcc $FLAGS -x hip -I"$src" -c "$src/$f" -o "$out/${f%.*}.o" & pids+=($!)
 done
 for p in "${pids[@]}"; do wait "$p"; done
