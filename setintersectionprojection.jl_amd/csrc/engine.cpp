@@ -193,7 +193,7 @@ class Engine : public EngineBase {
     (void)hipSetDevice(device_);
     (void)hipStreamSynchronize(stream_);
     for (auto& s : sets_) free_set(s);
-    for (void* p : {(void*)x0s_base_[0], (void*)x0s_base_[1], (void*)w_base_, (void*)x_base_, (void*)xold_, (void*)rhs_, (void*)m_base_, (void*)r_base_, (void*)p_base_, (void*)p2_base_, (void*)Ap_, (void*)Q_,
+    for (void* p : {(void*)x0s_base_[0], (void*)x0s_base_[1], (void*)w_base_, (void*)x_base_, (void*)xold_, (void*)rhs_, (void*)m_base_, (void*)r_base_, (void*)p_base_, (void*)p2_base_, (void*)Ap_, (void*)Q_, (void*)Q2_,
                     (void*)scr_v_, (void*)scr_c_, (void*)scr_i_, (void*)scr_w_, (void*)part_cg_, (void*)part_tmp_, (void*)part_sets_,
                     (void*)maxpart_, (void*)cg_dev_, (void*)gbuf_, (void*)stage_, (void*)sstage_, (void*)fbuf_})
       dfree(p);
@@ -423,6 +423,7 @@ class Engine : public EngineBase {
       const char* mu = std::getenv("SIPX_YL_MULTI");            // 0: one k_yl launch per set on every iteration (A/B switch, tests)
       yl_multi_ = !(mu && mu[0] == '0');
       if (const char* ra = std::getenv("SIPX_RESID_AHEAD")) resid_ahead_ = ra[0] != '0';      // A/B switch
+      if (const char* qf = std::getenv("SIPX_Q_FUSED")) q_fused_ = qf[0] != '0';               // A/B switch
       MultiArgs<T> probe;
       x0_mode_ = !(e && e[0] == '0') && sweep_applicable(SIPX_YL_FEAS | SIPX_YL_BB, probe, true);
       // Set streams when the sweep does the updates: all that runs on them is the threshold / scale searches, chains of short
@@ -751,8 +752,17 @@ class Engine : public EngineBase {
     const int dt = dtype_code();
     // the initial residual goes straight into the p buffer (p_1 = r_0, cg.jl:57): the first iteration reads it from there
     // as both r and p and writes r_1 into the r buffer, so the copy p <- r is never made
-    if (stencil_q_) K<T>::sq_resid(stream_, G_, sq_, x_, rhs_, p_, (T*)nullptr, xold_, part_cg_);
-    else K<T>::resid(stream_, Nx_, r0, r1, Q_, cds_, x_, rhs_, p_, (T*)nullptr, xold_, part_cg_);
+    bool done = false;
+    if (q_pending_ && !stencil_q_ && !comm_ && r0 == 0 && r1 == Nx_) {
+      if (!Q2_) Q2_ = dalloc<T>((size_t)Nx_ * cds_.d);
+      done = K<T>::resid_qupdate(stream_, G_, Nx_, Q_, Q2_, cds_, q_pending_args_, x_, rhs_, p_, (T*)nullptr, xold_, part_cg_);
+      if (done) { std::swap(Q_, Q2_); q_pending_ = false; }
+    }
+    if (!done) {
+      flush_q_pending();
+      if (stencil_q_) K<T>::sq_resid(stream_, G_, sq_, x_, rhs_, p_, (T*)nullptr, xold_, part_cg_);
+      else K<T>::resid(stream_, Nx_, r0, r1, Q_, cds_, x_, rhs_, p_, (T*)nullptr, xold_, part_cg_);
+    }
     if (comm_) {         // ||r_0||^2, ||rhs||^2 block partials [+ the per-set sums of the y/l update queued just before]; p_1 = r_0 is in p_
       comm_->allreduce_with_halo(part_cg_, (size_t)(2 * NB + merged_nslots_), SIPX_F64, p_ + r0, p_ + r0 - plane_, prev_, p_ + r1 - plane_,
                                  p_ + r1, next_, (size_t)plane_, dt, stream_);
@@ -1494,13 +1504,28 @@ class Engine : public EngineBase {
       mk_q_update(al);
       return;
     }
+    flush_q_pending();
     QArgs<T> a;
     a.nsets = 0;
     for (int i = 0; i < p_n_; ++i) {
       if (rho_new[i] == rho_old[i]) continue;                       // ind_updated, PARSDMM.jl:230
       push_qset(a, sets_[i], (T)rho_new[i] - (T)rho_old[i]);        // Q_update!.jl:47
     }
+    if (q_defer_ && q_fused_ && cds_.march != 0 && !comm_ && a.nsets > 0) {
+      bool generated = true;
+      for (int k = 0; k < a.nsets; ++k) generated &= a.s[k].ata == nullptr;
+      if (generated) {                       // applied by the residual product of the coming x-step
+        q_pending_args_ = a;
+        q_pending_ = true;
+        return;
+      }
+    }
     K<T>::q_update(stream_, G_, qr0_, qr1_, cds_, a, Q_);
+  }
+  void flush_q_pending() {
+    if (!q_pending_) return;
+    q_pending_ = false;
+    K<T>::q_update(stream_, G_, qr0_, qr1_, cds_, q_pending_args_, Q_);
   }
 
   // Warm start of this (finer) level from a solved coarser one, device to device: x by nearest-neighbour resampling of the
@@ -1806,8 +1831,10 @@ class Engine : public EngineBase {
         R.rhs_ready = true;
       }
       if (changed) {
+        q_defer_ = i < maxit;               // (the last iteration's update is applied at once: the context keeps a current Q)
         q_update(rho_new.data(), rho.data());                          // :230-243
-        mark(6);
+        q_defer_ = false;
+        if (!q_pending_) mark(6);
       }
       rho = rho_new;
     }
@@ -1822,6 +1849,7 @@ class Engine : public EngineBase {
       SIPX_HIP(hipStreamWaitEvent(stream_, ev_c_[1], 0));
       rs_pending_ = false;
     }
+    flush_q_pending();
     resolve_timing(log, 0);
     resolve_timing(log, 1);
     log->n_iter = n_iter;
@@ -1926,6 +1954,7 @@ class Engine : public EngineBase {
     if (offsets) for (int b = 0; b < cds_.d; ++b) offsets[b] = cds_.off[b];
     if (Q && stencil_q_) throw std::runtime_error("stencil Q mode stores no bands (use sipx_apply_Q)");
     if (Q && comm_ && comm_->world > 1) throw std::runtime_error("a sharded context maintains its slab of Q only");
+    flush_q_pending();
     if (Q && cds_.sym) {      // the negative bands are not maintained while solving: rebuild them from their partners
       K<T>::mirror_bands(stream_, Nx_, cds_, Q_);
       SIPX_HIP(hipStreamSynchronize(stream_));
@@ -1938,6 +1967,7 @@ class Engine : public EngineBase {
     if (comm_ && comm_->world > 1) throw std::runtime_error("a sharded context maintains its slab of Q only");
     SIPX_HIP(hipStreamSynchronize(stream_));
     SIPX_HIP(hipMemcpy(p_, x, Nx_ * sizeof(T), hipMemcpyHostToDevice));
+    flush_q_pending();
     if (stencil_q_) K<T>::sq_spmv(stream_, G_, sq_, p_, Ap_);
     else K<T>::spmv(stream_, G_, Nx_, Q_, cds_, p_, Ap_);
     SIPX_HIP(hipStreamSynchronize(stream_));
@@ -1946,6 +1976,7 @@ class Engine : public EngineBase {
 
   double time_spmv(int reps) override {
     need_final();
+    flush_q_pending();
     hipEvent_t a, b;
     SIPX_HIP(hipEventCreate(&a));
     SIPX_HIP(hipEventCreate(&b));
@@ -2757,6 +2788,15 @@ class Engine : public EngineBase {
   double* dres_ = nullptr;                  // device copy of the reduced per-set sums (all-reduce buffer)
   hipEvent_t ev_sums_ = nullptr, ev_cgb_ = nullptr;
   bool sums_pending_ = false, defer_sums_ = false;
+  // SIPX_Q_FUSED=1 (measured, NOT the default): a Q update decided at the end of an iteration of the whole-solve loop is not
+  // applied at once; the residual product that opens the next x-step applies it on the fly (K::resid_qupdate, z-marching matrices
+  // on one rank) into the second copy of Q, and the two copies swap roles; whoever else reads Q first flushes it through
+  // k_q_update.  Bit-identical (tested), 8 N w instead of 12 for update + product -- and slower: regenerating the band values costs
+  // the 512-thread march kernel more than the traffic saves (512^3: 115 -> 109 it/s), and at 256^3 the separate kernels meet
+  // in the Infinity Cache (k_q_update leaves the four bands there: 46 us for 8 N w; 774 -> 732 it/s).
+  bool q_fused_ = false, q_pending_ = false, q_defer_ = false;
+  QArgs<T> q_pending_args_;
+  T* Q2_ = nullptr;
   bool slab_dist_logs_ = false;       // slab-decomposed and a distance term among the sets: obj / evol_x sums come from its y/l update
   bool head_done_ = false;            // the residual product of the coming x-step is queued already (argmin_x_head)
   bool merge_sums_ = false;           // sharded whole-solve loop: the coming reduction of the set sums leaves its all-reduce to argmin_x_head

@@ -163,16 +163,73 @@ constexpr int march_role(int ord, int b) {
   constexpr int o1[7] = {0, 1, 2, 3, 4, 5, 6}, o2[7] = {0, 5, 3, 1, 2, 4, 6};
   return ord == 1 ? o1[b] : o2[b];
 }
+// value of (A'A)[g, g+o] for a difference operator (identity when nblk == 0), accumulated in ascending row order of A
+template <typename T>
+__device__ __forceinline__ T ata_value(const Grid& G, int nblk, const int* dir, const T* ihs, long long o, const Coord& c) {
+  T val = (nblk == 0 && o == 0) ? T(1) : T(0);   // identity: AtA = I (precompute_distribute.jl:44-45)
+  for (int q = 0; q < nblk; ++q) {
+    const int d = dir[q];
+    const T ih = ihs[q], nih = -ih;
+    const int cc = coord_of(c, d);
+    const long long st = G.st[d];
+    if (o == 0) {
+      if (cc > 0) val = val + ih * ih;              // row g-st holds +ih in column g
+      if (cc < G.n[d] - 1) val = val + nih * nih;   // row g holds -ih in column g
+    } else if (o == st) {
+      if (cc < G.n[d] - 1) val = val + nih * ih;    // row g: A[g,g]*A[g,g+st]
+    } else if (o == -st) {
+      if (cc > 0) val = val + ih * nih;             // row g-st: A[.,g]*A[.,g-st]
+    }
+  }
+  return val;
+}
+
+// What the residual product needs to apply a pending Q update on the fly (MODE 4 of the march): the changed sets with their
+// rho differences (the arithmetic of k_q_update, band values regenerated from the operator descriptors) and where the updated
+// bands go -- a second copy of Q: the tile in front, the row above and the plane below are still read from the old one.
+template <typename T>
+struct QUpd {
+  QArgs<T> a;
+  T* qn[4];       // the four stored bands (offsets 0, +1, +n1, +n1 n2) of the updated matrix
+  Grid G;
+};
+struct NoExtra {};
+template <typename T>
+__device__ __forceinline__ T q_upd_val(const QUpd<T>& u, long long o, const Coord& c, T qv) {
+  for (int si = 0; si < u.a.nsets; ++si) {           // the changed sets in order (Q_update!.jl:45-48)
+    const QSet<T>& S = u.a.s[si];
+    bool has = false;
+    for (int t = 0; t < S.nband; ++t) has |= S.off[t] == o;
+    if (has) qv = qv + S.alpha * ata_value<T>(u.G, S.nblk, S.dir, S.ih, o, c);
+  }
+  return qv;
+}
+template <typename T>
+__device__ __forceinline__ T q_upd_val(const NoExtra&, long long, const Coord&, T qv) { return qv; }
+template <typename T>
+__device__ __forceinline__ const Grid& extra_grid(const QUpd<T>& u) { return u.G; }
+__device__ __forceinline__ Grid extra_grid(const NoExtra&) { return Grid{}; }
+template <typename T, int V>
+__device__ __forceinline__ void store_bands(const QUpd<T>& u, long long r, const Vec<T, V>& r0, const Vec<T, V>& r1, const Vec<T, V>& r2,
+                                            const Vec<T, V>& r3) {
+  stv<T, V>(u.qn[0] + r, r0);
+  stv<T, V>(u.qn[1] + r, r1);
+  stv<T, V>(u.qn[2] + r, r2);
+  stv<T, V>(u.qn[3] + r, r3);
+}
+template <typename T, int V>
+__device__ __forceinline__ void store_bands(const NoExtra&, long long, const Vec<T, V>&, const Vec<T, V>&, const Vec<T, V>&, const Vec<T, V>&) {}
 __device__ __forceinline__ void publish_ticket(unsigned long long* ticket, unsigned seq, int iter, int done);      // (defined with the CG scalar steps below)
 constexpr int MARCH_NT = 512;
-template <typename T, int V, int ORD, int MODE>
+template <typename T, int V, int ORD, int MODE, typename X>
 __global__ __launch_bounds__(MARCH_NT) void k_cds_march(long long n1, long long n2, long long n3, long long z0, long long z1, const T* __restrict__ R0,
                                                         const T* __restrict__ R1, const T* __restrict__ R2, const T* __restrict__ R3,
                                                         const T* __restrict__ x, T* __restrict__ y, const T* __restrict__ b,
                                                         T* __restrict__ pout, T* __restrict__ xold, double* __restrict__ partials,
                                                         const int* __restrict__ done, int lgLX, int tiles_x, int tiles_y, int zchunk,
                                                         long long items, CgState<T>* __restrict__ st, CgState<T>* __restrict__ host,
-                                                        unsigned long long* ticket) {
+                                                        unsigned long long* ticket, X extra) {
+  constexpr bool UPD = MODE == 4;         // MODE 4 = MODE 2 (residual form) with the pending Q update applied on the fly
   if (MODE == 1 && *done) return;
   // MODE 3 (fused CG iteration, see k_cds_fused): the scalar step of iteration k (resvec, stop test, beta) and the product of
   // iteration k + 1 on p_{k+1} = r_{k+1} + beta p_k, formed wherever it is loaded (x = r_{k+1}, b = p_k; same arithmetic as
@@ -222,7 +279,13 @@ __global__ __launch_bounds__(MARCH_NT) void k_cds_march(long long n1, long long 
     if (active) {
       xm = ldx(st2 * (k0 - 1) + go);                            // (x carries a halo of a plane on both sides)
       x0 = ldx(st2 * k0 + go);
-      if (k0 > 0) rzm = ldv<T, V>(R3 + st2 * (k0 - 1) + go);
+      if (k0 > 0) {
+        rzm = ldv<T, V>(R3 + st2 * (k0 - 1) + go);
+        if (UPD) {
+#pragma unroll
+          for (int k = 0; k < V; ++k) rzm.v[k] = q_upd_val<T>(extra, st2, Coord{(int)(i0 + k), (int)j, (int)(k0 - 1)}, rzm.v[k]);
+        }
+      }
     }
     for (long long kz = k0; kz < k1; ++kz) {
       const int par = (int)(kz & 1);
@@ -234,7 +297,17 @@ __global__ __launch_bounds__(MARCH_NT) void k_cds_march(long long n1, long long 
         r1 = ldv_nt<T, V>(R1 + pz + go);
         r2 = ldv_nt<T, V>(R2 + pz + go);
         r3 = ldv_nt<T, V>(R3 + pz + go);
-        if (MODE == 2) bv = ldv<T, V>(b + pz + go);
+        if (MODE == 2 || MODE == 4) bv = ldv<T, V>(b + pz + go);
+        if (UPD) {
+#pragma unroll
+          for (int k = 0; k < V; ++k) {
+            const Coord ck{(int)(i0 + k), (int)j, (int)kz};
+            r0.v[k] = q_upd_val<T>(extra, 0, ck, r0.v[k]);
+            r1.v[k] = q_upd_val<T>(extra, 1, ck, r1.v[k]);
+            r2.v[k] = q_upd_val<T>(extra, st1, ck, r2.v[k]);
+            r3.v[k] = q_upd_val<T>(extra, st2, ck, r3.v[k]);
+          }
+        }
       }
 #pragma unroll
       for (int k = 0; k < V; ++k) { sx[par][k][tid] = x0.v[k]; sr[par][k][tid] = r2.v[k]; }
@@ -242,7 +315,11 @@ __global__ __launch_bounds__(MARCH_NT) void k_cds_march(long long n1, long long 
       T xl = __shfl_up(x0.v[V - 1], 1, 64), xr = __shfl_down(x0.v[0], 1, 64), rl = __shfl_up(r1.v[V - 1], 1, 64);
       const long long r = pz + go;               // row of element 0
       if (active) {
-        if (tx == 0 || (tid & 63) == 0) { xl = ldx1(r - 1); rl = r > 0 ? R1[r - 1] : T(0); }
+        if (tx == 0 || (tid & 63) == 0) {
+          xl = ldx1(r - 1);
+          rl = r > 0 ? R1[r - 1] : T(0);
+          if (UPD && r > 0) rl = q_upd_val<T>(extra, 1, coords(extra_grid(extra), r - 1), rl);     // (still the old value in memory)
+        }
         if (tx == LX - 1 || (tid & 63) == 63) xr = ldx1(r + V);
       }
       __syncthreads();
@@ -253,7 +330,13 @@ __global__ __launch_bounds__(MARCH_NT) void k_cds_march(long long n1, long long 
           for (int k = 0; k < V; ++k) { xu.v[k] = sx[par][k][tid - LX]; ru.v[k] = sr[par][k][tid - LX]; }
         } else {
           xu = ldx(r - st1);
-          if (r - st1 >= 0) ru = ldv<T, V>(R2 + r - st1);
+          if (r - st1 >= 0) {
+            ru = ldv<T, V>(R2 + r - st1);
+            if (UPD) {
+#pragma unroll
+              for (int k = 0; k < V; ++k) ru.v[k] = q_upd_val<T>(extra, st1, coords(extra_grid(extra), r - st1 + k), ru.v[k]);
+            }
+          }
         }
         if (ty < TY - 1 && j + 1 < n2) {
 #pragma unroll
@@ -297,6 +380,7 @@ __global__ __launch_bounds__(MARCH_NT) void k_cds_march(long long n1, long long 
           stv<T, V>(y + r, o);
           if (pout) stv<T, V>(pout + r, o);
           if (xold) stv<T, V>(xold + r, x0);
+          if (UPD) store_bands<T, V>(extra, r, r0, r1, r2, r3);
         }
       }
       xm = x0; x0 = xp; rzm = r3;
@@ -309,7 +393,7 @@ __global__ __launch_bounds__(MARCH_NT) void k_cds_march(long long n1, long long 
     __syncthreads();
     if ((tid & 63) == 0) { sm[0][tid >> 6] = v0; sm[1][tid >> 6] = v1; }
     __syncthreads();
-    if (tid < (MODE == 2 ? 2 : 1)) {
+    if (tid < ((MODE == 2 || MODE == 4) ? 2 : 1)) {
       double s = 0;
 #pragma unroll
       for (int i = 0; i < MARCH_NT / 64; ++i) s += sm[tid][i];
@@ -325,7 +409,7 @@ __global__ __launch_bounds__(MARCH_NT) void k_cds_march(long long n1, long long 
 template <typename T, int MODE>
 static bool try_march(hipStream_t s, long long N, long long r0, long long r1, const T* R, const CdsArgs& a, const T* x, T* y, const T* b,
                       T* pout, T* xold, double* partials, const int* done, CgState<T>* st = nullptr, CgState<T>* host = nullptr,
-                      unsigned long long* ticket = nullptr) {
+                      unsigned long long* ticket = nullptr, const QUpd<T>* upd = nullptr) {
   // SIPX_CDS_MARCH=0: never; =2: also on grids too small to fill the chip that way, in chunks of SIPX_CDS_MARCH_ZCHUNK planes (tests)
   static const int sw = [] { const char* e = getenv("SIPX_CDS_MARCH"); return e ? atoi(e) : 1; }();
   static const long long zc_env = [] { const char* e = getenv("SIPX_CDS_MARCH_ZCHUNK"); return e ? atoll(e) : 0ll; }();
@@ -347,11 +431,16 @@ static bool try_march(hipStream_t s, long long N, long long r0, long long r1, co
   if (items < 384 && sw != 2) return false;
   const int grid = (int)(items < NB ? items : NB);
   const T *R0 = R + (long long)a.mb[0] * N, *R1 = R + (long long)a.mb[1] * N, *R2 = R + (long long)a.mb[2] * N, *R3 = R + (long long)a.mb[3] * N;
-#define SIPX_MARCH(ORD)                                                                                                              \
-  hipLaunchKernelGGL((k_cds_march<T, V, ORD, MODE>), dim3(grid), dim3(MARCH_NT), 0, s, n1, n2, n3, r0 / st2, r1 / st2, R0, R1, R2, R3, x, y, b, pout, \
-                     xold, partials, done, lg, tiles_x, tiles_y, (int)zchunk, items, st, host, ticket)
-  if (a.march == 1) SIPX_MARCH(1);
-  else SIPX_MARCH(2);
+#define SIPX_MARCH(ORD, XT, XV)                                                                                                      \
+  hipLaunchKernelGGL((k_cds_march<T, V, ORD, MODE, XT>), dim3(grid), dim3(MARCH_NT), 0, s, n1, n2, n3, r0 / st2, r1 / st2, R0, R1, R2, R3, x, y, b, pout, \
+                     xold, partials, done, lg, tiles_x, tiles_y, (int)zchunk, items, st, host, ticket, XV)
+  if constexpr (MODE == 4) {
+    if (a.march == 1) SIPX_MARCH(1, QUpd<T>, *upd);
+    else SIPX_MARCH(2, QUpd<T>, *upd);
+  } else {
+    if (a.march == 1) SIPX_MARCH(1, NoExtra, NoExtra{});
+    else SIPX_MARCH(2, NoExtra, NoExtra{});
+  }
 #undef SIPX_MARCH
   return true;
 }
@@ -539,27 +628,6 @@ struct GenArgs {
   int nband;
   long long off[7];
 };
-// value of (A'A)[g, g+o] for a difference operator (identity when nblk == 0), accumulated in ascending row order of A
-template <typename T>
-__device__ __forceinline__ T ata_value(const Grid& G, int nblk, const int* dir, const T* ihs, long long o, const Coord& c) {
-  T val = (nblk == 0 && o == 0) ? T(1) : T(0);   // identity: AtA = I (precompute_distribute.jl:44-45)
-  for (int q = 0; q < nblk; ++q) {
-    const int d = dir[q];
-    const T ih = ihs[q], nih = -ih;
-    const int cc = coord_of(c, d);
-    const long long st = G.st[d];
-    if (o == 0) {
-      if (cc > 0) val = val + ih * ih;              // row g-st holds +ih in column g
-      if (cc < G.n[d] - 1) val = val + nih * nih;   // row g holds -ih in column g
-    } else if (o == st) {
-      if (cc < G.n[d] - 1) val = val + nih * ih;    // row g: A[g,g]*A[g,g+st]
-    } else if (o == -st) {
-      if (cc > 0) val = val + ih * nih;             // row g-st: A[.,g]*A[.,g-st]
-    }
-  }
-  return val;
-}
-
 template <typename T>
 __global__ __launch_bounds__(BLOCK) void k_gen_ata(Grid G, GenArgs a, T ih0, T ih1, T ih2, T* __restrict__ R) {
   const T ihs[3] = {ih0, ih1, ih2};
@@ -947,6 +1015,25 @@ void K<T>::spmv_fused(hipStream_t s, long long N, const T* R, const CdsArgs& a, 
   SIPX_HIP(hipGetLastError());
 }
 
+// The residual product of an x-step that follows a change of rho, with the Q update applied on the fly (z-marching matrices, one
+// rank, band values generated from the descriptors): reads the four stored bands of the OLD matrix once, adds the changed sets'
+// rho differences in k_q_update's order (same arithmetic: the same bits), uses the result in the product and writes it into the
+// second copy of Q -- 8 N w for update + product instead of 8 + 4, and one launch less.  false: not applicable (caller: k_q_update, then the product).
+template <typename T>
+bool K<T>::resid_qupdate(hipStream_t s, const Grid& g, long long N, const T* R_old, T* R_new, const CdsArgs& a, const QArgs<T>& qa, const T* x,
+                         const T* b, T* r, T* p, T* xold, double* partials) {
+  if (!a.march || !a.sym || a.d != 7 || qa.nsets == 0) return false;
+  for (int i = 0; i < qa.nsets; ++i)
+    if (qa.s[i].ata) return false;                     // caller-supplied A'A bands: the separate kernel reads them
+  QUpd<T> u;
+  u.a = qa;
+  for (int q = 0; q < 4; ++q) u.qn[q] = R_new + (long long)a.mb[q] * N;
+  u.G = g;
+  const double rw = (double)N * sizeof(T);
+  ObsScope obs(KID_CDS_RESID, s, (a.d + 4.0) * rw + 3.0 * 4.0 * rw, (4.0 + 4.0) * rw + 4.0 * rw);      // SURVEY: B_resid0 + B_Q; moved: 4 bands + x, b, r, x_old + 4 bands written
+  return try_march<T, 4>(s, N, 0, N, R_old, a, x, r, b, p, xold, partials, nullptr, nullptr, nullptr, nullptr, &u);
+}
+
 // ---------------------------------------------------------------------------------------------
 // out[slot] = sum of the NB partials of each slot (one block per slot, fixed order)
 __global__ __launch_bounds__(BLOCK) void k_fin_sum(const double* __restrict__ partials, double* __restrict__ out_dev,
@@ -984,6 +1071,8 @@ void K<T>::copy_f64(hipStream_t s, const double* src, double* dst, int n) {
                                  CgState<T>*, CgState<T>*, unsigned long long*);                                      \
   template void K<T>::resid(hipStream_t, long long, long long, long long, const T*, const CdsArgs&, const T*, const T*, T*, \
                             T*, T*, double*);                                                                         \
+  template bool K<T>::resid_qupdate(hipStream_t, const Grid&, long long, const T*, T*, const CdsArgs&, const QArgs<T>&, const T*, \
+                                    const T*, T*, T*, T*, double*);                                                   \
   template void K<T>::q_axpy(hipStream_t, long long, T*, const T*, T);                                               \
   template void K<T>::q_update_mk(hipStream_t, const Grid&, const CdsArgs&, const MkArgs<T>&, T*);                    \
   template void K<T>::mirror_bands(hipStream_t, long long, const CdsArgs&, T*);                                       \

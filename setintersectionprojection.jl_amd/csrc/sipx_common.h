@@ -369,6 +369,9 @@ struct K {
                        double* partials, const CgState<T>* st);
   static void resid(hipStream_t s, long long N, long long r0, long long r1, const T* R, const CdsArgs& a, const T* x, const T* b,
                     T* r, T* p, T* xold, double* partials);
+  // the same with a pending Q update applied on the fly (kernels_cds.hip); false when the z-marching form does not apply
+  static bool resid_qupdate(hipStream_t s, const Grid& g, long long N, const T* R_old, T* R_new, const CdsArgs& a, const QArgs<T>& qa,
+                            const T* x, const T* b, T* r, T* p, T* xold, double* partials);
   // the scalar step of CG iteration k (stop test, beta) + the product of iteration k+1 on p = r + beta p_old formed on the fly
   // (r, p_old carry a zero halo); writes p_new, Ap and the partials of p_new . Ap
   static void spmv_fused(hipStream_t s, long long N, const T* R, const CdsArgs& a, const T* r, const T* p_old, T* p_new, T* Ap,

@@ -402,3 +402,34 @@ def test_slab_decomposed_mid_size_ranks(sipx, tmp_path, world, n):
     xs, ls, _, _ = sipx.PARSDMM(m.copy(), AtAs, As, props, Ps, gs, os_)
     assert len(ls.obj) == len(r0["obj"])
     assert np.linalg.norm(r0["x"] - xs) / np.linalg.norm(xs) < 5e-4
+
+
+@pytest.mark.parametrize("TF,n", [(np.float32, (64, 40, 24)), (np.float64, (40, 24, 16))])
+def test_q_update_inside_the_residual_product_is_bit_identical(sipx, monkeypatch, TF, n):
+    """A change of rho decided at the end of an iteration is applied by the residual product that opens the next x-step
+    (k_cds_march<MODE 4>: the four stored bands of the old matrix read once, the changed sets' rho differences added in
+    k_q_update's order, the result used in the product and written into the second copy of Q) instead of by k_q_update
+    (SIPX_Q_FUSED=0): the same Q bit for bit -- read back after 11 steps, i.e. with an update still pending, and at the end of the
+    solve -- and the same x, CG counts and logs.  The march is forced on this small grid in chunks of 5 planes."""
+    from tests.test_gpu_parity import _c3_problem
+    m, g, opt, P, A, prop, AtA = _c3_problem(sipx, n, TF, maxit=30)
+    monkeypatch.setenv("SIPX_CDS_MARCH", "2")
+    monkeypatch.setenv("SIPX_CDS_MARCH_ZCHUNK", "5")
+    out = {}
+    for tag in ("0", "1"):
+        monkeypatch.setenv("SIPX_Q_FUSED", tag)
+        ctx = sipx.host.build_context(m, AtA, A, prop, P, g, opt)
+        ctx.parsdmm_begin(opt)
+        ctx.parsdmm_steps(11)
+        Qmid, off = ctx.get_Q()
+        ctx.parsdmm_steps(30)
+        Qend, _ = ctx.get_Q()
+        log = ctx.parsdmm_log()
+        x, l, y = ctx.download()
+        ctx.close()
+        out[tag] = (Qmid, Qend, x, log)
+    a, b = out["0"], out["1"]
+    assert len({tuple(r) for r in a[3].rho}) > 2                      # rho did change along the way
+    assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
+    assert np.array_equal(a[2], b[2]) and np.array_equal(a[3].cg_it, b[3].cg_it) and np.array_equal(a[3].obj, b[3].obj)
+    assert np.array_equal(a[3].rho, b[3].rho) and np.array_equal(a[3].r_pri, b[3].r_pri)
