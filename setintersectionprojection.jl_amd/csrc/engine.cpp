@@ -424,6 +424,11 @@ class Engine : public EngineBase {
       yl_multi_ = !(mu && mu[0] == '0');
       if (const char* ra = std::getenv("SIPX_RESID_AHEAD")) resid_ahead_ = ra[0] != '0';      // A/B switch
       if (const char* qf = std::getenv("SIPX_Q_FUSED")) q_fused_ = qf[0] != '0';               // A/B switch
+      // the lean first passes of the l1 searches in one sweep: pays where the re-reads of x are real traffic (512^3, settled
+      // iterations: 133 -> 139 it/s); at 256^3 three concurrent per-set passes on their own streams are as fast or faster
+      // (1028 against 1012 it/s settled, default window equal), so it is the default above 2^24 grid points only
+      lean_multi_ = G_.N > (1ll << 24);
+      if (const char* lm = std::getenv("SIPX_LEAN_MULTI")) lean_multi_ = lm[0] != '0';         // A/B switch, tests
       MultiArgs<T> probe;
       x0_mode_ = !(e && e[0] == '0') && sweep_applicable(SIPX_YL_FEAS | SIPX_YL_BB, probe, true);
       // Set streams when the sweep does the updates: all that runs on them is the threshold / scale searches, chains of short
@@ -1289,6 +1294,39 @@ class Engine : public EngineBase {
   // one rank (or no communicator): the searches of the two-pass sets on the set streams, joined before the sweep
   void sweep_searches(int flags, const double* rho, const double* gamma) {
     const bool feas = (flags & SIPX_YL_FEAS) != 0;
+    // The lean first passes of the l1 searches in ONE sweep (k_lean_multi: x read once): on iterations where no search of the
+    // group is rescaled or sampled first (the device-side state a lean pass needs is then final when the engine stream gets
+    // here), for two or three l1 sets on stencil operators of this grid.  Each set's chain then launches its full first
+    // pass only, which returns at once for the sets the sweep served.
+    std::vector<char> lean_done(p_n_, 0);
+    if (lean_multi_ && Gr_.n[0] % 4 == 0) {
+      LeanMulti<T> lm;
+      lm.ns = 0;
+      bool ok = true;
+      std::vector<int> who;
+      for (int i = 0; i < p_n_ && ok; ++i) {
+        SetState<T>& s = sets_[i];
+        if (!s.two_pass || s.prox != PX_L1 || s.custom || s.ext_kind) continue;
+        SetArgs<T> a = set_args(s, (T)rho[i], (T)gamma[i], flags);
+        if (a.flags & F_NOSPEC) continue;
+        const bool rescaled = s.last_rho > T(0) && s.last_rho != a.rho;
+        const bool sampled = l1_sample_ && (rescaled || (hlean_[i] & 0xff) != 0);
+        if (rescaled || sampled) { ok = false; break; }
+        if (lm.ns == LEAN_MAX) break;
+        LeanSet<T>& L = lm.s[lm.ns++];
+        L.a = a; L.a.ps = s.ps; L.ps = s.ps;
+        L.compact = s.cbuf ? s.cbuf : scr_c_;
+        L.partials = s.ptmp ? s.ptmp : part_tmp_;
+        L.maxpart = s.mpart ? s.mpart : maxpart_;
+        who.push_back(i);
+      }
+      bool own = true;                     // every set of the group needs scratch of its own
+      for (int i : who) own &= sets_[i].ptmp != nullptr && sets_[i].mpart != nullptr && sets_[i].cbuf != nullptr;
+      if (ok && own && lm.ns >= 2) {
+        K<T>::lean_multi(stream_, Gr_, lm);
+        for (int i : who) lean_done[i] = 1;
+      }
+    }
     if (set_streams_) SIPX_HIP(hipEventRecord(ev_fork_, stream_));       // x is final: the searches may start
     for (int i = 0; i < p_n_; ++i) {
       SetState<T>& s = sets_[i];
@@ -1307,6 +1345,7 @@ class Engine : public EngineBase {
       ctl.host_ovf = (int*)hovf_ + i;
       ctl.runs = l1_sample_runs_;
       ctl.enable = l1_sample_ && a.prox == PX_L1 && (rescaled || (hlean_[i] & 0xff) != 0);
+      ctl.lean_done = lean_done[i];
       K<T>::proj_scalars_set(q, Gr_, a, 0, s.ps, ptmp, mpart, cbuf, s.Mtrue, ctl, nullptr);
       s.last_rho = a.rho;
       s.last_gamma = a.gamma;
@@ -2798,6 +2837,7 @@ class Engine : public EngineBase {
   QArgs<T> q_pending_args_;
   T* Q2_ = nullptr;
   bool slab_dist_logs_ = false;       // slab-decomposed and a distance term among the sets: obj / evol_x sums come from its y/l update
+  bool lean_multi_ = false;           // k_lean_multi for the lean first passes of the l1 searches (finalize: above 2^24 grid points; SIPX_LEAN_MULTI=0/1)
   bool head_done_ = false;            // the residual product of the coming x-step is queued already (argmin_x_head)
   bool merge_sums_ = false;           // sharded whole-solve loop: the coming reduction of the set sums leaves its all-reduce to argmin_x_head
   int merged_nslots_ = 0;

@@ -253,6 +253,129 @@ __global__ __launch_bounds__(BLOCK) void k_pass(Grid G, SetArgs<T> a, int v_is_s
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// The LEAN first passes of up to three l1 searches in ONE sweep (round 3): the sets share x, so it is read once -- 1 + 2 per
+// block of every set instead of 3 per block -- and one launch replaces three.  For every set whose device-side state asks for
+// a lean pass (ProjScalars::lean; a set that does not is left to its own full first pass, launched as before) the kernel does
+// exactly what k_pass<M_LEAN> does: the same thread-to-element mapping, the same arithmetic, the same partial slots in the
+// set's own buffers, the same values gathered into the set's own buffer (in another order, which the solve does not depend on).
+template <typename T, int V>
+__global__ __launch_bounds__(BLOCK) void k_lean_multi(Grid G, LeanMulti<T> m) {
+  __shared__ T sbuf[LEAN_MAX][SPEC_CAP];
+  __shared__ unsigned int scnt[LEAN_MAX], sused[LEAN_MAX];
+  __shared__ int sovf[LEAN_MAX];
+  __shared__ unsigned long long sbase[LEAN_MAX];
+  bool on[LEAN_MAX];
+  T tlo[LEAN_MAX], thi[LEAN_MAX], vminp[LEAN_MAX];
+  double r_lo[LEAN_MAX], r_hi[LEAN_MAX], asum[LEAN_MAX], Slo[LEAN_MAX], Shi[LEAN_MAX];
+  unsigned int Clo[LEAN_MAX], Chi[LEAN_MAX];
+  bool any = false;
+#pragma unroll
+  for (int q = 0; q < LEAN_MAX; ++q) {
+    on[q] = false;
+    tlo[q] = thi[q] = (T)INFINITY; vminp[q] = (T)INFINITY;
+    r_lo[q] = 0; r_hi[q] = -1; asum[q] = Slo[q] = Shi[q] = 0; Clo[q] = Chi[q] = 0;
+    if (q < m.ns) {
+      const ProjScalars<T>* ps = m.s[q].ps;
+      r_lo[q] = ps->spec_lo; r_hi[q] = ps->spec_hi;
+      on[q] = ps->lean != 0 && r_hi[q] > r_lo[q];         // (the caller offers l1 sets without F_NOSPEC only)
+      tlo[q] = (T)ps->t[L1_WIN_LO]; thi[q] = (T)ps->t[L1_WIN_HI];
+      any |= on[q];
+    }
+  }
+  if (!any) return;
+  if (threadIdx.x < LEAN_MAX) { scnt[threadIdx.x] = 0; sused[threadIdx.x] = 0; sovf[threadIdx.x] = 0; }
+  __syncthreads();
+  const int lane = threadIdx.x & 63;
+  long long v0, nvec;
+  vec_range<V>(G, v0, nvec);
+  const long long nit = (nvec - v0 + (long long)gridDim.x * BLOCK - 1) / ((long long)gridDim.x * BLOCK);
+  const T* x = m.s[0].a.x;
+  for (long long it = 0; it < nit; ++it) {
+    const long long vi = v0 + it * (long long)gridDim.x * BLOCK + (long long)blockIdx.x * BLOCK + threadIdx.x;
+    const bool live = vi < nvec;
+    const long long g = live ? vi * V : 0;
+    const Coord c = coords(G, g);
+    const Vec<T, V> xc = ldv<T, V>(x + g);
+#pragma unroll
+    for (int q = 0; q < LEAN_MAX; ++q) {
+      if (q >= m.ns || !on[q]) continue;
+      const SetArgs<T>& a = m.s[q].a;
+      const bool ident = a.nblk == 0;
+      const int nb = ident ? 1 : a.nblk;
+      const bool relax = !(a.gamma == T(1));
+      const T gam = a.gamma, omg = T(1) - a.gamma;
+      for (int b = 0; b < nb; ++b) {
+        const long long e = (long long)b * G.N + g;
+        T s[V];
+        bool valid[V];
+        if (ident) {
+#pragma unroll
+          for (int k = 0; k < V; ++k) { s[k] = xc.v[k]; valid[k] = true; }
+        } else {
+          fwd_dir<T, V>(G, a.x, xc, g, c, a.dir[b], a.ih[b], s, valid);
+        }
+        const Vec<T, V> yv = ldv<T, V>(a.y + e), lv = ldv<T, V>(a.l + e);
+#pragma unroll
+        for (int k = 0; k < V; ++k) {
+          const T xh = relax ? (gam * s[k] + omg * yv.v[k]) : s[k];       // update_y_l.jl:72
+          const T vv = live ? (valid[k] ? (xh - lv.v[k] * a.rho1) : T(0)) : T(0);      // :67 / :74
+          const T av = fabs(vv);
+          const double ad = (double)av;
+          asum[q] += ad;
+          const bool o_lo = av > tlo[q], o_hi = av > thi[q];
+          Slo[q] += o_lo ? ad : 0.0; Clo[q] += o_lo ? 1u : 0u;
+          Shi[q] += o_hi ? ad : 0.0; Chi[q] += o_hi ? 1u : 0u;
+          vminp[q] = (av > T(0) && av < vminp[q]) ? av : vminp[q];
+          const bool in = ad > r_lo[q] && ad <= r_hi[q];
+          const unsigned long long mask = __ballot(in);
+          if (mask) {
+            const int leader = __ffsll((long long)mask) - 1;
+            const int cnt = __popcll(mask);
+            const int my = __popcll(mask & ((1ull << lane) - 1ull));
+            unsigned int base = SPEC_CAP;
+            if (lane == leader) base = atomicAdd(&scnt[q], (unsigned int)cnt);
+            base = __shfl(base, leader, 64);
+            if (base + cnt <= SPEC_CAP) {                   // room in the workgroup's LDS buffer of this set
+              if (in) sbuf[q][base + my] = av;
+              if (lane == leader) atomicMax(&sused[q], base + (unsigned int)cnt);
+            } else {
+              sovf[q] = 1;                                  // speculation gathered too much: give it up
+            }
+          }
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int q = 0; q < LEAN_MAX; ++q) {
+    if (q >= m.ns || !on[q]) continue;
+    __syncthreads();                                        // (the reduction helpers share their LDS scratch between calls)
+    double a5[5] = {asum[q], Slo[q], Shi[q], (double)Clo[q], (double)Chi[q]};
+    const int slots[5] = {0, 3 + L1_WIN_LO, 3 + L1_WIN_HI, 3 + L1_K + L1_WIN_LO, 3 + L1_K + L1_WIN_HI};
+    block_reduce_store_at<5>(a5, m.s[q].partials, slots);
+    block_min_store<T>(vminp[q], m.s[q].maxpart + NB);
+    __syncthreads();
+    const unsigned int cnt = sused[q];                      // reservations grow monotonically: the stored entries form the prefix [0, sused)
+    if (threadIdx.x == 0) {
+      sbase[q] = cnt ? atomicAdd(&m.s[q].ps->n_compact, (unsigned long long)cnt) : 0ull;
+      if (sovf[q]) atomicOr(&m.s[q].ps->spec_overflow, 1);
+    }
+    __syncthreads();
+    for (unsigned int i = threadIdx.x; i < cnt; i += BLOCK) m.s[q].compact[sbase[q] + i] = sbuf[q][i];
+  }
+}
+
+template <typename T>
+void K<T>::lean_multi(hipStream_t s, const Grid& g, const LeanMulti<T>& m) {
+  if (m.ns < 1 || m.ns > LEAN_MAX || g.n[0] % 4 != 0) throw std::runtime_error("lean_multi: unsupported call");
+  double bytes = (double)range_len(g);                 // x once, y and l of every block of every set
+  for (int q = 0; q < m.ns; ++q) bytes += 2.0 * (double)m.s[q].a.nblk_or1() * (double)range_len(g);
+  ObsScope obs_(KID_PASS_LEAN, s, bytes * sizeof(T));
+  hipLaunchKernelGGL((k_lean_multi<T, 4>), dim3(fit_grid(range_len(g) / 4, SIPX_PASS_GRID)), dim3(BLOCK), 0, s, g, m);
+  SIPX_HIP(hipGetLastError());
+}
+
 template <typename T>
 __global__ void k_ps_init(ProjScalars<T>* ps, long long* cidx) {
   ps->cidx = cidx;
@@ -1587,7 +1710,7 @@ static void chain_stage(int stage, hipStream_t s, const Grid& g, const SetArgs<T
       return;
     }
     SIPX_PASS(M_FIRST);
-    if (a.prox == PX_L1 && !(a.flags & F_NOSPEC)) SIPX_PASS(M_LEAN);
+    if (a.prox == PX_L1 && !(a.flags & F_NOSPEC) && !ctl.lean_done) SIPX_PASS(M_LEAN);      // (lean_done: k_lean_multi took this set's lean pass)
     // one rank: the last workgroup of the sums takes the decision (no k_decide launch); slab-decomposed: an all-reduce of the
     // caller sits between the two
     ObsScope obs_(KID_SLOT_SUMS, s, 0.0);
@@ -1784,6 +1907,7 @@ void K<T>::proj_dist_set(hipStream_t s, const Grid& g, const SetArgs<T>& a, int 
   template void K<T>::store_v(hipStream_t, const Grid&, const SetArgs<T>&, int, T*);                                                     \
   template void K<T>::proj_scalars_set(hipStream_t, const Grid&, const SetArgs<T>&, int, ProjScalars<T>*, double*, \
                                        T*, T*, long long, SampleCtl, const ChainHooks*);                                        \
+  template void K<T>::lean_multi(hipStream_t, const Grid&, const LeanMulti<T>&);                                                        \
   template void K<T>::proj_scalars_stage(int, hipStream_t, const Grid&, const SetArgs<T>&, int, ProjScalars<T>*, double*, T*, T*,   \
                                          long long, SampleCtl, const ChainHooks*, double*, T*, long long);                                                     \
   template void K<T>::proj_scalars_arr(hipStream_t, long long, const T*, int, T, T, ProjScalars<T>*, double*, T*, \

@@ -246,6 +246,7 @@ struct SampleCtl {
   // speculative exchange (slab-decomposed grid): pinned word of the set that k_spec_decide publishes, (seq << 2) | verdict bits
   unsigned* verdict = nullptr;
   unsigned seq = 0;
+  int lean_done = 0;       // the set's lean first pass was taken by k_lean_multi: the chain launches the full one only (gated as ever)
 };
 
 template <typename T>
@@ -264,6 +265,22 @@ struct SetArgs {
   int flags;
   int vsrc;                             // 1: read v from `v`; 2: read the already projected y from `v`
   int nblk_or1() const { return nblk > 0 ? nblk : 1; }
+};
+
+// the lean first passes of up to three l1 searches in one sweep (kernels_proj.hip, k_lean_multi): per set its arguments and buffers
+template <typename T>
+struct LeanSet {
+  SetArgs<T> a;
+  ProjScalars<T>* ps;
+  T* compact;
+  double* partials;
+  T* maxpart;
+};
+constexpr int LEAN_MAX = 3;
+template <typename T>
+struct LeanMulti {
+  int ns;
+  LeanSet<T> s[LEAN_MAX];
 };
 
 // ---- k_yl_multi: the y/l update of ALL sets in one z-marching sweep (kernels_multi.hip) --------------------------------------
@@ -427,6 +444,7 @@ struct K {
   // one stage (0..3) of the same search, for a caller that runs the searches of several sets in lock step with ONE collective
   // between the stages (slab-decomposed iteration): reg = the set's region of the all-reduced staging buffer, gseg0 / chunk =
   // its segment in rank 0's chunk of the exchange buffer and the distance to the next rank's
+  static void lean_multi(hipStream_t s, const Grid& g, const LeanMulti<T>& m);
   static void proj_scalars_stage(int stage, hipStream_t s, const Grid& g, const SetArgs<T>& a, int v_is_s, ProjScalars<T>* ps,
                                  double* partials, T* maxpart, T* compact, long long true_len, SampleCtl ctl, const ChainHooks* hooks,
                                  double* reg, T* gseg0, long long chunk);

@@ -433,3 +433,34 @@ def test_q_update_inside_the_residual_product_is_bit_identical(sipx, monkeypatch
     assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
     assert np.array_equal(a[2], b[2]) and np.array_equal(a[3].cg_it, b[3].cg_it) and np.array_equal(a[3].obj, b[3].obj)
     assert np.array_equal(a[3].rho, b[3].rho) and np.array_equal(a[3].r_pri, b[3].r_pri)
+
+
+@pytest.mark.parametrize("TF,n,kinds", [(np.float32, (64, 48, 40), ["bounds", "l1:D_x", "l1:D_y", "l1:D_z"]),
+                                         (np.float64, (48, 40, 24), ["bounds", "l1:D_x", "l1:D_z"]),
+                                         (np.float32, (256, 192), ["bounds", "l1:D_x", "l1:D_z"])])
+def test_lean_first_passes_in_one_sweep_are_bit_identical(sipx, monkeypatch, TF, n, kinds):
+    """k_lean_multi (the lean first passes of two or three l1 searches in one sweep, x read once) against one k_pass<M_LEAN> per
+    set (SIPX_LEAN_MULTI=0): the same partial sums, the same gathered values -- theta, x, the CG counts and every log bit for bit
+    over 60 iterations (the group pass runs on the iterations where no search is rescaled or sampled first; the kernel
+    statistics confirm that it did run)."""
+    h = (25.0, 25.0, 25.0)[:len(n)]
+    m = model(n, TF, seed=7)
+    gs, os_, Ps, As, props, AtAs = _problem(sipx, n, h, TF, kinds, m, dict(maxit=60))
+    os_.evol_rel_tol = os_.feas_tol = os_.obj_tol = 0.0
+    out = {}
+    for tag in ("0", "1"):
+        monkeypatch.setenv("SIPX_LEAN_MULTI", tag)
+        ctx = sipx.host.build_context(m, AtAs, As, props, Ps, gs, os_)
+        ctx.kernel_stats(2)
+        ctx.parsdmm_begin(os_)
+        ctx.parsdmm_steps(60)
+        stats = {k["name"]: k for k in ctx.kernel_stats_all(0)["kernels"]}
+        log = ctx.parsdmm_log()
+        x, l, y = ctx.download()
+        ctx.close()
+        out[tag] = (x, log, stats)
+    (x0, l0, s0), (x1, l1, s1) = out["0"], out["1"]
+    lean = [k for k in s0 if "LEAN" in k or "lean" in k]
+    assert lean and s1[lean[0]]["launches"] < s0[lean[0]]["launches"]          # fewer lean launches: the group pass took them
+    assert np.array_equal(x0, x1) and np.array_equal(l0.cg_it, l1.cg_it) and np.array_equal(l0.obj, l1.obj)
+    assert np.array_equal(l0.rho, l1.rho) and np.array_equal(l0.r_pri, l1.r_pri) and np.array_equal(l0.r_dual, l1.r_dual)
