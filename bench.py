@@ -741,12 +741,14 @@ def main():
         traffic, traffic_src = None, None
         if args.q_mode == "cds" and args.dtype == "f32" and world == 1:
             pmc = os.path.join(ROOT, "profiles", f"r03_{'c3_256' if config == 'c3' else config.replace('-', '_')}_pmc.json")
-            if os.path.exists(pmc):
-                rec = json.load(open(pmc))
-                if rec.get("libsipx_sha16") == lib_sha16():
+            try:                                             # (a profile file must never take the bench line with it)
+                rec = json.load(open(pmc)) if os.path.exists(pmc) else {}
+                if rec.get("libsipx_sha16") == lib_sha16() and "dominant_kernel" in rec:
                     traffic = rec["dominant_kernel"]["hbm_bytes_per_launch_corrected"]
                     traffic_src = (f"profiles/{os.path.basename(pmc)}: separate rocprofv3 --pmc passes on this build (libsipx.so sha256[:16] "
                                    f"{rec['libsipx_sha16']}), 2*FETCH_SIZE + WRITE_SIZE per launch (gfx950 correction); not measured in this run")
+            except Exception:
+                traffic, traffic_src = None, None
         finite = bool(np.isfinite(log.obj).all() and np.isfinite(log.r_pri_total).all())
         # Whole-iteration roofline with SURVEY 8(d)'s algorithmic bytes: B_rhs + B_resid0 + k B_cg_iter + B_yl + B_log
         # (+ B_adapt + B_Q when rho / gamma are re-adapted, + B_feas every 10th iteration), summed over the timed steps.

@@ -7,6 +7,7 @@ usage: python tools/summarize_kernel_trace.py <dir with *_kernel_trace.csv> <out
 import csv
 import glob
 import json
+import re
 import os
 import sys
 
@@ -29,7 +30,11 @@ def main():
     tot = sum(r["total_us"] for r in summary)
     for r in summary:
         r["percent"] = 100.0 * r["total_us"] / tot
-    dom = [(n, d) for n, d in per.items() if ("k_cds<" in n or "k_cds_march<" in n) and n.split("(")[0].rstrip().endswith(", 1>")]
+    def is_cg_product(n):      # MODE = 1 is the 4th template argument of k_cds and of k_cds_march
+        m = re.search(r"k_cds(?:_march)?<([^>]*)>", n)
+        a = [v.strip() for v in m.group(1).split(",")] if m else []
+        return len(a) >= 4 and a[3] == "1"
+    dom = [(n, d) for n, d in per.items() if is_cg_product(n)]
     res = {"trace_files": [os.path.basename(f) for f in files], "kernels": summary[:40]}
     if dom:
         name, d = max(dom, key=lambda t: sum(t[1]))

@@ -7,6 +7,7 @@ usage: python tools/summarize_pmc.py <dir of the FETCH_SIZE pass> <dir of the WR
 import csv
 import glob
 import json
+import re
 import os
 import sys
 
@@ -23,8 +24,12 @@ def load(d, counter):
 
 def is_cg_product(k):
     """k_cds<T, V, D, MODE = 1> or its z-marching form k_cds_march<T, V, ORD, MODE = 1>: the product fused with the dot product"""
-    k = k.rstrip()
-    return ("k_cds<" in k or "k_cds_march<" in k) and k.endswith(", 1>")
+    # the MODE argument is the 4th template argument of both (k_cds_march carries one more behind it)
+    m = re.search(r"k_cds(?:_march)?<([^>]*)>", k)
+    if not m:
+        return False
+    args = [a.strip() for a in m.group(1).split(",")]
+    return len(args) >= 4 and args[3] == "1"
 
 
 def main():
