@@ -769,6 +769,19 @@ def main():
                 b += sum(2 * r for r in rows[:pp])
             it_bytes += b * w
         it_gbs = it_bytes / dt / 1e9 / max(world, 1)                # per GPU
+        # Sharded: do the ranks hold the same x?  Every rank completes x (a collective in the slab decomposition), takes an exact
+        # integer checksum of its bits and the ranks compare -- the first thing to look at in a first multi-GPU run.
+        agree = None
+        if dist is not None:
+            try:
+                xs, _, _ = ctx.download(want_ly=False)
+                bits = xs.view(np.uint32 if xs.dtype == np.float32 else np.uint64)
+                chk = float(int(bits.astype(np.uint64).sum() % (1 << 52)))
+                tt = torch.tensor([chk, -chk], dtype=torch.float64, device="cuda")
+                dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+                agree = bool(float(tt[0].item()) == -float(tt[1].item())) and bool(np.isfinite(xs).all())
+            except Exception as e:                                  # (diagnostics only)
+                agree = f"check failed: {e!r}"[:200]
         ctx.close()
         frac_moved = (sym_bytes / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if launches else None
         frac_traffic = (traffic / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if (launches and traffic) else None
@@ -776,7 +789,8 @@ def main():
         return {
             "comm": {"rccl_nranks": comm_info["nranks"], "rccl_rank": comm_info["rank"], "rccl_version": comm_info["version"],
                      "decomposition": comm_info["decomposition"] if dist is not None else None,
-                     "slab_searches": searches if (dist is not None and slab) else None},
+                     "slab_searches": searches if (dist is not None and slab) else None,
+                     "ranks_agree_on_x": agree},
             "dominant_kernel": dominant, "kernels": table,
             "value": steps / dt, "ms_per_step": dt / steps * 1e3, "decomposition": ("slab" if slab else "sets") if dist is not None else None,
             # log.timing of the whole run (warm-up included), per iteration: where the time of an iteration goes on this rank

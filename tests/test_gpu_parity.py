@@ -1818,6 +1818,7 @@ def test_bench_contract_line(dist_env):
         assert d["value"] == d["decompositions"]["slab"]["value"]
         for v in d["decompositions"].values():
             assert v["value"] > 0 and v["comm"]["rccl_nranks"] == 1 and v["comm"]["rccl_version"].startswith("rccl ")
+            assert v["comm"]["ranks_agree_on_x"] is True
         ss = d["decompositions"]["slab"]["comm"]["slab_searches"]               # the engine's counters of the speculative exchange
         assert ss["speculative_exchange"] > 0 and 0 <= ss["fallbacks"] <= ss["speculative_exchange"]
     else:
