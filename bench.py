@@ -35,6 +35,10 @@ CONFIGS = {
     "c3-512": ((512, 512, 512), (25.0, 25.0, 25.0), ["bounds", "l1:D_x", "l1:D_y", "l1:D_z"]),
     "c3-768": ((768, 768, 768), (25.0, 25.0, 25.0), ["bounds", "l1:D_x", "l1:D_y", "l1:D_z"]),     # ~90 GB of device state
     "c3-small": ((64, 64, 64), (25.0, 25.0, 25.0), ["bounds", "l1:D_x", "l1:D_y", "l1:D_z"]),
+    # one rank's share of c3 / c3-512 on eight GPUs (a slab of 1 / 8 of the planes): with SIPX_FORCE_DIST=1 --decomp slab, what the
+    # slab-decomposed iteration costs a rank before any collective has a latency -- the floor of the strong-scaling curve
+    "c3-slab8": ((256, 256, 32), (25.0, 25.0, 25.0), ["bounds", "l1:D_x", "l1:D_y", "l1:D_z"]),
+    "c3-512-slab8": ((512, 512, 64), (25.0, 25.0, 25.0), ["bounds", "l1:D_x", "l1:D_y", "l1:D_z"]),
     # BASELINE configs[3] (SURVEY 8d "C4"): 8 constraint sets, two of them non-convex
     "c4": ((512, 512, 512), (25.0, 25.0, 25.0), ["bounds", "l1:D_x", "l1:D_y", "l1:D_z", "annulus", "l1dft", "rank:32", "card:D_z"]),
     "c4-256": ((256, 256, 256), (25.0, 25.0, 25.0), ["bounds", "l1:D_x", "l1:D_y", "l1:D_z", "annulus", "l1dft", "rank:32", "card:D_z"]),

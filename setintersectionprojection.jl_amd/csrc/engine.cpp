@@ -489,6 +489,7 @@ class Engine : public EngineBase {
       if (const char* e = std::getenv("SIPX_GATHER_FAST_CAP"))
         if (std::atoll(e) >= 4) hooks_.fcap = std::min<long long>(hooks_.gcap, std::atoll(e) / 4 * 4);
       if (const char* e = std::getenv("SIPX_SPEC_EXCHANGE")) spec_exchange_ = std::atoi(e) != 0;
+      if (const char* e = std::getenv("SIPX_SPEC_BATCH")) spec_batch_ = std::atoi(e) != 0;
       fbuf_ = dalloc<T>((size_t)comm_->world * std::max(n2, 1) * (hooks_.fcap + fast_hdr<T>()));
       stage_ = dalloc<double>((size_t)std::max(n2, 1) * (PREP_SLOTS + 1 + 2 * comm_->world));
       sstage_ = dalloc<double>((size_t)std::max(n2, 1) * (2 * SAMPLE_BINS + 3));
@@ -1210,6 +1211,38 @@ class Engine : public EngineBase {
         SIPX_HIP(hipStreamWaitEvent(stream_, last->ev, 0));
       }
     };
+    if (spec_batch_ && (int)tp.size() <= SPEC_MAX_SETS) {
+      // Batched form (the default): every set's first pass on the engine stream, then TWO launches for all sets -- sums of
+      // the partial slots + packing, and, after the all-gather, decision + unpacking + solve (one workgroup per set).  A rank's
+      // share of the grid is small when the ranks are many and the iteration is then bound by the launches the host can
+      // issue: 21 small kernels and four cross-stream dependencies of three searches become 8 launches on one stream.
+      SpecPackArgs<T> pk;
+      SpecFinishArgs<T> fa;
+      pk.nsets = fa.nsets = (int)tp.size();
+      pk.cap = hooks_.fcap;
+      fa.world = comm_->world; fa.fchunk = fchunk; fa.seq = seq;
+      for (size_t j = 0; j < tp.size(); ++j) {
+        SetState<T>& s = sets_[tp[j]];
+        ctl[j].verdict = (unsigned*)hverd_ + tp[j];
+        ctl[j].seq = seq;
+        K<T>::proj_scalars_stage(13, stream_, Gr_, args[j], v_is_s, PS(tp[j]), s.ptmp, s.mpart, s.cbuf, s.Mtrue, ctl[j], &hooks_,
+                                 stage_ + j * RS, gseg[j], chunk);
+        SpecPackSet<T>& P = pk.s[j];
+        P.ps = PS(tp[j]); P.partials = s.ptmp; P.maxpart = s.mpart; P.compact = s.cbuf;
+        P.seg = fbuf_ + (long long)comm_->rank * fchunk + (long long)j * fseg;
+        P.is_l1 = s.prox == PX_L1 ? 1 : 0;
+        SpecFinishSet<T>& F = fa.s[j];
+        F.ps = PS(tp[j]);
+        F.da = DecideArgs{args[j].prox, (args[j].flags & F_NOSPEC) ? 1 : 0, (double)args[j].plo, (double)args[j].phi, 64.0, (double)hooks_.gcap, s.Mtrue};
+        F.reg = stage_ + j * RS;
+        F.fseg0 = fbuf_ + (long long)j * fseg;
+        F.compact = s.cbuf; F.partials = s.ptmp; F.radius = args[j].phi;
+        F.host_want = ctl[j].host_want; F.verdict = ctl[j].verdict;
+      }
+      K<T>::spec_sums_pack(stream_, pk);
+      comm_->allgather(fbuf_, (size_t)fchunk, dtype_code(), stream_);
+      K<T>::spec_finish(stream_, fa);
+    } else {
     fork(ev_fork_);
     for (size_t j = 0; j < tp.size(); ++j) {
       SetState<T>& s = sets_[tp[j]];
@@ -1233,6 +1266,7 @@ class Engine : public EngineBase {
                                stage_ + j * RS, fbuf_ + (long long)j * fseg, fchunk);
     }
     join();
+    }
     std::vector<size_t> fb;                  // the sets whose search goes on (the same on every rank)
     bool refine = false;
     for (size_t j = 0; j < tp.size(); ++j) {
@@ -2804,6 +2838,7 @@ class Engine : public EngineBase {
   unsigned spec_seq_ = 0;
   long long spec_searches_ = 0, spec_fallbacks_ = 0, spec_rounds_ = 0;     // searches through the speculative exchange / of those, fallbacks / refinement rounds (all-reduces) of the fallbacks
   bool spec_exchange_ = true;         // SIPX_SPEC_EXCHANGE=0: every search through (all-reduce, ..., all-gather), as before
+  bool spec_batch_ = true;            // SIPX_SPEC_BATCH=0: the small steps of the exchange as one kernel per set on the set streams
   T* fbuf_ = nullptr;                 // fast segments: world x two-pass sets x (fcap + header)
   long long l1_sample_runs_ = 0;
   bool l1_sample_ = true;             // SIPX_L1_SAMPLE=0: no sampled prediction of theta (A/B switch)

@@ -487,11 +487,6 @@ __device__ __forceinline__ void place_probes(ProjScalars<T>* ps, double lo, doub
 template <typename T, int STAGE>
 __device__ void decide_body(ProjScalars<T>* ps, int prox, T pmin, T pmax, long long true_len, int nospec, double capdiv, int world,
                             double cap_max, const double* reg);
-struct DecideArgs {        // what the scalar decision needs besides the sums (k_slot_sums with FUSE: its last workgroup decides)
-  int prox, nospec;
-  double pmin, pmax, capdiv, cap_max;
-  long long true_len;
-};
 
 // FUSE (one rank: no all-reduce between the sums and the decision): every workgroup hands its value over with a device-scope
 // store, waits for it and takes a ticket; the workgroup that draws the last one reads them all back and its thread 0 takes
@@ -1163,10 +1158,12 @@ constexpr int SOLVE_G = 32;
 constexpr long long SOLVE_COOP_MIN = 1ll << 17;      // (documentation of the default; see solve_coop_min())
 static_assert(SOLVE_G <= SIPX_SOLVE_SLOTS, "ProjScalars holds SIPX_SOLVE_SLOTS cooperative slots");
 
+// (the body as a device function: k_l1_solve runs it on its own grid, k_spec_finish -- one workgroup per set -- behind the
+//  decision and the unpacking of a slab-decomposed search; G workgroups take part, this one is number wg)
 template <typename T>
-__global__ __launch_bounds__(SIPX_SOLVE_NT) void k_l1_solve(ProjScalars<T>* ps, T radius, const T* __restrict__ compact,
-                                                   const double* __restrict__ partials, long long true_len, double hw_max,
-                                                   int lean_on, int* host_want, long long coop_min, int only_if_settled) {
+__device__ void l1_solve_body(ProjScalars<T>* ps, T radius, const T* __restrict__ compact, const double* __restrict__ partials,
+                              long long true_len, double hw_max, int lean_on, int* host_want, long long coop_min, int only_if_settled,
+                              const int G, const int wg) {
   constexpr int NT = SIPX_SOLVE_NT;
   // (slab-decomposed, speculative exchange: queued before the host knows whether the search needs its fallback sweeps --
   //  then this launch is not the one that solves it)
@@ -1177,7 +1174,6 @@ __global__ __launch_bounds__(SIPX_SOLVE_NT) void k_l1_solve(ProjScalars<T>* ps, 
   __shared__ double sh_theta, sh_sa, sh_ca;
   __shared__ int sh_done;
   const int need = ps->need;
-  const int G = (int)gridDim.x, wg = (int)blockIdx.x;
   const long long n_all = need ? (long long)ps->n_compact : 0;
   const bool coop = G > 1 && n_all >= coop_min;
   if (!coop && wg != 0) return;
@@ -1350,6 +1346,14 @@ __global__ __launch_bounds__(SIPX_SOLVE_NT) void k_l1_solve(ProjScalars<T>* ps, 
     ps->rescaled = 0;
     if (host_want) __hip_atomic_store(host_want, ps->want_sample | (ps->rounds_used << 8), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
   }
+}
+
+template <typename T>
+__global__ __launch_bounds__(SIPX_SOLVE_NT) void k_l1_solve(ProjScalars<T>* ps, T radius, const T* __restrict__ compact,
+                                                   const double* __restrict__ partials, long long true_len, double hw_max,
+                                                   int lean_on, int* host_want, long long coop_min, int only_if_settled) {
+  l1_solve_body<T>(ps, radius, compact, partials, true_len, hw_max, lean_on, host_want, coop_min, only_if_settled, (int)gridDim.x,
+                   (int)blockIdx.x);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1615,6 +1619,122 @@ __global__ __launch_bounds__(BLOCK) void k_spec_unpack(const ProjScalars<T>* ps,
   }
 }
 
+// The same two steps for ALL sets of a slab-decomposed iteration in two launches (a rank's share of the grid is small when the
+// ranks are many, and the iteration is then bound by the number of launches the host can issue: twenty-one small kernels of
+// three searches become two): k_spec_sums_pack = k_slot_sums<0> + k_spec_pack of every set (grid.y = set; a workgroup per
+// partial slot writes its sum straight into the header of the rank's fast segment, one takes the extrema, the overflow flag and
+// the count, the others copy the gathered magnitudes); k_spec_finish = k_spec_decide + k_spec_unpack + the solve, one workgroup
+// per set.
+constexpr int SPEC_COPY_WG = 12;
+template <typename T>
+__global__ __launch_bounds__(BLOCK) void k_spec_sums_pack(SpecPackArgs<T> A) {
+  const SpecPackSet<T>& S = A.s[blockIdx.y];
+  double* h = reinterpret_cast<double*>(S.seg);
+  const int b = blockIdx.x;
+  if (b < PREP_SLOTS) {
+    const double v = block_sum_partials(S.partials + (long long)b * NB);
+    if (threadIdx.x == 0) h[b] = v;
+    return;
+  }
+  const long long n = S.is_l1 ? (long long)S.ps->n_compact : 0;
+  if (b == PREP_SLOTS) {
+    __shared__ T smax[BLOCK / 64], smin[BLOCK / 64];
+    T vmax = T(0), vmin = (T)INFINITY;
+    for (int i = threadIdx.x; i < NB; i += BLOCK) {
+      vmax = S.maxpart[i] > vmax ? S.maxpart[i] : vmax;
+      const T mn = S.maxpart[NB + i];               // 0 = entry beyond the pass's grid, or a workgroup that saw no non-zero magnitude
+      vmin = (mn > T(0) && mn < vmin) ? mn : vmin;
+    }
+    vmax = wave_max<T>(vmax);
+    vmin = -wave_max<T>(-vmin);
+    if ((threadIdx.x & 63) == 0) { smax[threadIdx.x >> 6] = vmax; smin[threadIdx.x >> 6] = vmin; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      for (int i = 0; i < BLOCK / 64; ++i) { vmax = smax[i] > vmax ? smax[i] : vmax; vmin = smin[i] < vmin ? smin[i] : vmin; }
+      h[FH_OVF] = S.ps->spec_overflow ? 1.0 : 0.0;
+      h[FH_MAX] = (double)vmax;
+      h[FH_MIN] = (vmin < (T)INFINITY) ? (double)vmin : 0.0;          // 0 = this rank saw no non-zero magnitude
+      h[FH_CNT] = n <= A.cap ? (double)n : -1.0;                      // -1: more than the fast segment holds
+    }
+    return;
+  }
+  const long long m = n <= A.cap ? n : 0;
+  for (long long i = (long long)(b - PREP_SLOTS - 1) * BLOCK + threadIdx.x; i < m; i += (long long)SPEC_COPY_WG * BLOCK)
+    S.seg[fast_hdr<T>() + i] = S.compact[i];
+}
+template <typename T>
+void K<T>::spec_sums_pack(hipStream_t s, const SpecPackArgs<T>& A) {
+  if (A.nsets < 1 || A.nsets > SPEC_MAX_SETS) throw std::runtime_error("spec_sums_pack: set count out of range");
+  ObsScope obs_(KID_SLOT_SUMS, s, 0.0);
+  hipLaunchKernelGGL((k_spec_sums_pack<T>), dim3(PREP_SLOTS + 1 + SPEC_COPY_WG, A.nsets), dim3(BLOCK), 0, s, A);
+  SIPX_HIP(hipGetLastError());
+}
+
+template <typename T>
+__global__ __launch_bounds__(SIPX_SOLVE_NT) void k_spec_finish(SpecFinishArgs<T> A) {
+  const SpecFinishSet<T>& S = A.s[blockIdx.x];
+  ProjScalars<T>* ps = S.ps;
+  __shared__ double sreg[PREP_SLOTS + 1 + 2 * SIPX_MAX_WORLD];
+  __shared__ double scount;
+  const int i = threadIdx.x, world = A.world;
+  if (i <= FH_OVF) {
+    double v = 0;
+    for (int r = 0; r < world; ++r) v += reinterpret_cast<const double*>(S.fseg0 + (long long)r * A.fchunk)[i];
+    sreg[i] = v;
+  }
+  if (i == FH_CNT) {
+    double tot = 0;
+    bool bad = false;
+    for (int r = 0; r < world; ++r) {
+      const double* h = reinterpret_cast<const double*>(S.fseg0 + (long long)r * A.fchunk);
+      sreg[PREP_SLOTS + 1 + 2 * r] = h[FH_MAX];
+      sreg[PREP_SLOTS + 1 + 2 * r + 1] = h[FH_MIN];
+      if (h[FH_CNT] < 0) bad = true; else tot += h[FH_CNT];
+    }
+    scount = bad ? -1.0 : tot;
+  }
+  __syncthreads();
+  if (i == 0 && scount < 0) sreg[FH_OVF] += 1.0;           // a fast segment overflowed: as if the speculation had
+  __syncthreads();
+  if (i < PREP_SLOTS + 1 + 2 * world) S.reg[i] = sreg[i];
+  if (i == 0) {
+    decide_body<T, 0>(ps, S.da.prox, (T)S.da.pmin, (T)S.da.pmax, S.da.true_len, S.da.nospec, S.da.capdiv, world, S.da.cap_max, sreg);
+    const bool settled = !(S.da.prox == PX_L1 && ps->need && !ps->spec_ok);
+    if (S.da.prox == PX_L1 && ps->need && ps->spec_ok) ps->n_compact = (unsigned long long)scount;
+    ps->gather_overflow = 0;
+    const unsigned word = (A.seq << 2) | (settled ? 0u : 1u) | ((!settled && ps->refine) ? 2u : 0u);
+    __hip_atomic_store(S.verdict, word, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
+  __threadfence_block();
+  __syncthreads();
+  if (S.da.prox != PX_L1) return;
+  if (ps->need && ps->spec_ok) {                            // the values every rank gathered inside the range, strung together in rank order
+    long long off = 0;
+    for (int r = 0; r < world; ++r) {
+      const T* seg = S.fseg0 + (long long)r * A.fchunk;
+      const long long n = (long long)reinterpret_cast<const double*>(seg)[FH_CNT];
+      const T* v = seg + fast_hdr<T>();
+      for (long long k = threadIdx.x; k < n; k += SIPX_SOLVE_NT) S.compact[off + k] = v[k];
+      off += n;
+    }
+  }
+  __threadfence_block();
+  __syncthreads();
+  l1_solve_body<T>(ps, S.radius, S.compact, S.partials, S.da.true_len, A.hw_max, A.lean_on, S.host_want, A.coop_min, 1, 1, 0);
+}
+template <typename T>
+void K<T>::spec_finish(hipStream_t s, SpecFinishArgs<T>& A) {
+  if (A.nsets < 1 || A.nsets > SPEC_MAX_SETS) throw std::runtime_error("spec_finish: set count out of range");
+  static const double capdiv = [] { const char* e = getenv("SIPX_L1_CAPDIV"); return e ? atof(e) : 64.0; }();
+  for (int j = 0; j < A.nsets; ++j) A.s[j].da.capdiv = capdiv;
+  A.hw_max = l1_hw_max();
+  A.lean_on = l1_lean_on();
+  A.coop_min = solve_coop_min();
+  ObsScope obs_(KID_L1_SOLVE, s, 0.0);
+  hipLaunchKernelGGL((k_spec_finish<T>), dim3(A.nsets), dim3(SIPX_SOLVE_NT), 0, s, A);
+  SIPX_HIP(hipGetLastError());
+}
+
 // v = x_hat - l/rho: where the multiplier term dominates, theta moves like 1/rho when rho is changed.  Re-centre the
 // probes of the coming call on the scaled prediction (and widen the range: the prediction is good to a few percent).
 template <typename T>
@@ -1716,6 +1836,9 @@ static void chain_stage(int stage, hipStream_t s, const Grid& g, const SetArgs<T
     ObsScope obs_(KID_SLOT_SUMS, s, 0.0);
     if (hk) hipLaunchKernelGGL((k_slot_sums<T, 0, false>), dim3(PREP_SLOTS + 1), dim3(BLOCK), 0, s, partials, maxpart, ps, rank, world, reg, da0);
     else hipLaunchKernelGGL((k_slot_sums<T, 0, true>), dim3(PREP_SLOTS + 1), dim3(BLOCK), 0, s, partials, maxpart, ps, rank, world, reg, da0);
+  } else if (stage == 13) {     // speculative exchange, batched form: the first pass only (its sums and the packing: K::spec_sums_pack for all sets)
+    SIPX_PASS(M_FIRST);
+    if (a.prox == PX_L1 && !(a.flags & F_NOSPEC) && !ctl.lean_done) SIPX_PASS(M_LEAN);
   } else if (stage == 5) {      // speculative exchange: this rank's sums and speculatively gathered magnitudes into its fast segment
     ObsScope obs_(KID_GATHER, s, 0.0);
     hipLaunchKernelGGL((k_spec_pack<T>), dim3(16), dim3(BLOCK), 0, s, ps, reg, rank, a.prox == PX_L1 ? 1 : 0, compact, gseg0 + (long long)rank * chunk,
@@ -1908,6 +2031,8 @@ void K<T>::proj_dist_set(hipStream_t s, const Grid& g, const SetArgs<T>& a, int 
   template void K<T>::proj_scalars_set(hipStream_t, const Grid&, const SetArgs<T>&, int, ProjScalars<T>*, double*, \
                                        T*, T*, long long, SampleCtl, const ChainHooks*);                                        \
   template void K<T>::lean_multi(hipStream_t, const Grid&, const LeanMulti<T>&);                                                        \
+  template void K<T>::spec_sums_pack(hipStream_t, const SpecPackArgs<T>&);                                                              \
+  template void K<T>::spec_finish(hipStream_t, SpecFinishArgs<T>&);                                                                     \
   template void K<T>::proj_scalars_stage(int, hipStream_t, const Grid&, const SetArgs<T>&, int, ProjScalars<T>*, double*, T*, T*,   \
                                          long long, SampleCtl, const ChainHooks*, double*, T*, long long);                                                     \
   template void K<T>::proj_scalars_arr(hipStream_t, long long, const T*, int, T, T, ProjScalars<T>*, double*, T*, \

@@ -267,6 +267,51 @@ struct SetArgs {
   int nblk_or1() const { return nblk > 0 ? nblk : 1; }
 };
 
+struct DecideArgs {        // what the scalar decision of a search needs besides the sums
+  int prox, nospec;
+  double pmin, pmax, capdiv, cap_max;
+  long long true_len;
+};
+// the small steps of a slab-decomposed search for all sets of an iteration at once (kernels_proj.hip: k_spec_sums_pack, k_spec_finish)
+constexpr int SPEC_MAX_SETS = 8;
+template <typename T>
+struct SpecPackSet {
+  const ProjScalars<T>* ps;
+  const double* partials;
+  const T* maxpart;
+  const T* compact;
+  T* seg;                 // this rank's fast segment of the set
+  int is_l1;
+};
+template <typename T>
+struct SpecPackArgs {
+  int nsets;
+  long long cap;
+  SpecPackSet<T> s[SPEC_MAX_SETS];
+};
+template <typename T>
+struct SpecFinishSet {
+  ProjScalars<T>* ps;
+  DecideArgs da;
+  double* reg;            // the set's region of the staging buffer: receives the summed header
+  const T* fseg0;         // the set's fast segment in rank 0's chunk
+  T* compact;
+  const double* partials;
+  T radius;
+  int* host_want;
+  unsigned* verdict;
+};
+template <typename T>
+struct SpecFinishArgs {
+  int nsets, world;
+  long long fchunk;
+  unsigned seq;
+  double hw_max;
+  int lean_on;
+  long long coop_min;
+  SpecFinishSet<T> s[SPEC_MAX_SETS];
+};
+
 // the lean first passes of up to three l1 searches in one sweep (kernels_proj.hip, k_lean_multi): per set its arguments and buffers
 template <typename T>
 struct LeanSet {
@@ -444,6 +489,8 @@ struct K {
   // one stage (0..3) of the same search, for a caller that runs the searches of several sets in lock step with ONE collective
   // between the stages (slab-decomposed iteration): reg = the set's region of the all-reduced staging buffer, gseg0 / chunk =
   // its segment in rank 0's chunk of the exchange buffer and the distance to the next rank's
+  static void spec_sums_pack(hipStream_t s, const SpecPackArgs<T>& A);
+  static void spec_finish(hipStream_t s, SpecFinishArgs<T>& A);
   static void lean_multi(hipStream_t s, const Grid& g, const LeanMulti<T>& m);
   static void proj_scalars_stage(int stage, hipStream_t s, const Grid& g, const SetArgs<T>& a, int v_is_s, ProjScalars<T>* ps,
                                  double* partials, T* maxpart, T* compact, long long true_len, SampleCtl ctl, const ChainHooks* hooks,
