@@ -906,13 +906,19 @@ class Engine : public EngineBase {
         std::vector<SetArgs<T>> args(tp.size());
         std::vector<T*> gseg(tp.size(), nullptr);
         int k1 = 0;
+        const bool batch = spec_exchange_ && spec_batch_ && (int)tp.size() <= SPEC_MAX_SETS;
+        RescaleMulti<T> rs;
+        rs.n = 0;
         for (size_t j = 0; j < tp.size(); ++j) {
           SetState<T>& s = sets_[tp[j]];
           args[j] = set_args(s, (T)rho[tp[j]], (T)gamma[tp[j]], flags);
           if (s.prox == PX_L1) gseg[j] = gbuf_ + (long long)(k1++) * seg;
-          if (s.prox == PX_L1 && s.last_rho > T(0) && s.last_rho != args[j].rho)      // v rescaled: theta moves like 1/rho
-            K<T>::ps_rescale(stream_, s.ps, (double)s.last_rho / (double)args[j].rho);
+          if (s.prox == PX_L1 && s.last_rho > T(0) && s.last_rho != args[j].rho) {    // v rescaled: theta moves like 1/rho
+            if (batch && rs.n < SPEC_MAX_SETS) { rs.ps[rs.n] = s.ps; rs.factor[rs.n++] = (double)s.last_rho / (double)args[j].rho; }
+            else K<T>::ps_rescale(stream_, s.ps, (double)s.last_rho / (double)args[j].rho);
+          }
         }
+        K<T>::ps_rescale_multi(stream_, rs);          // (one launch for all of them)
         // sampled prediction of theta (kernels_proj.hip, k_sample) for the l1 sets whose last search asked for it: every rank
         // samples its planes, ONE all-reduce adds the histograms (float64 holding exact integers), every rank decides alike
         std::vector<SampleCtl> ctl(tp.size());
@@ -927,7 +933,19 @@ class Engine : public EngineBase {
           ctl[j].enable = l1_sample_ && s.prox == PX_L1 && (rescaled || (hlean_[tp[j]] & 0xff) != 0);
           any_sample |= ctl[j].enable != 0;
         }
-        if (any_sample) {
+        if (any_sample && batch && Gr_.n[0] % 4 == 0) {      // every sampling set in one launch per stage
+          SampleMulti<T> sm;
+          sm.ns = 0;
+          for (size_t j = 0; j < tp.size(); ++j) {
+            if (!ctl[j].enable || sets_[tp[j]].prox != PX_L1) continue;
+            SampleSet<T>& S = sm.s[sm.ns++];
+            S.a = args[j]; S.a.ps = sets_[tp[j]].ps; S.ps = sets_[tp[j]].ps; S.partials = sets_[tp[j]].ptmp;
+            S.reg = sstage_ + j * SS; S.true_len = sets_[tp[j]].Mtrue;
+          }
+          K<T>::sample_multi(10, stream_, Gr_, sm, l1_sample_runs_, &hooks_);
+          comm_->allreduce_sum(sstage_, tp.size() * SS, SIPX_F64, stream_);
+          K<T>::sample_multi(11, stream_, Gr_, sm, l1_sample_runs_, &hooks_);
+        } else if (any_sample) {
           for (int stage = 10; stage <= 11; ++stage) {
             for (size_t j = 0; j < tp.size(); ++j)
               if (ctl[j].enable)

@@ -983,10 +983,12 @@ __device__ __forceinline__ void sample_decide(ProjScalars<T>* ps, double* __rest
   ps->samp_lo = sh_thN; ps->samp_hi = sh_thS; ps->samp_c = c_act;
 }
 
+// (the body as a device function: k_sample runs it for one set, k_sample_multi for every sampling set of a slab-decomposed
+//  iteration, grid.y = set; it uses blockIdx.x / gridDim.x only)
 template <typename T, int V>
-__global__ __launch_bounds__(SAMPLE_NT) void k_sample(Grid G, SetArgs<T> a, ProjScalars<T>* ps, double* __restrict__ partials,
-                                                      long long nchunks, long long nsamp, unsigned int stride, long long true_len,
-                                                      double hw_max, int lean_on, double gather_cap, double* __restrict__ defer_to) {
+__device__ void sample_body(const Grid& G, const SetArgs<T>& a, ProjScalars<T>* ps, double* __restrict__ partials,
+                            long long nchunks, long long nsamp, unsigned int stride, long long true_len,
+                            double hw_max, int lean_on, double gather_cap, double* __restrict__ defer_to) {
   if (!ps->want_sample || !(ps->theta_prev > 0)) return;
   constexpr int NT = SAMPLE_NT;
   __shared__ unsigned long long hs[SAMPLE_BINS];
@@ -1099,6 +1101,26 @@ __global__ __launch_bounds__(SAMPLE_NT) void k_sample(Grid G, SetArgs<T> a, Proj
     return;
   }
   sample_decide<T>(ps, partials, (int)gridDim.x, a.phi, true_len, hw_max, lean_on, gather_cap, sS, sC);
+}
+
+template <typename T, int V>
+__global__ __launch_bounds__(SAMPLE_NT) void k_sample(Grid G, SetArgs<T> a, ProjScalars<T>* ps, double* __restrict__ partials,
+                                                      long long nchunks, long long nsamp, unsigned int stride, long long true_len,
+                                                      double hw_max, int lean_on, double gather_cap, double* __restrict__ defer_to) {
+  sample_body<T, V>(G, a, ps, partials, nchunks, nsamp, stride, true_len, hw_max, lean_on, gather_cap, defer_to);
+}
+template <typename T, int V>
+__global__ __launch_bounds__(SAMPLE_NT) void k_sample_multi(Grid G, SampleMulti<T> A, long long nchunks, long long nsamp, unsigned int stride,
+                                                            double hw_max, int lean_on, double gather_cap) {
+  const SampleSet<T>& S = A.s[blockIdx.y];
+  sample_body<T, V>(G, S.a, S.ps, S.partials, nchunks, nsamp, stride, S.true_len, hw_max, lean_on, gather_cap, S.reg);
+}
+template <typename T>
+__global__ __launch_bounds__(SAMPLE_NT) void k_sample_decide2_multi(SampleMulti<T> A, double hw_max, int lean_on, double gather_cap) {
+  const SampleSet<T>& S = A.s[blockIdx.x];
+  if (!S.ps->want_sample || !(S.ps->theta_prev > 0)) return;
+  __shared__ double sS[SAMPLE_NT], sC[SAMPLE_NT];
+  sample_decide<T>(S.ps, nullptr, 0, S.a.phi, S.true_len, hw_max, lean_on, gather_cap, sS, sC, S.reg);
 }
 
 template <typename T>
@@ -1755,6 +1777,53 @@ void K<T>::ps_rescale(hipStream_t s, ProjScalars<T>* ps, double factor) {
   SIPX_HIP(hipGetLastError());
 }
 
+template <typename T>
+__global__ void k_ps_rescale_multi(RescaleMulti<T> A, double hw_max) {
+  ProjScalars<T>* ps = A.ps[blockIdx.x];
+  const double factor = A.factor[blockIdx.x];
+  if (!(ps->theta_prev > 0)) return;
+  ps->theta_prev *= factor;
+  ps->hw = hw_max;
+  ps->rescaled = 1;
+  if (ps->resc_bad) ps->want_sample = 1;   // the last such prediction missed the range: sample
+  for (int k = 0; k < L1_K; ++k) ps->t[k] = (double)(T)(ps->theta_prev * (1.0 + ps->hw * l1_probe_mult(k)));
+  ps->spec_lo = ps->t[L1_WIN_LO];
+  ps->spec_hi = ps->t[L1_WIN_HI];
+}
+template <typename T>
+void K<T>::ps_rescale_multi(hipStream_t s, const RescaleMulti<T>& A) {
+  if (A.n < 1) return;
+  ObsScope obs_(KID_PS_RESCALE, s, 0.0);
+  hipLaunchKernelGGL((k_ps_rescale_multi<T>), dim3(A.n), dim3(1), 0, s, A, l1_hw_max());
+  SIPX_HIP(hipGetLastError());
+}
+// The sampled prediction of every sampling set of a slab-decomposed iteration: stage 10 = each rank's share of the sample of
+// all sets in one launch (grid.y = set), stage 11 = the decisions on the all-reduced histograms in one launch.  Whether the
+// sample is taken, its stride and the capacity it plans for depend on the whole grid and the number of ranks only (see chain_stage).
+template <typename T>
+void K<T>::sample_multi(int stage, hipStream_t s, const Grid& g, const SampleMulti<T>& A, long long runs, const ChainHooks* hk) {
+  if (A.ns < 1 || g.n[0] % 4 != 0) return;
+  const int world = hk->world;
+  const double cap_max = (double)hk->gcap;
+  const long long nchunks = (range_len(g) / 4 + SAMPLE_RUN - 1) / SAMPLE_RUN;
+  const long long nchunks_all = (g.N / 4 + SAMPLE_RUN - 1) / SAMPLE_RUN;
+  const long long target = runs > 0 ? runs : (g.N >= (1ll << 26) ? 32768 : 16384);
+  const long long stride = nchunks_all / target;
+  const long long per_rank = (g.N / world + 3) / 4;
+  double gcap = 0.2 * (double)fit_grid(per_rank, SIPX_PASS_GRID) * (double)SPEC_CAP * (double)world;
+  if (gcap > 0.8 * cap_max) gcap = 0.8 * cap_max;
+  if (hk->fcap > 0 && gcap > 0.8 * (double)hk->fcap * (double)world) gcap = 0.8 * (double)hk->fcap * (double)world;
+  if (!(stride >= 4 && (g.N >= (1ll << 24) || runs > 0))) return;
+  const long long nsamp = nchunks / stride;            // may be 0 on a short slab
+  ObsScope obs_(stage != 11 ? KID_SAMPLE : KID_DECIDE, s, 0.0);
+  if (stage != 11)
+    hipLaunchKernelGGL((k_sample_multi<T, 4>), dim3((unsigned)(nsamp < 1 ? 1 : (nsamp < SAMPLE_WG ? nsamp : SAMPLE_WG)), A.ns), dim3(SAMPLE_NT), 0, s, g, A,
+                       nchunks, nsamp, (unsigned int)stride, l1_hw_max(), l1_lean_on(), gcap);
+  else
+    hipLaunchKernelGGL((k_sample_decide2_multi<T>), dim3(A.ns), dim3(SAMPLE_NT), 0, s, A, l1_hw_max(), l1_lean_on(), gcap);
+  SIPX_HIP(hipGetLastError());
+}
+
 // algorithmic bytes of one sweep of k_pass: x (+ y, l of every block unless the vector is s = A x itself), or the stored array
 template <typename T>
 static double pass_bytes(const Grid& g, const SetArgs<T>& a, int v_is_s, int src, long long len, bool stores) {
@@ -2032,6 +2101,8 @@ void K<T>::proj_dist_set(hipStream_t s, const Grid& g, const SetArgs<T>& a, int 
                                        T*, T*, long long, SampleCtl, const ChainHooks*);                                        \
   template void K<T>::lean_multi(hipStream_t, const Grid&, const LeanMulti<T>&);                                                        \
   template void K<T>::spec_sums_pack(hipStream_t, const SpecPackArgs<T>&);                                                              \
+  template void K<T>::ps_rescale_multi(hipStream_t, const RescaleMulti<T>&);                                                            \
+  template void K<T>::sample_multi(int, hipStream_t, const Grid&, const SampleMulti<T>&, long long, const ChainHooks*);                 \
   template void K<T>::spec_finish(hipStream_t, SpecFinishArgs<T>&);                                                                     \
   template void K<T>::proj_scalars_stage(int, hipStream_t, const Grid&, const SetArgs<T>&, int, ProjScalars<T>*, double*, T*, T*,   \
                                          long long, SampleCtl, const ChainHooks*, double*, T*, long long);                                                     \

@@ -312,6 +312,26 @@ struct SpecFinishArgs {
   SpecFinishSet<T> s[SPEC_MAX_SETS];
 };
 
+template <typename T>
+struct SampleSet {
+  SetArgs<T> a;
+  ProjScalars<T>* ps;
+  double* partials;
+  double* reg;            // the set's region of the sample staging buffer
+  long long true_len;
+};
+template <typename T>
+struct SampleMulti {
+  int ns;
+  SampleSet<T> s[SPEC_MAX_SETS];
+};
+template <typename T>
+struct RescaleMulti {
+  int n;
+  ProjScalars<T>* ps[SPEC_MAX_SETS];
+  double factor[SPEC_MAX_SETS];
+};
+
 // the lean first passes of up to three l1 searches in one sweep (kernels_proj.hip, k_lean_multi): per set its arguments and buffers
 template <typename T>
 struct LeanSet {
@@ -491,6 +511,8 @@ struct K {
   // its segment in rank 0's chunk of the exchange buffer and the distance to the next rank's
   static void spec_sums_pack(hipStream_t s, const SpecPackArgs<T>& A);
   static void spec_finish(hipStream_t s, SpecFinishArgs<T>& A);
+  static void ps_rescale_multi(hipStream_t s, const RescaleMulti<T>& A);
+  static void sample_multi(int stage, hipStream_t s, const Grid& g, const SampleMulti<T>& A, long long runs, const ChainHooks* hk);
   static void lean_multi(hipStream_t s, const Grid& g, const LeanMulti<T>& m);
   static void proj_scalars_stage(int stage, hipStream_t s, const Grid& g, const SetArgs<T>& a, int v_is_s, ProjScalars<T>* ps,
                                  double* partials, T* maxpart, T* compact, long long true_len, SampleCtl ctl, const ChainHooks* hooks,
