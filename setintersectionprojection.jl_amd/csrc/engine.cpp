@@ -490,6 +490,7 @@ class Engine : public EngineBase {
         if (std::atoll(e) >= 4) hooks_.fcap = std::min<long long>(hooks_.gcap, std::atoll(e) / 4 * 4);
       if (const char* e = std::getenv("SIPX_SPEC_EXCHANGE")) spec_exchange_ = std::atoi(e) != 0;
       if (const char* e = std::getenv("SIPX_SPEC_BATCH")) spec_batch_ = std::atoi(e) != 0;
+      if (const char* e = std::getenv("SIPX_SLAB_LEAN_MULTI")) slab_lean_multi_ = std::atoi(e) != 0;
       fbuf_ = dalloc<T>((size_t)comm_->world * std::max(n2, 1) * (hooks_.fcap + fast_hdr<T>()));
       stage_ = dalloc<double>((size_t)std::max(n2, 1) * (PREP_SLOTS + 1 + 2 * comm_->world));
       sstage_ = dalloc<double>((size_t)std::max(n2, 1) * (2 * SAMPLE_BINS + 3));
@@ -972,7 +973,7 @@ class Engine : public EngineBase {
         if (const char* e = std::getenv("SIPX_L1_ROUNDS_MIN")) rounds = std::min(6, std::max(rounds, std::atoi(e)));      // a problem whose brackets shrink slowly
         if (const char* e = std::getenv("SIPX_L1_ROUNDS_MAX")) rounds = std::max(1, std::min(rounds, std::atoi(e)));      // tests: force an overflow
         if (spec_exchange_) {
-          spec_exchange_searches(tp, args, ctl, gseg, chunk, 0, false, it);
+          spec_exchange_searches(tp, args, ctl, gseg, chunk, 0, false, it, rs.n == 0 && !any_sample);
         } else {
         const int order[4] = {0, 1, 2, 3};
         for (int si = 0; si < 4; ++si) {
@@ -1203,7 +1204,7 @@ class Engine : public EngineBase {
   // second scalar state and v = A x itself).  gseg[j] / chunk: the set's segment in rank 0's chunk of the full-size exchange
   // buffer; ctl[j]: the set's pinned words.
   void spec_exchange_searches(const std::vector<int>& tp, std::vector<SetArgs<T>>& args, std::vector<SampleCtl>& ctl,
-                              const std::vector<T*>& gseg, long long chunk, int v_is_s, bool feas_ps, int it) {
+                              const std::vector<T*>& gseg, long long chunk, int v_is_s, bool feas_ps, int it, bool lean_group = false) {
     const size_t RS = (size_t)(PREP_SLOTS + 1 + 2 * comm_->world);
     auto PS = [&](int i) { return feas_ps ? sets_[i].psf : sets_[i].ps; };
     // SPECULATIVE EXCHANGE (kernels_proj.hip, k_spec_pack): first pass of every set, then ONE all-gather carrying every
@@ -1239,6 +1240,23 @@ class Engine : public EngineBase {
       pk.nsets = fa.nsets = (int)tp.size();
       pk.cap = hooks_.fcap;
       fa.world = comm_->world; fa.fchunk = fchunk; fa.seq = seq;
+      // (the lean first passes of the l1 sets in one sweep, when none of them was rescaled or sampled on this iteration)
+      if (lean_group && !feas_ps && !v_is_s && Gr_.n[0] % 4 == 0 && slab_lean_multi_) {
+        LeanMulti<T> lm;
+        lm.ns = 0;
+        std::vector<size_t> who;
+        for (size_t j = 0; j < tp.size() && lm.ns < LEAN_MAX; ++j) {
+          SetState<T>& s = sets_[tp[j]];
+          if (s.prox != PX_L1 || (args[j].flags & F_NOSPEC)) continue;
+          LeanSet<T>& L = lm.s[lm.ns++];
+          L.a = args[j]; L.a.ps = s.ps; L.ps = s.ps; L.compact = s.cbuf; L.partials = s.ptmp; L.maxpart = s.mpart;
+          who.push_back(j);
+        }
+        if (lm.ns >= 2) {
+          K<T>::lean_multi(stream_, Gr_, lm);
+          for (size_t j : who) ctl[j].lean_done = 1;
+        }
+      }
       for (size_t j = 0; j < tp.size(); ++j) {
         SetState<T>& s = sets_[tp[j]];
         ctl[j].verdict = (unsigned*)hverd_ + tp[j];
@@ -2857,6 +2875,7 @@ class Engine : public EngineBase {
   long long spec_searches_ = 0, spec_fallbacks_ = 0, spec_rounds_ = 0;     // searches through the speculative exchange / of those, fallbacks / refinement rounds (all-reduces) of the fallbacks
   bool spec_exchange_ = true;         // SIPX_SPEC_EXCHANGE=0: every search through (all-reduce, ..., all-gather), as before
   bool spec_batch_ = true;            // SIPX_SPEC_BATCH=0: the small steps of the exchange as one kernel per set on the set streams
+  bool slab_lean_multi_ = true;       // SIPX_SLAB_LEAN_MULTI=0: one lean first pass per set in the batched exchange
   T* fbuf_ = nullptr;                 // fast segments: world x two-pass sets x (fcap + header)
   long long l1_sample_runs_ = 0;
   bool l1_sample_ = true;             // SIPX_L1_SAMPLE=0: no sampled prediction of theta (A/B switch)
