@@ -1240,8 +1240,10 @@ class Engine : public EngineBase {
       pk.nsets = fa.nsets = (int)tp.size();
       pk.cap = hooks_.fcap;
       fa.world = comm_->world; fa.fchunk = fchunk; fa.seq = seq;
-      // (the lean first passes of the l1 sets in one sweep, when none of them was rescaled or sampled on this iteration)
-      if (lean_group && !feas_ps && !v_is_s && Gr_.n[0] % 4 == 0 && slab_lean_multi_) {
+      // (the lean first passes of the l1 sets in one sweep: everything that prepares a search -- rescaling, sampled prediction --
+      //  was queued on this very stream before, so the device-side state a lean pass reads is final when the sweep starts)
+      (void)lean_group;
+      if (!feas_ps && !v_is_s && Gr_.n[0] % 4 == 0 && slab_lean_multi_) {
         LeanMulti<T> lm;
         lm.ns = 0;
         std::vector<size_t> who;
