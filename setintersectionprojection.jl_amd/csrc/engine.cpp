@@ -1256,7 +1256,10 @@ class Engine : public EngineBase {
         }
         if (lm.ns >= 2) {
           K<T>::lean_multi(stream_, Gr_, lm);
-          for (size_t j : who) ctl[j].lean_done = 1;
+          for (size_t j : who) {
+            ctl[j].lean_done = 1;
+            ctl[j].lean_known = (hlean_[tp[j]] >> 16) & 1;       // published by the set's last solve: its full first pass need not be launched
+          }
         }
       }
       for (size_t j = 0; j < tp.size(); ++j) {

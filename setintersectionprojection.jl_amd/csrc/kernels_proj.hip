@@ -1366,7 +1366,11 @@ __device__ void l1_solve_body(ProjScalars<T>* ps, T radius, const T* __restrict_
     ps->dbg_sampled = ps->sampled;
     ps->sampled = 0;
     ps->rescaled = 0;
-    if (host_want) __hip_atomic_store(host_want, ps->want_sample | (ps->rounds_used << 8), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    // (bit 16: the coming first pass will be a lean one -- nothing between here and that pass can take the flag back, so a caller
+    //  that reads the word may leave the full first pass unlaunched)
+    if (host_want)
+      __hip_atomic_store(host_want, ps->want_sample | (ps->rounds_used << 8) | ((ps->lean && ps->spec_hi > ps->spec_lo) ? (1 << 16) : 0), __ATOMIC_RELAXED,
+                         __HIP_MEMORY_SCOPE_SYSTEM);
   }
 }
 
@@ -1906,7 +1910,7 @@ static void chain_stage(int stage, hipStream_t s, const Grid& g, const SetArgs<T
     if (hk) hipLaunchKernelGGL((k_slot_sums<T, 0, false>), dim3(PREP_SLOTS + 1), dim3(BLOCK), 0, s, partials, maxpart, ps, rank, world, reg, da0);
     else hipLaunchKernelGGL((k_slot_sums<T, 0, true>), dim3(PREP_SLOTS + 1), dim3(BLOCK), 0, s, partials, maxpart, ps, rank, world, reg, da0);
   } else if (stage == 13) {     // speculative exchange, batched form: the first pass only (its sums and the packing: K::spec_sums_pack for all sets)
-    SIPX_PASS(M_FIRST);
+    if (!(ctl.lean_known && ctl.lean_done)) SIPX_PASS(M_FIRST);      // (known to be lean and served by k_lean_multi: the full pass would return at once)
     if (a.prox == PX_L1 && !(a.flags & F_NOSPEC) && !ctl.lean_done) SIPX_PASS(M_LEAN);
   } else if (stage == 5) {      // speculative exchange: this rank's sums and speculatively gathered magnitudes into its fast segment
     ObsScope obs_(KID_GATHER, s, 0.0);

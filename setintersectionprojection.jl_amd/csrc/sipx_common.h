@@ -247,6 +247,7 @@ struct SampleCtl {
   unsigned* verdict = nullptr;
   unsigned seq = 0;
   int lean_done = 0;       // the set's lean first pass was taken by k_lean_multi: the chain launches the full one only (gated as ever)
+  int lean_known = 0;      // the host has read from the set's pinned word that the coming first pass is a lean one
 };
 
 template <typename T>
