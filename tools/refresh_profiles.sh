@@ -74,6 +74,10 @@ if [ -z "$LIGHT" ]; then
   SIPX_FORCE_DIST=1 $T python tools/c5_multilevel.py 512 100 > $O/${R}_c5_512_f64_multilevel_rccl_world1_slab.json 2>>$O/bench.err
   SIPX_FORCE_DIST=1 $T python bench.py --no-cpu-baseline --no-c4 --no-c5 --decomp sets > $O/${R}_c3_bench_rccl_world1_sets.json 2>>$O/bench.err
   SIPX_FORCE_DIST=1 $T python bench.py --no-cpu-baseline --no-c4 --no-c5 --decomp slab > $O/${R}_c3_bench_rccl_world1_slab.json 2>>$O/bench.err
+  # one rank's share of c3 / c3-512 on eight GPUs, slab-decomposed through RCCL with one rank, the sampled prediction forced as the
+  # whole grid's size would switch it on: what the iteration costs a rank before any collective has a latency
+  SIPX_L1_SAMPLE_RUNS=2048 SIPX_FORCE_DIST=1 $T python bench.py --no-cpu-baseline --no-512 --no-c4 --no-c5 --config c3-slab8 --decomp slab > $O/${R}_c3_slab8_share_rccl_world1.json 2>>$O/bench.err
+  SIPX_L1_SAMPLE_RUNS=4096 SIPX_FORCE_DIST=1 $T python bench.py --no-cpu-baseline --no-512 --no-c4 --no-c5 --config c3-512-slab8 --decomp slab > $O/${R}_c3_512_slab8_share_rccl_world1.json 2>>$O/bench.err
 fi
 for f in $O/${R}_*bench*.json; do python - "$f" <<'PY'
 import json,sys
