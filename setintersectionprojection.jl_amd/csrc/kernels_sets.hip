@@ -76,11 +76,192 @@ __global__ __launch_bounds__(BLOCK) void k_rhs(Grid G, RhsArgs<T> a, T* __restri
     stv<T, V>(rhs + g, o);
   }
 }
+// The same sum marched along z (3-D grids, round 3): a workgroup owns a tile of (V LX) x TY points of a plane and walks a chunk
+// of planes.  w = rho y + l of every block is formed once per point; the adjoint stencils take w[g - stride] from the lane next
+// door (x; one element from memory at a wave / tile edge), from the thread one row up through LDS (y; the row in front of the
+// tile from memory) and from the thread's own value of the previous plane (z; the plane in front of a chunk from memory) --
+// where k_rhs re-reads y and l at g - stride through the caches (1.32 x its algorithmic bytes at 512^3).  Same products, same
+// order (per set: blocks in order, t += ih w[g - st] then t += -ih w[g] under the same masks; sets added in order): the same bits.
+constexpr int RM_NT = 256, RM_MAXB = 8, RM_MAXY = 3;
+template <typename T>
+struct RhsMarchBlk {
+  const T *y, *l;       // base of the block (already offset by q N)
+  T rho, ih;
+  int dir;              // -1: identity set (one "block"), 0 / 1 / 2: difference along x / y / z
+  int yslot;            // LDS slot of a y-difference block
+  int last;             // last block of its set: the set's sum is added to the result
+};
+template <typename T>
+struct RhsMarchArgs {
+  int nb;
+  RhsMarchBlk<T> b[RM_MAXB];
+};
+template <typename T, int V>
+__global__ __launch_bounds__(RM_NT) void k_rhs_march(Grid G, RhsMarchArgs<T> a, T* __restrict__ rhs, long long zlo, long long zhi, int lgLX,
+                                                     int tiles_x, int tiles_y, int zchunk, long long items) {
+  __shared__ T ybuf[2][RM_MAXY][V][RM_NT];
+  const int tid = threadIdx.x, LX = 1 << lgLX, tx = tid & (LX - 1), ty = tid >> lgLX, TY = RM_NT >> lgLX;
+  const long long n1 = G.n[0], n2 = G.n[1], st1 = G.st[1], st2 = G.st[2];
+  const long long tiles = (long long)tiles_x * tiles_y;
+  for (long long item = blockIdx.x; item < items; item += gridDim.x) {
+    const long long zc = item / tiles, tile = item - zc * tiles;
+    const int tile_y = (int)(tile / tiles_x), tile_x = (int)(tile - (long long)tile_y * tiles_x);
+    const long long i0 = ((long long)tile_x * LX + tx) * V, j = (long long)tile_y * TY + ty;
+    const bool active = i0 < n1 && j < n2;
+    const long long k0 = zlo + zc * zchunk, k1 = (k0 + zchunk < zhi) ? k0 + zchunk : zhi;
+    const long long go = active ? i0 + st1 * j : 0;
+    __syncthreads();                                   // the previous item's LDS traffic is over
+    T zprev[RM_MAXB][V];                               // w of the previous plane (z-difference blocks)
+#pragma unroll
+    for (int b = 0; b < RM_MAXB; ++b) {
+#pragma unroll
+      for (int k = 0; k < V; ++k) zprev[b][k] = T(0);
+      if (b < a.nb && a.b[b].dir == 2 && active) {     // (the vectors carry a front halo: plane k0 - 1 of plane 0 reads zeros, masked anyway)
+        const long long e = st2 * (k0 - 1) + go;
+        const Vec<T, V> yv = ldv_u<T, V>(a.b[b].y + e), lv = ldv_u<T, V>(a.b[b].l + e);
+#pragma unroll
+        for (int k = 0; k < V; ++k) zprev[b][k] = a.b[b].rho * yv.v[k] + lv.v[k];
+      }
+    }
+    for (long long kz = k0; kz < k1; ++kz) {
+      const int par = (int)(kz & 1);
+      const long long e0 = st2 * kz + go;
+      T w[RM_MAXB][V];
+#pragma unroll
+      for (int b = 0; b < RM_MAXB; ++b) {
+#pragma unroll
+        for (int k = 0; k < V; ++k) w[b][k] = T(0);
+        if (b < a.nb && active) {
+          const Vec<T, V> yv = ldv<T, V>(a.b[b].y + e0), lv = ldv<T, V>(a.b[b].l + e0);
+#pragma unroll
+          for (int k = 0; k < V; ++k) w[b][k] = a.b[b].rho * yv.v[k] + lv.v[k];
+        }
+        if (b < a.nb && a.b[b].dir == 1) {
+#pragma unroll
+          for (int k = 0; k < V; ++k) ybuf[par][a.b[b].yslot][k][tid] = w[b][k];
+        }
+      }
+      __syncthreads();
+      if (active) {
+        T out[V], t[V];
+#pragma unroll
+        for (int k = 0; k < V; ++k) out[k] = t[k] = T(0);
+#pragma unroll
+        for (int b = 0; b < RM_MAXB; ++b) {
+          if (b < a.nb) {
+            const RhsMarchBlk<T>& B = a.b[b];
+            if (B.dir < 0) {
+#pragma unroll
+              for (int k = 0; k < V; ++k) t[k] = w[b][k];
+            } else {
+              const T ih = B.ih, nih = -B.ih;
+              T wp[V];
+              int cd, nd;
+              if (B.dir == 0) {
+                T left = __shfl_up(w[b][V - 1], 1, 64);
+                if (tx == 0 || (tid & 63) == 0) left = B.rho * B.y[e0 - 1] + B.l[e0 - 1];       // (front halo: in bounds; masked at i = 0)
+                wp[0] = left;
+#pragma unroll
+                for (int k = 1; k < V; ++k) wp[k] = w[b][k - 1];
+                cd = (int)i0; nd = (int)n1;
+              } else if (B.dir == 1) {
+                if (ty > 0) {
+#pragma unroll
+                  for (int k = 0; k < V; ++k) wp[k] = ybuf[par][B.yslot][k][tid - LX];
+                } else {
+                  const Vec<T, V> yv = ldv_u<T, V>(B.y + e0 - st1), lv = ldv_u<T, V>(B.l + e0 - st1);
+#pragma unroll
+                  for (int k = 0; k < V; ++k) wp[k] = B.rho * yv.v[k] + lv.v[k];
+                }
+                cd = (int)j; nd = (int)n2;
+              } else {
+#pragma unroll
+                for (int k = 0; k < V; ++k) wp[k] = zprev[b][k];
+                cd = (int)kz; nd = (int)G.n[2];
+              }
+#pragma unroll
+              for (int k = 0; k < V; ++k) {
+                const int ck = cd + (B.dir == 0 ? k : 0);
+                const T t1 = t[k] + ih * wp[k];
+                t[k] = (ck > 0) ? t1 : t[k];
+                const T t2 = t[k] + nih * w[b][k];
+                t[k] = (ck < nd - 1) ? t2 : t[k];
+              }
+            }
+            if (B.last) {
+#pragma unroll
+              for (int k = 0; k < V; ++k) { out[k] = out[k] + t[k]; t[k] = T(0); }
+            }
+          }
+        }
+        Vec<T, V> o;
+#pragma unroll
+        for (int k = 0; k < V; ++k) o.v[k] = out[k];
+        stv<T, V>(rhs + e0, o);
+      }
+#pragma unroll
+      for (int b = 0; b < RM_MAXB; ++b)
+#pragma unroll
+        for (int k = 0; k < V; ++k) zprev[b][k] = w[b][k];
+    }
+  }
+}
+// false: the march does not apply (2-D grid, too many blocks, a grid too small to fill the chip that way): k_rhs
+template <typename T>
+static bool try_rhs_march(hipStream_t s, const Grid& g, const RhsArgs<T>& a, T* rhs) {
+  const char* e_sw = getenv("SIPX_RHS_MARCH");          // 0: never; 2: also on small grids, chunks of SIPX_RHS_MARCH_ZCHUNK planes (tests)
+  const int sw = e_sw ? atoi(e_sw) : 1;
+  constexpr int V = sizeof(T) == 8 ? 2 : 4;
+  const long long n1 = g.n[0], n2 = g.n[1], n3 = g.n[2], st2 = n1 * n2;
+  if (sw == 0 || n3 < 2 || n1 % V != 0 || a.nsets < 1) return false;
+  const long long e0 = g.e0, e1 = g.e1 < 0 ? g.N : g.e1;
+  if (e0 % st2 != 0 || e1 % st2 != 0 || e1 <= e0) return false;
+  RhsMarchArgs<T> m;
+  m.nb = 0;
+  int ny = 0;
+  for (int i = 0; i < a.nsets; ++i) {
+    const RhsSet<T>& S = a.s[i];
+    const int nb = S.nblk > 0 ? S.nblk : 1;
+    if (m.nb + nb > RM_MAXB) return false;
+    for (int q = 0; q < nb; ++q) {
+      RhsMarchBlk<T>& B = m.b[m.nb++];
+      B.y = S.y + (long long)q * g.N; B.l = S.l + (long long)q * g.N;
+      B.rho = S.rho; B.ih = S.nblk > 0 ? S.ih[q] : T(0);
+      B.dir = S.nblk > 0 ? S.dir[q] : -1;
+      B.yslot = 0;
+      if (B.dir == 1) { if (ny == RM_MAXY) return false; B.yslot = ny++; }
+      B.last = q == nb - 1 ? 1 : 0;
+    }
+  }
+  const long long nvx = n1 / V;
+  int lg = 0;
+  while ((1 << lg) < nvx && lg < 6) ++lg;
+  const int LX = 1 << lg, TY = RM_NT / LX;
+  const int tiles_x = (int)((nvx + LX - 1) / LX), tiles_y = (int)((n2 + TY - 1) / TY);
+  const long long tiles = (long long)tiles_x * tiles_y, planes = (e1 - e0) / st2;
+  long long zchunk = planes * tiles / 4096;
+  if (zchunk < 16) zchunk = 16;
+  const char* e_zc = getenv("SIPX_RHS_MARCH_ZCHUNK");
+  if (sw == 2 && e_zc && atoll(e_zc) > 0) zchunk = atoll(e_zc);
+  if (zchunk > planes) zchunk = planes;
+  const long long nchunks = (planes + zchunk - 1) / zchunk, items = tiles * nchunks;
+  // (up to 2^24 grid points y and l of the neighbouring planes are still in the Infinity Cache when k_rhs re-reads them: 256^3
+  //  140 us against 153 us marched; 512^3 1335 -> 1137 us)
+  if ((items < 768 || g.N <= (1ll << 24)) && sw != 2) return false;
+  const int grid = (int)(items < 2 * NB ? items : 2 * NB);
+  hipLaunchKernelGGL((k_rhs_march<T, V>), dim3(grid), dim3(RM_NT), 0, s, g, m, rhs, e0 / st2, e1 / st2, lg, tiles_x, tiles_y, (int)zchunk, items);
+  return true;
+}
+
 template <typename T>
 void K<T>::rhs_compose(hipStream_t s, const Grid& g, const RhsArgs<T>& a, T* rhs, int accumulate) {
   double vecs = 1.0 + (accumulate ? 1.0 : 0.0);      // (sum_i 2 M_i + N) w: y_i, l_i of every set read, rhs written (rhs_compose.jl:24-36)
   for (int i = 0; i < a.nsets; ++i) vecs += 2.0 * (a.s[i].nblk > 0 ? a.s[i].nblk : 1);
   ObsScope obs(KID_RHS, s, vecs * (double)range_len(g) * sizeof(T));
+  if (!accumulate && try_rhs_march<T>(s, g, a, rhs)) {
+    SIPX_HIP(hipGetLastError());
+    return;
+  }
   if (g.n[0] % 4 == 0)
     hipLaunchKernelGGL((k_rhs<T, 4>), dim3(fit_grid(range_len(g) / 4, NB)), dim3(BLOCK), 0, s, g, a, rhs, accumulate);
   else

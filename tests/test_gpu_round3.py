@@ -464,3 +464,30 @@ def test_lean_first_passes_in_one_sweep_are_bit_identical(sipx, monkeypatch, TF,
     assert lean and s1[lean[0]]["launches"] < s0[lean[0]]["launches"]          # fewer lean launches: the group pass took them
     assert np.array_equal(x0, x1) and np.array_equal(l0.cg_it, l1.cg_it) and np.array_equal(l0.obj, l1.obj)
     assert np.array_equal(l0.rho, l1.rho) and np.array_equal(l0.r_pri, l1.r_pri) and np.array_equal(l0.r_dual, l1.r_dual)
+
+
+@pytest.mark.parametrize("TF,n,kinds", [(np.float32, (64, 40, 24), ["bounds", "l1:D_x", "l1:D_y", "l1:D_z"]),
+                                         (np.float64, (40, 24, 16), ["bounds", "l1:TV"]),
+                                         (np.float32, (36, 20, 13), ["bounds", "l1:D_z", "l1:D_y"])])
+def test_z_marching_rhs_is_bit_identical(sipx, monkeypatch, TF, n, kinds):
+    """k_rhs_march (rhs = sum_i A_i'(rho_i y_i + l_i) marched along z: w of the previous plane in registers, of the row above in
+    LDS, of the point to the left from the lane next door) against k_rhs (SIPX_RHS_MARCH=0), forced on a small grid in chunks of 5
+    planes (tile edges, chunk edges, a last shorter chunk, a grid line shorter than a wave): the same products in the same order --
+    the right-hand side bit for bit, for multipliers and auxiliary vectors taken from a solve that has run 9 iterations."""
+    h = (25.0, 25.0, 25.0)
+    m = model(n, TF, seed=11)
+    gs, os_, Ps, As, props, AtAs = _problem(sipx, n, h, TF, kinds, m, dict(maxit=12))
+    os_.evol_rel_tol = os_.feas_tol = os_.obj_tol = 0.0
+    ctx = sipx.host.build_context(m, AtAs, As, props, Ps, gs, os_)
+    ctx.parsdmm_begin(os_)
+    ctx.parsdmm_steps(9)
+    rho = [0.7 + 0.9 * i for i in range(len(Ps) + 1)]
+    out = {}
+    for tag in ("0", "2"):
+        monkeypatch.setenv("SIPX_RHS_MARCH", tag)
+        monkeypatch.setenv("SIPX_RHS_MARCH_ZCHUNK", "5")
+        ctx.rhs_compose(rho)
+        out[tag] = ctx.get_rhs()
+    ctx.close()
+    assert np.isfinite(out["0"]).all() and np.abs(out["0"]).max() > 0
+    assert np.array_equal(out["0"], out["2"])
