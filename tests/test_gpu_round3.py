@@ -491,3 +491,27 @@ def test_z_marching_rhs_is_bit_identical(sipx, monkeypatch, TF, n, kinds):
     ctx.close()
     assert np.isfinite(out["0"]).all() and np.abs(out["0"]).max() > 0
     assert np.array_equal(out["0"], out["2"])
+
+
+@pytest.mark.timeout(600)
+def test_slab_decomposed_with_every_z_marching_kernel_forced(sipx, tmp_path):
+    """Three ranks (slabs of 8, 8 and 6 planes) with the z-marching product, the z-marching right-hand side and short chunks of the
+    sweep forced on the small grid -- the forms a rank's share of 512^3 runs on eight GPUs: row ranges that are slabs, the planes of
+    the neighbours read through the copies a rank keeps.  Every rank ends with identical iterates and logs, equal to the serial
+    solve to the reference's serial-vs-parallel tolerance."""
+    import torch.multiprocessing as mp
+    world, kinds, n = 3, ["bounds", "l1:D_x", "l1:D_y", "l1:D_z"], (64, 40, 22)
+    env = {"SIPX_CDS_MARCH": "2", "SIPX_CDS_MARCH_ZCHUNK": "5", "SIPX_RHS_MARCH": "2", "SIPX_RHS_MARCH_ZCHUNK": "5", "SIPX_MULTI_ZCHUNK": "5"}
+    mp.spawn(_slab_worker, args=(world, 31700 + os.getpid() % 1000, str(tmp_path), kinds, n, env), nprocs=world, join=True)
+    r0 = np.load(tmp_path / "r0.npz")
+    assert str(r0["err"]) == ""
+    for r in range(1, world):
+        r1 = np.load(tmp_path / f"r{r}.npz")
+        for k in ("x", "obj", "cg_it", "rho", "r_pri"):
+            assert np.array_equal(r0[k], r1[k], equal_nan=True), (r, k)
+    TF, h = np.float32, (25.0, 25.0, 25.0)
+    m = model(n, TF, seed=5)
+    gs, os_, Ps, As, props, AtAs = _problem(sipx, n, h, TF, kinds, m, dict(maxit=40))
+    xs, ls, _, _ = sipx.PARSDMM(m.copy(), AtAs, As, props, Ps, gs, os_)
+    assert len(ls.obj) == len(r0["obj"])
+    assert np.linalg.norm(r0["x"] - xs) / np.linalg.norm(xs) < 5e-4
