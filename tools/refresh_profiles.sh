@@ -61,6 +61,7 @@ print(json.dumps(out, indent=1))
 PY
   rm -rf $O/sp_engine_* $O/sp_march_*
 fi
+cp $O/${R}_c3_256_pmc.json $O/${R}_c3_512_pmc.json profiles/      # (this box's copy: the bench line quotes `traffic` from a profile of the running build)
 $T python bench.py > $O/${R}_bench_default.json 2>$O/bench.err
 if [ -z "$LIGHT" ]; then
   trace c2 c2_2048
