@@ -515,3 +515,26 @@ def test_slab_decomposed_with_every_z_marching_kernel_forced(sipx, tmp_path):
     xs, ls, _, _ = sipx.PARSDMM(m.copy(), AtAs, As, props, Ps, gs, os_)
     assert len(ls.obj) == len(r0["obj"])
     assert np.linalg.norm(r0["x"] - xs) / np.linalg.norm(xs) < 5e-4
+
+
+@pytest.mark.timeout(900)
+def test_full_size_512_large_grid_forms_are_bit_identical(sipx, monkeypatch):
+    """At BASELINE's 512^3 (where they are the default): the z-marching right-hand side and the shared lean first pass against the
+    flat right-hand side and one lean pass per set -- x, the CG counts and every log of 14 iterations bit for bit."""
+    from tests.test_gpu_parity import _c3_problem
+    TF, n = np.float32, (512, 512, 512)
+    m, g, opt, P, A, prop, AtA = _c3_problem(sipx, n, TF, maxit=14)
+    opt.evol_rel_tol = opt.feas_tol = opt.obj_tol = 0.0
+    out = {}
+    for tag, env in (("large", {}), ("flat", {"SIPX_RHS_MARCH": "0", "SIPX_LEAN_MULTI": "0"})):
+        for k in ("SIPX_RHS_MARCH", "SIPX_LEAN_MULTI"):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        x, log, l, y = sipx.PARSDMM(m.copy(), AtA, A, prop, P, g, opt)
+        out[tag] = (x, log)
+        del l, y
+    (x0, l0), (x1, l1) = out["large"], out["flat"]
+    assert len(l0.obj) == 14 and np.isfinite(x0).all()
+    assert np.array_equal(l0.cg_it, l1.cg_it) and np.array_equal(l0.rho, l1.rho) and np.array_equal(l0.obj, l1.obj)
+    assert np.array_equal(l0.r_pri, l1.r_pri) and np.array_equal(x0, x1)
