@@ -413,6 +413,8 @@ __global__ void k_ps_init(ProjScalars<T>* ps, long long* cidx) {
   ps->rescaled = 0;
   ps->resc_bad = 1;
   ps->samp_theta = 0;
+  ps->samp_bias = 0;
+  ps->samp_bias_ok = 0;
 }
 template <typename T>
 void K<T>::ps_init(hipStream_t s, ProjScalars<T>* ps, long long* cidx) {
@@ -937,6 +939,12 @@ __device__ __forceinline__ void sample_decide(ProjScalars<T>* ps, double* __rest
       if (C_top > 0) { const double mt = S_top / C_top - th; Q += C_top * mt * mt; }
       double m = 4.0 * sqrt(Q) / (c_act * th);        // four standard deviations, relative
       m = m < 5e-4 ? 5e-4 : (m > 0.5 ? 0.5 : m);
+      // the estimate corrected by what the last sampled estimate of this set was off by (the same entries are sampled every time:
+      // its error persists from iteration to iteration); a correction beyond a tenth of theta is not believed
+      double bias = ps->samp_bias_ok ? ps->samp_bias : 0.0;
+      if (!(fabs(bias) <= 0.1 * th)) bias = 0.0;
+      sh_thN -= bias;
+      sh_thS -= bias;
       sh_lo = sh_thN * (1.0 - m);
       sh_hi = sh_thS * (1.0 + m);
       sh_ok = 1;
@@ -1363,6 +1371,7 @@ __device__ void l1_solve_body(ProjScalars<T>* ps, T radius, const T* __restrict_
     }
     ps->n_compact = 0;
     ps->spec_overflow = 0;
+    if (ps->sampled && need && theta > 0) { ps->samp_bias = ps->samp_theta - theta; ps->samp_bias_ok = 1; }
     ps->dbg_sampled = ps->sampled;
     ps->sampled = 0;
     ps->rescaled = 0;

@@ -220,6 +220,11 @@ struct ProjScalars {
   int sampled;        // the probes of the coming first pass were centred by the sampled prediction (diagnostics: dbg_sampled)
   int dbg_sampled;
   double samp_theta;  // the sampled estimate itself
+  // ... minus the exact theta of the search it preceded: the error of a sampled estimate is dominated by WHICH entries are sampled,
+  // and they are the same from one iteration to the next, so it persists (+0.007 ... +0.005 over twelve iterations of the headline
+  // run while theta went from 8.6 to 0.41) -- the next sampled estimate is corrected by it
+  double samp_bias;
+  int samp_bias_ok;
   double samp_lo, samp_hi, samp_c;   // diagnostics: Newton / secant bounds of the sample's root, active sample count
 };
 
