@@ -15,6 +15,8 @@
 #include <rocblas/rocblas.h>
 #include <rocsolver/rocsolver.h>
 
+#include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -422,7 +424,8 @@ __global__ __launch_bounds__(BLOCK) void k_sub_residual(int k, int b, int r, int
                                                         const double* __restrict__ X, const double* __restrict__ W, int ldw,
                                                         const rocblas_int* __restrict__ info_chol,
                                                         const rocblas_int* __restrict__ info_eig,
-                                                        const double* __restrict__ fro2, unsigned long long* res) {
+                                                        const double* __restrict__ fro2, unsigned long long* res,
+                                                        double* __restrict__ per_matrix = nullptr) {
   __shared__ double sm[BLOCK / 64];
   const int l = blockIdx.x;
   const double tmax = W[(long long)l * ldw + b - 1];
@@ -445,6 +448,7 @@ __global__ __launch_bounds__(BLOCK) void k_sub_residual(int k, int b, int r, int
     const double rel = sqrt(t) / tmax;
     worst = rel > worst ? rel : worst;
   }
+  if (threadIdx.x == 0 && per_matrix) per_matrix[l] = worst;
   if (threadIdx.x == 0) {
     // Certificate that no eigenvalue above the r-th Ritz value hides outside the converged pairs.  With P the projector
     // on the subspace, ||G||_F^2 = ||H||_F^2 + 2 ||(I-P) G P||_F^2 + ||(I-P) G (I-P)||_F^2 and ||H||_F^2 = sum of the
@@ -464,6 +468,266 @@ __global__ __launch_bounds__(BLOCK) void k_sub_residual(int k, int b, int r, int
       atomicMax(res, (unsigned long long)__double_as_longlong(worst));
     }
   }
+}
+// ---- Chebyshev-filtered subspace iteration (rank projection on spectra without a gap behind the block) ----
+// Column j of the block carries its own damped interval [0, a_j], a_j = max(a, theta_j / CHEB_KAPPA), a = the end of the part of
+// the spectrum the block does not hold: everything outside the block (eigenvalues <= a) is damped in every column, the
+// column's own direction grows like T_m(2 theta_j / a_j - 1).  Directions whose Ritz value exceeds CHEB_KAPPA max(theta_j, a)
+// would outgrow column j by (theta_i / a_j)^m -- the constant part of a velocity slice is 1e5 times the rest -- so they are
+// projected out of the product G y_j at every step (k_cheb_mask: the filter then runs in the compression of G onto their
+// complement, whose spectrum has lost them up to the square of their error).  The Rayleigh-Ritz step behind the filter works
+// on the whole block again.
+#define CHEB_KAPPA 2.0
+// a = the Ritz value of guard column g (a few columns above the lowest; the g columns below it are not filtered), not the
+// lowest: the lowest Ritz values of a block that has not converged lie below eigenvalues the block does not hold, and what
+// lies above a is amplified -- an interval 5 % short loses a factor T_m(1.1) (250 at degree 14) of the contraction, one 5 %
+// long about 10.  And never below 0.9 of the (r+1)-th Ritz value: a guard column that had to be re-seeded (k_chol_inv) carries
+// a Rayleigh quotient from the middle of the spectrum, far below the block's true lower end.
+__device__ __forceinline__ double cheb_floor(const double* __restrict__ W, int b, int g, int r) {
+  const double top = W[b - 1];
+  double a = W[g];
+  const double lo = 0.9 * W[b - r - 1];
+  a = a > lo ? a : lo;
+  return a > 1e-14 * top ? a : 1e-14 * top;      // a block deeper than the rank of the matrix: no interval of zero width
+}
+// C (nl x b per matrix, leading dimension b) = X_L' Z for the nl last (largest) Ritz vectors: keep entry (i, j) only where
+// vector i is far above column j
+__global__ void k_cheb_mask(int b, int g, int r, int nl, int batch, const double* __restrict__ W, double* __restrict__ C) {
+  const long long per = (long long)nl * b, total = per * batch;
+  for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long long)gridDim.x * blockDim.x) {
+    const long long l = e / per;
+    const int o = (int)(e - l * per), j = o / nl, i = b - nl + (o - j * nl);
+    const double* Wl = W + l * b;
+    const double a = cheb_floor(Wl, b, g, r);
+    const double tj = Wl[j] > a ? Wl[j] : a;
+    if (!(Wl[i] > CHEB_KAPPA * tj)) C[l * (long long)b * b + (long long)j * b + (o - j * nl)] = 0.0;
+  }
+}
+// One step of the three-term recurrence, per column scalars: first = 1: out = (2/a_j) Z - Y0;  else out = (4/a_j) Z - 2 Y1 - Y0
+// (out may alias Z or Y0: every entry is read before it is written, by the same thread)
+__global__ __launch_bounds__(BLOCK) void k_cheb_step(int k, int b, int g, int r, int batch, const double* __restrict__ W, const double* Z,
+                                                     const double* Y1, const double* Y0, double* out, int first) {
+  const long long per = (long long)k * b, total = per * batch;
+  for (long long e = (long long)blockIdx.x * BLOCK + threadIdx.x; e < total; e += (long long)gridDim.x * BLOCK) {
+    const long long l = e / per;
+    const int j = (int)((e - l * per) / k);
+    const double* Wl = W + l * b;
+    const double a = cheb_floor(Wl, b, g, r);
+    const double aj = Wl[j] / CHEB_KAPPA > a ? Wl[j] / CHEB_KAPPA : a;
+    out[e] = first ? (2.0 / aj) * Z[e] - Y0[e] : (4.0 / aj) * Z[e] - 2.0 * Y1[e] - Y0[e];
+  }
+}
+// Cholesky QR without the triangular solve: M = Y'Y (b x b, b <= 64, column-major, both triangles) -> Rinv, the inverse of
+// the factor R of M = R'R, so that Q = Y Rinv is one GEMM.  One workgroup per matrix, everything in LDS; the columns are
+// scaled to unit length first (M' = D^-1 M D^-1), which is what keeps the factorisation of a filtered block -- columns of
+// very different length -- accurate.  info[l] is WRITTEN only on failure (a pivot that is not a number), so that two passes
+// can share it.
+__global__ __launch_bounds__(256) void k_chol_inv(int b, int batch, const double* __restrict__ M, double* __restrict__ Rinv,
+                                                  rocblas_int* __restrict__ info) {
+  __shared__ double A[64 * 65];
+  __shared__ double Bv[64 * 65];
+  __shared__ double dsc[64];
+  const int l = blockIdx.x, t = threadIdx.x;
+  const double* Ml = M + (long long)l * b * b;
+  double* Rl = Rinv + (long long)l * b * b;
+  if (t < b) {
+    const double dj = Ml[(long long)t * b + t];
+    dsc[t] = dj > 0 ? 1.0 / sqrt(dj) : 0.0;
+  }
+  __syncthreads();
+  for (int e = t; e < b * b; e += 256) {
+    const int i = e % b, c = e / b;
+    if (i <= c) A[i * 65 + c] = Ml[(long long)c * b + i] * dsc[i] * dsc[c];
+    Bv[i * 65 + c] = 0.0;
+  }
+  bool lost = false;
+  for (int j = 0; j < b; ++j) {
+    __syncthreads();
+    const double piv = A[j * 65 + j];
+    if (!(piv == piv)) { lost = true; break; }             // the same value in every thread: a uniform exit
+    // a column that depends on the ones before it to rounding (a guard vector the filter left nothing of): it is dropped --
+    // unit pivot, no coupling -- and comes back as a vector of negligible length, a Ritz value near zero at the low end
+    const bool dep = !(piv > 1e-13);
+    const double inv = dep ? 0.0 : 1.0 / sqrt(piv);
+    __syncthreads();
+    if (t == 0) A[j * 65 + j] = dep ? 1.0 : sqrt(piv);
+    for (int c = j + 1 + t; c < b; c += 256) A[j * 65 + c] *= inv;
+    __syncthreads();
+    const int nrem = b - j - 1;
+    for (int e = t; e < nrem * nrem; e += 256) {
+      const int ii = e / nrem, cc = e - ii * nrem;
+      if (cc >= ii) A[(j + 1 + ii) * 65 + j + 1 + cc] -= A[j * 65 + j + 1 + ii] * A[j * 65 + j + 1 + cc];
+    }
+  }
+  __syncthreads();
+  if (lost) {
+    if (t == 0) info[l] = 1;
+    for (int e = t; e < b * b; e += 256) Rl[e] = (e % b == e / b) ? 1.0 : 0.0;
+    return;
+  }
+  if (t < b) {                                               // column t of the inverse of the (scaled) factor, back substitution
+    const int c = t;
+    Bv[c * 65 + c] = 1.0 / A[c * 65 + c];
+    for (int i = c - 1; i >= 0; --i) {
+      double acc = 0;
+      for (int q = i + 1; q <= c; ++q) acc += A[i * 65 + q] * Bv[q * 65 + c];
+      Bv[i * 65 + c] = -acc / A[i * 65 + i];
+    }
+  }
+  __syncthreads();
+  for (int e = t; e < b * b; e += 256) {
+    const int i = e % b, c = e / b;
+    Rl[e] = i <= c ? Bv[i * 65 + c] * dsc[i] : 0.0;
+  }
+}
+// The b x b Ritz problem (b <= 64): cyclic two-sided Jacobi with the round-robin ordering -- b/2 disjoint rotations per step,
+// first from the right (columns of H and of the accumulated V), then from the left (rows of H) -- one workgroup per matrix,
+// H and V in LDS.  Sweeps until the off-diagonal mass is below 1e-30 of ||H||_F^2 (15 at most).  Eigenvalues ascending in W,
+// eigenvectors in the columns of S (column-major, leading dimension b; S may be H itself).  rocSOLVER's syevj takes 2.5 ms for
+// 512 problems of 48 x 48, most of it launches; this kernel about a fifth.
+__global__ __launch_bounds__(256) void k_ritz_jacobi(int b, int batch, const double* H_in, double* S, double* __restrict__ W,
+                                                     rocblas_int* __restrict__ info) {
+  __shared__ double H[64 * 65];
+  __shared__ double V[64 * 65];
+  __shared__ double rc[32], rs[32];
+  __shared__ int rp[32], rq[32];
+  __shared__ double red[4];
+  __shared__ double s_off, s_fro;
+  const int l = blockIdx.x, t = threadIdx.x;
+  const double* Hl = H_in + (long long)l * b * b;
+  for (int e = t; e < b * b; e += 256) {
+    const int i = e % b, c = e / b;
+    // the upper triangle is what the GEMM before filled reliably symmetric to rounding: mirror it
+    H[i * 65 + c] = i <= c ? Hl[(long long)c * b + i] : Hl[(long long)i * b + c];
+    V[i * 65 + c] = i == c ? 1.0 : 0.0;
+  }
+  const int n = b + (b & 1), half = n / 2;
+  auto block_sum = [&](double v) -> double {
+    v = wave_sum(v);
+    __syncthreads();
+    if ((t & 63) == 0) red[t >> 6] = v;
+    __syncthreads();
+    return red[0] + red[1] + red[2] + red[3];
+  };
+  __syncthreads();
+  {
+    double f = 0;
+    for (int e = t; e < b * b; e += 256) { const double h = H[(e % b) * 65 + e / b]; f += h * h; }
+    f = block_sum(f);
+    if (t == 0) s_fro = f;
+  }
+  int sweeps = 0;
+  bool done = false;
+  for (; sweeps < 15 && !done; ++sweeps) {
+    for (int step = 0; step < n - 1; ++step) {
+      __syncthreads();
+      if (t < half) {
+        int p, q;
+        if (t == 0) { p = n - 1; q = step; }
+        else { p = (step + t) % (n - 1); q = (step - t + n - 1) % (n - 1); }
+        if (p > q) { const int x = p; p = q; q = x; }
+        double c = 1.0, sn = 0.0;
+        if (q < b) {
+          const double hpq = H[p * 65 + q];
+          if (hpq != 0.0) {
+            const double tau = (H[q * 65 + q] - H[p * 65 + p]) / (2.0 * hpq);
+            const double tt = tau >= 0 ? 1.0 / (tau + sqrt(1.0 + tau * tau)) : 1.0 / (tau - sqrt(1.0 + tau * tau));
+            c = 1.0 / sqrt(1.0 + tt * tt);
+            sn = tt * c;
+          }
+        }
+        rp[t] = p; rq[t] = q; rc[t] = c; rs[t] = sn;
+      }
+      __syncthreads();
+      for (int it = t; it < half * b; it += 256) {         // H <- H J, V <- V J
+        const int i = it / b, e = it - i * b;
+        const int p = rp[i], q = rq[i];
+        if (q >= b) continue;
+        const double c = rc[i], sn = rs[i];
+        const double hp = H[e * 65 + p], hq = H[e * 65 + q];
+        H[e * 65 + p] = c * hp - sn * hq;
+        H[e * 65 + q] = sn * hp + c * hq;
+        const double vp = V[e * 65 + p], vq = V[e * 65 + q];
+        V[e * 65 + p] = c * vp - sn * vq;
+        V[e * 65 + q] = sn * vp + c * vq;
+      }
+      __syncthreads();
+      for (int it = t; it < half * b; it += 256) {         // H <- J' H
+        const int i = it / b, e = it - i * b;
+        const int p = rp[i], q = rq[i];
+        if (q >= b) continue;
+        const double c = rc[i], sn = rs[i];
+        const double hp = H[p * 65 + e], hq = H[q * 65 + e];
+        H[p * 65 + e] = c * hp - sn * hq;
+        H[q * 65 + e] = sn * hp + c * hq;
+      }
+    }
+    __syncthreads();
+    double off = 0;
+    for (int e = t; e < b * b; e += 256) {
+      const int i = e % b, c = e / b;
+      if (i != c) { const double h = H[i * 65 + c]; off += h * h; }
+    }
+    off = block_sum(off);
+    if (t == 0) s_off = off;
+    __syncthreads();
+    done = !(s_off > 1e-30 * s_fro);
+  }
+  __syncthreads();
+  if (t == 0) info[l] = (done && s_fro == s_fro) ? 0 : 1;
+  if (t < b) {                                               // ascending order: the rank of every eigenvalue
+    const double mine = H[t * 65 + t];
+    int pos = 0;
+    for (int j = 0; j < b; ++j) {
+      const double o = H[j * 65 + j];
+      pos += (o < mine || (o == mine && j < t)) ? 1 : 0;
+    }
+    W[(long long)l * b + pos] = mine;
+    // column t of V becomes column pos of S
+    double* Sl = S + (long long)l * b * b + (long long)pos * b;
+    for (int i = 0; i < b; ++i) Sl[i] = V[i * 65 + t];
+  }
+}
+// What the host needs to choose the next filter: res[2] <- min over the batch of t_r = 2 theta_r / a - 1 (bit pattern of a
+// positive double, start from +inf), res[3] <- max over the batch of the number of Ritz vectors far above the lowest column
+__global__ void k_cheb_plan(int b, int g, int r, int batch, const double* __restrict__ W, unsigned long long* res) {
+  const int l = blockIdx.x * blockDim.x + threadIdx.x;
+  if (l >= batch) return;
+  const double* Wl = W + (long long)l * b;
+  const double a = cheb_floor(Wl, b, g, r);
+  double t = 2.0 * Wl[b - r] / a - 1.0;
+  if (!(t > 1.0)) t = 1.0;
+  atomicMin(res + 2, (unsigned long long)__double_as_longlong(t));
+  int nl = 0;
+  for (int i = 0; i < b; ++i) nl += Wl[i] > CHEB_KAPPA * a ? 1 : 0;
+  atomicMax(res + 3, (unsigned long long)nl);
+}
+// Inertia certificate for a converged top-r block on a spectrum too flat for the energy bound of k_sub_residual:
+// B = mu I - G + X_r Theta_r X_r' is positive definite (its Cholesky factorisation exists) exactly when G, with the r found
+// pairs removed, has no eigenvalue above mu; mu = the middle of the gap between the r-th and the (r+1)-th Ritz value.
+// First half: B <- mu I - G and XT <- X_r Theta_r (the rank-r term is added by a GEMM).
+__global__ __launch_bounds__(BLOCK) void k_cert_shift(int k, int b, int r, int batch, const double* __restrict__ G, const double* __restrict__ W,
+                                                      double* __restrict__ B) {
+  const long long per = (long long)k * k, total = per * batch;
+  for (long long e = (long long)blockIdx.x * BLOCK + threadIdx.x; e < total; e += (long long)gridDim.x * BLOCK) {
+    const long long l = e / per, o = e - l * per;
+    const int row = (int)(o % k), col = (int)(o / k);
+    const double mu = 0.5 * (W[l * b + b - r] + W[l * b + b - r - 1]);
+    B[e] = (row == col ? mu : 0.0) - G[e];
+  }
+}
+__global__ __launch_bounds__(BLOCK) void k_cert_scale(int k, int b, int r, int batch, const double* __restrict__ X, const double* __restrict__ W,
+                                                      double* __restrict__ XT) {
+  const long long per = (long long)k * r, total = per * batch;
+  for (long long e = (long long)blockIdx.x * BLOCK + threadIdx.x; e < total; e += (long long)gridDim.x * BLOCK) {
+    const long long l = e / per, o = e - l * per;
+    const int j = b - r + (int)(o / k);
+    XT[l * (long long)k * b + (long long)(b - r) * k + o] = X[l * (long long)k * b + (long long)(b - r) * k + o] * W[l * b + j];
+  }
+}
+__global__ void k_cert_or(int batch, const rocblas_int* __restrict__ info, unsigned long long* res) {
+  const int l = blockIdx.x * blockDim.x + threadIdx.x;
+  if (l < batch && info[l] != 0) atomicOr(res + 1, 32ull);
 }
 // After a full decomposition (eigenvalues ascending, k per matrix): the contraction factor subspace iteration on b vectors
 // would see for the top-r space, theta_{b+1} / theta_r, maximum over the batch -> res[0] (bit pattern).
@@ -527,6 +791,11 @@ struct ExtImpl {
   double *Xs[2] = {nullptr, nullptr};              // Ritz vectors of the previous call (y update / feasibility estimate)
   bool sub_have[2] = {false, false}, sub_try[2] = {false, false};
   double *Qs = nullptr, *Zs = nullptr, *Hs = nullptr, *Ws = nullptr, *Es = nullptr, *Fro = nullptr;
+  // Chebyshev-filtered variant of the same route (spectra without a gap behind the block): one more block, the matrix of the
+  // inertia certificate (allocated when first needed), calls to sit out after a failed attempt
+  bool cheb = false;
+  double *Ys = nullptr, *Bd = nullptr, *Cs = nullptr;
+  int cheb_skip[2] = {0, 0}, cheb_fails[2] = {0, 0};
   unsigned long long* sub_res = nullptr;           // device: bit pattern of the largest relative residual, failure flag
   unsigned long long* sub_res_host = nullptr;      // pinned
   // DCT: orthonormal DCT-II matrices per dimension, two work arrays, inner projector state
@@ -702,8 +971,11 @@ ExtProj<T>::ExtProj(const ExtSpec& spec, hipStream_t stream) {
         I.Ws = I.template alloc<double>((size_t)I.sub_b * I.batch);
         I.Es = I.template alloc<double>((size_t)I.sub_b * I.batch);
         I.Fro = I.template alloc<double>((size_t)I.batch);
-        I.sub_res = I.template alloc<unsigned long long>(2);
-        SIPX_HIP(hipHostMalloc((void**)&I.sub_res_host, 2 * sizeof(unsigned long long), hipHostMallocDefault));
+        I.sub_res = I.template alloc<unsigned long long>(4);
+        SIPX_HIP(hipHostMalloc((void**)&I.sub_res_host, 4 * sizeof(unsigned long long), hipHostMallocDefault));
+        const char* ch_e = getenv("SIPX_RANK_CHEB");           // 0: plain subspace iteration only (spectra with a gap)
+        I.cheb = !(ch_e && ch_e[0] == '0');
+        if (I.cheb) { I.Ys = I.template alloc<double>(nb); I.Cs = I.template alloc<double>((size_t)I.sub_b * I.sub_b * I.batch); }
       }
     }
     I.info = I.template alloc<rocblas_int>((size_t)3 * I.batch);   // info, n_sweeps / second info, sweeps of the Ritz solver
@@ -839,6 +1111,182 @@ __global__ __launch_bounds__(BLOCK) void k_copy_if_needed(long long N, const T* 
   for (long long e = (long long)blockIdx.x * BLOCK + threadIdx.x; e < N; e += (long long)gridDim.x * BLOCK) dst[e] = src[e];
 }
 
+// Rank projection, Gram route: the top-r invariant subspace of every G_l from the Ritz vectors of the previous call (I.Xs[w]),
+// by Rayleigh-Ritz steps with a Chebyshev filter between them (kernels above).  One multiplication with G per filter degree
+// and one per Rayleigh-Ritz step; the degree of every filter is chosen from the residual still to be removed and the
+// flattest spectrum of the batch, T_m(t_r) >= 10 residual / tolerance.  Accepted when every top-r pair has a residual below
+// 1e-12 theta_max AND nothing above theta_r can hide outside the block: the energy bound of k_sub_residual where the
+// spectrum decays, the inertia of G with the found pairs removed (one batched Cholesky factorisation) where it is flat.
+// Returns false -- the caller then decomposes fully -- when the budget of multiplications cannot suffice, a factorisation
+// fails or the certificate does not hold.
+template <typename T>
+static bool rank_cheb_route(ExtImpl<T>& I, int w, int k) {
+  hipStream_t s = I.stream;
+  const int b = I.sub_b, r = I.r, batch = I.batch;
+  const double one = 1.0, zero = 0.0, mone = -1.0;
+  const long long sG = (long long)k * k, sX = (long long)k * b, sH = (long long)b * b;
+  const auto N_ = rocblas_operation_none, T_ = rocblas_operation_transpose;
+  const char* dbg_e = getenv("SIPX_EXT_DEBUG");
+  const int dbg = dbg_e ? atoi(dbg_e) : 0;
+  const char* bud_e = getenv("SIPX_RANK_CHEB_BUDGET");
+  const int budget = bud_e && atoi(bud_e) > 0 ? atoi(bud_e) : 160;      // multiplications with G a call may spend
+  const char* jac_e = getenv("SIPX_RANK_JACOBI");          // 0: rocSOLVER's syevj for the Ritz problems (A/B)
+  const bool own_jacobi = !(jac_e && jac_e[0] == '0');
+  const char* mm_e = getenv("SIPX_RANK_CHEB_MMAX");
+  const int m_cap = mm_e && atoi(mm_e) >= 2 ? atoi(mm_e) : 16;
+  const double tol = 1e-12;
+  const char* g_e = getenv("SIPX_RANK_CHEB_GUARD");
+  const int g = g_e ? std::max(0, std::min(atoi(g_e), b - r - 1)) : (b - r) / 8;      // index of the Ritz value that ends the damped interval
+  const auto t_start = std::chrono::steady_clock::now();
+  double ph[8] = {0, 0, 0, 0, 0, 0, 0, 0};                 // SIPX_EXT_DEBUG=2: milliseconds per phase (the stream is drained at every mark)
+  auto t_mark = t_start;
+  auto mark = [&](int which) {
+    if (dbg < 2) return;
+    SIPX_HIP(hipStreamSynchronize(s));
+    const auto now = std::chrono::steady_clock::now();
+    ph[which] += std::chrono::duration<double, std::milli>(now - t_mark).count();
+    t_mark = now;
+  };
+  double* X = I.Xs[w];
+  // three blocks in rotation: A the block to orthonormalise (then the orthonormal basis), F1 and F2 free
+  double *A = I.Qs, *F1 = I.Ys, *F2 = I.Zs;
+  hipLaunchKernelGGL(k_sub_fro, dim3(batch), dim3(BLOCK), 0, s, k, I.Gd, I.Fro);
+  SIPX_HIP(hipMemcpyAsync(A, X, sizeof(double) * (size_t)sX * batch, hipMemcpyDeviceToDevice, s));
+  mark(7);
+  int mults = 0, m_prev = 0;
+  double prev = -1;
+  bool ok = false;
+  for (int outer = 0; outer < 8; ++outer) {
+    // Rayleigh-Ritz on span(A): Cholesky QR (twice behind a filter: its columns lean on each other), H = Q'GQ, X = Q S
+    SIPX_HIP(hipMemsetAsync(I.info, 0, sizeof(rocblas_int) * batch, s));
+    for (int pass = 0; pass < (m_prev > 0 ? 2 : 1); ++pass) {
+      blas_check(rocblas_dgemm_strided_batched(I.blas, T_, N_, b, b, k, &one, A, k, sX, A, k, sX, &zero, I.Hs, b, sH, batch), "Y'Y");
+      hipLaunchKernelGGL(k_chol_inv, dim3(batch), dim3(256), 0, s, b, batch, I.Hs, I.Cs, I.info);
+      blas_check(rocblas_dgemm_strided_batched(I.blas, N_, N_, k, b, b, &one, A, k, sX, I.Cs, b, sH, &zero, F1, k, sX, batch), "Y Rinv");
+      std::swap(A, F1);
+    }
+    mark(0);
+    blas_check(rocblas_dgemm_strided_batched(I.blas, N_, N_, k, b, k, &one, I.Gd, k, sG, A, k, sX, &zero, F1, k, sX, batch), "G Q");
+    ++mults;
+    mark(1);
+    blas_check(rocblas_dgemm_strided_batched(I.blas, T_, N_, b, b, k, &one, A, k, sX, F1, k, sX, &zero, I.Hs, b, sH, batch), "Q'GQ");
+    mark(2);
+    if (own_jacobi)
+      hipLaunchKernelGGL(k_ritz_jacobi, dim3(batch), dim3(256), 0, s, b, batch, I.Hs, I.Hs, I.Ws, I.info + batch);
+    else
+      blas_check(rocsolver_dsyevj_strided_batched(I.blas, rocblas_esort_ascending, rocblas_evect_original, rocblas_fill_upper, b, I.Hs, b, sH,
+                                                  0.0, I.Es, 100, I.info + 2 * batch, I.Ws, b, I.info + batch, batch), "syevj (Ritz)");
+    mark(3);
+    blas_check(rocblas_dgemm_strided_batched(I.blas, N_, N_, k, b, b, &one, A, k, sX, I.Hs, b, sH, &zero, X, k, sX, batch), "Q Z");
+    blas_check(rocblas_dgemm_strided_batched(I.blas, N_, N_, k, b, b, &one, F1, k, sX, I.Hs, b, sH, &zero, F2, k, sX, batch), "(GQ) Z");
+    mark(2);
+    SIPX_HIP(hipMemsetAsync(I.sub_res, 0, 4 * sizeof(unsigned long long), s));
+    SIPX_HIP(hipMemsetAsync(I.sub_res + 2, 0x7f, sizeof(unsigned long long), s));       // a large positive double: the minimum starts there
+    hipLaunchKernelGGL(k_sub_residual, dim3(batch), dim3(BLOCK), 0, s, k, b, r, batch, F2, X, I.Ws, b, I.info, I.info + batch, I.Fro, I.sub_res, I.Es);
+    hipLaunchKernelGGL(k_cheb_plan, dim3((batch + 63) / 64), dim3(64), 0, s, b, g, r, batch, I.Ws, I.sub_res);
+    SIPX_HIP(hipMemcpyAsync(I.sub_res_host, I.sub_res, 4 * sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
+    SIPX_HIP(hipStreamSynchronize(s));
+    mark(4);
+    double res, tmin;
+    std::memcpy(&res, &I.sub_res_host[0], sizeof(double));
+    std::memcpy(&tmin, &I.sub_res_host[2], sizeof(double));
+    const bool failed = (I.sub_res_host[1] & 15ull) != 0;
+    const bool hidden = (I.sub_res_host[1] & 16ull) != 0;
+    const int nl = (int)I.sub_res_host[3];
+    if (dbg) fprintf(stderr, "[sipx rank] filtered subspace step %d: %d products, residual %.3e, fail-bits %llu, t_r %.4f, %d vectors far above, %.2f ms\n",
+                     outer, mults, res, I.sub_res_host[1], tmin, nl,
+                     std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_start).count());
+    if (failed) break;
+    // The previous call's vectors say little about this input (the first iterations of a solve): filters started from there
+    // were observed to swamp the guard columns and then stall at a residual of 1e-8 theta_max -- the full decomposition at once.
+    if (outer == 0 && res > 1e-3) break;
+    if (res <= tol) {
+      if (!hidden) { ok = true; break; }
+      // flat spectrum: the inertia certificate (X_r Theta_r goes through F1)
+      if (!I.Bd) I.Bd = I.template alloc<double>((size_t)k * k * batch);
+      hipLaunchKernelGGL(k_cert_shift, dim3(NB), dim3(BLOCK), 0, s, k, b, r, batch, I.Gd, I.Ws, I.Bd);
+      hipLaunchKernelGGL(k_cert_scale, dim3(NB), dim3(BLOCK), 0, s, k, b, r, batch, X, I.Ws, F1);
+      blas_check(rocblas_dgemm_strided_batched(I.blas, N_, T_, k, k, r, &one, F1 + (long long)(b - r) * k, k, sX, X + (long long)(b - r) * k, k, sX,
+                                               &one, I.Bd, k, sG, batch), "certificate: rank-r term");
+      blas_check(rocsolver_dpotrf_strided_batched(I.blas, rocblas_fill_upper, k, I.Bd, k, sG, I.info, batch), "certificate: potrf");
+      SIPX_HIP(hipMemsetAsync(I.sub_res, 0, 2 * sizeof(unsigned long long), s));
+      hipLaunchKernelGGL(k_cert_or, dim3((batch + 63) / 64), dim3(64), 0, s, batch, I.info, I.sub_res);
+      SIPX_HIP(hipMemcpyAsync(I.sub_res_host, I.sub_res, 2 * sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
+      SIPX_HIP(hipStreamSynchronize(s));
+      ok = (I.sub_res_host[1] & 32ull) == 0;
+      mark(7);
+      if (dbg) fprintf(stderr, "[sipx rank] inertia certificate %s, %.2f ms\n", ok ? "holds" : "fails",
+                       std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_start).count());
+      break;
+    }
+    if (prev > 0 && !(res < 0.5 * prev)) {               // the filter did not do what its degree promised
+      if (dbg) {                                           // which matrix, and what its Ritz values look like
+        std::vector<double> pm(batch), ww((size_t)b * batch);
+        SIPX_HIP(hipMemcpy(pm.data(), I.Es, sizeof(double) * batch, hipMemcpyDeviceToHost));
+        SIPX_HIP(hipMemcpy(ww.data(), I.Ws, sizeof(double) * b * batch, hipMemcpyDeviceToHost));
+        int worst_l = 0, above = 0;
+        for (int l = 0; l < batch; ++l) { if (pm[l] > pm[worst_l]) worst_l = l; above += pm[l] > tol ? 1 : 0; }
+        fprintf(stderr, "[sipx rank] stalled: %d matrices above the tolerance, worst %d (%.3e); its Ritz values:", above, worst_l, pm[worst_l]);
+        for (int j = 0; j < b; ++j) fprintf(stderr, " %.4e", ww[(size_t)worst_l * b + j]);
+        fprintf(stderr, "\n");
+      }
+      break;
+    }
+    prev = res;
+    // the next filter: T_m(t_r) = cosh(m acosh t_r) >= 10 res / tol, within the cap and the budget
+    const double need = std::acosh(std::max(10.0 * res / tol, 2.0));
+    const double per = std::acosh(std::max(tmin, 1.0 + 1e-9));
+    int m = (int)std::ceil(need / per);
+    if (m < 2) m = 2;
+    const int m_max = m_cap;
+    if (m > m_max) {                                      // several filters: can the budget still hold them?
+      const double outers = std::ceil(need / (per * m_max));
+      if (mults + outers * (m_max + 1) > budget) {
+        if (dbg) fprintf(stderr, "[sipx rank] filtered subspace: %g more products needed, over the budget\n", outers * (m_max + 1));
+        break;
+      }
+      m = m_max;
+    } else if (mults + m + 1 > budget) break;
+    // Y_0 = X, Y_1 = (2/a) P G X - X with G X = F2 already there; Y_{i+1} = (4/a) P G Y_i - 2 Y_i - Y_{i-1}.  X stays (the
+    // projections need it); products go to F1, the iterates alternate between F2 and A, each new one over the one two steps back
+    double *Y0 = X, *Y1 = X;
+    for (int i = 1; i <= m; ++i) {
+      double* Z = F2;
+      if (i > 1) {
+        blas_check(rocblas_dgemm_strided_batched(I.blas, N_, N_, k, b, k, &one, I.Gd, k, sG, Y1, k, sX, &zero, F1, k, sX, batch), "G Y");
+        ++mults;
+        Z = F1;
+        mark(1);
+      }
+      if (nl > 0) {
+        const double* XL = X + (long long)(b - nl) * k;
+        blas_check(rocblas_dgemm_strided_batched(I.blas, T_, N_, nl, b, k, &one, XL, k, sX, Z, k, sX, &zero, I.Hs, b, sH, batch), "X_L' Z");
+        hipLaunchKernelGGL(k_cheb_mask, dim3((unsigned)std::min<long long>(NB, ((long long)nl * b * batch + 255) / 256)), dim3(256), 0, s, b, g, r, nl, batch,
+                           I.Ws, I.Hs);
+        blas_check(rocblas_dgemm_strided_batched(I.blas, N_, N_, k, b, nl, &mone, XL, k, sX, I.Hs, b, sH, &one, Z, k, sX, batch), "Z - X_L C");
+      }
+      double* out = i == 1 ? F2 : (i == 2 ? A : Y0);
+      mark(5);
+      hipLaunchKernelGGL(k_cheb_step, dim3(NB), dim3(BLOCK), 0, s, k, b, g, r, batch, I.Ws, Z, Y1, Y0, out, i == 1 ? 1 : 0);
+      mark(6);
+      Y0 = Y1;
+      Y1 = out;
+    }
+    m_prev = m;
+    if (Y1 != A) std::swap(A, F2);                       // the filtered block is the one to orthonormalise next
+    // the g lowest columns sit inside the damped interval: T_m there is anything in [-1, 1], also (nearly) zero, and such a
+    // column would be nothing but what leaked in from above -- dependent on the other columns.  They stay what they were.
+    if (g > 0)
+      SIPX_HIP(hipMemcpy2DAsync(A, sizeof(double) * (size_t)sX, X, sizeof(double) * (size_t)sX, sizeof(double) * (size_t)k * g, batch,
+                                hipMemcpyDeviceToDevice, s));
+  }
+  if (dbg >= 2)
+    fprintf(stderr, "[sipx rank] phases (ms): orthonormalise %.2f, products with G %.2f (%d), small products %.2f, Ritz solver %.2f, residual %.2f, "
+                    "projections %.2f, recurrence %.2f, copy + certificate %.2f\n", ph[0], ph[1], mults, ph[2], ph[3], ph[4], ph[5], ph[6], ph[7]);
+  SIPX_HIP(hipGetLastError());
+  return ok;
+}
+
 // v <- P(v) in place.  `feas` selects the independent warm-start state used for the feasibility estimate.
 template <typename T>
 void ExtProj<T>::project(T* v, bool feas, double* partials, T* maxpart, T* compact) {
@@ -892,7 +1340,19 @@ void ExtProj<T>::project(T* v, bool feas, double* partials, T* maxpart, T* compa
       bool sub_ok = false;
       const int b = I.sub_b;
       const long long sX = (long long)k * b, sH = (long long)b * b;
-      if (b > 0 && I.sub_have[w] && I.sub_try[w]) {
+      if (b > 0 && I.cheb && I.sub_have[w]) {
+        // the filtered iteration does not need a gap behind the block; an attempt that failed costs its products on top of the
+        // full decomposition, so the next attempts wait (1, 2, 4, ... calls)
+        if (I.cheb_skip[w] > 0) {
+          --I.cheb_skip[w];
+        } else {
+          sub_ok = rank_cheb_route<T>(I, w, k);
+          if (sub_ok) I.cheb_fails[w] = 0;
+          else { I.cheb_skip[w] = 1 << std::min(I.cheb_fails[w], 5); ++I.cheb_fails[w]; }
+          const char* dbg_e = getenv("SIPX_EXT_DEBUG");
+          if (dbg_e && atoi(dbg_e)) fprintf(stderr, "[sipx rank] %s\n", sub_ok ? "subspace accepted" : "full decomposition");
+        }
+      } else if (b > 0 && I.sub_have[w] && I.sub_try[w]) {
         const char* dbg_e = getenv("SIPX_EXT_DEBUG");
         const int dbg = dbg_e ? atoi(dbg_e) : 0;
         const int max_it = 8;
