@@ -517,6 +517,42 @@ __global__ __launch_bounds__(BLOCK) void k_cheb_step(int k, int b, int g, int r,
     out[e] = first ? (2.0 / aj) * Z[e] - Y0[e] : (4.0 / aj) * Z[e] - 2.0 * Y1[e] - Y0[e];
   }
 }
+// The same step with the projection inside, for the common case that only the nl <= 2 largest Ritz vectors are far above
+// anything (a velocity slice: its constant part): one wave per column, z_j - x_i (x_i' z_j) for the masked i, then the recurrence.
+// Replaces two skinny GEMMs, the mask kernel and k_cheb_step by one launch.
+__global__ __launch_bounds__(256) void k_cheb_step_proj(int k, int b, int g, int r, int nl, int batch, const double* __restrict__ W,
+                                                        const double* __restrict__ X, const double* Z, const double* Y1, const double* Y0,
+                                                        double* out, int first) {
+  const long long col = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);       // (matrix, column) pairs, one per wave
+  if (col >= (long long)b * batch) return;
+  const int lane = threadIdx.x & 63;
+  const long long l = col / b;
+  const int j = (int)(col - l * b);
+  const double* Wl = W + l * b;
+  const double a = cheb_floor(Wl, b, g, r);
+  const double tj = Wl[j] > a ? Wl[j] : a;
+  const double aj = Wl[j] / CHEB_KAPPA > a ? Wl[j] / CHEB_KAPPA : a;
+  const long long base = l * (long long)k * b + (long long)j * k;
+  double c0 = 0, c1 = 0;
+  const bool m0 = nl >= 1 && Wl[b - 1] > CHEB_KAPPA * tj, m1 = nl >= 2 && Wl[b - 2] > CHEB_KAPPA * tj;
+  const double* x0 = X + l * (long long)k * b + (long long)(b - 1) * k;
+  const double* x1 = X + l * (long long)k * b + (long long)(b - 2) * k;
+  if (m0 || m1) {
+    for (int i = lane; i < k; i += 64) {
+      const double z = Z[base + i];
+      if (m0) c0 += x0[i] * z;
+      if (m1) c1 += x1[i] * z;
+    }
+    c0 = wave_sum(c0);
+    c1 = wave_sum(c1);
+  }
+  for (int i = lane; i < k; i += 64) {
+    double z = Z[base + i];
+    if (m0) z -= x0[i] * c0;
+    if (m1) z -= x1[i] * c1;
+    out[base + i] = first ? (2.0 / aj) * z - Y0[base + i] : (4.0 / aj) * z - 2.0 * Y1[base + i] - Y0[base + i];
+  }
+}
 // Cholesky QR without the triangular solve: M = Y'Y (b x b, b <= 64, column-major, both triangles) -> Rinv, the inverse of
 // the factor R of M = R'R, so that Q = Y Rinv is one GEMM.  One workgroup per matrix, everything in LDS; the columns are
 // scaled to unit length first (M' = D^-1 M D^-1), which is what keeps the factorisation of a filtered block -- columns of
@@ -1132,6 +1168,8 @@ static bool rank_cheb_route(ExtImpl<T>& I, int w, int k) {
   const int budget = bud_e && atoi(bud_e) > 0 ? atoi(bud_e) : 160;      // multiplications with G a call may spend
   const char* jac_e = getenv("SIPX_RANK_JACOBI");          // 0: rocSOLVER's syevj for the Ritz problems (A/B)
   const bool own_jacobi = !(jac_e && jac_e[0] == '0');
+  const char* fp_e = getenv("SIPX_RANK_CHEB_FUSED");       // 0: the GEMM form of the projections whatever their number (A/B)
+  const bool fused_proj = !(fp_e && fp_e[0] == '0');
   const char* mm_e = getenv("SIPX_RANK_CHEB_MMAX");
   const int m_cap = mm_e && atoi(mm_e) >= 2 ? atoi(mm_e) : 16;
   const double tol = 1e-12;
@@ -1258,6 +1296,16 @@ static bool rank_cheb_route(ExtImpl<T>& I, int w, int k) {
         Z = F1;
         mark(1);
       }
+      double* out = i == 1 ? F2 : (i == 2 ? A : Y0);
+      if (nl <= 2 && fused_proj) {
+        mark(5);
+        hipLaunchKernelGGL(k_cheb_step_proj, dim3((unsigned)(((long long)b * batch + 3) / 4)), dim3(256), 0, s, k, b, g, r, nl, batch, I.Ws, X, Z, Y1, Y0,
+                           out, i == 1 ? 1 : 0);
+        mark(6);
+        Y0 = Y1;
+        Y1 = out;
+        continue;
+      }
       if (nl > 0) {
         const double* XL = X + (long long)(b - nl) * k;
         blas_check(rocblas_dgemm_strided_batched(I.blas, T_, N_, nl, b, k, &one, XL, k, sX, Z, k, sX, &zero, I.Hs, b, sH, batch), "X_L' Z");
@@ -1265,7 +1313,6 @@ static bool rank_cheb_route(ExtImpl<T>& I, int w, int k) {
                            I.Ws, I.Hs);
         blas_check(rocblas_dgemm_strided_batched(I.blas, N_, N_, k, b, nl, &mone, XL, k, sX, I.Hs, b, sH, &one, Z, k, sX, batch), "Z - X_L C");
       }
-      double* out = i == 1 ? F2 : (i == 2 ? A : Y0);
       mark(5);
       hipLaunchKernelGGL(k_cheb_step, dim3(NB), dim3(BLOCK), 0, s, k, b, g, r, batch, I.Ws, Z, Y1, Y0, out, i == 1 ? 1 : 0);
       mark(6);

@@ -1520,6 +1520,46 @@ def test_rank_projection_subspace_route(sipx, capfd, monkeypatch):
     assert np.allclose(ls.obj[:K], lo.obj[:K], rtol=2e-3)
 
 
+def test_rank_projection_filtered_route_on_flat_spectra(sipx, capfd, monkeypatch):
+    """Slices that are a constant plus white noise (the synthetic model of BASELINE config 4) have no gap behind any block of
+    singular values: plain subspace iteration never gets there, the Chebyshev-filtered one (ext_proj.hip, rank_cheb_route)
+    does, and is accepted on the inertia certificate (one batched Cholesky factorisation of mu I - G + X_r Theta_r X_r').
+    The iterates must agree with the full decomposition of every call (SIPX_RANK_CHEB=0) and with the oracle's LAPACK SVD
+    (reference: src/projectors/project_rank!.jl:26-45)."""
+    TF = np.float32
+    n, h = (128, 128, 6), (25.0, 25.0, 25.0)
+    rng = np.random.default_rng(20240604)
+    zz = np.linspace(0.0, 1.0, n[2])[None, None, :]
+    m = (1500.0 + 2500.0 * zz + 150.0 * rng.standard_normal(n)).reshape(-1, order="F").astype(TF)
+
+    def solve(mod):
+        g = mod.compgrid(h, n)
+        c = [mod.set_definitions("bounds", "identity", 1600.0, 3900.0, ("matrix", "")),
+             mod.set_definitions("rank", "identity", 0, 8, ("slice", "z"))]
+        opt = mod.PARSDMM_options(FL=TF, maxit=14)
+        opt.evol_rel_tol = opt.feas_tol = opt.obj_tol = 0.0          # run all iterations
+        P, A, prop = mod.setup_constraints(c, g, TF)
+        A, AtA, l, y = mod.PARSDMM_precompute_distribute(A, prop, g, opt)
+        return mod.PARSDMM(m.copy(), AtA, A, prop, P, g, opt)
+
+    monkeypatch.setenv("SIPX_EXT_DEBUG", "1")
+    capfd.readouterr()
+    xs, ls, _, _ = solve(sipx)
+    err = capfd.readouterr().err
+    assert err.count("inertia certificate holds") >= 4, err[-3000:]   # flat spectra: the energy bound cannot certify them
+    assert err.count("subspace accepted") >= 4, err[-3000:]
+    monkeypatch.setenv("SIPX_EXT_DEBUG", "0")
+    monkeypatch.setenv("SIPX_RANK_CHEB", "0")
+    xf, lf, _, _ = solve(sipx)
+    monkeypatch.delenv("SIPX_RANK_CHEB")
+    xo, lo, _, _ = solve(O)
+    nrm = np.linalg.norm(xo)
+    assert np.linalg.norm(xs.astype(np.float64) - xf.astype(np.float64)) / nrm < 5e-6
+    assert np.linalg.norm(xs.astype(np.float64) - xo) / nrm < 1e-4
+    K = min(len(ls.obj), len(lo.obj), 8)
+    assert np.allclose(ls.obj[:K], lo.obj[:K], rtol=2e-3)
+
+
 # ---- BASELINE configs[3] (C4): 8 constraint sets, two of them non-convex ------------------------------------------------
 @pytest.mark.parametrize("TF", [np.float32, np.float64])
 def test_c4_nonconvex_switches_and_lockstep(sipx, TF):
