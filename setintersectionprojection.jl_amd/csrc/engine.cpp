@@ -183,6 +183,10 @@ class Engine : public EngineBase {
     }
     if (ndim == 3 && G_.n[2] == 1) ndim_ = 2;      // get_TD_operator.jl:30
     G_.N = G_.n[0] * G_.n[1] * G_.n[2];
+    // Up to 2^22 grid points the kernels of the searches are too short for a second stream to hide anything: the cross-stream
+    // dependencies (an event wait costs 15-25 us on this stack) outweigh the overlap.  2048^2, C2: 2130 -> 2300 it/s on one
+    // stream; 256^3 gains 6 % from its three.  SIPX_SERIAL_SETS=0 / SIPX_SET_STREAMS=k keep the streams whatever the size.
+    if (G_.N <= (1ll << 22) && !set_streams_forced_ && !std::getenv("SIPX_SERIAL_SETS")) set_streams_ = false;
     G_.st[0] = 1;
     G_.st[1] = G_.n[0];
     G_.st[2] = G_.n[0] * G_.n[1];

@@ -538,3 +538,36 @@ def test_full_size_512_large_grid_forms_are_bit_identical(sipx, monkeypatch):
     assert len(l0.obj) == 14 and np.isfinite(x0).all()
     assert np.array_equal(l0.cg_it, l1.cg_it) and np.array_equal(l0.rho, l1.rho) and np.array_equal(l0.obj, l1.obj)
     assert np.array_equal(l0.r_pri, l1.r_pri) and np.array_equal(x0, x1)
+
+
+@pytest.mark.parametrize("n,h,kinds", [((96, 80), (25.0, 6.0), ["bounds", "l1:TV"]),
+                                       ((40, 24, 20), (25.0, 25.0, 25.0), ["bounds", "l1:D_x", "l1:D_y", "l1:D_z"])])
+def test_set_streams_or_one_stream_is_bit_identical(sipx, monkeypatch, n, h, kinds):
+    """Up to 2^22 grid points every set runs on the engine stream (the default there: the event waits between streams cost more
+    than the overlap of such short kernels gains); SIPX_SERIAL_SETS=0 keeps the set / search streams of the larger grids.
+    Which stream a kernel runs on changes no arithmetic: x, y, l and the rho / gamma histories are identical bit for bit."""
+    TF = np.float32
+    m = model(n, TF, seed=11)
+    out = {}
+    for tag in ("default", "0", "1"):
+        if tag == "default":
+            monkeypatch.delenv("SIPX_SERIAL_SETS", raising=False)
+        else:
+            monkeypatch.setenv("SIPX_SERIAL_SETS", tag)
+        g, opt, P, A, prop, AtA = _problem(sipx, n, h, TF, kinds, m, dict(maxit=24, evol_rel_tol=0.0, feas_tol=0.0, obj_tol=0.0))
+        ctx = sipx.host.build_context(m, AtA, A, prop, P, g, opt)
+        try:
+            ctx.parsdmm_begin(opt)
+            ctx.parsdmm_steps(24)
+            log = ctx.parsdmm_log()
+            x, l, y = ctx.download()
+        finally:
+            ctx.close()
+        out[tag] = (x, l, y, log)
+    x0, l0, y0, g0 = out["default"]
+    for tag in ("0", "1"):
+        x1, l1, y1, g1 = out[tag]
+        assert np.array_equal(x0, x1), tag
+        for a, b in zip(y0 + l0, y1 + l1):
+            assert np.array_equal(a, b), tag
+        assert np.array_equal(g0.rho, g1.rho) and np.array_equal(g0.gamma, g1.gamma) and np.array_equal(g0.cg_it, g1.cg_it)
