@@ -605,6 +605,7 @@ SHARDED = [
     (2, ["bounds", "rank:3", "l1:D_z"], (32, 24, 16), False),
     (3, ["bounds", "rank:3", "l1:D_z"], (32, 24, 16), False),               # slabs of 6, 6 and 4 slices
     (4, ["bounds", "nuc:z"], (12, 10, 5), False),                           # 2, 2, 1 slices and a rank with none
+    (3, ["bounds", "rank:8", "l1:D_z"], (128, 128, 6), False),             # slices large enough for the warm-started (filtered) subspace route, per rank
     (4, C4_KINDS, (16, 12, 8), False),                                      # BASELINE config 4's set list over 4 ranks
 ]
 
