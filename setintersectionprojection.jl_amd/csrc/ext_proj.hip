@@ -828,10 +828,11 @@ struct ExtImpl {
   bool sub_have[2] = {false, false}, sub_try[2] = {false, false};
   double *Qs = nullptr, *Zs = nullptr, *Hs = nullptr, *Ws = nullptr, *Es = nullptr, *Fro = nullptr;
   // Chebyshev-filtered variant of the same route (spectra without a gap behind the block): one more block, the matrix of the
-  // inertia certificate (allocated when first needed), calls to sit out after a failed attempt
+  // inertia certificate, calls to sit out after a failed attempt
   bool cheb = false;
   double *Ys = nullptr, *Bd = nullptr, *Cs = nullptr;
   int cheb_skip[2] = {0, 0}, cheb_fails[2] = {0, 0};
+  bool cert_warm = false;
   unsigned long long* sub_res = nullptr;           // device: bit pattern of the largest relative residual, failure flag
   unsigned long long* sub_res_host = nullptr;      // pinned
   // DCT: orthonormal DCT-II matrices per dimension, two work arrays, inner projector state
@@ -1011,7 +1012,11 @@ ExtProj<T>::ExtProj(const ExtSpec& spec, hipStream_t stream) {
         SIPX_HIP(hipHostMalloc((void**)&I.sub_res_host, 4 * sizeof(unsigned long long), hipHostMallocDefault));
         const char* ch_e = getenv("SIPX_RANK_CHEB");           // 0: plain subspace iteration only (spectra with a gap)
         I.cheb = !(ch_e && ch_e[0] == '0');
-        if (I.cheb) { I.Ys = I.template alloc<double>(nb); I.Cs = I.template alloc<double>((size_t)I.sub_b * I.sub_b * I.batch); }
+        if (I.cheb) {
+          I.Ys = I.template alloc<double>(nb);
+          I.Cs = I.template alloc<double>((size_t)I.sub_b * I.sub_b * I.batch);
+          I.Bd = I.template alloc<double>((size_t)k * k * I.batch);       // the matrix of the inertia certificate
+        }
       }
     }
     I.info = I.template alloc<rocblas_int>((size_t)3 * I.batch);   // info, n_sweeps / second info, sweeps of the Ritz solver
@@ -1241,7 +1246,6 @@ static bool rank_cheb_route(ExtImpl<T>& I, int w, int k) {
     if (res <= tol) {
       if (!hidden) { ok = true; break; }
       // flat spectrum: the inertia certificate (X_r Theta_r goes through F1)
-      if (!I.Bd) I.Bd = I.template alloc<double>((size_t)k * k * batch);
       hipLaunchKernelGGL(k_cert_shift, dim3(NB), dim3(BLOCK), 0, s, k, b, r, batch, I.Gd, I.Ws, I.Bd);
       hipLaunchKernelGGL(k_cert_scale, dim3(NB), dim3(BLOCK), 0, s, k, b, r, batch, X, I.Ws, F1);
       blas_check(rocblas_dgemm_strided_batched(I.blas, N_, T_, k, k, r, &one, F1 + (long long)(b - r) * k, k, sX, X + (long long)(b - r) * k, k, sX,
@@ -1469,6 +1473,13 @@ void ExtProj<T>::project(T* v, bool feas, double* partials, T* maxpart, T* compa
           double q;
           std::memcpy(&q, &I.sub_res_host[0], sizeof(double));
           I.sub_have[w] = true;
+          if (I.cheb && !I.cert_warm) {
+            // the library sizes the workspace of a batched factorisation at its first call (a device allocation of its own, 100 ms
+            // and more): spend it here, behind a full decomposition, not inside the first accepted call of the filtered route
+            I.cert_warm = true;
+            SIPX_HIP(hipMemsetAsync(I.Bd, 0, sizeof(double) * (size_t)k * k * I.batch, s));
+            (void)rocsolver_dpotrf_strided_batched(I.blas, rocblas_fill_upper, k, I.Bd, k, sG, I.info, I.batch);
+          }
           I.sub_try[w] = q < 0.25;
           const char* dbg_e = getenv("SIPX_EXT_DEBUG");
           if (dbg_e && atoi(dbg_e)) fprintf(stderr, "[sipx rank] theta_{b+1}/theta_r = %.3e -> %s\n", q, I.sub_try[w] ? "subspace next" : "full next");

@@ -1559,7 +1559,7 @@ def test_rank_projection_filtered_route_on_flat_spectra(sipx, capfd, monkeypatch
     assert err.count("inertia certificate holds") >= 4, err[-3000:]   # flat spectra: the energy bound cannot certify them
     assert err.count("subspace accepted") >= 4, err[-3000:]
     far = [int(v) for v in re.findall(r"(\d+) vectors far above", err)]
-    assert far and (max(far) > 2) == (strong > 0), far              # strong directions: the GEMM form of the projections ran
+    assert far and (not strong or max(far) > 2), far                # strong directions: the GEMM form of the projections ran
     monkeypatch.setenv("SIPX_EXT_DEBUG", "0")
     monkeypatch.setenv("SIPX_RANK_CHEB", "0")
     xf, lf, _, _ = solve(sipx)

@@ -447,6 +447,9 @@ def test_lean_first_passes_in_one_sweep_are_bit_identical(sipx, monkeypatch, TF,
     m = model(n, TF, seed=7)
     gs, os_, Ps, As, props, AtAs = _problem(sipx, n, h, TF, kinds, m, dict(maxit=60))
     os_.evol_rel_tol = os_.feas_tol = os_.obj_tol = 0.0
+    # the group pass needs every set's own scratch, which exists with the set streams: those of the large grids it is made for
+    # (a grid this small runs on the engine stream alone by default)
+    monkeypatch.setenv("SIPX_SERIAL_SETS", "0")
     out = {}
     for tag in ("0", "1"):
         monkeypatch.setenv("SIPX_LEAN_MULTI", tag)

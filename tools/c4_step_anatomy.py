@@ -1,7 +1,7 @@
 """Anatomy of one C4 iteration from a rocprofv3 --kernel-trace CSV: the interval between the last two inertia certificates of
 the slice-rank projector (k_cert_or) is one iteration; inside it the span of the rank projector's own call (k_sub_fro ..
 k_cert_or), the union of kernel intervals inside and outside that span, and the largest kernels outside it.
-usage: python tools/c4_step_anatomy.py <dir with *kernel_trace.csv>"""
+usage: python tools/c4_step_anatomy.py <dir with *kernel_trace.csv> [iterations from the end = 3]"""
 import csv, glob, os, sys, collections
 rows = []
 for f in glob.glob(os.path.join(sys.argv[1], "**", "*kernel_trace.csv"), recursive=True):
@@ -19,7 +19,8 @@ def union(rs):
             tot += e - max(s, end)
             end = e
     return tot
-for a, b in zip(certs[-4:-1], certs[-3:]):
+last = min(int(sys.argv[2]) if len(sys.argv) > 2 else 3, len(certs) - 1)
+for a, b in zip(certs[-last - 1:-1], certs[-last:]):
     step = rows[a + 1:b + 1]
     t0, t1 = rows[a][1], rows[b][1]
     fro = max(i for i in fros if i <= b)
