@@ -1198,8 +1198,8 @@ static bool rank_cheb_route(ExtImpl<T>& I, int w, int k) {
   mark(7);
   int mults = 0, m_prev = 0;
   double prev = -1;
-  bool ok = false;
-  for (int outer = 0; outer < 8; ++outer) {
+  bool ok = false, fresh_start = true, tried_other = false;
+  for (int outer = 0; outer < 9; ++outer) {
     // Rayleigh-Ritz on span(A): Cholesky QR (twice behind a filter: its columns lean on each other), H = Q'GQ, X = Q S
     SIPX_HIP(hipMemsetAsync(I.info, 0, sizeof(rocblas_int) * batch, s));
     for (int pass = 0; pass < (m_prev > 0 ? 2 : 1); ++pass) {
@@ -1242,7 +1242,18 @@ static bool rank_cheb_route(ExtImpl<T>& I, int w, int k) {
     if (failed) break;
     // The previous call's vectors say little about this input (the first iterations of a solve): filters started from there
     // were observed to swamp the guard columns and then stall at a residual of 1e-8 theta_max -- the full decomposition at once.
-    if (outer == 0 && res > 1e-3) break;
+    if (fresh_start && res > 1e-3) {
+      // the feasibility estimate is asked for every tenth iteration only, its own vectors are ten iterations old: those of the
+      // y update of this iteration (another input, but the same x behind it) may be the better start
+      if (w == 1 && I.sub_have[0] && !tried_other) {
+        tried_other = true;
+        SIPX_HIP(hipMemcpyAsync(A, I.Xs[0], sizeof(double) * (size_t)sX * batch, hipMemcpyDeviceToDevice, s));
+        if (dbg) fprintf(stderr, "[sipx rank] poor start: once more from the vectors of the y update\n");
+        continue;
+      }
+      break;
+    }
+    fresh_start = false;
     if (res <= tol) {
       if (!hidden) { ok = true; break; }
       // flat spectrum: the inertia certificate (X_r Theta_r goes through F1)
