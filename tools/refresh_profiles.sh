@@ -79,6 +79,10 @@ if [ -z "$LIGHT" ]; then
   # whole grid's size would switch it on: what the iteration costs a rank before any collective has a latency
   SIPX_L1_SAMPLE_RUNS=2048 SIPX_FORCE_DIST=1 $T python bench.py --no-cpu-baseline --no-512 --no-c4 --no-c5 --config c3-slab8 --decomp slab > $O/${R}_c3_slab8_share_rccl_world1.json 2>>$O/bench.err
   SIPX_L1_SAMPLE_RUNS=4096 SIPX_FORCE_DIST=1 $T python bench.py --no-cpu-baseline --no-512 --no-c4 --no-c5 --config c3-512-slab8 --decomp slab > $O/${R}_c3_512_slab8_share_rccl_world1.json 2>>$O/bench.err
+  # the slice-rank projector on slices without a spectral gap (C4's model), filtered subspace route against the full decomposition
+  $T python tools/rank_flat_bench.py 512 32 12 > $O/${R}_rank_flat_512.json 2>>$O/bench.err
+  $T python tools/rank_flat_bench.py 256 32 12 > $O/${R}_rank_flat_256.json 2>>$O/bench.err
+  $T python bench.py --no-cpu-baseline --no-512 --no-c4 --no-c5 --config c3-768 --steps 6 --warmup 3 > $O/${R}_c3_768_bench.json 2>>$O/bench.err
 fi
 for f in $O/${R}_*bench*.json; do python - "$f" <<'PY'
 import json,sys
