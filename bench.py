@@ -796,6 +796,9 @@ def main():
                      "slab_searches": searches if (dist is not None and slab) else None,
                      "ranks_agree_on_x": agree},
             "dominant_kernel": dominant, "kernels": table,
+            # a slice-rank set in the list: which route its projector took since the context was built (engine counters: calls,
+            # calls served by the warm-started filtered subspace iteration, full decompositions, products with the Gram matrices)
+            "rank_route": (per_kernel.get("rank_route") if per_kernel and (per_kernel.get("rank_route") or {}).get("calls") else None),
             "value": steps / dt, "ms_per_step": dt / steps * 1e3, "decomposition": ("slab" if slab else "sets") if dist is not None else None,
             # log.timing of the whole run (warm-up included), per iteration: where the time of an iteration goes on this rank
             "timing_ms_per_iteration": {k: round(float(v) * 1e3 / max(len(log.obj), 1), 4) for k, v in (log.timing or {}).items()},
@@ -842,6 +845,8 @@ def main():
              "timing_ms_per_iteration": r["timing_ms_per_iteration"]}
         if full:
             o.update({"roofline": r["roofline"], "iteration_roofline": r["iteration_roofline"]})
+        if r.get("rank_route"):
+            o["rank_route"] = r["rank_route"]
         return o
 
     def safe(name, fn):
@@ -878,6 +883,8 @@ def main():
         "iteration_roofline": r["iteration_roofline"], "timing_ms_per_iteration": r["timing_ms_per_iteration"],
         "comm": r["comm"], "decomposition": r["decomposition"], "libsipx_sha16": lib_sha16(),
     }
+    if r.get("rank_route"):
+        out["rank_route"] = r["rank_route"]
     if both is not None:
         out["decompositions"] = both
         out["faster_decomposition"] = max(both, key=lambda k: both[k].get("value", 0.0))
@@ -888,7 +895,7 @@ def main():
     if args.config == "c3" and args.dtype == "f32" and args.q_mode == "cds" and not args.no_c4:
         # BASELINE configs[3]: 512^3, the eight constraint sets + distance term, at every N (the scaling target of the
         # contract is quoted on THIS set list: ">= 3.5x at 8 GPUs when 8 constraint sets are sharded").  Sets one per rank;
-        # the slice-rank set, 94 % of the single-GPU time, is projected by all ranks (each its slab of slices).
+        # the slice-rank set, half of the single-GPU time (94 % before its warm-started subspace route), is projected by all ranks (each its slab of slices).
         progress("c4_512 leg")
         out["c4_512"] = safe("c4_512", lambda: leg(measure("c4", 6, 2), 6, 2, full=False))
     if args.config == "c3" and args.dtype == "f32" and args.q_mode == "cds" and not args.no_c5:

@@ -2148,7 +2148,17 @@ class Engine : public EngineBase {
     // slab-decomposed solve: threshold searches that went through the speculative exchange since the context was finalised,
     // and how many of them needed their fallback (refinement rounds + full-size exchange)
     o += "], \"slab_searches\": {\"speculative_exchange\": " + std::to_string(spec_searches_) + ", \"fallbacks\": " +
-         std::to_string(spec_fallbacks_) + ", \"refinement_rounds\": " + std::to_string(spec_rounds_) + "}}";
+         std::to_string(spec_fallbacks_) + ", \"refinement_rounds\": " + std::to_string(spec_rounds_) + "}";
+    // slice-rank / matrix-rank sets: which route their projector took since the context was finalised (ext_proj.hip)
+    long long rc[4] = {0, 0, 0, 0};
+    for (const auto& st : sets_) {
+      if (!st.ext || st.ext_kind != EXT_RANK) continue;
+      long long c[4];
+      st.ext->route_counts(c);
+      for (int q = 0; q < 4; ++q) rc[q] += c[q];
+    }
+    o += ", \"rank_route\": {\"calls\": " + std::to_string(rc[0]) + ", \"warm_started_subspace\": " + std::to_string(rc[1]) +
+         ", \"full_decomposition\": " + std::to_string(rc[2]) + ", \"products_with_gram\": " + std::to_string(rc[3]) + "}}";
     start_stats(enable);
     return o.c_str();
   }

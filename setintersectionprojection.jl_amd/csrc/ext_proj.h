@@ -35,6 +35,9 @@ class ExtProj {
   ExtProj(const ExtProj&) = delete;
   // v <- P(v) in place (padded layout, G.N entries); feas selects the warm-start state of the feasibility estimate
   void project(T* v, bool feas, double* partials, T* maxpart, T* compact);
+  // rank projector: calls since construction, calls served by the warm-started subspace route, calls that decomposed fully,
+  // products with the Gram matrices the subspace route spent (all zero for the other kinds)
+  void route_counts(long long out[4]) const;
 
  private:
   ExtImpl<T>* impl_;

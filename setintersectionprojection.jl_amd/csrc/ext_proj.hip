@@ -833,6 +833,7 @@ struct ExtImpl {
   double *Ys = nullptr, *Bd = nullptr, *Cs = nullptr;
   int cheb_skip[2] = {0, 0}, cheb_fails[2] = {0, 0};
   bool cert_warm = false;
+  long long n_calls = 0, n_subspace = 0, n_full = 0, n_products = 0;       // route_counts()
   unsigned long long* sub_res = nullptr;           // device: bit pattern of the largest relative residual, failure flag
   unsigned long long* sub_res_host = nullptr;      // pinned
   // DCT: orthonormal DCT-II matrices per dimension, two work arrays, inner projector state
@@ -1345,6 +1346,7 @@ static bool rank_cheb_route(ExtImpl<T>& I, int w, int k) {
   if (dbg >= 2)
     fprintf(stderr, "[sipx rank] phases (ms): orthonormalise %.2f, products with G %.2f (%d), small products %.2f, Ritz solver %.2f, residual %.2f, "
                     "projections %.2f, recurrence %.2f, copy + certificate %.2f\n", ph[0], ph[1], mults, ph[2], ph[3], ph[4], ph[5], ph[6], ph[7]);
+  I.n_products += mults;
   SIPX_HIP(hipGetLastError());
   return ok;
 }
@@ -1460,6 +1462,8 @@ void ExtProj<T>::project(T* v, bool feas, double* partials, T* maxpart, T* compa
         }
         if (dbg) fprintf(stderr, "[sipx rank] %s\n", sub_ok ? "subspace accepted" : "full decomposition");
       }
+      ++I.n_calls;
+      if (sub_ok) ++I.n_subspace; else ++I.n_full;
       const double* Esel;
       long long ldsel_stride;
       if (sub_ok) {
@@ -1596,6 +1600,14 @@ void ExtProj<T>::project(T* v, bool feas, double* partials, T* maxpart, T* compa
     hipLaunchKernelGGL((k_seg_scatter<T, T>), dim3(NB), dim3(BLOCK), 0, s, I.map, I.X, v, (const int*)nullptr);
   }
   SIPX_HIP(hipGetLastError());
+}
+
+template <typename T>
+void ExtProj<T>::route_counts(long long out[4]) const {
+  out[0] = impl_ ? impl_->n_calls : 0;
+  out[1] = impl_ ? impl_->n_subspace : 0;
+  out[2] = impl_ ? impl_->n_full : 0;
+  out[3] = impl_ ? impl_->n_products : 0;
 }
 
 template class ExtProj<float>;

@@ -1841,6 +1841,26 @@ def test_multilevel_over_slab_decomposed_levels(sipx, tmp_path, world, n, h, lev
 
 
 @pytest.mark.timeout(300)
+def test_bench_line_reports_the_rank_projector_route():
+    """A set list with a slice-rank set (BASELINE config 4 at 256^3): the bench line carries the engine's own counters of the
+    rank projector's route -- calls, calls served by the warm-started filtered subspace iteration, full decompositions, products
+    with the Gram matrices -- so that a C4 number can be read together with what produced it."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--config", "c4-256", "--steps", "5", "--warmup", "2",
+                        "--no-cpu-baseline", "--no-512", "--no-c4", "--no-c5"], capture_output=True, text=True, timeout=280, env=dict(os.environ))
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = json.loads([ln for ln in r.stdout.strip().splitlines() if ln.strip()][-1])
+    rr = d["rank_route"]
+    assert rr["calls"] >= 7 and rr["calls"] == rr["warm_started_subspace"] + rr["full_decomposition"]
+    assert rr["warm_started_subspace"] >= 3 and rr["products_with_gram"] >= 10 * rr["warm_started_subspace"]
+    assert d["config"]["all_logs_finite"]
+
+
+@pytest.mark.timeout(300)
 @pytest.mark.parametrize("dist_env", [None, "1"])
 def test_bench_contract_line(dist_env):
     """bench.py prints ONE JSON line with the contract's fields (metric, value, unit, n_gpus, steps, warmup, ms_per_step,
