@@ -115,12 +115,7 @@ def _parallel_suite_serial_leg(mod, which):
     n = (201, 100)
     x = _draw(TF, n)
     g = mod.compgrid((1.0, 1.0), n)
-    if which == "TV":
-        TV = O.get_TD_operator(O.compgrid((1.0, 1.0), n), "TV", TF)[0]
-        c = [mod.set_definitions("l1", "TV", 0.0, float(TF(0.5) * np.abs(TV @ x).sum(dtype=TF)), ("matrix", ""))]
-    else:
-        Z = np.abs(np.fft.fftn(x.reshape(n, order="F").astype(np.float64), norm="ortho"))       # joDFT is unitary
-        c = [mod.set_definitions("l1", "DFT", 0.0, float(TF(0.5) * TF(Z.sum())), ("matrix", ""))]
+    c = _parallel_suite_sets(mod, which, x, n, TF)
     kw = dict(evol_rel_tol=1e-5, feas_tol=1e-5, obj_tol=1e-5, maxit=10000)
     xo, log, P, A, opt = _solve(mod, c, g, TF, x, kw)
     assert len(log.obj) < 10000
@@ -172,3 +167,63 @@ def test_engine_parallel_suite_serial_legs(sipx, which):
         xo = _parallel_suite_serial_leg(O, "TV")
         # `@test isapprox(x1, x3, rtol=5*1f-4)`, test_PARSDMM_parallel.jl:72: the reference's tolerance between two of its own paths
         assert np.linalg.norm(xs.astype(np.float64) - xo) <= 5e-4 * max(np.linalg.norm(xs.astype(np.float64)), np.linalg.norm(xo))
+
+
+# ---- test/test_PARSDMM_parallel.jl:4-72, 75-121, the parallel legs ("test is for 2 workers"): two ranks sharing the one GPU, the
+# engine's collectives over gloo callbacks; x_parallel is feasible and isapprox(x_parallel, x_serial, rtol = 5e-4) ---------------
+def _parallel_worker(rank, world, port, out, which, decomp):
+    import datetime
+    import os
+    import sys
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")
+    dist.init_process_group("gloo", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=180))
+    try:
+        root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+        sys.path.insert(0, root)
+        from __graft_entry__ import load_package
+        sipx = load_package()
+        from sipx import sharded
+        TF, n = np.float32, (201, 100)
+        x = _draw(TF, n)
+        g = sipx.compgrid((1.0, 1.0), n)
+        c = _parallel_suite_sets(sipx, which, x, n, TF)
+        opt = sipx.PARSDMM_options(FL=TF, evol_rel_tol=1e-5, feas_tol=1e-5, obj_tol=1e-5, maxit=10000)
+        P, A, prop = sipx.setup_constraints(c, g, TF)
+        A, AtA, l, y = sipx.PARSDMM_precompute_distribute(A, prop, g, opt)
+        xo, log, l, y = sharded.PARSDMM_sharded(x.copy(), AtA, A, prop, P, g, opt, dist=dist, device=0, comm_mode="torch", decomp=decomp)
+        np.savez(os.path.join(out, f"p{rank}.npz"), x=xo, its=len(log.obj))
+    finally:
+        dist.destroy_process_group()
+
+
+def _parallel_suite_sets(mod, which, x, n, TF):
+    if which == "TV":
+        TV = O.get_TD_operator(O.compgrid((1.0, 1.0), n), "TV", TF)[0]
+        return [mod.set_definitions("l1", "TV", 0.0, float(TF(0.5) * np.abs(TV @ x).sum(dtype=TF)), ("matrix", ""))]
+    Z = np.abs(np.fft.fftn(x.reshape(n, order="F").astype(np.float64), norm="ortho"))
+    return [mod.set_definitions("l1", "DFT", 0.0, float(TF(0.5) * TF(Z.sum())), ("matrix", ""))]
+
+
+@pytest.mark.gpu
+@pytest.mark.timeout(400)
+@pytest.mark.parametrize("which,decomp", [("TV", "sets"), ("TV", "slab"), ("DFT", "sets")])
+def test_engine_parallel_suite_two_ranks(sipx, tmp_path, which, decomp):
+    import os
+    import torch.multiprocessing as mp
+    port = 29400 + (os.getpid() % 2000) + (7 if decomp == "slab" else 0)
+    mp.spawn(_parallel_worker, args=(2, port, str(tmp_path), which, decomp), nprocs=2, join=True)
+    r0, r1 = np.load(tmp_path / "p0.npz"), np.load(tmp_path / "p1.npz")
+    assert np.array_equal(r0["x"], r1["x"]) and int(r0["its"]) == int(r1["its"]) < 10000      # every rank ends with the same x
+    x_par = r0["x"]
+    TF, n = np.float32, (201, 100)
+    x = _draw(TF, n)
+    g = sipx.compgrid((1.0, 1.0), n)
+    x_ser, log, P, A, opt = _solve(sipx, _parallel_suite_sets(sipx, which, x, n, TF), g, TF, x,
+                                   dict(evol_rel_tol=1e-5, feas_tol=1e-5, obj_tol=1e-5, maxit=10000))
+    _assert_feasible(x_par, P, A, 1.5, opt.feas_tol)                                            # test_PARSDMM_parallel.jl:34-38 / :115-119
+    a, b = x_par.astype(np.float64), x_ser.astype(np.float64)
+    assert np.linalg.norm(a - b) <= 5e-4 * max(np.linalg.norm(a), np.linalg.norm(b))            # :72 / :121
