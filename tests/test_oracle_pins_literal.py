@@ -4,7 +4,8 @@ are drawn here from numpy (Julia's RNG stream is not reproducible outside Julia)
 which is what makes it a pin.  tests/test_oracle_pins.py keeps the same facts at other sizes / precisions.
 
 What stays UNPINNED by the reference (no fixture exists, and none can be generated: no Julia toolchain here or on the GPU
-box): the Barzilai-Borwein rule of adapt_rho_gamma, the stop rules, and any iteration trace of PARSDMM.  For those the HIP
+box): the VALUES of the Barzilai-Borwein rule of adapt_rho_gamma (the reference only tests that its serial and per-worker forms agree:
+restated at the end of this file), the stop rules, and any iteration trace of PARSDMM.  For those the HIP
 engine is compared with this restatement only ("parity unpinned" above the leaf functions)."""
 import numpy as np
 import scipy.sparse as sp
@@ -332,3 +333,145 @@ def test_argmin_x_literal():
             assert res(x) <= 1e-5 and res(x) <= 2.0 * relres
             x, it, relres, _ = O.argmin_x(R, b, np.zeros(100), 1e-10, 5, off)              # more accurate  :53-57
             assert res(x) <= 1e-10 and res(x) <= 2.0 * relres
+
+
+# ---- test/test_update_y_l_parallel.jl:1-118 and test/test_adapt_rho_gamma_parallel.jl:1-141: one worker per set == the serial loop ------
+def _parallel_leaf_inputs(rng):
+    M = (51, 100)
+    vec = lambda: [rng.standard_normal(k) for k in M]
+    d = dict(x=rng.standard_normal(100), y=vec(), y_0=vec(), y_old=vec(), l_old=vec(), l=vec(), l_0=vec(), l_hat=vec(), l_hat_0=vec(),
+             x_hat=vec(), r_pri=vec(), s=vec(), s_0=vec(), m=rng.standard_normal(100))
+    d["rho"] = np.array([1.234, 10.23432])
+    d["gamma"] = np.array([1.0, 1.345])
+    d["TD_OP"] = [sp.csc_matrix(sp.eye(51, 100, format="csc") * 2.0), sp.identity(100, format="csc")]
+    return d
+
+
+def _bb_one_worker(TF, gamma, rho, adjust_gamma, adjust_rho, y, y_old, s, s_0, l, l_hat_0, l_0, l_old, y_0, l_hat):
+    """src/adapt_rho_gamma_parallel.jl:30-127 restated on its own (one set: index [1] of the worker's local part), in that file's
+    nesting -- the correlation test inside the reliability test -- which differs from the serial file the oracle follows."""
+    eps_correlation = TF(0.3)
+    safeguard = TF(1e-10) if TF == np.float64 else TF(1e-6)
+    l_hat[:] = l_old + rho * (-s + y_old)
+    d_l_hat, d_H_hat, d_l, d_G_hat = l_hat - l_hat_0, s - s_0, l - l_0, y_0 - y
+    d_dHh_dlh, d_dGh_dl = TF(np.dot(d_H_hat, d_l_hat)), TF(np.dot(d_G_hat, d_l))
+    n_d_H_hat, n_d_l_hat, n_d_l, n_d_G_hat = (TF(np.linalg.norm(v)) for v in (d_H_hat, d_l_hat, d_l, d_G_hat))
+    alpha_comp = beta_comp = False
+    if (n_d_H_hat * n_d_l_hat) > safeguard and (n_d_H_hat ** 2) > safeguard and d_dHh_dlh > safeguard:
+        if d_dHh_dlh / (n_d_H_hat * n_d_l_hat) > eps_correlation:
+            alpha_comp = True
+            mg, sd = d_dHh_dlh / (n_d_H_hat ** 2), (n_d_l_hat ** 2) / d_dHh_dlh
+            alpha_hat = mg if (TF(2.0) * mg) > sd else sd - mg / TF(2.0)
+    if (n_d_G_hat * n_d_l) > safeguard and (n_d_G_hat ** 2) > safeguard and d_dGh_dl > safeguard:
+        if d_dGh_dl / (n_d_G_hat * n_d_l) > eps_correlation:
+            beta_comp = True
+            mg, sd = d_dGh_dl / (n_d_G_hat ** 2), (n_d_l ** 2) / d_dGh_dl
+            beta_hat = mg if (TF(2.0) * mg) > sd else sd - mg / TF(2.0)
+    if adjust_rho:
+        if alpha_comp and beta_comp:
+            rho = TF(np.sqrt(alpha_hat * beta_hat))
+        elif alpha_comp:
+            rho = alpha_hat
+        elif beta_comp:
+            rho = beta_hat
+    if adjust_gamma:
+        if alpha_comp and beta_comp:
+            gamma = TF(1.0) + ((TF(2.0) * TF(np.sqrt(alpha_hat * beta_hat))) / (alpha_hat + beta_hat))
+        elif alpha_comp:
+            gamma = TF(1.9)
+        elif beta_comp:
+            gamma = TF(1.1)
+        else:
+            gamma = TF(1.5)
+    return rho, gamma, (alpha_comp, beta_comp)
+
+
+def _bb_compare(d, adjust_gamma=True, adjust_rho=True):
+    p, TF = 2, np.float64
+    cp = lambda v: [a.copy() for a in v]
+    # "distributed computation": every worker runs the rule on its own set
+    rho_d, gamma_d, l_hat_d, branches = d["rho"].copy(), d["gamma"].copy(), cp(d["l_hat"]), []
+    for k in range(p):
+        rho_d[k], gamma_d[k], b = _bb_one_worker(TF, TF(gamma_d[k]), TF(rho_d[k]), adjust_gamma, adjust_rho, d["y"][k], d["y_old"][k], d["s"][k],
+                                                 d["s_0"][k], d["l"][k], d["l_hat_0"][k], d["l_0"][k], d["l_old"][k], d["y_0"][k], l_hat_d[k])
+        branches.append(b)
+    # the same through the oracle's one-set entry (what the sharded oracle comparisons use) ...
+    rho_w, gamma_w, l_hat_w = d["rho"].copy(), d["gamma"].copy(), cp(d["l_hat"])
+    for k in range(p):
+        O.adapt_rho_gamma(gamma_w, rho_w, adjust_gamma, adjust_rho, d["y"], d["y_old"], d["s"], d["s_0"], d["l"], d["l_hat_0"], d["l_0"],
+                          d["l_old"], d["y_0"], p, l_hat_w, only=[k])
+    # ... and "serial computation"
+    rho, gamma, l_hat = d["rho"].copy(), d["gamma"].copy(), cp(d["l_hat"])
+    O.adapt_rho_gamma(gamma, rho, adjust_gamma, adjust_rho, d["y"], d["y_old"], d["s"], d["s_0"], d["l"], d["l_hat_0"], d["l_0"], d["l_old"],
+                      d["y_0"], p, l_hat)
+    assert np.array_equal(rho_d, rho) and np.array_equal(gamma, gamma_d)                 # `@test rho_d==rho`, `@test gamma==gamma_d`
+    assert np.array_equal(rho_w, rho) and np.array_equal(gamma_w, gamma)
+    for k in range(p):
+        assert isapprox(l_hat[k], l_hat_d[k], 10 * EPS) and np.array_equal(l_hat[k], l_hat_w[k])
+        # "another related piece of code" (:121-139): l_hat = l_old + rho (-s + y_old), here with the rho the rule was entered with
+        assert isapprox(d["l_old"][k] + d["rho"][k] * (-d["s"][k] + d["y_old"][k]), l_hat[k], 10 * EPS)
+    return branches, rho, gamma
+
+
+def test_adapt_rho_gamma_parallel_literal():
+    d = _parallel_leaf_inputs(np.random.default_rng(123))
+    branches, rho, gamma = _bb_compare(d)
+    # independent draws are uncorrelated: neither step length is computed, rho stays, gamma falls back to 1.5
+    assert branches == [(False, False)] * 2 and np.array_equal(rho, d["rho"]) and np.array_equal(gamma, [1.5, 1.5])
+
+
+def test_adapt_rho_gamma_parallel_every_branch():
+    """The same comparison on inputs built so that each combination of (alpha, beta) is computed: the differences of the
+    snapshots are made to correlate (or not) by construction."""
+    seen = set()
+    for seed in range(40):
+        rng = np.random.default_rng(1000 + seed)
+        d = _parallel_leaf_inputs(rng)
+        for k in range(2):
+            ca, cb = (seed >> (2 * k)) & 1, (seed >> (2 * k + 1)) & 1
+            if ca:       # l_hat - l_hat_0 along s - s_0:  l_hat = l_old + rho (y_old - s)
+                d["l_hat_0"][k] = d["l_old"][k] + d["rho"][k] * (-d["s"][k] + d["y_old"][k]) - (0.5 + rng.random()) * (d["s"][k] - d["s_0"][k]) \
+                    + 0.3 * rng.standard_normal(d["s"][k].size)
+            if cb:       # l - l_0 along y_0 - y
+                d["l_0"][k] = d["l"][k] - (0.5 + 2 * rng.random()) * (d["y_0"][k] - d["y"][k]) + 0.3 * rng.standard_normal(d["s"][k].size)
+        for ag, ar in ((True, True), (False, True), (True, False)):
+            branches, rho, gamma = _bb_compare(d, adjust_gamma=ag, adjust_rho=ar)
+            seen.update(branches)
+    assert seen == {(False, False), (True, False), (False, True), (True, True)}
+
+
+def test_update_y_l_parallel_literal():
+    rng = np.random.default_rng(123)
+    d = _parallel_leaf_inputs(rng)
+    p, i, maxit = 2, 10, 39
+    rho, gamma, x, TD_OP = d["rho"], d["gamma"], d["x"], d["TD_OP"]
+    prox = [lambda v: 1.0 * v, lambda v: O.prox_l2s(v, rho[1], d["m"])]
+    P_sub = [prox[0]]
+
+    class L: pass
+
+    def fresh_log():
+        g = L()
+        g.r_pri, g.r_dual, g.set_feasibility = np.zeros((maxit, p)), np.zeros((maxit, p)), np.zeros((maxit, p - 1))
+        return g
+    cp = lambda v: [a.copy() for a in v]
+    # reference solution (:86-98)
+    y2, l2, x_hat2 = cp(d["y"]), cp(d["l"]), [None, None]
+    for k in range(p):
+        x_hat2[k] = gamma[k] * (TD_OP[k] @ x) + (1 - gamma[k]) * y2[k]
+        y2[k] = prox[k](x_hat2[k] - l2[k] / rho[k])
+        l2[k] = l2[k] + rho[k] * (y2[k] - x_hat2[k])
+    rhs_ref = sum(TD_OP[k].T @ (l2[k] + y2[k]) for k in range(p))
+    # one worker per set (:68-76) -- the oracle's one-set entry -- and the serial call (:101-107)
+    outs = {}
+    for name, groups in (("workers", [[0], [1]]), ("serial", [None])):
+        y, l, y_old, l_old, x_hat, r_pri, s = (cp(d[k]) for k in ("y", "l", "y_old", "l_old", "x_hat", "r_pri", "s"))
+        log, counter = fresh_log(), 12
+        for only in groups:
+            counter = O.update_y_l(x, p, i, y, y_old, l, l_old, rho, gamma, prox, TD_OP, log, P_sub, counter, x_hat, r_pri, s, only=only)
+        outs[name] = dict(y=y, l=l, s=s, r_pri=r_pri, rhs=sum(TD_OP[k].T @ (l[k] + y[k]) for k in range(p)), log=log)
+    a, b = outs["serial"], outs["workers"]
+    assert isapprox(a["rhs"], rhs_ref, 10 * EPS) and isapprox(b["rhs"], rhs_ref, 10 * EPS)            # :109-110
+    for k in range(p):                                                                                 # :111-113
+        assert isapprox(a["s"][k], b["s"][k], 10 * EPS) and isapprox(a["l"][k], b["l"][k], 10 * EPS) and isapprox(a["r_pri"][k], b["r_pri"][k], 10 * EPS)
+    assert np.array_equal(a["log"].r_pri, b["log"].r_pri) and np.array_equal(a["log"].set_feasibility, b["log"].set_feasibility)
