@@ -595,6 +595,14 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch one rank per GPU (or run `python bench.py --gpus N` "
                          "without a launcher and let it spawn its own ranks)")
     dist = None
+    # SIPX_BENCH_SHARE_GPU=1: a REHEARSAL of the N > 1 flow on a box with one GPU -- every rank runs the real engine on device 0,
+    # the engine's collectives go through torch.distributed's gloo group as callbacks (RCCL refuses two ranks on one device).
+    # Every world > 1 branch of this script, every leg and both decompositions run as they will on N GPUs; the numbers mean
+    # nothing (N ranks share one card) and the line says so (`invalid_as_measurement`).
+    share_gpu = bool(os.environ.get("SIPX_BENCH_SHARE_GPU")) and world > 1
+    if share_gpu:
+        local_rank = 0
+    red_dev = "cpu" if share_gpu else "cuda"                  # where the script's own small all-reduces live
     torch.cuda.set_device(local_rank)
     force_dist = bool(os.environ.get("SIPX_FORCE_DIST"))      # exercise the RCCL path even with one rank
     saved_stdout = None
@@ -607,7 +615,12 @@ def main():
         import torch.distributed as dist
         if force_dist and "MASTER_ADDR" not in os.environ:
             os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="29533", RANK="0", WORLD_SIZE="1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if share_gpu:
+            import datetime
+            os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")
+            dist.init_process_group("gloo", timeout=datetime.timedelta(seconds=max(60.0, args.deadline or 600.0)))
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
     sipx.set_default_device(local_rank)
     TF = np.float32 if args.dtype == "f32" else np.float64
     w = np.dtype(TF).itemsize
@@ -715,7 +728,7 @@ def main():
             except Exception:
                 searches = None
         if world > 1:
-            tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
+            tt = torch.tensor([dt], dtype=torch.float64, device=red_dev)
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
             dt = float(tt.item())
         log = ctx.parsdmm_log()
@@ -781,7 +794,7 @@ def main():
                 xs, _, _ = ctx.download(want_ly=False)
                 bits = xs.view(np.uint32 if xs.dtype == np.float32 else np.uint64)
                 chk = float(int(bits.astype(np.uint64).sum() % (1 << 52)))
-                tt = torch.tensor([chk, -chk], dtype=torch.float64, device="cuda")
+                tt = torch.tensor([chk, -chk], dtype=torch.float64, device=red_dev)
                 dist.all_reduce(tt, op=dist.ReduceOp.MAX)
                 agree = bool(float(tt[0].item()) == -float(tt[1].item())) and bool(np.isfinite(xs).all())
             except Exception as e:                                  # (diagnostics only)
@@ -885,6 +898,9 @@ def main():
     }
     if r.get("rank_route"):
         out["rank_route"] = r["rank_route"]
+    if share_gpu:
+        out["invalid_as_measurement"] = True
+        out["rehearsal"] = f"SIPX_BENCH_SHARE_GPU: {world} ranks share GPU 0, the engine's collectives over gloo callbacks -- a rehearsal of the N > 1 flow, not a measurement"
     if both is not None:
         out["decompositions"] = both
         out["faster_decomposition"] = max(both, key=lambda k: both[k].get("value", 0.0))
@@ -909,7 +925,7 @@ def main():
             out[key] = r5m
     if dist is not None and (world > 1 or force_dist):
         progress("comm probe")
-        out["comm_probe_us"] = safe("comm probe", lambda: comm_probe(dist, torch, world, rank))
+        out["comm_probe_us"] = safe("comm probe", lambda: comm_probe(dist, torch, world, rank, dev=torch.device("cpu") if share_gpu else None))
     if rank == 0 and world == 1 and not args.no_cpu_baseline and args.dtype == "f32":
         progress("cpu baseline")
         out["cpu_baseline"] = cpu_baseline(args.config, n, h, kinds)

@@ -574,3 +574,32 @@ def test_set_streams_or_one_stream_is_bit_identical(sipx, monkeypatch, n, h, kin
         for a, b in zip(y0 + l0, y1 + l1):
             assert np.array_equal(a, b), tag
         assert np.array_equal(g0.rho, g1.rho) and np.array_equal(g0.gamma, g1.gamma) and np.array_equal(g0.cg_it, g1.cg_it)
+
+
+@pytest.mark.timeout(400)
+def test_bench_two_ranks_share_the_gpu():
+    """The N > 1 flow of bench.py with the REAL engine, rehearsed on a one-GPU box (`SIPX_BENCH_SHARE_GPU=1 python bench.py --gpus 2`:
+    the script spawns its two ranks, both run on device 0, the engine's collectives go through gloo callbacks): every world > 1
+    branch of the script runs -- rendezvous, both decompositions under fixed keys, max-over-ranks timing, what the communicator
+    reports, the ranks comparing their x, a 512^3 leg, the comm probe -- and rank 0 prints ONE line, marked as not a measurement."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, SIPX_BENCH_SHARE_GPU="1")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "2", "--no-c4", "--no-c5"],
+                       capture_output=True, text=True, timeout=380, env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.strip().splitlines() if ln.strip()]
+    assert len(lines) == 1, r.stdout[:2000]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 4 and d["value"] > 0 and d["invalid_as_measurement"] is True and "rehearsal" in d
+    assert set(d["decompositions"]) == {"slab", "sets"} and d["decomposition"] == "slab" and d["value"] == d["decompositions"]["slab"]["value"]
+    for v in list(d["decompositions"].values()) + [d["c3_512"]]:
+        assert "error" not in v, v
+        assert v["value"] > 0 and v["comm"]["rccl_nranks"] == 2 and v["comm"]["ranks_agree_on_x"] is True
+    assert d["c3_512"]["comm"]["decomposition"] == "slab" and d["config"]["all_logs_finite"]
+    assert isinstance(d["comm_probe_us"], dict) and "error" not in d["comm_probe_us"]
