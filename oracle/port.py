@@ -27,6 +27,9 @@ def run(n, h, sets, m, maxit, evol_rel_tol=1e-3, feas_tol=5e-2, obj_tol=1e-3, rh
     set_feasibility, evol_x, loop_seconds)."""
     TF = m.dtype.type
     lib = _lib(TF)
+    # never the OpenMP default: a GPU box shows every hardware thread of its host behind a CPU quota of 16, and a team that large
+    # spinning at every barrier of a small problem does not finish
+    nthreads = int(nthreads) or host_threads()
     pp, p = len(sets), len(sets) + 1
     nd = len(n)
     na = (C.c_int64 * 3)(*(list(n) + [1] * (3 - nd)))

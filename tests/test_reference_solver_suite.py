@@ -137,6 +137,45 @@ def test_oracle_parallel_suite_TV_leg():
     _parallel_suite_serial_leg(O, "TV")
 
 
+# ---- the second, independent restatement (oracle/parsdmm_port.c, C / OpenMP): EVERY block, the fixed-rho ones included ------------
+def _port_three_set_block(block):
+    from oracle import port
+    TF = np.float64
+    x = _draw(TF, N2)
+    g = O.compgrid((1.0, 1.0), N2)
+    c = _three_sets(O, x, g, TF)
+    o = O.PARSDMM_options(FL=TF, **BLOCKS[block])
+    O.convert_options(o, TF)
+    r = port.run(N2, (1.0, 1.0), [(k.set_type, k.TD_OP, k.min, k.max) for k in c], x, int(o.maxit), float(o.evol_rel_tol), float(o.feas_tol),
+                 float(o.obj_tol), rho_ini=float(np.atleast_1d(o.rho_ini)[0]), gamma_ini=float(o.gamma_ini), freq=int(o.rho_update_frequency),
+                 adjust_rho=bool(o.adjust_rho), adjust_gamma=bool(o.adjust_gamma), adjust_feasibility_rho=bool(o.adjust_feasibility_rho),
+                 nthreads=min(8, port.host_threads()))      # (never the OpenMP default: a GPU box shows every hardware thread of the host behind a quota of 16)
+    P, A, prop = O.setup_constraints(c, g, TF)
+    _assert_feasible(r["x"], P, A, 1.5, o.feas_tol)
+    return r
+
+
+_PORT_ITERATIONS = {}
+
+
+@pytest.mark.parametrize("block", list(BLOCKS))
+def test_port_three_sets_feasible(block):
+    r = _port_three_set_block(block)
+    _PORT_ITERATIONS[block] = r["n_iter"]
+    if not BLOCKS[block].get("adjust_rho", True):
+        assert r["n_iter"] == BLOCKS[block]["maxit"]        # a fixed rho uses all its iterations (why the reference gives it 10000 / 25000)
+
+
+def test_oracle_and_port_take_the_same_number_of_iterations():
+    """Two restatements written apart from each other (numpy; C with the reference's loop structure) stop at the same iteration."""
+    for block in ("default_79", "no_gamma_124"):
+        x = _draw(np.float64, N2)
+        g = O.compgrid((1.0, 1.0), N2)
+        xo, log, P, A, opt = _solve(O, _three_sets(O, x, g, np.float64), g, np.float64, x, BLOCKS[block])
+        n_port = _PORT_ITERATIONS.get(block) or _port_three_set_block(block)["n_iter"]
+        assert len(log.obj) == n_port, (block, len(log.obj), n_port)
+
+
 # ---- the HIP engine (GPU suite): every block, and the engine against the oracle on the blocks the oracle ran ---------------
 @pytest.mark.gpu
 def test_engine_feasible_input_untouched(sipx):
@@ -147,6 +186,12 @@ def test_engine_feasible_input_untouched(sipx):
 @pytest.mark.parametrize("block", list(BLOCKS))
 def test_engine_three_sets_feasible(sipx, block):
     xs = _three_set_block(sipx, block)
+    # the C restatement on the same block: same end point (both are feasible to the block's tolerance on a problem with one solution)
+    # (the two fixed-rho blocks take the port a minute: they are run by the CPU suite only)
+    if BLOCKS[block].get("adjust_rho", True):
+        rp = _port_three_set_block(block)
+        tol = 1e-9 if float(BLOCKS[block].get("feas_tol", 5e-2)) <= 1e-12 else 5e-4
+        assert np.linalg.norm(xs - rp["x"]) / np.linalg.norm(rp["x"]) <= tol, (block, np.linalg.norm(xs - rp["x"]) / np.linalg.norm(rp["x"]))
     if block == "accurate_92":
         # both have converged to 1e-12 feasibility on the same problem: the projection is unique, so the two end points agree far
         # inside the reference's Float64 comparison tolerances (1e-9 against a closed form, test_PARSDMM.jl:242)
