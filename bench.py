@@ -210,6 +210,125 @@ def dominant_kernel(per_kernel):
     return dom, [r for r in rows if r["share_of_kernel_time"] >= 0.01]
 
 
+LINE_LIMIT = 4096        # the driver keeps a few KB of stdout tail: the ONE line must fit with room to spare (round 3's grew to 24 KB and was cut)
+
+
+def _sig(v, sig=5):
+    """Numbers of the headline line carry five significant digits: enough for every figure it quotes, and a third of the bytes."""
+    if isinstance(v, bool) or v is None:
+        return v
+    if isinstance(v, float):
+        if v != v or v in (float("inf"), float("-inf")):
+            return None
+        return float(f"{v:.{sig}g}")
+    if isinstance(v, dict):
+        return {k: _sig(x, sig) for k, x in v.items()}
+    if isinstance(v, (list, tuple)):
+        return [_sig(x, sig) for x in v]
+    return v
+
+
+def _pick(d, keys):
+    return {k: d[k] for k in keys if isinstance(d, dict) and k in d}
+
+
+def headline(out, detail_path=None):
+    """The ONE stdout line: the contract's keys plus the handful of figures a review reads first; everything else (kernel tables,
+    timing buckets, definitions, search counters, per-level C5 detail, comm probe names) lives in the detail file written beside it.
+    Mirrors what the reference's own measurement is -- one wall clock per call (examples/test_scaling_3D.jl:116-117)."""
+    ROOF = ("kernel", "bound", "peak", "achieved", "unit", "frac", "frac_survey", "traffic", "frac_traffic", "launches", "avg_launch_ms",
+            "algorithmic_bytes_per_launch")
+    DOM = ("kernel", "bound", "frac", "launches", "avg_launch_ms", "algorithmic_bytes_per_launch", "share_of_kernel_time")
+    COMM = ("rccl_nranks", "rccl_version", "decomposition", "ranks_agree_on_x", "device_bytes_per_rank")
+    h = _pick(out, ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+                    "dtype", "data"))
+    h["config"] = _pick(out.get("config"), ("workload", "grid", "parallelism", "cg_iterations_in_timed_steps", "all_logs_finite"))
+    if isinstance(h["config"].get("parallelism"), str):
+        h["config"]["parallelism"] = h["config"]["parallelism"][:60]
+    if out.get("roofline") is not None:
+        h["roofline"] = _pick(out["roofline"], ROOF)
+        h["roofline"]["kernel"] = str(h["roofline"].get("kernel", "")).split(" (")[0]
+    else:
+        h["roofline"] = None
+    if out.get("dominant_kernel"):
+        h["dominant_kernel"] = _pick(out["dominant_kernel"], DOM)
+    if out.get("iteration_roofline"):
+        h["iteration_roofline"] = _pick(out["iteration_roofline"], ("frac", "bytes_moved_per_step", "frac_survey"))
+    if out.get("cpu_baseline"):
+        h["cpu_baseline"] = _pick(out["cpu_baseline"], ("value", "unit", "cores", "kind", "sample"))
+        if isinstance(h["cpu_baseline"].get("sample"), str):
+            h["cpu_baseline"]["sample"] = h["cpu_baseline"]["sample"][:160]
+    for key in ("c3_512", "c4_512"):
+        v = out.get(key)
+        if not isinstance(v, dict):
+            continue
+        if "error" in v:
+            h[key] = {"error": str(v["error"])[:160]}
+            continue
+        o = _pick(v, ("value", "ms_per_step", "steps", "warmup"))
+        if v.get("roofline"):
+            o["roofline"] = _pick(v["roofline"], ("frac", "frac_survey", "avg_launch_ms"))
+        if v.get("dominant_kernel"):
+            o["dominant_kernel"] = _pick(v["dominant_kernel"], ("kernel", "frac", "avg_launch_ms", "share_of_kernel_time"))
+        if v.get("iteration_roofline"):
+            o["iteration_roofline"] = _pick(v["iteration_roofline"], ("frac",))
+        if v.get("rank_route"):
+            o["rank_route"] = _pick(v["rank_route"], ("calls", "warm_started_subspace", "full_decomposition"))
+        if out.get("n_gpus", 1) > 1 and v.get("comm"):
+            o["comm"] = _pick(v["comm"], ("decomposition", "ranks_agree_on_x"))
+        h[key] = o
+    for key in ("c5", "c5_layered"):
+        v = out.get(key)
+        if isinstance(v, dict):
+            h[key] = ({"error": str(v["error"])[:160]} if "error" in v else
+                      _pick(v, ("whole_solve_s", "solve_only_s", "iterations_per_level", "finest_level_it_per_s", "finest_iterations_saved", "finite")))
+    if out.get("comm"):
+        h["comm"] = _pick(out["comm"], COMM)
+    if out.get("decompositions"):
+        h["decompositions"] = {k: ({"error": str(v["error"])[:120]} if "error" in v else
+                                   dict(_pick(v, ("value", "ms_per_step")), ranks_agree_on_x=(v.get("comm") or {}).get("ranks_agree_on_x")))
+                               for k, v in out["decompositions"].items()}
+        h["decomposition"] = out.get("decomposition")
+        h["faster_decomposition"] = out.get("faster_decomposition")
+    if isinstance(out.get("comm_probe_us"), dict):        # medians only, short keys (the descriptions are in the detail file)
+        h["comm_probe_us"] = {k.split(" ")[0]: v for k, v in out["comm_probe_us"].items() if isinstance(v, (int, float))}
+    for k in ("dry_comm", "invalid_as_measurement", "libsipx_sha16"):
+        if k in out:
+            h[k] = out[k]
+    if detail_path:
+        h["detail"] = os.path.basename(detail_path)
+    line = json.dumps(_sig(h), separators=(",", ":"))
+    if len(line) >= LINE_LIMIT:                           # never again a line the driver cannot parse: shed the optional objects
+        for k in ("comm_probe_us", "c5_layered", "iteration_roofline", "decompositions", "c4_512", "c5", "c3_512", "dominant_kernel"):
+            h.pop(k, None)
+            line = json.dumps(_sig(h), separators=(",", ":"))
+            if len(line) < LINE_LIMIT:
+                break
+    return line
+
+
+def emit(out, detail_path):
+    """Detail to the side file (and a copy under gpurun_out/ when that directory exists, so that it travels back from a GPU box)
+    and to stderr; the compact headline LAST and alone on stdout."""
+    paths = [detail_path] if detail_path else []
+    scratch = os.path.join(ROOT, "gpurun_out")
+    if detail_path and os.path.isdir(scratch) and os.path.dirname(os.path.abspath(detail_path)) != scratch:
+        paths.append(os.path.join(scratch, os.path.basename(detail_path)))
+    written = None
+    for p in paths:
+        try:
+            with open(p, "w") as f:
+                json.dump(out, f)
+            written = written or p
+        except OSError as e:                              # a read-only tree must not take the headline with it
+            print(f"bench: could not write {p}: {e}", file=sys.stderr)
+    print("bench detail: " + json.dumps(out), file=sys.stderr, flush=True)
+    line = headline(out, written)
+    assert len(line) < LINE_LIMIT, len(line)
+    print(line)
+    sys.stdout.flush()
+
+
 def bench_options(mod, TF, maxit):
     # tolerances at zero: the stop rules never fire, so exactly `steps` iterations are timed
     return mod.PARSDMM_options(FL=TF, maxit=maxit, evol_rel_tol=0.0, feas_tol=0.0, obj_tol=0.0)
@@ -542,8 +661,7 @@ def dry_comm(args):
            "roofline": None, "decomposition": "slab", "decompositions": res,
            "faster_decomposition": max(res, key=lambda k: res[k]["value"]), "comm": res["slab"]["comm"], "comm_probe_us": probe}
     if rank == 0:
-        print(json.dumps(out))
-        sys.stdout.flush()
+        emit(out, args.detail)
     progress("done")
     WATCHDOG.cancel()
     dist.destroy_process_group()
@@ -571,6 +689,8 @@ def main():
                     help="cds = the reference's banded Q (the contract workload); stencil = generated coefficients (SURVEY 8f-2)")
     ap.add_argument("--deadline", type=float, default=float(os.environ.get("SIPX_BENCH_DEADLINE_S", "560")),
                     help="seconds after which a rank that has not finished prints its last progress mark and exits with code 3 (0 = never)")
+    ap.add_argument("--detail", default=os.path.join(ROOT, "bench_detail.json"),
+                    help="file for everything that is not the headline: kernel tables, timing buckets, definitions, counters ('' = none)")
     ap.add_argument("--dry-comm", action="store_true",
                     help="rehearsal of the N > 1 flow WITHOUT the engine: launcher, rendezvous, stdout contract, both decompositions and the "
                          "comm probe, each step being the collective skeleton of one PARSDMM iteration (DESIGN 5) on dummy buffers; "
@@ -719,12 +839,13 @@ def main():
                                    "all-kernel statistics window / wall time of that window (the event records of the window cost "
                                    "a few percent) / peak: the bandwidth the iteration as BUILT sustains"}
         comm_info = ctx.comm_info()
+        dev_bytes = ctx.device_bytes()
         # slab-decomposed: threshold searches that went through the speculative exchange since the context was built, how many of
         # them needed their fallback, and the all-reduces (refinement rounds) those took -- the engine's own counters
         searches = per_kernel.get("slab_searches") if per_kernel else None
         if searches is None and dist is not None:
             try:
-                searches = ctx.kernel_stats_all(0).get("slab_searches")
+                searches = ctx.kernel_stats_all(-1).get("slab_searches")
             except Exception:
                 searches = None
         if world > 1:
@@ -807,7 +928,9 @@ def main():
             "comm": {"rccl_nranks": comm_info["nranks"], "rccl_rank": comm_info["rank"], "rccl_version": comm_info["version"],
                      "decomposition": comm_info["decomposition"] if dist is not None else None,
                      "slab_searches": searches if (dist is not None and slab) else None,
-                     "ranks_agree_on_x": agree},
+                     "ranks_agree_on_x": agree,
+                     # what this context allocated on its GPU (slab-decomposed: the rank's planes + halo planes only)
+                     "device_bytes_per_rank": dev_bytes["context"], "device_used_bytes": dev_bytes["device_used"]},
             "dominant_kernel": dominant, "kernels": table,
             # a slice-rank set in the list: which route its projector took since the context was built (engine counters: calls,
             # calls served by the warm-started filtered subspace iteration, full decompositions, products with the Gram matrices)
@@ -931,8 +1054,7 @@ def main():
         out["cpu_baseline"] = cpu_baseline(args.config, n, h, kinds)
     restore_stdout()
     if rank == 0:
-        print(json.dumps(out))
-        sys.stdout.flush()
+        emit(out, args.detail)
     progress("done")
     WATCHDOG.cancel()
     if dist is not None:

@@ -294,6 +294,11 @@ int sipx_set_comm(sipx_ctx* ctx, const sipx_comm* comm);
  * 2.x.y" from ncclGetVersion, "callbacks (sipx_set_comm)", "none" without a communicator; version_len bytes incl. the
  * terminator), and the decomposition in force (SIPX_DECOMP_*).  So that "did RCCL see N ranks" can be answered from a log. */
 int sipx_comm_info(sipx_ctx* ctx, int* nranks, int* rank, char* version, int version_len, int* decomposition);
+/* Device memory: bytes this context has allocated (its own arrays and the buffers of its library-backed projectors; library
+ * workspaces are not seen), and what the runtime reports for the whole device (used, total).  A slab-decomposed rank holds its
+ * planes only (plus halo planes), so context_bytes falls with the number of ranks -- the figure the bench line carries as
+ * comm.device_bytes_per_rank.  (No reference counterpart: Julia's GC owns the reference's arrays.) */
+int sipx_device_bytes(sipx_ctx* ctx, int64_t* context_bytes, int64_t* device_used, int64_t* device_total);
 /* this rank's slab of the x-step: rows [row0, row1) of Q / entries of x, and the elements per rank (chunk) of the padded
  * exchange buffers; without a communicator row0 = 0, row1 = chunk = N */
 int sipx_slab(sipx_ctx* ctx, int64_t* row0, int64_t* row1, int64_t* chunk);

@@ -142,6 +142,9 @@ int sipx_set_comm(sipx_ctx* c, const sipx_comm* comm) {
 int sipx_comm_info(sipx_ctx* c, int* nranks, int* rank, char* version, int version_len, int* decomposition) {
   SIPX_TRY(c->e->comm_info(nranks, rank, version, version_len, decomposition))
 }
+int sipx_device_bytes(sipx_ctx* c, int64_t* context_bytes, int64_t* device_used, int64_t* device_total) {
+  SIPX_TRY(c->e->device_bytes(context_bytes, device_used, device_total))
+}
 int sipx_slab(sipx_ctx* c, int64_t* row0, int64_t* row1, int64_t* chunk) { SIPX_TRY(c->e->slab(row0, row1, chunk)) }
 int sipx_set_q_mode(sipx_ctx* c, int mode) { SIPX_TRY(c->e->set_q_mode(mode)) }
 int sipx_set_decomp(sipx_ctx* c, int mode) { SIPX_TRY(c->e->set_decomp(mode)) }

@@ -85,6 +85,15 @@ class RcclComm : public Comm {
     ncclUniqueId uid;
     std::memcpy(&uid, id, sizeof(uid));
     nccl_check(rccl().CommInitRank(&comm_, world, uid, rank), "ncclCommInitRank");
+    // Whether an all-reduce and send/recv pairs travel in ONE ncclGroup is decided HERE, once, from facts every rank shares --
+    // the library's version (collectives and point-to-point calls may share a group from NCCL 2.8 on; RCCL follows NCCL's
+    // numbering) and SIPX_COMM_GROUP -- never from the outcome of a call inside a solve: a failed group leaves the
+    // communicator in an error state, part of it may have been launched, and a rank without neighbours would not even see the
+    // failure.  Any RCCL error during a solve is fatal (nccl_check).
+    int v = 0;
+    if (rccl().GetVersion) (void)rccl().GetVersion(&v);
+    const char* e = std::getenv("SIPX_COMM_GROUP");
+    grouped_ = v >= 20800 && !(e && e[0] == '0');
   }
   ~RcclComm() override {
     if (comm_) (void)rccl().CommDestroy(comm_);
@@ -139,38 +148,22 @@ class RcclComm : public Comm {
   // launch where the channels allow); SIPX_COMM_GROUP=0 issues them one after the other
   void allreduce_with_halo(void* buf, size_t count, int red_dtype, const void* send_prev, void* recv_prev, int prev,
                            const void* send_next, void* recv_next, int next, size_t hcount, int hdtype, hipStream_t s) override {
-    static const bool allowed = [] { const char* e = std::getenv("SIPX_COMM_GROUP"); return !(e && e[0] == '0'); }();
-    // Whether the group is used has to be the same on every rank (a rank without neighbours -- an empty slab -- still takes part in
-    // the all-reduce): it depends on the world size and on what RCCL answered to the FIRST grouped call only, which every
-    // rank makes with the same arguments kinds.
-    if (!allowed || !grouped_ || world == 1) {
+    if (!grouped_ || world == 1) {
       Comm::allreduce_with_halo(buf, count, red_dtype, send_prev, recv_prev, prev, send_next, recv_next, next, hcount, hdtype, s);
       return;
     }
     const RcclApi& a = rccl();
-    ncclResult_t r = a.GroupStart();
-    if (r == ncclSuccess) r = a.AllReduce(buf, buf, count, nccl_type(red_dtype), ncclSum, comm_, s);
-    if (r == ncclSuccess && prev >= 0) {
-      r = a.Send(send_prev, hcount, nccl_type(hdtype), prev, comm_, s);
-      if (r == ncclSuccess) r = a.Recv(recv_prev, hcount, nccl_type(hdtype), prev, comm_, s);
+    nccl_check(a.GroupStart(), "ncclGroupStart");
+    nccl_check(a.AllReduce(buf, buf, count, nccl_type(red_dtype), ncclSum, comm_, s), "ncclAllReduce (grouped)");
+    if (prev >= 0) {
+      nccl_check(a.Send(send_prev, hcount, nccl_type(hdtype), prev, comm_, s), "ncclSend (grouped)");
+      nccl_check(a.Recv(recv_prev, hcount, nccl_type(hdtype), prev, comm_, s), "ncclRecv (grouped)");
     }
-    if (r == ncclSuccess && next >= 0) {
-      r = a.Send(send_next, hcount, nccl_type(hdtype), next, comm_, s);
-      if (r == ncclSuccess) r = a.Recv(recv_next, hcount, nccl_type(hdtype), next, comm_, s);
+    if (next >= 0) {
+      nccl_check(a.Send(send_next, hcount, nccl_type(hdtype), next, comm_, s), "ncclSend (grouped)");
+      nccl_check(a.Recv(recv_next, hcount, nccl_type(hdtype), next, comm_, s), "ncclRecv (grouped)");
     }
-    const ncclResult_t e = a.GroupEnd();
-    if (r == ncclSuccess) r = e;
-    if (r == ncclSuccess) return;
-    if (r == ncclInvalidUsage || r == ncclInvalidArgument) {
-      // this RCCL does not take a collective and point-to-point transfers in one group: nothing of the group was enqueued --
-      // from here on one call after the other (every rank gets the same answer to the same call, so all of them switch together)
-      grouped_ = false;
-      std::fprintf(stderr, "libsipx: RCCL refused an all-reduce and send/recv in one group (%s); issuing them separately\n",
-                   a.GetErrorString ? a.GetErrorString(r) : "?");
-      Comm::allreduce_with_halo(buf, count, red_dtype, send_prev, recv_prev, prev, send_next, recv_next, next, hcount, hdtype, s);
-      return;
-    }
-    nccl_check(r, "grouped all-reduce + send/recv");
+    nccl_check(a.GroupEnd(), "ncclGroupEnd (all-reduce + send/recv in one group; SIPX_COMM_GROUP=0 issues them separately)");
   }
   // one group of point-to-point transfers: the root talks to its seven peers over seven links at once
   void scatter(void* buf, size_t chunk, int dtype, int root, hipStream_t s) override { fan(buf, chunk, dtype, root, s, true); }
@@ -196,7 +189,7 @@ class RcclComm : public Comm {
     nccl_check(a.GroupEnd(), "ncclGroupEnd");
   }
   ncclComm_t comm_ = nullptr;
-  bool grouped_ = true;       // all-reduce + neighbour exchange in one ncclGroup (until RCCL refuses one)
+  bool grouped_ = true;       // all-reduce + neighbour exchange in one ncclGroup: fixed at construction, the same on every rank
 };
 
 class CallbackComm : public Comm {

@@ -21,6 +21,31 @@ const LaunchObserver*& launch_observer() {
 }
 
 namespace {
+EnvKnobs g_env_knobs;
+}
+const EnvKnobs& env_knobs() { return g_env_knobs; }
+void refresh_env_knobs() {
+  auto num = [](const char* name, long long dflt) { const char* e = std::getenv(name); return e ? std::atoll(e) : dflt; };
+  EnvKnobs k;
+  k.cds_march = (int)num("SIPX_CDS_MARCH", 1);
+  k.cds_march_zchunk = num("SIPX_CDS_MARCH_ZCHUNK", 0);
+  k.multi_zchunk = num("SIPX_MULTI_ZCHUNK", 0);
+  k.rhs_march = (int)num("SIPX_RHS_MARCH", 1);
+  k.rhs_march_zchunk = num("SIPX_RHS_MARCH_ZCHUNK", 0);
+  g_env_knobs = k;
+}
+long long*& alloc_tally() {
+  static thread_local long long* t = nullptr;
+  return t;
+}
+
+namespace {
+
+struct TallyGuard {
+  long long* prev;
+  explicit TallyGuard(long long* t) : prev(alloc_tally()) { alloc_tally() = t; }
+  ~TallyGuard() { alloc_tally() = prev; }
+};
 
 // installs a context's observer for the duration of one entry point (the launchers consult it through launch_observer())
 struct ObserverGuard {
@@ -36,6 +61,7 @@ T* dalloc(size_t n, bool zero = true) {
   T* p = nullptr;
   if (n == 0) return p;
   SIPX_HIP(hipMalloc(&p, n * sizeof(T)));
+  if (long long* t = alloc_tally()) *t += (long long)(n * sizeof(T));
   if (zero) {
     // hipMemset is queued on the NULL stream; the engine stream is non-blocking, so wait here or the
     // zero-fill may land after kernels of the engine stream have already written the buffer.
@@ -277,6 +303,14 @@ class Engine : public EngineBase {
     else if (version && version_len > 0) std::snprintf(version, (size_t)version_len, "none");
   }
   void bind_device() override { SIPX_HIP(hipSetDevice(device_)); }
+  void device_bytes(int64_t* context_bytes, int64_t* device_used, int64_t* device_total) override {
+    SIPX_HIP(hipSetDevice(device_));
+    size_t fr = 0, tot = 0;
+    SIPX_HIP(hipMemGetInfo(&fr, &tot));
+    if (context_bytes) *context_bytes = dev_bytes_;
+    if (device_used) *device_used = (int64_t)(tot - fr);
+    if (device_total) *device_total = (int64_t)tot;
+  }
   void slab(int64_t* row0, int64_t* row1, int64_t* chunk) override {
     need_final();
     if (row0) *row0 = r0_;
@@ -296,6 +330,8 @@ class Engine : public EngineBase {
                 double* feasibility_initial) override {
     if (finalized_) throw std::runtime_error("sipx_finalize called twice");
     SIPX_HIP(hipSetDevice(device_));
+    refresh_env_knobs();                  // the launchers' A/B switches: read once per context, not per launch
+    TallyGuard tally(&dev_bytes_);
     pp_n_ = (int)sets_.size();
     feasibility_only_ = feasibility_only != 0;
     if (!feasibility_only_) {             // PARSDMM_precompute_distribute.jl:17-26: identity operator for 1/2||x-m||^2
@@ -765,7 +801,7 @@ class Engine : public EngineBase {
     // as both r and p and writes r_1 into the r buffer, so the copy p <- r is never made
     bool done = false;
     if (q_pending_ && !stencil_q_ && !comm_ && r0 == 0 && r1 == Nx_) {
-      if (!Q2_) Q2_ = dalloc<T>((size_t)Nx_ * cds_.d);
+      if (!Q2_) { TallyGuard tally(&dev_bytes_); Q2_ = dalloc<T>((size_t)Nx_ * cds_.d); }
       done = K<T>::resid_qupdate(stream_, G_, Nx_, Q_, Q2_, cds_, q_pending_args_, x_, rhs_, p_, (T*)nullptr, xold_, part_cg_);
       if (done) { std::swap(Q_, Q2_); q_pending_ = false; }
     }
@@ -1461,6 +1497,7 @@ class Engine : public EngineBase {
       SetArgs<T> a = set_args(s, (T)rho[i], (T)gamma[i], flags);
       target[i] = (!first && !bb && s.snap == 1) ? 2 : 0;
       if (target[i] == 2 && !s.y2) {
+        TallyGuard tally(&dev_bytes_);
         T* by = dalloc<T>(s.Mpad + halo_);
         T* bl = dalloc<T>(s.Mpad + halo_);
         s.halo_allocs.push_back(by);
@@ -1863,7 +1900,12 @@ class Engine : public EngineBase {
         mark(1);
         R.rhs_ready = true;
       }
-      if (R.rhs_ready && resid_ahead_) {     // ... and so is the residual product of the coming x-step
+      // (the product overwrites x_old: it may only be queued ahead when obj / evol_x of THIS iteration come out of the y/l
+      //  update itself -- the distance term's sums, or the slab sums of a sharded x-step.  A feasibility-only context has
+      //  neither: log_scalars reads x_old after this point, so there the product waits)
+      bool log_sums_from_update = comm_ != nullptr;
+      for (const auto& st : sets_) log_sums_from_update |= st.is_dist && st.owned;
+      if (R.rhs_ready && resid_ahead_ && log_sums_from_update) {     // ... and so is the residual product of the coming x-step
         argmin_x_head();
         if (comm_) {                         // (sharded: the sums arrive with the grouped call of the head)
           mark(2);
@@ -2126,9 +2168,11 @@ class Engine : public EngineBase {
     if (total_ms) *total_ms = a.ms;
     start_stats(enable);
   }
+  // enable = -1: the counters only (slab_searches, rank_route) -- no synchronisation, the collection and its samples stay as they are
   const char* kernel_stats_json(int enable) override {
     need_final();
-    std::vector<KAgg> agg = aggregate_samples();
+    const bool peek = enable < 0;
+    std::vector<KAgg> agg = peek ? std::vector<KAgg>(KID_COUNT) : aggregate_samples();
     std::string& o = stats_json_;
     o = "{\"mode\": " + std::to_string(stats_mode_) + ", \"event_pair_overhead_ms\": " + std::to_string(stat_pair_ms_) + ", \"kernels\": [";
     bool first = true;
@@ -2159,7 +2203,7 @@ class Engine : public EngineBase {
     }
     o += ", \"rank_route\": {\"calls\": " + std::to_string(rc[0]) + ", \"warm_started_subspace\": " + std::to_string(rc[1]) +
          ", \"full_decomposition\": " + std::to_string(rc[2]) + ", \"products_with_gram\": " + std::to_string(rc[3]) + "}}";
-    start_stats(enable);
+    if (!peek) start_stats(enable);
     return o.c_str();
   }
   double stat_pair_overhead_ms() const { return stat_pair_ms_; }
@@ -2927,6 +2971,7 @@ class Engine : public EngineBase {
   bool q_fused_ = false, q_pending_ = false, q_defer_ = false;
   QArgs<T> q_pending_args_;
   T* Q2_ = nullptr;
+  long long dev_bytes_ = 0;           // device bytes this context allocated (dalloc + the library-backed projectors' own buffers)
   bool slab_dist_logs_ = false;       // slab-decomposed and a distance term among the sets: obj / evol_x sums come from its y/l update
   bool lean_multi_ = false;           // k_lean_multi for the lean first passes of the l1 searches (finalize: above 2^24 grid points; SIPX_LEAN_MULTI=0/1)
   bool head_done_ = false;            // the residual product of the coming x-step is queued already (argmin_x_head)

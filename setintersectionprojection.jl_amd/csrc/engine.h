@@ -50,6 +50,7 @@ struct EngineBase {
   virtual void set_comm(Comm* c) = 0;       // takes ownership
   virtual void comm_info(int* nranks, int* rank, char* version, int version_len, int* decomposition) = 0;
   virtual void bind_device() = 0;           // makes the context's GPU the calling thread's current device
+  virtual void device_bytes(int64_t* context_bytes, int64_t* device_used, int64_t* device_total) = 0;
   virtual void slab(int64_t* row0, int64_t* row1, int64_t* chunk) = 0;
 };
 

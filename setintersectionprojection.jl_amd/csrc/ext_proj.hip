@@ -881,6 +881,7 @@ struct ExtImpl {
   Q* alloc(size_t count) {
     void* p = nullptr;
     SIPX_HIP(hipMalloc(&p, sizeof(Q) * (count ? count : 1)));
+    if (long long* t = alloc_tally()) *t += (long long)(sizeof(Q) * (count ? count : 1));
     owned.push_back(p);
     return (Q*)p;
   }

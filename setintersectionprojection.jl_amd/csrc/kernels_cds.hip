@@ -411,12 +411,9 @@ static bool try_march(hipStream_t s, long long N, long long r0, long long r1, co
                       T* pout, T* xold, double* partials, const int* done, CgState<T>* st = nullptr, CgState<T>* host = nullptr,
                       unsigned long long* ticket = nullptr, const QUpd<T>* upd = nullptr) {
   // SIPX_CDS_MARCH=0: never; =2: also on grids too small to fill the chip that way, in chunks of SIPX_CDS_MARCH_ZCHUNK planes (tests)
-  // (read at every launch, not cached: one cached copy per template instantiation, taken at each one's first launch, let a test
-  //  that sets the switch later force the march for some forms of the product and not for others)
-  const char* e_sw = getenv("SIPX_CDS_MARCH");
-  const char* e_zc = getenv("SIPX_CDS_MARCH_ZCHUNK");
-  const int sw = e_sw ? atoi(e_sw) : 1;
-  const long long zc_env = e_zc ? atoll(e_zc) : 0ll;
+  // (one copy for all instantiations, refreshed whenever a context is finalised: env_knobs)
+  const int sw = env_knobs().cds_march;
+  const long long zc_env = env_knobs().cds_march_zchunk;
   if (sw == 0 || !a.march || !a.sym || a.d != 7) return false;
   constexpr int V = sizeof(T) == 8 ? 2 : 4;
   const long long n1 = a.gn[0], n2 = a.gn[1], n3 = a.gn[2], st2 = n1 * n2;

@@ -567,8 +567,7 @@ static void launch_multi(hipStream_t s, const Grid& g, const MultiArgs<T>& a, do
   // chunks of planes: enough work items to fill the chip several times over, chunks long enough that the plane recomputed in
   // front of each stays a small share (<= 1 / 8 of one block's work)
   const long long planes = zhi - zlo;
-  const char* e_zc = getenv("SIPX_MULTI_ZCHUNK");             // (read per launch: a test may set it after the first launch of the process)
-  const long long zc_env = e_zc ? atoll(e_zc) : 0ll;
+  const long long zc_env = env_knobs().multi_zchunk;          // SIPX_MULTI_ZCHUNK, read when the context was finalised
   long long want = (4ll * NB_7 + tiles - 1) / tiles;          // chunks per tile column for ~4 items per workgroup slot
   if (want < 1) want = 1;
   long long zchunk = (planes + want - 1) / want;

@@ -209,8 +209,7 @@ __global__ __launch_bounds__(RM_NT) void k_rhs_march(Grid G, RhsMarchArgs<T> a, 
 // false: the march does not apply (2-D grid, too many blocks, a grid too small to fill the chip that way): k_rhs
 template <typename T>
 static bool try_rhs_march(hipStream_t s, const Grid& g, const RhsArgs<T>& a, T* rhs) {
-  const char* e_sw = getenv("SIPX_RHS_MARCH");          // 0: never; 2: also on small grids, chunks of SIPX_RHS_MARCH_ZCHUNK planes (tests)
-  const int sw = e_sw ? atoi(e_sw) : 1;
+  const int sw = env_knobs().rhs_march;                 // SIPX_RHS_MARCH 0: never; 2: also on small grids, chunks of SIPX_RHS_MARCH_ZCHUNK planes (tests)
   constexpr int V = sizeof(T) == 8 ? 2 : 4;
   const long long n1 = g.n[0], n2 = g.n[1], n3 = g.n[2], st2 = n1 * n2;
   if (sw == 0 || n3 < 2 || n1 % V != 0 || a.nsets < 1) return false;
@@ -241,8 +240,7 @@ static bool try_rhs_march(hipStream_t s, const Grid& g, const RhsArgs<T>& a, T* 
   const long long tiles = (long long)tiles_x * tiles_y, planes = (e1 - e0) / st2;
   long long zchunk = planes * tiles / 4096;
   if (zchunk < 16) zchunk = 16;
-  const char* e_zc = getenv("SIPX_RHS_MARCH_ZCHUNK");
-  if (sw == 2 && e_zc && atoll(e_zc) > 0) zchunk = atoll(e_zc);
+  if (sw == 2 && env_knobs().rhs_march_zchunk > 0) zchunk = env_knobs().rhs_march_zchunk;
   if (zchunk > planes) zchunk = planes;
   const long long nchunks = (planes + zchunk - 1) / zchunk, items = tiles * nchunks;
   // (up to 2^24 grid points y and l of the neighbouring planes are still in the Infinity Cache when k_rhs re-reads them: 256^3

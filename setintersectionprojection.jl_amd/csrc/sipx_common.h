@@ -79,6 +79,19 @@ struct LaunchObserver {
 };
 // the observer of the calling host thread (a context is driven by one thread at a time); nullptr: nothing is recorded
 const LaunchObserver*& launch_observer();
+// A/B switches of the launchers, read from the environment ONCE per context (sipx_finalize -> refresh_env_knobs) instead of by a
+// getenv at every launch: a test that sets a switch builds a new context afterwards.
+struct EnvKnobs {
+  int cds_march = 1;              // SIPX_CDS_MARCH: 0 never, 2 also on grids too small to fill the chip (tests)
+  long long cds_march_zchunk = 0; // SIPX_CDS_MARCH_ZCHUNK (with =2)
+  long long multi_zchunk = 0;     // SIPX_MULTI_ZCHUNK
+  int rhs_march = 1;              // SIPX_RHS_MARCH
+  long long rhs_march_zchunk = 0; // SIPX_RHS_MARCH_ZCHUNK
+};
+const EnvKnobs& env_knobs();
+void refresh_env_knobs();
+// device bytes allocated on behalf of the context the calling thread is building (nullptr: not counted)
+long long*& alloc_tally();
 struct ObsScope {
   const LaunchObserver* o;
   int kid;

@@ -34,7 +34,7 @@ EXPORTED_SYMBOLS = [
     "sipx_stream",
     "sipx_dev_rhs", "sipx_dev_x", "sipx_set_owned", "sipx_get_rhs", "sipx_prox_l2s",
     "sipx_rccl_unique_id", "sipx_set_comm_rccl", "sipx_set_comm", "sipx_slab", "sipx_warm_start_from", "sipx_set_decomp",
-    "sipx_kernel_stats_json", "sipx_comm_info",
+    "sipx_kernel_stats_json", "sipx_comm_info", "sipx_device_bytes",
 ]
 
 SIPX_F32, SIPX_F64 = 0, 1
@@ -787,12 +787,20 @@ class Context:
         return n.value, ms.value
 
     def kernel_stats_all(self, enable):
-        """Per-kernel statistics gathered since the last call, as a dict (sipx_kernel_stats_json); `enable` as above."""
+        """Per-kernel statistics gathered since the last call, as a dict (sipx_kernel_stats_json); `enable` as above.
+        enable = -1: the engine's counters only (`slab_searches`, `rank_route`) -- nothing is synchronised, a running
+        collection and its samples stay as they are."""
         import json
         txt = lib().sipx_kernel_stats_json(self.h, int(enable))
         if txt is None:
             raise SipxError(lib().sipx_last_error().decode())
         return json.loads(txt.decode())
+
+    def device_bytes(self):
+        """{"context": bytes this context allocated on its GPU, "device_used", "device_total": the runtime's figures} (sipx_device_bytes)."""
+        a, b, c = C.c_int64(), C.c_int64(), C.c_int64()
+        _chk(lib().sipx_device_bytes(self.h, C.byref(a), C.byref(b), C.byref(c)))
+        return {"context": a.value, "device_used": b.value, "device_total": c.value}
 
     def comm_info(self):
         """What the attached communicator reports: {"nranks", "rank", "version", "decomposition"} (sipx_comm_info)."""

@@ -388,7 +388,7 @@ def PARSDMM_sharded(m, AtA, TD_OP, set_Prop, P_sub, comp_grid, options, dist=Non
         else:
             log, feasible = ctx.parsdmm(options)
         try:        # slab-decomposed: how many threshold searches the speculative exchange settled (engine counters; diagnostics)
-            log.slab_searches = ctx.kernel_stats_all(0).get("slab_searches")
+            log.slab_searches = ctx.kernel_stats_all(-1).get("slab_searches")       # (-1: read-only, a caller's collection survives)
         except Exception:
             log.slab_searches = None
         if feasible:

@@ -1850,10 +1850,13 @@ def test_bench_line_reports_the_rank_projector_route():
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--config", "c4-256", "--steps", "5", "--warmup", "2",
+    import tempfile
+    detail = os.path.join(tempfile.mkdtemp(prefix="sipx_bench_"), "detail.json")
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--config", "c4-256", "--steps", "5", "--warmup", "2", "--detail", detail,
                         "--no-cpu-baseline", "--no-512", "--no-c4", "--no-c5"], capture_output=True, text=True, timeout=280, env=dict(os.environ))
     assert r.returncode == 0, r.stderr[-2000:]
-    d = json.loads([ln for ln in r.stdout.strip().splitlines() if ln.strip()][-1])
+    assert len(r.stdout.strip()) < 4096
+    d = json.load(open(detail))
     rr = d["rank_route"]
     assert rr["calls"] >= 7 and rr["calls"] == rr["warm_started_subspace"] + rr["full_decomposition"]
     assert rr["warm_started_subspace"] >= 3 and rr["products_with_gram"] >= 10 * rr["warm_started_subspace"]
@@ -1875,29 +1878,37 @@ def test_bench_contract_line(dist_env):
     env = dict(os.environ)
     if dist_env:
         env.update(SIPX_FORCE_DIST="1", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(32100 + os.getpid() % 2000), RANK="0", WORLD_SIZE="1")
-    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--config", "c3-small", "--steps", "4", "--warmup", "2",
+    import tempfile
+    detail = os.path.join(tempfile.mkdtemp(prefix="sipx_bench_"), "detail.json")
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--config", "c3-small", "--steps", "4", "--warmup", "2", "--detail", detail,
                         "--no-cpu-baseline", "--no-512", "--no-c4", "--no-c5"], capture_output=True, text=True, timeout=280, env=env)
     assert r.returncode == 0, r.stderr[-2000:]
     lines = [ln for ln in r.stdout.strip().splitlines() if ln.strip()]
     assert len(lines) == 1, r.stdout
-    d = json.loads(lines[0])
+    assert len(lines[0]) < 4096, len(lines[0])       # the driver keeps a few KB of stdout tail: round 3's line (24 KB) lost its head
+    h = json.loads(lines[0])                         # the headline: the contract's keys and the figures a review reads first
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
-              "dtype", "data", "config", "roofline", "iteration_roofline"):
-        assert k in d, k
-    assert d["n_gpus"] == 1 and d["steps"] == 4 and d["warmup"] == 2 and d["value"] > 0 and d["vs_baseline"] is None
-    assert "workload" in d["config"] and d["config"]["all_logs_finite"]
-    assert {"bound", "achieved", "peak", "unit", "frac", "frac_survey", "traffic"} <= set(d["roofline"])
-    assert d["roofline"]["frac"] <= d["roofline"]["frac_survey"]                 # bytes that move <= SURVEY's count
+              "dtype", "data", "config", "roofline", "iteration_roofline", "dominant_kernel", "comm"):
+        assert k in h, k
+    assert h["n_gpus"] == 1 and h["steps"] == 4 and h["warmup"] == 2 and h["value"] > 0 and h["vs_baseline"] is None
+    assert "workload" in h["config"] and h["config"]["all_logs_finite"]
+    assert {"bound", "achieved", "peak", "unit", "frac", "frac_survey", "traffic", "kernel", "launches", "avg_launch_ms"} <= set(h["roofline"])
+    assert h["roofline"]["frac"] <= h["roofline"]["frac_survey"]                 # bytes that move <= SURVEY's count
+    assert h["dominant_kernel"]["kernel"].startswith("k_") and len(h["libsipx_sha16"]) == 16
+    d = json.load(open(detail))                      # everything else: the side file
+    assert abs(d["value"] - h["value"]) <= 1e-4 * h["value"]
     dom = d["dominant_kernel"]
     assert dom["kernel"].startswith("k_") and dom["launches"] > 0 and dom["avg_launch_ms"] > 0 and 0 <= dom["frac"] < 1.2      # (64^3: a one-workgroup step may lead)
     assert any(r["kernel"] == dom["kernel"] for r in d["kernels"]) and len(d["libsipx_sha16"]) == 16
     if dist_env:
-        assert set(d["decompositions"]) == {"slab", "sets"} and d["decomposition"] == "slab" and d["faster_decomposition"] in ("slab", "sets")
-        assert d["value"] == d["decompositions"]["slab"]["value"]
+        assert set(h["decompositions"]) == {"slab", "sets"} and h["decomposition"] == "slab" and h["faster_decomposition"] in ("slab", "sets")
+        assert h["value"] == h["decompositions"]["slab"]["value"]
+        assert all(v["ranks_agree_on_x"] is True for v in h["decompositions"].values())
+        assert h["comm"]["rccl_nranks"] == 1 and h["comm"]["rccl_version"].startswith("rccl ") and h["comm"]["device_bytes_per_rank"] > 0
         for v in d["decompositions"].values():
             assert v["value"] > 0 and v["comm"]["rccl_nranks"] == 1 and v["comm"]["rccl_version"].startswith("rccl ")
             assert v["comm"]["ranks_agree_on_x"] is True
         ss = d["decompositions"]["slab"]["comm"]["slab_searches"]               # the engine's counters of the speculative exchange
         assert ss["speculative_exchange"] > 0 and 0 <= ss["fallbacks"] <= ss["speculative_exchange"]
     else:
-        assert d["comm"]["rccl_version"] == "none" and "decompositions" not in d
+        assert h["comm"]["rccl_version"] == "none" and "decompositions" not in h
