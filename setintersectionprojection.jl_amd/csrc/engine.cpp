@@ -32,6 +32,7 @@ void refresh_env_knobs() {
   k.multi_zchunk = num("SIPX_MULTI_ZCHUNK", 0);
   k.rhs_march = (int)num("SIPX_RHS_MARCH", 1);
   k.rhs_march_zchunk = num("SIPX_RHS_MARCH_ZCHUNK", 0);
+  k.q_plan = (int)num("SIPX_Q_PLAN", 1);
   g_env_knobs = k;
 }
 long long*& alloc_tally() {
@@ -483,6 +484,17 @@ class Engine : public EngineBase {
         for (const auto& st : sets_) ntp += st.two_pass ? 1 : 0;
         n_set_streams_ = std::max(2, std::min(3, ntp));
       }
+      {
+        // One rank and EVERY update through the sweep: the searches of all two-pass sets as one chain of launches on the engine
+        // stream (batched_searches) -- no set streams at all.  SIPX_SEARCH_BATCH=0 keeps the per-set chains (A/B switch, tests).
+        int ntp = 0;
+        for (const auto& st : sets_) ntp += st.two_pass ? 1 : 0;
+        const char* sb = std::getenv("SIPX_SEARCH_BATCH");
+        MultiArgs<T> probe3;
+        search_batch_ = !comm_ && !(sb && sb[0] == '0') && ntp >= 1 && ntp <= SPEC_MAX_SETS &&
+                        sweep_applicable(SIPX_YL_FEAS | SIPX_YL_BB, probe3, true);
+        if (search_batch_) set_streams_ = false;
+      }
       for (const auto& st : sets_) slab_dist_logs_ |= slab_ && !mk_ && st.is_dist;
       if (x0_mode_) {
         for (int k = 0; k < 2; ++k) { x0s_base_[k] = dalloc<T>(N + 2 * halo_); x0s_[k] = x0s_base_[k] + halo_; }
@@ -620,7 +632,7 @@ class Engine : public EngineBase {
         K<T>::ps_init(stream_, s.ps, scr_i_);
         K<T>::ps_init(stream_, s.psf, scr_i_);
       }
-      if (slab_ && s.two_pass) {        // searches in lock step: every set keeps its own partial slots and gather buffer
+      if ((slab_ || search_batch_) && s.two_pass) {        // searches in lock step: every set keeps its own partial slots and gather buffer
         s.ptmp = dalloc<double>((size_t)(PREP_SLOTS + 2) * NB);
         s.mpart = dalloc<T>(2 * NB);
         s.cbuf = dalloc<T>(s.Mpad);
@@ -658,6 +670,12 @@ class Engine : public EngineBase {
       }
       if (warm && l0 && l0[i]) upload_rows(s, (const T*)l0[i], s.l);
       if (warm && y0 && y0[i]) upload_rows(s, (const T*)y0[i], s.y);
+    }
+    if (search_batch_) {                    // the sets' header segments and decision registers of the batched searches
+      int n2 = 0;
+      for (auto& s : sets_) n2 += s.two_pass ? 1 : 0;
+      fbuf_ = dalloc<T>((size_t)n2 * fast_hdr<T>());
+      stage_ = dalloc<double>((size_t)n2 * (PREP_SLOTS + 1 + 2));
     }
     if (warm && x0) SIPX_HIP(hipMemcpy(x_, x0, Nx_ * sizeof(T), hipMemcpyHostToDevice));   // Minkowski: [u; v], 2N entries
 
@@ -917,7 +935,8 @@ class Engine : public EngineBase {
     const bool sweep = sweep_applicable(flags, ma);
     if (x0_mode_ && !sweep) throw std::runtime_error("internal: an x0-mode context met an update the one-sweep kernel does not take");
     if (sweep && !slab_) {
-      sweep_searches(flags, rho, gamma);
+      if (search_batch_) batched_searches(flags, rho, gamma);
+      else sweep_searches(flags, rho, gamma);
       sweep_launch(flags, rho, gamma, ma);
       reduce_set_sums(p_n_ * SLOTS);
       sums_flags_ = flags;
@@ -1403,6 +1422,125 @@ class Engine : public EngineBase {
         }
         if (stage == 12) comm_->allgather(gbuf_, (size_t)chunk, dtype_code(), stream_);
       }
+    }
+  }
+
+  // One rank, the sweep does the updates: the threshold / scale searches of ALL two-pass sets as ONE chain of launches on the
+  // engine stream (round 4) -- rescaling after a change of rho and the sampled prediction for every set that asks for them (one
+  // launch each), the lean first passes in one sweep that reads x once (k_lean_multi), a full first pass per set only where the
+  // host does not know that the pass will be a lean one, then two launches for all sets: sums of the partial slots (+ header),
+  // decision + solve (one workgroup per set) -- the batched form of the slab-decomposed search without its exchange.  Whether
+  // a set needs its fallback sweeps (theta left the speculative range) the host reads from one pinned word per set, published
+  // by the decision before the solve starts: the gated launches of the per-set chains -- three no-ops per search in the common
+  // case, each a few microseconds on the critical path -- are only made when they have work, and no stream forks or joins.
+  // Per iteration of the headline list: 5 launches instead of 27 on three streams, x read once instead of three times.
+  // Same decisions (decide_body with cap_max = 0), same gathered values, same double-double solve: theta bit for bit.
+  void batched_searches(int flags, const double* rho, const double* gamma) {
+    std::vector<int> tp;
+    for (int i = 0; i < p_n_; ++i)
+      if (sets_[i].two_pass) tp.push_back(i);
+    if (tp.empty()) return;
+    run_batched(tp, false, flags, rho, gamma);
+    if (flags & SIPX_YL_FEAS) {               // ||P_i(s) - s|| with s = A_i x itself: the sets' second scalar state
+      std::vector<int> tf;
+      for (int i : tp)
+        if (i < pp_n_) tf.push_back(i);
+      if (!tf.empty()) {
+        run_batched(tf, true, flags, rho, gamma);
+        for (int i : tf) {
+          SetArgs<T> a = set_args(sets_[i], (T)rho[i], (T)gamma[i], flags);
+          K<T>::proj_dist_set(stream_, Gr_, a, 1, sets_[i].psf, part_sets_ + ((size_t)i * SLOTS + SL_FE2) * NB);
+        }
+      }
+    }
+  }
+  void run_batched(const std::vector<int>& tp, bool feas_ps, int flags, const double* rho, const double* gamma) {
+    const size_t RS = (size_t)(PREP_SLOTS + 1 + 2);
+    const long long fseg = fast_hdr<T>();
+    const int v_is_s = feas_ps ? 1 : 0;
+    const unsigned seq = ++spec_seq_ & 0x3fffffffu;
+    std::vector<SetArgs<T>> args(tp.size());
+    std::vector<SampleCtl> ctl(tp.size());
+    auto PS = [&](int i) { return feas_ps ? sets_[i].psf : sets_[i].ps; };
+    const bool vec = Gr_.n[0] % 4 == 0;
+    RescaleMulti<T> rs;
+    rs.n = 0;
+    SampleMulti<T> sm;
+    sm.ns = 0;
+    LeanMulti<T> lm;
+    lm.ns = 0;
+    std::vector<size_t> lean_who;
+    for (size_t j = 0; j < tp.size(); ++j) {
+      SetState<T>& s = sets_[tp[j]];
+      args[j] = set_args(s, (T)rho[tp[j]], (T)gamma[tp[j]], flags);
+      ctl[j].verdict = (unsigned*)hverd_ + tp[j];
+      ctl[j].seq = seq;
+      if (feas_ps) continue;
+      ctl[j].host_want = (int*)hlean_ + tp[j];
+      ctl[j].runs = l1_sample_runs_;
+      const bool l1 = s.prox == PX_L1;
+      const bool rescaled = l1 && s.last_rho > T(0) && s.last_rho != args[j].rho;      // v rescaled: theta moves like 1/rho
+      if (rescaled) { rs.ps[rs.n] = s.ps; rs.factor[rs.n++] = (double)s.last_rho / (double)args[j].rho; }
+      if (l1_sample_ && l1 && vec && (rescaled || (hlean_[tp[j]] & 0xff) != 0)) {
+        SampleSet<T>& S = sm.s[sm.ns++];
+        S.a = args[j]; S.a.ps = s.ps; S.ps = s.ps; S.partials = s.ptmp; S.reg = nullptr; S.true_len = s.Mtrue;
+      }
+      if (l1 && vec && !(args[j].flags & F_NOSPEC) && lm.ns < LEAN_MAX) {
+        LeanSet<T>& L = lm.s[lm.ns++];
+        L.a = args[j]; L.a.ps = s.ps; L.ps = s.ps; L.compact = s.cbuf; L.partials = s.ptmp; L.maxpart = s.mpart;
+        lean_who.push_back(j);
+      }
+      s.last_rho = args[j].rho;
+      s.last_gamma = args[j].gamma;
+    }
+    K<T>::ps_rescale_multi(stream_, rs);
+    if (sm.ns > 0) K<T>::sample_multi(10, stream_, Gr_, sm, l1_sample_runs_, nullptr);
+    if (lm.ns > 0) {
+      K<T>::lean_multi(stream_, Gr_, lm);
+      for (size_t j : lean_who) {
+        ctl[j].lean_done = 1;
+        // published by the set's last solve (nothing since can have taken the flag back): its full first pass need not be launched
+        ctl[j].lean_known = (hlean_[tp[j]] >> 16) & 1;
+      }
+    }
+    SpecPackArgs<T> pk;
+    SpecFinishArgs<T> fa;
+    pk.nsets = fa.nsets = (int)tp.size();
+    pk.local = fa.local = 1;
+    pk.cap = 0;
+    fa.world = 1; fa.fchunk = (long long)tp.size() * fseg; fa.seq = seq;
+    for (size_t j = 0; j < tp.size(); ++j) {
+      SetState<T>& s = sets_[tp[j]];
+      K<T>::proj_scalars_stage(13, stream_, Gr_, args[j], v_is_s, PS(tp[j]), s.ptmp, s.mpart, s.cbuf, s.Mtrue, ctl[j], nullptr,
+                               stage_ + j * RS, nullptr, 0);
+      SpecPackSet<T>& P = pk.s[j];
+      P.ps = PS(tp[j]); P.partials = s.ptmp; P.maxpart = s.mpart; P.compact = s.cbuf;
+      P.seg = fbuf_ + (long long)j * fseg;
+      P.is_l1 = s.prox == PX_L1 ? 1 : 0;
+      SpecFinishSet<T>& F = fa.s[j];
+      F.ps = PS(tp[j]);
+      F.da = DecideArgs{args[j].prox, (args[j].flags & F_NOSPEC) ? 1 : 0, (double)args[j].plo, (double)args[j].phi, 64.0, 0.0, s.Mtrue};
+      F.reg = stage_ + j * RS;
+      F.fseg0 = fbuf_ + (long long)j * fseg;
+      F.compact = s.cbuf; F.partials = s.ptmp; F.radius = args[j].phi;
+      F.host_want = ctl[j].host_want; F.verdict = ctl[j].verdict;
+    }
+    K<T>::spec_sums_pack(stream_, pk);
+    K<T>::spec_finish(stream_, fa);
+    for (size_t j = 0; j < tp.size(); ++j) {
+      const unsigned w = wait_verdict(hverd_ + tp[j], seq);
+      batch_searches_ += 1;
+      if (!(w & 1u)) continue;
+      batch_fallbacks_ += 1;
+      // Fallback of this set (theta left the speculative range, or the range gathered too much): the gated stages of the
+      // per-set chain -- refinement pass + decision (only when the decision asked for one), compaction of the bracket, solve
+      SetState<T>& s = sets_[tp[j]];
+      if (w & 2u)
+        K<T>::proj_scalars_stage(1, stream_, Gr_, args[j], v_is_s, PS(tp[j]), s.ptmp, s.mpart, s.cbuf, s.Mtrue, ctl[j], nullptr,
+                                 stage_ + j * RS, nullptr, 0);
+      for (int stage : {2, 3})
+        K<T>::proj_scalars_stage(stage, stream_, Gr_, args[j], v_is_s, PS(tp[j]), s.ptmp, s.mpart, s.cbuf, s.Mtrue, ctl[j], nullptr,
+                                 stage_ + j * RS, nullptr, 0);
     }
   }
 
@@ -2193,6 +2331,8 @@ class Engine : public EngineBase {
     // and how many of them needed their fallback (refinement rounds + full-size exchange)
     o += "], \"slab_searches\": {\"speculative_exchange\": " + std::to_string(spec_searches_) + ", \"fallbacks\": " +
          std::to_string(spec_fallbacks_) + ", \"refinement_rounds\": " + std::to_string(spec_rounds_) + "}";
+    // one rank: searches through the batched chain (batched_searches) and how many of them needed their fallback sweeps
+    o += ", \"batched_searches\": {\"searches\": " + std::to_string(batch_searches_) + ", \"fallbacks\": " + std::to_string(batch_fallbacks_) + "}";
     // slice-rank / matrix-rank sets: which route their projector took since the context was finalised (ext_proj.hip)
     long long rc[4] = {0, 0, 0, 0};
     for (const auto& st : sets_) {
@@ -2937,6 +3077,8 @@ class Engine : public EngineBase {
   unsigned spec_seq_ = 0;
   long long spec_searches_ = 0, spec_fallbacks_ = 0, spec_rounds_ = 0;     // searches through the speculative exchange / of those, fallbacks / refinement rounds (all-reduces) of the fallbacks
   bool spec_exchange_ = true;         // SIPX_SPEC_EXCHANGE=0: every search through (all-reduce, ..., all-gather), as before
+  bool search_batch_ = false;         // one rank + sweep: the searches of all sets as one chain of launches (batched_searches; SIPX_SEARCH_BATCH=0: per-set chains on the set streams)
+  long long batch_searches_ = 0, batch_fallbacks_ = 0;
   bool spec_batch_ = true;            // SIPX_SPEC_BATCH=0: the small steps of the exchange as one kernel per set on the set streams
   bool slab_lean_multi_ = true;       // SIPX_SLAB_LEAN_MULTI=0: one lean first pass per set in the batched exchange
   T* fbuf_ = nullptr;                 // fast segments: world x two-pass sets x (fcap + header)

@@ -672,6 +672,155 @@ __global__ __launch_bounds__(BLOCK) void k_q_update(Grid G, long long r0, long l
     }
   }
 }
+
+// ---- the same update from a PLAN (round 4) ------------------------------------------------------------------------------------
+// k_q_update regenerates every band value per element -- loops over sets, a search for the band among the set's offsets, the
+// boundary tests of ata_value for every block -- and is bound by that arithmetic, not by the 2 N w per touched band it moves
+// (512^3, all sets changed: 1.47 ms for 8 N w = 2.9 TB/s).  But the contribution of a set to a band takes only a handful of
+// values: alpha_i * (A_i'A_i)[g, g + o] depends on g only through the CLASS of its coordinates along the set's difference
+// directions (first / interior / last point of the line).  The host forms those products ONCE per launch, with the arithmetic
+// of ata_value and the multiplication by alpha in TF (this translation unit is compiled with -ffp-contract=off like the kernels),
+// and the kernel adds them in set order: Q[:, col] = Q[:, col] + p_i(class(g)) -- the same numbers added in the same order as
+// k_q_update and CDS_scaled_add!.jl:16-22, so Q stays bit-identical (the engine's Q is compared bit for bit with the oracle's).
+constexpr int QP_MAXB = 9, QP_MAXT = 8, QP_TAB = 320;
+struct QPlanTerm {
+  int kind;          // 0: one value; 1: diagonal of a difference set -- table over the classes of its nblk directions, index
+                     // sum_q class(dir[q]) 3^q; 2 / 3: band +stride / -stride of direction dir[0]: (row exists ? tab[0] : tab[1])
+  int nblk;
+  int dir[3];
+  int tab;           // where its values start in QPlan::tab
+};
+template <typename T>
+struct QPlan {
+  int nbands;
+  int col[QP_MAXB], nterms[QP_MAXB];
+  QPlanTerm t[QP_MAXB][QP_MAXT];
+  int ntab;
+  T tab[QP_TAB];
+};
+
+template <typename T, int V>
+__global__ __launch_bounds__(BLOCK) void k_q_update_plan(Grid G, long long r0, long long r1, QPlan<T> p, T* __restrict__ Q) {
+  __shared__ T tab[QP_TAB];
+  for (int i = threadIdx.x; i < p.ntab; i += BLOCK) tab[i] = p.tab[i];
+  __syncthreads();
+  const int n1 = (int)G.n[0], n2 = (int)G.n[1], n3 = (int)G.n[2];
+  const long long nvec = r1 / V;
+  for (long long vi = r0 / V + (long long)blockIdx.x * BLOCK + threadIdx.x; vi < nvec; vi += (long long)gridDim.x * BLOCK) {
+    const long long g = vi * V;
+    const Coord c = coords(G, g);
+    // class of a coordinate: 0 first, 1 interior, 2 last point of its line (a line of one point is never differenced)
+    int cx[V];
+#pragma unroll
+    for (int k = 0; k < V; ++k) cx[k] = (c.i + k) == 0 ? 0 : ((c.i + k) == n1 - 1 ? 2 : 1);
+    const int cy = c.j == 0 ? 0 : (c.j == n2 - 1 ? 2 : 1), cz = c.k == 0 ? 0 : (c.k == n3 - 1 ? 2 : 1);
+    for (int b = 0; b < p.nbands; ++b) {
+      T* row = Q + (long long)p.col[b] * G.N + g;
+      Vec<T, V> qv = ldv<T, V>(row);
+      for (int ti = 0; ti < p.nterms[b]; ++ti) {
+        const QPlanTerm& t = p.t[b][ti];
+        if (t.kind == 0) {
+          const T v = tab[t.tab];
+#pragma unroll
+          for (int k = 0; k < V; ++k) qv.v[k] = qv.v[k] + v;
+        } else if (t.kind == 1) {
+          int base = 0, mulx = 0, m3 = 1;            // index = base + mulx * class_x: only x varies inside the vector
+          for (int q = 0; q < t.nblk; ++q) {
+            const int d = t.dir[q];
+            if (d == 0) mulx += m3; else base += (d == 1 ? cy : cz) * m3;
+            m3 *= 3;
+          }
+#pragma unroll
+          for (int k = 0; k < V; ++k) qv.v[k] = qv.v[k] + tab[t.tab + base + mulx * cx[k]];
+        } else {
+          const int d = t.dir[0];
+          const int edge = t.kind == 2 ? 2 : 0;      // +stride: the row exists unless this is the LAST point; -stride: unless the FIRST
+          const T on = tab[t.tab], off = tab[t.tab + 1];
+#pragma unroll
+          for (int k = 0; k < V; ++k) {
+            const int cl = d == 0 ? cx[k] : (d == 1 ? cy : cz);
+            qv.v[k] = qv.v[k] + (cl != edge ? on : off);
+          }
+        }
+      }
+      stv<T, V>(row, qv);
+    }
+  }
+}
+
+// builds the plan; false: the general kernel has to do it (explicit AtA bands, more bands / sets than the plan holds, two blocks
+// of one set with the same stride)
+template <typename T>
+static bool make_q_plan(const Grid& g, const CdsArgs& q, const QArgs<T>& a, QPlan<T>& p) {
+  p.nbands = 0;
+  p.ntab = 0;
+  for (int si = 0; si < a.nsets; ++si) {
+    const QSet<T>& S = a.s[si];
+    if (S.ata) return false;
+    for (int u = 0; u < S.nblk; ++u)
+      for (int w = u + 1; w < S.nblk; ++w)
+        if (g.st[S.dir[u]] == g.st[S.dir[w]]) return false;
+  }
+  for (int b = 0; b < q.d; ++b) {
+    const long long o = q.off[b];
+    if (q.sym && o < 0) continue;            // never read by the SpMV: rebuilt from the partner band on demand (k_mirror_bands)
+    int nt = 0;
+    QPlanTerm terms[QP_MAXT];
+    for (int si = 0; si < a.nsets; ++si) {
+      const QSet<T>& S = a.s[si];
+      bool has = false;
+      for (int t = 0; t < S.nband; ++t) has |= S.off[t] == o;
+      if (!has) continue;
+      if (nt == QP_MAXT) return false;
+      QPlanTerm& t = terms[nt++];
+      t.nblk = S.nblk;
+      for (int u = 0; u < 3; ++u) t.dir[u] = S.dir[u];
+      t.tab = p.ntab;
+      if (o == 0 && S.nblk == 0) {             // identity: AtA = I
+        t.kind = 0;
+        if (p.ntab + 1 > QP_TAB) return false;
+        p.tab[p.ntab++] = S.alpha * T(1);
+      } else if (o == 0) {                     // diagonal of a difference set: 3^nblk classes, ata_value's sums in block order
+        t.kind = 1;
+        int ncls = 1;
+        for (int u = 0; u < S.nblk; ++u) ncls *= 3;
+        if (p.ntab + ncls > QP_TAB) return false;
+        for (int idx = 0; idx < ncls; ++idx) {
+          T val = T(0);
+          int rem = idx;
+          for (int u = 0; u < S.nblk; ++u) {
+            const int cl = rem % 3;
+            rem /= 3;
+            const T ih = S.ih[u], nih = -ih;
+            if (cl != 0) val = val + ih * ih;          // cc > 0: row g - st holds +ih in column g
+            if (cl != 2) val = val + nih * nih;        // cc < n - 1: row g holds -ih in column g
+          }
+          p.tab[p.ntab++] = S.alpha * val;
+        }
+      } else {                                 // band +-stride of exactly one of the set's blocks
+        int u = -1;
+        for (int w = 0; w < S.nblk; ++w)
+          if (g.st[S.dir[w]] == (o > 0 ? o : -o)) u = w;
+        if (p.ntab + 2 > QP_TAB) return false;
+        const T ih = u >= 0 ? S.ih[u] : T(0), nih = -ih;
+        t.kind = o > 0 ? 2 : 3;
+        t.dir[0] = u >= 0 ? S.dir[u] : 0;
+        // (a listed offset that no block of the set has: ata_value is zero everywhere -- both entries alpha * 0)
+        const T val_on = u >= 0 ? (o > 0 ? T(0) + nih * ih : T(0) + ih * nih) : T(0);
+        p.tab[p.ntab++] = S.alpha * val_on;
+        p.tab[p.ntab++] = S.alpha * T(0);
+      }
+    }
+    if (nt == 0) continue;
+    if (p.nbands == QP_MAXB) return false;
+    p.col[p.nbands] = b;
+    p.nterms[p.nbands] = nt;
+    for (int t = 0; t < nt; ++t) p.t[p.nbands][t] = terms[t];
+    p.nbands += 1;
+  }
+  return true;
+}
+
 template <typename T>
 void K<T>::q_update(hipStream_t s, const Grid& g, long long r0, long long r1, const CdsArgs& q, const QArgs<T>& a, T* Q) {
   if (a.nsets == 0 || r1 <= r0) return;
@@ -690,6 +839,16 @@ void K<T>::q_update(hipStream_t s, const Grid& g, long long r0, long long r1, co
   }
   for (int si = 0; si < a.nsets; ++si) survey += 3.0 * a.s[si].nband;
   ObsScope obs(KID_Q_UPDATE, s, survey * (double)(r1 - r0) * sizeof(T), touched * (double)(r1 - r0) * sizeof(T));
+  QPlan<T> plan;
+  if (env_knobs().q_plan && make_q_plan<T>(g, q, a, plan)) {      // (SIPX_Q_PLAN=0: A/B switch, tests)
+    if (plan.nbands == 0) return;
+    if (g.n[0] % 4 == 0 && r0 % 4 == 0 && r1 % 4 == 0)
+      hipLaunchKernelGGL((k_q_update_plan<T, 4>), dim3(fit_grid((r1 - r0) / 4, NB)), dim3(BLOCK), 0, s, g, r0, r1, plan, Q);
+    else
+      hipLaunchKernelGGL((k_q_update_plan<T, 1>), dim3(fit_grid(r1 - r0, NB)), dim3(BLOCK), 0, s, g, r0, r1, plan, Q);
+    SIPX_HIP(hipGetLastError());
+    return;
+  }
   if (g.n[0] % 4 == 0 && r0 % 4 == 0 && r1 % 4 == 0)
     hipLaunchKernelGGL((k_q_update<T, 4>), dim3(fit_grid((r1 - r0) / 4, NB)), dim3(BLOCK), 0, s, g, r0, r1, q, a, Q);
   else

@@ -369,6 +369,7 @@ __global__ __launch_bounds__(BLOCK) void k_lean_multi(Grid G, LeanMulti<T> m) {
 template <typename T>
 void K<T>::lean_multi(hipStream_t s, const Grid& g, const LeanMulti<T>& m) {
   if (m.ns < 1 || m.ns > LEAN_MAX || g.n[0] % 4 != 0) throw std::runtime_error("lean_multi: unsupported call");
+  // (one set: the same kernel -- the caller keeps ONE chain of launches for every set list)
   double bytes = (double)range_len(g);                 // x once, y and l of every block of every set
   for (int q = 0; q < m.ns; ++q) bytes += 2.0 * (double)m.s[q].a.nblk_or1() * (double)range_len(g);
   ObsScope obs_(KID_PASS_LEAN, s, bytes * sizeof(T));
@@ -1356,7 +1357,19 @@ __device__ void l1_solve_body(ProjScalars<T>* ps, T radius, const T* __restrict_
         // accurate than a sample, whose error grows as theta shrinks against the spread of the values
         if (ps->rescaled) ps->resc_bad = d > hw_max ? 1 : 0;
         hw = 3.0 * d;                                  // theta moves slowly while rho, gamma stay put
-        hw = hw < 1e-3 ? 1e-3 : (hw > hw_max ? hw_max : hw);
+        // The floor of the half-width follows what the range GATHERS, not a fixed relative width: theta wanders by +-0.1 ... 0.2 %
+        // from one iteration to the next long after rho and gamma have settled (256^3, iterations 22 and 26 of the headline run:
+        // -0.19 % and +0.11 % against a range of +-0.1 %: two searches each fell back to their refinement + compaction sweeps,
+        // ~100 us apiece on the critical path), while a range of +-0.1 % holds a few thousand magnitudes -- a fraction of what the
+        // solve takes in its stride.  So: as wide as gathers about max(2^15, len / 1024) magnitudes (density from this search's own
+        // count when the speculative range was what it gathered), between 0.1 % and 0.4 %.
+        double hw_floor = 2e-3;
+        if (ps->spec_ok && n_all > 0 && ps->hw > 0) {
+          const double tgt = fmax(32768.0, (double)true_len / 1024.0);
+          hw_floor = ps->hw * tgt / (double)n_all;
+          hw_floor = hw_floor < 1e-3 ? 1e-3 : (hw_floor > 4e-3 ? 4e-3 : hw_floor);
+        }
+        hw = hw < hw_floor ? hw_floor : (hw > hw_max ? hw_max : hw);
         if (ps->spec_overflow) hw = ps->hw * 0.5;      // the last range gathered too much
       }
       ps->hw = hw;
@@ -1689,10 +1702,11 @@ __global__ __launch_bounds__(BLOCK) void k_spec_sums_pack(SpecPackArgs<T> A) {
       h[FH_OVF] = S.ps->spec_overflow ? 1.0 : 0.0;
       h[FH_MAX] = (double)vmax;
       h[FH_MIN] = (vmin < (T)INFINITY) ? (double)vmin : 0.0;          // 0 = this rank saw no non-zero magnitude
-      h[FH_CNT] = n <= A.cap ? (double)n : -1.0;                      // -1: more than the fast segment holds
+      h[FH_CNT] = (A.local || n <= A.cap) ? (double)n : -1.0;         // -1: more than the fast segment holds
     }
     return;
   }
+  if (A.local) return;
   const long long m = n <= A.cap ? n : 0;
   for (long long i = (long long)(b - PREP_SLOTS - 1) * BLOCK + threadIdx.x; i < m; i += (long long)SPEC_COPY_WG * BLOCK)
     S.seg[fast_hdr<T>() + i] = S.compact[i];
@@ -1701,7 +1715,7 @@ template <typename T>
 void K<T>::spec_sums_pack(hipStream_t s, const SpecPackArgs<T>& A) {
   if (A.nsets < 1 || A.nsets > SPEC_MAX_SETS) throw std::runtime_error("spec_sums_pack: set count out of range");
   ObsScope obs_(KID_SLOT_SUMS, s, 0.0);
-  hipLaunchKernelGGL((k_spec_sums_pack<T>), dim3(PREP_SLOTS + 1 + SPEC_COPY_WG, A.nsets), dim3(BLOCK), 0, s, A);
+  hipLaunchKernelGGL((k_spec_sums_pack<T>), dim3(PREP_SLOTS + 1 + (A.local ? 0 : SPEC_COPY_WG), A.nsets), dim3(BLOCK), 0, s, A);
   SIPX_HIP(hipGetLastError());
 }
 
@@ -1743,7 +1757,7 @@ __global__ __launch_bounds__(SIPX_SOLVE_NT) void k_spec_finish(SpecFinishArgs<T>
   __threadfence_block();
   __syncthreads();
   if (S.da.prox != PX_L1) return;
-  if (ps->need && ps->spec_ok) {                            // the values every rank gathered inside the range, strung together in rank order
+  if (ps->need && ps->spec_ok && !A.local) {                // the values every rank gathered inside the range, strung together in rank order
     long long off = 0;
     for (int r = 0; r < world; ++r) {
       const T* seg = S.fseg0 + (long long)r * A.fchunk;
@@ -1816,16 +1830,17 @@ void K<T>::ps_rescale_multi(hipStream_t s, const RescaleMulti<T>& A) {
 template <typename T>
 void K<T>::sample_multi(int stage, hipStream_t s, const Grid& g, const SampleMulti<T>& A, long long runs, const ChainHooks* hk) {
   if (A.ns < 1 || g.n[0] % 4 != 0) return;
-  const int world = hk->world;
-  const double cap_max = (double)hk->gcap;
+  // hk == nullptr: one rank, the decision is taken inside the sampling kernel (SampleSet::reg == nullptr), stage 10 only
+  const int world = hk ? hk->world : 1;
+  const double cap_max = hk ? (double)hk->gcap : 0.0;
   const long long nchunks = (range_len(g) / 4 + SAMPLE_RUN - 1) / SAMPLE_RUN;
   const long long nchunks_all = (g.N / 4 + SAMPLE_RUN - 1) / SAMPLE_RUN;
   const long long target = runs > 0 ? runs : (g.N >= (1ll << 26) ? 32768 : 16384);
   const long long stride = nchunks_all / target;
-  const long long per_rank = (g.N / world + 3) / 4;
+  const long long per_rank = hk ? (g.N / world + 3) / 4 : range_len(g) / 4;
   double gcap = 0.2 * (double)fit_grid(per_rank, SIPX_PASS_GRID) * (double)SPEC_CAP * (double)world;
-  if (gcap > 0.8 * cap_max) gcap = 0.8 * cap_max;
-  if (hk->fcap > 0 && gcap > 0.8 * (double)hk->fcap * (double)world) gcap = 0.8 * (double)hk->fcap * (double)world;
+  if (hk && gcap > 0.8 * cap_max) gcap = 0.8 * cap_max;
+  if (hk && hk->fcap > 0 && gcap > 0.8 * (double)hk->fcap * (double)world) gcap = 0.8 * (double)hk->fcap * (double)world;
   if (!(stride >= 4 && (g.N >= (1ll << 24) || runs > 0))) return;
   const long long nsamp = nchunks / stride;            // may be 0 on a short slab
   ObsScope obs_(stage != 11 ? KID_SAMPLE : KID_DECIDE, s, 0.0);

@@ -87,6 +87,7 @@ struct EnvKnobs {
   long long multi_zchunk = 0;     // SIPX_MULTI_ZCHUNK
   int rhs_march = 1;              // SIPX_RHS_MARCH
   long long rhs_march_zchunk = 0; // SIPX_RHS_MARCH_ZCHUNK
+  int q_plan = 1;                 // SIPX_Q_PLAN=0: the Q update regenerates every band value per element (k_q_update) instead of adding planned products
 };
 const EnvKnobs& env_knobs();
 void refresh_env_knobs();
@@ -305,6 +306,7 @@ struct SpecPackSet {
 template <typename T>
 struct SpecPackArgs {
   int nsets;
+  int local = 0;          // one rank, no exchange: the header only (the gathered magnitudes stay where the pass left them)
   long long cap;
   SpecPackSet<T> s[SPEC_MAX_SETS];
 };
@@ -322,6 +324,7 @@ struct SpecFinishSet {
 };
 template <typename T>
 struct SpecFinishArgs {
+  int local = 0;          // one rank, no exchange: nothing to string together
   int nsets, world;
   long long fchunk;
   unsigned seq;

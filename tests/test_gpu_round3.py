@@ -450,6 +450,7 @@ def test_lean_first_passes_in_one_sweep_are_bit_identical(sipx, monkeypatch, TF,
     # the group pass needs every set's own scratch, which exists with the set streams: those of the large grids it is made for
     # (a grid this small runs on the engine stream alone by default)
     monkeypatch.setenv("SIPX_SERIAL_SETS", "0")
+    monkeypatch.setenv("SIPX_SEARCH_BATCH", "0")        # (round 4's batched chain always takes the group pass: the per-set chains here)
     out = {}
     for tag in ("0", "1"):
         monkeypatch.setenv("SIPX_LEAN_MULTI", tag)

@@ -56,3 +56,90 @@ def test_device_bytes_and_read_only_counters(sipx):
         assert any(k["name"] == "k_cds<MODE=1>" and k["launches"] > 0 for k in st["kernels"])
     finally:
         ctx.close()
+
+
+@pytest.mark.parametrize("TF,n,kinds,runs", [
+    (np.float32, (64, 48, 40), ["bounds", "l1:D_x", "l1:D_y", "l1:D_z"], "0"),
+    (np.float32, (64, 48, 40), ["bounds", "l1:D_x", "l1:D_y", "l1:D_z"], "96"),        # with the sampled prediction forced on this small grid
+    (np.float64, (48, 40, 24), ["bounds", "l1:TV", "annulus"], "64"),
+    (np.float32, (256, 192), ["bounds", "l1:TV"], "0"),
+    (np.float32, (36, 30, 20), ["bounds", "l1:D_y"], "0"),                             # a grid line shorter than a wave, one searching set
+])
+def test_batched_searches_are_bit_identical(sipx, monkeypatch, TF, n, kinds, runs):
+    """One rank, the sweep does the updates: the threshold / scale searches of all sets as ONE chain of launches on the engine
+    stream (rescaling, sampled prediction, lean passes in one sweep, sums, decision + solve; the fallback sweeps launched only
+    for the sets whose pinned verdict asks for them) against the per-set chains on the set streams (SIPX_SEARCH_BATCH=0): the same
+    decisions on the same sums, the same gathered values, the same double-double solve -- theta, x, y, l, the CG counts and every
+    log bit for bit over 60 iterations that include feasibility estimates, rho changes and (where forced) sampled predictions."""
+    h = (25.0, 25.0, 25.0)[:len(n)]
+    m = model(n, TF, seed=7)
+    gs, os_, Ps, As, props, AtAs = _problem(sipx, n, h, TF, kinds, m, dict(maxit=60))
+    os_.evol_rel_tol = os_.feas_tol = os_.obj_tol = 0.0
+    if runs != "0":
+        monkeypatch.setenv("SIPX_L1_SAMPLE_RUNS", runs)
+    out = {}
+    for tag in ("0", "1"):
+        monkeypatch.setenv("SIPX_SEARCH_BATCH", tag)
+        ctx = sipx.host.build_context(m, AtAs, As, props, Ps, gs, os_)
+        ctx.parsdmm_begin(os_)
+        ctx.parsdmm_steps(60)
+        cnt = ctx.kernel_stats_all(-1)["batched_searches"]
+        log = ctx.parsdmm_log()
+        x, l, y = ctx.download()
+        ctx.close()
+        out[tag] = (x, l, y, log, cnt)
+    (x0, l0, y0, g0, c0), (x1, l1, y1, g1, c1) = out["0"], out["1"]
+    ntp = sum(1 for k in kinds if k.startswith("l1") or k == "annulus")
+    assert c0["searches"] == 0 and c1["searches"] == ntp * (60 + 6) and 0 <= c1["fallbacks"] < c1["searches"] // 2, (c0, c1)
+    assert np.array_equal(x0, x1)
+    for a, b in zip(y0 + l0, y1 + l1):
+        assert np.array_equal(a, b)
+    assert np.array_equal(g0.cg_it, g1.cg_it) and np.array_equal(g0.obj, g1.obj) and np.array_equal(g0.set_feasibility, g1.set_feasibility)
+    assert np.array_equal(g0.rho, g1.rho) and np.array_equal(g0.gamma, g1.gamma)
+    assert np.array_equal(g0.r_pri, g1.r_pri) and np.array_equal(g0.r_dual, g1.r_dual)
+
+
+@pytest.mark.parametrize("TF,n,h,kinds,full", [
+    (np.float32, (16, 12, 8), (25.0, 25.0, 25.0), ["bounds", "l1:D_x", "l1:D_y", "l1:D_z"], "0"),
+    (np.float64, (16, 12, 8), (25.0, 12.5, 6.0), ["bounds", "l1:TV", "l1:D_y"], "0"),
+    (np.float32, (32, 24), (25.0, 6.0), ["bounds", "l1:TV", "l1:D_x"], "0"),
+    (np.float32, (13, 7, 5), (1.0, 2.0, 3.0), ["bounds", "l1:D_z", "l1:TV"], "0"),            # scalar path (n1 not a multiple of 4)
+    (np.float64, (16, 12, 8), (25.0, 25.0, 25.0), ["bounds", "l1:D_x", "l1:TV"], "1"),         # every band maintained (SIPX_CDS_FULL)
+])
+def test_planned_q_update_is_bit_identical(sipx, monkeypatch, TF, n, h, kinds, full):
+    """k_q_update_plan (alpha_i * (A_i'A_i)[g, g+o] taken from a table over the boundary classes of g that the host formed with
+    ata_value's arithmetic, added in set order) against k_q_update (every value regenerated per element, SIPX_Q_PLAN=0) and
+    against the oracle's mat2CDS / CDS_scaled_add! (Q_update!.jl:45-48): the assembled Q and Q after three incremental updates
+    (all sets, one set, a subset with a negative step) bit for bit."""
+    m = model(n, TF, seed=5)
+    monkeypatch.setenv("SIPX_CDS_FULL", full)
+    go, oo, Po, Ao, propo, AtAo = _problem(O, n, h, TF, kinds, m)
+    gs, os_, Ps, As, props, AtAs = _problem(sipx, n, h, TF, kinds, m)
+    p = len(Ao)
+    rng = np.random.default_rng(1)
+    rhos = [list(np.round(rng.uniform(0.5, 20.0, p), 3))]
+    r1 = list(np.round(rng.uniform(0.5, 20.0, p), 3))
+    r2 = list(r1); r2[1] = 0.731
+    r3 = list(r2); r3[0] = 0.0625; r3[-1] = 17.5; r3[2] = r3[2] * 0.25
+    rhos += [r1, r2, r3]
+    os_.rho_ini = rhos[0]
+    got = {}
+    for tag in ("0", "1"):
+        monkeypatch.setenv("SIPX_Q_PLAN", tag)
+        ctx = sipx.host.build_context(m, AtAs, As, props, Ps, gs, os_)
+        Qs = [ctx.get_Q()]
+        for a, b in zip(rhos[:-1], rhos[1:]):
+            ctx.q_update(b, a)
+            Qs.append(ctx.get_Q())
+        ctx.close()
+        got[tag] = Qs
+    Qo, offo = O.assemble_Q(AtAo, propo.AtA_offsets, np.array(rhos[0], TF), TF)
+    for step, ((Q0, off0), (Q1, off1)) in enumerate(zip(got["0"], got["1"])):
+        assert list(off0) == list(off1) == list(offo)
+        assert np.array_equal(Q0, Q1), step
+        if step > 0:
+            class L: pass
+            log = L(); log.rho = np.array([rhos[step - 1]])
+            changed = [i for i in range(p) if TF(rhos[step][i]) != TF(rhos[step - 1][i])]
+            Qo = O.Q_update(Qo.copy(order="F"), AtAo, propo, np.array(rhos[step], TF), changed, log, 0, offo)
+        assert np.array_equal(Q1, Qo), step
