@@ -119,7 +119,7 @@ end
 
 # ---- options.parallel = true: one process per GPU, RCCL inside the engine (include/sipx.h, "sharded solve") ----------------
 # Launch (one node, 8 GPUs), every process running the SAME script:
-#     for r in 0:7:  SIPX_RANK=r SIPX_WORLD=8 SIPX_DEVICE=r SIPX_ID_FILE=/dev/shm/sipx.$JOB julia --project script.jl &
+#     for r in 0:7:  SIPX_RANK=r SIPX_WORLD=8 SIPX_DEVICE=r SIPX_ID_FILE=/dev/shm/sipx.$JOB SIPX_NONCE=$JOB julia --project script.jl &
 # (or under mpiexec with SIPX_RANK / SIPX_WORLD taken from the MPI environment).  Rank 0 obtains the 128-byte ncclUniqueId
 # from the engine and publishes it through SIPX_ID_FILE; the others wait for the file.  SIPX_DECOMP=slab (default where the
 # set list allows it: bounds / l1 / l2 / annulus on the identity or D_x / D_y / D_z / TV) divides the WHOLE iteration by
@@ -139,14 +139,31 @@ function attach_comm!(ctx, set_Prop)
     world = parse(Int, ENV["SIPX_WORLD"]); rank = parse(Int, ENV["SIPX_RANK"])
     idfile = ENV["SIPX_ID_FILE"]
     id = zeros(UInt8, 128)
+    # The id file must belong to THIS launch: a rerun with the same path would otherwise hand the previous job's ncclUniqueId to
+    # ranks that find the stale file before rank 0 has replaced it (ncclCommInitRank then hangs).  Every record starts with a
+    # nonce the launcher gives all ranks (SIPX_NONCE; without one, a record older than two minutes is taken to be stale).
+    nonce = rpad(get(ENV, "SIPX_NONCE", ""), 32)[1:32]
     if rank == 0
+        rm(idfile; force=true)
         check(ccall((:sipx_rccl_unique_id, libsipx), Cint, (Ptr{UInt8},), id))
-        write(idfile * ".tmp", id); mv(idfile * ".tmp", idfile; force=true)   # published atomically
+        write(idfile * ".tmp", vcat(Vector{UInt8}(nonce), id)); mv(idfile * ".tmp", idfile; force=true)   # published atomically
     else
-        while !isfile(idfile); sleep(0.01); end
-        id = read(idfile)
+        t_start = time()
+        while true
+            if isfile(idfile) && filesize(idfile) == 160
+                rec = read(idfile)
+                fresh = haskey(ENV, "SIPX_NONCE") ? true : (mtime(idfile) >= t_start - 120.0)
+                if String(rec[1:32]) == nonce && fresh
+                    id = rec[33:160]
+                    break
+                end
+            end
+            time() - t_start > 600.0 && error("sipx: no ncclUniqueId for this launch appeared in $idfile within 10 minutes")
+            sleep(0.01)
+        end
     end
     check(ccall((:sipx_set_comm_rccl, libsipx), Cint, (Ptr{Cvoid}, Ptr{UInt8}, Cint, Cint), ctx[], id, world, rank))
+    rank == 0 && rm(idfile; force=true)       # ncclCommInitRank is collective: every rank has read the record by now
     decomp = get(ENV, "SIPX_DECOMP", slab_decomposable(set_Prop) ? "slab" : "sets")
     decomp == "slab" && check(ccall((:sipx_set_decomp, libsipx), Cint, (Ptr{Cvoid}, Cint), ctx[], 1))
     # what RCCL itself reports (ncclCommCount / ncclCommUserRank / ncclGetVersion): worth one line in the job log

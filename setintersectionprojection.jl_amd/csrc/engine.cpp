@@ -495,6 +495,10 @@ class Engine : public EngineBase {
                         sweep_applicable(SIPX_YL_FEAS | SIPX_YL_BB, probe3, true);
         if (search_batch_) set_streams_ = false;
       }
+      {
+        MultiArgs<T> probe4;
+        sweep_plain_ = sweep_applicable(0, probe4, true);
+      }
       for (const auto& st : sets_) slab_dist_logs_ |= slab_ && !mk_ && st.is_dist;
       if (x0_mode_) {
         for (int k = 0; k < 2; ++k) { x0s_base_[k] = dalloc<T>(N + 2 * halo_); x0s_[k] = x0s_base_[k] + halo_; }
@@ -616,6 +620,10 @@ class Engine : public EngineBase {
       if (!x0_mode_) s.s0 = dalloc<T>(s.Mpad);
       s.y0 = halloc(s.Mpad); s.l0 = halloc(s.Mpad);       // take turns with y, l as the current iterate: same halo
       if (!s.ident) s.dy = halloc(s.Mpad);
+      // the third pair of the one-sweep update (two plain iterations in a row: the snapshot has to survive in the other pair
+      // and the sweep never writes in place) -- allocated HERE, so that running out of memory is an error of sipx_finalize and
+      // not of an iteration whose state has already advanced
+      if (sweep_plain_) { s.y2 = halloc(s.Mpad); s.l2 = halloc(s.Mpad); }
       if (s.custom) upload_custom(s);
       if (s.ext_kind && !s.dist_ext) {
         s.spec.lb = s.host_lb.empty() ? nullptr : s.host_lb.data();
@@ -680,6 +688,7 @@ class Engine : public EngineBase {
     if (warm && x0) SIPX_HIP(hipMemcpy(x_, x0, Nx_ * sizeof(T), hipMemcpyHostToDevice));   // Minkowski: [u; v], 2N entries
 
     assemble_Q();
+    if (q_fused_ && !stencil_q_ && !comm_ && cds_.march != 0) Q2_ = dalloc<T>((size_t)Nx_ * cds_.d);     // (SIPX_Q_FUSED=1 only)
     finalized_ = true;
 
     // initial feasibility ||P_i(A_i m) - A_i m|| / (||A_i m|| + 100 eps)   (PARSDMM_initialize.jl:97-99)
@@ -819,7 +828,7 @@ class Engine : public EngineBase {
     // as both r and p and writes r_1 into the r buffer, so the copy p <- r is never made
     bool done = false;
     if (q_pending_ && !stencil_q_ && !comm_ && r0 == 0 && r1 == Nx_) {
-      if (!Q2_) { TallyGuard tally(&dev_bytes_); Q2_ = dalloc<T>((size_t)Nx_ * cds_.d); }
+      if (!Q2_) throw std::runtime_error("internal: the second copy of Q (SIPX_Q_FUSED) was not allocated at sipx_finalize");
       done = K<T>::resid_qupdate(stream_, G_, Nx_, Q_, Q2_, cds_, q_pending_args_, x_, rhs_, p_, (T*)nullptr, xold_, part_cg_);
       if (done) { std::swap(Q_, Q2_); q_pending_ = false; }
     }
@@ -1634,15 +1643,7 @@ class Engine : public EngineBase {
       SetState<T>& s = sets_[i];
       SetArgs<T> a = set_args(s, (T)rho[i], (T)gamma[i], flags);
       target[i] = (!first && !bb && s.snap == 1) ? 2 : 0;
-      if (target[i] == 2 && !s.y2) {
-        TallyGuard tally(&dev_bytes_);
-        T* by = dalloc<T>(s.Mpad + halo_);
-        T* bl = dalloc<T>(s.Mpad + halo_);
-        s.halo_allocs.push_back(by);
-        s.halo_allocs.push_back(bl);
-        s.y2 = by + halo_;
-        s.l2 = bl + halo_;
-      }
+      if (target[i] == 2 && !s.y2) throw std::runtime_error("internal: the third y / l pair of the sweep was not allocated at sipx_finalize");
       T* ty = target[i] == 2 ? s.y2 : s.y0;
       T* tl = target[i] == 2 ? s.l2 : s.l0;
       for (int qb = 0; qb < s.nblk_or1(); ++qb) {
@@ -3077,6 +3078,7 @@ class Engine : public EngineBase {
   unsigned spec_seq_ = 0;
   long long spec_searches_ = 0, spec_fallbacks_ = 0, spec_rounds_ = 0;     // searches through the speculative exchange / of those, fallbacks / refinement rounds (all-reduces) of the fallbacks
   bool spec_exchange_ = true;         // SIPX_SPEC_EXCHANGE=0: every search through (all-reduce, ..., all-gather), as before
+  bool sweep_plain_ = false;          // the sweep takes the plain iterations of this context: every set carries a third y / l pair
   bool search_batch_ = false;         // one rank + sweep: the searches of all sets as one chain of launches (batched_searches; SIPX_SEARCH_BATCH=0: per-set chains on the set streams)
   long long batch_searches_ = 0, batch_fallbacks_ = 0;
   bool spec_batch_ = true;            // SIPX_SPEC_BATCH=0: the small steps of the exchange as one kernel per set on the set streams

@@ -143,3 +143,45 @@ def test_planned_q_update_is_bit_identical(sipx, monkeypatch, TF, n, h, kinds, f
             changed = [i for i in range(p) if TF(rhos[step][i]) != TF(rhos[step - 1][i])]
             Qo = O.Q_update(Qo.copy(order="F"), AtAo, propo, np.array(rhos[step], TF), changed, log, 0, offo)
         assert np.array_equal(Q1, Qo), step
+
+
+def test_full_size_c2_solver_properties(sipx):
+    """BASELINE configs[1] at its own size -- 2048 x 2048 Float32, {bounds on I, l1 on TV = [D_z; D_x]} + distance term, h = (25, 6)
+    as examples/projection_intersection_2D.jl:45 -- solved through the product's entry point: finite logs, the zero-start
+    conventions of the first iteration (cg.jl:51), per-set log shapes (PARSDMM_initialize.jl:233-236), the TV set gets closer to
+    feasible and ends inside 1.5 feas_tol like the reference's own solver test asks (test_PARSDMM.jl:86-89), y of the l1 set lies
+    in its ball, x within the bounds' reach, a second solve warm-started from (x, l, y) stops at once with the same x, and a model
+    that is feasible for every set comes back untouched (PARSDMM.jl:63-82)."""
+    TF, n, h = np.float32, (2048, 2048), (25.0, 6.0)
+    rng = np.random.default_rng(20240601 + 2)
+    z = np.linspace(0.0, 1.0, n[1]).reshape(1, -1)
+    m = (1500.0 + 2500.0 * z + 150.0 * rng.standard_normal(n)).astype(TF).reshape(-1, order="F")
+    g = sipx.compgrid(h, n)
+    TV = sipx.get_TD_operator(g, "TV", TF)[0]
+    sigma = float(0.5 * np.abs((TV @ m).astype(np.float64)).sum())
+    c = [sipx.set_definitions("bounds", "identity", 1600.0, 3900.0, ("matrix", "")),
+         sipx.set_definitions("l1", "TV", 0.0, sigma, ("matrix", ""))]
+    P, A, prop = sipx.setup_constraints(c, g, TF)
+    opt = sipx.PARSDMM_options(FL=TF, maxit=300)
+    A, AtA, _, _ = sipx.PARSDMM_precompute_distribute(A, prop, g, opt)
+    x, log, l, y = sipx.PARSDMM(m.copy(), AtA, A, prop, P, g, opt)
+    it = len(log.obj)
+    assert 6 < it <= 300
+    for v in (log.obj, log.r_pri, log.r_dual, log.rho, log.gamma, log.set_feasibility):
+        assert np.isfinite(v).all()
+    assert np.isnan(log.evol_x[0]) and log.cg_it[0] == 0 and (log.cg_it[1:] >= 1).all() and log.cg_it.max() < 40
+    assert log.r_pri.shape == (it, 3) and log.set_feasibility.shape[1] == 2 and len(y) == 3
+    assert [len(v) for v in y] == [op.shape[0] for op in A] == [n[0] * n[1], n[0] * (n[1] - 1) + (n[0] - 1) * n[1], n[0] * n[1]]
+    f0, f1 = log.set_feasibility[0], log.set_feasibility[-1]
+    assert f0[1] > 0.3 and f1[1] < f0[1] and (it == 300 or f1.max() < 1.5 * float(opt.feas_tol)), (it, f0, f1)
+    assert np.abs(y[1].astype(np.float64)).sum() <= sigma * (1 + 1e-5)
+    assert x.min() > 1500.0 and x.max() < 4000.0 and np.isfinite(x).all()
+    # the l1 norm of TV x itself has come down to the radius (to the feasibility the solve stopped at)
+    tvx = float(np.abs((TV @ x).astype(np.float64)).sum())
+    assert tvx <= sigma * (1 + 2 * max(float(f1[1]), 1e-3)), (tvx, sigma)
+    opt2 = sipx.PARSDMM_options(FL=TF, maxit=50, zero_ini_guess=False, rho_ini=[float(r) for r in log.rho[-1]])
+    x2, log2, _, _ = sipx.PARSDMM(m.copy(), AtA, A, prop, P, g, opt2, x.copy(), [v.copy() for v in l], [v.copy() for v in y])
+    assert len(log2.obj) <= 50 and np.linalg.norm(x2.astype(np.float64) - x) <= 2e-3 * np.linalg.norm(x.astype(np.float64))
+    flat = np.full(m.size, 2500.0, TF)
+    xf, logf, _, _ = sipx.PARSDMM(flat.copy(), AtA, A, prop, P, g, opt)
+    assert np.array_equal(xf, flat) and len(logf.obj) == 1
