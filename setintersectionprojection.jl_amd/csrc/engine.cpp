@@ -224,7 +224,7 @@ class Engine : public EngineBase {
     (void)hipSetDevice(device_);
     (void)hipStreamSynchronize(stream_);
     for (auto& s : sets_) free_set(s);
-    for (void* p : {(void*)x0s_base_[0], (void*)x0s_base_[1], (void*)w_base_, (void*)x_base_, (void*)xold_, (void*)rhs_, (void*)m_base_, (void*)r_base_, (void*)p_base_, (void*)p2_base_, (void*)Ap_, (void*)Q_, (void*)Q2_,
+    for (void* p : {(void*)xr_base_[0], (void*)xr_base_[1], (void*)xr_base_[2], (void*)w_base_, (void*)rhs_, (void*)m_base_, (void*)r_base_, (void*)p_base_, (void*)p2_base_, (void*)Ap_, (void*)Q_, (void*)Q2_,
                     (void*)scr_v_, (void*)scr_c_, (void*)scr_i_, (void*)scr_w_, (void*)part_cg_, (void*)part_tmp_, (void*)part_sets_,
                     (void*)maxpart_, (void*)cg_dev_, (void*)gbuf_, (void*)stage_, (void*)sstage_, (void*)fbuf_})
       dfree(p);
@@ -436,9 +436,11 @@ class Engine : public EngineBase {
       Gyl_.e0 = (prev_ >= 0) ? r0_ - plane_ : r0_; Gyl_.e1 = r1_; Gyl_.s0 = r0_;
       if (r1_ <= r0_) { Gr_.e0 = Gr_.e1 = 0; Gyl_.e0 = Gyl_.e1 = 0; }
     }
-    x_base_ = dalloc<T>(Npad + 2 * halo_); x_ = x_base_ + halo_;
+    for (int k = 0; k < 3; ++k) { xr_base_[k] = dalloc<T>(Npad + 2 * halo_); xr_[k] = xr_base_[k] + halo_; }
+    x_cur_ = 0; x_snap_ = -1;
+    x_ = xr_[0]; xold_ = x_;                // (no x-step yet: x_old names x itself)
     p_base_ = dalloc<T>(Nx_ + 2 * halo_); p_ = p_base_ + halo_;
-    xold_ = dalloc<T>(Nx_); rhs_ = dalloc<T>(Npad);
+    rhs_ = dalloc<T>(Npad);
     if (mk_) { w_base_ = dalloc<T>(N + 2 * halo_); w_ = w_base_ + halo_; }   // u + v, read through the stencils
     m_base_ = dalloc<T>(N + 2 * halo_); m_ = m_base_ + halo_;   // forward stencils of A m read past the end
     r_base_ = dalloc<T>(Nx_ + 2 * halo_); r_ = r_base_ + halo_;      // (halo: the fused CG product reads r through the bands)
@@ -500,9 +502,7 @@ class Engine : public EngineBase {
         sweep_plain_ = sweep_applicable(0, probe4, true);
       }
       for (const auto& st : sets_) slab_dist_logs_ |= slab_ && !mk_ && st.is_dist;
-      if (x0_mode_) {
-        for (int k = 0; k < 2; ++k) { x0s_base_[k] = dalloc<T>(N + 2 * halo_); x0s_[k] = x0s_base_[k] + halo_; }
-      }
+      // (the snapshot of x of the x0 mode is a member of the ring of x buffers: nothing to allocate)
     }
     long long maxpad = N;
     for (auto& s : sets_) maxpad = std::max(maxpad, s.Mpad);
@@ -829,13 +829,14 @@ class Engine : public EngineBase {
     bool done = false;
     if (q_pending_ && !stencil_q_ && !comm_ && r0 == 0 && r1 == Nx_) {
       if (!Q2_) throw std::runtime_error("internal: the second copy of Q (SIPX_Q_FUSED) was not allocated at sipx_finalize");
-      done = K<T>::resid_qupdate(stream_, G_, Nx_, Q_, Q2_, cds_, q_pending_args_, x_, rhs_, p_, (T*)nullptr, xold_, part_cg_);
+      done = K<T>::resid_qupdate(stream_, G_, Nx_, Q_, Q2_, cds_, q_pending_args_, x_, rhs_, p_, (T*)nullptr, (T*)nullptr, part_cg_);
       if (done) { std::swap(Q_, Q2_); q_pending_ = false; }
     }
     if (!done) {
       flush_q_pending();
-      if (stencil_q_) K<T>::sq_resid(stream_, G_, sq_, x_, rhs_, p_, (T*)nullptr, xold_, part_cg_);
-      else K<T>::resid(stream_, Nx_, r0, r1, Q_, cds_, x_, rhs_, p_, (T*)nullptr, xold_, part_cg_);
+      // (x_old is not written: the x-step leaves x_k behind in its own buffer, see the ring of x buffers)
+      if (stencil_q_) K<T>::sq_resid(stream_, G_, sq_, x_, rhs_, p_, (T*)nullptr, (T*)nullptr, part_cg_);
+      else K<T>::resid(stream_, Nx_, r0, r1, Q_, cds_, x_, rhs_, p_, (T*)nullptr, (T*)nullptr, part_cg_);
     }
     if (comm_) {         // ||r_0||^2, ||rhs||^2 block partials [+ the per-set sums of the y/l update queued just before]; p_1 = r_0 is in p_
       comm_->allreduce_with_halo(part_cg_, (size_t)(2 * NB + merged_nslots_), SIPX_F64, p_ + r0, p_ + r0 - plane_, prev_, p_ + r1 - plane_,
@@ -866,12 +867,16 @@ class Engine : public EngineBase {
     // The host enqueues iteration k+1 as soon as the ticket word says that k did not converge, which workgroup 0 of the
     // p-update publishes before it starts streaming: the GPU does not idle on the round trip and nothing is launched
     // for an iteration that does not run.
+    // where this x-step writes x: a ring buffer that holds neither the current x nor the snapshot of the x0 mode
+    int tgt = 0;
+    while (tgt == x_cur_ || tgt == x_snap_) ++tgt;
+    T* const xn = xr_[tgt];
     auto enqueue = [&](int k) {
       CgState<T>* mirror = cg_host_ + (k & 1);
       if (stencil_q_) K<T>::sq_spmv_dot(stream_, G_, sq_, p_, Ap_, part_cg_, cg_dev_);
       else K<T>::spmv_dot(stream_, Nx_, r0, r1, Q_, cds_, p_, Ap_, part_cg_, cg_dev_);
       if (comm_) comm_->allreduce_sum(part_cg_, NB, SIPX_F64, stream_);
-      K<T>::cg_update_xr(stream_, nloc, x_ + r0, (k == 1 ? p_ : r_) + r0, r_ + r0, p_ + r0, Ap_ + r0, part_cg_, cg_dev_, mirror, k,
+      K<T>::cg_update_xr(stream_, nloc, (k == 1 ? x_ : xn) + r0, xn + r0, (k == 1 ? p_ : r_) + r0, r_ + r0, p_ + r0, Ap_ + r0, part_cg_, cg_dev_, mirror, k,
                          (unsigned long long*)ticket_, hlo, hhi);
       if (comm_)
         comm_->allreduce_with_halo(part_cg_ + NB, NB, SIPX_F64, r_ + r0, r_ + r0 - plane_, prev_, r_ + r1 - plane_, r_ + r1, next_,
@@ -886,7 +891,7 @@ class Engine : public EngineBase {
       T* pk = (k & 1) ? p_ : p2_;
       T* pn = (k & 1) ? p2_ : p_;
       if (k == 1) K<T>::spmv_dot(stream_, Nx_, r0, r1, Q_, cds_, p_, Ap_, part_cg_, cg_dev_);
-      K<T>::cg_update_xr(stream_, nloc, x_, k == 1 ? p_ : r_, r_, pk, Ap_, part_cg_, cg_dev_, mirror, k, (unsigned long long*)ticket_);
+      K<T>::cg_update_xr(stream_, nloc, k == 1 ? x_ : xn, xn, k == 1 ? p_ : r_, r_, pk, Ap_, part_cg_, cg_dev_, mirror, k, (unsigned long long*)ticket_);
       K<T>::spmv_fused(stream_, Nx_, Q_, cds_, r_, pk, pn, Ap_, part_cg_, cg_dev_, mirror, (unsigned long long*)ticket_);
     };
     // (no event is recorded inside this loop: a record costs the stream about 5 us, more than the p-update of a small grid)
@@ -900,11 +905,12 @@ class Engine : public EngineBase {
     auto enq = [&](int k) { if (cg_fused_) enqueue_fused(k); else enqueue(k); };
     if (ahead) enq(1);
     bool done = wait_ticket(seq, 0, cg_host_);
+    const bool done_at_begin = done;
     CgState<T> fin;
     if (done) {
       fin = cg_host_[0];
       drop_samples_from(stat0);          // the iteration queued ahead returned at once: not a sample of its kernels
-      if (fin.flag == -9) SIPX_HIP(hipMemsetAsync(x_ + r0 - hlo, 0, (nloc + hlo + hhi) * sizeof(T), stream_));   // cg.jl:51 (the copies of the neighbours' planes too)
+      if (fin.flag == -9) SIPX_HIP(hipMemsetAsync(xn + r0 - hlo, 0, (nloc + hlo + hhi) * sizeof(T), stream_));   // cg.jl:51 (the copies of the neighbours' planes too)
     } else {
       const int maxIter = 1000;                       // argmin_x.jl:39
       int iter = 1;
@@ -919,6 +925,16 @@ class Engine : public EngineBase {
       fin = cg_host_[iter & 1];         // written before the ticket (release / acquire): complete
     }
     cg_host_[0] = fin;
+    // Did the solve write x?  Zero right-hand side (flag -9): x = 0, into the target buffer.  x already good enough (cg.jl:73-76),
+    // or the very first step refused (flag -2 at iteration 1, cg.jl:91-93): x is what it was, and x_old names the same buffer.
+    const bool wrote = fin.flag == -9 || (!done_at_begin && !(fin.flag == -2 && fin.iters <= 1));
+    if (wrote) {
+      xold_ = x_;
+      x_cur_ = tgt;
+      x_ = xn;
+    } else {
+      xold_ = x_;
+    }
     if (comm_) {
       // obj / evol_x sums over the slab (x_old is only kept for the slab), then x is completed on every rank
       // (slab-decomposed with a distance term: the y/l update of that set forms the same three sums over the same rows -- x, m
@@ -1666,15 +1682,15 @@ class Engine : public EngineBase {
       }
     }
     ma.x = x_; ma.m = m_; ma.xold = xold_;
-    ma.x0 = x0_mode_ ? x0s_[x0_cur_] : nullptr;
-    ma.x0w = x0_mode_ ? x0s_[x0_cur_ ^ 1] : nullptr;
+    // x0 mode: s_0 = A x_0 from the ring buffer that held x on the last BB / first iteration; the new snapshot is x itself --
+    // the coming x-steps leave its buffer alone (argmin_x)
+    ma.x0 = (x0_mode_ && x_snap_ >= 0) ? xr_[x_snap_] : (x0_mode_ ? x_ : nullptr);
+    ma.x0w = nullptr;
     ma.rhs = fuse_rhs_ ? rhs_ : nullptr;
     ma.partials = part_sets_;
-    if (x0_mode_ && slab_ && (first || bb) && next_ >= 0 && r1_ > r0_)        // the plane behind the slab belongs to the snapshot too
-      SIPX_HIP(hipMemcpyAsync(x0s_[x0_cur_ ^ 1] + r1_, x_ + r1_, plane_ * sizeof(T), hipMemcpyDeviceToDevice, stream_));
     if (!K<T>::yl_multi(stream_, G_, ma)) throw std::runtime_error("internal: the fused y/l sweep refused a block list it was prepared for");
     rhs_fused_ = ma.rhs != nullptr;
-    if (x0_mode_ && (first || bb)) x0_cur_ ^= 1;
+    if (x0_mode_ && (first || bb)) x_snap_ = x_cur_;
     for (int i = 0; i < p_n_; ++i) {           // (y, l) always names the current iterate; snap says where the snapshot sits
       SetState<T>& s = sets_[i];
       if (target[i] == 2) {
@@ -2039,12 +2055,10 @@ class Engine : public EngineBase {
         mark(1);
         R.rhs_ready = true;
       }
-      // (the product overwrites x_old: it may only be queued ahead when obj / evol_x of THIS iteration come out of the y/l
-      //  update itself -- the distance term's sums, or the slab sums of a sharded x-step.  A feasibility-only context has
-      //  neither: log_scalars reads x_old after this point, so there the product waits)
-      bool log_sums_from_update = comm_ != nullptr;
-      for (const auto& st : sets_) log_sums_from_update |= st.is_dist && st.owned;
-      if (R.rhs_ready && resid_ahead_ && log_sums_from_update) {     // ... and so is the residual product of the coming x-step
+      // (round 3 had the product store x_old <- x, which a context without a distance term -- feasibility only -- still had to read
+      //  for evol_x after this point: its logged evol_x was zero.  The product no longer touches x_old: x_k stays behind in its own
+      //  ring buffer when the x-step moves on, tests/test_gpu_round4.py::test_feasibility_only_logs_evol_x...)
+      if (R.rhs_ready && resid_ahead_) {     // ... and so is the residual product of the coming x-step
         argmin_x_head();
         if (comm_) {                         // (sharded: the sums arrive with the grouped call of the head)
           mark(2);
@@ -3088,8 +3102,12 @@ class Engine : public EngineBase {
   bool l1_sample_ = true;             // SIPX_L1_SAMPLE=0: no sampled prediction of theta (A/B switch)
   bool yl_multi_ = true;              // SIPX_YL_MULTI=0: never take the one-sweep y/l update (A/B switch)
   bool x0_mode_ = false;              // s_0 = A x_0 recomputed from a snapshot of x (see finalize)
-  T *x0s_base_[2] = {nullptr, nullptr}, *x0s_[2] = {nullptr, nullptr};
-  int x0_cur_ = 0;
+  // x lives in a RING of three buffers (round 4): the x-step writes x_{k+1} = x_k + alpha_1 p_1 into a buffer that holds neither
+  // x_k nor the Barzilai-Borwein snapshot x_0 and goes on in place there, so x_k stays behind untouched as x_old (the reference's
+  // copy, PARSDMM.jl:128, is never made -- the residual product used to write it: 1 N w per iteration) and the snapshot of the
+  // x0 mode is simply the buffer that held x on the last BB / first iteration (1 N w per BB iteration written before).
+  T *xr_base_[3] = {nullptr, nullptr, nullptr}, *xr_[3] = {nullptr, nullptr, nullptr};
+  int x_cur_ = 0, x_snap_ = -1;
   bool fuse_rhs_ = false;             // the whole-solve loop: rho cannot change before the next iteration, so the sweep may write its rhs
   bool rhs_fused_ = false;            // ... and did
   std::vector<hipEvent_t> ev_;

@@ -456,7 +456,8 @@ static void launch_cds(hipStream_t s, long long N, long long r0, long long r1, c
   int read_bands = a.d;
   if (a.sym) { read_bands = 0; for (int b = 0; b < a.d; ++b) read_bands += a.off[b] >= 0 ? 1 : 0; }
   const double rw = (double)(r1 - r0) * sizeof(T), extra = MODE == 2 ? 4.0 : 2.0;
-  ObsScope obs(MODE == 0 ? KID_CDS_SPMV : (MODE == 1 ? KID_CDS_DOT : KID_CDS_RESID), s, (a.d + extra) * rw, (read_bands + extra) * rw);
+  const double moved_extra = (MODE == 2 && !xold) ? 3.0 : extra;      // (x_old kept by buffer rotation: not written)
+  ObsScope obs(MODE == 0 ? KID_CDS_SPMV : (MODE == 1 ? KID_CDS_DOT : KID_CDS_RESID), s, (a.d + extra) * rw, (read_bands + moved_extra) * rw);
   if (try_march<T, MODE>(s, N, r0, r1, R, a, x, y, b, pout, xold, partials, done)) {
     SIPX_HIP(hipGetLastError());
     return;
@@ -558,7 +559,7 @@ __global__ __launch_bounds__(BLOCK) void k_sq(Grid G, StencilQ<T> q, const T* __
       }
       stv<T, V>(y + r, o);
       if (pout) stv<T, V>(pout + r, o);
-      stv<T, V>(xold + r, xv);
+      if (xold) stv<T, V>(xold + r, xv);
     }
   }
   if (MODE == 1) {
@@ -982,7 +983,7 @@ void K<T>::cg_begin(hipStream_t s, double* partials, CgState<T>* st, CgState<T>*
 //
 // alpha = dot(r,z) / dot(p,Ap) ; x += alpha p ; r -= alpha Ap ; partial ||r||^2 (slot 1)   (cg.jl:83-100)
 template <typename T, int V>
-__global__ __launch_bounds__(BLOCK) void k_cg_update_xr(long long N, T* __restrict__ x, const T* r_in, T* r,
+__global__ __launch_bounds__(BLOCK) void k_cg_update_xr(long long N, const T* x_in, T* x, const T* r_in, T* r,
                                                         const T* p, const T* __restrict__ Ap,
                                                         double* __restrict__ partials, CgState<T>* __restrict__ st,
                                                         CgState<T>* __restrict__ host, int iter,
@@ -1008,7 +1009,9 @@ __global__ __launch_bounds__(BLOCK) void k_cg_update_xr(long long N, T* __restri
   const long long nvec = N / V;
   double acc[1] = {0};
   for (long long vi = (long long)blockIdx.x * BLOCK + threadIdx.x; vi < nvec; vi += (long long)gridDim.x * BLOCK) {
-    Vec<T, V> xv = ldv<T, V>(x + vi * V), rv = ldv<T, V>(r_in + vi * V);     // r_in == p on the first iteration (p_1 = r_0)
+    // x_in: the iterate the solve started from on the first iteration (it stays behind untouched as x_old: the engine's x
+    // buffers take turns, PARSDMM.jl:128's copy is never made), x itself afterwards
+    Vec<T, V> xv = ldv<T, V>(x_in + vi * V), rv = ldv<T, V>(r_in + vi * V);     // r_in == p on the first iteration (p_1 = r_0)
     const Vec<T, V> pv = ldv<T, V>(p + vi * V), av = ldv_nt<T, V>(Ap + vi * V);     // Ap: written and read once per iteration
 #pragma unroll
     for (int k = 0; k < V; ++k) {
@@ -1023,18 +1026,18 @@ __global__ __launch_bounds__(BLOCK) void k_cg_update_xr(long long N, T* __restri
   // here: same alpha, same operands, same bits), so that x never has to be exchanged after the solve
   for (long long j = (long long)blockIdx.x * BLOCK + threadIdx.x; j < hlo + hhi; j += (long long)gridDim.x * BLOCK) {
     const long long i = j < hlo ? j - hlo : N + (j - hlo);
-    x[i] = x[i] + alpha * p[i];
+    x[i] = x_in[i] + alpha * p[i];
   }
   block_reduce_store<1>(acc, partials, 1);    // its own slot: other workgroups may still be reading slot 0
 }
 template <typename T>
-void K<T>::cg_update_xr(hipStream_t s, long long N, T* x, const T* r_in, T* r, const T* p, const T* Ap, double* partials,
+void K<T>::cg_update_xr(hipStream_t s, long long N, const T* x_in, T* x, const T* r_in, T* r, const T* p, const T* Ap, double* partials,
                         CgState<T>* st, CgState<T>* host, int iter, unsigned long long* ticket, long long hlo, long long hhi) {
   ObsScope obs(KID_CG_XR, s, 6.0 * (double)N * sizeof(T));        // x, r, p, Ap read; x, r written
-  if (N % 4 == 0 && aligned16(x, r_in, r, p, Ap))
-    hipLaunchKernelGGL((k_cg_update_xr<T, 4>), dim3(fit_grid(N / 4, SIPX_CG_GRID)), dim3(BLOCK), 0, s, N, x, r_in, r, p, Ap, partials, st, host, iter, ticket, hlo, hhi);
+  if (N % 4 == 0 && aligned16(x, r_in, r, p, Ap) && aligned16(x_in, x))
+    hipLaunchKernelGGL((k_cg_update_xr<T, 4>), dim3(fit_grid(N / 4, SIPX_CG_GRID)), dim3(BLOCK), 0, s, N, x_in, x, r_in, r, p, Ap, partials, st, host, iter, ticket, hlo, hhi);
   else
-    hipLaunchKernelGGL((k_cg_update_xr<T, 1>), dim3(fit_grid(N, SIPX_CG_GRID)), dim3(BLOCK), 0, s, N, x, r_in, r, p, Ap, partials, st, host, iter, ticket, hlo, hhi);
+    hipLaunchKernelGGL((k_cg_update_xr<T, 1>), dim3(fit_grid(N, SIPX_CG_GRID)), dim3(BLOCK), 0, s, N, x_in, x, r_in, r, p, Ap, partials, st, host, iter, ticket, hlo, hhi);
   SIPX_HIP(hipGetLastError());
 }
 
@@ -1243,7 +1246,7 @@ void K<T>::copy_f64(hipStream_t s, const double* src, double* dst, int n) {
   template void K<T>::q_update(hipStream_t, const Grid&, long long, long long, const CdsArgs&, const QArgs<T>&, T*);  \
   template void K<T>::gen_ata(hipStream_t, const Grid&, int, const int*, const T*, int, const long long*, T*);       \
   template void K<T>::cg_begin(hipStream_t, double*, CgState<T>*, CgState<T>*, int, T, unsigned, unsigned long long*);  \
-  template void K<T>::cg_update_xr(hipStream_t, long long, T*, const T*, T*, const T*, const T*, double*, CgState<T>*, \
+  template void K<T>::cg_update_xr(hipStream_t, long long, const T*, T*, const T*, T*, const T*, const T*, double*, CgState<T>*, \
                                    CgState<T>*, int, unsigned long long*, long long, long long);                     \
   template void K<T>::cg_update_p(hipStream_t, long long, T*, const T*, const double*, CgState<T>*, CgState<T>*,     \
                                   unsigned long long*, long long, long long);                                        \

@@ -260,7 +260,7 @@ __global__ __launch_bounds__(MULTI_NT, SIPX_MULTI_WAVES) void k_yl_multi(Grid G,
           if constexpr (NY > 0) x0py = ldv_u<T, V>(a.x0 + pz + st1 + go);
         }
         // the new snapshot goes into the OTHER snapshot array: neighbouring threads, tiles and chunks still read the old one
-        if (x0mode && (f_bb || f_first) && active) stv_nt<T, V>(a.x0w + pz + go, xc);
+        if (x0mode && a.x0w && (f_bb || f_first) && active) stv_nt<T, V>(a.x0w + pz + go, xc);     // (x0w == nullptr: the caller keeps x itself as the snapshot)
       }
       // ---- phase A: the update of every block; w = rho y + l and y - y_old stay in registers ---------------------------
       T wv[NBLK][V], dv[NBLK][V];
@@ -627,7 +627,7 @@ bool K<T>::yl_multi(hipStream_t s, const Grid& g, const MultiArgs<T>& a, bool pr
   const bool first = (a.flags & F_FIRST) != 0, bb = (a.flags & F_BB) != 0 && !first;
   const bool x0m = a.x0 != nullptr;       // s_0 recomputed from the snapshot of x: per block 4 (2) instead of 6 (3), + the snapshot itself
   for (int b = 0; b < a.nblk; ++b) vecs += 4.0 + (a.b[b].dist ? 2.0 : 0.0) + (bb ? (x0m ? 4.0 : 6.0) : (first ? (x0m ? 1.0 : 2.0) : 0.0));
-  if (x0m) vecs += bb ? 2.0 : (first ? 1.0 : 0.0);
+  if (x0m) vecs += (bb ? 1.0 : 0.0) + ((a.x0w && (bb || first)) ? 1.0 : 0.0);
   const double bytes = vecs * pts * sizeof(T);
 #define SIPX_TRY_LAYOUT(LL)                                    \
   if (code == (LL)) {                                          \

@@ -492,7 +492,7 @@ struct K {
   // CG
   static void cg_begin(hipStream_t s, double* partials, CgState<T>* st, CgState<T>* host, int it_outer, T tol_ref,
                        unsigned seq, unsigned long long* ticket);
-  static void cg_update_xr(hipStream_t s, long long N, T* x, const T* r_in, T* r, const T* p, const T* Ap, double* partials,
+  static void cg_update_xr(hipStream_t s, long long N, const T* x_in, T* x, const T* r_in, T* r, const T* p, const T* Ap, double* partials,
                            CgState<T>* st, CgState<T>* host, int iter, unsigned long long* ticket, long long hlo = 0,
                            long long hhi = 0);      // hlo / hhi: elements in front of / behind the range whose x (p) follows along
   static void cg_update_p(hipStream_t s, long long N, T* p, const T* r, const double* partials, CgState<T>* st,
