@@ -839,7 +839,10 @@ def main():
                                    "all-kernel statistics window / wall time of that window (the event records of the window cost "
                                    "a few percent) / peak: the bandwidth the iteration as BUILT sustains"}
         comm_info = ctx.comm_info()
-        dev_bytes = ctx.device_bytes()
+        try:
+            dev_bytes = ctx.device_bytes()
+        except AttributeError:                               # (an older build of the library under SIPX_LIBRARY: A/B runs)
+            dev_bytes = {"context": None, "device_used": None}
         # slab-decomposed: threshold searches that went through the speculative exchange since the context was built, how many of
         # them needed their fallback, and the all-reduces (refinement rounds) those took -- the engine's own counters
         searches = per_kernel.get("slab_searches") if per_kernel else None

@@ -496,6 +496,7 @@ class Engine : public EngineBase {
         search_batch_ = !comm_ && !(sb && sb[0] == '0') && ntp >= 1 && ntp <= SPEC_MAX_SETS &&
                         sweep_applicable(SIPX_YL_FEAS | SIPX_YL_BB, probe3, true);
         if (search_batch_) set_streams_ = false;
+        if (const char* pm = std::getenv("SIPX_PASS_MULTI")) pass_multi_ = pm[0] == '1';
       }
       {
         MultiArgs<T> probe4;
@@ -1492,9 +1493,6 @@ class Engine : public EngineBase {
     rs.n = 0;
     SampleMulti<T> sm;
     sm.ns = 0;
-    LeanMulti<T> lm;
-    lm.ns = 0;
-    std::vector<size_t> lean_who;
     for (size_t j = 0; j < tp.size(); ++j) {
       SetState<T>& s = sets_[tp[j]];
       args[j] = set_args(s, (T)rho[tp[j]], (T)gamma[tp[j]], flags);
@@ -1510,22 +1508,54 @@ class Engine : public EngineBase {
         SampleSet<T>& S = sm.s[sm.ns++];
         S.a = args[j]; S.a.ps = s.ps; S.ps = s.ps; S.partials = s.ptmp; S.reg = nullptr; S.true_len = s.Mtrue;
       }
-      if (l1 && vec && !(args[j].flags & F_NOSPEC) && lm.ns < LEAN_MAX) {
-        LeanSet<T>& L = lm.s[lm.ns++];
-        L.a = args[j]; L.a.ps = s.ps; L.ps = s.ps; L.compact = s.cbuf; L.partials = s.ptmp; L.maxpart = s.mpart;
-        lean_who.push_back(j);
-      }
       s.last_rho = args[j].rho;
       s.last_gamma = args[j].gamma;
     }
     K<T>::ps_rescale_multi(stream_, rs);
     if (sm.ns > 0) K<T>::sample_multi(10, stream_, Gr_, sm, l1_sample_runs_, nullptr);
-    if (lm.ns > 0) {
-      K<T>::lean_multi(stream_, Gr_, lm);
-      for (size_t j : lean_who) {
-        ctl[j].lean_done = 1;
-        // published by the set's last solve (nothing since can have taken the flag back): its full first pass need not be launched
-        ctl[j].lean_known = (hlean_[tp[j]] >> 16) & 1;
+    // the passes: groups of up to LEAN_MAX sets per launch (x read once per group) -- the lean first passes of the l1 sets whose
+    // device-side state asks for one, then the full first passes of everybody else; each kernel returns at once when no set
+    // of its group wants it.  (A grid whose lines are no multiple of four points keeps one scalar pass per set.)
+    auto group = [&](const std::vector<size_t>& who, size_t from) {
+      LeanMulti<T> L;
+      L.ns = 0;
+      L.v_is_s = v_is_s;
+      for (size_t k = from; k < who.size() && L.ns < LEAN_MAX; ++k) {
+        const size_t j = who[k];
+        SetState<T>& s = sets_[tp[j]];
+        LeanSet<T>& S = L.s[L.ns++];
+        S.a = args[j]; S.a.ps = PS(tp[j]); S.ps = PS(tp[j]); S.compact = s.cbuf; S.partials = s.ptmp; S.maxpart = s.mpart;
+      }
+      return L;
+    };
+    std::vector<size_t> all(tp.size());
+    for (size_t j = 0; j < tp.size(); ++j) all[j] = j;
+    // (pass_multi_: the FULL first passes and the fallback passes of a group in one sweep as well -- measured and NOT the
+    //  default: eight probes for three sets make that kernel ALU-bound at 161-173 VGPRs, 512^3 first passes 800-1000 us against
+    //  3 x 285 us one after the other, refinement 1009 against 3 x 264; 512^3 116.2 against 118.7 it/s.  SIPX_PASS_MULTI=1, tests)
+    if (vec && pass_multi_) {
+      std::vector<size_t> l1s;
+      for (size_t j = 0; j < tp.size(); ++j)
+        if (sets_[tp[j]].prox == PX_L1 && !(args[j].flags & F_NOSPEC)) l1s.push_back(j);
+      for (size_t k = 0; k < l1s.size(); k += LEAN_MAX) K<T>::lean_multi(stream_, Gr_, group(l1s, k));
+      for (size_t k = 0; k < all.size(); k += LEAN_MAX) K<T>::pass_multi(0, stream_, Gr_, group(all, k), v_is_s);
+    } else {
+      // the lean first passes of the l1 sets in one sweep (x read once), a full first pass per set only where the host does not
+      // know from the set's pinned word that the pass will be a lean one (it returns at once when the device-side state says lean)
+      if (vec) {
+        std::vector<size_t> l1s;
+        for (size_t j = 0; j < tp.size(); ++j)
+          if (sets_[tp[j]].prox == PX_L1 && !(args[j].flags & F_NOSPEC)) l1s.push_back(j);
+        for (size_t k = 0; k < l1s.size(); k += LEAN_MAX) K<T>::lean_multi(stream_, Gr_, group(l1s, k));
+        for (size_t j : l1s) {
+          ctl[j].lean_done = 1;
+          ctl[j].lean_known = feas_ps ? 0 : ((hlean_[tp[j]] >> 16) & 1);      // published by the set's last solve; nothing since can have taken the flag back
+        }
+      }
+      for (size_t j = 0; j < tp.size(); ++j) {
+        SetState<T>& s = sets_[tp[j]];
+        K<T>::proj_scalars_stage(13, stream_, Gr_, args[j], v_is_s, PS(tp[j]), s.ptmp, s.mpart, s.cbuf, s.Mtrue, ctl[j], nullptr,
+                                 stage_ + j * RS, nullptr, 0);
       }
     }
     SpecPackArgs<T> pk;
@@ -1536,8 +1566,6 @@ class Engine : public EngineBase {
     fa.world = 1; fa.fchunk = (long long)tp.size() * fseg; fa.seq = seq;
     for (size_t j = 0; j < tp.size(); ++j) {
       SetState<T>& s = sets_[tp[j]];
-      K<T>::proj_scalars_stage(13, stream_, Gr_, args[j], v_is_s, PS(tp[j]), s.ptmp, s.mpart, s.cbuf, s.Mtrue, ctl[j], nullptr,
-                               stage_ + j * RS, nullptr, 0);
       SpecPackSet<T>& P = pk.s[j];
       P.ps = PS(tp[j]); P.partials = s.ptmp; P.maxpart = s.mpart; P.compact = s.cbuf;
       P.seg = fbuf_ + (long long)j * fseg;
@@ -1552,20 +1580,42 @@ class Engine : public EngineBase {
     }
     K<T>::spec_sums_pack(stream_, pk);
     K<T>::spec_finish(stream_, fa);
+    // Fallback of the sets whose pinned verdict asks for it (theta left the speculative range, or the range gathered too much):
+    // refinement pass + decision (where the decision asked for one), compaction of the bracket, solve -- the passes of all
+    // such sets in one sweep each.
+    std::vector<size_t> fb;
+    bool refine = false;
     for (size_t j = 0; j < tp.size(); ++j) {
       const unsigned w = wait_verdict(hverd_ + tp[j], seq);
       batch_searches_ += 1;
       if (!(w & 1u)) continue;
       batch_fallbacks_ += 1;
-      // Fallback of this set (theta left the speculative range, or the range gathered too much): the gated stages of the
-      // per-set chain -- refinement pass + decision (only when the decision asked for one), compaction of the bracket, solve
-      SetState<T>& s = sets_[tp[j]];
-      if (w & 2u)
-        K<T>::proj_scalars_stage(1, stream_, Gr_, args[j], v_is_s, PS(tp[j]), s.ptmp, s.mpart, s.cbuf, s.Mtrue, ctl[j], nullptr,
-                                 stage_ + j * RS, nullptr, 0);
-      for (int stage : {2, 3})
-        K<T>::proj_scalars_stage(stage, stream_, Gr_, args[j], v_is_s, PS(tp[j]), s.ptmp, s.mpart, s.cbuf, s.Mtrue, ctl[j], nullptr,
-                                 stage_ + j * RS, nullptr, 0);
+      fb.push_back(j);
+      refine |= (w & 2u) != 0;
+    }
+    if (fb.empty()) return;
+    auto tail = [&](int stage) {
+      for (size_t j : fb) {
+        SetState<T>& s = sets_[tp[j]];
+        K<T>::search_tail(stage, stream_, args[j], PS(tp[j]), s.ptmp, s.mpart, s.cbuf, s.Mtrue, ctl[j], stage_ + j * RS);
+      }
+    };
+    if (vec && pass_multi_) {
+      if (refine) {
+        for (size_t k = 0; k < fb.size(); k += LEAN_MAX) K<T>::pass_multi(1, stream_, Gr_, group(fb, k), v_is_s);
+        tail(1);
+      }
+      for (size_t k = 0; k < fb.size(); k += LEAN_MAX) K<T>::pass_multi(2, stream_, Gr_, group(fb, k), v_is_s);
+      tail(3);
+    } else {
+      for (size_t j : fb) {
+        SetState<T>& s = sets_[tp[j]];
+        for (int stage : {1, 2, 3}) {
+          if (stage == 1 && !refine) continue;
+          K<T>::proj_scalars_stage(stage, stream_, Gr_, args[j], v_is_s, PS(tp[j]), s.ptmp, s.mpart, s.cbuf, s.Mtrue, ctl[j], nullptr,
+                                   stage_ + j * RS, nullptr, 0);
+        }
+      }
     }
   }
 
@@ -3092,6 +3142,7 @@ class Engine : public EngineBase {
   unsigned spec_seq_ = 0;
   long long spec_searches_ = 0, spec_fallbacks_ = 0, spec_rounds_ = 0;     // searches through the speculative exchange / of those, fallbacks / refinement rounds (all-reduces) of the fallbacks
   bool spec_exchange_ = true;         // SIPX_SPEC_EXCHANGE=0: every search through (all-reduce, ..., all-gather), as before
+  bool pass_multi_ = false;           // SIPX_PASS_MULTI=1: full first passes / fallback passes of the batched searches in one sweep per group (measured slower)
   bool sweep_plain_ = false;          // the sweep takes the plain iterations of this context: every set carries a third y / l pair
   bool search_batch_ = false;         // one rank + sweep: the searches of all sets as one chain of launches (batched_searches; SIPX_SEARCH_BATCH=0: per-set chains on the set streams)
   long long batch_searches_ = 0, batch_fallbacks_ = 0;

@@ -315,11 +315,12 @@ __global__ __launch_bounds__(BLOCK) void k_lean_multi(Grid G, LeanMulti<T> m) {
         } else {
           fwd_dir<T, V>(G, a.x, xc, g, c, a.dir[b], a.ih[b], s, valid);
         }
-        const Vec<T, V> yv = ldv<T, V>(a.y + e), lv = ldv<T, V>(a.l + e);
+        Vec<T, V> yv = zerov<T, V>(), lv = zerov<T, V>();
+        if (!m.v_is_s) { yv = ldv<T, V>(a.y + e); lv = ldv<T, V>(a.l + e); }
 #pragma unroll
         for (int k = 0; k < V; ++k) {
           const T xh = relax ? (gam * s[k] + omg * yv.v[k]) : s[k];       // update_y_l.jl:72
-          const T vv = live ? (valid[k] ? (xh - lv.v[k] * a.rho1) : T(0)) : T(0);      // :67 / :74
+          const T vv = m.v_is_s ? (live ? s[k] : T(0)) : (live ? (valid[k] ? (xh - lv.v[k] * a.rho1) : T(0)) : T(0));      // :67 / :74
           const T av = fabs(vv);
           const double ad = (double)av;
           asum[q] += ad;
@@ -371,9 +372,194 @@ void K<T>::lean_multi(hipStream_t s, const Grid& g, const LeanMulti<T>& m) {
   if (m.ns < 1 || m.ns > LEAN_MAX || g.n[0] % 4 != 0) throw std::runtime_error("lean_multi: unsupported call");
   // (one set: the same kernel -- the caller keeps ONE chain of launches for every set list)
   double bytes = (double)range_len(g);                 // x once, y and l of every block of every set
-  for (int q = 0; q < m.ns; ++q) bytes += 2.0 * (double)m.s[q].a.nblk_or1() * (double)range_len(g);
+  for (int q = 0; q < m.ns; ++q) bytes += (m.v_is_s ? 0.0 : 2.0) * (double)m.s[q].a.nblk_or1() * (double)range_len(g);
   ObsScope obs_(KID_PASS_LEAN, s, bytes * sizeof(T));
   hipLaunchKernelGGL((k_lean_multi<T, 4>), dim3(fit_grid(range_len(g) / 4, SIPX_PASS_GRID)), dim3(BLOCK), 0, s, g, m);
+  SIPX_HIP(hipGetLastError());
+}
+
+
+// ---------------------------------------------------------------------------------------------
+// The FULL first passes, the gated refinement passes or the gated compaction passes of up to three searches in ONE sweep
+// (round 4; the lean first passes have k_lean_multi): x is read once, one launch replaces three, and sets that have nothing to
+// do in this mode (device-side state, exactly the tests k_pass makes) cost nothing.  For every set that takes part the kernel
+// does what k_pass<MODE> does -- the same thread-to-element mapping on the same grid, the same arithmetic, the same partial
+// slots in the set's own buffers, the same values gathered into the set's own buffer (in another order, which the solve does
+// not depend on) -- so sums, decisions and theta are those of the per-set passes, bit for bit.  v_is_s: the searches of the
+// feasibility estimates (the vector is s = A x itself).  Cardinality searches keep their own chain.
+template <typename T, int V, int MODE>
+__global__ __launch_bounds__(BLOCK) void k_pass_multi(Grid G, LeanMulti<T> m, int v_is_s) {
+  static_assert(MODE == M_FIRST || MODE == M_PROBE || MODE == M_COMPACT, "modes of k_pass_multi");
+  constexpr bool GATHERS = MODE == M_FIRST || MODE == M_COMPACT;
+  __shared__ T sbuf[GATHERS ? LEAN_MAX : 1][GATHERS ? SPEC_CAP : 1];
+  __shared__ unsigned int scnt[LEAN_MAX], sused[LEAN_MAX];
+  __shared__ int sovf[LEAN_MAX];
+  __shared__ unsigned long long sbase[LEAN_MAX];
+  bool on[LEAN_MAX], gather[LEAN_MAX];
+  double r_lo[LEAN_MAX], r_hi[LEAN_MAX], above_s[LEAN_MAX], above_c[LEAN_MAX];
+  T vmax[LEAN_MAX], vminp[LEAN_MAX];
+  ProbeAcc<T> pa[LEAN_MAX];
+  bool any = false;
+#pragma unroll
+  for (int q = 0; q < LEAN_MAX; ++q) {
+    on[q] = gather[q] = false;
+    r_lo[q] = 0; r_hi[q] = -1; above_s[q] = above_c[q] = 0;
+    vmax[q] = T(0); vminp[q] = (T)INFINITY;
+    if (q < m.ns) {
+      const ProjScalars<T>* ps = m.s[q].ps;
+      const SetArgs<T>& a = m.s[q].a;
+      const bool l1 = a.prox == PX_L1;
+      if (MODE == M_FIRST) {
+        if (l1 && !(a.flags & F_NOSPEC)) { r_lo[q] = ps->spec_lo; r_hi[q] = ps->spec_hi; }
+        gather[q] = r_hi[q] > r_lo[q];
+        on[q] = !(l1 && gather[q] && ps->lean != 0);       // (a lean search has had its pass: k_lean_multi / k_pass<M_LEAN>)
+      } else if (MODE == M_PROBE) {
+        on[q] = l1 && ps->need && !ps->spec_ok && ps->refine;
+      } else {
+        on[q] = l1 && ps->need && !ps->spec_ok;
+        r_lo[q] = ps->lo; r_hi[q] = ps->hi;
+        gather[q] = r_hi[q] > r_lo[q];
+      }
+      if (on[q] && l1 && MODE != M_COMPACT) {
+#pragma unroll
+        for (int k = 0; k < L1_K; ++k) pa[q].t[k] = (T)ps->t[k];      // stored TF-rounded: exact
+      }
+      any |= on[q];
+    }
+  }
+  if (!any) return;
+  if (GATHERS) {
+    if (threadIdx.x < LEAN_MAX) { scnt[threadIdx.x] = 0; sused[threadIdx.x] = 0; sovf[threadIdx.x] = 0; }
+    __syncthreads();
+  }
+  const int lane = threadIdx.x & 63;
+  long long v0, nvec;
+  vec_range<V>(G, v0, nvec);
+  const long long nit = (nvec - v0 + (long long)gridDim.x * BLOCK - 1) / ((long long)gridDim.x * BLOCK);
+  const T* x = m.s[0].a.x;
+  for (long long it = 0; it < nit; ++it) {
+    const long long vi = v0 + it * (long long)gridDim.x * BLOCK + (long long)blockIdx.x * BLOCK + threadIdx.x;
+    const bool live = vi < nvec;
+    const long long g = live ? vi * V : 0;
+    const Coord c = coords(G, g);
+    const Vec<T, V> xc = ldv<T, V>(x + g);
+#pragma unroll
+    for (int q = 0; q < LEAN_MAX; ++q) {
+      if (q >= m.ns || !on[q]) continue;
+      const SetArgs<T>& a = m.s[q].a;
+      const bool ident = a.nblk == 0;
+      const int nb = ident ? 1 : a.nblk;
+      const bool relax = !(a.gamma == T(1));
+      const T gam = a.gamma, omg = T(1) - a.gamma;
+      for (int b = 0; b < nb; ++b) {
+        const long long e = (long long)b * G.N + g;
+        T s[V];
+        bool valid[V];
+        if (ident) {
+#pragma unroll
+          for (int k = 0; k < V; ++k) { s[k] = xc.v[k]; valid[k] = true; }
+        } else {
+          fwd_dir<T, V>(G, a.x, xc, g, c, a.dir[b], a.ih[b], s, valid);
+        }
+        T out[V];
+        if (v_is_s) {
+#pragma unroll
+          for (int k = 0; k < V; ++k) out[k] = s[k];
+        } else {
+          const Vec<T, V> yv = ldv<T, V>(a.y + e), lv = ldv<T, V>(a.l + e);
+#pragma unroll
+          for (int k = 0; k < V; ++k) {
+            const T xh = relax ? (gam * s[k] + omg * yv.v[k]) : s[k];       // update_y_l.jl:72
+            out[k] = valid[k] ? (xh - lv.v[k] * a.rho1) : T(0);            // :67 / :74
+          }
+        }
+#pragma unroll
+        for (int k = 0; k < V; ++k) {
+          const T vv = live ? out[k] : T(0);
+          const T av = fabs(vv);
+          const double ad = (double)av;
+          if (MODE == M_FIRST || MODE == M_PROBE) {
+            pa[q].add(av, vv);
+            vmax[q] = av > vmax[q] ? av : vmax[q];
+            if (MODE == M_FIRST) vminp[q] = (av > T(0) && av < vminp[q]) ? av : vminp[q];
+          }
+          if (MODE == M_COMPACT && ad > r_hi[q]) { above_s[q] += ad; above_c[q] += 1.0; }
+          if (GATHERS && gather[q]) {
+            const bool in = ad > r_lo[q] && ad <= r_hi[q];
+            const unsigned long long mask = __ballot(in);
+            if (mask) {
+              const int leader = __ffsll((long long)mask) - 1;
+              const int cnt = __popcll(mask);
+              const int my = __popcll(mask & ((1ull << lane) - 1ull));
+              unsigned int base = SPEC_CAP;
+              if (lane == leader) base = atomicAdd(&scnt[q], (unsigned int)cnt);
+              base = __shfl(base, leader, 64);
+              if (base + cnt <= SPEC_CAP) {                   // room in the workgroup's LDS buffer of this set
+                if (in) sbuf[GATHERS ? q : 0][base + my] = av;
+                if (lane == leader) atomicMax(&sused[q], base + (unsigned int)cnt);
+              } else if (MODE == M_FIRST) {
+                sovf[q] = 1;                                  // speculation gathered too much: give it up
+              } else {                                        // the compaction never drops: global memory
+                unsigned long long gb = 0;
+                if (lane == leader) gb = atomicAdd(&m.s[q].ps->n_compact, (unsigned long long)cnt);
+                gb = __shfl(gb, leader, 64);
+                if (in) m.s[q].compact[gb + my] = av;
+              }
+            }
+          }
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int q = 0; q < LEAN_MAX; ++q) {
+    if (q >= m.ns || !on[q]) continue;
+    __syncthreads();                                          // (the reduction helpers share their LDS scratch between calls)
+    if (MODE == M_FIRST || MODE == M_PROBE) {
+      double acc[PREP_SLOTS];
+      pa[q].to_slots(acc);
+      block_reduce_store<PREP_SLOTS>(acc, m.s[q].partials, 0);
+      if (MODE == M_FIRST) {
+        __syncthreads();
+        block_max_store<T>(vmax[q], m.s[q].maxpart);
+        __syncthreads();
+        block_min_store<T>(vminp[q], m.s[q].maxpart + NB);
+      }
+    } else {
+      double a2[2] = {above_s[q], above_c[q]};
+      block_reduce_store<2>(a2, m.s[q].partials, SL_ABOVE_S);
+    }
+    if (GATHERS && gather[q]) {
+      __syncthreads();
+      const unsigned int cnt = sused[q];                      // reservations grow monotonically: the stored entries form the prefix [0, sused)
+      if (threadIdx.x == 0) {
+        sbase[q] = cnt ? atomicAdd(&m.s[q].ps->n_compact, (unsigned long long)cnt) : 0ull;
+        if (MODE == M_FIRST && sovf[q]) atomicOr(&m.s[q].ps->spec_overflow, 1);
+      }
+      __syncthreads();
+      for (unsigned int i = threadIdx.x; i < cnt; i += BLOCK) m.s[q].compact[sbase[q] + i] = sbuf[GATHERS ? q : 0][i];
+    }
+  }
+}
+
+template <typename T>
+void K<T>::pass_multi(int mode, hipStream_t s, const Grid& g, const LeanMulti<T>& m, int v_is_s) {
+  if (m.ns < 1 || m.ns > LEAN_MAX || g.n[0] % 4 != 0) throw std::runtime_error("pass_multi: unsupported call");
+  double bytes = (double)range_len(g);                 // x once, y and l of every block of every set (gated sets are not booked: see noop_launches)
+  for (int q = 0; q < m.ns; ++q) bytes += (v_is_s ? 0.0 : 2.0) * (double)m.s[q].a.nblk_or1() * (double)range_len(g);
+  const dim3 grid(fit_grid(range_len(g) / 4, SIPX_PASS_GRID));
+  if (mode == M_FIRST) {
+    ObsScope obs_(KID_PASS_FIRST, s, bytes * sizeof(T));
+    hipLaunchKernelGGL((k_pass_multi<T, 4, M_FIRST>), grid, dim3(BLOCK), 0, s, g, m, v_is_s);
+  } else if (mode == M_PROBE) {
+    ObsScope obs_(KID_PASS_PROBE, s, bytes * sizeof(T));
+    hipLaunchKernelGGL((k_pass_multi<T, 4, M_PROBE>), grid, dim3(BLOCK), 0, s, g, m, v_is_s);
+  } else if (mode == M_COMPACT) {
+    ObsScope obs_(KID_PASS_COMPACT, s, bytes * sizeof(T));
+    hipLaunchKernelGGL((k_pass_multi<T, 4, M_COMPACT>), grid, dim3(BLOCK), 0, s, g, m, v_is_s);
+  } else {
+    throw std::runtime_error("pass_multi: unknown mode");
+  }
   SIPX_HIP(hipGetLastError());
 }
 
@@ -2066,6 +2252,23 @@ static void launch_chain(hipStream_t s, const Grid& g, const SetArgs<T>& a, int 
 }
 
 template <typename T>
+void K<T>::search_tail(int stage, hipStream_t s, const SetArgs<T>& a, ProjScalars<T>* ps, double* partials, T* maxpart, T* compact,
+                       long long true_len, SampleCtl ctl, double* reg) {
+  static const double capdiv = [] { const char* e = getenv("SIPX_L1_CAPDIV"); return e ? atof(e) : 64.0; }();
+  if (a.prox != PX_L1) return;
+  if (stage == 1) {
+    const DecideArgs da1{a.prox, 0, (double)a.plo, (double)a.phi, capdiv, 0.0, true_len};
+    ObsScope obs_(KID_SLOT_SUMS, s, 0.0);
+    hipLaunchKernelGGL((k_slot_sums<T, 1, true>), dim3(PREP_SLOTS), dim3(BLOCK), 0, s, partials, maxpart, ps, 0, 1, reg ? reg : ps->red, da1);
+  } else {
+    ObsScope obs_(KID_L1_SOLVE, s, 0.0);
+    hipLaunchKernelGGL((k_l1_solve<T>), dim3(SOLVE_G), dim3(SIPX_SOLVE_NT), 0, s, ps, a.phi, compact, partials, true_len, l1_hw_max(), l1_lean_on(),
+                       ctl.host_want, solve_coop_min(), 0);
+  }
+  SIPX_HIP(hipGetLastError());
+}
+
+template <typename T>
 void K<T>::proj_scalars_set(hipStream_t s, const Grid& g, const SetArgs<T>& a, int v_is_s, ProjScalars<T>* ps,
                             double* partials, T* maxpart, T* compact, long long true_len, SampleCtl ctl, const ChainHooks* hooks) {
   SetArgs<T> b = a;
@@ -2128,6 +2331,8 @@ void K<T>::proj_dist_set(hipStream_t s, const Grid& g, const SetArgs<T>& a, int 
   template void K<T>::proj_scalars_set(hipStream_t, const Grid&, const SetArgs<T>&, int, ProjScalars<T>*, double*, \
                                        T*, T*, long long, SampleCtl, const ChainHooks*);                                        \
   template void K<T>::lean_multi(hipStream_t, const Grid&, const LeanMulti<T>&);                                                        \
+  template void K<T>::pass_multi(int, hipStream_t, const Grid&, const LeanMulti<T>&, int);                                              \
+  template void K<T>::search_tail(int, hipStream_t, const SetArgs<T>&, ProjScalars<T>*, double*, T*, T*, long long, SampleCtl, double*);   \
   template void K<T>::spec_sums_pack(hipStream_t, const SpecPackArgs<T>&);                                                              \
   template void K<T>::ps_rescale_multi(hipStream_t, const RescaleMulti<T>&);                                                            \
   template void K<T>::sample_multi(int, hipStream_t, const Grid&, const SampleMulti<T>&, long long, const ChainHooks*);                 \

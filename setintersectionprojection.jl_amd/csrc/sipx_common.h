@@ -366,6 +366,7 @@ struct LeanSet {
 constexpr int LEAN_MAX = 3;
 template <typename T>
 struct LeanMulti {
+  int v_is_s = 0;         // the vector is s = A x itself (searches of the feasibility estimates)
   int ns;
   LeanSet<T> s[LEAN_MAX];
 };
@@ -536,6 +537,11 @@ struct K {
   static void ps_rescale_multi(hipStream_t s, const RescaleMulti<T>& A);
   static void sample_multi(int stage, hipStream_t s, const Grid& g, const SampleMulti<T>& A, long long runs, const ChainHooks* hk);
   static void lean_multi(hipStream_t s, const Grid& g, const LeanMulti<T>& m);
+  // mode 0 / 1 / 2: the full first passes / gated refinement passes / gated compaction passes of up to LEAN_MAX searches in one sweep
+  static void pass_multi(int mode, hipStream_t s, const Grid& g, const LeanMulti<T>& m, int v_is_s);
+  // stages 1 (sums of a refinement pass + decision) and 3 (solve) of a search without their passes (those came from pass_multi)
+  static void search_tail(int stage, hipStream_t s, const SetArgs<T>& a, ProjScalars<T>* ps, double* partials, T* maxpart, T* compact,
+                          long long true_len, SampleCtl ctl, double* reg);
   static void proj_scalars_stage(int stage, hipStream_t s, const Grid& g, const SetArgs<T>& a, int v_is_s, ProjScalars<T>* ps,
                                  double* partials, T* maxpart, T* compact, long long true_len, SampleCtl ctl, const ChainHooks* hooks,
                                  double* reg, T* gseg0, long long chunk);

@@ -65,7 +65,8 @@ def test_device_bytes_and_read_only_counters(sipx):
     (np.float32, (256, 192), ["bounds", "l1:TV"], "0"),
     (np.float32, (36, 30, 20), ["bounds", "l1:D_y"], "0"),                             # a grid line shorter than a wave, one searching set
 ])
-def test_batched_searches_are_bit_identical(sipx, monkeypatch, TF, n, kinds, runs):
+@pytest.mark.parametrize("multi", ["0", "1"])
+def test_batched_searches_are_bit_identical(sipx, monkeypatch, TF, n, kinds, runs, multi):
     """One rank, the sweep does the updates: the threshold / scale searches of all sets as ONE chain of launches on the engine
     stream (rescaling, sampled prediction, lean passes in one sweep, sums, decision + solve; the fallback sweeps launched only
     for the sets whose pinned verdict asks for them) against the per-set chains on the set streams (SIPX_SEARCH_BATCH=0): the same
@@ -77,6 +78,8 @@ def test_batched_searches_are_bit_identical(sipx, monkeypatch, TF, n, kinds, run
     os_.evol_rel_tol = os_.feas_tol = os_.obj_tol = 0.0
     if runs != "0":
         monkeypatch.setenv("SIPX_L1_SAMPLE_RUNS", runs)
+    # multi = 1: the full first passes and the fallback passes of the chain as one sweep per group of sets too (k_pass_multi)
+    monkeypatch.setenv("SIPX_PASS_MULTI", multi)
     out = {}
     for tag in ("0", "1"):
         monkeypatch.setenv("SIPX_SEARCH_BATCH", tag)
