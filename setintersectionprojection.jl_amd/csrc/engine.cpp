@@ -149,6 +149,7 @@ struct SetState {
   long long blk_rows[3] = {0, 0, 0};
   T plo = 0, phi = 0;
   bool ident = true, two_pass = false, is_dist = false, owned = true;
+  bool in_sweep = false;             // the one-sweep update (k_yl_multi) takes this set; the others keep their per-set kernels
   // y, l: the arrays holding the current iterate; y0, l0: the other pair.  The snapshot (y_0, l_0) of the BB rule lives
   // in whichever pair `snap` names: on a snapshot iteration the update is written over the old snapshot (after it has
   // been read), on the others into the pair that is not the snapshot -- the reference's copies y_0 <- y, l_0 <- l never
@@ -472,8 +473,26 @@ class Engine : public EngineBase {
       // (1028 against 1012 it/s settled, default window equal), so it is the default above 2^24 grid points only
       lean_multi_ = G_.N > (1ll << 24);
       if (const char* lm = std::getenv("SIPX_LEAN_MULTI")) lean_multi_ = lm[0] != '0';         // A/B switch, tests
+      {
+        // which sets the sweep takes: all of them (the layouts of C2 / C3 / C5 and of the short lists), or -- one rank only -- the
+        // element-wise and l1 / l2 terms of a list with sets it cannot take (C4), provided the layout of that subset is compiled in
+        MultiArgs<T> probe0;
+        const bool any_sweep = sweep_applicable(0, probe0, true);
+        has_loose_ = false;
+        for (auto& st : sets_) {
+          st.in_sweep = any_sweep && sweep_eligible(st);
+          has_loose_ |= any_sweep && st.owned && !st.in_sweep;
+        }
+        const char* sp = std::getenv("SIPX_SWEEP_PARTIAL");      // 0: such lists keep one k_yl launch per set (A/B switch, tests)
+        if (has_loose_ && sp && sp[0] == '0') {
+          for (auto& st : sets_) st.in_sweep = false;
+          has_loose_ = false;
+          yl_multi_ = false;
+        }
+        sweep_partial_ = has_loose_;
+      }
       MultiArgs<T> probe;
-      x0_mode_ = !(e && e[0] == '0') && sweep_applicable(SIPX_YL_FEAS | SIPX_YL_BB, probe, true);
+      x0_mode_ = !(e && e[0] == '0') && !has_loose_ && sweep_applicable(SIPX_YL_FEAS | SIPX_YL_BB, probe, true);
       // Set streams when the sweep does the updates: all that runs on them is the threshold / scale searches, chains of short
       // kernels whose latencies should overlap -- every searching set a stream of its own (up to three; one of them the engine
       // stream, so that its search starts without a cross-stream dependency), the other sets on the engine stream.  256^3, C3:
@@ -490,7 +509,7 @@ class Engine : public EngineBase {
         // One rank and EVERY update through the sweep: the searches of all two-pass sets as one chain of launches on the engine
         // stream (batched_searches) -- no set streams at all.  SIPX_SEARCH_BATCH=0 keeps the per-set chains (A/B switch, tests).
         int ntp = 0;
-        for (const auto& st : sets_) ntp += st.two_pass ? 1 : 0;
+        for (const auto& st : sets_) ntp += (st.two_pass && st.in_sweep) ? 1 : 0;
         const char* sb = std::getenv("SIPX_SEARCH_BATCH");
         MultiArgs<T> probe3;
         search_batch_ = !comm_ && !(sb && sb[0] == '0') && ntp >= 1 && ntp <= SPEC_MAX_SETS &&
@@ -624,7 +643,7 @@ class Engine : public EngineBase {
       // the third pair of the one-sweep update (two plain iterations in a row: the snapshot has to survive in the other pair
       // and the sweep never writes in place) -- allocated HERE, so that running out of memory is an error of sipx_finalize and
       // not of an iteration whose state has already advanced
-      if (sweep_plain_) { s.y2 = halloc(s.Mpad); s.l2 = halloc(s.Mpad); }
+      if (sweep_plain_ && s.in_sweep) { s.y2 = halloc(s.Mpad); s.l2 = halloc(s.Mpad); }
       if (s.custom) upload_custom(s);
       if (s.ext_kind && !s.dist_ext) {
         s.spec.lb = s.host_lb.empty() ? nullptr : s.host_lb.data();
@@ -960,22 +979,30 @@ class Engine : public EngineBase {
     MultiArgs<T> ma;
     const bool sweep = sweep_applicable(flags, ma);
     if (x0_mode_ && !sweep) throw std::runtime_error("internal: an x0-mode context met an update the one-sweep kernel does not take");
-    if (sweep && !slab_) {
+    // PARTIAL sweep (round 4): set lists with terms the sweep cannot take -- a projector behind a transform or a factorisation,
+    // cardinality (BASELINE config 4: l1 behind the DFT, slice rank, cardinality on D_z) -- have their element-wise and l1 / l2 terms
+    // updated by the sweep all the same (x read once for them, r_dual in the same pass); the other sets ("loose") keep their
+    // per-set kernels below, on the engine stream.  The fused right-hand side then holds the sets in front of the first loose
+    // one (MultiBlk::in_rhs; the sets are added in order, rhs_compose.jl:24-31) and k_rhs adds the rest.
+    const bool loose_only = sweep && !slab_;
+    if (loose_only) {
       if (search_batch_) batched_searches(flags, rho, gamma);
       else sweep_searches(flags, rho, gamma);
       sweep_launch(flags, rho, gamma, ma);
-      reduce_set_sums(p_n_ * SLOTS);
-      sums_flags_ = flags;
-      sums_pending_ = true;
-      if (!defer_sums_) {
-        SIPX_HIP(hipEventRecord(ev_sums_, stream_));
-        sums_event_ = ev_sums_;
-        collect_set_sums(rho, r_pri, r_dual, feas);
+      if (!has_loose_) {
+        reduce_set_sums(p_n_ * SLOTS);
+        sums_flags_ = flags;
+        sums_pending_ = true;
+        if (!defer_sums_) {
+          SIPX_HIP(hipEventRecord(ev_sums_, stream_));
+          sums_event_ = ev_sums_;
+          collect_set_sums(rho, r_pri, r_dual, feas);
+        }
+        return;
       }
-      return;
     }
     if (mk_) K<T>::sum_uv(stream_, G_.N, x_, x_ + G_.N, w_);
-    if (set_streams_ && !slab_) SIPX_HIP(hipEventRecord(ev_fork_, stream_));     // x (and u + v) are final: the sets may start
+    if (set_streams_ && !slab_ && !loose_only) SIPX_HIP(hipEventRecord(ev_fork_, stream_));     // x (and u + v) are final: the sets may start
     if (slab_) {
       // Slab-decomposed iteration: the threshold / scale searches of ALL sets in lock step -- every rank sweeps its planes,
       // ONE all-reduce makes the probe sums of all sets global (twice: first pass, gated refinement), ONE all-gather strings
@@ -1126,10 +1153,11 @@ class Engine : public EngineBase {
     for (int i = 0; i < p_n_ && !(slab_ && sweep); ++i) {
       SetState<T>& s = sets_[i];
       if (!s.owned || s.dist_ext) continue;
+      if (loose_only && s.in_sweep) continue;             // (updated by the sweep above)
       SetArgs<T> a = set_args(s, (T)rho[i], (T)gamma[i], flags);
       if (mk_) a.x = s.comp == 1 ? x_ : (s.comp == 2 ? x_ + G_.N : w_);
       double* part = part_sets_ + (size_t)i * SLOTS * NB;
-      hipStream_t q = s.st ? s.st : stream_;
+      hipStream_t q = (s.st && !loose_only) ? s.st : stream_;
       // slab-decomposed: a feasibility search carries collectives -- those stay on the engine stream, in one order on every rank
       if (slab_ && (flags & SIPX_YL_FEAS) && s.two_pass && i < pp_n_) q = stream_;
       double* ptmp = s.ptmp ? s.ptmp : part_tmp_;
@@ -1231,7 +1259,26 @@ class Engine : public EngineBase {
       }
       if ((flags & SIPX_YL_FEAS) && i < pp_n_) dist_feasibility(s, x_, part + (size_t)SL_FE2 * NB);
     }
-    for (size_t k = 0; k < pool_.size() && !(slab_ && sweep); ++k) {   // join: the reductions below see every set
+    if (loose_only && rhs_fused_) {
+      // the sweep wrote the sum over the sets in front of the first loose one; the rest, in order
+      RhsArgs<T> ra;
+      ra.nsets = 0;
+      bool behind = false;
+      for (int i = 0; i < p_n_; ++i) {
+        const SetState<T>& s = sets_[i];
+        behind |= !s.in_sweep;
+        if (!behind) continue;
+        RhsSet<T>& r = ra.s[ra.nsets++];
+        r.y = s.y; r.l = s.l; r.rho = (T)rho[i]; r.nblk = s.nblk;
+        for (int qd = 0; qd < 3; ++qd) { r.dir[qd] = s.dir[qd]; r.ih[qd] = s.ih[qd]; }
+        if (ra.nsets == MAX_SETS) {
+          K<T>::rhs_compose(stream_, Gr_, ra, rhs_, 1);
+          ra.nsets = 0;
+        }
+      }
+      if (ra.nsets > 0) K<T>::rhs_compose(stream_, Gr_, ra, rhs_, 1);
+    }
+    for (size_t k = 0; k < pool_.size() && !(slab_ && sweep) && !loose_only; ++k) {   // join: the reductions below see every set
       if (pool_[k] == stream_) continue;
       SetState<T>* last = nullptr;                                      // (one event per set stream: after its last set)
       for (int i = 0; i < p_n_; ++i)
@@ -1267,9 +1314,16 @@ class Engine : public EngineBase {
       ma.zhi = r1_ / plane_;
       if (r1_ <= r0_) ma.zlo = ma.zhi = ma.zsum = 0;
     }
+    bool behind = false;                        // a loose set has been seen: what follows is not part of the fused right-hand side
     for (int i = 0; i < p_n_; ++i) {
       const SetState<T>& s = sets_[i];
-      if (!s.owned || s.custom || s.ext_kind || s.dist_ext) return false;
+      if (planning ? !sweep_eligible(s) : !s.in_sweep) {
+        // a set the sweep cannot take: it keeps its per-set kernels (one rank only; never a caller-supplied sparse operator,
+        // whose right-hand side term is added out of order)
+        if (slab_ || comm_ || s.custom || !s.owned || s.dist_ext || (planning ? false : !sweep_partial_)) return false;
+        behind = true;
+        continue;
+      }
       if (ma.nblk + s.nblk_or1() > MULTI_MAXB) return false;
       // (the sweep takes the feasibility estimate of an element-wise set on the identity only)
       if (feas && i < pp_n_ && !s.two_pass && s.nblk > 0) return false;
@@ -1279,9 +1333,15 @@ class Engine : public EngineBase {
         B.last = qb == s.nblk_or1() - 1;
         B.dist = s.is_dist ? 1 : 0;
         B.prox = s.prox;
+        B.in_rhs = behind ? 0 : 1;
       }
     }
+    if (ma.nblk == 0) return false;
     return K<T>::yl_multi(stream_, G_, ma, true);
+  }
+  static bool sweep_eligible(const SetState<T>& s) {
+    return s.owned && !s.custom && !s.ext_kind && !s.dist_ext &&
+           (s.prox == PX_BOUNDS || s.prox == PX_L1 || s.prox == PX_PROX_L1 || s.prox == PX_L2 || s.prox == PX_ANNULUS || s.prox == PX_DIST);
   }
 
   // Threshold / scale searches of the two-pass sets `tp` of a slab-decomposed grid, all in lock step, through the SPECULATIVE
@@ -1464,7 +1524,7 @@ class Engine : public EngineBase {
   void batched_searches(int flags, const double* rho, const double* gamma) {
     std::vector<int> tp;
     for (int i = 0; i < p_n_; ++i)
-      if (sets_[i].two_pass) tp.push_back(i);
+      if (sets_[i].two_pass && sets_[i].in_sweep) tp.push_back(i);
     if (tp.empty()) return;
     run_batched(tp, false, flags, rho, gamma);
     if (flags & SIPX_YL_FEAS) {               // ||P_i(s) - s|| with s = A_i x itself: the sets' second scalar state
@@ -1634,7 +1694,7 @@ class Engine : public EngineBase {
       std::vector<int> who;
       for (int i = 0; i < p_n_ && ok; ++i) {
         SetState<T>& s = sets_[i];
-        if (!s.two_pass || s.prox != PX_L1 || s.custom || s.ext_kind) continue;
+        if (!s.two_pass || !s.in_sweep || s.prox != PX_L1 || s.custom || s.ext_kind) continue;
         SetArgs<T> a = set_args(s, (T)rho[i], (T)gamma[i], flags);
         if (a.flags & F_NOSPEC) continue;
         const bool rescaled = s.last_rho > T(0) && s.last_rho != a.rho;
@@ -1658,7 +1718,7 @@ class Engine : public EngineBase {
     if (set_streams_) SIPX_HIP(hipEventRecord(ev_fork_, stream_));       // x is final: the searches may start
     for (int i = 0; i < p_n_; ++i) {
       SetState<T>& s = sets_[i];
-      if (!s.two_pass) continue;
+      if (!s.two_pass || !s.in_sweep) continue;
       SetArgs<T> a = set_args(s, (T)rho[i], (T)gamma[i], flags);
       hipStream_t q = s.st ? s.st : stream_;
       double* ptmp = s.ptmp ? s.ptmp : part_tmp_;
@@ -1686,7 +1746,7 @@ class Engine : public EngineBase {
       if (pool_[k] == stream_) continue;
       SetState<T>* last = nullptr;
       for (int i = 0; i < p_n_; ++i)
-        if (sets_[i].two_pass && sets_[i].st == pool_[k]) last = &sets_[i];
+        if (sets_[i].two_pass && sets_[i].in_sweep && sets_[i].st == pool_[k]) last = &sets_[i];
       if (!last) continue;
       SIPX_HIP(hipEventRecord(last->ev, last->st));
       SIPX_HIP(hipStreamWaitEvent(stream_, last->ev, 0));
@@ -1705,8 +1765,10 @@ class Engine : public EngineBase {
     const bool first = (flags & SIPX_YL_FIRST) != 0, bb = (flags & SIPX_YL_BB) != 0 && !first;
     ma.nblk = 0;
     std::vector<int> target(p_n_, 0);          // 0: the other pair (y0, l0); 2: the third pair
+    bool behind = false;
     for (int i = 0; i < p_n_; ++i) {
       SetState<T>& s = sets_[i];
+      if (!s.in_sweep) { behind = true; target[i] = -1; continue; }
       SetArgs<T> a = set_args(s, (T)rho[i], (T)gamma[i], flags);
       target[i] = (!first && !bb && s.snap == 1) ? 2 : 0;
       if (target[i] == 2 && !s.y2) throw std::runtime_error("internal: the third y / l pair of the sweep was not allocated at sipx_finalize");
@@ -1729,6 +1791,7 @@ class Engine : public EngineBase {
         B.ih = s.nblk == 0 ? T(0) : s.ih[qb];
         B.rho = a.rho; B.rho1 = a.rho1; B.gamma = a.gamma;
         B.prox = s.prox; B.plo = s.plo; B.phi = s.phi;
+        B.in_rhs = behind ? 0 : 1;
       }
     }
     ma.x = x_; ma.m = m_; ma.xold = xold_;
@@ -1743,6 +1806,7 @@ class Engine : public EngineBase {
     if (x0_mode_ && (first || bb)) x_snap_ = x_cur_;
     for (int i = 0; i < p_n_; ++i) {           // (y, l) always names the current iterate; snap says where the snapshot sits
       SetState<T>& s = sets_[i];
+      if (target[i] < 0) continue;
       if (target[i] == 2) {
         std::swap(s.y, s.y2); std::swap(s.l, s.l2);                     // the snapshot stays in (y0, l0)
       } else {
@@ -3142,6 +3206,7 @@ class Engine : public EngineBase {
   unsigned spec_seq_ = 0;
   long long spec_searches_ = 0, spec_fallbacks_ = 0, spec_rounds_ = 0;     // searches through the speculative exchange / of those, fallbacks / refinement rounds (all-reduces) of the fallbacks
   bool spec_exchange_ = true;         // SIPX_SPEC_EXCHANGE=0: every search through (all-reduce, ..., all-gather), as before
+  bool sweep_partial_ = false, has_loose_ = false;   // the sweep takes a subset of the sets (in_sweep); some owned set keeps its per-set kernels
   bool pass_multi_ = false;           // SIPX_PASS_MULTI=1: full first passes / fallback passes of the batched searches in one sweep per group (measured slower)
   bool sweep_plain_ = false;          // the sweep takes the plain iterations of this context: every set carries a third y / l pair
   bool search_batch_ = false;         // one rank + sweep: the searches of all sets as one chain of launches (batched_searches; SIPX_SEARCH_BATCH=0: per-set chains on the set streams)

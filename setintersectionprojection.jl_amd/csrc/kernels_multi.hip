@@ -468,7 +468,7 @@ __global__ __launch_bounds__(MULTI_NT, SIPX_MULTI_WAVES) void k_yl_multi(Grid G,
         if constexpr (lay_last(L, b)) {
 #pragma unroll
           for (int k = 0; k < V; ++k) {
-            out[k] = out[k] + tr[k];                            // sets added in order (rhs_compose.jl:24-31)
+            if (B.in_rhs) out[k] = out[k] + tr[k];              // sets added in order (rhs_compose.jl:24-31)
             if constexpr (KIND != LK_I && KIND != LK_D) { if (active && own) acc_du[b] += (double)td[k] * (double)td[k]; }
           }
         }
@@ -600,7 +600,8 @@ static void launch_multi(hipStream_t s, const Grid& g, const MultiArgs<T>& a, do
   F(lay_pack(lay_blk(LK_I, 1), lay_blk(LK_Y, 1), lay_blk(LK_D, 1)))                                       /* I Y D */               \
   F(lay_pack(lay_blk(LK_I, 1), lay_blk(LK_X, 1), lay_blk(LK_D, 1)))                                       /* I X D */               \
   F(lay_pack(lay_blk(LK_I, 1), lay_blk(LK_Z, 0), lay_blk(LK_Y, 0), lay_blk(LK_X, 1), lay_blk(LK_I, 1), lay_blk(LK_D, 1)))   /* I [Z Y X] I D */ \
-  F(lay_pack(lay_blk(LK_I, 1), lay_blk(LK_D, 1)))                                                         /* I D */
+  F(lay_pack(lay_blk(LK_I, 1), lay_blk(LK_D, 1)))                                                         /* I D */ \
+  F(lay_pack(lay_blk(LK_I, 1), lay_blk(LK_X, 1), lay_blk(LK_Y, 1), lay_blk(LK_Z, 1), lay_blk(LK_I, 1), lay_blk(LK_D, 1)))   /* C4's element-wise and l1 terms: I X Y Z I(annulus) D */
 
 template <typename T>
 bool K<T>::yl_multi(hipStream_t s, const Grid& g, const MultiArgs<T>& a, bool probe_only) {

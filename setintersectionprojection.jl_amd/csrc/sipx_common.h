@@ -385,6 +385,8 @@ struct MultiBlk {
   int first, last;                // first / last block of its set
   int dist;                       // the distance term
   int feas_el;                    // element-wise set (bounds, prox_l1): its feasibility estimate is taken in the sweep (F_FEAS)
+  int in_rhs = 1;                 // the set's A'(rho y + l) goes into the fused right-hand side (0: a set behind one the sweep does not take -- the
+                                  // sets are added in order, rhs_compose.jl:24-31, so the caller adds the rest with k_rhs)
   T ih, rho, rho1, gamma;
   int prox;
   T plo, phi;
