@@ -266,6 +266,10 @@ int sipx_rccl_unique_id(void* id128);
  *     (every rank calls it: it gathers the slabs of x, y_i, l_i). */
 #define SIPX_DECOMP_SETS 0
 #define SIPX_DECOMP_SLAB 1
+/* the same decomposition with FULL-size arrays on every rank: SIPX_DECOMP_SLAB backs every N-sized array of a rank with memory for
+ * its planes and the halo planes around them only (device bytes per rank fall with the number of ranks); levels of a multilevel solve,
+ * whose warm start resamples whole arrays (sipx_warm_start_from), ask for this mode */
+#define SIPX_DECOMP_SLAB_FULL 2
 int sipx_set_decomp(sipx_ctx* ctx, int mode);
 int sipx_set_comm_rccl(sipx_ctx* ctx, const void* id128, int world, int rank);
 /* sipx_set_comm: the same operations supplied by the caller.  Each callback enqueues its operation on `stream`

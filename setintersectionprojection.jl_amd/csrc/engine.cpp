@@ -12,6 +12,8 @@
 #include <cstdlib>
 #include <cstring>
 #include <limits>
+#include <map>
+#include <mutex>
 
 namespace sipx {
 
@@ -33,6 +35,7 @@ void refresh_env_knobs() {
   k.rhs_march = (int)num("SIPX_RHS_MARCH", 1);
   k.rhs_march_zchunk = num("SIPX_RHS_MARCH_ZCHUNK", 0);
   k.q_plan = (int)num("SIPX_Q_PLAN", 1);
+  k.trace_kernels = (int)num("SIPX_TRACE_KERNELS", 0);
   g_env_knobs = k;
 }
 long long*& alloc_tally() {
@@ -71,8 +74,95 @@ T* dalloc(size_t n, bool zero = true) {
   }
   return p;
 }
+// SPARSE arrays (round 4, slab-decomposed contexts): the array keeps its GLOBAL index space -- the whole range is reserved in the
+// virtual address space, so every kernel indexes it exactly as before -- but only the element ranges a rank touches (its planes,
+// the halo planes around them) are backed by memory (hipMemAddressReserve / hipMemCreate / hipMemMap, 2 MiB granules).  A rank of
+// eight then holds an eighth of every N-vector (plus three planes) instead of all of it: the decomposition grows the problem that
+// fits, not only its speed.  An access outside the mapped ranges faults instead of reading stale data.
+struct SparseBlock {
+  size_t total = 0;
+  std::vector<std::pair<size_t, size_t>> maps;                   // (offset, length) in bytes
+  std::vector<hipMemGenericAllocationHandle_t> handles;
+};
+inline std::map<void*, SparseBlock>& sparse_registry() {
+  static std::map<void*, SparseBlock> reg;
+  return reg;
+}
+inline std::mutex& sparse_mutex() {
+  static std::mutex m;
+  return m;
+}
+constexpr size_t SPARSE_GRAN = 2ull << 20;
+// ranges: [first, last) in BYTES of the array's address space; returns the base of the reservation (zero-filled where mapped)
+inline void* sparse_alloc_bytes(size_t total_bytes, std::vector<std::pair<size_t, size_t>> ranges, int device) {
+  const size_t total = (total_bytes + SPARSE_GRAN - 1) / SPARSE_GRAN * SPARSE_GRAN;
+  for (auto& r : ranges) {
+    r.first = r.first / SPARSE_GRAN * SPARSE_GRAN;
+    r.second = std::min(total, (r.second + SPARSE_GRAN - 1) / SPARSE_GRAN * SPARSE_GRAN);
+  }
+  std::sort(ranges.begin(), ranges.end());
+  std::vector<std::pair<size_t, size_t>> merged;
+  for (const auto& r : ranges) {
+    if (r.second <= r.first) continue;
+    if (!merged.empty() && r.first <= merged.back().second) merged.back().second = std::max(merged.back().second, r.second);
+    else merged.push_back(r);
+  }
+  void* base = nullptr;
+  SIPX_HIP(hipMemAddressReserve(&base, total, SPARSE_GRAN, nullptr, 0));
+  SparseBlock blk;
+  blk.total = total;
+  hipMemAllocationProp prop = {};
+  prop.type = hipMemAllocationTypePinned;
+  prop.location.type = hipMemLocationTypeDevice;
+  prop.location.id = device;
+  hipMemAccessDesc acc = {};
+  acc.location.type = hipMemLocationTypeDevice;
+  acc.location.id = device;
+  acc.flags = hipMemAccessFlagsProtReadWrite;
+  // Every mapping of a reservation has the SAME size, one granule: hipMemSetAccess of this runtime (ROCm 7.2) answers "invalid
+  // argument" for a mapping whose size differs from the others inside one reservation (4 + 4 + 2 MiB fails at the third,
+  // 2 + 4 at the second; uniform sizes are fine -- probed with scratch/vmm_test3).  2 MiB is the native large page.
+  for (const auto& r : merged) {
+    for (size_t off = r.first; off < r.second; off += SPARSE_GRAN) {
+      const size_t len = SPARSE_GRAN;
+      auto chk = [&](hipError_t e, const char* what) {
+        if (e == hipSuccess) return;
+        char msg[256];
+        std::snprintf(msg, sizeof msg, "sparse array: %s failed (%s): reservation %zu bytes at %p, granule at %zu of range [%zu, %zu)", what,
+                      hipGetErrorString(e), total, base, off, r.first, r.second);
+        throw std::runtime_error(msg);
+      };
+      hipMemGenericAllocationHandle_t h;
+      chk(hipMemCreate(&h, len, &prop, 0), "hipMemCreate");
+      chk(hipMemMap((char*)base + off, len, 0, h, 0), "hipMemMap");
+      chk(hipMemSetAccess((char*)base + off, len, &acc, 1), "hipMemSetAccess");
+      blk.maps.push_back({off, len});
+      blk.handles.push_back(h);
+      if (long long* t = alloc_tally()) *t += (long long)len;
+    }
+    SIPX_HIP(hipMemset((char*)base + r.first, 0, r.second - r.first));
+  }
+  SIPX_HIP(hipStreamSynchronize(nullptr));
+  std::lock_guard<std::mutex> lk(sparse_mutex());
+  sparse_registry()[base] = std::move(blk);
+  return base;
+}
 inline void dfree(void* p) {
-  if (p) (void)hipFree(p);
+  if (!p) return;
+  {
+    std::lock_guard<std::mutex> lk(sparse_mutex());
+    auto it = sparse_registry().find(p);
+    if (it != sparse_registry().end()) {
+      for (size_t k = 0; k < it->second.maps.size(); ++k) {
+        (void)hipMemUnmap((char*)p + it->second.maps[k].first, it->second.maps[k].second);
+        (void)hipMemRelease(it->second.handles[k]);
+      }
+      (void)hipMemAddressFree(p, it->second.total);
+      sparse_registry().erase(it);
+      return;
+    }
+  }
+  (void)hipFree(p);
 }
 
 
@@ -180,6 +270,7 @@ struct SetState {
   // search overlap with the streaming passes of another set instead of leaving the GPU idle
   hipStream_t st = nullptr;
   hipEvent_t ev = nullptr;
+  long long cbuf_len = 0;            // elements cbuf holds
   double* ptmp = nullptr;
   T *mpart = nullptr, *cbuf = nullptr;
 };
@@ -287,8 +378,9 @@ class Engine : public EngineBase {
 
   void set_decomp(int mode) override {
     if (finalized_) throw std::runtime_error("sipx_set_decomp must precede sipx_finalize");
-    if (mode != SIPX_DECOMP_SETS && mode != SIPX_DECOMP_SLAB) throw std::runtime_error("unknown decomposition");
-    slab_req_ = mode == SIPX_DECOMP_SLAB;
+    if (mode != SIPX_DECOMP_SETS && mode != SIPX_DECOMP_SLAB && mode != SIPX_DECOMP_SLAB_FULL) throw std::runtime_error("unknown decomposition");
+    slab_req_ = mode != SIPX_DECOMP_SETS;
+    slab_full_req_ = mode == SIPX_DECOMP_SLAB_FULL;
   }
 
   void set_comm(Comm* c) override {
@@ -437,15 +529,34 @@ class Engine : public EngineBase {
       Gyl_.e0 = (prev_ >= 0) ? r0_ - plane_ : r0_; Gyl_.e1 = r1_; Gyl_.s0 = r0_;
       if (r1_ <= r0_) { Gr_.e0 = Gr_.e1 = 0; Gyl_.e0 = Gyl_.e1 = 0; }
     }
-    for (int k = 0; k < 3; ++k) { xr_base_[k] = dalloc<T>(Npad + 2 * halo_); xr_[k] = xr_base_[k] + halo_; }
+    wlo_ = -halo_; whi_ = Npad + halo_;
+    if (slab_ && !slab_full_req_) {
+      const char* e = std::getenv("SIPX_SLAB_LOCAL");        // 0: full-size arrays on every rank, as before (A/B switch; a fallback should a communicator refuse mapped memory)
+      int vmm = 0;
+      (void)hipDeviceGetAttribute(&vmm, hipDeviceAttributeVirtualMemoryManagementSupported, device_);
+      slab_local_ = vmm != 0 && !(e && e[0] == '0');
+      for (const auto& st : sets_) {
+        // per-element bound vectors arrive whole; the initial feasibility of an element-wise set on a difference operator
+        // takes the whole-grid kernels: such lists keep full-size arrays
+        if (st.prox == PX_BOUNDS_VEC || (!st.two_pass && st.nblk > 0) || !st.host_ata.empty()) slab_local_ = false;
+      }
+      if (slab_local_) {
+        // what a rank's kernels touch: its planes, one plane behind (forward differences, the neighbour's copy of x and p), two
+        // planes in front (the recomputed last plane of the rank below, and the plane the z-march loads in front of THAT one)
+        const long long a = r1_ > r0_ ? r0_ : N, b = r1_ > r0_ ? r1_ : N;
+        wlo_ = std::max<long long>(-halo_, a - 2 * plane_ - 64);
+        whi_ = std::min<long long>(Npad + halo_, b + plane_ + 64);
+      }
+    }
+    for (int k = 0; k < 3; ++k) { xr_base_[k] = galloc(Npad + 2 * halo_, halo_, 1, 0); xr_[k] = xr_base_[k] + halo_; }
     x_cur_ = 0; x_snap_ = -1;
     x_ = xr_[0]; xold_ = x_;                // (no x-step yet: x_old names x itself)
-    p_base_ = dalloc<T>(Nx_ + 2 * halo_); p_ = p_base_ + halo_;
-    rhs_ = dalloc<T>(Npad);
+    p_base_ = galloc(Nx_ + 2 * halo_, halo_, 1, 0); p_ = p_base_ + halo_;
+    rhs_ = galloc(Npad, 0, 1, 0);
     if (mk_) { w_base_ = dalloc<T>(N + 2 * halo_); w_ = w_base_ + halo_; }   // u + v, read through the stencils
-    m_base_ = dalloc<T>(N + 2 * halo_); m_ = m_base_ + halo_;   // forward stencils of A m read past the end
-    r_base_ = dalloc<T>(Nx_ + 2 * halo_); r_ = r_base_ + halo_;      // (halo: the fused CG product reads r through the bands)
-    Ap_ = dalloc<T>(Nx_);
+    m_base_ = galloc(N + 2 * halo_, halo_, 1, 0); m_ = m_base_ + halo_;   // forward stencils of A m read past the end
+    r_base_ = galloc(Nx_ + 2 * halo_, halo_, 1, 0); r_ = r_base_ + halo_;      // (halo: the fused CG product reads r through the bands)
+    Ap_ = galloc(Nx_, 0, 1, 0);
     {
       // CG iterations from the second on as ONE kernel (scalar step + product on p = r + beta p_old formed on the fly,
       // k_cds_fused): one launch and a host round trip less per iteration -- what a launch-bound grid (2048^2) is made of --
@@ -457,7 +568,10 @@ class Engine : public EngineBase {
       cg_fused_ = !comm_ && !stencil_q_ && (e ? e[0] == '1' : (small || cds_.march != 0));
       if (cg_fused_) { p2_base_ = dalloc<T>(Nx_ + 2 * halo_); p2_ = p2_base_ + halo_; }
     }
-    SIPX_HIP(hipMemcpy(m_, m, N * sizeof(T), hipMemcpyHostToDevice));
+    {
+      const long long c0 = std::max<long long>(0, wlo_), c1 = std::min<long long>(N, whi_);      // (sparse arrays: the rank's share only)
+      if (c1 > c0) SIPX_HIP(hipMemcpy(m_ + c0, (const T*)m + c0, (c1 - c0) * sizeof(T), hipMemcpyHostToDevice));
+    }
     {
       // x0 mode of the one-sweep update: when EVERY y/l update of this context goes through the sweep (its block layout is
       // compiled in, no set needs the per-set kernels on feasibility iterations), s_0 = A x_0 is recomputed from a snapshot of
@@ -571,8 +685,15 @@ class Engine : public EngineBase {
       stage_ = dalloc<double>((size_t)std::max(n2, 1) * (PREP_SLOTS + 1 + 2 * comm_->world));
       sstage_ = dalloc<double>((size_t)std::max(n2, 1) * (2 * SAMPLE_BINS + 3));
     }
+    if (slab_local_) {                 // the whole-array scratch is not needed: searches compact at most what the rank's planes hold
+      int nbmax = 1;
+      for (auto& s : sets_) nbmax = std::max(nbmax, s.nblk_or1());
+      // (... or what the exchange of a search strings together from all ranks: at most gcap magnitudes, by the search's own rule)
+      maxpad = std::min<long long>(maxpad, std::max<long long>((long long)nbmax * (whi_ - wlo_), hooks_.gcap + 64));
+    }
     scr_v_ = dalloc<T>(maxpad);
     scr_c_ = dalloc<T>(maxpad);
+    scr_c_len_ = maxpad;
     if (need_idx_) scr_i_ = dalloc<long long>(maxpad);
     if (need_ext_) scr_w_ = dalloc<T>(maxpad);
     // (the reduced per-set sums sit right behind the CG partials: sharded, ONE all-reduce can carry both, see argmin_x_head)
@@ -631,13 +752,13 @@ class Engine : public EngineBase {
       if (!s.owned) continue;
       // vectors read through adjoint stencils (w[g - stride]) carry a zero front halo: no bounds checks in the kernels
       auto halloc = [&](long long n) {
-        T* base = dalloc<T>(n + halo_);
+        T* base = galloc(n + halo_, halo_, s.nblk_or1(), N);
         s.halo_allocs.push_back(base);
         return base + halo_;
       };
       s.y = halloc(s.Mpad); s.l = halloc(s.Mpad);
-      s.lh0 = dalloc<T>(s.Mpad);
-      if (!x0_mode_) s.s0 = dalloc<T>(s.Mpad);
+      s.lh0 = galloc(s.Mpad, 0, s.nblk_or1(), N);
+      if (!x0_mode_) s.s0 = galloc(s.Mpad, 0, s.nblk_or1(), N);
       s.y0 = halloc(s.Mpad); s.l0 = halloc(s.Mpad);       // take turns with y, l as the current iterate: same halo
       if (!s.ident) s.dy = halloc(s.Mpad);
       // the third pair of the one-sweep update (two plain iterations in a row: the snapshot has to survive in the other pair
@@ -663,7 +784,8 @@ class Engine : public EngineBase {
       if ((slab_ || search_batch_) && s.two_pass) {        // searches in lock step: every set keeps its own partial slots and gather buffer
         s.ptmp = dalloc<double>((size_t)(PREP_SLOTS + 2) * NB);
         s.mpart = dalloc<T>(2 * NB);
-        s.cbuf = dalloc<T>(s.Mpad);
+        s.cbuf_len = slab_local_ ? std::min<long long>(s.Mpad, std::max<long long>((long long)s.nblk_or1() * (whi_ - wlo_), hooks_.gcap + 64)) : s.Mpad;
+        s.cbuf = dalloc<T>(s.cbuf_len);
       }
       const bool had_scratch = s.ptmp != nullptr;
       if (set_streams_ && !s.ext_kind && s.prox != PX_CARD) {     // those two share the engine-wide scratch: main stream
@@ -696,8 +818,8 @@ class Engine : public EngineBase {
         upload_rows(s, s.host_lb.data(), s.lb);
         upload_rows(s, s.host_ub.data(), s.ub);
       }
-      if (warm && l0 && l0[i]) upload_rows(s, (const T*)l0[i], s.l);
-      if (warm && y0 && y0[i]) upload_rows(s, (const T*)y0[i], s.y);
+      if (warm && l0 && l0[i]) upload_rows_ranged(s, (const T*)l0[i], s.l);
+      if (warm && y0 && y0[i]) upload_rows_ranged(s, (const T*)y0[i], s.y);
     }
     if (search_batch_) {                    // the sets' header segments and decision registers of the batched searches
       int n2 = 0;
@@ -705,7 +827,10 @@ class Engine : public EngineBase {
       fbuf_ = dalloc<T>((size_t)n2 * fast_hdr<T>());
       stage_ = dalloc<double>((size_t)n2 * (PREP_SLOTS + 1 + 2));
     }
-    if (warm && x0) SIPX_HIP(hipMemcpy(x_, x0, Nx_ * sizeof(T), hipMemcpyHostToDevice));   // Minkowski: [u; v], 2N entries
+    if (warm && x0) {                        // Minkowski: [u; v], 2N entries (sparse arrays: the rank's share)
+      const long long c0 = slab_local_ ? std::max<long long>(0, wlo_) : 0, c1 = slab_local_ ? std::min<long long>(Nx_, whi_) : Nx_;
+      if (c1 > c0) SIPX_HIP(hipMemcpy(x_ + c0, (const T*)x0 + c0, (c1 - c0) * sizeof(T), hipMemcpyHostToDevice));
+    }
 
     assemble_Q();
     if (q_fused_ && !stencil_q_ && !comm_ && cds_.march != 0) Q2_ = dalloc<T>((size_t)Nx_ * cds_.d);     // (SIPX_Q_FUSED=1 only)
@@ -720,6 +845,12 @@ class Engine : public EngineBase {
         continue;
       }
       if (!s.owned) continue;
+      if (slab_local_ && !s.two_pass && !s.ext_kind && !s.custom) {      // an element-wise set on the identity: every rank its planes
+        SetArgs<T> a = set_args(s, rho_[i], gamma_[i], 0);
+        a.x = m_;
+        K<T>::proj_dist_set(stream_, Gr_, a, 1, (const ProjScalars<T>*)nullptr, part_sets_ + ((size_t)i * SLOTS + SL_FE2) * NB);
+        continue;
+      }
       if (slab_ && !s.two_pass && comm_->rank != 0) continue;      // an element-wise set: rank 0 takes the whole grid (one-off)
       double* dst = part_sets_ + ((size_t)i * SLOTS + SL_FE2) * NB;
       // Minkowski: TD_OP[i] * [m; 0] = A m for components 1 and 3, A 0 = 0 for component 2 (w_ is still all zero here)
@@ -743,6 +874,7 @@ class Engine : public EngineBase {
         a.x = mm;                                              // s = A m produced on the fly
         SampleCtl cf;
         cf.host_ovf = (int*)hovf_ + i;
+        cf.compact_cap = scr_c_len_;
         K<T>::proj_scalars_set(stream_, Gr_, a, 1, s.psf, part_tmp_, maxpart_, scr_c_, s.Mtrue, cf, hooks());
         K<T>::proj_dist_set(stream_, Gr_, a, 1, s.psf, dst);
       } else {
@@ -1041,6 +1173,7 @@ class Engine : public EngineBase {
           SetState<T>& s = sets_[tp[j]];
           ctl[j].host_want = (int*)hlean_ + tp[j];
           ctl[j].host_ovf = (int*)hovf_ + tp[j];
+          ctl[j].compact_cap = sets_[tp[j]].cbuf_len;
           ctl[j].runs = l1_sample_runs_;
           const bool rescaled = s.prox == PX_L1 && s.last_rho > T(0) && s.last_rho != args[j].rho;
           ctl[j].enable = l1_sample_ && s.prox == PX_L1 && (rescaled || (hlean_[tp[j]] & 0xff) != 0);
@@ -1130,6 +1263,7 @@ class Engine : public EngineBase {
           for (size_t j = 0; j < tf.size(); ++j) {
             fa[j] = set_args(sets_[tf[j]], (T)rho[tf[j]], (T)gamma[tf[j]], flags);
             fc[j].host_ovf = (int*)hovf_ + tf[j];
+            fc[j].compact_cap = sets_[tf[j]].cbuf_len;
             if (sets_[tf[j]].prox == PX_L1) fg[j] = gbuf_ + (long long)(k1++) * seg;
           }
           spec_exchange_searches(tf, fa, fc, fg, chunk, 1, true, it);
@@ -1143,6 +1277,7 @@ class Engine : public EngineBase {
           SetArgs<T> a = set_args(s, (T)rho[i], (T)gamma[i], flags);
           SampleCtl cf;
           cf.host_ovf = (int*)hovf_ + i;
+          cf.compact_cap = s.cbuf ? s.cbuf_len : scr_c_len_;
           K<T>::proj_scalars_set(stream_, Gr_, a, 1, s.psf, s.ptmp ? s.ptmp : part_tmp_, s.mpart ? s.mpart : maxpart_, s.cbuf ? s.cbuf : scr_c_,
                                  s.Mtrue, cf, hooks());
           K<T>::proj_dist_set(stream_, Gr_, a, 1, s.psf, part_sets_ + ((size_t)i * SLOTS + SL_FE2) * NB);
@@ -1215,6 +1350,7 @@ class Engine : public EngineBase {
         // ||P_i(s) - s|| with s = A_i x produced on the fly; its own warm-started scalars (psf)
         SampleCtl cf;
         cf.host_ovf = (int*)hovf_ + i;
+        cf.compact_cap = s.cbuf ? s.cbuf_len : scr_c_len_;
         K<T>::proj_scalars_set(q, gs, a, 1, s.psf, ptmp, mpart, cbuf, s.Mtrue, cf, hooks());
         K<T>::proj_dist_set(q, gs, a, 1, s.psf, part + (size_t)SL_FE2 * NB);
       }
@@ -1297,6 +1433,19 @@ class Engine : public EngineBase {
       sums_event_ = ev_sums_;
       collect_set_sums(rho, r_pri, r_dual, feas);
     }
+  }
+
+  // An array over the grid: `total` elements, entry g of block q at front + q * bstride + g.  Full size, or (slab_local_) backed
+  // by memory for the grid points [wlo_, whi_) of every block only.
+  T* galloc(long long total, long long front, int nblk, long long bstride) {
+    if (!slab_local_) return dalloc<T>((size_t)total);
+    std::vector<std::pair<size_t, size_t>> rg;
+    for (int q = 0; q < std::max(nblk, 1); ++q) {
+      const long long lo = std::max<long long>(0, front + (long long)q * bstride + wlo_);
+      const long long hi = std::min<long long>(total, front + (long long)q * bstride + whi_);
+      if (hi > lo) rg.push_back({(size_t)lo * sizeof(T), (size_t)hi * sizeof(T)});
+    }
+    return (T*)sparse_alloc_bytes((size_t)total * sizeof(T), rg, device_);
   }
 
   // does the sweep take this context / iteration?  (asked before any search is queued; fills the layout part of `ma`)
@@ -1965,6 +2114,8 @@ class Engine : public EngineBase {
     if (c->p_n_ != p_n_ || c->ndim_ != ndim_ || mk_ || c->mk_) throw std::runtime_error("warm start: the two levels must hold the same sets");
     if ((comm_ != nullptr) != (c->comm_ != nullptr) || (comm_ && !(slab_ && c->slab_)))
       throw std::runtime_error("warm start between levels of a sharded solve needs both levels slab-decomposed (sipx_set_decomp)");
+    if (slab_local_ || c->slab_local_)
+      throw std::runtime_error("warm start between slab-decomposed levels resamples whole arrays: ask for SIPX_DECOMP_SLAB_FULL on both levels");
     if (c->slab_) {      // the coarse iterate, whole on every rank (a collective); the resampling below is then local and the
       std::vector<char> all(c->p_n_, 1);      // fine level starts from arrays that are complete -- slab, halo planes and all
       c->gather_slabs(true, all, all);
@@ -2044,8 +2195,43 @@ class Engine : public EngineBase {
       }
   }
 
+  // Sparse arrays: nothing whole exists on a rank.  x and the requested y_i, l_i are completed in whole-size TEMPORARIES (the
+  // exchange buffer of one N-vector, and the blocks of one set strung together) and go to the host from there.  A collective.
+  void download_sparse(void* x, void* const* l, void* const* y) {
+    const int dt = dtype_code();
+    const long long N = G_.N, Npad = chunk_ * comm_->world, nloc = r1_ - r0_;
+    int nbmax = 1;
+    for (auto& s : sets_) nbmax = std::max(nbmax, s.nblk_or1());
+    T* exch = dalloc<T>((size_t)Npad);
+    T* whole = dalloc<T>((size_t)nbmax * N);
+    auto complete = [&](const T* src) {      // src: a block of a sparse array (global indexing); afterwards exch[0, N) holds all of it
+      if (nloc > 0) SIPX_HIP(hipMemcpyAsync(exch + r0_, src + r0_, nloc * sizeof(T), hipMemcpyDeviceToDevice, stream_));
+      comm_->allgather(exch, (size_t)chunk_, dt, stream_);
+    };
+    if (x) {
+      complete(x_);
+      SIPX_HIP(hipStreamSynchronize(stream_));
+      SIPX_HIP(hipMemcpy(x, exch, N * sizeof(T), hipMemcpyDeviceToHost));
+    }
+    for (int i = 0; i < p_n_; ++i)
+      for (int which = 0; which < 2; ++which) {
+        void* const* dst = which ? y : l;
+        if (!(dst && dst[i])) continue;
+        const T* arr = which ? sets_[i].y : sets_[i].l;
+        for (int q = 0; q < sets_[i].nblk_or1(); ++q) {
+          complete(arr + (long long)q * N);
+          SIPX_HIP(hipMemcpyAsync(whole + (long long)q * N, exch, N * sizeof(T), hipMemcpyDeviceToDevice, stream_));
+        }
+        download_rows(sets_[i], whole, (T*)dst[i]);
+      }
+    SIPX_HIP(hipStreamSynchronize(stream_));
+    dfree(exch);
+    dfree(whole);
+  }
+
   void download(void* x, void* const* l, void* const* y) override {
     need_final();
+    if (slab_local_) { download_sparse(x, l, y); return; }
     if (slab_) {       // every rank holds its planes only: complete x and the requested y, l (a collective: every rank calls it)
       std::vector<char> wl(p_n_, 0), wy(p_n_, 0);
       for (int i = 0; i < p_n_; ++i) { wl[i] = l && l[i]; wy[i] = y && y[i]; }
@@ -2083,7 +2269,10 @@ class Engine : public EngineBase {
     const double maxf = julia_maximum(feas_init_.begin(), feas_init_.end());
     R.active = true;
     if (pp > 0 && maxf < (double)R.feas_tol) {                        // :101-104, PARSDMM.jl:63-82
-      SIPX_HIP(hipMemcpyAsync(x_, m_, G_.N * sizeof(T), hipMemcpyDeviceToDevice, stream_));
+      {
+        const long long c0 = slab_local_ ? std::max<long long>(0, wlo_) : 0, c1 = slab_local_ ? std::min<long long>(G_.N, whi_) : G_.N;
+        if (c1 > c0) SIPX_HIP(hipMemcpyAsync(x_ + c0, m_ + c0, (c1 - c0) * sizeof(T), hipMemcpyDeviceToDevice, stream_));
+      }
       if (mk_) SIPX_HIP(hipMemsetAsync(x_ + G_.N, 0, G_.N * sizeof(T), stream_));      // x = [m; 0]  PARSDMM.jl:64-69
       SIPX_HIP(hipStreamSynchronize(stream_));
       log->n_iter = 1;
@@ -2461,6 +2650,7 @@ class Engine : public EngineBase {
     o += "], \"slab_searches\": {\"speculative_exchange\": " + std::to_string(spec_searches_) + ", \"fallbacks\": " +
          std::to_string(spec_fallbacks_) + ", \"refinement_rounds\": " + std::to_string(spec_rounds_) + "}";
     // one rank: searches through the batched chain (batched_searches) and how many of them needed their fallback sweeps
+    o += std::string(", \"sparse_arrays\": ") + (slab_local_ ? "true" : "false");
     o += ", \"batched_searches\": {\"searches\": " + std::to_string(batch_searches_) + ", \"fallbacks\": " + std::to_string(batch_fallbacks_) + "}";
     // slice-rank / matrix-rank sets: which route their projector took since the context was finalised (ext_proj.hip)
     long long rc[4] = {0, 0, 0, 0};
@@ -2498,6 +2688,7 @@ class Engine : public EngineBase {
   void* dev_x() override { return x_; }
   void get_rhs(void* out) override {
     need_final();
+    if (slab_local_ && comm_->world > 1) throw std::runtime_error("a slab-decomposed context holds its planes of rhs only");
     SIPX_HIP(hipStreamSynchronize(stream_));
     SIPX_HIP(hipMemcpy(out, rhs_, Nx_ * sizeof(T), hipMemcpyDeviceToHost));
   }
@@ -2915,7 +3106,22 @@ class Engine : public EngineBase {
       stencil_weights(r.data());
       return;
     }
-    Q_ = dalloc<T>((size_t)Nx_ * cds_.d);
+    // (sparse arrays: the rows of every band that the rank's part of the x-step reads)
+    if (slab_local_) {
+      std::vector<std::pair<size_t, size_t>> rg;
+      long long maxoff = 0;
+      for (int b = 0; b < cds_.d; ++b) maxoff = std::max<long long>(maxoff, std::llabs(cds_.off[b]));
+      for (int b = 0; b < cds_.d; ++b) {
+        // rows [r0 - maxoff, r1) of every band: the symmetric read takes band +o at row r - o -- for the first rows of the grid
+        // that is the TAIL of the band stored in front (masked, but loaded), so the range is not clipped at the band's first row
+        const long long lo = std::max<long long>(0, (long long)b * Nx_ + (r1_ > r0_ ? r0_ : 0) - maxoff - 64);
+        const long long hi = std::min<long long>((long long)Nx_ * cds_.d, (long long)b * Nx_ + std::max(qr1_, qr0_) + 64);
+        if (hi > lo) rg.push_back({(size_t)lo * sizeof(T), (size_t)hi * sizeof(T)});
+      }
+      Q_ = (T*)sparse_alloc_bytes((size_t)Nx_ * cds_.d * sizeof(T), rg, device_);
+    } else {
+      Q_ = dalloc<T>((size_t)Nx_ * cds_.d);
+    }
     if (mk_) {
       std::vector<T> al(rho_.begin(), rho_.end());
       mk_q_update(al);
@@ -3025,6 +3231,17 @@ class Engine : public EngineBase {
     }
     SIPX_HIP(hipStreamSynchronize(stream_));
     dfree(tmp);
+  }
+  // (sparse arrays: through a whole-size temporary, of which the rank's share is kept)
+  void upload_rows_ranged(const SetState<T>& s, const T* rows, T* dev) const {
+    if (!slab_local_) { upload_rows(s, rows, dev); return; }
+    T* full = dalloc<T>((size_t)s.Mpad);
+    upload_rows(s, rows, full);
+    const long long c0 = std::max<long long>(0, wlo_), c1 = std::min<long long>(G_.N, whi_);
+    for (int q = 0; q < s.nblk_or1() && c1 > c0; ++q)
+      SIPX_HIP(hipMemcpy(dev + (long long)q * G_.N + c0, full + (long long)q * G_.N + c0, (c1 - c0) * sizeof(T), hipMemcpyDeviceToDevice));
+    SIPX_HIP(hipDeviceSynchronize());
+    dfree(full);
   }
   void download_rows(const SetState<T>& s, const T* dev, T* rows) const {
     SIPX_HIP(hipStreamSynchronize(stream_));
@@ -3182,6 +3399,7 @@ class Engine : public EngineBase {
   T *x_ = nullptr, *xold_ = nullptr, *rhs_ = nullptr, *m_ = nullptr, *r_ = nullptr, *p_ = nullptr, *Ap_ = nullptr;
   T *Q_ = nullptr, *scr_v_ = nullptr, *scr_c_ = nullptr, *maxpart_ = nullptr;
   long long* scr_i_ = nullptr;
+  long long scr_c_len_ = 0;
   T* scr_w_ = nullptr;
   bool need_idx_ = false, need_ext_ = false;
   CdsArgs cds_;
@@ -3262,6 +3480,10 @@ class Engine : public EngineBase {
   // slab decomposition of the whole iteration (sipx_set_decomp): the grids the set kernels are launched on, the collectives
   // of the threshold searches, the exchange buffer of their gathered magnitudes
   bool slab_req_ = false, slab_ = false;
+  // slab-decomposed with SPARSE arrays: every N-sized array of the context is backed by memory for the rank's planes (and the
+  // halo planes around them) only -- see SparseBlock.  [wlo_, whi_): the grid points whose entries exist on this rank.
+  bool slab_full_req_ = false, slab_local_ = false;
+  long long wlo_ = 0, whi_ = 0;
   Grid Gr_, Gyl_;
   ChainHooks hooks_;
   T* gbuf_ = nullptr;

@@ -134,7 +134,7 @@ __global__ __launch_bounds__(BLOCK) void k_pass(Grid G, SetArgs<T> a, int v_is_s
       acc[1] += 1.0;
     }
     if (MODE == M_STORE && live) compact[e] = x;
-    if (MODE == M_DIST) {
+    if (MODE == M_DIST && live) {          // (lanes beyond the range carry x = 0, and P(0) - 0 is not zero for every set: bounds away from zero)
       const T pv = prox_apply<T>(pc, x, T(0), T(0), T(0), e);
       const T dlt = pv - x;
       acc[0] += (double)dlt * (double)dlt;
@@ -188,7 +188,7 @@ __global__ __launch_bounds__(BLOCK) void k_pass(Grid G, SetArgs<T> a, int v_is_s
     for (long long it = 0; it < nit; ++it) {
       const long long vi = v0 + it * (long long)gridDim.x * BLOCK + (long long)blockIdx.x * BLOCK + threadIdx.x;
       const bool live = vi < nvec;
-      const long long g = live ? vi * V : 0;
+      const long long g = live ? vi * V : v0 * V;      // (lanes beyond the range shadow its first point: every array is backed there)
       const Coord c = coords(G, g);
       const Vec<T, V> xc = ldv<T, V>(a.x + g);
       for (int q = 0; q < nb; ++q) {
@@ -294,7 +294,7 @@ __global__ __launch_bounds__(BLOCK) void k_lean_multi(Grid G, LeanMulti<T> m) {
   for (long long it = 0; it < nit; ++it) {
     const long long vi = v0 + it * (long long)gridDim.x * BLOCK + (long long)blockIdx.x * BLOCK + threadIdx.x;
     const bool live = vi < nvec;
-    const long long g = live ? vi * V : 0;
+    const long long g = live ? vi * V : v0 * V;      // (lanes beyond the range shadow its first point: every array is backed there)
     const Coord c = coords(G, g);
     const Vec<T, V> xc = ldv<T, V>(x + g);
 #pragma unroll
@@ -440,7 +440,7 @@ __global__ __launch_bounds__(BLOCK) void k_pass_multi(Grid G, LeanMulti<T> m, in
   for (long long it = 0; it < nit; ++it) {
     const long long vi = v0 + it * (long long)gridDim.x * BLOCK + (long long)blockIdx.x * BLOCK + threadIdx.x;
     const bool live = vi < nvec;
-    const long long g = live ? vi * V : 0;
+    const long long g = live ? vi * V : v0 * V;      // (lanes beyond the range shadow its first point: every array is backed there)
     const Coord c = coords(G, g);
     const Vec<T, V> xc = ldv<T, V>(x + g);
 #pragma unroll
@@ -1210,7 +1210,7 @@ __device__ void sample_body(const Grid& G, const SetArgs<T>& a, ProjScalars<T>* 
     if (ru >= nchunks) ru = u * stride;
     const long long vi = t < total ? v0 + ru * SAMPLE_RUN + (t % SAMPLE_RUN) : nvec;
     const bool live = vi < nvec;
-    const long long g = live ? vi * V : 0;
+    const long long g = live ? vi * V : v0 * V;      // (lanes beyond the range shadow its first point: every array is backed there)
     const Coord cd = coords(G, g);
     const Vec<T, V> xc = ldv<T, V>(a.x + g);
     for (int q = 0; q < nb; ++q) {
@@ -2273,7 +2273,8 @@ void K<T>::proj_scalars_set(hipStream_t s, const Grid& g, const SetArgs<T>& a, i
                             double* partials, T* maxpart, T* compact, long long true_len, SampleCtl ctl, const ChainHooks* hooks) {
   SetArgs<T> b = a;
   b.ps = ps;
-  launch_chain<T, 1>(s, g, b, v_is_s, nullptr, 0, ps, partials, maxpart, compact, true_len, ctl, hooks, (long long)a.nblk_or1() * g.N);
+  launch_chain<T, 1>(s, g, b, v_is_s, nullptr, 0, ps, partials, maxpart, compact, true_len, ctl, hooks,
+                     ctl.compact_cap > 0 ? ctl.compact_cap : (long long)a.nblk_or1() * g.N);
 }
 template <typename T>
 void K<T>::proj_scalars_stage(int stage, hipStream_t s, const Grid& g, const SetArgs<T>& a, int v_is_s, ProjScalars<T>* ps,
@@ -2283,7 +2284,7 @@ void K<T>::proj_scalars_stage(int stage, hipStream_t s, const Grid& g, const Set
   SetArgs<T> b = a;
   b.ps = ps;
   chain_stage<T, 1>(stage, s, g, b, v_is_s, nullptr, 0, ps, partials, maxpart, compact, true_len, ctl, hooks,
-                    (long long)a.nblk_or1() * g.N, reg ? reg : ps->red, gseg0, chunk);
+                    ctl.compact_cap > 0 ? ctl.compact_cap : (long long)a.nblk_or1() * g.N, reg ? reg : ps->red, gseg0, chunk);
 }
 template <typename T>
 void K<T>::proj_scalars_arr(hipStream_t s, long long len, const T* v, int prox, T pmin, T pmax, ProjScalars<T>* ps,

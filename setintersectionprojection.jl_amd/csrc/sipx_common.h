@@ -4,6 +4,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <cstdio>
 
 namespace sipx {
 
@@ -79,6 +80,7 @@ struct LaunchObserver {
 };
 // the observer of the calling host thread (a context is driven by one thread at a time); nullptr: nothing is recorded
 const LaunchObserver*& launch_observer();
+
 // A/B switches of the launchers, read from the environment ONCE per context (sipx_finalize -> refresh_env_knobs) instead of by a
 // getenv at every launch: a test that sets a switch builds a new context afterwards.
 struct EnvKnobs {
@@ -87,6 +89,7 @@ struct EnvKnobs {
   long long multi_zchunk = 0;     // SIPX_MULTI_ZCHUNK
   int rhs_march = 1;              // SIPX_RHS_MARCH
   long long rhs_march_zchunk = 0; // SIPX_RHS_MARCH_ZCHUNK
+  int trace_kernels = 0;          // SIPX_TRACE_KERNELS=1 (debugging): name every launch on stderr and drain the stream behind it
   int q_plan = 1;                 // SIPX_Q_PLAN=0: the Q update regenerates every band value per element (k_q_update) instead of adding planned products
 };
 const EnvKnobs& env_knobs();
@@ -98,10 +101,15 @@ struct ObsScope {
   int kid;
   hipStream_t s;
   ObsScope(int kid_, hipStream_t s_, double bytes_survey, double bytes_moved = -1.0) : o(launch_observer()), kid(kid_), s(s_) {
+    if (env_knobs().trace_kernels) fprintf(stderr, "[sipx trace] %s\n", kernel_name(kid));
     if (o) o->begin(o->user, kid, s, bytes_survey, bytes_moved < 0 ? bytes_survey : bytes_moved);
   }
   ~ObsScope() {
     if (o) o->end(o->user, kid, s);
+    if (env_knobs().trace_kernels) {       // SIPX_TRACE_KERNELS=1: every launch named and drained -- a faulting kernel is the last one named
+      (void)hipStreamSynchronize(s);
+      fprintf(stderr, "[sipx trace]   done\n");
+    }
   }
   ObsScope(const ObsScope&) = delete;
   ObsScope& operator=(const ObsScope&) = delete;
@@ -267,6 +275,7 @@ struct SampleCtl {
   unsigned seq = 0;
   int lean_done = 0;       // the set's lean first pass was taken by k_lean_multi: the chain launches the full one only (gated as ever)
   int lean_known = 0;      // the host has read from the set's pinned word that the coming first pass is a lean one
+  long long compact_cap = 0;   // elements the set's compaction buffer holds (0: one per entry of the set's vector); what the exchange strings together must fit
 };
 
 template <typename T>

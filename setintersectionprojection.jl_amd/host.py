@@ -646,9 +646,10 @@ class Context:
 
     def set_decomp(self, mode: str):
         """"sets": the reference's split by constraint set; "slab": every rank works on its z-slab of every set (sipx.h)."""
-        if mode not in ("sets", "slab"):
-            raise SipxError(f"unknown decomposition {mode!r} (sets | slab)")
-        _chk(lib().sipx_set_decomp(self.h, 1 if mode == "slab" else 0))
+        if mode not in ("sets", "slab", "slab_full"):
+            raise SipxError(f"unknown decomposition {mode!r} (sets | slab | slab_full)")
+        # slab: a rank's arrays hold its planes only (sparse arrays); slab_full: whole arrays on every rank (levels of a multilevel solve)
+        _chk(lib().sipx_set_decomp(self.h, {"sets": 0, "slab": 1, "slab_full": 2}[mode]))
 
     def set_owned(self, owned: Sequence[int]):
         a = np.zeros(len(self.rows) + 1, np.int32)       # constraint sets + the distance term

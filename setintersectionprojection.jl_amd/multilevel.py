@@ -115,7 +115,7 @@ def PARSDMM_multi_level(m, TD_OP_levels, AtA_levels, P_sub_levels, set_Prop_leve
 
         def attach(ctx):
             keep.append(sharded.attach_comm(ctx, dist, torch.device("cuda", 0 if device is None else device), comm_mode))
-            ctx.set_decomp("slab")
+            ctx.set_decomp("slab_full")      # the warm start between levels resamples whole arrays (sipx_warm_start_from)
     n_levels = len(TD_OP_levels)
     n0 = tuple(int(v) for v in comp_grid_levels[0].n)
     dim3 = len(n0) == 3 and n0[2] > 1

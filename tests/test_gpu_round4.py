@@ -188,3 +188,74 @@ def test_full_size_c2_solver_properties(sipx):
     flat = np.full(m.size, 2500.0, TF)
     xf, logf, _, _ = sipx.PARSDMM(flat.copy(), AtA, A, prop, P, g, opt)
     assert np.array_equal(xf, flat) and len(logf.obj) == 1
+
+
+def _slab_local_worker(rank, world, port, out, kinds, n):
+    import datetime
+    import os
+    import sys
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")
+    dist.init_process_group("gloo", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=180))
+    try:
+        root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+        sys.path.insert(0, root)
+        from __graft_entry__ import load_package
+        sipx = load_package()
+        from sipx import sharded
+        import torch
+        TF = np.float32
+        h = (25.0, 25.0, 25.0)[:len(n)]
+        m = model(n, TF, seed=5)
+        for tag in ("0", "1"):
+            os.environ["SIPX_SLAB_LOCAL"] = tag
+            g, opt, P, A, prop, AtA = _problem(sipx, n, h, TF, kinds, m, dict(maxit=30, evol_rel_tol=0.0, feas_tol=0.0, obj_tol=0.0))
+            A, AtA2, _, _ = A, AtA, None, None
+            keep = []
+
+            def attach(cx):
+                keep.append(sharded.attach_comm(cx, dist, torch.device("cuda", 0), "torch"))
+                cx.set_decomp("slab")
+            ctx = sipx.host.build_context(m, AtA, A, prop, P, g, opt, device=0, owned=[1] * len(A), attach=attach)
+            nbytes = ctx.device_bytes()["context"]
+            sparse = ctx.kernel_stats_all(-1)["sparse_arrays"]
+            log, _ = ctx.parsdmm(opt)
+            x, l, y = ctx.download()
+            ctx.close()
+            np.savez(os.path.join(out, f"loc{tag}_r{rank}.npz"), x=x, obj=log.obj, rho=log.rho, cg_it=log.cg_it, r_pri=log.r_pri, feas=log.set_feasibility,
+                     nbytes=nbytes, sparse=sparse, **{f"y{i}": v for i, v in enumerate(y)}, **{f"l{i}": v for i, v in enumerate(l)})
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(400)
+@pytest.mark.parametrize("world,kinds,n", [
+    (4, ["bounds", "l1:D_x", "l1:D_y", "l1:D_z"], (32, 24, 32)),       # eight planes per rank
+    (3, ["bounds", "l1:TV", "annulus"], (32, 24, 16)),                 # ragged slabs (6, 6, 4); a set of three blocks
+    (4, ["bounds", "l1:D_z", "l1:D_x"], (12, 10, 5)),                  # 2, 2, 1 planes and a rank with none
+    (2, ["bounds", "l1:TV"], (64, 48)),                                # 2-D: slabs of rows
+    (4, ["bounds", "l1:D_x", "l1:D_y", "l1:D_z"], (256, 128, 64)),     # arrays of 8 MiB: the mapping is really sparse (2 MiB granules)
+])
+def test_slab_ranks_hold_their_planes_only(sipx, tmp_path, world, kinds, n):
+    """sipx_set_decomp(SIPX_DECOMP_SLAB) with sparse arrays (every N-sized array keeps its global index space but is backed by
+    memory for the rank's planes and the halo planes around them only) against full-size arrays on every rank (SIPX_SLAB_LOCAL=0):
+    x, every y_i, l_i and the logs are IDENTICAL on every rank in both modes (no kernel changed; an access outside a rank's share
+    would fault), and what a context allocates falls with the number of ranks."""
+    import os
+    import torch.multiprocessing as mp
+    port = 30100 + (os.getpid() % 1500) + 7 * world
+    mp.spawn(_slab_local_worker, args=(world, port, str(tmp_path), kinds, n), nprocs=world, join=True)
+    full = [np.load(tmp_path / f"loc0_r{r}.npz") for r in range(world)]
+    loc = [np.load(tmp_path / f"loc1_r{r}.npz") for r in range(world)]
+    for r in range(world):
+        assert not bool(full[r]["sparse"]) and bool(loc[r]["sparse"])
+        for k in full[0].files:
+            if k in ("nbytes", "sparse"):
+                continue
+            assert np.array_equal(full[0][k], loc[r][k], equal_nan=True), (r, k)
+            assert np.array_equal(full[0][k], full[r][k], equal_nan=True), (r, k)
+    N = int(np.prod(n))
+    if N >= (1 << 21):                # (smaller grids: an array is one or two 2 MiB granules of the mapping whatever the rank holds)
+        assert max(int(v["nbytes"]) for v in loc) < 0.8 * int(full[0]["nbytes"]), ([int(v["nbytes"]) for v in loc], int(full[0]["nbytes"]))
