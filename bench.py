@@ -275,7 +275,7 @@ def headline(out, detail_path=None):
         if v.get("rank_route"):
             o["rank_route"] = _pick(v["rank_route"], ("calls", "warm_started_subspace", "full_decomposition"))
         if out.get("n_gpus", 1) > 1 and v.get("comm"):
-            o["comm"] = _pick(v["comm"], ("decomposition", "ranks_agree_on_x"))
+            o["comm"] = _pick(v["comm"], ("decomposition", "ranks_agree_on_x", "device_bytes_per_rank"))
         h[key] = o
     for key in ("c5", "c5_layered"):
         v = out.get(key)

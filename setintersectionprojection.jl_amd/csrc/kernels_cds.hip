@@ -187,25 +187,66 @@ __device__ __forceinline__ T ata_value(const Grid& G, int nblk, const int* dir, 
 // What the residual product needs to apply a pending Q update on the fly (MODE 4 of the march): the changed sets with their
 // rho differences (the arithmetic of k_q_update, band values regenerated from the operator descriptors) and where the updated
 // bands go -- a second copy of Q: the tile in front, the row above and the plane below are still read from the old one.
+// (the plan of the update: see k_q_update_plan below for what it holds and why its products are the bits of k_q_update's)
+constexpr int QP_MAXB = 9, QP_MAXT = 8, QP_TAB = 160;
+struct QPlanTerm {
+  int kind;          // 0: one value; 1: diagonal of a difference set -- table over the classes of its nblk directions, index
+                     // sum_q class(dir[q]) 3^q; 2 / 3: band +stride / -stride of direction dir[0]: (row exists ? tab[0] : tab[1])
+  int nblk;
+  int dir[3];
+  int tab;           // where its values start in QPlan::tab
+};
+template <typename T>
+struct QPlan {
+  int nbands;
+  int col[QP_MAXB], nterms[QP_MAXB];
+  QPlanTerm t[QP_MAXB][QP_MAXT];
+  int ntab;
+  T tab[QP_TAB];
+};
+
 template <typename T>
 struct QUpd {
-  QArgs<T> a;
-  T* qn[4];       // the four stored bands (offsets 0, +1, +n1, +n1 n2) of the updated matrix
+  QPlan<T> plan;  // alpha_i * (A_i'A_i)[g, g + o] per boundary class of g, the changed sets in order (Q_update!.jl:45-48)
+  int pb[4];      // the plan's band for the stored bands with offsets 0, +1, +n1, +n1 n2 (-1: not touched by this update)
+  T* qn[4];       // the four stored bands of the updated matrix
   Grid G;
 };
 struct NoExtra {};
+// value of stored band `role` at the point with coordinates c after the pending update; tab: the plan's products (LDS copy)
 template <typename T>
-__device__ __forceinline__ T q_upd_val(const QUpd<T>& u, long long o, const Coord& c, T qv) {
-  for (int si = 0; si < u.a.nsets; ++si) {           // the changed sets in order (Q_update!.jl:45-48)
-    const QSet<T>& S = u.a.s[si];
-    bool has = false;
-    for (int t = 0; t < S.nband; ++t) has |= S.off[t] == o;
-    if (has) qv = qv + S.alpha * ata_value<T>(u.G, S.nblk, S.dir, S.ih, o, c);
+__device__ __forceinline__ T q_upd_val(const QUpd<T>& u, const T* __restrict__ tab, int role, const Coord& c, T qv) {
+  const int b = u.pb[role];
+  if (b < 0) return qv;
+  const int cx = c.i == 0 ? 0 : (c.i == (int)u.G.n[0] - 1 ? 2 : 1), cy = c.j == 0 ? 0 : (c.j == (int)u.G.n[1] - 1 ? 2 : 1),
+            cz = c.k == 0 ? 0 : (c.k == (int)u.G.n[2] - 1 ? 2 : 1);
+  for (int ti = 0; ti < u.plan.nterms[b]; ++ti) {
+    const QPlanTerm& t = u.plan.t[b][ti];
+    if (t.kind == 0) {
+      qv = qv + tab[t.tab];
+    } else if (t.kind == 1) {
+      int idx = 0, m3 = 1;
+      for (int q = 0; q < t.nblk; ++q) {
+        const int d = t.dir[q];
+        idx += (d == 0 ? cx : (d == 1 ? cy : cz)) * m3;
+        m3 *= 3;
+      }
+      qv = qv + tab[t.tab + idx];
+    } else {
+      const int d = t.dir[0], cl = d == 0 ? cx : (d == 1 ? cy : cz);
+      qv = qv + (cl != (t.kind == 2 ? 2 : 0) ? tab[t.tab] : tab[t.tab + 1]);
+    }
   }
   return qv;
 }
 template <typename T>
-__device__ __forceinline__ T q_upd_val(const NoExtra&, long long, const Coord&, T qv) { return qv; }
+__device__ __forceinline__ T q_upd_val(const NoExtra&, const T*, int, const Coord&, T qv) { return qv; }
+template <typename T>
+__device__ __forceinline__ void load_plan_tab(const QUpd<T>& u, T* tab) {
+  for (int i = threadIdx.x; i < u.plan.ntab; i += blockDim.x) tab[i] = u.plan.tab[i];
+}
+template <typename T>
+__device__ __forceinline__ void load_plan_tab(const NoExtra&, T*) {}
 template <typename T>
 __device__ __forceinline__ const Grid& extra_grid(const QUpd<T>& u) { return u.G; }
 __device__ __forceinline__ Grid extra_grid(const NoExtra&) { return Grid{}; }
@@ -263,6 +304,11 @@ __global__ __launch_bounds__(MARCH_NT) void k_cds_march(long long n1, long long 
   };
   auto ldx1 = [&](long long at) -> T { return MODE == 3 ? x[at] + beta * b[at] : x[at]; };
   __shared__ T sx[2][V][MARCH_NT], sr[2][V][MARCH_NT];
+  __shared__ T qtab[UPD ? QP_TAB : 1];
+  if (UPD) {
+    load_plan_tab<T>(extra, qtab);
+    __syncthreads();
+  }
   const int tid = threadIdx.x, LX = 1 << lgLX, tx = tid & (LX - 1), ty = tid >> lgLX, TY = MARCH_NT >> lgLX;
   const long long st1 = n1, st2 = n1 * n2, N = st2 * n3;
   const long long tiles = (long long)tiles_x * tiles_y;
@@ -283,7 +329,7 @@ __global__ __launch_bounds__(MARCH_NT) void k_cds_march(long long n1, long long 
         rzm = ldv<T, V>(R3 + st2 * (k0 - 1) + go);
         if (UPD) {
 #pragma unroll
-          for (int k = 0; k < V; ++k) rzm.v[k] = q_upd_val<T>(extra, st2, Coord{(int)(i0 + k), (int)j, (int)(k0 - 1)}, rzm.v[k]);
+          for (int k = 0; k < V; ++k) rzm.v[k] = q_upd_val<T>(extra, qtab, 3, Coord{(int)(i0 + k), (int)j, (int)(k0 - 1)}, rzm.v[k]);
         }
       }
     }
@@ -302,10 +348,10 @@ __global__ __launch_bounds__(MARCH_NT) void k_cds_march(long long n1, long long 
 #pragma unroll
           for (int k = 0; k < V; ++k) {
             const Coord ck{(int)(i0 + k), (int)j, (int)kz};
-            r0.v[k] = q_upd_val<T>(extra, 0, ck, r0.v[k]);
-            r1.v[k] = q_upd_val<T>(extra, 1, ck, r1.v[k]);
-            r2.v[k] = q_upd_val<T>(extra, st1, ck, r2.v[k]);
-            r3.v[k] = q_upd_val<T>(extra, st2, ck, r3.v[k]);
+            r0.v[k] = q_upd_val<T>(extra, qtab, 0, ck, r0.v[k]);
+            r1.v[k] = q_upd_val<T>(extra, qtab, 1, ck, r1.v[k]);
+            r2.v[k] = q_upd_val<T>(extra, qtab, 2, ck, r2.v[k]);
+            r3.v[k] = q_upd_val<T>(extra, qtab, 3, ck, r3.v[k]);
           }
         }
       }
@@ -318,7 +364,7 @@ __global__ __launch_bounds__(MARCH_NT) void k_cds_march(long long n1, long long 
         if (tx == 0 || (tid & 63) == 0) {
           xl = ldx1(r - 1);
           rl = r > 0 ? R1[r - 1] : T(0);
-          if (UPD && r > 0) rl = q_upd_val<T>(extra, 1, coords(extra_grid(extra), r - 1), rl);     // (still the old value in memory)
+          if (UPD && r > 0) rl = q_upd_val<T>(extra, qtab, 1, coords(extra_grid(extra), r - 1), rl);     // (still the old value in memory)
         }
         if (tx == LX - 1 || (tid & 63) == 63) xr = ldx1(r + V);
       }
@@ -334,7 +380,7 @@ __global__ __launch_bounds__(MARCH_NT) void k_cds_march(long long n1, long long 
             ru = ldv<T, V>(R2 + r - st1);
             if (UPD) {
 #pragma unroll
-              for (int k = 0; k < V; ++k) ru.v[k] = q_upd_val<T>(extra, st1, coords(extra_grid(extra), r - st1 + k), ru.v[k]);
+              for (int k = 0; k < V; ++k) ru.v[k] = q_upd_val<T>(extra, qtab, 2, coords(extra_grid(extra), r - st1 + k), ru.v[k]);
             }
           }
         }
@@ -682,24 +728,7 @@ __global__ __launch_bounds__(BLOCK) void k_q_update(Grid G, long long r0, long l
 // directions (first / interior / last point of the line).  The host forms those products ONCE per launch, with the arithmetic
 // of ata_value and the multiplication by alpha in TF (this translation unit is compiled with -ffp-contract=off like the kernels),
 // and the kernel adds them in set order: Q[:, col] = Q[:, col] + p_i(class(g)) -- the same numbers added in the same order as
-// k_q_update and CDS_scaled_add!.jl:16-22, so Q stays bit-identical (the engine's Q is compared bit for bit with the oracle's).
-constexpr int QP_MAXB = 9, QP_MAXT = 8, QP_TAB = 320;
-struct QPlanTerm {
-  int kind;          // 0: one value; 1: diagonal of a difference set -- table over the classes of its nblk directions, index
-                     // sum_q class(dir[q]) 3^q; 2 / 3: band +stride / -stride of direction dir[0]: (row exists ? tab[0] : tab[1])
-  int nblk;
-  int dir[3];
-  int tab;           // where its values start in QPlan::tab
-};
-template <typename T>
-struct QPlan {
-  int nbands;
-  int col[QP_MAXB], nterms[QP_MAXB];
-  QPlanTerm t[QP_MAXB][QP_MAXT];
-  int ntab;
-  T tab[QP_TAB];
-};
-
+// k_q_update and CDS_scaled_add!.jl:16-22, so Q stays bit-identical (the tests compare the engine's Q bit for bit with mat2CDS / CDS_scaled_add! restated on the CPU).
 template <typename T, int V>
 __global__ __launch_bounds__(BLOCK) void k_q_update_plan(Grid G, long long r0, long long r1, QPlan<T> p, T* __restrict__ Q) {
   __shared__ T tab[QP_TAB];
@@ -1189,8 +1218,13 @@ bool K<T>::resid_qupdate(hipStream_t s, const Grid& g, long long N, const T* R_o
   for (int i = 0; i < qa.nsets; ++i)
     if (qa.s[i].ata) return false;                     // caller-supplied A'A bands: the separate kernel reads them
   QUpd<T> u;
-  u.a = qa;
-  for (int q = 0; q < 4; ++q) u.qn[q] = R_new + (long long)a.mb[q] * N;
+  if (!make_q_plan<T>(g, a, qa, u.plan)) return false;
+  for (int q = 0; q < 4; ++q) {
+    u.qn[q] = R_new + (long long)a.mb[q] * N;
+    u.pb[q] = -1;
+    for (int b = 0; b < u.plan.nbands; ++b)
+      if (u.plan.col[b] == a.mb[q]) u.pb[q] = b;
+  }
   u.G = g;
   const double rw = (double)N * sizeof(T);
   ObsScope obs(KID_CDS_RESID, s, (a.d + 4.0) * rw + 3.0 * 4.0 * rw, (4.0 + 4.0) * rw + 4.0 * rw);      // SURVEY: B_resid0 + B_Q; moved: 4 bands + x, b, r, x_old + 4 bands written

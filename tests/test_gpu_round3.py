@@ -607,7 +607,8 @@ def test_bench_two_ranks_share_the_gpu():
     assert h["n_gpus"] == 2 and h["steps"] == 4 and h["value"] > 0 and h["invalid_as_measurement"] is True
     assert set(h["decompositions"]) == {"slab", "sets"} and h["decomposition"] == "slab" and h["value"] == h["decompositions"]["slab"]["value"]
     assert all(v["ranks_agree_on_x"] is True for v in h["decompositions"].values()) and h["comm"]["rccl_nranks"] == 2
-    assert h["c3_512"]["value"] > 0 and h["c3_512"]["comm"] == {"decomposition": "slab", "ranks_agree_on_x": True}
+    assert h["c3_512"]["value"] > 0 and h["c3_512"]["comm"]["decomposition"] == "slab" and h["c3_512"]["comm"]["ranks_agree_on_x"] is True
+    assert 0 < h["c3_512"]["comm"]["device_bytes_per_rank"] < 20e9          # sparse arrays: half of the 27 GB a single GPU holds, plus halo planes
     assert isinstance(h["comm_probe_us"], dict) and len(h["comm_probe_us"]) >= 8
     assert h["comm"]["device_bytes_per_rank"] > 0
     d = json.load(open(detail))                                 # everything else: the side file
