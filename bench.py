@@ -881,7 +881,7 @@ def main():
         # profiles/ holds a summary taken on THIS build of libsipx.so (its hash is recorded by tools/summarize_pmc.py), else null
         traffic, traffic_src = None, None
         if args.q_mode == "cds" and args.dtype == "f32" and world == 1:
-            pmc = os.path.join(ROOT, "profiles", f"r03_{'c3_256' if config == 'c3' else config.replace('-', '_')}_pmc.json")
+            pmc = os.path.join(ROOT, "profiles", f"r04_{'c3_256' if config == 'c3' else config.replace('-', '_')}_pmc.json")
             try:                                             # (a profile file must never take the bench line with it)
                 rec = json.load(open(pmc)) if os.path.exists(pmc) else {}
                 if rec.get("libsipx_sha16") == lib_sha16() and "dominant_kernel" in rec:

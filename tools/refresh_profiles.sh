@@ -1,8 +1,8 @@
 #!/bin/bash
 # Regenerates the round's profile files on a GPU box (run through gpurun from the repo root); outputs under gpurun_out/prof/,
-# to be copied into profiles/ by the caller.  usage: tools/refresh_profiles.sh [round tag, default r03] [light]
+# to be copied into profiles/ by the caller.  usage: tools/refresh_profiles.sh [round tag, default r04] [light]
 set -e -o pipefail
-R=${1:-r03}
+R=${1:-r04}
 LIGHT=${2:-}
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 O=gpurun_out/prof; mkdir -p $O
