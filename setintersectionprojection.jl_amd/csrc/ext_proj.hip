@@ -726,17 +726,49 @@ __global__ __launch_bounds__(256) void k_ritz_jacobi(int b, int batch, const dou
 }
 // What the host needs to choose the next filter: res[2] <- min over the batch of t_r = 2 theta_r / a - 1 (bit pattern of a
 // positive double, start from +inf), res[3] <- max over the batch of the number of Ritz vectors far above the lowest column
-__global__ void k_cheb_plan(int b, int g, int r, int batch, const double* __restrict__ W, unsigned long long* res) {
+// -- both over the matrices whose residual (per_matrix, k_sub_residual) is still above tol: the others are not what the next
+// filter is for (res[3]); res[5] <- the count of far-above vectors over ALL matrices (a filter that runs on the whole batch must
+// project for the converged ones too: their vectors would lose what they have to a direction 1e5 times larger)
+__global__ void k_cheb_plan(int b, int g, int r, int batch, const double* __restrict__ W, const double* __restrict__ per_matrix, double tol,
+                            unsigned long long* res) {
   const int l = blockIdx.x * blockDim.x + threadIdx.x;
   if (l >= batch) return;
   const double* Wl = W + (long long)l * b;
   const double a = cheb_floor(Wl, b, g, r);
+  int nl = 0;
+  for (int i = 0; i < b; ++i) nl += Wl[i] > CHEB_KAPPA * a ? 1 : 0;
+  atomicMax(res + 5, (unsigned long long)nl);
+  if (!(per_matrix[l] > tol)) return;
   double t = 2.0 * Wl[b - r] / a - 1.0;
   if (!(t > 1.0)) t = 1.0;
   atomicMin(res + 2, (unsigned long long)__double_as_longlong(t));
-  int nl = 0;
-  for (int i = 0; i < b; ++i) nl += Wl[i] > CHEB_KAPPA * a ? 1 : 0;
   atomicMax(res + 3, (unsigned long long)nl);
+}
+// The matrices whose residual is still above tol, in ascending order -> idx, their number -> res[4] (one workgroup).
+__global__ __launch_bounds__(256) void k_sub_list(int batch, const double* __restrict__ per_matrix, double tol, int* __restrict__ idx,
+                                                  unsigned long long* res) {
+  __shared__ int cnt[256];
+  const int t = threadIdx.x;
+  const int chunk = (batch + 255) / 256, lo = t * chunk, hi = lo + chunk < batch ? lo + chunk : batch;
+  int c = 0;
+  for (int l = lo; l < hi; ++l) c += per_matrix[l] > tol ? 1 : 0;
+  cnt[t] = c;
+  __syncthreads();
+  int base = 0;
+  for (int j = 0; j < t; ++j) base += cnt[j];
+  for (int l = lo; l < hi; ++l)
+    if (per_matrix[l] > tol) idx[base++] = l;
+  if (t == 255) res[4] = (unsigned long long)base;
+}
+// dst[j] <- src[idx[j]] (gather) or dst[idx[j]] <- src[j] (scatter), `per` values per matrix
+__global__ __launch_bounds__(BLOCK) void k_sub_move(long long per, int n, const int* __restrict__ idx, const double* __restrict__ src,
+                                                    double* __restrict__ dst, int scatter) {
+  const long long total = per * n;
+  for (long long e = (long long)blockIdx.x * BLOCK + threadIdx.x; e < total; e += (long long)gridDim.x * BLOCK) {
+    const long long j = e / per, o = e - j * per;
+    if (scatter) dst[(long long)idx[j] * per + o] = src[e];
+    else dst[e] = src[(long long)idx[j] * per + o];
+  }
 }
 // Inertia certificate for a converged top-r block on a spectrum too flat for the energy bound of k_sub_residual:
 // B = mu I - G + X_r Theta_r X_r' is positive definite (its Cholesky factorisation exists) exactly when G, with the r found
@@ -831,6 +863,11 @@ struct ExtImpl {
   // inertia certificate, calls to sit out after a failed attempt
   bool cheb = false;
   double *Ys = nullptr, *Bd = nullptr, *Cs = nullptr;
+  // the matrices that still need a filter when most of the batch has converged, packed (rank_cheb_route)
+  double *Xc = nullptr, *Wc = nullptr, *Froc = nullptr;
+  int* sub_idx = nullptr;
+  int sub_cap = 0;
+  long long n_packed = 0;
   int cheb_skip[2] = {0, 0}, cheb_fails[2] = {0, 0};
   bool cert_warm = false;
   long long n_calls = 0, n_subspace = 0, n_full = 0, n_products = 0;       // route_counts()
@@ -1010,14 +1047,21 @@ ExtProj<T>::ExtProj(const ExtSpec& spec, hipStream_t stream) {
         I.Ws = I.template alloc<double>((size_t)I.sub_b * I.batch);
         I.Es = I.template alloc<double>((size_t)I.sub_b * I.batch);
         I.Fro = I.template alloc<double>((size_t)I.batch);
-        I.sub_res = I.template alloc<unsigned long long>(4);
-        SIPX_HIP(hipHostMalloc((void**)&I.sub_res_host, 4 * sizeof(unsigned long long), hipHostMallocDefault));
+        I.sub_res = I.template alloc<unsigned long long>(8);
+        SIPX_HIP(hipHostMalloc((void**)&I.sub_res_host, 8 * sizeof(unsigned long long), hipHostMallocDefault));
         const char* ch_e = getenv("SIPX_RANK_CHEB");           // 0: plain subspace iteration only (spectra with a gap)
         I.cheb = !(ch_e && ch_e[0] == '0');
         if (I.cheb) {
           I.Ys = I.template alloc<double>(nb);
           I.Cs = I.template alloc<double>((size_t)I.sub_b * I.sub_b * I.batch);
           I.Bd = I.template alloc<double>((size_t)k * k * I.batch);       // the matrix of the inertia certificate
+          I.sub_cap = I.batch / 4;
+          if (I.sub_cap > 0) {
+            I.Xc = I.template alloc<double>((size_t)k * I.sub_b * I.sub_cap);
+            I.Wc = I.template alloc<double>((size_t)I.sub_b * I.sub_cap);
+            I.Froc = I.template alloc<double>((size_t)I.sub_cap);
+            I.sub_idx = I.template alloc<int>((size_t)I.batch);
+          }
         }
       }
     }
@@ -1163,7 +1207,7 @@ __global__ __launch_bounds__(BLOCK) void k_copy_if_needed(long long N, const T* 
 // Returns false -- the caller then decomposes fully -- when the budget of multiplications cannot suffice, a factorisation
 // fails or the certificate does not hold.
 template <typename T>
-static bool rank_cheb_route(ExtImpl<T>& I, int w, int k) {
+static bool rank_cheb_route(ExtImpl<T>& I, int w, int k, bool& cheap_fail) {
   hipStream_t s = I.stream;
   const int b = I.sub_b, r = I.r, batch = I.batch;
   const double one = 1.0, zero = 0.0, mone = -1.0;
@@ -1179,7 +1223,8 @@ static bool rank_cheb_route(ExtImpl<T>& I, int w, int k) {
   const bool fused_proj = !(fp_e && fp_e[0] == '0');
   const char* mm_e = getenv("SIPX_RANK_CHEB_MMAX");
   const int m_cap = mm_e && atoi(mm_e) >= 2 ? atoi(mm_e) : 16;
-  const double tol = 1e-12;
+  const char* tol_e = getenv("SIPX_RANK_CHEB_TOL");        // (experiments: is a difference between the routes a matter of this tolerance?)
+  const double tol = tol_e && atof(tol_e) > 0 ? atof(tol_e) : 1e-12;
   const char* g_e = getenv("SIPX_RANK_CHEB_GUARD");
   const int g = g_e ? std::max(0, std::min(atoi(g_e), b - r - 1)) : (b - r) / 8;      // index of the Ritz value that ends the damped interval
   const auto t_start = std::chrono::steady_clock::now();
@@ -1195,52 +1240,73 @@ static bool rank_cheb_route(ExtImpl<T>& I, int w, int k) {
   double* X = I.Xs[w];
   // three blocks in rotation: A the block to orthonormalise (then the orthonormal basis), F1 and F2 free
   double *A = I.Qs, *F1 = I.Ys, *F2 = I.Zs;
+  // what the loop works on: the whole batch -- or, once three quarters of it have converged, the matrices that have not, packed
+  // (G into the certificate's matrix, which is free until the end; X into a block of its own: the converged matrices' vectors
+  // stay where they are; the scratch blocks are used from their front).  The second and later filters of a call were observed
+  // to run for 1 to 27 of 512 slices.
+  int nb = batch;
+  double *Gd = I.Gd, *Ws = I.Ws, *Fro = I.Fro;
+  bool packed = false;
+  const char* pk_e = getenv("SIPX_RANK_PACK");             // 0: every filter on the whole batch (A/B)
+  const bool may_pack = I.sub_cap > 0 && !(pk_e && pk_e[0] == '0');
   hipLaunchKernelGGL(k_sub_fro, dim3(batch), dim3(BLOCK), 0, s, k, I.Gd, I.Fro);
   SIPX_HIP(hipMemcpyAsync(A, X, sizeof(double) * (size_t)sX * batch, hipMemcpyDeviceToDevice, s));
   mark(7);
   int mults = 0, m_prev = 0;
   double prev = -1;
   bool ok = false, fresh_start = true, tried_other = false;
+  cheap_fail = false;
   for (int outer = 0; outer < 9; ++outer) {
     // Rayleigh-Ritz on span(A): Cholesky QR (twice behind a filter: its columns lean on each other), H = Q'GQ, X = Q S
-    SIPX_HIP(hipMemsetAsync(I.info, 0, sizeof(rocblas_int) * batch, s));
+    SIPX_HIP(hipMemsetAsync(I.info, 0, sizeof(rocblas_int) * 2 * batch, s));
     for (int pass = 0; pass < (m_prev > 0 ? 2 : 1); ++pass) {
-      blas_check(rocblas_dgemm_strided_batched(I.blas, T_, N_, b, b, k, &one, A, k, sX, A, k, sX, &zero, I.Hs, b, sH, batch), "Y'Y");
-      hipLaunchKernelGGL(k_chol_inv, dim3(batch), dim3(256), 0, s, b, batch, I.Hs, I.Cs, I.info);
-      blas_check(rocblas_dgemm_strided_batched(I.blas, N_, N_, k, b, b, &one, A, k, sX, I.Cs, b, sH, &zero, F1, k, sX, batch), "Y Rinv");
+      blas_check(rocblas_dgemm_strided_batched(I.blas, T_, N_, b, b, k, &one, A, k, sX, A, k, sX, &zero, I.Hs, b, sH, nb), "Y'Y");
+      hipLaunchKernelGGL(k_chol_inv, dim3(nb), dim3(256), 0, s, b, nb, I.Hs, I.Cs, I.info);
+      blas_check(rocblas_dgemm_strided_batched(I.blas, N_, N_, k, b, b, &one, A, k, sX, I.Cs, b, sH, &zero, F1, k, sX, nb), "Y Rinv");
       std::swap(A, F1);
     }
     mark(0);
-    blas_check(rocblas_dgemm_strided_batched(I.blas, N_, N_, k, b, k, &one, I.Gd, k, sG, A, k, sX, &zero, F1, k, sX, batch), "G Q");
+    blas_check(rocblas_dgemm_strided_batched(I.blas, N_, N_, k, b, k, &one, Gd, k, sG, A, k, sX, &zero, F1, k, sX, nb), "G Q");
     ++mults;
     mark(1);
-    blas_check(rocblas_dgemm_strided_batched(I.blas, T_, N_, b, b, k, &one, A, k, sX, F1, k, sX, &zero, I.Hs, b, sH, batch), "Q'GQ");
+    blas_check(rocblas_dgemm_strided_batched(I.blas, T_, N_, b, b, k, &one, A, k, sX, F1, k, sX, &zero, I.Hs, b, sH, nb), "Q'GQ");
     mark(2);
     if (own_jacobi)
-      hipLaunchKernelGGL(k_ritz_jacobi, dim3(batch), dim3(256), 0, s, b, batch, I.Hs, I.Hs, I.Ws, I.info + batch);
+      hipLaunchKernelGGL(k_ritz_jacobi, dim3(nb), dim3(256), 0, s, b, nb, I.Hs, I.Hs, Ws, I.info + batch);
     else
       blas_check(rocsolver_dsyevj_strided_batched(I.blas, rocblas_esort_ascending, rocblas_evect_original, rocblas_fill_upper, b, I.Hs, b, sH,
-                                                  0.0, I.Es, 100, I.info + 2 * batch, I.Ws, b, I.info + batch, batch), "syevj (Ritz)");
+                                                  0.0, I.Es, 100, I.info + 2 * batch, Ws, b, I.info + batch, nb), "syevj (Ritz)");
     mark(3);
-    blas_check(rocblas_dgemm_strided_batched(I.blas, N_, N_, k, b, b, &one, A, k, sX, I.Hs, b, sH, &zero, X, k, sX, batch), "Q Z");
-    blas_check(rocblas_dgemm_strided_batched(I.blas, N_, N_, k, b, b, &one, F1, k, sX, I.Hs, b, sH, &zero, F2, k, sX, batch), "(GQ) Z");
+    blas_check(rocblas_dgemm_strided_batched(I.blas, N_, N_, k, b, b, &one, A, k, sX, I.Hs, b, sH, &zero, X, k, sX, nb), "Q Z");
+    blas_check(rocblas_dgemm_strided_batched(I.blas, N_, N_, k, b, b, &one, F1, k, sX, I.Hs, b, sH, &zero, F2, k, sX, nb), "(GQ) Z");
     mark(2);
-    SIPX_HIP(hipMemsetAsync(I.sub_res, 0, 4 * sizeof(unsigned long long), s));
+    SIPX_HIP(hipMemsetAsync(I.sub_res, 0, 8 * sizeof(unsigned long long), s));
     SIPX_HIP(hipMemsetAsync(I.sub_res + 2, 0x7f, sizeof(unsigned long long), s));       // a large positive double: the minimum starts there
-    hipLaunchKernelGGL(k_sub_residual, dim3(batch), dim3(BLOCK), 0, s, k, b, r, batch, F2, X, I.Ws, b, I.info, I.info + batch, I.Fro, I.sub_res, I.Es);
-    hipLaunchKernelGGL(k_cheb_plan, dim3((batch + 63) / 64), dim3(64), 0, s, b, g, r, batch, I.Ws, I.sub_res);
-    SIPX_HIP(hipMemcpyAsync(I.sub_res_host, I.sub_res, 4 * sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
+    hipLaunchKernelGGL(k_sub_residual, dim3(nb), dim3(BLOCK), 0, s, k, b, r, nb, F2, X, Ws, b, I.info, I.info + batch, Fro, I.sub_res, I.Es);
+    hipLaunchKernelGGL(k_cheb_plan, dim3((nb + 63) / 64), dim3(64), 0, s, b, g, r, nb, Ws, I.Es, tol, I.sub_res);
+    if (may_pack && !packed) hipLaunchKernelGGL(k_sub_list, dim3(1), dim3(256), 0, s, nb, I.Es, tol, I.sub_idx, I.sub_res);
+    SIPX_HIP(hipMemcpyAsync(I.sub_res_host, I.sub_res, 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
     SIPX_HIP(hipStreamSynchronize(s));
     mark(4);
     double res, tmin;
     std::memcpy(&res, &I.sub_res_host[0], sizeof(double));
     std::memcpy(&tmin, &I.sub_res_host[2], sizeof(double));
     const bool failed = (I.sub_res_host[1] & 15ull) != 0;
-    const bool hidden = (I.sub_res_host[1] & 16ull) != 0;
-    const int nl = (int)I.sub_res_host[3];
-    if (dbg) fprintf(stderr, "[sipx rank] filtered subspace step %d: %d products, residual %.3e, fail-bits %llu, t_r %.4f, %d vectors far above, %.2f ms\n",
-                     outer, mults, res, I.sub_res_host[1], tmin, nl,
+    const bool hidden = packed || (I.sub_res_host[1] & 16ull) != 0;      // (packed: the bit of the converged matrices is no longer seen)
+    const int n_open = (int)I.sub_res_host[4];
+    const bool pack_now = may_pack && !packed && res > tol && n_open >= 1 && n_open <= I.sub_cap;
+    const int nl = (int)I.sub_res_host[(packed || pack_now) ? 3 : 5];
+    if (dbg) fprintf(stderr, "[sipx rank] filtered subspace step %d: %d products, residual %.3e, fail-bits %llu, t_r %.4f, %d vectors far above, "
+                             "%d of %d matrices%s, %.2f ms\n",
+                     outer, mults, res, I.sub_res_host[1], tmin, nl, nb, batch, packed ? " (packed)" : "",
                      std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_start).count());
+    if (dbg >= 3) {                                        // how many matrices of the batch still need a filter
+      std::vector<double> pm(nb);
+      SIPX_HIP(hipMemcpy(pm.data(), I.Es, sizeof(double) * nb, hipMemcpyDeviceToHost));
+      int a12 = 0, a10 = 0, a8 = 0;
+      for (int l = 0; l < nb; ++l) { a12 += pm[l] > 1e-12; a10 += pm[l] > 1e-10; a8 += pm[l] > 1e-8; }
+      fprintf(stderr, "[sipx rank]   matrices above 1e-12: %d, above 1e-10: %d, above 1e-8: %d (of %d)\n", a12, a10, a8, nb);
+    }
     if (failed) break;
     // The previous call's vectors say little about this input (the first iterations of a solve): filters started from there
     // were observed to swamp the guard columns and then stall at a residual of 1e-8 theta_max -- the full decomposition at once.
@@ -1253,10 +1319,20 @@ static bool rank_cheb_route(ExtImpl<T>& I, int w, int k) {
         if (dbg) fprintf(stderr, "[sipx rank] poor start: once more from the vectors of the y update\n");
         continue;
       }
+      cheap_fail = true;              // one Rayleigh-Ritz step spent: nothing the next call should sit out for
       break;
     }
     fresh_start = false;
     if (res <= tol) {
+      if (packed) {                   // the vectors and Ritz values of the packed matrices go back to their places
+        hipLaunchKernelGGL(k_sub_move, dim3(NB), dim3(BLOCK), 0, s, sX, nb, I.sub_idx, X, I.Xs[w], 1);
+        hipLaunchKernelGGL(k_sub_move, dim3(64), dim3(BLOCK), 0, s, (long long)b, nb, I.sub_idx, Ws, I.Ws, 1);
+        X = I.Xs[w];
+        Ws = I.Ws;
+        Gd = I.Gd;
+        Fro = I.Fro;
+        nb = batch;
+      }
       if (!hidden) { ok = true; break; }
       // flat spectrum: the inertia certificate (X_r Theta_r goes through F1)
       hipLaunchKernelGGL(k_cert_shift, dim3(NB), dim3(BLOCK), 0, s, k, b, r, batch, I.Gd, I.Ws, I.Bd);
@@ -1276,11 +1352,11 @@ static bool rank_cheb_route(ExtImpl<T>& I, int w, int k) {
     }
     if (prev > 0 && !(res < 0.5 * prev)) {               // the filter did not do what its degree promised
       if (dbg) {                                           // which matrix, and what its Ritz values look like
-        std::vector<double> pm(batch), ww((size_t)b * batch);
-        SIPX_HIP(hipMemcpy(pm.data(), I.Es, sizeof(double) * batch, hipMemcpyDeviceToHost));
-        SIPX_HIP(hipMemcpy(ww.data(), I.Ws, sizeof(double) * b * batch, hipMemcpyDeviceToHost));
+        std::vector<double> pm(nb), ww((size_t)b * nb);
+        SIPX_HIP(hipMemcpy(pm.data(), I.Es, sizeof(double) * nb, hipMemcpyDeviceToHost));
+        SIPX_HIP(hipMemcpy(ww.data(), Ws, sizeof(double) * b * nb, hipMemcpyDeviceToHost));
         int worst_l = 0, above = 0;
-        for (int l = 0; l < batch; ++l) { if (pm[l] > pm[worst_l]) worst_l = l; above += pm[l] > tol ? 1 : 0; }
+        for (int l = 0; l < nb; ++l) { if (pm[l] > pm[worst_l]) worst_l = l; above += pm[l] > tol ? 1 : 0; }
         fprintf(stderr, "[sipx rank] stalled: %d matrices above the tolerance, worst %d (%.3e); its Ritz values:", above, worst_l, pm[worst_l]);
         for (int j = 0; j < b; ++j) fprintf(stderr, " %.4e", ww[(size_t)worst_l * b + j]);
         fprintf(stderr, "\n");
@@ -1288,6 +1364,21 @@ static bool rank_cheb_route(ExtImpl<T>& I, int w, int k) {
       break;
     }
     prev = res;
+    if (pack_now) {
+      // X, G X, the Ritz values, ||G||_F^2 and G itself of the open matrices, packed; G X lands in F1 (free: the product G Q
+      // has gone into F2 = (G Q) Z), which then takes the place of F2
+      hipLaunchKernelGGL(k_sub_move, dim3(NB), dim3(BLOCK), 0, s, sG, n_open, I.sub_idx, I.Gd, I.Bd, 0);
+      hipLaunchKernelGGL(k_sub_move, dim3(NB), dim3(BLOCK), 0, s, sX, n_open, I.sub_idx, X, I.Xc, 0);
+      hipLaunchKernelGGL(k_sub_move, dim3(NB), dim3(BLOCK), 0, s, sX, n_open, I.sub_idx, F2, F1, 0);
+      hipLaunchKernelGGL(k_sub_move, dim3(64), dim3(BLOCK), 0, s, (long long)b, n_open, I.sub_idx, I.Ws, I.Wc, 0);
+      hipLaunchKernelGGL(k_sub_move, dim3(1), dim3(BLOCK), 0, s, 1LL, n_open, I.sub_idx, I.Fro, I.Froc, 0);
+      std::swap(F1, F2);
+      Gd = I.Bd; X = I.Xc; Ws = I.Wc; Fro = I.Froc;
+      nb = n_open;
+      packed = true;
+      ++I.n_packed;
+      mark(7);
+    }
     // the next filter: T_m(t_r) = cosh(m acosh t_r) >= 10 res / tol, within the cap and the budget
     const double need = std::acosh(std::max(10.0 * res / tol, 2.0));
     const double per = std::acosh(std::max(tmin, 1.0 + 1e-9));
@@ -1308,7 +1399,7 @@ static bool rank_cheb_route(ExtImpl<T>& I, int w, int k) {
     for (int i = 1; i <= m; ++i) {
       double* Z = F2;
       if (i > 1) {
-        blas_check(rocblas_dgemm_strided_batched(I.blas, N_, N_, k, b, k, &one, I.Gd, k, sG, Y1, k, sX, &zero, F1, k, sX, batch), "G Y");
+        blas_check(rocblas_dgemm_strided_batched(I.blas, N_, N_, k, b, k, &one, Gd, k, sG, Y1, k, sX, &zero, F1, k, sX, nb), "G Y");
         ++mults;
         Z = F1;
         mark(1);
@@ -1316,7 +1407,7 @@ static bool rank_cheb_route(ExtImpl<T>& I, int w, int k) {
       double* out = i == 1 ? F2 : (i == 2 ? A : Y0);
       if (nl <= 2 && fused_proj) {
         mark(5);
-        hipLaunchKernelGGL(k_cheb_step_proj, dim3((unsigned)(((long long)b * batch + 3) / 4)), dim3(256), 0, s, k, b, g, r, nl, batch, I.Ws, X, Z, Y1, Y0,
+        hipLaunchKernelGGL(k_cheb_step_proj, dim3((unsigned)(((long long)b * nb + 3) / 4)), dim3(256), 0, s, k, b, g, r, nl, nb, Ws, X, Z, Y1, Y0,
                            out, i == 1 ? 1 : 0);
         mark(6);
         Y0 = Y1;
@@ -1325,13 +1416,13 @@ static bool rank_cheb_route(ExtImpl<T>& I, int w, int k) {
       }
       if (nl > 0) {
         const double* XL = X + (long long)(b - nl) * k;
-        blas_check(rocblas_dgemm_strided_batched(I.blas, T_, N_, nl, b, k, &one, XL, k, sX, Z, k, sX, &zero, I.Hs, b, sH, batch), "X_L' Z");
-        hipLaunchKernelGGL(k_cheb_mask, dim3((unsigned)std::min<long long>(NB, ((long long)nl * b * batch + 255) / 256)), dim3(256), 0, s, b, g, r, nl, batch,
-                           I.Ws, I.Hs);
-        blas_check(rocblas_dgemm_strided_batched(I.blas, N_, N_, k, b, nl, &mone, XL, k, sX, I.Hs, b, sH, &one, Z, k, sX, batch), "Z - X_L C");
+        blas_check(rocblas_dgemm_strided_batched(I.blas, T_, N_, nl, b, k, &one, XL, k, sX, Z, k, sX, &zero, I.Hs, b, sH, nb), "X_L' Z");
+        hipLaunchKernelGGL(k_cheb_mask, dim3((unsigned)std::min<long long>(NB, ((long long)nl * b * nb + 255) / 256)), dim3(256), 0, s, b, g, r, nl, nb,
+                           Ws, I.Hs);
+        blas_check(rocblas_dgemm_strided_batched(I.blas, N_, N_, k, b, nl, &mone, XL, k, sX, I.Hs, b, sH, &one, Z, k, sX, nb), "Z - X_L C");
       }
       mark(5);
-      hipLaunchKernelGGL(k_cheb_step, dim3(NB), dim3(BLOCK), 0, s, k, b, g, r, batch, I.Ws, Z, Y1, Y0, out, i == 1 ? 1 : 0);
+      hipLaunchKernelGGL(k_cheb_step, dim3(NB), dim3(BLOCK), 0, s, k, b, g, r, nb, Ws, Z, Y1, Y0, out, i == 1 ? 1 : 0);
       mark(6);
       Y0 = Y1;
       Y1 = out;
@@ -1341,7 +1432,7 @@ static bool rank_cheb_route(ExtImpl<T>& I, int w, int k) {
     // the g lowest columns sit inside the damped interval: T_m there is anything in [-1, 1], also (nearly) zero, and such a
     // column would be nothing but what leaked in from above -- dependent on the other columns.  They stay what they were.
     if (g > 0)
-      SIPX_HIP(hipMemcpy2DAsync(A, sizeof(double) * (size_t)sX, X, sizeof(double) * (size_t)sX, sizeof(double) * (size_t)k * g, batch,
+      SIPX_HIP(hipMemcpy2DAsync(A, sizeof(double) * (size_t)sX, X, sizeof(double) * (size_t)sX, sizeof(double) * (size_t)k * g, nb,
                                 hipMemcpyDeviceToDevice, s));
   }
   if (dbg >= 2)
@@ -1411,9 +1502,12 @@ void ExtProj<T>::project(T* v, bool feas, double* partials, T* maxpart, T* compa
         if (I.cheb_skip[w] > 0) {
           --I.cheb_skip[w];
         } else {
-          sub_ok = rank_cheb_route<T>(I, w, k);
+          // (an attempt given up at its first Rayleigh-Ritz step -- the start said too little about this input, the second
+          //  iteration of a solve -- has cost a fiftieth of a decomposition: the next call simply tries again)
+          bool cheap_fail = false;
+          sub_ok = rank_cheb_route<T>(I, w, k, cheap_fail);
           if (sub_ok) I.cheb_fails[w] = 0;
-          else { I.cheb_skip[w] = 1 << std::min(I.cheb_fails[w], 5); ++I.cheb_fails[w]; }
+          else if (!cheap_fail) { I.cheb_skip[w] = 1 << std::min(I.cheb_fails[w], 5); ++I.cheb_fails[w]; }
           const char* dbg_e = getenv("SIPX_EXT_DEBUG");
           if (dbg_e && atoi(dbg_e)) fprintf(stderr, "[sipx rank] %s\n", sub_ok ? "subspace accepted" : "full decomposition");
         }

@@ -1573,7 +1573,10 @@ def test_rank_projection_filtered_route_on_flat_spectra(sipx, capfd, monkeypatch
     # the two routes agree to Float32 rounding -- unless the full decomposition itself has left the oracle (r = 7: sigma_7 and
     # sigma_8 of one slice come within 1e-2 of each other on the way and the truncation there is all but discontinuous; the
     # filtered route stays at 1e-5 of the oracle, the full one ends at 2e-4): then they cannot both be near it
-    assert d_sf < 5e-6 + 1.5 * d_fo, (d_so, d_fo, d_sf)
+    # (the bound is the spread of trajectories, not of accuracy: with the acceptance tolerance of the filtered route at 1e-14,
+    #  1e-12 -- the product's -- and 1e-10 the r = 8 case ends 2.0e-6, 6.7e-6 and 2.2e-6 from the oracle, scratch run of round 4:
+    #  white noise truncated inside its own flat spectrum amplifies which Float32 roundings a call happened to make)
+    assert d_sf < 1e-5 + 1.5 * d_fo, (d_so, d_fo, d_sf)
     K = min(len(ls.obj), len(lo.obj), 8)
     assert np.allclose(ls.obj[:K], lo.obj[:K], rtol=2e-3)
 

@@ -1,5 +1,7 @@
 """GPU tests added in round 4: the logged evol_x of a context without a distance term (the residual product queued ahead must
 not overwrite x_old before the log reads it), the device-memory figure of a context, the read-only counters call."""
+import re
+
 import numpy as np
 import pytest
 
@@ -259,3 +261,49 @@ def test_slab_ranks_hold_their_planes_only(sipx, tmp_path, world, kinds, n):
     N = int(np.prod(n))
     if N >= (1 << 21):                # (smaller grids: an array is one or two 2 MiB granules of the mapping whatever the rank holds)
         assert max(int(v["nbytes"]) for v in loc) < 0.8 * int(full[0]["nbytes"]), ([int(v["nbytes"]) for v in loc], int(full[0]["nbytes"]))
+
+
+def test_rank_route_packs_the_slices_that_still_need_a_filter(sipx, capfd, monkeypatch):
+    """Filtered subspace route of the slice-rank projector (ext_proj.hip, rank_cheb_route): once three quarters of the batch have
+    converged, the remaining matrices are packed and the later filters run on those alone.  Fourteen slices with a clear gap behind
+    the block and two that are a constant plus white noise: the packed route must be taken, accept on the inertia certificate, and
+    end where the whole-batch route (SIPX_RANK_PACK=0) and the full decomposition of every call (SIPX_RANK_CHEB=0) end.
+    Reference: src/projectors/project_rank!.jl:26-45."""
+    TF = np.float32
+    n, h = (128, 128, 16), (25.0, 25.0, 25.0)
+    rng = np.random.default_rng(20241005)
+    m3 = np.zeros(n)
+    for k in range(n[2]):
+        if k in (5, 11):
+            m3[:, :, k] = 2000.0 + 100.0 * k + 150.0 * rng.standard_normal(n[:2])
+        else:
+            U, V = rng.standard_normal((n[0], 6)), rng.standard_normal((6, n[1]))
+            m3[:, :, k] = 2500.0 + 200.0 * (U @ V) / 6.0 + 1.0 * rng.standard_normal(n[:2])
+    m = m3.reshape(-1, order="F").astype(TF)
+
+    def solve():
+        g = sipx.compgrid(h, n)
+        c = [sipx.set_definitions("bounds", "identity", 1000.0, 4500.0, ("matrix", "")),
+             sipx.set_definitions("rank", "identity", 0, 8, ("slice", "z"))]
+        opt = sipx.PARSDMM_options(FL=TF, maxit=12)
+        opt.evol_rel_tol = opt.feas_tol = opt.obj_tol = 0.0          # run all iterations
+        P, A, prop = sipx.setup_constraints(c, g, TF)
+        A, AtA, l, y = sipx.PARSDMM_precompute_distribute(A, prop, g, opt)
+        return sipx.PARSDMM(m.copy(), AtA, A, prop, P, g, opt)[0].astype(np.float64)
+
+    monkeypatch.setenv("SIPX_EXT_DEBUG", "1")
+    capfd.readouterr()
+    xp = solve()
+    err = capfd.readouterr().err
+    assert "(packed)" in err and err.count("subspace accepted") >= 4, err[-3000:]
+    packed = [int(a) for a in re.findall(r"(\d+) of 16 matrices \(packed\)", err)]
+    assert packed and max(packed) <= 4, packed
+    monkeypatch.setenv("SIPX_EXT_DEBUG", "0")
+    monkeypatch.setenv("SIPX_RANK_PACK", "0")
+    xw = solve()
+    monkeypatch.delenv("SIPX_RANK_PACK")
+    monkeypatch.setenv("SIPX_RANK_CHEB", "0")
+    xf = solve()
+    nrm = np.linalg.norm(xf)
+    assert np.linalg.norm(xp - xw) / nrm < 5e-6, np.linalg.norm(xp - xw) / nrm
+    assert np.linalg.norm(xp - xf) / nrm < 2e-5, np.linalg.norm(xp - xf) / nrm
