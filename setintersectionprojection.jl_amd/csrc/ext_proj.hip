@@ -774,13 +774,14 @@ __global__ __launch_bounds__(BLOCK) void k_sub_move(long long per, int n, const 
 // B = mu I - G + X_r Theta_r X_r' is positive definite (its Cholesky factorisation exists) exactly when G, with the r found
 // pairs removed, has no eigenvalue above mu; mu = the middle of the gap between the r-th and the (r+1)-th Ritz value.
 // First half: B <- mu I - G and XT <- X_r Theta_r (the rank-r term is added by a GEMM).
+// (low = 1, SIPX_RANK_CERT_CHECK only: mu = half the (r+1)-th Ritz value, below an eigenvalue B must then have -- never definite)
 __global__ __launch_bounds__(BLOCK) void k_cert_shift(int k, int b, int r, int batch, const double* __restrict__ G, const double* __restrict__ W,
-                                                      double* __restrict__ B) {
+                                                      double* __restrict__ B, int low = 0) {
   const long long per = (long long)k * k, total = per * batch;
   for (long long e = (long long)blockIdx.x * BLOCK + threadIdx.x; e < total; e += (long long)gridDim.x * BLOCK) {
     const long long l = e / per, o = e - l * per;
     const int row = (int)(o % k), col = (int)(o / k);
-    const double mu = 0.5 * (W[l * b + b - r] + W[l * b + b - r - 1]);
+    const double mu = low ? 0.5 * W[l * b + b - r - 1] : 0.5 * (W[l * b + b - r] + W[l * b + b - r - 1]);
     B[e] = (row == col ? mu : 0.0) - G[e];
   }
 }
@@ -791,6 +792,61 @@ __global__ __launch_bounds__(BLOCK) void k_cert_scale(int k, int b, int r, int b
     const long long l = e / per, o = e - l * per;
     const int j = b - r + (int)(o / k);
     XT[l * (long long)k * b + (long long)(b - r) * k + o] = X[l * (long long)k * b + (long long)(b - r) * k + o] * W[l * b + j];
+  }
+}
+// Blocked Cholesky for that certificate (only its success matters): the bs x bs diagonal block at (J, J) of every matrix --
+// upper triangle, column-major, leading dimension k -- is factored in LDS, D = U'U, and the inverse of U goes to Winv (64 x 64 per
+// matrix, leading dimension 64), so that the block row of the factor is one GEMM, U_J,rest = Winv' B_J,rest, and the trailing
+// matrix takes one more, B_rest,rest -= U_J,rest' U_J,rest (rank_cert_factor below).  A pivot that is not positive raises info[l]
+// and leaves the identity in Winv: the matrix is not positive definite, whatever the later steps make of it.
+// (rocSOLVER's potrf_strided_batched: 7.3 ms for 512 matrices of 512 x 512, a fifth of the call.)
+__global__ __launch_bounds__(256) void k_chol_diag(int k, int J, int bs, const double* __restrict__ B, long long sB, double* __restrict__ Winv,
+                                                   rocblas_int* __restrict__ info) {
+  __shared__ double A[64 * 65];
+  __shared__ double Bv[64 * 65];
+  const int l = blockIdx.x, t = threadIdx.x;
+  const double* Bl = B + (long long)l * sB + (long long)J * k + J;
+  double* Wl = Winv + (long long)l * 4096;
+  for (int e = t; e < bs * bs; e += 256) {
+    const int i = e % bs, c = e / bs;
+    if (i <= c) A[i * 65 + c] = Bl[(long long)c * k + i];
+    Bv[i * 65 + c] = 0.0;
+  }
+  bool bad = false;
+  for (int j = 0; j < bs; ++j) {
+    __syncthreads();
+    const double piv = A[j * 65 + j];
+    if (!(piv > 0.0)) { bad = true; break; }               // the same value in every thread: a uniform exit (NaN lands here too)
+    const double inv = 1.0 / sqrt(piv);
+    __syncthreads();
+    if (t == 0) A[j * 65 + j] = sqrt(piv);
+    for (int c = j + 1 + t; c < bs; c += 256) A[j * 65 + c] *= inv;
+    __syncthreads();
+    const int nrem = bs - j - 1;
+    for (int e = t; e < nrem * nrem; e += 256) {
+      const int ii = e / nrem, cc = e - ii * nrem;
+      if (cc >= ii) A[(j + 1 + ii) * 65 + j + 1 + cc] -= A[j * 65 + j + 1 + ii] * A[j * 65 + j + 1 + cc];
+    }
+  }
+  __syncthreads();
+  if (bad) {
+    if (t == 0) info[l] = 1;
+    for (int e = t; e < 4096; e += 256) Wl[e] = (e % 64 == e / 64) ? 1.0 : 0.0;
+    return;
+  }
+  if (t < bs) {                                              // column t of the inverse of U, back substitution
+    const int c = t;
+    Bv[c * 65 + c] = 1.0 / A[c * 65 + c];
+    for (int i = c - 1; i >= 0; --i) {
+      double acc = 0;
+      for (int q = i + 1; q <= c; ++q) acc += A[i * 65 + q] * Bv[q * 65 + c];
+      Bv[i * 65 + c] = -acc / A[i * 65 + i];
+    }
+  }
+  __syncthreads();
+  for (int e = t; e < 4096; e += 256) {
+    const int i = e % 64, c = e / 64;
+    Wl[e] = (i <= c && c < bs) ? Bv[i * 65 + c] : 0.0;
   }
 }
 __global__ void k_cert_or(int batch, const rocblas_int* __restrict__ info, unsigned long long* res) {
@@ -865,6 +921,7 @@ struct ExtImpl {
   double *Ys = nullptr, *Bd = nullptr, *Cs = nullptr;
   // the matrices that still need a filter when most of the batch has converged, packed (rank_cheb_route)
   double *Xc = nullptr, *Wc = nullptr, *Froc = nullptr;
+  double *cert_w = nullptr, *cert_p = nullptr;     // the certificate's blocked Cholesky: inverse diagonal factors, one block row
   int* sub_idx = nullptr;
   int sub_cap = 0;
   long long n_packed = 0;
@@ -1037,8 +1094,14 @@ ExtProj<T>::ExtProj(const ExtSpec& spec, hipStream_t stream) {
       if (kind == EXT_NUCLEAR) I.Gs = I.template alloc<double>((size_t)k * k * I.batch);
       const char* sub_e = getenv("SIPX_RANK_SUBSPACE");      // read per projector: 0 keeps the full decomposition every call
       const int sub_env = sub_e ? atoi(sub_e) : 1;
-      if (kind == EXT_RANK && sub_env && (I.r + 16) * 4 <= k && I.r + 16 <= 64) {      // worth it only for r << k
-        I.sub_b = I.r + 16;
+      // columns the block holds beyond the r wanted ones: 24 where the matrices are large enough for the route with them, else 16.
+      // (C4, 512 slices of 512 x 512, r = 32, round 4: 12 / 16 / 20 / 24 / 28 / 32 guards -> 15.7 / 15.4 / 16.3 / 16.5 / 16.4 / 16.1 it/s:
+      //  more guards move the end of the damped interval away from theta_r, and the library's GEMM tiles are 32 columns wide --
+      //  48 columns cost what 64 do.)  SIPX_RANK_GUARDS: experiments.
+      const char* ex_e = getenv("SIPX_RANK_GUARDS");
+      const int extra = ex_e && atoi(ex_e) >= 4 ? atoi(ex_e) : ((I.r + 24) * 4 <= k && I.r + 24 <= 64 ? 24 : 16);
+      if (kind == EXT_RANK && sub_env && (I.r + extra) * 4 <= k && I.r + extra <= 64) {      // worth it only for r << k
+        I.sub_b = I.r + extra;
         const size_t nb = (size_t)k * I.sub_b * I.batch;
         for (int w = 0; w < 2; ++w) I.Xs[w] = I.template alloc<double>(nb);
         I.Qs = I.template alloc<double>(nb);
@@ -1055,6 +1118,8 @@ ExtProj<T>::ExtProj(const ExtSpec& spec, hipStream_t stream) {
           I.Ys = I.template alloc<double>(nb);
           I.Cs = I.template alloc<double>((size_t)I.sub_b * I.sub_b * I.batch);
           I.Bd = I.template alloc<double>((size_t)k * k * I.batch);       // the matrix of the inertia certificate
+          I.cert_w = I.template alloc<double>((size_t)4096 * I.batch);
+          I.cert_p = I.template alloc<double>((size_t)64 * k * I.batch);
           I.sub_cap = I.batch / 4;
           if (I.sub_cap > 0) {
             I.Xc = I.template alloc<double>((size_t)k * I.sub_b * I.sub_cap);
@@ -1198,6 +1263,30 @@ __global__ __launch_bounds__(BLOCK) void k_copy_if_needed(long long N, const T* 
   for (long long e = (long long)blockIdx.x * BLOCK + threadIdx.x; e < N; e += (long long)gridDim.x * BLOCK) dst[e] = src[e];
 }
 
+// Is every matrix of I.Bd positive definite?  info[l] != 0 where not.  Right-looking blocked Cholesky, 64 columns a step:
+// k_chol_diag, then the block row and the trailing update as two batched GEMMs (the whole trailing square: the lower half is
+// wasted work the library does faster than a loop over block columns would save).
+template <typename T>
+static void rank_cert_factor(ExtImpl<T>& I, int k) {
+  hipStream_t s = I.stream;
+  const double one = 1.0, zero = 0.0, mone = -1.0;
+  const long long sG = (long long)k * k, sP = (long long)64 * k;
+  const auto N_ = rocblas_operation_none, T_ = rocblas_operation_transpose;
+  SIPX_HIP(hipMemsetAsync(I.info, 0, sizeof(rocblas_int) * I.batch, s));
+  for (int J = 0; J < k; J += 64) {
+    const int bs = std::min(64, k - J), rem = k - J - bs;
+    hipLaunchKernelGGL(k_chol_diag, dim3(I.batch), dim3(256), 0, s, k, J, bs, I.Bd, sG, I.cert_w, I.info);
+    if (rem <= 0) break;
+    double* panel = I.Bd + (long long)(J + bs) * k + J;            // rows J .. J+bs, columns from J+bs on
+    blas_check(rocblas_dgemm_strided_batched(I.blas, T_, N_, bs, rem, bs, &one, I.cert_w, 64, 4096, panel, k, sG, &zero, I.cert_p, 64, sP, I.batch),
+               "certificate: block row");
+    double* trail = I.Bd + (long long)(J + bs) * k + (J + bs);
+    blas_check(rocblas_dgemm_strided_batched(I.blas, T_, N_, rem, rem, bs, &mone, I.cert_p, 64, sP, I.cert_p, 64, sP, &one, trail, k, sG, I.batch),
+               "certificate: trailing update");
+  }
+  SIPX_HIP(hipGetLastError());
+}
+
 // Rank projection, Gram route: the top-r invariant subspace of every G_l from the Ritz vectors of the previous call (I.Xs[w]),
 // by Rayleigh-Ritz steps with a Chebyshev filter between them (kernels above).  One multiplication with G per filter degree
 // and one per Rayleigh-Ritz step; the degree of every filter is chosen from the residual still to be removed and the
@@ -1226,7 +1315,8 @@ static bool rank_cheb_route(ExtImpl<T>& I, int w, int k, bool& cheap_fail) {
   const char* tol_e = getenv("SIPX_RANK_CHEB_TOL");        // (experiments: is a difference between the routes a matter of this tolerance?)
   const double tol = tol_e && atof(tol_e) > 0 ? atof(tol_e) : 1e-12;
   const char* g_e = getenv("SIPX_RANK_CHEB_GUARD");
-  const int g = g_e ? std::max(0, std::min(atoi(g_e), b - r - 1)) : (b - r) / 8;      // index of the Ritz value that ends the damped interval
+  // index of the Ritz value that ends the damped interval (C4 with 24 guards: 2 / 3 / 4 / 6 -> 16.8 / 16.5 / 16.6 / 16.0 it/s)
+  const int g = g_e ? std::max(0, std::min(atoi(g_e), b - r - 1)) : std::max(2, (b - r) / 12);
   const auto t_start = std::chrono::steady_clock::now();
   double ph[8] = {0, 0, 0, 0, 0, 0, 0, 0};                 // SIPX_EXT_DEBUG=2: milliseconds per phase (the stream is drained at every mark)
   auto t_mark = t_start;
@@ -1247,6 +1337,8 @@ static bool rank_cheb_route(ExtImpl<T>& I, int w, int k, bool& cheap_fail) {
   int nb = batch;
   double *Gd = I.Gd, *Ws = I.Ws, *Fro = I.Fro;
   bool packed = false;
+  const char* ce_e = getenv("SIPX_RANK_CERT_POTRF");       // 1: the library's factorisation for the certificate (A/B)
+  const bool own_cert = !(ce_e && ce_e[0] == '1');
   const char* pk_e = getenv("SIPX_RANK_PACK");             // 0: every filter on the whole batch (A/B)
   const bool may_pack = I.sub_cap > 0 && !(pk_e && pk_e[0] == '0');
   hipLaunchKernelGGL(k_sub_fro, dim3(batch), dim3(BLOCK), 0, s, k, I.Gd, I.Fro);
@@ -1339,13 +1431,36 @@ static bool rank_cheb_route(ExtImpl<T>& I, int w, int k, bool& cheap_fail) {
       hipLaunchKernelGGL(k_cert_scale, dim3(NB), dim3(BLOCK), 0, s, k, b, r, batch, X, I.Ws, F1);
       blas_check(rocblas_dgemm_strided_batched(I.blas, N_, T_, k, k, r, &one, F1 + (long long)(b - r) * k, k, sX, X + (long long)(b - r) * k, k, sX,
                                                &one, I.Bd, k, sG, batch), "certificate: rank-r term");
-      blas_check(rocsolver_dpotrf_strided_batched(I.blas, rocblas_fill_upper, k, I.Bd, k, sG, I.info, batch), "certificate: potrf");
+      if (own_cert) rank_cert_factor<T>(I, k);
+      else blas_check(rocsolver_dpotrf_strided_batched(I.blas, rocblas_fill_upper, k, I.Bd, k, sG, I.info, batch), "certificate: potrf");
       SIPX_HIP(hipMemsetAsync(I.sub_res, 0, 2 * sizeof(unsigned long long), s));
       hipLaunchKernelGGL(k_cert_or, dim3((batch + 63) / 64), dim3(64), 0, s, batch, I.info, I.sub_res);
       SIPX_HIP(hipMemcpyAsync(I.sub_res_host, I.sub_res, 2 * sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
       SIPX_HIP(hipStreamSynchronize(s));
       ok = (I.sub_res_host[1] & 32ull) == 0;
       mark(7);
+      if (getenv("SIPX_RANK_CERT_CHECK")) {
+        // the blocked factorisation against the library's, matrix by matrix, on the certificate's own matrices and on matrices
+        // that cannot be definite (tests)
+        for (int low = 0; low < 2; ++low) {
+          std::vector<rocblas_int> v[2];
+          for (int lib = 0; lib < 2; ++lib) {
+            hipLaunchKernelGGL(k_cert_shift, dim3(NB), dim3(BLOCK), 0, s, k, b, r, batch, I.Gd, I.Ws, I.Bd, low);
+            blas_check(rocblas_dgemm_strided_batched(I.blas, N_, T_, k, k, r, &one, F1 + (long long)(b - r) * k, k, sX, X + (long long)(b - r) * k, k, sX,
+                                                     &one, I.Bd, k, sG, batch), "certificate: rank-r term");
+            if (lib) blas_check(rocsolver_dpotrf_strided_batched(I.blas, rocblas_fill_upper, k, I.Bd, k, sG, I.info, batch), "certificate: potrf");
+            else rank_cert_factor<T>(I, k);
+            v[lib].resize(batch);
+            SIPX_HIP(hipStreamSynchronize(s));
+            SIPX_HIP(hipMemcpy(v[lib].data(), I.info, sizeof(rocblas_int) * batch, hipMemcpyDeviceToHost));
+          }
+          int differ = 0, indef = 0;
+          for (int l = 0; l < batch; ++l) { differ += (v[0][l] != 0) != (v[1][l] != 0); indef += v[1][l] != 0; }
+          fprintf(stderr, "[sipx rank] certificate check (%s shift): %d of %d matrices not positive definite, the two factorisations differ on %d\n",
+                  low ? "low" : "the certificate's", indef, batch, differ);
+          if (differ) throw std::runtime_error("internal: the blocked Cholesky of the inertia certificate and the library's disagree");
+        }
+      }
       if (dbg) fprintf(stderr, "[sipx rank] inertia certificate %s, %.2f ms\n", ok ? "holds" : "fails",
                        std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_start).count());
       break;
@@ -1583,7 +1698,8 @@ void ExtProj<T>::project(T* v, bool feas, double* partials, T* maxpart, T* compa
           double q;
           std::memcpy(&q, &I.sub_res_host[0], sizeof(double));
           I.sub_have[w] = true;
-          if (I.cheb && !I.cert_warm) {
+          const char* ce_e = getenv("SIPX_RANK_CERT_POTRF");
+          if (I.cheb && !I.cert_warm && ce_e && ce_e[0] == '1') {
             // the library sizes the workspace of a batched factorisation at its first call (a device allocation of its own, 100 ms
             // and more): spend it here, behind a full decomposition, not inside the first accepted call of the filtered route
             I.cert_warm = true;

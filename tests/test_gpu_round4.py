@@ -307,3 +307,34 @@ def test_rank_route_packs_the_slices_that_still_need_a_filter(sipx, capfd, monke
     nrm = np.linalg.norm(xf)
     assert np.linalg.norm(xp - xw) / nrm < 5e-6, np.linalg.norm(xp - xw) / nrm
     assert np.linalg.norm(xp - xf) / nrm < 2e-5, np.linalg.norm(xp - xf) / nrm
+
+
+def test_certificate_factorisation_agrees_with_the_library(sipx, capfd, monkeypatch):
+    """The inertia certificate of the filtered rank route factors mu I - G + X_r Theta_r X_r' with a blocked Cholesky of its own
+    (ext_proj.hip, rank_cert_factor: k_chol_diag + two batched GEMMs per 64 columns).  SIPX_RANK_CERT_CHECK runs it and rocSOLVER's
+    potrf side by side on the certificate's matrices (positive definite when the certificate holds) and on matrices shifted below an
+    eigenvalue (never definite): same verdict for every matrix, at 128 x 128 (two blocks) and 160 x 160 (a ragged last block)."""
+    TF = np.float32
+    for n in ((128, 128, 6), (160, 160, 5)):
+        h = (25.0, 25.0, 25.0)
+        rng = np.random.default_rng(20241006)
+        zz = np.linspace(0.0, 1.0, n[2])[None, None, :]
+        m = (1500.0 + 2500.0 * zz + 150.0 * rng.standard_normal(n)).reshape(-1, order="F").astype(TF)
+        g = sipx.compgrid(h, n)
+        c = [sipx.set_definitions("bounds", "identity", 1600.0, 3900.0, ("matrix", "")),
+             sipx.set_definitions("rank", "identity", 0, 8, ("slice", "z"))]
+        opt = sipx.PARSDMM_options(FL=TF, maxit=8)
+        opt.evol_rel_tol = opt.feas_tol = opt.obj_tol = 0.0
+        P, A, prop = sipx.setup_constraints(c, g, TF)
+        A, AtA, l, y = sipx.PARSDMM_precompute_distribute(A, prop, g, opt)
+        monkeypatch.setenv("SIPX_RANK_CERT_CHECK", "1")
+        capfd.readouterr()
+        sipx.PARSDMM(m.copy(), AtA, A, prop, P, g, opt)
+        err = capfd.readouterr().err
+        monkeypatch.delenv("SIPX_RANK_CERT_CHECK")
+        lines = re.findall(r"certificate check \((.*?) shift\): (\d+) of (\d+) matrices not positive definite, the two factorisations differ on (\d+)", err)
+        assert len(lines) >= 4, err[-2000:]
+        for which, indef, batch, differ in lines:
+            assert int(differ) == 0
+            if which == "low":
+                assert int(indef) == int(batch) == n[2]
