@@ -14,6 +14,8 @@
 #include <limits>
 #include <map>
 #include <mutex>
+#include <thread>
+#include <exception>
 
 namespace sipx {
 
@@ -314,6 +316,10 @@ class Engine : public EngineBase {
   }
   ~Engine() override {
     (void)hipSetDevice(device_);
+    if (lane_thr_.joinable()) lane_thr_.join();
+    if (lane_st_) { (void)hipStreamSynchronize(lane_st_); (void)hipStreamDestroy(lane_st_); }
+    for (hipEvent_t e : {lane_fork_, lane_ev_}) if (e) (void)hipEventDestroy(e);
+    dfree(lane_v_);
     (void)hipStreamSynchronize(stream_);
     for (auto& s : sets_) free_set(s);
     for (void* p : {(void*)xr_base_[0], (void*)xr_base_[1], (void*)xr_base_[2], (void*)w_base_, (void*)rhs_, (void*)m_base_, (void*)r_base_, (void*)p_base_, (void*)p2_base_, (void*)Ap_, (void*)Q_, (void*)Q2_,
@@ -834,6 +840,25 @@ class Engine : public EngineBase {
 
     assemble_Q();
     if (q_fused_ && !stencil_q_ && !comm_ && cds_.march != 0) Q2_ = dalloc<T>((size_t)Nx_ * cds_.d);     // (SIPX_Q_FUSED=1 only)
+    {
+      // The lane: one rank, a list the sweep takes in part (C4) -- the slice-rank / nuclear-norm set, a chain of batched GEMMs and
+      // small factorisations with host round trips in it (ext_proj.hip), runs on a stream of its own, queued by a host thread of
+      // its own, beside the searches, the sweep and the other loose sets on the engine stream; its update only needs x.
+      // SIPX_RANK_LANE=0: in turn on the engine stream (A/B switch, tests).
+      const char* ln = std::getenv("SIPX_RANK_LANE");
+      lane_set_ = -1;
+      if (!comm_ && !mk_ && sweep_partial_ && !(ln && ln[0] == '0'))
+        for (int i = 0; i < p_n_ && lane_set_ < 0; ++i) {
+          const SetState<T>& s = sets_[i];
+          if (s.owned && !s.in_sweep && !s.dist_ext && s.ident && !s.custom && s.ext && (s.ext_kind == EXT_RANK || s.ext_kind == EXT_NUCLEAR)) lane_set_ = i;
+        }
+      if (lane_set_ >= 0) {
+        SIPX_HIP(hipStreamCreateWithFlags(&lane_st_, hipStreamNonBlocking));
+        SIPX_HIP(hipEventCreateWithFlags(&lane_fork_, hipEventDisableTiming));
+        SIPX_HIP(hipEventCreateWithFlags(&lane_ev_, hipEventDisableTiming));
+        lane_v_ = dalloc<T>((size_t)sets_[lane_set_].Mpad);
+      }
+    }
     finalized_ = true;
 
     // initial feasibility ||P_i(A_i m) - A_i m|| / (||A_i m|| + 100 eps)   (PARSDMM_initialize.jl:97-99)
@@ -1117,6 +1142,13 @@ class Engine : public EngineBase {
     // per-set kernels below, on the engine stream.  The fused right-hand side then holds the sets in front of the first loose
     // one (MultiBlk::in_rhs; the sets are added in order, rhs_compose.jl:24-31) and k_rhs adds the rest.
     const bool loose_only = sweep && !slab_;
+    // (the all-kernel statistics window keeps everything on the engine stream: its event pairs time one kernel at a time)
+    const bool lane_now = loose_only && lane_set_ >= 0 && stats_mode_ != 2;
+    struct LaneGuard {                       // whatever ends this call, the lane's host thread is joined first
+      Engine<T>* e;
+      ~LaneGuard() { if (e->lane_thr_.joinable()) e->lane_thr_.join(); }
+    } lane_guard{this};
+    if (lane_now) lane_start(flags, rho, gamma);
     if (loose_only) {
       if (search_batch_) batched_searches(flags, rho, gamma);
       else sweep_searches(flags, rho, gamma);
@@ -1289,6 +1321,7 @@ class Engine : public EngineBase {
       SetState<T>& s = sets_[i];
       if (!s.owned || s.dist_ext) continue;
       if (loose_only && s.in_sweep) continue;             // (updated by the sweep above)
+      if (lane_now && i == lane_set_) continue;           // (on its lane, lane_start)
       SetArgs<T> a = set_args(s, (T)rho[i], (T)gamma[i], flags);
       if (mk_) a.x = s.comp == 1 ? x_ : (s.comp == 2 ? x_ + G_.N : w_);
       double* part = part_sets_ + (size_t)i * SLOTS * NB;
@@ -1395,6 +1428,7 @@ class Engine : public EngineBase {
       }
       if ((flags & SIPX_YL_FEAS) && i < pp_n_) dist_feasibility(s, x_, part + (size_t)SL_FE2 * NB);
     }
+    if (lane_now) lane_join(flags);
     if (loose_only && rhs_fused_) {
       // the sweep wrote the sum over the sets in front of the first loose one; the rest, in order
       RhsArgs<T> ra;
@@ -1432,6 +1466,63 @@ class Engine : public EngineBase {
       SIPX_HIP(hipEventRecord(ev_sums_, stream_));
       sums_event_ = ev_sums_;
       collect_set_sums(rho, r_pri, r_dual, feas);
+    }
+  }
+
+  // The lane set's y/l update (see sipx_finalize): x is final on the engine stream; store v, project it, update y and l on the
+  // lane stream, queued by a host thread (the projector waits for its own stream between its steps).  The pointer rotation of
+  // the set happens here, on the caller's thread; the thread only launches.
+  void lane_start(int flags, const double* rho, const double* gamma) {
+    SetState<T>& s = sets_[lane_set_];
+    SetArgs<T> a = set_args(s, (T)rho[lane_set_], (T)gamma[lane_set_], flags);
+    const bool snapshot = (flags & (SIPX_YL_BB | SIPX_YL_FIRST)) != 0;
+    const bool first = (flags & SIPX_YL_FIRST) != 0;
+    const bool to_other = snapshot ? (!first && s.snap != 0) : (s.snap == 0);
+    a.yo = to_other ? s.y0 : s.y;
+    a.lo = to_other ? s.l0 : s.l;
+    a.v = lane_v_;
+    lane_args_ = a;
+    SIPX_HIP(hipEventRecord(lane_fork_, stream_));
+    SIPX_HIP(hipStreamWaitEvent(lane_st_, lane_fork_, 0));
+    s.ext->set_stream(lane_st_);
+    lane_err_ = nullptr;
+    double* part = part_sets_ + (size_t)lane_set_ * SLOTS * NB;
+    double* ptmp = s.ptmp ? s.ptmp : part_tmp_;
+    T* mpart = s.mpart ? s.mpart : maxpart_;
+    T* cbuf = s.cbuf ? s.cbuf : scr_c_;
+    ExtProj<T>* ext = s.ext.get();
+    lane_thr_ = std::thread([this, a, part, ptmp, mpart, cbuf, ext]() {
+      try {
+        SIPX_HIP(hipSetDevice(device_));
+        K<T>::store_v(lane_st_, G_, a, 0, lane_v_);
+        ext->project(lane_v_, false, ptmp, mpart, cbuf);
+        SetArgs<T> a2 = a;
+        a2.vsrc = 2;
+        K<T>::yl(lane_st_, Gyl_, a2, part);
+        SIPX_HIP(hipEventRecord(lane_ev_, lane_st_));
+      } catch (...) {
+        lane_err_ = std::current_exception();
+      }
+    });
+    if (to_other) { std::swap(s.y, s.y0); std::swap(s.l, s.l0); }     // (y, l) always names the current iterate
+    if (snapshot) s.snap = 0;
+    else if (to_other && s.snap == 0) s.snap = 1;
+  }
+  void lane_join(int flags) {
+    SetState<T>& s = sets_[lane_set_];
+    if (lane_thr_.joinable()) lane_thr_.join();
+    s.ext->set_stream(stream_);
+    if (lane_err_) {
+      (void)hipStreamSynchronize(lane_st_);
+      std::exception_ptr e = lane_err_;
+      lane_err_ = nullptr;
+      std::rethrow_exception(e);
+    }
+    SIPX_HIP(hipStreamWaitEvent(stream_, lane_ev_, 0));
+    if ((flags & SIPX_YL_FEAS) && lane_set_ < pp_n_) {
+      SetArgs<T> a = lane_args_;
+      a.v = scr_v_;
+      ext_feasibility(s, a, part_sets_ + ((size_t)lane_set_ * SLOTS + SL_FE2) * NB);
     }
   }
 
@@ -2651,6 +2742,7 @@ class Engine : public EngineBase {
          std::to_string(spec_fallbacks_) + ", \"refinement_rounds\": " + std::to_string(spec_rounds_) + "}";
     // one rank: searches through the batched chain (batched_searches) and how many of them needed their fallback sweeps
     o += std::string(", \"sparse_arrays\": ") + (slab_local_ ? "true" : "false");
+    o += ", \"lane_set\": " + std::to_string(lane_set_);       // the set updated on a stream of its own (-1: none), lane_start
     o += ", \"batched_searches\": {\"searches\": " + std::to_string(batch_searches_) + ", \"fallbacks\": " + std::to_string(batch_fallbacks_) + "}";
     // slice-rank / matrix-rank sets: which route their projector took since the context was finalised (ext_proj.hip)
     long long rc[4] = {0, 0, 0, 0};
@@ -3424,6 +3516,14 @@ class Engine : public EngineBase {
   unsigned spec_seq_ = 0;
   long long spec_searches_ = 0, spec_fallbacks_ = 0, spec_rounds_ = 0;     // searches through the speculative exchange / of those, fallbacks / refinement rounds (all-reduces) of the fallbacks
   bool spec_exchange_ = true;         // SIPX_SPEC_EXCHANGE=0: every search through (all-reduce, ..., all-gather), as before
+  // the lane of the slice-rank / nuclear-norm set (sipx_finalize, lane_start)
+  int lane_set_ = -1;
+  hipStream_t lane_st_ = nullptr;
+  hipEvent_t lane_fork_ = nullptr, lane_ev_ = nullptr;
+  T* lane_v_ = nullptr;
+  std::thread lane_thr_;
+  std::exception_ptr lane_err_;
+  SetArgs<T> lane_args_;
   bool sweep_partial_ = false, has_loose_ = false;   // the sweep takes a subset of the sets (in_sweep); some owned set keeps its per-set kernels
   bool pass_multi_ = false;           // SIPX_PASS_MULTI=1: full first passes / fallback passes of the batched searches in one sweep per group (measured slower)
   bool sweep_plain_ = false;          // the sweep takes the plain iterations of this context: every set carries a third y / l pair

@@ -38,6 +38,8 @@ class ExtProj {
   // rank projector: calls since construction, calls served by the warm-started subspace route, calls that decomposed fully,
   // products with the Gram matrices the subspace route spent (all zero for the other kinds)
   void route_counts(long long out[4]) const;
+  // the stream of the calls to come (the engine runs the slice-rank set of a long list on a lane of its own)
+  void set_stream(hipStream_t s);
 
  private:
   ExtImpl<T>* impl_;

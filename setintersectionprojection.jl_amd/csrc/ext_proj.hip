@@ -622,7 +622,7 @@ __global__ __launch_bounds__(256) void k_chol_inv(int b, int batch, const double
 // eigenvectors in the columns of S (column-major, leading dimension b; S may be H itself).  rocSOLVER's syevj takes 2.5 ms for
 // 512 problems of 48 x 48, most of it launches; this kernel about a fifth.
 __global__ __launch_bounds__(256) void k_ritz_jacobi(int b, int batch, const double* H_in, double* S, double* __restrict__ W,
-                                                     rocblas_int* __restrict__ info) {
+                                                     rocblas_int* __restrict__ info, rocblas_int* __restrict__ nsweeps = nullptr) {
   __shared__ double H[64 * 65];
   __shared__ double V[64 * 65];
   __shared__ double rc[32], rs[32];
@@ -711,6 +711,7 @@ __global__ __launch_bounds__(256) void k_ritz_jacobi(int b, int batch, const dou
   }
   __syncthreads();
   if (t == 0) info[l] = (done && s_fro == s_fro) ? 0 : 1;
+  if (t == 0 && nsweeps) nsweeps[l] = sweeps;
   if (t < b) {                                               // ascending order: the rank of every eigenvalue
     const double mine = H[t * 65 + t];
     int pos = 0;
@@ -1364,7 +1365,7 @@ static bool rank_cheb_route(ExtImpl<T>& I, int w, int k, bool& cheap_fail) {
     blas_check(rocblas_dgemm_strided_batched(I.blas, T_, N_, b, b, k, &one, A, k, sX, F1, k, sX, &zero, I.Hs, b, sH, nb), "Q'GQ");
     mark(2);
     if (own_jacobi)
-      hipLaunchKernelGGL(k_ritz_jacobi, dim3(nb), dim3(256), 0, s, b, nb, I.Hs, I.Hs, Ws, I.info + batch);
+      hipLaunchKernelGGL(k_ritz_jacobi, dim3(nb), dim3(256), 0, s, b, nb, I.Hs, I.Hs, Ws, I.info + batch, I.info + 2 * batch);
     else
       blas_check(rocsolver_dsyevj_strided_batched(I.blas, rocblas_esort_ascending, rocblas_evect_original, rocblas_fill_upper, b, I.Hs, b, sH,
                                                   0.0, I.Es, 100, I.info + 2 * batch, Ws, b, I.info + batch, nb), "syevj (Ritz)");
@@ -1392,6 +1393,13 @@ static bool rank_cheb_route(ExtImpl<T>& I, int w, int k, bool& cheap_fail) {
                              "%d of %d matrices%s, %.2f ms\n",
                      outer, mults, res, I.sub_res_host[1], tmin, nl, nb, batch, packed ? " (packed)" : "",
                      std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_start).count());
+    if (dbg >= 3 && own_jacobi) {
+      std::vector<rocblas_int> sw(nb);
+      SIPX_HIP(hipMemcpy(sw.data(), I.info + 2 * batch, sizeof(rocblas_int) * nb, hipMemcpyDeviceToHost));
+      long long tot = 0; int mx = 0;
+      for (int l = 0; l < nb; ++l) { tot += sw[l]; mx = std::max(mx, (int)sw[l]); }
+      fprintf(stderr, "[sipx rank]   Jacobi sweeps: mean %.1f, max %d\n", (double)tot / nb, mx);
+    }
     if (dbg >= 3) {                                        // how many matrices of the batch still need a filter
       std::vector<double> pm(nb);
       SIPX_HIP(hipMemcpy(pm.data(), I.Es, sizeof(double) * nb, hipMemcpyDeviceToHost));
@@ -1811,6 +1819,15 @@ void ExtProj<T>::project(T* v, bool feas, double* partials, T* maxpart, T* compa
     hipLaunchKernelGGL((k_seg_scatter<T, T>), dim3(NB), dim3(BLOCK), 0, s, I.map, I.X, v, (const int*)nullptr);
   }
   SIPX_HIP(hipGetLastError());
+}
+
+template <typename T>
+void ExtProj<T>::set_stream(hipStream_t s) {
+  ExtImpl<T>& I = *impl_;
+  if (I.stream == s) return;
+  I.stream = s;
+  if (I.blas) blas_check(rocblas_set_stream(I.blas, s), "set stream");
+  if (I.have_plan) fft_check(hipfftSetStream(I.plan, s), "set stream");
 }
 
 template <typename T>

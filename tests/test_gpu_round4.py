@@ -338,3 +338,39 @@ def test_certificate_factorisation_agrees_with_the_library(sipx, capfd, monkeypa
             assert int(differ) == 0
             if which == "low":
                 assert int(indef) == int(batch) == n[2]
+
+
+@pytest.mark.parametrize("TF,n", [(np.float32, (32, 32, 12)), (np.float64, (16, 12, 8))])
+def test_rank_set_on_its_lane_is_bit_identical(sipx, TF, n):
+    """One rank, BASELINE config 4's list: the slice-rank set's update runs on a stream of its own, queued by a host thread of its
+    own (engine.cpp, lane_start / lane_join), beside the searches, the sweep and the other loose sets.  Same kernels on the same
+    operands: x, y, l and every logged scalar must equal the in-turn run (SIPX_RANK_LANE=0) bit for bit, feasibility iterations
+    (the lane set's estimate is formed after the join) and Barzilai-Borwein iterations included.
+    Reference: src/update_y_l.jl:36-101 (the sets are independent given x)."""
+    import os
+    h = (25.0, 25.0, 25.0)
+    m = model(n, TF, seed=11)
+    kinds = ["bounds", "l1:D_x", "l1:D_y", "l1:D_z", "annulus", "l1dft", "rank:3", "card:D_z"]
+    kw = dict(maxit=23)
+    out = []
+    for lane in ("1", "0"):
+        os.environ["SIPX_RANK_LANE"] = lane
+        try:
+            g, o, P, A, prop, AtA = _problem(sipx, n, h, TF, kinds, m, kw)
+            o.evol_rel_tol = o.feas_tol = o.obj_tol = 0.0
+            out.append(sipx.PARSDMM(m.copy(), AtA, A, prop, P, g, o))
+        finally:
+            del os.environ["SIPX_RANK_LANE"]
+    g, o, P, A, prop, AtA = _problem(sipx, n, h, TF, kinds, m, kw)
+    ctx = sipx.host.build_context(m, AtA, A, prop, P, g, o)
+    try:
+        assert ctx.kernel_stats_all(-1)["lane_set"] == 6          # the rank set
+    finally:
+        ctx.close()
+    (x1, log1, l1, y1), (x0, log0, l0, y0) = out
+    assert len(log1.obj) == len(log0.obj) == 23
+    assert np.array_equal(x1, x0)
+    for a, b in zip(list(l1) + list(y1), list(l0) + list(y0)):
+        assert np.array_equal(a, b)
+    for f in ("obj", "evol_x", "r_pri", "r_dual", "rho", "gamma", "set_feasibility", "cg_it"):
+        assert np.array_equal(np.asarray(getattr(log1, f)), np.asarray(getattr(log0, f)), equal_nan=True), f
