@@ -620,7 +620,9 @@ __global__ __launch_bounds__(256) void k_chol_inv(int b, int batch, const double
 // first from the right (columns of H and of the accumulated V), then from the left (rows of H) -- one workgroup per matrix,
 // H and V in LDS.  Sweeps until the off-diagonal mass is below 1e-30 of ||H||_F^2 (15 at most).  Eigenvalues ascending in W,
 // eigenvectors in the columns of S (column-major, leading dimension b; S may be H itself).  rocSOLVER's syevj takes 2.5 ms for
-// 512 problems of 48 x 48, most of it launches; this kernel about a fifth.
+// 512 problems of 48 x 48, most of it launches; this kernel about a fifth.  (Round 4: the two passes of a step as one pass over
+// 2 x 2 blocks, loads staged in front of the stores -- the same operations in the same order, the same bits: 1.5 -> 0.9 ms for 512
+// problems of 56 x 56, 5-7 sweeps.)
 __global__ __launch_bounds__(256) void k_ritz_jacobi(int b, int batch, const double* H_in, double* S, double* __restrict__ W,
                                                      rocblas_int* __restrict__ info, rocblas_int* __restrict__ nsweeps = nullptr) {
   __shared__ double H[64 * 65];
@@ -631,13 +633,14 @@ __global__ __launch_bounds__(256) void k_ritz_jacobi(int b, int batch, const dou
   __shared__ double s_off, s_fro;
   const int l = blockIdx.x, t = threadIdx.x;
   const double* Hl = H_in + (long long)l * b * b;
-  for (int e = t; e < b * b; e += 256) {
-    const int i = e % b, c = e / b;
-    // the upper triangle is what the GEMM before filled reliably symmetric to rounding: mirror it
-    H[i * 65 + c] = i <= c ? Hl[(long long)c * b + i] : Hl[(long long)i * b + c];
+  const int n = b + (b & 1), half = n / 2;
+  for (int e = t; e < n * n; e += 256) {
+    const int i = e % n, c = e / n;
+    // the upper triangle is what the GEMM before filled reliably symmetric to rounding: mirror it (an odd b is padded by a
+    // row and a column of zeros: the rotations that involve the pad are the identity, its entries stay zero)
+    H[i * 65 + c] = (i < b && c < b) ? (i <= c ? Hl[(long long)c * b + i] : Hl[(long long)i * b + c]) : 0.0;
     V[i * 65 + c] = i == c ? 1.0 : 0.0;
   }
-  const int n = b + (b & 1), half = n / 2;
   auto block_sum = [&](double v) -> double {
     v = wave_sum(v);
     __syncthreads();
@@ -660,7 +663,10 @@ __global__ __launch_bounds__(256) void k_ritz_jacobi(int b, int batch, const dou
       if (t < half) {
         int p, q;
         if (t == 0) { p = n - 1; q = step; }
-        else { p = (step + t) % (n - 1); q = (step - t + n - 1) % (n - 1); }
+        else {                                 // (step + t) and (step - t) modulo n - 1; t < n - 1
+          p = step + t; if (p >= n - 1) p -= n - 1;
+          q = step - t; if (q < 0) q += n - 1;
+        }
         if (p > q) { const int x = p; p = q; q = x; }
         double c = 1.0, sn = 0.0;
         if (q < b) {
@@ -675,27 +681,60 @@ __global__ __launch_bounds__(256) void k_ritz_jacobi(int b, int batch, const dou
         rp[t] = p; rq[t] = q; rc[t] = c; rs[t] = sn;
       }
       __syncthreads();
-      for (int it = t; it < half * b; it += 256) {         // H <- H J, V <- V J
-        const int i = it / b, e = it - i * b;
-        const int p = rp[i], q = rq[i];
-        if (q >= b) continue;
-        const double c = rc[i], sn = rs[i];
-        const double hp = H[e * 65 + p], hq = H[e * 65 + q];
-        H[e * 65 + p] = c * hp - sn * hq;
-        H[e * 65 + q] = sn * hp + c * hq;
-        const double vp = V[e * 65 + p], vq = V[e * 65 + q];
-        V[e * 65 + p] = c * vp - sn * vq;
-        V[e * 65 + q] = sn * vp + c * vq;
+      // H <- J' (H J), one thread per 2 x 2 block (row pair i, column pair j): the column rotation of the block's two rows, then
+      // the row rotation of its two columns -- the operations of a column pass followed by a row pass, in their order, without
+      // the barrier between the passes and with half the LDS traffic.  Operands of all of a thread's blocks are loaded before
+      // any is stored (the blocks are disjoint, which the compiler cannot know: it would wait for every store).
+      {
+        double h00[4], h01[4], h10[4], h11[4], c1[4], s1[4], c2[4], s2[4];
+        int a00[4], a01[4], a10[4], a11[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const int it = t + 256 * k;
+          if (it < half * half) {
+            const int i = it / half, j = it - i * half;
+            const int p1 = rp[i], q1 = rq[i], p2 = rp[j], q2 = rq[j];
+            c1[k] = rc[i]; s1[k] = rs[i]; c2[k] = rc[j]; s2[k] = rs[j];
+            a00[k] = p1 * 65 + p2; a01[k] = p1 * 65 + q2; a10[k] = q1 * 65 + p2; a11[k] = q1 * 65 + q2;
+            h00[k] = H[a00[k]]; h01[k] = H[a01[k]]; h10[k] = H[a10[k]]; h11[k] = H[a11[k]];
+          }
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const int it = t + 256 * k;
+          if (it < half * half) {
+            const double r0 = c2[k] * h00[k] - s2[k] * h01[k], r1 = s2[k] * h00[k] + c2[k] * h01[k];       // row p1 after H J
+            const double u0 = c2[k] * h10[k] - s2[k] * h11[k], u1 = s2[k] * h10[k] + c2[k] * h11[k];       // row q1 after H J
+            H[a00[k]] = c1[k] * r0 - s1[k] * u0;
+            H[a10[k]] = s1[k] * r0 + c1[k] * u0;
+            H[a01[k]] = c1[k] * r1 - s1[k] * u1;
+            H[a11[k]] = s1[k] * r1 + c1[k] * u1;
+          }
+        }
       }
-      __syncthreads();
-      for (int it = t; it < half * b; it += 256) {         // H <- J' H
-        const int i = it / b, e = it - i * b;
-        const int p = rp[i], q = rq[i];
-        if (q >= b) continue;
-        const double c = rc[i], sn = rs[i];
-        const double hp = H[p * 65 + e], hq = H[q * 65 + e];
-        H[p * 65 + e] = c * hp - sn * hq;
-        H[q * 65 + e] = sn * hp + c * hq;
+      {                                                     // V <- V J, staged the same way
+        double vp[8], vq[8], cc[8], ss[8];
+        int ap[8], aq[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+          const int it = t + 256 * k;
+          ap[k] = -1;
+          if (it < half * b) {
+            const int i = it / b, e = it - i * b;
+            const int p = rp[i], q = rq[i];
+            if (q < b) {
+              cc[k] = rc[i]; ss[k] = rs[i];
+              ap[k] = e * 65 + p; aq[k] = e * 65 + q;
+              vp[k] = V[ap[k]]; vq[k] = V[aq[k]];
+            }
+          }
+        }
+#pragma unroll
+        for (int k = 0; k < 8; ++k)
+          if (ap[k] >= 0) {
+            V[ap[k]] = cc[k] * vp[k] - ss[k] * vq[k];
+            V[aq[k]] = ss[k] * vp[k] + cc[k] * vq[k];
+          }
       }
     }
     __syncthreads();

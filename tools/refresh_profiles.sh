@@ -21,6 +21,7 @@ trace() {      # <config> <tag> [extra bench args]: rocprofv3 --kernel-trace --s
   python tools/summarize_kernel_trace.py $O/kt $O/${R}_${tag}_kernel_trace_summary.json > /dev/null
   python tools/timeline.py $O/kt 0.75 > $O/${R}_${tag}_timeline.txt
   cp $(find $O/kt -name "*kernel_stats.csv" | head -1) $O/${R}_${tag}_kernel_stats.csv
+  if [[ $tag == c4* ]]; then python tools/c4_iter_groups.py $(find $O/kt -name "*kernel_trace.csv" | head -1) > $O/${R}_${tag}_iteration_groups.txt; fi
   rm -rf $O/kt
 }
 pmc_pair c3 c3_256
@@ -64,6 +65,12 @@ fi
 cp $O/${R}_c3_256_pmc.json $O/${R}_c3_512_pmc.json profiles/      # (this box's copy: the bench line quotes `traffic` from a profile of the running build)
 $T python bench.py > $O/${R}_bench_default.json 2>$O/bench.err
 if [ -z "$LIGHT" ]; then
+  # C4 (eight sets, 512^3) iteration by iteration: with the slice-rank set on its lane (the product), and in turn on the engine
+  # stream (kernel times that do not overlap: what each group costs alone)
+  trace c4 c4_512 --steps 6 --warmup 2
+  export SIPX_RANK_LANE=0
+  trace c4 c4_512_in_turn --steps 6 --warmup 2
+  unset SIPX_RANK_LANE
   trace c2 c2_2048
   $T python bench.py --no-cpu-baseline --no-512 --no-c4 --no-c5 --warmup 100 --steps 100 > $O/${R}_c3_256_bench_steady_it101_200.json 2>>$O/bench.err
   $T python bench.py --no-cpu-baseline --no-c4 --no-c5 --config c3-512 --warmup 100 --steps 60 > $O/${R}_c3_512_bench_steady_it101_160.json 2>>$O/bench.err
