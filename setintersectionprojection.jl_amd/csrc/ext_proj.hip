@@ -960,6 +960,19 @@ struct ExtImpl {
   bool cheb = false;
   double *Ys = nullptr, *Bd = nullptr, *Cs = nullptr;
   // the matrices that still need a filter when most of the batch has converged, packed (rank_cheb_route)
+  // switches of the rank routes, read once when the projector is built (tests and A/B runs set them before they build a context)
+  struct RankKnobs {
+    int dbg = 0;                  // SIPX_EXT_DEBUG: 1 the route of every call on stderr, 2 milliseconds per phase, 3 open matrices and Jacobi sweeps per step
+    int budget = 160;             // SIPX_RANK_CHEB_BUDGET: multiplications with G a call may spend
+    bool own_jacobi = true;       // SIPX_RANK_JACOBI=0: rocSOLVER's syevj for the Ritz problems
+    bool fused_proj = true;       // SIPX_RANK_CHEB_FUSED=0: the GEMM form of the projections whatever their number
+    int m_cap = 16;               // SIPX_RANK_CHEB_MMAX: degree of one filter at most
+    double tol = 1e-12;           // SIPX_RANK_CHEB_TOL (experiments: is a difference between the routes a matter of this tolerance?)
+    int guard = -1;               // SIPX_RANK_CHEB_GUARD: index of the Ritz value that ends the damped interval (-1: chosen from the block)
+    bool own_cert = true;         // SIPX_RANK_CERT_POTRF=1: the library's factorisation for the certificate
+    bool pack = true;             // SIPX_RANK_PACK=0: every filter on the whole batch
+    bool cert_check = false;      // SIPX_RANK_CERT_CHECK: both factorisations, compared matrix by matrix (tests)
+  } knobs;
   double *Xc = nullptr, *Wc = nullptr, *Froc = nullptr;
   double *cert_w = nullptr, *cert_p = nullptr;     // the certificate's blocked Cholesky: inverse diagonal factors, one block row
   int* sub_idx = nullptr;
@@ -1132,6 +1145,20 @@ ExtProj<T>::ExtProj(const ExtSpec& spec, hipStream_t stream) {
       I.Gd = I.template alloc<double>((size_t)k * k * I.batch);
       I.Wd = I.template alloc<double>((size_t)k * I.batch);
       if (kind == EXT_NUCLEAR) I.Gs = I.template alloc<double>((size_t)k * k * I.batch);
+      {
+        auto env = [](const char* n) { return getenv(n); };
+        auto& K_ = I.knobs;
+        if (const char* e = env("SIPX_EXT_DEBUG")) K_.dbg = atoi(e);
+        if (const char* e = env("SIPX_RANK_CHEB_BUDGET")) K_.budget = atoi(e) > 0 ? atoi(e) : K_.budget;
+        if (const char* e = env("SIPX_RANK_JACOBI")) K_.own_jacobi = e[0] != '0';
+        if (const char* e = env("SIPX_RANK_CHEB_FUSED")) K_.fused_proj = e[0] != '0';
+        if (const char* e = env("SIPX_RANK_CHEB_MMAX")) K_.m_cap = atoi(e) >= 2 ? atoi(e) : K_.m_cap;
+        if (const char* e = env("SIPX_RANK_CHEB_TOL")) K_.tol = atof(e) > 0 ? atof(e) : K_.tol;
+        if (const char* e = env("SIPX_RANK_CHEB_GUARD")) K_.guard = std::max(0, atoi(e));
+        if (const char* e = env("SIPX_RANK_CERT_POTRF")) K_.own_cert = e[0] != '1';
+        if (const char* e = env("SIPX_RANK_PACK")) K_.pack = e[0] != '0';
+        K_.cert_check = env("SIPX_RANK_CERT_CHECK") != nullptr;
+      }
       const char* sub_e = getenv("SIPX_RANK_SUBSPACE");      // read per projector: 0 keeps the full decomposition every call
       const int sub_env = sub_e ? atoi(sub_e) : 1;
       // columns the block holds beyond the r wanted ones: 24 where the matrices are large enough for the route with them, else 16.
@@ -1342,21 +1369,12 @@ static bool rank_cheb_route(ExtImpl<T>& I, int w, int k, bool& cheap_fail) {
   const double one = 1.0, zero = 0.0, mone = -1.0;
   const long long sG = (long long)k * k, sX = (long long)k * b, sH = (long long)b * b;
   const auto N_ = rocblas_operation_none, T_ = rocblas_operation_transpose;
-  const char* dbg_e = getenv("SIPX_EXT_DEBUG");
-  const int dbg = dbg_e ? atoi(dbg_e) : 0;
-  const char* bud_e = getenv("SIPX_RANK_CHEB_BUDGET");
-  const int budget = bud_e && atoi(bud_e) > 0 ? atoi(bud_e) : 160;      // multiplications with G a call may spend
-  const char* jac_e = getenv("SIPX_RANK_JACOBI");          // 0: rocSOLVER's syevj for the Ritz problems (A/B)
-  const bool own_jacobi = !(jac_e && jac_e[0] == '0');
-  const char* fp_e = getenv("SIPX_RANK_CHEB_FUSED");       // 0: the GEMM form of the projections whatever their number (A/B)
-  const bool fused_proj = !(fp_e && fp_e[0] == '0');
-  const char* mm_e = getenv("SIPX_RANK_CHEB_MMAX");
-  const int m_cap = mm_e && atoi(mm_e) >= 2 ? atoi(mm_e) : 16;
-  const char* tol_e = getenv("SIPX_RANK_CHEB_TOL");        // (experiments: is a difference between the routes a matter of this tolerance?)
-  const double tol = tol_e && atof(tol_e) > 0 ? atof(tol_e) : 1e-12;
-  const char* g_e = getenv("SIPX_RANK_CHEB_GUARD");
+  const auto& KN = I.knobs;
+  const int dbg = KN.dbg, budget = KN.budget, m_cap = KN.m_cap;
+  const bool own_jacobi = KN.own_jacobi, fused_proj = KN.fused_proj;
+  const double tol = KN.tol;
   // index of the Ritz value that ends the damped interval (C4 with 24 guards: 2 / 3 / 4 / 6 -> 16.8 / 16.5 / 16.6 / 16.0 it/s)
-  const int g = g_e ? std::max(0, std::min(atoi(g_e), b - r - 1)) : std::max(2, (b - r) / 12);
+  const int g = KN.guard >= 0 ? std::min(KN.guard, b - r - 1) : std::max(2, (b - r) / 12);
   const auto t_start = std::chrono::steady_clock::now();
   double ph[8] = {0, 0, 0, 0, 0, 0, 0, 0};                 // SIPX_EXT_DEBUG=2: milliseconds per phase (the stream is drained at every mark)
   auto t_mark = t_start;
@@ -1377,10 +1395,8 @@ static bool rank_cheb_route(ExtImpl<T>& I, int w, int k, bool& cheap_fail) {
   int nb = batch;
   double *Gd = I.Gd, *Ws = I.Ws, *Fro = I.Fro;
   bool packed = false;
-  const char* ce_e = getenv("SIPX_RANK_CERT_POTRF");       // 1: the library's factorisation for the certificate (A/B)
-  const bool own_cert = !(ce_e && ce_e[0] == '1');
-  const char* pk_e = getenv("SIPX_RANK_PACK");             // 0: every filter on the whole batch (A/B)
-  const bool may_pack = I.sub_cap > 0 && !(pk_e && pk_e[0] == '0');
+  const bool own_cert = KN.own_cert;
+  const bool may_pack = I.sub_cap > 0 && KN.pack;
   hipLaunchKernelGGL(k_sub_fro, dim3(batch), dim3(BLOCK), 0, s, k, I.Gd, I.Fro);
   SIPX_HIP(hipMemcpyAsync(A, X, sizeof(double) * (size_t)sX * batch, hipMemcpyDeviceToDevice, s));
   mark(7);
@@ -1486,7 +1502,7 @@ static bool rank_cheb_route(ExtImpl<T>& I, int w, int k, bool& cheap_fail) {
       SIPX_HIP(hipStreamSynchronize(s));
       ok = (I.sub_res_host[1] & 32ull) == 0;
       mark(7);
-      if (getenv("SIPX_RANK_CERT_CHECK")) {
+      if (KN.cert_check) {
         // the blocked factorisation against the library's, matrix by matrix, on the certificate's own matrices and on matrices
         // that cannot be definite (tests)
         for (int low = 0; low < 2; ++low) {
@@ -1670,12 +1686,10 @@ void ExtProj<T>::project(T* v, bool feas, double* partials, T* maxpart, T* compa
           sub_ok = rank_cheb_route<T>(I, w, k, cheap_fail);
           if (sub_ok) I.cheb_fails[w] = 0;
           else if (!cheap_fail) { I.cheb_skip[w] = 1 << std::min(I.cheb_fails[w], 5); ++I.cheb_fails[w]; }
-          const char* dbg_e = getenv("SIPX_EXT_DEBUG");
-          if (dbg_e && atoi(dbg_e)) fprintf(stderr, "[sipx rank] %s\n", sub_ok ? "subspace accepted" : "full decomposition");
+          if (I.knobs.dbg) fprintf(stderr, "[sipx rank] %s\n", sub_ok ? "subspace accepted" : "full decomposition");
         }
       } else if (b > 0 && I.sub_have[w] && I.sub_try[w]) {
-        const char* dbg_e = getenv("SIPX_EXT_DEBUG");
-        const int dbg = dbg_e ? atoi(dbg_e) : 0;
+        const int dbg = I.knobs.dbg;
         const int max_it = 8;
         const double tol = 1e-12;
         double prev = -1;
@@ -1745,8 +1759,7 @@ void ExtProj<T>::project(T* v, bool feas, double* partials, T* maxpart, T* compa
           double q;
           std::memcpy(&q, &I.sub_res_host[0], sizeof(double));
           I.sub_have[w] = true;
-          const char* ce_e = getenv("SIPX_RANK_CERT_POTRF");
-          if (I.cheb && !I.cert_warm && ce_e && ce_e[0] == '1') {
+          if (I.cheb && !I.cert_warm && !I.knobs.own_cert) {
             // the library sizes the workspace of a batched factorisation at its first call (a device allocation of its own, 100 ms
             // and more): spend it here, behind a full decomposition, not inside the first accepted call of the filtered route
             I.cert_warm = true;
@@ -1754,8 +1767,7 @@ void ExtProj<T>::project(T* v, bool feas, double* partials, T* maxpart, T* compa
             (void)rocsolver_dpotrf_strided_batched(I.blas, rocblas_fill_upper, k, I.Bd, k, sG, I.info, I.batch);
           }
           I.sub_try[w] = q < 0.25;
-          const char* dbg_e = getenv("SIPX_EXT_DEBUG");
-          if (dbg_e && atoi(dbg_e)) fprintf(stderr, "[sipx rank] theta_{b+1}/theta_r = %.3e -> %s\n", q, I.sub_try[w] ? "subspace next" : "full next");
+          if (I.knobs.dbg) fprintf(stderr, "[sipx rank] theta_{b+1}/theta_r = %.3e -> %s\n", q, I.sub_try[w] ? "subspace next" : "full next");
         }
       }
       const int* flag = nullptr;
