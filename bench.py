@@ -935,6 +935,8 @@ def main():
                      # what this context allocated on its GPU (slab-decomposed: the rank's planes + halo planes only)
                      "device_bytes_per_rank": dev_bytes["context"], "device_used_bytes": dev_bytes["device_used"]},
             "dominant_kernel": dominant, "kernels": table,
+            # one rank: threshold searches through the batched chain since the context was built, and how many needed their fallback sweeps
+            "batched_searches": (per_kernel.get("batched_searches") if per_kernel else None),
             # a slice-rank set in the list: which route its projector took since the context was built (engine counters: calls,
             # calls served by the warm-started filtered subspace iteration, full decompositions, products with the Gram matrices)
             "rank_route": (per_kernel.get("rank_route") if per_kernel and (per_kernel.get("rank_route") or {}).get("calls") else None),
@@ -986,6 +988,8 @@ def main():
             o.update({"roofline": r["roofline"], "iteration_roofline": r["iteration_roofline"]})
         if r.get("rank_route"):
             o["rank_route"] = r["rank_route"]
+        if r.get("batched_searches"):
+            o["batched_searches"] = r["batched_searches"]
         return o
 
     def safe(name, fn):
@@ -1024,6 +1028,8 @@ def main():
     }
     if r.get("rank_route"):
         out["rank_route"] = r["rank_route"]
+    if r.get("batched_searches"):
+        out["batched_searches"] = r["batched_searches"]
     if share_gpu:
         out["invalid_as_measurement"] = True
         out["rehearsal"] = f"SIPX_BENCH_SHARE_GPU: {world} ranks share GPU 0, the engine's collectives over gloo callbacks -- a rehearsal of the N > 1 flow, not a measurement"

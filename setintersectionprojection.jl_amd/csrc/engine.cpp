@@ -37,6 +37,7 @@ void refresh_env_knobs() {
   k.rhs_march = (int)num("SIPX_RHS_MARCH", 1);
   k.rhs_march_zchunk = num("SIPX_RHS_MARCH_ZCHUNK", 0);
   k.q_plan = (int)num("SIPX_Q_PLAN", 1);
+  k.trace_searches = (int)num("SIPX_TRACE_SEARCHES", 0);
   k.trace_kernels = (int)num("SIPX_TRACE_KERNELS", 0);
   g_env_knobs = k;
 }
@@ -635,6 +636,7 @@ class Engine : public EngineBase {
         search_batch_ = !comm_ && !(sb && sb[0] == '0') && ntp >= 1 && ntp <= SPEC_MAX_SETS &&
                         sweep_applicable(SIPX_YL_FEAS | SIPX_YL_BB, probe3, true);
         if (search_batch_) set_streams_ = false;
+        if (const char* fs = std::getenv("SIPX_FEAS_SAMPLE")) feas_sample_ = fs[0] != '0';
         if (const char* pm = std::getenv("SIPX_PASS_MULTI")) pass_multi_ = pm[0] == '1';
       }
       {
@@ -1798,7 +1800,16 @@ class Engine : public EngineBase {
       args[j] = set_args(s, (T)rho[tp[j]], (T)gamma[tp[j]], flags);
       ctl[j].verdict = (unsigned*)hverd_ + tp[j];
       ctl[j].seq = seq;
-      if (feas_ps) continue;
+      if (feas_ps) {
+        // the search of a feasibility estimate comes every tenth iteration: its own last theta is ten iterations old and missed
+        // the range every time (three fallbacks of two sweeps each per such iteration: 7 % of the 512^3 window) -- a sampled
+        // estimate first, whenever the set's last such search asked for one (device side: ProjScalars::want_sample)
+        if (feas_sample_ && l1_sample_ && s.prox == PX_L1 && vec) {
+          SampleSet<T>& S = sm.s[sm.ns++];
+          S.a = args[j]; S.a.ps = s.psf; S.ps = s.psf; S.partials = s.ptmp; S.reg = nullptr; S.true_len = s.Mtrue;
+        }
+        continue;
+      }
       ctl[j].host_want = (int*)hlean_ + tp[j];
       ctl[j].runs = l1_sample_runs_;
       const bool l1 = s.prox == PX_L1;
@@ -1812,6 +1823,7 @@ class Engine : public EngineBase {
       s.last_gamma = args[j].gamma;
     }
     K<T>::ps_rescale_multi(stream_, rs);
+    sm.v_is_s = v_is_s;
     if (sm.ns > 0) K<T>::sample_multi(10, stream_, Gr_, sm, l1_sample_runs_, nullptr);
     // the passes: groups of up to LEAN_MAX sets per launch (x read once per group) -- the lean first passes of the l1 sets whose
     // device-side state asks for one, then the full first passes of everybody else; each kernel returns at once when no set
@@ -1890,6 +1902,8 @@ class Engine : public EngineBase {
       batch_searches_ += 1;
       if (!(w & 1u)) continue;
       batch_fallbacks_ += 1;
+      if (env_knobs().trace_searches)
+        std::fprintf(stderr, "[sipx search] search %lld (set %d%s): fallback%s\n", batch_searches_, tp[j], feas_ps ? ", feasibility" : "", (w & 2u) ? " with refinement" : "");
       fb.push_back(j);
       refine |= (w & 2u) != 0;
     }
@@ -1978,7 +1992,10 @@ class Engine : public EngineBase {
       s.last_rho = a.rho;
       s.last_gamma = a.gamma;
       if (feas && i < pp_n_) {                 // ||P_i(s) - s|| with s = A_i x produced on the fly; its own warm-started scalars
-        K<T>::proj_scalars_set(q, Gr_, a, 1, s.psf, ptmp, mpart, cbuf, s.Mtrue, SampleCtl(), nullptr);
+        SampleCtl cf;                          // (a sampled estimate first, as in the batched chain: run_batched)
+        cf.runs = l1_sample_runs_;
+        cf.enable = feas_sample_ && l1_sample_ && a.prox == PX_L1;
+        K<T>::proj_scalars_set(q, Gr_, a, 1, s.psf, ptmp, mpart, cbuf, s.Mtrue, cf, nullptr);
         K<T>::proj_dist_set(q, Gr_, a, 1, s.psf, part + (size_t)SL_FE2 * NB);
       }
     }
@@ -3527,6 +3544,7 @@ class Engine : public EngineBase {
   bool sweep_partial_ = false, has_loose_ = false;   // the sweep takes a subset of the sets (in_sweep); some owned set keeps its per-set kernels
   bool pass_multi_ = false;           // SIPX_PASS_MULTI=1: full first passes / fallback passes of the batched searches in one sweep per group (measured slower)
   bool sweep_plain_ = false;          // the sweep takes the plain iterations of this context: every set carries a third y / l pair
+  bool feas_sample_ = true;           // SIPX_FEAS_SAMPLE=0: the feasibility searches of the batched chain start from their own last theta (A/B switch)
   bool search_batch_ = false;         // one rank + sweep: the searches of all sets as one chain of launches (batched_searches; SIPX_SEARCH_BATCH=0: per-set chains on the set streams)
   long long batch_searches_ = 0, batch_fallbacks_ = 0;
   bool spec_batch_ = true;            // SIPX_SPEC_BATCH=0: the small steps of the exchange as one kernel per set on the set streams

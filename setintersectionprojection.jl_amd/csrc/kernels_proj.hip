@@ -1183,7 +1183,7 @@ __device__ __forceinline__ void sample_decide(ProjScalars<T>* ps, double* __rest
 template <typename T, int V>
 __device__ void sample_body(const Grid& G, const SetArgs<T>& a, ProjScalars<T>* ps, double* __restrict__ partials,
                             long long nchunks, long long nsamp, unsigned int stride, long long true_len,
-                            double hw_max, int lean_on, double gather_cap, double* __restrict__ defer_to) {
+                            double hw_max, int lean_on, double gather_cap, double* __restrict__ defer_to, int v_is_s = 0) {
   if (!ps->want_sample || !(ps->theta_prev > 0)) return;
   constexpr int NT = SAMPLE_NT;
   __shared__ unsigned long long hs[SAMPLE_BINS];
@@ -1223,12 +1223,18 @@ __device__ void sample_body(const Grid& G, const SetArgs<T>& a, ProjScalars<T>* 
       } else {
         fwd_dir<T, V>(G, a.x, xc, g, cd, a.dir[q], a.ih[q], s, valid);
       }
-      const Vec<T, V> yv = ldv<T, V>(a.y + e), lv = ldv<T, V>(a.l + e);
+      Vec<T, V> yv, lv;
+      if (!v_is_s) { yv = ldv<T, V>(a.y + e); lv = ldv<T, V>(a.l + e); }
 #pragma unroll
       for (int k = 0; k < V; ++k) {
         if (!(live && valid[k])) continue;
-        const T xh = relax ? (gam * s[k] + omg * yv.v[k]) : s[k];       // update_y_l.jl:72
-        const T av = fabs(xh - lv.v[k] * a.rho1);                       // :67 / :74
+        T av;
+        if (v_is_s) {
+          av = fabs(s[k]);                                              // the feasibility estimate projects s = A x itself
+        } else {
+          const T xh = relax ? (gam * s[k] + omg * yv.v[k]) : s[k];     // update_y_l.jl:72
+          av = fabs(xh - lv.v[k] * a.rho1);                             // :67 / :74
+        }
         acc[2] += 1.0;
         const long long j = KeyBits<T>::key(av) - key_lo;
         if (j >= SAMPLE_BINS) {
@@ -1295,20 +1301,23 @@ __device__ void sample_body(const Grid& G, const SetArgs<T>& a, ProjScalars<T>* 
     }
     return;
   }
+  // (a feasibility estimate's last sample is ten iterations old: what it was off by then says nothing now -- iteration 20 of the
+  //  headline run missed its range WITH the correction of iteration 10)
+  if (v_is_s && threadIdx.x == 0) ps->samp_bias_ok = 0;
   sample_decide<T>(ps, partials, (int)gridDim.x, a.phi, true_len, hw_max, lean_on, gather_cap, sS, sC);
 }
 
 template <typename T, int V>
 __global__ __launch_bounds__(SAMPLE_NT) void k_sample(Grid G, SetArgs<T> a, ProjScalars<T>* ps, double* __restrict__ partials,
                                                       long long nchunks, long long nsamp, unsigned int stride, long long true_len,
-                                                      double hw_max, int lean_on, double gather_cap, double* __restrict__ defer_to) {
-  sample_body<T, V>(G, a, ps, partials, nchunks, nsamp, stride, true_len, hw_max, lean_on, gather_cap, defer_to);
+                                                      double hw_max, int lean_on, double gather_cap, double* __restrict__ defer_to, int v_is_s) {
+  sample_body<T, V>(G, a, ps, partials, nchunks, nsamp, stride, true_len, hw_max, lean_on, gather_cap, defer_to, v_is_s);
 }
 template <typename T, int V>
 __global__ __launch_bounds__(SAMPLE_NT) void k_sample_multi(Grid G, SampleMulti<T> A, long long nchunks, long long nsamp, unsigned int stride,
                                                             double hw_max, int lean_on, double gather_cap) {
   const SampleSet<T>& S = A.s[blockIdx.y];
-  sample_body<T, V>(G, S.a, S.ps, S.partials, nchunks, nsamp, stride, S.true_len, hw_max, lean_on, gather_cap, S.reg);
+  sample_body<T, V>(G, S.a, S.ps, S.partials, nchunks, nsamp, stride, S.true_len, hw_max, lean_on, gather_cap, S.reg, A.v_is_s);
 }
 template <typename T>
 __global__ __launch_bounds__(SAMPLE_NT) void k_sample_decide2_multi(SampleMulti<T> A, double hw_max, int lean_on, double gather_cap) {
@@ -2082,7 +2091,7 @@ static void chain_stage(int stage, hipStream_t s, const Grid& g, const SetArgs<T
     // stage 0: sampled prediction with the decision inside the kernel (one rank).  Slab-decomposed: stage 10 = this rank's
     // share of the sample into the set's region `reg` of the sample staging buffer (2 SAMPLE_BINS + 3 doubles), an all-reduce
     // of the caller, stage 11 = the decision on the summed histogram.
-    if (SRC == 1 && vec && ctl.enable && a.prox == PX_L1 && !v_is_s) {
+    if (SRC == 1 && vec && ctl.enable && a.prox == PX_L1 && (!v_is_s || (!hk && stage == 0))) {      // (v = A x itself: one rank only)
       // about a million grid points (times the operator's blocks); not worth it when that is more than a quarter of the vector.
       // Slab-decomposed grid: WHETHER the sample is taken, its stride and the capacity it plans for are functions of the
       // whole grid and the number of ranks only -- a rank with a short (or empty) slab must take the same decisions as the
@@ -2103,7 +2112,7 @@ static void chain_stage(int stage, hipStream_t s, const Grid& g, const SetArgs<T
         if (stage != 11)
           hipLaunchKernelGGL((k_sample<T, 4>), dim3((unsigned)(nsamp < 1 ? 1 : (nsamp < SAMPLE_WG ? nsamp : SAMPLE_WG))), dim3(SAMPLE_NT), 0, s, g, a, ps,
                              partials, nchunks, nsamp, (unsigned int)stride, true_len, l1_hw_max(), l1_lean_on(), gcap,
-                             stage == 10 ? reg : (double*)nullptr);
+                             stage == 10 ? reg : (double*)nullptr, v_is_s);
         else
           hipLaunchKernelGGL((k_sample_decide2<T>), dim3(1), dim3(SAMPLE_NT), 0, s, ps, reg, a.phi, true_len, l1_hw_max(), l1_lean_on(), gcap);
       }

@@ -90,6 +90,7 @@ struct EnvKnobs {
   int rhs_march = 1;              // SIPX_RHS_MARCH
   long long rhs_march_zchunk = 0; // SIPX_RHS_MARCH_ZCHUNK
   int trace_kernels = 0;          // SIPX_TRACE_KERNELS=1 (debugging): name every launch on stderr and drain the stream behind it
+  int trace_searches = 0;         // SIPX_TRACE_SEARCHES=1: every threshold search of the batched chain that needed its fallback sweeps, on stderr
   int q_plan = 1;                 // SIPX_Q_PLAN=0: the Q update regenerates every band value per element (k_q_update) instead of adding planned products
 };
 const EnvKnobs& env_knobs();
@@ -353,6 +354,7 @@ struct SampleSet {
 };
 template <typename T>
 struct SampleMulti {
+  int v_is_s = 0;         // the vector is s = A x itself (searches of the feasibility estimates: no y, no l)
   int ns;
   SampleSet<T> s[SPEC_MAX_SETS];
 };

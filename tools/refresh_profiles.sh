@@ -63,7 +63,7 @@ PY
   rm -rf $O/sp_engine_* $O/sp_march_*
 fi
 cp $O/${R}_c3_256_pmc.json $O/${R}_c3_512_pmc.json profiles/      # (this box's copy: the bench line quotes `traffic` from a profile of the running build)
-$T python bench.py > $O/${R}_bench_default.json 2>$O/bench.err
+$T python bench.py --detail $O/${R}_bench_default_detail.json > $O/${R}_bench_default.json 2>$O/bench.err
 if [ -z "$LIGHT" ]; then
   # C4 (eight sets, 512^3) iteration by iteration: with the slice-rank set on its lane (the product), and in turn on the engine
   # stream (kernel times that do not overlap: what each group costs alone)
