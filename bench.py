@@ -992,31 +992,89 @@ def main():
             o["batched_searches"] = r["batched_searches"]
         return o
 
-    def safe(name, fn):
-        """A secondary leg that fails must not take the headline with it: an engine error that every rank raises alike (say, a
-        threshold search that does not fit its exchange segments on some node) is recorded under the leg's key and the run goes
-        on.  (A failure on ONE rank only leaves the others in a collective: that is the watchdog's case.)"""
+    # ---- secondary legs that cannot take the headline with them ----------------------------------------------------------
+    # One rank, or an engine error that every rank raises alike (a threshold search that does not fit its exchange segments on
+    # some node): the error is recorded under the leg's key and the run goes on.  A failure on ONE rank only (round 4's rehearsal
+    # with four ranks on one GPU: the fourth ran out of device memory in the c5 leg) used to send that rank on into the next
+    # leg's collectives while the others waited in this one's -- a mismatch, an abort, no bench line at all.  Now: the ranks that
+    # fail tell the others through the process group's store and wait for them; if not every rank arrives within AGREE_S the
+    # failure is rank-local -- rank 0 prints the line it has (headline + the legs done so far) and exits 0, the others park.  A rank
+    # still waiting in the leg's collectives is released by the leg's own deadline the same way.
+    partial = {"out": None}
+    LEG_KEY = {"comm probe": "comm_probe_us", "sets-decomposed headline": "decompositions"}
+    leg_deadline_env = float(os.environ.get("SIPX_BENCH_LEG_DEADLINE", "0") or 0)        # (tests)
+    agree_s = float(os.environ.get("SIPX_BENCH_AGREE_S", "20") or 20)
+    store = None
+    if dist is not None and world > 1:
         try:
+            from torch.distributed import distributed_c10d as _c10d
+            store = _c10d._get_default_store()
+        except Exception:
+            store = None
+
+    def give_up(name, why):
+        if rank == 0 and partial["out"] is not None:
+            o = partial["out"]
+            err = {"error": str(why)[:600], "rank_local_failure": True}
+            if name == "sets-decomposed headline":
+                o["decompositions"] = {"sets": err}
+            else:
+                o[LEG_KEY.get(name, name)] = err
+            o["legs_abandoned_at"] = name
+            progress(f"{name}: giving the remaining legs up, printing the line as it stands")
+            try:
+                if saved_stdout is not None:
+                    os.dup2(saved_stdout, 1)
+            except OSError:
+                pass
+            emit(o, args.detail)
+        else:
+            progress(f"{name}: giving the remaining legs up")
+        os._exit(0 if (rank != 0 or partial["out"] is not None) else 3)
+
+    def failed_alike(name):
+        if store is None:
+            return False
+        import datetime
+        key = f"sipx_bench/fail/{name}/"
+        try:
+            store.set(key + str(rank), "1")
+            store.wait([key + str(r) for r in range(world)], datetime.timedelta(seconds=agree_s))
+            return True
+        except Exception:
+            return False
+
+    def safe(name, fn, deadline=300.0):
+        timer = None
+        dl = leg_deadline_env or deadline
+        if world > 1:
+            import threading
+            timer = threading.Timer(dl, lambda: give_up(name, f"no result after {dl:.0f} s: a failure on one rank leaves the others in the leg's collectives"))
+            timer.daemon = True
+            timer.start()
+        try:
+            if os.environ.get("SIPX_BENCH_FAIL_LEG") == f"{name}:{rank}":        # tests: a failure on this rank only
+                raise RuntimeError("test hook: this rank fails this leg")
             return fn()
         except Exception as e:
             import gc
             progress(f"{name} leg failed: {e!r}")
+            if world > 1 and not failed_alike(name):
+                if timer is not None:
+                    timer.cancel()
+                if rank == 0:
+                    give_up(name, repr(e))
+                progress(f"{name}: failed on this rank only; parked until the others give the leg up")
+                time.sleep(dl + agree_s + 5.0)
+                os._exit(0)
             gc.collect()                                        # contexts of the failed leg give their device memory back
             return {"error": repr(e)[:600]}
+        finally:
+            if timer is not None:
+                timer.cancel()
 
     progress(f"headline {args.config}: {args.warmup} warm-up + {args.steps} timed steps")
     r = measure(args.config, args.steps, args.warmup)
-    both = None
-    if (world > 1 or force_dist) and args.decomp == "auto" and r.get("decomposition") == "slab":
-        # Which of the two decompositions is faster on a given node depends on RCCL's small-message latency (slab: small
-        # collectives only) against its bandwidth (sets: two N-vector exchanges).  Both are timed for the same K steps and
-        # reported under fixed keys; the headline `value` is ALWAYS the slab decomposition -- the one DESIGN 5 chooses for this
-        # set list -- so that it means the same thing from run to run and from node to node.
-        progress("headline workload again, sharded by constraint set")
-        r2 = safe("sets-decomposed headline", lambda: measure(args.config, args.steps, args.warmup, decomp="sets"))
-        both = {k: (v if "error" in v else
-                    {"value": v["value"], "ms_per_step": v["ms_per_step"], "parallelism": v["config"]["parallelism"], "comm": v["comm"],
-                     "timing_ms_per_iteration": v["timing_ms_per_iteration"]}) for k, v in (("slab", r), ("sets", r2))}
     n, h, kinds = CONFIGS[args.config]
     out = {
         "metric": "PARSDMM iterations/sec", "value": r["value"], "unit": "it/s", "n_gpus": world,
@@ -1033,6 +1091,18 @@ def main():
     if share_gpu:
         out["invalid_as_measurement"] = True
         out["rehearsal"] = f"SIPX_BENCH_SHARE_GPU: {world} ranks share GPU 0, the engine's collectives over gloo callbacks -- a rehearsal of the N > 1 flow, not a measurement"
+    partial["out"] = out
+    both = None
+    if (world > 1 or force_dist) and args.decomp == "auto" and r.get("decomposition") == "slab":
+        # Which of the two decompositions is faster on a given node depends on RCCL's small-message latency (slab: small
+        # collectives only) against its bandwidth (sets: two N-vector exchanges).  Both are timed for the same K steps and
+        # reported under fixed keys; the headline `value` is ALWAYS the slab decomposition -- the one DESIGN 5 chooses for this
+        # set list -- so that it means the same thing from run to run and from node to node.
+        progress("headline workload again, sharded by constraint set")
+        r2 = safe("sets-decomposed headline", lambda: measure(args.config, args.steps, args.warmup, decomp="sets"))
+        both = {k: (v if "error" in v else
+                    {"value": v["value"], "ms_per_step": v["ms_per_step"], "parallelism": v["config"]["parallelism"], "comm": v["comm"],
+                     "timing_ms_per_iteration": v["timing_ms_per_iteration"]}) for k, v in (("slab", r), ("sets", r2))}
     if both is not None:
         out["decompositions"] = both
         out["faster_decomposition"] = max(both, key=lambda k: both[k].get("value", 0.0))
@@ -1052,7 +1122,9 @@ def main():
         # model; `c5_layered`: a velocity-model-like field, the kind the reference's own timing runs on (c5_model).
         for key, model in (("c5", "survey"), ("c5_layered", "layered")):
             progress(f"{key} leg (PARSDMM_multi_level 512^3 Float64, 3 levels)")
-            r5m = safe(key, lambda: run_c5(sipx, (512, 512, 512), maxit=100, model=model, device=local_rank, dist=dist))
+            # (rehearsal with the ranks on ONE GPU: every rank's full-size Float64 arrays of 512^3 do not fit beside each other)
+            n5 = (256, 256, 256) if share_gpu else (512, 512, 512)
+            r5m = safe(key, lambda: run_c5(sipx, n5, maxit=100, model=model, device=local_rank, dist=dist))
             r5m["n_gpus"] = world
             out[key] = r5m
     if dist is not None and (world > 1 or force_dist):

@@ -374,3 +374,32 @@ def test_rank_set_on_its_lane_is_bit_identical(sipx, TF, n):
         assert np.array_equal(a, b)
     for f in ("obj", "evol_x", "r_pri", "r_dual", "rho", "gamma", "set_feasibility", "cg_it"):
         assert np.array_equal(np.asarray(getattr(log1, f)), np.asarray(getattr(log0, f)), equal_nan=True), f
+
+
+def test_bench_headline_survives_a_leg_that_fails_on_one_rank():
+    """bench.py at N > 1: a secondary leg that fails on ONE rank (round 4's four-rank rehearsal: the fourth rank ran out of device
+    memory in the c5 leg, went on into the next leg's collectives while the others waited in this one's -- gloo aborted on the
+    mismatch and no line was printed).  The failing rank now waits for the others on the process group's store and parks when they
+    do not arrive; the rank left in the leg's collectives is released by the leg's deadline; rank 0 prints the line it has -- the
+    headline and both decompositions -- with the leg's error, exit code 0.  Rehearsed with two ranks on the one GPU, rank 1 failing
+    the c3_512 leg by a test hook."""
+    import json
+    import os
+    import subprocess
+    import sys
+    import tempfile
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, SIPX_BENCH_SHARE_GPU="1", SIPX_BENCH_FAIL_LEG="c3_512:1", SIPX_BENCH_LEG_DEADLINE="25", SIPX_BENCH_AGREE_S="4")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    detail = os.path.join(tempfile.mkdtemp(prefix="sipx_bench_"), "detail.json")
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "2", "--no-c4", "--no-c5",
+                        "--detail", detail], capture_output=True, text=True, timeout=300, env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.strip().splitlines() if ln.strip()]
+    assert len(lines) == 1 and len(lines[0]) < 4096, r.stdout[:2000]
+    h = json.loads(lines[0])
+    assert h["n_gpus"] == 2 and h["value"] > 0 and set(h["decompositions"]) == {"slab", "sets"}
+    assert "error" in h["c3_512"] and "comm_probe_us" not in h             # the leg's error; nothing behind it was attempted
+    d = json.load(open(detail))
+    assert d["legs_abandoned_at"] == "c3_512" and d["c3_512"]["rank_local_failure"] is True
