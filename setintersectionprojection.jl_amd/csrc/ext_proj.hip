@@ -91,6 +91,27 @@ __global__ __launch_bounds__(BLOCK) void k_unpack(long long N, const Cplx<T>* __
   for (long long e = (long long)blockIdx.x * BLOCK + threadIdx.x; e < N; e += (long long)gridDim.x * BLOCK)
     v[e] = z[e].re * scale;
 }
+// The same set through the REAL transform (round 4): the model is real, so the hipFFT R2C transform returns the nh1 = n1/2 + 1
+// planes k1 = 0 .. n1/2 of the spectrum and the other n1 - nh1 are their conjugates -- half the transform, no packing.  The l1 norm
+// runs over ALL N coefficients: the magnitudes of the stored ones fill mag[0, Nh), those of the planes 1 .. n1 - nh1 (whose
+// conjugates are not stored) are written a second time behind them, N entries in all, and the search sees the vector it always saw.
+template <typename T>
+__global__ __launch_bounds__(BLOCK) void k_cabs_half(long long Nh, int nh1, int ndup, const Cplx<T>* __restrict__ z, T* __restrict__ mag) {
+  for (long long e = (long long)blockIdx.x * BLOCK + threadIdx.x; e < Nh; e += (long long)gridDim.x * BLOCK) {
+    const T m = (T)hypot((double)z[e].re, (double)z[e].im);
+    mag[e] = m;
+    const long long row = e / nh1;
+    const int k1 = (int)(e - row * nh1);
+    if (k1 >= 1 && k1 <= ndup) mag[Nh + row * ndup + (k1 - 1)] = m;
+  }
+}
+// v <- w * scale (w: the output of the C2R transform) unless v already lies inside the ball (see k_unpack)
+template <typename T>
+__global__ __launch_bounds__(BLOCK) void k_unpack_real(long long N, const T* __restrict__ w, T* __restrict__ v, T scale,
+                                                       const ProjScalars<T>* __restrict__ ps) {
+  if (!ps->need) return;
+  for (long long e = (long long)blockIdx.x * BLOCK + threadIdx.x; e < N; e += (long long)gridDim.x * BLOCK) v[e] = w[e] * scale;
+}
 // U[:, j] *= S[j] for the first r columns of every slice
 template <typename T>
 __global__ __launch_bounds__(BLOCK) void k_scale_cols(int m, int r, int ldu, long long strideU, long long strideS,
@@ -940,6 +961,10 @@ struct ExtImpl {
   // DFT
   hipfftHandle plan = 0;
   bool have_plan = false;
+  hipfftHandle plan_r2c = 0, plan_c2r = 0;        // l1 behind the DFT through the real transform (half the spectrum)
+  bool real_fft = false;
+  int nh1 = 0, ndup = 0;
+  long long Nh = 0;
   Cplx<T>* z = nullptr;
   T* mag = nullptr;
   ProjScalars<T>*ps = nullptr, *psf = nullptr;
@@ -1097,12 +1122,31 @@ ExtProj<T>::ExtProj(const ExtSpec& spec, hipStream_t stream) {
     SIPX_HIP(hipMemcpy(I.mag, spec.ub, sizeof(T) * N, hipMemcpyHostToDevice));
   } else if (kind == EXT_L1_DFT) {
     if (!(spec.pmax > 0)) throw std::runtime_error("Radius of L1 ball is negative");
-    const hipfftType ty = sizeof(T) == 4 ? HIPFFT_C2C : HIPFFT_Z2Z;
-    if (spec.ndim == 2) fft_check(hipfftPlan2d(&I.plan, (int)G.n[1], (int)G.n[0], ty), "plan2d");   // slowest dimension first
-    else fft_check(hipfftPlan3d(&I.plan, (int)G.n[2], (int)G.n[1], (int)G.n[0], ty), "plan3d");
-    I.have_plan = true;
-    fft_check(hipfftSetStream(I.plan, stream), "set stream");
-    I.z = I.template alloc<Cplx<T>>(N);
+    const char* rf_e = getenv("SIPX_DFT_REAL");            // 0: the complex transform of the packed model (A/B switch, tests)
+    I.real_fft = !(rf_e && rf_e[0] == '0') && G.n[0] >= 4;
+    if (I.real_fft) {
+      const hipfftType tf = sizeof(T) == 4 ? HIPFFT_R2C : HIPFFT_D2Z, tb = sizeof(T) == 4 ? HIPFFT_C2R : HIPFFT_Z2D;
+      if (spec.ndim == 2) {
+        fft_check(hipfftPlan2d(&I.plan_r2c, (int)G.n[1], (int)G.n[0], tf), "plan2d (real)");
+        fft_check(hipfftPlan2d(&I.plan_c2r, (int)G.n[1], (int)G.n[0], tb), "plan2d (real, inverse)");
+      } else {
+        fft_check(hipfftPlan3d(&I.plan_r2c, (int)G.n[2], (int)G.n[1], (int)G.n[0], tf), "plan3d (real)");
+        fft_check(hipfftPlan3d(&I.plan_c2r, (int)G.n[2], (int)G.n[1], (int)G.n[0], tb), "plan3d (real, inverse)");
+      }
+      fft_check(hipfftSetStream(I.plan_r2c, stream), "set stream");
+      fft_check(hipfftSetStream(I.plan_c2r, stream), "set stream");
+      I.nh1 = (int)(G.n[0] / 2 + 1);
+      I.ndup = (int)G.n[0] - I.nh1;
+      I.Nh = (long long)I.nh1 * (N / G.n[0]);
+      I.z = I.template alloc<Cplx<T>>(I.Nh);
+    } else {
+      const hipfftType ty = sizeof(T) == 4 ? HIPFFT_C2C : HIPFFT_Z2Z;
+      if (spec.ndim == 2) fft_check(hipfftPlan2d(&I.plan, (int)G.n[1], (int)G.n[0], ty), "plan2d");   // slowest dimension first
+      else fft_check(hipfftPlan3d(&I.plan, (int)G.n[2], (int)G.n[1], (int)G.n[0], ty), "plan3d");
+      I.have_plan = true;
+      fft_check(hipfftSetStream(I.plan, stream), "set stream");
+      I.z = I.template alloc<Cplx<T>>(N);
+    }
     I.mag = I.template alloc<T>(N);
     I.ps = I.template alloc<ProjScalars<T>>(1);
     I.psf = I.template alloc<ProjScalars<T>>(1);
@@ -1291,6 +1335,8 @@ ExtProj<T>::~ExtProj() {
   if (!impl_) return;
   ExtImpl<T>& I = *impl_;
   if (I.have_plan) (void)hipfftDestroy(I.plan);
+  if (I.plan_r2c) (void)hipfftDestroy(I.plan_r2c);
+  if (I.plan_c2r) (void)hipfftDestroy(I.plan_c2r);
   if (I.blas) (void)rocblas_destroy_handle(I.blas);
   if (I.sub_res_host) (void)hipHostFree(I.sub_res_host);
   if (I.fail_host) (void)hipHostFree(I.fail_host);
@@ -1636,6 +1682,18 @@ void ExtProj<T>::project(T* v, bool feas, double* partials, T* maxpart, T* compa
     if (sizeof(T) == 4) fft_check(hipfftExecC2C(I.plan, (hipfftComplex*)I.z, (hipfftComplex*)I.z, HIPFFT_BACKWARD), "inverse");
     else fft_check(hipfftExecZ2Z(I.plan, (hipfftDoubleComplex*)I.z, (hipfftDoubleComplex*)I.z, HIPFFT_BACKWARD), "inverse");
     hipLaunchKernelGGL((k_unpack_all<T>), dim3(NB), dim3(BLOCK), 0, s, N, I.z, v, (T)(1.0 / (double)N));
+  } else if (kind == EXT_L1_DFT && I.real_fft) {
+    ProjScalars<T>* ps = feas ? I.psf : I.ps;
+    if (sizeof(T) == 4) fft_check(hipfftExecR2C(I.plan_r2c, (hipfftReal*)v, (hipfftComplex*)I.z), "forward (real)");
+    else fft_check(hipfftExecD2Z(I.plan_r2c, (hipfftDoubleReal*)v, (hipfftDoubleComplex*)I.z), "forward (real)");
+    hipLaunchKernelGGL((k_cabs_half<T>), dim3(NB), dim3(BLOCK), 0, s, I.Nh, I.nh1, I.ndup, I.z, I.mag);
+    K<T>::proj_scalars_arr(s, N, I.mag, PX_L1, T(0), I.radius_raw, ps, partials, maxpart, compact, N);
+    hipLaunchKernelGGL((k_csoft<T>), dim3(NB), dim3(BLOCK), 0, s, I.Nh, I.z, I.mag, ps);
+    // (the inverse real transform may overwrite its input; its output goes through mag, free by now, so that v stays untouched
+    //  when it already lies inside the ball)
+    if (sizeof(T) == 4) fft_check(hipfftExecC2R(I.plan_c2r, (hipfftComplex*)I.z, (hipfftReal*)I.mag), "inverse (real)");
+    else fft_check(hipfftExecZ2D(I.plan_c2r, (hipfftDoubleComplex*)I.z, (hipfftDoubleReal*)I.mag), "inverse (real)");
+    hipLaunchKernelGGL((k_unpack_real<T>), dim3(NB), dim3(BLOCK), 0, s, N, I.mag, v, (T)(1.0 / (double)N), ps);
   } else if (kind == EXT_L1_DFT) {
     ProjScalars<T>* ps = feas ? I.psf : I.ps;
     hipLaunchKernelGGL((k_pack<T>), dim3(NB), dim3(BLOCK), 0, s, N, v, I.z);
@@ -1879,6 +1937,8 @@ void ExtProj<T>::set_stream(hipStream_t s) {
   I.stream = s;
   if (I.blas) blas_check(rocblas_set_stream(I.blas, s), "set stream");
   if (I.have_plan) fft_check(hipfftSetStream(I.plan, s), "set stream");
+  if (I.plan_r2c) fft_check(hipfftSetStream(I.plan_r2c, s), "set stream");
+  if (I.plan_c2r) fft_check(hipfftSetStream(I.plan_c2r, s), "set stream");
 }
 
 template <typename T>

@@ -476,7 +476,11 @@ def test_parsdmm_matches_oracle(sipx, TF, name, n, h, kinds):
     # reference's own serial-vs-parallel tolerance (test/test_PARSDMM_parallel.jl:72), unless the case is listed in
     # DOCUMENTED_EXCEPTIONS with the reason and its own measured bound.
     Kc = min(len(ls.obj), len(lo.obj))
-    sep = next((k for k in range(Kc) if ls.cg_it[k] != lo.cg_it[k] or not np.allclose(ls.rho[k], lo.rho[k], rtol=1e-5)), None)
+    # (Float64: a rho history counts as separated at the tolerance the lock-step comparison below asserts -- the eight-set list with
+    #  the l1-DFT set through the REAL transform, round 4, has one rho 1.4e-6 off at iteration 60: the BB ratio of a set whose
+    #  multiplier is FFT rounding noise; with 1e-5 here that fell between "separated" and "in lock step")
+    sep_rt = 1e-5 if TF == np.float32 else 1e-6
+    sep = next((k for k in range(Kc) if ls.cg_it[k] != lo.cg_it[k] or not np.allclose(ls.rho[k], lo.rho[k], rtol=sep_rt)), None)
     upto = Kc if sep is None else sep
     for f in ("obj", "r_pri_total", "rho", "gamma"):      # lock-step up to the first separation, at the reference's own tolerance
         a, b = np.asarray(getattr(ls, f))[:upto], np.asarray(getattr(lo, f))[:upto]
