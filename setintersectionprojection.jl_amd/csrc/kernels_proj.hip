@@ -172,10 +172,28 @@ __global__ __launch_bounds__(BLOCK) void k_pass(Grid G, SetArgs<T> a, int v_is_s
     }
   };
 
+  // Fallback compaction: the workgroup's LDS buffer is emptied into the global one whenever it is more than half full (one global
+  // atomic per 512 values).  Round 3 let a full buffer send every further wave to the global counter by itself: a bracket that holds
+  // a percent of a 512^3 vector (the first search of a set, the magnitudes behind the DFT) made that two million atomics on one
+  // address -- 2.8 ms for a pass that streams in 0.2 (C4: once per iteration for the l1-DFT set; 4.8 ms per set at sipx_finalize).
+  auto drain = [&]() {
+    if (MODE != M_COMPACT || !gather || cidx) return;      // (uniform over the workgroup)
+    __syncthreads();
+    if (scnt <= SPEC_CAP / 2) return;
+    const unsigned int cnt = sused;
+    if (threadIdx.x == 0) sbase = cnt ? atomicAdd(&ps->n_compact, (unsigned long long)cnt) : 0ull;
+    __syncthreads();
+    for (unsigned int i = threadIdx.x; i < cnt; i += BLOCK) compact[sbase + i] = sbuf[i];
+    __syncthreads();
+    if (threadIdx.x == 0) { scnt = 0; sused = 0; }
+    __syncthreads();
+  };
   if (SRC == 0) {
+    int round = 0;
     for (long long e0 = (long long)blockIdx.x * BLOCK; e0 < len; e0 += (long long)gridDim.x * BLOCK) {
       const long long e = e0 + threadIdx.x;
       body(e < len ? varr[e] : T(0), e, e < len);   // uniform trip count: every lane takes part in the ballots
+      if ((++round & 3) == 0) drain();              // (a round is 256 values: looked at every 1024, as on the stencil path)
     }
   } else {
     const bool ident = a.nblk == 0;
@@ -216,6 +234,7 @@ __global__ __launch_bounds__(BLOCK) void k_pass(Grid G, SetArgs<T> a, int v_is_s
 #pragma unroll
         for (int k = 0; k < V; ++k) body(live ? out[k] : T(0), e + k, live);
       }
+      drain();
     }
   }
 
