@@ -37,6 +37,7 @@ void refresh_env_knobs() {
   k.rhs_march = (int)num("SIPX_RHS_MARCH", 1);
   k.rhs_march_zchunk = num("SIPX_RHS_MARCH_ZCHUNK", 0);
   k.q_plan = (int)num("SIPX_Q_PLAN", 1);
+  k.mark_stride = (int)std::max<long long>(0, num("SIPX_MARK_STRIDE", 0));
   k.trace_searches = (int)num("SIPX_TRACE_SEARCHES", 0);
   k.trace_kernels = (int)num("SIPX_TRACE_KERNELS", 0);
   g_env_knobs = k;
@@ -331,10 +332,13 @@ class Engine : public EngineBase {
     if (cstream_) (void)hipStreamDestroy(cstream_);
     for (auto e : ev_c_) if (e) (void)hipEventDestroy(e);
     if (ev_sums_) (void)hipEventDestroy(ev_sums_);
+    for (hipEvent_t e : open_ev_) if (e) (void)hipEventDestroy(e);
     if (ev_cgb_) (void)hipEventDestroy(ev_cgb_);
     if (ticket_) (void)hipHostFree((void*)ticket_);
     if (cg_host_) (void)hipHostFree(cg_host_);
     if (hres_) (void)hipHostFree(hres_);
+    if (sums_word_) (void)hipHostFree((void*)sums_word_);
+    dfree(sums_ticket_);
     if (hlean_) (void)hipHostFree((void*)hlean_);
     if (hovf_) (void)hipHostFree((void*)hovf_);
     if (hverd_) (void)hipHostFree((void*)hverd_);
@@ -720,6 +724,9 @@ class Engine : public EngineBase {
     SIPX_HIP(hipEventCreateWithFlags(&ev_sums_, hipEventDisableTiming));
     SIPX_HIP(hipHostMalloc((void**)&hres_, sizeof(double) * (p_n_ + 1) * SLOTS, hipHostMallocDefault));
     std::memset(hres_, 0, sizeof(double) * (p_n_ + 1) * SLOTS);
+    SIPX_HIP(hipHostMalloc((void**)&sums_word_, 64, hipHostMallocDefault));
+    std::memset((void*)sums_word_, 0, 64);
+    sums_ticket_ = dalloc<unsigned>(1);
     SIPX_HIP(hipHostMalloc((void**)&hlean_, sizeof(int) * (p_n_ + 1), hipHostMallocDefault));
     std::memset((void*)hlean_, 0, sizeof(int) * (p_n_ + 1));
     SIPX_HIP(hipHostMalloc((void**)&hovf_, sizeof(int) * (p_n_ + 1), hipHostMallocDefault));
@@ -2080,7 +2087,8 @@ class Engine : public EngineBase {
     if (!sums_pending_) throw std::runtime_error("no y/l update is pending");
     sums_pending_ = false;
     const int flags = sums_flags_;
-    SIPX_HIP(hipEventSynchronize(sums_event_));
+    if (sums_by_word_) wait_word(sums_word_, sums_seq_);
+    else SIPX_HIP(hipEventSynchronize(sums_event_));
     have_log_sums_ = false;
     if (slab_) {
       // a threshold search whose final bracket, over all ranks, held more magnitudes than the exchange segments: every rank saw
@@ -2364,6 +2372,8 @@ class Engine : public EngineBase {
     Run& R = run_;
     R = Run();
     head_done_ = false;
+    for (bool& v : open_valid_) v = false;
+    mark_weight_[0] = mark_weight_[1] = 1.0;
     R.log = log;
     R.maxit = opt->maxit;
     const int p = p_n_, pp = pp_n_;
@@ -2412,11 +2422,28 @@ class Engine : public EngineBase {
     const int i = ++R.i;
     const int par = i & 1;
     resolve_timing(log, par);            // marks recorded two steps ago have long completed
+    // Grids of up to 2^23 points on one rank: the marks are recorded on iterations 1-4 and on every seventh after them (coprime
+    // with the usual rho_update_frequency 2 / 3 and with the feasibility estimate's 10, so that the sample holds plain,
+    // Barzilai-Borwein and feasibility iterations in their proportions), what they measure stands for the iterations since the
+    // last such one, and the sums of the y/l update are awaited on a pinned word instead of the record behind them (k_fin_sum).
+    // A record costs the stream up to 6 us -- two on a plain iteration, five on one that may change rho: 2048^2 2277 -> 2352 it/s,
+    // the buckets then estimates (within 12 % of the every-iteration figures over 35 iterations); at 256^3 the same buys 0.4 % and
+    // the buckets stay exact.  SIPX_MARK_STRIDE: 1 = every iteration, k = every k-th, whatever the grid.
+    const int stride = comm_ ? 1 : (env_knobs().mark_stride > 0 ? env_knobs().mark_stride : (Nx_ <= (1ll << 23) ? 7 : 1));
+    auto is_timed = [&](int it) { return stride <= 1 || it <= 4 || it % stride == 0; };
+    const bool timed = is_timed(i), next_timed = i < maxit && is_timed(i + 1);
+    mark_step_[par] = i;
+    if (timed) {
+      mark_weight_[par] = (double)(i - R.last_timed);
+      R.last_timed = i;
+    }
+    word_sums_ = stride > 1;
+    struct WordSumsOff { bool& f; ~WordSumsOff() { f = false; } } word_sums_off{word_sums_};      // (the phase entry points keep the event)
     // Section timing: ONE chain of marks on the engine stream (a record costs the stream about 5 us); the time between two
     // consecutive marks goes to the section named at the later one (-1: a mark that only opens an interval), four marks per
     // step in the common path.  The two host-only sections (stop rule, rho / gamma rules) use the host clock.
     auto mark = [&](int section) {
-      if (nmark_[par] >= MAXMARK) return;
+      if (!timed || nmark_[par] >= MAXMARK) return;
       SIPX_HIP(hipEventRecord(ev_[par * MAXMARK + nmark_[par]], stream_));
       mark_sec_[par][nmark_[par]++] = section;
     };
@@ -2430,7 +2457,8 @@ class Engine : public EngineBase {
       return ((R.adjust_rho || R.adjust_gamma) && it % R.freq == 0) || (R.adjust_feas_rho && it % 10 == 0 && it > 10 && pp > 0);
     };
     {
-      if (!head_done_) mark(-1);           // (head queued ahead: the interval since the last mark belongs to the x-step)
+      // (the x-step's section opens where its residual product is queued: here, or in the step before when that was queued ahead)
+      if (!head_done_ && timed) open_section(i);
       if (!R.rhs_ready) {
         rhs_compose(rho.data());
         mark(1);
@@ -2453,8 +2481,8 @@ class Engine : public EngineBase {
       fuse_rhs_ = false;
       defer_sums_ = false;
       merge_sums_ = false;
-      mark(3);                             // also the event the host waits on for the sums
-      sums_event_ = ev_[par * MAXMARK + nmark_[par] - 1];
+      mark(3);                             // also the event the host waits on for the sums (unless they come with the pinned word)
+      if (nmark_[par] > 0) sums_event_ = ev_[par * MAXMARK + nmark_[par] - 1];
       // Software pipeline: nothing the GPU is given next may depend on the sums the host is about to read.  When the rules
       // below cannot touch rho, rhs_{i+1} = sum_i A_i'(rho_i y_i + l_i) (and, sharded, its reduce-scatter on the
       // communication stream) is queued now and runs while the host waits for the sums and evaluates the stop rule.  A
@@ -2470,6 +2498,7 @@ class Engine : public EngineBase {
       //  for evol_x after this point: its logged evol_x was zero.  The product no longer touches x_old: x_k stays behind in its own
       //  ring buffer when the x-step moves on, tests/test_gpu_round4.py::test_feasibility_only_logs_evol_x...)
       if (R.rhs_ready && resid_ahead_) {     // ... and so is the residual product of the coming x-step
+        if (next_timed) open_section(i + 1);         // (the coming step is a timed one: its x-step section opens here)
         argmin_x_head();
         if (comm_) {                         // (sharded: the sums arrive with the grouped call of the head)
           mark(2);
@@ -3369,19 +3398,31 @@ class Engine : public EngineBase {
     dfree(tmp);
   }
 
+  // the event a timed step's first interval starts from (round 4: the first mark of a step used to open nothing when the residual
+  // product had been queued ahead, and the x-step of every such iteration went uncounted -- "argmin x" read 0.21 of 0.5 ms)
+  // (four slots, by step: the opening of step i + 1 is recorded during step i, before the marks of step i - 1 are resolved)
+  void open_section(int step) {
+    const int k = step & 3;
+    if (!open_ev_[k]) SIPX_HIP(hipEventCreate(&open_ev_[k]));
+    SIPX_HIP(hipEventRecord(open_ev_[k], stream_));
+    open_valid_[k] = true;
+  }
   void resolve_timing(sipx_log* log, int par) {
     const int n = nmark_[par];
-    if (!n) return;
+    const int slot = mark_step_[par] & 3;
+    if (!n) { open_valid_[slot] = false; return; }
     nmark_[par] = 0;
     // timing_ms: [0] initialization (host side) [1] rhs [2] argmin x [3] y/l update [4] stop rule [5] rho / gamma rules [6] Q update
     SIPX_HIP(hipEventSynchronize(ev_[par * MAXMARK + n - 1]));
-    hipEvent_t prev = nullptr;
+    hipEvent_t prev = open_valid_[slot] ? open_ev_[slot] : nullptr;
+    open_valid_[slot] = false;
+    const double w = mark_weight_[par] > 0 ? mark_weight_[par] : 1.0;      // the iterations this timed one stands for
     for (int k = 0; k < n; ++k) {
       hipEvent_t e = ev_[par * MAXMARK + k];
       const int sec = mark_sec_[par][k];
       if (sec >= 0 && prev) {
         float ms = 0;
-        if (hipEventElapsedTime(&ms, prev, e) == hipSuccess) log->timing_ms[sec] += ms;
+        if (hipEventElapsedTime(&ms, prev, e) == hipSuccess) log->timing_ms[sec] += w * ms;
         else (void)hipGetLastError();
       }
       prev = e;
@@ -3400,9 +3441,15 @@ class Engine : public EngineBase {
       K<T>::fin_sum(stream_, part_sets_, nslots, dres_, nullptr);
       comm_->allreduce_sum(dres_, (size_t)nslots, SIPX_F64, stream_);
       K<T>::copy_f64(stream_, dres_, hres_, nslots);
+    } else if (word_sums_) {
+      // (one rank, whole-solve loop: the host spins on a pinned word the last workgroup publishes, see k_fin_sum)
+      K<T>::fin_sum(stream_, part_sets_, nslots, nullptr, hres_, sums_ticket_, (unsigned long long*)sums_word_, ++sums_seq_);
+      sums_by_word_ = true;
+      return;
     } else {
       K<T>::fin_sum(stream_, part_sets_, nslots, nullptr, hres_);
     }
+    sums_by_word_ = false;
   }
 
   // Verdict of CG iteration `iter` of solve `seq`: spins on the ticket word, which the device publishes as soon as the
@@ -3429,6 +3476,22 @@ class Engine : public EngineBase {
         }
         if (q != hipErrorNotReady) SIPX_HIP(q);
         (void)hipGetLastError();        // hipErrorNotReady is not an error: keep it out of the launch checks
+      }
+    }
+  }
+
+  // the sequence number k_fin_sum publishes behind the sums (pinned; see there)
+  void wait_word(volatile unsigned long long* word, unsigned long long seq) {
+    for (unsigned spins = 1;; ++spins) {
+      if (__atomic_load_n((unsigned long long*)word, __ATOMIC_ACQUIRE) == seq) return;
+      if ((spins & 0x3ffff) == 0) {
+        const hipError_t q = hipStreamQuery(stream_);
+        if (q == hipSuccess) {
+          if (__atomic_load_n((unsigned long long*)word, __ATOMIC_ACQUIRE) == seq) return;
+          throw std::runtime_error("internal: the stream ran dry without the sums of the y/l update (a kernel faulted?)");
+        }
+        if (q != hipErrorNotReady) SIPX_HIP(q);
+        (void)hipGetLastError();
       }
     }
   }
@@ -3483,7 +3546,7 @@ class Engine : public EngineBase {
   struct Run {     // state of one whole solve (sipx_parsdmm_begin / _steps)
     bool active = false, done = false;
     sipx_log* log = nullptr;
-    int maxit = 0, freq = 2, counter = 2, ind_ref = 0, i = 0;
+    int maxit = 0, freq = 2, counter = 2, ind_ref = 0, i = 0, last_timed = 0;
     T evol_rel_tol = 0, feas_tol = 0, obj_tol = 0;
     bool adjust_rho = true, adjust_gamma = true, adjust_feas_rho = true;
     double tol_ref = 1.0;
@@ -3527,6 +3590,10 @@ class Engine : public EngineBase {
   double *part_cg_ = nullptr, *part_tmp_ = nullptr, *part_sets_ = nullptr;
   CgState<T>*cg_dev_ = nullptr, *cg_host_ = nullptr;
   double* hres_ = nullptr;
+  volatile unsigned long long* sums_word_ = nullptr;   // pinned: sequence number of the latest reduction of the set sums (k_fin_sum)
+  unsigned* sums_ticket_ = nullptr;
+  unsigned long long sums_seq_ = 0;
+  bool sums_by_word_ = false, word_sums_ = false;      // word_sums_: set by the whole-solve loop for the duration of a step (one rank)
   volatile int* hlean_ = nullptr;     // per set: the coming l1 search wants a sampled prediction (written by k_l1_solve)
   volatile int* hovf_ = nullptr;      // per set: the slab-decomposed search overflowed its exchange segments (k_gather_unpack)
   volatile unsigned* hverd_ = nullptr;   // per set: verdict of the speculative exchange of a slab-decomposed search (k_spec_decide)
@@ -3563,6 +3630,10 @@ class Engine : public EngineBase {
   bool fuse_rhs_ = false;             // the whole-solve loop: rho cannot change before the next iteration, so the sweep may write its rhs
   bool rhs_fused_ = false;            // ... and did
   std::vector<hipEvent_t> ev_;
+  hipEvent_t open_ev_[4] = {nullptr, nullptr, nullptr, nullptr};
+  bool open_valid_[4] = {false, false, false, false};
+  int mark_step_[2] = {0, 0};          // the step whose marks sit in a parity's slots
+  double mark_weight_[2] = {1.0, 1.0};
   int nmark_[2] = {0, 0};
   int mark_sec_[2][MAXMARK];
   hipEvent_t sums_event_ = nullptr;

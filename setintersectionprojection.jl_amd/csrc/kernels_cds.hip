@@ -1233,18 +1233,32 @@ bool K<T>::resid_qupdate(hipStream_t s, const Grid& g, long long N, const T* R_o
 
 // ---------------------------------------------------------------------------------------------
 // out[slot] = sum of the NB partials of each slot (one block per slot, fixed order)
+// word (pinned, optional): the workgroup that finishes last publishes `seq` there with a system-scope release store, behind every
+// workgroup's sum -- the host spins on the word instead of waiting on an event record (which costs the stream about 6 us: the
+// engine records section marks on a sample of the iterations only, parsdmm_step)
 __global__ __launch_bounds__(BLOCK) void k_fin_sum(const double* __restrict__ partials, double* __restrict__ out_dev,
-                                                   double* __restrict__ out_host) {
+                                                   double* __restrict__ out_host, unsigned* __restrict__ ticket,
+                                                   unsigned long long* __restrict__ word, unsigned long long seq) {
   const double s = block_sum_partials(partials + (long long)blockIdx.x * NB);
   if (threadIdx.x == 0) {
     if (out_dev) out_dev[blockIdx.x] = s;
     if (out_host) out_host[blockIdx.x] = s;
+    if (word) {
+      __threadfence_system();
+      const unsigned t = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+      if (t == gridDim.x - 1) {
+        __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __threadfence_system();
+        __hip_atomic_store(word, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+      }
+    }
   }
 }
 template <typename T>
-void K<T>::fin_sum(hipStream_t s, const double* partials, int nslots, double* out_dev, double* out_host) {
+void K<T>::fin_sum(hipStream_t s, const double* partials, int nslots, double* out_dev, double* out_host, unsigned* ticket,
+                   unsigned long long* word, unsigned long long seq) {
   ObsScope obs(KID_FIN_SUM, s, (double)nslots * NB * sizeof(double));
-  hipLaunchKernelGGL(k_fin_sum, dim3(nslots), dim3(BLOCK), 0, s, partials, out_dev, out_host);
+  hipLaunchKernelGGL(k_fin_sum, dim3(nslots), dim3(BLOCK), 0, s, partials, out_dev, out_host, ticket, word, seq);
   SIPX_HIP(hipGetLastError());
 }
 
@@ -1284,7 +1298,7 @@ void K<T>::copy_f64(hipStream_t s, const double* src, double* dst, int n) {
                                    CgState<T>*, int, unsigned long long*, long long, long long);                     \
   template void K<T>::cg_update_p(hipStream_t, long long, T*, const T*, const double*, CgState<T>*, CgState<T>*,     \
                                   unsigned long long*, long long, long long);                                        \
-  template void K<T>::fin_sum(hipStream_t, const double*, int, double*, double*);                                   \
+  template void K<T>::fin_sum(hipStream_t, const double*, int, double*, double*, unsigned*, unsigned long long*, unsigned long long); \
   template void K<T>::copy_f64(hipStream_t, const double*, double*, int);
 SIPX_INST(float)
 SIPX_INST(double)

@@ -91,6 +91,7 @@ struct EnvKnobs {
   long long rhs_march_zchunk = 0; // SIPX_RHS_MARCH_ZCHUNK
   int trace_kernels = 0;          // SIPX_TRACE_KERNELS=1 (debugging): name every launch on stderr and drain the stream behind it
   int trace_searches = 0;         // SIPX_TRACE_SEARCHES=1: every threshold search of the batched chain that needed its fallback sweeps, on stderr
+  int mark_stride = 0;            // SIPX_MARK_STRIDE: section timing marks on iterations 1-4 and every such iteration after them (1: every iteration; 0: by grid size, parsdmm_step)
   int q_plan = 1;                 // SIPX_Q_PLAN=0: the Q update regenerates every band value per element (k_q_update) instead of adding planned products
 };
 const EnvKnobs& env_knobs();
@@ -533,7 +534,8 @@ struct K {
                            double* partials);
   static void rows_pack(hipStream_t s, const Grid& g, int dir, long long nrows, const T* pad, T* rows);
   static void rows_unpack(hipStream_t s, const Grid& g, int dir, long long nrows, const T* rows, T* pad);
-  static void fin_sum(hipStream_t s, const double* partials, int nslots, double* out_dev, double* out_host);
+  static void fin_sum(hipStream_t s, const double* partials, int nslots, double* out_dev, double* out_host, unsigned* ticket = nullptr,
+                      unsigned long long* word = nullptr, unsigned long long seq = 0);
   static void copy_f64(hipStream_t s, const double* src, double* dst, int n);      // device -> pinned host, by a kernel
   // Scalars of the two-pass projectors (l1 threshold, l2 / annulus scale) of a vector that is either
   // produced on the fly by a set (v = x_hat - l/rho, or s = A x when v_is_s) or stored in an array.

@@ -433,3 +433,37 @@ def test_l1_behind_the_dft_through_the_real_transform(sipx, monkeypatch, TF, n):
     P1 = sipx.setup_constraints([sipx.set_definitions("l1", "DFT", 0.0, 1e30, ("matrix", ""))], sipx.compgrid(h, n), TF)[0]
     v = m.copy()
     assert np.array_equal(np.asarray(P1[0](v.copy())), v)
+
+
+@pytest.mark.parametrize("stride", ["1", "7"])
+def test_section_timing_adds_up(sipx, monkeypatch, stride):
+    """log_PARSDMM's timing sections (src/PARSDMM.jl:84-257: T_rhs, T_cg, T_y_l_upd, T_Q_upd ...) are intervals between event records on
+    the engine stream.  Round 4: a step whose residual product had been queued ahead opened its x-step interval nowhere, and "argmin x"
+    went uncounted on every such iteration (0.21 of 0.5 ms at 256^3: the sections summed to 82 % of the wall time) -- the interval
+    now opens where the product is queued.  With a record on every iteration the sections add up to the wall time of the loop; on
+    small grids the engine records on a sample of the iterations (every seventh) and scales: an estimate, still within a quarter."""
+    import time
+    TF, n, h = np.float32, (128, 128, 96), (25.0, 25.0, 25.0)
+    m = model(n, TF, seed=9)
+    monkeypatch.setenv("SIPX_MARK_STRIDE", stride)
+    g, o, P, A, prop, AtA = _problem(sipx, n, h, TF, ["bounds", "l1:D_x", "l1:D_y", "l1:D_z"], m,
+                                     dict(maxit=90, evol_rel_tol=0.0, feas_tol=0.0, obj_tol=0.0))
+    ctx = sipx.host.build_context(m, AtA, A, prop, P, g, o)
+    try:
+        ctx.parsdmm_begin(o)
+        ctx.parsdmm_steps(6)                       # (first launches of every kernel)
+        ctx.debug_proj(1, 0)                       # (drains the engine's stream)
+        t0 = time.perf_counter()
+        done = ctx.parsdmm_steps(84)
+        ctx.debug_proj(1, 0)
+        wall = time.perf_counter() - t0
+        log = ctx.parsdmm_log()
+        assert len(log.obj) == 90 and done
+        secs = {k: v for k, v in log.timing.items() if k != "initialization"}
+        total = sum(secs.values())
+        # (the six warm-up iterations are in the sections too: a fifteenth of the run)
+        lo, hi = (0.9, 1.25) if stride == "1" else (0.7, 1.45)
+        assert lo * wall < total < hi * wall, (wall, total, secs)
+        assert secs["argmin x"] > 0.2 * total and secs["argmin y and l update"] > 0.3 * total, secs
+    finally:
+        ctx.close()
