@@ -71,6 +71,8 @@ if [ -z "$LIGHT" ]; then
   export SIPX_RANK_LANE=0
   trace c4 c4_512_in_turn --steps 6 --warmup 2
   unset SIPX_RANK_LANE
+  # ... and over 80 iterations: what a long solve of that list sustains (the slice-rank projector's route on inputs that keep moving)
+  $T python bench.py --no-cpu-baseline --no-512 --no-c4 --no-c5 --config c4 --steps 80 --warmup 2 > $O/${R}_c4_512_bench_80_iterations.json 2>>$O/bench.err
   trace c2 c2_2048
   $T python bench.py --no-cpu-baseline --no-512 --no-c4 --no-c5 --warmup 100 --steps 100 > $O/${R}_c3_256_bench_steady_it101_200.json 2>>$O/bench.err
   $T python bench.py --no-cpu-baseline --no-c4 --no-c5 --config c3-512 --warmup 100 --steps 60 > $O/${R}_c3_512_bench_steady_it101_160.json 2>>$O/bench.err
