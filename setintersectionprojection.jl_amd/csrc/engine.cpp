@@ -2429,7 +2429,10 @@ class Engine : public EngineBase {
     // A record costs the stream up to 6 us -- two on a plain iteration, five on one that may change rho: 2048^2 2277 -> 2352 it/s,
     // the buckets then estimates (within 12 % of the every-iteration figures over 35 iterations); at 256^3 the same buys 0.4 % and
     // the buckets stay exact.  SIPX_MARK_STRIDE: 1 = every iteration, k = every k-th, whatever the grid.
-    const int stride = comm_ ? 1 : (env_knobs().mark_stride > 0 ? env_knobs().mark_stride : (Nx_ <= (1ll << 23) ? 7 : 1));
+    // (sharded: every iteration, unless SIPX_MARK_STRIDE says otherwise -- a rank's share of the headline on eight GPUs through RCCL
+    //  with a world of one ran at 2215 it/s with the marks sampled and at 2219 without: its collectives leave gaps the records hide
+    //  in; the sums then keep an event of their own, ev_sums_, where the marks are left out)
+    const int stride = env_knobs().mark_stride > 0 ? env_knobs().mark_stride : ((!comm_ && Nx_ <= (1ll << 23)) ? 7 : 1);
     auto is_timed = [&](int it) { return stride <= 1 || it <= 4 || it % stride == 0; };
     const bool timed = is_timed(i), next_timed = i < maxit && is_timed(i + 1);
     mark_step_[par] = i;
@@ -2437,7 +2440,7 @@ class Engine : public EngineBase {
       mark_weight_[par] = (double)(i - R.last_timed);
       R.last_timed = i;
     }
-    word_sums_ = stride > 1;
+    word_sums_ = stride > 1 && !comm_;
     struct WordSumsOff { bool& f; ~WordSumsOff() { f = false; } } word_sums_off{word_sums_};      // (the phase entry points keep the event)
     // Section timing: ONE chain of marks on the engine stream (a record costs the stream about 5 us); the time between two
     // consecutive marks goes to the section named at the later one (-1: a mark that only opens an interval), four marks per
@@ -2482,7 +2485,11 @@ class Engine : public EngineBase {
       defer_sums_ = false;
       merge_sums_ = false;
       mark(3);                             // also the event the host waits on for the sums (unless they come with the pinned word)
-      if (nmark_[par] > 0) sums_event_ = ev_[par * MAXMARK + nmark_[par] - 1];
+      if (timed && nmark_[par] > 0) sums_event_ = ev_[par * MAXMARK + nmark_[par] - 1];
+      else if (!word_sums_) {              // (a step without marks whose sums do not come with the pinned word: sharded)
+        SIPX_HIP(hipEventRecord(ev_sums_, stream_));
+        sums_event_ = ev_sums_;
+      }
       // Software pipeline: nothing the GPU is given next may depend on the sums the host is about to read.  When the rules
       // below cannot touch rho, rhs_{i+1} = sum_i A_i'(rho_i y_i + l_i) (and, sharded, its reduce-scatter on the
       // communication stream) is queued now and runs while the host waits for the sums and evaluates the stop rule.  A
@@ -2501,8 +2508,13 @@ class Engine : public EngineBase {
         if (next_timed) open_section(i + 1);         // (the coming step is a timed one: its x-step section opens here)
         argmin_x_head();
         if (comm_) {                         // (sharded: the sums arrive with the grouped call of the head)
-          mark(2);
-          sums_event_ = ev_[par * MAXMARK + nmark_[par] - 1];
+          // (an opening mark: the head's time belongs to the coming step's x-step section, which opened in front of it)
+          mark(-1);
+          if (timed && nmark_[par] > 0) sums_event_ = ev_[par * MAXMARK + nmark_[par] - 1];
+          else {
+            SIPX_HIP(hipEventRecord(ev_sums_, stream_));
+            sums_event_ = ev_sums_;
+          }
         }
       }
       collect_set_sums(rho.data(), rpri.data(), rdual.data(), feas.data());
