@@ -156,6 +156,19 @@ int sipx_finalize(sipx_ctx* ctx, const void* m, const double* rho_ini, int n_rho
                   int feasibility_only, int zero_ini_guess, const void* x0, const void* const* l0,
                   const void* const* y0, double* feasibility_initial);
 
+/* The same sets on the same grid, once more: a new model m (and, optionally, another warm start and rho_ini) on a context that
+ * has been finalised -- and, usually, solved -- before.  This is how the reference's callers use this entry point: PARSDMM wrapped
+ * as a projector and called again and again inside an outer loop (examples/constrained_freq_FWI_simple.jl:468,
+ * examples/Constraint_examples_2D.jl:222-223, examples/Dykstra_parallel_vs_PARSDMM.jl:134); every such call of the reference runs
+ * PARSDMM_initialize again (src/PARSDMM.jl:58-61).  Here nothing is allocated and no plan, handle, stream or event is created:
+ * every array is zero-filled, m uploaded, rho / gamma set as sipx_finalize sets them, Q assembled again (the solve updated it
+ * incrementally, src/Q_update!.jl:45-48), every warm start inside the context forgotten, feasibility_initial[pp] taken again
+ * (src/PARSDMM_initialize.jl:97-99).  The context is then in the state sipx_finalize leaves it in: a solve on it returns the bits a
+ * newly built context returns.  Arguments as for sipx_finalize (feasibility_only stays what it was).  Not available for a rank of a
+ * sharded solve. */
+int sipx_reset(sipx_ctx* ctx, const void* m, const double* rho_ini, int n_rho, double gamma_ini, int zero_ini_guess,
+               const void* x0, const void* const* l0, const void* const* y0, double* feasibility_initial);
+
 /* ---- A. phase level ---- */
 /* rhs = sum_i A_i'(rho_i y_i + l_i)                                   (src/rhs_compose.jl:24-36) */
 int sipx_rhs_compose(sipx_ctx* ctx, const double* rho);
@@ -223,7 +236,11 @@ const char* sipx_kernel_stats_json(sipx_ctx* ctx, int enable);
 int sipx_debug_proj(sipx_ctx* ctx, int set, int which, double* out16);
 /* engine stream handle (hipStream_t) so a host harness can order its own work / collectives against it */
 void* sipx_stream(sipx_ctx* ctx);
-/* device pointers of rhs / x (TF[N]) for in-place collectives on the sharded path */
+/* device pointers of rhs / x (TF[N]) for in-place collectives on the sharded path.
+ * sipx_dev_x: x lives in a ring of three buffers -- every x-step that changes x (sipx_argmin_x, sipx_parsdmm_steps) moves it to
+ * another one and leaves the old iterate behind as x_old.  The pointer is therefore valid ONLY UNTIL THE NEXT x-step: ask again
+ * after every step, never cache it (a cached pointer names x_old, or the Barzilai-Borwein snapshot, one step later).  Before the
+ * first x-step x_old names x itself (the zero / warm start): evol_x of an update taken then is ||x - x|| = 0. */
 void* sipx_dev_rhs(sipx_ctx* ctx);
 void* sipx_dev_x(sipx_ctx* ctx);
 /* rhs as composed by the last sipx_rhs_compose (host TF[N]; TF[2N] in Minkowski mode)           (src/rhs_compose.jl:24-36) */

@@ -62,6 +62,10 @@ int sipx_finalize(sipx_ctx* c, const void* m, const double* rho_ini, int n_rho, 
   SIPX_TRY(c->e->finalize(m, rho_ini, n_rho, gamma_ini, feasibility_only, zero_ini_guess, x0, l0, y0,
                           feasibility_initial))
 }
+int sipx_reset(sipx_ctx* c, const void* m, const double* rho_ini, int n_rho, double gamma_ini, int zero_ini_guess, const void* x0,
+               const void* const* l0, const void* const* y0, double* feasibility_initial) {
+  SIPX_TRY(c->e->reset(m, rho_ini, n_rho, gamma_ini, zero_ini_guess, x0, l0, y0, feasibility_initial))
+}
 int sipx_rhs_compose(sipx_ctx* c, const double* rho) { SIPX_TRY(c->e->rhs_compose(rho)) }
 int sipx_argmin_x(sipx_ctx* c, int it, double* tol_ref_io, int64_t* cg_it, double* cg_relres, int* cg_flag) {
   SIPX_TRY(c->e->argmin_x(it, tol_ref_io, cg_it, cg_relres, cg_flag))

@@ -64,12 +64,46 @@ struct ObserverGuard {
 
 constexpr int SLOTS = SET_SLOTS;      // reduction slots per set: 0..12 k_yl, 13 ||A'dy||^2, 14/15 two-pass feasibility
 
+// what the tally counted for an allocation, so that freeing it while a tally is active takes the bytes back (the temporaries of
+// sipx_finalize -- upload_rows' staging, the whole-size buffer of upload_rows_ranged -- used to stay in device_bytes_per_rank)
+inline std::map<void*, long long>& tally_sizes() {
+  static std::map<void*, long long> m;
+  return m;
+}
+inline std::mutex& tally_mutex() {
+  static std::mutex m;
+  return m;
+}
+inline void tally_add(void* p, long long bytes) {
+  if (long long* t = alloc_tally()) {
+    *t += bytes;
+    std::lock_guard<std::mutex> lk(tally_mutex());
+    tally_sizes()[p] += bytes;
+  }
+}
+inline void tally_release(void* p) {
+  long long* t = alloc_tally();
+  std::lock_guard<std::mutex> lk(tally_mutex());
+  auto it = tally_sizes().find(p);
+  if (it == tally_sizes().end()) return;
+  if (t) *t -= it->second;
+  tally_sizes().erase(it);
+}
+// bytes of every plain allocation (sipx_reset zeroes a context's arrays without knowing each one's length)
+inline std::map<void*, size_t>& alloc_sizes() {
+  static std::map<void*, size_t> m;
+  return m;
+}
 template <typename T>
 T* dalloc(size_t n, bool zero = true) {
   T* p = nullptr;
   if (n == 0) return p;
   SIPX_HIP(hipMalloc(&p, n * sizeof(T)));
-  if (long long* t = alloc_tally()) *t += (long long)(n * sizeof(T));
+  tally_add(p, (long long)(n * sizeof(T)));
+  {
+    std::lock_guard<std::mutex> lk(tally_mutex());
+    alloc_sizes()[p] = n * sizeof(T);
+  }
   if (zero) {
     // hipMemset is queued on the NULL stream; the engine stream is non-blocking, so wait here or the
     // zero-fill may land after kernels of the engine stream have already written the buffer.
@@ -142,7 +176,7 @@ inline void* sparse_alloc_bytes(size_t total_bytes, std::vector<std::pair<size_t
       chk(hipMemSetAccess((char*)base + off, len, &acc, 1), "hipMemSetAccess");
       blk.maps.push_back({off, len});
       blk.handles.push_back(h);
-      if (long long* t = alloc_tally()) *t += (long long)len;
+      tally_add(base, (long long)len);
     }
     SIPX_HIP(hipMemset((char*)base + r.first, 0, r.second - r.first));
   }
@@ -153,6 +187,7 @@ inline void* sparse_alloc_bytes(size_t total_bytes, std::vector<std::pair<size_t
 }
 inline void dfree(void* p) {
   if (!p) return;
+  tally_release(p);
   {
     std::lock_guard<std::mutex> lk(sparse_mutex());
     auto it = sparse_registry().find(p);
@@ -166,7 +201,31 @@ inline void dfree(void* p) {
       return;
     }
   }
+  {
+    std::lock_guard<std::mutex> lk(tally_mutex());
+    alloc_sizes().erase(p);
+  }
   (void)hipFree(p);
+}
+// zero-fill of an allocation made by dalloc or sparse_alloc_bytes (its mapped granules), queued on `s`
+inline void dzero(void* p, hipStream_t s) {
+  if (!p) return;
+  {
+    std::lock_guard<std::mutex> lk(sparse_mutex());
+    auto it = sparse_registry().find(p);
+    if (it != sparse_registry().end()) {
+      for (const auto& mp : it->second.maps) SIPX_HIP(hipMemsetAsync((char*)p + mp.first, 0, mp.second, s));
+      return;
+    }
+  }
+  size_t bytes = 0;
+  {
+    std::lock_guard<std::mutex> lk(tally_mutex());
+    auto it = alloc_sizes().find(p);
+    if (it == alloc_sizes().end()) throw std::runtime_error("internal: dzero of an allocation the engine did not make");
+    bytes = it->second;
+  }
+  SIPX_HIP(hipMemsetAsync(p, 0, bytes, s));
 }
 
 
@@ -541,11 +600,18 @@ class Engine : public EngineBase {
       if (r1_ <= r0_) { Gr_.e0 = Gr_.e1 = 0; Gyl_.e0 = Gyl_.e1 = 0; }
     }
     wlo_ = -halo_; whi_ = Npad + halo_;
+    bool sparse_wanted = false;
     if (slab_ && !slab_full_req_) {
-      const char* e = std::getenv("SIPX_SLAB_LOCAL");        // 0: full-size arrays on every rank, as before (A/B switch; a fallback should a communicator refuse mapped memory)
+      const char* e = std::getenv("SIPX_SLAB_LOCAL");        // 0: full-size arrays on every rank, as before (A/B switch)
       int vmm = 0;
       (void)hipDeviceGetAttribute(&vmm, hipDeviceAttributeVirtualMemoryManagementSupported, device_);
-      slab_local_ = vmm != 0 && !(e && e[0] == '0');
+      sparse_wanted = vmm != 0 && !(e && e[0] == '0');
+      for (const auto& st : sets_)
+        if (st.prox == PX_BOUNDS_VEC || (!st.two_pass && st.nblk > 0) || !st.host_ata.empty()) sparse_wanted = false;
+    }
+    if (comm_) comm_self_test(sparse_wanted);               // (every rank takes the same branch: the verdict is all-reduced)
+    if (slab_ && !slab_full_req_) {
+      slab_local_ = sparse_wanted && !selftest_mapped_failed_;
       for (const auto& st : sets_) {
         // per-element bound vectors arrive whole; the initial feasibility of an element-wise set on a difference operator
         // takes the whole-grid kernels: such lists keep full-size arrays
@@ -870,6 +936,94 @@ class Engine : public EngineBase {
     }
     finalized_ = true;
 
+    initial_feasibility(feasibility_initial);
+  }
+
+  // ------------------------------------------------------------------------------------------
+  // sipx_reset (round 5): the SAME sets on the SAME grid with a new model m (and, optionally, a new warm start and rho_ini) --
+  // what the reference's callers do when they wrap PARSDMM as a projector inside an outer loop
+  // (examples/constrained_freq_FWI_simple.jl:468, examples/Constraint_examples_2D.jl:222-223).  Nothing is allocated, no plan,
+  // handle, stream or event is created: every array of the context is zero-filled, m is uploaded, rho / gamma return to their
+  // initial values, Q is assembled again (the solve updated it incrementally: Q_update!.jl:45-48), every warm start of the
+  // searches and of the library-backed projectors is forgotten, the initial feasibility is taken again.  The context then is in
+  // the state sipx_finalize leaves, and a solve on it gives the bits a new context gives (tests/test_gpu_round5.py).
+  void reset(const void* m, const double* rho_ini, int n_rho, double gamma_ini, int zero_ini_guess, const void* x0,
+             const void* const* l0, const void* const* y0, double* feasibility_initial) override {
+    need_final();
+    if (comm_) throw std::runtime_error("sipx_reset is not available for a rank of a sharded solve (build a new context)");
+    SIPX_HIP(hipSetDevice(device_));
+    if (lane_thr_.joinable()) lane_thr_.join();
+    lane_err_ = nullptr;
+    SIPX_HIP(hipStreamSynchronize(stream_));
+    for (hipStream_t q : pool_) if (q && q != stream_) SIPX_HIP(hipStreamSynchronize(q));
+    if (lane_st_) SIPX_HIP(hipStreamSynchronize(lane_st_));
+    if (cstream_) SIPX_HIP(hipStreamSynchronize(cstream_));
+    const long long N = G_.N;
+    // ---- arrays
+    for (int k = 0; k < 3; ++k) dzero(xr_base_[k], stream_);
+    dzero(p_base_, stream_); dzero(rhs_, stream_); dzero(r_base_, stream_); dzero(Ap_, stream_);
+    dzero(p2_base_, stream_); dzero(w_base_, stream_); dzero(Q2_, stream_);
+    dzero(part_cg_, stream_); dzero(part_tmp_, stream_); dzero(part_sets_, stream_); dzero(maxpart_, stream_);
+    dzero(cg_dev_, stream_); dzero(sums_ticket_, stream_);
+    dzero(fbuf_, stream_); dzero(stage_, stream_); dzero(sstage_, stream_); dzero(gbuf_, stream_);
+    dzero(scr_v_, stream_); dzero(scr_c_, stream_); dzero(scr_w_, stream_);
+    if (scr_i_) dzero(scr_i_, stream_);
+    dzero(lane_v_, stream_);
+    SIPX_HIP(hipMemcpyAsync(m_, m, N * sizeof(T), hipMemcpyHostToDevice, stream_));
+    x_cur_ = 0; x_snap_ = -1;
+    x_ = xr_[0]; xold_ = x_;
+    // ---- rho, gamma (PARSDMM_initialize.jl:58-63,107-114,159)
+    if (n_rho == 1) std::fill(rho_.begin(), rho_.end(), (T)rho_ini[0]);
+    else if (n_rho == p_n_) for (int i = 0; i < p_n_; ++i) rho_[i] = (T)rho_ini[i];
+    else throw std::runtime_error("rho_ini must have 1 or p entries");
+    T g0 = (T)gamma_ini;
+    if (any_ncvx_) g0 = T(0.75);
+    std::fill(gamma_.begin(), gamma_.end(), g0);
+    // ---- sets
+    const bool warm = !zero_ini_guess;
+    for (int i = 0; i < p_n_; ++i) {
+      SetState<T>& s = sets_[i];
+      for (void* b : s.halo_allocs) dzero(b, stream_);
+      dzero(s.lh0, stream_); dzero(s.s0, stream_);
+      dzero(s.sbuf, stream_);
+      dzero(s.ptmp, stream_); dzero(s.mpart, stream_); dzero(s.cbuf, stream_);
+      s.snap = -1;
+      s.searches_done = 0;
+      std::fill(s.sums, s.sums + SLOTS, 0.0);
+      s.bb_valid = false;
+      s.last_rho = T(-1); s.last_gamma = T(-1);
+      if (s.ps) K<T>::ps_init(stream_, s.ps, scr_i_);
+      if (s.psf) K<T>::ps_init(stream_, s.psf, scr_i_);
+      if (s.ext) { s.ext->set_stream(stream_); s.ext->reset(); }
+      if (warm && l0 && l0[i]) upload_rows_ranged(s, (const T*)l0[i], s.l);
+      if (warm && y0 && y0[i]) upload_rows_ranged(s, (const T*)y0[i], s.y);
+    }
+    if (warm && x0) SIPX_HIP(hipMemcpyAsync(x_, x0, Nx_ * sizeof(T), hipMemcpyHostToDevice, stream_));
+    // ---- pinned words and the scalars that live beside them
+    std::memset(cg_host_, 0, 2 * sizeof(CgState<T>));
+    std::memset((void*)ticket_, 0xff, 64);
+    std::memset(hres_, 0, sizeof(double) * (p_n_ + 1) * SLOTS);
+    std::memset((void*)sums_word_, 0, 64);
+    std::memset((void*)hlean_, 0, sizeof(int) * (p_n_ + 1));
+    std::memset((void*)hovf_, 0, sizeof(int) * (p_n_ + 1));
+    std::memset((void*)hverd_, 0, sizeof(unsigned) * (p_n_ + 1));
+    sums_seq_ = 0; cg_seq_ = 0; spec_seq_ = 0;
+    spec_searches_ = spec_fallbacks_ = spec_rounds_ = 0;
+    batch_searches_ = batch_fallbacks_ = 0;
+    head_done_ = false; rs_pending_ = false; sums_pending_ = false; defer_sums_ = false; merge_sums_ = false; merged_nslots_ = 0;
+    q_pending_ = false; q_defer_ = false; rhs_fused_ = false; fuse_rhs_ = false; have_log_sums_ = false;
+    obj_ss_ = evo_ss_ = xx_ss_ = 0;
+    sums_flags_ = 0; word_sums_ = false;
+    for (bool& v : open_valid_) v = false;
+    mark_weight_[0] = mark_weight_[1] = 1.0;
+    nmark_[0] = nmark_[1] = 0;
+    mark_step_[0] = mark_step_[1] = 0;
+    run_ = Run();
+    assemble_Q();
+    initial_feasibility(feasibility_initial);
+  }
+
+  void initial_feasibility(double* feasibility_initial) {
     // initial feasibility ||P_i(A_i m) - A_i m|| / (||A_i m|| + 100 eps)   (PARSDMM_initialize.jl:97-99)
     feas_init_.assign(pp_n_, 0.0);
     for (int i = 0; i < pp_n_; ++i) {
@@ -1532,6 +1686,160 @@ class Engine : public EngineBase {
       SetArgs<T> a = lane_args_;
       a.v = scr_v_;
       ext_feasibility(s, a, part_sets_ + ((size_t)lane_set_ * SLOTS + SL_FE2) * NB);
+    }
+  }
+
+
+  // ---- communicator self-test (round 5) -------------------------------------------------------------------------
+  // RcclComm has only ever run with a world of one here (a gpurun box has one GPU), and the slab decomposition hands RCCL halo
+  // planes that live in hipMemMap-backed memory.  Before any array of the context is allocated every rank therefore runs the
+  // communicator's operations once on KNOWN data -- the grouped all-reduce + neighbour exchange, the in-place reduce-scatter and
+  // all-gather (the offsets RcclComm computes), the fan scatter / gather, all on plain memory; then the neighbour exchange once
+  // more with its four buffers inside a mapped granule between two unmapped ones -- compares what arrived with what must have
+  // arrived, and the ranks agree on the outcome through one more all-reduce on plain memory.  Wrong data from a base operation
+  // is an error of sipx_finalize on every rank alike (the caller may attach another communicator: bench.py goes on with
+  // torch.distributed callbacks); a failure of the mapped exchange alone switches THIS context to full-size arrays on every
+  // rank.  SIPX_COMM_SELFTEST=0 skips it.  The same code runs through the callback communicator (tests: 2-4 ranks on one GPU).
+  void comm_self_test(bool want_mapped) {
+    const char* e = std::getenv("SIPX_COMM_SELFTEST");
+    if (e && e[0] == '0') { selftest_ = "skipped (SIPX_COMM_SELFTEST=0)"; return; }
+    Comm& c = *comm_;
+    const int W = c.world, R = c.rank, dt = dtype_code();
+    const size_t chunk = 1024, hc = 256;
+    const int prev = R > 0 ? R - 1 : -1, next = R + 1 < W ? R + 1 : -1;
+    auto val = [](int r, size_t e) { return (double)((r + 1) * 256 + (int)(e & 255)); };
+    std::vector<T> h(std::max<size_t>(W * chunk, 4 * hc));
+    std::vector<double> hr(64);
+    T* buf = dalloc<T>(W * chunk);
+    T* hal = dalloc<T>(4 * hc);
+    double* red = dalloc<double>(64);
+    T* vm_base = nullptr;
+    std::string why;
+    auto put = [&](T* dst, size_t n) { SIPX_HIP(hipMemcpy(dst, h.data(), n * sizeof(T), hipMemcpyHostToDevice)); };
+    auto get = [&](const T* src, size_t n) {
+      SIPX_HIP(hipStreamSynchronize(stream_));
+      SIPX_HIP(hipMemcpy(h.data(), src, n * sizeof(T), hipMemcpyDeviceToHost));
+    };
+    auto fill_halo = [&](T* base) {            // [send_prev | send_next | recv_prev | recv_next], hc entries each
+      for (size_t j = 0; j < hc; ++j) { h[j] = (T)((R + 1) * 4096 + (int)j); h[hc + j] = (T)((R + 1) * 4096 + 2048 + (int)j); h[2 * hc + j] = h[3 * hc + j] = T(-1); }
+      put(base, 4 * hc);
+    };
+    auto check_halo = [&](const T* base, const char* what) {
+      get(base, 4 * hc);
+      for (size_t j = 0; j < hc; ++j) {
+        if (prev >= 0 && h[2 * hc + j] != (T)(R * 4096 + 2048 + (int)j)) { why = std::string(what) + ": the plane received from the rank below is not what it sent"; return false; }
+        if (next >= 0 && h[3 * hc + j] != (T)((R + 2) * 4096 + (int)j)) { why = std::string(what) + ": the plane received from the rank above is not what it sent"; return false; }
+        if (prev < 0 && h[2 * hc + j] != T(-1)) { why = std::string(what) + ": a receive buffer without a neighbour was written"; return false; }
+      }
+      return true;
+    };
+    auto red_fill = [&]() {
+      for (int i = 0; i < 64; ++i) hr[i] = (double)((R + 1) * 1000 + i);
+      SIPX_HIP(hipMemcpy(red, hr.data(), 64 * sizeof(double), hipMemcpyHostToDevice));
+    };
+    auto red_check = [&](const char* what) {
+      SIPX_HIP(hipStreamSynchronize(stream_));
+      SIPX_HIP(hipMemcpy(hr.data(), red, 64 * sizeof(double), hipMemcpyDeviceToHost));
+      for (int i = 0; i < 64; ++i)
+        if (hr[i] != 1000.0 * W * (W + 1) / 2 + (double)W * i) { why = std::string(what) + ": the all-reduced sums are wrong"; return false; }
+      return true;
+    };
+    bool ok = true, mapped_ok = true;
+    try {
+      // A: grouped all-reduce + neighbour exchange, plain memory
+      red_fill();
+      fill_halo(hal);
+      c.allreduce_with_halo(red, 64, SIPX_F64, hal, hal + 2 * hc, prev, hal + hc, hal + 3 * hc, next, hc, dt, stream_);
+      ok = red_check("all-reduce + neighbour exchange") && check_halo(hal, "all-reduce + neighbour exchange");
+      // B: reduce-scatter in place
+      if (ok) {
+        for (size_t q = 0; q < W * chunk; ++q) h[q] = (T)val(R, q);
+        put(buf, W * chunk);
+        c.reduce_scatter_sum(buf, chunk, dt, stream_);
+        get(buf, W * chunk);
+        for (size_t q = R * chunk; q < (R + 1) * chunk && ok; ++q)
+          if (h[q] != (T)(256.0 * W * (W + 1) / 2 + (double)W * (double)(q & 255))) { ok = false; why = "reduce-scatter (in place): the rank's range does not hold the sums"; }
+      }
+      // C: all-gather in place
+      if (ok) {
+        for (size_t q = 0; q < W * chunk; ++q) h[q] = (q / chunk == (size_t)R) ? (T)val(R, q) : T(-3);
+        put(buf, W * chunk);
+        c.allgather(buf, chunk, dt, stream_);
+        get(buf, W * chunk);
+        for (size_t q = 0; q < W * chunk && ok; ++q)
+          if (h[q] != (T)val((int)(q / chunk), q)) { ok = false; why = "all-gather (in place): a range does not hold its rank's values"; }
+      }
+      // D: fan scatter from rank 0, fan gather to the last rank
+      if (ok) {
+        for (size_t q = 0; q < W * chunk; ++q) h[q] = R == 0 ? (T)(val((int)(q / chunk), q) + 7.0) : T(-5);
+        put(buf, W * chunk);
+        c.scatter(buf, chunk, dt, 0, stream_);
+        get(buf, W * chunk);
+        for (size_t q = R * chunk; q < (R + 1) * chunk && ok; ++q)
+          if (h[q] != (T)(val(R, q) + 7.0)) { ok = false; why = "scatter: the rank's range is not what the root sent"; }
+      }
+      if (ok) {
+        for (size_t q = 0; q < W * chunk; ++q) h[q] = (q / chunk == (size_t)R) ? (T)(val(R, q) + 11.0) : T(-7);
+        put(buf, W * chunk);
+        c.gather(buf, chunk, dt, W - 1, stream_);
+        get(buf, W * chunk);
+        if (R == W - 1)
+          for (size_t q = 0; q < W * chunk && ok; ++q)
+            if (h[q] != (T)(val((int)(q / chunk), q) + 11.0)) { ok = false; why = "gather: a range at the root is not what its rank sent"; }
+      }
+    } catch (const std::exception& ex) {
+      ok = false;
+      why = std::string("an operation failed: ") + ex.what();
+    }
+    // E: the neighbour exchange out of / into hipMemMap-backed memory (one mapped granule between two that are not)
+    if (ok && want_mapped) {
+      try {
+        vm_base = (T*)sparse_alloc_bytes(3 * SPARSE_GRAN, {{SPARSE_GRAN, 2 * SPARSE_GRAN}}, device_);
+        T* vm = (T*)((char*)vm_base + SPARSE_GRAN) + 64;
+        red_fill();
+        fill_halo(vm);
+        c.allreduce_with_halo(red, 64, SIPX_F64, vm, vm + 2 * hc, prev, vm + hc, vm + 3 * hc, next, hc, dt, stream_);
+        std::string keep = why;
+        mapped_ok = red_check("mapped memory") && check_halo(vm, "mapped memory");
+        if (!mapped_ok) mapped_why_ = why;
+        why = keep;
+      } catch (const std::exception& ex) {
+        mapped_ok = false;
+        mapped_why_ = ex.what();
+      }
+    }
+    if (const char* f = std::getenv("SIPX_COMM_SELFTEST_FAIL")) {      // tests: "mapped" / "base", optionally ":rank" (one rank only)
+      const char* colon = std::strchr(f, ':');
+      if (!colon || std::atoi(colon + 1) == R) {
+        if (!std::strncmp(f, "mapped", 6) && want_mapped) { mapped_ok = false; mapped_why_ = "test hook"; }
+        if (!std::strncmp(f, "base", 4)) { ok = false; why = "test hook"; }
+      }
+    }
+    // the verdict, the same on every rank
+    bool all_ok = ok, all_mapped = mapped_ok;
+    try {
+      hr[0] = 4096.0 + (ok ? 0.0 : 1.0);
+      hr[1] = 4096.0 + (mapped_ok ? 0.0 : 1.0);
+      SIPX_HIP(hipMemcpy(red, hr.data(), 2 * sizeof(double), hipMemcpyHostToDevice));
+      c.allreduce_sum(red, 2, SIPX_F64, stream_);
+      SIPX_HIP(hipStreamSynchronize(stream_));
+      SIPX_HIP(hipMemcpy(hr.data(), red, 2 * sizeof(double), hipMemcpyDeviceToHost));
+      all_ok = hr[0] == 4096.0 * W;
+      all_mapped = hr[1] == 4096.0 * W;
+    } catch (const std::exception& ex) {
+      all_ok = false;
+      if (why.empty()) why = std::string("the verdict's all-reduce failed: ") + ex.what();
+    }
+    dfree(buf); dfree(hal); dfree(red);
+    if (vm_base) dfree(vm_base);
+    if (!all_ok)
+      throw std::runtime_error("communicator self-test failed (" + std::string(c.kind()) + ", rank " + std::to_string(R) + " of " + std::to_string(W) +
+                               "): " + (why.empty() ? std::string("another rank reports wrong data") : why));
+    selftest_ = "passed";
+    if (want_mapped && !all_mapped) {
+      selftest_ = "passed; exchange out of hipMemMap-backed memory failed (" + (mapped_why_.empty() ? std::string("on another rank") : mapped_why_) +
+                  "): full-size arrays";
+      selftest_mapped_failed_ = true;
     }
   }
 
@@ -2800,6 +3108,11 @@ class Engine : public EngineBase {
          std::to_string(spec_fallbacks_) + ", \"refinement_rounds\": " + std::to_string(spec_rounds_) + "}";
     // one rank: searches through the batched chain (batched_searches) and how many of them needed their fallback sweeps
     o += std::string(", \"sparse_arrays\": ") + (slab_local_ ? "true" : "false");
+    {
+      std::string t = selftest_;
+      for (auto& ch : t) if (ch == '"' || ch == '\\' || (unsigned char)ch < 32) ch = ' ';
+      o += ", \"comm_selftest\": \"" + t + "\"";
+    }
     o += ", \"lane_set\": " + std::to_string(lane_set_);       // the set updated on a stream of its own (-1: none), lane_start
     o += ", \"batched_searches\": {\"searches\": " + std::to_string(batch_searches_) + ", \"fallbacks\": " + std::to_string(batch_fallbacks_) + "}";
     // slice-rank / matrix-rank sets: which route their projector took since the context was finalised (ext_proj.hip)
@@ -3257,7 +3570,9 @@ class Engine : public EngineBase {
       return;
     }
     // (sparse arrays: the rows of every band that the rank's part of the x-step reads)
-    if (slab_local_) {
+    if (Q_) {                       // sipx_reset: the bands are there, zero them and add the sets up again
+      dzero(Q_, stream_);
+    } else if (slab_local_) {
       std::vector<std::pair<size_t, size_t>> rg;
       long long maxoff = 0;
       for (int b = 0; b < cds_.d; ++b) maxoff = std::max<long long>(maxoff, std::llabs(cds_.off[b]));
@@ -3684,6 +3999,9 @@ class Engine : public EngineBase {
   // slab-decomposed with SPARSE arrays: every N-sized array of the context is backed by memory for the rank's planes (and the
   // halo planes around them) only -- see SparseBlock.  [wlo_, whi_): the grid points whose entries exist on this rank.
   bool slab_full_req_ = false, slab_local_ = false;
+  // verdict of the communicator self-test of sipx_finalize ("none" without a communicator)
+  std::string selftest_ = "none", mapped_why_;
+  bool selftest_mapped_failed_ = false;
   long long wlo_ = 0, whi_ = 0;
   Grid Gr_, Gyl_;
   ChainHooks hooks_;

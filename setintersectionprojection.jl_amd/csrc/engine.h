@@ -20,6 +20,8 @@ struct EngineBase {
   virtual void finalize(const void* m, const double* rho_ini, int n_rho, double gamma_ini, int feasibility_only,
                         int zero_ini_guess, const void* x0, const void* const* l0, const void* const* y0,
                         double* feasibility_initial) = 0;
+  virtual void reset(const void* m, const double* rho_ini, int n_rho, double gamma_ini, int zero_ini_guess, const void* x0,
+                     const void* const* l0, const void* const* y0, double* feasibility_initial) = 0;
   virtual void rhs_compose(const double* rho) = 0;
   virtual void argmin_x(int it, double* tol_ref_io, int64_t* cg_it, double* cg_relres, int* cg_flag) = 0;
   virtual void update_y_l(int it, int flags, const double* rho, const double* gamma, double* r_pri, double* r_dual,

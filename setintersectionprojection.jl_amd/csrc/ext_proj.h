@@ -40,6 +40,8 @@ class ExtProj {
   void route_counts(long long out[4]) const;
   // the stream of the calls to come (the engine runs the slice-rank set of a long list on a lane of its own)
   void set_stream(hipStream_t s);
+  // forget every warm start and counter: the projector behaves like a newly built one (sipx_reset)
+  void reset();
 
  private:
   ExtImpl<T>* impl_;

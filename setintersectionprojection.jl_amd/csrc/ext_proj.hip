@@ -424,7 +424,8 @@ __global__ __launch_bounds__(BLOCK) void k_sub_normalize(int k, int b, int batch
   }
 }
 // ||G_l||_F^2 of every matrix of the batch (one workgroup each).
-__global__ __launch_bounds__(BLOCK) void k_sub_fro(int k, const double* __restrict__ G, double* __restrict__ fro2) {
+__global__ __launch_bounds__(BLOCK) void k_sub_fro(int k, const double* __restrict__ G, double* __restrict__ fro2,
+                                                   unsigned long long* res = nullptr) {
   __shared__ double sm[BLOCK / 64];
   const double* Gl = G + (long long)blockIdx.x * k * k;
   double a = 0;
@@ -436,21 +437,46 @@ __global__ __launch_bounds__(BLOCK) void k_sub_fro(int k, const double* __restri
     double t = 0;
     for (int w = 0; w < BLOCK / 64; ++w) t += sm[w];
     fro2[blockIdx.x] = t;
+    if (res) atomicMax(res + 7, (unsigned long long)__double_as_longlong(t));      // t >= 0: the bit patterns order like the values
+  }
+}
+// A start for a projector that has none (the first call of a solve; project_rank!.jl:26-45 has no state at all): fixed
+// pseudo-random columns, the same hash as the re-seeded columns of k_sub_normalize.
+__global__ __launch_bounds__(BLOCK) void k_sub_seed(int k, int b, int batch, double* __restrict__ X) {
+  const long long per = (long long)k * b, total = per * batch;
+  for (long long e = (long long)blockIdx.x * BLOCK + threadIdx.x; e < total; e += (long long)gridDim.x * BLOCK) {
+    const long long l = e / per, o = e - l * per;
+    const int j = (int)(o / k), i = (int)(o - (long long)j * k);
+    unsigned h = (unsigned)(i * 2654435761u) ^ (unsigned)((j + 1) * 40503u) ^ (unsigned)((unsigned)l * 69069u);
+    h ^= h >> 15; h *= 2246822519u; h ^= h >> 13; h *= 3266489917u; h ^= h >> 16;
+    X[e] = ((double)(h >> 8) / 16777216.0 - 0.5) / sqrt((double)k / 12.0);
   }
 }
 // Largest residual of the top-r Ritz pairs, relative to the largest Ritz value: max_j ||(G Q) z_j - theta_j x_j|| / theta_max,
 // with ZH = (G Q) Z and X = Q Z given (k x b per matrix, Ritz values ascending).  res[0] collects the maximum over the
 // batch (bit pattern of a non-negative double), res[1] is raised when a factorisation failed or a value is not finite.
+// eps_bw > 0 (Float32 models, round 5): the residual of pair j is measured against what a backward stable Float32 SVD of the slice
+// X itself leaves -- project_rank!.jl:28-41 calls svd() in TF.  With theta = x'Gx the residual rho = G x - theta x is orthogonal to
+// x, and (sigma, u = X x / sigma, x) is an EXACT singular triplet of X + E with E = -u rho' / sigma, ||E||_2 = ||rho|| / sigma_j: the
+// pair is accepted when that is at most eps_bw ||X||_2, i.e. ||rho_j|| <= eps_bw sqrt(theta_max theta_j).  What is stored and compared
+// with tol everywhere (the host's decisions, k_cheb_plan, k_sub_list) is the residual in units of its acceptance level times tol,
+// never asking for more than the strict level tol theta_max; res[6] <- the largest residual / theta_max as before (what a start is
+// judged by).
 __global__ __launch_bounds__(BLOCK) void k_sub_residual(int k, int b, int r, int batch, const double* __restrict__ ZH,
                                                         const double* __restrict__ X, const double* __restrict__ W, int ldw,
                                                         const rocblas_int* __restrict__ info_chol,
                                                         const rocblas_int* __restrict__ info_eig,
                                                         const double* __restrict__ fro2, unsigned long long* res,
-                                                        double* __restrict__ per_matrix = nullptr) {
+                                                        double* __restrict__ per_matrix = nullptr, double eps_bw = 0.0,
+                                                        double tol = 1e-12) {
   __shared__ double sm[BLOCK / 64];
   const int l = blockIdx.x;
   const double tmax = W[(long long)l * ldw + b - 1];
-  double worst = 0;
+  if (fro2[l] == 0.0) {               // a slice of zeros (the first iteration of a solve projects v = 0): nothing to find, nothing to certify
+    if (threadIdx.x == 0 && per_matrix) per_matrix[l] = 0.0;
+    return;
+  }
+  double worst = 0, worst_raw = 0;
   for (int j = b - r; j < b; ++j) {
     const double th = W[(long long)l * ldw + j];
     const double* z = ZH + ((long long)l * b + j) * k;
@@ -466,8 +492,14 @@ __global__ __launch_bounds__(BLOCK) void k_sub_residual(int k, int b, int r, int
     __syncthreads();
     double t = 0;
     for (int w = 0; w < BLOCK / 64; ++w) t += sm[w];
-    const double rel = sqrt(t) / tmax;
+    const double raw = sqrt(t) / tmax;
+    double rel = raw;
+    if (eps_bw > 0.0) {
+      const double lvl = eps_bw * sqrt(tmax * (th > 0.0 ? th : 0.0));
+      if (lvl > tol * tmax) rel = sqrt(t) / lvl * tol;
+    }
     worst = rel > worst ? rel : worst;
+    worst_raw = raw > worst_raw ? raw : worst_raw;
   }
   if (threadIdx.x == 0 && per_matrix) per_matrix[l] = worst;
   if (threadIdx.x == 0) {
@@ -487,6 +519,7 @@ __global__ __launch_bounds__(BLOCK) void k_sub_residual(int k, int b, int r, int
     else {
       if (hidden) atomicOr(res + 1, 16ull);      // 16: not certified (yet): fine while the residual is still above the tolerance
       atomicMax(res, (unsigned long long)__double_as_longlong(worst));
+      atomicMax(res + 6, (unsigned long long)__double_as_longlong(worst_raw));
     }
   }
 }
@@ -504,10 +537,11 @@ __global__ __launch_bounds__(BLOCK) void k_sub_residual(int k, int b, int r, int
 // lies above a is amplified -- an interval 5 % short loses a factor T_m(1.1) (250 at degree 14) of the contraction, one 5 %
 // long about 10.  And never below 0.9 of the (r+1)-th Ritz value: a guard column that had to be re-seeded (k_chol_inv) carries
 // a Rayleigh quotient from the middle of the spectrum, far below the block's true lower end.
+__device__ double g_cheb_floor_factor = 0.9;      // SIPX_RANK_FLOOR (experiments): the interval never ends below this share of the (r+1)-th Ritz value
 __device__ __forceinline__ double cheb_floor(const double* __restrict__ W, int b, int g, int r) {
   const double top = W[b - 1];
   double a = W[g];
-  const double lo = 0.9 * W[b - r - 1];
+  const double lo = g_cheb_floor_factor * W[b - r - 1];
   a = a > lo ? a : lo;
   return a > 1e-14 * top ? a : 1e-14 * top;      // a block deeper than the rank of the matrix: no interval of zero width
 }
@@ -536,6 +570,25 @@ __global__ __launch_bounds__(BLOCK) void k_cheb_step(int k, int b, int g, int r,
     const double a = cheb_floor(Wl, b, g, r);
     const double aj = Wl[j] / CHEB_KAPPA > a ? Wl[j] / CHEB_KAPPA : a;
     out[e] = first ? (2.0 / aj) * Z[e] - Y0[e] : (4.0 / aj) * Z[e] - 2.0 * Y1[e] - Y0[e];
+  }
+}
+// Columns the filter must not touch (round 5): the g lowest ones as before, and EVERY column whose Ritz value lies inside the damped
+// interval [0, a] of its matrix.  The interval never ends below 0.9 of the (r+1)-th Ritz value (cheb_floor), so on a flat spectrum
+// about half of the guard columns lie inside it: their own direction is damped (|T_m| <= 1) while what leaked in from the columns
+// above is amplified 1e4 ... 1e7 times -- the column that comes out depends on the others to 1e-4 ... 1e-7, and what the
+// orthonormalisation leaves of it is amplified rounding error: a direction of garbage with a Rayleigh quotient anywhere in the
+// spectrum.  A dozen of those per call sorted in AMONG the top-r Ritz values (SIPX_EXT_DEBUG=4 showed residuals of 0.1 ... 0.4
+// theta_j at columns 14-16, 32 and 43 of 56 beside 1e-5 at their neighbours) and every one of them had to be filtered back into
+// an eigenvector before the call could end: 25-45 products per call where 12-17 do.  Such columns now stay the Ritz vectors they
+// were: no help, no harm, and their Ritz values remain honest lower bounds (Cauchy interlacing) of the eigenvalues they stand for.
+__global__ __launch_bounds__(BLOCK) void k_cheb_keep(int k, int b, int g, int r, int batch, const double* __restrict__ W,
+                                                     const double* __restrict__ X, double* __restrict__ A) {
+  const long long per = (long long)k * b, total = per * batch;
+  for (long long e = (long long)blockIdx.x * BLOCK + threadIdx.x; e < total; e += (long long)gridDim.x * BLOCK) {
+    const long long l = e / per;
+    const int j = (int)((e - l * per) / k);
+    const double* Wl = W + l * b;
+    if (j < g || !(Wl[j] > cheb_floor(Wl, b, g, r))) A[e] = X[e];
   }
 }
 // The same step with the projection inside, for the common case that only the nl <= 2 largest Ritz vectors are far above
@@ -997,6 +1050,14 @@ struct ExtImpl {
     bool own_cert = true;         // SIPX_RANK_CERT_POTRF=1: the library's factorisation for the certificate
     bool pack = true;             // SIPX_RANK_PACK=0: every filter on the whole batch
     bool cert_check = false;      // SIPX_RANK_CERT_CHECK: both factorisations, compared matrix by matrix (tests)
+    // Round 5.  eps_bw: the acceptance level of a Ritz pair as a backward error on the slice itself, ||E||_2 <= eps_bw ||X||_2
+    // (k_sub_residual) -- the class of the reference's svd() in TF (project_rank!.jl:28-41).  2^-21 = 4 eps(Float32): LAPACK's
+    // sgesdd, the routine behind Julia's svd, leaves 1.4e-7 (median) to 5.9e-7 (largest) by the same measure on a slice of the C4
+    // model (tests/test_svd_class.py::test_float32_svd_backward_error_class).  0 = the strict level tol theta_max of rounds 3-4
+    // (SIPX_RANK_STRICT=1; Float64 models never come here: they keep the one-sided Jacobi SVD).
+    double eps_bw = 4.76837158203125e-07;
+    bool cold = true;             // SIPX_RANK_COLD=0: a call without a usable start decomposes fully (rounds 3-4)
+    bool keep_damped = false;     // SIPX_RANK_KEEP=1 (measured, NOT the default): every column inside the damped interval stays out of the filter
   } knobs;
   double *Xc = nullptr, *Wc = nullptr, *Froc = nullptr;
   double *cert_w = nullptr, *cert_p = nullptr;     // the certificate's blocked Cholesky: inverse diagonal factors, one block row
@@ -1202,6 +1263,14 @@ ExtProj<T>::ExtProj(const ExtSpec& spec, hipStream_t stream) {
         if (const char* e = env("SIPX_RANK_CERT_POTRF")) K_.own_cert = e[0] != '1';
         if (const char* e = env("SIPX_RANK_PACK")) K_.pack = e[0] != '0';
         K_.cert_check = env("SIPX_RANK_CERT_CHECK") != nullptr;
+        if (const char* e = env("SIPX_RANK_STRICT")) { if (e[0] != '0') K_.eps_bw = 0.0; }
+        if (const char* e = env("SIPX_RANK_EPS")) K_.eps_bw = atof(e) >= 0 ? atof(e) : K_.eps_bw;
+        if (const char* e = env("SIPX_RANK_COLD")) K_.cold = e[0] != '0';
+        if (const char* e = env("SIPX_RANK_KEEP")) K_.keep_damped = e[0] != '0';
+        if (const char* e = env("SIPX_RANK_FLOOR")) {
+          const double f = atof(e);
+          if (f > 0 && f < 1) SIPX_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_cheb_floor_factor), &f, sizeof(double)));
+        }
       }
       const char* sub_e = getenv("SIPX_RANK_SUBSPACE");      // read per projector: 0 keeps the full decomposition every call
       const int sub_env = sub_e ? atoi(sub_e) : 1;
@@ -1409,7 +1478,7 @@ static void rank_cert_factor(ExtImpl<T>& I, int k) {
 // Returns false -- the caller then decomposes fully -- when the budget of multiplications cannot suffice, a factorisation
 // fails or the certificate does not hold.
 template <typename T>
-static bool rank_cheb_route(ExtImpl<T>& I, int w, int k, bool& cheap_fail) {
+static bool rank_cheb_route(ExtImpl<T>& I, int w, int k, bool& cheap_fail, bool cold = false) {
   hipStream_t s = I.stream;
   const int b = I.sub_b, r = I.r, batch = I.batch;
   const double one = 1.0, zero = 0.0, mone = -1.0;
@@ -1451,7 +1520,19 @@ static bool rank_cheb_route(ExtImpl<T>& I, int w, int k, bool& cheap_fail) {
   bool ok = false, fresh_start = true, tried_other = false, retried = false;
   int m_lim = m_cap;
   cheap_fail = false;
-  for (int outer = 0; outer < 9; ++outer) {
+  // A start that says nothing about this input -- none at all (the block is pseudo-random: `cold`), or the previous call's vectors
+  // on the second iteration of a solve (first residual above 1e-3 theta_max) -- is RAMPED instead of given up (rounds 3-4 decomposed
+  // fully: 105-185 ms for 512 slices of 512 x 512).  What went wrong with long filters from such a block (DESIGN_HISTORY, round 3):
+  // a direction 1e5 times the rest that the block holds only roughly cannot be projected out of the products, is amplified in every
+  // column and leaves a block of dependent columns; and the Ritz values of a cold block say nothing about where the unwanted part
+  // of the spectrum ends.  So: three steps of degree one (a shifted power step each, no product beyond the Rayleigh-Ritz step's own:
+  // whatever is far above the rest converges by its ratio per step), then degrees 2, 4, 8 -- every Rayleigh-Ritz step moves the
+  // interval ends towards the spectrum's -- then the usual filters.  The stall rule waits until the ramp is over.
+  int ramp = cold ? 0 : -1;                                 // stage of the ramp, -1: none
+  static const int ramp_deg[6] = {1, 1, 1, 2, 4, 8};
+  const int budget_all = budget * 2;
+  int max_outer = cold ? 24 : 9;
+  for (int outer = 0; outer < max_outer; ++outer) {
     // Rayleigh-Ritz on span(A): Cholesky QR (twice behind a filter: its columns lean on each other), H = Q'GQ, X = Q S
     SIPX_HIP(hipMemsetAsync(I.info, 0, sizeof(rocblas_int) * 2 * batch, s));
     for (int pass = 0; pass < (m_prev > 0 ? 2 : 1); ++pass) {
@@ -1477,23 +1558,25 @@ static bool rank_cheb_route(ExtImpl<T>& I, int w, int k, bool& cheap_fail) {
     mark(2);
     SIPX_HIP(hipMemsetAsync(I.sub_res, 0, 8 * sizeof(unsigned long long), s));
     SIPX_HIP(hipMemsetAsync(I.sub_res + 2, 0x7f, sizeof(unsigned long long), s));       // a large positive double: the minimum starts there
-    hipLaunchKernelGGL(k_sub_residual, dim3(nb), dim3(BLOCK), 0, s, k, b, r, nb, F2, X, Ws, b, I.info, I.info + batch, Fro, I.sub_res, I.Es);
+    hipLaunchKernelGGL(k_sub_residual, dim3(nb), dim3(BLOCK), 0, s, k, b, r, nb, F2, X, Ws, b, I.info, I.info + batch, Fro, I.sub_res, I.Es,
+                       KN.eps_bw, tol);
     hipLaunchKernelGGL(k_cheb_plan, dim3((nb + 63) / 64), dim3(64), 0, s, b, g, r, nb, Ws, I.Es, tol, I.sub_res);
     if (may_pack && !packed) hipLaunchKernelGGL(k_sub_list, dim3(1), dim3(256), 0, s, nb, I.Es, tol, I.sub_idx, I.sub_res);
     SIPX_HIP(hipMemcpyAsync(I.sub_res_host, I.sub_res, 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
     SIPX_HIP(hipStreamSynchronize(s));
     mark(4);
-    double res, tmin;
+    double res, tmin, res_raw;
     std::memcpy(&res, &I.sub_res_host[0], sizeof(double));
     std::memcpy(&tmin, &I.sub_res_host[2], sizeof(double));
+    std::memcpy(&res_raw, &I.sub_res_host[6], sizeof(double));
     const bool failed = (I.sub_res_host[1] & 15ull) != 0;
     const bool hidden = packed || (I.sub_res_host[1] & 16ull) != 0;      // (packed: the bit of the converged matrices is no longer seen)
     const int n_open = (int)I.sub_res_host[4];
     const bool pack_now = may_pack && !packed && res > tol && n_open >= 1 && n_open <= I.sub_cap;
     const int nl = (int)I.sub_res_host[(packed || pack_now) ? 3 : 5];
-    if (dbg) fprintf(stderr, "[sipx rank] filtered subspace step %d: %d products, residual %.3e, fail-bits %llu, t_r %.4f, %d vectors far above, "
-                             "%d of %d matrices%s, %.2f ms\n",
-                     outer, mults, res, I.sub_res_host[1], tmin, nl, nb, batch, packed ? " (packed)" : "",
+    if (dbg) fprintf(stderr, "[sipx rank] filtered subspace step %d: %d products, residual %.3e (%.3e of theta_max), fail-bits %llu, t_r %.4f, "
+                             "%d vectors far above, %d of %d matrices%s%s, %.2f ms\n",
+                     outer, mults, res, res_raw, I.sub_res_host[1], tmin, nl, nb, batch, packed ? " (packed)" : "", ramp >= 0 ? " (ramp)" : "",
                      std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_start).count());
     if (dbg >= 3 && own_jacobi) {
       std::vector<rocblas_int> sw(nb);
@@ -1505,14 +1588,27 @@ static bool rank_cheb_route(ExtImpl<T>& I, int w, int k, bool& cheap_fail) {
     if (dbg >= 3) {                                        // how many matrices of the batch still need a filter
       std::vector<double> pm(nb);
       SIPX_HIP(hipMemcpy(pm.data(), I.Es, sizeof(double) * nb, hipMemcpyDeviceToHost));
-      int a12 = 0, a10 = 0, a8 = 0;
-      for (int l = 0; l < nb; ++l) { a12 += pm[l] > 1e-12; a10 += pm[l] > 1e-10; a8 += pm[l] > 1e-8; }
+      int a12 = 0, a10 = 0, a8 = 0, worst_l = 0;
+      for (int l = 0; l < nb; ++l) { a12 += pm[l] > 1e-12; a10 += pm[l] > 1e-10; a8 += pm[l] > 1e-8; if (pm[l] > pm[worst_l]) worst_l = l; }
       fprintf(stderr, "[sipx rank]   matrices above 1e-12: %d, above 1e-10: %d, above 1e-8: %d (of %d)\n", a12, a10, a8, nb);
+      if (dbg >= 4) {                                      // the worst matrix: its Ritz values and the residual of every column, in units of theta_j
+        std::vector<double> ww(b), zz((size_t)k * b), xx((size_t)k * b);
+        SIPX_HIP(hipMemcpy(ww.data(), Ws + (size_t)worst_l * b, sizeof(double) * b, hipMemcpyDeviceToHost));
+        SIPX_HIP(hipMemcpy(zz.data(), F2 + (size_t)worst_l * sX, sizeof(double) * sX, hipMemcpyDeviceToHost));
+        SIPX_HIP(hipMemcpy(xx.data(), X + (size_t)worst_l * sX, sizeof(double) * sX, hipMemcpyDeviceToHost));
+        fprintf(stderr, "[sipx rank]   worst matrix %d (%.3e): column: Ritz value / theta_max, residual / theta_j\n", worst_l, pm[worst_l]);
+        for (int j = b - 1; j >= 0; --j) {
+          double t = 0;
+          for (int i = 0; i < k; ++i) { const double d = zz[(size_t)j * k + i] - ww[j] * xx[(size_t)j * k + i]; t += d * d; }
+          fprintf(stderr, " %d:%.3e/%.2e", b - j, ww[j] / ww[b - 1], std::sqrt(t) / (ww[j] > 0 ? ww[j] : 1.0));
+        }
+        fprintf(stderr, "\n");
+      }
     }
     if (failed) break;
     // The previous call's vectors say little about this input (the first iterations of a solve): filters started from there
     // were observed to swamp the guard columns and then stall at a residual of 1e-8 theta_max -- the full decomposition at once.
-    if (fresh_start && res > 1e-3) {
+    if (fresh_start && ramp < 0 && res_raw > 1e-3) {
       // the feasibility estimate is asked for every tenth iteration only, its own vectors are ten iterations old: those of the
       // y update of this iteration (another input, but the same x behind it) may be the better start
       if (w == 1 && I.sub_have[0] && !tried_other) {
@@ -1521,8 +1617,15 @@ static bool rank_cheb_route(ExtImpl<T>& I, int w, int k, bool& cheap_fail) {
         if (dbg) fprintf(stderr, "[sipx rank] poor start: once more from the vectors of the y update\n");
         continue;
       }
-      cheap_fail = true;              // one Rayleigh-Ritz step spent: nothing the next call should sit out for
-      break;
+      if (KN.cold) {
+        ramp = 0;                     // go on from what the step left, by the ramp
+        max_outer = 24;
+        cold = true;                  // (its budget)
+        if (dbg) fprintf(stderr, "[sipx rank] poor start (%.3e of theta_max): ramped filters\n", res_raw);
+      } else {
+        cheap_fail = true;            // one Rayleigh-Ritz step spent: nothing the next call should sit out for
+        break;
+      }
     }
     fresh_start = false;
     if (res <= tol) {
@@ -1575,6 +1678,7 @@ static bool rank_cheb_route(ExtImpl<T>& I, int w, int k, bool& cheap_fail) {
                        std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_start).count());
       break;
     }
+    if (ramp >= 0) prev = -1;                             // (no verdict on a filter while the intervals are still being found)
     if (prev > 0 && !(res < 0.5 * prev) && !retried) {
       // The filter did not do what its degree promised -- in a long C4 solve (80 iterations) the residual ROSE behind a filter in
       // one call of nine (4.9e-5 -> 1.4e-4 for all 512 slices, 3.6e-8 -> 3.0e-6 for seven): the intervals of a call's first filter
@@ -1623,14 +1727,21 @@ static bool rank_cheb_route(ExtImpl<T>& I, int w, int k, bool& cheap_fail) {
     int m = (int)std::ceil(need / per);
     if (m < 2) m = 2;
     const int m_max = m_lim;
-    if (m > m_max) {                                      // several filters: can the budget still hold them?
+    const bool ramp_filter = ramp >= 0;                   // (a block that is still being found keeps only its g lowest columns: the
+                                                          //  others have to grow into guards first)
+    if (ramp >= 0) {
+      const int md = ramp_deg[ramp];
+      m = ramp < 3 ? md : std::min(std::max(m, 2), md);   // (a block that is nearly there does not need the whole ramp's degrees)
+      if (++ramp >= 6) ramp = -1;
+      if (mults + m + 1 > budget_all) break;
+    } else if (m > m_max) {                               // several filters: can the budget still hold them?
       const double outers = std::ceil(need / (per * m_max));
-      if (mults + outers * (m_max + 1) > budget) {
+      if (mults + outers * (m_max + 1) > (cold ? budget_all : budget)) {
         if (dbg) fprintf(stderr, "[sipx rank] filtered subspace: %g more products needed, over the budget\n", outers * (m_max + 1));
         break;
       }
       m = m_max;
-    } else if (mults + m + 1 > budget) break;
+    } else if (mults + m + 1 > (cold ? budget_all : budget)) break;
     // Y_0 = X, Y_1 = (2/a) P G X - X with G X = F2 already there; Y_{i+1} = (4/a) P G Y_i - 2 Y_i - Y_{i-1}.  X stays (the
     // projections need it); products go to F1, the iterates alternate between F2 and A, each new one over the one two steps back
     double *Y0 = X, *Y1 = X;
@@ -1669,7 +1780,9 @@ static bool rank_cheb_route(ExtImpl<T>& I, int w, int k, bool& cheap_fail) {
     if (Y1 != A) std::swap(A, F2);                       // the filtered block is the one to orthonormalise next
     // the g lowest columns sit inside the damped interval: T_m there is anything in [-1, 1], also (nearly) zero, and such a
     // column would be nothing but what leaked in from above -- dependent on the other columns.  They stay what they were.
-    if (g > 0)
+    if (KN.keep_damped && !ramp_filter)
+      hipLaunchKernelGGL(k_cheb_keep, dim3(NB), dim3(BLOCK), 0, s, k, b, g, r, nb, Ws, X, A);
+    else if (g > 0)
       SIPX_HIP(hipMemcpy2DAsync(A, sizeof(double) * (size_t)sX, X, sizeof(double) * (size_t)sX, sizeof(double) * (size_t)k * g, nb,
                                 hipMemcpyDeviceToDevice, s));
   }
@@ -1746,16 +1859,33 @@ void ExtProj<T>::project(T* v, bool feas, double* partials, T* maxpart, T* compa
       bool sub_ok = false;
       const int b = I.sub_b;
       const long long sX = (long long)k * b, sH = (long long)b * b;
-      if (b > 0 && I.cheb && I.sub_have[w]) {
+      if (b > 0 && I.cheb && (I.sub_have[w] || I.knobs.cold)) {
         // the filtered iteration does not need a gap behind the block; an attempt that failed costs its products on top of the
         // full decomposition, so the next attempts wait (1, 2, 4, ... calls)
-        if (I.cheb_skip[w] > 0) {
+        const bool cold = !I.sub_have[w];
+        if (cold) {
+          // No start (round 5): is there anything to project?  The first iteration of a solve from zero hands over v = 0
+          // (rhs = 0, x = 0: PARSDMM.jl:101-107 with y = l = 0) -- rounds 3-4 decomposed 512 zero matrices for 119 ms and kept
+          // their arbitrary eigenvectors as the next start.  P(0) = 0: v stays as it is, the state stays cold.
+          SIPX_HIP(hipMemsetAsync(I.sub_res, 0, 8 * sizeof(unsigned long long), s));
+          hipLaunchKernelGGL(k_sub_fro, dim3(I.batch), dim3(BLOCK), 0, s, k, I.Gd, I.Fro, I.sub_res);
+          SIPX_HIP(hipMemcpyAsync(I.sub_res_host, I.sub_res, 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
+          SIPX_HIP(hipStreamSynchronize(s));
+          if (I.sub_res_host[7] == 0ull) {
+            if (I.knobs.dbg) fprintf(stderr, "[sipx rank] every slice is zero: nothing to project\n");
+            ++I.n_calls; ++I.n_subspace;
+            return;
+          }
+          hipLaunchKernelGGL(k_sub_seed, dim3(NB), dim3(BLOCK), 0, s, k, b, I.batch, I.Xs[w]);
+        }
+        if (I.cheb_skip[w] > 0 && !cold) {
           --I.cheb_skip[w];
         } else {
           // (an attempt given up at its first Rayleigh-Ritz step -- the start said too little about this input, the second
           //  iteration of a solve -- has cost a fiftieth of a decomposition: the next call simply tries again)
           bool cheap_fail = false;
-          sub_ok = rank_cheb_route<T>(I, w, k, cheap_fail);
+          sub_ok = rank_cheb_route<T>(I, w, k, cheap_fail, cold);
+          if (sub_ok) I.sub_have[w] = true;
           if (sub_ok) I.cheb_fails[w] = 0;
           // (the decomposition that follows a failure leaves exact vectors behind, the best start there is: the next call tries
           //  again; only a second failure in a row makes calls sit out -- 1, 2, 4 ...)
@@ -1955,6 +2085,20 @@ void ExtProj<T>::set_stream(hipStream_t s) {
   if (I.have_plan) fft_check(hipfftSetStream(I.plan, s), "set stream");
   if (I.plan_r2c) fft_check(hipfftSetStream(I.plan_r2c, s), "set stream");
   if (I.plan_c2r) fft_check(hipfftSetStream(I.plan_c2r, s), "set stream");
+}
+
+// Back to the state of a freshly built projector (sipx_reset): no warm start of any kind, no pending status, counters at zero.
+// A reused context then walks through exactly the calls of a new one -- same bits -- without its allocations, plans and handles.
+template <typename T>
+void ExtProj<T>::reset() {
+  if (!impl_) return;
+  ExtImpl<T>& I = *impl_;
+  if (I.fail_pending) { I.fail_pending = false; (void)hipEventSynchronize(I.fail_ev); }
+  if (I.ps) K<T>::ps_init(I.stream, I.ps, I.cidx);
+  if (I.psf) K<T>::ps_init(I.stream, I.psf, I.cidx);
+  for (int w = 0; w < 2; ++w) { I.sub_have[w] = I.sub_try[w] = false; I.cheb_skip[w] = I.cheb_fails[w] = 0; }
+  I.n_calls = I.n_subspace = I.n_full = I.n_products = 0;
+  I.n_packed = 0;
 }
 
 template <typename T>

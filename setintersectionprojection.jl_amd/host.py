@@ -34,7 +34,7 @@ EXPORTED_SYMBOLS = [
     "sipx_stream",
     "sipx_dev_rhs", "sipx_dev_x", "sipx_set_owned", "sipx_get_rhs", "sipx_prox_l2s",
     "sipx_rccl_unique_id", "sipx_set_comm_rccl", "sipx_set_comm", "sipx_slab", "sipx_warm_start_from", "sipx_set_decomp",
-    "sipx_kernel_stats_json", "sipx_comm_info", "sipx_device_bytes",
+    "sipx_kernel_stats_json", "sipx_comm_info", "sipx_device_bytes", "sipx_reset",
 ]
 
 SIPX_F32, SIPX_F64 = 0, 1
@@ -693,6 +693,39 @@ class Context:
             self.rows.append(self.N)
         return feas[:npp]
 
+    def reset(self, m, rho_ini, gamma_ini, zero_ini_guess=True, x0=None, l0=None, y0=None):
+        """The same sets on the same grid, once more (sipx_reset): a new model m -- and, optionally, a new warm start and rho_ini --
+        on this finalised context, without any allocation.  Returns the initial feasibilities.  A solve that follows gives the
+        bits a newly built context gives."""
+        m = np.ascontiguousarray(m, self.TF)
+        if m.shape != (self.N,):
+            raise SipxError("length of m does not match the grid")
+        rho = np.ascontiguousarray(rho_ini, np.float64)
+        npp = self.pp
+        feas = np.zeros(max(npp, 1))
+        keep = []
+
+        def arr_list(lst):
+            if lst is None or len(lst) == 0:
+                return None
+            if len(lst) != len(self.rows):
+                raise SipxError("warm start: l and y need one vector per term (sets plus the distance term)")
+            ptrs = (C.c_void_p * len(lst))()
+            for i, a in enumerate(lst):
+                a = np.ascontiguousarray(a, self.TF)
+                if a.shape != (self.rows[i],):
+                    raise SipxError(f"warm start: vector {i} has {a.shape} entries, operator {i} has {self.rows[i]} rows")
+                keep.append(a)
+                ptrs[i] = a.ctypes.data
+            return ptrs
+        x0a = None if x0 is None else np.ascontiguousarray(x0, self.TF)
+        if x0a is not None and x0a.shape != (self.Nx,):
+            raise SipxError("length of x does not match the grid")
+        _chk(lib().sipx_reset(self.h, _ptr(m), rho.ctypes.data_as(C.c_void_p), len(rho), C.c_double(gamma_ini),
+                              int(zero_ini_guess), _ptr(x0a), arr_list(l0), arr_list(y0), feas.ctypes.data_as(C.c_void_p)))
+        self.feasibility_initial = feas[:npp]
+        return self.feasibility_initial
+
     # ---- phases ----
     def rhs_compose(self, rho):
         rho = np.ascontiguousarray(rho, np.float64)
@@ -726,8 +759,14 @@ class Context:
         a = np.ascontiguousarray(rho_new, np.float64); b = np.ascontiguousarray(rho_old, np.float64)
         _chk(lib().sipx_q_update(self.h, a.ctypes.data_as(C.c_void_p), b.ctypes.data_as(C.c_void_p)))
 
-    def download(self, want_ly=True):
-        x = np.empty(self.Nx, self.TF)
+    def download(self, want_ly=True, x_out=None):
+        # the reference overwrites the x argument in place (cg.jl:95, PARSDMM.jl:64): a caller's array of the right kind is the
+        # destination itself -- its pages exist already, a fresh array pays a page fault per 4 KiB of the copy
+        if (x_out is not None and isinstance(x_out, np.ndarray) and x_out.dtype == self.TF and x_out.shape == (self.Nx,)
+                and x_out.flags.c_contiguous and x_out.flags.writeable):
+            x = x_out
+        else:
+            x = np.empty(self.Nx, self.TF)
         l = [np.zeros(r, self.TF) for r in self.rows] if want_ly else None
         y = [np.zeros(r, self.TF) for r in self.rows] if want_ly else None
 
@@ -886,19 +925,89 @@ def build_context(m, AtA, TD_OP, set_Prop, P_sub, comp_grid, options, x=None, l=
     return ctx
 
 
-def PARSDMM(m, AtA, TD_OP, set_Prop, P_sub, comp_grid, options, x=None, l=None, y=None, device=None):
-    """Drop-in for src/PARSDMM.jl:25-258 (serial path): returns (x, log_PARSDMM, l, y)."""
+# Contexts kept between calls of PARSDMM (round 5).  The reference's callers wrap PARSDMM as a projector and call it again and again
+# with the same sets on the same grid (examples/constrained_freq_FWI_simple.jl:468, examples/Constraint_examples_2D.jl:222-223,
+# examples/Dykstra_parallel_vs_PARSDMM.jl:134); every such call of the reference allocates its 16 work vectors per set again
+# (src/PARSDMM_initialize.jl:129-184).  Here a call looks its context up by (device, precision, grid, Q mode, set descriptors): a
+# hit costs sipx_reset -- zero-fills, the upload of m, Q assembled again, the initial feasibility -- instead of sipx_create ...
+# sipx_finalize.  Only descriptors without array arguments are cached (scalar bounds, radii, ranks ...: what their bytes are is what
+# they are); a list with bound vectors, a subspace basis, a caller-supplied operator or explicit A'A bands builds a context per call
+# as before.  SIPX_CONTEXT_CACHE=0 switches the cache off, SIPX_CONTEXT_CACHE=k keeps k contexts (default 2: each holds the whole
+# device state of its problem); clear_context_cache() frees them.
+_ctx_cache: "dict" = {}
+
+
+def clear_context_cache():
+    for ctx in list(_ctx_cache.values()):
+        ctx.close()
+    _ctx_cache.clear()
+
+
+def _cache_limit() -> int:
+    e = os.environ.get("SIPX_CONTEXT_CACHE")
+    if e is None or e == "":
+        return 2
+    try:
+        return max(0, int(e))
+    except ValueError:
+        return 2
+
+
+def _context_key(m, AtA, TD_OP, set_Prop, P_sub, comp_grid, options, device):
+    """None when this problem must not be cached (array arguments inside a descriptor, explicit A'A bands, sharded set ownership)."""
+    n, h = _grid(comp_grid)
+    sig = []
+    for i, P in enumerate(P_sub):
+        if not isinstance(P, Projector) or P.lb is not None or P.ub is not None or P.basis is not None:
+            return None
+        op = TD_OP[i]
+        if not isinstance(op, TDOperator) or op.kind == "custom" or (AtA is not None and AtA[i] is not None):
+            return None
+        sig.append((op.kind, int(getattr(op, "component", 0)), P.kind, P.pmin, P.pmax, P.mode, P.dir, P.transform, bool(set_Prop.ncvx[i])))
+    dev = _default_device if device is None else device
+    # (the engine reads its A/B switches when a context is built: a context built under other switches is another context)
+    env = tuple(sorted((k, v) for k, v in os.environ.items() if k.startswith("SIPX_")))
+    return (dev, np.dtype(m.dtype).str, tuple(n), tuple(h), bool(options.feasibility_only), getattr(options, "Q_mode", "cds"), tuple(sig), env)
+
+
+def PARSDMM(m, AtA, TD_OP, set_Prop, P_sub, comp_grid, options, x=None, l=None, y=None, device=None, outputs="all"):
+    """Drop-in for src/PARSDMM.jl:25-258 (serial path): returns (x, log_PARSDMM, l, y).
+    outputs="x": l and y are not copied back (returned as None) -- a caller that uses PARSDMM as a projector reads x only
+    (examples/constrained_freq_FWI_simple.jl:468 keeps `[1]` of the result)."""
     import time
     t0 = time.perf_counter()
-    ctx = build_context(m, AtA, TD_OP, set_Prop, P_sub, comp_grid, options, x, l, y, device)
-    t_init = time.perf_counter() - t0
+    if outputs not in ("all", "x"):
+        raise SipxError("outputs must be 'all' or 'x'")
+    if not (np.isrealobj(m) and (x is None or np.isrealobj(x))):
+        raise SipxError("input for PARSDMM is not real")                 # src/PARSDMM.jl:50-52
+    limit = _cache_limit()
+    key = _context_key(m, AtA, TD_OP, set_Prop, P_sub, comp_grid, options, device) if limit > 0 else None
+    ctx = _ctx_cache.pop(key, None) if key is not None else None
+    reused = ctx is not None
     try:
+        if reused:
+            TF = np.dtype(m.dtype).type
+            zero = bool(options.zero_ini_guess)
+            rho_ini = [float(TF(r)) for r in options.rho_ini]
+            ctx.reset(m, rho_ini, float(TF(options.gamma_ini)), zero, None if zero else x, None if zero else l, None if zero else y)
+        else:
+            ctx = build_context(m, AtA, TD_OP, set_Prop, P_sub, comp_grid, options, x, l, y, device)
+        t_init = time.perf_counter() - t0
         log, _ = ctx.parsdmm(options)
         log.timing[TIMING_SECTIONS[0]] = t_init          # "initialization": PARSDMM_initialize (src/PARSDMM.jl:40)
-        xo, lo, yo = ctx.download()
-    finally:
+        xo, lo, yo = ctx.download(want_ly=(outputs == "all"), x_out=x)
+    except Exception:
+        if ctx is not None:
+            ctx.close()
+        raise
+    if key is not None:
+        while len(_ctx_cache) >= limit:                 # the oldest entry goes (dicts keep insertion order)
+            _ctx_cache.pop(next(iter(_ctx_cache))).close()
+        _ctx_cache[key] = ctx
+    else:
         ctx.close()
-    if x is not None and len(x) == len(xo):
+    log.context_reused = reused
+    if x is not None and xo is not x and len(x) == len(xo):
         x[:] = xo                         # the reference overwrites the x argument in place
         xo = x
     return xo, log, lo, yo
