@@ -161,6 +161,44 @@ def run_c5(sipx, n, h=(25.0, 25.0, 25.0), TF=np.float64, maxit=100, model="surve
     return out
 
 
+def whole_call(sipx, config, TF, calls=3):
+    """PARSDMM(m, AtA, TD_OP, set_Prop, P_sub, comp_grid, options) -> (x, log, l, y) as a caller sees it: wall clock of the first call
+    (context built: sipx_create ... sipx_finalize), of a second call with another model of the same kind (context reset: sipx_reset,
+    everything returned) and of a third that asks for x only, into the caller's own array (what a projector inside an outer loop
+    does: examples/constrained_freq_FWI_simple.jl:468).  Default options: maxit 200, the stop rules decide."""
+    n, h, kinds = CONFIGS[config]
+    gs = sipx.compgrid(h, n)
+    ms = [synthetic_model(n, TF, 20240601 + 3 + k) for k in range(calls)]
+
+    def radius_of(opname):
+        s = sipx.get_TD_operator(gs, opname, TF)[0] @ ms[0]
+        return float(0.5 * np.abs(s.astype(np.float64)).sum())
+    g, c = build_problem(sipx, n, h, kinds, ms[0], TF, radius_of)
+    P, A, prop = sipx.setup_constraints(c, g, TF)
+    opt = sipx.PARSDMM_options(FL=TF)
+    A, AtA, _, _ = sipx.PARSDMM_precompute_distribute(A, prop, g, opt)
+    sipx.clear_context_cache()
+    xbuf = np.zeros_like(ms[0])
+    rows = []
+    for k in range(calls):
+        kw = dict(x=xbuf, outputs="x") if k == 2 else {}
+        t0 = time.perf_counter()
+        x, log, l, y = sipx.PARSDMM(ms[k], AtA, A, prop, P, g, opt, **kw)
+        dt = time.perf_counter() - t0
+        solve = float(sum(v for kk, v in log.timing.items() if kk != "initialization"))
+        rows.append({"call": k + 1, "whole_call_s": dt, "initialization_s": float(log.timing["initialization"]), "solve_s": solve,
+                     "download_and_rest_s": dt - solve - float(log.timing["initialization"]), "iterations": int(len(log.obj)),
+                     "context_reused": bool(getattr(log, "context_reused", False)), "outputs": "x" if k == 2 else "x, l, y",
+                     "finite": bool(np.isfinite(x).all())})
+        del x, l, y
+    sipx.clear_context_cache()
+    return {"workload": f"{config}: whole calls of PARSDMM(...), default options (stop rules active)", "calls": rows,
+            "first_call_s": rows[0]["whole_call_s"], "second_call_s": rows[1]["whole_call_s"],
+            "second_call_overhead": (rows[1]["whole_call_s"] - rows[1]["solve_s"]) / rows[1]["solve_s"],
+            "x_only_call_s": rows[2]["whole_call_s"] if len(rows) > 2 else None,
+            "x_only_call_overhead": ((rows[2]["whole_call_s"] - rows[2]["solve_s"]) / rows[2]["solve_s"]) if len(rows) > 2 else None}
+
+
 _LIB_SHA = None
 
 
@@ -239,7 +277,7 @@ def headline(out, detail_path=None):
     ROOF = ("kernel", "bound", "peak", "achieved", "unit", "frac", "frac_survey", "traffic", "frac_traffic", "launches", "avg_launch_ms",
             "algorithmic_bytes_per_launch")
     DOM = ("kernel", "bound", "frac", "launches", "avg_launch_ms", "algorithmic_bytes_per_launch", "share_of_kernel_time")
-    COMM = ("rccl_nranks", "rccl_version", "decomposition", "ranks_agree_on_x", "device_bytes_per_rank")
+    COMM = ("rccl_nranks", "rccl_version", "decomposition", "ranks_agree_on_x", "device_bytes_per_rank", "sparse_arrays", "comm_mode", "fell_back_from")
     h = _pick(out, ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
                     "dtype", "data"))
     h["config"] = _pick(out.get("config"), ("workload", "grid", "parallelism", "cg_iterations_in_timed_steps", "all_logs_finite"))
@@ -277,6 +315,13 @@ def headline(out, detail_path=None):
         if out.get("n_gpus", 1) > 1 and v.get("comm"):
             o["comm"] = _pick(v["comm"], ("decomposition", "ranks_agree_on_x", "device_bytes_per_rank"))
         h[key] = o
+    v = out.get("c2_2048")
+    if isinstance(v, dict):
+        h["c2_2048"] = {"error": str(v["error"])[:160]} if "error" in v else _pick(v, ("value", "ms_per_step"))
+    v = out.get("whole_call")
+    if isinstance(v, dict):
+        h["whole_call"] = ({"error": str(v["error"])[:160]} if "error" in v else
+                           _pick(v, ("first_call_s", "second_call_s", "second_call_overhead", "x_only_call_s", "x_only_call_overhead")))
     for key in ("c5", "c5_layered"):
         v = out.get(key)
         if isinstance(v, dict):
@@ -292,14 +337,17 @@ def headline(out, detail_path=None):
         h["faster_decomposition"] = out.get("faster_decomposition")
     if isinstance(out.get("comm_probe_us"), dict):        # medians only, short keys (the descriptions are in the detail file)
         h["comm_probe_us"] = {k.split(" ")[0]: v for k, v in out["comm_probe_us"].items() if isinstance(v, (int, float))}
-    for k in ("dry_comm", "invalid_as_measurement", "libsipx_sha16"):
+    if out.get("headline_attempts") and any(not a.get("ok") for a in out["headline_attempts"]):
+        h["headline_attempts"] = [{"attempt": a["attempt"][:48], "ok": a["ok"], **({"error": a["error"][:100]} if a.get("error") else {})}
+                                  for a in out["headline_attempts"]]
+    for k in ("dry_comm", "invalid_as_measurement", "libsipx_sha16", "error"):
         if k in out:
             h[k] = out[k]
     if detail_path:
         h["detail"] = os.path.basename(detail_path)
     line = json.dumps(_sig(h), separators=(",", ":"))
     if len(line) >= LINE_LIMIT:                           # never again a line the driver cannot parse: shed the optional objects
-        for k in ("comm_probe_us", "c5_layered", "iteration_roofline", "decompositions", "c4_512", "c5", "c3_512", "dominant_kernel"):
+        for k in ("comm_probe_us", "c5_layered", "whole_call", "iteration_roofline", "c2_2048", "decompositions", "c4_512", "c5", "c3_512", "dominant_kernel"):
             h.pop(k, None)
             line = json.dumps(_sig(h), separators=(",", ":"))
             if len(line) < LINE_LIMIT:
@@ -373,6 +421,12 @@ class _Watchdog:
 
         def fire():
             print(f"bench watchdog: no bench line after {seconds:.0f} s; last mark: {_PROGRESS['last']}", file=sys.stderr, flush=True)
+            cb = _PROGRESS.get("on_deadline")
+            if cb is not None:                     # rank 0: a parseable line with what there is (the headline and the legs done so far,
+                try:                               # or value 0 and the mark the run stopped at) -- never an empty stdout
+                    cb(f"deadline of {seconds:.0f} s passed; last mark: {_PROGRESS['last']}")
+                except Exception as e:             # pragma: no cover
+                    print(f"bench watchdog: could not print a line: {e!r}", file=sys.stderr, flush=True)
             os._exit(3)
         if seconds and seconds > 0:
             self.timer = threading.Timer(seconds, fire)
@@ -679,6 +733,8 @@ def main():
     ap.add_argument("--no-c4", action="store_true", help="skip the short leg on BASELINE config 4 (512^3, eight sets) that follows the default run")
     ap.add_argument("--no-kernel-table", action="store_true",
                     help="skip the all-kernel statistics window that follows the timed steps (profiling runs: its event records would show up as gaps)")
+    ap.add_argument("--no-c2", action="store_true", help="skip the leg on BASELINE config 2 (2048^2, {bounds, l1:TV})")
+    ap.add_argument("--no-whole-call", action="store_true", help="skip the whole-call leg (first and later calls of PARSDMM(...) with default options)")
     ap.add_argument("--no-c5", action="store_true", help="skip the leg on BASELINE config 5 (PARSDMM_multi_level, 512^3 Float64, 3 levels) that follows the default run")
     ap.add_argument("--dtype", default="f32", choices=["f32", "f64"],
                     help="f32 = the contract workload; f64 = the same sets in Float64 (BASELINE config 5 computes in Float64)")
@@ -754,9 +810,11 @@ def main():
             os.close(saved_stdout)
             saved_stdout = None
 
-    def measure(config, steps, warmup, decomp=None):
+    def measure(config, steps, warmup, decomp=None, comm_mode=None, slab_full=False, mid_hook=None):
         """One workload: builds the context, runs `warmup` untimed and `steps` timed PARSDMM iterations of the native loop
-        (sipx_parsdmm_begin / _steps; sharded: the same loop with the engine's collectives inside), returns the numbers."""
+        (sipx_parsdmm_begin / _steps; sharded: the same loop with the engine's collectives inside), returns the numbers.
+        comm_mode: "rccl" (native, inside the engine) or "torch" (torch.distributed collectives as callbacks); slab_full: whole
+        arrays on every rank of a slab-decomposed context instead of the rank's planes (the headline's fallbacks)."""
         n, h, kinds = CONFIGS[config]
         N = int(np.prod(n))
         m = synthetic_model(n, TF, 20240601 + 3)
@@ -783,14 +841,16 @@ def main():
             raise SystemExit(f"--decomp slab: the sets of {config} cannot be decomposed by slab")
         if dist is not None:
             def attach(cx):
-                keep.append(sharded.attach_comm(cx, dist, torch.device("cuda", local_rank)))
+                keep.append(sharded.attach_comm(cx, dist, torch.device("cuda", local_rank), mode=comm_mode))
                 if slab:
-                    cx.set_decomp("slab")
+                    cx.set_decomp("slab_full" if slab_full else "slab")
         ctx = sipx.host.build_context(m, AtA, A, prop, P, g, opt, device=local_rank, owned=owned, attach=attach)
         ctx.parsdmm_begin(opt)
         logs = ctx._run[2]
         for _ in range(warmup):
             ctx.parsdmm_steps(1)
+        if mid_hook is not None:
+            mid_hook()
         restore_stdout()
         ctx.kernel_stats(True)
         if world > 1:
@@ -839,6 +899,10 @@ def main():
                                    "all-kernel statistics window / wall time of that window (the event records of the window cost "
                                    "a few percent) / peak: the bandwidth the iteration as BUILT sustains"}
         comm_info = ctx.comm_info()
+        try:
+            counters = ctx.kernel_stats_all(-1)
+        except Exception:
+            counters = {}
         try:
             dev_bytes = ctx.device_bytes()
         except AttributeError:                               # (an older build of the library under SIPX_LIBRARY: A/B runs)
@@ -932,6 +996,10 @@ def main():
                      "decomposition": comm_info["decomposition"] if dist is not None else None,
                      "slab_searches": searches if (dist is not None and slab) else None,
                      "ranks_agree_on_x": agree,
+                     # the rank's planes only (hipMemMap-backed sparse arrays) or whole arrays; the verdict of sipx_finalize's
+                     # communicator self-test; which communicator carried the collectives
+                     "sparse_arrays": counters.get("sparse_arrays"), "comm_selftest": counters.get("comm_selftest"),
+                     "comm_mode": (comm_mode or os.environ.get("SIPX_COMM") or ("rccl" if dist.get_backend() == "nccl" else "torch")) if dist is not None else None,
                      # what this context allocated on its GPU (slab-decomposed: the rank's planes + halo planes only)
                      "device_bytes_per_rank": dev_bytes["context"], "device_used_bytes": dev_bytes["device_used"]},
             "dominant_kernel": dominant, "kernels": table,
@@ -1073,9 +1141,132 @@ def main():
             if timer is not None:
                 timer.cancel()
 
-    progress(f"headline {args.config}: {args.warmup} warm-up + {args.steps} timed steps")
-    r = measure(args.config, args.steps, args.warmup)
+    # ---- the headline (round 5): it cannot come back empty either -------------------------------------------------------------
+    # One rank: one attempt, an error is the run's error.  More ranks: a chain of attempts, each safer than the one before --
+    #   1. the decomposition asked for (auto: z-slabs, the rank's planes only in hipMemMap-backed arrays), RCCL inside the engine;
+    #   2. the same with whole arrays on every rank (SIPX_DECOMP_SLAB_FULL: no mapped memory anywhere near RCCL);
+    #   3. the same through torch.distributed's collectives as callbacks (another implementation of every operation: RcclComm's
+    #      in-place offsets and grouped calls have never run on more than one GPU here);
+    #   4. the reference's own split by constraint set, callbacks.
+    # Before an attempt the ranks tell each other through the process group's store that they are ready (a rank whose set-up
+    # failed says so and EVERY rank moves on to the next attempt: no collective has been entered yet); sipx_finalize makes a
+    # rank-local allocation failure an error on every rank (engine.cpp); after an attempt every rank posts its outcome and waits
+    # for the others -- all fine: done; an error somewhere: next attempt; a rank that never answers (it sits in a collective the
+    # failed rank left): the line is printed with what there is.  `headline_attempts` and `comm.fell_back_from` say what happened.
     n, h, kinds = CONFIGS[args.config]
+    attempts_log = []
+    hl_deadline = float(os.environ.get("SIPX_BENCH_HEADLINE_DEADLINE", "0") or 0) or 240.0
+
+    def post_and_wait(key, mine, timeout_s):
+        """every rank posts `mine` under key/<rank>; returns {rank: text} of the ranks that answered within timeout_s"""
+        import datetime
+        got = {}
+        if store is None:
+            return {rank: mine}
+        try:
+            store.set(f"{key}/{rank}", mine)
+        except Exception:
+            return {rank: mine}
+        t_end = time.time() + timeout_s
+        for rr in range(world):
+            try:
+                store.wait([f"{key}/{rr}"], datetime.timedelta(seconds=max(0.5, t_end - time.time())))
+                got[rr] = store.get(f"{key}/{rr}").decode()
+            except Exception:
+                pass
+        return got
+
+    def headline_attempt(k, label, kw):
+        hook = os.environ.get("SIPX_BENCH_FAIL_LEG", "")
+        err = None
+        try:
+            if hook == f"headline:{rank}" and k == 0:                      # tests: this rank's set-up of the first attempt fails
+                raise RuntimeError("test hook: this rank fails the headline's first attempt")
+        except Exception as e:
+            err = repr(e)
+        ready = post_and_wait(f"sipx_bench/headline/{k}/ready", "ok" if err is None else "fail: " + err[:300], agree_s)
+        bad = {rr: v for rr, v in ready.items() if v != "ok"}
+        if len(ready) < world or bad:
+            why = ("; ".join(f"rank {rr}: {v}" for rr, v in sorted(bad.items())) or
+                   f"ranks {sorted(set(range(world)) - set(ready))} did not report ready within {agree_s:.0f} s")
+            return None, why
+
+        def mid():
+            if hook == f"headline-mid:{rank}" and k == 0:                  # tests: this rank fails inside the first attempt
+                raise RuntimeError("test hook: this rank fails in the middle of the headline's first attempt")
+        res, err = None, None
+        try:
+            res = measure(args.config, args.steps, args.warmup, mid_hook=mid, **kw)
+        except BaseException as e:                                         # (SystemExit of --decomp slab on an unsuitable list included)
+            if isinstance(e, KeyboardInterrupt):
+                raise
+            import gc
+            err = repr(e)
+            progress(f"headline attempt {k} ({label}) failed on this rank: {err[:300]}")
+            gc.collect()
+        done = post_and_wait(f"sipx_bench/headline/{k}/done", "ok" if err is None else "fail: " + err[:300], hl_deadline)
+        bad = {rr: v for rr, v in done.items() if v != "ok"}
+        if len(done) == world and not bad:
+            return res, None
+        why = "; ".join(f"rank {rr}: {v}" for rr, v in sorted(bad.items()))
+        if len(done) < world:
+            why += f"{'; ' if why else ''}ranks {sorted(set(range(world)) - set(done))} did not finish the attempt within {hl_deadline:.0f} s"
+        return None, why
+
+    def on_deadline(why):
+        if rank != 0:
+            return
+        o = partial["out"] or {"metric": "PARSDMM iterations/sec", "value": 0.0, "unit": "it/s", "n_gpus": world, "steps": args.steps,
+                               "warmup": args.warmup, "ms_per_step": None, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+                               "dtype": args.dtype, "data": "synthetic", "config": {"workload": f"{args.config}: the headline did not finish"},
+                               "roofline": None, "libsipx_sha16": lib_sha16()}
+        o["error"] = str(why)[:300]
+        if attempts_log:
+            o["headline_attempts"] = attempts_log
+        try:
+            if saved_stdout is not None:
+                os.dup2(saved_stdout, 1)
+        except OSError:
+            pass
+        emit(o, args.detail)
+    _PROGRESS["on_deadline"] = on_deadline
+
+    progress(f"headline {args.config}: {args.warmup} warm-up + {args.steps} timed steps")
+    r = None
+    if dist is None or (world == 1 and not os.environ.get("SIPX_BENCH_HEADLINE_CHAIN")):
+        r = measure(args.config, args.steps, args.warmup)
+    else:
+        native = None if share_gpu else "rccl"                              # (the rehearsal on one GPU runs on callbacks throughout)
+        chain = []
+        if args.decomp in ("auto", "slab"):
+            chain.append(("slab, sparse arrays, " + ("callbacks" if share_gpu else "RCCL in the engine"), dict(decomp=args.decomp, comm_mode=native)))
+            chain.append(("slab, full arrays, " + ("callbacks" if share_gpu else "RCCL in the engine"), dict(decomp=args.decomp, comm_mode=native, slab_full=True)))
+            if not share_gpu:
+                chain.append(("slab, full arrays, torch.distributed callbacks", dict(decomp=args.decomp, comm_mode="torch", slab_full=True)))
+        else:
+            chain.append(("sets, " + ("callbacks" if share_gpu else "RCCL in the engine"), dict(decomp="sets", comm_mode=native)))
+        chain.append(("sets, torch.distributed callbacks", dict(decomp="sets", comm_mode="torch")))
+        for k, (label, kw) in enumerate(chain):
+            progress(f"headline attempt {k}: {label}")
+            r, why = headline_attempt(k, label, kw)
+            attempts_log.append({"attempt": label, "ok": r is not None, **({} if r is not None else {"error": (why or "")[:400]})})
+            if r is not None:
+                break
+            unanswered = why and "did not" in why
+            if unanswered:                                                  # some rank is beyond reach: no further collective can end
+                break
+        if r is None:
+            restore_stdout()
+            if rank == 0:
+                emit({"metric": "PARSDMM iterations/sec", "value": 0.0, "unit": "it/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+                      "ms_per_step": None, "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+                      "config": {"workload": f"{args.config}: no attempt of the headline finished on every rank"}, "roofline": None,
+                      "headline_attempts": attempts_log, "error": "every attempt of the headline failed", "libsipx_sha16": lib_sha16()}, args.detail)
+            progress("headline: every attempt failed")
+            WATCHDOG.cancel()
+            os._exit(0 if rank != 0 else 4)
+        if len(attempts_log) > 1:
+            r["comm"]["fell_back_from"] = [a["attempt"] for a in attempts_log[:-1]]
     out = {
         "metric": "PARSDMM iterations/sec", "value": r["value"], "unit": "it/s", "n_gpus": world,
         "steps": args.steps, "warmup": args.warmup, "ms_per_step": r["ms_per_step"],
@@ -1084,6 +1275,8 @@ def main():
         "iteration_roofline": r["iteration_roofline"], "timing_ms_per_iteration": r["timing_ms_per_iteration"],
         "comm": r["comm"], "decomposition": r["decomposition"], "libsipx_sha16": lib_sha16(),
     }
+    if attempts_log:
+        out["headline_attempts"] = attempts_log
     if r.get("rank_route"):
         out["rank_route"] = r["rank_route"]
     if r.get("batched_searches"):
@@ -1094,18 +1287,24 @@ def main():
     partial["out"] = out
     both = None
     if (world > 1 or force_dist) and args.decomp == "auto" and r.get("decomposition") == "slab":
+        # (the set-sharded run keeps the communicator the headline ended up with)
+        sets_mode = (r["comm"].get("comm_mode") if r["comm"].get("fell_back_from") else None)
         # Which of the two decompositions is faster on a given node depends on RCCL's small-message latency (slab: small
         # collectives only) against its bandwidth (sets: two N-vector exchanges).  Both are timed for the same K steps and
         # reported under fixed keys; the headline `value` is ALWAYS the slab decomposition -- the one DESIGN 5 chooses for this
         # set list -- so that it means the same thing from run to run and from node to node.
         progress("headline workload again, sharded by constraint set")
-        r2 = safe("sets-decomposed headline", lambda: measure(args.config, args.steps, args.warmup, decomp="sets"))
+        r2 = safe("sets-decomposed headline", lambda: measure(args.config, args.steps, args.warmup, decomp="sets", comm_mode=sets_mode))
         both = {k: (v if "error" in v else
                     {"value": v["value"], "ms_per_step": v["ms_per_step"], "parallelism": v["config"]["parallelism"], "comm": v["comm"],
                      "timing_ms_per_iteration": v["timing_ms_per_iteration"]}) for k, v in (("slab", r), ("sets", r2))}
     if both is not None:
         out["decompositions"] = both
         out["faster_decomposition"] = max(both, key=lambda k: both[k].get("value", 0.0))
+    elif dist is not None and r.get("decomposition"):
+        # (a headline that ended up set-sharded, or --decomp sets / slab: the one decomposition that ran, under the same key)
+        out["decompositions"] = {r["decomposition"]: {"value": r["value"], "ms_per_step": r["ms_per_step"], "comm": r["comm"],
+                                                      "parallelism": r["config"]["parallelism"], "timing_ms_per_iteration": r["timing_ms_per_iteration"]}}
     if args.config == "c3" and args.dtype == "f32" and not args.no_512:
         # the honest HBM point (Q = 3.5 GiB, nothing fits the 256 MiB Infinity Cache): a short run of the same sets at 512^3
         progress("c3_512 leg")
@@ -1130,9 +1329,19 @@ def main():
     if dist is not None and (world > 1 or force_dist):
         progress("comm probe")
         out["comm_probe_us"] = safe("comm probe", lambda: comm_probe(dist, torch, world, rank, dev=torch.device("cpu") if share_gpu else None))
+    if args.config == "c3" and args.dtype == "f32" and args.q_mode == "cds" and world == 1 and dist is None and not args.no_c2:
+        # BASELINE configs[1]: 2048^2 Float32, {bounds, l1:TV} -- launch bound, Infinity-Cache resident (Q = 80 MiB): it/s only
+        progress("c2_2048 leg")
+        out["c2_2048"] = safe("c2_2048", lambda: leg(measure("c2", 20, 5), 20, 5, full=False))
+    if args.config == "c3" and args.dtype == "f32" and args.q_mode == "cds" and world == 1 and dist is None and not args.no_whole_call:
+        # the reference's own measurement is one wall clock around the call (examples/test_scaling_3D.jl:116-117: `@timed PARSDMM(...)`
+        # after a first call): PARSDMM(m, AtA, TD_OP, set_Prop, P_sub, comp_grid, options) with default options, stop rules active,
+        # first call (the context is built) and the calls after it (the context is reset: sipx_reset)
+        progress("whole-call leg")
+        out["whole_call"] = safe("whole_call", lambda: whole_call(sipx, args.config, TF))
     if rank == 0 and world == 1 and not args.no_cpu_baseline and args.dtype == "f32":
         progress("cpu baseline")
-        out["cpu_baseline"] = cpu_baseline(args.config, n, h, kinds)
+        out["cpu_baseline"] = safe("cpu_baseline", lambda: cpu_baseline(args.config, n, h, kinds))
     restore_stdout()
     if rank == 0:
         emit(out, args.detail)

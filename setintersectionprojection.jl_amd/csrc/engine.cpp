@@ -385,7 +385,7 @@ class Engine : public EngineBase {
     for (auto& s : sets_) free_set(s);
     for (void* p : {(void*)xr_base_[0], (void*)xr_base_[1], (void*)xr_base_[2], (void*)w_base_, (void*)rhs_, (void*)m_base_, (void*)r_base_, (void*)p_base_, (void*)p2_base_, (void*)Ap_, (void*)Q_, (void*)Q2_,
                     (void*)scr_v_, (void*)scr_c_, (void*)scr_i_, (void*)scr_w_, (void*)part_cg_, (void*)part_tmp_, (void*)part_sets_,
-                    (void*)maxpart_, (void*)cg_dev_, (void*)gbuf_, (void*)stage_, (void*)sstage_, (void*)fbuf_})
+                    (void*)maxpart_, (void*)cg_dev_, (void*)gbuf_, (void*)stage_, (void*)sstage_, (void*)fbuf_, (void*)agree_buf_})
       dfree(p);
     comm_.reset();
     if (cstream_) (void)hipStreamDestroy(cstream_);
@@ -610,6 +610,14 @@ class Engine : public EngineBase {
         if (st.prox == PX_BOUNDS_VEC || (!st.two_pass && st.nblk > 0) || !st.host_ata.empty()) sparse_wanted = false;
     }
     if (comm_) comm_self_test(sparse_wanted);               // (every rank takes the same branch: the verdict is all-reduced)
+    // Everything from here to the initial feasibility allocates and uploads -- no collective.  A rank that fails in there (out of
+    // device memory: the likeliest rank-local failure of a first multi-GPU run) used to throw by itself while the others went on
+    // into the collectives of the initial feasibility and waited for it for ever; now every rank reports to one all-reduce on the
+    // self-test's plain buffer and all of them throw together (bench.py then falls back to the next decomposition on every rank).
+    std::string alloc_err;
+    try {
+    if (const char* f = std::getenv("SIPX_FINALIZE_FAIL_RANK"))       // tests: this rank "runs out of memory"
+      if (comm_ && std::atoi(f) == comm_->rank) throw std::runtime_error("test hook: out of device memory");
     if (slab_ && !slab_full_req_) {
       slab_local_ = sparse_wanted && !selftest_mapped_failed_;
       for (const auto& st : sets_) {
@@ -933,6 +941,26 @@ class Engine : public EngineBase {
         SIPX_HIP(hipEventCreateWithFlags(&lane_ev_, hipEventDisableTiming));
         lane_v_ = dalloc<T>((size_t)sets_[lane_set_].Mpad);
       }
+    }
+    } catch (const std::exception& ex) {
+      if (!comm_ || comm_->world <= 1 || !agree_buf_) throw;
+      alloc_err = ex.what();
+    }
+    if (comm_ && comm_->world > 1 && agree_buf_) {
+      const double flag = alloc_err.empty() ? 0.0 : 1.0;
+      double sum = flag;
+      try {
+        SIPX_HIP(hipMemcpy(agree_buf_, &flag, sizeof(double), hipMemcpyHostToDevice));
+        comm_->allreduce_sum(agree_buf_, 1, SIPX_F64, stream_);
+        SIPX_HIP(hipStreamSynchronize(stream_));
+        SIPX_HIP(hipMemcpy(&sum, agree_buf_, sizeof(double), hipMemcpyDeviceToHost));
+      } catch (const std::exception& ex) {
+        throw std::runtime_error(std::string("sipx_finalize: the ranks could not agree on the outcome of their allocations (") + ex.what() + ")" +
+                                 (alloc_err.empty() ? "" : "; this rank: " + alloc_err));
+      }
+      if (sum != 0.0)
+        throw std::runtime_error("sipx_finalize failed on " + std::to_string((int)sum) + " of " + std::to_string(comm_->world) + " ranks while allocating" +
+                                 (alloc_err.empty() ? std::string(" (not on this one)") : ": " + alloc_err));
     }
     finalized_ = true;
 
@@ -1702,7 +1730,11 @@ class Engine : public EngineBase {
   // rank.  SIPX_COMM_SELFTEST=0 skips it.  The same code runs through the callback communicator (tests: 2-4 ranks on one GPU).
   void comm_self_test(bool want_mapped) {
     const char* e = std::getenv("SIPX_COMM_SELFTEST");
-    if (e && e[0] == '0') { selftest_ = "skipped (SIPX_COMM_SELFTEST=0)"; return; }
+    if (e && e[0] == '0') {
+      selftest_ = "skipped (SIPX_COMM_SELFTEST=0)";
+      if (!agree_buf_) agree_buf_ = dalloc<double>(64);
+      return;
+    }
     Comm& c = *comm_;
     const int W = c.world, R = c.rank, dt = dtype_code();
     const size_t chunk = 1024, hc = 256;
@@ -1830,7 +1862,8 @@ class Engine : public EngineBase {
       all_ok = false;
       if (why.empty()) why = std::string("the verdict's all-reduce failed: ") + ex.what();
     }
-    dfree(buf); dfree(hal); dfree(red);
+    dfree(buf); dfree(hal);
+    if (agree_buf_) dfree(red); else agree_buf_ = red;      // (kept: the ranks agree on the outcome of their allocations through it)
     if (vm_base) dfree(vm_base);
     if (!all_ok)
       throw std::runtime_error("communicator self-test failed (" + std::string(c.kind()) + ", rank " + std::to_string(R) + " of " + std::to_string(W) +
@@ -4001,6 +4034,7 @@ class Engine : public EngineBase {
   bool slab_full_req_ = false, slab_local_ = false;
   // verdict of the communicator self-test of sipx_finalize ("none" without a communicator)
   std::string selftest_ = "none", mapped_why_;
+  double* agree_buf_ = nullptr;
   bool selftest_mapped_failed_ = false;
   long long wlo_ = 0, whi_ = 0;
   Grid Gr_, Gyl_;

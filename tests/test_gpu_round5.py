@@ -160,7 +160,7 @@ def _flat_slices(n, TF, seed):
 def test_slice_rank_projection_is_in_the_class_of_the_float32_svd(sipx, n, r, capfd, monkeypatch):
     """The reference projects a Float32 slice through svd() IN Float32 (src/projectors/project_rank!.jl:26-45: LAPACK's sgesdd).
     Round 5 accepts a Ritz pair of the slice-rank projector at the backward error such an SVD leaves on the slice itself,
-    ||E||_2 <= 2^-21 ||X||_2 (ext_proj.hip, k_sub_residual), instead of 1e-12 theta_max on the Gram matrix in Float64.  Leaf test of
+    ||E||_2 <= 2^-23 ||X||_2 = eps(Float32) ||X||_2 (ext_proj.hip, k_sub_residual), instead of 1e-12 theta_max on the Gram matrix in Float64.  Leaf test of
     that class against the oracle's Float32 LAPACK SVD, on slices without a spectral gap, the projector starting COLD (no previous
     call: the ramp of short filters, no full decomposition):
       * the engine's projection is as close to the exact (Float64 SVD) projection of the same Float32 slices as the reference's
@@ -305,3 +305,49 @@ def test_communicator_self_test_at_finalize(sipx, tmp_path, world, backend, mode
         else:
             assert r["comm_selftest"] == "passed" and r["sparse_arrays"] is True, r
     assert len({r["x_sum"] for r in res}) == 1, res
+
+
+def _bench_two_ranks(extra_env, extra_args=(), timeout=400):
+    import json
+    import subprocess
+    import sys
+    import tempfile
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, SIPX_BENCH_SHARE_GPU="1", SIPX_BENCH_AGREE_S="5", **extra_env)
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    detail = os.path.join(tempfile.mkdtemp(prefix="sipx_bench_"), "detail.json")
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "2", "--no-512", "--no-c4",
+                        "--no-c5", "--detail", detail, *extra_args], capture_output=True, text=True, timeout=timeout, env=env)
+    lines = [ln for ln in r.stdout.strip().splitlines() if ln.strip()]
+    return r, lines, (json.load(open(detail)) if os.path.exists(detail) else None)
+
+
+def test_bench_headline_survives_a_rank_that_fails_it():
+    """bench.py at N > 1 (round 5): the HEADLINE fails on one rank before any collective (SIPX_BENCH_FAIL_LEG=headline:1) -- the ranks
+    tell each other through the store, every rank moves on to the next attempt of the chain (whole arrays instead of the rank's
+    planes), and the line carries `value`, both decompositions, what was fallen back from and the error; exit code 0.  Round 4 ran the
+    headline outside every protection: the run came back empty."""
+    import json
+    r, lines, d = _bench_two_ranks({"SIPX_BENCH_FAIL_LEG": "headline:1"})
+    assert r.returncode == 0, r.stderr[-3000:]
+    assert len(lines) == 1 and len(lines[0]) < 4096, r.stdout[:2000]
+    h = json.loads(lines[0])
+    assert h["n_gpus"] == 2 and h["value"] > 0 and set(h["decompositions"]) == {"slab", "sets"}
+    assert h["comm"]["fell_back_from"] and h["comm"]["sparse_arrays"] is False and h["comm"]["ranks_agree_on_x"] is True
+    att = h["headline_attempts"]
+    assert att[0]["ok"] is False and "test hook" in att[0]["error"] and att[1]["ok"] is True
+
+
+def test_bench_headline_falls_back_when_finalize_fails_on_one_rank():
+    """A rank that runs out of device memory inside sipx_finalize (test hook SIPX_FINALIZE_FAIL_RANK) used to throw by itself while the
+    others waited for it in the collectives of the initial feasibility.  sipx_finalize now lets the ranks agree on the outcome of their
+    allocations (one all-reduce on the self-test's buffer): every rank raises, bench.py's agreement sees the attempt fail alike and the
+    chain goes on -- here to its end, because the hook fails every context of rank 1: the line then says so, value 0, and still prints."""
+    import json
+    r, lines, d = _bench_two_ranks({"SIPX_FINALIZE_FAIL_RANK": "1"})
+    assert len(lines) == 1, (r.stdout[:2000], r.stderr[-3000:])
+    h = json.loads(lines[0])
+    assert h["value"] == 0.0 and "every attempt" in h["error"]
+    assert len(h["headline_attempts"]) >= 3 and all(not a["ok"] for a in h["headline_attempts"])
+    assert all("failed on 1 of 2 ranks" in a["error"] for a in d["headline_attempts"]), d["headline_attempts"]

@@ -4,14 +4,14 @@ leaves on a slice of BASELINE config 4's model, in the measure the engine's slic
 Float32 array is LAPACK's sgesdd, the routine behind Julia's svd)."""
 import numpy as np
 
-ENGINE_EPS_BW = 2.0 ** -21          # ExtImpl::RankKnobs::eps_bw
+ENGINE_EPS_BW = 2.0 ** -23          # ExtImpl::RankKnobs::eps_bw
 
 
 def test_float32_svd_backward_error_class():
     """For theta = v'Gv (G = X'X) the residual rho = G v - theta v is orthogonal to v and (sigma, u = X v / sigma, v) is an EXACT
     singular triplet of X + E with E = -u rho' / sigma, ||E||_2 = ||rho|| / sigma: the backward error of the computed right vector.
     On a 512 x 512 slice (a constant plus white noise: one singular value 200 times the flat rest) the Float32 SVD's top 32 triplets
-    carry ||E|| / ||X||_2 between 1e-8 (the dominant one) and several 1e-7; the engine accepts a pair at 2^-21 = 4.8e-7, i.e. inside
+    carry ||E|| / ||X||_2 between 1e-8 (the dominant one) and several 1e-7; the engine accepts a pair at 2^-23 = 1.2e-7, i.e. at the median of
     what the reference's own arithmetic delivers, and the rank-32 projection built on such vectors is as far from the exact one as
     Float32 storage of the result is (1e-7 of the slice's norm)."""
     rng = np.random.default_rng(1)
@@ -29,7 +29,7 @@ def test_float32_svd_backward_error_class():
     assert bw[0] < 1e-7                                              # the dominant triplet
     assert 5e-8 < np.median(bw[1:]) < 1e-6 and bw[1:].max() < 5e-6, (np.median(bw[1:]), bw[1:].max())
     # the engine's level is not tighter than the median and not looser than a few times the largest of the reference's arithmetic
-    assert np.median(bw[1:]) * 0.5 < ENGINE_EPS_BW < 4.0 * bw[1:].max(), (np.median(bw[1:]), bw[1:].max())
+    assert ENGINE_EPS_BW <= 1.2 * np.median(bw[1:]) and ENGINE_EPS_BW < bw[1:].max(), (np.median(bw[1:]), bw[1:].max())
     P32 = (U[:, :r] * s[:r]) @ Vt[:r]
     P64 = (U64[:, :r] * s64[:r]) @ Vt64[:r]
     assert np.linalg.norm(P32 - P64) < 1e-6 * np.linalg.norm(P64)

@@ -4,7 +4,11 @@ last `frac` of the run (the timed steps), reports
   * the time during which ONLY one-workgroup kernels (decide / solve / finalize) are running: latency-bound tail,
   * per kernel: launches, median / mean duration of the launches that did work (>= 5 us).
 
-usage: python tools/timeline.py <dir with *_kernel_trace.csv> [frac=0.6]"""
+usage: python tools/timeline.py <dir with *_kernel_trace.csv> [frac=0.6 | iters=A:B]
+  frac=0.6     the last 60 % of the dispatches (rounds 1-4; with bench.py's one-call-per-step warm-up in front of the timed steps this
+               window holds warm-up iterations too -- round 4's r04_c3_*_timeline.txt did)
+  iters=A:B    PARSDMM iterations A..B (1-based, inclusive) of the LAST context of the run: an iteration opens with its k_cg_begin
+               launch (one per x-step).  bench.py --warmup W --steps K: iters=W+1:W+K is exactly the timed region."""
 import csv
 import glob
 import os
@@ -17,14 +21,23 @@ SMALL = ("k_decide", "k_l1_solve", "k_fin", "k_cg_fin", "k_cg_begin", "k_card_de
 
 def main():
     src = sys.argv[1]
-    frac = float(sys.argv[2]) if len(sys.argv) > 2 else 0.6
+    arg = sys.argv[2] if len(sys.argv) > 2 else "0.6"
+    frac = None if arg.startswith("iters=") else float(arg)
     files = glob.glob(os.path.join(src, "**", "*kernel_trace.csv"), recursive=True)
     rows = []
     for f in files:
         for r in csv.DictReader(open(f)):
             rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r.get("Kernel_Name") or r.get("Name")))
     rows.sort()
-    rows = rows[int(len(rows) * (1 - frac)):]
+    if frac is not None:
+        rows = rows[int(len(rows) * (1 - frac)):]
+    else:
+        a, b = (int(v) for v in arg[len("iters="):].split(":"))
+        opens = [i for i, r in enumerate(rows) if "k_cg_begin" in r[2]]
+        if len(opens) < b + 1:
+            raise SystemExit(f"the trace holds {len(opens)} x-steps, iters={a}:{b} needs {b + 1} (the one after the window closes it)")
+        rows = rows[opens[a - 1]:opens[b]]
+        print(f"PARSDMM iterations {a}..{b} (k_cg_begin launches {a}..{b + 1} of {len(opens)})")
     t0, t1 = rows[0][0], max(r[1] for r in rows)
     # sweep
     ev = []
