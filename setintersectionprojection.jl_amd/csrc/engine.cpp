@@ -1337,7 +1337,17 @@ class Engine : public EngineBase {
     const bool lane_now = loose_only && lane_set_ >= 0 && stats_mode_ != 2;
     struct LaneGuard {                       // whatever ends this call, the lane's host thread is joined first
       Engine<T>* e;
-      ~LaneGuard() { if (e->lane_thr_.joinable()) e->lane_thr_.join(); }
+      ~LaneGuard() {
+        if (!e->lane_thr_.joinable()) return;              // (lane_join has run: nothing is left over)
+        // an exception on the caller's thread between lane_start and lane_join: the lane's work is waited for, its projector
+        // goes back to the engine stream, its own error (if any) is dropped in favour of the one that is propagating.  The
+        // iterate of the lane set may be half updated: the solve is over, sipx_reset gives the context a defined state again.
+        e->lane_thr_.join();
+        if (e->lane_st_) (void)hipStreamSynchronize(e->lane_st_);
+        try { e->sets_[e->lane_set_].ext->set_stream(e->stream_); } catch (...) {}
+        e->lane_err_ = nullptr;
+        e->lane_sample_ = -1;
+      }
     } lane_guard{this};
     if (lane_now) lane_start(flags, rho, gamma);
     if (loose_only) {
@@ -1677,6 +1687,16 @@ class Engine : public EngineBase {
     SIPX_HIP(hipStreamWaitEvent(lane_st_, lane_fork_, 0));
     s.ext->set_stream(lane_st_);
     lane_err_ = nullptr;
+    // the lane's kernels are launched by a thread without a launch observer (the sample list is not shared between threads): the
+    // whole update of the set is booked from HERE as one inclusive interval on the lane stream, closed in lane_join -- in the
+    // all-kernel statistics the slice-rank set of C4 used to be missing altogether
+    lane_sample_ = -1;
+    if (stats_mode_ >= 2) {
+      const size_t i = samples_.size();
+      samples_.push_back(KSample{KID_EXT, 0.0, 0.0});
+      SIPX_HIP(hipEventRecord(stat_event(2 * i), lane_st_));
+      lane_sample_ = (long long)i;
+    }
     double* part = part_sets_ + (size_t)lane_set_ * SLOTS * NB;
     double* ptmp = s.ptmp ? s.ptmp : part_tmp_;
     T* mpart = s.mpart ? s.mpart : maxpart_;
@@ -1703,6 +1723,9 @@ class Engine : public EngineBase {
     SetState<T>& s = sets_[lane_set_];
     if (lane_thr_.joinable()) lane_thr_.join();
     s.ext->set_stream(stream_);
+    if (lane_sample_ >= 0 && (size_t)lane_sample_ < samples_.size())
+      SIPX_HIP(hipEventRecord(stat_event(2 * (size_t)lane_sample_ + 1), lane_st_));
+    lane_sample_ = -1;
     if (lane_err_) {
       (void)hipStreamSynchronize(lane_st_);
       std::exception_ptr e = lane_err_;
@@ -2773,7 +2796,9 @@ class Engine : public EngineBase {
     // (sharded: every iteration, unless SIPX_MARK_STRIDE says otherwise -- a rank's share of the headline on eight GPUs through RCCL
     //  with a world of one ran at 2215 it/s with the marks sampled and at 2219 without: its collectives leave gaps the records hide
     //  in; the sums then keep an event of their own, ev_sums_, where the marks are left out)
-    const int stride = env_knobs().mark_stride > 0 ? env_knobs().mark_stride : ((!comm_ && Nx_ <= (1ll << 23)) ? 7 : 1);
+    // (round 5: every iteration by default at every size -- log.timing is a public field and means the same thing for every
+    //  caller; the sampling that round 4 switched on by itself for grids of up to 2^23 points is opt-in: SIPX_MARK_STRIDE=7)
+    const int stride = env_knobs().mark_stride > 0 ? env_knobs().mark_stride : 1;
     auto is_timed = [&](int it) { return stride <= 1 || it <= 4 || it % stride == 0; };
     const bool timed = is_timed(i), next_timed = i < maxit && is_timed(i + 1);
     mark_step_[par] = i;
@@ -3967,6 +3992,7 @@ class Engine : public EngineBase {
   T* lane_v_ = nullptr;
   std::thread lane_thr_;
   std::exception_ptr lane_err_;
+  long long lane_sample_ = -1;        // index of the statistics sample that books the lane's interval (-1: none open)
   SetArgs<T> lane_args_;
   bool sweep_partial_ = false, has_loose_ = false;   // the sweep takes a subset of the sets (in_sweep); some owned set keeps its per-set kernels
   bool pass_multi_ = false;           // SIPX_PASS_MULTI=1: full first passes / fallback passes of the batched searches in one sweep per group (measured slower)

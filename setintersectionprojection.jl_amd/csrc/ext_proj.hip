@@ -468,7 +468,7 @@ __global__ __launch_bounds__(BLOCK) void k_sub_residual(int k, int b, int r, int
                                                         const rocblas_int* __restrict__ info_eig,
                                                         const double* __restrict__ fro2, unsigned long long* res,
                                                         double* __restrict__ per_matrix = nullptr, double eps_bw = 0.0,
-                                                        double tol = 1e-12) {
+                                                        double tol = 1e-12, int extra = 0) {
   __shared__ double sm[BLOCK / 64];
   const int l = blockIdx.x;
   const double tmax = W[(long long)l * ldw + b - 1];
@@ -477,7 +477,9 @@ __global__ __launch_bounds__(BLOCK) void k_sub_residual(int k, int b, int r, int
     return;
   }
   double worst = 0, worst_raw = 0;
-  for (int j = b - r; j < b; ++j) {
+  // (extra: the pairs BELOW the r wanted ones that are held to the same level -- the eigenvalues of these slices cross from one
+  //  PARSDMM iteration to the next, and a pair that enters the top r next time is then one the block already holds)
+  for (int j = (b - r - extra > 0 ? b - r - extra : 0); j < b; ++j) {
     const double th = W[(long long)l * ldw + j];
     const double* z = ZH + ((long long)l * b + j) * k;
     const double* x = X + ((long long)l * b + j) * k;
@@ -1059,6 +1061,7 @@ struct ExtImpl {
     // come here: they keep the one-sided Jacobi SVD).
     double eps_bw = 1.1920928955078125e-07;
     bool cold = true;             // SIPX_RANK_COLD=0: a call without a usable start decomposes fully (rounds 3-4)
+    int window = 0;               // SIPX_RANK_WINDOW: guard pairs below the r-th that are held to the acceptance level as well
     bool keep_damped = false;     // SIPX_RANK_KEEP=1 (measured, NOT the default): every column inside the damped interval stays out of the filter
   } knobs;
   double *Xc = nullptr, *Wc = nullptr, *Froc = nullptr;
@@ -1268,6 +1271,7 @@ ExtProj<T>::ExtProj(const ExtSpec& spec, hipStream_t stream) {
         if (const char* e = env("SIPX_RANK_STRICT")) { if (e[0] != '0') K_.eps_bw = 0.0; }
         if (const char* e = env("SIPX_RANK_EPS")) K_.eps_bw = atof(e) >= 0 ? atof(e) : K_.eps_bw;
         if (const char* e = env("SIPX_RANK_COLD")) K_.cold = e[0] != '0';
+        if (const char* e = env("SIPX_RANK_WINDOW")) K_.window = std::max(0, atoi(e));
         if (const char* e = env("SIPX_RANK_KEEP")) K_.keep_damped = e[0] != '0';
         if (const char* e = env("SIPX_RANK_FLOOR")) {
           const double f = atof(e);
@@ -1561,7 +1565,7 @@ static bool rank_cheb_route(ExtImpl<T>& I, int w, int k, bool& cheap_fail, bool 
     SIPX_HIP(hipMemsetAsync(I.sub_res, 0, 8 * sizeof(unsigned long long), s));
     SIPX_HIP(hipMemsetAsync(I.sub_res + 2, 0x7f, sizeof(unsigned long long), s));       // a large positive double: the minimum starts there
     hipLaunchKernelGGL(k_sub_residual, dim3(nb), dim3(BLOCK), 0, s, k, b, r, nb, F2, X, Ws, b, I.info, I.info + batch, Fro, I.sub_res, I.Es,
-                       KN.eps_bw, tol);
+                       KN.eps_bw, tol, std::min(KN.window, b - r - g - 1));
     hipLaunchKernelGGL(k_cheb_plan, dim3((nb + 63) / 64), dim3(64), 0, s, b, g, r, nb, Ws, I.Es, tol, I.sub_res);
     if (may_pack && !packed) hipLaunchKernelGGL(k_sub_list, dim3(1), dim3(256), 0, s, nb, I.Es, tol, I.sub_idx, I.sub_res);
     SIPX_HIP(hipMemcpyAsync(I.sub_res_host, I.sub_res, 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost, s));

@@ -217,6 +217,7 @@ MULTI_CASES = [
     ((36, 28, 30), (25.0, 25.0, 25.0), ["bounds", "l1:D_x", "l1:D_z"], np.float32, {"rho_update_frequency": 3}, True),   # two plain iterations in a row: the third pair
     ((36, 20, 9), (25.0, 20.0, 10.0), ["l2", "l1:D_z", "bnd:D_y"], np.float64, {}, False),                           # a layout that is not instantiated: per-set kernels
     ((96, 80), (25.0, 6.0), ["bounds", "l1:D_z", "card:D_x"], np.float32, {}, True),                                 # round 4, partial sweep: I Z D in the sweep, cardinality per set
+    ((96, 80), (25.0, 6.0), ["bounds", "l1:D_z", "card:D_x"], np.float64, {}, True),                                 # ... and in Float64 (the case round 4 had replaced)
     # BASELINE config 4's list: the sweep takes I X Y Z I(annulus) D; l1 behind the DFT, slice rank and cardinality keep their kernels,
     # the fused right-hand side holds the five sets in front of the first of them, k_rhs adds the rest in order
     ((32, 24, 16), (25.0, 25.0, 25.0), ["bounds", "l1:D_x", "l1:D_y", "l1:D_z", "annulus", "l1dft", "rank:4", "card:D_z"], np.float32, {}, True),

@@ -34,10 +34,11 @@ def main():
     else:
         a, b = (int(v) for v in arg[len("iters="):].split(":"))
         opens = [i for i, r in enumerate(rows) if "k_cg_begin" in r[2]]
-        if len(opens) < b + 1:
-            raise SystemExit(f"the trace holds {len(opens)} x-steps, iters={a}:{b} needs {b + 1} (the one after the window closes it)")
-        rows = rows[opens[a - 1]:opens[b]]
-        print(f"PARSDMM iterations {a}..{b} (k_cg_begin launches {a}..{b + 1} of {len(opens)})")
+        if len(opens) < b:
+            raise SystemExit(f"the trace holds {len(opens)} x-steps, iters={a}:{b} needs {b}")
+        # (the window closes where iteration b + 1 opens, or -- b being the run's last iteration -- with the trace)
+        rows = rows[opens[a - 1]:(opens[b] if b < len(opens) else len(rows))]
+        print(f"PARSDMM iterations {a}..{b} (x-steps {a}..{b} of {len(opens)} in the trace)")
     t0, t1 = rows[0][0], max(r[1] for r in rows)
     # sweep
     ev = []
