@@ -3174,15 +3174,16 @@ class Engine : public EngineBase {
     o += ", \"lane_set\": " + std::to_string(lane_set_);       // the set updated on a stream of its own (-1: none), lane_start
     o += ", \"batched_searches\": {\"searches\": " + std::to_string(batch_searches_) + ", \"fallbacks\": " + std::to_string(batch_fallbacks_) + "}";
     // slice-rank / matrix-rank sets: which route their projector took since the context was finalised (ext_proj.hip)
-    long long rc[4] = {0, 0, 0, 0};
+    long long rc[6] = {0, 0, 0, 0, 0, 0};
     for (const auto& st : sets_) {
       if (!st.ext || st.ext_kind != EXT_RANK) continue;
-      long long c[4];
+      long long c[6];
       st.ext->route_counts(c);
-      for (int q = 0; q < 4; ++q) rc[q] += c[q];
+      for (int q = 0; q < 6; ++q) rc[q] += c[q];
     }
     o += ", \"rank_route\": {\"calls\": " + std::to_string(rc[0]) + ", \"warm_started_subspace\": " + std::to_string(rc[1]) +
-         ", \"full_decomposition\": " + std::to_string(rc[2]) + ", \"products_with_gram\": " + std::to_string(rc[3]) + "}}";
+         ", \"full_decomposition\": " + std::to_string(rc[2]) + ", \"products_with_gram\": " + std::to_string(rc[3]) +
+         ", \"float32_loops\": " + std::to_string(rc[4]) + ", \"float32_gave_up\": " + std::to_string(rc[5]) + "}}";
     if (!peek) start_stats(enable);
     return o.c_str();
   }

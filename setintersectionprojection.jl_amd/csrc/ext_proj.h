@@ -36,8 +36,9 @@ class ExtProj {
   // v <- P(v) in place (padded layout, G.N entries); feas selects the warm-start state of the feasibility estimate
   void project(T* v, bool feas, double* partials, T* maxpart, T* compact);
   // rank projector: calls since construction, calls served by the warm-started subspace route, calls that decomposed fully,
-  // products with the Gram matrices the subspace route spent (all zero for the other kinds)
-  void route_counts(long long out[4]) const;
+  // products with the Gram matrices the subspace route spent, calls whose filters ran in Float32 on the deflated matrices, and
+  // those of them that went back to Float64 (all zero for the other kinds)
+  void route_counts(long long out[6]) const;
   // the stream of the calls to come (the engine runs the slice-rank set of a long list on a lane of its own)
   void set_stream(hipStream_t s);
   // forget every warm start and counter: the projector behaves like a newly built one (sipx_reset)

@@ -462,16 +462,26 @@ __global__ __launch_bounds__(BLOCK) void k_sub_seed(int k, int b, int batch, dou
 // with tol everywhere (the host's decisions, k_cheb_plan, k_sub_list) is the residual in units of its acceptance level times tol,
 // never asking for more than the strict level tol theta_max; res[6] <- the largest residual / theta_max as before (what a start is
 // judged by).
-__global__ __launch_bounds__(BLOCK) void k_sub_residual(int k, int b, int r, int batch, const double* __restrict__ ZH,
-                                                        const double* __restrict__ X, const double* __restrict__ W, int ldw,
+template <typename TS>
+__global__ __launch_bounds__(BLOCK) void k_sub_residual(int k, int b, int r, int batch, const TS* __restrict__ ZH,
+                                                        const TS* __restrict__ X, const double* __restrict__ W, int ldw,
                                                         const rocblas_int* __restrict__ info_chol,
                                                         const rocblas_int* __restrict__ info_eig,
                                                         const double* __restrict__ fro2, unsigned long long* res,
                                                         double* __restrict__ per_matrix = nullptr, double eps_bw = 0.0,
-                                                        double tol = 1e-12, int extra = 0) {
+                                                        double tol = 1e-12, int extra = 0, const int* __restrict__ nd = nullptr,
+                                                        const double* __restrict__ tmax_of = nullptr) {
+  // nd / tmax_of (the Float32 iteration on the deflated matrices): the nd[l] largest pairs of matrix l were taken out of the matrix
+  // before it was rounded to Float32 -- the block then owes r - nd[l] pairs -- and the residuals are still measured against the
+  // largest eigenvalue of the matrix AS IT WAS, tmax_of[l]
   __shared__ double sm[BLOCK / 64];
   const int l = blockIdx.x;
-  const double tmax = W[(long long)l * ldw + b - 1];
+  if (nd) r -= nd[l];
+  const double tmax = tmax_of ? tmax_of[l] : W[(long long)l * ldw + b - 1];
+  if (r <= 0) {                       // every wanted pair was deflated: nothing left to find here
+    if (threadIdx.x == 0 && per_matrix) per_matrix[l] = 0.0;
+    return;
+  }
   if (fro2[l] == 0.0) {               // a slice of zeros (the first iteration of a solve projects v = 0): nothing to find, nothing to certify
     if (threadIdx.x == 0 && per_matrix) per_matrix[l] = 0.0;
     return;
@@ -481,11 +491,11 @@ __global__ __launch_bounds__(BLOCK) void k_sub_residual(int k, int b, int r, int
   //  PARSDMM iteration to the next, and a pair that enters the top r next time is then one the block already holds)
   for (int j = (b - r - extra > 0 ? b - r - extra : 0); j < b; ++j) {
     const double th = W[(long long)l * ldw + j];
-    const double* z = ZH + ((long long)l * b + j) * k;
-    const double* x = X + ((long long)l * b + j) * k;
+    const TS* z = ZH + ((long long)l * b + j) * k;
+    const TS* x = X + ((long long)l * b + j) * k;
     double a = 0;
     for (int i = threadIdx.x; i < k; i += BLOCK) {
-      const double d = z[i] - th * x[i];
+      const double d = (double)z[i] - th * (double)x[i];
       a += d * d;
     }
     a = wave_sum(a);
@@ -549,29 +559,33 @@ __device__ __forceinline__ double cheb_floor(const double* __restrict__ W, int b
 }
 // C (nl x b per matrix, leading dimension b) = X_L' Z for the nl last (largest) Ritz vectors: keep entry (i, j) only where
 // vector i is far above column j
-__global__ void k_cheb_mask(int b, int g, int r, int nl, int batch, const double* __restrict__ W, double* __restrict__ C) {
+template <typename TS>
+__global__ void k_cheb_mask(int b, int g, int r, int nl, int batch, const double* __restrict__ W, TS* __restrict__ C,
+                            const int* __restrict__ nd = nullptr) {
   const long long per = (long long)nl * b, total = per * batch;
   for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long long)gridDim.x * blockDim.x) {
     const long long l = e / per;
     const int o = (int)(e - l * per), j = o / nl, i = b - nl + (o - j * nl);
     const double* Wl = W + l * b;
-    const double a = cheb_floor(Wl, b, g, r);
+    const double a = cheb_floor(Wl, b, g, r - (nd ? nd[l] : 0));
     const double tj = Wl[j] > a ? Wl[j] : a;
-    if (!(Wl[i] > CHEB_KAPPA * tj)) C[l * (long long)b * b + (long long)j * b + (o - j * nl)] = 0.0;
+    if (!(Wl[i] > CHEB_KAPPA * tj)) C[l * (long long)b * b + (long long)j * b + (o - j * nl)] = TS(0);
   }
 }
 // One step of the three-term recurrence, per column scalars: first = 1: out = (2/a_j) Z - Y0;  else out = (4/a_j) Z - 2 Y1 - Y0
 // (out may alias Z or Y0: every entry is read before it is written, by the same thread)
-__global__ __launch_bounds__(BLOCK) void k_cheb_step(int k, int b, int g, int r, int batch, const double* __restrict__ W, const double* Z,
-                                                     const double* Y1, const double* Y0, double* out, int first) {
+template <typename TS>
+__global__ __launch_bounds__(BLOCK) void k_cheb_step(int k, int b, int g, int r, int batch, const double* __restrict__ W, const TS* Z,
+                                                     const TS* Y1, const TS* Y0, TS* out, int first, const int* __restrict__ nd = nullptr) {
   const long long per = (long long)k * b, total = per * batch;
   for (long long e = (long long)blockIdx.x * BLOCK + threadIdx.x; e < total; e += (long long)gridDim.x * BLOCK) {
     const long long l = e / per;
     const int j = (int)((e - l * per) / k);
     const double* Wl = W + l * b;
-    const double a = cheb_floor(Wl, b, g, r);
+    const double a = cheb_floor(Wl, b, g, r - (nd ? nd[l] : 0));
     const double aj = Wl[j] / CHEB_KAPPA > a ? Wl[j] / CHEB_KAPPA : a;
-    out[e] = first ? (2.0 / aj) * Z[e] - Y0[e] : (4.0 / aj) * Z[e] - 2.0 * Y1[e] - Y0[e];
+    // (TS = float: the coefficients are rounded once, the recurrence runs in Float32 like the products it combines)
+    out[e] = first ? TS(2.0 / aj) * Z[e] - Y0[e] : TS(4.0 / aj) * Z[e] - TS(2) * Y1[e] - Y0[e];
   }
 }
 // Columns the filter must not touch (round 5): the g lowest ones as before, and EVERY column whose Ritz value lies inside the damped
@@ -583,50 +597,52 @@ __global__ __launch_bounds__(BLOCK) void k_cheb_step(int k, int b, int g, int r,
 // theta_j at columns 14-16, 32 and 43 of 56 beside 1e-5 at their neighbours) and every one of them had to be filtered back into
 // an eigenvector before the call could end: 25-45 products per call where 12-17 do.  Such columns now stay the Ritz vectors they
 // were: no help, no harm, and their Ritz values remain honest lower bounds (Cauchy interlacing) of the eigenvalues they stand for.
+template <typename TS>
 __global__ __launch_bounds__(BLOCK) void k_cheb_keep(int k, int b, int g, int r, int batch, const double* __restrict__ W,
-                                                     const double* __restrict__ X, double* __restrict__ A) {
+                                                     const TS* __restrict__ X, TS* __restrict__ A, const int* __restrict__ nd = nullptr) {
   const long long per = (long long)k * b, total = per * batch;
   for (long long e = (long long)blockIdx.x * BLOCK + threadIdx.x; e < total; e += (long long)gridDim.x * BLOCK) {
     const long long l = e / per;
     const int j = (int)((e - l * per) / k);
     const double* Wl = W + l * b;
-    if (j < g || !(Wl[j] > cheb_floor(Wl, b, g, r))) A[e] = X[e];
+    if (j < g || !(Wl[j] > cheb_floor(Wl, b, g, r - (nd ? nd[l] : 0)))) A[e] = X[e];
   }
 }
 // The same step with the projection inside, for the common case that only the nl <= 2 largest Ritz vectors are far above
 // anything (a velocity slice: its constant part): one wave per column, z_j - x_i (x_i' z_j) for the masked i, then the recurrence.
 // Replaces two skinny GEMMs, the mask kernel and k_cheb_step by one launch.
+template <typename TS>
 __global__ __launch_bounds__(256) void k_cheb_step_proj(int k, int b, int g, int r, int nl, int batch, const double* __restrict__ W,
-                                                        const double* __restrict__ X, const double* Z, const double* Y1, const double* Y0,
-                                                        double* out, int first) {
+                                                        const TS* __restrict__ X, const TS* Z, const TS* Y1, const TS* Y0,
+                                                        TS* out, int first, const int* __restrict__ nd = nullptr) {
   const long long col = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);       // (matrix, column) pairs, one per wave
   if (col >= (long long)b * batch) return;
   const int lane = threadIdx.x & 63;
   const long long l = col / b;
   const int j = (int)(col - l * b);
   const double* Wl = W + l * b;
-  const double a = cheb_floor(Wl, b, g, r);
+  const double a = cheb_floor(Wl, b, g, r - (nd ? nd[l] : 0));
   const double tj = Wl[j] > a ? Wl[j] : a;
   const double aj = Wl[j] / CHEB_KAPPA > a ? Wl[j] / CHEB_KAPPA : a;
   const long long base = l * (long long)k * b + (long long)j * k;
   double c0 = 0, c1 = 0;
   const bool m0 = nl >= 1 && Wl[b - 1] > CHEB_KAPPA * tj, m1 = nl >= 2 && Wl[b - 2] > CHEB_KAPPA * tj;
-  const double* x0 = X + l * (long long)k * b + (long long)(b - 1) * k;
-  const double* x1 = X + l * (long long)k * b + (long long)(b - 2) * k;
+  const TS* x0 = X + l * (long long)k * b + (long long)(b - 1) * k;
+  const TS* x1 = X + l * (long long)k * b + (long long)(b - 2) * k;
   if (m0 || m1) {
     for (int i = lane; i < k; i += 64) {
-      const double z = Z[base + i];
-      if (m0) c0 += x0[i] * z;
-      if (m1) c1 += x1[i] * z;
+      const double z = (double)Z[base + i];
+      if (m0) c0 += (double)x0[i] * z;
+      if (m1) c1 += (double)x1[i] * z;
     }
     c0 = wave_sum(c0);
     c1 = wave_sum(c1);
   }
   for (int i = lane; i < k; i += 64) {
-    double z = Z[base + i];
-    if (m0) z -= x0[i] * c0;
-    if (m1) z -= x1[i] * c1;
-    out[base + i] = first ? (2.0 / aj) * z - Y0[base + i] : (4.0 / aj) * z - 2.0 * Y1[base + i] - Y0[base + i];
+    TS z = Z[base + i];
+    if (m0) z -= x0[i] * (TS)c0;
+    if (m1) z -= x1[i] * (TS)c1;
+    out[base + i] = first ? TS(2.0 / aj) * z - Y0[base + i] : TS(4.0 / aj) * z - TS(2) * Y1[base + i] - Y0[base + i];
   }
 }
 // Cholesky QR without the triangular solve: M = Y'Y (b x b, b <= 64, column-major, both triangles) -> Rinv, the inverse of
@@ -634,14 +650,15 @@ __global__ __launch_bounds__(256) void k_cheb_step_proj(int k, int b, int g, int
 // scaled to unit length first (M' = D^-1 M D^-1), which is what keeps the factorisation of a filtered block -- columns of
 // very different length -- accurate.  info[l] is WRITTEN only on failure (a pivot that is not a number), so that two passes
 // can share it.
-__global__ __launch_bounds__(256) void k_chol_inv(int b, int batch, const double* __restrict__ M, double* __restrict__ Rinv,
+template <typename TO>
+__global__ __launch_bounds__(256) void k_chol_inv(int b, int batch, const double* __restrict__ M, TO* __restrict__ Rinv,
                                                   rocblas_int* __restrict__ info) {
   __shared__ double A[64 * 65];
   __shared__ double Bv[64 * 65];
   __shared__ double dsc[64];
   const int l = blockIdx.x, t = threadIdx.x;
   const double* Ml = M + (long long)l * b * b;
-  double* Rl = Rinv + (long long)l * b * b;
+  TO* Rl = Rinv + (long long)l * b * b;
   if (t < b) {
     const double dj = Ml[(long long)t * b + t];
     dsc[t] = dj > 0 ? 1.0 / sqrt(dj) : 0.0;
@@ -674,7 +691,7 @@ __global__ __launch_bounds__(256) void k_chol_inv(int b, int batch, const double
   __syncthreads();
   if (lost) {
     if (t == 0) info[l] = 1;
-    for (int e = t; e < b * b; e += 256) Rl[e] = (e % b == e / b) ? 1.0 : 0.0;
+    for (int e = t; e < b * b; e += 256) Rl[e] = (e % b == e / b) ? TO(1) : TO(0);
     return;
   }
   if (t < b) {                                               // column t of the inverse of the (scaled) factor, back substitution
@@ -689,7 +706,7 @@ __global__ __launch_bounds__(256) void k_chol_inv(int b, int batch, const double
   __syncthreads();
   for (int e = t; e < b * b; e += 256) {
     const int i = e % b, c = e / b;
-    Rl[e] = i <= c ? Bv[i * 65 + c] * dsc[i] : 0.0;
+    Rl[e] = i <= c ? (TO)(Bv[i * 65 + c] * dsc[i]) : TO(0);
   }
 }
 // The b x b Ritz problem (b <= 64): cyclic two-sided Jacobi with the round-robin ordering -- b/2 disjoint rotations per step,
@@ -699,7 +716,8 @@ __global__ __launch_bounds__(256) void k_chol_inv(int b, int batch, const double
 // 512 problems of 48 x 48, most of it launches; this kernel about a fifth.  (Round 4: the two passes of a step as one pass over
 // 2 x 2 blocks, loads staged in front of the stores -- the same operations in the same order, the same bits: 1.5 -> 0.9 ms for 512
 // problems of 56 x 56, 5-7 sweeps.)
-__global__ __launch_bounds__(256) void k_ritz_jacobi(int b, int batch, const double* H_in, double* S, double* __restrict__ W,
+template <typename TO>
+__global__ __launch_bounds__(256) void k_ritz_jacobi(int b, int batch, const double* H_in, TO* S, double* __restrict__ W,
                                                      rocblas_int* __restrict__ info, rocblas_int* __restrict__ nsweeps = nullptr) {
   __shared__ double H[64 * 65];
   __shared__ double V[64 * 65];
@@ -836,8 +854,8 @@ __global__ __launch_bounds__(256) void k_ritz_jacobi(int b, int batch, const dou
     }
     W[(long long)l * b + pos] = mine;
     // column t of V becomes column pos of S
-    double* Sl = S + (long long)l * b * b + (long long)pos * b;
-    for (int i = 0; i < b; ++i) Sl[i] = V[i * 65 + t];
+    TO* Sl = S + (long long)l * b * b + (long long)pos * b;
+    for (int i = 0; i < b; ++i) Sl[i] = (TO)V[i * 65 + t];
   }
 }
 // What the host needs to choose the next filter: res[2] <- min over the batch of t_r = 2 theta_r / a - 1 (bit pattern of a
@@ -846,10 +864,12 @@ __global__ __launch_bounds__(256) void k_ritz_jacobi(int b, int batch, const dou
 // filter is for (res[3]); res[5] <- the count of far-above vectors over ALL matrices (a filter that runs on the whole batch must
 // project for the converged ones too: their vectors would lose what they have to a direction 1e5 times larger)
 __global__ void k_cheb_plan(int b, int g, int r, int batch, const double* __restrict__ W, const double* __restrict__ per_matrix, double tol,
-                            unsigned long long* res) {
+                            unsigned long long* res, const int* __restrict__ nd = nullptr) {
   const int l = blockIdx.x * blockDim.x + threadIdx.x;
   if (l >= batch) return;
   const double* Wl = W + (long long)l * b;
+  if (nd) r -= nd[l];
+  if (r <= 0) return;
   const double a = cheb_floor(Wl, b, g, r);
   int nl = 0;
   for (int i = 0; i < b; ++i) nl += Wl[i] > CHEB_KAPPA * a ? 1 : 0;
@@ -877,8 +897,9 @@ __global__ __launch_bounds__(256) void k_sub_list(int batch, const double* __res
   if (t == 255) res[4] = (unsigned long long)base;
 }
 // dst[j] <- src[idx[j]] (gather) or dst[idx[j]] <- src[j] (scatter), `per` values per matrix
-__global__ __launch_bounds__(BLOCK) void k_sub_move(long long per, int n, const int* __restrict__ idx, const double* __restrict__ src,
-                                                    double* __restrict__ dst, int scatter) {
+template <typename TS>
+__global__ __launch_bounds__(BLOCK) void k_sub_move(long long per, int n, const int* __restrict__ idx, const TS* __restrict__ src,
+                                                    TS* __restrict__ dst, int scatter) {
   const long long total = per * n;
   for (long long e = (long long)blockIdx.x * BLOCK + threadIdx.x; e < total; e += (long long)gridDim.x * BLOCK) {
     const long long j = e / per, o = e - j * per;
@@ -1062,9 +1083,20 @@ struct ExtImpl {
     double eps_bw = 1.1920928955078125e-07;
     bool cold = true;             // SIPX_RANK_COLD=0: a call without a usable start decomposes fully (rounds 3-4)
     int window = 0;               // SIPX_RANK_WINDOW: guard pairs below the r-th that are held to the acceptance level as well
+    bool f32 = true;              // SIPX_RANK_F32=0: every filter in Float64 (rounds 3-4)
     bool keep_damped = false;     // SIPX_RANK_KEEP=1 (measured, NOT the default): every column inside the damped interval stays out of the filter
   } knobs;
   double *Xc = nullptr, *Wc = nullptr, *Froc = nullptr;
+  // the Float32 loop on the deflated matrices (round 5): its own matrices and blocks, the Ritz values of the deflated problem,
+  // deflated pairs per matrix and the largest eigenvalue of every matrix as it was
+  float *G32 = nullptr, *Gp32 = nullptr, *X32 = nullptr, *A32 = nullptr, *F32a = nullptr, *F32b = nullptr, *Xc32 = nullptr;
+  float *Cs32 = nullptr, *Zs32 = nullptr;
+  double *W32 = nullptr, *tmax32 = nullptr, *tmax32c = nullptr;
+  double *Xtop = nullptr, *Ytop = nullptr, *theta32 = nullptr;      // the refined top block (k x DEFL_N per matrix), its Rayleigh quotients
+  double* Wprev[2] = {nullptr, nullptr};                            // Ritz values the last accepted call of each state ended with
+  bool have_wprev[2] = {false, false};
+  int *nd32 = nullptr, *nd32c = nullptr;
+  long long n_f32 = 0, n_f32_back = 0;
   double *cert_w = nullptr, *cert_p = nullptr;     // the certificate's blocked Cholesky: inverse diagonal factors, one block row
   int* sub_idx = nullptr;
   int sub_cap = 0;
@@ -1272,6 +1304,7 @@ ExtProj<T>::ExtProj(const ExtSpec& spec, hipStream_t stream) {
         if (const char* e = env("SIPX_RANK_EPS")) K_.eps_bw = atof(e) >= 0 ? atof(e) : K_.eps_bw;
         if (const char* e = env("SIPX_RANK_COLD")) K_.cold = e[0] != '0';
         if (const char* e = env("SIPX_RANK_WINDOW")) K_.window = std::max(0, atoi(e));
+        if (const char* e = env("SIPX_RANK_F32")) K_.f32 = e[0] != '0';
         if (const char* e = env("SIPX_RANK_KEEP")) K_.keep_damped = e[0] != '0';
         if (const char* e = env("SIPX_RANK_FLOOR")) {
           const double f = atof(e);
@@ -1312,6 +1345,23 @@ ExtProj<T>::ExtProj(const ExtSpec& spec, hipStream_t stream) {
             I.Wc = I.template alloc<double>((size_t)I.sub_b * I.sub_cap);
             I.Froc = I.template alloc<double>((size_t)I.sub_cap);
             I.sub_idx = I.template alloc<int>((size_t)I.batch);
+          }
+          if (I.knobs.f32 && I.knobs.eps_bw > 0) {           // the Float32 loop's own arrays
+            const size_t nb32 = (size_t)k * I.sub_b * I.batch, bb = (size_t)I.sub_b * I.sub_b * I.batch;
+            I.G32 = I.template alloc<float>((size_t)k * k * I.batch);
+            I.X32 = I.template alloc<float>(nb32); I.A32 = I.template alloc<float>(nb32);
+            I.F32a = I.template alloc<float>(nb32); I.F32b = I.template alloc<float>(nb32);
+            I.Cs32 = I.template alloc<float>(bb); I.Zs32 = I.template alloc<float>(bb);
+            I.W32 = I.template alloc<double>((size_t)I.sub_b * I.batch);
+            I.tmax32 = I.template alloc<double>((size_t)I.batch); I.nd32 = I.template alloc<int>((size_t)I.batch);
+            I.Xtop = I.template alloc<double>((size_t)k * 8 * I.batch); I.Ytop = I.template alloc<double>((size_t)k * 8 * I.batch);
+            I.theta32 = I.template alloc<double>((size_t)8 * I.batch);
+            for (int w2 = 0; w2 < 2; ++w2) I.Wprev[w2] = I.template alloc<double>((size_t)I.sub_b * I.batch);
+            if (I.sub_cap > 0) {
+              I.Gp32 = I.template alloc<float>((size_t)k * k * I.sub_cap);
+              I.Xc32 = I.template alloc<float>((size_t)k * I.sub_b * I.sub_cap);
+              I.tmax32c = I.template alloc<double>((size_t)I.sub_cap); I.nd32c = I.template alloc<int>((size_t)I.sub_cap);
+            }
           }
         }
       }
@@ -1475,57 +1525,303 @@ static void rank_cert_factor(ExtImpl<T>& I, int k) {
   SIPX_HIP(hipGetLastError());
 }
 
-// Rank projection, Gram route: the top-r invariant subspace of every G_l from the Ritz vectors of the previous call (I.Xs[w]),
-// by Rayleigh-Ritz steps with a Chebyshev filter between them (kernels above).  One multiplication with G per filter degree
-// and one per Rayleigh-Ritz step; the degree of every filter is chosen from the residual still to be removed and the
-// flattest spectrum of the batch, T_m(t_r) >= 10 residual / tolerance.  Accepted when every top-r pair has a residual below
-// 1e-12 theta_max AND nothing above theta_r can hide outside the block: the energy bound of k_sub_residual where the
-// spectrum decays, the inertia of G with the found pairs removed (one batched Cholesky factorisation) where it is flat.
-// Returns false -- the caller then decomposes fully -- when the budget of multiplications cannot suffice, a factorisation
-// fails or the certificate does not hold.
-template <typename T>
-static bool rank_cheb_route(ExtImpl<T>& I, int w, int k, bool& cheap_fail, bool cold = false) {
+// ---- Float32 iteration on deflated Gram matrices (round 5) ------------------------------------------------------------------------
+// The products with the Gram matrices are what a call of the filtered route is made of (28 of them, 0.36 ms each for 512 matrices of
+// 512 x 512 in Float64: 42 TFLOP/s; the same product in Float32 takes 0.20 ms).  A Gram matrix of a velocity slice cannot be rounded
+// to Float32 as it is: its constant part is 1e5 ... 1e7 times the eigenvalues the block is after, and 6e-8 of THAT is several percent
+// of them.  With the pairs far above the rest taken out first -- G~ = G - sum theta_d x_d x_d', formed in Float64 from Ritz pairs the
+// first Rayleigh-Ritz step of the call has left accurate to 1e-15 theta_1 (they converge by a factor 1e-5 per step), then rounded --
+// what is left has entries of the size of the wanted eigenvalues, its rounding (6e-8 theta_2) is 300 times below the acceptance level
+// of a pair (k_sub_residual: eps(Float32) sqrt(theta_1 theta_j) = 3e-5 theta_j on such a slice), and filters, orthonormalisation and
+// Rayleigh-Ritz steps run in Float32 on it: SGEMM for the big products, the small Gram matrices (Y'Y, Q'G~Q) accumulated in Float64
+// by a kernel of the engine's own (Cholesky-QR of a filtered block in Float32 would need its condition below 3e3), Cholesky factor
+// and Ritz problem in Float64 as before.  The deflated pairs keep their places in the Float64 block; inside G~ they are null vectors
+// -- the lowest columns, which no filter touches anyway.  Acceptance is the level of k_sub_residual against the largest eigenvalue of
+// the matrix as it was; the inertia certificate then runs in Float64 on G itself with the merged block, as for the Float64 loop.
+// Anything the Float32 loop cannot do (a pair to deflate that is not accurate, more than 16 of them, a wanted eigenvalue so small
+// that Float32's floor is above its level, a stall) goes back to the Float64 loop from the state the first step left.
+// SIPX_RANK_F32=0 keeps every filter in Float64; SIPX_RANK_STRICT=1 does too (its level is out of Float32's reach).
+#define DEFL_RATIO 32.0
+#define DEFL_N 8              // columns of the refined top block (a matrix with more pairs far above the rest keeps the Float64 loop)
+// How many of the largest Ritz pairs of the PREVIOUS call lie far above the r-th (nd), per matrix; the top DEFL_N columns of the
+// previous block, largest first, into Xtop (k x DEFL_N per matrix: column 0 the largest).
+__global__ __launch_bounds__(BLOCK) void k_defl_top(int k, int b, int r, int batch, const double* __restrict__ Wprev, const double* __restrict__ X,
+                                                    int* __restrict__ nd, double* __restrict__ Xtop) {
+  const long long per = (long long)k * DEFL_N, total = per * batch;
+  for (long long e = (long long)blockIdx.x * BLOCK + threadIdx.x; e < total; e += (long long)gridDim.x * BLOCK) {
+    const long long l = e / per, o = e - l * per;
+    const int d = (int)(o / k), i = (int)(o - (long long)d * k);
+    Xtop[e] = X[l * (long long)k * b + (long long)(b - 1 - d) * k + i];
+    if (o == 0) {
+      const double* Wl = Wprev + l * b;
+      const double thr = Wl[b - r];
+      int n = 0;
+      for (int j = b - 1; j >= 0 && Wl[j] > DEFL_RATIO * thr; --j) ++n;
+      nd[l] = n;
+    }
+  }
+}
+// One step of block power iteration on the top block: Xtop <- orthonormalised Y (= G Xtop), the larger columns first (modified
+// Gram-Schmidt: column d loses what it shares with columns 0 .. d-1, then is scaled to unit length).  One workgroup per matrix.
+__global__ __launch_bounds__(BLOCK) void k_defl_gs(int k, int batch, const double* __restrict__ Y, double* __restrict__ Xtop) {
+  __shared__ double sm[BLOCK / 64];
+  __shared__ double s_c;
+  const int l = blockIdx.x;
+  const double* Yl = Y + (long long)l * k * DEFL_N;
+  double* Xl = Xtop + (long long)l * k * DEFL_N;
+  auto block_sum = [&](double v) -> double {
+    v = wave_sum(v);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = v;
+    __syncthreads();
+    double t = 0;
+    for (int q = 0; q < BLOCK / 64; ++q) t += sm[q];
+    return t;
+  };
+  for (int d = 0; d < DEFL_N; ++d) {
+    for (int i = threadIdx.x; i < k; i += BLOCK) Xl[(long long)d * k + i] = Yl[(long long)d * k + i];
+    __syncthreads();
+    for (int e = 0; e < d; ++e) {
+      double a = 0;
+      for (int i = threadIdx.x; i < k; i += BLOCK) a += Xl[(long long)e * k + i] * Xl[(long long)d * k + i];
+      a = block_sum(a);
+      for (int i = threadIdx.x; i < k; i += BLOCK) Xl[(long long)d * k + i] -= a * Xl[(long long)e * k + i];
+      __syncthreads();
+    }
+    double n2 = 0;
+    for (int i = threadIdx.x; i < k; i += BLOCK) n2 += Xl[(long long)d * k + i] * Xl[(long long)d * k + i];
+    n2 = block_sum(n2);
+    if (threadIdx.x == 0) s_c = n2 > 0 ? 1.0 / sqrt(n2) : 0.0;
+    __syncthreads();
+    const double c = s_c;
+    for (int i = threadIdx.x; i < k; i += BLOCK) Xl[(long long)d * k + i] *= c;
+    __syncthreads();
+  }
+}
+// With Y = G Xtop of the refined block: theta_d = x_d'y_d and the residual of every pair that is to be deflated; tmax; the verdict.
+// res[1] |= 64 when the Float32 loop must not run for this batch: more than DEFL_N pairs far above, a pair that is not an eigenpair
+// to 3 % of the level of the r-th pair (what is left of it stays in G~), a level that Float32's own floor (3e-7 of the largest
+// eigenvalue of G~) does not clear by a factor of four, a matrix without a positive r-th eigenvalue.
+__global__ __launch_bounds__(BLOCK) void k_defl_plan(int k, int b, int r, int batch, const double* __restrict__ Wprev, const double* __restrict__ Y,
+                                                     const double* __restrict__ Xtop, double eps_bw, double tol, int* __restrict__ nd,
+                                                     double* __restrict__ theta, double* __restrict__ tmax, unsigned long long* res) {
+  __shared__ double sm[BLOCK / 64];
+  const int l = blockIdx.x;
+  const double* Wl = Wprev + (long long)l * b;
+  const double thr = Wl[b - r];
+  const int n = nd[l];
+  bool bad = !(thr > 0) || n > DEFL_N || n >= r;
+  auto block_sum = [&](double v) -> double {
+    v = wave_sum(v);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = v;
+    __syncthreads();
+    double t = 0;
+    for (int q = 0; q < BLOCK / 64; ++q) t += sm[q];
+    return t;
+  };
+  double top = Wl[b - 1];
+  double th[DEFL_N], rs[DEFL_N];
+  for (int d = 0; d < DEFL_N; ++d) {
+    const double* y = Y + ((long long)l * DEFL_N + d) * k;
+    const double* x = Xtop + ((long long)l * DEFL_N + d) * k;
+    double a = 0;
+    for (int i = threadIdx.x; i < k; i += BLOCK) a += x[i] * y[i];
+    th[d] = block_sum(a);
+    double q = 0;
+    for (int i = threadIdx.x; i < k; i += BLOCK) { const double dd = y[i] - th[d] * x[i]; q += dd * dd; }
+    rs[d] = sqrt(block_sum(q));
+  }
+  if (n > 0) top = th[0];
+  const double lvl = fmax(eps_bw * sqrt(fmax(top, 0.0) * fmax(thr, 0.0)), tol * top);
+  for (int d = 0; d < n && d < DEFL_N; ++d)
+    if (!(rs[d] < 0.03 * lvl) || !(th[d] > 0.5 * DEFL_RATIO * thr)) bad = true;
+  // the largest eigenvalue G~ keeps: the next pair of the previous call, or the first refined one that is not deflated
+  const double next = n < DEFL_N ? fmax(th[n], Wl[b - 1 - n]) : Wl[b - 1 - n];
+  if (!(top > 0) || !(3e-7 * next < 0.25 * lvl)) bad = true;
+  if (threadIdx.x == 0) {
+    for (int d = 0; d < DEFL_N; ++d) theta[(long long)l * DEFL_N + d] = th[d];
+    tmax[l] = top;
+    if (bad) { nd[l] = 0; atomicOr(res + 1, 64ull); }
+  }
+}
+// G32 <- fl32(G - sum_{d < nd[l]} theta_d x_d x_d')
+__global__ __launch_bounds__(BLOCK) void k_defl_build(int k, int batch, const double* __restrict__ G, const double* __restrict__ theta,
+                                                      const double* __restrict__ Xtop, const int* __restrict__ nd, float* __restrict__ G32) {
+  const long long per = (long long)k * k, total = per * batch;
+  for (long long e = (long long)blockIdx.x * BLOCK + threadIdx.x; e < total; e += (long long)gridDim.x * BLOCK) {
+    const long long l = e / per, o = e - l * per;
+    const int row = (int)(o % k), col = (int)(o / k);
+    double v = G[e];
+    const int n = nd[l];
+    for (int d = 0; d < n; ++d) {
+      const double* x = Xtop + (l * DEFL_N + d) * (long long)k;
+      v -= theta[l * DEFL_N + d] * x[row] * x[col];
+    }
+    G32[e] = (float)v;
+  }
+}
+// The start block of the Float32 loop in the order of G~'s spectrum: the deflated pairs first (refined: null vectors of G~), then
+// the previous call's other vectors, ascending as before.
+__global__ __launch_bounds__(BLOCK) void k_defl_convert(int k, int b, int batch, const double* __restrict__ X, const double* __restrict__ Xtop,
+                                                        const int* __restrict__ nd, float* __restrict__ X32) {
+  const long long per = (long long)k * b, total = per * batch;
+  for (long long e = (long long)blockIdx.x * BLOCK + threadIdx.x; e < total; e += (long long)gridDim.x * BLOCK) {
+    const long long l = e / per, o = e - l * per;
+    const int jj = (int)(o / k), i = (int)(o - (long long)jj * k);          // destination column jj
+    const int n = nd[l];
+    X32[e] = jj < n ? (float)Xtop[(l * DEFL_N + jj) * (long long)k + i]      // (any order among the null vectors)
+                    : (float)X[l * per + (long long)(jj - n) * k + i];
+  }
+}
+// back: the b - nd[l] largest Ritz pairs of G~ take the places below the deflated pairs, which go to the top (largest last)
+__global__ __launch_bounds__(BLOCK) void k_defl_merge(int k, int b, int batch, const double* __restrict__ W32, const float* __restrict__ X32,
+                                                      const int* __restrict__ nd, const double* __restrict__ theta, const double* __restrict__ Xtop,
+                                                      double* __restrict__ W, double* __restrict__ X) {
+  const long long per = (long long)k * b, total = per * batch;
+  for (long long e = (long long)blockIdx.x * BLOCK + threadIdx.x; e < total; e += (long long)gridDim.x * BLOCK) {
+    const long long l = e / per, o = e - l * per;
+    const int j = (int)(o / k), i = (int)(o - (long long)j * k);            // destination column j
+    const int n = nd[l];
+    if (j >= b - n) {
+      const int d = b - 1 - j;                                               // column b - 1: the largest pair, d = 0
+      X[e] = Xtop[(l * DEFL_N + d) * (long long)k + i];
+      if (i == 0) W[l * b + j] = theta[l * DEFL_N + d];
+    } else {
+      X[e] = (double)X32[l * per + (long long)(j + n) * k + i];
+      if (i == 0) W[l * b + j] = W32[l * b + j + n];
+    }
+  }
+}
+// H (b x b, Float64, both triangles, column-major) = A'B for k x b blocks stored in TS: what Cholesky-QR and the Ritz problem are
+// built on, accumulated in Float64 whatever the storage.  One workgroup per matrix, 16 x 16 threads, 4 x 4 outputs each, the
+// operands staged through LDS 64 rows at a time.
+template <typename TS>
+__global__ __launch_bounds__(256) void k_gram_bb(int k, int b, const TS* __restrict__ A, const TS* __restrict__ B, double* __restrict__ H) {
+  __shared__ TS sa[64 * 65];
+  __shared__ TS sb[64 * 65];
+  const int l = blockIdx.x, t = threadIdx.x, ti = t & 15, tj = t >> 4;
+  const TS* Al = A + (long long)l * k * b;
+  const TS* Bl = B + (long long)l * k * b;
+  double acc[4][4];
+#pragma unroll
+  for (int p = 0; p < 4; ++p)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) acc[p][q] = 0.0;
+  for (int r0 = 0; r0 < k; r0 += 64) {
+    const int rows = k - r0 < 64 ? k - r0 : 64;
+    __syncthreads();
+    for (int e = t; e < 64 * 64; e += 256) {
+      const int rr = e & 63, c = e >> 6;
+      const bool in = rr < rows && c < b;
+      sa[c * 65 + rr] = in ? Al[(long long)c * k + r0 + rr] : TS(0);
+      sb[c * 65 + rr] = in ? Bl[(long long)c * k + r0 + rr] : TS(0);
+    }
+    __syncthreads();
+    for (int rr = 0; rr < rows; ++rr) {
+      double av[4], bv[4];
+#pragma unroll
+      for (int p = 0; p < 4; ++p) { av[p] = (double)sa[(ti * 4 + p) * 65 + rr]; bv[p] = (double)sb[(tj * 4 + p) * 65 + rr]; }
+#pragma unroll
+      for (int p = 0; p < 4; ++p)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) acc[p][q] += av[p] * bv[q];
+    }
+  }
+  double* Hl = H + (long long)l * b * b;
+#pragma unroll
+  for (int p = 0; p < 4; ++p)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int i = ti * 4 + p, j = tj * 4 + q;
+      if (i < b && j < b) Hl[(long long)j * b + i] = acc[p][q];
+    }
+}
+
+static rocblas_status gemm_sbx(rocblas_handle h, rocblas_operation ta, rocblas_operation tb, int m, int n, int k, float alpha, const float* A,
+                               int lda, long long sa, const float* B, int ldb, long long sb, float beta, float* C, int ldc, long long sc, int batch) {
+  return rocblas_sgemm_strided_batched(h, ta, tb, m, n, k, &alpha, A, lda, sa, B, ldb, sb, &beta, C, ldc, sc, batch);
+}
+static rocblas_status gemm_sbx(rocblas_handle h, rocblas_operation ta, rocblas_operation tb, int m, int n, int k, double alpha, const double* A,
+                               int lda, long long sa, const double* B, int ldb, long long sb, double beta, double* C, int ldc, long long sc, int batch) {
+  return rocblas_dgemm_strided_batched(h, ta, tb, m, n, k, &alpha, A, lda, sa, B, ldb, sb, &beta, C, ldc, sc, batch);
+}
+
+// the buffers of one precision of the filtered iteration
+template <typename TS>
+struct RouteBufs {
+  TS *G, *Gp;              // the matrices; room for the packed ones
+  TS* X;                   // Ritz vectors: the start, then every Rayleigh-Ritz step's result
+  TS *A, *F1, *F2;         // three blocks in rotation
+  TS* Xc;                  // Ritz vectors of the packed matrices
+  TS* Cs;                  // b x b per matrix: inverse Cholesky factor / masked projection coefficients
+  TS* Zs;                  // b x b per matrix: eigenvectors of the Ritz problem
+};
+// what a call carries from one loop to the next (the Float64 front step, the Float32 loop, the Float64 loop again)
+struct ChebCtl {
+  int w = 0, k = 0;
+  bool cold = false;
+  int mults = 0;
+  bool fresh_start = true, tried_other = false;
+  int ramp = -1, max_outer = 9;
+  bool cheap_fail = false;
+  bool start_rr = false;        // X, F2 = G X and the Ritz values are there already: the loop opens with that step's decisions
+  bool handover = false;        // leave after the first Rayleigh-Ritz step of a warm call (the Float32 loop takes over)
+  const int* nd = nullptr;      // Float32 loop: deflated pairs per matrix, the largest eigenvalue of the matrix as it was
+  const double* tmax = nullptr;
+  int* nd_c = nullptr;          // ... of the packed matrices
+  double* tmax_c = nullptr;
+  double* W = nullptr;          // Ritz values of the full batch (b per matrix) in this loop's order
+  double ph[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  std::chrono::steady_clock::time_point t_start, t_mark;
+  double last_res = -1, last_raw = -1;
+  bool hidden = true;           // at convergence: the energy bound of k_sub_residual does NOT rule out a larger eigenvalue outside the block
+};
+enum { CHEB_GIVE_UP = 0, CHEB_CONVERGED = 1, CHEB_HANDOVER = 2 };
+
+// The loop of the filtered route in the precision TS of its big arrays: Rayleigh-Ritz step, residual, decisions, filter.
+// CHEB_CONVERGED: every wanted pair is below its level (B.X and C.W hold the pairs of the whole batch, unpacked);
+// CHEB_HANDOVER: the first step of a warm call is done and another loop may go on from it; CHEB_GIVE_UP: the caller decomposes fully.
+template <typename T, typename TS>
+static int cheb_loop(ExtImpl<T>& I, RouteBufs<TS> B, ChebCtl& C) {
   hipStream_t s = I.stream;
+  const int k = C.k, w = C.w;
   const int b = I.sub_b, r = I.r, batch = I.batch;
-  const double one = 1.0, zero = 0.0, mone = -1.0;
   const long long sG = (long long)k * k, sX = (long long)k * b, sH = (long long)b * b;
   const auto N_ = rocblas_operation_none, T_ = rocblas_operation_transpose;
   const auto& KN = I.knobs;
   const int dbg = KN.dbg, budget = KN.budget, m_cap = KN.m_cap;
   const bool own_jacobi = KN.own_jacobi, fused_proj = KN.fused_proj;
   const double tol = KN.tol;
+  constexpr bool F32 = std::is_same<TS, float>::value;
+  const char* prec = F32 ? "Float32" : "Float64";
   // index of the Ritz value that ends the damped interval (C4 with 24 guards: 2 / 3 / 4 / 6 -> 16.8 / 16.5 / 16.6 / 16.0 it/s)
   const int g = KN.guard >= 0 ? std::min(KN.guard, b - r - 1) : std::max(2, (b - r) / 12);
-  const auto t_start = std::chrono::steady_clock::now();
-  double ph[8] = {0, 0, 0, 0, 0, 0, 0, 0};                 // SIPX_EXT_DEBUG=2: milliseconds per phase (the stream is drained at every mark)
-  auto t_mark = t_start;
   auto mark = [&](int which) {
     if (dbg < 2) return;
     SIPX_HIP(hipStreamSynchronize(s));
     const auto now = std::chrono::steady_clock::now();
-    ph[which] += std::chrono::duration<double, std::milli>(now - t_mark).count();
-    t_mark = now;
+    C.ph[which] += std::chrono::duration<double, std::milli>(now - C.t_mark).count();
+    C.t_mark = now;
   };
-  double* X = I.Xs[w];
+  TS* X = B.X;
   // three blocks in rotation: A the block to orthonormalise (then the orthonormal basis), F1 and F2 free
-  double *A = I.Qs, *F1 = I.Ys, *F2 = I.Zs;
+  TS *A = B.A, *F1 = B.F1, *F2 = B.F2;
   // what the loop works on: the whole batch -- or, once three quarters of it have converged, the matrices that have not, packed
   // (G into the certificate's matrix, which is free until the end; X into a block of its own: the converged matrices' vectors
   // stay where they are; the scratch blocks are used from their front).  The second and later filters of a call were observed
   // to run for 1 to 27 of 512 slices.
   int nb = batch;
-  double *Gd = I.Gd, *Ws = I.Ws, *Fro = I.Fro;
+  TS* Gd = B.G;
+  double *Ws = C.W, *Fro = I.Fro;
+  const int* nd = C.nd;
+  const double* tmax = C.tmax;
   bool packed = false;
-  const bool own_cert = KN.own_cert;
   const bool may_pack = I.sub_cap > 0 && KN.pack;
-  hipLaunchKernelGGL(k_sub_fro, dim3(batch), dim3(BLOCK), 0, s, k, I.Gd, I.Fro);
-  SIPX_HIP(hipMemcpyAsync(A, X, sizeof(double) * (size_t)sX * batch, hipMemcpyDeviceToDevice, s));
-  mark(7);
-  int mults = 0, m_prev = 0;
+  int m_prev = 0;
   double prev = -1;
-  bool ok = false, fresh_start = true, tried_other = false, retried = false;
+  bool retried = false;
   int m_lim = m_cap;
-  cheap_fail = false;
   // A start that says nothing about this input -- none at all (the block is pseudo-random: `cold`), or the previous call's vectors
   // on the second iteration of a solve (first residual above 1e-3 theta_max) -- is RAMPED instead of given up (rounds 3-4 decomposed
   // fully: 105-185 ms for 512 slices of 512 x 512).  What went wrong with long filters from such a block (DESIGN_HISTORY, round 3):
@@ -1534,39 +1830,46 @@ static bool rank_cheb_route(ExtImpl<T>& I, int w, int k, bool& cheap_fail, bool 
   // of the spectrum ends.  So: three steps of degree one (a shifted power step each, no product beyond the Rayleigh-Ritz step's own:
   // whatever is far above the rest converges by its ratio per step), then degrees 2, 4, 8 -- every Rayleigh-Ritz step moves the
   // interval ends towards the spectrum's -- then the usual filters.  The stall rule waits until the ramp is over.
-  int ramp = cold ? 0 : -1;                                 // stage of the ramp, -1: none
   static const int ramp_deg[6] = {1, 1, 1, 2, 4, 8};
   const int budget_all = budget * 2;
-  int max_outer = cold ? 24 : 9;
-  for (int outer = 0; outer < max_outer; ++outer) {
-    // Rayleigh-Ritz on span(A): Cholesky QR (twice behind a filter: its columns lean on each other), H = Q'GQ, X = Q S
-    SIPX_HIP(hipMemsetAsync(I.info, 0, sizeof(rocblas_int) * 2 * batch, s));
-    for (int pass = 0; pass < (m_prev > 0 ? 2 : 1); ++pass) {
-      blas_check(rocblas_dgemm_strided_batched(I.blas, T_, N_, b, b, k, &one, A, k, sX, A, k, sX, &zero, I.Hs, b, sH, nb), "Y'Y");
-      hipLaunchKernelGGL(k_chol_inv, dim3(nb), dim3(256), 0, s, b, nb, I.Hs, I.Cs, I.info);
-      blas_check(rocblas_dgemm_strided_batched(I.blas, N_, N_, k, b, b, &one, A, k, sX, I.Cs, b, sH, &zero, F1, k, sX, nb), "Y Rinv");
-      std::swap(A, F1);
+  bool have_rr = C.start_rr;
+  C.start_rr = false;
+  for (int outer = 0; outer < C.max_outer; ++outer) {
+    if (!have_rr) {
+      // Rayleigh-Ritz on span(A): Cholesky QR (twice behind a filter: its columns lean on each other), H = Q'GQ, X = Q S
+      SIPX_HIP(hipMemsetAsync(I.info, 0, sizeof(rocblas_int) * 2 * batch, s));
+      for (int pass = 0; pass < (m_prev > 0 ? 2 : 1); ++pass) {
+        if constexpr (F32) hipLaunchKernelGGL((k_gram_bb<TS>), dim3(nb), dim3(256), 0, s, k, b, A, A, I.Hs);
+        else blas_check(gemm_sbx(I.blas, T_, N_, b, b, k, TS(1), A, k, sX, A, k, sX, TS(0), (TS*)I.Hs, b, sH, nb), "Y'Y");
+        hipLaunchKernelGGL((k_chol_inv<TS>), dim3(nb), dim3(256), 0, s, b, nb, I.Hs, B.Cs, I.info);
+        blas_check(gemm_sbx(I.blas, N_, N_, k, b, b, TS(1), A, k, sX, B.Cs, b, sH, TS(0), F1, k, sX, nb), "Y Rinv");
+        std::swap(A, F1);
+      }
+      mark(0);
+      blas_check(gemm_sbx(I.blas, N_, N_, k, b, k, TS(1), Gd, k, sG, A, k, sX, TS(0), F1, k, sX, nb), "G Q");
+      ++C.mults;
+      mark(1);
+      if constexpr (F32) hipLaunchKernelGGL((k_gram_bb<TS>), dim3(nb), dim3(256), 0, s, k, b, A, F1, I.Hs);
+      else blas_check(gemm_sbx(I.blas, T_, N_, b, b, k, TS(1), A, k, sX, F1, k, sX, TS(0), (TS*)I.Hs, b, sH, nb), "Q'GQ");
+      mark(2);
+      if (own_jacobi || F32)
+        hipLaunchKernelGGL((k_ritz_jacobi<TS>), dim3(nb), dim3(256), 0, s, b, nb, I.Hs, B.Zs, Ws, I.info + batch, I.info + 2 * batch);
+      else
+        blas_check(rocsolver_dsyevj_strided_batched(I.blas, rocblas_esort_ascending, rocblas_evect_original, rocblas_fill_upper, b, I.Hs, b, sH,
+                                                    0.0, I.Es, 100, I.info + 2 * batch, Ws, b, I.info + batch, nb), "syevj (Ritz)");
+      mark(3);
+      blas_check(gemm_sbx(I.blas, N_, N_, k, b, b, TS(1), A, k, sX, B.Zs, b, sH, TS(0), X, k, sX, nb), "Q Z");
+      blas_check(gemm_sbx(I.blas, N_, N_, k, b, b, TS(1), F1, k, sX, B.Zs, b, sH, TS(0), F2, k, sX, nb), "(GQ) Z");
+      mark(2);
+    } else {
+      SIPX_HIP(hipMemsetAsync(I.info, 0, sizeof(rocblas_int) * 2 * batch, s));
     }
-    mark(0);
-    blas_check(rocblas_dgemm_strided_batched(I.blas, N_, N_, k, b, k, &one, Gd, k, sG, A, k, sX, &zero, F1, k, sX, nb), "G Q");
-    ++mults;
-    mark(1);
-    blas_check(rocblas_dgemm_strided_batched(I.blas, T_, N_, b, b, k, &one, A, k, sX, F1, k, sX, &zero, I.Hs, b, sH, nb), "Q'GQ");
-    mark(2);
-    if (own_jacobi)
-      hipLaunchKernelGGL(k_ritz_jacobi, dim3(nb), dim3(256), 0, s, b, nb, I.Hs, I.Hs, Ws, I.info + batch, I.info + 2 * batch);
-    else
-      blas_check(rocsolver_dsyevj_strided_batched(I.blas, rocblas_esort_ascending, rocblas_evect_original, rocblas_fill_upper, b, I.Hs, b, sH,
-                                                  0.0, I.Es, 100, I.info + 2 * batch, Ws, b, I.info + batch, nb), "syevj (Ritz)");
-    mark(3);
-    blas_check(rocblas_dgemm_strided_batched(I.blas, N_, N_, k, b, b, &one, A, k, sX, I.Hs, b, sH, &zero, X, k, sX, nb), "Q Z");
-    blas_check(rocblas_dgemm_strided_batched(I.blas, N_, N_, k, b, b, &one, F1, k, sX, I.Hs, b, sH, &zero, F2, k, sX, nb), "(GQ) Z");
-    mark(2);
+    have_rr = false;
     SIPX_HIP(hipMemsetAsync(I.sub_res, 0, 8 * sizeof(unsigned long long), s));
     SIPX_HIP(hipMemsetAsync(I.sub_res + 2, 0x7f, sizeof(unsigned long long), s));       // a large positive double: the minimum starts there
-    hipLaunchKernelGGL(k_sub_residual, dim3(nb), dim3(BLOCK), 0, s, k, b, r, nb, F2, X, Ws, b, I.info, I.info + batch, Fro, I.sub_res, I.Es,
-                       KN.eps_bw, tol, std::min(KN.window, b - r - g - 1));
-    hipLaunchKernelGGL(k_cheb_plan, dim3((nb + 63) / 64), dim3(64), 0, s, b, g, r, nb, Ws, I.Es, tol, I.sub_res);
+    hipLaunchKernelGGL((k_sub_residual<TS>), dim3(nb), dim3(BLOCK), 0, s, k, b, r, nb, F2, X, Ws, b, I.info, I.info + batch, Fro, I.sub_res, I.Es,
+                       KN.eps_bw, tol, std::min(KN.window, b - r - g - 1), nd, tmax);
+    hipLaunchKernelGGL(k_cheb_plan, dim3((nb + 63) / 64), dim3(64), 0, s, b, g, r, nb, Ws, I.Es, tol, I.sub_res, nd);
     if (may_pack && !packed) hipLaunchKernelGGL(k_sub_list, dim3(1), dim3(256), 0, s, nb, I.Es, tol, I.sub_idx, I.sub_res);
     SIPX_HIP(hipMemcpyAsync(I.sub_res_host, I.sub_res, 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
     SIPX_HIP(hipStreamSynchronize(s));
@@ -1575,16 +1878,16 @@ static bool rank_cheb_route(ExtImpl<T>& I, int w, int k, bool& cheap_fail, bool 
     std::memcpy(&res, &I.sub_res_host[0], sizeof(double));
     std::memcpy(&tmin, &I.sub_res_host[2], sizeof(double));
     std::memcpy(&res_raw, &I.sub_res_host[6], sizeof(double));
+    C.last_res = res; C.last_raw = res_raw;
     const bool failed = (I.sub_res_host[1] & 15ull) != 0;
-    const bool hidden = packed || (I.sub_res_host[1] & 16ull) != 0;      // (packed: the bit of the converged matrices is no longer seen)
     const int n_open = (int)I.sub_res_host[4];
     const bool pack_now = may_pack && !packed && res > tol && n_open >= 1 && n_open <= I.sub_cap;
     const int nl = (int)I.sub_res_host[(packed || pack_now) ? 3 : 5];
-    if (dbg) fprintf(stderr, "[sipx rank] filtered subspace step %d: %d products, residual %.3e (%.3e of theta_max), fail-bits %llu, t_r %.4f, "
+    if (dbg) fprintf(stderr, "[sipx rank] filtered subspace step %d (%s): %d products, residual %.3e (%.3e of theta_max), fail-bits %llu, t_r %.4g, "
                              "%d vectors far above, %d of %d matrices%s%s, %.2f ms\n",
-                     outer, mults, res, res_raw, I.sub_res_host[1], tmin, nl, nb, batch, packed ? " (packed)" : "", ramp >= 0 ? " (ramp)" : "",
-                     std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_start).count());
-    if (dbg >= 3 && own_jacobi) {
+                     outer, prec, C.mults, res, res_raw, I.sub_res_host[1], tmin, nl, nb, batch, packed ? " (packed)" : "", C.ramp >= 0 ? " (ramp)" : "",
+                     std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - C.t_start).count());
+    if (dbg >= 3 && (own_jacobi || F32)) {
       std::vector<rocblas_int> sw(nb);
       SIPX_HIP(hipMemcpy(sw.data(), I.info + 2 * batch, sizeof(rocblas_int) * nb, hipMemcpyDeviceToHost));
       long long tot = 0; int mx = 0;
@@ -1598,14 +1901,15 @@ static bool rank_cheb_route(ExtImpl<T>& I, int w, int k, bool& cheap_fail, bool 
       for (int l = 0; l < nb; ++l) { a12 += pm[l] > 1e-12; a10 += pm[l] > 1e-10; a8 += pm[l] > 1e-8; if (pm[l] > pm[worst_l]) worst_l = l; }
       fprintf(stderr, "[sipx rank]   matrices above 1e-12: %d, above 1e-10: %d, above 1e-8: %d (of %d)\n", a12, a10, a8, nb);
       if (dbg >= 4) {                                      // the worst matrix: its Ritz values and the residual of every column, in units of theta_j
-        std::vector<double> ww(b), zz((size_t)k * b), xx((size_t)k * b);
+        std::vector<double> ww(b);
+        std::vector<TS> zz((size_t)k * b), xx((size_t)k * b);
         SIPX_HIP(hipMemcpy(ww.data(), Ws + (size_t)worst_l * b, sizeof(double) * b, hipMemcpyDeviceToHost));
-        SIPX_HIP(hipMemcpy(zz.data(), F2 + (size_t)worst_l * sX, sizeof(double) * sX, hipMemcpyDeviceToHost));
-        SIPX_HIP(hipMemcpy(xx.data(), X + (size_t)worst_l * sX, sizeof(double) * sX, hipMemcpyDeviceToHost));
+        SIPX_HIP(hipMemcpy(zz.data(), F2 + (size_t)worst_l * sX, sizeof(TS) * sX, hipMemcpyDeviceToHost));
+        SIPX_HIP(hipMemcpy(xx.data(), X + (size_t)worst_l * sX, sizeof(TS) * sX, hipMemcpyDeviceToHost));
         fprintf(stderr, "[sipx rank]   worst matrix %d (%.3e): column: Ritz value / theta_max, residual / theta_j\n", worst_l, pm[worst_l]);
         for (int j = b - 1; j >= 0; --j) {
           double t = 0;
-          for (int i = 0; i < k; ++i) { const double d = zz[(size_t)j * k + i] - ww[j] * xx[(size_t)j * k + i]; t += d * d; }
+          for (int i = 0; i < k; ++i) { const double d = (double)zz[(size_t)j * k + i] - ww[j] * (double)xx[(size_t)j * k + i]; t += d * d; }
           fprintf(stderr, " %d:%.3e/%.2e", b - j, ww[j] / ww[b - 1], std::sqrt(t) / (ww[j] > 0 ? ww[j] : 1.0));
         }
         fprintf(stderr, "\n");
@@ -1613,78 +1917,41 @@ static bool rank_cheb_route(ExtImpl<T>& I, int w, int k, bool& cheap_fail, bool 
     }
     if (failed) break;
     // The previous call's vectors say little about this input (the first iterations of a solve): filters started from there
-    // were observed to swamp the guard columns and then stall at a residual of 1e-8 theta_max -- the full decomposition at once.
-    if (fresh_start && ramp < 0 && res_raw > 1e-3) {
+    // were observed to swamp the guard columns and then stall at a residual of 1e-8 theta_max.
+    if (F32 && C.fresh_start && res_raw > 1e-3) break;   // (a start that says too little: the Float64 loop has the ramp for it)
+    if (C.fresh_start && C.ramp < 0 && res_raw > 1e-3) {
       // the feasibility estimate is asked for every tenth iteration only, its own vectors are ten iterations old: those of the
       // y update of this iteration (another input, but the same x behind it) may be the better start
-      if (w == 1 && I.sub_have[0] && !tried_other) {
-        tried_other = true;
+      if (!F32 && w == 1 && I.sub_have[0] && !C.tried_other) {
+        C.tried_other = true;
         SIPX_HIP(hipMemcpyAsync(A, I.Xs[0], sizeof(double) * (size_t)sX * batch, hipMemcpyDeviceToDevice, s));
         if (dbg) fprintf(stderr, "[sipx rank] poor start: once more from the vectors of the y update\n");
         continue;
       }
       if (KN.cold) {
-        ramp = 0;                     // go on from what the step left, by the ramp
-        max_outer = 24;
-        cold = true;                  // (its budget)
+        C.ramp = 0;                   // go on from what the step left, by the ramp
+        C.max_outer = 24;
+        C.cold = true;                // (its budget)
         if (dbg) fprintf(stderr, "[sipx rank] poor start (%.3e of theta_max): ramped filters\n", res_raw);
       } else {
-        cheap_fail = true;            // one Rayleigh-Ritz step spent: nothing the next call should sit out for
+        C.cheap_fail = true;          // one Rayleigh-Ritz step spent: nothing the next call should sit out for
         break;
       }
     }
-    fresh_start = false;
+    C.fresh_start = false;
     if (res <= tol) {
       if (packed) {                   // the vectors and Ritz values of the packed matrices go back to their places
-        hipLaunchKernelGGL(k_sub_move, dim3(NB), dim3(BLOCK), 0, s, sX, nb, I.sub_idx, X, I.Xs[w], 1);
-        hipLaunchKernelGGL(k_sub_move, dim3(64), dim3(BLOCK), 0, s, (long long)b, nb, I.sub_idx, Ws, I.Ws, 1);
-        X = I.Xs[w];
-        Ws = I.Ws;
-        Gd = I.Gd;
-        Fro = I.Fro;
-        nb = batch;
+        hipLaunchKernelGGL((k_sub_move<TS>), dim3(NB), dim3(BLOCK), 0, s, sX, nb, I.sub_idx, X, B.X, 1);
+        hipLaunchKernelGGL((k_sub_move<double>), dim3(64), dim3(BLOCK), 0, s, (long long)b, nb, I.sub_idx, Ws, C.W, 1);
       }
-      if (!hidden) { ok = true; break; }
-      // flat spectrum: the inertia certificate (X_r Theta_r goes through F1)
-      hipLaunchKernelGGL(k_cert_shift, dim3(NB), dim3(BLOCK), 0, s, k, b, r, batch, I.Gd, I.Ws, I.Bd);
-      hipLaunchKernelGGL(k_cert_scale, dim3(NB), dim3(BLOCK), 0, s, k, b, r, batch, X, I.Ws, F1);
-      blas_check(rocblas_dgemm_strided_batched(I.blas, N_, T_, k, k, r, &one, F1 + (long long)(b - r) * k, k, sX, X + (long long)(b - r) * k, k, sX,
-                                               &one, I.Bd, k, sG, batch), "certificate: rank-r term");
-      if (own_cert) rank_cert_factor<T>(I, k);
-      else blas_check(rocsolver_dpotrf_strided_batched(I.blas, rocblas_fill_upper, k, I.Bd, k, sG, I.info, batch), "certificate: potrf");
-      SIPX_HIP(hipMemsetAsync(I.sub_res, 0, 2 * sizeof(unsigned long long), s));
-      hipLaunchKernelGGL(k_cert_or, dim3((batch + 63) / 64), dim3(64), 0, s, batch, I.info, I.sub_res);
-      SIPX_HIP(hipMemcpyAsync(I.sub_res_host, I.sub_res, 2 * sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
-      SIPX_HIP(hipStreamSynchronize(s));
-      ok = (I.sub_res_host[1] & 32ull) == 0;
-      mark(7);
-      if (KN.cert_check) {
-        // the blocked factorisation against the library's, matrix by matrix, on the certificate's own matrices and on matrices
-        // that cannot be definite (tests)
-        for (int low = 0; low < 2; ++low) {
-          std::vector<rocblas_int> v[2];
-          for (int lib = 0; lib < 2; ++lib) {
-            hipLaunchKernelGGL(k_cert_shift, dim3(NB), dim3(BLOCK), 0, s, k, b, r, batch, I.Gd, I.Ws, I.Bd, low);
-            blas_check(rocblas_dgemm_strided_batched(I.blas, N_, T_, k, k, r, &one, F1 + (long long)(b - r) * k, k, sX, X + (long long)(b - r) * k, k, sX,
-                                                     &one, I.Bd, k, sG, batch), "certificate: rank-r term");
-            if (lib) blas_check(rocsolver_dpotrf_strided_batched(I.blas, rocblas_fill_upper, k, I.Bd, k, sG, I.info, batch), "certificate: potrf");
-            else rank_cert_factor<T>(I, k);
-            v[lib].resize(batch);
-            SIPX_HIP(hipStreamSynchronize(s));
-            SIPX_HIP(hipMemcpy(v[lib].data(), I.info, sizeof(rocblas_int) * batch, hipMemcpyDeviceToHost));
-          }
-          int differ = 0, indef = 0;
-          for (int l = 0; l < batch; ++l) { differ += (v[0][l] != 0) != (v[1][l] != 0); indef += v[1][l] != 0; }
-          fprintf(stderr, "[sipx rank] certificate check (%s shift): %d of %d matrices not positive definite, the two factorisations differ on %d\n",
-                  low ? "low" : "the certificate's", indef, batch, differ);
-          if (differ) throw std::runtime_error("internal: the blocked Cholesky of the inertia certificate and the library's disagree");
-        }
-      }
-      if (dbg) fprintf(stderr, "[sipx rank] inertia certificate %s, %.2f ms\n", ok ? "holds" : "fails",
-                       std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_start).count());
-      break;
+      // (packed: the bit of the converged matrices is no longer seen; Float32: the bound was taken on the deflated matrices)
+      C.hidden = F32 || packed || (I.sub_res_host[1] & 16ull) != 0;
+      return CHEB_CONVERGED;
     }
-    if (ramp >= 0) prev = -1;                             // (no verdict on a filter while the intervals are still being found)
+    // (the Float32 loop takes over from the first step of a warm call: that step has told how far the start is off and has left the
+    //  pairs far above the rest accurate enough to be taken out of the matrices)
+    if (C.handover && C.ramp < 0 && !packed) return CHEB_HANDOVER;
+    if (C.ramp >= 0) prev = -1;                           // (no verdict on a filter while the intervals are still being found)
     if (prev > 0 && !(res < 0.5 * prev) && !retried) {
       // The filter did not do what its degree promised -- in a long C4 solve (80 iterations) the residual ROSE behind a filter in
       // one call of nine (4.9e-5 -> 1.4e-4 for all 512 slices, 3.6e-8 -> 3.0e-6 for seven): the intervals of a call's first filter
@@ -1715,13 +1982,18 @@ static bool rank_cheb_route(ExtImpl<T>& I, int w, int k, bool& cheap_fail, bool 
     if (pack_now) {
       // X, G X, the Ritz values, ||G||_F^2 and G itself of the open matrices, packed; G X lands in F1 (free: the product G Q
       // has gone into F2 = (G Q) Z), which then takes the place of F2
-      hipLaunchKernelGGL(k_sub_move, dim3(NB), dim3(BLOCK), 0, s, sG, n_open, I.sub_idx, I.Gd, I.Bd, 0);
-      hipLaunchKernelGGL(k_sub_move, dim3(NB), dim3(BLOCK), 0, s, sX, n_open, I.sub_idx, X, I.Xc, 0);
-      hipLaunchKernelGGL(k_sub_move, dim3(NB), dim3(BLOCK), 0, s, sX, n_open, I.sub_idx, F2, F1, 0);
-      hipLaunchKernelGGL(k_sub_move, dim3(64), dim3(BLOCK), 0, s, (long long)b, n_open, I.sub_idx, I.Ws, I.Wc, 0);
-      hipLaunchKernelGGL(k_sub_move, dim3(1), dim3(BLOCK), 0, s, 1LL, n_open, I.sub_idx, I.Fro, I.Froc, 0);
+      hipLaunchKernelGGL((k_sub_move<TS>), dim3(NB), dim3(BLOCK), 0, s, sG, n_open, I.sub_idx, B.G, B.Gp, 0);
+      hipLaunchKernelGGL((k_sub_move<TS>), dim3(NB), dim3(BLOCK), 0, s, sX, n_open, I.sub_idx, X, B.Xc, 0);
+      hipLaunchKernelGGL((k_sub_move<TS>), dim3(NB), dim3(BLOCK), 0, s, sX, n_open, I.sub_idx, F2, F1, 0);
+      hipLaunchKernelGGL((k_sub_move<double>), dim3(64), dim3(BLOCK), 0, s, (long long)b, n_open, I.sub_idx, C.W, I.Wc, 0);
+      hipLaunchKernelGGL((k_sub_move<double>), dim3(1), dim3(BLOCK), 0, s, 1LL, n_open, I.sub_idx, I.Fro, I.Froc, 0);
+      if (nd) {
+        hipLaunchKernelGGL((k_sub_move<int>), dim3(1), dim3(BLOCK), 0, s, 1LL, n_open, I.sub_idx, C.nd, C.nd_c, 0);
+        hipLaunchKernelGGL((k_sub_move<double>), dim3(1), dim3(BLOCK), 0, s, 1LL, n_open, I.sub_idx, C.tmax, C.tmax_c, 0);
+        nd = C.nd_c; tmax = C.tmax_c;
+      }
       std::swap(F1, F2);
-      Gd = I.Bd; X = I.Xc; Ws = I.Wc; Fro = I.Froc;
+      Gd = B.Gp; X = B.Xc; Ws = I.Wc; Fro = I.Froc;
       nb = n_open;
       packed = true;
       ++I.n_packed;
@@ -1733,51 +2005,51 @@ static bool rank_cheb_route(ExtImpl<T>& I, int w, int k, bool& cheap_fail, bool 
     int m = (int)std::ceil(need / per);
     if (m < 2) m = 2;
     const int m_max = m_lim;
-    const bool ramp_filter = ramp >= 0;                   // (a block that is still being found keeps only its g lowest columns: the
+    const bool ramp_filter = C.ramp >= 0;                 // (a block that is still being found keeps only its g lowest columns: the
                                                           //  others have to grow into guards first)
-    if (ramp >= 0) {
-      const int md = ramp_deg[ramp];
-      m = ramp < 3 ? md : std::min(std::max(m, 2), md);   // (a block that is nearly there does not need the whole ramp's degrees)
-      if (++ramp >= 6) ramp = -1;
-      if (mults + m + 1 > budget_all) break;
+    if (C.ramp >= 0) {
+      const int md = ramp_deg[C.ramp];
+      m = C.ramp < 3 ? md : std::min(std::max(m, 2), md);   // (a block that is nearly there does not need the whole ramp's degrees)
+      if (++C.ramp >= 6) C.ramp = -1;
+      if (C.mults + m + 1 > budget_all) break;
     } else if (m > m_max) {                               // several filters: can the budget still hold them?
       const double outers = std::ceil(need / (per * m_max));
-      if (mults + outers * (m_max + 1) > (cold ? budget_all : budget)) {
+      if (C.mults + outers * (m_max + 1) > (C.cold ? budget_all : budget)) {
         if (dbg) fprintf(stderr, "[sipx rank] filtered subspace: %g more products needed, over the budget\n", outers * (m_max + 1));
         break;
       }
       m = m_max;
-    } else if (mults + m + 1 > (cold ? budget_all : budget)) break;
+    } else if (C.mults + m + 1 > (C.cold ? budget_all : budget)) break;
     // Y_0 = X, Y_1 = (2/a) P G X - X with G X = F2 already there; Y_{i+1} = (4/a) P G Y_i - 2 Y_i - Y_{i-1}.  X stays (the
     // projections need it); products go to F1, the iterates alternate between F2 and A, each new one over the one two steps back
-    double *Y0 = X, *Y1 = X;
+    TS *Y0 = X, *Y1 = X;
     for (int i = 1; i <= m; ++i) {
-      double* Z = F2;
+      TS* Z = F2;
       if (i > 1) {
-        blas_check(rocblas_dgemm_strided_batched(I.blas, N_, N_, k, b, k, &one, Gd, k, sG, Y1, k, sX, &zero, F1, k, sX, nb), "G Y");
-        ++mults;
+        blas_check(gemm_sbx(I.blas, N_, N_, k, b, k, TS(1), Gd, k, sG, Y1, k, sX, TS(0), F1, k, sX, nb), "G Y");
+        ++C.mults;
         Z = F1;
         mark(1);
       }
-      double* out = i == 1 ? F2 : (i == 2 ? A : Y0);
+      TS* out = i == 1 ? F2 : (i == 2 ? A : Y0);
       if (nl <= 2 && fused_proj) {
         mark(5);
-        hipLaunchKernelGGL(k_cheb_step_proj, dim3((unsigned)(((long long)b * nb + 3) / 4)), dim3(256), 0, s, k, b, g, r, nl, nb, Ws, X, Z, Y1, Y0,
-                           out, i == 1 ? 1 : 0);
+        hipLaunchKernelGGL((k_cheb_step_proj<TS>), dim3((unsigned)(((long long)b * nb + 3) / 4)), dim3(256), 0, s, k, b, g, r, nl, nb, Ws, X, Z, Y1, Y0,
+                           out, i == 1 ? 1 : 0, nd);
         mark(6);
         Y0 = Y1;
         Y1 = out;
         continue;
       }
       if (nl > 0) {
-        const double* XL = X + (long long)(b - nl) * k;
-        blas_check(rocblas_dgemm_strided_batched(I.blas, T_, N_, nl, b, k, &one, XL, k, sX, Z, k, sX, &zero, I.Hs, b, sH, nb), "X_L' Z");
-        hipLaunchKernelGGL(k_cheb_mask, dim3((unsigned)std::min<long long>(NB, ((long long)nl * b * nb + 255) / 256)), dim3(256), 0, s, b, g, r, nl, nb,
-                           Ws, I.Hs);
-        blas_check(rocblas_dgemm_strided_batched(I.blas, N_, N_, k, b, nl, &mone, XL, k, sX, I.Hs, b, sH, &one, Z, k, sX, nb), "Z - X_L C");
+        const TS* XL = X + (long long)(b - nl) * k;
+        blas_check(gemm_sbx(I.blas, T_, N_, nl, b, k, TS(1), XL, k, sX, Z, k, sX, TS(0), B.Cs, b, sH, nb), "X_L' Z");
+        hipLaunchKernelGGL((k_cheb_mask<TS>), dim3((unsigned)std::min<long long>(NB, ((long long)nl * b * nb + 255) / 256)), dim3(256), 0, s, b, g, r, nl, nb,
+                           Ws, B.Cs, nd);
+        blas_check(gemm_sbx(I.blas, N_, N_, k, b, nl, TS(-1), XL, k, sX, B.Cs, b, sH, TS(1), Z, k, sX, nb), "Z - X_L C");
       }
       mark(5);
-      hipLaunchKernelGGL(k_cheb_step, dim3(NB), dim3(BLOCK), 0, s, k, b, g, r, nb, Ws, Z, Y1, Y0, out, i == 1 ? 1 : 0);
+      hipLaunchKernelGGL((k_cheb_step<TS>), dim3(NB), dim3(BLOCK), 0, s, k, b, g, r, nb, Ws, Z, Y1, Y0, out, i == 1 ? 1 : 0, nd);
       mark(6);
       Y0 = Y1;
       Y1 = out;
@@ -1787,15 +2059,159 @@ static bool rank_cheb_route(ExtImpl<T>& I, int w, int k, bool& cheap_fail, bool 
     // the g lowest columns sit inside the damped interval: T_m there is anything in [-1, 1], also (nearly) zero, and such a
     // column would be nothing but what leaked in from above -- dependent on the other columns.  They stay what they were.
     if (KN.keep_damped && !ramp_filter)
-      hipLaunchKernelGGL(k_cheb_keep, dim3(NB), dim3(BLOCK), 0, s, k, b, g, r, nb, Ws, X, A);
+      hipLaunchKernelGGL((k_cheb_keep<TS>), dim3(NB), dim3(BLOCK), 0, s, k, b, g, r, nb, Ws, X, A, nd);
     else if (g > 0)
-      SIPX_HIP(hipMemcpy2DAsync(A, sizeof(double) * (size_t)sX, X, sizeof(double) * (size_t)sX, sizeof(double) * (size_t)k * g, nb,
+      SIPX_HIP(hipMemcpy2DAsync(A, sizeof(TS) * (size_t)sX, X, sizeof(TS) * (size_t)sX, sizeof(TS) * (size_t)k * g, nb,
                                 hipMemcpyDeviceToDevice, s));
+  }
+  return CHEB_GIVE_UP;
+}
+
+// Rank projection, Gram route: the top-r invariant subspace of every G_l from the Ritz vectors of the previous call (I.Xs[w]),
+// by Rayleigh-Ritz steps with a Chebyshev filter between them (kernels above).  One multiplication with G per filter degree
+// and one per Rayleigh-Ritz step; the degree of every filter is chosen from the residual still to be removed and the
+// flattest spectrum of the batch, T_m(t_r) >= 10 residual / tolerance.  Accepted when every top-r pair has a residual below
+// its level (k_sub_residual) AND nothing above theta_r can hide outside the block: the energy bound of k_sub_residual where the
+// spectrum decays, the inertia of G with the found pairs removed (one batched Cholesky factorisation) where it is flat.
+// Returns false -- the caller then decomposes fully -- when the budget of multiplications cannot suffice, a factorisation
+// fails or the certificate does not hold.
+template <typename T>
+static bool rank_cheb_route(ExtImpl<T>& I, int w, int k, bool& cheap_fail, bool cold = false) {
+  hipStream_t s = I.stream;
+  const int b = I.sub_b, r = I.r, batch = I.batch;
+  const double one = 1.0;
+  const long long sG = (long long)k * k, sX = (long long)k * b;
+  const auto N_ = rocblas_operation_none, T_ = rocblas_operation_transpose;
+  const auto& KN = I.knobs;
+  const int dbg = KN.dbg;
+  ChebCtl C;
+  C.w = w; C.k = k; C.cold = cold;
+  C.ramp = cold ? 0 : -1;
+  C.max_outer = cold ? 24 : 9;
+  C.W = I.Ws;
+  C.t_start = C.t_mark = std::chrono::steady_clock::now();
+  auto mark = [&](int which) {
+    if (dbg < 2) return;
+    SIPX_HIP(hipStreamSynchronize(s));
+    const auto now = std::chrono::steady_clock::now();
+    C.ph[which] += std::chrono::duration<double, std::milli>(now - C.t_mark).count();
+    C.t_mark = now;
+  };
+  RouteBufs<double> B64{I.Gd, I.Bd, I.Xs[w], I.Qs, I.Ys, I.Zs, I.Xc, I.Cs, I.Hs};
+  double* X = I.Xs[w];
+  hipLaunchKernelGGL(k_sub_fro, dim3(batch), dim3(BLOCK), 0, s, k, I.Gd, I.Fro);
+  // Float32 loop (see above): a warm call whose previous call has left Ritz values (Wprev) to tell which pairs are far above the rest
+  const bool want32 = I.G32 != nullptr && KN.f32 && KN.eps_bw > 0 && !cold && I.have_wprev[w];
+  int rc = CHEB_GIVE_UP;
+  bool done32 = false;
+  if (want32) {
+    const double zero = 0.0;
+    const long long sT = (long long)k * DEFL_N;
+    double* Wp = I.Wprev[w];
+    double *Xtop = I.Xtop, *Ytop = I.Ytop;
+    // the top block of the previous call, refined on THIS call's matrices: two steps of block power iteration (whatever is far above
+    // the rest converges by its ratio per step: 1e-5 for the constant part of a velocity slice), then one more product for the
+    // Rayleigh quotients and the residuals the verdict is taken from -- three skinny products, each reads the Gram matrices once
+    hipLaunchKernelGGL(k_defl_top, dim3(NB), dim3(BLOCK), 0, s, k, b, r, batch, Wp, X, I.nd32, Xtop);
+    for (int step = 0; step < 3; ++step) {
+      blas_check(rocblas_dgemm_strided_batched(I.blas, N_, N_, k, DEFL_N, k, &one, I.Gd, k, sG, Xtop, k, sT, &zero, Ytop, k, sT, batch), "G X_top");
+      if (step < 2) hipLaunchKernelGGL(k_defl_gs, dim3(batch), dim3(BLOCK), 0, s, k, batch, Ytop, Xtop);
+    }
+    SIPX_HIP(hipMemsetAsync(I.sub_res, 0, 8 * sizeof(unsigned long long), s));
+    hipLaunchKernelGGL(k_defl_plan, dim3(batch), dim3(BLOCK), 0, s, k, b, r, batch, Wp, Ytop, Xtop, KN.eps_bw, KN.tol, I.nd32, I.theta32, I.tmax32, I.sub_res);
+    SIPX_HIP(hipMemcpyAsync(I.sub_res_host, I.sub_res, 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
+    SIPX_HIP(hipStreamSynchronize(s));
+    const bool use32 = (I.sub_res_host[1] & 64ull) == 0;
+    if (dbg) fprintf(stderr, "[sipx rank] Float32 loop on the deflated matrices: %s, %.2f ms\n",
+                     use32 ? "yes" : "no (a pair to deflate is not accurate, too many of them, or a level below Float32's floor)",
+                     std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - C.t_start).count());
+    mark(7);
+    if (use32) {
+      hipLaunchKernelGGL(k_defl_build, dim3(NB), dim3(BLOCK), 0, s, k, batch, I.Gd, I.theta32, Xtop, I.nd32, I.G32);
+      hipLaunchKernelGGL(k_defl_convert, dim3(NB), dim3(BLOCK), 0, s, k, b, batch, X, Xtop, I.nd32, I.A32);
+      mark(7);
+      RouteBufs<float> B32{I.G32, I.Gp32, I.X32, I.A32, I.F32a, I.F32b, I.Xc32, I.Cs32, I.Zs32};
+      ChebCtl C32 = C;
+      C32.nd = I.nd32; C32.tmax = I.tmax32; C32.nd_c = I.nd32c; C32.tmax_c = I.tmax32c;
+      C32.W = I.W32;
+      ++I.n_f32;
+      rc = cheb_loop<T, float>(I, B32, C32);
+      C.mults = C32.mults;
+      for (int q = 0; q < 8; ++q) C.ph[q] = C32.ph[q];
+      C.t_mark = C32.t_mark;
+      C.hidden = true;
+      if (rc == CHEB_CONVERGED) {
+        hipLaunchKernelGGL(k_defl_merge, dim3(NB), dim3(BLOCK), 0, s, k, b, batch, I.W32, I.X32, I.nd32, I.theta32, Xtop, I.Ws, X);
+        mark(7);
+        done32 = true;
+      } else {
+        // (a start that said too little, a stall in Float32, a failed factorisation: the Float64 loop starts over from the previous
+        //  call's vectors, which are untouched)
+        if (dbg) fprintf(stderr, "[sipx rank] the Float32 loop gave up (residual %.3e): the Float64 loop takes the call\n", C32.last_res);
+        ++I.n_f32_back;
+      }
+    }
+  }
+  if (!done32) {
+    hipLaunchKernelGGL(k_sub_fro, dim3(batch), dim3(BLOCK), 0, s, k, I.Gd, I.Fro);
+    SIPX_HIP(hipMemcpyAsync(B64.A, X, sizeof(double) * (size_t)sX * batch, hipMemcpyDeviceToDevice, s));
+    mark(7);
+    C.W = I.Ws;
+    rc = cheb_loop<T, double>(I, B64, C);
+  }
+  cheap_fail = C.cheap_fail;
+  bool ok = false;
+  if (rc == CHEB_CONVERGED && !C.hidden) {
+    ok = true;                        // a spectrum that decays behind the block: the energy bound has certified the pairs
+  } else if (rc == CHEB_CONVERGED) {
+    double* F1 = I.Ys;
+    const bool own_cert = KN.own_cert;
+    // flat spectrum: the inertia certificate (X_r Theta_r goes through F1)
+    hipLaunchKernelGGL(k_cert_shift, dim3(NB), dim3(BLOCK), 0, s, k, b, r, batch, I.Gd, I.Ws, I.Bd);
+    hipLaunchKernelGGL(k_cert_scale, dim3(NB), dim3(BLOCK), 0, s, k, b, r, batch, X, I.Ws, F1);
+    blas_check(rocblas_dgemm_strided_batched(I.blas, N_, T_, k, k, r, &one, F1 + (long long)(b - r) * k, k, sX, X + (long long)(b - r) * k, k, sX,
+                                             &one, I.Bd, k, sG, batch), "certificate: rank-r term");
+    if (own_cert) rank_cert_factor<T>(I, k);
+    else blas_check(rocsolver_dpotrf_strided_batched(I.blas, rocblas_fill_upper, k, I.Bd, k, sG, I.info, batch), "certificate: potrf");
+    SIPX_HIP(hipMemsetAsync(I.sub_res, 0, 2 * sizeof(unsigned long long), s));
+    hipLaunchKernelGGL(k_cert_or, dim3((batch + 63) / 64), dim3(64), 0, s, batch, I.info, I.sub_res);
+    SIPX_HIP(hipMemcpyAsync(I.sub_res_host, I.sub_res, 2 * sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
+    SIPX_HIP(hipStreamSynchronize(s));
+    ok = (I.sub_res_host[1] & 32ull) == 0;
+    mark(7);
+    if (KN.cert_check) {
+      // the blocked factorisation against the library's, matrix by matrix, on the certificate's own matrices and on matrices
+      // that cannot be definite (tests)
+      for (int low = 0; low < 2; ++low) {
+        std::vector<rocblas_int> v[2];
+        for (int lib = 0; lib < 2; ++lib) {
+          hipLaunchKernelGGL(k_cert_shift, dim3(NB), dim3(BLOCK), 0, s, k, b, r, batch, I.Gd, I.Ws, I.Bd, low);
+          blas_check(rocblas_dgemm_strided_batched(I.blas, N_, T_, k, k, r, &one, F1 + (long long)(b - r) * k, k, sX, X + (long long)(b - r) * k, k, sX,
+                                                   &one, I.Bd, k, sG, batch), "certificate: rank-r term");
+          if (lib) blas_check(rocsolver_dpotrf_strided_batched(I.blas, rocblas_fill_upper, k, I.Bd, k, sG, I.info, batch), "certificate: potrf");
+          else rank_cert_factor<T>(I, k);
+          v[lib].resize(batch);
+          SIPX_HIP(hipStreamSynchronize(s));
+          SIPX_HIP(hipMemcpy(v[lib].data(), I.info, sizeof(rocblas_int) * batch, hipMemcpyDeviceToHost));
+        }
+        int differ = 0, indef = 0;
+        for (int l = 0; l < batch; ++l) { differ += (v[0][l] != 0) != (v[1][l] != 0); indef += v[1][l] != 0; }
+        fprintf(stderr, "[sipx rank] certificate check (%s shift): %d of %d matrices not positive definite, the two factorisations differ on %d\n",
+                low ? "low" : "the certificate's", indef, batch, differ);
+        if (differ) throw std::runtime_error("internal: the blocked Cholesky of the inertia certificate and the library's disagree");
+      }
+    }
+    if (dbg) fprintf(stderr, "[sipx rank] inertia certificate %s, %.2f ms\n", ok ? "holds" : "fails",
+                     std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - C.t_start).count());
+  }
+  if (ok && I.Wprev[w]) {             // the next call's deflation is planned from these
+    SIPX_HIP(hipMemcpyAsync(I.Wprev[w], I.Ws, sizeof(double) * (size_t)b * batch, hipMemcpyDeviceToDevice, s));
+    I.have_wprev[w] = true;
   }
   if (dbg >= 2)
     fprintf(stderr, "[sipx rank] phases (ms): orthonormalise %.2f, products with G %.2f (%d), small products %.2f, Ritz solver %.2f, residual %.2f, "
-                    "projections %.2f, recurrence %.2f, copy + certificate %.2f\n", ph[0], ph[1], mults, ph[2], ph[3], ph[4], ph[5], ph[6], ph[7]);
-  I.n_products += mults;
+                    "projections %.2f, recurrence %.2f, copy + certificate %.2f\n", C.ph[0], C.ph[1], C.mults, C.ph[2], C.ph[3], C.ph[4], C.ph[5], C.ph[6], C.ph[7]);
+  I.n_products += C.mults;
   SIPX_HIP(hipGetLastError());
   return ok;
 }
@@ -1969,6 +2385,7 @@ void ExtProj<T>::project(T* v, bool feas, double* partials, T* maxpart, T* compa
           double q;
           std::memcpy(&q, &I.sub_res_host[0], sizeof(double));
           I.sub_have[w] = true;
+          I.have_wprev[w] = false;          // (the Ritz values of the last filtered call no longer describe the block)
           if (I.cheb && !I.cert_warm && !I.knobs.own_cert) {
             // the library sizes the workspace of a batched factorisation at its first call (a device allocation of its own, 100 ms
             // and more): spend it here, behind a full decomposition, not inside the first accepted call of the filtered route
@@ -2102,17 +2519,20 @@ void ExtProj<T>::reset() {
   if (I.fail_pending) { I.fail_pending = false; (void)hipEventSynchronize(I.fail_ev); }
   if (I.ps) K<T>::ps_init(I.stream, I.ps, I.cidx);
   if (I.psf) K<T>::ps_init(I.stream, I.psf, I.cidx);
-  for (int w = 0; w < 2; ++w) { I.sub_have[w] = I.sub_try[w] = false; I.cheb_skip[w] = I.cheb_fails[w] = 0; }
+  for (int w = 0; w < 2; ++w) { I.sub_have[w] = I.sub_try[w] = false; I.cheb_skip[w] = I.cheb_fails[w] = 0; I.have_wprev[w] = false; }
   I.n_calls = I.n_subspace = I.n_full = I.n_products = 0;
   I.n_packed = 0;
+  I.n_f32 = I.n_f32_back = 0;
 }
 
 template <typename T>
-void ExtProj<T>::route_counts(long long out[4]) const {
+void ExtProj<T>::route_counts(long long out[6]) const {
   out[0] = impl_ ? impl_->n_calls : 0;
   out[1] = impl_ ? impl_->n_subspace : 0;
   out[2] = impl_ ? impl_->n_full : 0;
   out[3] = impl_ ? impl_->n_products : 0;
+  out[4] = impl_ ? impl_->n_f32 : 0;
+  out[5] = impl_ ? impl_->n_f32_back : 0;
 }
 
 template class ExtProj<float>;
