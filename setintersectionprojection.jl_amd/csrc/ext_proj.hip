@@ -1083,7 +1083,7 @@ struct ExtImpl {
     double eps_bw = 1.1920928955078125e-07;
     bool cold = true;             // SIPX_RANK_COLD=0: a call without a usable start decomposes fully (rounds 3-4)
     int window = 0;               // SIPX_RANK_WINDOW: guard pairs below the r-th that are held to the acceptance level as well
-    bool f32 = true;              // SIPX_RANK_F32=0: every filter in Float64 (rounds 3-4)
+    bool f32 = false;             // SIPX_RANK_F32=1 (measured, NOT the default): the filters of a warm call in Float32 on deflated matrices
     bool keep_damped = false;     // SIPX_RANK_KEEP=1 (measured, NOT the default): every column inside the damped interval stays out of the filter
   } knobs;
   double *Xc = nullptr, *Wc = nullptr, *Froc = nullptr;
@@ -1540,7 +1540,14 @@ static void rank_cert_factor(ExtImpl<T>& I, int k) {
 // the matrix as it was; the inertia certificate then runs in Float64 on G itself with the merged block, as for the Float64 loop.
 // Anything the Float32 loop cannot do (a pair to deflate that is not accurate, more than 16 of them, a wanted eigenvalue so small
 // that Float32's floor is above its level, a stall) goes back to the Float64 loop from the state the first step left.
-// SIPX_RANK_F32=0 keeps every filter in Float64; SIPX_RANK_STRICT=1 does too (its level is out of Float32's reach).
+// MEASURED AND NOT THE DEFAULT (SIPX_RANK_F32=1 switches it on; SIPX_RANK_STRICT=1 always keeps Float64, its level is out of
+// Float32's reach).  512 slices of 512 x 512, r = 32: a filter degree costs 0.35 ms instead of 0.53 (product 0.20 instead of 0.36, the
+// recurrence kernel half its bytes), the three skinny products and the conversions 1.2 ms per call, and the iterates stay where the
+// Float64 loop's are (1.06e-5 against 1.06e-5 from the strict route after 16 iterations of C4) -- but the loop spends MORE products
+// (C4, 18 calls: 662 against 519; {bounds, rank} alone: 223 against 245) and the first Float32 call of a context pays 1.4 s for the
+// library's Float32 kernels, the first call with more than two directions to project another 0.35 s: C4 47.1 against 47.5 ms per
+// iteration once those are paid, 52.6 against 50.9 over iterations 3-16.  Not worth its 600 lines as a default; kept, tested
+// (tests/test_gpu_round5.py::test_float32_loop_of_the_rank_projector), for the batch sizes and ranks where the products dominate.
 #define DEFL_RATIO 32.0
 #define DEFL_N 8              // columns of the refined top block (a matrix with more pairs far above the rest keeps the Float64 loop)
 // How many of the largest Ritz pairs of the PREVIOUS call lie far above the r-th (nd), per matrix; the top DEFL_N columns of the

@@ -351,3 +351,34 @@ def test_bench_headline_falls_back_when_finalize_fails_on_one_rank():
     assert h["value"] == 0.0 and "every attempt" in h["error"]
     assert len(h["headline_attempts"]) >= 3 and all(not a["ok"] for a in h["headline_attempts"])
     assert all("failed on 1 of 2 ranks" in a["error"] for a in d["headline_attempts"]), d["headline_attempts"]
+
+
+def test_float32_loop_of_the_rank_projector(sipx, capfd, monkeypatch):
+    """SIPX_RANK_F32=1 (measured, not the default: DESIGN 3): the filters of a warm call run in Float32 on the Gram matrices with the
+    pairs far above the rest taken out in Float64 (ext_proj.hip, k_defl_*, cheb_loop<T, float>).  The loop must be taken, end in
+    accepted calls (inertia certificate in Float64 on the matrices themselves) and leave the iterates where the Float64 loop leaves
+    them -- both inside the reference's serial-vs-parallel tolerance of the oracle's Float32 LAPACK SVD (test_PARSDMM_parallel.jl:72)."""
+    TF, n, h, r = np.float32, (128, 128, 6), (25.0, 25.0, 25.0), 8
+    m = _flat_slices(n, TF, 20240604)
+    kw = dict(maxit=14, evol_rel_tol=0.0, feas_tol=0.0, obj_tol=0.0)
+
+    def solve(mod):
+        g, opt, P, A, prop, AtA = _problem(mod, n, h, TF, ["bounds", f"rank:{r}"], m, kw)
+        return mod.PARSDMM(m.copy(), AtA, A, prop, P, g, opt)
+
+    monkeypatch.setenv("SIPX_RANK_F32", "1")
+    monkeypatch.setenv("SIPX_EXT_DEBUG", "1")
+    capfd.readouterr()
+    x32, l32, _, _ = solve(sipx)
+    err = capfd.readouterr().err
+    monkeypatch.delenv("SIPX_EXT_DEBUG")
+    monkeypatch.delenv("SIPX_RANK_F32")
+    assert err.count("Float32 loop on the deflated matrices: yes") >= 6 and "(Float32)" in err, err[-3000:]
+    assert err.count("subspace accepted") >= 11 and "full decomposition" not in err
+    x64, l64, _, _ = solve(sipx)
+    xo, lo, _, _ = solve(O)
+    nrm = np.linalg.norm(xo)
+    d32, d64 = np.linalg.norm(x32.astype(np.float64) - xo) / nrm, np.linalg.norm(x64.astype(np.float64) - xo) / nrm
+    print(f"Float32 loop - oracle {d32:.2e}, Float64 loop - oracle {d64:.2e}")
+    assert d32 < 5e-4 and d64 < 5e-4
+    assert np.allclose(l32.obj[:8], lo.obj[:8], rtol=2e-3)
