@@ -945,9 +945,10 @@ def main():
         # profiles/ holds a summary taken on THIS build of libsipx.so (its hash is recorded by tools/summarize_pmc.py), else null
         traffic, traffic_src = None, None
         if args.q_mode == "cds" and args.dtype == "f32" and world == 1:
-            pmc = os.path.join(ROOT, "profiles", f"r04_{'c3_256' if config == 'c3' else config.replace('-', '_')}_pmc.json")
+            tag = 'c3_256' if config == 'c3' else config.replace('-', '_')
+            pmc = next((q for q in (os.path.join(ROOT, "profiles", f"r{rr:02d}_{tag}_pmc.json") for rr in (6, 5, 4)) if os.path.exists(q)), "")
             try:                                             # (a profile file must never take the bench line with it)
-                rec = json.load(open(pmc)) if os.path.exists(pmc) else {}
+                rec = json.load(open(pmc)) if pmc else {}
                 if rec.get("libsipx_sha16") == lib_sha16() and "dominant_kernel" in rec:
                     traffic = rec["dominant_kernel"]["hbm_bytes_per_launch_corrected"]
                     traffic_src = (f"profiles/{os.path.basename(pmc)}: separate rocprofv3 --pmc passes on this build (libsipx.so sha256[:16] "

@@ -858,6 +858,10 @@ __global__ __launch_bounds__(256) void k_ritz_jacobi(int b, int batch, const dou
     for (int i = 0; i < b; ++i) Sl[i] = (TO)V[i * 65 + t];
   }
 }
+// (Round 5, measured and dropped: the same solver with ONE WAVE per matrix -- no workgroup barriers, three workgroups per CU, the 2 x 2
+//  blocks of a step walked four per lane -- gives the same bits and takes TWICE as long: 512 problems of 56 x 56 in a C4 iteration
+//  59.9 against 49.8 ms per iteration, a 64-slice share 25.4 against 12.3 ms.  The step's LDS round trips are latency, and 64 lanes
+//  queue twelve of them behind each other where 256 threads queue four.)
 // What the host needs to choose the next filter: res[2] <- min over the batch of t_r = 2 theta_r / a - 1 (bit pattern of a
 // positive double, start from +inf), res[3] <- max over the batch of the number of Ritz vectors far above the lowest column
 // -- both over the matrices whose residual (per_matrix, k_sub_residual) is still above tol: the others are not what the next

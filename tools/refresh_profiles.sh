@@ -1,33 +1,37 @@
 #!/bin/bash
 # Regenerates the round's profile files on a GPU box (run through gpurun from the repo root); outputs under gpurun_out/prof/,
-# to be copied into profiles/ by the caller.  usage: tools/refresh_profiles.sh [round tag, default r04] [light]
+# to be copied into profiles/ by the caller.  usage: tools/refresh_profiles.sh [round tag, default r05] [part: a | b | c | all]
+#   a: PMC passes, kernel traces + timelines of c3 / c3-512, the default bench run;  b: C4 traces, its 80-iteration run, C2;
+#   c: steady-state, Float64, C5, RCCL-world-of-one, rank-share and 768^3 runs.  (One gpurun call holds 20 minutes: a part each.)
 set -e -o pipefail
-R=${1:-r04}
-LIGHT=${2:-}
+R=${1:-r05}
+PART=${2:-all}
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 O=gpurun_out/prof; mkdir -p $O
 T="timeout -k 10 500"
 # profiled runs: the headline workload only, without the all-kernel statistics window (its event records would show up as gaps)
-B="--no-cpu-baseline --no-512 --no-c4 --no-c5 --no-kernel-table"
+B="--no-cpu-baseline --no-512 --no-c4 --no-c5 --no-c2 --no-whole-call --no-kernel-table"
+S="--no-cpu-baseline --no-c4 --no-c5 --no-c2 --no-whole-call"      # plain runs of one workload (the 512^3 leg kept where the config is c3)
 pmc_pair() {   # <config> <tag>: the two HBM-side passes (FETCH_SIZE / WRITE_SIZE in separate runs, --kernel-trace only)
   $T rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $O/pmc_f -o t --output-format csv -- python3 bench.py $B --config $1 --steps 6 --warmup 2 > /dev/null 2>$O/pmc.err
   $T rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $O/pmc_w -o t --output-format csv -- python3 bench.py $B --config $1 --steps 6 --warmup 2 > /dev/null 2>>$O/pmc.err
   python tools/summarize_pmc.py $O/pmc_f $O/pmc_w $O/${R}_$2_pmc.json "bench.py $B --config $1 --steps 6 --warmup 2" > /dev/null
   rm -rf $O/pmc_f $O/pmc_w
 }
-trace() {      # <config> <tag> [extra bench args]: rocprofv3 --kernel-trace --stats of the bench command + per-dispatch summary + timeline
-  local cfg=$1 tag=$2; shift 2
+trace() {      # <config> <tag> <first:last timed iteration> [extra bench args]: rocprofv3 --kernel-trace --stats of the bench command + per-dispatch summary + timeline
+  local cfg=$1 tag=$2 win=$3; shift 3
   $T rocprofv3 --kernel-trace --stats -d $O/kt -o t --output-format csv -- python3 bench.py $B --config $cfg "$@" > $O/${R}_${tag}_bench_under_rocprof.json 2>$O/kt.err
   python tools/summarize_kernel_trace.py $O/kt $O/${R}_${tag}_kernel_trace_summary.json > /dev/null
-  python tools/timeline.py $O/kt 0.75 > $O/${R}_${tag}_timeline.txt
+  python tools/timeline.py $O/kt iters=$win > $O/${R}_${tag}_timeline.txt
   cp $(find $O/kt -name "*kernel_stats.csv" | head -1) $O/${R}_${tag}_kernel_stats.csv
   if [[ $tag == c4* ]]; then python tools/c4_iter_groups.py $(find $O/kt -name "*kernel_trace.csv" | head -1) > $O/${R}_${tag}_iteration_groups.txt; fi
   rm -rf $O/kt
 }
+if [[ $PART == a || $PART == all ]]; then
 pmc_pair c3 c3_256
 pmc_pair c3-512 c3_512
-trace c3 c3_256
-trace c3-512 c3_512 --steps 10 --warmup 5
+trace c3 c3_256 6:25
+trace c3-512 c3_512 6:15 --steps 10 --warmup 5
 # the product kernel alone, k_cds against its z-marching form: time (stand-alone microbenchmark) and fabric-side traffic
 if [ -x scratch/spmv_bench ]; then
   SPMV_QUICK=1 $T scratch/spmv_bench 256 > $O/${R}_spmv_march_256.txt 2>&1
@@ -64,34 +68,37 @@ PY
 fi
 cp $O/${R}_c3_256_pmc.json $O/${R}_c3_512_pmc.json profiles/      # (this box's copy: the bench line quotes `traffic` from a profile of the running build)
 $T python bench.py --detail $O/${R}_bench_default_detail.json > $O/${R}_bench_default.json 2>$O/bench.err
-if [ -z "$LIGHT" ]; then
+fi
+if [[ $PART == b || $PART == all ]]; then
   # C4 (eight sets, 512^3) iteration by iteration: with the slice-rank set on its lane (the product), and in turn on the engine
   # stream (kernel times that do not overlap: what each group costs alone)
-  trace c4 c4_512 --steps 6 --warmup 2
+  trace c4 c4_512 3:8 --steps 6 --warmup 2
   export SIPX_RANK_LANE=0
-  trace c4 c4_512_in_turn --steps 6 --warmup 2
+  trace c4 c4_512_in_turn 3:8 --steps 6 --warmup 2
   unset SIPX_RANK_LANE
   # ... and over 80 iterations: what a long solve of that list sustains (the slice-rank projector's route on inputs that keep moving)
-  $T python bench.py --no-cpu-baseline --no-512 --no-c4 --no-c5 --config c4 --steps 80 --warmup 2 > $O/${R}_c4_512_bench_80_iterations.json 2>>$O/bench.err
-  trace c2 c2_2048
-  $T python bench.py --no-cpu-baseline --no-512 --no-c4 --no-c5 --warmup 100 --steps 100 > $O/${R}_c3_256_bench_steady_it101_200.json 2>>$O/bench.err
-  $T python bench.py --no-cpu-baseline --no-c4 --no-c5 --config c3-512 --warmup 100 --steps 60 > $O/${R}_c3_512_bench_steady_it101_160.json 2>>$O/bench.err
-  $T python bench.py --no-cpu-baseline --no-c4 --no-c5 --config c2 > $O/${R}_c2_2048_bench.json 2>>$O/bench.err
-  $T python bench.py --no-cpu-baseline --no-512 --no-c4 --no-c5 --dtype f64 > $O/${R}_c3_256_f64_bench.json 2>>$O/bench.err
-  $T python bench.py --no-cpu-baseline --no-c4 --no-c5 --dtype f64 --config c3-512 > $O/${R}_c3_512_f64_bench.json 2>>$O/bench.err
+  $T python bench.py $S --no-512 --config c4 --steps 80 --warmup 2 > $O/${R}_c4_512_bench_80_iterations.json 2>>$O/bench.err
+  trace c2 c2_2048 6:25
+  $T python bench.py $S --config c2 > $O/${R}_c2_2048_bench.json 2>>$O/bench.err
+fi
+if [[ $PART == c || $PART == all ]]; then
+  $T python bench.py $S --no-512 --warmup 100 --steps 100 > $O/${R}_c3_256_bench_steady_it101_200.json 2>>$O/bench.err
+  $T python bench.py $S --config c3-512 --warmup 100 --steps 60 > $O/${R}_c3_512_bench_steady_it101_160.json 2>>$O/bench.err
+  $T python bench.py $S --no-512 --dtype f64 > $O/${R}_c3_256_f64_bench.json 2>>$O/bench.err
+  $T python bench.py $S --dtype f64 --config c3-512 > $O/${R}_c3_512_f64_bench.json 2>>$O/bench.err
   $T python tools/c5_multilevel.py 512 100 > $O/${R}_c5_512_f64_multilevel.json 2>>$O/bench.err
   $T python tools/c5_multilevel.py 512 100 model=layered > $O/${R}_c5_512_f64_multilevel_layered.json 2>>$O/bench.err
   SIPX_FORCE_DIST=1 $T python tools/c5_multilevel.py 512 100 > $O/${R}_c5_512_f64_multilevel_rccl_world1_slab.json 2>>$O/bench.err
-  SIPX_FORCE_DIST=1 $T python bench.py --no-cpu-baseline --no-c4 --no-c5 --decomp sets > $O/${R}_c3_bench_rccl_world1_sets.json 2>>$O/bench.err
-  SIPX_FORCE_DIST=1 $T python bench.py --no-cpu-baseline --no-c4 --no-c5 --decomp slab > $O/${R}_c3_bench_rccl_world1_slab.json 2>>$O/bench.err
+  SIPX_FORCE_DIST=1 $T python bench.py $S --decomp sets > $O/${R}_c3_bench_rccl_world1_sets.json 2>>$O/bench.err
+  SIPX_FORCE_DIST=1 $T python bench.py $S --decomp slab > $O/${R}_c3_bench_rccl_world1_slab.json 2>>$O/bench.err
   # one rank's share of c3 / c3-512 on eight GPUs, slab-decomposed through RCCL with one rank, the sampled prediction forced as the
   # whole grid's size would switch it on: what the iteration costs a rank before any collective has a latency
-  SIPX_L1_SAMPLE_RUNS=2048 SIPX_FORCE_DIST=1 $T python bench.py --no-cpu-baseline --no-512 --no-c4 --no-c5 --config c3-slab8 --decomp slab > $O/${R}_c3_slab8_share_rccl_world1.json 2>>$O/bench.err
-  SIPX_L1_SAMPLE_RUNS=4096 SIPX_FORCE_DIST=1 $T python bench.py --no-cpu-baseline --no-512 --no-c4 --no-c5 --config c3-512-slab8 --decomp slab > $O/${R}_c3_512_slab8_share_rccl_world1.json 2>>$O/bench.err
+  SIPX_L1_SAMPLE_RUNS=2048 SIPX_FORCE_DIST=1 $T python bench.py $S --no-512 --config c3-slab8 --decomp slab > $O/${R}_c3_slab8_share_rccl_world1.json 2>>$O/bench.err
+  SIPX_L1_SAMPLE_RUNS=4096 SIPX_FORCE_DIST=1 $T python bench.py $S --no-512 --config c3-512-slab8 --decomp slab > $O/${R}_c3_512_slab8_share_rccl_world1.json 2>>$O/bench.err
   # the slice-rank projector on slices without a spectral gap (C4's model), filtered subspace route against the full decomposition
   $T python tools/rank_flat_bench.py 512 32 12 > $O/${R}_rank_flat_512.json 2>>$O/bench.err
   $T python tools/rank_flat_bench.py 256 32 12 > $O/${R}_rank_flat_256.json 2>>$O/bench.err
-  $T python bench.py --no-cpu-baseline --no-512 --no-c4 --no-c5 --config c3-768 --steps 6 --warmup 3 > $O/${R}_c3_768_bench.json 2>>$O/bench.err
+  $T python bench.py $S --no-512 --config c3-768 --steps 6 --warmup 3 > $O/${R}_c3_768_bench.json 2>>$O/bench.err
 fi
 for f in $O/${R}_*bench*.json; do python - "$f" <<'PY'
 import json,sys
