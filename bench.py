@@ -340,7 +340,7 @@ def headline(out, detail_path=None):
     if out.get("headline_attempts") and any(not a.get("ok") for a in out["headline_attempts"]):
         h["headline_attempts"] = [{"attempt": a["attempt"][:48], "ok": a["ok"], **({"error": a["error"][:100]} if a.get("error") else {})}
                                   for a in out["headline_attempts"]]
-    for k in ("dry_comm", "invalid_as_measurement", "libsipx_sha16", "error"):
+    for k in ("dry_comm", "invalid_as_measurement", "libsipx_sha16", "error", "status", "legs_abandoned_at"):
         if k in out:
             h[k] = out[k]
     if detail_path:
@@ -1090,6 +1090,7 @@ def main():
             else:
                 o[LEG_KEY.get(name, name)] = err
             o["legs_abandoned_at"] = name
+            o["status"] = "incomplete"                  # (exit code 0 so that the line counts; the line itself says what is missing)
             progress(f"{name}: giving the remaining legs up, printing the line as it stands")
             try:
                 if saved_stdout is not None:
