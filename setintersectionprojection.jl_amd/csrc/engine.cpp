@@ -318,6 +318,14 @@ struct SetState {
   // each factorising the slices of its z-slab (`ext` is then built for the slab on every rank, owner or not)
   bool dist_ext = false;
   int owner_rank = 0;
+  // Slab-decomposed solve (round 5, the long lists: BASELINE config 4): y, l of EVERY set live on the ranks' z-slabs; a set whose
+  // projector cannot work from sums over the grid is projected on a materialised v --
+  //   slab_ext: slice-wise rank / nuclear norm on the z-slices of the identity: every rank projects the slices of its own slab,
+  //             nothing crosses the fabric;
+  //   fan:      everything else (a projector behind a transform, cardinality): rank fan_owner gathers v, projects the whole
+  //             array, scatters P(v) back (two fan exchanges of N w bytes for that set; the others stay slab-local).
+  bool slab_ext = false, fan = false;
+  int fan_owner = 0;
   ExtSpec spec;
   std::vector<T> host_basis;
   std::shared_ptr<ExtProj<T>> ext;
@@ -537,11 +545,18 @@ class Engine : public EngineBase {
     slab_ = slab_req_ && comm_ != nullptr;
     if (slab_) {
       if (mk_ || stencil_q_) throw std::runtime_error("the slab decomposition is not available for Minkowski contexts or the stencil form of Q");
+      int nfan = 0;
       for (int i = 0; i < p_n_; ++i) {
-        const SetState<T>& s = sets_[i];
-        if (s.custom || s.ext_kind || s.prox == PX_CARD)
-          throw std::runtime_error("the slab decomposition needs sets whose projector works on sums over the grid (set " + std::to_string(i) + " does not): use the set decomposition");
-        sets_[i].owned = true;
+        SetState<T>& s = sets_[i];
+        if (s.custom)
+          throw std::runtime_error("the slab decomposition has no form for a caller-supplied sparse operator (set " + std::to_string(i) + "): use the set decomposition");
+        const bool sliced = (s.ext_kind == EXT_RANK || s.ext_kind == EXT_NUCLEAR) && s.spec.mode == SIPX_MODE_SLICE &&
+                            s.spec.dir == ndim_ - 1 && s.ident;
+        if (sliced) s.slab_ext = true;
+        else if (s.ext_kind || s.prox == PX_CARD) { s.fan = true; s.fan_owner = (nfan++) % comm_->world; }
+        if (s.fan && s.nblk > 1) throw std::runtime_error("internal: a gathered set with more than one operator block");
+        slab_loose_ |= s.slab_ext || s.fan;
+        s.owned = true;
       }
       // (the searches with their collectives run on the engine stream, in one order on every rank; the y/l updates that
       // follow have no collectives inside and are dealt onto the set streams as usual)
@@ -608,6 +623,7 @@ class Engine : public EngineBase {
       sparse_wanted = vmm != 0 && !(e && e[0] == '0');
       for (const auto& st : sets_)
         if (st.prox == PX_BOUNDS_VEC || (!st.two_pass && st.nblk > 0) || !st.host_ata.empty()) sparse_wanted = false;
+      if (slab_loose_) sparse_wanted = false;            // (materialised vectors travel through the whole-size exchange layout)
     }
     if (comm_) comm_self_test(sparse_wanted);               // (every rank takes the same branch: the verdict is all-reduced)
     // Everything from here to the initial feasibility allocates and uploads -- no collective.  A rank that fails in there (out of
@@ -732,7 +748,7 @@ class Engine : public EngineBase {
         s.owner_rank = i % comm_->world;
         const bool sliced = (s.ext_kind == EXT_RANK || s.ext_kind == EXT_NUCLEAR) && s.spec.mode == SIPX_MODE_SLICE &&
                             s.spec.dir == ndim_ - 1 && s.ident;
-        if (!sliced) continue;
+        if (!sliced || slab_) continue;               // (slab-decomposed: SetState::slab_ext, no exchange at all)
         if (s.owned != (s.owner_rank == comm_->rank))
           throw std::runtime_error("a slice-wise rank / nuclear set is projected by all ranks: it needs the default set ownership (set i on rank i mod world)");
         s.dist_ext = true;
@@ -740,6 +756,7 @@ class Engine : public EngineBase {
         maxpad = std::max(maxpad, Npad);            // v travels through the padded exchange layout of x
       }
     }
+    if (slab_loose_) need_ext_ = true;              // (the feasibility estimates keep a copy of s = A x)
     if (slab_) {
       maxpad = std::max(maxpad, Npad);              // slabs of y, l are gathered through the padded exchange layout at download
       hooks_.world = comm_->world; hooks_.rank = comm_->rank; hooks_.user = comm_.get();
@@ -830,7 +847,7 @@ class Engine : public EngineBase {
         s.host_ata.clear();
         s.host_ata.shrink_to_fit();
       }
-      if (s.dist_ext && r1_ > r0_) {              // this rank's share of the slices: the projector on the slab grid
+      if ((s.dist_ext || s.slab_ext) && r1_ > r0_) {              // this rank's share of the slices: the projector on the slab grid
         ExtSpec sp = s.spec;
         const long long planes = (r1_ - r0_) / plane_;
         sp.G.n[ndim_ - 1] = planes;
@@ -855,7 +872,7 @@ class Engine : public EngineBase {
       // not of an iteration whose state has already advanced
       if (sweep_plain_ && s.in_sweep) { s.y2 = halloc(s.Mpad); s.l2 = halloc(s.Mpad); }
       if (s.custom) upload_custom(s);
-      if (s.ext_kind && !s.dist_ext) {
+      if (s.ext_kind && !s.dist_ext && !s.slab_ext && !(s.fan && s.fan_owner != comm_->rank)) {      // (a gathered set: its owner only)
         s.spec.lb = s.host_lb.empty() ? nullptr : s.host_lb.data();
         s.spec.ub = s.host_ub.empty() ? nullptr : s.host_ub.data();
         s.spec.basis = s.host_basis.empty() ? nullptr : s.host_basis.data();
@@ -1056,8 +1073,14 @@ class Engine : public EngineBase {
     feas_init_.assign(pp_n_, 0.0);
     for (int i = 0; i < pp_n_; ++i) {
       SetState<T>& s = sets_[i];
-      if (s.dist_ext) {                         // every rank: its slab of slices
+      if (s.dist_ext || s.slab_ext) {           // every rank: its slab of slices
         dist_feasibility(s, m_, part_sets_ + ((size_t)i * SLOTS + SL_FE2) * NB);
+        continue;
+      }
+      if (s.fan) {                              // the set's owner, on the gathered array
+        SetArgs<T> a = set_args(s, rho_[i], gamma_[i], 0);
+        a.x = m_;
+        fan_feasibility(s, a, part_sets_ + ((size_t)i * SLOTS + SL_FE2) * NB);
         continue;
       }
       if (!s.owned) continue;
@@ -1374,7 +1397,7 @@ class Engine : public EngineBase {
       // the gathered magnitudes of all l1 sets together; every rank then solves the same small problems (same bits).
       std::vector<int> tp;
       for (int i = 0; i < p_n_; ++i)
-        if (sets_[i].two_pass) tp.push_back(i);
+        if (sets_[i].two_pass && !sets_[i].fan) tp.push_back(i);
       if (!tp.empty()) {
         const size_t RS = (size_t)(PREP_SLOTS + 1 + 2 * comm_->world);
         const long long seg = hooks_.gcap + GATHER_HDR;
@@ -1548,7 +1571,21 @@ class Engine : public EngineBase {
         a.x = s.sbuf;
         a.flags |= F_STORE_DY;
       }
-      if (s.ext_kind) {   // library-backed projector: materialise v, project it in place, hand y to the fused update
+      if (s.slab_ext) {   // slab-decomposed, slices of the rank's own planes: nothing crosses the fabric
+        q = stream_;
+        K<T>::store_v(q, Gr_, a, 0, scr_v_);
+        if (r1_ > r0_) {
+          ObsScope obs(KID_EXT, stream_, 0.0);
+          s.ext->project(scr_v_ + r0_, false, ptmp, mpart, cbuf);
+        }
+        a.vsrc = 2;
+      } else if (s.fan) { // slab-decomposed, a projector that needs the whole array: its owner gathers v and scatters P(v)
+        q = stream_;
+        fan_collect(s, a, 0);
+        if (comm_->rank == s.fan_owner) fan_project_owner(s, false);
+        fan_return(s);
+        a.vsrc = 2;
+      } else if (s.ext_kind) {   // library-backed projector: materialise v, project it in place, hand y to the fused update
         K<T>::store_v(q, G_, a, 0, scr_v_);
         {
           ObsScope obs(KID_EXT, stream_, 0.0);
@@ -1556,7 +1593,10 @@ class Engine : public EngineBase {
         }
         a.vsrc = 2;
       }
-      if (s.two_pass && slab_) {          // (searched above, in lock step with the other sets)
+      if (s.fan) {                        // (projected above)
+        s.last_rho = a.rho;
+        s.last_gamma = a.gamma;
+      } else if (s.two_pass && slab_) {          // (searched above, in lock step with the other sets)
         s.last_rho = a.rho;
         s.last_gamma = a.gamma;
       } else if (s.two_pass) {   // threshold / scale of prox_i from one pass that produces v on the fly (nothing stored)
@@ -1576,11 +1616,13 @@ class Engine : public EngineBase {
         s.last_rho = a.rho;
         s.last_gamma = a.gamma;
       }
-      K<T>::yl(q, gy, a, part);
+      K<T>::yl(q, (s.slab_ext || (s.fan && s.ident)) ? gs : gy, a, part);      // (no adjoint stencil reads the plane below: nothing to recompute)
       if (s.custom) K<T>::csc_adj_norm(q, G_.N, s.d_colptr, s.d_rowval, s.d_nzval, s.dy, part + (size_t)SL_ADJ * NB);
       else if (!s.ident) K<T>::adj_norm(q, gs, a, part + (size_t)SL_ADJ * NB);
-      if ((flags & SIPX_YL_FEAS) && s.ext_kind && i < pp_n_) ext_feasibility(s, a, part + (size_t)SL_FE2 * NB);
-      if ((flags & SIPX_YL_FEAS) && s.two_pass && i < pp_n_) {
+      if ((flags & SIPX_YL_FEAS) && s.slab_ext && i < pp_n_) dist_feasibility(s, x_, part + (size_t)SL_FE2 * NB);
+      else if ((flags & SIPX_YL_FEAS) && s.fan && i < pp_n_) fan_feasibility(s, a, part + (size_t)SL_FE2 * NB);
+      else if ((flags & SIPX_YL_FEAS) && s.ext_kind && i < pp_n_) ext_feasibility(s, a, part + (size_t)SL_FE2 * NB);
+      if ((flags & SIPX_YL_FEAS) && s.two_pass && !s.fan && i < pp_n_) {
         // ||P_i(s) - s|| with s = A_i x produced on the fly; its own warm-started scalars (psf)
         SampleCtl cf;
         cf.host_ovf = (int*)hovf_ + i;
@@ -3167,6 +3209,16 @@ class Engine : public EngineBase {
     // one rank: searches through the batched chain (batched_searches) and how many of them needed their fallback sweeps
     o += std::string(", \"sparse_arrays\": ") + (slab_local_ ? "true" : "false");
     {
+      // slab-decomposed long lists: which sets are projected on a materialised v -- by every rank on its own slices, or by an
+      // owner rank on the gathered array -- and the fan exchanges (gathers + scatters of N w bytes) that took so far
+      std::string loc, fan;
+      for (int i = 0; i < p_n_; ++i) {
+        if (sets_[i].slab_ext) loc += (loc.empty() ? "" : ", ") + std::to_string(i);
+        if (sets_[i].fan) fan += (fan.empty() ? "" : ", ") + std::to_string(i);
+      }
+      o += ", \"slab_loose\": {\"slab_local_sets\": [" + loc + "], \"gathered_sets\": [" + fan + "], \"fan_exchanges\": " + std::to_string(fan_exchanges_) + "}";
+    }
+    {
       std::string t = selftest_;
       for (auto& ch : t) if (ch == '"' || ch == '\\' || (unsigned char)ch < 32) ch = ' ';
       o += ", \"comm_selftest\": \"" + t + "\"";
@@ -3727,6 +3779,43 @@ class Engine : public EngineBase {
     ext_dist2<T>(stream_, nloc, scr_v_ + r0_, scr_w_ + r0_, dst);
   }
 
+  // A gathered set of a slab-decomposed solve (SetState::fan).  fan_collect: every rank materialises v (v_is_s = 0) or s = A x
+  // (1) on its planes -- rows a difference operator does not have stay zero -- and the owner gathers the whole array;
+  // fan_project_owner: P in place on the owner (a library-backed projector, or the cardinality search on the array: the k-th
+  // magnitude and the tie rule by lowest padded index are those of the on-the-fly search, the zeros of the missing rows are the
+  // smallest magnitudes there are); fan_return: every rank receives its planes of P(v), and the last plane of the rank below,
+  // which the update recomputes for the adjoint stencils (Gyl_).  Engine stream, set order: the same on every rank.
+  void fan_collect(SetState<T>& s, const SetArgs<T>& a, int v_is_s) {
+    if (r1_ > r0_) SIPX_HIP(hipMemsetAsync(scr_v_ + r0_, 0, (size_t)(r1_ - r0_) * sizeof(T), stream_));
+    K<T>::store_v(stream_, Gr_, a, v_is_s, scr_v_);
+    comm_->gather(scr_v_, (size_t)chunk_, dtype_code(), s.fan_owner, stream_);
+    ++fan_exchanges_;
+  }
+  void fan_project_owner(SetState<T>& s, bool feas) {
+    ObsScope obs(KID_EXT, stream_, 0.0);
+    if (s.ext_kind) {
+      s.ext->project(scr_v_, feas, part_tmp_, maxpart_, scr_c_);
+    } else {
+      ProjScalars<T>* ps = feas ? s.psf : s.ps;
+      K<T>::proj_scalars_arr(stream_, G_.N, scr_v_, s.prox, s.plo, s.phi, ps, part_tmp_, maxpart_, scr_c_, s.Mtrue);
+      proj_apply_grid<T>(stream_, G_, s.nblk, s.dir, G_.N, scr_v_, s.prox, s.plo, s.phi, (const T*)nullptr, (const T*)nullptr, ps);
+    }
+  }
+  void fan_return(SetState<T>& s) {
+    const int dt = dtype_code();
+    comm_->scatter(scr_v_, (size_t)chunk_, dt, s.fan_owner, stream_);
+    ++fan_exchanges_;
+    if (!s.ident && r1_ > r0_ && (prev_ >= 0 || next_ >= 0))
+      comm_->halo_exchange(scr_v_ + r0_, scr_v_ + r0_ - plane_, prev_, scr_v_ + r1_ - plane_, scr_v_ + r1_, next_, (size_t)plane_, dt, stream_);
+  }
+  void fan_feasibility(SetState<T>& s, const SetArgs<T>& a, double* dst) {
+    fan_collect(s, a, 1);
+    if (comm_->rank != s.fan_owner) return;
+    SIPX_HIP(hipMemcpyAsync(scr_w_, scr_v_, (size_t)s.Mpad * sizeof(T), hipMemcpyDeviceToDevice, stream_));
+    fan_project_owner(s, true);
+    ext_dist2<T>(stream_, s.Mpad, scr_v_, scr_w_, dst);
+  }
+
   // ||P(s) - s||^2, ||s||^2 for a library-backed projector: s = A x materialised twice, one copy projected
   void ext_feasibility(SetState<T>& s, const SetArgs<T>& a, double* dst) {
     K<T>::store_v(stream_, G_, a, 1, scr_v_);
@@ -4056,6 +4145,8 @@ class Engine : public EngineBase {
   // slab decomposition of the whole iteration (sipx_set_decomp): the grids the set kernels are launched on, the collectives
   // of the threshold searches, the exchange buffer of their gathered magnitudes
   bool slab_req_ = false, slab_ = false;
+  long long fan_exchanges_ = 0;       // gathers + scatters of the gathered sets so far (stats)
+  bool slab_loose_ = false;           // slab-decomposed with sets projected on a materialised v (SetState::slab_ext, fan)
   // slab-decomposed with SPARSE arrays: every N-sized array of the context is backed by memory for the rank's planes (and the
   // halo planes around them) only -- see SparseBlock.  [wlo_, whi_): the grid points whose entries exist on this rank.
   bool slab_full_req_ = false, slab_local_ = false;

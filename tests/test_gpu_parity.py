@@ -627,6 +627,29 @@ SLAB = [
 ]
 
 
+# Round 5: the long lists inside the slab iteration.  The slice-wise rank / nuclear-norm set is projected by every rank on the
+# z-slices of its own slab (no exchange); a projector that needs the whole array (l1 behind the DFT, cardinality) by an owner rank
+# on the gathered v (two fan exchanges for that set); y, l of every set stay on the slabs.  Even, ragged and empty slabs, a
+# gathered set on D_z (its adjoint reads the plane below: one more plane of P(v) travels), BASELINE config 4's list.
+SLAB_LOOSE = [
+    (2, ["bounds", "rank:3", "l1:D_z"], (32, 24, 16)),
+    (3, ["bounds", "rank:3", "l1:D_z"], (32, 24, 16)),
+    (4, ["bounds", "nuc:z"], (12, 10, 5)),
+    (2, ["bounds", "l1dft"], (32, 24, 16)),
+    (3, ["bounds", "card:D_z", "l1:D_x"], (32, 24, 16)),
+    (4, ["bounds", "card:D_z"], (12, 10, 5)),
+    (2, ["l1dft", "card:D_z", "bounds"], (32, 24, 16)),      # two gathered sets: two owners
+    (4, C4_KINDS, (16, 12, 8)),
+    (3, ["bounds", "rank:8", "l1:D_z"], (128, 128, 6)),      # the warm-started (filtered) subspace route per rank
+]
+
+
+@pytest.mark.timeout(400)
+@pytest.mark.parametrize("world,kinds,n", SLAB_LOOSE)
+def test_slab_decomposed_long_lists(sipx, tmp_path, world, kinds, n):
+    test_sharded_ranks_on_one_gpu(sipx, tmp_path, world, kinds, n, False, decomp="slab")
+
+
 @pytest.mark.timeout(400)
 def test_slab_decomposed_in_float64(sipx, tmp_path):
     test_sharded_ranks_on_one_gpu(sipx, tmp_path, 3, ["bounds", "l1:D_x", "l1:D_z", "annulus"], (32, 24, 16), False, decomp="slab", tf="f64")
