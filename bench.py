@@ -42,6 +42,10 @@ CONFIGS = {
     # BASELINE configs[3] (SURVEY 8d "C4"): 8 constraint sets, two of them non-convex
     "c4": ((512, 512, 512), (25.0, 25.0, 25.0), ["bounds", "l1:D_x", "l1:D_y", "l1:D_z", "annulus", "l1dft", "rank:32", "card:D_z"]),
     "c4-256": ((256, 256, 256), (25.0, 25.0, 25.0), ["bounds", "l1:D_x", "l1:D_y", "l1:D_z", "annulus", "l1dft", "rank:32", "card:D_z"]),
+    # one rank's share of c4 on eight GPUs with the WHOLE iteration on z-slabs (SIPX_FORCE_DIST=1 --decomp slab): 64 of the 512 slices
+    # for the rank set; the gathered sets (l1-DFT, cardinality) at 1 / 8 of their size -- on eight GPUs their owners project the whole
+    # array while the others wait at the scatter (DESIGN 5 adds that to this figure)
+    "c4-slab8": ((512, 512, 64), (25.0, 25.0, 25.0), ["bounds", "l1:D_x", "l1:D_y", "l1:D_z", "annulus", "l1dft", "rank:32", "card:D_z"]),
     "c4-small": ((64, 64, 64), (25.0, 25.0, 25.0), ["bounds", "l1:D_x", "l1:D_y", "l1:D_z", "annulus", "l1dft", "rank:8", "card:D_z"]),
 }
 
@@ -315,6 +319,10 @@ def headline(out, detail_path=None):
         if out.get("n_gpus", 1) > 1 and v.get("comm"):
             o["comm"] = _pick(v["comm"], ("decomposition", "ranks_agree_on_x", "device_bytes_per_rank"))
         h[key] = o
+    v = out.get("c4_512_slab")
+    if isinstance(v, dict):      # (N > 1: the same list with the WHOLE iteration on z-slabs, the rank set slab-local, DFT / cardinality gathered)
+        h["c4_512_slab"] = ({"error": str(v["error"])[:160]} if "error" in v else
+                            dict(_pick(v, ("value", "ms_per_step")), **_pick(v.get("comm") or {}, ("ranks_agree_on_x", "device_bytes_per_rank"))))
     v = out.get("c2_2048")
     if isinstance(v, dict):
         h["c2_2048"] = {"error": str(v["error"])[:160]} if "error" in v else _pick(v, ("value", "ms_per_step"))
@@ -347,7 +355,7 @@ def headline(out, detail_path=None):
         h["detail"] = os.path.basename(detail_path)
     line = json.dumps(_sig(h), separators=(",", ":"))
     if len(line) >= LINE_LIMIT:                           # never again a line the driver cannot parse: shed the optional objects
-        for k in ("comm_probe_us", "c5_layered", "whole_call", "iteration_roofline", "c2_2048", "decompositions", "c4_512", "c5", "c3_512", "dominant_kernel"):
+        for k in ("comm_probe_us", "c5_layered", "whole_call", "c4_512_slab", "iteration_roofline", "c2_2048", "decompositions", "c4_512", "c5", "c3_512", "dominant_kernel"):
             h.pop(k, None)
             line = json.dumps(_sig(h), separators=(",", ":"))
             if len(line) < LINE_LIMIT:
@@ -836,7 +844,8 @@ def main():
         keep = []
         attach = None
         want = decomp or args.decomp
-        slab = (dist is not None and want != "sets" and args.q_mode == "cds" and sharded.slab_decomposable(P, A))
+        slab = (dist is not None and want != "sets" and args.q_mode == "cds" and
+                (sharded.slab_admissible(P, A) if want == "slab" else sharded.slab_decomposable(P, A)))
         if want == "slab" and dist is not None and not slab:
             raise SystemExit(f"--decomp slab: the sets of {config} cannot be decomposed by slab")
         if dist is not None:
@@ -1317,6 +1326,11 @@ def main():
         # the slice-rank set, half of the single-GPU time (94 % before its warm-started subspace route), is projected by all ranks (each its slab of slices).
         progress("c4_512 leg")
         out["c4_512"] = safe("c4_512", lambda: leg(measure("c4", 6, 2), 6, 2, full=False))
+        if dist is not None:
+            # ... and with the whole iteration on z-slabs (round 5): y, l of every set on the ranks' planes, the slice-rank set
+            # projected by every rank on its own slices, l1-DFT and cardinality by an owner rank on the gathered vector
+            progress("c4_512 leg, slab-decomposed")
+            out["c4_512_slab"] = safe("c4_512_slab", lambda: leg(measure("c4", 6, 2, decomp="slab", comm_mode=("torch" if share_gpu else None)), 6, 2, full=False))
     if args.config == "c3" and args.dtype == "f32" and args.q_mode == "cds" and not args.no_c5:
         # BASELINE configs[4]: PARSDMM_multi_level, 512^3 Float64, 3 levels, {bounds, l1:TV}, timed as ONE call
         # (examples/test_scaling_3D.jl:144-148); at N > 1 every level is slab-decomposed over the ranks.  `c5`: SURVEY 8(d)'s

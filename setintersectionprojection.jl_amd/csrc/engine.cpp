@@ -324,7 +324,9 @@ struct SetState {
   //             nothing crosses the fabric;
   //   fan:      everything else (a projector behind a transform, cardinality): rank fan_owner gathers v, projects the whole
   //             array, scatters P(v) back (two fan exchanges of N w bytes for that set; the others stay slab-local).
-  bool slab_ext = false, fan = false;
+  //   slab_card: cardinality of the whole array: a search of its own through the slab collectives (all-reduced probe counts, the
+  //             pairs inside the final bracket all-gathered: launch_chain, kernels_proj.hip), then the per-set update.
+  bool slab_ext = false, fan = false, slab_card = false;
   int fan_owner = 0;
   ExtSpec spec;
   std::vector<T> host_basis;
@@ -552,10 +554,12 @@ class Engine : public EngineBase {
           throw std::runtime_error("the slab decomposition has no form for a caller-supplied sparse operator (set " + std::to_string(i) + "): use the set decomposition");
         const bool sliced = (s.ext_kind == EXT_RANK || s.ext_kind == EXT_NUCLEAR) && s.spec.mode == SIPX_MODE_SLICE &&
                             s.spec.dir == ndim_ - 1 && s.ident;
+        const char* gc = std::getenv("SIPX_SLAB_CARD_GATHER");      // 1: cardinality through an owner rank as well (A/B switch, tests)
         if (sliced) s.slab_ext = true;
+        else if (s.prox == PX_CARD && !s.ext_kind && !(gc && gc[0] == '1')) s.slab_card = true;
         else if (s.ext_kind || s.prox == PX_CARD) { s.fan = true; s.fan_owner = (nfan++) % comm_->world; }
         if (s.fan && s.nblk > 1) throw std::runtime_error("internal: a gathered set with more than one operator block");
-        slab_loose_ |= s.slab_ext || s.fan;
+        slab_loose_ |= s.slab_ext || s.fan || s.slab_card;
         s.owned = true;
       }
       // (the searches with their collectives run on the engine stream, in one order on every rank; the y/l updates that
@@ -1397,7 +1401,7 @@ class Engine : public EngineBase {
       // the gathered magnitudes of all l1 sets together; every rank then solves the same small problems (same bits).
       std::vector<int> tp;
       for (int i = 0; i < p_n_; ++i)
-        if (sets_[i].two_pass && !sets_[i].fan) tp.push_back(i);
+        if (sets_[i].two_pass && !sets_[i].fan && !sets_[i].slab_card) tp.push_back(i);
       if (!tp.empty()) {
         const size_t RS = (size_t)(PREP_SLOTS + 1 + 2 * comm_->world);
         const long long seg = hooks_.gcap + GATHER_HDR;
@@ -1506,7 +1510,7 @@ class Engine : public EngineBase {
         // second scalar state) in lock step through the same exchange -- one all-gather for all of them -- then the distances
         std::vector<int> tf;
         for (int i = 0; i < pp_n_; ++i)
-          if (sets_[i].two_pass) tf.push_back(i);
+          if (sets_[i].two_pass && !sets_[i].fan && !sets_[i].slab_card) tf.push_back(i);
         if (!tf.empty()) {
           const long long seg = hooks_.gcap + GATHER_HDR;
           int nl1 = 0;
@@ -1529,7 +1533,7 @@ class Engine : public EngineBase {
       } else if (flags & SIPX_YL_FEAS) {
         for (int i = 0; i < pp_n_; ++i) {
           SetState<T>& s = sets_[i];
-          if (!s.two_pass) continue;
+          if (!s.two_pass || s.fan || s.slab_card) continue;
           SetArgs<T> a = set_args(s, (T)rho[i], (T)gamma[i], flags);
           SampleCtl cf;
           cf.host_ovf = (int*)hovf_ + i;
@@ -1541,10 +1545,10 @@ class Engine : public EngineBase {
       }
     }
     if (set_streams_ && slab_ && !sweep) SIPX_HIP(hipEventRecord(ev_fork_, stream_));      // the searches are done: the updates may start
-    for (int i = 0; i < p_n_ && !(slab_ && sweep); ++i) {
+    for (int i = 0; i < p_n_; ++i) {
       SetState<T>& s = sets_[i];
       if (!s.owned || s.dist_ext) continue;
-      if (loose_only && s.in_sweep) continue;             // (updated by the sweep above)
+      if ((loose_only || (slab_ && sweep)) && s.in_sweep) continue;             // (updated by the sweep above)
       if (lane_now && i == lane_set_) continue;           // (on its lane, lane_start)
       SetArgs<T> a = set_args(s, (T)rho[i], (T)gamma[i], flags);
       if (mk_) a.x = s.comp == 1 ? x_ : (s.comp == 2 ? x_ + G_.N : w_);
@@ -1596,7 +1600,7 @@ class Engine : public EngineBase {
       if (s.fan) {                        // (projected above)
         s.last_rho = a.rho;
         s.last_gamma = a.gamma;
-      } else if (s.two_pass && slab_) {          // (searched above, in lock step with the other sets)
+      } else if (s.two_pass && slab_ && !s.slab_card) {          // (searched above, in lock step with the other sets)
         s.last_rho = a.rho;
         s.last_gamma = a.gamma;
       } else if (s.two_pass) {   // threshold / scale of prox_i from one pass that produces v on the fly (nothing stored)
@@ -1672,7 +1676,7 @@ class Engine : public EngineBase {
       if ((flags & SIPX_YL_FEAS) && i < pp_n_) dist_feasibility(s, x_, part + (size_t)SL_FE2 * NB);
     }
     if (lane_now) lane_join(flags);
-    if (loose_only && rhs_fused_) {
+    if ((loose_only || (slab_ && sweep)) && rhs_fused_) {
       // the sweep wrote the sum over the sets in front of the first loose one; the rest, in order
       RhsArgs<T> ra;
       ra.nsets = 0;
@@ -1975,7 +1979,8 @@ class Engine : public EngineBase {
       if (planning ? !sweep_eligible(s) : !s.in_sweep) {
         // a set the sweep cannot take: it keeps its per-set kernels (one rank only; never a caller-supplied sparse operator,
         // whose right-hand side term is added out of order)
-        if (slab_ || comm_ || s.custom || !s.owned || s.dist_ext || (planning ? false : !sweep_partial_)) return false;
+        // (... or slab-decomposed, the sets projected on a materialised v: SetState::slab_ext, fan)
+        if ((slab_ && !(s.slab_ext || s.fan || s.slab_card)) || (comm_ && !slab_) || s.custom || !s.owned || s.dist_ext || (planning ? false : !sweep_partial_)) return false;
         behind = true;
         continue;
       }
@@ -3213,7 +3218,7 @@ class Engine : public EngineBase {
       // owner rank on the gathered array -- and the fan exchanges (gathers + scatters of N w bytes) that took so far
       std::string loc, fan;
       for (int i = 0; i < p_n_; ++i) {
-        if (sets_[i].slab_ext) loc += (loc.empty() ? "" : ", ") + std::to_string(i);
+        if (sets_[i].slab_ext || sets_[i].slab_card) loc += (loc.empty() ? "" : ", ") + std::to_string(i);
         if (sets_[i].fan) fan += (fan.empty() ? "" : ", ") + std::to_string(i);
       }
       o += ", \"slab_loose\": {\"slab_local_sets\": [" + loc + "], \"gathered_sets\": [" + fan + "], \"fan_exchanges\": " + std::to_string(fan_exchanges_) + "}";

@@ -1624,24 +1624,42 @@ __global__ __launch_bounds__(SIPX_SOLVE_NT) void k_l1_solve(ProjScalars<T>* ps, 
 constexpr double CARD_CAP = 8192.0;
 constexpr int CARD_REFINES = 5;
 
-template <typename T, int STAGE>
+// SLAB 0: one rank -- sums of the pass's partial slots, decision.  Slab-decomposed grid (round 5): SLAB 1 leaves the sums of THIS
+// rank's planes in ps->red (and its largest magnitude in its own entry of ps->mm, zeros in the others) for ONE all-reduce, SLAB 2
+// decides from the all-reduced values -- counts are sums of exact integers, the largest magnitude a maximum: every rank takes the
+// decisions a single rank would take, bit for bit.
+template <typename T, int STAGE, int SLAB = 0>
 __global__ __launch_bounds__(1024) void k_card_decide(const double* __restrict__ partials,
                                                       const T* __restrict__ maxpart, ProjScalars<T>* ps, long long k,
-                                                      long long true_len) {
-  if (STAGE == 1 && !(ps->need && ps->refine)) return;
+                                                      long long true_len, int world = 1, int rank = 0, double cap_max = CARD_CAP) {
+  if (STAGE == 1 && !(ps->need && ps->refine)) return;        // (the same verdict on every rank)
   __shared__ double red[PREP_SLOTS];
   __shared__ T smax[16];
-  reduce_slots<1024>(partials, red);
   T vmax = T(0);
-  if (STAGE == 0) {
-    for (int i = threadIdx.x; i < NB; i += 1024) vmax = maxpart[i] > vmax ? maxpart[i] : vmax;
-    vmax = wave_max<T>(vmax);
-    if ((threadIdx.x & 63) == 0) smax[threadIdx.x >> 6] = vmax;
+  if (SLAB != 2) {
+    reduce_slots<1024>(partials, red);
+    if (STAGE == 0) {
+      for (int i = threadIdx.x; i < NB; i += 1024) vmax = maxpart[i] > vmax ? maxpart[i] : vmax;
+      vmax = wave_max<T>(vmax);
+      if ((threadIdx.x & 63) == 0) smax[threadIdx.x >> 6] = vmax;
+    }
   }
   __syncthreads();
   if (threadIdx.x != 0) return;
-  if (STAGE == 0) {
+  if (SLAB != 2 && STAGE == 0)
     for (int i = 0; i < 16; ++i) vmax = smax[i] > vmax ? smax[i] : vmax;
+  if (SLAB == 1) {
+    for (int i = 0; i < PREP_SLOTS; ++i) ps->red[i] = red[i];
+    ps->ovf = 0;
+    for (int r = 0; r < 2 * world; ++r) ps->mm[r] = 0;
+    if (STAGE == 0) ps->mm[2 * rank] = (double)vmax;
+    return;
+  }
+  if (SLAB == 2) {
+    for (int i = 0; i < PREP_SLOTS; ++i) red[i] = ps->red[i];
+    for (int r = 0; r < world; ++r) vmax = (T)ps->mm[2 * r] > vmax ? (T)ps->mm[2 * r] : vmax;
+  }
+  if (STAGE == 0) {
     ps->vmax = vmax;
     ps->asum = red[0];
     ps->need = 0;
@@ -1667,7 +1685,8 @@ __global__ __launch_bounds__(1024) void k_card_decide(const double* __restrict__
   // second sweep: a probe accepted as `lo` early may lie above one accepted as `hi` later -- cannot happen,
   // C is non-increasing in t, so the accepted lo's are all below the accepted hi's.
   ps->lo = lo; ps->hi = hi; ps->c_lo = clo; ps->c_hi = chi;
-  if (clo - chi > CARD_CAP && hi > lo) {
+  // (slab-decomposed: what the bracket holds over ALL ranks has to fit one rank's exchange segment -- all of it may sit on one rank)
+  if (clo - chi > cap_max && hi > lo) {
     ps->refine = 1;
     for (int j = 0; j < L1_K; ++j) ps->t[j] = (double)(T)(lo + (hi - lo) * (double)(j + 1) / (double)(L1_K + 1));
   } else {
@@ -1735,6 +1754,50 @@ __global__ __launch_bounds__(1024) void k_card_select(ProjScalars<T>* ps, long l
     }
     ps->n_compact = 0;
   }
+}
+
+// Slab-decomposed cardinality search: every rank has gathered the (magnitude, padded index) pairs of ITS planes inside the final
+// bracket.  k_card_pack puts them into the rank's segment of the exchange buffer -- a count (-1: more than the segment holds),
+// the indices, the magnitudes -- and after the all-gather k_card_unpack strings the segments together again, in rank order; the
+// selection that follows (k_card_select: binary search on bit patterns, index cut among the ties) does not depend on the order
+// of the pairs, so every rank arrives at the tau and the index cut of a single rank.
+template <typename T>
+__global__ __launch_bounds__(BLOCK) void k_card_pack(const ProjScalars<T>* ps, const T* __restrict__ compact, char* __restrict__ seg,
+                                                     long long cap) {
+  const long long n = ps->need ? (long long)ps->n_compact : 0;
+  if (blockIdx.x == 0 && threadIdx.x == 0) reinterpret_cast<double*>(seg)[0] = n <= cap ? (double)n : -1.0;
+  if (n > cap) return;
+  long long* si = reinterpret_cast<long long*>(seg + 16);
+  T* sv = reinterpret_cast<T*>(seg + 16 + cap * 8);
+  const long long* idx = ps->cidx;
+  for (long long i = (long long)blockIdx.x * BLOCK + threadIdx.x; i < n; i += (long long)gridDim.x * BLOCK) { si[i] = idx[i]; sv[i] = compact[i]; }
+}
+template <typename T>
+__global__ __launch_bounds__(1024) void k_card_unpack(ProjScalars<T>* ps, T* __restrict__ compact, const char* __restrict__ seg0,
+                                                      long long seg_bytes, int world, long long cap, int* host_ovf) {
+  if (!ps->need) return;
+  long long off = 0;
+  bool ovf = false;
+  for (int r = 0; r < world; ++r) ovf |= reinterpret_cast<const double*>(seg0 + (long long)r * seg_bytes)[0] < 0;
+  if (ovf) {                                     // (every rank reads the same headers: the same verdict everywhere)
+    if (threadIdx.x == 0) {
+      ps->gather_overflow = 1;
+      ps->n_compact = 0;
+      if (host_ovf) __hip_atomic_store(host_ovf, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+    return;
+  }
+  long long* idx = ps->cidx;
+  for (int r = 0; r < world; ++r) {
+    const char* seg = seg0 + (long long)r * seg_bytes;
+    const long long n = (long long)reinterpret_cast<const double*>(seg)[0];
+    const long long* si = reinterpret_cast<const long long*>(seg + 16);
+    const T* sv = reinterpret_cast<const T*>(seg + 16 + cap * 8);
+    for (long long i = threadIdx.x; i < n; i += 1024) { idx[off + i] = si[i]; compact[off + i] = sv[i]; }
+    off += n;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) ps->n_compact = (unsigned long long)off;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -2232,7 +2295,6 @@ template <typename T, int SRC>
 static void launch_chain(hipStream_t s, const Grid& g, const SetArgs<T>& a, int v_is_s, const T* varr, long long len,
                          ProjScalars<T>* ps, double* partials, T* maxpart, T* compact, long long true_len,
                          SampleCtl ctl = SampleCtl(), const ChainHooks* hk = nullptr, long long compact_len = 0) {
-  if (hk && a.prox == PX_CARD) throw std::runtime_error("the cardinality search is not available on a slab-decomposed grid");
   if (a.prox == PX_CARD) {
     const bool vec = SRC == 1 && g.n[0] % 4 == 0;
 #define SIPX_PASS(MODE)                                                                                            \
@@ -2246,6 +2308,40 @@ static void launch_chain(hipStream_t s, const Grid& g, const SetArgs<T>& a, int 
                          partials, maxpart);                                                                       \
   } while (0)
     const long long kc = (long long)a.phi;
+    if (hk) {
+      // slab-decomposed grid (round 5): every rank passes over its planes; one all-reduce per decision makes the probe counts
+      // global, one all-gather strings the (magnitude, index) pairs inside the final bracket together; the same rounds on every rank
+      const int world = hk->world, rank = hk->rank;
+      const long long seg_T = hk->gcap + GATHER_HDR, seg_bytes = seg_T * (long long)sizeof(T);
+      const long long cap = std::min<long long>(1ll << 16, (seg_bytes - 16) / (8 + (long long)sizeof(T)));
+      if (cap < 1) throw std::runtime_error("the exchange segments are too small for a cardinality search");
+      char* gb = static_cast<char*>(hk->gbuf);
+      double* reg = ps->red;
+      const size_t nreg = (size_t)(PREP_SLOTS + 1 + 2 * world);
+      SIPX_PASS(M_FIRST);
+      { ObsScope obs_(KID_CARD, s, 0.0); hipLaunchKernelGGL((k_card_decide<T, 0, 1>), dim3(1), dim3(1024), 0, s, partials, maxpart, ps, kc, true_len, world, rank, (double)std::min<long long>((long long)CARD_CAP, cap)); }
+      hk->allreduce_sum(hk->user, reg, nreg, s);
+      { ObsScope obs_(KID_CARD, s, 0.0); hipLaunchKernelGGL((k_card_decide<T, 0, 2>), dim3(1), dim3(1024), 0, s, partials, maxpart, ps, kc, true_len, world, rank, (double)std::min<long long>((long long)CARD_CAP, cap)); }
+      for (int r = 0; r < CARD_REFINES; ++r) {
+        SIPX_PASS(M_PROBE);
+        { ObsScope obs_(KID_CARD, s, 0.0); hipLaunchKernelGGL((k_card_decide<T, 1, 1>), dim3(1), dim3(1024), 0, s, partials, maxpart, ps, kc, true_len, world, rank, (double)std::min<long long>((long long)CARD_CAP, cap)); }
+        hk->allreduce_sum(hk->user, reg, (size_t)PREP_SLOTS, s);
+        { ObsScope obs_(KID_CARD, s, 0.0); hipLaunchKernelGGL((k_card_decide<T, 1, 2>), dim3(1), dim3(1024), 0, s, partials, maxpart, ps, kc, true_len, world, rank, (double)std::min<long long>((long long)CARD_CAP, cap)); }
+      }
+      SIPX_PASS(M_COMPACT);
+      {
+        ObsScope obs_(KID_GATHER, s, 0.0);
+        hipLaunchKernelGGL((k_card_pack<T>), dim3(16), dim3(BLOCK), 0, s, ps, compact, gb + (long long)rank * seg_bytes, cap);
+      }
+      hk->allgather(hk->user, gb, (size_t)seg_T, sizeof(T) == 8 ? 1 : 0, s);
+      {
+        ObsScope obs_(KID_GATHER, s, 0.0);
+        hipLaunchKernelGGL((k_card_unpack<T>), dim3(1), dim3(1024), 0, s, ps, compact, gb, seg_bytes, world, cap, ctl.host_ovf);
+      }
+      { ObsScope obs_(KID_CARD, s, 0.0); hipLaunchKernelGGL((k_card_select<T>), dim3(1), dim3(1024), 0, s, ps, kc, compact); }
+      SIPX_HIP(hipGetLastError());
+      return;
+    }
     SIPX_PASS(M_FIRST);
     { ObsScope obs_(KID_CARD, s, 0.0); hipLaunchKernelGGL((k_card_decide<T, 0>), dim3(1), dim3(1024), 0, s, partials, maxpart, ps, kc, true_len); }
     for (int r = 0; r < CARD_REFINES; ++r) {

@@ -355,12 +355,26 @@ def slab_decomposable(P_sub, TD_OP) -> bool:
     return True
 
 
+def slab_admissible(P_sub, TD_OP) -> bool:
+    """Does the slab decomposition TAKE this list (round 5)?  Beyond the lists of `slab_decomposable`: a slice-wise rank /
+    nuclear-norm set on the z-slices of the identity (every rank projects the slices of its own slab) and sets whose projector
+    needs the whole array -- l1 / bounds behind the DFT, cardinality, the DCT sets, histogram, subspace -- which an owner rank
+    projects on the gathered vector (two fan exchanges of N w bytes per such set and iteration).  Not taken: caller-supplied
+    sparse operators, Minkowski components (the engine says so at sipx_finalize)."""
+    ok_ops = {"identity", "D_x", "D_y", "D_z", "TV", "D2D", "D3D"}
+    for P, A in zip(P_sub, TD_OP):
+        if getattr(A, "kind", None) not in ok_ops or getattr(A, "component", 0) != 0:
+            return False
+    return True
+
+
 def PARSDMM_sharded(m, AtA, TD_OP, set_Prop, P_sub, comp_grid, options, dist=None, device=0, x=None, l=None, y=None,
                     comm_mode: Optional[str] = None, phase_driver: bool = False, decomp: str = "sets"):
     """PARSDMM as one rank of a sharded solve over ``dist`` (torch.distributed, one process per GPU).  Returns
     (x, log, l, y); x and the log are complete and identical on every rank.  decomp "sets": the reference's split by
     constraint set -- l / y hold the locally owned sets (zeros elsewhere); "slab": every rank works on its z-slab of every
-    set (sipx.h, sipx_set_decomp) -- l / y are complete on every rank; "auto": "slab" where the sets allow it.
+    set (sipx.h, sipx_set_decomp) -- l / y are complete on every rank; "auto": "slab" where every projector works from sums
+    over the grid (`slab_decomposable`; a list with gathered sets, `slab_admissible`, is slab-decomposed when asked for).
     phase_driver=True runs the loop over the phase entry points instead of sipx_parsdmm."""
     from .host import build_context, set_default_device
     world = dist.get_world_size() if dist is not None else 1

@@ -628,9 +628,10 @@ SLAB = [
 
 
 # Round 5: the long lists inside the slab iteration.  The slice-wise rank / nuclear-norm set is projected by every rank on the
-# z-slices of its own slab (no exchange); a projector that needs the whole array (l1 behind the DFT, cardinality) by an owner rank
-# on the gathered v (two fan exchanges for that set); y, l of every set stay on the slabs.  Even, ragged and empty slabs, a
-# gathered set on D_z (its adjoint reads the plane below: one more plane of P(v) travels), BASELINE config 4's list.
+# z-slices of its own slab (no exchange); cardinality through a search of its own over the slab collectives (all-reduced probe
+# counts, the pairs inside the final bracket all-gathered); a projector that needs the whole array (l1 behind the DFT) by an owner
+# rank on the gathered v (two fan exchanges for that set); y, l of every set stay on the slabs.  Even, ragged and empty slabs,
+# BASELINE config 4's list.
 SLAB_LOOSE = [
     (2, ["bounds", "rank:3", "l1:D_z"], (32, 24, 16)),
     (3, ["bounds", "rank:3", "l1:D_z"], (32, 24, 16)),
@@ -638,7 +639,8 @@ SLAB_LOOSE = [
     (2, ["bounds", "l1dft"], (32, 24, 16)),
     (3, ["bounds", "card:D_z", "l1:D_x"], (32, 24, 16)),
     (4, ["bounds", "card:D_z"], (12, 10, 5)),
-    (2, ["l1dft", "card:D_z", "bounds"], (32, 24, 16)),      # two gathered sets: two owners
+    (2, ["l1dft", "card:D_z", "bounds"], (32, 24, 16)),
+    (2, ["bounds", "card:identity"], (64, 48)),             # 2-D, the identity
     (4, C4_KINDS, (16, 12, 8)),
     (3, ["bounds", "rank:8", "l1:D_z"], (128, 128, 6)),      # the warm-started (filtered) subspace route per rank
 ]
@@ -647,6 +649,15 @@ SLAB_LOOSE = [
 @pytest.mark.timeout(400)
 @pytest.mark.parametrize("world,kinds,n", SLAB_LOOSE)
 def test_slab_decomposed_long_lists(sipx, tmp_path, world, kinds, n):
+    test_sharded_ranks_on_one_gpu(sipx, tmp_path, world, kinds, n, False, decomp="slab")
+
+
+@pytest.mark.timeout(400)
+@pytest.mark.parametrize("world,kinds,n", [(3, ["bounds", "card:D_z", "l1:D_x"], (32, 24, 16)), (4, ["bounds", "card:D_z"], (12, 10, 5))])
+def test_slab_cardinality_through_an_owner_rank(sipx, tmp_path, monkeypatch, world, kinds, n):
+    """The gathered form of a set on D_z (SIPX_SLAB_CARD_GATHER=1: cardinality projected by an owner rank on the whole array instead
+    of the search through the slab collectives): one more plane of P(v) travels for the adjoint stencil; ragged and empty slabs."""
+    monkeypatch.setenv("SIPX_SLAB_CARD_GATHER", "1")
     test_sharded_ranks_on_one_gpu(sipx, tmp_path, world, kinds, n, False, decomp="slab")
 
 
