@@ -322,7 +322,8 @@ def headline(out, detail_path=None):
     v = out.get("c4_512_slab")
     if isinstance(v, dict):      # (N > 1: the same list with the WHOLE iteration on z-slabs, the rank set slab-local, DFT / cardinality gathered)
         h["c4_512_slab"] = ({"error": str(v["error"])[:160]} if "error" in v else
-                            dict(_pick(v, ("value", "ms_per_step")), **_pick(v.get("comm") or {}, ("ranks_agree_on_x", "device_bytes_per_rank"))))
+                            dict(_pick(v, ("value", "ms_per_step")), **_pick(v.get("comm") or {}, ("ranks_agree_on_x", "device_bytes_per_rank")),
+                                 collectives_per_step=((v.get("comm") or {}).get("collectives_per_step") or {}).get("total")))
     v = out.get("c2_2048")
     if isinstance(v, dict):
         h["c2_2048"] = {"error": str(v["error"])[:160]} if "error" in v else _pick(v, ("value", "ms_per_step"))
@@ -862,6 +863,15 @@ def main():
             mid_hook()
         restore_stdout()
         ctx.kernel_stats(True)
+
+        def collective_counts():            # the engine's own counters of the calls it made on its communicator (read-only)
+            if dist is None:
+                return None
+            try:
+                return ctx.kernel_stats_all(-1).get("collectives")
+            except Exception:
+                return None
+        coll0 = collective_counts()
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
@@ -884,6 +894,11 @@ def main():
         if world > 1:
             dist.barrier()
         dt = time.perf_counter() - t0
+        coll1 = collective_counts()
+        coll_per_step = None
+        if coll0 and coll1:
+            coll_per_step = {k: round((coll1[k] - coll0.get(k, 0)) / max(steps, 1), 2) for k in coll1}
+            coll_per_step["total"] = round(sum(coll_per_step.values()), 2)
         # the product of the CG iteration over the timed steps; then EVERY kernel over a window of its own (two event records
         # around each launch cost about 5 us: not something to have inside the timed region)
         want_table = not ended and not args.no_kernel_table
@@ -1009,6 +1024,9 @@ def main():
                      # the rank's planes only (hipMemMap-backed sparse arrays) or whole arrays; the verdict of sipx_finalize's
                      # communicator self-test; which communicator carried the collectives
                      "sparse_arrays": counters.get("sparse_arrays"), "comm_selftest": counters.get("comm_selftest"),
+                     # calls the engine made on its communicator per timed step, by kind (scatter_gather: the fan exchanges of the
+                     # gathered sets of a slab-decomposed long list); which sets of such a list are slab-local / gathered
+                     "collectives_per_step": coll_per_step, "slab_loose": counters.get("slab_loose"),
                      "comm_mode": (comm_mode or os.environ.get("SIPX_COMM") or ("rccl" if dist.get_backend() == "nccl" else "torch")) if dist is not None else None,
                      # what this context allocated on its GPU (slab-decomposed: the rank's planes + halo planes only)
                      "device_bytes_per_rank": dev_bytes["context"], "device_used_bytes": dev_bytes["device_used"]},

@@ -44,6 +44,32 @@ struct Comm {
   virtual void gather(void* buf, size_t chunk, int dtype, int root, hipStream_t s) = 0;
 };
 
+// Forwards every operation to the communicator it wraps and counts the calls by kind (the engine reports them in its statistics:
+// how many collectives an iteration of a decomposition issues is the first thing its scaling depends on).
+struct CountingComm : Comm {
+  Comm* inner;
+  long long n_allreduce = 0, n_reduce_scatter = 0, n_allgather = 0, n_halo = 0, n_grouped = 0, n_fan = 0;
+  explicit CountingComm(Comm* c) : inner(c) { world = c->world; rank = c->rank; }
+  ~CountingComm() override { delete inner; }
+  const char* kind() const override { return inner->kind(); }
+  void info(int* nranks, int* rank_out, char* version, size_t version_len) const override { inner->info(nranks, rank_out, version, version_len); }
+  void allreduce_sum(void* buf, size_t count, int dtype, hipStream_t s) override { ++n_allreduce; inner->allreduce_sum(buf, count, dtype, s); }
+  void reduce_scatter_sum(void* buf, size_t chunk, int dtype, hipStream_t s) override { ++n_reduce_scatter; inner->reduce_scatter_sum(buf, chunk, dtype, s); }
+  void allgather(void* buf, size_t chunk, int dtype, hipStream_t s) override { ++n_allgather; inner->allgather(buf, chunk, dtype, s); }
+  void halo_exchange(const void* send_prev, void* recv_prev, int prev, const void* send_next, void* recv_next, int next, size_t count, int dtype,
+                     hipStream_t s) override {
+    ++n_halo;
+    inner->halo_exchange(send_prev, recv_prev, prev, send_next, recv_next, next, count, dtype, s);
+  }
+  void allreduce_with_halo(void* buf, size_t count, int red_dtype, const void* send_prev, void* recv_prev, int prev, const void* send_next,
+                           void* recv_next, int next, size_t hcount, int hdtype, hipStream_t s) override {
+    ++n_grouped;
+    inner->allreduce_with_halo(buf, count, red_dtype, send_prev, recv_prev, prev, send_next, recv_next, next, hcount, hdtype, s);
+  }
+  void scatter(void* buf, size_t chunk, int dtype, int root, hipStream_t s) override { ++n_fan; inner->scatter(buf, chunk, dtype, root, s); }
+  void gather(void* buf, size_t chunk, int dtype, int root, hipStream_t s) override { ++n_fan; inner->gather(buf, chunk, dtype, root, s); }
+};
+
 Comm* make_rccl_comm(const void* unique_id, int world, int rank);
 void rccl_unique_id(void* out128);
 Comm* make_callback_comm(const sipx_comm* cb);

@@ -328,6 +328,9 @@ struct SetState {
   //             pairs inside the final bracket all-gathered: launch_chain, kernels_proj.hip), then the per-set update.
   bool slab_ext = false, fan = false, slab_card = false;
   int fan_owner = 0;
+  bool fan_on_side = false;          // this update's projection was queued on the fan stream
+  T* fanv = nullptr;                 // a gathered set's own whole-size vector (v, then P(v)): its owner projects it on the fan stream
+  hipEvent_t fan_ev = nullptr;       // ... and records this when P(v) is ready
   ExtSpec spec;
   std::vector<T> host_basis;
   std::shared_ptr<ExtProj<T>> ext;
@@ -391,6 +394,9 @@ class Engine : public EngineBase {
     if (lane_st_) { (void)hipStreamSynchronize(lane_st_); (void)hipStreamDestroy(lane_st_); }
     for (hipEvent_t e : {lane_fork_, lane_ev_}) if (e) (void)hipEventDestroy(e);
     dfree(lane_v_);
+    if (fan_st_) { (void)hipStreamSynchronize(fan_st_); (void)hipStreamDestroy(fan_st_); }
+    if (fan_fork_) (void)hipEventDestroy(fan_fork_);
+    for (void* p : {(void*)fan_ptmp_, (void*)fan_mpart_, (void*)fan_c_}) dfree(p);
     (void)hipStreamSynchronize(stream_);
     for (auto& s : sets_) free_set(s);
     for (void* p : {(void*)xr_base_[0], (void*)xr_base_[1], (void*)xr_base_[2], (void*)w_base_, (void*)rhs_, (void*)m_base_, (void*)r_base_, (void*)p_base_, (void*)p2_base_, (void*)Ap_, (void*)Q_, (void*)Q2_,
@@ -466,7 +472,8 @@ class Engine : public EngineBase {
   void set_comm(Comm* c) override {
     std::unique_ptr<Comm> hold(c);
     if (finalized_) throw std::runtime_error("the communicator must be attached before sipx_finalize");
-    comm_ = std::move(hold);
+    counting_ = c ? new CountingComm(hold.release()) : nullptr;      // (owns c)
+    comm_.reset(counting_);
   }
   void comm_info(int* nranks, int* rank, char* version, int version_len, int* decomposition) override {
     if (version && version_len > 0) version[0] = 0;
@@ -554,6 +561,7 @@ class Engine : public EngineBase {
           throw std::runtime_error("the slab decomposition has no form for a caller-supplied sparse operator (set " + std::to_string(i) + "): use the set decomposition");
         const bool sliced = (s.ext_kind == EXT_RANK || s.ext_kind == EXT_NUCLEAR) && s.spec.mode == SIPX_MODE_SLICE &&
                             s.spec.dir == ndim_ - 1 && s.ident;
+        if (const char* fo = std::getenv("SIPX_FAN_OVERLAP")) fan_overlap_ = fo[0] != '0';
         const char* gc = std::getenv("SIPX_SLAB_CARD_GATHER");      // 1: cardinality through an owner rank as well (A/B switch, tests)
         if (sliced) s.slab_ext = true;
         else if (s.prox == PX_CARD && !s.ext_kind && !(gc && gc[0] == '1')) s.slab_card = true;
@@ -884,6 +892,19 @@ class Engine : public EngineBase {
         if (s.ext_kind == EXT_HISTOGRAM) { s.host_lb.clear(); s.host_ub.clear(); }
         s.host_basis.clear();
         s.host_basis.shrink_to_fit();
+      }
+      if (s.fan) {
+        // the gathered sets are collected FIRST in an update (update_y_l), their owners project on a stream of their own while
+        // every rank goes on with the sets of its own slab: each such set keeps its own whole-size vector, the fan stream its scratch
+        s.fanv = dalloc<T>(maxpad);
+        SIPX_HIP(hipEventCreateWithFlags(&s.fan_ev, hipEventDisableTiming));
+        if (s.fan_owner == comm_->rank && !fan_st_) {
+          SIPX_HIP(hipStreamCreateWithFlags(&fan_st_, hipStreamNonBlocking));
+          SIPX_HIP(hipEventCreateWithFlags(&fan_fork_, hipEventDisableTiming));
+          fan_ptmp_ = dalloc<double>((size_t)(PREP_SLOTS + 2) * NB);
+          fan_mpart_ = dalloc<T>(2 * NB);
+          fan_c_ = dalloc<T>(maxpad);
+        }
       }
       if (s.two_pass) {
         s.ps = dalloc<ProjScalars<T>>(1);
@@ -1545,6 +1566,8 @@ class Engine : public EngineBase {
       }
     }
     if (set_streams_ && slab_ && !sweep) SIPX_HIP(hipEventRecord(ev_fork_, stream_));      // the searches are done: the updates may start
+    for (int i = 0; i < p_n_ && slab_loose_; ++i)          // the gathered sets first: their owners project beside what follows
+      if (sets_[i].fan) fan_begin(sets_[i], set_args(sets_[i], (T)rho[i], (T)gamma[i], flags));
     for (int i = 0; i < p_n_; ++i) {
       SetState<T>& s = sets_[i];
       if (!s.owned || s.dist_ext) continue;
@@ -1583,11 +1606,10 @@ class Engine : public EngineBase {
           s.ext->project(scr_v_ + r0_, false, ptmp, mpart, cbuf);
         }
         a.vsrc = 2;
-      } else if (s.fan) { // slab-decomposed, a projector that needs the whole array: its owner gathers v and scatters P(v)
-        q = stream_;
-        fan_collect(s, a, 0);
-        if (comm_->rank == s.fan_owner) fan_project_owner(s, false);
+      } else if (s.fan) { // slab-decomposed, a projector that needs the whole array: its owner has gathered v (fan_begin, in front of
+        q = stream_;      // this loop) and scatters P(v)
         fan_return(s);
+        a.v = s.fanv;
         a.vsrc = 2;
       } else if (s.ext_kind) {   // library-backed projector: materialise v, project it in place, hand y to the fused update
         K<T>::store_v(q, G_, a, 0, scr_v_);
@@ -3221,6 +3243,10 @@ class Engine : public EngineBase {
         if (sets_[i].slab_ext || sets_[i].slab_card) loc += (loc.empty() ? "" : ", ") + std::to_string(i);
         if (sets_[i].fan) fan += (fan.empty() ? "" : ", ") + std::to_string(i);
       }
+      if (counting_)
+        o += ", \"collectives\": {\"allreduce\": " + std::to_string(counting_->n_allreduce) + ", \"allreduce_with_halo\": " + std::to_string(counting_->n_grouped) +
+             ", \"allgather\": " + std::to_string(counting_->n_allgather) + ", \"reduce_scatter\": " + std::to_string(counting_->n_reduce_scatter) +
+             ", \"halo\": " + std::to_string(counting_->n_halo) + ", \"scatter_gather\": " + std::to_string(counting_->n_fan) + "}";
       o += ", \"slab_loose\": {\"slab_local_sets\": [" + loc + "], \"gathered_sets\": [" + fan + "], \"fan_exchanges\": " + std::to_string(fan_exchanges_) + "}";
     }
     {
@@ -3790,34 +3816,55 @@ class Engine : public EngineBase {
   // magnitude and the tie rule by lowest padded index are those of the on-the-fly search, the zeros of the missing rows are the
   // smallest magnitudes there are); fan_return: every rank receives its planes of P(v), and the last plane of the rank below,
   // which the update recomputes for the adjoint stencils (Gyl_).  Engine stream, set order: the same on every rank.
-  void fan_collect(SetState<T>& s, const SetArgs<T>& a, int v_is_s) {
-    if (r1_ > r0_) SIPX_HIP(hipMemsetAsync(scr_v_ + r0_, 0, (size_t)(r1_ - r0_) * sizeof(T), stream_));
-    K<T>::store_v(stream_, Gr_, a, v_is_s, scr_v_);
-    comm_->gather(scr_v_, (size_t)chunk_, dtype_code(), s.fan_owner, stream_);
+  // In an update the gathered sets come FIRST (fan_begin: collect, the owner projects on the fan stream, which waits for the
+  // gather), then every rank's own sets on the engine stream, and only then the scatters (fan_return waits for the fan stream): an
+  // owner's whole-array projection runs beside its share of the slab-local sets instead of in front of everybody's.
+  void fan_collect(SetState<T>& s, const SetArgs<T>& a, int v_is_s, T* buf) {
+    if (r1_ > r0_) SIPX_HIP(hipMemsetAsync(buf + r0_, 0, (size_t)(r1_ - r0_) * sizeof(T), stream_));
+    SetArgs<T> b = a;
+    b.v = buf;
+    K<T>::store_v(stream_, Gr_, b, v_is_s, buf);
+    comm_->gather(buf, (size_t)chunk_, dtype_code(), s.fan_owner, stream_);
     ++fan_exchanges_;
   }
-  void fan_project_owner(SetState<T>& s, bool feas) {
-    ObsScope obs(KID_EXT, stream_, 0.0);
+  void fan_project_owner(SetState<T>& s, bool feas, T* buf, hipStream_t q, double* ptmp, T* mpart, T* cbuf) {
+    ObsScope obs(KID_EXT, q, 0.0);
     if (s.ext_kind) {
-      s.ext->project(scr_v_, feas, part_tmp_, maxpart_, scr_c_);
+      s.ext->set_stream(q);
+      s.ext->project(buf, feas, ptmp, mpart, cbuf);
     } else {
       ProjScalars<T>* ps = feas ? s.psf : s.ps;
-      K<T>::proj_scalars_arr(stream_, G_.N, scr_v_, s.prox, s.plo, s.phi, ps, part_tmp_, maxpart_, scr_c_, s.Mtrue);
-      proj_apply_grid<T>(stream_, G_, s.nblk, s.dir, G_.N, scr_v_, s.prox, s.plo, s.phi, (const T*)nullptr, (const T*)nullptr, ps);
+      K<T>::proj_scalars_arr(q, G_.N, buf, s.prox, s.plo, s.phi, ps, ptmp, mpart, cbuf, s.Mtrue);
+      proj_apply_grid<T>(q, G_, s.nblk, s.dir, G_.N, buf, s.prox, s.plo, s.phi, (const T*)nullptr, (const T*)nullptr, ps);
     }
+  }
+  void fan_begin(SetState<T>& s, const SetArgs<T>& a) {
+    fan_collect(s, a, 0, s.fanv);
+    if (comm_->rank != s.fan_owner) return;
+    // (the all-kernel statistics window times one kernel at a time on the engine stream: in turn there)
+    hipStream_t q = (fan_st_ && stats_mode_ != 2 && fan_overlap_) ? fan_st_ : stream_;
+    if (q != stream_) {
+      SIPX_HIP(hipEventRecord(fan_fork_, stream_));
+      SIPX_HIP(hipStreamWaitEvent(q, fan_fork_, 0));
+    }
+    fan_project_owner(s, false, s.fanv, q, q == stream_ ? part_tmp_ : fan_ptmp_, q == stream_ ? maxpart_ : fan_mpart_, q == stream_ ? scr_c_ : fan_c_);
+    if (q != stream_) SIPX_HIP(hipEventRecord(s.fan_ev, q));
+    s.fan_on_side = q != stream_;
   }
   void fan_return(SetState<T>& s) {
     const int dt = dtype_code();
-    comm_->scatter(scr_v_, (size_t)chunk_, dt, s.fan_owner, stream_);
+    T* buf = s.fanv;
+    if (s.fan_on_side) { SIPX_HIP(hipStreamWaitEvent(stream_, s.fan_ev, 0)); s.fan_on_side = false; }
+    comm_->scatter(buf, (size_t)chunk_, dt, s.fan_owner, stream_);
     ++fan_exchanges_;
     if (!s.ident && r1_ > r0_ && (prev_ >= 0 || next_ >= 0))
-      comm_->halo_exchange(scr_v_ + r0_, scr_v_ + r0_ - plane_, prev_, scr_v_ + r1_ - plane_, scr_v_ + r1_, next_, (size_t)plane_, dt, stream_);
+      comm_->halo_exchange(buf + r0_, buf + r0_ - plane_, prev_, buf + r1_ - plane_, buf + r1_, next_, (size_t)plane_, dt, stream_);
   }
   void fan_feasibility(SetState<T>& s, const SetArgs<T>& a, double* dst) {
-    fan_collect(s, a, 1);
+    fan_collect(s, a, 1, scr_v_);
     if (comm_->rank != s.fan_owner) return;
     SIPX_HIP(hipMemcpyAsync(scr_w_, scr_v_, (size_t)s.Mpad * sizeof(T), hipMemcpyDeviceToDevice, stream_));
-    fan_project_owner(s, true);
+    fan_project_owner(s, true, scr_v_, stream_, part_tmp_, maxpart_, scr_c_);
     ext_dist2<T>(stream_, s.Mpad, scr_v_, scr_w_, dst);
   }
 
@@ -4014,6 +4061,8 @@ class Engine : public EngineBase {
   void free_set(SetState<T>& s) {
     if (s.st) (void)hipStreamSynchronize(s.st);
     if (s.ev) (void)hipEventDestroy(s.ev);
+    if (s.fan_ev) (void)hipEventDestroy(s.fan_ev);
+    dfree(s.fanv);
     for (void* p : {(void*)s.ptmp, (void*)s.mpart, (void*)s.cbuf, (void*)s.d_colptr, (void*)s.d_rowval, (void*)s.d_rowptr,
                     (void*)s.d_colidx, (void*)s.d_nzval, (void*)s.d_rval, (void*)s.sbuf})
       dfree(p);
@@ -4120,6 +4169,7 @@ class Engine : public EngineBase {
   hipEvent_t sums_event_ = nullptr;
   // sharded solve: communicator, this rank's slab [r0_, r1_) of the x-step, rows of Q it maintains
   std::unique_ptr<Comm> comm_;
+  CountingComm* counting_ = nullptr;   // comm_ itself, with its call counters
   long long plane_ = 0, chunk_ = 0, r0_ = 0, r1_ = 0, qr0_ = 0, qr1_ = 0;
   int prev_ = -1, next_ = -1;
   hipStream_t cstream_ = nullptr;           // communication stream: the reduce-scatter of rhs runs beside the engine stream
@@ -4150,7 +4200,12 @@ class Engine : public EngineBase {
   // slab decomposition of the whole iteration (sipx_set_decomp): the grids the set kernels are launched on, the collectives
   // of the threshold searches, the exchange buffer of their gathered magnitudes
   bool slab_req_ = false, slab_ = false;
+  hipStream_t fan_st_ = nullptr;      // the stream a gathered set's owner projects on (beside the engine stream)
+  hipEvent_t fan_fork_ = nullptr;
+  double* fan_ptmp_ = nullptr;
+  T *fan_mpart_ = nullptr, *fan_c_ = nullptr;
   long long fan_exchanges_ = 0;       // gathers + scatters of the gathered sets so far (stats)
+  bool fan_overlap_ = true;           // SIPX_FAN_OVERLAP=0: the owner projects in turn on the engine stream (A/B switch)
   bool slab_loose_ = false;           // slab-decomposed with sets projected on a materialised v (SetState::slab_ext, fan)
   // slab-decomposed with SPARSE arrays: every N-sized array of the context is backed by memory for the rank's planes (and the
   // halo planes around them) only -- see SparseBlock.  [wlo_, whi_): the grid points whose entries exist on this rank.
