@@ -95,6 +95,16 @@ if [[ $PART == c || $PART == all ]]; then
   # whole grid's size would switch it on: what the iteration costs a rank before any collective has a latency
   SIPX_L1_SAMPLE_RUNS=2048 SIPX_FORCE_DIST=1 $T python bench.py $S --no-512 --config c3-slab8 --decomp slab > $O/${R}_c3_slab8_share_rccl_world1.json 2>>$O/bench.err
   SIPX_L1_SAMPLE_RUNS=4096 SIPX_FORCE_DIST=1 $T python bench.py $S --no-512 --config c3-512-slab8 --decomp slab > $O/${R}_c3_512_slab8_share_rccl_world1.json 2>>$O/bench.err
+  # BASELINE config 4's list with the WHOLE iteration on z-slabs (round 5): through RCCL with one rank at full size, and a rank's
+  # share of eight (512 x 512 x 64: 64 slices for the rank set, every other set at 1 / 8); the same share over 40 iterations
+  SIPX_FORCE_DIST=1 $T python bench.py $S --no-512 --config c4 --decomp slab --steps 6 --warmup 2 > $O/${R}_c4_512_slab_rccl_world1.json 2>>$O/bench.err
+  SIPX_FORCE_DIST=1 $T python bench.py $S --no-512 --config c4 --decomp sets --steps 6 --warmup 2 > $O/${R}_c4_512_sets_rccl_world1.json 2>>$O/bench.err
+  SIPX_FORCE_DIST=1 $T python bench.py $S --no-512 --config c4-slab8 --decomp slab --steps 6 --warmup 2 --detail $O/${R}_c4_slab8_share_rccl_world1_detail.json > $O/${R}_c4_slab8_share_rccl_world1.json 2>>$O/bench.err
+  SIPX_FORCE_DIST=1 $T python bench.py $S --no-512 --config c4-slab8 --decomp slab --steps 40 --warmup 2 > $O/${R}_c4_slab8_share_rccl_world1_40its.json 2>>$O/bench.err
+  # a chain of dependent small kernels, launched one by one and as a captured graph: what a launch-bound iteration (2048^2) can gain
+  if [ -x scratch/launch_gap_bench ]; then $T scratch/launch_gap_bench > $O/${R}_launch_gap.txt 2>&1; fi
+  # NOT a measurement: the N > 1 flow of the whole bench with four ranks on this one GPU (headline chain, every leg incl. c4_512_slab)
+  SIPX_BENCH_SHARE_GPU=1 timeout -k 10 700 python bench.py --gpus 4 --no-c5 --no-512 --detail $O/${R}_bench_4ranks_share_one_gpu_rehearsal_detail.json > $O/${R}_bench_4ranks_share_one_gpu_rehearsal.json 2>>$O/bench.err
   # the slice-rank projector on slices without a spectral gap (C4's model), filtered subspace route against the full decomposition
   $T python tools/rank_flat_bench.py 512 32 12 > $O/${R}_rank_flat_512.json 2>>$O/bench.err
   $T python tools/rank_flat_bench.py 256 32 12 > $O/${R}_rank_flat_256.json 2>>$O/bench.err
