@@ -141,6 +141,9 @@ def run_c5(sipx, n, h=(25.0, 25.0, 25.0), TF=np.float64, maxit=100, model="surve
            "solve_only_s": sum(v["solve_s"] for v in T["levels"]), "warm_start_total_s": sum(v["warm_start_s"] for v in T["levels"]),
            "context_total_s": sum(v["context_s"] for v in T["levels"]), "download_s": T.get("download_s"),
            "per_level": T["levels"], "iterations_per_level": [v["iterations"] for v in T["levels"]],
+           # what each level's context holds on this rank's GPU (N > 1: the rank's planes + halo planes, sparse arrays)
+           "device_bytes_per_level": [v.get("device_bytes") for v in T["levels"]],
+           "sparse_arrays_per_level": [v.get("sparse_arrays") for v in T["levels"]],
            "every_level_iterates": bool(all(v["iterations"] > 1 for v in T["levels"])),
            "finest_iterations": fin["iterations"], "finest_cg": fin["cg_iterations"],
            "finest_level_it_per_s": fin["iterations"] / fin["solve_s"],
@@ -335,7 +338,8 @@ def headline(out, detail_path=None):
         v = out.get(key)
         if isinstance(v, dict):
             h[key] = ({"error": str(v["error"])[:160]} if "error" in v else
-                      _pick(v, ("whole_solve_s", "solve_only_s", "iterations_per_level", "finest_level_it_per_s", "finest_iterations_saved", "finite")))
+                      dict(_pick(v, ("whole_solve_s", "solve_only_s", "iterations_per_level", "finest_level_it_per_s", "finest_iterations_saved", "finite")),
+                           **({"finest_device_bytes": (v.get("device_bytes_per_level") or [None])[-1]} if out.get("n_gpus", 1) > 1 else {})))
     if out.get("comm"):
         h["comm"] = _pick(out["comm"], COMM)
     if out.get("decompositions"):

@@ -2663,66 +2663,58 @@ class Engine : public EngineBase {
     if (c->p_n_ != p_n_ || c->ndim_ != ndim_ || mk_ || c->mk_) throw std::runtime_error("warm start: the two levels must hold the same sets");
     if ((comm_ != nullptr) != (c->comm_ != nullptr) || (comm_ && !(slab_ && c->slab_)))
       throw std::runtime_error("warm start between levels of a sharded solve needs both levels slab-decomposed (sipx_set_decomp)");
-    if (slab_local_ || c->slab_local_)
-      throw std::runtime_error("warm start between slab-decomposed levels resamples whole arrays: ask for SIPX_DECOMP_SLAB_FULL on both levels");
-    if (c->slab_) {      // the coarse iterate, whole on every rank (a collective); the resampling below is then local and the
-      std::vector<char> all(c->p_n_, 1);      // fine level starts from arrays that are complete -- slab, halo planes and all
-      c->gather_slabs(true, all, all);
-    }
-    SIPX_HIP(hipStreamSynchronize(c->stream_));
+    // Block by block (x, then l_i and y_i of every set): the coarse block is completed in ONE whole-size temporary of the COARSE
+    // level -- an all-gather of the coarse ranks' slabs where that level is slab-decomposed (a collective: every rank makes the same
+    // calls); one rank: the block itself -- and resampled from there, padded layout to padded layout (k_resample_padded: entry by entry
+    // the copy the reference makes on the chunks in row order, interpolate_y_l.jl:16-94), into the grid points THIS rank stores of
+    // the fine block: its planes and the halo planes around them where the fine level holds sparse arrays (round 5: the levels of a
+    // slab-decomposed multilevel solve no longer need whole arrays, PARSDMM_multi_level.jl:56-83), all of it otherwise.  A coarse
+    // array is 1 / 8 of a fine one: the temporary is the size of a rank's slab of the fine grid on eight GPUs.
     long long nc[3], nf[3];
     for (int a = 0; a < 3; ++a) { nc[a] = c->G_.n[a]; nf[a] = G_.n[a]; }
-    resample_nn<T>(stream_, nc, nf, c->x_, x_);
-    long long maxc = 1, maxf = 1;
-    for (int i = 0; i < p_n_; ++i) { maxc = std::max(maxc, c->sets_[i].Mtrue); maxf = std::max(maxf, sets_[i].Mtrue); }
-    T* rc = dalloc<T>(maxc, false);
-    T* rf = dalloc<T>(maxf, false);
+    const long long Nc = c->G_.N, Nf = G_.N;
+    const long long cpad = c->comm_ ? c->chunk_ * c->comm_->world : Nc;
+    int nbmax = 1;
+    for (auto& st : c->sets_) nbmax = std::max(nbmax, st.nblk_or1());
+    T* whole = c->slab_ ? dalloc<T>((size_t)nbmax * cpad, false) : nullptr;
+    const int dt = dtype_code();
+    const long long f0 = slab_local_ ? std::max<long long>(0, wlo_) : 0, f1 = slab_local_ ? std::min<long long>(Nf, whi_) : Nf;
+    // (all blocks of a set's coarse vector side by side: a chunk of the reference's row vector may straddle two of them)
+    auto complete = [&](const T* src, int nb) -> const T* {
+      if (!c->slab_) return src;             // one rank: the blocks themselves (stride Nc)
+      const long long nloc = c->r1_ - c->r0_;
+      for (int q = 0; q < nb; ++q) {          // the coarse ranks' planes -> the whole block
+        T* w = whole + (long long)q * cpad;
+        if (nloc > 0) SIPX_HIP(hipMemcpyAsync(w + c->r0_, src + (long long)q * Nc + c->r0_, nloc * sizeof(T), hipMemcpyDeviceToDevice, stream_));
+        c->comm_->allgather(w, (size_t)c->chunk_, dt, stream_);
+      }
+      return whole;
+    };
+    const long long cstride = c->slab_ ? cpad : Nc;
+    SIPX_HIP(hipStreamSynchronize(c->stream_));
+    resample_nn_padded<T>(stream_, nc, nf, nc, nf, f0, f1, complete(c->x_, 1), x_);
     for (int i = 0; i < p_n_; ++i) {
       SetState<T>&f = sets_[i], &g = c->sets_[i];
       if (f.custom || g.custom || f.nblk != g.nblk) throw std::runtime_error("warm start: operator kinds differ between the levels");
+      for (int q = 0; q < f.nblk; ++q)
+        if (f.dir[q] != g.dir[q]) throw std::runtime_error("warm start: operator kinds differ between the levels");
       if (!f.owned || !g.owned) continue;
-      // chunk shapes on both levels
-      int nchunk = 1;
-      long long sc[3][3], sf[3][3];
-      for (int a = 0; a < 3; ++a) { sc[0][a] = nc[a]; sf[0][a] = nf[a]; }
-      if (f.nblk == 1) { sc[0][f.dir[0]] -= 1; sf[0][f.dir[0]] -= 1; }        // TD_n of the operator (get_TD_operator.jl)
-      if (f.nblk >= 2) {                                                        // interpolate_y_l.jl:21-30,53-57
-        nchunk = f.nblk;
-        for (int q = 0; q < nchunk; ++q)
-          for (int a = 0; a < 3; ++a) { sc[q][a] = nc[a] - (a == q ? 1 : 0); sf[q][a] = nf[a] - (a == q ? 1 : 0); }   // chunk q: D_x-, D_y-, D_z-sized
-      }
       for (int which = 0; which < 2; ++which) {
-        const T* src = which ? g.y : g.l;
+        const T* src = complete(which ? g.y : g.l, g.nblk_or1());
         T* dst = which ? f.y : f.l;
-        const T* rows_c = src;
-        if (!g.ident) {                                                          // padded -> reference row order
-          long long r0 = 0;
-          for (int q = 0; q < g.nblk; ++q) {
-            K<T>::rows_pack(stream_, c->G_, g.dir[q], g.blk_rows[q], src + (long long)q * c->G_.N, rc + r0);
-            r0 += g.blk_rows[q];
-          }
-          rows_c = rc;
-        }
-        T* rows_f = f.ident ? dst : rf;
-        long long oc = 0, of = 0;
-        for (int q = 0; q < nchunk; ++q) {
-          resample_nn<T>(stream_, sc[q], sf[q], rows_c + oc, rows_f + of);
-          oc += sc[q][0] * sc[q][1] * sc[q][2];
-          of += sf[q][0] * sf[q][1] * sf[q][2];
-        }
-        if (oc != g.Mtrue || of != f.Mtrue) throw std::runtime_error("warm start: chunk sizes do not add up to the rows of the operator");
-        if (!f.ident) {
-          long long r0 = 0;
-          for (int q = 0; q < f.nblk; ++q) {
-            K<T>::rows_unpack(stream_, G_, f.dir[q], f.blk_rows[q], rf + r0, dst + (long long)q * G_.N);
-            r0 += f.blk_rows[q];
-          }
+        if (f.nblk >= 2) {       // TV / D2D / D3D: the reference's D_x-, D_y-, D_z-sized chunks of the row vector (interpolate_y_l.jl:21-30,53-57)
+          for (int q = 0; q < f.nblk; ++q)
+            resample_nn_rows<T>(stream_, nc, nf, f.nblk, f.dir, q, cstride, f0, f1, src, dst + (long long)q * Nf);
+        } else {                 // one block: the grid, minus one along the direction of its difference operator (TD_n, get_TD_operator.jl)
+          long long cc[3], cf[3];
+          for (int a = 0; a < 3; ++a) { cc[a] = nc[a]; cf[a] = nf[a]; }
+          if (f.nblk == 1) { cc[f.dir[0]] -= 1; cf[f.dir[0]] -= 1; }
+          resample_nn_padded<T>(stream_, nc, nf, cc, cf, f0, f1, src, dst);
         }
       }
     }
     SIPX_HIP(hipStreamSynchronize(stream_));
-    dfree(rc);
-    dfree(rf);
+    dfree(whole);
   }
 
   // Slab-decomposed context: completes x and / or the y_i, l_i named on every rank from the ranks' slabs (all-gathers on the

@@ -737,6 +737,95 @@ void resample_nn(hipStream_t s, const long long* nc, const long long* nf, const 
   SIPX_HIP(hipGetLastError());
 }
 
+// The same transfer between two PADDED arrays (every block of a set's vector is laid out over the whole grid: entry (i, j, k) of a
+// chunk with dims cf <= nf sits at i + nf0 (j + nf1 k)), for the fine grid points e0 <= g < e1 only: what a rank of a slab-decomposed
+// level stores.  Entry by entry the copy resample_nn makes on the chunks in row order (the pads are left alone).
+struct RsPadArgs {
+  long long nc[3], nf[3];      // the grids
+  long long cc[3], cf[3];      // dims of the chunk on either level (the grid's, minus one along the direction of a difference operator)
+  long long e0, e1;
+};
+template <typename T>
+__global__ __launch_bounds__(BLOCK) void k_resample_padded(RsPadArgs a, const T* __restrict__ in, T* __restrict__ out) {
+  for (long long e = a.e0 + (long long)blockIdx.x * BLOCK + threadIdx.x; e < a.e1; e += (long long)gridDim.x * BLOCK) {
+    const long long i = e % a.nf[0], jk = e / a.nf[0], j = jk % a.nf[1], k = jk / a.nf[1];
+    if (i >= a.cf[0] || j >= a.cf[1] || k >= a.cf[2]) continue;
+    const long long ci = nn_index(i, a.cc[0], a.cf[0]), cj = nn_index(j, a.cc[1], a.cf[1]), ck = nn_index(k, a.cc[2], a.cf[2]);
+    out[e] = in[ci + a.nc[0] * (cj + a.nc[1] * ck)];
+  }
+}
+template <typename T>
+void resample_nn_padded(hipStream_t s, const long long* nc, const long long* nf, const long long* cc, const long long* cf, long long e0,
+                        long long e1, const T* in, T* out) {
+  if (e1 <= e0) return;
+  RsPadArgs a;
+  for (int q = 0; q < 3; ++q) { a.nc[q] = nc[q]; a.nf[q] = nf[q]; a.cc[q] = cc[q]; a.cf[q] = cf[q]; }
+  a.e0 = e0; a.e1 = e1;
+  hipLaunchKernelGGL((k_resample_padded<T>), dim3(fit_grid(e1 - e0, NB)), dim3(BLOCK), 0, s, a, in, out);
+  SIPX_HIP(hipGetLastError());
+}
+
+// A set on TV / D2D / D3D: the reference cuts the ROW vector of l, y into a D_x-, a D_y- and a D_z-sized chunk, in that order,
+// whatever order the operator's blocks have, and resamples each chunk as an array of its shape (interpolate_y_l.jl:21-30,53-57;
+// the engine's blocks are ordered z, y, x, so a chunk straddles blocks).  The same copy, padded blocks to padded block, for the
+// grid points e0 <= g < e1 of fine block b: padded entry -> row of the fine vector -> chunk and position in it -> nearest
+// position of the coarse chunk -> row of the coarse vector -> coarse block and padded entry.
+struct RsRowsArgs {
+  long long nc[3], nf[3];
+  int nblk, b;
+  int dir[3];                  // direction of block q's difference operator (both levels)
+  long long cs_c[4], cs_f[4];  // first row of chunk q (q = 0, 1, 2: the D_x-, D_y-, D_z-sized one) on either level
+  long long ro_c[4], ro_f[4];  // first row of block q
+  long long cstride;           // distance between the coarse blocks in `in`
+  long long e0, e1;
+};
+template <typename T>
+__global__ __launch_bounds__(BLOCK) void k_resample_rows(RsRowsArgs a, const T* __restrict__ in, T* __restrict__ out) {
+  const int db = a.dir[a.b];
+  long long fb[3] = {a.nf[0], a.nf[1], a.nf[2]};
+  fb[db] -= 1;
+  for (long long e = a.e0 + (long long)blockIdx.x * BLOCK + threadIdx.x; e < a.e1; e += (long long)gridDim.x * BLOCK) {
+    const long long i = e % a.nf[0], jk = e / a.nf[0], j = jk % a.nf[1], k = jk / a.nf[1];
+    if (i >= fb[0] || j >= fb[1] || k >= fb[2]) continue;                       // (a pad of the block)
+    const long long r = a.ro_f[a.b] + i + fb[0] * (j + fb[1] * k);             // row of the fine vector
+    int q = 0;
+    while (q + 1 < a.nblk && r >= a.cs_f[q + 1]) ++q;                          // its chunk: dims n - e_q
+    long long sf[3] = {a.nf[0], a.nf[1], a.nf[2]}, sc[3] = {a.nc[0], a.nc[1], a.nc[2]};
+    sf[q] -= 1; sc[q] -= 1;
+    const long long lf = r - a.cs_f[q];
+    const long long ii = lf % sf[0], jjkk = lf / sf[0], jj = jjkk % sf[1], kk = jjkk / sf[1];
+    const long long ci = nn_index(ii, sc[0], sf[0]), cj = nn_index(jj, sc[1], sf[1]), ck = nn_index(kk, sc[2], sf[2]);
+    const long long rc = a.cs_c[q] + ci + sc[0] * (cj + sc[1] * ck);          // row of the coarse vector
+    int p = 0;
+    while (p + 1 < a.nblk && rc >= a.ro_c[p + 1]) ++p;                         // its block: dims n - e_dir[p]
+    long long cb[3] = {a.nc[0], a.nc[1], a.nc[2]};
+    cb[a.dir[p]] -= 1;
+    const long long lc = rc - a.ro_c[p];
+    const long long pi = lc % cb[0], pjk = lc / cb[0], pj = pjk % cb[1], pk = pjk / cb[1];
+    out[e] = in[(long long)p * a.cstride + pi + a.nc[0] * (pj + a.nc[1] * pk)];
+  }
+}
+template <typename T>
+void resample_nn_rows(hipStream_t s, const long long* nc, const long long* nf, int nblk, const int* dir, int b, long long cstride,
+                      long long e0, long long e1, const T* in, T* out) {
+  if (e1 <= e0) return;
+  RsRowsArgs a;
+  for (int q = 0; q < 3; ++q) { a.nc[q] = nc[q]; a.nf[q] = nf[q]; a.dir[q] = q < nblk ? dir[q] : 0; }
+  a.nblk = nblk; a.b = b; a.cstride = cstride; a.e0 = e0; a.e1 = e1;
+  a.cs_c[0] = a.cs_f[0] = a.ro_c[0] = a.ro_f[0] = 0;
+  for (int q = 0; q < nblk; ++q) {
+    long long sc = 1, sf = 1, bc = 1, bf = 1;
+    for (int d = 0; d < 3; ++d) {
+      sc *= nc[d] - (d == q ? 1 : 0); sf *= nf[d] - (d == q ? 1 : 0);
+      bc *= nc[d] - (d == dir[q] ? 1 : 0); bf *= nf[d] - (d == dir[q] ? 1 : 0);
+    }
+    a.cs_c[q + 1] = a.cs_c[q] + sc; a.cs_f[q + 1] = a.cs_f[q] + sf;
+    a.ro_c[q + 1] = a.ro_c[q] + bc; a.ro_f[q + 1] = a.ro_f[q] + bf;
+  }
+  hipLaunchKernelGGL((k_resample_rows<T>), dim3(fit_grid(e1 - e0, NB)), dim3(BLOCK), 0, s, a, in, out);
+  SIPX_HIP(hipGetLastError());
+}
+
 // x = (x*rho + m) / (rho + 1.0) through the same device function k_yl applies for the distance term (prox_l2s!.jl:3-6)
 template <typename T>
 __global__ __launch_bounds__(BLOCK) void k_prox_l2s(long long n, T* __restrict__ x, const T* __restrict__ m, T rho) {
@@ -753,6 +842,10 @@ void prox_l2s_dev(hipStream_t s, long long n, T* x, const T* m, T rho) {
 #define SIPX_INST(T)                                                                                              \
   template void prox_l2s_dev<T>(hipStream_t, long long, T*, const T*, T);                                         \
   template void resample_nn<T>(hipStream_t, const long long*, const long long*, const T*, T*);                   \
+  template void resample_nn_rows<T>(hipStream_t, const long long*, const long long*, int, const int*, int, long long, long long, \
+                                    long long, const T*, T*);                                                     \
+  template void resample_nn_padded<T>(hipStream_t, const long long*, const long long*, const long long*, const long long*, long long, \
+                                      long long, const T*, T*);                                                   \
   template void K<T>::sum_uv(hipStream_t, long long, const T*, const T*, T*);                                      \
   template void K<T>::csr_spmv(hipStream_t, long long, const long long*, const long long*, const T*, const T*, T*);  \
   template void K<T>::csc_adj_rhs(hipStream_t, long long, const long long*, const long long*, const T*, const T*,    \

@@ -585,6 +585,14 @@ void prox_l2s_dev(hipStream_t s, long long n, T* x, const T* m, T rho);
 // nearest-neighbour grid transfer (multilevel): out (shape nf) <- in (shape nc)
 template <typename T>
 void resample_nn(hipStream_t s, const long long* nc, const long long* nf, const T* in, T* out);
+// ... a set on TV / D2D / D3D: the reference's chunks of the row vector (kernels_sets.hip, k_resample_rows)
+template <typename T>
+void resample_nn_rows(hipStream_t s, const long long* nc, const long long* nf, int nblk, const int* dir, int b, long long cstride,
+                      long long e0, long long e1, const T* in, T* out);
+// ... between padded arrays, for the fine grid points [e0, e1) (kernels_sets.hip)
+template <typename T>
+void resample_nn_padded(hipStream_t s, const long long* nc, const long long* nf, const long long* cc, const long long* cf, long long e0,
+                        long long e1, const T* in, T* out);
 
 #define SIPX_HIP(expr)                                                                       \
   do {                                                                                       \

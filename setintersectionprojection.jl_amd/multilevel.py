@@ -16,6 +16,7 @@ from __future__ import annotations
 import copy
 import math
 
+import os
 import numpy as np
 
 from . import host
@@ -100,7 +101,8 @@ def PARSDMM_multi_level(m, TD_OP_levels, AtA_levels, P_sub_levels, set_Prop_leve
     host.resample_nn / interpolate_y_l, upload at sipx_finalize) for A/B comparison.
     dist (torch.distributed, one process per GPU): every level is solved slab-decomposed over the ranks (sharded.py,
     sipx_set_decomp -- the set lists of the multilevel examples, bounds and l1 / TV, allow it); between levels the coarse
-    slabs are all-gathered on the device and every rank resamples the whole iterate.  Every rank makes the same calls and
+    slabs are all-gathered on the device one block at a time (a coarse-sized temporary) and every rank resamples the grid points
+    it stores.  Every rank makes the same calls and
     returns the same x, log, l, y."""
     import time
     attach = None
@@ -115,7 +117,9 @@ def PARSDMM_multi_level(m, TD_OP_levels, AtA_levels, P_sub_levels, set_Prop_leve
 
         def attach(ctx):
             keep.append(sharded.attach_comm(ctx, dist, torch.device("cuda", 0 if device is None else device), comm_mode))
-            ctx.set_decomp("slab_full")      # the warm start between levels resamples whole arrays (sipx_warm_start_from)
+            # (sparse arrays on every level since round 5: sipx_warm_start_from completes one coarse block at a time in a
+            #  coarse-sized temporary and writes the grid points the fine rank stores; SIPX_MULTILEVEL_SLAB_FULL=1: whole arrays)
+            ctx.set_decomp("slab_full" if os.environ.get("SIPX_MULTILEVEL_SLAB_FULL") == "1" else "slab")
     n_levels = len(TD_OP_levels)
     n0 = tuple(int(v) for v in comp_grid_levels[0].n)
     dim3 = len(n0) == 3 and n0[2] > 1
@@ -150,6 +154,11 @@ def PARSDMM_multi_level(m, TD_OP_levels, AtA_levels, P_sub_levels, set_Prop_leve
             t3 = time.perf_counter()
             rec["levels"].append({"grid": [int(v) for v in comp_grid_levels[i].n], "context_s": t1 - t0, "warm_start_s": t2 - t1,
                                   "solve_s": t3 - t2, "iterations": int(len(log.obj)), "cg_iterations": int(np.sum(log.cg_it))})
+            try:                                                             # what this level's context holds on this rank's GPU
+                rec["levels"][-1]["device_bytes"] = int(ctx.device_bytes()["context"])
+                rec["levels"][-1]["sparse_arrays"] = bool(ctx.kernel_stats_all(-1).get("sparse_arrays"))
+            except Exception:
+                pass
             _carry_rho(options, log)                                         # :57,83
             if host_transfers:
                 x, l, y = ctx.download()
