@@ -1350,7 +1350,8 @@ def main():
         out["c4_512"] = safe("c4_512", lambda: leg(measure("c4", 6, 2), 6, 2, full=False))
         if dist is not None:
             # ... and with the whole iteration on z-slabs (round 5): y, l of every set on the ranks' planes, the slice-rank set
-            # projected by every rank on its own slices, l1-DFT and cardinality by an owner rank on the gathered vector
+            # projected by every rank on its own slices, cardinality searched through the slab collectives, l1-DFT projected by an
+            # owner rank on the gathered vector
             progress("c4_512 leg, slab-decomposed")
             out["c4_512_slab"] = safe("c4_512_slab", lambda: leg(measure("c4", 6, 2, decomp="slab", comm_mode=("torch" if share_gpu else None)), 6, 2, full=False))
     if args.config == "c3" and args.dtype == "f32" and args.q_mode == "cds" and not args.no_c5:
@@ -1359,8 +1360,12 @@ def main():
         # model; `c5_layered`: a velocity-model-like field, the kind the reference's own timing runs on (c5_model).
         for key, model in (("c5", "survey"), ("c5_layered", "layered")):
             progress(f"{key} leg (PARSDMM_multi_level 512^3 Float64, 3 levels)")
-            # (rehearsal with the ranks on ONE GPU: every rank's full-size Float64 arrays of 512^3 do not fit beside each other)
-            n5 = (256, 256, 256) if share_gpu else (512, 512, 512)
+            # (rehearsal with the ranks on ONE GPU: rounds 3-4 ran 256^3 there -- every level held whole arrays and four ranks' Float64
+            #  arrays of 512^3 did not fit beside each other; every level holds sparse arrays since round 5: the real size, 17 GB per
+            #  rank of four at the finest level.  SIPX_BENCH_C5_N: another size)
+            n5 = (512, 512, 512)
+            if os.environ.get("SIPX_BENCH_C5_N"):
+                n5 = (int(os.environ["SIPX_BENCH_C5_N"]),) * 3
             r5m = safe(key, lambda: run_c5(sipx, n5, maxit=100, model=model, device=local_rank, dist=dist))
             r5m["n_gpus"] = world
             out[key] = r5m
