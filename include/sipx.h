@@ -284,8 +284,8 @@ int sipx_rccl_unique_id(void* id128);
 #define SIPX_DECOMP_SETS 0
 #define SIPX_DECOMP_SLAB 1
 /* the same decomposition with FULL-size arrays on every rank: SIPX_DECOMP_SLAB backs every N-sized array of a rank with memory for
- * its planes and the halo planes around them only (device bytes per rank fall with the number of ranks); levels of a multilevel solve,
- * whose warm start resamples whole arrays (sipx_warm_start_from), ask for this mode */
+ * its planes and the halo planes around them only (device bytes per rank fall with the number of ranks; the levels of a multilevel
+ * solve included since round 5); this mode is the A/B switch and the fallback when mapped memory cannot be exchanged */
 #define SIPX_DECOMP_SLAB_FULL 2
 int sipx_set_decomp(sipx_ctx* ctx, int mode);
 int sipx_set_comm_rccl(sipx_ctx* ctx, const void* id128, int world, int rank);
@@ -297,7 +297,9 @@ int sipx_set_comm_rccl(sipx_ctx* ctx, const void* id128, int world, int rank);
  *   allgather:          buf[r*chunk .. (r+1)*chunk) <- that range of rank r, for every r
  *   halo_exchange:      send `count` elements to, and receive as many from, rank prev and rank next (-1 = no neighbour)
  *   scatter / gather:   in place on world * chunk elements: rank r receives buf[r*chunk .. (r+1)*chunk) of rank `root`, or
- *                       rank `root` receives that range of every rank r */
+ *                       rank `root` receives that range of every rank r.  On a rank OTHER than `root` only its own range
+ *                       buf[rank*chunk .. (rank+1)*chunk) is memory the callback may touch (round 5: with sparse arrays the rest of
+ *                       the exchange layout is not backed there) */
 typedef struct {
   void* user;
   int32_t world, rank;

@@ -397,6 +397,7 @@ class Engine : public EngineBase {
     if (fan_st_) { (void)hipStreamSynchronize(fan_st_); (void)hipStreamDestroy(fan_st_); }
     if (fan_fork_) (void)hipEventDestroy(fan_fork_);
     for (void* p : {(void*)fan_ptmp_, (void*)fan_mpart_, (void*)fan_c_}) dfree(p);
+    if (loose_owned_) { dfree(loose_v_); dfree(loose_w_); }
     (void)hipStreamSynchronize(stream_);
     for (auto& s : sets_) free_set(s);
     for (void* p : {(void*)xr_base_[0], (void*)xr_base_[1], (void*)xr_base_[2], (void*)w_base_, (void*)rhs_, (void*)m_base_, (void*)r_base_, (void*)p_base_, (void*)p2_base_, (void*)Ap_, (void*)Q_, (void*)Q2_,
@@ -635,7 +636,10 @@ class Engine : public EngineBase {
       sparse_wanted = vmm != 0 && !(e && e[0] == '0');
       for (const auto& st : sets_)
         if (st.prox == PX_BOUNDS_VEC || (!st.two_pass && st.nblk > 0) || !st.host_ata.empty()) sparse_wanted = false;
-      if (slab_loose_) sparse_wanted = false;            // (materialised vectors travel through the whole-size exchange layout)
+      // (lists with materialised sets keep sparse arrays too: their vectors are addressed by global index -- loose_v_ / loose_w_ --
+      //  and whole only on the rank that projects a gathered set.  SIPX_SLAB_LOOSE_SPARSE=0: whole arrays for such lists, A/B switch)
+      if (slab_loose_)
+        if (const char* ls = std::getenv("SIPX_SLAB_LOOSE_SPARSE")) if (ls[0] == '0') sparse_wanted = false;
     }
     if (comm_) comm_self_test(sparse_wanted);               // (every rank takes the same branch: the verdict is all-reduced)
     // Everything from here to the initial feasibility allocates and uploads -- no collective.  A rank that fails in there (out of
@@ -800,6 +804,7 @@ class Engine : public EngineBase {
       stage_ = dalloc<double>((size_t)std::max(n2, 1) * (PREP_SLOTS + 1 + 2 * comm_->world));
       sstage_ = dalloc<double>((size_t)std::max(n2, 1) * (2 * SAMPLE_BINS + 3));
     }
+    const long long fullpad = maxpad;   // (what a whole vector of the exchange layout takes: the owner of a gathered set)
     if (slab_local_) {                 // the whole-array scratch is not needed: searches compact at most what the rank's planes hold
       int nbmax = 1;
       for (auto& s : sets_) nbmax = std::max(nbmax, s.nblk_or1());
@@ -811,6 +816,18 @@ class Engine : public EngineBase {
     scr_c_len_ = maxpad;
     if (need_idx_) scr_i_ = dalloc<long long>(maxpad);
     if (need_ext_) scr_w_ = dalloc<T>(maxpad);
+    // the vectors the materialised sets of a slab-decomposed list are stored into, addressed by GLOBAL index (v, P(v), s = A x and
+    // its copy): the engine-wide scratch where that is whole; with sparse arrays a rank that projects a gathered set holds them
+    // whole, every other rank its planes only
+    loose_v_ = scr_v_; loose_w_ = scr_w_;
+    if (slab_local_ && slab_loose_) {
+      bool owner = false;
+      for (auto& st : sets_) owner |= st.fan && st.fan_owner == comm_->rank;
+      loose_whole_ = owner;
+      loose_v_ = owner ? dalloc<T>(fullpad) : loose_alloc(Npad);
+      loose_w_ = owner ? dalloc<T>(fullpad) : loose_alloc(Npad);
+      loose_owned_ = true;
+    }
     // (the reduced per-set sums sit right behind the CG partials: sharded, ONE all-reduce can carry both, see argmin_x_head)
     part_cg_ = dalloc<double>(2 * NB + (size_t)(p_n_ + 1) * SLOTS);
     part_tmp_ = dalloc<double>((size_t)(PREP_SLOTS + 2) * NB);
@@ -896,14 +913,14 @@ class Engine : public EngineBase {
       if (s.fan) {
         // the gathered sets are collected FIRST in an update (update_y_l), their owners project on a stream of their own while
         // every rank goes on with the sets of its own slab: each such set keeps its own whole-size vector, the fan stream its scratch
-        s.fanv = dalloc<T>(maxpad);
+        s.fanv = (s.fan_owner == comm_->rank || !slab_local_) ? dalloc<T>(fullpad) : loose_alloc(Npad);
         SIPX_HIP(hipEventCreateWithFlags(&s.fan_ev, hipEventDisableTiming));
         if (s.fan_owner == comm_->rank && !fan_st_) {
           SIPX_HIP(hipStreamCreateWithFlags(&fan_st_, hipStreamNonBlocking));
           SIPX_HIP(hipEventCreateWithFlags(&fan_fork_, hipEventDisableTiming));
           fan_ptmp_ = dalloc<double>((size_t)(PREP_SLOTS + 2) * NB);
           fan_mpart_ = dalloc<T>(2 * NB);
-          fan_c_ = dalloc<T>(maxpad);
+          fan_c_ = dalloc<T>(fullpad);
         }
       }
       if (s.two_pass) {
@@ -1600,11 +1617,12 @@ class Engine : public EngineBase {
       }
       if (s.slab_ext) {   // slab-decomposed, slices of the rank's own planes: nothing crosses the fabric
         q = stream_;
-        K<T>::store_v(q, Gr_, a, 0, scr_v_);
+        K<T>::store_v(q, Gr_, a, 0, loose_v_);
         if (r1_ > r0_) {
           ObsScope obs(KID_EXT, stream_, 0.0);
-          s.ext->project(scr_v_ + r0_, false, ptmp, mpart, cbuf);
+          s.ext->project(loose_v_ + r0_, false, ptmp, mpart, cbuf);
         }
+        a.v = loose_v_;
         a.vsrc = 2;
       } else if (s.fan) { // slab-decomposed, a projector that needs the whole array: its owner has gathered v (fan_begin, in front of
         q = stream_;      // this loop) and scatters P(v)
@@ -1980,6 +1998,16 @@ class Engine : public EngineBase {
     return (T*)sparse_alloc_bytes((size_t)total * sizeof(T), rg, device_);
   }
 
+  // A rank's part of a whole vector of the exchange layout (sparse arrays, a materialised set this rank does not project whole):
+  // backed for its chunk of the layout -- what a fan gather sends and a scatter receives -- and for the planes its kernels touch
+  // around its slab.
+  T* loose_alloc(long long Npad) {
+    const long long c0 = (long long)comm_->rank * chunk_, c1 = c0 + chunk_;
+    const long long lo = std::min(std::max<long long>(0, wlo_), c0), hi = std::min(Npad, std::max(std::max<long long>(0, whi_), c1));
+    std::vector<std::pair<size_t, size_t>> rg{{(size_t)lo * sizeof(T), (size_t)hi * sizeof(T)}};
+    return (T*)sparse_alloc_bytes((size_t)Npad * sizeof(T), rg, device_);
+  }
+
   // does the sweep take this context / iteration?  (asked before any search is queued; fills the layout part of `ma`)
   bool sweep_applicable(int flags, MultiArgs<T>& ma, bool planning = false) {
     if (!yl_multi_ || mk_ || (comm_ && !slab_)) return false;
@@ -2346,6 +2374,11 @@ class Engine : public EngineBase {
         std::fprintf(stderr, "[sipx search] search %lld (set %d%s): fallback%s\n", batch_searches_, tp[j], feas_ps ? ", feasibility" : "", (w & 2u) ? " with refinement" : "");
       fb.push_back(j);
       refine |= (w & 2u) != 0;
+    }
+    static const bool spec_debug = std::getenv("SIPX_SPEC_DEBUG") != nullptr;
+    if (spec_debug && !feas_ps) {                // (diagnostics: the state every search of the chain ended its first stage with; synchronises)
+      std::fprintf(stderr, "[sipx spec] batched chain, search seq %u\n", seq);
+      for (size_t j = 0; j < tp.size(); ++j) dump_ps(tp[j], stage_ + j * RS);
     }
     if (fb.empty()) return;
     auto tail = [&](int stage) {
@@ -3795,11 +3828,11 @@ class Engine : public EngineBase {
   void dist_feasibility(SetState<T>& s, const T* src, double* dst) {
     const long long nloc = r1_ - r0_;
     if (nloc > 0) {
-      SIPX_HIP(hipMemcpyAsync(scr_v_ + r0_, src + r0_, nloc * sizeof(T), hipMemcpyDeviceToDevice, stream_));
-      SIPX_HIP(hipMemcpyAsync(scr_w_ + r0_, src + r0_, nloc * sizeof(T), hipMemcpyDeviceToDevice, stream_));
-      s.ext->project(scr_v_ + r0_, true, part_tmp_, maxpart_, scr_c_);
+      SIPX_HIP(hipMemcpyAsync(loose_v_ + r0_, src + r0_, nloc * sizeof(T), hipMemcpyDeviceToDevice, stream_));
+      SIPX_HIP(hipMemcpyAsync(loose_w_ + r0_, src + r0_, nloc * sizeof(T), hipMemcpyDeviceToDevice, stream_));
+      s.ext->project(loose_v_ + r0_, true, part_tmp_, maxpart_, scr_c_);
     }
-    ext_dist2<T>(stream_, nloc, scr_v_ + r0_, scr_w_ + r0_, dst);
+    ext_dist2<T>(stream_, nloc, loose_v_ + r0_, loose_w_ + r0_, dst);
   }
 
   // A gathered set of a slab-decomposed solve (SetState::fan).  fan_collect: every rank materialises v (v_is_s = 0) or s = A x
@@ -3839,7 +3872,8 @@ class Engine : public EngineBase {
       SIPX_HIP(hipEventRecord(fan_fork_, stream_));
       SIPX_HIP(hipStreamWaitEvent(q, fan_fork_, 0));
     }
-    fan_project_owner(s, false, s.fanv, q, q == stream_ ? part_tmp_ : fan_ptmp_, q == stream_ ? maxpart_ : fan_mpart_, q == stream_ ? scr_c_ : fan_c_);
+    // (in turn on the engine stream the fan stream's scratch is idle: its compaction buffer is whole-size, the engine's may not be)
+    fan_project_owner(s, false, s.fanv, q, fan_ptmp_, fan_mpart_, fan_c_);
     if (q != stream_) SIPX_HIP(hipEventRecord(s.fan_ev, q));
     s.fan_on_side = q != stream_;
   }
@@ -3853,11 +3887,11 @@ class Engine : public EngineBase {
       comm_->halo_exchange(buf + r0_, buf + r0_ - plane_, prev_, buf + r1_ - plane_, buf + r1_, next_, (size_t)plane_, dt, stream_);
   }
   void fan_feasibility(SetState<T>& s, const SetArgs<T>& a, double* dst) {
-    fan_collect(s, a, 1, scr_v_);
+    fan_collect(s, a, 1, loose_v_);
     if (comm_->rank != s.fan_owner) return;
-    SIPX_HIP(hipMemcpyAsync(scr_w_, scr_v_, (size_t)s.Mpad * sizeof(T), hipMemcpyDeviceToDevice, stream_));
-    fan_project_owner(s, true, scr_v_, stream_, part_tmp_, maxpart_, scr_c_);
-    ext_dist2<T>(stream_, s.Mpad, scr_v_, scr_w_, dst);
+    SIPX_HIP(hipMemcpyAsync(loose_w_, loose_v_, (size_t)s.Mpad * sizeof(T), hipMemcpyDeviceToDevice, stream_));
+    fan_project_owner(s, true, loose_v_, stream_, part_tmp_, maxpart_, fan_c_);      // (fan_c_: whole-size, this rank owns a gathered set)
+    ext_dist2<T>(stream_, s.Mpad, loose_v_, loose_w_, dst);
   }
 
   // ||P(s) - s||^2, ||s||^2 for a library-backed projector: s = A x materialised twice, one copy projected
@@ -4094,6 +4128,8 @@ class Engine : public EngineBase {
   long long* scr_i_ = nullptr;
   long long scr_c_len_ = 0;
   T* scr_w_ = nullptr;
+  T *loose_v_ = nullptr, *loose_w_ = nullptr;    // global-indexed vectors of the materialised sets of a slab-decomposed list (finalize)
+  bool loose_owned_ = false, loose_whole_ = false;
   bool need_idx_ = false, need_ext_ = false;
   CdsArgs cds_;
   bool cds_full_ = false;         // SIPX_CDS_FULL=1: read all d bands of Q (no symmetric partner reads)

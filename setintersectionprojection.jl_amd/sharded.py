@@ -197,11 +197,31 @@ class TorchComm:
             self._run(stream, [(sp if prev >= 0 else None, count, dtype, False), (rp if prev >= 0 else None, count, dtype, True),
                                (sn if nxt >= 0 else None, count, dtype, False), (rn if nxt >= 0 else None, count, dtype, True)],
                       lambda t: self.halo_exchange(t[0], t[1], prev, t[2], t[3], nxt))
+        def fan(buf, chunk, dtype, root, stream, out):
+            # (a rank other than the root may touch its own range of the exchange layout only -- sipx.h: with sparse arrays the
+            #  rest is not backed there -- so that range alone is aliased, shifted to where _fan looks for it)
+            if self.rank == root:
+                self._run(stream, [(buf, chunk * self.world, dtype, True)], lambda t: self._fan(t[0], chunk, root, out))
+                return
+            item = 8 if dtype == 1 else 4
+            mine = buf + self.rank * chunk * item
+
+            class _Shift:                       # t[rank*chunk:(rank+1)*chunk] of the whole layout == the aliased range
+                def __init__(self, v, r, c):
+                    self.v, self.r, self.c = v, r, c
+
+                def __getitem__(self, sl):
+                    assert sl.start == self.r * self.c and sl.stop == (self.r + 1) * self.c
+                    return self.v
+            self._run(stream, [(mine, chunk, dtype, out)], lambda t: self._fan(_Shift(t[0], self.rank, chunk), chunk, root, out))
+
         def sc(user, buf, chunk, dtype, root, stream):
-            self._run(stream, [(buf, chunk * self.world, dtype, True)], lambda t: self.scatter_(t[0], chunk, root))
+            self.calls["scatter"] += 1
+            fan(buf, chunk, dtype, root, stream, True)
 
         def ga(user, buf, chunk, dtype, root, stream):
-            self._run(stream, [(buf, chunk * self.world, dtype, True)], lambda t: self.gather_(t[0], chunk, root))
+            self.calls["gather"] += 1
+            fan(buf, chunk, dtype, root, stream, False)
         cs = _SipxComm(None, self.world, self.rank, _SipxComm._AR(guard(ar)), _SipxComm._AR(guard(rs)), _SipxComm._AR(guard(ag)),
                        _SipxComm._HX(guard(hx)), _SipxComm._BC(guard(sc)), _SipxComm._BC(guard(ga)))
         self._keep = cs                                   # the engine holds the function pointers
