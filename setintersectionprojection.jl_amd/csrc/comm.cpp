@@ -168,6 +168,24 @@ class RcclComm : public Comm {
   // one group of point-to-point transfers: the root talks to its seven peers over seven links at once
   void scatter(void* buf, size_t chunk, int dtype, int root, hipStream_t s) override { fan(buf, chunk, dtype, root, s, true); }
   void gather(void* buf, size_t chunk, int dtype, int root, hipStream_t s) override { fan(buf, chunk, dtype, root, s, false); }
+  // one group of world sends and world receives (the pattern of ncclAllToAll): every pair of ranks over its own xGMI link
+  void alltoall(const void* send, void* recv, void* tmp, size_t chunk, int dtype, hipStream_t s) override {
+    (void)tmp;
+    const RcclApi& a = rccl();
+    const size_t bytes = chunk * type_size(dtype);
+    if (world == 1) {
+      if (hipMemcpyAsync(recv, send, bytes, hipMemcpyDeviceToDevice, s) != hipSuccess) throw std::runtime_error("all-to-all of one rank: copy failed");
+      return;
+    }
+    const char* sb = static_cast<const char*>(send);
+    char* rb = static_cast<char*>(recv);
+    nccl_check(a.GroupStart(), "ncclGroupStart");
+    for (int p = 0; p < world; ++p) {
+      nccl_check(a.Send(sb + (size_t)p * bytes, chunk, nccl_type(dtype), p, comm_, s), "ncclSend (all-to-all)");
+      nccl_check(a.Recv(rb + (size_t)p * bytes, chunk, nccl_type(dtype), p, comm_, s), "ncclRecv (all-to-all)");
+    }
+    nccl_check(a.GroupEnd(), "ncclGroupEnd (all-to-all)");
+  }
 
  private:
   void fan(void* buf, size_t chunk, int dtype, int root, hipStream_t s, bool out) {

@@ -42,6 +42,18 @@ struct Comm {
   // receives that range from every rank r (gather); the root's own range stays where it is
   virtual void scatter(void* buf, size_t chunk, int dtype, int root, hipStream_t s) = 0;
   virtual void gather(void* buf, size_t chunk, int dtype, int root, hipStream_t s) = 0;
+  // recv[r*chunk .. (r+1)*chunk) <- send[rank*chunk .. (rank+1)*chunk) of rank r, for every r (the transposition of the slab-decomposed
+  // DFT, round 5).  send, recv and tmp are distinct buffers of world * chunk elements; tmp is scratch for communicators without
+  // an all-to-all of their own: the default strings it together from one scatter per root (callbacks: sipx_comm has none).
+  virtual void alltoall(const void* send, void* recv, void* tmp, size_t chunk, int dtype, hipStream_t s) {
+    const size_t bytes = chunk * (dtype == SIPX_F64 ? 8 : 4);
+    for (int root = 0; root < world; ++root) {
+      if (rank == root) (void)hipMemcpyAsync(tmp, send, bytes * (size_t)world, hipMemcpyDeviceToDevice, s);
+      scatter(tmp, chunk, dtype, root, s);
+      (void)hipMemcpyAsync(static_cast<char*>(recv) + (size_t)root * bytes, static_cast<char*>(tmp) + (size_t)rank * bytes, bytes,
+                           hipMemcpyDeviceToDevice, s);
+    }
+  }
 };
 
 // Forwards every operation to the communicator it wraps and counts the calls by kind (the engine reports them in its statistics:
@@ -68,6 +80,11 @@ struct CountingComm : Comm {
   }
   void scatter(void* buf, size_t chunk, int dtype, int root, hipStream_t s) override { ++n_fan; inner->scatter(buf, chunk, dtype, root, s); }
   void gather(void* buf, size_t chunk, int dtype, int root, hipStream_t s) override { ++n_fan; inner->gather(buf, chunk, dtype, root, s); }
+  void alltoall(const void* send, void* recv, void* tmp, size_t chunk, int dtype, hipStream_t s) override {
+    ++n_alltoall;
+    inner->alltoall(send, recv, tmp, chunk, dtype, s);
+  }
+  long long n_alltoall = 0;
 };
 
 Comm* make_rccl_comm(const void* unique_id, int world, int rank);

@@ -3,6 +3,7 @@
 // No CPU fallback exists: every numerical step below is a kernel launch.
 #include "engine.h"
 #include "comm.h"
+#include "dist_dft.h"
 #include "ext_proj.h"
 
 #include <algorithm>
@@ -326,7 +327,10 @@ struct SetState {
   //             array, scatters P(v) back (two fan exchanges of N w bytes for that set; the others stay slab-local).
   //   slab_card: cardinality of the whole array: a search of its own through the slab collectives (all-reduced probe counts, the
   //             pairs inside the final bracket all-gathered: launch_chain, kernels_proj.hip), then the per-set update.
-  bool slab_ext = false, fan = false, slab_card = false;
+  //   slab_dft:  the l1 ball behind the DFT on a 3-D grid: the transform itself is slab-decomposed (dist_dft.h: 2-D transforms of
+  //             the rank's planes, one all-to-all, 1-D transforms along z; the threshold through the slab collectives).
+  bool slab_ext = false, fan = false, slab_card = false, slab_dft = false;
+  std::shared_ptr<DistDft<T>> ddft;
   int fan_owner = 0;
   bool fan_on_side = false;          // this update's projection was queued on the fan stream
   T* fanv = nullptr;                 // a gathered set's own whole-size vector (v, then P(v)): its owner projects it on the fan stream
@@ -564,11 +568,13 @@ class Engine : public EngineBase {
                             s.spec.dir == ndim_ - 1 && s.ident;
         if (const char* fo = std::getenv("SIPX_FAN_OVERLAP")) fan_overlap_ = fo[0] != '0';
         const char* gc = std::getenv("SIPX_SLAB_CARD_GATHER");      // 1: cardinality through an owner rank as well (A/B switch, tests)
+        const char* gd = std::getenv("SIPX_SLAB_DFT_GATHER");       // 1: the l1-DFT set through an owner rank (A/B switch, tests)
         if (sliced) s.slab_ext = true;
         else if (s.prox == PX_CARD && !s.ext_kind && !(gc && gc[0] == '1')) s.slab_card = true;
+        else if (s.ext_kind == EXT_L1_DFT && ndim_ == 3 && s.ident && G_.n[0] >= 2 && !(gd && gd[0] == '1')) s.slab_dft = true;
         else if (s.ext_kind || s.prox == PX_CARD) { s.fan = true; s.fan_owner = (nfan++) % comm_->world; }
         if (s.fan && s.nblk > 1) throw std::runtime_error("internal: a gathered set with more than one operator block");
-        slab_loose_ |= s.slab_ext || s.fan || s.slab_card;
+        slab_loose_ |= s.slab_ext || s.fan || s.slab_card || s.slab_dft;
         s.owned = true;
       }
       // (the searches with their collectives run on the engine stream, in one order on every rank; the y/l updates that
@@ -901,7 +907,11 @@ class Engine : public EngineBase {
       // not of an iteration whose state has already advanced
       if (sweep_plain_ && s.in_sweep) { s.y2 = halloc(s.Mpad); s.l2 = halloc(s.Mpad); }
       if (s.custom) upload_custom(s);
-      if (s.ext_kind && !s.dist_ext && !s.slab_ext && !(s.fan && s.fan_owner != comm_->rank)) {      // (a gathered set: its owner only)
+      if (s.slab_dft) {
+        const long long nn[3] = {G_.n[0], G_.n[1], G_.n[2]};
+        s.ddft = std::make_shared<DistDft<T>>(nn, r0_ / plane_, r1_ / plane_, chunk_ / plane_, comm_->world, comm_->rank, (double)s.spec.pmax, stream_);
+      }
+      if (s.ext_kind && !s.dist_ext && !s.slab_ext && !s.slab_dft && !(s.fan && s.fan_owner != comm_->rank)) {      // (a gathered set: its owner only)
         s.spec.lb = s.host_lb.empty() ? nullptr : s.host_lb.data();
         s.spec.ub = s.host_ub.empty() ? nullptr : s.host_ub.data();
         s.spec.basis = s.host_basis.empty() ? nullptr : s.host_basis.data();
@@ -1115,8 +1125,8 @@ class Engine : public EngineBase {
     feas_init_.assign(pp_n_, 0.0);
     for (int i = 0; i < pp_n_; ++i) {
       SetState<T>& s = sets_[i];
-      if (s.dist_ext || s.slab_ext) {           // every rank: its slab of slices
-        dist_feasibility(s, m_, part_sets_ + ((size_t)i * SLOTS + SL_FE2) * NB);
+      if (s.dist_ext || s.slab_ext || s.slab_dft) {           // every rank: its slab of slices / its planes of the transform
+        dist_feasibility(s, m_, part_sets_ + ((size_t)i * SLOTS + SL_FE2) * NB, i);
         continue;
       }
       if (s.fan) {                              // the set's owner, on the gathered array
@@ -1624,6 +1634,15 @@ class Engine : public EngineBase {
         }
         a.v = loose_v_;
         a.vsrc = 2;
+      } else if (s.slab_dft) {   // slab-decomposed transform: every rank its planes, one all-to-all each way, the threshold over all ranks
+        q = stream_;
+        K<T>::store_v(q, Gr_, a, 0, loose_v_);
+        {
+          ObsScope obs(KID_EXT, stream_, 0.0);
+          s.ddft->project(loose_v_ + r0_, false, comm_.get(), &hooks_, part_tmp_, maxpart_, scr_c_, scr_c_len_, (int*)hovf_ + i);
+        }
+        a.v = loose_v_;
+        a.vsrc = 2;
       } else if (s.fan) { // slab-decomposed, a projector that needs the whole array: its owner has gathered v (fan_begin, in front of
         q = stream_;      // this loop) and scatters P(v)
         fan_return(s);
@@ -1660,10 +1679,10 @@ class Engine : public EngineBase {
         s.last_rho = a.rho;
         s.last_gamma = a.gamma;
       }
-      K<T>::yl(q, (s.slab_ext || (s.fan && s.ident)) ? gs : gy, a, part);      // (no adjoint stencil reads the plane below: nothing to recompute)
+      K<T>::yl(q, (s.slab_ext || s.slab_dft || (s.fan && s.ident)) ? gs : gy, a, part);      // (no adjoint stencil reads the plane below: nothing to recompute)
       if (s.custom) K<T>::csc_adj_norm(q, G_.N, s.d_colptr, s.d_rowval, s.d_nzval, s.dy, part + (size_t)SL_ADJ * NB);
       else if (!s.ident) K<T>::adj_norm(q, gs, a, part + (size_t)SL_ADJ * NB);
-      if ((flags & SIPX_YL_FEAS) && s.slab_ext && i < pp_n_) dist_feasibility(s, x_, part + (size_t)SL_FE2 * NB);
+      if ((flags & SIPX_YL_FEAS) && (s.slab_ext || s.slab_dft) && i < pp_n_) dist_feasibility(s, x_, part + (size_t)SL_FE2 * NB, i);
       else if ((flags & SIPX_YL_FEAS) && s.fan && i < pp_n_) fan_feasibility(s, a, part + (size_t)SL_FE2 * NB);
       else if ((flags & SIPX_YL_FEAS) && s.ext_kind && i < pp_n_) ext_feasibility(s, a, part + (size_t)SL_FE2 * NB);
       if ((flags & SIPX_YL_FEAS) && s.two_pass && !s.fan && i < pp_n_) {
@@ -2030,7 +2049,7 @@ class Engine : public EngineBase {
         // a set the sweep cannot take: it keeps its per-set kernels (one rank only; never a caller-supplied sparse operator,
         // whose right-hand side term is added out of order)
         // (... or slab-decomposed, the sets projected on a materialised v: SetState::slab_ext, fan)
-        if ((slab_ && !(s.slab_ext || s.fan || s.slab_card)) || (comm_ && !slab_) || s.custom || !s.owned || s.dist_ext || (planning ? false : !sweep_partial_)) return false;
+        if ((slab_ && !(s.slab_ext || s.fan || s.slab_card || s.slab_dft)) || (comm_ && !slab_) || s.custom || !s.owned || s.dist_ext || (planning ? false : !sweep_partial_)) return false;
         behind = true;
         continue;
       }
@@ -3265,13 +3284,14 @@ class Engine : public EngineBase {
       // owner rank on the gathered array -- and the fan exchanges (gathers + scatters of N w bytes) that took so far
       std::string loc, fan;
       for (int i = 0; i < p_n_; ++i) {
-        if (sets_[i].slab_ext || sets_[i].slab_card) loc += (loc.empty() ? "" : ", ") + std::to_string(i);
+        if (sets_[i].slab_ext || sets_[i].slab_card || sets_[i].slab_dft) loc += (loc.empty() ? "" : ", ") + std::to_string(i);
         if (sets_[i].fan) fan += (fan.empty() ? "" : ", ") + std::to_string(i);
       }
       if (counting_)
         o += ", \"collectives\": {\"allreduce\": " + std::to_string(counting_->n_allreduce) + ", \"allreduce_with_halo\": " + std::to_string(counting_->n_grouped) +
              ", \"allgather\": " + std::to_string(counting_->n_allgather) + ", \"reduce_scatter\": " + std::to_string(counting_->n_reduce_scatter) +
-             ", \"halo\": " + std::to_string(counting_->n_halo) + ", \"scatter_gather\": " + std::to_string(counting_->n_fan) + "}";
+             ", \"halo\": " + std::to_string(counting_->n_halo) + ", \"scatter_gather\": " + std::to_string(counting_->n_fan) +
+             ", \"alltoall\": " + std::to_string(counting_->n_alltoall) + "}";
       o += ", \"slab_loose\": {\"slab_local_sets\": [" + loc + "], \"gathered_sets\": [" + fan + "], \"fan_exchanges\": " + std::to_string(fan_exchanges_) + "}";
     }
     {
@@ -3825,13 +3845,15 @@ class Engine : public EngineBase {
 
   // The same for a set that all ranks project together (identity operator: s = src): this rank's slab of slices only, the
   // partial sums of the ranks add up in the all-reduce of the packed per-set sums.
-  void dist_feasibility(SetState<T>& s, const T* src, double* dst) {
+  void dist_feasibility(SetState<T>& s, const T* src, double* dst, int set = 0) {
     const long long nloc = r1_ - r0_;
     if (nloc > 0) {
       SIPX_HIP(hipMemcpyAsync(loose_v_ + r0_, src + r0_, nloc * sizeof(T), hipMemcpyDeviceToDevice, stream_));
       SIPX_HIP(hipMemcpyAsync(loose_w_ + r0_, src + r0_, nloc * sizeof(T), hipMemcpyDeviceToDevice, stream_));
-      s.ext->project(loose_v_ + r0_, true, part_tmp_, maxpart_, scr_c_);
+      if (!s.slab_dft) s.ext->project(loose_v_ + r0_, true, part_tmp_, maxpart_, scr_c_);
     }
+    // (the slab-decomposed transform is a collective: ranks without planes take part)
+    if (s.slab_dft) s.ddft->project(loose_v_ + r0_, true, comm_.get(), &hooks_, part_tmp_, maxpart_, scr_c_, scr_c_len_, (int*)hovf_ + set);
     ext_dist2<T>(stream_, nloc, loose_v_ + r0_, loose_w_ + r0_, dst);
   }
 

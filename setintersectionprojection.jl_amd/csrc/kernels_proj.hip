@@ -2422,6 +2422,24 @@ void K<T>::proj_scalars_arr(hipStream_t s, long long len, const T* v, int prox, 
   g.n[0] = len; g.n[1] = 1; g.n[2] = 1; g.N = len; g.st[0] = 1; g.st[1] = len; g.st[2] = len;
   launch_chain<T, 0>(s, g, a, 0, v, len, ps, partials, maxpart, compact, true_len);
 }
+// ... of a stored array that is this rank's share of a vector spread over the ranks of a slab-decomposed solve (the coefficients
+// of the slab-decomposed DFT, dist_dft.hip): the chain with the slab collectives of `hooks` between its stages -- all-reduced
+// probe sums, all-gathered bracket -- so that every rank arrives at the same scalars.  true_len: entries over ALL ranks.
+template <typename T>
+void K<T>::proj_scalars_arr_slab(hipStream_t s, long long len, const T* v, int prox, T pmin, T pmax, ProjScalars<T>* ps,
+                                 double* partials, T* maxpart, T* compact, long long true_len, const ChainHooks* hooks,
+                                 long long compact_len, int* host_ovf) {
+  SetArgs<T> a = {};
+  a.prox = prox;
+  a.plo = pmin;
+  a.phi = pmax;
+  a.ps = ps;
+  Grid g = {};
+  g.n[0] = len > 0 ? len : 1; g.n[1] = 1; g.n[2] = 1; g.N = len; g.st[0] = 1; g.st[1] = g.n[0]; g.st[2] = g.n[0];
+  SampleCtl ctl;
+  ctl.host_ovf = host_ovf;
+  launch_chain<T, 0>(s, g, a, 0, v, len, ps, partials, maxpart, compact, true_len, ctl, hooks, compact_len);
+}
 template <typename T>
 void K<T>::store_v(hipStream_t s, const Grid& g, const SetArgs<T>& a, int v_is_s, T* out) {
   ObsScope obs_(KID_PASS_STORE, s, pass_bytes<T>(g, a, v_is_s, 1, 0, true));
@@ -2466,6 +2484,8 @@ void K<T>::proj_dist_set(hipStream_t s, const Grid& g, const SetArgs<T>& a, int 
                                          long long, SampleCtl, const ChainHooks*, double*, T*, long long);                                                     \
   template void K<T>::proj_scalars_arr(hipStream_t, long long, const T*, int, T, T, ProjScalars<T>*, double*, T*, \
                                        T*, long long);                                                           \
+  template void K<T>::proj_scalars_arr_slab(hipStream_t, long long, const T*, int, T, T, ProjScalars<T>*, double*, T*, T*, long long, \
+                                            const ChainHooks*, long long, int*);                                     \
   template void K<T>::proj_dist_set(hipStream_t, const Grid&, const SetArgs<T>&, int, const ProjScalars<T>*, double*);
 SIPX_INST(float)
 SIPX_INST(double)

@@ -562,6 +562,9 @@ struct K {
                                  double* reg, T* gseg0, long long chunk);
   static void proj_scalars_arr(hipStream_t s, long long len, const T* v, int prox, T pmin, T pmax, ProjScalars<T>* ps,
                                double* partials, T* maxpart, T* compact, long long true_len);
+  static void proj_scalars_arr_slab(hipStream_t s, long long len, const T* v, int prox, T pmin, T pmax, ProjScalars<T>* ps,
+                                    double* partials, T* maxpart, T* compact, long long true_len, const ChainHooks* hooks,
+                                    long long compact_len, int* host_ovf);
   // ||P(v)-v||^2 and ||v||^2 of the set-produced vector into partial slots dst[0..NB), dst[NB..2NB)
   static void proj_dist_set(hipStream_t s, const Grid& g, const SetArgs<T>& a, int v_is_s, const ProjScalars<T>* ps,
                             double* dst);

@@ -636,7 +636,9 @@ SLAB_LOOSE = [
     (2, ["bounds", "rank:3", "l1:D_z"], (32, 24, 16)),
     (3, ["bounds", "rank:3", "l1:D_z"], (32, 24, 16)),
     (4, ["bounds", "nuc:z"], (12, 10, 5)),
-    (2, ["bounds", "l1dft"], (32, 24, 16)),
+    (2, ["bounds", "l1dft"], (32, 24, 16)),                  # the slab-decomposed transform: 8 + 8 planes, 12 + 12 rows
+    (3, ["bounds", "l1dft"], (20, 18, 10)),                  # ragged: 4 + 4 + 2 planes, 6 + 6 + 6 rows
+    (4, ["l1dft", "bounds"], (12, 10, 5)),                   # 2 + 2 + 1 planes and an empty slab; rows 3 + 3 + 3 + 1
     (3, ["bounds", "card:D_z", "l1:D_x"], (32, 24, 16)),
     (4, ["bounds", "card:D_z"], (12, 10, 5)),
     (2, ["l1dft", "card:D_z", "bounds"], (32, 24, 16)),
@@ -658,6 +660,15 @@ def test_slab_cardinality_through_an_owner_rank(sipx, tmp_path, monkeypatch, wor
     """The gathered form of a set on D_z (SIPX_SLAB_CARD_GATHER=1: cardinality projected by an owner rank on the whole array instead
     of the search through the slab collectives): one more plane of P(v) travels for the adjoint stencil; ragged and empty slabs."""
     monkeypatch.setenv("SIPX_SLAB_CARD_GATHER", "1")
+    test_sharded_ranks_on_one_gpu(sipx, tmp_path, world, kinds, n, False, decomp="slab")
+
+
+@pytest.mark.timeout(400)
+@pytest.mark.parametrize("world,kinds,n", [(2, ["bounds", "l1dft"], (32, 24, 16)), (3, ["l1dft", "card:D_z", "bounds"], (20, 18, 10))])
+def test_slab_dft_through_an_owner_rank(sipx, tmp_path, monkeypatch, world, kinds, n):
+    """The gathered form of the l1-DFT set (SIPX_SLAB_DFT_GATHER=1: an owner rank projects the whole array on a stream of its own)
+    instead of the slab-decomposed transform."""
+    monkeypatch.setenv("SIPX_SLAB_DFT_GATHER", "1")
     test_sharded_ranks_on_one_gpu(sipx, tmp_path, world, kinds, n, False, decomp="slab")
 
 
@@ -731,7 +742,11 @@ def test_sharded_ranks_on_one_gpu(sipx, tmp_path, world, kinds, n, phase, decomp
                 ref = (y_s if k[0] == "y" else l_s)[i]
                 # a multiplier of a set that is not active is a rounding residue of size rho * eps * |y|: that is its scale
                 scale = max(np.linalg.norm(ref), float(ls.rho.max()) * np.finfo(TF).eps * np.linalg.norm(y_s[i]))
-                assert np.linalg.norm(yl[k] - ref) <= 5e-4 * scale, (r, k)
+                # (the slab-decomposed DFT rounds differently from hipFFT's 3-D plan of the serial run: x agrees to 1e-7, and a
+                #  multiplier that is nothing but rho * (rounding of y - s) then differs by about its own size -- 1.1e-3 of the
+                #  scale above for the inactive bounds set beside the l1-DFT set, measured)
+                dft_slab = decomp == "slab" and "l1dft" in kinds and len(n) == 3 and os.environ.get("SIPX_SLAB_DFT_GATHER") != "1"
+                assert np.linalg.norm(yl[k] - ref) <= (5e-3 if dft_slab else 5e-4) * scale, (r, k)
 
 
 def test_sharded_one_rank_through_rccl(sipx, tmp_path):
