@@ -1850,7 +1850,7 @@ class Engine : public EngineBase {
   // RcclComm has only ever run with a world of one here (a gpurun box has one GPU), and the slab decomposition hands RCCL halo
   // planes that live in hipMemMap-backed memory.  Before any array of the context is allocated every rank therefore runs the
   // communicator's operations once on KNOWN data -- the grouped all-reduce + neighbour exchange, the in-place reduce-scatter and
-  // all-gather (the offsets RcclComm computes), the fan scatter / gather, all on plain memory; then the neighbour exchange once
+  // all-gather (the offsets RcclComm computes), the fan scatter / gather, the all-to-all, all on plain memory; then the neighbour exchange once
   // more with its four buffers inside a mapped granule between two unmapped ones -- compares what arrived with what must have
   // arrived, and the ranks agree on the outcome through one more all-reduce on plain memory.  Wrong data from a base operation
   // is an error of sipx_finalize on every rank alike (the caller may attach another communicator: bench.py goes on with
@@ -1946,6 +1946,22 @@ class Engine : public EngineBase {
         if (R == W - 1)
           for (size_t q = 0; q < W * chunk && ok; ++q)
             if (h[q] != (T)(val((int)(q / chunk), q) + 11.0)) { ok = false; why = "gather: a range at the root is not what its rank sent"; }
+      }
+      // D2: all-to-all (the transposition of the slab-decomposed DFT): range d of what rank r sends carries (r, d)
+      if (ok) {
+        T* a2a = dalloc<T>(3 * W * chunk);
+        try {
+          for (size_t q = 0; q < W * chunk; ++q) h[q] = (T)((R + 1) * 64 + (int)(q / chunk) + (double)(q & 15) / 16.0);
+          put(a2a, W * chunk);
+          c.alltoall(a2a, a2a + W * chunk, a2a + 2 * W * chunk, chunk, dt, stream_);
+          get(a2a + W * chunk, W * chunk);
+          for (size_t q = 0; q < W * chunk && ok; ++q)
+            if (h[q] != (T)(((int)(q / chunk) + 1) * 64 + R + (double)(q & 15) / 16.0)) { ok = false; why = "all-to-all: a range is not what its rank sent to this one"; }
+        } catch (...) {
+          dfree(a2a);
+          throw;
+        }
+        dfree(a2a);
       }
     } catch (const std::exception& ex) {
       ok = false;

@@ -678,6 +678,14 @@ def test_slab_decomposed_in_float64(sipx, tmp_path):
 
 
 @pytest.mark.timeout(400)
+@pytest.mark.parametrize("kinds,n", [(["bounds", "l1dft"], (15, 12, 10)), (["bounds", "l1dft", "l1:D_z"], (16, 12, 10))])
+def test_slab_decomposed_dft_in_float64(sipx, tmp_path, kinds, n):
+    """The slab-decomposed transform in Float64 (D2Z / Z2Z / Z2D plans), three ranks with a ragged last slab; odd n0 (the half
+    spectrum then has no Nyquist column) and even."""
+    test_sharded_ranks_on_one_gpu(sipx, tmp_path, 3, kinds, n, False, decomp="slab", tf="f64")
+
+
+@pytest.mark.timeout(400)
 def test_slab_decomposed_with_the_sampled_prediction(sipx, tmp_path, monkeypatch):
     """The sampled prediction of theta inside the slab-decomposed iteration (every rank samples its planes, one all-reduce of
     the histograms), forced on for a grid this small: same end point as the serial solve, identical on every rank."""
@@ -743,10 +751,11 @@ def test_sharded_ranks_on_one_gpu(sipx, tmp_path, world, kinds, n, phase, decomp
                 # a multiplier of a set that is not active is a rounding residue of size rho * eps * |y|: that is its scale
                 scale = max(np.linalg.norm(ref), float(ls.rho.max()) * np.finfo(TF).eps * np.linalg.norm(y_s[i]))
                 # (the slab-decomposed DFT rounds differently from hipFFT's 3-D plan of the serial run: x agrees to 1e-7, and a
-                #  multiplier that is nothing but rho * (rounding of y - s) then differs by about its own size -- 1.1e-3 of the
-                #  scale above for the inactive bounds set beside the l1-DFT set, measured)
+                #  multiplier that is nothing but rho * (rounding of y - s) then differs by about its own size -- 1e-3 (Float32) to
+                #  2e-2 (Float64) of rho * eps * |y| for the inactive bounds set beside the l1-DFT set, measured: allowed on top)
                 dft_slab = decomp == "slab" and "l1dft" in kinds and len(n) == 3 and os.environ.get("SIPX_SLAB_DFT_GATHER") != "1"
-                assert np.linalg.norm(yl[k] - ref) <= (5e-3 if dft_slab else 5e-4) * scale, (r, k)
+                noise = float(ls.rho.max()) * np.finfo(TF).eps * np.linalg.norm(y_s[i])
+                assert np.linalg.norm(yl[k] - ref) <= 5e-4 * scale + (5e-2 * noise if dft_slab else 0.0), (r, k)
 
 
 def test_sharded_one_rank_through_rccl(sipx, tmp_path):
