@@ -277,10 +277,14 @@ int sipx_rccl_unique_id(void* id128);
  *   SIPX_DECOMP_SLAB: by z-slab of the grid, for the WHOLE iteration: every rank holds every set and works on its planes of
  *     the (globally indexed) arrays.  No N-vector crosses the fabric: the right-hand side needs no reduction, x no all-gather
  *     (one halo plane to each neighbour instead), the threshold searches all-reduce their 19 probe sums and all-gather the few
- *     magnitudes inside the final bracket, and every per-set sum goes through the one all-reduce of sipx_update_y_l.  For
- *     sets whose projector only needs sums over the grid: bounds, l1 / l2 ball, annulus, prox_l1 on the identity or on
- *     D_x / D_y / D_z / TV (sipx_finalize refuses others).  sipx_set_owned is ignored; sipx_download is then a collective
- *     (every rank calls it: it gathers the slabs of x, y_i, l_i). */
+ *     magnitudes inside the final bracket, and every per-set sum goes through the one all-reduce of sipx_update_y_l.  Sets
+ *     whose projector only needs sums over the grid -- bounds, l1 / l2 ball, annulus, prox_l1 on the identity or on D_x / D_y /
+ *     D_z / TV -- work that way; since round 5 the others are taken too (y_i, l_i on the slabs as well): slice-wise rank /
+ *     nuclear norm on z-slices by every rank on its own slices, cardinality by a search over the same collectives, the l1 ball
+ *     behind the DFT on a 3-D grid by a slab-decomposed transform (one all-to-all each way), any other projector by an owner
+ *     rank on the gathered vector (two fan exchanges for that set).  Refused: caller-supplied sparse operators, Minkowski
+ *     contexts, the stencil form of Q.  sipx_set_owned is ignored; sipx_download is then a collective (every rank calls it: it
+ *     gathers the slabs of x, y_i, l_i). */
 #define SIPX_DECOMP_SETS 0
 #define SIPX_DECOMP_SLAB 1
 /* the same decomposition with FULL-size arrays on every rank: SIPX_DECOMP_SLAB backs every N-sized array of a rank with memory for
