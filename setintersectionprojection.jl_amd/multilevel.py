@@ -166,6 +166,12 @@ def PARSDMM_multi_level(m, TD_OP_levels, AtA_levels, P_sub_levels, set_Prop_leve
             else:
                 prev = ctx
         if not host_transfers:
+            if timings is not None and dist is None:
+                # (what a caller that only wants x would wait for: sipx_download with x alone -- timed apart, the caller of this
+                #  function subtracts it from its own clock)
+                t0 = time.perf_counter()
+                prev.download(want_ly=False)
+                rec["download_x_only_s"] = time.perf_counter() - t0
             t0 = time.perf_counter()
             x, l, y = prev.download()
             rec["download_s"] = time.perf_counter() - t0
