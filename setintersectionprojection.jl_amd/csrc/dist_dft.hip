@@ -5,6 +5,8 @@
 #include <hipfft/hipfft.h>
 
 #include <cmath>
+#include <cstdio>
+#include <cstdlib>
 #include <stdexcept>
 #include <string>
 
@@ -101,6 +103,11 @@ struct DistDftImpl {
   bool have2 = false, havez = false;
   Cx<T>*A = nullptr, *S = nullptr, *R = nullptr, *X = nullptr;
   T *mag = nullptr, *wr = nullptr;
+  // scratch of the threshold search, this projector's own (partial slots, per-block extrema, the compaction buffer, the exchange
+  // segments of the bracket): nothing it leaves behind can be read by another set's search
+  double* sp = nullptr;
+  T *sm = nullptr, *sc = nullptr, *sg = nullptr;
+  long long sc_len = 0, sg_len = 0;
   ProjScalars<T>*ps = nullptr, *psf = nullptr;
   T radius_raw = 0;
   long long bytes = 0;
@@ -109,7 +116,10 @@ struct DistDftImpl {
     U* p = nullptr;
     if (count <= 0) count = 1;
     SIPX_HIP(hipMalloc((void**)&p, (size_t)count * sizeof(U)));
-    SIPX_HIP(hipMemset(p, 0, (size_t)count * sizeof(U)));
+    // (on the projector's own stream: a fill on the null stream is not ordered against a non-blocking stream -- the initialisation
+    //  kernel of the search state that follows would race with it, and a rank whose state came out all zero takes other decisions
+    //  than the ranks it shares every collective with)
+    SIPX_HIP(hipMemsetAsync(p, 0, (size_t)count * sizeof(U), stream));
     bytes += count * (long long)sizeof(U);
     if (long long* t = alloc_tally()) *t += count * (long long)sizeof(U);
     return p;
@@ -132,6 +142,7 @@ DistDft<T>::DistDft(const long long n[3], long long z0, long long z1, long long 
   const long long a1 = std::min<long long>(n[1], (long long)rank * I.c1), b1 = std::min<long long>(n[1], (long long)(rank + 1) * I.c1);
   I.m1 = b1 - a1;
   I.chunk = I.zc * I.c1 * I.nh0;
+  I.stream = stream;
   I.A = I.template alloc<Cx<T>>(I.pz * n[1] * I.nh0);
   I.S = I.template alloc<Cx<T>>(I.chunk * world);
   I.R = I.template alloc<Cx<T>>(I.chunk * world);
@@ -142,6 +153,7 @@ DistDft<T>::DistDft(const long long n[3], long long z0, long long z1, long long 
   I.psf = I.template alloc<ProjScalars<T>>(1);
   K<T>::ps_init(stream, I.ps, nullptr);
   K<T>::ps_init(stream, I.psf, nullptr);
+  SIPX_HIP(hipStreamSynchronize(stream));
   I.radius_raw = (T)(radius * sqrt((double)I.N));        // ||F_unitary v||_1 <= b  <=>  ||FFT v||_1 <= b sqrt(N)
   const bool dbl = sizeof(T) == 8;
   if (I.pz > 0) {
@@ -167,7 +179,8 @@ DistDft<T>::~DistDft() {
   DistDftImpl<T>& I = *impl_;
   if (I.have2) { (void)hipfftDestroy(I.p_fwd2); (void)hipfftDestroy(I.p_inv2); }
   if (I.havez) (void)hipfftDestroy(I.p_z);
-  for (void* p : {(void*)I.A, (void*)I.S, (void*)I.R, (void*)I.X, (void*)I.mag, (void*)I.wr, (void*)I.ps, (void*)I.psf})
+  for (void* p : {(void*)I.A, (void*)I.S, (void*)I.R, (void*)I.X, (void*)I.mag, (void*)I.wr, (void*)I.ps, (void*)I.psf, (void*)I.sp, (void*)I.sm,
+                  (void*)I.sc, (void*)I.sg})
     if (p) (void)hipFree(p);
   delete impl_;
 }
@@ -212,8 +225,27 @@ void DistDft<T>::project(T* v, bool feas, Comm* comm, const ChainHooks* hooks, d
     hipLaunchKernelGGL((k_dft_abs<T>), dim3(fit_grid(I.n[2] * I.m1 * I.nh0, NB)), dim3(BLOCK), 0, s, I.n[2], I.m1, I.c1, I.nh0, I.ndup, I.R, I.mag);
   }
   // ---- the threshold: this rank's share of the N magnitudes, the sums and the bracket through the slab collectives
-  K<T>::proj_scalars_arr_slab(s, I.n[2] * I.m1 * I.n[0], I.mag, PX_L1, T(0), I.radius_raw, ps, partials, maxpart, compact, I.N, hooks, compact_len,
-                              host_ovf);
+  (void)partials; (void)maxpart; (void)compact; (void)compact_len;
+  if (!I.sp) {
+    I.sp = I.template alloc<double>((long long)(PREP_SLOTS + 2) * NB);
+    I.sm = I.template alloc<T>(2 * NB);
+    I.sc_len = std::max<long long>(I.n[2] * I.c1 * I.n[0], hooks->gcap + 64) + 64;
+    I.sc = I.template alloc<T>(I.sc_len);
+    I.sg_len = (long long)I.world * (hooks->gcap + GATHER_HDR);
+    I.sg = I.template alloc<T>(I.sg_len);
+  }
+  ChainHooks hk = *hooks;
+  hk.gbuf = I.sg;
+  K<T>::proj_scalars_arr_slab(s, I.n[2] * I.m1 * I.n[0], I.mag, PX_L1, T(0), I.radius_raw, ps, I.sp, I.sm, I.sc, I.N, &hk, I.sc_len, host_ovf);
+  static const bool dbg = getenv("SIPX_DFT_DEBUG") != nullptr;      // the state the search ended in, per rank, on stderr (synchronises)
+  if (dbg) {
+    ProjScalars<T> h;
+    SIPX_HIP(hipStreamSynchronize(s));
+    SIPX_HIP(hipMemcpy(&h, ps, sizeof(h), hipMemcpyDeviceToHost));
+    fprintf(stderr, "[sipx dft] rank %d feas %d: need %d theta %.9g asum %.9g vmax %.9g bracket (%.9g, %.9g] spec (%.9g, %.9g] spec_ok %d ovf %d gather_ovf %d n_compact %llu refine %d rounds %d\n",
+            I.rank, (int)feas, h.need, (double)h.theta, h.asum, (double)h.vmax, h.lo, h.hi, h.spec_lo, h.spec_hi, h.spec_ok, h.spec_overflow, h.gather_overflow,
+            (unsigned long long)h.n_compact, h.refine, h.rounds_used);
+  }
   // ---- shrinkage and the way back (every rank makes the same calls whether or not v lies inside the ball: the collectives match;
   //      inside the ball nothing is stored at the end)
   if (I.m1 > 0) {
