@@ -664,6 +664,24 @@ def test_slab_cardinality_through_an_owner_rank(sipx, tmp_path, monkeypatch, wor
 
 
 @pytest.mark.timeout(400)
+def test_slab_decomposed_runs_repeat_bit_for_bit(sipx, tmp_path):
+    """Two runs of BASELINE config 4's list on four ranks: the same bits in x and in every log.  (Every collective protocol of the
+    slab decomposition rests on all ranks taking the same decisions from the same state; round 5 found a set-up race -- a zero-fill
+    on the null stream against a kernel on the non-blocking engine stream -- through runs that differed.)"""
+    import os
+    import torch.multiprocessing as mp
+    res = []
+    for rep in range(2):
+        out = tmp_path / f"run{rep}"
+        out.mkdir()
+        mp.spawn(_sharded_worker, args=(4, 30900 + (os.getpid() % 1000) + rep, str(out), C4_KINDS, (16, 12, 8), "gloo", "torch", False, "slab", "f32"),
+                 nprocs=4, join=True)
+        res.append(np.load(out / "r0.npz"))
+    for k in res[0].files:
+        assert np.array_equal(res[0][k], res[1][k], equal_nan=True), k
+
+
+@pytest.mark.timeout(400)
 @pytest.mark.parametrize("world,kinds,n", [(2, ["bounds", "l1dft"], (32, 24, 16)), (3, ["l1dft", "card:D_z", "bounds"], (20, 18, 10))])
 def test_slab_dft_through_an_owner_rank(sipx, tmp_path, monkeypatch, world, kinds, n):
     """The gathered form of the l1-DFT set (SIPX_SLAB_DFT_GATHER=1: an owner rank projects the whole array on a stream of its own)
