@@ -95,7 +95,7 @@ def _carry_rho(options, log):
 
 
 def PARSDMM_multi_level(m, TD_OP_levels, AtA_levels, P_sub_levels, set_Prop_levels, comp_grid_levels, options,
-                        device=None, timings=None, host_transfers=False, dist=None, comm_mode=None):
+                        device=None, timings=None, host_transfers=False, dist=None, comm_mode=None, outputs="all"):
     """src/PARSDMM_multi_level.jl:8-89.  `timings` (a dict) receives per-level wall times: context set-up, the device-side
     warm start, the solve, its iteration count.  host_transfers=True keeps the round-1 path (download, resample through
     host.resample_nn / interpolate_y_l, upload at sipx_finalize) for A/B comparison.
@@ -103,7 +103,10 @@ def PARSDMM_multi_level(m, TD_OP_levels, AtA_levels, P_sub_levels, set_Prop_leve
     sipx_set_decomp -- the set lists of the multilevel examples, bounds and l1 / TV, allow it); between levels the coarse
     slabs are all-gathered on the device one block at a time (a coarse-sized temporary) and every rank resamples the grid points
     it stores.  Every rank makes the same calls and
-    returns the same x, log, l, y."""
+    returns the same x, log, l, y.  outputs="x": l and y stay on the device and come back as None (a caller that uses the projection
+    alone does not wait for their copies: 8 of the 9 vectors of the {bounds, l1 TV} list)."""
+    if outputs not in ("all", "x"):
+        raise host.SipxError(f"outputs must be 'all' or 'x', not {outputs!r}")
     import time
     attach = None
     keep = []
@@ -166,6 +169,11 @@ def PARSDMM_multi_level(m, TD_OP_levels, AtA_levels, P_sub_levels, set_Prop_leve
             else:
                 prev = ctx
         if not host_transfers:
+            if outputs == "x":
+                t0 = time.perf_counter()
+                x, l, y = prev.download(want_ly=False)
+                rec["download_s"] = rec["download_x_only_s"] = time.perf_counter() - t0
+                return x, log, None, None
             if timings is not None and dist is None:
                 # (what a caller that only wants x would wait for: sipx_download with x alone -- timed apart, the caller of this
                 #  function subtracts it from its own clock)

@@ -382,3 +382,18 @@ def test_float32_loop_of_the_rank_projector(sipx, capfd, monkeypatch):
     print(f"Float32 loop - oracle {d32:.2e}, Float64 loop - oracle {d64:.2e}")
     assert d32 < 5e-4 and d64 < 5e-4
     assert np.allclose(l32.obj[:8], lo.obj[:8], rtol=2e-3)
+
+
+@pytest.mark.gpu
+def test_multilevel_returns_x_alone_when_asked(sipx):
+    """PARSDMM_multi_level(..., outputs="x"): the same x and log, l and y left on the device (None) -- what a caller that uses the
+    projection alone asks for (bench.py reports the difference as c5.whole_solve_x_only_s)."""
+    from sipx import multilevel as ML
+    from tests.test_gpu_parity import _ml_problem
+    ML_, m, opt, L = _ml_problem(sipx, (24, 20, 16), (25.0, 20.0, 10.0), np.float32, 2)
+    xa, loga, la, ya = ML.PARSDMM_multi_level(m.copy(), *L[:5], opt)
+    xb, logb, lb, yb = ML.PARSDMM_multi_level(m.copy(), *L[:5], opt, outputs="x")
+    assert lb is None and yb is None and la is not None
+    assert np.array_equal(xa, xb) and np.array_equal(loga.obj, logb.obj)
+    with pytest.raises(sipx.host.SipxError):
+        ML.PARSDMM_multi_level(m.copy(), *L[:5], opt, outputs="y")
