@@ -127,9 +127,21 @@ struct DistDftImpl {
 };
 
 template <typename T>
+static void dist_dft_release(DistDftImpl<T>* impl) {
+  DistDftImpl<T>& I = *impl;
+  if (I.p_fwd2) (void)hipfftDestroy(I.p_fwd2);
+  if (I.p_inv2) (void)hipfftDestroy(I.p_inv2);
+  if (I.p_z) (void)hipfftDestroy(I.p_z);
+  for (void* p : {(void*)I.A, (void*)I.S, (void*)I.R, (void*)I.X, (void*)I.mag, (void*)I.wr, (void*)I.ps, (void*)I.psf, (void*)I.sp, (void*)I.sm,
+                  (void*)I.sc, (void*)I.sg})
+    if (p) (void)hipFree(p);
+  delete impl;
+}
+template <typename T>
 DistDft<T>::DistDft(const long long n[3], long long z0, long long z1, long long zchunk, int world, int rank, double radius, hipStream_t stream)
     : impl_(new DistDftImpl<T>()) {
   DistDftImpl<T>& I = *impl_;
+  try {
   for (int a = 0; a < 3; ++a) I.n[a] = n[a];
   I.N = n[0] * n[1] * n[2];
   I.z0 = z0; I.z1 = z1 > z0 ? z1 : z0; I.pz = I.z1 - I.z0; I.zc = zchunk;
@@ -172,18 +184,15 @@ DistDft<T>::DistDft(const long long n[3], long long z0, long long z1, long long 
     fftc(hipfftSetStream(I.p_z, stream), "set stream");
     I.havez = true;
   }
+  } catch (...) {          // (an allocation or a plan failed: nothing of a half-built projector stays behind)
+    dist_dft_release(impl_);
+    impl_ = nullptr;
+    throw;
+  }
 }
 
 template <typename T>
-DistDft<T>::~DistDft() {
-  DistDftImpl<T>& I = *impl_;
-  if (I.have2) { (void)hipfftDestroy(I.p_fwd2); (void)hipfftDestroy(I.p_inv2); }
-  if (I.havez) (void)hipfftDestroy(I.p_z);
-  for (void* p : {(void*)I.A, (void*)I.S, (void*)I.R, (void*)I.X, (void*)I.mag, (void*)I.wr, (void*)I.ps, (void*)I.psf, (void*)I.sp, (void*)I.sm,
-                  (void*)I.sc, (void*)I.sg})
-    if (p) (void)hipFree(p);
-  delete impl_;
-}
+DistDft<T>::~DistDft() { dist_dft_release(impl_); }
 
 template <typename T>
 void DistDft<T>::set_stream(hipStream_t s) {
