@@ -476,3 +476,7 @@ def test_slab_decomposable_classifier(sipx):
     for bad in (sd("cardinality", "D_z", 0, 10, ("matrix", "")), sd("rank", "identity", 0, 2, ("slice", "z")),
                 sd("l1", "DFT", 0.0, 1.0, ("matrix", "")), sd("bounds", "identity", 0.0, 1.0, ("fiber", "z"))):
         assert not sharded.slab_decomposable(*build(c3[:2] + [bad]))
+        # ... but the slab decomposition TAKES such lists when it is asked for (round 5: slab-local slices, a search over the slab
+        # collectives, a slab-decomposed transform, an owner rank): "auto" stays with the lists whose every projector works from sums
+        assert sharded.slab_admissible(*build(c3[:2] + [bad]))
+    assert sharded.slab_admissible(*build(c3))
