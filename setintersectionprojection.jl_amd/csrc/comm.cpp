@@ -179,8 +179,12 @@ class RcclComm : public Comm {
     }
     const char* sb = static_cast<const char*>(send);
     char* rb = static_cast<char*>(recv);
+    // (the rank's own range: a copy on the stream, not a send to itself)
+    if (hipMemcpyAsync(rb + (size_t)rank * bytes, sb + (size_t)rank * bytes, bytes, hipMemcpyDeviceToDevice, s) != hipSuccess)
+      throw std::runtime_error("all-to-all: the copy of the rank's own range failed");
     nccl_check(a.GroupStart(), "ncclGroupStart");
     for (int p = 0; p < world; ++p) {
+      if (p == rank) continue;
       nccl_check(a.Send(sb + (size_t)p * bytes, chunk, nccl_type(dtype), p, comm_, s), "ncclSend (all-to-all)");
       nccl_check(a.Recv(rb + (size_t)p * bytes, chunk, nccl_type(dtype), p, comm_, s), "ncclRecv (all-to-all)");
     }

@@ -647,7 +647,17 @@ class Engine : public EngineBase {
       if (slab_loose_)
         if (const char* ls = std::getenv("SIPX_SLAB_LOOSE_SPARSE")) if (ls[0] == '0') sparse_wanted = false;
     }
-    if (comm_) comm_self_test(sparse_wanted);               // (every rank takes the same branch: the verdict is all-reduced)
+    if (comm_) {                                            // (every rank takes the same branch: the verdict is all-reduced)
+      bool any_dft = false;
+      for (const auto& st : sets_) any_dft |= st.slab_dft;
+      comm_self_test(sparse_wanted, any_dft);
+      if (selftest_alltoall_failed_) {       // the transposition of the slab-decomposed DFT does not work here: an owner rank projects such sets
+        int nfan = 0;
+        for (auto& st : sets_) nfan += st.fan ? 1 : 0;
+        for (auto& st : sets_)
+          if (st.slab_dft) { st.slab_dft = false; st.fan = true; st.fan_owner = (nfan++) % comm_->world; }
+      }
+    }
     // Everything from here to the initial feasibility allocates and uploads -- no collective.  A rank that fails in there (out of
     // device memory: the likeliest rank-local failure of a first multi-GPU run) used to throw by itself while the others went on
     // into the collectives of the initial feasibility and waited for it for ever; now every rank reports to one all-reduce on the
@@ -1856,7 +1866,7 @@ class Engine : public EngineBase {
   // is an error of sipx_finalize on every rank alike (the caller may attach another communicator: bench.py goes on with
   // torch.distributed callbacks); a failure of the mapped exchange alone switches THIS context to full-size arrays on every
   // rank.  SIPX_COMM_SELFTEST=0 skips it.  The same code runs through the callback communicator (tests: 2-4 ranks on one GPU).
-  void comm_self_test(bool want_mapped) {
+  void comm_self_test(bool want_mapped, bool want_a2a = false) {
     const char* e = std::getenv("SIPX_COMM_SELFTEST");
     if (e && e[0] == '0') {
       selftest_ = "skipped (SIPX_COMM_SELFTEST=0)";
@@ -1904,7 +1914,7 @@ class Engine : public EngineBase {
         if (hr[i] != 1000.0 * W * (W + 1) / 2 + (double)W * i) { why = std::string(what) + ": the all-reduced sums are wrong"; return false; }
       return true;
     };
-    bool ok = true, mapped_ok = true;
+    bool ok = true, mapped_ok = true, a2a_ok = true;
     try {
       // A: grouped all-reduce + neighbour exchange, plain memory
       red_fill();
@@ -1947,25 +1957,27 @@ class Engine : public EngineBase {
           for (size_t q = 0; q < W * chunk && ok; ++q)
             if (h[q] != (T)(val((int)(q / chunk), q) + 11.0)) { ok = false; why = "gather: a range at the root is not what its rank sent"; }
       }
-      // D2: all-to-all (the transposition of the slab-decomposed DFT): range d of what rank r sends carries (r, d)
-      if (ok) {
-        T* a2a = dalloc<T>(3 * W * chunk);
-        try {
-          for (size_t q = 0; q < W * chunk; ++q) h[q] = (T)((R + 1) * 64 + (int)(q / chunk) + (double)(q & 15) / 16.0);
-          put(a2a, W * chunk);
-          c.alltoall(a2a, a2a + W * chunk, a2a + 2 * W * chunk, chunk, dt, stream_);
-          get(a2a + W * chunk, W * chunk);
-          for (size_t q = 0; q < W * chunk && ok; ++q)
-            if (h[q] != (T)(((int)(q / chunk) + 1) * 64 + R + (double)(q & 15) / 16.0)) { ok = false; why = "all-to-all: a range is not what its rank sent to this one"; }
-        } catch (...) {
-          dfree(a2a);
-          throw;
-        }
-        dfree(a2a);
-      }
     } catch (const std::exception& ex) {
       ok = false;
       why = std::string("an operation failed: ") + ex.what();
+    }
+    // D2 (only where a set needs it: the slab-decomposed DFT): all-to-all -- range d of what rank r sends carries (r, d).  A failure
+    // here does not fail sipx_finalize: the set goes through an owner rank instead (two fan exchanges), on every rank alike.
+    if (ok && want_a2a) {
+      T* a2a = nullptr;
+      try {
+        a2a = dalloc<T>(3 * W * chunk);
+        for (size_t q = 0; q < W * chunk; ++q) h[q] = (T)((R + 1) * 64 + (int)(q / chunk) + (double)(q & 15) / 16.0);
+        put(a2a, W * chunk);
+        c.alltoall(a2a, a2a + W * chunk, a2a + 2 * W * chunk, chunk, dt, stream_);
+        get(a2a + W * chunk, W * chunk);
+        for (size_t q = 0; q < W * chunk && a2a_ok; ++q)
+          if (h[q] != (T)(((int)(q / chunk) + 1) * 64 + R + (double)(q & 15) / 16.0)) { a2a_ok = false; a2a_why_ = "a range is not what its rank sent to this one"; }
+      } catch (const std::exception& ex) {
+        a2a_ok = false;
+        a2a_why_ = ex.what();
+      }
+      dfree(a2a);
     }
     // E: the neighbour exchange out of / into hipMemMap-backed memory (one mapped granule between two that are not)
     if (ok && want_mapped) {
@@ -1989,19 +2001,22 @@ class Engine : public EngineBase {
       if (!colon || std::atoi(colon + 1) == R) {
         if (!std::strncmp(f, "mapped", 6) && want_mapped) { mapped_ok = false; mapped_why_ = "test hook"; }
         if (!std::strncmp(f, "base", 4)) { ok = false; why = "test hook"; }
+        if (!std::strncmp(f, "alltoall", 8) && want_a2a) { a2a_ok = false; a2a_why_ = "test hook"; }
       }
     }
     // the verdict, the same on every rank
-    bool all_ok = ok, all_mapped = mapped_ok;
+    bool all_ok = ok, all_mapped = mapped_ok, all_a2a = a2a_ok;
     try {
       hr[0] = 4096.0 + (ok ? 0.0 : 1.0);
       hr[1] = 4096.0 + (mapped_ok ? 0.0 : 1.0);
-      SIPX_HIP(hipMemcpy(red, hr.data(), 2 * sizeof(double), hipMemcpyHostToDevice));
-      c.allreduce_sum(red, 2, SIPX_F64, stream_);
+      hr[2] = 4096.0 + (a2a_ok ? 0.0 : 1.0);
+      SIPX_HIP(hipMemcpy(red, hr.data(), 3 * sizeof(double), hipMemcpyHostToDevice));
+      c.allreduce_sum(red, 3, SIPX_F64, stream_);
       SIPX_HIP(hipStreamSynchronize(stream_));
-      SIPX_HIP(hipMemcpy(hr.data(), red, 2 * sizeof(double), hipMemcpyDeviceToHost));
+      SIPX_HIP(hipMemcpy(hr.data(), red, 3 * sizeof(double), hipMemcpyDeviceToHost));
       all_ok = hr[0] == 4096.0 * W;
       all_mapped = hr[1] == 4096.0 * W;
+      all_a2a = hr[2] == 4096.0 * W;
     } catch (const std::exception& ex) {
       all_ok = false;
       if (why.empty()) why = std::string("the verdict's all-reduce failed: ") + ex.what();
@@ -2017,6 +2032,10 @@ class Engine : public EngineBase {
       selftest_ = "passed; exchange out of hipMemMap-backed memory failed (" + (mapped_why_.empty() ? std::string("on another rank") : mapped_why_) +
                   "): full-size arrays";
       selftest_mapped_failed_ = true;
+    }
+    if (want_a2a && !all_a2a) {
+      selftest_ += "; all-to-all failed (" + (a2a_why_.empty() ? std::string("on another rank") : a2a_why_) + "): the l1-DFT set through an owner rank";
+      selftest_alltoall_failed_ = true;
     }
   }
 
@@ -4279,7 +4298,8 @@ class Engine : public EngineBase {
   // verdict of the communicator self-test of sipx_finalize ("none" without a communicator)
   std::string selftest_ = "none", mapped_why_;
   double* agree_buf_ = nullptr;
-  bool selftest_mapped_failed_ = false;
+  bool selftest_mapped_failed_ = false, selftest_alltoall_failed_ = false;
+  std::string a2a_why_;
   long long wlo_ = 0, whi_ = 0;
   Grid Gr_, Gyl_;
   ChainHooks hooks_;
