@@ -123,7 +123,9 @@ end
 # (or under mpiexec with SIPX_RANK / SIPX_WORLD taken from the MPI environment).  Rank 0 obtains the 128-byte ncclUniqueId
 # from the engine and publishes it through SIPX_ID_FILE; the others wait for the file.  SIPX_DECOMP=slab (default where the
 # set list allows it: bounds / l1 / l2 / annulus on the identity or D_x / D_y / D_z / TV) divides the WHOLE iteration by
-# z-slab; SIPX_DECOMP=sets is the reference's own split by constraint set.  Every rank returns the same x and log;
+# z-slab; SIPX_DECOMP=sets is the reference's own split by constraint set.  SIPX_DECOMP=slab may also be ASKED for with the
+# other set lists (round 5: slice-wise rank / nuclear norm on z-slices, cardinality, the l1 ball behind the DFT run inside the slab
+# iteration, any other projector through an owner rank; sipx.h, sipx_set_decomp).  Every rank returns the same x and log;
 # with the set decomposition l[i], y[i] are filled on the rank that owns set i only.
 localize(v) = (isdefined(Main, :DistributedArrays) && v isa Main.DistributedArrays.DArray) ? convert(Vector, v) : v
 
