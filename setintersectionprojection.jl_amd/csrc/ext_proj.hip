@@ -10,6 +10,8 @@
 //   slice / matrix rank  x[:,:,i] <- U_r S_r V_r'      reference: projectors/project_rank!.jl:3-48
 //       rocSOLVER batched SVD + rocBLAS batched GEMM: the one unit of the path that is not
 //       bandwidth bound, so it is a library call, not a hand-written kernel.
+#define ROCBLAS_BETA_FEATURES_API 1
+#define ROCBLAS_NO_DEPRECATED_WARNINGS 1
 #include <hipcub/hipcub.hpp>
 #include <hipfft/hipfft.h>
 #include <rocblas/rocblas.h>
@@ -21,6 +23,8 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <map>
+#include <mutex>
 #include <stdexcept>
 #include <string>
 #include <vector>
@@ -1750,11 +1754,156 @@ __global__ __launch_bounds__(256) void k_gram_bb(int k, int b, const TS* __restr
 }
 
 static rocblas_status gemm_sbx(rocblas_handle h, rocblas_operation ta, rocblas_operation tb, int m, int n, int k, float alpha, const float* A,
-                               int lda, long long sa, const float* B, int ldb, long long sb, float beta, float* C, int ldc, long long sc, int batch) {
+                               int lda, long long sa, const float* B, int ldb, long long sb, float beta, float* C, int ldc, long long sc, int batch,
+                               int tune = 0) {
+  (void)tune;
   return rocblas_sgemm_strided_batched(h, ta, tb, m, n, k, &alpha, A, lda, sa, B, ldb, sb, &beta, C, ldc, sc, batch);
 }
+// ---- which rocBLAS kernel for a Float64 batched product (round 5) ----------------------------------------------------------------
+// The library's own choice for the filter product G V (512 x 56 x 512 per slice) is a 64 x 32 macro tile: the 56 columns fall into
+// two tiles and every Gram matrix crosses the fabric twice (profiles/r05_c4_512_pmc.json: 2.58 GB per launch against 1.3 GB);
+// rocblas_gemm_strided_batched_ex lets the caller name a solution, and another one runs the same product in 0.26 instead of 0.36 ms
+// (b x b x k: 0.035 instead of 0.061 ms; tools/gemm_solutions_bench.cpp).  The first call of a shape in a process therefore tries
+// every solution the library lists for it, on the call's own operands (beta = 0: the output is simply written again):
+//   * solutions are grouped by the BITS they produce (a hash of the output: kernels that add in the same order give the same bits --
+//     all the fast ones of a shape do) -- the group is chosen by a rule that does not depend on timing noise (the library's own
+//     group unless another is more than 8 % faster; among groups within 5 % of the fastest the one with the lowest solution number),
+//     so that every process, every rank and every run of a library version ends with the same arithmetic;
+//   * inside the group the fastest member by the clock (any member gives the same bits).
+// The choice is kept per shape for the life of the process.  SIPX_GEMM_TUNE=0: the library's choice (A/B switch).
+struct GemmShape {
+  int ta, tb, m, n, k, lda, ldb, ldc;
+  bool operator<(const GemmShape& o) const {
+    return std::memcmp(this, &o, sizeof(GemmShape)) < 0;
+  }
+};
+__global__ __launch_bounds__(256) void k_hash_bits(const unsigned long long* __restrict__ p, long long n, unsigned long long* out) {
+  unsigned long long acc = 0;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) acc += p[i] * (2ull * (unsigned long long)i + 1ull);
+  atomicAdd(out, acc);       // (integer sums: the order of arrival does not matter)
+}
+static std::mutex& gemm_tune_mutex() { static std::mutex m; return m; }
+static std::map<GemmShape, int>& gemm_tune_table() { static std::map<GemmShape, int> t; return t; }
+static bool gemm_tune_on() {
+  static const bool on = [] { const char* e = getenv("SIPX_GEMM_TUNE"); return !(e && e[0] == '0'); }();
+  return on;
+}
+static rocblas_status dgemm_ex(rocblas_handle h, rocblas_operation ta, rocblas_operation tb, int m, int n, int k, const double* alpha, const double* A, int lda,
+                               long long sa, const double* B, int ldb, long long sb, const double* beta, double* C, int ldc, long long sc, int batch, int sol) {
+  return rocblas_gemm_strided_batched_ex(h, ta, tb, m, n, k, alpha, A, rocblas_datatype_f64_r, lda, sa, B, rocblas_datatype_f64_r, ldb, sb, beta, C,
+                                         rocblas_datatype_f64_r, ldc, sc, C, rocblas_datatype_f64_r, ldc, sc, batch, rocblas_datatype_f64_r,
+                                         sol ? rocblas_gemm_algo_solution_index : rocblas_gemm_algo_standard, sol, 0);
+}
+static int gemm_tune(rocblas_handle h, const GemmShape& key, const double* A, long long sa, const double* B, long long sb, double* C, long long sc, int batch) {
+  const rocblas_operation ta = (rocblas_operation)key.ta, tb = (rocblas_operation)key.tb;
+  const double one = 1.0, zero = 0.0;
+  hipStream_t s = nullptr;
+  if (rocblas_get_stream(h, &s) != rocblas_status_success) return 0;
+  rocblas_int ns = 0;
+  if (rocblas_gemm_strided_batched_ex_get_solutions(h, ta, tb, key.m, key.n, key.k, &one, A, rocblas_datatype_f64_r, key.lda, sa, B, rocblas_datatype_f64_r, key.ldb,
+                                                    sb, &zero, C, rocblas_datatype_f64_r, key.ldc, sc, C, rocblas_datatype_f64_r, key.ldc, sc, batch,
+                                                    rocblas_datatype_f64_r, rocblas_gemm_algo_solution_index, 0, nullptr, &ns) != rocblas_status_success || ns < 1)
+    return 0;
+  std::vector<rocblas_int> sols(ns);
+  if (rocblas_gemm_strided_batched_ex_get_solutions(h, ta, tb, key.m, key.n, key.k, &one, A, rocblas_datatype_f64_r, key.lda, sa, B, rocblas_datatype_f64_r, key.ldb,
+                                                    sb, &zero, C, rocblas_datatype_f64_r, key.ldc, sc, C, rocblas_datatype_f64_r, key.ldc, sc, batch,
+                                                    rocblas_datatype_f64_r, rocblas_gemm_algo_solution_index, 0, sols.data(), &ns) != rocblas_status_success)
+    return 0;
+  sols.resize(ns);
+  unsigned long long* dh = nullptr;
+  hipEvent_t e0 = nullptr, e1 = nullptr;
+  if (hipMalloc((void**)&dh, sizeof(unsigned long long)) != hipSuccess) return 0;
+  (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
+  const long long span = sc * (long long)batch;
+  struct Res { int sol; unsigned long long hash; float ms; };
+  std::vector<Res> res;
+  auto probe = [&](int sol, Res& r) -> bool {
+    r.sol = sol;
+    if (dgemm_ex(h, ta, tb, key.m, key.n, key.k, &one, A, key.lda, sa, B, key.ldb, sb, &zero, C, key.ldc, sc, batch, sol) != rocblas_status_success) return false;
+    (void)hipMemsetAsync(dh, 0, sizeof(unsigned long long), s);
+    hipLaunchKernelGGL(k_hash_bits, dim3(1024), dim3(256), 0, s, reinterpret_cast<const unsigned long long*>(C), span, dh);
+    if (hipMemcpyAsync(&r.hash, dh, sizeof(unsigned long long), hipMemcpyDeviceToHost, s) != hipSuccess) return false;
+    (void)hipEventRecord(e0, s);
+    for (int rep = 0; rep < 2; ++rep)
+      if (dgemm_ex(h, ta, tb, key.m, key.n, key.k, &one, A, key.lda, sa, B, key.ldb, sb, &zero, C, key.ldc, sc, batch, sol) != rocblas_status_success) return false;
+    (void)hipEventRecord(e1, s);
+    if (hipEventSynchronize(e1) != hipSuccess) return false;
+    r.ms = 0;
+    (void)hipEventElapsedTime(&r.ms, e0, e1);
+    return r.ms > 0;
+  };
+  Res def{};
+  const bool have_def = probe(0, def);
+  for (int sol : sols) { Res r{}; if (probe(sol, r)) res.push_back(r); }
+  int choice = 0;
+  if (have_def && !res.empty()) {
+    // groups by output bits: fastest member, lowest solution number
+    std::map<unsigned long long, std::pair<float, int>> best;      // hash -> (fastest time, its solution)
+    std::map<unsigned long long, int> lowest;
+    for (const Res& r : res) {
+      auto it = best.find(r.hash);
+      if (it == best.end() || r.ms < it->second.first) best[r.hash] = {r.ms, r.sol};
+      auto lt = lowest.find(r.hash);
+      if (lt == lowest.end() || r.sol < lt->second) lowest[r.hash] = r.sol;
+    }
+    float t_best = 1e30f;
+    for (auto& kv : best) t_best = std::min(t_best, kv.second.first);
+    const float t_def_group = best.count(def.hash) ? std::min(def.ms, best[def.hash].first) : def.ms;
+    if (t_def_group <= 1.08f * t_best) {
+      choice = (best.count(def.hash) && best[def.hash].first < def.ms) ? best[def.hash].second : 0;      // the library's own arithmetic, its fastest kernel
+    } else {
+      unsigned long long pick = 0;
+      int low = 0x7fffffff;
+      for (auto& kv : best)
+        if (kv.second.first <= 1.05f * t_best && lowest[kv.first] < low) { low = lowest[kv.first]; pick = kv.first; }
+      choice = best[pick].second;
+    }
+    if (getenv("SIPX_GEMM_TUNE_DEBUG"))
+      fprintf(stderr, "[sipx gemm] %c%c %d x %d x %d, batch %d: %d solutions in %zu groups by bits; library %.3f ms, fastest %.3f ms; solution %d\n",
+              key.ta == rocblas_operation_none ? 'N' : 'T', key.tb == rocblas_operation_none ? 'N' : 'T', key.m, key.n, key.k, batch, ns, best.size(),
+              def.ms / 2, t_best / 2, choice);
+  }
+  // the call's own result, by the kernel that was chosen (the probes left another candidate's output in C)
+  (void)dgemm_ex(h, ta, tb, key.m, key.n, key.k, &one, A, key.lda, sa, B, key.ldb, sb, &zero, C, key.ldc, sc, batch, choice);
+  (void)hipStreamSynchronize(s);
+  (void)hipFree(dh);
+  if (e0) (void)hipEventDestroy(e0);
+  if (e1) (void)hipEventDestroy(e1);
+  return choice;
+}
 static rocblas_status gemm_sbx(rocblas_handle h, rocblas_operation ta, rocblas_operation tb, int m, int n, int k, double alpha, const double* A,
-                               int lda, long long sa, const double* B, int ldb, long long sb, double beta, double* C, int ldc, long long sc, int batch) {
+                               int lda, long long sa, const double* B, int ldb, long long sb, double beta, double* C, int ldc, long long sc, int batch,
+                               int tune = 0) {
+  // (the tuned path: plain products C = A B with whole outputs.  tune 1: a FIXED shape -- what the filter loop is made of; tune 2: a
+  //  shape whose first dimension follows the data -- the projection on the vectors far above the rest, X_L' Z with 6 ... 31 rows,
+  //  for which the library's choice takes 0.2-0.56 ms where another kernel takes 0.03: tried once, at the first such call, and the
+  //  solution kept for every row count (a call it does not take falls back to the library's); 0: the library's choice)
+  if (tune && gemm_tune_on() && alpha == 1.0 && beta == 0.0 && batch > 0 && (const double*)C != A && (const double*)C != B && (long long)m * n * k >= (1ll << 16)) {
+    const GemmShape key{(int)ta, (int)tb, tune == 2 ? -1 : m, n, k, lda, ldb, ldc};
+    int sol = 0;
+    bool known = false;
+    {
+      std::lock_guard<std::mutex> lk(gemm_tune_mutex());
+      auto it = gemm_tune_table().find(key);
+      if (it != gemm_tune_table().end()) { sol = it->second; known = true; }
+    }
+    if (!known) {
+      GemmShape probe = key;
+      probe.m = m;
+      sol = gemm_tune(h, probe, A, sa, B, sb, C, sc, batch);      // (leaves the product in C)
+      std::lock_guard<std::mutex> lk(gemm_tune_mutex());
+      gemm_tune_table()[key] = sol;
+      return rocblas_status_success;
+    }
+    if (sol != 0) {
+      const rocblas_status st = dgemm_ex(h, ta, tb, m, n, k, &alpha, A, lda, sa, B, ldb, sb, &beta, C, ldc, sc, batch, sol);
+      if (st == rocblas_status_success) return st;
+      if (tune != 2) {
+        std::lock_guard<std::mutex> lk(gemm_tune_mutex());      // (a solution that does not take this batch count: the library's choice from here on)
+        gemm_tune_table()[key] = 0;
+      }
+    }
+  }
   return rocblas_dgemm_strided_batched(h, ta, tb, m, n, k, &alpha, A, lda, sa, B, ldb, sb, &beta, C, ldc, sc, batch);
 }
 
@@ -1851,17 +2000,17 @@ static int cheb_loop(ExtImpl<T>& I, RouteBufs<TS> B, ChebCtl& C) {
       SIPX_HIP(hipMemsetAsync(I.info, 0, sizeof(rocblas_int) * 2 * batch, s));
       for (int pass = 0; pass < (m_prev > 0 ? 2 : 1); ++pass) {
         if constexpr (F32) hipLaunchKernelGGL((k_gram_bb<TS>), dim3(nb), dim3(256), 0, s, k, b, A, A, I.Hs);
-        else blas_check(gemm_sbx(I.blas, T_, N_, b, b, k, TS(1), A, k, sX, A, k, sX, TS(0), (TS*)I.Hs, b, sH, nb), "Y'Y");
+        else blas_check(gemm_sbx(I.blas, T_, N_, b, b, k, TS(1), A, k, sX, A, k, sX, TS(0), (TS*)I.Hs, b, sH, nb, 1), "Y'Y");
         hipLaunchKernelGGL((k_chol_inv<TS>), dim3(nb), dim3(256), 0, s, b, nb, I.Hs, B.Cs, I.info);
-        blas_check(gemm_sbx(I.blas, N_, N_, k, b, b, TS(1), A, k, sX, B.Cs, b, sH, TS(0), F1, k, sX, nb), "Y Rinv");
+        blas_check(gemm_sbx(I.blas, N_, N_, k, b, b, TS(1), A, k, sX, B.Cs, b, sH, TS(0), F1, k, sX, nb, 1), "Y Rinv");
         std::swap(A, F1);
       }
       mark(0);
-      blas_check(gemm_sbx(I.blas, N_, N_, k, b, k, TS(1), Gd, k, sG, A, k, sX, TS(0), F1, k, sX, nb), "G Q");
+      blas_check(gemm_sbx(I.blas, N_, N_, k, b, k, TS(1), Gd, k, sG, A, k, sX, TS(0), F1, k, sX, nb, 1), "G Q");
       ++C.mults;
       mark(1);
       if constexpr (F32) hipLaunchKernelGGL((k_gram_bb<TS>), dim3(nb), dim3(256), 0, s, k, b, A, F1, I.Hs);
-      else blas_check(gemm_sbx(I.blas, T_, N_, b, b, k, TS(1), A, k, sX, F1, k, sX, TS(0), (TS*)I.Hs, b, sH, nb), "Q'GQ");
+      else blas_check(gemm_sbx(I.blas, T_, N_, b, b, k, TS(1), A, k, sX, F1, k, sX, TS(0), (TS*)I.Hs, b, sH, nb, 1), "Q'GQ");
       mark(2);
       if (own_jacobi || F32)
         hipLaunchKernelGGL((k_ritz_jacobi<TS>), dim3(nb), dim3(256), 0, s, b, nb, I.Hs, B.Zs, Ws, I.info + batch, I.info + 2 * batch);
@@ -1869,8 +2018,8 @@ static int cheb_loop(ExtImpl<T>& I, RouteBufs<TS> B, ChebCtl& C) {
         blas_check(rocsolver_dsyevj_strided_batched(I.blas, rocblas_esort_ascending, rocblas_evect_original, rocblas_fill_upper, b, I.Hs, b, sH,
                                                     0.0, I.Es, 100, I.info + 2 * batch, Ws, b, I.info + batch, nb), "syevj (Ritz)");
       mark(3);
-      blas_check(gemm_sbx(I.blas, N_, N_, k, b, b, TS(1), A, k, sX, B.Zs, b, sH, TS(0), X, k, sX, nb), "Q Z");
-      blas_check(gemm_sbx(I.blas, N_, N_, k, b, b, TS(1), F1, k, sX, B.Zs, b, sH, TS(0), F2, k, sX, nb), "(GQ) Z");
+      blas_check(gemm_sbx(I.blas, N_, N_, k, b, b, TS(1), A, k, sX, B.Zs, b, sH, TS(0), X, k, sX, nb, 1), "Q Z");
+      blas_check(gemm_sbx(I.blas, N_, N_, k, b, b, TS(1), F1, k, sX, B.Zs, b, sH, TS(0), F2, k, sX, nb, 1), "(GQ) Z");
       mark(2);
     } else {
       SIPX_HIP(hipMemsetAsync(I.info, 0, sizeof(rocblas_int) * 2 * batch, s));
@@ -2037,7 +2186,7 @@ static int cheb_loop(ExtImpl<T>& I, RouteBufs<TS> B, ChebCtl& C) {
     for (int i = 1; i <= m; ++i) {
       TS* Z = F2;
       if (i > 1) {
-        blas_check(gemm_sbx(I.blas, N_, N_, k, b, k, TS(1), Gd, k, sG, Y1, k, sX, TS(0), F1, k, sX, nb), "G Y");
+        blas_check(gemm_sbx(I.blas, N_, N_, k, b, k, TS(1), Gd, k, sG, Y1, k, sX, TS(0), F1, k, sX, nb, 1), "G Y");
         ++C.mults;
         Z = F1;
         mark(1);
@@ -2054,7 +2203,7 @@ static int cheb_loop(ExtImpl<T>& I, RouteBufs<TS> B, ChebCtl& C) {
       }
       if (nl > 0) {
         const TS* XL = X + (long long)(b - nl) * k;
-        blas_check(gemm_sbx(I.blas, T_, N_, nl, b, k, TS(1), XL, k, sX, Z, k, sX, TS(0), B.Cs, b, sH, nb), "X_L' Z");
+        blas_check(gemm_sbx(I.blas, T_, N_, nl, b, k, TS(1), XL, k, sX, Z, k, sX, TS(0), B.Cs, b, sH, nb, 2), "X_L' Z");
         hipLaunchKernelGGL((k_cheb_mask<TS>), dim3((unsigned)std::min<long long>(NB, ((long long)nl * b * nb + 255) / 256)), dim3(256), 0, s, b, g, r, nl, nb,
                            Ws, B.Cs, nd);
         blas_check(gemm_sbx(I.blas, N_, N_, k, b, nl, TS(-1), XL, k, sX, B.Cs, b, sH, TS(1), Z, k, sX, nb), "Z - X_L C");
@@ -2280,9 +2429,9 @@ void ExtProj<T>::project(T* v, bool feas, double* partials, T* maxpart, T* compa
       const bool right = I.n <= I.m;          // eigenvectors of X'X (right singular vectors) or of XX' (left ones)
       const auto N_ = rocblas_operation_none, T_ = rocblas_operation_transpose;
       if (right)
-        blas_check(rocblas_dgemm_strided_batched(I.blas, T_, N_, k, k, I.m, &one, I.Ad, I.m, sA, I.Ad, I.m, sA, &zero, I.Gd, k, sG, I.batch), "gram");
+        blas_check(gemm_sbx(I.blas, T_, N_, k, k, I.m, 1.0, I.Ad, I.m, sA, I.Ad, I.m, sA, 0.0, I.Gd, k, sG, I.batch, 1), "gram");
       else
-        blas_check(rocblas_dgemm_strided_batched(I.blas, N_, T_, k, k, I.n, &one, I.Ad, I.m, sA, I.Ad, I.m, sA, &zero, I.Gd, k, sG, I.batch), "gram");
+        blas_check(gemm_sbx(I.blas, N_, T_, k, k, I.n, 1.0, I.Ad, I.m, sA, I.Ad, I.m, sA, 0.0, I.Gd, k, sG, I.batch, 1), "gram");
       // Rank projection: only the span of the top-r eigenvectors is needed, and it moves little from one PARSDMM
       // iteration to the next.  Block subspace iteration with Rayleigh-Ritz on b = r + 16 vectors, started from the
       // previous call's Ritz vectors, is accepted when every top-r pair has a residual below 1e-12 theta_max (far inside
@@ -2333,21 +2482,21 @@ void ExtProj<T>::project(T* v, bool feas, double* partials, T* maxpart, T* compa
         double* X = I.Xs[w];
         hipLaunchKernelGGL(k_sub_fro, dim3(I.batch), dim3(BLOCK), 0, s, k, I.Gd, I.Fro);
         for (int it = 0; it < max_it; ++it) {
-          blas_check(rocblas_dgemm_strided_batched(I.blas, N_, N_, k, b, k, &one, I.Gd, k, sG, X, k, sX, &zero, I.Qs, k, sX, I.batch), "G X");
+          blas_check(gemm_sbx(I.blas, N_, N_, k, b, k, 1.0, I.Gd, k, sG, X, k, sX, 0.0, I.Qs, k, sX, I.batch, 1), "G X");
           hipLaunchKernelGGL(k_sub_normalize, dim3(I.batch), dim3(BLOCK), 0, s, k, b, I.batch, I.Qs);
-          blas_check(rocblas_dgemm_strided_batched(I.blas, T_, N_, b, b, k, &one, I.Qs, k, sX, I.Qs, k, sX, &zero, I.Hs, b, sH, I.batch), "Y'Y");
+          blas_check(gemm_sbx(I.blas, T_, N_, b, b, k, 1.0, I.Qs, k, sX, I.Qs, k, sX, 0.0, I.Hs, b, sH, I.batch, 1), "Y'Y");
           blas_check(rocsolver_dpotrf_strided_batched(I.blas, rocblas_fill_upper, b, I.Hs, b, sH, I.info, I.batch), "potrf");
           blas_check(rocblas_dtrsm_strided_batched(I.blas, rocblas_side_right, rocblas_fill_upper, N_, rocblas_diagonal_non_unit, k, b, &one,
                                                    I.Hs, b, sH, I.Qs, k, sX, I.batch), "trsm");          // Qs: orthonormal basis
-          blas_check(rocblas_dgemm_strided_batched(I.blas, N_, N_, k, b, k, &one, I.Gd, k, sG, I.Qs, k, sX, &zero, I.Zs, k, sX, I.batch), "G Q");
-          blas_check(rocblas_dgemm_strided_batched(I.blas, T_, N_, b, b, k, &one, I.Qs, k, sX, I.Zs, k, sX, &zero, I.Hs, b, sH, I.batch), "Q'GQ");
+          blas_check(gemm_sbx(I.blas, N_, N_, k, b, k, 1.0, I.Gd, k, sG, I.Qs, k, sX, 0.0, I.Zs, k, sX, I.batch, 1), "G Q");
+          blas_check(gemm_sbx(I.blas, T_, N_, b, b, k, 1.0, I.Qs, k, sX, I.Zs, k, sX, 0.0, I.Hs, b, sH, I.batch, 1), "Q'GQ");
           // b x b Ritz problem: one-kernel Jacobi (the divide-and-conquer driver applies its b-1 reflectors one launch at a
           // time, 50 ms for 256 matrices of 48 x 48)
           blas_check(rocsolver_dsyevj_strided_batched(I.blas, rocblas_esort_ascending, rocblas_evect_original, rocblas_fill_upper, b, I.Hs,
                                                       b, sH, 0.0, I.Es, 100, I.info + 2 * I.batch, I.Ws, b, I.info + I.batch, I.batch),
                      "syevj (Ritz)");
-          blas_check(rocblas_dgemm_strided_batched(I.blas, N_, N_, k, b, b, &one, I.Qs, k, sX, I.Hs, b, sH, &zero, X, k, sX, I.batch), "Q Z");
-          blas_check(rocblas_dgemm_strided_batched(I.blas, N_, N_, k, b, b, &one, I.Zs, k, sX, I.Hs, b, sH, &zero, I.Qs, k, sX, I.batch), "(GQ) Z");
+          blas_check(gemm_sbx(I.blas, N_, N_, k, b, b, 1.0, I.Qs, k, sX, I.Hs, b, sH, 0.0, X, k, sX, I.batch, 1), "Q Z");
+          blas_check(gemm_sbx(I.blas, N_, N_, k, b, b, 1.0, I.Zs, k, sX, I.Hs, b, sH, 0.0, I.Qs, k, sX, I.batch, 1), "(GQ) Z");
           SIPX_HIP(hipMemsetAsync(I.sub_res, 0, 2 * sizeof(unsigned long long), s));
           hipLaunchKernelGGL(k_sub_residual, dim3(I.batch), dim3(BLOCK), 0, s, k, b, I.r, I.batch, I.Qs, X, I.Ws, b, I.info,
                              I.info + I.batch, I.Fro, I.sub_res);
@@ -2421,11 +2570,11 @@ void ExtProj<T>::project(T* v, bool feas, double* partials, T* maxpart, T* compa
         ldsel_stride = sG;
       }
       if (right) {       // X <- (X * Escl) * Esel'
-        blas_check(rocblas_dgemm_strided_batched(I.blas, N_, N_, I.m, inner, k, &one, I.Ad, I.m, sA, Escl, k, ldsel_stride, &zero, I.Ud, I.m, sU, I.batch), "gemm X V");
-        blas_check(rocblas_dgemm_strided_batched(I.blas, N_, T_, I.m, I.n, inner, &one, I.Ud, I.m, sU, Esel, k, ldsel_stride, &zero, I.Ad, I.m, sA, I.batch), "gemm (XV) V'");
+        blas_check(gemm_sbx(I.blas, N_, N_, I.m, inner, k, 1.0, I.Ad, I.m, sA, Escl, k, ldsel_stride, 0.0, I.Ud, I.m, sU, I.batch), "gemm X V");
+        blas_check(gemm_sbx(I.blas, N_, T_, I.m, I.n, inner, 1.0, I.Ud, I.m, sU, Esel, k, ldsel_stride, 0.0, I.Ad, I.m, sA, I.batch), "gemm (XV) V'");
       } else {           // X <- Escl * (Esel' * X)
-        blas_check(rocblas_dgemm_strided_batched(I.blas, T_, N_, inner, I.n, k, &one, Esel, k, ldsel_stride, I.Ad, I.m, sA, &zero, I.Vd, k, sV, I.batch), "gemm U' X");
-        blas_check(rocblas_dgemm_strided_batched(I.blas, N_, N_, I.m, I.n, inner, &one, Escl, k, ldsel_stride, I.Vd, k, sV, &zero, I.Ad, I.m, sA, I.batch), "gemm U (U'X)");
+        blas_check(gemm_sbx(I.blas, T_, N_, inner, I.n, k, 1.0, Esel, k, ldsel_stride, I.Ad, I.m, sA, 0.0, I.Vd, k, sV, I.batch), "gemm U' X");
+        blas_check(gemm_sbx(I.blas, N_, N_, I.m, I.n, inner, 1.0, Escl, k, ldsel_stride, I.Vd, k, sV, 0.0, I.Ad, I.m, sA, I.batch), "gemm U (U'X)");
       }
       hipLaunchKernelGGL((k_seg_scatter<T, double>), dim3(NB), dim3(BLOCK), 0, s, I.map, I.Ad, v, flag);
       SIPX_HIP(hipGetLastError());

@@ -78,6 +78,12 @@ if [[ $PART == b || $PART == all ]]; then
   unset SIPX_RANK_LANE
   # ... and over 80 iterations: what a long solve of that list sustains (the slice-rank projector's route on inputs that keep moving)
   $T python bench.py $S --no-512 --config c4 --steps 80 --warmup 2 > $O/${R}_c4_512_bench_80_iterations.json 2>>$O/bench.err
+  # fabric-side traffic of C4's kernels (the rank projector's GEMMs included): two counter passes of the c4 command
+  B4="--no-cpu-baseline --no-512 --no-c4 --no-c5 --no-c2 --no-whole-call --no-kernel-table"
+  $T rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $O/pmc_f -o t --output-format csv -- python3 bench.py $B4 --config c4 --steps 6 --warmup 2 > /dev/null 2>$O/pmc.err
+  $T rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $O/pmc_w -o t --output-format csv -- python3 bench.py $B4 --config c4 --steps 6 --warmup 2 > /dev/null 2>>$O/pmc.err
+  python tools/summarize_pmc.py $O/pmc_f $O/pmc_w $O/${R}_c4_512_pmc.json "bench.py $B4 --config c4 --steps 6 --warmup 2" > /dev/null
+  rm -rf $O/pmc_f $O/pmc_w
   trace c2 c2_2048 6:25
   $T python bench.py $S --config c2 > $O/${R}_c2_2048_bench.json 2>>$O/bench.err
 fi
