@@ -1878,7 +1878,9 @@ static rocblas_status gemm_sbx(rocblas_handle h, rocblas_operation ta, rocblas_o
   //  shape whose first dimension follows the data -- the projection on the vectors far above the rest, X_L' Z with 6 ... 31 rows,
   //  for which the library's choice takes 0.2-0.56 ms where another kernel takes 0.03: tried once, at the first such call, and the
   //  solution kept for every row count (a call it does not take falls back to the library's); 0: the library's choice)
-  if (tune && gemm_tune_on() && alpha == 1.0 && beta == 0.0 && batch > 0 && (const double*)C != A && (const double*)C != B && (long long)m * n * k >= (1ll << 16)) {
+  //  3: no trial, but the kernel a trial of the same shape has chosen, if there was one -- products that accumulate, beta = 1)
+  const bool may_try = (tune == 1 || tune == 2) && alpha == 1.0 && beta == 0.0 && (const double*)C != A && (const double*)C != B;
+  if (tune && gemm_tune_on() && batch > 0 && (long long)m * n * k >= (1ll << 16)) {
     const GemmShape key{(int)ta, (int)tb, tune == 2 ? -1 : m, n, k, lda, ldb, ldc};
     int sol = 0;
     bool known = false;
@@ -1887,7 +1889,7 @@ static rocblas_status gemm_sbx(rocblas_handle h, rocblas_operation ta, rocblas_o
       auto it = gemm_tune_table().find(key);
       if (it != gemm_tune_table().end()) { sol = it->second; known = true; }
     }
-    if (!known) {
+    if (!known && may_try) {
       GemmShape probe = key;
       probe.m = m;
       sol = gemm_tune(h, probe, A, sa, B, sb, C, sc, batch);      // (leaves the product in C)
@@ -2329,8 +2331,8 @@ static bool rank_cheb_route(ExtImpl<T>& I, int w, int k, bool& cheap_fail, bool 
     // flat spectrum: the inertia certificate (X_r Theta_r goes through F1)
     hipLaunchKernelGGL(k_cert_shift, dim3(NB), dim3(BLOCK), 0, s, k, b, r, batch, I.Gd, I.Ws, I.Bd);
     hipLaunchKernelGGL(k_cert_scale, dim3(NB), dim3(BLOCK), 0, s, k, b, r, batch, X, I.Ws, F1);
-    blas_check(rocblas_dgemm_strided_batched(I.blas, N_, T_, k, k, r, &one, F1 + (long long)(b - r) * k, k, sX, X + (long long)(b - r) * k, k, sX,
-                                             &one, I.Bd, k, sG, batch), "certificate: rank-r term");
+    blas_check(gemm_sbx(I.blas, N_, T_, k, k, r, 1.0, F1 + (long long)(b - r) * k, k, sX, X + (long long)(b - r) * k, k, sX, 1.0, I.Bd, k, sG, batch, 3),
+               "certificate: rank-r term");
     if (own_cert) rank_cert_factor<T>(I, k);
     else blas_check(rocsolver_dpotrf_strided_batched(I.blas, rocblas_fill_upper, k, I.Bd, k, sG, I.info, batch), "certificate: potrf");
     SIPX_HIP(hipMemsetAsync(I.sub_res, 0, 2 * sizeof(unsigned long long), s));
@@ -2570,11 +2572,11 @@ void ExtProj<T>::project(T* v, bool feas, double* partials, T* maxpart, T* compa
         ldsel_stride = sG;
       }
       if (right) {       // X <- (X * Escl) * Esel'
-        blas_check(gemm_sbx(I.blas, N_, N_, I.m, inner, k, 1.0, I.Ad, I.m, sA, Escl, k, ldsel_stride, 0.0, I.Ud, I.m, sU, I.batch), "gemm X V");
-        blas_check(gemm_sbx(I.blas, N_, T_, I.m, I.n, inner, 1.0, I.Ud, I.m, sU, Esel, k, ldsel_stride, 0.0, I.Ad, I.m, sA, I.batch), "gemm (XV) V'");
+        blas_check(gemm_sbx(I.blas, N_, N_, I.m, inner, k, 1.0, I.Ad, I.m, sA, Escl, k, ldsel_stride, 0.0, I.Ud, I.m, sU, I.batch, 1), "gemm X V");
+        blas_check(gemm_sbx(I.blas, N_, T_, I.m, I.n, inner, 1.0, I.Ud, I.m, sU, Esel, k, ldsel_stride, 0.0, I.Ad, I.m, sA, I.batch, 1), "gemm (XV) V'");
       } else {           // X <- Escl * (Esel' * X)
-        blas_check(gemm_sbx(I.blas, T_, N_, inner, I.n, k, 1.0, Esel, k, ldsel_stride, I.Ad, I.m, sA, 0.0, I.Vd, k, sV, I.batch), "gemm U' X");
-        blas_check(gemm_sbx(I.blas, N_, N_, I.m, I.n, inner, 1.0, Escl, k, ldsel_stride, I.Vd, k, sV, 0.0, I.Ad, I.m, sA, I.batch), "gemm U (U'X)");
+        blas_check(gemm_sbx(I.blas, T_, N_, inner, I.n, k, 1.0, Esel, k, ldsel_stride, I.Ad, I.m, sA, 0.0, I.Vd, k, sV, I.batch, 1), "gemm U' X");
+        blas_check(gemm_sbx(I.blas, N_, N_, I.m, I.n, inner, 1.0, Escl, k, ldsel_stride, I.Vd, k, sV, 0.0, I.Ad, I.m, sA, I.batch, 1), "gemm U (U'X)");
       }
       hipLaunchKernelGGL((k_seg_scatter<T, double>), dim3(NB), dim3(BLOCK), 0, s, I.map, I.Ad, v, flag);
       SIPX_HIP(hipGetLastError());
