@@ -2261,9 +2261,9 @@ static bool rank_cheb_route(ExtImpl<T>& I, int w, int k, bool& cheap_fail, bool 
   };
   RouteBufs<double> B64{I.Gd, I.Bd, I.Xs[w], I.Qs, I.Ys, I.Zs, I.Xc, I.Cs, I.Hs};
   double* X = I.Xs[w];
-  hipLaunchKernelGGL(k_sub_fro, dim3(batch), dim3(BLOCK), 0, s, k, I.Gd, I.Fro);
   // Float32 loop (see above): a warm call whose previous call has left Ritz values (Wprev) to tell which pairs are far above the rest
   const bool want32 = I.G32 != nullptr && KN.f32 && KN.eps_bw > 0 && !cold && I.have_wprev[w];
+  if (want32) hipLaunchKernelGGL(k_sub_fro, dim3(batch), dim3(BLOCK), 0, s, k, I.Gd, I.Fro);      // (the Float64 loop takes the norms below, once)
   int rc = CHEB_GIVE_UP;
   bool done32 = false;
   if (want32) {
