@@ -1036,6 +1036,8 @@ def main():
                      # calls the engine made on its communicator per timed step, by kind (scatter_gather: the fan exchanges of the
                      # gathered sets of a slab-decomposed long list); which sets of such a list are slab-local / gathered
                      "collectives_per_step": coll_per_step, "slab_loose": counters.get("slab_loose"),
+                     # the set updated on a stream and host thread of its own beside the rest (C4's slice-rank set; -1: none)
+                     "lane_set": counters.get("lane_set"),
                      "comm_mode": (comm_mode or os.environ.get("SIPX_COMM") or ("rccl" if dist.get_backend() == "nccl" else "torch")) if dist is not None else None,
                      # what this context allocated on its GPU (slab-decomposed: the rank's planes + halo planes only)
                      "device_bytes_per_rank": dev_bytes["context"], "device_used_bytes": dev_bytes["device_used"]},

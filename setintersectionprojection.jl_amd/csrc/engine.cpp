@@ -1045,11 +1045,31 @@ class Engine : public EngineBase {
           const SetState<T>& s = sets_[i];
           if (s.owned && !s.in_sweep && !s.dist_ext && s.ident && !s.custom && s.ext && (s.ext_kind == EXT_RANK || s.ext_kind == EXT_NUCLEAR)) lane_set_ = i;
         }
+      // Slab-decomposed (round 5): the slice-rank set of a long list projects the z-slices of the rank's own planes -- no collective
+      // anywhere in its update -- so it takes the same lane, beside the lock-step searches, the sweep and the transform set with
+      // their collectives on the engine stream.  A rank's share of C4 is where this pays most: a call on 64 slices is a chain of
+      // small launches with host round trips in it that leaves most of the chip idle.
+      if (comm_ && slab_ && slab_loose_ && !mk_ && sweep_partial_ && !(ln && ln[0] == '0'))
+        for (int i = 0; i < p_n_ && lane_set_ < 0; ++i) {
+          const SetState<T>& s = sets_[i];
+          if (s.owned && !s.in_sweep && s.slab_ext && s.ident && !s.custom && s.ext && (s.ext_kind == EXT_RANK || s.ext_kind == EXT_NUCLEAR)) lane_set_ = i;      // (s.ext: a rank without planes has no projector and nothing to overlap)
+        }
       if (lane_set_ >= 0) {
-        SIPX_HIP(hipStreamCreateWithFlags(&lane_st_, hipStreamNonBlocking));
+        // A stream of the highest priority: the runtime keeps its hardware queues per priority, so the lane can never share a
+        // queue with the engine stream (streams of one priority are dealt onto four queues in turn; in the slab-decomposed
+        // context the lane had landed on the engine stream's queue and ran strictly behind it: tools/lane_overlap.py, 0.00 ms
+        // together), and the chain of small launches that is the iteration's critical path does not wait behind the sweep.
+        // SIPX_LANE_PRIORITY=0: a plain stream (A/B switch).
+        const char* lp = std::getenv("SIPX_LANE_PRIORITY");
+        int pr_least = 0, pr_greatest = 0;
+        SIPX_HIP(hipDeviceGetStreamPriorityRange(&pr_least, &pr_greatest));
+        if (lp && lp[0] == '0') SIPX_HIP(hipStreamCreateWithFlags(&lane_st_, hipStreamNonBlocking));
+        else SIPX_HIP(hipStreamCreateWithPriority(&lane_st_, hipStreamNonBlocking, lp && lp[0] == 'l' ? pr_least : pr_greatest));
         SIPX_HIP(hipEventCreateWithFlags(&lane_fork_, hipEventDisableTiming));
         SIPX_HIP(hipEventCreateWithFlags(&lane_ev_, hipEventDisableTiming));
-        lane_v_ = dalloc<T>((size_t)sets_[lane_set_].Mpad);
+        // (slab-decomposed: a vector of the exchange layout addressed by global index, like loose_v_)
+        if (slab_) lane_v_ = (slab_local_ && !loose_whole_) ? loose_alloc(Npad) : dalloc<T>((size_t)std::max<long long>(fullpad, sets_[lane_set_].Mpad));
+        else lane_v_ = dalloc<T>((size_t)sets_[lane_set_].Mpad);
       }
     }
     } catch (const std::exception& ex) {
@@ -1450,7 +1470,7 @@ class Engine : public EngineBase {
     // one (MultiBlk::in_rhs; the sets are added in order, rhs_compose.jl:24-31) and k_rhs adds the rest.
     const bool loose_only = sweep && !slab_;
     // (the all-kernel statistics window keeps everything on the engine stream: its event pairs time one kernel at a time)
-    const bool lane_now = loose_only && lane_set_ >= 0 && stats_mode_ != 2;
+    const bool lane_now = (loose_only || (slab_ && sweep)) && lane_set_ >= 0 && stats_mode_ != 2;
     struct LaneGuard {                       // whatever ends this call, the lane's host thread is joined first
       Engine<T>* e;
       ~LaneGuard() {
@@ -1851,11 +1871,12 @@ class Engine : public EngineBase {
     lane_thr_ = std::thread([this, a, part, ptmp, mpart, cbuf, ext]() {
       try {
         SIPX_HIP(hipSetDevice(device_));
-        K<T>::store_v(lane_st_, G_, a, 0, lane_v_);
-        ext->project(lane_v_, false, ptmp, mpart, cbuf);
+        K<T>::store_v(lane_st_, slab_ ? Gr_ : G_, a, 0, lane_v_);
+        if (!slab_) ext->project(lane_v_, false, ptmp, mpart, cbuf);
+        else if (r1_ > r0_) ext->project(lane_v_ + r0_, false, ptmp, mpart, cbuf);      // (the slices of the rank's own planes)
         SetArgs<T> a2 = a;
         a2.vsrc = 2;
-        K<T>::yl(lane_st_, Gyl_, a2, part);
+        K<T>::yl(lane_st_, slab_ ? Gr_ : Gyl_, a2, part);
         SIPX_HIP(hipEventRecord(lane_ev_, lane_st_));
       } catch (...) {
         lane_err_ = std::current_exception();
@@ -1880,9 +1901,12 @@ class Engine : public EngineBase {
     }
     SIPX_HIP(hipStreamWaitEvent(stream_, lane_ev_, 0));
     if ((flags & SIPX_YL_FEAS) && lane_set_ < pp_n_) {
-      SetArgs<T> a = lane_args_;
-      a.v = scr_v_;
-      ext_feasibility(s, a, part_sets_ + ((size_t)lane_set_ * SLOTS + SL_FE2) * NB);
+      if (slab_) dist_feasibility(s, x_, part_sets_ + ((size_t)lane_set_ * SLOTS + SL_FE2) * NB, lane_set_);
+      else {
+        SetArgs<T> a = lane_args_;
+        a.v = scr_v_;
+        ext_feasibility(s, a, part_sets_ + ((size_t)lane_set_ * SLOTS + SL_FE2) * NB);
+      }
     }
   }
 

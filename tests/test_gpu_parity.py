@@ -691,6 +691,28 @@ def test_slab_decomposed_runs_repeat_bit_for_bit(sipx, tmp_path):
 
 
 @pytest.mark.timeout(400)
+def test_slab_decomposed_rank_set_on_its_lane_is_bit_identical(sipx, tmp_path, monkeypatch):
+    """Slab-decomposed, BASELINE config 4's list on three ranks (a ragged last slab): the slice-rank set -- the z-slices of a
+    rank's own planes, no collective in its update -- runs on the lane (engine.cpp, lane_start / lane_join: a stream and a host
+    thread of its own) beside the lock-step searches, the sweep and the decomposed transform.  Same kernels on the same
+    operands: x, y, l and every log equal the in-turn run (SIPX_RANK_LANE=0) bit for bit.
+    Reference: src/update_y_l_parallel.jl:6-90 (the sets are independent given x)."""
+    import os
+    import torch.multiprocessing as mp
+    res = []
+    for rep, lane in enumerate(("1", "0")):
+        monkeypatch.setenv("SIPX_RANK_LANE", lane)
+        out = tmp_path / f"lane{lane}"
+        out.mkdir()
+        mp.spawn(_sharded_worker, args=(3, 31900 + (os.getpid() % 1000) + rep, str(out), C4_KINDS, (16, 12, 8), "gloo", "torch", False, "slab", "f32"),
+                 nprocs=3, join=True)
+        res.append(np.load(out / "r0.npz"))
+    assert len(res[0].files) > 3
+    for k in res[0].files:
+        assert np.array_equal(res[0][k], res[1][k], equal_nan=True), k
+
+
+@pytest.mark.timeout(400)
 @pytest.mark.parametrize("world,kinds,n", [(2, ["bounds", "l1dft"], (32, 24, 16)), (3, ["l1dft", "card:D_z", "bounds"], (20, 18, 10))])
 def test_slab_dft_through_an_owner_rank(sipx, tmp_path, monkeypatch, world, kinds, n):
     """The gathered form of the l1-DFT set (SIPX_SLAB_DFT_GATHER=1: an owner rank projects the whole array on a stream of its own)

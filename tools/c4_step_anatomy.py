@@ -1,5 +1,5 @@
 """Anatomy of one C4 iteration from a rocprofv3 --kernel-trace CSV: the interval between the last two inertia certificates of
-the slice-rank projector (k_cert_or) is one iteration; inside it the span of the rank projector's own call (k_sub_fro ..
+the slice-rank projector (k_cert_or) is one iteration; inside it the span of the rank projector's own call (k_sub_fro_part ..
 k_cert_or), the union of kernel intervals inside and outside that span, and the largest kernels outside it.
 usage: python tools/c4_step_anatomy.py <dir with *kernel_trace.csv> [iterations from the end = 3]"""
 import csv, glob, os, sys, collections
@@ -9,7 +9,7 @@ for f in glob.glob(os.path.join(sys.argv[1], "**", "*kernel_trace.csv"), recursi
         rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), (r.get("Kernel_Name") or r.get("Name"))))
 rows.sort()
 certs = [i for i, r in enumerate(rows) if "k_cert_or" in r[2]]
-fros = [i for i, r in enumerate(rows) if "k_sub_fro" in r[2]]
+fros = [i for i, r in enumerate(rows) if "k_sub_fro_part" in r[2]]
 if len(certs) < 3:
     sys.exit("fewer than three certified calls in the trace")
 def union(rs):
