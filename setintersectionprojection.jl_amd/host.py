@@ -937,10 +937,15 @@ def build_context(m, AtA, TD_OP, set_Prop, P_sub, comp_grid, options, x=None, l=
 _ctx_cache: "dict" = {}
 
 
+_extra_caches: "list" = []           # (multilevel.py keeps the level contexts of its last call: cleared together with these)
+
+
 def clear_context_cache():
     for ctx in list(_ctx_cache.values()):
         ctx.close()
     _ctx_cache.clear()
+    for f in _extra_caches:
+        f()
 
 
 def _cache_limit() -> int:

@@ -94,6 +94,40 @@ def _carry_rho(options, log):
         options.rho_ini = last
 
 
+# The level contexts of the last multilevel call, kept for the next one (round 5, late).  A caller that projects again and again
+# (the reference's examples wrap the call as a projector just like PARSDMM's: examples/constrained_freq_FWI_simple.jl:468) pays
+# more than the allocations for building the levels anew: the driver wipes released device memory asynchronously and an allocation
+# that follows a large release waits for the wipe -- 512^3 Float64: 2.4 s per call back to back where a call on a device at rest
+# takes 1.0.  One entry (the levels of ONE problem: device, precision, grids, set descriptors -- host._context_key per level), only
+# for lists whose descriptors carry no arrays, one rank, and only while the levels together hold at most 40 % of the device; a call
+# with another problem releases it first.  A hit costs sipx_reset per level (the bits of a newly built context,
+# tests/test_gpu_round5.py).  SIPX_MULTILEVEL_CACHE=0 switches it off; clear_level_cache() -- also reached through
+# host.clear_context_cache() -- frees it.
+_level_cache: "dict" = {}
+
+
+def clear_level_cache():
+    for ctxs in list(_level_cache.values()):
+        for c in ctxs:
+            c.close()
+    _level_cache.clear()
+
+
+host._extra_caches.append(clear_level_cache)
+
+
+def _level_keys(m_levels, TD_OP_levels, AtA_levels, P_sub_levels, set_Prop_levels, comp_grid_levels, options, device):
+    if os.environ.get("SIPX_MULTILEVEL_CACHE") == "0" or host._cache_limit() <= 0:
+        return None
+    keys = []
+    for i in range(len(TD_OP_levels)):
+        k = host._context_key(m_levels[i], AtA_levels[i], TD_OP_levels[i], set_Prop_levels[i], P_sub_levels[i], comp_grid_levels[i], options, device)
+        if k is None:
+            return None
+        keys.append(k)
+    return tuple(keys)
+
+
 def PARSDMM_multi_level(m, TD_OP_levels, AtA_levels, P_sub_levels, set_Prop_levels, comp_grid_levels, options,
                         device=None, timings=None, host_transfers=False, dist=None, comm_mode=None, outputs="all"):
     """src/PARSDMM_multi_level.jl:8-89.  `timings` (a dict) receives per-level wall times: context set-up, the device-side
@@ -133,6 +167,15 @@ def PARSDMM_multi_level(m, TD_OP_levels, AtA_levels, P_sub_levels, set_Prop_leve
     prev = None
     x = l = y = None
     log = None
+    key = None
+    if dist is None and not host_transfers:
+        key = _level_keys(m_levels, TD_OP_levels, AtA_levels, P_sub_levels, set_Prop_levels, comp_grid_levels, options, device)
+    cached = _level_cache.pop(key, None) if key is not None else None
+    if cached is None:
+        clear_level_cache()                    # (another problem's levels: released before this one's are allocated)
+    used = [None] * n_levels                   # the contexts of this call, by level
+    rec["contexts_reused"] = cached is not None
+    done = False
     try:
         for i in range(n_levels - 1, -1, -1):
             t0 = time.perf_counter()
@@ -144,13 +187,21 @@ def PARSDMM_multi_level(m, TD_OP_levels, AtA_levels, P_sub_levels, set_Prop_leve
                 x = host.resample_nn(x, nc, nf)
                 l, y = interpolate_y_l(list(l), list(y), set_Prop_levels, comp_grid_levels, dim3, i)
                 options.zero_ini_guess = False
-            ctx = host.build_context(m_levels[i], AtA_levels[i], TD_OP_levels[i], set_Prop_levels[i], P_sub_levels[i],
-                                     comp_grid_levels[i], options, x if host_transfers else None, l if host_transfers else None,
-                                     y if host_transfers else None, device, None, attach)
+            if cached is not None:
+                ctx = cached[i]
+                TF = np.dtype(m.dtype).type
+                ctx.reset(m_levels[i], [float(TF(r)) for r in options.rho_ini], float(TF(options.gamma_ini)), True)
+            else:
+                ctx = host.build_context(m_levels[i], AtA_levels[i], TD_OP_levels[i], set_Prop_levels[i], P_sub_levels[i],
+                                         comp_grid_levels[i], options, x if host_transfers else None, l if host_transfers else None,
+                                         y if host_transfers else None, device, None, attach)
+            used[i] = ctx
             t1 = time.perf_counter()
             if prev is not None:
                 ctx.warm_start_from(prev)                                    # x, l_i, y_i: coarse -> fine on the device
-                prev.close()
+                if key is None:
+                    prev.close()
+                    used[i + 1] = None
                 prev = None
             t2 = time.perf_counter()
             log, feasible = ctx.parsdmm(options)
@@ -166,6 +217,7 @@ def PARSDMM_multi_level(m, TD_OP_levels, AtA_levels, P_sub_levels, set_Prop_leve
             if host_transfers:
                 x, l, y = ctx.download()
                 ctx.close()
+                used[i] = None
             else:
                 prev = ctx
         if not host_transfers:
@@ -173,6 +225,7 @@ def PARSDMM_multi_level(m, TD_OP_levels, AtA_levels, P_sub_levels, set_Prop_leve
                 t0 = time.perf_counter()
                 x, l, y = prev.download(want_ly=False)
                 rec["download_s"] = rec["download_x_only_s"] = time.perf_counter() - t0
+                done = True
                 return x, log, None, None
             if timings is not None and dist is None:
                 # (what a caller that only wants x would wait for: sipx_download with x alone -- timed apart, the caller of this
@@ -183,9 +236,25 @@ def PARSDMM_multi_level(m, TD_OP_levels, AtA_levels, P_sub_levels, set_Prop_leve
             t0 = time.perf_counter()
             x, l, y = prev.download()
             rec["download_s"] = time.perf_counter() - t0
+        done = True
     finally:
-        if prev is not None:
-            prev.close()
+        keep_them = False
+        if done and key is not None and all(c is not None for c in used):
+            try:                                   # (kept only while the levels together leave most of the device to others)
+                held = sum(int(c.device_bytes()["context"]) for c in used)
+                keep_them = held <= 0.4 * int(used[0].device_bytes()["device_total"])
+            except Exception:
+                keep_them = False
+        if keep_them:
+            _level_cache[key] = used
+        else:
+            for c in used:
+                if c is not None:
+                    c.close()
+            if cached is not None:
+                for c in cached:                   # (a reused context that this call did not get to is not left behind)
+                    if c is not None and not any(c is u for u in used):
+                        c.close()
         options.rho_ini = rho_orig                                           # :87
         options.zero_ini_guess = n_levels == 1                               # :53,81 leave it false after a warm-started level
     return x, log, l, y

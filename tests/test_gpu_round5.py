@@ -397,3 +397,54 @@ def test_multilevel_returns_x_alone_when_asked(sipx):
     assert np.array_equal(xa, xb) and np.array_equal(loga.obj, logb.obj)
     with pytest.raises(sipx.host.SipxError):
         ML.PARSDMM_multi_level(m.copy(), *L[:5], opt, outputs="y")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("TF,levels", [(np.float32, 3), (np.float64, 2)])
+def test_multilevel_keeps_its_level_contexts_for_the_next_call(sipx, monkeypatch, TF, levels):
+    """PARSDMM_multi_level called again with the same sets on the same grids (the projector of an outer loop,
+    examples/constrained_freq_FWI_simple.jl:468): the level contexts of the last call are reset (sipx_reset) instead of built anew
+    -- an allocation right behind the release of the last call's arrays waits for the driver's wipe of them, 2.4 s against 1.0 at
+    512^3 Float64 -- and the call returns the bits of a call that builds them (another model, carried rho, warm start between the
+    levels included).  Another problem releases the kept contexts; SIPX_MULTILEVEL_CACHE=0 keeps none.
+    Reference: src/PARSDMM_multi_level.jl:8-89."""
+    from sipx import multilevel as ML
+    from tests.test_gpu_parity import _ml_problem
+    _, m, opt, L = _ml_problem(sipx, (24, 20, 16), (25.0, 20.0, 10.0), TF, levels)
+    m2 = (m + TF(7.0) * np.sin(np.arange(m.size, dtype=TF) * TF(0.01))).astype(TF)
+    fields = ("obj", "evol_x", "r_pri", "r_dual", "rho", "gamma", "set_feasibility", "cg_it")
+
+    def same(a, b):
+        assert np.array_equal(a[0], b[0])
+        for u, v in zip(list(a[2]) + list(a[3]), list(b[2]) + list(b[3])):
+            assert np.array_equal(u, v)
+        for f in fields:
+            assert np.array_equal(np.asarray(getattr(a[1], f)), np.asarray(getattr(b[1], f)), equal_nan=True), f
+
+    sipx.clear_context_cache()
+    try:
+        T = [{} for _ in range(5)]
+        ML.PARSDMM_multi_level(m.copy(), *L[:5], opt, timings=T[0])
+        assert T[0]["contexts_reused"] is False and len(ML._level_cache) == 1
+        hit = ML.PARSDMM_multi_level(m2.copy(), *L[:5], opt, timings=T[1])            # the kept levels, another model
+        assert T[1]["contexts_reused"] is True and len(ML._level_cache) == 1
+        hit_x = ML.PARSDMM_multi_level(m2.copy(), *L[:5], opt, timings=T[2], outputs="x")
+        assert T[2]["contexts_reused"] is True and np.array_equal(hit_x[0], hit[0]) and hit_x[2] is None
+        sipx.clear_context_cache()
+        assert len(ML._level_cache) == 0
+        new = ML.PARSDMM_multi_level(m2.copy(), *L[:5], opt, timings=T[3])            # built anew
+        assert T[3]["contexts_reused"] is False
+        same(hit, new)
+        # another problem (another grid): the kept contexts go, this call's stay
+        key = next(iter(ML._level_cache))
+        _, mb, opt_b, Lb = _ml_problem(sipx, (20, 16, 16), (25.0, 20.0, 10.0), TF, levels)
+        ML.PARSDMM_multi_level(mb.copy(), *Lb[:5], opt_b, timings=T[4])
+        assert T[4]["contexts_reused"] is False and len(ML._level_cache) == 1 and next(iter(ML._level_cache)) != key
+        monkeypatch.setenv("SIPX_MULTILEVEL_CACHE", "0")
+        sipx.clear_context_cache()
+        Tn = {}
+        off = ML.PARSDMM_multi_level(m2.copy(), *L[:5], opt, timings=Tn)
+        assert Tn["contexts_reused"] is False and len(ML._level_cache) == 0
+        same(off, new)
+    finally:
+        sipx.clear_context_cache()
