@@ -75,3 +75,35 @@ def test_setup_constraints_mirrors_reference_properties(sipx):
     assert all(np.array_equal(a, b) for a, b in zip(ps.AtA_offsets, po.AtA_offsets))
     with pytest.raises(sipx.SipxError):
         sipx.setup_constraints([sipx.set_definitions("l1", "TV", 0.0, 1.0, ("fiber", "x"))], sipx.compgrid(h, n), TF)
+
+
+def test_multilevel_level_keys(sipx, monkeypatch):
+    """Which multilevel problems may keep their level contexts between calls (multilevel.py, _level_keys; host logic, no device): the
+    same descriptors on the same grids give the same keys whatever the model holds, another grid or another radius gives others,
+    a descriptor with an array argument (bound vectors) or SIPX_MULTILEVEL_CACHE=0 / SIPX_CONTEXT_CACHE=0 gives none.
+    Reference: src/PARSDMM_multi_level.jl:8-89 (every call builds all levels anew)."""
+    from sipx import multilevel as ML
+    TF = np.float64
+    for k in list(os.environ):
+        if k.startswith("SIPX_"):
+            monkeypatch.delenv(k)
+
+    def keys(n, radius, lb=1600.0):
+        g = sipx.compgrid((25.0, 25.0, 25.0), n)
+        m = np.linspace(1600.0, 3900.0, int(np.prod(n))).astype(TF)
+        c = [sipx.set_definitions("bounds", "identity", lb, 3900.0, ("tensor", "")),
+             sipx.set_definitions("l1", "TV", 0.0, radius, ("tensor", ""))]
+        opt = sipx.PARSDMM_options(FL=TF, maxit=10)
+        L = ML.setup_multi_level_PARSDMM(m, 3, 2, g, c, opt)
+        ms = [np.zeros(int(np.prod(gg.n)), TF) for gg in L[4]]
+        return ML._level_keys(ms, *L[:5], opt, 0)
+
+    a, b = keys((24, 24, 24), 1e5), keys((24, 24, 24), 1e5)
+    assert a is not None and len(a) == 3 and a == b and len(set(a)) == 3
+    assert keys((24, 24, 20), 1e5) != a and keys((24, 24, 24), 2e5) != a
+    assert keys((24, 24, 24), 1e5, lb=np.full(24 ** 3, 1600.0)) is None
+    monkeypatch.setenv("SIPX_MULTILEVEL_CACHE", "0")
+    assert keys((24, 24, 24), 1e5) is None
+    monkeypatch.delenv("SIPX_MULTILEVEL_CACHE")
+    monkeypatch.setenv("SIPX_CONTEXT_CACHE", "0")
+    assert keys((24, 24, 24), 1e5) is None
